@@ -1,0 +1,228 @@
+/*
+ * modsx.h -- C ABI of the MI355X-native MODS inner loop (libmodsx.so).
+ *
+ * Every entry point replaces one interface of the reference (ducha-aiki/mods);
+ * the file:line it replaces is cited on each declaration.  Plain pointers and
+ * sizes only; no exceptions cross this boundary.  Conventions: an int return is
+ * a count (>= 0) or a negative modsx_status; arrays returned through a `**`
+ * parameter are malloc'd by the library and released with modsx_free(); device
+ * state lives behind opaque handles; one modsx_ctx per calling thread (the
+ * reference calls its detectors concurrently from nested OpenMP threads,
+ * imagerepresentation.cpp:612-622 -- a ctx owns one HIP stream).
+ *
+ * The library needs a gfx950 device: modsx_create() fails (NULL +
+ * modsx_last_error()) when none is present.  There is no CPU fallback.
+ */
+#ifndef MODSX_H
+#define MODSX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MODSX_VERSION 100
+
+typedef enum modsx_status {
+  MODSX_OK = 0,
+  MODSX_ERR_ARG = -1,
+  MODSX_ERR_DEVICE = -2,
+  MODSX_ERR_NOMEM = -3,
+  MODSX_ERR_INTERNAL = -4
+} modsx_status;
+
+/* detection_mode_t, detectors/structures.hpp:11-15 */
+enum { MODSX_FIXED_TH = 0, MODSX_RELATIVE_TH = 1, MODSX_FIXED_REG_NUMBER = 2, MODSX_RELATIVE_REG_NUMBER = 3,
+       MODSX_NOT_LESS_THAN_REGIONS = 4 };
+/* detector_type / descriptor_type, detectors/structures.hpp:17-38, 75-96 */
+enum { MODSX_DET_HESSIAN = 0 };
+enum { MODSX_DESC_SIFT = 0, MODSX_DESC_ROOT_SIFT = 1 };
+/* ScaleSpaceDetector point types, affinedetectors/pyramid.h:32-36 */
+enum { MODSX_HESSIAN_DARK = 0, MODSX_HESSIAN_BRIGHT = 1, MODSX_HESSIAN_SADDLE = 2 };
+
+/* == struct AffineKeypoint, detectors/structures.hpp:187-199 (same field order and layout) */
+typedef struct modsx_keypoint {
+  double x, y;
+  double a11, a12, a21, a22;
+  double s;
+  double response;
+  int octave_number;
+  double pyramid_scale;
+  int sub_type;
+} modsx_keypoint;
+
+/* == struct AffineRegion minus the heap-allocated Descriptor, detectors/structures.hpp:222-233.
+ * Descriptors travel next to the region array as a dense [n][128] f32 matrix holding the
+ * integers 0..255 the reference stores in Descriptor::vec (matching/siftdesc.cpp:218-274). */
+typedef struct modsx_region {
+  int img_id, img_reproj_id, id, parent_id, type;
+  modsx_keypoint det_kp, reproj_kp;
+} modsx_region;
+
+/* PyramidParams + AffineShapeParams of ScaleSpaceDetectorParams,
+ * detectors/structures.hpp:125-160, affinedetectors/affine.h:27-62, scale-space-detector.hpp:20-28 */
+typedef struct modsx_hessaff_params {
+  float threshold;
+  int mode;
+  int reg_number;
+  float rel_threshold;
+  float rel_reg_number;
+  int numberOfScales;
+  float initialSigma;
+  double edgeEigenValueRatio;
+  int border;
+  int maxIterations;
+  float convergenceThreshold;
+  int smmWindowSize;
+  float affInitialSigma;
+  int doBaumberg;
+} modsx_hessaff_params;
+
+/* scale-space keypoint before affine adaptation: the arguments of
+ * KeypointCallback::onKeypointDetected, affinedetectors/pyramid.h:23-27 */
+typedef struct modsx_sskp {
+  int octave, level, r0, c0, r, c, type, pad;
+  float b0, b1, b2, val;
+  float x, y, s, pixelDistance;
+} modsx_sskp;
+
+/* the fields MatchFlannFGINN fills in a TentativeCorrespExt (matching/matching.hpp:39-52):
+ * first = list1[q], second = list2[t0], secondbad = list2[tj], secondbadby2ndcl = list2[t1] */
+typedef struct modsx_tentative {
+  int q, t0, tj, t1;
+  double d1, d2, d2by2ndcl, ratio;
+} modsx_tentative;
+
+/* parameters of one identity-view HessAff -> SIFT -> FGINN -> LO-RANSAC pass over an image pair
+ * (the body of mods.cpp:229-415 for one step); defaults = build/config_iter_mods_cviu.ini */
+typedef struct modsx_pair_params {
+  modsx_hessaff_params det;
+  double ori_mrSize; int ori_patchSize; int ori_maxAngles; double ori_threshold; /* [DominantOrientation] :102-108 */
+  double desc_mrSize; int desc_patchSize; int desc_photoNorm; int desc_type; double desc_maxBinValue; /* [SIFTDescriptor] :109-116 */
+  double match_ratio; double contradDist; int nn;       /* FGINNThreshold, [Matching] contradDist :147 */
+  double duplicateDist;                                  /* [DuplicateFiltering] :156-159, mode bestFGINN */
+  double err_threshold, confidence; int max_samples; int localOptimization; double HLAFCoef; int doSymmCheck; /* [RANSAC] :162-170 */
+  unsigned ransac_seed;
+} modsx_pair_params;
+
+typedef struct modsx_pair_result {
+  int n_regions1, n_regions2;    /* described regions per image */
+  int n_tentatives;              /* after MatchFlannFGINN */
+  int n_unique;                  /* after DuplicateFiltering */
+  int n_ransac_inliers;          /* exp_ransacHcustom inliers */
+  int n_verified;                /* after NaiveHCheck + H_LAF_check */
+  int ransac_samples, ransac_lo;
+  double H[9];                   /* row-major, image 1 -> image 2 (LORANSACFiltering's H) */
+  /* malloc'd arrays (modsx_free): tentatives after duplicate filtering in RANSAC order,
+   * inlier flags from RANSAC, flags after the LAF check */
+  modsx_tentative *tentatives;
+  unsigned char *ransac_inlier;
+  unsigned char *verified;
+} modsx_pair_result;
+
+typedef struct modsx_ctx modsx_ctx;
+typedef struct modsx_image modsx_image;
+
+int modsx_version(void);
+const char *modsx_last_error(void);
+void modsx_free(void *p);
+
+modsx_ctx *modsx_create(int device_id);
+void modsx_destroy(modsx_ctx *ctx);
+int modsx_synchronize(modsx_ctx *ctx);
+
+void modsx_default_hessaff_params(modsx_hessaff_params *p);
+void modsx_default_pair_params(modsx_pair_params *p);
+
+/* Image upload.  dtype 0 = u8, 1 = f32; channels 1 or 3 (BGR as cv::imread gives).  3-channel input is
+ * converted with the reference's (B+G+R)/3 rule: GenerateSynthImageCorr, synth-detection.cpp:253-262
+ * (identity view: out_img.pixels = gray, :278-289). */
+modsx_image *modsx_image_upload(modsx_ctx *ctx, const void *pixels, int rows, int cols, int channels, int dtype);
+/* wrap pixels that already live in HBM (f32, 1 channel, dense rows); not owned */
+modsx_image *modsx_image_wrap_device(modsx_ctx *ctx, const float *dev_pixels, int rows, int cols);
+void modsx_image_free(modsx_ctx *ctx, modsx_image *img);
+int modsx_image_download(modsx_ctx *ctx, const modsx_image *img, float *out);
+
+/* int DetectAffineKeypoints(cv::Mat &input, vector<AffineKeypoint> &out1, ScaleSpaceDetectorParams params,
+ *                           ScalePyramid &scale_pyramid, const double tilt, const double zoom)
+ * affinedetectors/scale-space-detector.hpp:231, .cpp:43-85 */
+int modsx_detect_affine_keypoints(modsx_ctx *ctx, const modsx_image *img, const modsx_hessaff_params *par,
+                                  double tilt, double zoom, modsx_keypoint **out);
+/* stage tap: ScaleSpaceDetector::detectPyramidKeypoints without the affine callback (pyramid.cpp:540-573) */
+int modsx_detect_scalespace(modsx_ctx *ctx, const modsx_image *img, const modsx_hessaff_params *par,
+                            modsx_sskp **out);
+/* stage tap: the 5 blur and 5 response levels of the first octave built from `img` as its first level
+ * (ScaleSpaceDetector::detectOctaveKeypoints, pyramid.cpp:455-538); each output is 5*rows*cols f32 */
+int modsx_octave_levels(modsx_ctx *ctx, const modsx_image *img, const modsx_hessaff_params *par, float *blurs,
+                        float *resps);
+/* stage taps for the two image primitives: gaussianBlur (detectors/helpers.cpp:717-724) and
+ * cv::resize(.., 0.5, 0.5, INTER_LINEAR) (pyramid.cpp:520) */
+int modsx_gaussian_blur(modsx_ctx *ctx, const modsx_image *img, float sigma, float *out);
+int modsx_resize_half(modsx_ctx *ctx, const modsx_image *img, float *out, int *orows, int *ocols);
+
+/* template DetectAffineRegions<>: scale by sqrt|det A| and rectify, synth-detection.hpp:93-126 (host math) */
+int modsx_detect_affine_regions(const modsx_keypoint *kps, int n, int img_id, int det_type, modsx_region *out);
+
+/* int DetectOrientation(AffineRegionList &in, AffineRegionList &out, SynthImage &img, double mrSize,
+ *                       int patchSize, int doHalfSIFT, int maxAngNum, double th, bool addUpRight)
+ * synth-detection.hpp:151-159, .cpp:841-919 */
+int modsx_detect_orientation(modsx_ctx *ctx, const modsx_image *img, const modsx_region *in, int n, double mrSize,
+                             int patchSize, int doHalfSIFT, int maxAngNum, double th, int addUpRight,
+                             modsx_region **out);
+
+/* int ReprojectRegions(AffineRegionList &keypoints, double *H, int orig_w, int orig_h)
+ * synth-detection.cpp:541-616; filters in place, returns the new count (host math) */
+int modsx_reproject_regions(modsx_region *regs, int n, const double *H, int orig_w, int orig_h);
+
+/* template DescribeRegions<SIFTDescriptor>(AffineRegionList&, SynthImage&, FuncType, double mrSize,
+ *            int patchSize, bool fast_extraction, bool photoNorm)     synth-detection.hpp:169-255
+ * with SIFTDescriptor::operator() matching/siftdesc.cpp:401-442.  desc: n*128 f32 (integers 0..255). */
+int modsx_describe_regions(modsx_ctx *ctx, const modsx_image *img, const modsx_region *regs, int n, double mrSize,
+                           int patchSize, int fast_extraction, int photoNorm, int desc_type, double maxBinValue,
+                           float *desc);
+
+/* int MatchFlannFGINN(const AffineRegionList &list1, const AffineRegionList &list2,
+ *                     TentativeCorrespListExt &corresp, const MatchPars &par, const int nn = 50)
+ * matching/matching.hpp:268-269, .cpp:357-461 with vector_matcher = linear, vector_dist = L2.
+ * desc*: [n][128] f32 holding integers 0..255; pos2: [n2][2] reproj_kp x,y of list2. */
+int modsx_match_fginn(modsx_ctx *ctx, const float *desc1, int n1, const float *desc2, int n2, const double *pos2,
+                      double ratio, double contradDist, int nn, modsx_tentative **out);
+
+/* void DuplicateFiltering(TentativeCorrespListExt&, const double r, const int mode) matching/matching.hpp:300,
+ * .cpp:2983-3047.  pts: [T][4] = x1 y1 x2 y2; key: |ratio| (bestFGINN), d1 or scale; order[] receives the
+ * permutation of the sort, keep[] the survivor flags in sorted order.  Returns the survivor count. */
+int modsx_duplicate_filtering(const double *pts, const double *key, int T, double r, int do_sort, int *order,
+                              unsigned char *keep);
+
+/* Score exp_ransacHcustom(double *u, int len, double th, double conf, int max_sam, double *H,
+ *          unsigned char *inl, int iter_type, int *data_out, int oriented_constraint, unsigned inlLimit,
+ *          double **resids, HDsPtr, HDsiPtr, HDsidxPtr, int doSymCheck)       degensac/exp_ranH.h:29-36
+ * with the Sampson error functions (HDs/HDsi/HDsidx) and iter_type 4, plus an explicit seed in place of
+ * srand(time(NULL)) (exp_ranH.c:823).  u: [len][6] = x1 y1 1 x2 y2 1; H: column-major-as-returned (maps
+ * image 2 -> image 1 transposed, see matching.cpp:922-938); data_out[0..2] = samples, LO count, orientation
+ * rejects.  Returns the inlier count. */
+int modsx_ransac_h(const double *u, int len, double th, double conf, int max_sam, double *H, unsigned char *inl,
+                   int *data_out, int oriented_constraint, int doSymCheck, unsigned seed, double *score_J);
+
+/* int LORANSACFiltering(TentativeCorrespListExt &in, TentativeCorrespListExt &out, double *H,
+ *                       const RANSACPars pars)   matching/matching.hpp:284-286, .cpp:806-980 (useF = 0,
+ * errorType SAMPSON).  pts [T][4]; laf1/laf2 [T][5] = reproj a11 a12 a21 a22 s.  Outputs H (row-major
+ * img1->img2), Hraw (as exp_ransacHcustom returned it), inl (RANSAC), keep (after NaiveHCheck + H_LAF_check).
+ * Returns the verified count. */
+int modsx_loransac_h(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold,
+                     double confidence, int max_samples, int localOptimization, double HLAFCoef, int doSymmCheck,
+                     unsigned seed, double *H, double *Hraw, unsigned char *inl, unsigned char *keep,
+                     int *data_out);
+
+/* One step of mods.cpp's iteration loop (:229-415) for an identity view: detect + orient + describe both
+ * images, match, filter duplicates, verify.  Images and all intermediates stay in HBM between stages. */
+int modsx_match_pair(modsx_ctx *ctx, const modsx_image *img1, const modsx_image *img2,
+                     const modsx_pair_params *par, modsx_pair_result *res);
+void modsx_pair_result_release(modsx_pair_result *res);
+
+/* per-stage time of the last modsx_match_pair in ms: detect, orient, describe, match, verify, total */
+int modsx_last_timings(modsx_ctx *ctx, double *ms6);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,345 @@
+"""mods_amd -- Python harness over the C ABI of libmodsx.so (include/modsx.h).
+
+The product is the shared library (HIP kernels + C++ host engine); this module only
+binds it with ctypes so the tests and bench.py can drive it.  There is no Python or
+CPU implementation of the path in here: without the built library, or without a GPU,
+every device entry point raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmodsx.so")
+
+KEYPOINT = np.dtype([("x", "f8"), ("y", "f8"), ("a11", "f8"), ("a12", "f8"), ("a21", "f8"), ("a22", "f8"),
+                     ("s", "f8"), ("response", "f8"), ("octave_number", "i4"), ("pyramid_scale", "f8"),
+                     ("sub_type", "i4")], align=True)
+REGION = np.dtype([("img_id", "i4"), ("img_reproj_id", "i4"), ("id", "i4"), ("parent_id", "i4"), ("type", "i4"),
+                   ("det_kp", KEYPOINT), ("reproj_kp", KEYPOINT)], align=True)
+SSKP = np.dtype([("octave", "i4"), ("level", "i4"), ("r0", "i4"), ("c0", "i4"), ("r", "i4"), ("c", "i4"),
+                 ("type", "i4"), ("pad", "i4"), ("b0", "f4"), ("b1", "f4"), ("b2", "f4"), ("val", "f4"),
+                 ("x", "f4"), ("y", "f4"), ("s", "f4"), ("pixelDistance", "f4")], align=True)
+TENT = np.dtype([("q", "i4"), ("t0", "i4"), ("tj", "i4"), ("t1", "i4"), ("d1", "f8"), ("d2", "f8"),
+                 ("d2by2ndcl", "f8"), ("ratio", "f8")], align=True)
+
+
+class HessAffParams(C.Structure):
+    _fields_ = [("threshold", C.c_float), ("mode", C.c_int), ("reg_number", C.c_int),
+                ("rel_threshold", C.c_float), ("rel_reg_number", C.c_float), ("numberOfScales", C.c_int),
+                ("initialSigma", C.c_float), ("edgeEigenValueRatio", C.c_double), ("border", C.c_int),
+                ("maxIterations", C.c_int), ("convergenceThreshold", C.c_float), ("smmWindowSize", C.c_int),
+                ("affInitialSigma", C.c_float), ("doBaumberg", C.c_int)]
+
+
+class PairParams(C.Structure):
+    _fields_ = [("det", HessAffParams),
+                ("ori_mrSize", C.c_double), ("ori_patchSize", C.c_int), ("ori_maxAngles", C.c_int),
+                ("ori_threshold", C.c_double),
+                ("desc_mrSize", C.c_double), ("desc_patchSize", C.c_int), ("desc_photoNorm", C.c_int),
+                ("desc_type", C.c_int), ("desc_maxBinValue", C.c_double),
+                ("match_ratio", C.c_double), ("contradDist", C.c_double), ("nn", C.c_int),
+                ("duplicateDist", C.c_double),
+                ("err_threshold", C.c_double), ("confidence", C.c_double), ("max_samples", C.c_int),
+                ("localOptimization", C.c_int), ("HLAFCoef", C.c_double), ("doSymmCheck", C.c_int),
+                ("ransac_seed", C.c_uint)]
+
+
+class PairResult(C.Structure):
+    _fields_ = [("n_regions1", C.c_int), ("n_regions2", C.c_int), ("n_tentatives", C.c_int), ("n_unique", C.c_int),
+                ("n_ransac_inliers", C.c_int), ("n_verified", C.c_int), ("ransac_samples", C.c_int),
+                ("ransac_lo", C.c_int), ("H", C.c_double * 9), ("tentatives", C.c_void_p),
+                ("ransac_inlier", C.c_void_p), ("verified", C.c_void_p)]
+
+
+EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "modsx_destroy", "modsx_synchronize",
+           "modsx_default_hessaff_params", "modsx_default_pair_params", "modsx_image_upload",
+           "modsx_image_wrap_device", "modsx_image_free", "modsx_image_download", "modsx_detect_affine_keypoints",
+           "modsx_detect_scalespace", "modsx_octave_levels", "modsx_gaussian_blur", "modsx_resize_half",
+           "modsx_detect_affine_regions", "modsx_detect_orientation", "modsx_reproject_regions",
+           "modsx_describe_regions", "modsx_match_fginn", "modsx_duplicate_filtering", "modsx_ransac_h",
+           "modsx_loransac_h", "modsx_match_pair", "modsx_pair_result_release", "modsx_last_timings"]
+
+
+def build(force=False):
+    """Compile libmodsx.so for gfx950 with hipcc (in-tree)."""
+    src = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(src, f) for f in os.listdir(src) if f.endswith((".hip", ".cpp", ".hpp"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "modsx.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", src, "-j8"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libmodsx.so is not built; run __graft_entry__.build() (needs hipcc)")
+        L = C.CDLL(LIB_PATH)
+        L.modsx_last_error.restype = C.c_char_p
+        L.modsx_create.restype = C.c_void_p
+        L.modsx_create.argtypes = [C.c_int]
+        L.modsx_destroy.argtypes = [C.c_void_p]
+        L.modsx_free.argtypes = [C.c_void_p]
+        L.modsx_image_upload.restype = C.c_void_p
+        L.modsx_image_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.modsx_image_wrap_device.restype = C.c_void_p
+        L.modsx_image_wrap_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.modsx_image_free.argtypes = [C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _err():
+    return lib().modsx_last_error().decode()
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, _err()))
+    return rc
+
+
+def default_hessaff_params(**kw):
+    p = HessAffParams()
+    lib().modsx_default_hessaff_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def default_pair_params(**kw):
+    p = PairParams()
+    lib().modsx_default_pair_params(C.byref(p))
+    for k, v in kw.items():
+        if hasattr(p.det, k) and not hasattr(p, k):
+            setattr(p.det, k, v)
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def _take(ptr, n, dtype):
+    """Copy a malloc'd array returned through `**out` into numpy and free it."""
+    if n <= 0:
+        if ptr:
+            lib().modsx_free(ptr)
+        return np.zeros(0, dtype)
+    buf = (C.c_char * (n * dtype.itemsize)).from_address(ptr.value if hasattr(ptr, "value") else ptr)
+    arr = np.frombuffer(buf, dtype=dtype, count=n).copy()
+    lib().modsx_free(ptr)
+    return arr
+
+
+# ---- host-only entry points (no device needed) ---------------------------------------------------
+def detect_affine_regions(kps, img_id=0, det_type=0):
+    kps = np.ascontiguousarray(kps, KEYPOINT)
+    out = np.zeros(len(kps), REGION)
+    _check(lib().modsx_detect_affine_regions(_p(kps), len(kps), img_id, det_type, _p(out)), "detect_affine_regions")
+    return out
+
+
+def reproject_regions(regs, H, w, h):
+    regs = np.ascontiguousarray(regs, REGION).copy()
+    H = np.ascontiguousarray(H, np.float64).reshape(9)
+    n = _check(lib().modsx_reproject_regions(_p(regs), len(regs), _p(H), int(w), int(h)), "reproject_regions")
+    return regs[:n].copy()
+
+
+def duplicate_filtering(pts, key, r=2.0, do_sort=True):
+    pts = np.ascontiguousarray(pts, np.float64)
+    key = np.ascontiguousarray(key, np.float64)
+    T = len(pts)
+    order = np.zeros(max(T, 1), np.int32)
+    keep = np.zeros(max(T, 1), np.uint8)
+    _check(lib().modsx_duplicate_filtering(_p(pts), _p(key), T, C.c_double(r), int(do_sort), _p(order), _p(keep)),
+           "duplicate_filtering")
+    return order[:T], keep[:T].astype(bool)
+
+
+def ransac_h(u, th, conf=0.99, max_sam=100000, oriented=1, sym_check=1, seed=1):
+    u = np.ascontiguousarray(u, np.float64)
+    n = len(u)
+    H = np.zeros(9)
+    inl = np.zeros(n, np.uint8)
+    dout = np.zeros(3, np.int32)
+    J = C.c_double(0)
+    rc = _check(lib().modsx_ransac_h(_p(u), n, C.c_double(th), C.c_double(conf), int(max_sam), _p(H), _p(inl), _p(dout),
+                                     int(oriented), int(sym_check), C.c_uint(seed), C.byref(J)), "ransac_h")
+    return dict(n=rc, H=H, inl=inl.astype(bool), samples=int(dout[0]), lo_count=int(dout[1]),
+                ori_rejects=int(dout[2]), J=J.value)
+
+
+def loransac_h(pts, laf1, laf2, err_threshold=3.0, confidence=0.99, max_samples=100000, lo=1, hlaf_coef=12.0,
+               sym_check=1, seed=1):
+    pts = np.ascontiguousarray(pts, np.float64)
+    laf1 = np.ascontiguousarray(laf1, np.float64)
+    laf2 = np.ascontiguousarray(laf2, np.float64)
+    T = len(pts)
+    H, Hraw = np.zeros(9), np.zeros(9)
+    inl = np.zeros(max(T, 1), np.uint8)
+    keep = np.zeros(max(T, 1), np.uint8)
+    dout = np.zeros(3, np.int32)
+    n = _check(lib().modsx_loransac_h(_p(pts), _p(laf1), _p(laf2), T, C.c_double(err_threshold),
+                                      C.c_double(confidence), int(max_samples), int(lo), C.c_double(hlaf_coef),
+                                      int(sym_check), C.c_uint(seed), _p(H), _p(Hraw), _p(inl), _p(keep), _p(dout)),
+               "loransac_h")
+    return dict(n=n, H=H.reshape(3, 3), Hraw=Hraw, inl=inl[:T].astype(bool), keep=keep[:T].astype(bool),
+                samples=int(dout[0]), lo_count=int(dout[1]), ori_rejects=int(dout[2]))
+
+
+# ---- device path -------------------------------------------------------------------------------
+class Image(object):
+    def __init__(self, ctx, handle, rows, cols):
+        self.ctx, self.h, self.rows, self.cols = ctx, handle, rows, cols
+
+    def free(self):
+        if self.h:
+            lib().modsx_image_free(self.ctx.h, self.h)
+            self.h = None
+
+    def download(self):
+        out = np.empty((self.rows, self.cols), np.float32)
+        _check(lib().modsx_image_download(C.c_void_p(self.ctx.h), C.c_void_p(self.h), _p(out)), "image_download")
+        return out
+
+
+class Context(object):
+    """One modsx_ctx (one HIP stream).  Raises if no gfx950 device is available."""
+
+    def __init__(self, device=0):
+        self.h = lib().modsx_create(int(device))
+        if not self.h:
+            raise RuntimeError("modsx_create failed: " + _err())
+
+    def close(self):
+        if self.h:
+            lib().modsx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _c(self):
+        return C.c_void_p(self.h)
+
+    def upload(self, pixels):
+        a = np.ascontiguousarray(pixels)
+        if a.dtype == np.uint8:
+            dtype = 0
+        else:
+            a = np.ascontiguousarray(a, np.float32)
+            dtype = 1
+        ch = 1 if a.ndim == 2 else a.shape[2]
+        h = lib().modsx_image_upload(self._c(), _p(a), a.shape[0], a.shape[1], ch, dtype)
+        if not h:
+            raise RuntimeError("modsx_image_upload failed: " + _err())
+        return Image(self, h, a.shape[0], a.shape[1])
+
+    def wrap_device(self, dev_ptr, rows, cols):
+        h = lib().modsx_image_wrap_device(self._c(), C.c_void_p(dev_ptr), rows, cols)
+        if not h:
+            raise RuntimeError("modsx_image_wrap_device failed: " + _err())
+        return Image(self, h, rows, cols)
+
+    def synchronize(self):
+        _check(lib().modsx_synchronize(self._c()), "synchronize")
+
+    def gaussian_blur(self, img, sigma):
+        out = np.empty((img.rows, img.cols), np.float32)
+        _check(lib().modsx_gaussian_blur(self._c(), C.c_void_p(img.h), C.c_float(sigma), _p(out)), "gaussian_blur")
+        return out
+
+    def resize_half(self, img):
+        r, c = C.c_int(), C.c_int()
+        _check(lib().modsx_resize_half(self._c(), C.c_void_p(img.h), None, C.byref(r), C.byref(c)), "resize_half")
+        out = np.empty((r.value, c.value), np.float32)
+        _check(lib().modsx_resize_half(self._c(), C.c_void_p(img.h), _p(out), C.byref(r), C.byref(c)), "resize_half")
+        return out
+
+    def octave_levels(self, img, params):
+        L = params.numberOfScales + 2
+        blurs = np.empty((L, img.rows, img.cols), np.float32)
+        resps = np.empty((L, img.rows, img.cols), np.float32)
+        _check(lib().modsx_octave_levels(self._c(), C.c_void_p(img.h), C.byref(params), _p(blurs), _p(resps)),
+               "octave_levels")
+        return blurs, resps
+
+    def detect_scalespace(self, img, params):
+        out = C.c_void_p()
+        n = _check(lib().modsx_detect_scalespace(self._c(), C.c_void_p(img.h), C.byref(params), C.byref(out)),
+                   "detect_scalespace")
+        return _take(out, n, SSKP)
+
+    def detect_affine_keypoints(self, img, params, tilt=1.0, zoom=1.0):
+        out = C.c_void_p()
+        n = _check(lib().modsx_detect_affine_keypoints(self._c(), C.c_void_p(img.h), C.byref(params),
+                                                       C.c_double(tilt), C.c_double(zoom), C.byref(out)),
+                   "detect_affine_keypoints")
+        return _take(out, n, KEYPOINT)
+
+    def detect_orientation(self, img, regs, mr_size=1.0, patch_size=41, half=0, max_ang=1, th=0.8, upright=0):
+        regs = np.ascontiguousarray(regs, REGION)
+        out = C.c_void_p()
+        n = _check(lib().modsx_detect_orientation(self._c(), C.c_void_p(img.h), _p(regs), len(regs),
+                                                  C.c_double(mr_size), patch_size, half, max_ang, C.c_double(th),
+                                                  upright, C.byref(out)), "detect_orientation")
+        return _take(out, n, REGION)
+
+    def describe_regions(self, img, regs, mr_size=5.1962, patch_size=41, fast=0, photo_norm=1, desc_type=1,
+                         max_bin=0.2):
+        regs = np.ascontiguousarray(regs, REGION)
+        desc = np.zeros((len(regs), 128), np.float32)
+        _check(lib().modsx_describe_regions(self._c(), C.c_void_p(img.h), _p(regs), len(regs), C.c_double(mr_size),
+                                            patch_size, fast, photo_norm, desc_type, C.c_double(max_bin), _p(desc)),
+               "describe_regions")
+        return desc
+
+    def match_fginn(self, d1, d2, pos2, ratio=0.8, contrad_dist=30.0, nn=50):
+        d1 = np.ascontiguousarray(d1, np.float32)
+        d2 = np.ascontiguousarray(d2, np.float32)
+        pos2 = np.ascontiguousarray(pos2, np.float64)
+        out = C.c_void_p()
+        n = _check(lib().modsx_match_fginn(self._c(), _p(d1), len(d1), _p(d2), len(d2), _p(pos2), C.c_double(ratio),
+                                           C.c_double(contrad_dist), nn, C.byref(out)), "match_fginn")
+        return _take(out, n, TENT)
+
+    def match_pair(self, img1, img2, params):
+        res = PairResult()
+        _check(lib().modsx_match_pair(self._c(), C.c_void_p(img1.h), C.c_void_p(img2.h), C.byref(params),
+                                      C.byref(res)), "match_pair")
+        T = res.n_unique
+        out = dict(n_regions=(res.n_regions1, res.n_regions2), n_tentatives=res.n_tentatives, n_unique=T,
+                   n_ransac_inliers=res.n_ransac_inliers, n_verified=res.n_verified,
+                   ransac_samples=res.ransac_samples, ransac_lo=res.ransac_lo,
+                   H=np.array(list(res.H)).reshape(3, 3))
+        if T > 0:
+            out["tentatives"] = np.frombuffer((C.c_char * (T * TENT.itemsize)).from_address(res.tentatives),
+                                              dtype=TENT, count=T).copy()
+            out["ransac_inlier"] = np.frombuffer((C.c_char * T).from_address(res.ransac_inlier), np.uint8, T).astype(bool)
+            out["verified"] = np.frombuffer((C.c_char * T).from_address(res.verified), np.uint8, T).astype(bool)
+        else:
+            out["tentatives"] = np.zeros(0, TENT)
+            out["ransac_inlier"] = np.zeros(0, bool)
+            out["verified"] = np.zeros(0, bool)
+        lib().modsx_pair_result_release(C.byref(res))
+        return out
+
+    def last_timings(self):
+        t = (C.c_double * 6)()
+        _check(lib().modsx_last_timings(self._c(), t), "last_timings")
+        return dict(zip(["detect", "orient", "describe", "match", "verify", "total"], list(t)))

@@ -1,0 +1,286 @@
+// capi.hip -- the extern "C" boundary declared in include/modsx.h.
+#include <math.h>
+#include "engine_api.hpp"
+
+using namespace mx;
+
+#define NEED(c)                                             \
+  do {                                                      \
+    if (!(c)) { mx::set_error("null argument: " #c); return MODSX_ERR_ARG; } \
+  } while (0)
+
+template <typename T>
+static T *to_malloc(const std::vector<T> &v) {
+  T *p = (T *)malloc(sizeof(T) * (v.size() ? v.size() : 1));
+  if (p && !v.empty()) memcpy(p, v.data(), sizeof(T) * v.size());
+  return p;
+}
+
+extern "C" {
+
+int modsx_version(void) { return MODSX_VERSION; }
+const char *modsx_last_error(void) { return mx::last_error(); }
+void modsx_free(void *p) { free(p); }
+
+modsx_ctx *modsx_create(int device_id) { return ctx_create(device_id); }
+void modsx_destroy(modsx_ctx *ctx) { ctx_destroy(ctx); }
+int modsx_synchronize(modsx_ctx *ctx) {
+  NEED(ctx);
+  MX_HIP(hipStreamSynchronize(ctx->stream));
+  return MODSX_OK;
+}
+
+void modsx_default_hessaff_params(modsx_hessaff_params *p) {
+  // build/config_iter_mods_cviu.ini:13-27; structures.hpp:141-160; affine.h:47-58
+  p->threshold = 5.3333f;
+  p->mode = MODSX_FIXED_TH;
+  p->reg_number = 2000;
+  p->rel_threshold = -1;
+  p->rel_reg_number = -1;
+  p->numberOfScales = 3;
+  p->initialSigma = 1.6f;
+  p->edgeEigenValueRatio = 10.0;
+  p->border = 5;
+  p->maxIterations = 16;
+  p->convergenceThreshold = 0.05f;
+  p->smmWindowSize = 19;
+  p->affInitialSigma = 1.6f;
+  p->doBaumberg = 1;
+}
+
+void modsx_default_pair_params(modsx_pair_params *p) {
+  memset(p, 0, sizeof *p);
+  modsx_default_hessaff_params(&p->det);
+  p->ori_mrSize = 1.0; p->ori_patchSize = 41; p->ori_maxAngles = 1; p->ori_threshold = 0.8;
+  p->desc_mrSize = 5.1962; p->desc_patchSize = 41; p->desc_photoNorm = 1; p->desc_type = MODSX_DESC_ROOT_SIFT;
+  p->desc_maxBinValue = 0.2;
+  p->match_ratio = 0.8; p->contradDist = 30.0; p->nn = 50;
+  p->duplicateDist = 2.0;
+  p->err_threshold = 3.0; p->confidence = 0.99; p->max_samples = 100000; p->localOptimization = 1;
+  p->HLAFCoef = 12.0; p->doSymmCheck = 1;
+  p->ransac_seed = 1;
+}
+
+modsx_image *modsx_image_upload(modsx_ctx *ctx, const void *pixels, int rows, int cols, int channels, int dtype) {
+  if (!ctx || !pixels || rows <= 0 || cols <= 0 || (channels != 1 && channels != 3) || (dtype != 0 && dtype != 1)) {
+    mx::set_error("modsx_image_upload: bad argument");
+    return nullptr;
+  }
+  hipSetDevice(ctx->dev);
+  const size_t n = (size_t)rows * cols;
+  const size_t inBytes = n * channels * (dtype == 0 ? 1 : 4);
+  modsx_image *im = new modsx_image();
+  im->rows = rows; im->cols = cols; im->owned = true; im->d = nullptr;
+  if (hipMalloc(&im->d, n * 4) != hipSuccess) { mx::set_error("hipMalloc image"); delete im; return nullptr; }
+  if (!ctx->misc.ensure(inBytes)) { hipFree(im->d); delete im; return nullptr; }
+  if (hipMemcpyAsync(ctx->misc.p, pixels, inBytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+    mx::set_error("image H2D copy failed"); hipFree(im->d); delete im; return nullptr;
+  }
+  launch_gray(ctx->stream, ctx->misc.p, im->d, n, channels, dtype);
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) { mx::set_error("image upload sync failed"); hipFree(im->d); delete im; return nullptr; }
+  return im;
+}
+
+modsx_image *modsx_image_wrap_device(modsx_ctx *ctx, const float *dev_pixels, int rows, int cols) {
+  if (!ctx || !dev_pixels || rows <= 0 || cols <= 0) { mx::set_error("modsx_image_wrap_device: bad argument"); return nullptr; }
+  modsx_image *im = new modsx_image();
+  im->d = const_cast<float *>(dev_pixels); im->rows = rows; im->cols = cols; im->owned = false;
+  return im;
+}
+
+void modsx_image_free(modsx_ctx *ctx, modsx_image *img) {
+  if (!img) return;
+  if (ctx) hipSetDevice(ctx->dev);
+  if (img->owned && img->d) hipFree(img->d);
+  delete img;
+}
+
+int modsx_image_download(modsx_ctx *ctx, const modsx_image *img, float *out) {
+  NEED(ctx); NEED(img); NEED(out);
+  MX_HIP(hipMemcpyAsync(out, img->d, (size_t)img->rows * img->cols * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MX_HIP(hipStreamSynchronize(ctx->stream));
+  return MODSX_OK;
+}
+
+int modsx_detect_affine_keypoints(modsx_ctx *ctx, const modsx_image *img, const modsx_hessaff_params *par, double tilt,
+                                  double zoom, modsx_keypoint **out) {
+  NEED(ctx); NEED(img); NEED(par); NEED(out);
+  hipSetDevice(ctx->dev);
+  std::vector<modsx_keypoint> k[1];
+  const modsx_image *imgs[1] = {img};
+  int rc = detect_keypoints_batch(ctx, imgs, 1, *par, tilt, zoom, k);
+  if (rc) return rc;
+  *out = to_malloc(k[0]);
+  return (int)k[0].size();
+}
+
+int modsx_detect_scalespace(modsx_ctx *ctx, const modsx_image *img, const modsx_hessaff_params *par, modsx_sskp **out) {
+  NEED(ctx); NEED(img); NEED(par); NEED(out);
+  hipSetDevice(ctx->dev);
+  std::vector<modsx_sskp> k[1];
+  const modsx_image *imgs[1] = {img};
+  int rc = detect_scalespace_batch(ctx, imgs, 1, *par, k);
+  if (rc) return rc;
+  *out = to_malloc(k[0]);
+  return (int)k[0].size();
+}
+
+int modsx_octave_levels(modsx_ctx *ctx, const modsx_image *img, const modsx_hessaff_params *par, float *blurs,
+                        float *resps) {
+  NEED(ctx); NEED(img); NEED(par); NEED(blurs); NEED(resps);
+  hipSetDevice(ctx->dev);
+  const modsx_image *imgs[1] = {img};
+  int rc = build_pyramids(ctx, imgs, 1, *par, true);
+  if (rc) return rc;
+  const int L = par->numberOfScales + 2;
+  const size_t npx = (size_t)img->rows * img->cols;
+  const Octave &o = ctx->pyr[0].oct[0];
+  for (int l = 0; l < L; l++) {
+    MX_HIP(hipMemcpyAsync(blurs + l * npx, o.blur[l], npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MX_HIP(hipMemcpyAsync(resps + l * npx, o.resp[l], npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  MX_HIP(hipStreamSynchronize(ctx->stream));
+  return L;
+}
+
+int modsx_gaussian_blur(modsx_ctx *ctx, const modsx_image *img, float sigma, float *out) {
+  NEED(ctx); NEED(img); NEED(out);
+  hipSetDevice(ctx->dev);
+  const size_t npx = (size_t)img->rows * img->cols;
+  if (!ctx->scratchA.ensure(npx * 4)) return MODSX_ERR_NOMEM;
+  BlurBatch b;
+  memset(&b, 0, sizeof b);
+  int n = blur_ksize(sigma);
+  if (n > MAX_TAPS) { mx::set_error("modsx_gaussian_blur: ksize > 17"); return MODSX_ERR_ARG; }
+  if (n == 1) {
+    MX_HIP(hipMemcpyAsync(out, img->d, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MX_HIP(hipStreamSynchronize(ctx->stream));
+    return MODSX_OK;
+  }
+  std::vector<float> k = gaussian_kernel(n, sigma);
+  b.n = n;
+  for (int i = 0; i < n; i++) b.k[i] = k[i];
+  b.j[0].src = img->d; b.j[0].blur = (float *)ctx->scratchA.p; b.j[0].resp = nullptr; b.j[0].rows = img->rows;
+  b.j[0].cols = img->cols; b.j[0].norm = 1.f;
+  launch_blur_hess(ctx->stream, b, 1, img->rows, img->cols);
+  MX_HIP(hipMemcpyAsync(out, ctx->scratchA.p, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MX_HIP(hipStreamSynchronize(ctx->stream));
+  MX_HIP(hipGetLastError());
+  return MODSX_OK;
+}
+
+int modsx_resize_half(modsx_ctx *ctx, const modsx_image *img, float *out, int *orows, int *ocols) {
+  NEED(ctx); NEED(img); NEED(orows); NEED(ocols);
+  hipSetDevice(ctx->dev);
+  const int dr = (int)lrint(img->rows * 0.5), dc = (int)lrint(img->cols * 0.5);
+  *orows = dr; *ocols = dc;
+  if (!out) return MODSX_OK;
+  if (!ctx->scratchA.ensure((size_t)dr * dc * 4 + 4)) return MODSX_ERR_NOMEM;
+  ResizeBatch rb;
+  memset(&rb, 0, sizeof rb);
+  rb.j[0].src = img->d; rb.j[0].dst = (float *)ctx->scratchA.p;
+  rb.j[0].srows = img->rows; rb.j[0].scols = img->cols; rb.j[0].drows = dr; rb.j[0].dcols = dc;
+  launch_resize_half(ctx->stream, rb, 1, dr, dc);
+  MX_HIP(hipMemcpyAsync(out, ctx->scratchA.p, (size_t)dr * dc * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MX_HIP(hipStreamSynchronize(ctx->stream));
+  MX_HIP(hipGetLastError());
+  return MODSX_OK;
+}
+
+int modsx_detect_affine_regions(const modsx_keypoint *kps, int n, int img_id, int det_type, modsx_region *out) {
+  if (n < 0 || (n > 0 && (!kps || !out))) { mx::set_error("modsx_detect_affine_regions: bad argument"); return MODSX_ERR_ARG; }
+  detect_affine_regions(kps, n, img_id, det_type, out);
+  return n;
+}
+
+int modsx_detect_orientation(modsx_ctx *ctx, const modsx_image *img, const modsx_region *in, int n, double mrSize,
+                             int patchSize, int doHalfSIFT, int maxAngNum, double th, int addUpRight,
+                             modsx_region **out) {
+  NEED(ctx); NEED(img); NEED(out);
+  if (n < 0 || (n > 0 && !in)) { mx::set_error("modsx_detect_orientation: bad argument"); return MODSX_ERR_ARG; }
+  hipSetDevice(ctx->dev);
+  std::vector<modsx_region> vin[1], vout[1];
+  vin[0].assign(in, in + n);
+  const modsx_image *imgs[1] = {img};
+  int rc = detect_orientation_batch(ctx, imgs, 1, vin, mrSize, patchSize, doHalfSIFT, maxAngNum, th, addUpRight, vout);
+  if (rc) return rc;
+  *out = to_malloc(vout[0]);
+  return (int)vout[0].size();
+}
+
+int modsx_reproject_regions(modsx_region *regs, int n, const double *H, int orig_w, int orig_h) {
+  if (n < 0 || (n > 0 && !regs) || !H) { mx::set_error("modsx_reproject_regions: bad argument"); return MODSX_ERR_ARG; }
+  return reproject_regions(regs, n, H, orig_w, orig_h);
+}
+
+int modsx_describe_regions(modsx_ctx *ctx, const modsx_image *img, const modsx_region *regs, int n, double mrSize,
+                           int patchSize, int fast_extraction, int photoNorm, int desc_type, double maxBinValue,
+                           float *desc) {
+  NEED(ctx); NEED(img);
+  if (n < 0 || (n > 0 && (!regs || !desc))) { mx::set_error("modsx_describe_regions: bad argument"); return MODSX_ERR_ARG; }
+  if (desc_type != MODSX_DESC_SIFT && desc_type != MODSX_DESC_ROOT_SIFT) { mx::set_error("descriptor type"); return MODSX_ERR_ARG; }
+  hipSetDevice(ctx->dev);
+  std::vector<modsx_region> v[1];
+  v[0].assign(regs, regs + n);
+  const modsx_image *imgs[1] = {img};
+  float *hosts[1] = {desc};
+  int rc = describe_batch(ctx, imgs, 1, v, mrSize, patchSize, fast_extraction, photoNorm, desc_type, maxBinValue, hosts);
+  if (rc) return rc;
+  return n;
+}
+
+int modsx_match_fginn(modsx_ctx *ctx, const float *desc1, int n1, const float *desc2, int n2, const double *pos2,
+                      double ratio, double contradDist, int nn, modsx_tentative **out) {
+  NEED(ctx); NEED(out);
+  if (n1 < 0 || n2 < 0 || (n1 > 0 && !desc1) || (n2 > 0 && (!desc2 || !pos2))) { mx::set_error("modsx_match_fginn: bad argument"); return MODSX_ERR_ARG; }
+  hipSetDevice(ctx->dev);
+  std::vector<modsx_tentative> t;
+  int rc = match_host_desc(ctx, desc1, n1, desc2, n2, pos2, ratio, contradDist, nn, t);
+  if (rc) return rc;
+  *out = to_malloc(t);
+  return (int)t.size();
+}
+
+int modsx_duplicate_filtering(const double *pts, const double *key, int T, double r, int do_sort, int *order,
+                              unsigned char *keep) {
+  if (T < 0 || (T > 0 && (!pts || !order || !keep))) { mx::set_error("modsx_duplicate_filtering: bad argument"); return MODSX_ERR_ARG; }
+  return duplicate_filtering(pts, key, T, r, do_sort, order, keep);
+}
+
+int modsx_ransac_h(const double *u, int len, double th, double conf, int max_sam, double *H, unsigned char *inl,
+                   int *data_out, int oriented_constraint, int doSymCheck, unsigned seed, double *score_J) {
+  if (!u || !H || !inl || !data_out || len < 4) { mx::set_error("modsx_ransac_h: bad argument"); return MODSX_ERR_ARG; }
+  return ransac_h(u, len, th, conf, max_sam, H, inl, data_out, oriented_constraint, doSymCheck, seed, score_J);
+}
+
+int modsx_loransac_h(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold,
+                     double confidence, int max_samples, int localOptimization, double HLAFCoef, int doSymmCheck,
+                     unsigned seed, double *H, double *Hraw, unsigned char *inl, unsigned char *keep, int *data_out) {
+  if (T < 0 || !H || !Hraw || !data_out || (T > 0 && (!pts || !laf1 || !laf2 || !inl || !keep))) {
+    mx::set_error("modsx_loransac_h: bad argument");
+    return MODSX_ERR_ARG;
+  }
+  return loransac_h(pts, laf1, laf2, T, err_threshold, confidence, max_samples, localOptimization, HLAFCoef, doSymmCheck,
+                    seed, H, Hraw, inl, keep, data_out);
+}
+
+int modsx_match_pair(modsx_ctx *ctx, const modsx_image *img1, const modsx_image *img2, const modsx_pair_params *par,
+                     modsx_pair_result *res) {
+  NEED(ctx); NEED(img1); NEED(img2); NEED(par); NEED(res);
+  hipSetDevice(ctx->dev);
+  return match_pair(ctx, img1, img2, *par, res);
+}
+
+void modsx_pair_result_release(modsx_pair_result *res) {
+  if (!res) return;
+  free(res->tentatives); free(res->ransac_inlier); free(res->verified);
+  res->tentatives = nullptr; res->ransac_inlier = nullptr; res->verified = nullptr;
+}
+
+int modsx_last_timings(modsx_ctx *ctx, double *ms6) {
+  NEED(ctx); NEED(ms6);
+  for (int i = 0; i < 6; i++) ms6[i] = ctx->timings[i];
+  return MODSX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,804 @@
+// engine.hip -- host orchestration of the device path (C++ above HIP, below the C ABI).
+//
+// Mirrors, stage by stage, what the reference does per synthesised view in
+// ImageRepresentation::SynthDetectDescribeKeypoints (imagerepresentation.cpp:603-2047) and per pair
+// in mods.cpp:229-415.  Dense per-pixel / per-patch work runs in the HIP kernels; the host keeps the
+// order-dependent bookkeeping (detection order, first-come octaveMap claims, std::sort) and the few
+// libm transcendentals (powf / cos / sin / exp) so they are evaluated by the same libm as on the CPU path.
+#include <math.h>
+#include <algorithm>
+#include <chrono>
+#include <map>
+#include <unordered_set>
+#include "engine_api.hpp"
+
+namespace mx {
+
+static thread_local std::string g_err;
+void set_error(const std::string &s) { g_err = s; }
+const char *last_error() { return g_err.c_str(); }
+
+bool DevBuf::ensure(size_t bytes) {
+  if (bytes <= cap) return true;
+  release();
+  size_t want = bytes + bytes / 4 + 256;
+  if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; cap = 0; set_error("hipMalloc failed"); return false; }
+  cap = want;
+  return true;
+}
+void DevBuf::release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+bool PinBuf::ensure(size_t bytes) {
+  if (bytes <= cap) return true;
+  release();
+  size_t want = bytes + bytes / 4 + 256;
+  if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; cap = 0; set_error("hipHostMalloc failed"); return false; }
+  cap = want;
+  return true;
+}
+void PinBuf::release() { if (p) hipHostFree(p); p = nullptr; cap = 0; }
+
+static double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+static int upload_tables(modsx_ctx *c) {
+  const int PS = 41;
+  std::vector<float> m(PS * PS);
+  MX_HIP(hipMalloc(&c->dOriMask, PS * PS * 4));
+  circular_gauss_mask(m.data(), PS, PS / 3.0f);  // EstimateDominantAnglesFunctor ctor, synth-detection.cpp:757-762
+  MX_HIP(hipMemcpy(c->dOriMask, m.data(), PS * PS * 4, hipMemcpyHostToDevice));
+  MX_HIP(hipMalloc(&c->dSiftMask, PS * PS * 4));
+  circular_gauss_mask(m.data(), PS, 0);          // SIFTDescriptor ctor / DescribeRegions, siftdesc.h:87
+  MX_HIP(hipMemcpy(c->dSiftMask, m.data(), PS * PS * 4, hipMemcpyHostToDevice));
+  MX_HIP(hipMalloc(&c->dAtan, 256 * 8));
+  MX_HIP(hipMemcpy(c->dAtan, atan_lut_host(), 256 * 8, hipMemcpyHostToDevice));
+  // precomputeBinsAndWeights, matching/siftdesc.cpp:22-71 (spatialBins 4, orientationBins 8, patch 41)
+  int bins[2 * PS];
+  double w[2 * PS];
+  const int spatialBins = 4, orientationBins = 8;
+  int halfSize = PS >> 1;
+  float step = float(spatialBins + 1) / (2 * halfSize);
+  for (int i = 0; i < PS; i++) {
+    float x = step * i;
+    int xi = (int)(x);
+    int b0 = xi - 1, b1 = xi;
+    double w1 = x - xi;
+    double w0 = 1.0f - w1;
+    if (b0 < 0) { b0 = 0; w0 = 0; }
+    if (b0 >= spatialBins) { b0 = spatialBins - 1; w0 = 0; }
+    if (b1 < 0) { b1 = 0; w1 = 0; }
+    if (b1 >= spatialBins) { b1 = spatialBins - 1; w1 = 0; }
+    bins[i] = b0 * orientationBins; bins[PS + i] = b1 * orientationBins;
+    w[i] = w0; w[PS + i] = w1;
+  }
+  MX_HIP(hipMalloc(&c->dSiftBins, sizeof bins));
+  MX_HIP(hipMemcpy(c->dSiftBins, bins, sizeof bins, hipMemcpyHostToDevice));
+  MX_HIP(hipMalloc(&c->dSiftW, sizeof w));
+  MX_HIP(hipMemcpy(c->dSiftW, w, sizeof w, hipMemcpyHostToDevice));
+  return MODSX_OK;
+}
+
+modsx_ctx *ctx_create(int device_id) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("no HIP device visible: libmodsx needs an MI355X (gfx950); there is no CPU fallback");
+    return nullptr;
+  }
+  if (device_id < 0 || device_id >= ndev) { set_error("device id out of range"); return nullptr; }
+  if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
+  modsx_ctx *c = new modsx_ctx();
+  c->dev = device_id;
+  if (hipStreamCreate(&c->stream) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
+  for (int i = 0; i < 8; i++) hipEventCreate(&c->ev[i]);
+  for (int i = 0; i < 6; i++) c->timings[i] = 0;
+  if (upload_tables(c) != MODSX_OK) { delete c; return nullptr; }
+  return c;
+}
+
+void ctx_destroy(modsx_ctx *c) {
+  if (!c) return;
+  hipSetDevice(c->dev);
+  hipStreamSynchronize(c->stream);
+  for (int i = 0; i < MAXB; i++) c->pyr[i].store.release();
+  DevBuf *bufs[] = {&c->cand, &c->counter, &c->affJobs, &c->affOut, &c->oriJobs, &c->oriOut, &c->descJobs, &c->tilePrefix,
+                    &c->taps, &c->imgRefs, &c->scratchA, &c->scratchB, &c->descF[0], &c->descF[1], &c->descU8[0],
+                    &c->descU8[1], &c->pos2, &c->matchRows, &c->misc};
+  for (DevBuf *b : bufs) b->release();
+  PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc};
+  for (PinBuf *b : pins) b->release();
+  hipFree(c->dSmmMask); hipFree(c->dOriMask); hipFree(c->dSiftMask); hipFree(c->dAtan); hipFree(c->dSiftBins);
+  hipFree(c->dSiftW);
+  for (int i = 0; i < 8; i++) hipEventDestroy(c->ev[i]);
+  hipStreamDestroy(c->stream);
+  delete c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pyramid
+// ------------------------------------------------------------------------------------------------
+static int cv_round(double v) { return (int)lrint(v); }  // cvRound: round half to even
+
+struct SigmaPlan {
+  int levels;
+  float sigmaStep;
+  float curSigma[8];   // sigma of level i (pyramid.cpp:458-459, 532)
+  float incSigma[8];   // blur applied to level i-1 to get level i (:483)
+};
+
+static SigmaPlan make_sigma_plan(const modsx_hessaff_params &p) {
+  SigmaPlan s;
+  s.levels = p.numberOfScales + 2;
+  s.sigmaStep = powf(2.0f, 1.0f / (float)p.numberOfScales);
+  float cur = p.initialSigma;
+  s.curSigma[0] = cur; s.incSigma[0] = 0;
+  for (int i = 1; i < s.levels; i++) {
+    s.incSigma[i] = cur * sqrtf(s.sigmaStep * s.sigmaStep - 1.0f);
+    cur *= s.sigmaStep;
+    s.curSigma[i] = cur;
+  }
+  return s;
+}
+
+static int fill_taps(BlurBatch &b, float sigma) {
+  int n = blur_ksize(sigma);
+  if (n > MAX_TAPS) { set_error("pyramid blur kernel larger than 17 taps is not supported"); return MODSX_ERR_ARG; }
+  std::vector<float> k = gaussian_kernel(n, sigma);
+  b.n = n;
+  for (int i = 0; i < n; i++) b.k[i] = k[i];
+  return MODSX_OK;
+}
+
+// ScaleSpaceDetector::detectPyramidKeypoints / detectOctaveKeypoints (pyramid.cpp:455-573) for a batch
+// of images: builds every blur and response level in HBM.  firstLevelGiven: the image IS the first level
+// of a single octave (stage tap used by modsx_octave_levels).
+int build_pyramids(modsx_ctx *c, const modsx_image *const *imgs, int n, const modsx_hessaff_params &p,
+                   bool singleOctaveFromFirstLevel) {
+  if (n <= 0 || n > MAXB) { set_error("batch size"); return MODSX_ERR_ARG; }
+  if (p.numberOfScales < 1 || p.numberOfScales > 6) { set_error("numberOfScales"); return MODSX_ERR_ARG; }
+  const SigmaPlan sp = make_sigma_plan(p);
+  const int L = sp.levels;
+  const int minSize = 2 * p.border + 2;
+  int maxOct = 0;
+  for (int i = 0; i < n; i++) {
+    Pyramid &py = c->pyr[i];
+    py.nOct = 0;
+    int rows = imgs[i]->rows, cols = imgs[i]->cols;
+    float pd = 1.0f;
+    size_t total = 0;
+    while (rows > minSize && cols > minSize && py.nOct < 24) {
+      Octave &o = py.oct[py.nOct++];
+      o.rows = rows; o.cols = cols; o.pixelDistance = pd;
+      total += (size_t)2 * L * rows * cols;
+      pd *= 2.0;
+      rows = cv_round(rows * 0.5); cols = cv_round(cols * 0.5);
+      if (singleOctaveFromFirstLevel) break;
+    }
+    if (!py.store.ensure(total * sizeof(float) + 64)) return MODSX_ERR_NOMEM;
+    float *ptr = (float *)py.store.p;
+    for (int o = 0; o < py.nOct; o++) {
+      size_t npx = (size_t)py.oct[o].rows * py.oct[o].cols;
+      for (int l = 0; l < L; l++) { py.oct[o].blur[l] = ptr; ptr += npx; }
+      for (int l = 0; l < L; l++) { py.oct[o].resp[l] = ptr; ptr += npx; }
+    }
+    maxOct = std::max(maxOct, py.nOct);
+  }
+  hipStream_t s = c->stream;
+  for (int o = 0; o < maxOct; o++) {
+    // first level of the octave
+    BlurBatch bb;
+    memset(&bb, 0, sizeof bb);
+    int nj = 0, mr = 0, mc = 0;
+    if (o == 0) {
+      const float curSigma0 = 0.5f;
+      const bool preBlur = !singleOctaveFromFirstLevel && p.initialSigma > curSigma0;
+      if (preBlur) {
+        float sigma = sqrtf(p.initialSigma * p.initialSigma - curSigma0 * curSigma0);
+        int rc = fill_taps(bb, sigma);
+        if (rc) return rc;
+      }
+      for (int i = 0; i < n; i++) {
+        if (c->pyr[i].nOct <= 0) continue;
+        Octave &oc = c->pyr[i].oct[0];
+        BlurJob &j = bb.j[nj++];
+        j.src = imgs[i]->d; j.blur = oc.blur[0]; j.resp = oc.resp[0]; j.rows = oc.rows; j.cols = oc.cols;
+        j.norm = sp.curSigma[0] * sp.curSigma[0];
+        mr = std::max(mr, oc.rows); mc = std::max(mc, oc.cols);
+        if (!preBlur) {
+          MX_HIP(hipMemcpyAsync(oc.blur[0], imgs[i]->d, (size_t)oc.rows * oc.cols * 4, hipMemcpyDeviceToDevice, s));
+          j.src = oc.blur[0];
+        }
+      }
+      if (nj) { if (preBlur) launch_blur_hess(s, bb, nj, mr, mc); else launch_hessian(s, bb, nj, mr, mc); }
+    } else {
+      ResizeBatch rb;
+      memset(&rb, 0, sizeof rb);
+      for (int i = 0; i < n; i++) {
+        if (c->pyr[i].nOct <= o) continue;
+        Octave &pv = c->pyr[i].oct[o - 1], &oc = c->pyr[i].oct[o];
+        ResizeJob &r = rb.j[nj];
+        r.src = pv.blur[p.numberOfScales]; r.dst = oc.blur[0];
+        r.srows = pv.rows; r.scols = pv.cols; r.drows = oc.rows; r.dcols = oc.cols;
+        BlurJob &j = bb.j[nj++];
+        j.src = oc.blur[0]; j.blur = nullptr; j.resp = oc.resp[0]; j.rows = oc.rows; j.cols = oc.cols;
+        j.norm = sp.curSigma[0] * sp.curSigma[0];
+        mr = std::max(mr, oc.rows); mc = std::max(mc, oc.cols);
+      }
+      if (nj) { launch_resize_half(s, rb, nj, mr, mc); launch_hessian(s, bb, nj, mr, mc); }
+    }
+    if (!nj) continue;
+    for (int l = 1; l < L; l++) {
+      BlurBatch b2;
+      memset(&b2, 0, sizeof b2);
+      int rc = fill_taps(b2, sp.incSigma[l]);
+      if (rc) return rc;
+      int k = 0;
+      for (int i = 0; i < n; i++) {
+        if (c->pyr[i].nOct <= o) continue;
+        Octave &oc = c->pyr[i].oct[o];
+        BlurJob &j = b2.j[k++];
+        j.src = oc.blur[l - 1]; j.blur = oc.blur[l]; j.resp = oc.resp[l]; j.rows = oc.rows; j.cols = oc.cols;
+        j.norm = sp.curSigma[l] * sp.curSigma[l];
+      }
+      launch_blur_hess(s, b2, k, mr, mc);
+    }
+  }
+  MX_HIP(hipGetLastError());
+  return MODSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// detection: extrema + localisation on device, detection order + octaveMap + scale on host
+// ------------------------------------------------------------------------------------------------
+static const unsigned CAND_CAP = 1u << 21;
+
+int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const modsx_hessaff_params &p,
+                            std::vector<modsx_sskp> *out) {
+  int rc = build_pyramids(c, imgs, n, p, false);
+  if (rc) return rc;
+  hipStream_t s = c->stream;
+  if (!c->cand.ensure((size_t)CAND_CAP * sizeof(Candidate))) return MODSX_ERR_NOMEM;
+  if (!c->counter.ensure(64)) return MODSX_ERR_NOMEM;
+  MX_HIP(hipMemsetAsync(c->counter.p, 0, 4, s));
+  // thresholds, affinedetectors/pyramid.h:47-67 (DET_HESSIAN)
+  NmsBatch nb;
+  memset(&nb, 0, sizeof nb);
+  nb.edgeScoreThreshold = (p.edgeEigenValueRatio + 1.0f) * (p.edgeEigenValueRatio + 1.0f) / p.edgeEigenValueRatio;
+  float finalTh = p.threshold;
+  float posTh = (float)(0.8 * finalTh);
+  float negTh = -posTh;
+  finalTh = p.threshold * p.threshold;
+  if (p.mode != MODSX_FIXED_TH) finalTh = posTh = negTh = 0.0f;
+  nb.posTh = posTh; nb.negTh = negTh; nb.finalTh = finalTh; nb.border = p.border;
+  int maxOct = 0;
+  for (int i = 0; i < n; i++) maxOct = std::max(maxOct, c->pyr[i].nOct);
+  for (int o = 0; o < maxOct; o++) {
+    int nj = 0, mr = 0, mc = 0;
+    for (int i = 0; i < n; i++) {
+      if (c->pyr[i].nOct <= o) continue;
+      Octave &oc = c->pyr[i].oct[o];
+      for (int l = 1; l <= p.numberOfScales; l++) {
+        NmsJob &j = nb.j[nj++];
+        j.low = oc.resp[l - 1]; j.cur = oc.resp[l]; j.high = oc.resp[l + 1]; j.blur = oc.blur[l];
+        j.rows = oc.rows; j.cols = oc.cols; j.img = i; j.octave = o; j.level = l;
+        mr = std::max(mr, oc.rows); mc = std::max(mc, oc.cols);
+      }
+    }
+    launch_nms(s, nb, nj, mr, mc, (Candidate *)c->cand.p, (unsigned *)c->counter.p, CAND_CAP);
+  }
+  if (!c->hMisc.ensure(64)) return MODSX_ERR_NOMEM;
+  MX_HIP(hipMemcpyAsync(c->hMisc.p, c->counter.p, 4, hipMemcpyDeviceToHost, s));
+  MX_HIP(hipStreamSynchronize(s));
+  unsigned cnt = *(unsigned *)c->hMisc.p;
+  if (cnt > CAND_CAP) { set_error("candidate buffer overflow"); return MODSX_ERR_NOMEM; }
+  if (!c->hCand.ensure((size_t)std::max(1u, cnt) * sizeof(Candidate))) return MODSX_ERR_NOMEM;
+  if (cnt) {
+    MX_HIP(hipMemcpyAsync(c->hCand.p, c->cand.p, (size_t)cnt * sizeof(Candidate), hipMemcpyDeviceToHost, s));
+    MX_HIP(hipStreamSynchronize(s));
+  }
+  Candidate *cd = (Candidate *)c->hCand.p;
+  // the reference visits (octave, level, row, col) in this order (pyramid.cpp:438-451, 490-498, 564-571)
+  std::sort(cd, cd + cnt, [](const Candidate &a, const Candidate &b) {
+    if (a.img != b.img) return a.img < b.img;
+    if (a.octave != b.octave) return a.octave < b.octave;
+    if (a.level != b.level) return a.level < b.level;
+    if (a.r0 != b.r0) return a.r0 < b.r0;
+    return a.c0 < b.c0;
+  });
+  const SigmaPlan sp = make_sigma_plan(p);
+  for (int i = 0; i < n; i++) out[i].clear();
+  std::unordered_set<unsigned long long> claimed;  // octaveMap(r,c) per (image, octave), pyramid.cpp:414-418
+  claimed.reserve(cnt * 2 + 16);
+  for (unsigned k = 0; k < cnt; k++) {
+    const Candidate &q = cd[k];
+    unsigned long long key = ((unsigned long long)q.img << 58) | ((unsigned long long)q.octave << 52) |
+                             ((unsigned long long)q.r << 26) | (unsigned long long)q.c;
+    if (!claimed.insert(key).second) continue;
+    const float pixelDistance = c->pyr[q.img].oct[q.octave].pixelDistance;
+    const float curScale = sp.curSigma[q.level];
+    float scale = curScale * powf(2.0f, q.b2 / p.numberOfScales);
+    modsx_sskp kp;
+    kp.octave = q.octave; kp.level = q.level; kp.r0 = q.r0; kp.c0 = q.c0; kp.r = q.r; kp.c = q.c; kp.type = q.type;
+    kp.pad = 0;
+    kp.b0 = q.b0; kp.b1 = q.b1; kp.b2 = q.b2; kp.val = q.val;
+    kp.x = pixelDistance * (q.c + q.b0);
+    kp.y = pixelDistance * (q.r + q.b1);
+    kp.s = pixelDistance * scale;
+    kp.pixelDistance = pixelDistance;
+    out[q.img].push_back(kp);
+  }
+  return MODSX_OK;
+}
+
+static int ensure_smm_mask(modsx_ctx *c, int W) {
+  if (c->smmW == W && c->dSmmMask) return MODSX_OK;
+  if (W < 3 || W > 19 || !(W & 1)) { set_error("smmWindowSize must be odd and <= 19"); return MODSX_ERR_ARG; }
+  if (c->dSmmMask) hipFree(c->dSmmMask);
+  std::vector<float> m(W * W);
+  gauss_mask(m.data(), W);
+  MX_HIP(hipMalloc(&c->dSmmMask, W * W * 4));
+  MX_HIP(hipMemcpy(c->dSmmMask, m.data(), W * W * 4, hipMemcpyHostToDevice));
+  c->smmW = W;
+  return MODSX_OK;
+}
+
+// AffineDetector::prepareKeysForExport, scale-space-detector.hpp:118-198
+static void prepare_keys_for_export(std::vector<modsx_keypoint> &keys, const modsx_hessaff_params &p) {
+  if (keys.empty() || p.mode == MODSX_FIXED_TH) return;
+  auto cmpv = [](modsx_keypoint k1, modsx_keypoint k2) { return fabs(k1.response) > fabs(k2.response); };
+  std::sort(keys.begin(), keys.end(), cmpv);
+  double maxResponse = fabs(keys[0].response);
+  int regNumber = (int)keys.size();
+  auto cmp = [](const modsx_keypoint &k1, const modsx_keypoint &k2) { return fabs(k1.response) > fabs(k2.response); };
+  switch (p.mode) {
+    case MODSX_RELATIVE_TH: {
+      modsx_keypoint t = keys[0];
+      t.response = (float)(maxResponse * p.rel_threshold);
+      keys.resize(std::lower_bound(keys.begin(), keys.end(), t, cmp) - keys.begin());
+      break;
+    }
+    case MODSX_FIXED_REG_NUMBER: {
+      int nn = p.reg_number;
+      if (p.doBaumberg) nn = (int)floor(3.0 * (double)nn);
+      if ((nn < regNumber) && (nn >= 0)) keys.resize(nn);
+      break;
+    }
+    case MODSX_RELATIVE_REG_NUMBER: {
+      keys.resize((int)floor(p.rel_reg_number * (double)keys.size()));
+      break;
+    }
+    case MODSX_NOT_LESS_THAN_REGIONS: {
+      modsx_keypoint t = keys[0];
+      t.response = p.threshold;
+      int fix = (int)(std::lower_bound(keys.begin(), keys.end(), t, cmp) - keys.begin());
+      if (fix < p.reg_number) keys.resize(std::min(p.reg_number, regNumber));
+      else keys.resize(std::min(fix, regNumber));
+      break;
+    }
+    default: break;
+  }
+  if (p.mode == MODSX_FIXED_REG_NUMBER && (int)keys.size() > p.reg_number) keys.resize(p.reg_number);
+}
+
+// DetectAffineKeypoints (scale-space-detector.cpp:43-85) for a batch of images
+int detect_keypoints_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const modsx_hessaff_params &par,
+                           double tilt, double zoom, std::vector<modsx_keypoint> *out) {
+  modsx_hessaff_params p = par;
+  if ((tilt > 2.0) || (zoom < 0.5)) p.reg_number = (int)floor(zoom * (double)p.reg_number / tilt);
+  std::vector<modsx_sskp> ss[MAXB];
+  int rc = detect_scalespace_batch(c, imgs, n, p, ss);
+  if (rc) return rc;
+  rc = ensure_smm_mask(c, p.smmWindowSize);
+  if (rc) return rc;
+  size_t total = 0;
+  for (int i = 0; i < n; i++) total += ss[i].size();
+  for (int i = 0; i < n; i++) out[i].clear();
+  if (!total) return MODSX_OK;
+  hipStream_t s = c->stream;
+  if (!c->hAff.ensure(total * sizeof(AffJob) + total * sizeof(AffOut))) return MODSX_ERR_NOMEM;
+  if (!c->affJobs.ensure(total * sizeof(AffJob)) || !c->affOut.ensure(total * sizeof(AffOut))) return MODSX_ERR_NOMEM;
+  AffJob *hj = (AffJob *)c->hAff.p;
+  AffOut *ho = (AffOut *)((char *)c->hAff.p + total * sizeof(AffJob));
+  size_t k = 0;
+  for (int i = 0; i < n; i++)
+    for (const modsx_sskp &q : ss[i]) {
+      const Octave &oc = c->pyr[i].oct[q.octave];
+      AffJob &j = hj[k++];
+      j.blur = oc.blur[q.level - 1];  // prevBlur: one level below the detection level (pyramid.cpp:428-429)
+      j.rows = oc.rows; j.cols = oc.cols;
+      j.x = q.x; j.y = q.y; j.s = q.s; j.pixelDistance = q.pixelDistance;
+    }
+  if (p.doBaumberg) {
+    MX_HIP(hipMemcpyAsync(c->affJobs.p, hj, total * sizeof(AffJob), hipMemcpyHostToDevice, s));
+    launch_baumberg(s, (AffJob *)c->affJobs.p, (AffOut *)c->affOut.p, (int)total, c->dSmmMask, p.smmWindowSize,
+                    p.maxIterations, p.convergenceThreshold, p.affInitialSigma);
+    MX_HIP(hipMemcpyAsync(ho, c->affOut.p, total * sizeof(AffOut), hipMemcpyDeviceToHost, s));
+    MX_HIP(hipStreamSynchronize(s));
+  } else {
+    for (size_t i = 0; i < total; i++) { ho[i].u11 = 1; ho[i].u12 = 0; ho[i].u21 = 0; ho[i].u22 = 1; ho[i].ok = 1; ho[i].iters = 0; }
+  }
+  k = 0;
+  for (int i = 0; i < n; i++) {
+    for (const modsx_sskp &q : ss[i]) {
+      const AffOut &a = ho[k++];
+      if (!a.ok) continue;
+      modsx_keypoint kp;
+      memset(&kp, 0, sizeof kp);
+      kp.x = q.x; kp.y = q.y; kp.s = q.s;
+      kp.a11 = a.u11; kp.a12 = a.u12; kp.a21 = a.u21; kp.a22 = a.u22;
+      kp.response = q.val;
+      kp.sub_type = q.type;
+      out[i].push_back(kp);
+    }
+    prepare_keys_for_export(out[i], p);
+  }
+  return MODSX_OK;
+}
+
+// DetectAffineRegions<>, synth-detection.hpp:93-126
+void detect_affine_regions(const modsx_keypoint *kps, int n, int img_id, int det_type, modsx_region *out) {
+  for (int i = 0; i < n; i++) {
+    modsx_keypoint k = kps[i];
+    modsx_region r;
+    memset(&r, 0, sizeof r);
+    r.img_id = img_id; r.img_reproj_id = 0; r.type = det_type; r.id = i;
+    r.det_kp.s = k.s * sqrt(fabs(k.a11 * k.a22 - k.a12 * k.a21));
+    rectify(k.a11, k.a12, k.a21, k.a22);
+    r.det_kp.x = k.x; r.det_kp.y = k.y;
+    r.det_kp.a11 = k.a11; r.det_kp.a12 = k.a12; r.det_kp.a21 = k.a21; r.det_kp.a22 = k.a22;
+    r.det_kp.response = k.response;
+    r.det_kp.sub_type = k.sub_type;
+    out[i] = r;
+  }
+}
+
+static const double K_SIGMA = 2 * 3.0 * sqrt(3.0);  // synth-detection.cpp:28
+
+static int upload_img_refs(modsx_ctx *c, const modsx_image *const *imgs, int n) {
+  if (!c->imgRefs.ensure(MAXB * sizeof(ImgRef))) return MODSX_ERR_NOMEM;
+  ImgRef refs[MAXB];
+  memset(refs, 0, sizeof refs);
+  for (int i = 0; i < n; i++) { refs[i].d = imgs[i]->d; refs[i].rows = imgs[i]->rows; refs[i].cols = imgs[i]->cols; }
+  MX_HIP(hipMemcpyAsync(c->imgRefs.p, refs, sizeof refs, hipMemcpyHostToDevice, c->stream));
+  MX_HIP(hipStreamSynchronize(c->stream));  // refs[] is a stack buffer
+  return MODSX_OK;
+}
+
+// DetectOrientation, synth-detection.cpp:841-919, for a batch of (image, region list)
+int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const std::vector<modsx_region> *in,
+                             double mrSize, int patchSize, int doHalfSIFT, int maxAngNum, double th, int addUpRight,
+                             std::vector<modsx_region> *out) {
+  if (patchSize != 41) { set_error("orientation patchSize must be 41"); return MODSX_ERR_ARG; }
+  for (int i = 0; i < n; i++) out[i].clear();
+  double mrScale = (double)mrSize;
+  int patchImageSize = 2 * int(mrScale) + 1;
+  double imageToPatchScale = double(patchImageSize) / (double)patchSize;
+  struct Ref { int img, idx; };
+  std::vector<Ref> refs;
+  std::vector<OriJob> jobs;
+  std::vector<char> passed[MAXB];
+  for (int i = 0; i < n; i++) {
+    passed[i].assign(in[i].size(), 0);
+    for (size_t r = 0; r < in[i].size(); r++) {
+      const modsx_keypoint &k = in[i][r].det_kp;
+      if (check_borders_host(imgs[i]->cols, imgs[i]->rows, (float)k.x, (float)k.y, (float)k.a11, (float)k.a12,
+                             (float)k.a21, (float)k.a22, (int)(K_SIGMA * k.s), (int)(K_SIGMA * k.s)))
+        continue;
+      passed[i][r] = 1;
+      if (maxAngNum > 0) {
+        float curr_sc = imageToPatchScale * k.s;
+        OriJob j;
+        j.img = i; j.x = (float)k.x; j.y = (float)k.y;
+        j.a11 = (float)k.a11 * curr_sc; j.a12 = (float)k.a12 * curr_sc;
+        j.a21 = (float)k.a21 * curr_sc; j.a22 = (float)k.a22 * curr_sc;
+        jobs.push_back(j);
+        refs.push_back({i, (int)r});
+      }
+    }
+  }
+  std::vector<OriOut> res(jobs.size());
+  if (!jobs.empty()) {
+    int rc = upload_img_refs(c, imgs, n);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    size_t nj = jobs.size();
+    if (!c->oriJobs.ensure(nj * sizeof(OriJob)) || !c->oriOut.ensure(nj * sizeof(OriOut))) return MODSX_ERR_NOMEM;
+    MX_HIP(hipMemcpyAsync(c->oriJobs.p, jobs.data(), nj * sizeof(OriJob), hipMemcpyHostToDevice, s));
+    int maxA = maxAngNum == -1 ? 7 : std::min(maxAngNum, 7);
+    launch_orientation(s, (OriJob *)c->oriJobs.p, (OriOut *)c->oriOut.p, (int)nj, (ImgRef *)c->imgRefs.p, c->dOriMask,
+                       c->dAtan, doHalfSIFT, th, maxA);
+    MX_HIP(hipMemcpyAsync(res.data(), c->oriOut.p, nj * sizeof(OriOut), hipMemcpyDeviceToHost, s));
+    MX_HIP(hipStreamSynchronize(s));
+  }
+  size_t jk = 0;
+  for (int i = 0; i < n; i++) {
+    for (size_t r = 0; r < in[i].size(); r++) {
+      if (!passed[i][r]) continue;
+      modsx_region base = in[i][r];
+      if (maxAngNum > 0) {
+        base.id = 0;  // const_temp_region.id = count, count is never incremented (synth-detection.cpp:854,889)
+        const OriOut &o = res[jk++];
+        for (int a = 0; a < o.n; a++) {
+          double ci = cos(-o.ang[a]);
+          double si = sin(-o.ang[a]);
+          modsx_region t = base;
+          t.det_kp.a11 = base.det_kp.a11 * ci - base.det_kp.a12 * si;
+          t.det_kp.a12 = base.det_kp.a11 * si + base.det_kp.a12 * ci;
+          t.det_kp.a21 = base.det_kp.a21 * ci - base.det_kp.a22 * si;
+          t.det_kp.a22 = base.det_kp.a21 * si + base.det_kp.a22 * ci;
+          out[i].push_back(t);
+        }
+      }
+      if (addUpRight) out[i].push_back(base);
+    }
+  }
+  return MODSX_OK;
+}
+
+// ReprojectRegions, synth-detection.cpp:541-616
+int reproject_regions(modsx_region *regs, int n, const double *H, int orig_w, int orig_h) {
+  double eyeTest = fabs(H[0] - 1.0) + fabs(H[1]) + fabs(H[2]) + fabs(H[3]) + fabs(H[4] - 1.0) + fabs(H[5]) + fabs(H[6]) +
+                   fabs(H[7]) + fabs(H[8] - 1.0);
+  double Hi[9];
+  invert3(H, Hi);
+  for (int i = 0; i < n; i++) {
+    regs[i].reproj_kp = regs[i].det_kp;
+    if (!(eyeTest < 0.01)) {
+      const modsx_keypoint k = regs[i].det_kp;
+      modsx_keypoint &o = regs[i].reproj_kp;
+      o.x = (Hi[0] * k.x + Hi[1] * k.y + Hi[2]);
+      o.y = (Hi[3] * k.x + Hi[4] * k.y + Hi[5]);
+      o.a11 = (Hi[0] * k.a11 + Hi[1] * k.a21);
+      o.a12 = (Hi[0] * k.a12 + Hi[1] * k.a22);
+      o.a21 = (Hi[3] * k.a11 + Hi[4] * k.a21);
+      o.a22 = (Hi[3] * k.a12 + Hi[4] * k.a22);
+    }
+  }
+  int m = 0;
+  for (int i = 0; i < n; i++) {
+    const modsx_keypoint &k = regs[i].reproj_kp;
+    if ((k.x < orig_w) && (k.y < orig_h) && (k.x > 0) && (k.y > 0)) {
+      if (!check_borders_host(orig_w, orig_h, (float)k.x, (float)k.y, (float)k.a11, (float)k.a12, (float)k.a21,
+                              (float)k.a22, (int)(K_SIGMA * k.s), (int)(K_SIGMA * k.s)))
+        regs[m++] = regs[i];
+    }
+  }
+  return m;
+}
+
+// DescribeRegions<SIFTDescriptor>, synth-detection.hpp:169-255, for a batch.  Descriptors stay in HBM
+// (c->descF[i], c->descU8[i]); descHost[i] (optional) receives the f32 copy.
+int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const std::vector<modsx_region> *regs,
+                   double mrSize, int patchSize, int fast, int photoNorm, int descType, double maxBin,
+                   float *const *descHost) {
+  if (patchSize != 41) { set_error("descriptor patchSize must be 41"); return MODSX_ERR_ARG; }
+  if (n > 2) { set_error("describe batch > 2 images"); return MODSX_ERR_ARG; }
+  hipStream_t s = c->stream;
+  int rc = upload_img_refs(c, imgs, n);
+  if (rc) return rc;
+  const size_t ARENA_FLOATS = (size_t)192 << 20;  // 768 MiB per arena per chunk
+  for (int i = 0; i < n; i++) {
+    const size_t nr = regs[i].size();
+    if (!c->descF[i].ensure(std::max<size_t>(1, nr) * 128 * 4) || !c->descU8[i].ensure(std::max<size_t>(1, nr) * 128))
+      return MODSX_ERR_NOMEM;
+    size_t done = 0;
+    while (done < nr) {
+      std::vector<DescJob> jobs;
+      std::vector<int> pfxSample(1, 0), pfxBlur(1, 0);
+      std::vector<float> taps;
+      std::map<int, std::pair<int, int>> tapIdx;  // P -> (offset, ksize)
+      size_t arena = 0;
+      size_t r = done;
+      for (; r < nr; r++) {
+        const modsx_keypoint &k = regs[i][r].det_kp;
+        DescJob j;
+        memset(&j, 0, sizeof j);
+        j.img = i;
+        j.x = (float)k.x; j.y = (float)k.y;
+        if (!fast) {
+          float mrScale = (float)ceil(k.s * mrSize);
+          int patchImageSize = 2 * int(mrScale) + 1;
+          float i2p = float(patchImageSize) / float(patchSize);
+          j.i2p = i2p;
+          if (i2p > 0.4) {
+            patchImageSize += 2;
+            size_t need = (size_t)patchImageSize * patchImageSize;
+            if (arena + need > ARENA_FLOATS && !jobs.empty()) break;
+            j.P = patchImageSize;
+            j.a11 = (float)k.a11; j.a12 = (float)k.a12; j.a21 = (float)k.a21; j.a22 = (float)k.a22;
+            j.scratchOfs = arena;
+            arena += need;
+            auto it = tapIdx.find(patchImageSize);
+            if (it == tapIdx.end()) {
+              float sigma = 1.5f * i2p;
+              int ks = blur_ksize(sigma);
+              if (ks > patchImageSize * 2 + 1) ks = ks;  // replicate border handles any ksize
+              std::vector<float> kk = gaussian_kernel(ks, sigma);
+              it = tapIdx.insert({patchImageSize, {(int)taps.size(), ks}}).first;
+              taps.insert(taps.end(), kk.begin(), kk.end());
+            }
+            j.tapOfs = it->second.first; j.ksize = it->second.second;
+          } else {
+            j.P = 0;
+            j.a11 = (float)k.a11 * i2p; j.a12 = (float)k.a12 * i2p; j.a21 = (float)k.a21 * i2p; j.a22 = (float)k.a22 * i2p;
+          }
+        } else {
+          double mrScale = (double)mrSize * k.s;
+          int patchImageSize = 2 * int(mrScale) + 1;
+          double i2pd = double(patchImageSize) / (double)patchSize;
+          float curr_sc = i2pd;
+          j.P = 0; j.i2p = curr_sc;
+          j.a11 = (float)k.a11 * curr_sc; j.a12 = (float)k.a12 * curr_sc; j.a21 = (float)k.a21 * curr_sc; j.a22 = (float)k.a22 * curr_sc;
+        }
+        jobs.push_back(j);
+        pfxSample.push_back(pfxSample.back() + (j.P > 0 ? (j.P + 63) / 64 : 0));
+        pfxBlur.push_back(pfxBlur.back() + (j.P > 0 ? (j.P * j.P + 255) / 256 : 0));
+      }
+      const size_t nj = jobs.size();
+      if (!c->descJobs.ensure(nj * sizeof(DescJob)) || !c->tilePrefix.ensure((nj + 1) * 8) ||
+          !c->taps.ensure(std::max<size_t>(1, taps.size()) * 4) || !c->scratchA.ensure(std::max<size_t>(1, arena) * 4) ||
+          !c->scratchB.ensure(std::max<size_t>(1, arena) * 4))
+        return MODSX_ERR_NOMEM;
+      int *dPfxS = (int *)c->tilePrefix.p, *dPfxB = dPfxS + (nj + 1);
+      MX_HIP(hipMemcpyAsync(c->descJobs.p, jobs.data(), nj * sizeof(DescJob), hipMemcpyHostToDevice, s));
+      MX_HIP(hipMemcpyAsync(dPfxS, pfxSample.data(), (nj + 1) * 4, hipMemcpyHostToDevice, s));
+      MX_HIP(hipMemcpyAsync(dPfxB, pfxBlur.data(), (nj + 1) * 4, hipMemcpyHostToDevice, s));
+      if (!taps.empty()) MX_HIP(hipMemcpyAsync(c->taps.p, taps.data(), taps.size() * 4, hipMemcpyHostToDevice, s));
+      const DescJob *dj = (const DescJob *)c->descJobs.p;
+      launch_patch_sample(s, dj, dPfxS, (int)nj, pfxSample.back(), (ImgRef *)c->imgRefs.p, (float *)c->scratchA.p);
+      launch_patch_blur(s, dj, dPfxB, (int)nj, pfxBlur.back(), (float *)c->taps.p, (float *)c->scratchA.p,
+                        (float *)c->scratchB.p, 0);
+      launch_patch_blur(s, dj, dPfxB, (int)nj, pfxBlur.back(), (float *)c->taps.p, (float *)c->scratchB.p,
+                        (float *)c->scratchA.p, 1);
+      launch_describe(s, dj, (int)nj, (ImgRef *)c->imgRefs.p, (float *)c->scratchA.p, c->dSiftMask, c->dAtan,
+                      c->dSiftBins, c->dSiftW, photoNorm, descType == MODSX_DESC_ROOT_SIFT, maxBin,
+                      (float *)c->descF[i].p + done * 128, (uint8_t *)c->descU8[i].p + done * 128);
+      MX_HIP(hipStreamSynchronize(s));  // jobs/taps/prefix are host vectors reused by the next chunk
+      done = r;
+    }
+    if (descHost && descHost[i] && nr) {
+      MX_HIP(hipMemcpyAsync(descHost[i], c->descF[i].p, nr * 128 * 4, hipMemcpyDeviceToHost, s));
+      MX_HIP(hipStreamSynchronize(s));
+    }
+  }
+  MX_HIP(hipGetLastError());
+  return MODSX_OK;
+}
+
+// MatchFlannFGINN (matching/matching.cpp:357-461, linear index) on descriptors resident in HBM
+int match_device(modsx_ctx *c, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2Host,
+                 double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out) {
+  out.clear();
+  if (n1 == 0 || n2 == 0) return MODSX_OK;
+  hipStream_t s = c->stream;
+  const double sqminratio = ratioT * ratioT, contrDistSq = contradDist * contradDist;
+  if (!(sqminratio < 1.0)) { set_error("match ratio >= 1 (PDF mode of MatchFlannFGINN) is not supported"); return MODSX_ERR_ARG; }
+  if (!c->pos2.ensure((size_t)n2 * 16) || !c->matchRows.ensure((size_t)n1 * sizeof(MatchRow))) return MODSX_ERR_NOMEM;
+  MX_HIP(hipMemcpyAsync(c->pos2.p, pos2Host, (size_t)n2 * 16, hipMemcpyHostToDevice, s));
+  launch_match(s, d1, n1, d2, n2, (const double *)c->pos2.p, sqminratio, contrDistSq, (MatchRow *)c->matchRows.p);
+  std::vector<MatchRow> rows(n1);
+  MX_HIP(hipMemcpyAsync(rows.data(), c->matchRows.p, (size_t)n1 * sizeof(MatchRow), hipMemcpyDeviceToHost, s));
+  MX_HIP(hipStreamSynchronize(s));
+  MX_HIP(hipGetLastError());
+  out.reserve(n1 / 4 + 16);
+  for (int q = 0; q < n1; q++) {
+    const MatchRow &r = rows[q];
+    // rank of the first ratio-passing neighbour is nless+1; it must be <= nn-1 and every neighbour
+    // before it must lie within contradDist of NN0 (matching.cpp:435-457)
+    if (r.t0 < 0 || r.tj < 0 || r.nbad != 0 || r.nless > nn - 2) continue;
+    modsx_tentative t;
+    t.q = q; t.t0 = r.t0; t.tj = r.tj;
+    t.t1 = r.t1;
+    t.d1 = r.d0; t.d2 = r.dj; t.d2by2ndcl = r.d1;
+    double ratio = r.d0 / r.dj;  // f32 / f32, then widened (matching.cpp:437)
+    t.ratio = sqrt(ratio);
+    out.push_back(t);
+  }
+  return MODSX_OK;
+}
+
+static void desc_f32_to_u8(const float *f, size_t n, uint8_t *u) {
+  for (size_t i = 0; i < n; i++) {
+    float v = f[i];
+    int b = (int)v;
+    u[i] = (uint8_t)(b < 0 ? 0 : (b > 255 ? 255 : b));
+  }
+}
+
+int match_host_desc(modsx_ctx *c, const float *desc1, int n1, const float *desc2, int n2, const double *pos2,
+                    double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out) {
+  out.clear();
+  if (n1 == 0 || n2 == 0) return MODSX_OK;
+  std::vector<uint8_t> u1((size_t)n1 * 128), u2((size_t)n2 * 128);
+  desc_f32_to_u8(desc1, u1.size(), u1.data());
+  desc_f32_to_u8(desc2, u2.size(), u2.data());
+  if (!c->descU8[0].ensure(u1.size()) || !c->descU8[1].ensure(u2.size())) return MODSX_ERR_NOMEM;
+  MX_HIP(hipMemcpyAsync(c->descU8[0].p, u1.data(), u1.size(), hipMemcpyHostToDevice, c->stream));
+  MX_HIP(hipMemcpyAsync(c->descU8[1].p, u2.data(), u2.size(), hipMemcpyHostToDevice, c->stream));
+  MX_HIP(hipStreamSynchronize(c->stream));
+  return match_device(c, (uint8_t *)c->descU8[0].p, n1, (uint8_t *)c->descU8[1].p, n2, pos2, ratioT, contradDist, nn, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// one step of the mods.cpp loop for an identity view
+// ------------------------------------------------------------------------------------------------
+int match_pair(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_pair_params &pp,
+               modsx_pair_result *res) {
+  memset(res, 0, sizeof *res);
+  for (int i = 0; i < 9; i++) res->H[i] = -1;
+  const modsx_image *imgs[2] = {img1, img2};
+  const double t0 = now_ms();
+  std::vector<modsx_keypoint> kps[2];
+  int rc = detect_keypoints_batch(c, imgs, 2, pp.det, 1.0, 1.0, kps);
+  if (rc) return rc;
+  std::vector<modsx_region> regs[2], oriented[2];
+  for (int i = 0; i < 2; i++) {
+    regs[i].resize(kps[i].size());
+    detect_affine_regions(kps[i].data(), (int)kps[i].size(), 0, MODSX_DET_HESSIAN, regs[i].data());
+  }
+  const double t1 = now_ms();
+  rc = detect_orientation_batch(c, imgs, 2, regs, pp.ori_mrSize, pp.ori_patchSize, 0, pp.ori_maxAngles, pp.ori_threshold,
+                                0, oriented);
+  if (rc) return rc;
+  const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int i = 0; i < 2; i++) {
+    int m = reproject_regions(oriented[i].data(), (int)oriented[i].size(), eye, imgs[i]->cols, imgs[i]->rows);
+    oriented[i].resize(m);
+  }
+  const double t2 = now_ms();
+  rc = describe_batch(c, imgs, 2, oriented, pp.desc_mrSize, pp.desc_patchSize, 0, pp.desc_photoNorm, pp.desc_type,
+                      pp.desc_maxBinValue, nullptr);
+  if (rc) return rc;
+  const double t3 = now_ms();
+  res->n_regions1 = (int)oriented[0].size();
+  res->n_regions2 = (int)oriented[1].size();
+  std::vector<double> pos2(oriented[1].size() * 2 + 2);
+  for (size_t i = 0; i < oriented[1].size(); i++) { pos2[2 * i] = oriented[1][i].reproj_kp.x; pos2[2 * i + 1] = oriented[1][i].reproj_kp.y; }
+  std::vector<modsx_tentative> tents;
+  rc = match_device(c, (uint8_t *)c->descU8[0].p, res->n_regions1, (uint8_t *)c->descU8[1].p, res->n_regions2,
+                    pos2.data(), pp.match_ratio, pp.contradDist, pp.nn, tents);
+  if (rc) return rc;
+  const double t4 = now_ms();
+  res->n_tentatives = (int)tents.size();
+  const int T0 = (int)tents.size();
+  std::vector<double> pts((size_t)T0 * 4 + 4), key(T0 + 1);
+  for (int i = 0; i < T0; i++) {
+    const modsx_keypoint &a = oriented[0][tents[i].q].reproj_kp, &b = oriented[1][tents[i].t0].reproj_kp;
+    pts[4 * i] = a.x; pts[4 * i + 1] = a.y; pts[4 * i + 2] = b.x; pts[4 * i + 3] = b.y;
+    key[i] = tents[i].ratio;
+  }
+  std::vector<int> order(T0 + 1);
+  std::vector<unsigned char> keepd(T0 + 1);
+  duplicate_filtering(pts.data(), key.data(), T0, pp.duplicateDist, 1, order.data(), keepd.data());
+  std::vector<modsx_tentative> uniq;
+  for (int i = 0; i < T0; i++) if (keepd[i]) uniq.push_back(tents[order[i]]);
+  const int T = (int)uniq.size();
+  res->n_unique = T;
+  std::vector<double> p2((size_t)T * 4 + 4), l1((size_t)T * 5 + 5), l2((size_t)T * 5 + 5);
+  for (int i = 0; i < T; i++) {
+    const modsx_keypoint &a = oriented[0][uniq[i].q].reproj_kp, &b = oriented[1][uniq[i].t0].reproj_kp;
+    p2[4 * i] = a.x; p2[4 * i + 1] = a.y; p2[4 * i + 2] = b.x; p2[4 * i + 3] = b.y;
+    l1[5 * i] = a.a11; l1[5 * i + 1] = a.a12; l1[5 * i + 2] = a.a21; l1[5 * i + 3] = a.a22; l1[5 * i + 4] = a.s;
+    l2[5 * i] = b.a11; l2[5 * i + 1] = b.a12; l2[5 * i + 2] = b.a21; l2[5 * i + 3] = b.a22; l2[5 * i + 4] = b.s;
+  }
+  res->tentatives = (modsx_tentative *)malloc(sizeof(modsx_tentative) * std::max(1, T));
+  res->ransac_inlier = (unsigned char *)calloc(std::max(1, T), 1);
+  res->verified = (unsigned char *)calloc(std::max(1, T), 1);
+  for (int i = 0; i < T; i++) res->tentatives[i] = uniq[i];
+  double Hraw[9];
+  int dout[3] = {0, 0, 0};
+  int nv = loransac_h(p2.data(), l1.data(), l2.data(), T, pp.err_threshold, pp.confidence, pp.max_samples,
+                      pp.localOptimization, pp.HLAFCoef, pp.doSymmCheck, pp.ransac_seed, res->H, Hraw, res->ransac_inlier,
+                      res->verified, dout);
+  res->n_verified = nv < 0 ? 0 : nv;
+  for (int i = 0; i < T; i++) res->n_ransac_inliers += res->ransac_inlier[i];
+  res->ransac_samples = dout[0]; res->ransac_lo = dout[1];
+  const double t5 = now_ms();
+  c->timings[0] = t1 - t0; c->timings[1] = t2 - t1; c->timings[2] = t3 - t2; c->timings[3] = t4 - t3;
+  c->timings[4] = t5 - t4; c->timings[5] = t5 - t0;
+  return MODSX_OK;
+}
+
+}  // namespace mx

@@ -1,0 +1,179 @@
+// engine.hpp -- internal types of libmodsx (device job descriptors, context, host helpers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/modsx.h"
+#include "kmath.hpp"
+
+namespace mx {
+
+// ---- device job descriptors (passed by value in kernel arguments) ----------------------
+constexpr int MAXB = 8;        // images per batched pyramid launch
+constexpr int NMS_MAXJ = 48;   // (image, octave, level) jobs per NMS launch
+constexpr int MAX_TAPS = 17;   // pyramid kernels: ksize <= 17
+
+struct BlurJob {
+  const float *src;
+  float *blur;   // may alias nothing; nullptr for k_hessian
+  float *resp;   // nullptr = no response
+  int rows, cols;
+  float norm;    // sigma^2 passed to HessianResponse
+  int pad;
+};
+struct BlurBatch {
+  int n;                 // ksize
+  float k[MAX_TAPS];
+  BlurJob j[MAXB];
+};
+struct ResizeJob {
+  const float *src;
+  float *dst;
+  int srows, scols, drows, dcols;
+};
+struct ResizeBatch { ResizeJob j[MAXB]; };
+struct NmsJob {
+  const float *low, *cur, *high, *blur;
+  int rows, cols, img, octave, level, pad;
+};
+struct NmsBatch {
+  float posTh, negTh, finalTh;
+  int border;
+  double edgeScoreThreshold;
+  NmsJob j[NMS_MAXJ];
+};
+struct Candidate {
+  int img, octave, level, type;
+  int r0, c0, r, c;
+  float b0, b1, b2, val;
+};
+
+// Baumberg: one wave per scale-space keypoint
+struct AffJob {
+  const float *blur;  // prevBlur level
+  int rows, cols;
+  float x, y, s, pixelDistance;
+};
+struct AffOut { float u11, u12, u21, u22; int ok; int iters; };
+
+// orientation: one wave per region
+struct OriJob {
+  int img;
+  float x, y, a11, a12, a21, a22;  // A * curr_sc, f32 (synth-detection.cpp:892-898)
+};
+struct OriOut { int n; float ang[7]; };
+
+// describe
+struct DescJob {
+  int img;
+  int P;              // patchImageSize (+2 when smoothed), 0 = direct mode
+  int ksize;          // blur kernel size for 1.5*imageToPatchScale
+  int tapOfs;         // offset into the tap table
+  float x, y, a11, a12, a21, a22;   // direct mode: A * imageToPatchScale
+  float i2p;          // imageToPatchScale
+  unsigned long long scratchOfs;    // float offset of this region's (P x P) scratch
+};
+struct ImgRef { const float *d; int rows, cols, pad; };
+
+// matching
+struct MatchRow {     // per-query result of the device matcher
+  int t0, t1, tj, nless, nbad;
+  float d0, d1, dj;
+};
+
+// ---- host side ---------------------------------------------------------------------------
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  bool ensure(size_t bytes);
+  void release();
+};
+struct PinBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  bool ensure(size_t bytes);
+  void release();
+};
+
+struct Octave {
+  int rows, cols;
+  float pixelDistance;
+  float *blur[8];
+  float *resp[8];
+};
+struct Pyramid {
+  int nOct = 0;
+  Octave oct[24];
+  DevBuf store;
+};
+
+void set_error(const std::string &s);
+#define MX_HIP(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      mx::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+      return MODSX_ERR_DEVICE;                                                                \
+    }                                                                                         \
+  } while (0)
+
+// tables.cpp (host precomputation, reference semantics)
+std::vector<float> gaussian_kernel(int n, double sigma);
+int blur_ksize(float sigma);
+void gauss_mask(float *mask, int size);
+void circular_gauss_mask(float *mask, int size, float sigma);
+const double *atan_lut_host();
+bool check_borders_host(int w, int h, float ofsx, float ofsy, float a11, float a12, float a21, float a22, int rw, int rh);
+bool invert3(const double *S, double *t);
+void rectify(double &a11, double &a12, double &a21, double &a22);
+
+// kernel launchers
+void launch_blur_hess(hipStream_t s, const BlurBatch &b, int nj, int maxRows, int maxCols);
+void launch_hessian(hipStream_t s, const BlurBatch &b, int nj, int maxRows, int maxCols);
+void launch_resize_half(hipStream_t s, const ResizeBatch &b, int nj, int maxRows, int maxCols);
+void launch_nms(hipStream_t s, const NmsBatch &b, int nj, int maxRows, int maxCols, Candidate *out, unsigned *counter,
+                unsigned cap);
+void launch_gray(hipStream_t s, const void *src, float *dst, size_t n, int channels, int dtype);
+void launch_baumberg(hipStream_t s, const AffJob *jobs, AffOut *out, int n, const float *mask, int W, int maxIter,
+                     float convTh, float affInitialSigma);
+void launch_orientation(hipStream_t s, const OriJob *jobs, OriOut *out, int n, const ImgRef *imgs, const float *orimask,
+                        const double *atanLut, int doHalf, double th, int maxAngles);
+void launch_patch_sample(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, int nTiles,
+                         const ImgRef *imgs, float *scratch);
+void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, int nTiles,
+                       const float *taps, const float *src, float *dst, int pass);
+void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *imgs, const float *scratch,
+                     const float *mask, const double *atanLut, const int *bins, const double *wts, int photoNorm,
+                     int rootsift, double maxBin, float *descF, uint8_t *descU8);
+void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2,
+                  double sqminratio, double contrDistSq, MatchRow *rows);
+
+}  // namespace mx
+
+struct modsx_image {
+  float *d;
+  int rows, cols;
+  bool owned;
+};
+
+struct modsx_ctx {
+  int dev;
+  hipStream_t stream;
+  mx::Pyramid pyr[mx::MAXB];
+  mx::DevBuf cand, counter, affJobs, affOut, oriJobs, oriOut, descJobs, tilePrefix, taps, imgRefs, scratchA, scratchB,
+      descF[2], descU8[2], pos2, matchRows, misc;
+  mx::PinBuf hCand, hAff, hOri, hDesc, hMisc;
+  // constant tables on device
+  float *dSmmMask = nullptr;   // 19x19 computeGaussMask
+  int smmW = 0;
+  float *dOriMask = nullptr;   // 41x41 circular mask, sigma = 41/3
+  float *dSiftMask = nullptr;  // 41x41 circular mask, sigma2 = 0.9 r^2
+  double *dAtan = nullptr;
+  int *dSiftBins = nullptr;    // bin0[41], bin1[41]
+  double *dSiftW = nullptr;    // w0[41], w1[41]
+  hipEvent_t ev[8];
+  double timings[6];
+};

@@ -1,0 +1,40 @@
+// engine_api.hpp -- functions shared between engine.hip, ransac.cpp, filters.cpp and capi.hip.
+#pragma once
+#include <vector>
+#include "engine.hpp"
+
+namespace mx {
+const char *last_error();
+modsx_ctx *ctx_create(int device_id);
+void ctx_destroy(modsx_ctx *c);
+int build_pyramids(modsx_ctx *c, const modsx_image *const *imgs, int n, const modsx_hessaff_params &p,
+                   bool singleOctaveFromFirstLevel);
+int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const modsx_hessaff_params &p,
+                            std::vector<modsx_sskp> *out);
+int detect_keypoints_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const modsx_hessaff_params &par,
+                           double tilt, double zoom, std::vector<modsx_keypoint> *out);
+void detect_affine_regions(const modsx_keypoint *kps, int n, int img_id, int det_type, modsx_region *out);
+int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const std::vector<modsx_region> *in,
+                             double mrSize, int patchSize, int doHalfSIFT, int maxAngNum, double th, int addUpRight,
+                             std::vector<modsx_region> *out);
+int reproject_regions(modsx_region *regs, int n, const double *H, int orig_w, int orig_h);
+int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const std::vector<modsx_region> *regs,
+                   double mrSize, int patchSize, int fast, int photoNorm, int descType, double maxBin,
+                   float *const *descHost);
+int match_device(modsx_ctx *c, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2Host,
+                 double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out);
+int match_host_desc(modsx_ctx *c, const float *desc1, int n1, const float *desc2, int n2, const double *pos2,
+                    double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out);
+int match_pair(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_pair_params &pp,
+               modsx_pair_result *res);
+
+// filters.cpp / ransac.cpp (host)
+int duplicate_filtering(const double *pts, const double *key, int T, double r, int do_sort, int *order,
+                        unsigned char *keep);
+int ransac_h(const double *u, int len, double th, double conf, int max_sam, double *H, unsigned char *inl, int *data_out,
+             int oriented_constraint, int doSymCheck, unsigned seed0, double *scoreJ);
+void hds_sym(const double *u, const double *H, double *p, int len, bool takeMax);
+int loransac_h(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold,
+               double confidence, int max_samples, int lo, double HLAFCoef, int doSymmCheck, unsigned seed, double *H,
+               double *Hraw, unsigned char *inl, unsigned char *keep, int *data_out);
+}  // namespace mx

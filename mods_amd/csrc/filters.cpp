@@ -1,0 +1,109 @@
+// filters.cpp -- host-side correspondence filters around the verifier.
+//   DuplicateFiltering                       matching/matching.cpp:2983-3047
+//   LORANSACFiltering (H branch, Sampson)    matching/matching.cpp:806-980
+//   NaiveHCheck                              matching/matching.cpp:1171-1200
+//   H_LAF_check                              matching/matching.cpp:251-309
+#include <math.h>
+#include <algorithm>
+#include "engine_api.hpp"
+
+namespace mx {
+
+// The reference sorts the tentatives with std::sort (unstable) on |ratio| before the greedy O(T^2)
+// pass; the same libstdc++ introsort on the same key sequence yields the same permutation.
+int duplicate_filtering(const double *pts, const double *key, int T, double r, int do_sort, int *order,
+                        unsigned char *keep) {
+  struct E { double key; int i; };
+  std::vector<E> v(T);
+  for (int i = 0; i < T; i++) { v[i].key = key ? key[i] : 0; v[i].i = i; }
+  if (r <= 0) {
+    for (int i = 0; i < T; i++) { order[i] = i; keep[i] = 1; }
+    return T;
+  }
+  if (do_sort) std::sort(v.begin(), v.end(), [](E a, E b) { return fabs(a.key) < fabs(b.key); });
+  const double r_sq = r * r;
+  std::vector<char> uniq(T, 1);
+  for (int i = 0; i < T; i++) {
+    if (!uniq[i]) continue;
+    const double *p1 = pts + 4 * v[i].i;
+    for (int j = i + 1; j < T; j++) {
+      if (!uniq[j]) continue;
+      const double *p2 = pts + 4 * v[j].i;
+      double dx = p1[0] - p2[0], dy = p1[1] - p2[1];
+      double d1 = dx * dx + dy * dy;
+      if (d1 > r_sq) continue;
+      dx = p1[2] - p2[2]; dy = p1[3] - p2[3];
+      double d2 = dx * dx + dy * dy;
+      if (d2 <= r_sq) uniq[j] = 0;
+    }
+  }
+  int kept = 0;
+  for (int i = 0; i < T; i++) { order[i] = v[i].i; keep[i] = uniq[i]; kept += uniq[i]; }
+  return kept;
+}
+
+int loransac_h(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold,
+               double confidence, int max_samples_, int lo, double HLAFCoef, int doSymmCheck, unsigned seed, double *H,
+               double *Hraw, unsigned char *inl, unsigned char *keep, int *data_out3) {
+  (void)lo;  // the reference ignores localOptimization on the H path (iter_type is the constant 4)
+  for (int i = 0; i < T; i++) { inl[i] = 0; keep[i] = 0; }
+  for (int i = 0; i < 9; i++) { H[i] = -1; Hraw[i] = 0; }
+  data_out3[0] = data_out3[1] = data_out3[2] = 0;
+  if (T < 8) return 0;  // MIN_POINTS, matching.hpp:27
+  int max_samples = max_samples_;
+  if (T <= 20) max_samples = 1000;
+  std::vector<double> u2((size_t)T * 6);
+  for (int i = 0; i < T; i++) {
+    u2[6 * i] = pts[4 * i]; u2[6 * i + 1] = pts[4 * i + 1]; u2[6 * i + 2] = 1.;
+    u2[6 * i + 3] = pts[4 * i + 2]; u2[6 * i + 4] = pts[4 * i + 3]; u2[6 * i + 5] = 1.;
+  }
+  double Hloran[9];
+  ransac_h(u2.data(), T, err_threshold * err_threshold, confidence, max_samples, Hloran, inl, data_out3, 1, doSymmCheck,
+           seed, nullptr);
+  for (int i = 0; i < 9; i++) Hraw[i] = Hloran[i];
+  double Ht[9] = {Hloran[0], Hloran[3], Hloran[6], Hloran[1], Hloran[4], Hloran[7], Hloran[2], Hloran[5], Hloran[8]};
+  double Hinv[9];
+  invert3(Ht, Hinv);
+  bool nz = false;
+  for (int i = 0; i < 9; i++) nz = nz || (Hinv[i] != 0.0);
+  if (!nz) { for (int i = 0; i < T; i++) inl[i] = 0; return 0; }
+  for (int i = 0; i < 9; i++) H[i] = Hinv[i];
+  std::vector<int> ril;
+  for (int i = 0; i < T; i++) if (inl[i]) ril.push_back(i);
+  double Hi2[9];
+  invert3(H, Hi2);
+  int good = 0;
+  for (int i : ril) {
+    const double x1 = pts[4 * i], y1 = pts[4 * i + 1], x2 = pts[4 * i + 2], y2 = pts[4 * i + 3];
+    double xa = (H[0] * x1 + H[1] * y1 + H[2]) / (H[6] * x1 + H[7] * y1 + H[8]);
+    double ya = (H[3] * x1 + H[4] * y1 + H[5]) / (H[6] * x1 + H[7] * y1 + H[8]);
+    double d1 = (x2 - xa) * (x2 - xa) + (y2 - ya) * (y2 - ya);
+    xa = (Hi2[0] * x2 + Hi2[1] * y2 + Hi2[2]) / (Hi2[6] * x2 + Hi2[7] * y2 + Hi2[8]);
+    ya = (Hi2[3] * x2 + Hi2[4] * y2 + Hi2[5]) / (Hi2[6] * x2 + Hi2[7] * y2 + Hi2[8]);
+    double d2 = (x1 - xa) * (x1 - xa) + (y1 - ya) * (y1 - ya);
+    if ((d1 <= 100.0) && (d2 <= 100.0)) good++;
+  }
+  if (good < 8) ril.clear();
+  const double affErr = 3.0 * HLAFCoef * err_threshold;
+  std::vector<int> kept;
+  if (affErr > 0) {
+    for (int i : ril) {
+      double u[18], err[3];
+      const double *A = laf1 + 5 * i, *B = laf2 + 5 * i;
+      u[0] = pts[4 * i]; u[1] = pts[4 * i + 1]; u[2] = 1.0;
+      u[3] = pts[4 * i + 2]; u[4] = pts[4 * i + 3]; u[5] = 1.0;
+      u[6] = u[0] + 3.0 * A[1] * A[4]; u[7] = u[1] + 3.0 * A[3] * A[4]; u[8] = 1.0;
+      u[9] = u[3] + 3.0 * B[1] * B[4]; u[10] = u[4] + 3.0 * B[3] * B[4]; u[11] = 1.0;
+      u[12] = u[0] + 3.0 * A[0] * A[4]; u[13] = u[1] + 3.0 * A[2] * A[4]; u[14] = 1.0;
+      u[15] = u[3] + 3.0 * B[0] * B[4]; u[16] = u[4] + 3.0 * B[2] * B[4]; u[17] = 1.0;
+      hds_sym(u, Hloran, err, 3, true);
+      double sumErr = sqrt(err[0] + err[1] + err[2]);
+      if (!(sumErr > affErr)) kept.push_back(i);
+    }
+  } else kept = ril;
+  if ((int)kept.size() < 8) kept.clear();
+  for (int i : kept) keep[i] = 1;
+  return (int)kept.size();
+}
+
+}  // namespace mx

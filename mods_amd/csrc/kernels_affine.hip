@@ -1,0 +1,102 @@
+// kernels_affine.hip -- Baumberg affine shape adaptation, one wavefront per keypoint.
+//
+// Reference: AffineShape::findAffineShape (AFF_BMBRG_SMM), detectors/affinedetectors/affine.cpp:26-169
+//   interpolate        detectors/helpers.cpp:551-626  (f32 coordinates accumulated incrementally)
+//   computeGradient    detectors/helpers.cpp:779-797
+//   invSqrt / getEigenvalues   detectors/helpers.cpp:463-515
+// The 19x19 window lives in LDS.  The 64 lanes produce the warped samples and the
+// gradient products in parallel; the three second-moment sums are accumulated by three
+// lanes in raster order because the reference's f32 running sums are order dependent.
+#include "engine.hpp"
+
+namespace mx {
+
+constexpr int AW_MAX = 19;
+
+__global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out, int n, const float *mask, int W,
+                                                 int maxIter, float convTh, float affInitialSigma) {
+  const int k = blockIdx.x;
+  if (k >= n) return;
+  const int lane = threadIdx.x;
+  __shared__ float smask[AW_MAX * AW_MAX];
+  __shared__ float simg[AW_MAX * AW_MAX];
+  __shared__ float pa[AW_MAX * AW_MAX], pb[AW_MAX * AW_MAX], pc[AW_MAX * AW_MAX];
+  __shared__ float rxs[AW_MAX], rys[AW_MAX];
+  const AffJob jb = jobs[k];
+  const int WW = W * W, half = W >> 1;
+  for (int i = lane; i < WW; i += 64) smask[i] = mask[i];
+  float u11 = 1.0f, u12 = 0.0f, u21 = 0.0f, u22 = 1.0f, l1 = 1.0f, l2 = 1.0f;
+  float era = 0.0f, erb = 0.0f;
+  const float lx = jb.x / jb.pixelDistance, ly = jb.y / jb.pixelDistance;
+  const float ratio = jb.s / (affInitialSigma * jb.pixelDistance);
+  int ok = 0, l = 0;
+  __syncthreads();
+  for (l = 0; l < maxIter; l++) {
+    const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
+    const bool touch = check_borders(jb.cols, jb.rows, lx, ly, a11, a12, a21, a22, W, W);
+    if (lane < W) {
+      float rx = lx - (float)half * a12;
+      float ry = ly - (float)half * a22;
+      for (int j = 0; j < lane; j++) { rx += a12; ry += a22; }
+      rxs[lane] = rx; rys[lane] = ry;
+    }
+    __syncthreads();
+    for (int p = lane; p < WW; p += 64) {
+      const int j = p / W, i = p - j * W;
+      float WX = rxs[j] - (float)half * a11;
+      float WY = rys[j] - (float)half * a21;
+      for (int t = 0; t < i; t++) { WX += a11; WY += a21; }
+      simg[p] = bilinear_tap(jb.blur, jb.rows, jb.cols, WX, WY, touch);
+    }
+    __syncthreads();
+    for (int p = lane; p < WW; p += 64) {
+      const int r = p / W, c = p - r * W;
+      float gx, gy;
+      if (c == 0) gx = simg[p + 1] - simg[p];
+      else if (c == W - 1) gx = simg[p] - simg[p - 1];
+      else gx = simg[p + 1] - simg[p - 1];
+      if (r == 0) gy = simg[p + W] - simg[p];
+      else if (r == W - 1) gy = simg[p] - simg[p - W];
+      else gy = simg[p + W] - simg[p - W];
+      const float v = smask[p];
+      const float gxy = gx * gy;
+      pa[p] = gx * gx * v;
+      pb[p] = gxy * v;
+      pc[p] = gy * gy * v;
+    }
+    __syncthreads();
+    float acc = 0.f;
+    if (lane < 3) {
+      const float *arr = lane == 0 ? pa : (lane == 1 ? pb : pc);
+      for (int i = 0; i < WW; i++) acc += arr[i];
+    }
+    float a = __shfl(acc, 0), b = __shfl(acc, 1), c = __shfl(acc, 2);
+    a /= (float)WW; b /= (float)WW; c /= (float)WW;
+    inv_sqrt(a, b, c, l1, l2);
+    if ((a != a) || (b != b) || (c != c)) break;
+    erb = era;
+    era = (float)(1.0 - (double)(l2 / l1));
+    const float u11t = u11, u12t = u12;
+    u11 = a * u11t + b * u21;
+    u12 = a * u12t + b * u22;
+    u21 = b * u11t + c * u21;
+    u22 = b * u12t + c * u22;
+    if (!eigenvalues(u11, u12, u21, u22, l1, l2)) break;
+    if ((l1 / l2 > 6) || (l2 / l1 > 6)) break;
+    if (era < convTh && erb < convTh) { ok = 1; break; }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    AffOut o;
+    o.u11 = u11; o.u12 = u12; o.u21 = u21; o.u22 = u22; o.ok = ok; o.iters = l;
+    out[k] = o;
+  }
+}
+
+void launch_baumberg(hipStream_t s, const AffJob *jobs, AffOut *out, int n, const float *mask, int W, int maxIter,
+                     float convTh, float affInitialSigma) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_baumberg, dim3(n), dim3(64), 0, s, jobs, out, n, mask, W, maxIter, convTh, affInitialSigma);
+}
+
+}  // namespace mx

@@ -1,0 +1,279 @@
+// kernels_pyramid.hip -- scale-space pyramid, Hessian response, 3-D extrema + localisation.
+//
+// Reference: ScaleSpaceDetector, detectors/affinedetectors/pyramid.cpp
+//   gaussianBlur (helpers.cpp:717-724) -> cv::GaussianBlur f32 separable, BORDER_REPLICATE
+//   HessianResponse   pyramid.cpp:223-281
+//   cv::resize 0.5    pyramid.cpp:520 (area-fast 2x2)
+//   findLevelKeypoints + isMax/isMin   pyramid.cpp:432-452, 42-64
+//   localizeKeypoint  pyramid.cpp:308-430 (everything except the octaveMap claim and the
+//                     powf scale, which the host applies in detection order)
+// All kernels take a small by-value batch of jobs; blockIdx.z selects the job, so the two
+// images of a pair (or several views) run in one launch.
+#include "engine.hpp"
+
+namespace mx {
+
+// ---------------------------------------------------------------------------------------
+// Fused separable Gaussian blur (+ optional Hessian response of the blurred tile).
+// Tile: 64 x 32 outputs per 256-thread workgroup, staged through LDS:
+//   src  (TH+2+2R) x (TW+2+2R)   clamped (replicate) input tile
+//   tmp  (TH+2+2R) x (TW+2)      row-filtered
+//   blr  (TH+2)    x (TW+2)      blurred tile incl. the 1-px ring the 3x3 Hessian needs
+// Row pass accumulates taps left to right (cv RowFilter, ksize > 5) or centre + symmetric
+// pairs (SymmRowSmallFilter, ksize <= 5); column pass is centre + (below + above) * k
+// (SymmColumnFilter) -- the same f32 operation order as the CPU filter engine.
+// ---------------------------------------------------------------------------------------
+constexpr int TW = 64, TH = 32, RMAX = 8;
+constexpr int SRC_W = TW + 2 + 2 * RMAX, SRC_H = TH + 2 + 2 * RMAX;
+
+__global__ __launch_bounds__(256) void k_blur_hess(BlurBatch batch) {
+  const BlurJob jb = batch.j[blockIdx.z];
+  const int rows = jb.rows, cols = jb.cols;
+  const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+  if (tx0 >= cols || ty0 >= rows) return;
+  const int R = batch.n >> 1;
+  const int n = batch.n;
+  __shared__ float src[SRC_H * SRC_W];
+  __shared__ float tmp[SRC_H * (TW + 2)];
+  __shared__ float blr[(TH + 2) * (TW + 2)];
+  const int tid = threadIdx.x;
+  const int sh = TH + 2 + 2 * R, sw = TW + 2 + 2 * R;
+  // stage 1: clamped input tile
+  for (int i = tid; i < sh * sw; i += 256) {
+    int ly = i / sw, lx = i - ly * sw;
+    int gy = ty0 - 1 - R + ly, gx = tx0 - 1 - R + lx;
+    gy = gy < 0 ? 0 : (gy > rows - 1 ? rows - 1 : gy);
+    gx = gx < 0 ? 0 : (gx > cols - 1 ? cols - 1 : gx);
+    src[ly * SRC_W + lx] = jb.src[(size_t)gy * cols + gx];
+  }
+  __syncthreads();
+  // stage 2: row filter
+  const int tw2 = TW + 2;
+  for (int i = tid; i < sh * tw2; i += 256) {
+    int ly = i / tw2, lx = i - ly * tw2;
+    const float *S = src + ly * SRC_W + lx;  // taps S[0..n-1], centre at S[R]
+    float v;
+    if (n <= 5) {
+      v = S[R] * batch.k[R];
+      for (int j = 1; j <= R; j++) v = v + (S[R - j] + S[R + j]) * batch.k[R + j];
+    } else {
+      v = 0.f;
+      for (int j = 0; j < n; j++) v = v + S[j] * batch.k[j];
+    }
+    tmp[ly * tw2 + lx] = v;
+  }
+  __syncthreads();
+  // stage 3: column filter -> blurred tile with 1-px ring
+  const int bh = TH + 2;
+  for (int i = tid; i < bh * tw2; i += 256) {
+    int ly = i / tw2, lx = i - ly * tw2;
+    const float *S = tmp + (ly + R) * tw2 + lx;
+    float v = batch.k[R] * S[0] + 0.f;
+    for (int j = 1; j <= R; j++) v = v + batch.k[R + j] * (S[j * tw2] + S[-j * tw2]);
+    blr[ly * tw2 + lx] = v;
+  }
+  __syncthreads();
+  // stage 4: write blur and response
+  const float norm2 = jb.norm * jb.norm;
+  for (int i = tid; i < TH * TW; i += 256) {
+    int ly = i / TW, lx = i - ly * TW;
+    int gy = ty0 + ly, gx = tx0 + lx;
+    if (gy >= rows || gx >= cols) continue;
+    const float *B = blr + (ly + 1) * tw2 + (lx + 1);
+    jb.blur[(size_t)gy * cols + gx] = B[0];
+    if (jb.resp) {
+      float o = 0.f;
+      if (gy >= 1 && gy < rows - 1 && gx >= 1 && gx < cols - 1) {
+        const float v11 = B[-tw2 - 1], v12 = B[-tw2], v13 = B[-tw2 + 1];
+        const float v21 = B[-1], v22 = B[0], v23 = B[1];
+        const float v31 = B[tw2 - 1], v32 = B[tw2], v33 = B[tw2 + 1];
+        float Lxx = (v21 - 2 * v22 + v23);
+        float Lyy = (v12 - 2 * v22 + v32);
+        float Lxy = (v13 - v11 + v31 - v33) / 4.0f;
+        o = (Lxx * Lyy - Lxy * Lxy) * norm2;
+      }
+      jb.resp[(size_t)gy * cols + gx] = o;
+    }
+  }
+}
+
+// HessianResponse of an existing level (first level of octaves >= 1), pyramid.cpp:223-281
+__global__ __launch_bounds__(256) void k_hessian(BlurBatch batch) {
+  const BlurJob jb = batch.j[blockIdx.z];
+  const int rows = jb.rows, cols = jb.cols;
+  const int gx = blockIdx.x * 64 + (threadIdx.x & 63), gy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (gx >= cols || gy >= rows) return;
+  float o = 0.f;
+  if (gy >= 1 && gy < rows - 1 && gx >= 1 && gx < cols - 1) {
+    const float *B = jb.src + (size_t)gy * cols + gx;
+    const float v11 = B[-cols - 1], v12 = B[-cols], v13 = B[-cols + 1];
+    const float v21 = B[-1], v22 = B[0], v23 = B[1];
+    const float v31 = B[cols - 1], v32 = B[cols], v33 = B[cols + 1];
+    float Lxx = (v21 - 2 * v22 + v23);
+    float Lyy = (v12 - 2 * v22 + v32);
+    float Lxy = (v13 - v11 + v31 - v33) / 4.0f;
+    o = (Lxx * Lyy - Lxy * Lxy) * (jb.norm * jb.norm);
+  }
+  jb.resp[(size_t)gy * cols + gx] = o;
+}
+
+// cv::resize(src, dst, Size(0,0), 0.5, 0.5, INTER_LINEAR) == area-fast 2x2 (pyramid.cpp:520):
+// full blocks ((s00+s01)+s10)+s11)*0.25f, partial blocks sum(available)/count.
+__global__ __launch_bounds__(256) void k_resize_half(ResizeBatch batch) {
+  const ResizeJob jb = batch.j[blockIdx.z];
+  const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (dx >= jb.dcols || dy >= jb.drows) return;
+  const int sr = jb.srows, sc = jb.scols;
+  const int sy0 = dy * 2, sx0 = dx * 2;
+  float out;
+  if (sy0 >= sr) out = 0.f;
+  else if (sy0 + 2 <= sr && dx < sc / 2) {
+    const float *S = jb.src + (size_t)sy0 * sc + sx0;
+    float sum = 0.f;
+    sum = sum + (((S[0] + S[1]) + S[sc]) + S[sc + 1]);
+    out = sum * 0.25f;
+  } else {
+    float sum = 0.f; int count = 0;
+    for (int sy = 0; sy < 2; sy++) {
+      if (sy0 + sy >= sr) break;
+      for (int sx = 0; sx < 2; sx++) {
+        if (sx0 + sx >= sc) break;
+        sum += jb.src[(size_t)(sy0 + sy) * sc + sx0 + sx];
+        count++;
+      }
+    }
+    out = (sx0 >= sc) ? 0.f : sum / (float)count;
+  }
+  jb.dst[(size_t)dy * jb.dcols + dx] = out;
+}
+
+// ---------------------------------------------------------------------------------------
+// 3x3x3 extremum scan + sub-pixel localisation.  One thread per pixel of the scan window
+// [border, dim-border); a thread that finds an extremum runs the <= 5 Newton steps itself
+// and appends a candidate record.  The first-come-first-served octaveMap rule
+// (pyramid.cpp:414-418) depends on scan order, so it is applied by the host after sorting
+// the candidates by (image, octave, level, row, col).
+// ---------------------------------------------------------------------------------------
+MX_D bool is_max9(float val, const float *p, int cols) {
+  bool ok = true;
+#pragma unroll
+  for (int dr = -1; dr <= 1; dr++)
+#pragma unroll
+    for (int dc = -1; dc <= 1; dc++) ok = ok && !(p[dr * cols + dc] > val);
+  return ok;
+}
+MX_D bool is_min9(float val, const float *p, int cols) {
+  bool ok = true;
+#pragma unroll
+  for (int dr = -1; dr <= 1; dr++)
+#pragma unroll
+    for (int dc = -1; dc <= 1; dc++) ok = ok && !(p[dr * cols + dc] < val);
+  return ok;
+}
+
+__global__ __launch_bounds__(256) void k_nms_localize(NmsBatch batch, Candidate *out, unsigned *counter, unsigned cap) {
+  const NmsJob jb = batch.j[blockIdx.z];
+  const int rows = jb.rows, cols = jb.cols, B = batch.border;
+  int c = B + blockIdx.x * 64 + (threadIdx.x & 63), r = B + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (r >= rows - B || c >= cols - B) return;
+  const size_t off = (size_t)r * cols + c;
+  const float v0 = jb.cur[off];
+  bool cand = false;
+  if (v0 > batch.posTh) cand = is_max9(v0, jb.cur + off, cols) && is_max9(v0, jb.low + off, cols) && is_max9(v0, jb.high + off, cols);
+  else if (v0 < batch.negTh) cand = is_min9(v0, jb.cur + off, cols) && is_min9(v0, jb.low + off, cols) && is_min9(v0, jb.high + off, cols);
+  if (!cand) return;
+  const int r0 = r, c0 = c;
+  float b[3] = {0.f, 0.f, 0.f};
+  float val = 0.f;
+  int nr = r, nc = c;
+  for (int iter = 0; iter < 5; iter++) {
+    r = nr; c = nc;
+    const float *c1 = jb.cur + (size_t)r * cols, *c0p = c1 - cols, *c2 = c1 + cols;
+    const float *l1 = jb.low + (size_t)r * cols, *l0 = l1 - cols, *l2 = l1 + cols;
+    const float *h1 = jb.high + (size_t)r * cols, *h0 = h1 - cols, *h2 = h1 + cols;
+    float dxx = c1[c - 1] - 2.0f * c1[c] + c1[c + 1];
+    float dyy = c0p[c] - 2.0f * c1[c] + c2[c];
+    float dss = l1[c] - 2.0f * c1[c] + h1[c];
+    float dxy = 0.25f * (c2[c + 1] - c2[c - 1] - c0p[c + 1] + c0p[c - 1]);
+    if (iter == 0) {
+      float edgeScore = (dxx + dyy) * (dxx + dyy) / (dxx * dyy - dxy * dxy);
+      if ((double)edgeScore >= batch.edgeScoreThreshold || edgeScore < 0) return;
+    }
+    float dxs = 0.25f * (h1[c + 1] - h1[c - 1] - l1[c + 1] + l1[c - 1]);
+    float dys = 0.25f * (h2[c] - h0[c] - l2[c] + l0[c]);
+    float A[9] = {dxx, dxy, dxs, dxy, dyy, dys, dxs, dys, dss};
+    float dx = 0.5f * (c1[c + 1] - c1[c - 1]);
+    float dy = 0.5f * (c2[c] - c0p[c]);
+    float ds = 0.5f * (h1[c] - l1[c]);
+    b[0] = -dx; b[1] = -dy; b[2] = -ds;
+    solve3(A, b);
+    if (isnan(b[0]) || isnan(b[1]) || isnan(b[2])) return;
+    val = c1[c] + 0.5f * (dx * b[0] + dy * b[1] + ds * b[2]);
+    if ((double)b[0] > 0.6) { if (c < cols - 3) nc++; else return; }
+    if ((double)b[1] > 0.6) { if (r < rows - 3) nr++; else return; }
+    if ((double)b[0] < -0.6) { if (c > 3) nc--; else return; }
+    if ((double)b[1] < -0.6) { if (r > 3) nr--; else return; }
+    if (nr == r && nc == c) break;
+  }
+  if (fabsf(b[0]) > 1.5f || fabsf(b[1]) > 1.5f || fabsf(b[2]) > 1.5f || fabsf(val) < batch.finalTh) return;
+  int type;
+  if (val < 0) type = 2;
+  else {
+    const float *p = jb.blur + (size_t)r * cols + c;
+    float Lxx = (p[-1] - 2 * p[0] + p[1]);
+    type = (Lxx < 0) ? 0 : 1;
+  }
+  unsigned slot = atomicAdd(counter, 1u);
+  if (slot >= cap) return;
+  Candidate k;
+  k.img = jb.img; k.octave = jb.octave; k.level = jb.level; k.type = type;
+  k.r0 = r0; k.c0 = c0; k.r = r; k.c = c;
+  k.b0 = b[0]; k.b1 = b[1]; k.b2 = b[2]; k.val = val;
+  out[slot] = k;
+}
+
+// (B+G+R)/3 of GenerateSynthImageCorr (synth-detection.cpp:253-262): a cv::MatExpr that OpenCV
+// evaluates as addWeighted(B+G, 1/3., R, 1/3., 0) in f64 for CV_32F.
+__global__ void k_gray_u8(const uint8_t *src, float *dst, size_t n, int channels) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (channels == 1) { dst[i] = (float)src[i]; return; }
+  const double k = 1. / 3.0;
+  float t = (float)src[3 * i] + (float)src[3 * i + 1];
+  dst[i] = (float)((double)t * k + (double)(float)src[3 * i + 2] * k + 0.0);
+}
+__global__ void k_gray_f32(const float *src, float *dst, size_t n, int channels) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (channels == 1) { dst[i] = src[i]; return; }
+  const double k = 1. / 3.0;
+  float t = src[3 * i] + src[3 * i + 1];
+  dst[i] = (float)((double)t * k + (double)src[3 * i + 2] * k + 0.0);
+}
+
+void launch_blur_hess(hipStream_t s, const BlurBatch &b, int nj, int maxRows, int maxCols) {
+  dim3 grid((maxCols + TW - 1) / TW, (maxRows + TH - 1) / TH, nj);
+  hipLaunchKernelGGL(k_blur_hess, grid, dim3(256), 0, s, b);
+}
+void launch_hessian(hipStream_t s, const BlurBatch &b, int nj, int maxRows, int maxCols) {
+  dim3 grid((maxCols + 63) / 64, (maxRows + 3) / 4, nj);
+  hipLaunchKernelGGL(k_hessian, grid, dim3(256), 0, s, b);
+}
+void launch_resize_half(hipStream_t s, const ResizeBatch &b, int nj, int maxRows, int maxCols) {
+  dim3 grid((maxCols + 63) / 64, (maxRows + 3) / 4, nj);
+  hipLaunchKernelGGL(k_resize_half, grid, dim3(256), 0, s, b);
+}
+void launch_nms(hipStream_t s, const NmsBatch &b, int nj, int maxRows, int maxCols, Candidate *out, unsigned *counter,
+                unsigned cap) {
+  int w = maxCols - 2 * b.border, h = maxRows - 2 * b.border;
+  if (w <= 0 || h <= 0 || nj <= 0) return;
+  dim3 grid((w + 63) / 64, (h + 3) / 4, nj);
+  hipLaunchKernelGGL(k_nms_localize, grid, dim3(256), 0, s, b, out, counter, cap);
+}
+void launch_gray(hipStream_t s, const void *src, float *dst, size_t n, int channels, int dtype) {
+  dim3 grid((unsigned)((n + 255) / 256));
+  if (dtype == 0) hipLaunchKernelGGL(k_gray_u8, grid, dim3(256), 0, s, (const uint8_t *)src, dst, n, channels);
+  else hipLaunchKernelGGL(k_gray_f32, grid, dim3(256), 0, s, (const float *)src, dst, n, channels);
+}
+
+}  // namespace mx

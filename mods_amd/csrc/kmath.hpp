@@ -1,0 +1,142 @@
+// kmath.hpp -- scalar device/host math shared by the HIP kernels of libmodsx.
+//
+// Every function states the reference lines whose arithmetic (operation order,
+// f32/f64 placement, truncations) it reproduces bit for bit.  Compiled with
+// -ffp-contract=off: no FMA contraction anywhere, IEEE f32/f64 div and sqrt.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#define MX_HD __host__ __device__ __forceinline__
+#define MX_D __device__ __forceinline__
+
+namespace mx {
+
+// atan2LUTff, detectors/helpers.cpp:160-207; L = 256-entry f64 table (:30-72)
+MX_HD float atan2lut(const double *L, float y, float x) {
+  const float PI_2f = 1.57079632679489661923f, PIf = 3.14159265358979323846f;
+  if (x > 0.f) {
+    if (y > 0.f) {
+      if (x > y) return (float)L[(int)(255.f * y / x)];
+      return (float)((double)PI_2f - L[(int)(255.f * x / y)]);
+    }
+    float ay = fabsf(y);
+    if (x > ay) return (float)(-L[(int)(255.f * ay / x)]);
+    return (float)((double)(-PI_2f) + L[(int)(255.f * x / ay)]);
+  }
+  if (y > 0.f) {
+    float ax = fabsf(x);
+    if (ax > y) return (float)((double)PIf - L[(int)(255.f * y / ax)]);
+    return (float)((double)PI_2f + L[(int)(255.f * ax / y)]);
+  }
+  float ax = fabsf(x), ay = fabsf(y);
+  if (ax > ay) return (float)((double)(-PIf) + L[(int)(255.f * ay / ax)]);
+  if (x == 0.f) return 0.f;
+  return (float)((double)(-PI_2f) - L[(int)(255.f * ax / ay)]);
+}
+
+// solveLinear3x3, detectors/helpers.cpp:309-368
+MX_HD void solve3(float *A, float *b) {
+  int i = 0, pr = 0;
+  float vp = fabsf(A[0]);
+  float tmp = fabsf(A[3]);
+  if (tmp > vp) { pr = 3; i = 1; vp = tmp; }
+  if (fabsf(A[6]) > vp) { pr = 6; i = 2; }
+  if (pr != 0) {
+    float t;
+    t = A[pr]; A[pr] = A[0]; A[0] = t;
+    t = A[pr + 1]; A[pr + 1] = A[1]; A[1] = t;
+    t = A[pr + 2]; A[pr + 2] = A[2]; A[2] = t;
+    t = b[i]; b[i] = b[0]; b[0] = t;
+  }
+  vp = A[3] / A[0];
+  A[4] -= vp * A[1]; A[5] -= vp * A[2]; b[1] -= vp * b[0];
+  vp = A[6] / A[0];
+  A[7] -= vp * A[1]; A[8] -= vp * A[2]; b[2] -= vp * b[0];
+  if (fabsf(A[4]) < fabsf(A[7])) {
+    float t;
+    t = A[7]; A[7] = A[4]; A[4] = t;
+    t = A[8]; A[8] = A[5]; A[5] = t;
+    t = b[2]; b[2] = b[1]; b[1] = t;
+  }
+  vp = A[7] / A[4];
+  A[8] -= vp * A[5]; b[2] -= vp * b[1];
+  b[2] = (b[2]) / A[8];
+  b[1] = (b[1] - A[5] * b[2]) / A[4];
+  b[0] = (b[0] - A[2] * b[2] - A[1] * b[1]) / A[0];
+}
+
+// invSqrt, detectors/helpers.cpp:463-502 (Jacobi rotation in f64, f32 in/out)
+MX_HD void inv_sqrt(float &a, float &b, float &c, float &l1, float &l2) {
+  double t, r;
+  if (b != 0) {
+    r = double(c - a) / (2 * b);
+    if (r >= 0) t = 1.0 / (r + sqrt(1 + r * r));
+    else t = -1.0 / (-r + sqrt(1 + r * r));
+    r = 1.0 / sqrt(1 + t * t);
+    t = t * r;
+  } else { r = 1; t = 0; }
+  double x = 1.0 / sqrt(r * r * a - 2 * r * t * b + t * t * c);
+  double z = 1.0 / sqrt(t * t * a + 2 * r * t * b + r * r * c);
+  double d = sqrt(x * z);
+  x /= d; z /= d;
+  if (x < z) { l1 = float(z); l2 = float(x); } else { l1 = float(x); l2 = float(z); }
+  a = float(r * r * x + t * t * z);
+  b = float(-r * t * x + t * r * z);
+  c = float(t * t * x + r * r * z);
+}
+
+// getEigenvalues, detectors/helpers.cpp:504-515
+MX_HD bool eigenvalues(float a, float b, float c, float d, float &l1, float &l2) {
+  float trace = a + d;
+  float delta1 = (trace * trace - 4 * (a * d - b * c));
+  if (delta1 < 0) return false;
+  float delta = sqrtf(delta1);
+  l1 = (trace + delta) / 2.0f;
+  l2 = (trace - delta) / 2.0f;
+  return true;
+}
+
+// interpolateCheckBorders, detectors/helpers.cpp:524-549
+MX_HD bool check_borders(int orig_w, int orig_h, float ofsx, float ofsy, float a11, float a12, float a21, float a22,
+                         int res_w, int res_h) {
+  const int width = orig_w - 2, height = orig_h - 2;
+  const float hw = (float)ceil((double)(float)res_w / 2.0);
+  const float hh = (float)ceil((double)(float)res_h / 2.0);
+  bool touch = false;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float xs = (i < 2) ? -hw : hw;
+    const float ys = (i & 1) ? hh : -hh;
+    float imx = ofsx + xs * a11 + ys * a12;
+    float imy = ofsy + xs * a21 + ys * a22;
+    if (floorf(imx) <= 0 || floorf(imy) <= 0 || ceilf(imx) >= width || ceilf(imy) >= height) touch = true;
+  }
+  return touch;
+}
+
+// one bilinear sample of interpolate(), detectors/helpers.cpp:566-616.
+// touch = false: the (int) truncation branch; touch = true: floor + bounds branch (0 outside).
+MX_HD float bilinear_tap(const float *im, int rows, int cols, float WX, float WY, bool touch) {
+  if (!touch) {
+    int x = (int)WX, y = (int)WY;
+    // the reference would fault on NaN / far out-of-range coordinates; keep device loads in bounds
+    x = x < 0 ? 0 : (x > cols - 2 ? cols - 2 : x);
+    y = y < 0 ? 0 : (y > rows - 2 ? rows - 2 : y);
+    const float wx = WX - (float)x;
+    const float *R0 = im + (size_t)y * cols, *R1 = R0 + cols;
+    const float I1 = wx * (R0[x + 1] - R0[x]) + R0[x];
+    return (WY - (float)y) * (wx * (R1[x + 1] - R1[x]) + R1[x] - I1) + I1;
+  }
+  const int x = (int)floorf(WX), y = (int)floorf(WY);
+  if (WX >= 0 && WY >= 0 && x < cols - 1 && y < rows - 1) {
+    const float wx = WX - (float)x;
+    const float *R0 = im + (size_t)y * cols, *R1 = R0 + cols;
+    const float I1 = wx * (R0[x + 1] - R0[x]) + R0[x];
+    return (WY - (float)y) * (wx * (R1[x + 1] - R1[x]) + R1[x] - I1) + I1;
+  }
+  return 0.f;
+}
+
+}  // namespace mx

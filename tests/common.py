@@ -1,0 +1,62 @@
+"""Shared helpers for the parity tests (oracle-side pipelines, synthetic correspondences)."""
+import numpy as np
+
+
+def oracle_features(O, g, mode=0, rootsift=1, **kw):
+    p = O.default_params(mode=mode, **kw)
+    k = O.detect_hessaff(g, p)
+    r = O.detect_affine_regions(k)
+    ro = O.detect_orientation(g, r)
+    rr = O.reproject_regions(ro, np.eye(3), g.shape[1], g.shape[0])
+    d = O.describe_regions(g, rr, rootsift=rootsift)
+    return k, rr, d
+
+
+def laf_of(regs, idx):
+    k = regs["reproj_kp"][idx]
+    return np.stack([k["a11"], k["a12"], k["a21"], k["a22"], k["s"]], 1)
+
+
+def oracle_pair(O, a, b, seed=1, mode=0, ratio=0.8, contrad=30.0):
+    k1, r1, d1 = oracle_features(O, a, mode)
+    k2, r2, d2 = oracle_features(O, b, mode)
+    pos2 = np.stack([r2["reproj_kp"]["x"], r2["reproj_kp"]["y"]], 1)
+    tent = O.match_fginn(d1, d2, pos2, ratio, contrad)
+    pts = np.stack([r1["reproj_kp"]["x"][tent["q"]], r1["reproj_kp"]["y"][tent["q"]],
+                    r2["reproj_kp"]["x"][tent["t0"]], r2["reproj_kp"]["y"][tent["t0"]]], 1)
+    order, keep = O.duplicate_filtering(pts, tent["ratio"], 2.0, True)
+    sel = order[keep]
+    tu, pu = tent[sel], pts[sel]
+    res = O.loransac_h(pu, laf_of(r1, tu["q"]), laf_of(r2, tu["t0"]), seed=seed) if O.ref_available() else None
+    return dict(r1=r1, r2=r2, d1=d1, d2=d2, tent=tent, uniq=tu, pts=pu, ransac=res)
+
+
+def synth_corr(T, frac, noise=0.7, seed=0):
+    rs = np.random.RandomState(seed)
+    H = np.array([[1.1, 0.05, 20], [-0.03, 0.95, -10], [1e-5, 2e-5, 1]])
+    p1 = rs.uniform(20, 1000, (T, 2))
+    x = np.c_[p1, np.ones(T)] @ H.T
+    p2 = x[:, :2] / x[:, 2:] + rs.normal(0, noise, (T, 2))
+    out = rs.rand(T) > frac
+    p2[out] = rs.uniform(20, 1000, (int(out.sum()), 2))
+    laf = np.tile([1, 0, 0, 1, 5.0], (T, 1)).astype(float)
+    return np.c_[p1, p2], laf, H
+
+
+def normH(H):
+    H = np.asarray(H, float).reshape(3, 3)
+    return H / H[2, 2]
+
+
+def same_records(a, b):
+    """Field-wise equality of two structured arrays (ignores struct padding bytes)."""
+    if len(a) != len(b):
+        return False
+    for name in a.dtype.names:
+        x, y = a[name], b[name]
+        if x.dtype.names:
+            if not same_records(x, y):
+                return False
+        elif not np.array_equal(x, y):
+            return False
+    return True

@@ -1,0 +1,205 @@
+"""GPU: parity of the HIP path (through the C ABI of libmodsx.so) with the CPU oracle, stage by stage.
+
+Bar: bit-exact.  Every stage of this path ends in discrete decisions (extrema, thresholds, quantised
+descriptors, ratio tests, RANSAC samples), so the f32/f64 intermediates are compared for exact equality too.
+"""
+import numpy as np
+import pytest
+
+from common import oracle_features, oracle_pair, laf_of, normH, same_records
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_img(rows, cols, seed):
+    rs = np.random.RandomState(seed)
+    y, x = np.mgrid[0:rows, 0:cols]
+    img = 128 + 60 * np.sin(x / 7.0) * np.cos(y / 5.0) + rs.uniform(-30, 30, (rows, cols))
+    return np.clip(np.floor(img), 0, 255).astype(np.float32)
+
+
+def test_native_library_is_loaded(modsx, ctx):
+    import os
+    maps = open("/proc/self/maps").read()
+    assert "libmodsx.so" in maps
+    assert os.path.exists(modsx.LIB_PATH)
+
+
+def test_gray_conversion(ctx, oracle, cat_pair):
+    cat, cat2, _ = cat_pair
+    for bgr in (cat, cat2):
+        im = ctx.upload(bgr)
+        assert np.array_equal(im.download(), oracle.gray_from_bgr(bgr))
+        im.free()
+    g = _rand_img(50, 70, 1)
+    im = ctx.upload(g)
+    assert np.array_equal(im.download(), g)
+    im.free()
+
+
+@pytest.mark.parametrize("shape", [(97, 131), (64, 64), (33, 200), (13, 17)])
+@pytest.mark.parametrize("sigma", [0.7, 1.2263, 1.5199, 1.9466, 2.4525])
+def test_gaussian_blur_bit_exact(ctx, oracle, shape, sigma):
+    img = _rand_img(shape[0], shape[1], 3)
+    im = ctx.upload(img)
+    got = ctx.gaussian_blur(im, sigma)
+    im.free()
+    assert np.array_equal(got, oracle.gaussian_blur(img, sigma))
+
+
+@pytest.mark.parametrize("shape", [(96, 128), (97, 131), (75, 125), (38, 63), (13, 14)])
+def test_resize_half_bit_exact(ctx, oracle, shape):
+    img = _rand_img(shape[0], shape[1], 4)
+    im = ctx.upload(img)
+    got = ctx.resize_half(im)
+    im.free()
+    ref = oracle.resize_half(img)
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("shape", [(120, 160), (101, 77)])
+def test_octave_levels_bit_exact(ctx, modsx, oracle, shape):
+    img = _rand_img(shape[0], shape[1], 5)
+    im = ctx.upload(img)
+    blurs, resps = ctx.octave_levels(im, modsx.default_hessaff_params())
+    im.free()
+    rb, rr = oracle.octave_levels(img, oracle.default_params())
+    assert np.array_equal(blurs, rb)
+    assert np.array_equal(resps[:, 1:-1, 1:-1], rr[:, 1:-1, 1:-1])
+
+
+def _check_sskp(a, b):
+    assert len(a) == len(b)
+    for f in ("octave", "level", "r0", "c0", "r", "c", "type", "b0", "b1", "b2", "val", "x", "y", "s", "pixelDistance"):
+        assert np.array_equal(a[f], b[f]), f
+
+
+@pytest.mark.parametrize("mode", [0, 4])
+def test_scalespace_keypoints_bit_exact(ctx, modsx, oracle, small_pair, mode):
+    for img in small_pair[:2]:
+        im = ctx.upload(img)
+        got = ctx.detect_scalespace(im, modsx.default_hessaff_params(mode=mode))
+        im.free()
+        ref = oracle.detect_scalespace(img, oracle.default_params(mode=mode))
+        assert len(ref) > 50
+        _check_sskp(got, ref)
+
+
+@pytest.mark.parametrize("mode,regn", [(0, 2000), (4, 150), (2, 40)])
+def test_affine_keypoints_bit_exact(ctx, modsx, oracle, small_pair, mode, regn):
+    for img in small_pair[:2]:
+        im = ctx.upload(img)
+        got = ctx.detect_affine_keypoints(im, modsx.default_hessaff_params(mode=mode, reg_number=regn))
+        im.free()
+        ref = oracle.detect_hessaff(img, oracle.default_params(mode=mode, reg_number=regn))
+        assert len(ref) > 20
+        assert same_records(got, ref.view(modsx.KEYPOINT))
+
+
+def test_orientation_and_description_bit_exact(ctx, modsx, oracle, small_pair):
+    img = small_pair[0]
+    im = ctx.upload(img)
+    k = oracle.detect_hessaff(img, oracle.default_params())
+    regs = oracle.detect_affine_regions(k)
+    for mr, max_ang in ((1.0, 1), (5.1962, 5)):
+        ref = oracle.detect_orientation(img, regs, mr_size=mr, max_ang=max_ang)
+        got = ctx.detect_orientation(im, regs.view(modsx.REGION), mr_size=mr, max_ang=max_ang)
+        assert len(ref) > 20 and same_records(got, ref.view(modsx.REGION))
+    ro = oracle.detect_orientation(img, regs)
+    rr = oracle.reproject_regions(ro, np.eye(3), img.shape[1], img.shape[0])
+    for rootsift in (1, 0):
+        for photo in (1, 0):
+            ref = oracle.describe_regions(img, rr, rootsift=rootsift, photo_norm=photo)
+            got = ctx.describe_regions(im, rr.view(modsx.REGION), desc_type=rootsift, photo_norm=photo)
+            assert np.array_equal(got, ref), (rootsift, photo, int((got != ref).any(1).sum()), len(ref))
+    # fast extraction branch (synth-detection.hpp:232-253) and a tiny-scale region (direct branch, i2p <= 0.4)
+    ref = oracle.describe_regions(img, rr, fast=1)
+    got = ctx.describe_regions(im, rr.view(modsx.REGION), fast=1)
+    assert np.array_equal(got, ref)
+    tiny = rr[:8].copy()
+    tiny["det_kp"]["s"] = 0.9
+    assert np.array_equal(ctx.describe_regions(im, tiny.view(modsx.REGION)), oracle.describe_regions(img, tiny))
+    im.free()
+
+
+def _check_tents(a, b):
+    assert len(a) == len(b)
+    for f in a.dtype.names:
+        assert np.array_equal(a[f], b[f]), f
+
+
+def test_match_fginn_bit_exact_on_real_descriptors(ctx, oracle, small_pair):
+    a, b, _ = small_pair
+    _, r1, d1 = oracle_features(oracle, a)
+    _, r2, d2 = oracle_features(oracle, b)
+    pos2 = np.stack([r2["reproj_kp"]["x"], r2["reproj_kp"]["y"]], 1)
+    for ratio, cd in ((0.8, 30.0), (0.9, 10.0), (0.6, 3.0)):
+        ref = oracle.match_fginn(d1, d2, pos2, ratio, cd)
+        got = ctx.match_fginn(d1, d2, pos2, ratio, cd)
+        assert len(ref) > 5
+        _check_tents(got, ref)
+
+
+def test_match_fginn_ties_ranks_and_ragged_sizes(ctx, oracle):
+    rs = np.random.RandomState(9)
+    for n1, n2 in ((1, 50), (33, 95), (70, 257), (5, 64)):
+        # low-entropy descriptors: many exact distance ties, duplicates, zero distances
+        d1 = rs.randint(0, 3, (n1, 128)).astype(np.float32) * 40
+        d2 = rs.randint(0, 3, (n2, 128)).astype(np.float32) * 40
+        d2[n2 // 2:] = d2[: n2 - n2 // 2]                       # duplicated trains
+        d1[0] = d2[3]                                          # exact hit (d0 = 0)
+        pos2 = rs.uniform(0, 60, (n2, 2))                      # dense positions: long walks through consistent NNs
+        for ratio, cd in ((0.8, 30.0), (0.95, 80.0), (0.8, 5.0)):
+            _check_tents(ctx.match_fginn(d1, d2, pos2, ratio, cd), oracle.match_fginn(d1, d2, pos2, ratio, cd))
+    assert len(ctx.match_fginn(np.zeros((0, 128)), np.zeros((4, 128)), np.zeros((4, 2)))) == 0
+
+
+def test_pair_end_to_end_identical_inliers(ctx, modsx, oracle, small_pair):
+    a, b, H = small_pair
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    for seed in (1, 77):
+        got = ctx.match_pair(ia, ib, modsx.default_pair_params(ransac_seed=seed))
+        ref = oracle_pair(oracle, a, b, seed=seed)
+        assert got["n_regions"] == (len(ref["d1"]), len(ref["d2"]))
+        assert got["n_tentatives"] == len(ref["tent"]) and got["n_unique"] == len(ref["uniq"])
+        _check_tents(got["tentatives"], ref["uniq"])
+        rr = ref["ransac"]
+        assert np.array_equal(got["ransac_inlier"], rr["inl"])          # identical inlier indices
+        assert np.array_equal(got["verified"], rr["keep"]) and got["n_verified"] == rr["n"]
+        assert np.abs(normH(got["H"]) - normH(rr["H"])).max() < 1e-4    # H within 1e-4 (north star)
+        assert got["ransac_samples"] == rr["samples"]
+    ia.free(); ib.free()
+
+
+def test_cat_pair_golden_counts(ctx, modsx, cat_pair):
+    cat, cat2, _ = cat_pair
+    i1, i2 = ctx.upload(cat), ctx.upload(cat2)
+    p = modsx.default_hessaff_params()
+    assert len(ctx.detect_affine_keypoints(i1, p)) == 255
+    assert len(ctx.detect_affine_keypoints(i2, p)) == 414
+    p = modsx.default_hessaff_params(mode=4)
+    assert len(ctx.detect_affine_keypoints(i1, p)) == 2000
+    assert len(ctx.detect_affine_keypoints(i2, p)) == 2000
+    i1.free(); i2.free()
+
+
+def test_full_size_pair_properties(ctx, modsx, oracle):
+    """BASELINE config 1: one 1024x768 synthetic pair, 1 view.  Checked through size-independent properties
+    plus a full oracle comparison of the (cheap) detection stage."""
+    from mods_amd import synthetic
+    a, b, H = synthetic.make_pair()
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    got = ctx.match_pair(ia, ib, modsx.default_pair_params(ransac_seed=5))
+    assert got["n_regions"][0] > 1500 and got["n_tentatives"] > 500
+    assert got["n_verified"] > 300
+    assert np.abs(normH(got["H"]) - H).max() < 1.0
+    t = got["tentatives"]
+    assert np.all(t["ratio"] <= 0.8 + 1e-12) and np.all(np.diff(np.abs(t["ratio"])) >= 0)   # sorted by FGINN ratio
+    assert np.all(t["d1"] <= t["d2by2ndcl"]) and np.all(t["d2by2ndcl"] <= t["d2"])
+    k = ctx.detect_affine_keypoints(ia, modsx.default_hessaff_params())
+    assert same_records(k, oracle.detect_hessaff(a, oracle.default_params()).view(modsx.KEYPOINT))
+    again = ctx.match_pair(ia, ib, modsx.default_pair_params(ransac_seed=5))                # idempotent
+    assert np.array_equal(again["ransac_inlier"], got["ransac_inlier"]) and np.array_equal(again["H"], got["H"])
+    ia.free(); ib.free()

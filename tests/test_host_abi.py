@@ -1,0 +1,108 @@
+"""CPU: the C-ABI library loads, exports what include/modsx.h declares, and its host-side entry points
+(no device involved) agree with the oracle / the reference's degensac."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from common import synth_corr, normH, same_records
+from conftest import HAS_GPU, ROOT
+
+
+def test_library_exports_every_declared_symbol(modsx):
+    hdr = open(os.path.join(ROOT, "include", "modsx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(modsx_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(modsx.EXPORTS)
+    L = modsx.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert L.modsx_version() == 100
+
+
+def test_struct_layouts_match_reference_structs(modsx):
+    # AffineKeypoint is 8 doubles + int + double + int (88 B); AffineRegion = 5 ints + 2 keypoints
+    assert modsx.KEYPOINT.itemsize == 88 and modsx.REGION.itemsize == 200
+    assert modsx.KEYPOINT.fields["pyramid_scale"][1] == 72 and modsx.REGION.fields["det_kp"][1] == 24
+    assert ctypes.sizeof(modsx.HessAffParams) == 64
+
+
+@pytest.mark.skipif(HAS_GPU, reason="only meaningful without a device")
+def test_create_fails_loudly_without_device(modsx):
+    with pytest.raises(RuntimeError, match="no HIP device|CPU fallback"):
+        modsx.Context(0)
+
+
+def test_affine_regions_and_reproject_match_oracle(modsx, oracle):
+    rs = np.random.RandomState(5)
+    n = 300
+    k = np.zeros(n, oracle.KEYPOINT)
+    k["x"] = rs.uniform(0, 1024, n); k["y"] = rs.uniform(0, 768, n); k["s"] = rs.uniform(1, 30, n)
+    k["a11"] = rs.uniform(0.5, 2, n); k["a12"] = rs.uniform(-1, 1, n)
+    k["a21"] = rs.uniform(-1, 1, n); k["a22"] = rs.uniform(0.5, 2, n)
+    k["response"] = rs.uniform(-100, 100, n); k["sub_type"] = rs.randint(0, 3, n)
+    ro = oracle.detect_affine_regions(k)
+    rm = modsx.detect_affine_regions(k.view(modsx.KEYPOINT))
+    assert same_records(ro, rm)
+    for H in (np.eye(3), np.array([[0.5, 0.1, 10], [-0.2, 0.7, 5], [0, 0, 1.0]])):
+        a = oracle.reproject_regions(ro, H, 1024, 768)
+        b = modsx.reproject_regions(rm, H, 1024, 768)
+        assert same_records(a, b)
+        assert 0 < len(a) < n
+
+
+def test_duplicate_filtering_matches_oracle(modsx, oracle):
+    rs = np.random.RandomState(2)
+    base = rs.uniform(0, 200, (150, 4))
+    pts = np.concatenate([base, base[:60] + rs.uniform(-1, 1, (60, 4)), base[:20]])
+    key = np.round(rs.uniform(0.3, 0.8, len(pts)), 2)          # many ties -> exercises the unstable sort
+    for r, s in ((2.0, True), (3.0, True), (2.0, False), (0.0, True)):
+        oa, ka = oracle.duplicate_filtering(pts, key, r, s)
+        ob, kb = modsx.duplicate_filtering(pts, key, r, s)
+        assert np.array_equal(oa, ob) and np.array_equal(ka, kb)
+    assert ka.all()                                             # r = 0: no filtering
+
+
+@pytest.mark.parametrize("T,frac,seed", [(500, 0.66, 1), (200, 0.3, 2), (1500, 0.9, 3), (60, 0.5, 4), (30, 0.5, 5),
+                                         (12, 0.9, 6), (2000, 0.15, 7)])
+def test_loransac_h_matches_reference_degensac(modsx, oracle, T, frac, seed):
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    pts, laf, H = synth_corr(T, frac, seed=seed)
+    for rseed in (1, 12345, 99):
+        a = oracle.loransac_h(pts, laf, laf, seed=rseed)
+        b = modsx.loransac_h(pts, laf, laf, seed=rseed)
+        # identical sampling trajectory (same glibc PRNG stream), identical inlier indices, H within 1e-4
+        assert (a["samples"], a["lo_count"], a["ori_rejects"]) == (b["samples"], b["lo_count"], b["ori_rejects"])
+        assert np.array_equal(a["inl"], b["inl"]) and np.array_equal(a["keep"], b["keep"]) and a["n"] == b["n"]
+        assert np.abs(normH(a["H"]) - normH(b["H"])).max() < 1e-4
+
+
+def test_loransac_edge_cases(modsx, oracle):
+    pts, laf, _ = synth_corr(7, 1.0, seed=1)
+    r = modsx.loransac_h(pts, laf, laf)
+    assert r["n"] == 0 and not r["inl"].any() and np.all(r["H"] == -1)     # < MIN_POINTS (matching.hpp:27)
+    r = modsx.loransac_h(np.zeros((0, 4)), np.zeros((0, 5)), np.zeros((0, 5)))
+    assert r["n"] == 0
+    if oracle.ref_available():
+        pts, laf, _ = synth_corr(40, 0.0, seed=3)              # pure outliers
+        a, b = oracle.loransac_h(pts, laf, laf, seed=5), modsx.loransac_h(pts, laf, laf, seed=5)
+        assert np.array_equal(a["inl"], b["inl"]) and a["n"] == b["n"] and a["samples"] == b["samples"]
+
+
+def test_glibc_prng_restatement(modsx):
+    # modsx_ransac_h seeds its own copy of glibc's TYPE_3 random(); with an identical trajectory the number of
+    # samples drawn is a function of the seed only -> different seeds give different trajectories, same seed
+    # repeats exactly (re-entrancy: no process-global state).
+    pts, laf, _ = synth_corr(300, 0.5, seed=11)
+    u = np.c_[pts[:, :2], np.ones(len(pts)), pts[:, 2:], np.ones(len(pts))]
+    a = modsx.ransac_h(u, 9.0, seed=42)
+    b = modsx.ransac_h(u, 9.0, seed=42)
+    assert a["samples"] == b["samples"] and np.array_equal(a["inl"], b["inl"]) and np.array_equal(a["H"], b["H"])
+    libc = ctypes.CDLL("libc.so.6")
+    libc.random.restype = ctypes.c_long
+    libc.srand(42)
+    first = [libc.random() for _ in range(3)]
+    assert first[0] == 71876166 and first[1] == 708592740        # glibc srand(42) known answers
