@@ -521,8 +521,9 @@ int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n
         base.id = 0;  // const_temp_region.id = count, count is never incremented (synth-detection.cpp:854,889)
         const OriOut &o = res[jk++];
         for (int a = 0; a < o.n; a++) {
-          double ci = cos(-o.ang[a]);
-          double si = sin(-o.ang[a]);
+          // `using namespace std` in synth-detection.cpp:30 => cos/sin(float) are the f32 overloads
+          double ci = cosf(-o.ang[a]);
+          double si = sinf(-o.ang[a]);
           modsx_region t = base;
           t.det_kp.a11 = base.det_kp.a11 * ci - base.det_kp.a12 * si;
           t.det_kp.a12 = base.det_kp.a11 * si + base.det_kp.a12 * ci;

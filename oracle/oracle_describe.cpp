@@ -265,8 +265,10 @@ int orc_detect_orientation(const float *img_, int rows, int cols, const orc_regi
                   patch);
       dominant_angles(patch, doHalfSIFT, th, maxAngNum, angles1);
       for (size_t j = 0; j < angles1.size(); j++) {
-        double ci = cos(-angles1[j]);
-        double si = sin(-angles1[j]);
+        /* synth-detection.cpp:30 has `using namespace std`, so cos/sin of a float resolve to the
+           f32 overloads (cosf/sinf); the result is then widened to double (:900-901) */
+        double ci = cosf(-angles1[j]);
+        double si = sinf(-angles1[j]);
         orc_region t = base;
         t.det_kp.a11 = base.det_kp.a11 * ci - base.det_kp.a12 * si;
         t.det_kp.a12 = base.det_kp.a11 * si + base.det_kp.a12 * ci;
