@@ -222,6 +222,14 @@ void modsx_pair_result_release(modsx_pair_result *res);
 /* per-stage time of the last modsx_match_pair in ms: detect, orient, describe, match, verify, total */
 int modsx_last_timings(modsx_ctx *ctx, double *ms6);
 
+/* Measurement hooks (no reference counterpart; the reference only keeps wall-clock TimeLog, structures.hpp:51-74).
+ * modsx_profile(ctx, 1) brackets every kernel launch with HIP events on the ctx stream and accumulates, per kernel
+ * class, GPU milliseconds, launch count and algorithmic work (bytes; flops for the matcher).  Classes in order:
+ * blur_hess, hessian, resize, nms_localize, baumberg, orientation, patch_sample, patch_blur, describe, match_fginn,
+ * gray.  modsx_kernel_stats returns the number of classes. */
+int modsx_profile(modsx_ctx *ctx, int enable);
+int modsx_kernel_stats(modsx_ctx *ctx, double *ms, double *work, long *launches, int n);
+
 #ifdef __cplusplus
 }
 #endif

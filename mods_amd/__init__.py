@@ -60,7 +60,11 @@ EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "m
            "modsx_detect_scalespace", "modsx_octave_levels", "modsx_gaussian_blur", "modsx_resize_half",
            "modsx_detect_affine_regions", "modsx_detect_orientation", "modsx_reproject_regions",
            "modsx_describe_regions", "modsx_match_fginn", "modsx_duplicate_filtering", "modsx_ransac_h",
-           "modsx_loransac_h", "modsx_match_pair", "modsx_pair_result_release", "modsx_last_timings"]
+           "modsx_loransac_h", "modsx_match_pair", "modsx_pair_result_release", "modsx_last_timings", "modsx_profile",
+           "modsx_kernel_stats"]
+
+KERNEL_CLASSES = ["blur_hess", "hessian", "resize", "nms_localize", "baumberg", "orientation", "patch_sample",
+                  "patch_blur", "describe", "match_fginn", "gray"]
 
 
 def build(force=False):
@@ -338,6 +342,16 @@ class Context(object):
             out["verified"] = np.zeros(0, bool)
         lib().modsx_pair_result_release(C.byref(res))
         return out
+
+    def profile(self, enable=True):
+        _check(lib().modsx_profile(self._c(), int(enable)), "profile")
+
+    def kernel_stats(self):
+        n = len(KERNEL_CLASSES)
+        ms, work = (C.c_double * n)(), (C.c_double * n)()
+        launches = (C.c_long * n)()
+        _check(lib().modsx_kernel_stats(self._c(), ms, work, launches, n), "kernel_stats")
+        return {k: dict(ms=ms[i], work=work[i], launches=launches[i]) for i, k in enumerate(KERNEL_CLASSES)}
 
     def last_timings(self):
         t = (C.c_double * 6)()

@@ -283,4 +283,17 @@ int modsx_last_timings(modsx_ctx *ctx, double *ms6) {
   return MODSX_OK;
 }
 
+int modsx_profile(modsx_ctx *ctx, int enable) {
+  NEED(ctx);
+  prof_reset(ctx, enable != 0);
+  return MODSX_OK;
+}
+
+int modsx_kernel_stats(modsx_ctx *ctx, double *ms, double *work, long *launches, int n) {
+  NEED(ctx); NEED(ms); NEED(work); NEED(launches);
+  prof_collect(ctx);
+  for (int i = 0; i < n && i < K_NCLASS; i++) { ms[i] = ctx->prof.ms[i]; work[i] = ctx->prof.work[i]; launches[i] = ctx->prof.launches[i]; }
+  return K_NCLASS;
+}
+
 }  // extern "C"

@@ -37,6 +37,43 @@ bool PinBuf::ensure(size_t bytes) {
 }
 void PinBuf::release() { if (p) hipHostFree(p); p = nullptr; cap = 0; }
 
+// ---- per-kernel-class GPU timing with HIP events on the launch stream ------------------------------
+struct ProfScope {
+  modsx_ctx *c;
+  bool on;
+  size_t slot = 0;
+  ProfScope(modsx_ctx *c_, int cls, double work) : c(c_), on(c_->prof.enabled) {
+    if (!on) return;
+    Profiler &p = c->prof;
+    if (p.used == p.evA.size()) {
+      hipEvent_t a, b;
+      hipEventCreate(&a); hipEventCreate(&b);
+      p.evA.push_back(a); p.evB.push_back(b); p.cls.push_back(0);
+    }
+    slot = p.used++;
+    p.cls[slot] = cls;
+    p.work[cls] += work;
+    p.launches[cls]++;
+    hipEventRecord(p.evA[slot], c->stream);
+  }
+  ~ProfScope() { if (on) hipEventRecord(c->prof.evB[slot], c->stream); }
+};
+void prof_collect(modsx_ctx *c) {
+  Profiler &p = c->prof;
+  if (!p.enabled || !p.used) return;
+  hipStreamSynchronize(c->stream);
+  for (size_t i = 0; i < p.used; i++) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.evA[i], p.evB[i]) == hipSuccess) p.ms[p.cls[i]] += ms;
+  }
+  p.used = 0;
+}
+void prof_reset(modsx_ctx *c, bool enable) {
+  Profiler &p = c->prof;
+  p.enabled = enable; p.used = 0;
+  for (int i = 0; i < K_NCLASS; i++) { p.ms[i] = 0; p.work[i] = 0; p.launches[i] = 0; }
+}
+
 static double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -211,7 +248,12 @@ int build_pyramids(modsx_ctx *c, const modsx_image *const *imgs, int n, const mo
           j.src = oc.blur[0];
         }
       }
-      if (nj) { if (preBlur) launch_blur_hess(s, bb, nj, mr, mc); else launch_hessian(s, bb, nj, mr, mc); }
+      double px = 0;
+      for (int q = 0; q < nj; q++) px += (double)bb.j[q].rows * bb.j[q].cols;
+      if (nj) {
+        if (preBlur) { ProfScope ps(c, K_BLUR_HESS, px * 12); launch_blur_hess(s, bb, nj, mr, mc); }
+        else { ProfScope ps(c, K_HESSIAN, px * 8); launch_hessian(s, bb, nj, mr, mc); }
+      }
     } else {
       ResizeBatch rb;
       memset(&rb, 0, sizeof rb);
@@ -226,7 +268,12 @@ int build_pyramids(modsx_ctx *c, const modsx_image *const *imgs, int n, const mo
         j.norm = sp.curSigma[0] * sp.curSigma[0];
         mr = std::max(mr, oc.rows); mc = std::max(mc, oc.cols);
       }
-      if (nj) { launch_resize_half(s, rb, nj, mr, mc); launch_hessian(s, bb, nj, mr, mc); }
+      if (nj) {
+        double spx = 0, dpx = 0;
+        for (int q = 0; q < nj; q++) { spx += (double)rb.j[q].srows * rb.j[q].scols; dpx += (double)rb.j[q].drows * rb.j[q].dcols; }
+        { ProfScope ps(c, K_RESIZE, (spx + dpx) * 4); launch_resize_half(s, rb, nj, mr, mc); }
+        { ProfScope ps(c, K_HESSIAN, dpx * 8); launch_hessian(s, bb, nj, mr, mc); }
+      }
     }
     if (!nj) continue;
     for (int l = 1; l < L; l++) {
@@ -242,6 +289,9 @@ int build_pyramids(modsx_ctx *c, const modsx_image *const *imgs, int n, const mo
         j.src = oc.blur[l - 1]; j.blur = oc.blur[l]; j.resp = oc.resp[l]; j.rows = oc.rows; j.cols = oc.cols;
         j.norm = sp.curSigma[l] * sp.curSigma[l];
       }
+      double px = 0;
+      for (int q = 0; q < k; q++) px += (double)b2.j[q].rows * b2.j[q].cols;
+      ProfScope ps(c, K_BLUR_HESS, px * 12);
       launch_blur_hess(s, b2, k, mr, mc);
     }
   }
@@ -286,6 +336,9 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
         mr = std::max(mr, oc.rows); mc = std::max(mc, oc.cols);
       }
     }
+    double px = 0;
+    for (int q = 0; q < nj; q++) px += (double)nb.j[q].rows * nb.j[q].cols;
+    ProfScope ps(c, K_NMS, px * 12);
     launch_nms(s, nb, nj, mr, mc, (Candidate *)c->cand.p, (unsigned *)c->counter.p, CAND_CAP);
   }
   if (!c->hMisc.ensure(64)) return MODSX_ERR_NOMEM;
@@ -412,6 +465,7 @@ int detect_keypoints_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, 
     }
   if (p.doBaumberg) {
     MX_HIP(hipMemcpyAsync(c->affJobs.p, hj, total * sizeof(AffJob), hipMemcpyHostToDevice, s));
+    ProfScope ps(c, K_BAUMBERG, (double)total * 361 * 4 * 2);
     launch_baumberg(s, (AffJob *)c->affJobs.p, (AffOut *)c->affOut.p, (int)total, c->dSmmMask, p.smmWindowSize,
                     p.maxIterations, p.convergenceThreshold, p.affInitialSigma);
     MX_HIP(hipMemcpyAsync(ho, c->affOut.p, total * sizeof(AffOut), hipMemcpyDeviceToHost, s));
@@ -507,6 +561,7 @@ int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n
     if (!c->oriJobs.ensure(nj * sizeof(OriJob)) || !c->oriOut.ensure(nj * sizeof(OriOut))) return MODSX_ERR_NOMEM;
     MX_HIP(hipMemcpyAsync(c->oriJobs.p, jobs.data(), nj * sizeof(OriJob), hipMemcpyHostToDevice, s));
     int maxA = maxAngNum == -1 ? 7 : std::min(maxAngNum, 7);
+    ProfScope ps(c, K_ORIENT, (double)nj * 41 * 41 * 4);
     launch_orientation(s, (OriJob *)c->oriJobs.p, (OriOut *)c->oriOut.p, (int)nj, (ImgRef *)c->imgRefs.p, c->dOriMask,
                        c->dAtan, doHalfSIFT, th, maxA);
     MX_HIP(hipMemcpyAsync(res.data(), c->oriOut.p, nj * sizeof(OriOut), hipMemcpyDeviceToHost, s));
@@ -648,11 +703,15 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       MX_HIP(hipMemcpyAsync(dPfxB, pfxBlur.data(), (nj + 1) * 4, hipMemcpyHostToDevice, s));
       if (!taps.empty()) MX_HIP(hipMemcpyAsync(c->taps.p, taps.data(), taps.size() * 4, hipMemcpyHostToDevice, s));
       const DescJob *dj = (const DescJob *)c->descJobs.p;
-      launch_patch_sample(s, dj, dPfxS, (int)nj, pfxSample.back(), (ImgRef *)c->imgRefs.p, (float *)c->scratchA.p);
-      launch_patch_blur(s, dj, dPfxB, (int)nj, pfxBlur.back(), (float *)c->taps.p, (float *)c->scratchA.p,
-                        (float *)c->scratchB.p, 0);
-      launch_patch_blur(s, dj, dPfxB, (int)nj, pfxBlur.back(), (float *)c->taps.p, (float *)c->scratchB.p,
-                        (float *)c->scratchA.p, 1);
+      { ProfScope ps(c, K_PATCH_SAMPLE, (double)arena * 8);
+        launch_patch_sample(s, dj, dPfxS, (int)nj, pfxSample.back(), (ImgRef *)c->imgRefs.p, (float *)c->scratchA.p); }
+      { ProfScope ps(c, K_PATCH_BLUR, (double)arena * 8);
+        launch_patch_blur(s, dj, dPfxB, (int)nj, pfxBlur.back(), (float *)c->taps.p, (float *)c->scratchA.p,
+                          (float *)c->scratchB.p, 0); }
+      { ProfScope ps(c, K_PATCH_BLUR, (double)arena * 8);
+        launch_patch_blur(s, dj, dPfxB, (int)nj, pfxBlur.back(), (float *)c->taps.p, (float *)c->scratchB.p,
+                          (float *)c->scratchA.p, 1); }
+      ProfScope psd(c, K_DESCRIBE, (double)nj * (41 * 41 * 4 + 128 * 5));
       launch_describe(s, dj, (int)nj, (ImgRef *)c->imgRefs.p, (float *)c->scratchA.p, c->dSiftMask, c->dAtan,
                       c->dSiftBins, c->dSiftW, photoNorm, descType == MODSX_DESC_ROOT_SIFT, maxBin,
                       (float *)c->descF[i].p + done * 128, (uint8_t *)c->descU8[i].p + done * 128);
@@ -678,7 +737,10 @@ int match_device(modsx_ctx *c, const uint8_t *d1, int n1, const uint8_t *d2, int
   if (!(sqminratio < 1.0)) { set_error("match ratio >= 1 (PDF mode of MatchFlannFGINN) is not supported"); return MODSX_ERR_ARG; }
   if (!c->pos2.ensure((size_t)n2 * 16) || !c->matchRows.ensure((size_t)n1 * sizeof(MatchRow))) return MODSX_ERR_NOMEM;
   MX_HIP(hipMemcpyAsync(c->pos2.p, pos2Host, (size_t)n2 * 16, hipMemcpyHostToDevice, s));
-  launch_match(s, d1, n1, d2, n2, (const double *)c->pos2.p, sqminratio, contrDistSq, (MatchRow *)c->matchRows.p);
+  {
+    ProfScope ps(c, K_MATCH, 2.0 * n1 * (double)n2 * 128);
+    launch_match(s, d1, n1, d2, n2, (const double *)c->pos2.p, sqminratio, contrDistSq, (MatchRow *)c->matchRows.p);
+  }
   std::vector<MatchRow> rows(n1);
   MX_HIP(hipMemcpyAsync(rows.data(), c->matchRows.p, (size_t)n1 * sizeof(MatchRow), hipMemcpyDeviceToHost, s));
   MX_HIP(hipStreamSynchronize(s));
@@ -797,6 +859,7 @@ int match_pair(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, c
   for (int i = 0; i < T; i++) res->n_ransac_inliers += res->ransac_inlier[i];
   res->ransac_samples = dout[0]; res->ransac_lo = dout[1];
   const double t5 = now_ms();
+  prof_collect(c);
   c->timings[0] = t1 - t0; c->timings[1] = t2 - t1; c->timings[2] = t3 - t2; c->timings[3] = t4 - t3;
   c->timings[4] = t5 - t4; c->timings[5] = t5 - t0;
   return MODSX_OK;

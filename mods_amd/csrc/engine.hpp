@@ -153,6 +153,20 @@ void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, i
 
 }  // namespace mx
 
+namespace mx {
+enum KClass { K_BLUR_HESS = 0, K_HESSIAN, K_RESIZE, K_NMS, K_BAUMBERG, K_ORIENT, K_PATCH_SAMPLE, K_PATCH_BLUR, K_DESCRIBE,
+              K_MATCH, K_GRAY, K_NCLASS };
+struct Profiler {
+  bool enabled = false;
+  std::vector<hipEvent_t> evA, evB;
+  std::vector<int> cls;
+  size_t used = 0;
+  double ms[K_NCLASS] = {0};
+  double work[K_NCLASS] = {0};   // algorithmic bytes (flops for K_MATCH)
+  long launches[K_NCLASS] = {0};
+};
+}  // namespace mx
+
 struct modsx_image {
   float *d;
   int rows, cols;
@@ -176,4 +190,5 @@ struct modsx_ctx {
   double *dSiftW = nullptr;    // w0[41], w1[41]
   hipEvent_t ev[8];
   double timings[6];
+  mx::Profiler prof;
 };

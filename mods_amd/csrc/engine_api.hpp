@@ -5,6 +5,8 @@
 
 namespace mx {
 const char *last_error();
+void prof_collect(modsx_ctx *c);
+void prof_reset(modsx_ctx *c, bool enable);
 modsx_ctx *ctx_create(int device_id);
 void ctx_destroy(modsx_ctx *c);
 int build_pyramids(modsx_ctx *c, const modsx_image *const *imgs, int n, const modsx_hessaff_params &p,
