@@ -90,6 +90,13 @@ static int upload_tables(modsx_ctx *c) {
   MX_HIP(hipMalloc(&c->dSiftMask, PS * PS * 4));
   circular_gauss_mask(m.data(), PS, 0);          // SIFTDescriptor ctor / DescribeRegions, siftdesc.h:87
   MX_HIP(hipMemcpy(c->dSiftMask, m.data(), PS * PS * 4, hipMemcpyHostToDevice));
+  {
+    std::vector<unsigned short> idx;
+    for (int i = 0; i < PS * PS; i++) if (m[i] > 0) idx.push_back((unsigned short)i);
+    c->nSiftMask = (int)idx.size();
+    MX_HIP(hipMalloc(&c->dSiftMaskIdx, idx.size() * 2));
+    MX_HIP(hipMemcpy(c->dSiftMaskIdx, idx.data(), idx.size() * 2, hipMemcpyHostToDevice));
+  }
   MX_HIP(hipMalloc(&c->dAtan, 256 * 8));
   MX_HIP(hipMemcpy(c->dAtan, atan_lut_host(), 256 * 8, hipMemcpyHostToDevice));
   // precomputeBinsAndWeights, matching/siftdesc.cpp:22-71 (spatialBins 4, orientationBins 8, patch 41)
@@ -146,7 +153,7 @@ void ctx_destroy(modsx_ctx *c) {
   for (DevBuf *b : bufs) b->release();
   PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc};
   for (PinBuf *b : pins) b->release();
-  hipFree(c->dSmmMask); hipFree(c->dOriMask); hipFree(c->dSiftMask); hipFree(c->dAtan); hipFree(c->dSiftBins);
+  hipFree(c->dSmmMask); hipFree(c->dOriMask); hipFree(c->dSiftMask); hipFree(c->dSiftMaskIdx); hipFree(c->dAtan); hipFree(c->dSiftBins);
   hipFree(c->dSiftW);
   for (int i = 0; i < 8; i++) hipEventDestroy(c->ev[i]);
   hipStreamDestroy(c->stream);
@@ -712,7 +719,8 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
         launch_patch_blur(s, dj, dPfxB, (int)nj, pfxBlur.back(), (float *)c->taps.p, (float *)c->scratchB.p,
                           (float *)c->scratchA.p, 1); }
       ProfScope psd(c, K_DESCRIBE, (double)nj * (41 * 41 * 4 + 128 * 5));
-      launch_describe(s, dj, (int)nj, (ImgRef *)c->imgRefs.p, (float *)c->scratchA.p, c->dSiftMask, c->dAtan,
+      launch_describe(s, dj, (int)nj, (ImgRef *)c->imgRefs.p, (float *)c->scratchA.p, c->dSiftMask, c->dSiftMaskIdx,
+                      c->nSiftMask, c->dAtan,
                       c->dSiftBins, c->dSiftW, photoNorm, descType == MODSX_DESC_ROOT_SIFT, maxBin,
                       (float *)c->descF[i].p + done * 128, (uint8_t *)c->descU8[i].p + done * 128);
       MX_HIP(hipStreamSynchronize(s));  // jobs/taps/prefix are host vectors reused by the next chunk

@@ -146,8 +146,8 @@ void launch_patch_sample(hipStream_t s, const DescJob *jobs, const int *tilePref
 void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, int nTiles,
                        const float *taps, const float *src, float *dst, int pass);
 void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *imgs, const float *scratch,
-                     const float *mask, const double *atanLut, const int *bins, const double *wts, int photoNorm,
-                     int rootsift, double maxBin, float *descF, uint8_t *descU8);
+                     const float *mask, const unsigned short *maskIdx, int nmask, const double *atanLut, const int *bins,
+                     const double *wts, int photoNorm, int rootsift, double maxBin, float *descF, uint8_t *descU8);
 void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2,
                   double sqminratio, double contrDistSq, MatchRow *rows);
 
@@ -185,6 +185,8 @@ struct modsx_ctx {
   int smmW = 0;
   float *dOriMask = nullptr;   // 41x41 circular mask, sigma = 41/3
   float *dSiftMask = nullptr;  // 41x41 circular mask, sigma2 = 0.9 r^2
+  unsigned short *dSiftMaskIdx = nullptr;  // raster-ordered indices of the pixels with mask > 0
+  int nSiftMask = 0;
   double *dAtan = nullptr;
   int *dSiftBins = nullptr;    // bin0[41], bin1[41]
   double *dSiftW = nullptr;    // w0[41], w1[41]

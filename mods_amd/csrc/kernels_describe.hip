@@ -110,76 +110,118 @@ __global__ __launch_bounds__(256) void k_patch_blur(const DescJob *jobs, const i
 }
 
 // --- stage 3: 41x41 patch, photometric normalisation, SIFT histogram ----------------------------
-constexpr int PS = 41, NPX = PS * PS;
+// One 128-thread workgroup per region.  Everything order-dependent in the reference is kept in its
+// order but fed from LDS so that the serial chains are pure dependent adds:
+//   * sample coordinates: 41 lanes run the f32 running sums of interpolate() and park (WX, WY) in LDS,
+//     then all 128 threads take the 1681 bilinear taps in parallel;
+//   * photometricallyNormalize: the masked pixels (a disc, 1257 of 1681) are compacted in raster order
+//     and summed by one lane with 16-byte LDS reads (mean, then variance);
+//   * samplePatch: thread t owns bin t = 32*rb + 8*cb + ob and walks the 16x16 pixel block that can
+//     reach it (rows 8rb..8rb+15, cols 8cb..8cb+15) in raster order with an f64 accumulator.  For rows
+//     8rb..8rb+7 the bin is the pixel's bin1 (weight w1), for rows 8rb+8..8rb+15 its bin0 (weight w0);
+//     same for columns -- this is precomputeBinsAndWeights (siftdesc.cpp:22-71) for 4 spatial bins
+//     and patch 41, where step = 5/40 makes xi = i/8.
+constexpr int PS = 41, NPX = PS * PS, PSP = 44;  // PSP: padded row stride (16-byte aligned rows)
+constexpr int NMASK_MAX = 1300;
 
 struct SiftConst {
-  int lo[4], hi[4];  // pixel index range touching spatial bin k (rows and columns alike)
+  int nmask;   // number of pixels with mask > 0
 };
 
 __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, const ImgRef *imgs, const float *scratch,
-                                                  const float *mask, const double *atanLut, const int *binTab,
-                                                  const double *wTab, SiftConst sc, int photoNorm, int rootsift,
-                                                  double maxBin, float *descF, uint8_t *descU8) {
+                                                  const float *mask, const unsigned short *maskIdx,
+                                                  const double *atanLut, const int *binTab, const double *wTab,
+                                                  SiftConst sc, int photoNorm, int rootsift, double maxBin,
+                                                  float *descF, uint8_t *descU8) {
   const int k = blockIdx.x;
   if (k >= n) return;
   const int tid = threadIdx.x;
-  __shared__ float patch[NPX];
-  __shared__ float sval[NPX];   // mask * gradient magnitude
-  __shared__ float swo1[NPX];   // orientation interpolation weight
-  __shared__ unsigned char sbo0[NPX];
-  __shared__ float smask[NPX];
-  __shared__ int sbin0[PS], sbin1[PS];
-  __shared__ double sw0[PS], sw1[PS];
-  __shared__ double vec[128];
+  __shared__ __attribute__((aligned(16))) float patch[NPX];
+  __shared__ __attribute__((aligned(16))) float bufA[PS * PSP];   // WX, later wc0 = (float)(w0[c] * val)
+  __shared__ __attribute__((aligned(16))) float bufB[PS * PSP];   // WY, later wc1 = (float)(w1[c] * val)
+  __shared__ __attribute__((aligned(16))) float bufC[PS * PSP];   // compacted masked values, later wo1
+  __shared__ __attribute__((aligned(16))) unsigned char sbo0[PS * PSP];
+  __shared__ float swr0[PS], swr1[PS];
+  __shared__ double swc0[PS], swc1[PS];
+  __shared__ __attribute__((aligned(16))) double vec[128];
+  __shared__ __attribute__((aligned(16))) double part[32];
   __shared__ float sstat[2];
+  __shared__ double sfac;
+  __shared__ int schanged;
   const DescJob jb = jobs[k];
-  for (int i = tid; i < NPX; i += 128) smask[i] = mask[i];
-  if (tid < PS) { sbin0[tid] = binTab[tid]; sbin1[tid] = binTab[PS + tid]; sw0[tid] = wTab[tid]; sw1[tid] = wTab[PS + tid]; }
-  // -- resample to 41x41: lane j walks row j
   if (tid < PS) {
-    const float *src; int srows, scols; float ox, oy, a11, a12, a21, a22;
-    if (jb.P > 0) {
-      src = scratch + jb.scratchOfs; srows = jb.P; scols = jb.P;
-      ox = (float)(jb.P >> 1); oy = ox;
-      a11 = jb.i2p; a12 = 0.f; a21 = 0.f; a22 = jb.i2p;
-    } else {
-      const ImgRef im = imgs[jb.img];
-      src = im.d; srows = im.rows; scols = im.cols;
-      ox = jb.x; oy = jb.y; a11 = jb.a11; a12 = jb.a12; a21 = jb.a21; a22 = jb.a22;
-    }
+    swr0[tid] = (float)wTab[tid]; swr1[tid] = (float)wTab[PS + tid];   // const float wr0 = w0[r] (siftdesc.cpp:79-81)
+    swc0[tid] = wTab[tid]; swc1[tid] = wTab[PS + tid];
+  }
+  // -- sample coordinates (interpolate(), helpers.cpp:563-585)
+  const float *src; int srows, scols; float ox, oy, a11, a12, a21, a22;
+  if (jb.P > 0) {
+    src = scratch + jb.scratchOfs; srows = jb.P; scols = jb.P;
+    ox = (float)(jb.P >> 1); oy = ox;
+    a11 = jb.i2p; a12 = 0.f; a21 = 0.f; a22 = jb.i2p;
+  } else {
+    const ImgRef im = imgs[jb.img];
+    src = im.d; srows = im.rows; scols = im.cols;
+    ox = jb.x; oy = jb.y; a11 = jb.a11; a12 = jb.a12; a21 = jb.a21; a22 = jb.a22;
+  }
+  const bool touch = check_borders(scols, srows, ox, oy, a11, a12, a21, a22, PS, PS);
+  if (tid < PS) {
     const int half = PS >> 1;
-    const bool touch = check_borders(scols, srows, ox, oy, a11, a12, a21, a22, PS, PS);
     float rx = ox - (float)half * a12;
     float ry = oy - (float)half * a22;
     for (int j = 0; j < tid; j++) { rx += a12; ry += a22; }
     float WX = rx - (float)half * a11;
     float WY = ry - (float)half * a21;
+#pragma unroll 1
     for (int i = 0; i < PS; i++) {
-      patch[tid * PS + i] = bilinear_tap(src, srows, scols, WX, WY, touch);
+      bufA[tid * PSP + i] = WX;
+      bufB[tid * PSP + i] = WY;
       WX += a11;
       WY += a21;
     }
   }
   __syncthreads();
-  // -- photometricallyNormalize: sequential f32 sums over the masked pixels (order dependent)
+  for (int p = tid; p < NPX; p += 128) {
+    const int r = p / PS, c = p - r * PS;
+    patch[p] = bilinear_tap(src, srows, scols, bufA[r * PSP + c], bufB[r * PSP + c], touch);
+  }
+  __syncthreads();
+  // -- photometricallyNormalize (helpers.cpp:666-715): f32 running sums over the masked pixels
   if (photoNorm) {
+    const int nm = sc.nmask, nm4 = (nm + 3) & ~3;
+    for (int i = tid; i < nm4; i += 128) bufC[i] = i < nm ? patch[maskIdx[i]] : 0.f;
+    __syncthreads();
     if (tid == 0) {
-      float sum = 0.f, gsum = 0.f;
-      for (int i = 0; i < NPX; i++)
-        if (smask[i] > 0) { sum += patch[i]; gsum += 1.0f; }
-      sum = sum / gsum;
-      float var = 0.f;
-      for (int i = 0; i < NPX; i++)
-        if (smask[i] > 0) var += (sum - patch[i]) * (sum - patch[i]);
-      var = sqrtf(var / gsum);
-      sstat[0] = sum; sstat[1] = var;
+      float sum = 0.f;
+      const float4 *v4 = reinterpret_cast<const float4 *>(bufC);
+      const int full = nm >> 2;
+#pragma unroll 8
+      for (int i = 0; i < full; i++) { const float4 v = v4[i]; sum += v.x; sum += v.y; sum += v.z; sum += v.w; }
+      for (int i = full * 4; i < nm; i++) sum += bufC[i];
+      float gsum = 0.f;
+      for (int i = 0; i < nm; i++) gsum += 1.0f;   // gsum++ per masked pixel (exact in f32)
+      sstat[0] = sum / gsum;
+      sstat[1] = gsum;
     }
     __syncthreads();
-    const float sum = sstat[0], var = sstat[1];
+    const float mean = sstat[0], gsum = sstat[1];
+    for (int i = tid; i < nm4; i += 128) { const float d = mean - bufC[i]; bufC[i] = i < nm ? d * d : 0.f; }
+    __syncthreads();
+    if (tid == 0) {
+      float var = 0.f;
+      const float4 *v4 = reinterpret_cast<const float4 *>(bufC);
+      const int full = nm >> 2;
+#pragma unroll 8
+      for (int i = 0; i < full; i++) { const float4 v = v4[i]; var += v.x; var += v.y; var += v.z; var += v.w; }
+      for (int i = full * 4; i < nm; i++) var += bufC[i];
+      sstat[1] = sqrtf(var / gsum);
+    }
+    __syncthreads();
+    const float var = sstat[1];
     if (!((double)var < 0.0001)) {
       const float fac = 50.0f / var;
       for (int i = tid; i < NPX; i += 128) {
-        float v = 128.f + fac * (patch[i] - sum);
+        float v = 128.f + fac * (patch[i] - mean);
         if (v > 255.f) v = 255.f;
         if (v < 0.f) v = 0.f;
         patch[i] = v;
@@ -187,7 +229,7 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
     }
     __syncthreads();
   }
-  // -- gradients, orientation, per-pixel weights
+  // -- gradients, orientation, per-pixel weights (siftdesc.cpp:346-379, 73-131)
   const double TWO_PI = 6.28318530718;
   for (int p = tid; p < NPX; p += 128) {
     const int r = p / PS, c = p - r * PS;
@@ -200,58 +242,62 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
     else yg = patch[p + PS] - patch[p - PS];
     const float g = sqrtf(xg * xg + yg * yg);
     const float ori = atan2lut(atanLut, yg, xg);
-    const float val = (float)(0.0 + (1.0 * (double)smask[p]) * (double)g);
+    const float val = (float)(0.0 + (1.0 * (double)mask[p]) * (double)g);
     const float o = (float)((double)8.0f * ((double)ori + TWO_PI) / TWO_PI);
-    int bo0 = (int)o;
-    swo1[p] = o - (float)bo0;
-    sbo0[p] = (unsigned char)(bo0 % 8);
-    sval[p] = val;
+    const int bo0 = (int)o;
+    const int q = r * PSP + c;
+    bufC[q] = o - (float)bo0;                      // wo1
+    sbo0[q] = (unsigned char)(bo0 % 8);
+    bufA[q] = (float)(swc0[c] * (double)val);      // wc0
+    bufB[q] = (float)(swc1[c] * (double)val);      // wc1
   }
-  if (tid < 128) vec[tid] = 0.0;
   __syncthreads();
-  // -- samplePatch: thread = one of the 128 bins, gathers its pixels in raster order (f64 accumulator)
+  // -- samplePatch: bin t gathers its 16x16 pixel block in raster order
   {
     const int rb = tid >> 5, cb = (tid >> 3) & 3, ob = tid & 7;
-    const int binR = rb * 8, binC = cb * 8;  // bin0/bin1 tables hold spatialBin*8
     double acc = 0.0;
-    for (int r = sc.lo[rb]; r <= sc.hi[rb]; r++) {
-      const float wr0 = (float)sw0[r], wr1 = (float)sw1[r];
-      const bool r0m = sbin0[r] == binR, r1m = sbin1[r] == binR;
-      if (!r0m && !r1m) continue;
-      for (int c = sc.lo[cb]; c <= sc.hi[cb]; c++) {
-        const bool c0m = sbin0[c] == binC, c1m = sbin1[c] == binC;
-        if (!c0m && !c1m) continue;
-        const int p = r * PS + c;
-        const int bo0 = sbo0[p];
-        const int bo1 = (bo0 + 1) % 8;
-        if (bo0 != ob && bo1 != ob) continue;
-        const float val = sval[p];
-        const float wc0 = (float)(sw0[c] * (double)val);
-        const float wc1 = (float)(sw1[c] * (double)val);
-        const float wo1 = swo1[p];
-        const float wo0 = 1.0f - wo1;
-        const float wo = (bo0 == ob) ? wo0 : wo1;
-        float v;
-        if (r0m && c0m) { v = wr0 * wc0; if (v > 0) acc += (double)(v * wo); }
-        if (r0m && c1m) { v = wr0 * wc1; if (v > 0) acc += (double)(v * wo); }
-        if (r1m && c0m) { v = wr1 * wc0; if (v > 0) acc += (double)(v * wo); }
-        if (r1m && c1m) { v = wr1 * wc1; if (v > 0) acc += (double)(v * wo); }
+#pragma unroll 1
+    for (int rr = 0; rr < 16; rr++) {
+      const int r = 8 * rb + rr;
+      const float wr = rr < 8 ? swr1[r] : swr0[r];
+      const int q0 = r * PSP + 8 * cb;
+#pragma unroll
+      for (int seg = 0; seg < 4; seg++) {
+        const int q = q0 + 4 * seg;
+        const float4 wc = seg < 2 ? *reinterpret_cast<const float4 *>(bufB + q) : *reinterpret_cast<const float4 *>(bufA + q);
+        const float4 w1v = *reinterpret_cast<const float4 *>(bufC + q);
+        const unsigned bo = *reinterpret_cast<const unsigned *>(sbo0 + q);
+        const float wcs[4] = {wc.x, wc.y, wc.z, wc.w};
+        const float wos[4] = {w1v.x, w1v.y, w1v.z, w1v.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int b0 = (bo >> (8 * e)) & 0xff;
+          const int b1 = (b0 + 1) & 7;
+          const float wo1 = wos[e];
+          const float wo0 = 1.0f - wo1;
+          const float v = wr * wcs[e];
+          if (v > 0) {
+            if (b0 == ob) acc += (double)(v * wo0);
+            else if (b1 == ob) acc += (double)(v * wo1);
+          }
+        }
       }
     }
     vec[tid] = acc;
   }
   __syncthreads();
-  // -- normalize / clip / renormalize / (RootSIFT) / quantise -- sequential f64 sums on one lane
-  __shared__ double sfac;
-  __shared__ int schanged;
+  // -- normalize / clip / renormalize (siftdesc.cpp:136-158, 199-221, 247-262)
   for (int pass = 0; pass < 2; pass++) {
+    if (tid < 32) {
+      const double s0 = vec[4 * tid] * vec[4 * tid], s1 = vec[4 * tid + 1] * vec[4 * tid + 1],
+                   s2 = vec[4 * tid + 2] * vec[4 * tid + 2], s3 = vec[4 * tid + 3] * vec[4 * tid + 3];
+      part[tid] = s0 + s1 + s2 + s3;
+    }
+    __syncthreads();
     if (tid == 0) {
       double len = 0.0;
-      for (int i = 0; i < 128; i += 4) {
-        const double s0 = vec[i] * vec[i], s1 = vec[i + 1] * vec[i + 1], s2 = vec[i + 2] * vec[i + 2],
-                     s3 = vec[i + 3] * vec[i + 3];
-        len += s0 + s1 + s2 + s3;
-      }
+#pragma unroll
+      for (int i = 0; i < 32; i++) len += part[i];
       len = sqrt(len);
       sfac = 1.0 / len;
       schanged = 0;
@@ -269,6 +315,7 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
   if (rootsift) {
     if (tid == 0) {
       double sum = 0.;
+#pragma unroll 16
       for (int i = 0; i < 128; i++) sum += fabs(vec[i]);
       sfac = sum;
     }
@@ -297,16 +344,12 @@ void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix
   hipLaunchKernelGGL(k_patch_blur, dim3(nTiles), dim3(256), 0, s, jobs, tilePrefix, nJobs, taps, src, dst, pass);
 }
 void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *imgs, const float *scratch,
-                     const float *mask, const double *atanLut, const int *bins, const double *wts, int photoNorm,
-                     int rootsift, double maxBin, float *descF, uint8_t *descU8) {
+                     const float *mask, const unsigned short *maskIdx, int nmask, const double *atanLut, const int *bins,
+                     const double *wts, int photoNorm, int rootsift, double maxBin, float *descF, uint8_t *descU8) {
   if (n <= 0) return;
-  // spatial bin k receives pixels i with bin0[i]/8 == k or bin1[i]/8 == k; with step 5/40 that is the
-  // contiguous range [8k-?, 8k+15]; computed by the host from the same tables (engine.cpp) -> here the
-  // ranges are conservative supersets: rows whose bins do not match are skipped inside the kernel.
   SiftConst sc;
-  for (int k = 0; k < 4; k++) { sc.lo[k] = 8 * k - 8 < 0 ? 0 : 8 * k - 8; sc.hi[k] = 8 * k + 16 > 40 ? 40 : 8 * k + 16; }
-  sc.hi[3] = 40;
-  hipLaunchKernelGGL(k_describe, dim3(n), dim3(128), 0, s, jobs, n, imgs, scratch, mask, atanLut, bins, wts, sc,
+  sc.nmask = nmask;
+  hipLaunchKernelGGL(k_describe, dim3(n), dim3(128), 0, s, jobs, n, imgs, scratch, mask, maskIdx, atanLut, bins, wts, sc,
                      photoNorm, rootsift, maxBin, descF, descU8);
 }
 
