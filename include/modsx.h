@@ -219,6 +219,14 @@ int modsx_match_pair(modsx_ctx *ctx, const modsx_image *img1, const modsx_image 
                      const modsx_pair_params *par, modsx_pair_result *res);
 void modsx_pair_result_release(modsx_pair_result *res);
 
+/* A batch of independent pairs, pipelined over n_ctx contexts (one host thread + one HIP stream each), the
+ * counterpart of the reference's OpenMP parallelism over images / views (mods.cpp:255-271,
+ * imagerepresentation.cpp:612-622): host-side bookkeeping of one pair overlaps device work of another.
+ * All contexts must live on the device that holds the images.  Returns n_pairs. */
+int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *const *imgs1,
+                      const modsx_image *const *imgs2, int n_pairs, const modsx_pair_params *par,
+                      modsx_pair_result *results);
+
 /* per-stage time of the last modsx_match_pair in ms: detect, orient, describe, match, verify, total */
 int modsx_last_timings(modsx_ctx *ctx, double *ms6);
 

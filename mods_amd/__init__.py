@@ -60,7 +60,7 @@ EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "m
            "modsx_detect_scalespace", "modsx_octave_levels", "modsx_gaussian_blur", "modsx_resize_half",
            "modsx_detect_affine_regions", "modsx_detect_orientation", "modsx_reproject_regions",
            "modsx_describe_regions", "modsx_match_fginn", "modsx_duplicate_filtering", "modsx_ransac_h",
-           "modsx_loransac_h", "modsx_match_pair", "modsx_pair_result_release", "modsx_last_timings", "modsx_profile",
+           "modsx_loransac_h", "modsx_match_pair", "modsx_match_pairs", "modsx_pair_result_release", "modsx_last_timings", "modsx_profile",
            "modsx_kernel_stats"]
 
 KERNEL_CLASSES = ["blur_hess", "hessian", "resize", "nms_localize", "baumberg", "orientation", "patch_sample",
@@ -326,6 +326,37 @@ class Context(object):
         res = PairResult()
         _check(lib().modsx_match_pair(self._c(), C.c_void_p(img1.h), C.c_void_p(img2.h), C.byref(params),
                                       C.byref(res)), "match_pair")
+        return _unpack_pair_result(res)
+
+    def last_timings(self):
+        t = (C.c_double * 6)()
+        _check(lib().modsx_last_timings(self._c(), t), "last_timings")
+        return dict(zip(["detect", "orient", "describe", "match", "verify", "total"], list(t)))
+
+    def profile(self, enable=True):
+        _check(lib().modsx_profile(self._c(), int(enable)), "profile")
+
+    def kernel_stats(self):
+        n = len(KERNEL_CLASSES)
+        ms, work = (C.c_double * n)(), (C.c_double * n)()
+        launches = (C.c_long * n)()
+        _check(lib().modsx_kernel_stats(self._c(), ms, work, launches, n), "kernel_stats")
+        return {k: dict(ms=ms[i], work=work[i], launches=launches[i]) for i, k in enumerate(KERNEL_CLASSES)}
+
+
+def match_pairs(ctxs, imgs1, imgs2, params):
+    """modsx_match_pairs: a batch of pairs pipelined over several contexts (threads + streams)."""
+    n = len(imgs1)
+    carr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    a1 = (C.c_void_p * n)(*[im.h for im in imgs1])
+    a2 = (C.c_void_p * n)(*[im.h for im in imgs2])
+    res = (PairResult * n)()
+    _check(lib().modsx_match_pairs(carr, len(ctxs), a1, a2, n, C.byref(params), res), "match_pairs")
+    return [_unpack_pair_result(res[i]) for i in range(n)]
+
+
+def _unpack_pair_result(res):
+    if True:
         T = res.n_unique
         out = dict(n_regions=(res.n_regions1, res.n_regions2), n_tentatives=res.n_tentatives, n_unique=T,
                    n_ransac_inliers=res.n_ransac_inliers, n_verified=res.n_verified,
@@ -342,18 +373,3 @@ class Context(object):
             out["verified"] = np.zeros(0, bool)
         lib().modsx_pair_result_release(C.byref(res))
         return out
-
-    def profile(self, enable=True):
-        _check(lib().modsx_profile(self._c(), int(enable)), "profile")
-
-    def kernel_stats(self):
-        n = len(KERNEL_CLASSES)
-        ms, work = (C.c_double * n)(), (C.c_double * n)()
-        launches = (C.c_long * n)()
-        _check(lib().modsx_kernel_stats(self._c(), ms, work, launches, n), "kernel_stats")
-        return {k: dict(ms=ms[i], work=work[i], launches=launches[i]) for i, k in enumerate(KERNEL_CLASSES)}
-
-    def last_timings(self):
-        t = (C.c_double * 6)()
-        _check(lib().modsx_last_timings(self._c(), t), "last_timings")
-        return dict(zip(["detect", "orient", "describe", "match", "verify", "total"], list(t)))

@@ -1,5 +1,8 @@
 // capi.hip -- the extern "C" boundary declared in include/modsx.h.
 #include <math.h>
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include "engine_api.hpp"
 
 using namespace mx;
@@ -269,6 +272,38 @@ int modsx_match_pair(modsx_ctx *ctx, const modsx_image *img1, const modsx_image 
   NEED(ctx); NEED(img1); NEED(img2); NEED(par); NEED(res);
   hipSetDevice(ctx->dev);
   return match_pair(ctx, img1, img2, *par, res);
+}
+
+int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *const *imgs1,
+                      const modsx_image *const *imgs2, int n_pairs, const modsx_pair_params *par,
+                      modsx_pair_result *results) {
+  NEED(ctxs); NEED(par); NEED(results);
+  if (n_ctx <= 0 || n_pairs < 0 || (n_pairs > 0 && (!imgs1 || !imgs2))) { mx::set_error("modsx_match_pairs: bad argument"); return MODSX_ERR_ARG; }
+  for (int i = 0; i < n_ctx; i++) NEED(ctxs[i]);
+  std::atomic<int> next(0), failed(0);
+  std::string firstErr;
+  std::mutex *mu = new std::mutex();
+  auto worker = [&](int w) {
+    modsx_ctx *c = ctxs[w];
+    hipSetDevice(c->dev);
+    for (;;) {
+      int i = next.fetch_add(1);
+      if (i >= n_pairs) break;
+      int rc = match_pair(c, imgs1[i], imgs2[i], *par, &results[i]);
+      if (rc) {
+        std::lock_guard<std::mutex> g(*mu);
+        if (!failed.exchange(rc)) firstErr = mx::last_error();
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  const int nw = n_ctx < n_pairs ? n_ctx : n_pairs;
+  for (int w = 1; w < nw; w++) th.emplace_back(worker, w);
+  if (nw > 0) worker(0);
+  for (auto &t : th) t.join();
+  delete mu;
+  if (failed.load()) { mx::set_error(firstErr); return failed.load(); }
+  return n_pairs;
 }
 
 void modsx_pair_result_release(modsx_pair_result *res) {

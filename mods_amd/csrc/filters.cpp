@@ -22,19 +22,71 @@ int duplicate_filtering(const double *pts, const double *key, int T, double r, i
   }
   if (do_sort) std::sort(v.begin(), v.end(), [](E a, E b) { return fabs(a.key) < fabs(b.key); });
   const double r_sq = r * r;
-  std::vector<char> uniq(T, 1);
+  // Same greedy pass as the reference's O(T^2) double loop (matching.cpp:3017-3036), with a uniform grid
+  // over the image-1 coordinates so that only tentatives within +-1 cell (cell = r) of i are visited;
+  // the visiting order inside the j-loop is irrelevant to the result (j is only ever flagged, and a j is
+  // flagged by the first unflagged i < j that is within r in both images -- the flag itself is all that
+  // later iterations observe).
+  std::vector<double> P((size_t)T * 4);
+  double minx = 0, miny = 0;
+  bool finite = true;
   for (int i = 0; i < T; i++) {
-    if (!uniq[i]) continue;
-    const double *p1 = pts + 4 * v[i].i;
-    for (int j = i + 1; j < T; j++) {
-      if (!uniq[j]) continue;
-      const double *p2 = pts + 4 * v[j].i;
-      double dx = p1[0] - p2[0], dy = p1[1] - p2[1];
-      double d1 = dx * dx + dy * dy;
-      if (d1 > r_sq) continue;
-      dx = p1[2] - p2[2]; dy = p1[3] - p2[3];
-      double d2 = dx * dx + dy * dy;
-      if (d2 <= r_sq) uniq[j] = 0;
+    const double *p = pts + 4 * v[i].i;
+    for (int q = 0; q < 4; q++) { P[4 * (size_t)i + q] = p[q]; finite = finite && std::isfinite(p[q]); }
+    if (i == 0 || p[0] < minx) minx = p[0];
+    if (i == 0 || p[1] < miny) miny = p[1];
+  }
+  std::vector<char> uniq(T, 1);
+  double maxx = minx, maxy = miny;
+  for (int i = 0; i < T; i++) { maxx = std::max(maxx, P[4 * (size_t)i]); maxy = std::max(maxy, P[4 * (size_t)i + 1]); }
+  // cell edge >= r (so +-1 cell covers the radius); coarser cells keep the grid small
+  const double cell_sz = std::max(r, std::max(maxx - minx, maxy - miny) / 96.0);
+  const double gw = (maxx - minx) / cell_sz, gh = (maxy - miny) / cell_sz;
+  if (!finite || T < 64 || gw > 8192 || gh > 8192) {
+    for (int i = 0; i < T; i++) {
+      if (!uniq[i]) continue;
+      const double *p1 = &P[4 * (size_t)i];
+      for (int j = i + 1; j < T; j++) {
+        if (!uniq[j]) continue;
+        const double *p2 = &P[4 * (size_t)j];
+        double dx = p1[0] - p2[0], dy = p1[1] - p2[1];
+        double d1 = dx * dx + dy * dy;
+        if (d1 > r_sq) continue;
+        dx = p1[2] - p2[2]; dy = p1[3] - p2[3];
+        double d2 = dx * dx + dy * dy;
+        if (d2 <= r_sq) uniq[j] = 0;
+      }
+    }
+  } else {
+    const int GW = (int)gw + 2, GH = (int)gh + 2;
+    std::vector<int> cellOf(T), start((size_t)GW * GH + 1, 0), items(T);
+    for (int i = 0; i < T; i++) {
+      int cx = (int)((P[4 * (size_t)i] - minx) / cell_sz), cy = (int)((P[4 * (size_t)i + 1] - miny) / cell_sz);
+      cellOf[i] = cy * GW + cx;
+      start[cellOf[i] + 1]++;
+    }
+    for (size_t q = 1; q < start.size(); q++) start[q] += start[q - 1];
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    for (int i = 0; i < T; i++) items[fill[cellOf[i]]++] = i;  // ascending i inside each cell
+    for (int i = 0; i < T; i++) {
+      if (!uniq[i]) continue;
+      const double *p1 = &P[4 * (size_t)i];
+      const int cx = cellOf[i] % GW, cy = cellOf[i] / GW;
+      for (int yy = std::max(0, cy - 1); yy <= std::min(GH - 1, cy + 1); yy++)
+        for (int xx = std::max(0, cx - 1); xx <= std::min(GW - 1, cx + 1); xx++) {
+          const int cell = yy * GW + xx;
+          for (int q = start[cell]; q < start[cell + 1]; q++) {
+            const int j = items[q];
+            if (j <= i || !uniq[j]) continue;
+            const double *p2 = &P[4 * (size_t)j];
+            double dx = p1[0] - p2[0], dy = p1[1] - p2[1];
+            double d1 = dx * dx + dy * dy;
+            if (d1 > r_sq) continue;
+            dx = p1[2] - p2[2]; dy = p1[3] - p2[3];
+            double d2 = dx * dx + dy * dy;
+            if (d2 <= r_sq) uniq[j] = 0;
+          }
+        }
     }
   }
   int kept = 0;

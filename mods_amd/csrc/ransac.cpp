@@ -223,16 +223,20 @@ static void lin_hgN(const double *u, double *p, const int *inl, int len, const d
   }
 }
 
-// cov_mat, utools.c:170-183
+// cov_mat, utools.c:170-183: Cv[i][j] = sum_k Z[k][i] * Z[k][j].  The row loop is hoisted outside so the 45
+// running sums advance together; each individual sum still adds its terms in row order k = 0, 1, ...
 static void cov_mat(double *Cv, const double *Z, int len, int siz) {
-  const int lenM = len * siz;
-  for (int i = 0; i < siz; i++)
-    for (int j = 0; j <= i; j++) {
-      double val = 0;
-      for (int k = 0; k < lenM; k += siz) val += Z[k + i] * Z[k + j];
-      Cv[siz * i + j] = val;
-      Cv[i + siz * j] = val;
+  double acc[9][9];
+  for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) acc[i][j] = 0;
+  for (int k = 0; k < len; k++) {
+    const double *z = Z + (size_t)k * siz;
+    for (int i = 0; i < siz; i++) {
+      const double zi = z[i];
+      for (int j = 0; j <= i; j++) acc[i][j] += zi * z[j];
     }
+  }
+  for (int i = 0; i < siz; i++)
+    for (int j = 0; j <= i; j++) { Cv[siz * i + j] = acc[i][j]; Cv[i + siz * j] = acc[i][j]; }
 }
 
 // eigenvector of the smallest eigenvalue of a symmetric 9x9 (stands in for lap_eig = dsyev_, whose
@@ -318,12 +322,13 @@ static void u2h(const double *u, const int *inl, int len, double *H, double *buf
 }
 
 // pinvJ + HDs (Sampson error), Htools.c:132-196
+// `lin` is the same linearisation as lin_hg() but stored row-major (18 doubles per point: the 9 entries of
+// row 2i, then of row 2i+1) -- identical products in identical order, contiguous in memory.
 static void HDs(const double *lin, const double *u, const double *H, double *p, int len) {
-  const int shift = 2 * len;
   for (int i = 0; i < len; i++) {
     double r1 = 0, r2 = 0;
-    const double *l = lin + 2 * i;
-    for (int j = 0; j < 9; j++) { r1 += H[j] * *l; r2 += H[j] * l[1]; l += shift; }
+    const double *l = lin + (size_t)18 * i;
+    for (int j = 0; j < 9; j++) { r1 += H[j] * l[j]; r2 += H[j] * l[9 + j]; }
     double a = H[0] - H[2] * u[0];
     double b = H[3] - H[5] * u[0];
     double c = -H[8] - H[2] * u[3] - H[5] * u[4];
@@ -418,7 +423,7 @@ static int all_hori_valid(const double *us, const int *idx) {
 struct Ransac {
   const double *u;
   int len;
-  std::vector<double> Z, buffer, err;
+  std::vector<double> Z, Zrow, buffer, err;
   double *errs[5];
   HashTable ht;
   GlibcRandom rng;
@@ -445,7 +450,7 @@ struct Ransac {
     memcpy(h, H, sizeof h);  // defined start value; overwritten below since S.I >= 4
     u2h(u, inliers, S.I, h, buffer.data());
     for (int it = 0; it < steps; it++) {
-      HDs(Z.data(), u, h, d, len);
+      HDs(Zrow.data(), u, h, d, len);
       Ss = inlidxs(d, len, th, inliers);
       uint32_t hash = super_fast_hash((const char *)inliers, (int)(Ss.I * sizeof(int)));
       int ret = ht.contains(hash, (int)Ss.I, iterID);
@@ -461,7 +466,7 @@ struct Ransac {
       u2h(u, inliers, S.I, h, buffer.data());
       ths -= dth;
     }
-    HDs(Z.data(), u, h, d, len);
+    HDs(Zrow.data(), u, h, d, len);
     S = inlidxs(d, len, th, inliers);
     if (score_less(maxS, S)) {
       maxS = S;
@@ -484,7 +489,7 @@ struct Ransac {
     for (int i = 0; i < rep; i++) {
       int *sample = randsubset(inliers, ninl, ssiz);
       u2h(u, sample, ssiz, h, buffer.data());
-      HDs(Z.data(), u, h, errs[0], len);
+      HDs(Zrow.data(), u, h, errs[0], len);
       errs[4] = errs[0];
       S = iterH(intbuff.data(), th, 4 * th, 4, h, ++*iterID);
       if (score_less(maxS, S)) {
@@ -516,6 +521,12 @@ int ransac_h(const double *u, int len, double th, double conf, int max_sam, doub
   for (int i = 0; i < len; i++) pool[i] = i;
   R.Z.resize((size_t)len * 18);
   lin_hg(u, R.Z.data(), pool.data(), len);
+  R.Zrow.resize((size_t)len * 18);
+  for (int i = 0; i < len; i++)
+    for (int c = 0; c < 9; c++) {
+      R.Zrow[(size_t)18 * i + c] = R.Z[(size_t)c * 2 * len + 2 * i];
+      R.Zrow[(size_t)18 * i + 9 + c] = R.Z[(size_t)c * 2 * len + 2 * i + 1];
+    }
   R.buffer.resize((size_t)len * 18);
   R.err.assign((size_t)len * 4, 0.0);
   std::vector<double> d_check(len);
@@ -552,7 +563,7 @@ int ransac_h(const double *u, int len, double th, double conf, int max_sam, doub
     d = R.errs[0];
     S = inlidxs(R.errs[4], len, 4 * th * 2, inliers.data());
     u2h(u, inliers.data(), S.I, h, R.buffer.data());
-    HDs(R.Z.data(), u, h, d, len);
+    HDs(R.Zrow.data(), u, h, d, len);
     S = inlidxs(d, len, th, inliers.data());
     S = R.inHrani(inliers.data(), (int)S.I, th, h, 10, &iterID);
   };
@@ -582,7 +593,7 @@ int ransac_h(const double *u, int len, double th, double conf, int max_sam, doub
     double tol = tol_of(h);
     if (fabs(v / tol) < 10e-2) continue;
     d = R.errs[0];
-    HDs(R.Z.data(), u, h, d, len);
+    HDs(R.Zrow.data(), u, h, d, len);
     S = score_of(d);
     int do_iterate;
     if (score_less(maxS, S)) {
