@@ -119,6 +119,12 @@ typedef struct modsx_pair_result {
   unsigned char *verified;
 } modsx_pair_result;
 
+/* == struct ViewSynthParameters (the geometric part), detectors/structures.hpp:201-214 */
+typedef struct modsx_view {
+  double zoom, tilt, phi, InitSigma;
+  int doBlur;
+} modsx_view;
+
 typedef struct modsx_ctx modsx_ctx;
 typedef struct modsx_image modsx_image;
 
@@ -230,11 +236,48 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
 /* per-stage time of the last modsx_match_pair in ms: detect, orient, describe, match, verify, total */
 int modsx_last_timings(modsx_ctx *ctx, double *ms6);
 
+/* int SetVSPars(scale_set, tilt_set, phi_base, FGINNThreshold, DistanceThreshold, descriptors, par, prev_par,
+ *               InitSigma, doBlur, dsplevels, minSigma, maxSigma)            synth-detection.cpp:103-234
+ * The view ladder of one step, de-duplicated against the views of earlier steps (prev[0..*nprev) is extended).
+ * Returns the number of new views (host only). */
+int modsx_set_vs_pars(const double *scale_set, int ns, const double *tilt_set, int nt, double phi_base,
+                      double InitSigma, int doBlur, modsx_view *par, int cap, modsx_view *prev, int *nprev,
+                      int cap_prev);
+
+/* void GenerateSynthImageCorr(const cv::Mat &in_img, SynthImage &out_img, name, tilt, phi, zoom, InitSigma,
+ *                             doBlur, img_id, convert2gray)                    synth-detection.cpp:236-430
+ * gray: an uploaded image (gray conversion already applied).  Returns a new image handle (modsx_image_free),
+ * H9 = SynthImage::H (original -> view); *is_identity = 1 when the reference takes its "original image"
+ * short-cut (the handle then aliases `gray`). */
+modsx_image *modsx_synth_view(modsx_ctx *ctx, const modsx_image *gray, const modsx_view *view, double *H9,
+                              int *is_identity);
+
+/* The HessianAffine / SIFT-family branch of ImageRepresentation::SynthDetectDescribeKeypoints
+ * (imagerepresentation.cpp:603-2047) for the views view_begin, view_begin+view_step, ...: synthesise, detect,
+ * orient, reproject to the original frame, describe.  regs: malloc'd, in view order, ids re-based as
+ * AddRegions does (:588-600, :2044-2045) when the call covers all views (view_step == 1), otherwise local to
+ * each view block (img_id = view index) so that shards can be merged.  desc (optional): malloc'd [n][128] f32.
+ * dev_desc_u8 (optional): device buffer of capacity dev_cap regions that receives the [n][128] u8 descriptors
+ * (what the matcher consumes) without leaving HBM. */
+int modsx_detect_describe_views(modsx_ctx *ctx, const modsx_image *img, const modsx_view *views, int nviews,
+                                const modsx_pair_params *par, int view_begin, int view_step, modsx_region **regs,
+                                float **desc, void *dev_desc_u8, long dev_cap);
+
+/* MatchFlannFGINN on u8 descriptors that already live in HBM (e.g. after an all-gather over xGMI) */
+int modsx_match_fginn_device(modsx_ctx *ctx, const void *dev_desc1_u8, int n1, const void *dev_desc2_u8, int n2,
+                             const double *pos2, double ratio, double contradDist, int nn, modsx_tentative **out);
+
+/* One step of mods.cpp:229-415 with a ladder of synthesised views per image (same views for both images,
+ * as in iters_mods_cviu.ini). */
+int modsx_match_pair_views(modsx_ctx *ctx, const modsx_image *img1, const modsx_image *img2,
+                           const modsx_view *views, int nviews, const modsx_pair_params *par,
+                           modsx_pair_result *res);
+
 /* Measurement hooks (no reference counterpart; the reference only keeps wall-clock TimeLog, structures.hpp:51-74).
  * modsx_profile(ctx, 1) brackets every kernel launch with HIP events on the ctx stream and accumulates, per kernel
  * class, GPU milliseconds, launch count and algorithmic work (bytes; flops for the matcher).  Classes in order:
  * blur_hess, hessian, resize, nms_localize, baumberg, orientation, patch_sample, patch_blur, describe, match_fginn,
- * gray.  modsx_kernel_stats returns the number of classes. */
+ * gray, warp_affine, view_blur.  modsx_kernel_stats returns the number of classes. */
 int modsx_profile(modsx_ctx *ctx, int enable);
 int modsx_kernel_stats(modsx_ctx *ctx, double *ms, double *work, long *launches, int n);
 

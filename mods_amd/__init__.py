@@ -47,6 +47,24 @@ class PairParams(C.Structure):
                 ("ransac_seed", C.c_uint)]
 
 
+class View(C.Structure):
+    _fields_ = [("zoom", C.c_double), ("tilt", C.c_double), ("phi", C.c_double), ("InitSigma", C.c_double),
+                ("doBlur", C.c_int)]
+
+
+def make_view(tilt=1.0, phi=0.0, zoom=1.0, init_sigma=0.5, do_blur=1):
+    v = View()
+    v.zoom, v.tilt, v.phi, v.InitSigma, v.doBlur = zoom, tilt, phi, init_sigma, do_blur
+    return v
+
+
+def _view_array(views):
+    arr = (View * len(views))()
+    for i, v in enumerate(views):
+        arr[i].zoom, arr[i].tilt, arr[i].phi, arr[i].InitSigma, arr[i].doBlur = v.zoom, v.tilt, v.phi, v.InitSigma, v.doBlur
+    return arr
+
+
 class PairResult(C.Structure):
     _fields_ = [("n_regions1", C.c_int), ("n_regions2", C.c_int), ("n_tentatives", C.c_int), ("n_unique", C.c_int),
                 ("n_ransac_inliers", C.c_int), ("n_verified", C.c_int), ("ransac_samples", C.c_int),
@@ -60,11 +78,13 @@ EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "m
            "modsx_detect_scalespace", "modsx_octave_levels", "modsx_gaussian_blur", "modsx_resize_half",
            "modsx_detect_affine_regions", "modsx_detect_orientation", "modsx_reproject_regions",
            "modsx_describe_regions", "modsx_match_fginn", "modsx_duplicate_filtering", "modsx_ransac_h",
-           "modsx_loransac_h", "modsx_match_pair", "modsx_match_pairs", "modsx_pair_result_release", "modsx_last_timings", "modsx_profile",
+           "modsx_loransac_h", "modsx_match_pair", "modsx_match_pairs", "modsx_pair_result_release",
+           "modsx_set_vs_pars", "modsx_synth_view", "modsx_detect_describe_views", "modsx_match_fginn_device",
+           "modsx_match_pair_views", "modsx_last_timings", "modsx_profile",
            "modsx_kernel_stats"]
 
 KERNEL_CLASSES = ["blur_hess", "hessian", "resize", "nms_localize", "baumberg", "orientation", "patch_sample",
-                  "patch_blur", "describe", "match_fginn", "gray"]
+                  "patch_blur", "describe", "match_fginn", "gray", "warp_affine", "view_blur"]
 
 
 def build(force=False):
@@ -97,6 +117,8 @@ def lib():
         L.modsx_image_wrap_device.restype = C.c_void_p
         L.modsx_image_wrap_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.modsx_image_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.modsx_synth_view.restype = C.c_void_p
+        L.modsx_synth_view.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -201,6 +223,23 @@ def loransac_h(pts, laf1, laf2, err_threshold=3.0, confidence=0.99, max_samples=
                "loransac_h")
     return dict(n=n, H=H.reshape(3, 3), Hraw=Hraw, inl=inl[:T].astype(bool), keep=keep[:T].astype(bool),
                 samples=int(dout[0]), lo_count=int(dout[1]), ori_rejects=int(dout[2]))
+
+
+def set_vs_pars(scale_set, tilt_set, phi_base, init_sigma=0.5, do_blur=1, prev=None):
+    """SetVSPars (host): returns the new views of this step; `prev` (list of View) is extended in place."""
+    prev = [] if prev is None else prev
+    ss = np.ascontiguousarray(scale_set, np.float64)
+    ts = np.ascontiguousarray(tilt_set, np.float64)
+    cap = 4096
+    par = (View * cap)()
+    pv = (View * cap)(*prev)
+    npv = C.c_int(len(prev))
+    n = _check(lib().modsx_set_vs_pars(_p(ss), len(ss), _p(ts), len(ts), C.c_double(phi_base), C.c_double(init_sigma),
+                                       int(do_blur), par, cap, pv, C.byref(npv), cap), "set_vs_pars")
+    del prev[:]
+    for i in range(npv.value):
+        prev.append(make_view(pv[i].tilt, pv[i].phi, pv[i].zoom, pv[i].InitSigma, pv[i].doBlur))
+    return [make_view(par[i].tilt, par[i].phi, par[i].zoom, par[i].InitSigma, par[i].doBlur) for i in range(n)]
 
 
 # ---- device path -------------------------------------------------------------------------------
@@ -322,6 +361,51 @@ class Context(object):
                                            C.c_double(contrad_dist), nn, C.byref(out)), "match_fginn")
         return _take(out, n, TENT)
 
+    def synth_view(self, img, view):
+        H = np.zeros(9)
+        ident = C.c_int(0)
+        h = lib().modsx_synth_view(self._c(), C.c_void_p(img.h), C.byref(view), _p(H), C.byref(ident))
+        if not h:
+            raise RuntimeError("modsx_synth_view failed: " + _err())
+        rows, cols = C.c_int(), C.c_int()
+        out = Image(self, h, 0, 0)
+        # query the size through the resize tap (cheap): rows/cols live in the handle; read them via download size
+        out.rows, out.cols = _image_dims(h)
+        return out, H.reshape(3, 3), bool(ident.value)
+
+    def detect_describe_views(self, img, views, params, view_begin=0, view_step=1, want_desc=True, dev_desc=None,
+                              dev_cap=0):
+        arr = _view_array(views)
+        regs = C.c_void_p()
+        desc = C.c_void_p()
+        n = _check(lib().modsx_detect_describe_views(self._c(), C.c_void_p(img.h), arr, len(views), C.byref(params),
+                                                     int(view_begin), int(view_step), C.byref(regs),
+                                                     C.byref(desc) if want_desc else None,
+                                                     C.c_void_p(dev_desc) if dev_desc else None, C.c_long(dev_cap)),
+                   "detect_describe_views")
+        r = _take(regs, n, REGION)
+        d = None
+        if want_desc:
+            d = _take(desc, n * 128, np.dtype("f4")).reshape(n, 128) if n else np.zeros((0, 128), np.float32)
+            if n == 0 and desc:
+                pass
+        return r, d
+
+    def match_fginn_device(self, d1_ptr, n1, d2_ptr, n2, pos2, ratio=0.8, contrad_dist=30.0, nn=50):
+        pos2 = np.ascontiguousarray(pos2, np.float64)
+        out = C.c_void_p()
+        n = _check(lib().modsx_match_fginn_device(self._c(), C.c_void_p(d1_ptr), int(n1), C.c_void_p(d2_ptr), int(n2),
+                                                  _p(pos2), C.c_double(ratio), C.c_double(contrad_dist), nn,
+                                                  C.byref(out)), "match_fginn_device")
+        return _take(out, n, TENT)
+
+    def match_pair_views(self, img1, img2, views, params):
+        arr = _view_array(views)
+        res = PairResult()
+        _check(lib().modsx_match_pair_views(self._c(), C.c_void_p(img1.h), C.c_void_p(img2.h), arr, len(views),
+                                            C.byref(params), C.byref(res)), "match_pair_views")
+        return _unpack_pair_result(res)
+
     def match_pair(self, img1, img2, params):
         res = PairResult()
         _check(lib().modsx_match_pair(self._c(), C.c_void_p(img1.h), C.c_void_p(img2.h), C.byref(params),
@@ -342,6 +426,15 @@ class Context(object):
         launches = (C.c_long * n)()
         _check(lib().modsx_kernel_stats(self._c(), ms, work, launches, n), "kernel_stats")
         return {k: dict(ms=ms[i], work=work[i], launches=launches[i]) for i, k in enumerate(KERNEL_CLASSES)}
+
+
+class _ImageStruct(C.Structure):   # mirrors struct modsx_image (engine.hpp) for reading rows/cols of a handle
+    _fields_ = [("d", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("owned", C.c_bool)]
+
+
+def _image_dims(handle):
+    st = _ImageStruct.from_address(handle)
+    return st.rows, st.cols
 
 
 def match_pairs(ctxs, imgs1, imgs2, params):

@@ -111,7 +111,7 @@ int modsx_detect_affine_keypoints(modsx_ctx *ctx, const modsx_image *img, const 
   hipSetDevice(ctx->dev);
   std::vector<modsx_keypoint> k[1];
   const modsx_image *imgs[1] = {img};
-  int rc = detect_keypoints_batch(ctx, imgs, 1, *par, tilt, zoom, k);
+  int rc = detect_keypoints_batch(ctx, imgs, 1, *par, &tilt, &zoom, k);
   if (rc) return rc;
   *out = to_malloc(k[0]);
   return (int)k[0].size();
@@ -227,7 +227,8 @@ int modsx_describe_regions(modsx_ctx *ctx, const modsx_image *img, const modsx_r
   v[0].assign(regs, regs + n);
   const modsx_image *imgs[1] = {img};
   float *hosts[1] = {desc};
-  int rc = describe_batch(ctx, imgs, 1, v, mrSize, patchSize, fast_extraction, photoNorm, desc_type, maxBinValue, hosts);
+  int rc = describe_batch(ctx, imgs, 1, v, mrSize, patchSize, fast_extraction, photoNorm, desc_type, maxBinValue, hosts,
+                          nullptr, nullptr);
   if (rc) return rc;
   return n;
 }
@@ -316,6 +317,89 @@ int modsx_last_timings(modsx_ctx *ctx, double *ms6) {
   NEED(ctx); NEED(ms6);
   for (int i = 0; i < 6; i++) ms6[i] = ctx->timings[i];
   return MODSX_OK;
+}
+
+int modsx_set_vs_pars(const double *scale_set, int ns, const double *tilt_set, int nt, double phi_base,
+                      double InitSigma, int doBlur, modsx_view *par, int cap, modsx_view *prev, int *nprev,
+                      int cap_prev) {
+  if (ns < 0 || nt < 0 || !par || !prev || !nprev || (ns > 0 && !scale_set) || (nt > 0 && !tilt_set)) {
+    mx::set_error("modsx_set_vs_pars: bad argument");
+    return MODSX_ERR_ARG;
+  }
+  return set_vs_pars(scale_set, ns, tilt_set, nt, phi_base, InitSigma, doBlur, par, cap, prev, nprev, cap_prev);
+}
+
+modsx_image *modsx_synth_view(modsx_ctx *ctx, const modsx_image *gray, const modsx_view *view, double *H9,
+                              int *is_identity) {
+  if (!ctx || !gray || !view || !H9 || !is_identity) { mx::set_error("modsx_synth_view: null argument"); return nullptr; }
+  hipSetDevice(ctx->dev);
+  modsx_image *out = nullptr;
+  if (synth_view(ctx, gray, *view, &out, H9, is_identity) != MODSX_OK) return nullptr;
+  return out;
+}
+
+int modsx_detect_describe_views(modsx_ctx *ctx, const modsx_image *img, const modsx_view *views, int nviews,
+                                const modsx_pair_params *par, int view_begin, int view_step, modsx_region **regs,
+                                float **desc, void *dev_desc_u8, long dev_cap) {
+  NEED(ctx); NEED(img); NEED(views); NEED(par); NEED(regs);
+  if (nviews <= 0 || view_begin < 0) { mx::set_error("modsx_detect_describe_views: bad argument"); return MODSX_ERR_ARG; }
+  hipSetDevice(ctx->dev);
+  std::vector<modsx_region> r;
+  size_t cap = dev_desc_u8 ? (size_t)dev_cap : ((size_t)1 << 16);
+  int rc;
+  for (;;) {
+    if (!ctx->descAllF[0].ensure(cap * 512)) return MODSX_ERR_NOMEM;
+    uint8_t *du8 = (uint8_t *)dev_desc_u8;
+    if (!du8) { if (!ctx->descAllU8[0].ensure(cap * 128)) return MODSX_ERR_NOMEM; du8 = (uint8_t *)ctx->descAllU8[0].p; }
+    rc = detect_describe_views(ctx, img, views, nviews, *par, view_begin, view_step, r, (float *)ctx->descAllF[0].p, du8,
+                               cap, nullptr);
+    if (rc == MODSX_ERR_NOMEM && !dev_desc_u8 && cap < ((size_t)1 << 24)) { cap *= 4; continue; }
+    break;
+  }
+  if (rc) return rc;
+  if (view_step <= 1 && view_begin == 0) {
+    size_t start = 0;
+    while (start < r.size()) {
+      size_t end = start;
+      while (end < r.size() && r[end].img_id == r[start].img_id) end++;
+      for (size_t i = start; i < end; i++) { r[i].id += (int)start; r[i].parent_id += (int)start; }
+      start = end;
+    }
+  }
+  if (desc) {
+    *desc = (float *)malloc(std::max<size_t>(1, r.size()) * 512);
+    if (!r.empty()) {
+      MX_HIP(hipMemcpyAsync(*desc, ctx->descAllF[0].p, r.size() * 512, hipMemcpyDeviceToHost, ctx->stream));
+      MX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+  }
+  *regs = to_malloc(r);
+  return (int)r.size();
+}
+
+int modsx_match_fginn_device(modsx_ctx *ctx, const void *dev_desc1_u8, int n1, const void *dev_desc2_u8, int n2,
+                             const double *pos2, double ratio, double contradDist, int nn, modsx_tentative **out) {
+  NEED(ctx); NEED(out);
+  if (n1 < 0 || n2 < 0 || (n1 > 0 && !dev_desc1_u8) || (n2 > 0 && (!dev_desc2_u8 || !pos2))) {
+    mx::set_error("modsx_match_fginn_device: bad argument");
+    return MODSX_ERR_ARG;
+  }
+  hipSetDevice(ctx->dev);
+  std::vector<modsx_tentative> t;
+  int rc = match_device(ctx, (const uint8_t *)dev_desc1_u8, n1, (const uint8_t *)dev_desc2_u8, n2, pos2, ratio,
+                        contradDist, nn, t);
+  if (rc) return rc;
+  *out = to_malloc(t);
+  return (int)t.size();
+}
+
+int modsx_match_pair_views(modsx_ctx *ctx, const modsx_image *img1, const modsx_image *img2,
+                           const modsx_view *views, int nviews, const modsx_pair_params *par,
+                           modsx_pair_result *res) {
+  NEED(ctx); NEED(img1); NEED(img2); NEED(views); NEED(par); NEED(res);
+  if (nviews <= 0) { mx::set_error("modsx_match_pair_views: nviews"); return MODSX_ERR_ARG; }
+  hipSetDevice(ctx->dev);
+  return match_pair_views(ctx, img1, img2, views, nviews, *par, res);
 }
 
 int modsx_profile(modsx_ctx *ctx, int enable) {

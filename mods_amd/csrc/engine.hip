@@ -58,6 +58,22 @@ struct ProfScope {
   }
   ~ProfScope() { if (on) hipEventRecord(c->prof.evB[slot], c->stream); }
 };
+void prof_begin(modsx_ctx *c, int cls, double work, size_t *slot) {
+  *slot = (size_t)-1;
+  Profiler &p = c->prof;
+  if (!p.enabled) return;
+  if (p.used == p.evA.size()) {
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    p.evA.push_back(a); p.evB.push_back(b); p.cls.push_back(0);
+  }
+  *slot = p.used++;
+  p.cls[*slot] = cls;
+  p.work[cls] += work;
+  p.launches[cls]++;
+  hipEventRecord(p.evA[*slot], c->stream);
+}
+void prof_end(modsx_ctx *c, size_t slot) { if (slot != (size_t)-1) hipEventRecord(c->prof.evB[slot], c->stream); }
 void prof_collect(modsx_ctx *c) {
   Profiler &p = c->prof;
   if (!p.enabled || !p.used) return;
@@ -148,9 +164,10 @@ void ctx_destroy(modsx_ctx *c) {
   hipStreamSynchronize(c->stream);
   for (int i = 0; i < MAXB; i++) c->pyr[i].store.release();
   DevBuf *bufs[] = {&c->cand, &c->counter, &c->affJobs, &c->affOut, &c->oriJobs, &c->oriOut, &c->descJobs, &c->tilePrefix,
-                    &c->taps, &c->imgRefs, &c->scratchA, &c->scratchB, &c->descF[0], &c->descF[1], &c->descU8[0],
-                    &c->descU8[1], &c->pos2, &c->matchRows, &c->misc};
+                    &c->taps, &c->imgRefs, &c->scratchA, &c->scratchB, &c->descAllF[0], &c->descAllF[1], &c->descAllU8[0],
+                    &c->descAllU8[1], &c->pos2, &c->matchRows, &c->misc, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps};
   for (DevBuf *b : bufs) b->release();
+  for (int i = 0; i < MAXB; i++) { c->descF[i].release(); c->descU8[i].release(); }
   PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc};
   for (PinBuf *b : pins) b->release();
   hipFree(c->dSmmMask); hipFree(c->dOriMask); hipFree(c->dSiftMask); hipFree(c->dSiftMaskIdx); hipFree(c->dAtan); hipFree(c->dSiftBins);
@@ -444,9 +461,8 @@ static void prepare_keys_for_export(std::vector<modsx_keypoint> &keys, const mod
 
 // DetectAffineKeypoints (scale-space-detector.cpp:43-85) for a batch of images
 int detect_keypoints_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const modsx_hessaff_params &par,
-                           double tilt, double zoom, std::vector<modsx_keypoint> *out) {
-  modsx_hessaff_params p = par;
-  if ((tilt > 2.0) || (zoom < 0.5)) p.reg_number = (int)floor(zoom * (double)p.reg_number / tilt);
+                           const double *tilts, const double *zooms, std::vector<modsx_keypoint> *out) {
+  modsx_hessaff_params p = par;  // reg_number is rescaled per image just before the export step (it only matters there)
   std::vector<modsx_sskp> ss[MAXB];
   int rc = detect_scalespace_batch(c, imgs, n, p, ss);
   if (rc) return rc;
@@ -493,7 +509,10 @@ int detect_keypoints_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, 
       kp.sub_type = q.type;
       out[i].push_back(kp);
     }
-    prepare_keys_for_export(out[i], p);
+    modsx_hessaff_params pe = p;
+    const double tilt = tilts ? tilts[i] : 1.0, zoom = zooms ? zooms[i] : 1.0;
+    if ((tilt > 2.0) || (zoom < 0.5)) pe.reg_number = (int)floor(zoom * (double)pe.reg_number / tilt);
+    prepare_keys_for_export(out[i], pe);
   }
   return MODSX_OK;
 }
@@ -635,17 +654,19 @@ int reproject_regions(modsx_region *regs, int n, const double *H, int orig_w, in
 // (c->descF[i], c->descU8[i]); descHost[i] (optional) receives the f32 copy.
 int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const std::vector<modsx_region> *regs,
                    double mrSize, int patchSize, int fast, int photoNorm, int descType, double maxBin,
-                   float *const *descHost) {
+                   float *const *descHost, float *const *devF, uint8_t *const *devU8) {
   if (patchSize != 41) { set_error("descriptor patchSize must be 41"); return MODSX_ERR_ARG; }
-  if (n > 2) { set_error("describe batch > 2 images"); return MODSX_ERR_ARG; }
+  if (n > MAXB) { set_error("describe batch too large"); return MODSX_ERR_ARG; }
   hipStream_t s = c->stream;
   int rc = upload_img_refs(c, imgs, n);
   if (rc) return rc;
   const size_t ARENA_FLOATS = (size_t)192 << 20;  // 768 MiB per arena per chunk
   for (int i = 0; i < n; i++) {
     const size_t nr = regs[i].size();
-    if (!c->descF[i].ensure(std::max<size_t>(1, nr) * 128 * 4) || !c->descU8[i].ensure(std::max<size_t>(1, nr) * 128))
-      return MODSX_ERR_NOMEM;
+    float *outF = devF ? devF[i] : nullptr;
+    uint8_t *outU8 = devU8 ? devU8[i] : nullptr;
+    if (!outF) { if (!c->descF[i].ensure(std::max<size_t>(1, nr) * 128 * 4)) return MODSX_ERR_NOMEM; outF = (float *)c->descF[i].p; }
+    if (!outU8) { if (!c->descU8[i].ensure(std::max<size_t>(1, nr) * 128)) return MODSX_ERR_NOMEM; outU8 = (uint8_t *)c->descU8[i].p; }
     size_t done = 0;
     while (done < nr) {
       std::vector<DescJob> jobs;
@@ -722,12 +743,12 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       launch_describe(s, dj, (int)nj, (ImgRef *)c->imgRefs.p, (float *)c->scratchA.p, c->dSiftMask, c->dSiftMaskIdx,
                       c->nSiftMask, c->dAtan,
                       c->dSiftBins, c->dSiftW, photoNorm, descType == MODSX_DESC_ROOT_SIFT, maxBin,
-                      (float *)c->descF[i].p + done * 128, (uint8_t *)c->descU8[i].p + done * 128);
+                      outF + done * 128, outU8 + done * 128);
       MX_HIP(hipStreamSynchronize(s));  // jobs/taps/prefix are host vectors reused by the next chunk
       done = r;
     }
     if (descHost && descHost[i] && nr) {
-      MX_HIP(hipMemcpyAsync(descHost[i], c->descF[i].p, nr * 128 * 4, hipMemcpyDeviceToHost, s));
+      MX_HIP(hipMemcpyAsync(descHost[i], outF, nr * 128 * 4, hipMemcpyDeviceToHost, s));
       MX_HIP(hipStreamSynchronize(s));
     }
   }
@@ -802,7 +823,7 @@ int match_pair(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, c
   const modsx_image *imgs[2] = {img1, img2};
   const double t0 = now_ms();
   std::vector<modsx_keypoint> kps[2];
-  int rc = detect_keypoints_batch(c, imgs, 2, pp.det, 1.0, 1.0, kps);
+  int rc = detect_keypoints_batch(c, imgs, 2, pp.det, nullptr, nullptr, kps);
   if (rc) return rc;
   std::vector<modsx_region> regs[2], oriented[2];
   for (int i = 0; i < 2; i++) {
@@ -820,7 +841,7 @@ int match_pair(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, c
   }
   const double t2 = now_ms();
   rc = describe_batch(c, imgs, 2, oriented, pp.desc_mrSize, pp.desc_patchSize, 0, pp.desc_photoNorm, pp.desc_type,
-                      pp.desc_maxBinValue, nullptr);
+                      pp.desc_maxBinValue, nullptr, nullptr, nullptr);
   if (rc) return rc;
   const double t3 = now_ms();
   res->n_regions1 = (int)oriented[0].size();

@@ -78,6 +78,16 @@ struct DescJob {
 };
 struct ImgRef { const float *d; int rows, cols, pad; };
 
+// view synthesis
+struct WarpJob {
+  const float *src;
+  float *dst;
+  int srows, scols, drows, dcols;
+  double M[6];   // inverse map (dst -> src), already inverted on the host in f64
+  float cval;
+  int pad;
+};
+
 // matching
 struct MatchRow {     // per-query result of the device matcher
   int t0, t1, tj, nless, nbad;
@@ -148,6 +158,8 @@ void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix
 void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *imgs, const float *scratch,
                      const float *mask, const unsigned short *maskIdx, int nmask, const double *atanLut, const int *bins,
                      const double *wts, int photoNorm, int rootsift, double maxBin, float *descF, uint8_t *descU8);
+void launch_warp_affine(hipStream_t s, const WarpJob &jb);
+void launch_blur_pass(hipStream_t s, const float *src, float *dst, int rows, int cols, const float *taps, int n, int pass);
 void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2,
                   double sqminratio, double contrDistSq, MatchRow *rows);
 
@@ -155,7 +167,7 @@ void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, i
 
 namespace mx {
 enum KClass { K_BLUR_HESS = 0, K_HESSIAN, K_RESIZE, K_NMS, K_BAUMBERG, K_ORIENT, K_PATCH_SAMPLE, K_PATCH_BLUR, K_DESCRIBE,
-              K_MATCH, K_GRAY, K_NCLASS };
+              K_MATCH, K_GRAY, K_WARP, K_VIEW_BLUR, K_NCLASS };
 struct Profiler {
   bool enabled = false;
   std::vector<hipEvent_t> evA, evB;
@@ -178,7 +190,7 @@ struct modsx_ctx {
   hipStream_t stream;
   mx::Pyramid pyr[mx::MAXB];
   mx::DevBuf cand, counter, affJobs, affOut, oriJobs, oriOut, descJobs, tilePrefix, taps, imgRefs, scratchA, scratchB,
-      descF[2], descU8[2], pos2, matchRows, misc;
+      descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], pos2, matchRows, misc, viewTmp[2], viewTaps;
   mx::PinBuf hCand, hAff, hOri, hDesc, hMisc;
   // constant tables on device
   float *dSmmMask = nullptr;   // 19x19 computeGaussMask

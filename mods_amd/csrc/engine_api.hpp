@@ -14,7 +14,7 @@ int build_pyramids(modsx_ctx *c, const modsx_image *const *imgs, int n, const mo
 int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const modsx_hessaff_params &p,
                             std::vector<modsx_sskp> *out);
 int detect_keypoints_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const modsx_hessaff_params &par,
-                           double tilt, double zoom, std::vector<modsx_keypoint> *out);
+                           const double *tilts, const double *zooms, std::vector<modsx_keypoint> *out);
 void detect_affine_regions(const modsx_keypoint *kps, int n, int img_id, int det_type, modsx_region *out);
 int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const std::vector<modsx_region> *in,
                              double mrSize, int patchSize, int doHalfSIFT, int maxAngNum, double th, int addUpRight,
@@ -22,7 +22,18 @@ int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n
 int reproject_regions(modsx_region *regs, int n, const double *H, int orig_w, int orig_h);
 int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const std::vector<modsx_region> *regs,
                    double mrSize, int patchSize, int fast, int photoNorm, int descType, double maxBin,
-                   float *const *descHost);
+                   float *const *descHost, float *const *devF, uint8_t *const *devU8);
+struct ProfScopeFwd;
+int set_vs_pars(const double *scale_set, int ns, const double *tilt_set, int nt, double phi_base, double InitSigma,
+                int doBlur, modsx_view *par, int cap, modsx_view *prev, int *nprev, int cap_prev);
+int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx_image **out, double *H, int *identity);
+int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_view *views, int nv,
+                          const modsx_pair_params &pp, int view_begin, int view_step, std::vector<modsx_region> &regs,
+                          float *devF, uint8_t *devU8, size_t devCapRegions, float *hostDesc);
+int match_pair_views(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_view *views, int nv,
+                     const modsx_pair_params &pp, modsx_pair_result *res);
+void prof_begin(modsx_ctx *c, int cls, double work, size_t *slot);
+void prof_end(modsx_ctx *c, size_t slot);
 int match_device(modsx_ctx *c, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2Host,
                  double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out);
 int match_host_desc(modsx_ctx *c, const float *desc1, int n1, const float *desc2, int n2, const double *pos2,

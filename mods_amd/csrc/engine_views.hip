@@ -1,0 +1,342 @@
+// engine_views.hip -- on-demand view synthesis and the per-view loop (host orchestration).
+//
+//   SetVSPars                      synth-detection.cpp:103-234   (view ladder of one step)
+//   GenerateSynthImageCorr         synth-detection.cpp:236-430   (rotate, anti-alias blur, tilt/zoom)
+//   SynthDetectDescribeKeypoints   imagerepresentation.cpp:603-2047, HessianAffine branch for one SIFT-family
+//                                  descriptor: per view detect -> orient -> reproject -> describe, then
+//                                  AddRegions in view order with id re-basing (:588-600, :2044-2045)
+// Views are independent until that concatenation, so `view_begin/view_step` let a caller take every G-th view
+// (the shard of one GPU); the caller gathers the per-view blocks afterwards.
+#include <math.h>
+#include <algorithm>
+#include "engine_api.hpp"
+
+namespace mx {
+
+int set_vs_pars(const double *scale_set, int ns, const double *tilt_set, int nt, double phi_base, double InitSigma,
+                int doBlur, modsx_view *par, int cap, modsx_view *prev, int *nprev, int cap_prev) {
+  const double eps1 = 0.01;
+  std::vector<modsx_view> tmp;
+  auto mk = [&](double phi, double tilt, double zoom, int blur) {
+    modsx_view v; v.phi = phi; v.tilt = tilt; v.zoom = zoom; v.InitSigma = InitSigma; v.doBlur = blur;
+    return v;
+  };
+  if (ns == 0 || nt == 0) tmp.push_back(mk(0, 0, 0, 0));
+  for (int sc = 0; sc < ns; sc++)
+    for (int t = 0; t < nt; t++) {
+      if (fabs(tilt_set[t] - 1) > eps1) {
+        int n_rot1 = floor(180.0 * tilt_set[t] / phi_base);
+        double delta_phi = M_PI / n_rot1;
+        if (n_rot1 < 0) {  // "no rotation" mode: one vertical tilt
+          n_rot1 = 1; delta_phi = 0;
+          tmp.push_back(mk(0, -tilt_set[t], scale_set[sc], doBlur));
+        }
+        for (int r = 0; r < n_rot1; r++) tmp.push_back(mk(delta_phi * r, tilt_set[t], scale_set[sc], doBlur));
+      } else tmp.push_back(mk(0, tilt_set[t], scale_set[sc], doBlur));
+    }
+  int n = 0;
+  std::vector<modsx_view> added;
+  for (size_t i = 0; i < tmp.size(); i++) {
+    bool uniq = true;
+    for (int j = 0; j < *nprev; j++)
+      if ((fabs(tmp[i].zoom - prev[j].zoom) <= eps1) && (fabs(tmp[i].tilt - prev[j].tilt) <= eps1) &&
+          (fabs(tmp[i].phi - prev[j].phi) <= eps1)) { uniq = false; break; }
+    if (uniq) { if (n < cap) par[n] = tmp[i]; n++; added.push_back(tmp[i]); }
+  }
+  for (const modsx_view &v : added) if (*nprev < cap_prev) prev[(*nprev)++] = v;
+  return n;
+}
+
+// cv::warpAffine inverts the forward 2x3 matrix in f64 before the pixel loop (imgwarp.cpp)
+static void invert_affine(const double *Min, double *M) {
+  for (int i = 0; i < 6; i++) M[i] = Min[i];
+  double D = M[0] * M[4] - M[1] * M[3];
+  D = D != 0 ? 1. / D : 0;
+  double A11 = M[4] * D, A22 = M[0] * D;
+  M[0] = A11; M[1] *= -D;
+  M[3] *= -D; M[4] = A22;
+  double b1 = -M[0] * M[2] - M[1] * M[5];
+  double b2 = -M[3] * M[2] - M[4] * M[5];
+  M[2] = b1; M[5] = b2;
+}
+
+int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx_image **out, double *H, int *identity) {
+  double tilt = v.tilt;
+  const double phi = v.phi, zoom = v.zoom, InitSigma = v.InitSigma;
+  int zoomed = 0;
+  bool vertical_tilt = false;
+  if (tilt < 0) { tilt = -tilt; vertical_tilt = true; }
+  if (fabs(zoom - 1.0f) >= 0.05) zoomed = 1;
+  const int w = gray->cols, h = gray->rows;
+  int wS1 = (int)(w * zoom), hS1 = (int)(h * zoom);
+  *out = nullptr;
+  if ((fabs(tilt - 1.) <= 0.1) && (fabs(phi) <= 0.2) && (fabs(zoom - 1.) <= 0.1)) {  // original image, :278-289
+    const double E[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < 9; i++) H[i] = E[i];
+    *identity = 1;
+    modsx_image *im = new modsx_image();
+    im->d = gray->d; im->rows = h; im->cols = w; im->owned = false;
+    *out = im;
+    return MODSX_OK;
+  }
+  *identity = 0;
+  double d, d2, w_new, h_new;
+  double kV = 1., kH = 1.;
+  if (zoomed) { kV = (double)w / (double)wS1; kH = (double)h / (double)hS1; }
+  const bool q1 = (phi >= 0) && (phi < M_PI / 2);
+  if (vertical_tilt) {
+    if (q1) {
+      w_new = floor((0.5 + cos(phi) * w + sin(phi) * h) / (kH));
+      h_new = floor((0.5 + sin(phi) * w + cos(phi) * h) / (tilt * kV));
+      H[0] = cos(phi) / kH; H[1] = sin(phi) / kH; H[2] = 0;
+      H[3] = -sin(phi) / (tilt * kV); H[4] = cos(phi) / (tilt * kV); H[5] = floor(0.5 + sin(phi) * w / (tilt * kV));
+    } else {
+      w_new = floor((0.5 - cos(phi) * w + sin(phi) * h) / (kH));
+      h_new = floor((0.5 + sin(phi) * w - cos(phi) * h) / (tilt * kV));
+      d = -floor(cos(phi) * w / kH);
+      d2 = floor(0.5 + (sin(phi) * w - cos(phi) * h) / (tilt * kV));
+      H[0] = cos(phi) / kH; H[1] = sin(phi) / kH; H[2] = d;
+      H[3] = -sin(phi) / (tilt * kV); H[4] = cos(phi) / (tilt * kV); H[5] = d2;
+    }
+  } else {
+    if (q1) {
+      w_new = floor((0.5 + cos(phi) * w + sin(phi) * h) / (tilt * kH));
+      h_new = floor((0.5 + sin(phi) * w + cos(phi) * h) / (kV));
+      H[0] = cos(phi) / (tilt * kH); H[1] = sin(phi) / (tilt * kH); H[2] = 0;
+      H[3] = -sin(phi) / kV; H[4] = cos(phi) / kV; H[5] = floor(0.5 + sin(phi) * w / kV);
+    } else {
+      w_new = floor((0.5 - cos(phi) * w + sin(phi) * h) / (tilt * kH));
+      h_new = floor((0.5 + sin(phi) * w - cos(phi) * h) / (kV));
+      d = -floor(cos(phi) * w / (tilt * kH));
+      d2 = floor(0.5 + (sin(phi) * w - cos(phi) * h) / kV);
+      H[0] = cos(phi) / (tilt * kH); H[1] = sin(phi) / (tilt * kH); H[2] = d;
+      H[3] = -sin(phi) / kV; H[4] = cos(phi) / kV; H[5] = d2;
+    }
+  }
+  H[6] = 0; H[7] = 0; H[8] = 1;
+  double sigma_aa_2 = zoomed ? InitSigma / (4.0 * zoom) : InitSigma / 2.0;
+  double sigma_aa = InitSigma * tilt / (2.0 * zoom);
+  double sigma_x = vertical_tilt ? sigma_aa_2 : sigma_aa, sigma_y = vertical_tilt ? sigma_aa : sigma_aa_2;
+  int w_rot, h_rot;
+  double R[6];
+  if (q1) {
+    w_rot = floor((0.5 + cos(phi) * w + sin(phi) * h));
+    h_rot = floor((0.5 + sin(phi) * w + cos(phi) * h));
+    R[0] = cos(phi); R[1] = sin(phi); R[2] = 0;
+    R[3] = -sin(phi); R[4] = cos(phi); R[5] = floor(0.5 + sin(phi) * w);
+  } else {
+    w_rot = floor((0.5 - cos(phi) * w + sin(phi) * h));
+    h_rot = floor((0.5 + sin(phi) * w - cos(phi) * h));
+    d = -floor(cos(phi) * w);
+    d2 = floor(0.5 + (sin(phi) * w - cos(phi) * h));
+    R[0] = cos(phi); R[1] = sin(phi); R[2] = d;
+    R[3] = -sin(phi); R[4] = cos(phi); R[5] = d2;
+  }
+  const int ow = (int)w_new, oh = (int)h_new;
+  if (w_rot <= 0 || h_rot <= 0 || ow <= 0 || oh <= 0) { set_error("degenerate synthesised view"); return MODSX_ERR_ARG; }
+  hipStream_t s = c->stream;
+  const size_t rotPx = (size_t)w_rot * h_rot;
+  if (!c->viewTmp[0].ensure(rotPx * 4) || !c->viewTmp[1].ensure(rotPx * 4)) return MODSX_ERR_NOMEM;
+  float *t0 = (float *)c->viewTmp[0].p, *t1 = (float *)c->viewTmp[1].p;
+  WarpJob wj;
+  memset(&wj, 0, sizeof wj);
+  wj.src = gray->d; wj.dst = t0; wj.srows = h; wj.scols = w; wj.drows = h_rot; wj.dcols = w_rot; wj.cval = 128.f;
+  invert_affine(R, wj.M);
+  size_t slot;
+  prof_begin(c, K_WARP, ((double)w * h + (double)rotPx) * 4, &slot);
+  launch_warp_affine(s, wj);
+  prof_end(c, slot);
+  float *cur = t0;
+  if (v.doBlur) {
+    int kx = floor(2.0 * 3.0 * sigma_x + 1.0);
+    if (kx % 2 == 0) kx++;
+    if (kx < 3) kx = 3;
+    int ky = floor(2.0 * 3.0 * sigma_y + 1.0);
+    if (ky % 2 == 0) ky++;
+    if (ky < 3) ky = 3;
+    if (h_rot == 1) ky = 1;
+    if (w_rot == 1) kx = 1;
+    std::vector<float> KX = gaussian_kernel(kx, std::max(sigma_x, 0.));
+    std::vector<float> KY = (ky == kx && fabs(sigma_x - sigma_y) < 2.220446049250313e-16) ? KX : gaussian_kernel(ky, std::max(sigma_y, 0.));
+    std::vector<float> taps(KX);
+    taps.insert(taps.end(), KY.begin(), KY.end());
+    if (!c->viewTaps.ensure(taps.size() * 4)) return MODSX_ERR_NOMEM;
+    MX_HIP(hipMemcpyAsync(c->viewTaps.p, taps.data(), taps.size() * 4, hipMemcpyHostToDevice, s));
+    MX_HIP(hipStreamSynchronize(s));  // taps is a stack-scoped vector
+    prof_begin(c, K_VIEW_BLUR, (double)rotPx * 16, &slot);
+    launch_blur_pass(s, t0, t1, h_rot, w_rot, (float *)c->viewTaps.p, kx, 0);
+    launch_blur_pass(s, t1, t0, h_rot, w_rot, (float *)c->viewTaps.p + kx, ky, 1);
+    prof_end(c, slot);
+    cur = t0;
+  }
+  modsx_image *im = new modsx_image();
+  im->rows = oh; im->cols = ow; im->owned = true; im->d = nullptr;
+  if (hipMalloc(&im->d, (size_t)ow * oh * 4) != hipSuccess) { delete im; set_error("hipMalloc view"); return MODSX_ERR_NOMEM; }
+  double Wz[6] = {0, 0, 0, 0, 0, 0};
+  if (vertical_tilt) { Wz[0] = 1.0 / kH; Wz[4] = 1.0 / (tilt * kV); }
+  else { Wz[0] = 1.0 / (tilt * kH); Wz[4] = 1.0 / kV; }
+  memset(&wj, 0, sizeof wj);
+  wj.src = cur; wj.dst = im->d; wj.srows = h_rot; wj.scols = w_rot; wj.drows = oh; wj.dcols = ow; wj.cval = 128.f;
+  invert_affine(Wz, wj.M);
+  prof_begin(c, K_WARP, ((double)rotPx + (double)ow * oh) * 4, &slot);
+  launch_warp_affine(s, wj);
+  prof_end(c, slot);
+  MX_HIP(hipStreamSynchronize(s));  // viewTmp is reused by the next view
+  MX_HIP(hipGetLastError());
+  *out = im;
+  return MODSX_OK;
+}
+
+// The per-view loop for views view_begin, view_begin+view_step, ... < nv.  Output regions carry
+// img_id = view index (0 for the identity view) and ids local to their view block; `viewCount[v]` gets the
+// number of described regions of view v (0 for views not taken).  Descriptors are written view block after
+// view block at devU8/devF (device, capacity devCapRegions) and optionally copied to hostDesc.
+int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_view *views, int nv,
+                          const modsx_pair_params &pp, int view_begin, int view_step, std::vector<modsx_region> &regs,
+                          float *devF, uint8_t *devU8, size_t devCapRegions, float *hostDesc) {
+  regs.clear();
+  if (view_step < 1) view_step = 1;
+  std::vector<int> take;
+  for (int v = view_begin; v < nv; v += view_step) take.push_back(v);
+  size_t total = 0;
+  for (size_t g0 = 0; g0 < take.size(); g0 += MAXB) {
+    const int n = (int)std::min<size_t>(MAXB, take.size() - g0);
+    modsx_image *vimg[MAXB];
+    const modsx_image *cimg[MAXB];
+    double Hs[MAXB][9], tilts[MAXB], zooms[MAXB];
+    int ident[MAXB];
+    int rc = MODSX_OK;
+    for (int i = 0; i < n; i++) vimg[i] = nullptr;
+    for (int i = 0; i < n && !rc; i++) {
+      const modsx_view &v = views[take[g0 + i]];
+      rc = synth_view(c, gray, v, &vimg[i], Hs[i], &ident[i]);
+      cimg[i] = vimg[i];
+      tilts[i] = ident[i] ? 1.0 : fabs(v.tilt);   // SynthImage::tilt / zoom as GenerateSynthImageCorr leaves them
+      zooms[i] = ident[i] ? 1.0 : v.zoom;
+    }
+    std::vector<modsx_keypoint> kps[MAXB];
+    std::vector<modsx_region> r0[MAXB], ro[MAXB];
+    if (!rc) rc = detect_keypoints_batch(c, cimg, n, pp.det, tilts, zooms, kps);
+    if (!rc) {
+      for (int i = 0; i < n; i++) {
+        r0[i].resize(kps[i].size());
+        detect_affine_regions(kps[i].data(), (int)kps[i].size(), ident[i] ? 0 : take[g0 + i], MODSX_DET_HESSIAN, r0[i].data());
+      }
+      rc = detect_orientation_batch(c, cimg, n, r0, pp.ori_mrSize, pp.ori_patchSize, 0, pp.ori_maxAngles, pp.ori_threshold,
+                                    0, ro);
+    }
+    if (!rc) {
+      float *dF[MAXB];
+      uint8_t *dU[MAXB];
+      size_t ofs = total;
+      for (int i = 0; i < n; i++) {
+        int m = reproject_regions(ro[i].data(), (int)ro[i].size(), Hs[i], gray->cols, gray->rows);
+        ro[i].resize(m);
+        dF[i] = devF ? devF + ofs * 128 : nullptr;
+        dU[i] = devU8 ? devU8 + ofs * 128 : nullptr;
+        ofs += m;
+      }
+      if (ofs > devCapRegions && (devF || devU8)) { set_error("descriptor buffer too small"); rc = MODSX_ERR_NOMEM; }
+      if (!rc) rc = describe_batch(c, cimg, n, ro, pp.desc_mrSize, pp.desc_patchSize, 0, pp.desc_photoNorm, pp.desc_type,
+                                   pp.desc_maxBinValue, nullptr, devF ? dF : nullptr, devU8 ? dU : nullptr);
+      if (!rc) {
+        for (int i = 0; i < n; i++) {
+          if (hostDesc && !ro[i].empty()) {
+            if (devF) {
+              hipMemcpyAsync(hostDesc + total * 128, dF[i], ro[i].size() * 512, hipMemcpyDeviceToHost, c->stream);
+            } else {
+              hipMemcpyAsync(hostDesc + total * 128, c->descF[i].p, ro[i].size() * 512, hipMemcpyDeviceToHost, c->stream);
+            }
+          }
+          regs.insert(regs.end(), ro[i].begin(), ro[i].end());
+          total += ro[i].size();
+        }
+        hipStreamSynchronize(c->stream);
+      }
+    }
+    for (int i = 0; i < n; i++)
+      if (vimg[i]) { if (vimg[i]->owned && vimg[i]->d) hipFree(vimg[i]->d); delete vimg[i]; }
+    if (rc) return rc;
+  }
+  return MODSX_OK;
+}
+
+// AddRegionsToList (imagerepresentation.cpp:588-600): ids of each appended view block are shifted by the size
+// of the list so far
+static void rebase_ids(std::vector<modsx_region> &regs) {
+  size_t start = 0;
+  while (start < regs.size()) {
+    size_t end = start;
+    // a view block = maximal run produced by one view; orientation leaves id = 0 for every region of a view
+    // (synth-detection.cpp:854,889), so blocks are delimited by img_id changes
+    while (end < regs.size() && regs[end].img_id == regs[start].img_id) end++;
+    for (size_t i = start; i < end; i++) { regs[i].id += (int)start; regs[i].parent_id += (int)start; }
+    start = end;
+  }
+}
+
+int match_pair_views(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_view *views, int nv,
+                     const modsx_pair_params &pp, modsx_pair_result *res) {
+  memset(res, 0, sizeof *res);
+  for (int i = 0; i < 9; i++) res->H[i] = -1;
+  const modsx_image *imgs[2] = {img1, img2};
+  std::vector<modsx_region> regs[2];
+  size_t cap = 1 << 16;
+  for (int side = 0; side < 2; side++) {
+    for (;;) {
+      if (!c->descAllU8[side].ensure(cap * 128) || !c->descAllF[side].ensure(cap * 512)) return MODSX_ERR_NOMEM;
+      int rc = detect_describe_views(c, imgs[side], views, nv, pp, 0, 1, regs[side], (float *)c->descAllF[side].p,
+                                     (uint8_t *)c->descAllU8[side].p, cap, nullptr);
+      if (rc == MODSX_ERR_NOMEM && cap < ((size_t)1 << 24)) { cap *= 4; continue; }
+      if (rc) return rc;
+      break;
+    }
+    rebase_ids(regs[side]);
+  }
+  res->n_regions1 = (int)regs[0].size();
+  res->n_regions2 = (int)regs[1].size();
+  std::vector<double> pos2(regs[1].size() * 2 + 2);
+  for (size_t i = 0; i < regs[1].size(); i++) { pos2[2 * i] = regs[1][i].reproj_kp.x; pos2[2 * i + 1] = regs[1][i].reproj_kp.y; }
+  std::vector<modsx_tentative> tents;
+  int rc = match_device(c, (uint8_t *)c->descAllU8[0].p, res->n_regions1, (uint8_t *)c->descAllU8[1].p, res->n_regions2,
+                        pos2.data(), pp.match_ratio, pp.contradDist, pp.nn, tents);
+  if (rc) return rc;
+  res->n_tentatives = (int)tents.size();
+  const int T0 = (int)tents.size();
+  std::vector<double> pts((size_t)T0 * 4 + 4), key(T0 + 1);
+  for (int i = 0; i < T0; i++) {
+    const modsx_keypoint &a = regs[0][tents[i].q].reproj_kp, &b = regs[1][tents[i].t0].reproj_kp;
+    pts[4 * i] = a.x; pts[4 * i + 1] = a.y; pts[4 * i + 2] = b.x; pts[4 * i + 3] = b.y;
+    key[i] = tents[i].ratio;
+  }
+  std::vector<int> order(T0 + 1);
+  std::vector<unsigned char> keepd(T0 + 1);
+  duplicate_filtering(pts.data(), key.data(), T0, pp.duplicateDist, 1, order.data(), keepd.data());
+  std::vector<modsx_tentative> uniq;
+  for (int i = 0; i < T0; i++) if (keepd[i]) uniq.push_back(tents[order[i]]);
+  const int T = (int)uniq.size();
+  res->n_unique = T;
+  std::vector<double> p2((size_t)T * 4 + 4), l1((size_t)T * 5 + 5), l2((size_t)T * 5 + 5);
+  for (int i = 0; i < T; i++) {
+    const modsx_keypoint &a = regs[0][uniq[i].q].reproj_kp, &b = regs[1][uniq[i].t0].reproj_kp;
+    p2[4 * i] = a.x; p2[4 * i + 1] = a.y; p2[4 * i + 2] = b.x; p2[4 * i + 3] = b.y;
+    l1[5 * i] = a.a11; l1[5 * i + 1] = a.a12; l1[5 * i + 2] = a.a21; l1[5 * i + 3] = a.a22; l1[5 * i + 4] = a.s;
+    l2[5 * i] = b.a11; l2[5 * i + 1] = b.a12; l2[5 * i + 2] = b.a21; l2[5 * i + 3] = b.a22; l2[5 * i + 4] = b.s;
+  }
+  res->tentatives = (modsx_tentative *)malloc(sizeof(modsx_tentative) * std::max(1, T));
+  res->ransac_inlier = (unsigned char *)calloc(std::max(1, T), 1);
+  res->verified = (unsigned char *)calloc(std::max(1, T), 1);
+  for (int i = 0; i < T; i++) res->tentatives[i] = uniq[i];
+  double Hraw[9];
+  int dout[3] = {0, 0, 0};
+  int nvf = loransac_h(p2.data(), l1.data(), l2.data(), T, pp.err_threshold, pp.confidence, pp.max_samples,
+                       pp.localOptimization, pp.HLAFCoef, pp.doSymmCheck, pp.ransac_seed, res->H, Hraw, res->ransac_inlier,
+                       res->verified, dout);
+  res->n_verified = nvf < 0 ? 0 : nvf;
+  for (int i = 0; i < T; i++) res->n_ransac_inliers += res->ransac_inlier[i];
+  res->ransac_samples = dout[0]; res->ransac_lo = dout[1];
+  prof_collect(c);
+  return MODSX_OK;
+}
+
+}  // namespace mx

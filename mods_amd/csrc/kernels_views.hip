@@ -1,0 +1,84 @@
+// kernels_views.hip -- view synthesis on device.
+//
+// Reference: GenerateSynthImageCorr, synth-detection.cpp:236-430: rotate (cv::warpAffine, INTER_LINEAR,
+// BORDER_CONSTANT 128), anisotropic anti-alias blur (cv::GaussianBlur, default BORDER_REFLECT_101), tilt/zoom
+// scale (cv::warpAffine again).  The OpenCV 2.4.9 arithmetic restated: inverse map in f64, source coordinates
+// in 1/1024 fixed point (cvRound = round half to even), rounded to 1/32 px, weights = products of multiples
+// of 1/32 (exact in f32), four taps accumulated left to right in f32.
+#include "engine.hpp"
+
+namespace mx {
+
+__global__ __launch_bounds__(256) void k_warp_affine(WarpJob jb) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= jb.dcols || y >= jb.drows) return;
+  const int AB_SCALE = 1024;
+  const int adelta = (int)rint(jb.M[0] * x * AB_SCALE), bdelta = (int)rint(jb.M[3] * x * AB_SCALE);
+  const int X0 = (int)rint((jb.M[1] * y + jb.M[2]) * AB_SCALE) + 16;
+  const int Y0 = (int)rint((jb.M[4] * y + jb.M[5]) * AB_SCALE) + 16;
+  const int X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+  int sx = X >> 5, sy = Y >> 5;
+  sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx);
+  sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
+  const float fx = (float)(X & 31) * (1.f / 32), fy = (float)(Y & 31) * (1.f / 32);
+  const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
+  const int sw = jb.scols, sh = jb.srows;
+  float out;
+  if (sx >= 0 && sx < sw - 1 && sy >= 0 && sy < sh - 1) {
+    const float *S = jb.src + (size_t)sy * sw + sx;
+    out = S[0] * w0 + S[1] * w1 + S[sw] * w2 + S[sw + 1] * w3;
+  } else if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) {
+    out = jb.cval;
+  } else {
+    const bool x0 = sx >= 0 && sx < sw, x1 = sx + 1 >= 0 && sx + 1 < sw, y0 = sy >= 0 && sy < sh, y1 = sy + 1 >= 0 && sy + 1 < sh;
+    const float v0 = (x0 && y0) ? jb.src[(size_t)sy * sw + sx] : jb.cval;
+    const float v1 = (x1 && y0) ? jb.src[(size_t)sy * sw + sx + 1] : jb.cval;
+    const float v2 = (x0 && y1) ? jb.src[(size_t)(sy + 1) * sw + sx] : jb.cval;
+    const float v3 = (x1 && y1) ? jb.src[(size_t)(sy + 1) * sw + sx + 1] : jb.cval;
+    out = v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
+  }
+  jb.dst[(size_t)y * jb.dcols + x] = out;
+}
+
+MX_D int reflect101(int p, int n) {
+  if (n == 1) return 0;
+  while (p < 0 || p >= n) { if (p < 0) p = -p; else p = 2 * n - 2 - p; }
+  return p;
+}
+
+// one pass of a separable Gaussian with BORDER_REFLECT_101: pass 0 = rows (RowFilter / SymmRowSmallFilter order),
+// pass 1 = columns (SymmColumnFilter order)
+__global__ __launch_bounds__(256) void k_blur_pass(const float *src, float *dst, int rows, int cols, const float *taps,
+                                                   int n, int pass) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= cols || y >= rows) return;
+  const int R = n >> 1;
+  float v;
+  if (n == 1) v = src[(size_t)y * cols + x];
+  else if (pass == 0) {
+    const float *row = src + (size_t)y * cols;
+    if (n <= 5) {
+      v = row[x] * taps[R];
+      for (int j = 1; j <= R; j++) v = v + (row[reflect101(x - j, cols)] + row[reflect101(x + j, cols)]) * taps[R + j];
+    } else {
+      v = 0.f;
+      for (int j = 0; j < n; j++) v = v + row[reflect101(x + j - R, cols)] * taps[j];
+    }
+  } else {
+    v = taps[R] * src[(size_t)y * cols + x] + 0.f;
+    for (int j = 1; j <= R; j++)
+      v = v + taps[R + j] * (src[(size_t)reflect101(y + j, rows) * cols + x] + src[(size_t)reflect101(y - j, rows) * cols + x]);
+  }
+  dst[(size_t)y * cols + x] = v;
+}
+
+void launch_warp_affine(hipStream_t s, const WarpJob &jb) {
+  dim3 grid((jb.dcols + 63) / 64, (jb.drows + 3) / 4);
+  hipLaunchKernelGGL(k_warp_affine, grid, dim3(256), 0, s, jb);
+}
+void launch_blur_pass(hipStream_t s, const float *src, float *dst, int rows, int cols, const float *taps, int n, int pass) {
+  dim3 grid((cols + 63) / 64, (rows + 3) / 4);
+  hipLaunchKernelGGL(k_blur_pass, grid, dim3(256), 0, s, src, dst, rows, cols, taps, n, pass);
+}
+
+}  // namespace mx

@@ -85,6 +85,24 @@ int  orc_interpolate(const float *im, int rows, int cols, float ofsx, float ofsy
 float orc_atan2lut(float y, float x);
 const double *orc_atan_lut(void);
 
+/* view synthesis: ViewSynthParameters (detectors/structures.hpp:201-214) and GenerateSynthImageCorr */
+typedef struct orc_view {
+  double zoom, tilt, phi, InitSigma;
+  int doBlur;
+} orc_view;
+/* cv::warpAffine(src, dst, M(2x3 forward), Size(dcols,drows), INTER_LINEAR, BORDER_CONSTANT, 128) */
+void orc_warp_affine(const float *src, int rows, int cols, const double *M6, float *dst, int drows, int dcols,
+                     float border);
+/* cv::GaussianBlur(img, img, Size(kx,ky), sx, sy) with BORDER_REFLECT_101 */
+void orc_gaussian_blur_xy(const float *in, int rows, int cols, int kx, int ky, double sx, double sy, float *out);
+/* GenerateSynthImageCorr (synth-detection.cpp:236-430) on a gray f32 image: returns view size and H (orig->view);
+ * pass out = NULL to query the size */
+int orc_synth_view(const float *gray, int rows, int cols, const orc_view *v, float *out, int *orows, int *ocols,
+                   double *H9);
+/* SetVSPars (synth-detection.cpp:103-234): prev[] is updated in place (capacity cap_prev) */
+int orc_set_vs_pars(const double *scale_set, int ns, const double *tilt_set, int nt, double phi_base,
+                    double InitSigma, int doBlur, orc_view *par, int cap, orc_view *prev, int *nprev, int cap_prev);
+
 /* pyramid of one octave: blurs[5], responses[5] (each rows*cols), returns next octave base */
 void orc_octave_levels(const float *first, int rows, int cols, const orc_hessaff_params *p,
                        float *blurs, float *resps);

@@ -32,6 +32,11 @@ class HessAffParams(C.Structure):
                 ("affInitialSigma", C.c_float), ("doBaumberg", C.c_int)]
 
 
+class View(C.Structure):
+    _fields_ = [("zoom", C.c_double), ("tilt", C.c_double), ("phi", C.c_double), ("InitSigma", C.c_double),
+                ("doBlur", C.c_int)]
+
+
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".hpp", ".h", ".c"))]
@@ -266,3 +271,78 @@ def loransac_h(pts, laf1, laf2, err_threshold=3.0, confidence=0.99, max_samples=
                              _p(inl), _p(keep), _p(dout))
     return dict(n=n, H=H.reshape(3, 3), Hraw=Hraw, inl=inl[:T].astype(bool), keep=keep[:T].astype(bool),
                 samples=int(dout[0]), lo_count=int(dout[1]), ori_rejects=int(dout[2]))
+
+
+def warp_affine(img, M6, drows, dcols, border=128.0):
+    img = _f32(img)
+    M6 = np.ascontiguousarray(M6, np.float64).reshape(6)
+    out = np.empty((drows, dcols), np.float32)
+    lib().orc_warp_affine(_p(img), img.shape[0], img.shape[1], _p(M6), _p(out), drows, dcols, C.c_float(border))
+    return out
+
+
+def gaussian_blur_xy(img, kx, ky, sx, sy):
+    img = _f32(img)
+    out = np.empty_like(img)
+    lib().orc_gaussian_blur_xy(_p(img), img.shape[0], img.shape[1], kx, ky, C.c_double(sx), C.c_double(sy), _p(out))
+    return out
+
+
+def make_view(tilt=1.0, phi=0.0, zoom=1.0, init_sigma=0.5, do_blur=1):
+    v = View()
+    v.zoom, v.tilt, v.phi, v.InitSigma, v.doBlur = zoom, tilt, phi, init_sigma, do_blur
+    return v
+
+
+def synth_view(gray, view):
+    gray = _f32(gray)
+    r, c = C.c_int(), C.c_int()
+    H = np.zeros(9)
+    lib().orc_synth_view(_p(gray), gray.shape[0], gray.shape[1], C.byref(view), None, C.byref(r), C.byref(c), _p(H))
+    out = np.empty((r.value, c.value), np.float32)
+    ident = lib().orc_synth_view(_p(gray), gray.shape[0], gray.shape[1], C.byref(view), _p(out), C.byref(r),
+                                 C.byref(c), _p(H))
+    return out, H.reshape(3, 3), bool(ident)
+
+
+def set_vs_pars(scale_set, tilt_set, phi_base, init_sigma=0.5, do_blur=1, prev=None):
+    """SetVSPars; prev is a python list of View that is extended in place (de-duplication across steps)."""
+    prev = [] if prev is None else prev
+    ss = np.ascontiguousarray(scale_set, np.float64)
+    ts = np.ascontiguousarray(tilt_set, np.float64)
+    cap = 4096
+    par = (View * cap)()
+    pv = (View * cap)(*prev)
+    npv = C.c_int(len(prev))
+    n = lib().orc_set_vs_pars(_p(ss), len(ss), _p(ts), len(ts), C.c_double(phi_base), C.c_double(init_sigma),
+                              int(do_blur), par, cap, pv, C.byref(npv), cap)
+    del prev[:]
+    for i in range(npv.value):
+        prev.append(make_view(pv[i].tilt, pv[i].phi, pv[i].zoom, pv[i].InitSigma, pv[i].doBlur))
+    return [make_view(par[i].tilt, par[i].phi, par[i].zoom, par[i].InitSigma, par[i].doBlur) for i in range(n)]
+
+
+def detect_describe_views(gray, views, params=None, ori=(1.0, 41, 1, 0.8), desc=(5.1962, 41, 0, 1, 1, 0.2)):
+    """The HessianAffine branch of SynthDetectDescribeKeypoints (imagerepresentation.cpp:603-2047) for one
+    descriptor: per view synthesise, detect, orient, reproject, describe; concatenate in view order with
+    AddRegionsToList id re-basing (:588-600).  Returns (regions, descriptors)."""
+    gray = _f32(gray)
+    params = params or default_params()
+    all_regs, all_desc = [], []
+    size = 0
+    for vi, v in enumerate(views):
+        img, H, ident = synth_view(gray, v)
+        k = detect_hessaff(img, params, tilt=abs(v.tilt) if not ident else 1.0, zoom=v.zoom if not ident else 1.0)
+        regs = detect_affine_regions(k, img_id=0 if ident else vi)
+        ro = detect_orientation(img, regs, mr_size=ori[0], patch_size=ori[1], max_ang=ori[2], th=ori[3])
+        rr = reproject_regions(ro, H.reshape(9), gray.shape[1], gray.shape[0])
+        d = describe_regions(img, rr, mr_size=desc[0], patch_size=desc[1], fast=desc[2], photo_norm=desc[3],
+                             rootsift=desc[4], max_bin=desc[5])
+        rr = rr.copy()
+        rr["id"] += size
+        rr["parent_id"] += size
+        size += len(rr)
+        all_regs.append(rr)
+        all_desc.append(d)
+    return np.concatenate(all_regs) if all_regs else np.zeros(0, REGION), \
+        np.concatenate(all_desc) if all_desc else np.zeros((0, 128), np.float32)

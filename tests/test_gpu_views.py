@@ -1,0 +1,98 @@
+"""GPU: view synthesis and the multi-view loop against the oracle (bit-exact)."""
+import numpy as np
+import pytest
+
+from common import laf_of, normH, same_records
+
+pytestmark = pytest.mark.gpu
+
+
+def _views(oracle, modsx, tilts, phi, sigma=0.2):
+    vo = oracle.set_vs_pars([1.0], tilts, phi, sigma, 1, [])
+    vm = modsx.set_vs_pars([1.0], tilts, phi, sigma, 1, [])
+    return vo, vm
+
+
+@pytest.mark.parametrize("tilt,phi,zoom,sigma", [(2.0, 0.0, 1.0, 0.2), (4.0, np.pi / 2, 1.0, 0.2), (6.0, 2 * np.pi / 3, 1.0, 0.5),
+                                                 (3.0, 0.0, 0.5, 0.5), (-2.0, 0.0, 1.0, 0.5), (8.0, 1.0, 1.0, 0.5),
+                                                 (1.0, 0.0, 0.7, 0.5), (1.0, 0.0, 1.0, 0.5)])
+def test_synth_view_bit_exact(ctx, modsx, oracle, small_pair, tilt, phi, zoom, sigma):
+    a = small_pair[0]
+    im = ctx.upload(a)
+    vo = oracle.make_view(tilt, phi, zoom, sigma, 1)
+    vm = modsx.make_view(tilt, phi, zoom, sigma, 1)
+    ref, Href, ident_ref = oracle.synth_view(a, vo)
+    got, H, ident = ctx.synth_view(im, vm)
+    assert ident == ident_ref and np.array_equal(H, Href)
+    assert (got.rows, got.cols) == ref.shape
+    assert np.array_equal(got.download(), ref)
+    got.free(); im.free()
+
+
+def test_detect_describe_views_bit_exact(ctx, modsx, oracle, small_pair):
+    a = small_pair[0]
+    im = ctx.upload(a)
+    vo, vm = _views(oracle, modsx, [1, 2, 3, 4, 6], 360.0)
+    assert len(vm) == 8
+    regs_ref, desc_ref = oracle.detect_describe_views(a, vo)
+    regs, desc = ctx.detect_describe_views(im, vm, modsx.default_pair_params())
+    assert len(regs_ref) > 300
+    assert same_records(regs, regs_ref.view(modsx.REGION))
+    assert np.array_equal(desc, desc_ref)
+    # a shard (every 2nd view starting at 1) equals the corresponding view blocks, ids local to the block
+    r2, d2 = ctx.detect_describe_views(im, vm, modsx.default_pair_params(), view_begin=1, view_step=2)
+    sel = np.isin(regs_ref["img_id"], [1, 3, 5, 7])
+    assert len(r2) == sel.sum() and np.array_equal(d2, desc_ref[sel])
+    assert np.array_equal(r2["reproj_kp"]["x"], regs_ref["reproj_kp"]["x"][sel])
+    im.free()
+
+
+def test_pair_views_end_to_end(ctx, modsx, oracle, small_pair):
+    a, b, H = small_pair
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    vo, vm = _views(oracle, modsx, [1, 2, 3], 360.0)
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    got = ctx.match_pair_views(ia, ib, vm, modsx.default_pair_params(ransac_seed=4))
+    r1, d1 = oracle.detect_describe_views(a, vo)
+    r2, d2 = oracle.detect_describe_views(b, vo)
+    assert got["n_regions"] == (len(r1), len(r2))
+    pos2 = np.stack([r2["reproj_kp"]["x"], r2["reproj_kp"]["y"]], 1)
+    tent = oracle.match_fginn(d1, d2, pos2, 0.8, 30.0)
+    assert got["n_tentatives"] == len(tent)
+    pts = np.stack([r1["reproj_kp"]["x"][tent["q"]], r1["reproj_kp"]["y"][tent["q"]],
+                    r2["reproj_kp"]["x"][tent["t0"]], r2["reproj_kp"]["y"][tent["t0"]]], 1)
+    order, keep = oracle.duplicate_filtering(pts, tent["ratio"], 2.0, True)
+    sel = order[keep]
+    tu, pu = tent[sel], pts[sel]
+    for f in tu.dtype.names:
+        assert np.array_equal(got["tentatives"][f], tu[f]), f
+    rr = oracle.loransac_h(pu, laf_of(r1, tu["q"]), laf_of(r2, tu["t0"]), seed=4)
+    assert np.array_equal(got["ransac_inlier"], rr["inl"]) and np.array_equal(got["verified"], rr["keep"])
+    assert np.abs(normH(got["H"]) - normH(rr["H"])).max() < 1e-4
+    assert np.abs(normH(got["H"]) - H).max() < 1.5
+    ia.free(); ib.free()
+
+
+def test_cat_pair_with_views_recovers_ground_truth(ctx, modsx, cat_pair):
+    """The example pair of the reference (build/examples/cat.png, cat2.png) needs synthesised views; with the
+    HessianAffine ladder of iters_mods_cviu.ini step 4 (TiltSet 1,2,4,6,8, Phi 360, initSigma 0.2) the verified
+    homography must agree with the shipped ground truth build/examples/cat.txt."""
+    cat, cat2, Hgt = cat_pair
+    i1, i2 = ctx.upload(cat), ctx.upload(cat2)
+    views = modsx.set_vs_pars([1.0], [1, 2, 4, 6, 8], 360.0, 0.2, 1, [])
+    par = modsx.default_pair_params(ransac_seed=3)
+    got = ctx.match_pair_views(i1, i2, views, par)
+    r1, _ = ctx.detect_describe_views(i1, views, par, want_desc=False)
+    r2, _ = ctx.detect_describe_views(i2, views, par, want_desc=False)
+    i1.free(); i2.free()
+    assert got["n_regions"] == (len(r1), len(r2))
+    assert got["n_verified"] >= 15                                   # minMatches of the reference configs
+    t = got["tentatives"][got["verified"]]
+    p1 = np.stack([r1["reproj_kp"]["x"][t["q"]], r1["reproj_kp"]["y"][t["q"]], np.ones(len(t))], 1)
+    p2 = np.stack([r2["reproj_kp"]["x"][t["t0"]], r2["reproj_kp"]["y"][t["t0"]]], 1)
+    proj = p1 @ normH(Hgt).T
+    proj = proj[:, :2] / proj[:, 2:]
+    err = np.linalg.norm(proj - p2, axis=1)
+    # the verified correspondences obey the shipped ground-truth homography (cat.txt)
+    assert np.mean(err < 10.0) > 0.8, (np.sort(err)[:10], len(err))

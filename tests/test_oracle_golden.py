@@ -142,3 +142,32 @@ def test_ref_ransac_recovers_homography(oracle):
     r = oracle.loransac_h(pts, laf, laf, seed=1)
     assert (r["inl"].sum(), r["samples"], r["lo_count"]) == (343, 50, 1)
     assert np.abs(normH(r["H"]) - H).max() < 0.5
+
+
+def test_cat_pair_ground_truth_homography(oracle, cat_pair):
+    """The reference's one end-to-end known answer: build/examples/cat.txt, the ground-truth homography of
+    examples/cat.png -> cat2.png (README.md:60-67).  With the HessianAffine ladder of iters_mods_cviu.ini step 4
+    (TiltSet 1,2,4,6,8, Phi 360, initSigma 0.2, RootSIFT, FGINN 0.8) the oracle's verified correspondences
+    must obey that homography."""
+    from common import laf_of
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    cat, cat2, Hgt = cat_pair
+    g1, g2 = oracle.gray_from_bgr(cat), oracle.gray_from_bgr(cat2)
+    views = oracle.set_vs_pars([1.0], [1, 2, 4, 6, 8], 360.0, 0.2, 1, [])
+    assert len(views) == 11
+    r1, d1 = oracle.detect_describe_views(g1, views)
+    r2, d2 = oracle.detect_describe_views(g2, views)
+    pos2 = np.stack([r2["reproj_kp"]["x"], r2["reproj_kp"]["y"]], 1)
+    tent = oracle.match_fginn(d1, d2, pos2, 0.8, 30.0)
+    pts = np.stack([r1["reproj_kp"]["x"][tent["q"]], r1["reproj_kp"]["y"][tent["q"]],
+                    r2["reproj_kp"]["x"][tent["t0"]], r2["reproj_kp"]["y"][tent["t0"]]], 1)
+    order, keep = oracle.duplicate_filtering(pts, tent["ratio"], 2.0, True)
+    sel = order[keep]
+    tu, pu = tent[sel], pts[sel]
+    res = oracle.loransac_h(pu, laf_of(r1, tu["q"]), laf_of(r2, tu["t0"]), seed=3)
+    assert res["n"] >= 15                                    # minMatches: the reference would stop here
+    P = pu[res["keep"]]
+    proj = np.c_[P[:, :2], np.ones(len(P))] @ normH(Hgt).T
+    err = np.linalg.norm(proj[:, :2] / proj[:, 2:] - P[:, 2:], axis=1)
+    assert np.mean(err < 10.0) > 0.8
