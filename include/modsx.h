@@ -258,10 +258,10 @@ modsx_image *modsx_synth_view(modsx_ctx *ctx, const modsx_image *gray, const mod
  * AddRegions does (:588-600, :2044-2045) when the call covers all views (view_step == 1), otherwise local to
  * each view block (img_id = view index) so that shards can be merged.  desc (optional): malloc'd [n][128] f32.
  * dev_desc_u8 (optional): device buffer of capacity dev_cap regions that receives the [n][128] u8 descriptors
- * (what the matcher consumes) without leaving HBM. */
+ * (what the matcher consumes) without leaving HBM.  view_counts (optional): [nviews] regions per view. */
 int modsx_detect_describe_views(modsx_ctx *ctx, const modsx_image *img, const modsx_view *views, int nviews,
                                 const modsx_pair_params *par, int view_begin, int view_step, modsx_region **regs,
-                                float **desc, void *dev_desc_u8, long dev_cap);
+                                float **desc, void *dev_desc_u8, long dev_cap, int *view_counts);
 
 /* MatchFlannFGINN on u8 descriptors that already live in HBM (e.g. after an all-gather over xGMI) */
 int modsx_match_fginn_device(modsx_ctx *ctx, const void *dev_desc1_u8, int n1, const void *dev_desc2_u8, int n2,

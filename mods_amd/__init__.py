@@ -374,21 +374,23 @@ class Context(object):
         return out, H.reshape(3, 3), bool(ident.value)
 
     def detect_describe_views(self, img, views, params, view_begin=0, view_step=1, want_desc=True, dev_desc=None,
-                              dev_cap=0):
+                              dev_cap=0, want_counts=False):
         arr = _view_array(views)
         regs = C.c_void_p()
         desc = C.c_void_p()
+        counts = (C.c_int * len(views))()
         n = _check(lib().modsx_detect_describe_views(self._c(), C.c_void_p(img.h), arr, len(views), C.byref(params),
                                                      int(view_begin), int(view_step), C.byref(regs),
                                                      C.byref(desc) if want_desc else None,
-                                                     C.c_void_p(dev_desc) if dev_desc else None, C.c_long(dev_cap)),
+                                                     C.c_void_p(dev_desc) if dev_desc else None, C.c_long(dev_cap),
+                                                     counts),
                    "detect_describe_views")
         r = _take(regs, n, REGION)
         d = None
         if want_desc:
             d = _take(desc, n * 128, np.dtype("f4")).reshape(n, 128) if n else np.zeros((0, 128), np.float32)
-            if n == 0 and desc:
-                pass
+        if want_counts:
+            return r, d, np.array(list(counts), np.int64)
         return r, d
 
     def match_fginn_device(self, d1_ptr, n1, d2_ptr, n2, pos2, ratio=0.8, contrad_dist=30.0, nn=50):

@@ -340,7 +340,7 @@ modsx_image *modsx_synth_view(modsx_ctx *ctx, const modsx_image *gray, const mod
 
 int modsx_detect_describe_views(modsx_ctx *ctx, const modsx_image *img, const modsx_view *views, int nviews,
                                 const modsx_pair_params *par, int view_begin, int view_step, modsx_region **regs,
-                                float **desc, void *dev_desc_u8, long dev_cap) {
+                                float **desc, void *dev_desc_u8, long dev_cap, int *view_counts) {
   NEED(ctx); NEED(img); NEED(views); NEED(par); NEED(regs);
   if (nviews <= 0 || view_begin < 0) { mx::set_error("modsx_detect_describe_views: bad argument"); return MODSX_ERR_ARG; }
   hipSetDevice(ctx->dev);
@@ -352,7 +352,7 @@ int modsx_detect_describe_views(modsx_ctx *ctx, const modsx_image *img, const mo
     uint8_t *du8 = (uint8_t *)dev_desc_u8;
     if (!du8) { if (!ctx->descAllU8[0].ensure(cap * 128)) return MODSX_ERR_NOMEM; du8 = (uint8_t *)ctx->descAllU8[0].p; }
     rc = detect_describe_views(ctx, img, views, nviews, *par, view_begin, view_step, r, (float *)ctx->descAllF[0].p, du8,
-                               cap, nullptr);
+                               cap, nullptr, view_counts);
     if (rc == MODSX_ERR_NOMEM && !dev_desc_u8 && cap < ((size_t)1 << 24)) { cap *= 4; continue; }
     break;
   }

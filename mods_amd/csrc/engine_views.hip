@@ -193,8 +193,9 @@ int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx
 // view block at devU8/devF (device, capacity devCapRegions) and optionally copied to hostDesc.
 int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_view *views, int nv,
                           const modsx_pair_params &pp, int view_begin, int view_step, std::vector<modsx_region> &regs,
-                          float *devF, uint8_t *devU8, size_t devCapRegions, float *hostDesc) {
+                          float *devF, uint8_t *devU8, size_t devCapRegions, float *hostDesc, int *viewCounts) {
   regs.clear();
+  if (viewCounts) for (int v = 0; v < nv; v++) viewCounts[v] = 0;
   if (view_step < 1) view_step = 1;
   std::vector<int> take;
   for (int v = view_begin; v < nv; v += view_step) take.push_back(v);
@@ -248,6 +249,7 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
               hipMemcpyAsync(hostDesc + total * 128, c->descF[i].p, ro[i].size() * 512, hipMemcpyDeviceToHost, c->stream);
             }
           }
+          if (viewCounts) viewCounts[take[g0 + i]] = (int)ro[i].size();
           regs.insert(regs.end(), ro[i].begin(), ro[i].end());
           total += ro[i].size();
         }
@@ -286,7 +288,7 @@ int match_pair_views(modsx_ctx *c, const modsx_image *img1, const modsx_image *i
     for (;;) {
       if (!c->descAllU8[side].ensure(cap * 128) || !c->descAllF[side].ensure(cap * 512)) return MODSX_ERR_NOMEM;
       int rc = detect_describe_views(c, imgs[side], views, nv, pp, 0, 1, regs[side], (float *)c->descAllF[side].p,
-                                     (uint8_t *)c->descAllU8[side].p, cap, nullptr);
+                                     (uint8_t *)c->descAllU8[side].p, cap, nullptr, nullptr);
       if (rc == MODSX_ERR_NOMEM && cap < ((size_t)1 << 24)) { cap *= 4; continue; }
       if (rc) return rc;
       break;

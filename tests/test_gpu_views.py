@@ -96,3 +96,39 @@ def test_cat_pair_with_views_recovers_ground_truth(ctx, modsx, cat_pair):
     err = np.linalg.norm(proj - p2, axis=1)
     # the verified correspondences obey the shipped ground-truth homography (cat.txt)
     assert np.mean(err < 10.0) > 0.8, (np.sort(err)[:10], len(err))
+
+
+def test_view_shard_path_world1_nccl(ctx, modsx, small_pair):
+    """The RCCL code path of mods_amd.distributed on one GPU (world_size 1): device tensors, all-gather,
+    reorder, device matcher -- must equal the unsharded library call."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from mods_amd import distributed as D
+    a, b, _ = small_pair
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29631")
+    created = False
+    if not dist.is_initialized():
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        views = modsx.set_vs_pars([1.0], [1, 2, 3, 4], 360.0, 0.2, 1, [])
+        par = modsx.default_pair_params()
+        ia, ib = ctx.upload(a), ctx.upload(b)
+        r1, d1 = D.detect_describe_views_sharded(ctx, ia, views, par)
+        r2, d2 = D.detect_describe_views_sharded(ctx, ib, views, par)
+        ref1, refd1 = ctx.detect_describe_views(ia, views, par)
+        assert same_records(r1, ref1) and np.array_equal(d1.cpu().numpy().astype(np.float32), refd1)
+        tent = D.match_sharded(ctx, r1, d1, r2, d2, 0.8, 30.0)
+        ref2, refd2 = ctx.detect_describe_views(ib, views, par)
+        pos2 = np.stack([ref2["reproj_kp"]["x"], ref2["reproj_kp"]["y"]], 1)
+        reft = ctx.match_fginn(refd1, refd2, pos2, 0.8, 30.0)
+        assert len(tent) == len(reft) > 10
+        for f in reft.dtype.names:
+            assert np.array_equal(tent[f], reft[f]), f
+        ia.free(); ib.free()
+    finally:
+        if created:
+            dist.destroy_process_group()
