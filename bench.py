@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="pairs per step per GPU")
     ap.add_argument("--workers", type=int, default=4, help="contexts (thread + stream) per GPU")
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic pairs cycled through the batch")
+    ap.add_argument("--tilts", type=str, default="", help="e.g. 1,2,3,4,6: synthesise views (configs[2]); default 1 view")
+    ap.add_argument("--phi", type=float, default=360.0)
+    ap.add_argument("--init-sigma", type=float, default=0.2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -98,15 +101,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    views = None
+    if args.tilts:
+        views = mods_amd.set_vs_pars([1.0], [float(t) for t in args.tilts.split(",")], args.phi, args.init_sigma, 1, [])
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(len(ctxs))
+
+    def run_batch():
+        if views is None:
+            return mods_amd.match_pairs(ctxs, imgs1, imgs2, params)
+        # multi-view pairs: one python thread per context (ctypes releases the GIL inside the library)
+        def work(w):
+            out = []
+            for i in range(w, args.batch, len(ctxs)):
+                out.append((i, ctxs[w].match_pair_views(imgs1[i], imgs2[i], views, params)))
+            return out
+        res = [None] * args.batch
+        for part in pool.map(work, range(len(ctxs))):
+            for i, r in part:
+                res[i] = r
+        return res
+
     for _ in range(args.warmup):
-        results = mods_amd.match_pairs(ctxs, imgs1, imgs2, params)
+        results = run_batch()
     for c in ctxs:
         c.profile(True)
     barrier()
     t0 = time.perf_counter()
     ndesc = 0
     for _ in range(args.steps):
-        results = mods_amd.match_pairs(ctxs, imgs1, imgs2, params)
+        results = run_batch()
         for r in results:
             ndesc += r["n_regions"][0] + r["n_regions"][1]
     barrier()
@@ -156,8 +180,11 @@ def main():
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: single %dx%d synthetic pair, 1 view, HessAff+RootSIFT, brute-force "
-                                   "FGINN match + LO-RANSAC H" % (args.cols, args.rows),
+            "config": {"workload": ("configs[1]: single %dx%d synthetic pair, 1 view, HessAff+RootSIFT, brute-force "
+                                    "FGINN match + LO-RANSAC H" % (args.cols, args.rows)) if views is None else
+                                   ("configs[2]: %dx%d synthetic pair, %d affine-synth views (tilts %s, phi %g), "
+                                    "HessAff+RootSIFT, MFMA distance matrix + FGINN, LO-RANSAC H"
+                                    % (args.cols, args.rows, len(views), args.tilts, args.phi)),
                        "pairs_per_step_per_gpu": args.batch, "workers_per_gpu": len(ctxs),
                        "parallelism": "pairs sharded over ranks, no collective"},
             "descriptors_per_s": ndesc_total / elapsed,

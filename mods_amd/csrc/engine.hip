@@ -165,7 +165,7 @@ void ctx_destroy(modsx_ctx *c) {
   for (int i = 0; i < MAXB; i++) c->pyr[i].store.release();
   DevBuf *bufs[] = {&c->cand, &c->counter, &c->affJobs, &c->affOut, &c->oriJobs, &c->oriOut, &c->descJobs, &c->tilePrefix,
                     &c->taps, &c->imgRefs, &c->scratchA, &c->scratchB, &c->descAllF[0], &c->descAllF[1], &c->descAllU8[0],
-                    &c->descAllU8[1], &c->pos2, &c->matchRows, &c->misc, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps};
+                    &c->descAllU8[1], &c->pos2, &c->matchRows, &c->matchWork, &c->misc, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps};
   for (DevBuf *b : bufs) b->release();
   for (int i = 0; i < MAXB; i++) { c->descF[i].release(); c->descU8[i].release(); }
   PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc};
@@ -764,11 +764,15 @@ int match_device(modsx_ctx *c, const uint8_t *d1, int n1, const uint8_t *d2, int
   hipStream_t s = c->stream;
   const double sqminratio = ratioT * ratioT, contrDistSq = contradDist * contradDist;
   if (!(sqminratio < 1.0)) { set_error("match ratio >= 1 (PDF mode of MatchFlannFGINN) is not supported"); return MODSX_ERR_ARG; }
-  if (!c->pos2.ensure((size_t)n2 * 16) || !c->matchRows.ensure((size_t)n1 * sizeof(MatchRow))) return MODSX_ERR_NOMEM;
+  int S_, tps_;
+  if (!c->pos2.ensure((size_t)n2 * 16) || !c->matchRows.ensure((size_t)n1 * sizeof(MatchRow)) ||
+      !c->matchWork.ensure(match_workspace_bytes(n1, n2, &S_, &tps_) + 4096))
+    return MODSX_ERR_NOMEM;
   MX_HIP(hipMemcpyAsync(c->pos2.p, pos2Host, (size_t)n2 * 16, hipMemcpyHostToDevice, s));
   {
     ProfScope ps(c, K_MATCH, 2.0 * n1 * (double)n2 * 128);
-    launch_match(s, d1, n1, d2, n2, (const double *)c->pos2.p, sqminratio, contrDistSq, (MatchRow *)c->matchRows.p);
+    launch_match(s, d1, n1, d2, n2, (const double *)c->pos2.p, sqminratio, contrDistSq, (MatchRow *)c->matchRows.p,
+                 c->matchWork.p);
   }
   std::vector<MatchRow> rows(n1);
   MX_HIP(hipMemcpyAsync(rows.data(), c->matchRows.p, (size_t)n1 * sizeof(MatchRow), hipMemcpyDeviceToHost, s));

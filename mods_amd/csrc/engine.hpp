@@ -160,8 +160,9 @@ void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *im
                      const double *wts, int photoNorm, int rootsift, double maxBin, float *descF, uint8_t *descU8);
 void launch_warp_affine(hipStream_t s, const WarpJob &jb);
 void launch_blur_pass(hipStream_t s, const float *src, float *dst, int rows, int cols, const float *taps, int n, int pass);
+size_t match_workspace_bytes(int n1, int n2, int *S_out, int *tilesPerSplit_out);
 void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2,
-                  double sqminratio, double contrDistSq, MatchRow *rows);
+                  double sqminratio, double contrDistSq, MatchRow *rows, void *workspace);
 
 }  // namespace mx
 
@@ -190,7 +191,7 @@ struct modsx_ctx {
   hipStream_t stream;
   mx::Pyramid pyr[mx::MAXB];
   mx::DevBuf cand, counter, affJobs, affOut, oriJobs, oriOut, descJobs, tilePrefix, taps, imgRefs, scratchA, scratchB,
-      descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], pos2, matchRows, misc, viewTmp[2], viewTaps;
+      descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps;
   mx::PinBuf hCand, hAff, hOri, hDesc, hMisc;
   // constant tables on device
   float *dSmmMask = nullptr;   // 19x19 computeGaussMask

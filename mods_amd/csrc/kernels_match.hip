@@ -5,16 +5,23 @@
 //   ascending with ties by ascending train index, walk j = 1..nn-1:
 //     accept at the first j with (float)d0/(float)dj <= ratio^2,
 //     give up at the first j whose position is farther than contradDist from NN0's.
-// The walk is restated as reductions over the N x M distance matrix (no top-50 sort):
-//   sweep 1:  NN0 = lexicographic min (d, t)
-//   Dmin(q)  = smallest integer distance that passes the ratio test against d0 (monotone)
-//   sweep 2:  NN1 = lex-min over t != NN0;  NNj = lex-min over d >= Dmin;
-//             nless = #{t != NN0 : d < Dmin};  nbad = #{those farther than contradDist from NN0}
-//   accept  <=>  NNj exists, nbad == 0, nless <= nn-2      (rank of NNj is nless+1)
+// Restated as reductions over the N x M distance matrix (no top-50 sort):
+//   sweep 1   top-2 of (d, t) per query: NN0, NN1
+//   decide    j = 1 of the walk needs only NN0/NN1: ratio(d0, d1) passes -> ACCEPT (NNj = NN1);
+//             NN1 farther than contradDist from NN0 -> REJECT; otherwise UNDECIDED
+//   sweep 2   only for UNDECIDED queries: Dmin = smallest integer distance passing the ratio test against
+//             d0 (the predicate is monotone); NNj = lex-min over d >= Dmin; nless = #{t != NN0 : d < Dmin};
+//             nbad = #{those farther than contradDist from NN0}
+//   accept  <=>  NNj exists, nbad == 0, nless <= nn-2          (rank of NNj is nless+1)
 // Distances come from the int8 matrix cores: with a' = a-128, b' = b-128 (both in [-128,127])
 // |a-b|^2 = |a'|^2 + |b'|^2 - 2 a'.b' exactly in int32;  a'.b' = v_mfma_i32_32x32x32_i8 over K = 128.
-// One wavefront owns 32 queries and streams all trains in 32-wide tiles; lane l holds train column
-// l&31 and query rows (reg&3)+8*(reg>>2)+4*(l>>5) of each 32x32 tile.
+//
+// Work decomposition: a 256-thread workgroup owns 128 queries (one 32-query A fragment set per wave,
+// resident in registers for the whole sweep) and one of S contiguous ranges of train tiles (M is split so
+// that small N still fills the chip).  Train tiles (32 descriptors = 4 KB) are loaded with fully coalesced
+// 16-byte-per-lane reads, staged in a double-buffered LDS tile shared by the 4 waves, and read back as MFMA
+// B fragments with ds_read_b128.  Each lane keeps running minima for its 16 accumulator rows as packed
+// (distance << 9 | local tile) keys: one shift-or and one or two integer min per element.
 #include "engine.hpp"
 
 namespace mx {
@@ -22,35 +29,32 @@ namespace mx {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-MX_D int sumsq_i8x16(v4i v) {
+constexpr int BIG = 0x7fffffff;
+constexpr unsigned UBIG = 0xffffffffu;
+constexpr int TILES_PER_SPLIT_MAX = 512;   // 9 bits of local tile index in the packed key
+
+__global__ __launch_bounds__(256) void k_desc_norms(const uint8_t *d, int n, int *norms) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const v4i *p = reinterpret_cast<const v4i *>(d + (size_t)i * 128);
   int s = 0;
 #pragma unroll
-  for (int w = 0; w < 4; w++) {
-    const int x = v[w];
+  for (int q = 0; q < 8; q++) {
+    const v4i v = p[q];
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-      const int e = (int)(signed char)((x >> (8 * b)) & 0xff);
-      s += e * e;
+    for (int w = 0; w < 4; w++) {
+      const int x = v[w] ^ 0x80808080;
+#pragma unroll
+      for (int b = 0; b < 4; b++) { const int e = (int)(signed char)((x >> (8 * b)) & 0xff); s += e * e; }
     }
   }
-  return s;
-}
-
-MX_D v4i load_frag(const uint8_t *base, int row, int nrows, int kb, int hi) {
-  // 16 bytes [32*kb + 16*hi, +16) of descriptor `row`, converted u8 -> i8 by subtracting 128
-  v4i v = {0, 0, 0, 0};
-  if (row < nrows) {
-    v = *reinterpret_cast<const v4i *>(base + (size_t)row * 128 + 32 * kb + 16 * hi);
-    v[0] ^= 0x80808080; v[1] ^= 0x80808080; v[2] ^= 0x80808080; v[3] ^= 0x80808080;
-  }
-  return v;
+  norms[i] = s;
 }
 
 MX_D bool ratio_pass(float d0, float d, double sqminratio) {
   const float r = d0 / d;            // f32 division as in `double ratio = distsRow[0]/distsRow[j]`
   return (double)r <= sqminratio;    // NaN (0/0) fails
 }
-
 // smallest integer D > d0 with ratio_pass(d0, D); the predicate is monotone in D
 MX_D int ratio_dmin(int d0i, double sqminratio) {
   const float d0 = (float)d0i;
@@ -61,132 +65,277 @@ MX_D int ratio_dmin(int d0i, double sqminratio) {
   while (D < 2000000000 && !ratio_pass(d0, (float)D, sqminratio)) D++;
   return D;
 }
-
 MX_D bool lex_less(int da, int ia, int db, int ib) { return da < db || (da == db && ia < ib); }
 
-constexpr int BIG = 0x7fffffff;
+// A fragment: 16 bytes [32*kb + 16*hi, +16) of a descriptor, u8 -> i8 (x - 128 == x ^ 0x80)
+MX_D v4i load_a(const uint8_t *base, int row, int kb, int hi) {
+  v4i v = *reinterpret_cast<const v4i *>(base + (size_t)row * 128 + 32 * kb + 16 * hi);
+  v[0] ^= 0x80808080; v[1] ^= 0x80808080; v[2] ^= 0x80808080; v[3] ^= 0x80808080;
+  return v;
+}
 
-__global__ __launch_bounds__(256) void k_match_fginn(const uint8_t *d1, int n1, const uint8_t *d2, int n2,
-                                                     const double *pos2, double sqminratio, double contrDistSq,
-                                                     MatchRow *rows) {
-  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  const int q0 = wave * 32;
-  if (q0 >= n1) return;
+struct MatchGeom {
+  int n1, n2, S, tilesPerSplit;
+};
+
+// stage one 32-descriptor tile (4 KB) into LDS: thread t copies bytes [16 t, 16 t + 16) of the tile.
+// fetch_tile issues the global load early (next tile, in flight during the MFMAs); put_tile parks it in LDS.
+MX_D v4i fetch_tile(const uint8_t *d2, int n2, int tile, int tid) {
+  const int row = tile * 32 + (tid >> 3);
+  v4i v = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};  // rows past the end: a' = 0
+  if (row < n2) v = *reinterpret_cast<const v4i *>(d2 + (size_t)tile * 4096 + (size_t)tid * 16);
+  return v;
+}
+MX_D void put_tile(v4i v, unsigned char *lds, int tid) {
+  v[0] ^= 0x80808080; v[1] ^= 0x80808080; v[2] ^= 0x80808080; v[3] ^= 0x80808080;
+  // LDS image: row r at r*128, XOR-swizzled in 16-byte slots so the b128 fragment reads spread over banks
+  const int r = tid >> 3, slot = tid & 7;
+  *reinterpret_cast<v4i *>(lds + r * 128 + ((slot ^ (r & 7)) << 4)) = v;
+}
+MX_D void stage_tile(const uint8_t *d2, int n2, int tile, unsigned char *lds, int tid) {
+  put_tile(fetch_tile(d2, n2, tile, tid), lds, tid);
+}
+MX_D v4i read_b(const unsigned char *lds, int col, int kb, int hi) {
+  const int slot = 2 * kb + hi;
+  return *reinterpret_cast<const v4i *>(lds + col * 128 + ((slot ^ (col & 7)) << 4));
+}
+
+// ---------------- sweep 1: per (query, split) top-2 -------------------------------------------------------
+__global__ __launch_bounds__(256) void k_match_sweep1(const uint8_t *d1, const int *norm1, const uint8_t *d2,
+                                                      const int *norm2, MatchGeom g, int4 *partial) {
+  __shared__ __attribute__((aligned(16))) unsigned char tileBuf[2][4096];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 31, hi = lane >> 5;
-  // A fragments: query row q0 + (lane&31), k-blocks 0..3
+  const int qb = blockIdx.x, sp = blockIdx.y;
+  const int q0 = qb * 128 + wave * 32;
+  const int qrow = min(q0 + col, g.n1 - 1);
   v4i a[4];
-  int na_part = 0;
 #pragma unroll
-  for (int kb = 0; kb < 4; kb++) { a[kb] = load_frag(d1, q0 + col, n1, kb, hi); na_part += sumsq_i8x16(a[kb]); }
-  const int na_row = na_part + __shfl_xor(na_part, 32);  // |a'|^2 of query q0 + (lane&31)
+  for (int kb = 0; kb < 4; kb++) a[kb] = load_a(d1, qrow, kb, hi);
   int na[16];
 #pragma unroll
-  for (int r = 0; r < 16; r++) na[r] = __shfl(na_row, (r & 3) + 8 * (r >> 2) + 4 * hi);
-
-  const int ntiles = (n2 + 31) >> 5;
-  // ---------------- sweep 1: nearest neighbour ----------------
-  int bd[16], bi[16];
+  for (int r = 0; r < 16; r++) na[r] = norm1[min(q0 + (r & 3) + 8 * (r >> 2) + 4 * hi, g.n1 - 1)];
+  const int ntilesAll = (g.n2 + 31) >> 5;
+  const int tBeg = sp * g.tilesPerSplit, tEnd = min(tBeg + g.tilesPerSplit, ntilesAll);
+  unsigned m1[16], m2[16];
 #pragma unroll
-  for (int r = 0; r < 16; r++) { bd[r] = BIG; bi[r] = BIG; }
-  for (int t = 0; t < ntiles; t++) {
-    const int trow = t * 32 + col;
+  for (int r = 0; r < 16; r++) { m1[r] = UBIG; m2[r] = UBIG; }
+  if (tBeg < tEnd) stage_tile(d2, g.n2, tBeg, tileBuf[0], tid);
+  __syncthreads();
+  for (int t = tBeg; t < tEnd; t++) {
+    const int cur = (t - tBeg) & 1;
+    v4i nxt = {0, 0, 0, 0};
+    if (t + 1 < tEnd) nxt = fetch_tile(d2, g.n2, t + 1, tid);
     v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int nb_part = 0;
 #pragma unroll
-    for (int kb = 0; kb < 4; kb++) {
-      const v4i b = load_frag(d2, trow, n2, kb, hi);
-      nb_part += sumsq_i8x16(b);
-      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], b, acc, 0, 0, 0);
-    }
-    const int nb = nb_part + __shfl_xor(nb_part, 32);
-    if (trow < n2) {
+    for (int kb = 0; kb < 4; kb++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], read_b(tileBuf[cur], col, kb, hi), acc, 0, 0, 0);
+    const int trow = t * 32 + col;
+    if (trow < g.n2) {
+      const int nb = norm2[trow];
+      const unsigned lt = (unsigned)(t - tBeg);
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const int d = na[r] + nb - 2 * acc[r];
-        if (d < bd[r]) { bd[r] = d; bi[r] = trow; }  // tiles ascend, so a tie keeps the lower index
+        const unsigned d = (unsigned)(na[r] + nb - 2 * acc[r]);
+        const unsigned key = (d << 9) | lt;
+        const unsigned hi2 = max(m1[r], key);
+        m1[r] = min(m1[r], key);
+        m2[r] = min(m2[r], hi2);
       }
     }
+    if (t + 1 < tEnd) put_tile(nxt, tileBuf[cur ^ 1], tid);
+    __syncthreads();
   }
-  // reduce over the 32 lanes that share the same rows (same hi): lexicographic min
+  // unpack and merge the per-lane top-2 over the 32 lanes that hold the same rows
 #pragma unroll
   for (int r = 0; r < 16; r++) {
+    int d0 = m1[r] == UBIG ? BIG : (int)(m1[r] >> 9), i0 = m1[r] == UBIG ? BIG : (tBeg + (int)(m1[r] & 511)) * 32 + col;
+    int dd1 = m2[r] == UBIG ? BIG : (int)(m2[r] >> 9), i1 = m2[r] == UBIG ? BIG : (tBeg + (int)(m2[r] & 511)) * 32 + col;
 #pragma unroll
     for (int m = 16; m >= 1; m >>= 1) {
-      const int od = __shfl_xor(bd[r], m), oi = __shfl_xor(bi[r], m);
-      if (lex_less(od, oi, bd[r], bi[r])) { bd[r] = od; bi[r] = oi; }
-    }
-  }
-  // ---------------- per-row threshold and NN0 position ----------------
-  int dmin[16];
-#pragma unroll
-  for (int r = 0; r < 16; r++) dmin[r] = (bi[r] == BIG) ? BIG : ratio_dmin(bd[r], sqminratio);
-  // ---------------- sweep 2 ----------------
-  int d1v[16], i1v[16], djv[16], ijv[16], nless[16], nbad[16];
-#pragma unroll
-  for (int r = 0; r < 16; r++) { d1v[r] = BIG; i1v[r] = BIG; djv[r] = BIG; ijv[r] = BIG; nless[r] = 0; nbad[r] = 0; }
-  for (int t = 0; t < ntiles; t++) {
-    const int trow = t * 32 + col;
-    v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int nb_part = 0;
-#pragma unroll
-    for (int kb = 0; kb < 4; kb++) {
-      const v4i b = load_frag(d2, trow, n2, kb, hi);
-      nb_part += sumsq_i8x16(b);
-      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], b, acc, 0, 0, 0);
-    }
-    const int nb = nb_part + __shfl_xor(nb_part, 32);
-    if (trow < n2) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int d = na[r] + nb - 2 * acc[r];
-        if (trow != bi[r]) {
-          if (d < d1v[r]) { d1v[r] = d; i1v[r] = trow; }
-          if (d < dmin[r]) {
-            nless[r]++;
-            // rare path: geometric consistency with NN0 (distanceSq, matching.cpp:174-179), f64
-            const double dx = pos2[2 * bi[r]] - pos2[2 * trow], dy = pos2[2 * bi[r] + 1] - pos2[2 * trow + 1];
-            if (dx * dx + dy * dy > contrDistSq) nbad[r]++;
-          } else if (d < djv[r]) { djv[r] = d; ijv[r] = trow; }
-        }
+      const int od0 = __shfl_xor(d0, m), oi0 = __shfl_xor(i0, m), od1 = __shfl_xor(dd1, m), oi1 = __shfl_xor(i1, m);
+      // merge two sorted pairs (d0,i0)<=(dd1,i1) and (od0,oi0)<=(od1,oi1)
+      if (lex_less(od0, oi0, d0, i0)) {
+        // other's best wins; second = min(mine best, other's second)
+        if (lex_less(od1, oi1, d0, i0)) { dd1 = od1; i1 = oi1; } else { dd1 = d0; i1 = i0; }
+        d0 = od0; i0 = oi0;
+      } else {
+        if (lex_less(od0, oi0, dd1, i1)) { dd1 = od0; i1 = oi0; }
       }
     }
-  }
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) {
-      int od = __shfl_xor(d1v[r], m), oi = __shfl_xor(i1v[r], m);
-      if (lex_less(od, oi, d1v[r], i1v[r])) { d1v[r] = od; i1v[r] = oi; }
-      od = __shfl_xor(djv[r], m); oi = __shfl_xor(ijv[r], m);
-      if (lex_less(od, oi, djv[r], ijv[r])) { djv[r] = od; ijv[r] = oi; }
-      nless[r] += __shfl_xor(nless[r], m);
-      nbad[r] += __shfl_xor(nbad[r], m);
-    }
-  }
-  if (col == 0) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
+    if (col == 0) {
       const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (q < n1) {
-        MatchRow o;
-        o.t0 = bi[r] == BIG ? -1 : bi[r];
-        o.t1 = i1v[r] == BIG ? -1 : i1v[r];
-        o.tj = ijv[r] == BIG ? -1 : ijv[r];
-        o.nless = nless[r]; o.nbad = nbad[r];
-        o.d0 = (float)bd[r]; o.d1 = (float)d1v[r]; o.dj = (float)djv[r];
-        rows[q] = o;
-      }
+      if (q < g.n1) partial[(size_t)q * g.S + sp] = make_int4(d0, i0, dd1, i1);
     }
   }
 }
 
+// ---------------- decide: merge splits, j = 1 of the walk, compact the undecided queries --------------------
+__global__ __launch_bounds__(256) void k_match_decide(const int4 *partial, MatchGeom g, const double *pos2,
+                                                      double sqminratio, double contrDistSq, MatchRow *rows, int *dmin,
+                                                      int *undecided, int *nUndecided) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= g.n1) return;
+  int d0 = BIG, i0 = BIG, d1 = BIG, i1 = BIG;
+  for (int s = 0; s < g.S; s++) {
+    const int4 p = partial[(size_t)q * g.S + s];
+    if (lex_less(p.x, p.y, d0, i0)) {
+      if (lex_less(p.z, p.w, d0, i0)) { d1 = p.z; i1 = p.w; } else { d1 = d0; i1 = i0; }
+      d0 = p.x; i0 = p.y;
+    } else if (lex_less(p.x, p.y, d1, i1)) { d1 = p.x; i1 = p.y; }
+  }
+  MatchRow o;
+  o.t0 = i0 == BIG ? -1 : i0; o.t1 = i1 == BIG ? -1 : i1; o.tj = -1; o.nless = 0; o.nbad = 0;
+  o.d0 = (float)d0; o.d1 = (float)d1; o.dj = 0.f;
+  int dm = 0;
+  if (i0 != BIG && i1 != BIG) {
+    if (ratio_pass((float)d0, (float)d1, sqminratio)) { o.tj = i1; o.dj = (float)d1; }       // accepted at j = 1
+    else {
+      const double dx = pos2[2 * i0] - pos2[2 * i1], dy = pos2[2 * i0 + 1] - pos2[2 * i1 + 1];
+      if (dx * dx + dy * dy > contrDistSq) o.nbad = 1;                                      // first contradictive
+      else {
+        dm = ratio_dmin(d0, sqminratio);
+        const int slot = atomicAdd(nUndecided, 1);
+        undecided[slot] = q;
+        o.nless = -1;   // filled by sweep 2
+      }
+    }
+  }
+  rows[q] = o;
+  dmin[q] = dm;
+}
+
+// ---------------- sweep 2 over the undecided queries ----------------------------------------------------------
+__global__ __launch_bounds__(256) void k_match_sweep2(const uint8_t *d1, const int *norm1, const uint8_t *d2,
+                                                      const int *norm2, MatchGeom g, const double *pos2,
+                                                      double contrDistSq, const MatchRow *rows, const int *dmin,
+                                                      const int *undecided, const int *nUndecided, int4 *partial2) {
+  __shared__ __attribute__((aligned(16))) unsigned char tileBuf[2][4096];
+  const int nU = *nUndecided;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int col = lane & 31, hi = lane >> 5;
+  const int qb = blockIdx.x, sp = blockIdx.y;
+  if (qb * 128 >= nU) return;
+  const int u0 = qb * 128 + wave * 32;
+  const int qA = undecided[min(u0 + col, nU - 1)];
+  v4i a[4];
+#pragma unroll
+  for (int kb = 0; kb < 4; kb++) a[kb] = load_a(d1, qA, kb, hi);
+  int na[16], dm[16], t0[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int q = undecided[min(u0 + (r & 3) + 8 * (r >> 2) + 4 * hi, nU - 1)];
+    na[r] = norm1[q]; dm[r] = dmin[q]; t0[r] = rows[q].t0;
+  }
+  const int ntilesAll = (g.n2 + 31) >> 5;
+  const int tBeg = sp * g.tilesPerSplit, tEnd = min(tBeg + g.tilesPerSplit, ntilesAll);
+  unsigned mj[16];
+  int nless[16], nbad[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) { mj[r] = UBIG; nless[r] = 0; nbad[r] = 0; }
+  if (tBeg < tEnd) stage_tile(d2, g.n2, tBeg, tileBuf[0], tid);
+  __syncthreads();
+  for (int t = tBeg; t < tEnd; t++) {
+    const int cur = (t - tBeg) & 1;
+    v4i nxt = {0, 0, 0, 0};
+    if (t + 1 < tEnd) nxt = fetch_tile(d2, g.n2, t + 1, tid);
+    v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], read_b(tileBuf[cur], col, kb, hi), acc, 0, 0, 0);
+    const int trow = t * 32 + col;
+    if (trow < g.n2) {
+      const int nb = norm2[trow];
+      const unsigned lt = (unsigned)(t - tBeg);
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int d = na[r] + nb - 2 * acc[r];
+        if (d >= dm[r]) mj[r] = min(mj[r], ((unsigned)d << 9) | lt);
+        else if (trow != t0[r]) {
+          nless[r]++;
+          // rare path: geometric consistency with NN0 (distanceSq, matching.cpp:174-179), f64
+          const double dx = pos2[2 * t0[r]] - pos2[2 * trow], dy = pos2[2 * t0[r] + 1] - pos2[2 * trow + 1];
+          if (dx * dx + dy * dy > contrDistSq) nbad[r]++;
+        }
+      }
+    }
+    if (t + 1 < tEnd) put_tile(nxt, tileBuf[cur ^ 1], tid);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    int dj = mj[r] == UBIG ? BIG : (int)(mj[r] >> 9), ij = mj[r] == UBIG ? BIG : (tBeg + (int)(mj[r] & 511)) * 32 + col;
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+      const int od = __shfl_xor(dj, m), oi = __shfl_xor(ij, m);
+      if (lex_less(od, oi, dj, ij)) { dj = od; ij = oi; }
+      nless[r] += __shfl_xor(nless[r], m);
+      nbad[r] += __shfl_xor(nbad[r], m);
+    }
+    if (col == 0) {
+      const int u = u0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (u < nU) partial2[(size_t)u * g.S + sp] = make_int4(dj, ij, nless[r], nbad[r]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_match_finish(const int4 *partial2, MatchGeom g, const int *undecided,
+                                                      const int *nUndecided, MatchRow *rows) {
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= *nUndecided) return;
+  int dj = BIG, ij = BIG, nless = 0, nbad = 0;
+  for (int s = 0; s < g.S; s++) {
+    const int4 p = partial2[(size_t)u * g.S + s];
+    if (lex_less(p.x, p.y, dj, ij)) { dj = p.x; ij = p.y; }
+    nless += p.z; nbad += p.w;
+  }
+  const int q = undecided[u];
+  MatchRow o = rows[q];
+  o.tj = ij == BIG ? -1 : ij;
+  o.dj = (float)dj;
+  o.nless = nless; o.nbad = nbad;
+  rows[q] = o;
+}
+
+size_t match_workspace_bytes(int n1, int n2, int *S_out, int *tilesPerSplit_out) {
+  const int nQB = (n1 + 127) / 128;
+  const int ntiles = (n2 + 31) / 32;
+  int S = (768 + nQB - 1) / nQB;                 // aim at >= 3 workgroups per CU
+  if (S > ntiles / 4) S = ntiles / 4;           // at least 4 tiles per split
+  if (S < 1) S = 1;
+  int tps = (ntiles + S - 1) / S;
+  if (tps > TILES_PER_SPLIT_MAX) { tps = TILES_PER_SPLIT_MAX; }
+  S = (ntiles + tps - 1) / tps;
+  if (S < 1) S = 1;
+  *S_out = S; *tilesPerSplit_out = tps;
+  size_t bytes = 0;
+  bytes += (size_t)(n1 + n2) * 4 + 256;          // norms
+  bytes += (size_t)n1 * S * 16 * 2 + 256;        // partial, partial2
+  bytes += (size_t)n1 * 4 * 2 + 256;             // dmin, undecided
+  bytes += 256;                                  // counter
+  return bytes;
+}
+
 void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2,
-                  double sqminratio, double contrDistSq, MatchRow *rows) {
+                  double sqminratio, double contrDistSq, MatchRow *rows, void *workspace) {
   if (n1 <= 0 || n2 <= 0) return;
-  const int waves = (n1 + 31) / 32;
-  const int blocks = (waves + 3) / 4;
-  hipLaunchKernelGGL(k_match_fginn, dim3(blocks), dim3(256), 0, s, d1, n1, d2, n2, pos2, sqminratio, contrDistSq, rows);
+  MatchGeom g;
+  g.n1 = n1; g.n2 = n2;
+  match_workspace_bytes(n1, n2, &g.S, &g.tilesPerSplit);
+  char *w = (char *)workspace;
+  auto take = [&](size_t bytes) { char *p = w; w += (bytes + 255) & ~(size_t)255; return p; };
+  int *norm1 = (int *)take((size_t)n1 * 4), *norm2 = (int *)take((size_t)n2 * 4);
+  int4 *partial = (int4 *)take((size_t)n1 * g.S * 16), *partial2 = (int4 *)take((size_t)n1 * g.S * 16);
+  int *dmin = (int *)take((size_t)n1 * 4), *undecided = (int *)take((size_t)n1 * 4);
+  int *counter = (int *)take(64);
+  hipMemsetAsync(counter, 0, 4, s);
+  hipLaunchKernelGGL(k_desc_norms, dim3((n1 + 255) / 256), dim3(256), 0, s, d1, n1, norm1);
+  hipLaunchKernelGGL(k_desc_norms, dim3((n2 + 255) / 256), dim3(256), 0, s, d2, n2, norm2);
+  const dim3 grid((n1 + 127) / 128, g.S);
+  hipLaunchKernelGGL(k_match_sweep1, grid, dim3(256), 0, s, d1, norm1, d2, norm2, g, partial);
+  hipLaunchKernelGGL(k_match_decide, dim3((n1 + 255) / 256), dim3(256), 0, s, partial, g, pos2, sqminratio, contrDistSq,
+                     rows, dmin, undecided, counter);
+  hipLaunchKernelGGL(k_match_sweep2, grid, dim3(256), 0, s, d1, norm1, d2, norm2, g, pos2, contrDistSq, rows, dmin,
+                     undecided, counter, partial2);
+  hipLaunchKernelGGL(k_match_finish, dim3((n1 + 255) / 256), dim3(256), 0, s, partial2, g, undecided, counter, rows);
 }
 
 }  // namespace mx
