@@ -20,8 +20,7 @@ __global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out
   const int lane = threadIdx.x;
   __shared__ float smask[AW_MAX * AW_MAX];
   __shared__ float simg[AW_MAX * AW_MAX];
-  __shared__ float pa[AW_MAX * AW_MAX], pb[AW_MAX * AW_MAX], pc[AW_MAX * AW_MAX];
-  __shared__ float rxs[AW_MAX], rys[AW_MAX];
+  __shared__ __attribute__((aligned(16))) float pa[AW_MAX * AW_MAX + 3], pb[AW_MAX * AW_MAX + 3], pc[AW_MAX * AW_MAX + 3];
   const AffJob jb = jobs[k];
   const int WW = W * W, half = W >> 1;
   for (int i = lane; i < WW; i += 64) smask[i] = mask[i];
@@ -34,20 +33,24 @@ __global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out
   for (l = 0; l < maxIter; l++) {
     const float a11 = u11 * ratio, a12 = u12 * ratio, a21 = u21 * ratio, a22 = u22 * ratio;
     const bool touch = check_borders(jb.cols, jb.rows, lx, ly, a11, a12, a21, a22, W, W);
+    // sample coordinates: lane j runs the f32 running sums of row j (helpers.cpp:563-585) into LDS,
+    // then all lanes take the bilinear taps
     if (lane < W) {
       float rx = lx - (float)half * a12;
       float ry = ly - (float)half * a22;
       for (int j = 0; j < lane; j++) { rx += a12; ry += a22; }
-      rxs[lane] = rx; rys[lane] = ry;
+      float WX = rx - (float)half * a11;
+      float WY = ry - (float)half * a21;
+#pragma unroll 1
+      for (int i = 0; i < W; i++) {
+        pa[lane * W + i] = WX;
+        pb[lane * W + i] = WY;
+        WX += a11;
+        WY += a21;
+      }
     }
     __syncthreads();
-    for (int p = lane; p < WW; p += 64) {
-      const int j = p / W, i = p - j * W;
-      float WX = rxs[j] - (float)half * a11;
-      float WY = rys[j] - (float)half * a21;
-      for (int t = 0; t < i; t++) { WX += a11; WY += a21; }
-      simg[p] = bilinear_tap(jb.blur, jb.rows, jb.cols, WX, WY, touch);
-    }
+    for (int p = lane; p < WW; p += 64) simg[p] = bilinear_tap(jb.blur, jb.rows, jb.cols, pa[p], pb[p], touch);
     __syncthreads();
     for (int p = lane; p < WW; p += 64) {
       const int r = p / W, c = p - r * W;
@@ -68,7 +71,11 @@ __global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out
     float acc = 0.f;
     if (lane < 3) {
       const float *arr = lane == 0 ? pa : (lane == 1 ? pb : pc);
-      for (int i = 0; i < WW; i++) acc += arr[i];
+      const float4 *a4 = reinterpret_cast<const float4 *>(arr);
+      const int full = WW >> 2;
+#pragma unroll 6
+      for (int i = 0; i < full; i++) { const float4 v = a4[i]; acc += v.x; acc += v.y; acc += v.z; acc += v.w; }
+      for (int i = full * 4; i < WW; i++) acc += arr[i];
     }
     float a = __shfl(acc, 0), b = __shfl(acc, 1), c = __shfl(acc, 2);
     a /= (float)WW; b /= (float)WW; c /= (float)WW;

@@ -12,7 +12,7 @@
 
 namespace mx {
 
-constexpr int PS = 41;
+constexpr int PS = 41, PSP = 44;   // PSP: padded row stride so rows start 16-byte aligned in LDS
 
 __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *out, int n, const ImgRef *imgs,
                                                     const float *orimask, const double *atanLut, int doHalf,
@@ -20,51 +20,74 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
   const int k = blockIdx.x;
   if (k >= n) return;
   const int lane = threadIdx.x;
-  __shared__ float patch[PS * PS];
-  __shared__ float wgt[PS * PS];
-  __shared__ int bins[PS * PS];
+  __shared__ __attribute__((aligned(16))) float patch[PS * PS];
+  __shared__ __attribute__((aligned(16))) float bufX[PS * PSP];   // WX, later the histogram weights
+  __shared__ __attribute__((aligned(16))) float bufY[PS * PSP];   // WY
+  __shared__ __attribute__((aligned(16))) unsigned char sbin[PS * PSP];
   __shared__ float hist[40];
   const OriJob jb = jobs[k];
   const ImgRef im = imgs[jb.img];
   const int half = PS >> 1;
   const bool touch = check_borders(im.cols, im.rows, jb.x, jb.y, jb.a11, jb.a12, jb.a21, jb.a22, PS, PS);
+  // sample coordinates: the f32 running sums of interpolate() (helpers.cpp:563-585), one lane per row
   if (lane < PS) {
     float rx = jb.x - (float)half * jb.a12;
     float ry = jb.y - (float)half * jb.a22;
     for (int j = 0; j < lane; j++) { rx += jb.a12; ry += jb.a22; }
     float WX = rx - (float)half * jb.a11;
     float WY = ry - (float)half * jb.a21;
+#pragma unroll 1
     for (int i = 0; i < PS; i++) {
-      patch[lane * PS + i] = bilinear_tap(im.d, im.rows, im.cols, WX, WY, touch);
+      bufX[lane * PSP + i] = WX;
+      bufY[lane * PSP + i] = WY;
       WX += jb.a11;
       WY += jb.a21;
     }
   }
   __syncthreads();
-  const float PIf = float(M_PI);
   for (int p = lane; p < PS * PS; p += 64) {
     const int r = p / PS, c = p - r * PS;
-    int bin = -1;
+    patch[p] = bilinear_tap(im.d, im.rows, im.cols, bufX[r * PSP + c], bufY[r * PSP + c], touch);
+  }
+  __syncthreads();
+  const float PIf = float(M_PI);
+  for (int p = lane; p < PS * PSP; p += 64) {
+    const int r = p / PSP, c = p - r * PSP;
+    unsigned char bin = 255;
     float w = 0.f;
     if (r >= 1 && r < PS - 1 && c >= 1 && c < PS - 1) {
-      const float xg = patch[p + 1] - patch[p - 1];
-      const float yg = patch[p + PS] - patch[p - PS];
+      const int q = r * PS + c;
+      const float xg = patch[q + 1] - patch[q - 1];
+      const float yg = patch[q + PS] - patch[q - PS];
       const float mag = sqrtf(xg * xg + yg * yg);
       const float ori = atan2lut(atanLut, yg, xg);
-      const float m = orimask[p];
+      const float m = orimask[q];
       if (m > 0 && mag > 1.0f) {
-        bin = (int)(36 * (ori / PIf + 1.0f) / 2.0f);
+        bin = (unsigned char)(int)(36 * (ori / PIf + 1.0f) / 2.0f);
         w = mag * m;
       }
     }
-    bins[p] = bin;
-    wgt[p] = w;
+    sbin[p] = bin;
+    bufX[p] = w;
   }
   __syncthreads();
+  // lane b owns histogram bin b and adds its pixels in raster order (f32 running sum of the reference)
   if (lane < 36) {
     float h = 0.f;
-    for (int p = PS; p < PS * (PS - 1); p++)
-      if (bins[p] == lane) h += wgt[p];
+#pragma unroll 1
+    for (int r = 1; r < PS - 1; r++) {
+      const unsigned *b4 = reinterpret_cast<const unsigned *>(sbin + r * PSP);
+      const float4 *w4 = reinterpret_cast<const float4 *>(bufX + r * PSP);
+#pragma unroll
+      for (int g = 0; g < PSP / 4; g++) {
+        const unsigned b = b4[g];
+        const float4 w = w4[g];
+        if ((int)(b & 0xff) == lane) h += w.x;
+        if ((int)((b >> 8) & 0xff) == lane) h += w.y;
+        if ((int)((b >> 16) & 0xff) == lane) h += w.z;
+        if ((int)(b >> 24) == lane) h += w.w;
+      }
+    }
     hist[lane] = h;
   }
   __syncthreads();
