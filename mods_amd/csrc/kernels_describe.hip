@@ -13,6 +13,19 @@
 
 namespace mx {
 
+// Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own L2.  Neighbouring
+// tiles of one window share halo rows/columns, so runs of G consecutive logical tiles are mapped to the same XCD;
+// the runs themselves stay interleaved over the XCDs so that windows of very different cost (ksize grows with the
+// window) remain balanced.  Bijective on [0, n) for the full super-groups; the ragged tail is left as is.
+MX_D int xcd_swizzle(int b, int n) {
+  const int G = 8, SG = 8 * G;
+  const int full = (n / SG) * SG;
+  if (b >= full) return b;
+  const int sg = b / SG, r = b - sg * SG;
+  const int xcd = r & 7, k = r >> 3;      // this block runs on XCD `xcd`; it is that XCD's k-th block of the super-group
+  return sg * SG + xcd * G + k;
+}
+
 MX_D int find_job(const int *prefix, int nJobs, int tile) {
   int lo = 0, hi = nJobs;  // prefix[lo] <= tile < prefix[hi]
   while (hi - lo > 1) {
@@ -27,7 +40,7 @@ MX_D int find_job(const int *prefix, int nJobs, int tile) {
 // f32 running sums); 32-column chunks are transposed through LDS so the stores are row-contiguous.
 __global__ __launch_bounds__(64) void k_patch_sample(const DescJob *jobs, const int *tilePrefix, int nJobs,
                                                      const ImgRef *imgs, float *scratch) {
-  const int tile = blockIdx.x;
+  const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
   const int jid = find_job(tilePrefix, nJobs, tile);
   const DescJob jb = jobs[jid];
   const int P = jb.P;
@@ -70,7 +83,7 @@ __global__ __launch_bounds__(64) void k_patch_sample(const DescJob *jobs, const 
 // pass 1: columns (SymmColumnFilter: centre + (below + above) * k)
 __global__ __launch_bounds__(256) void k_patch_blur(const DescJob *jobs, const int *tilePrefix, int nJobs,
                                                     const float *taps, const float *src, float *dst, int pass) {
-  const int tile = blockIdx.x;
+  const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
   const int jid = find_job(tilePrefix, nJobs, tile);
   const DescJob jb = jobs[jid];
   const int P = jb.P;
