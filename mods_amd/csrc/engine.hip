@@ -165,7 +165,7 @@ void ctx_destroy(modsx_ctx *c) {
   for (int i = 0; i < MAXB; i++) c->pyr[i].store.release();
   DevBuf *bufs[] = {&c->cand, &c->counter, &c->affJobs, &c->affOut, &c->oriJobs, &c->oriOut, &c->descJobs, &c->tilePrefix,
                     &c->taps, &c->imgRefs, &c->scratchA, &c->scratchB, &c->descAllF[0], &c->descAllF[1], &c->descAllU8[0],
-                    &c->descAllU8[1], &c->pos2, &c->matchRows, &c->matchWork, &c->misc, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps};
+                    &c->descAllU8[1], &c->pos2, &c->matchRows, &c->matchWork, &c->misc, &c->scratchC, &c->needTab, &c->coordTab, &c->tileJob, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps};
   for (DevBuf *b : bufs) b->release();
   for (int i = 0; i < MAXB; i++) { c->descF[i].release(); c->descU8[i].release(); }
   PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc};
@@ -670,10 +670,12 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
     size_t done = 0;
     while (done < nr) {
       std::vector<DescJob> jobs;
-      std::vector<int> pfxSample(1, 0), pfxBlur(1, 0);
-      std::vector<float> taps;
-      std::map<int, std::pair<int, int>> tapIdx;  // P -> (offset, ksize)
-      size_t arena = 0;
+      std::vector<int> pfxSample(1, 0), pfxRow(1, 0), pfxCol(1, 0);
+      std::vector<float> taps, coordTab;
+      std::vector<int> needTab;
+      struct PInfo { int tapOfs, ksize, needOfs, NC, coordOfs, touch; };
+      std::map<int, PInfo> pinfo;  // per window size P
+      size_t arenaA = 0, arenaB = 0, arenaC = 0;
       size_t r = done;
       for (; r < nr; r++) {
         const modsx_keypoint &k = regs[i][r].det_kp;
@@ -688,22 +690,66 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
           j.i2p = i2p;
           if (i2p > 0.4) {
             patchImageSize += 2;
-            size_t need = (size_t)patchImageSize * patchImageSize;
-            if (arena + need > ARENA_FLOATS && !jobs.empty()) break;
-            j.P = patchImageSize;
-            j.a11 = (float)k.a11; j.a12 = (float)k.a12; j.a21 = (float)k.a21; j.a22 = (float)k.a22;
-            j.scratchOfs = arena;
-            arena += need;
-            auto it = tapIdx.find(patchImageSize);
-            if (it == tapIdx.end()) {
+            const int P = patchImageSize;
+            auto it = pinfo.find(P);
+            if (it == pinfo.end()) {
+              PInfo pi;
               float sigma = 1.5f * i2p;
-              int ks = blur_ksize(sigma);
-              if (ks > patchImageSize * 2 + 1) ks = ks;  // replicate border handles any ksize
-              std::vector<float> kk = gaussian_kernel(ks, sigma);
-              it = tapIdx.insert({patchImageSize, {(int)taps.size(), ks}}).first;
+              pi.ksize = blur_ksize(sigma);
+              std::vector<float> kk = gaussian_kernel(pi.ksize, sigma);
+              pi.tapOfs = (int)taps.size();
               taps.insert(taps.end(), kk.begin(), kk.end());
+              // coordinates of interpolate(smoothed, P/2, P/2, i2p, 0, 0, i2p, patch41): f32 running sums
+              // (helpers.cpp:563-585); rows and columns run the same recurrence (a12 = a21 = 0, ofsx = ofsy)
+              const float o = (float)(P >> 1);
+              pi.touch = check_borders_host(P, P, o, o, i2p, 0.f, 0.f, i2p, 41, 41) ? 1 : 0;
+              float W[41];
+              {
+                float rx = o - (float)20 * 0.f;
+                float WX = rx - (float)20 * i2p;
+                for (int q = 0; q < 41; q++) { W[q] = WX; WX += i2p; }
+              }
+              int x0[41], valid[41];
+              std::vector<int> need;
+              for (int q = 0; q < 41; q++) {
+                if (!pi.touch) {
+                  int x = (int)W[q];
+                  x = x < 0 ? 0 : (x > P - 2 ? P - 2 : x);
+                  x0[q] = x; valid[q] = 1;
+                } else {
+                  int x = (int)floorf(W[q]);
+                  valid[q] = (W[q] >= 0 && x < P - 1) ? 1 : 0;
+                  x0[q] = valid[q] ? x : 0;
+                }
+                if (valid[q]) { need.push_back(x0[q]); need.push_back(x0[q] + 1); }
+              }
+              std::sort(need.begin(), need.end());
+              need.erase(std::unique(need.begin(), need.end()), need.end());
+              if (need.empty()) need.push_back(0);
+              pi.NC = (int)need.size();
+              pi.needOfs = (int)needTab.size();
+              needTab.insert(needTab.end(), need.begin(), need.end());
+              for (int q = 0; q < 41; q++) {
+                int i0 = 0, i1 = 0;
+                if (valid[q]) {
+                  i0 = (int)(std::lower_bound(need.begin(), need.end(), x0[q]) - need.begin());
+                  i1 = (int)(std::lower_bound(need.begin(), need.end(), x0[q] + 1) - need.begin());
+                }
+                needTab.push_back(i0); needTab.push_back(i1); needTab.push_back(x0[q]); needTab.push_back(valid[q]);
+              }
+              pi.coordOfs = (int)coordTab.size();
+              coordTab.insert(coordTab.end(), W, W + 41);
+              it = pinfo.insert({P, pi}).first;
             }
-            j.tapOfs = it->second.first; j.ksize = it->second.second;
+            const PInfo &pi = it->second;
+            size_t needA = (size_t)P * P;
+            if (arenaA + needA > ARENA_FLOATS && !jobs.empty()) break;
+            j.P = P;
+            j.a11 = (float)k.a11; j.a12 = (float)k.a12; j.a21 = (float)k.a21; j.a22 = (float)k.a22;
+            j.tapOfs = pi.tapOfs; j.ksize = pi.ksize; j.NC = pi.NC; j.needOfs = pi.needOfs; j.coordOfs = pi.coordOfs;
+            j.touch = pi.touch;
+            j.scratchOfs = arenaA; j.rowOfs = arenaB; j.gridOfs = arenaC;
+            arenaA += needA; arenaB += (size_t)P * pi.NC; arenaC += (size_t)pi.NC * pi.NC;
           } else {
             j.P = 0;
             j.a11 = (float)k.a11 * i2p; j.a12 = (float)k.a12 * i2p; j.a21 = (float)k.a21 * i2p; j.a22 = (float)k.a22 * i2p;
@@ -718,30 +764,41 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
         }
         jobs.push_back(j);
         pfxSample.push_back(pfxSample.back() + (j.P > 0 ? (j.P + 63) / 64 : 0));
-        pfxBlur.push_back(pfxBlur.back() + (j.P > 0 ? (j.P * j.P + 255) / 256 : 0));
+        pfxRow.push_back(pfxRow.back() + (j.P > 0 ? (j.P * j.NC + 255) / 256 : 0));
+        pfxCol.push_back(pfxCol.back() + (j.P > 0 ? (j.NC * j.NC + 255) / 256 : 0));
       }
       const size_t nj = jobs.size();
-      if (!c->descJobs.ensure(nj * sizeof(DescJob)) || !c->tilePrefix.ensure((nj + 1) * 8) ||
-          !c->taps.ensure(std::max<size_t>(1, taps.size()) * 4) || !c->scratchA.ensure(std::max<size_t>(1, arena) * 4) ||
-          !c->scratchB.ensure(std::max<size_t>(1, arena) * 4))
+      if (!c->descJobs.ensure(nj * sizeof(DescJob)) || !c->tilePrefix.ensure((nj + 1) * 12) ||
+          !c->taps.ensure(std::max<size_t>(1, taps.size()) * 4) || !c->needTab.ensure(std::max<size_t>(1, needTab.size()) * 4) ||
+          !c->coordTab.ensure(std::max<size_t>(1, coordTab.size()) * 4) ||
+          !c->scratchA.ensure(std::max<size_t>(1, arenaA) * 4) || !c->scratchB.ensure(std::max<size_t>(1, arenaB) * 4) ||
+          !c->scratchC.ensure(std::max<size_t>(1, arenaC) * 4) ||
+          !c->tileJob.ensure(((size_t)pfxSample.back() + pfxRow.back() + pfxCol.back() + 3) * 4))
         return MODSX_ERR_NOMEM;
-      int *dPfxS = (int *)c->tilePrefix.p, *dPfxB = dPfxS + (nj + 1);
+      int *tjS = (int *)c->tileJob.p, *tjR = tjS + pfxSample.back(), *tjC = tjR + pfxRow.back();
+      int *dPfxS = (int *)c->tilePrefix.p, *dPfxR = dPfxS + (nj + 1), *dPfxC = dPfxR + (nj + 1);
       MX_HIP(hipMemcpyAsync(c->descJobs.p, jobs.data(), nj * sizeof(DescJob), hipMemcpyHostToDevice, s));
       MX_HIP(hipMemcpyAsync(dPfxS, pfxSample.data(), (nj + 1) * 4, hipMemcpyHostToDevice, s));
-      MX_HIP(hipMemcpyAsync(dPfxB, pfxBlur.data(), (nj + 1) * 4, hipMemcpyHostToDevice, s));
+      MX_HIP(hipMemcpyAsync(dPfxR, pfxRow.data(), (nj + 1) * 4, hipMemcpyHostToDevice, s));
+      MX_HIP(hipMemcpyAsync(dPfxC, pfxCol.data(), (nj + 1) * 4, hipMemcpyHostToDevice, s));
       if (!taps.empty()) MX_HIP(hipMemcpyAsync(c->taps.p, taps.data(), taps.size() * 4, hipMemcpyHostToDevice, s));
+      if (!needTab.empty()) MX_HIP(hipMemcpyAsync(c->needTab.p, needTab.data(), needTab.size() * 4, hipMemcpyHostToDevice, s));
+      if (!coordTab.empty()) MX_HIP(hipMemcpyAsync(c->coordTab.p, coordTab.data(), coordTab.size() * 4, hipMemcpyHostToDevice, s));
       const DescJob *dj = (const DescJob *)c->descJobs.p;
-      { ProfScope ps(c, K_PATCH_SAMPLE, (double)arena * 8);
-        launch_patch_sample(s, dj, dPfxS, (int)nj, pfxSample.back(), (ImgRef *)c->imgRefs.p, (float *)c->scratchA.p); }
-      { ProfScope ps(c, K_PATCH_BLUR, (double)arena * 8);
-        launch_patch_blur(s, dj, dPfxB, (int)nj, pfxBlur.back(), (float *)c->taps.p, (float *)c->scratchA.p,
+      launch_expand_tiles(s, dPfxS, (int)nj, tjS);
+      launch_expand_tiles(s, dPfxR, (int)nj, tjR);
+      launch_expand_tiles(s, dPfxC, (int)nj, tjC);
+      { ProfScope ps(c, K_PATCH_SAMPLE, (double)arenaA * 8);
+        launch_patch_sample(s, dj, dPfxS, tjS, pfxSample.back(), (ImgRef *)c->imgRefs.p, (float *)c->scratchA.p); }
+      { ProfScope ps(c, K_PATCH_BLUR, ((double)arenaA + arenaB) * 4);
+        launch_patch_blur(s, dj, dPfxR, tjR, pfxRow.back(), (float *)c->taps.p, (int *)c->needTab.p, (float *)c->scratchA.p,
                           (float *)c->scratchB.p, 0); }
-      { ProfScope ps(c, K_PATCH_BLUR, (double)arena * 8);
-        launch_patch_blur(s, dj, dPfxB, (int)nj, pfxBlur.back(), (float *)c->taps.p, (float *)c->scratchB.p,
-                          (float *)c->scratchA.p, 1); }
-      ProfScope psd(c, K_DESCRIBE, (double)nj * (41 * 41 * 4 + 128 * 5));
-      launch_describe(s, dj, (int)nj, (ImgRef *)c->imgRefs.p, (float *)c->scratchA.p, c->dSiftMask, c->dSiftMaskIdx,
-                      c->nSiftMask, c->dAtan,
+      { ProfScope ps(c, K_PATCH_BLUR, ((double)arenaB + arenaC) * 4);
+        launch_patch_blur(s, dj, dPfxC, tjC, pfxCol.back(), (float *)c->taps.p, (int *)c->needTab.p, (float *)c->scratchB.p,
+                          (float *)c->scratchC.p, 1); }
+      ProfScope psd(c, K_DESCRIBE, (double)arenaC * 4 + (double)nj * (128 * 5));
+      launch_describe(s, dj, (int)nj, (ImgRef *)c->imgRefs.p, (float *)c->scratchC.p, (int *)c->needTab.p, (float *)c->coordTab.p,
+                      c->dSiftMask, c->dSiftMaskIdx, c->nSiftMask, c->dAtan,
                       c->dSiftBins, c->dSiftW, photoNorm, descType == MODSX_DESC_ROOT_SIFT, maxBin,
                       outF + done * 128, outU8 + done * 128);
       MX_HIP(hipStreamSynchronize(s));  // jobs/taps/prefix are host vectors reused by the next chunk

@@ -74,7 +74,13 @@ struct DescJob {
   int tapOfs;         // offset into the tap table
   float x, y, a11, a12, a21, a22;   // direct mode: A * imageToPatchScale
   float i2p;          // imageToPatchScale
-  unsigned long long scratchOfs;    // float offset of this region's (P x P) scratch
+  int NC;             // number of window columns (= rows) the 41x41 resampling reads (<= 82)
+  int needOfs;        // offset into the int table: NC needed indices, then 41 x {idx of x0, idx of x0+1, valid}
+  int coordOfs;       // offset into the float table: 41 sample coordinates WX_i (= WY_j)
+  int touch;          // interpolate()'s border branch for the 41x41 resampling
+  unsigned long long scratchOfs;    // float offset of this region's P x P window (arena A)
+  unsigned long long rowOfs;        // float offset of its P x NC row-filtered block (arena B)
+  unsigned long long gridOfs;       // float offset of its NC x NC blurred grid (arena C)
 };
 struct ImgRef { const float *d; int rows, cols, pad; };
 
@@ -151,11 +157,13 @@ void launch_baumberg(hipStream_t s, const AffJob *jobs, AffOut *out, int n, cons
                      float convTh, float affInitialSigma);
 void launch_orientation(hipStream_t s, const OriJob *jobs, OriOut *out, int n, const ImgRef *imgs, const float *orimask,
                         const double *atanLut, int doHalf, double th, int maxAngles);
-void launch_patch_sample(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, int nTiles,
+void launch_expand_tiles(hipStream_t s, const int *prefix, int nJobs, int *tileJob);
+void launch_patch_sample(hipStream_t s, const DescJob *jobs, const int *tilePrefix, const int *tileJob, int nTiles,
                          const ImgRef *imgs, float *scratch);
-void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, int nTiles,
-                       const float *taps, const float *src, float *dst, int pass);
-void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *imgs, const float *scratch,
+void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix, const int *tileJob, int nTiles,
+                       const float *taps, const int *needTab, const float *src, float *dst, int pass);
+void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *imgs, const float *grid,
+                     const int *needTab, const float *coordTab,
                      const float *mask, const unsigned short *maskIdx, int nmask, const double *atanLut, const int *bins,
                      const double *wts, int photoNorm, int rootsift, double maxBin, float *descF, uint8_t *descU8);
 void launch_warp_affine(hipStream_t s, const WarpJob &jb);
@@ -191,7 +199,7 @@ struct modsx_ctx {
   hipStream_t stream;
   mx::Pyramid pyr[mx::MAXB];
   mx::DevBuf cand, counter, affJobs, affOut, oriJobs, oriOut, descJobs, tilePrefix, taps, imgRefs, scratchA, scratchB,
-      descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps;
+      descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps, scratchC, needTab, coordTab, tileJob;
   mx::PinBuf hCand, hAff, hOri, hDesc, hMisc;
   // constant tables on device
   float *dSmmMask = nullptr;   // 19x19 computeGaussMask

@@ -26,22 +26,22 @@ MX_D int xcd_swizzle(int b, int n) {
   return sg * SG + xcd * G + k;
 }
 
-MX_D int find_job(const int *prefix, int nJobs, int tile) {
-  int lo = 0, hi = nJobs;  // prefix[lo] <= tile < prefix[hi]
-  while (hi - lo > 1) {
-    int mid = (lo + hi) >> 1;
-    if (prefix[mid] <= tile) lo = mid; else hi = mid;
-  }
-  return lo;
+// tile -> job table: a per-workgroup binary search over the prefix array costs ~12 dependent L2 round trips,
+// longer than the useful work of a 256-element tile, so the prefix array is expanded once per launch set
+__global__ __launch_bounds__(64) void k_expand_tiles(const int *prefix, int nJobs, int *tileJob) {
+  const int j = blockIdx.x;
+  if (j >= nJobs) return;
+  const int b = prefix[j], e = prefix[j + 1];
+  for (int t = b + threadIdx.x; t < e; t += 64) tileJob[t] = j;
 }
 
 // --- stage 1: interpolate(img, x, y, A, smoothed(P x P)) ---------------------------------------
 // One wavefront per 64 rows of one window.  Lane j walks row j left to right (sample coordinates are
 // f32 running sums); 32-column chunks are transposed through LDS so the stores are row-contiguous.
-__global__ __launch_bounds__(64) void k_patch_sample(const DescJob *jobs, const int *tilePrefix, int nJobs,
+__global__ __launch_bounds__(64) void k_patch_sample(const DescJob *jobs, const int *tilePrefix, const int *tileJob,
                                                      const ImgRef *imgs, float *scratch) {
   const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int jid = find_job(tilePrefix, nJobs, tile);
+  const int jid = tileJob[tile];
   const DescJob jb = jobs[jid];
   const int P = jb.P;
   if (P <= 0) return;
@@ -79,26 +79,32 @@ __global__ __launch_bounds__(64) void k_patch_sample(const DescJob *jobs, const 
 }
 
 // --- stage 2: separable Gaussian blur of each window, replicate border -------------------------
-// pass 0: rows (cv RowFilter: taps left->right; SymmRowSmallFilter when ksize <= 5)
-// pass 1: columns (SymmColumnFilter: centre + (below + above) * k)
-__global__ __launch_bounds__(256) void k_patch_blur(const DescJob *jobs, const int *tilePrefix, int nJobs,
-                                                    const float *taps, const float *src, float *dst, int pass) {
+// The 41x41 resampling of stage 3 reads the blurred window only at NC <= 82 columns and the same NC rows
+// (x0_i, x0_i + 1 for the 41 sample coordinates), so
+//   pass 0 filters the rows only at those columns:      P x NC outputs   (cv RowFilter order: taps left->right;
+//                                                                         SymmRowSmallFilter when ksize <= 5)
+//   pass 1 filters the columns only at those rows:      NC x NC outputs  (SymmColumnFilter: centre + (below+above)*k)
+// Every output is the same sum of the same terms in the same order as in the full blur.
+__global__ __launch_bounds__(256) void k_patch_blur(const DescJob *jobs, const int *tilePrefix, const int *tileJob,
+                                                    const float *taps, const int *needTab, const float *src,
+                                                    float *dst, int pass) {
   const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int jid = find_job(tilePrefix, nJobs, tile);
+  const int jid = tileJob[tile];
   const DescJob jb = jobs[jid];
-  const int P = jb.P;
+  const int P = jb.P, NC = jb.NC;
   if (P <= 0) return;
-  const int px = (tile - tilePrefix[jid]) * 256 + threadIdx.x;
-  if (px >= P * P) return;
-  const int r = px / P, c = px - r * P;
+  const int e = (tile - tilePrefix[jid]) * 256 + threadIdx.x;
   const int n = jb.ksize, R = n >> 1;
   const float *k = taps + jb.tapOfs;
-  const float *S = src + jb.scratchOfs;
-  float v;
-  if (n == 1) v = S[px];
-  else if (pass == 0) {
-    const float *row = S + (size_t)r * P;
-    if (n <= 5) {
+  const int *need = needTab + jb.needOfs;
+  if (pass == 0) {
+    if (e >= P * NC) return;
+    const int r = e / NC, ci = e - r * NC;
+    const int c = need[ci];
+    const float *row = src + jb.scratchOfs + (size_t)r * P;
+    float v;
+    if (n == 1) v = row[c];
+    else if (n <= 5) {
       v = row[c] * k[R];
       for (int j = 1; j <= R; j++) {
         int cm = c - j < 0 ? 0 : c - j, cp = c + j > P - 1 ? P - 1 : c + j;
@@ -112,14 +118,23 @@ __global__ __launch_bounds__(256) void k_patch_blur(const DescJob *jobs, const i
         v = v + row[cc] * k[j];
       }
     }
+    dst[jb.rowOfs + e] = v;
   } else {
-    v = k[R] * S[px] + 0.f;
-    for (int j = 1; j <= R; j++) {
-      int rp = r + j > P - 1 ? P - 1 : r + j, rm = r - j < 0 ? 0 : r - j;
-      v = v + k[R + j] * (S[(size_t)rp * P + c] + S[(size_t)rm * P + c]);
+    if (e >= NC * NC) return;
+    const int ri = e / NC, ci = e - ri * NC;
+    const int r = need[ri];
+    const float *S = src + jb.rowOfs;   // P x NC
+    float v;
+    if (n == 1) v = S[(size_t)r * NC + ci];
+    else {
+      v = k[R] * S[(size_t)r * NC + ci] + 0.f;
+      for (int j = 1; j <= R; j++) {
+        int rp = r + j > P - 1 ? P - 1 : r + j, rm = r - j < 0 ? 0 : r - j;
+        v = v + k[R + j] * (S[(size_t)rp * NC + ci] + S[(size_t)rm * NC + ci]);
+      }
     }
+    dst[jb.gridOfs + e] = v;
   }
-  dst[jb.scratchOfs + px] = v;
 }
 
 // --- stage 3: 41x41 patch, photometric normalisation, SIFT histogram ----------------------------
@@ -141,7 +156,8 @@ struct SiftConst {
   int nmask;   // number of pixels with mask > 0
 };
 
-__global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, const ImgRef *imgs, const float *scratch,
+__global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, const ImgRef *imgs, const float *grid,
+                                                  const int *needTab, const float *coordTab,
                                                   const float *mask, const unsigned short *maskIdx,
                                                   const double *atanLut, const int *binTab, const double *wTab,
                                                   SiftConst sc, int photoNorm, int rootsift, double maxBin,
@@ -166,37 +182,55 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
     swr0[tid] = (float)wTab[tid]; swr1[tid] = (float)wTab[PS + tid];   // const float wr0 = w0[r] (siftdesc.cpp:79-81)
     swc0[tid] = wTab[tid]; swc1[tid] = wTab[PS + tid];
   }
-  // -- sample coordinates (interpolate(), helpers.cpp:563-585)
-  const float *src; int srows, scols; float ox, oy, a11, a12, a21, a22;
   if (jb.P > 0) {
-    src = scratch + jb.scratchOfs; srows = jb.P; scols = jb.P;
-    ox = (float)(jb.P >> 1); oy = ox;
-    a11 = jb.i2p; a12 = 0.f; a21 = 0.f; a22 = jb.i2p;
-  } else {
-    const ImgRef im = imgs[jb.img];
-    src = im.d; srows = im.rows; scols = im.cols;
-    ox = jb.x; oy = jb.y; a11 = jb.a11; a12 = jb.a12; a21 = jb.a21; a22 = jb.a22;
-  }
-  const bool touch = check_borders(scols, srows, ox, oy, a11, a12, a21, a22, PS, PS);
-  if (tid < PS) {
-    const int half = PS >> 1;
-    float rx = ox - (float)half * a12;
-    float ry = oy - (float)half * a22;
-    for (int j = 0; j < tid; j++) { rx += a12; ry += a22; }
-    float WX = rx - (float)half * a11;
-    float WY = ry - (float)half * a21;
-#pragma unroll 1
-    for (int i = 0; i < PS; i++) {
-      bufA[tid * PSP + i] = WX;
-      bufB[tid * PSP + i] = WY;
-      WX += a11;
-      WY += a21;
+    // interpolate(smoothed, P/2, P/2, i2p, 0, 0, i2p, patch) (synth-detection.hpp:211-212) on the compact blurred grid:
+    // the host ran the coordinate recurrences once per window size; sample (j, i) blends grid rows idx(y0_j), idx(y0_j+1)
+    // and columns idx(x0_i), idx(x0_i+1) with wx = WX_i - x0_i, wy = WY_j - y0_j -- the expression of helpers.cpp:575-577.
+    const float *G = grid + jb.gridOfs;
+    const int NC = jb.NC;
+    const int *need = needTab + jb.needOfs;
+    const int *map = need + NC;          // 41 x {idx0, idx1, x0, valid}
+    const float *W = coordTab + jb.coordOfs;
+    for (int p = tid; p < NPX; p += 128) {
+      const int r = p / PS, c = p - r * PS;
+      float v = 0.f;
+      if (map[4 * r + 3] && map[4 * c + 3]) {
+        const int y0 = map[4 * r], y1 = map[4 * r + 1], x0 = map[4 * c], x1 = map[4 * c + 1];
+        const float wx = W[c] - (float)map[4 * c + 2];
+        const float wyd = W[r] - (float)map[4 * r + 2];
+        const float *R0 = G + (size_t)y0 * NC, *R1 = G + (size_t)y1 * NC;
+        const float I1 = wx * (R0[x1] - R0[x0]) + R0[x0];
+        v = wyd * (wx * (R1[x1] - R1[x0]) + R1[x0] - I1) + I1;
+      }
+      patch[p] = v;
     }
-  }
-  __syncthreads();
-  for (int p = tid; p < NPX; p += 128) {
-    const int r = p / PS, c = p - r * PS;
-    patch[p] = bilinear_tap(src, srows, scols, bufA[r * PSP + c], bufB[r * PSP + c], touch);
+  } else {
+    // -- direct branch (imageToPatchScale <= 0.4 or fast extraction): interpolate() straight from the view
+    const ImgRef im = imgs[jb.img];
+    const float *src = im.d;
+    const int srows = im.rows, scols = im.cols;
+    const float ox = jb.x, oy = jb.y, a11 = jb.a11, a12 = jb.a12, a21 = jb.a21, a22 = jb.a22;
+    const bool touch = check_borders(scols, srows, ox, oy, a11, a12, a21, a22, PS, PS);
+    if (tid < PS) {
+      const int half = PS >> 1;
+      float rx = ox - (float)half * a12;
+      float ry = oy - (float)half * a22;
+      for (int j = 0; j < tid; j++) { rx += a12; ry += a22; }
+      float WX = rx - (float)half * a11;
+      float WY = ry - (float)half * a21;
+#pragma unroll 1
+      for (int i = 0; i < PS; i++) {
+        bufA[tid * PSP + i] = WX;
+        bufB[tid * PSP + i] = WY;
+        WX += a11;
+        WY += a21;
+      }
+    }
+    __syncthreads();
+    for (int p = tid; p < NPX; p += 128) {
+      const int r = p / PS, c = p - r * PS;
+      patch[p] = bilinear_tap(src, srows, scols, bufA[r * PSP + c], bufB[r * PSP + c], touch);
+    }
   }
   __syncthreads();
   // -- photometricallyNormalize (helpers.cpp:666-715): f32 running sums over the masked pixels
@@ -346,23 +380,28 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
   }
 }
 
-void launch_patch_sample(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, int nTiles,
+void launch_expand_tiles(hipStream_t s, const int *prefix, int nJobs, int *tileJob) {
+  if (nJobs <= 0) return;
+  hipLaunchKernelGGL(k_expand_tiles, dim3(nJobs), dim3(64), 0, s, prefix, nJobs, tileJob);
+}
+void launch_patch_sample(hipStream_t s, const DescJob *jobs, const int *tilePrefix, const int *tileJob, int nTiles,
                          const ImgRef *imgs, float *scratch) {
   if (nTiles <= 0) return;
-  hipLaunchKernelGGL(k_patch_sample, dim3(nTiles), dim3(64), 0, s, jobs, tilePrefix, nJobs, imgs, scratch);
+  hipLaunchKernelGGL(k_patch_sample, dim3(nTiles), dim3(64), 0, s, jobs, tilePrefix, tileJob, imgs, scratch);
 }
-void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, int nTiles,
-                       const float *taps, const float *src, float *dst, int pass) {
+void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix, const int *tileJob, int nTiles,
+                       const float *taps, const int *needTab, const float *src, float *dst, int pass) {
   if (nTiles <= 0) return;
-  hipLaunchKernelGGL(k_patch_blur, dim3(nTiles), dim3(256), 0, s, jobs, tilePrefix, nJobs, taps, src, dst, pass);
+  hipLaunchKernelGGL(k_patch_blur, dim3(nTiles), dim3(256), 0, s, jobs, tilePrefix, tileJob, taps, needTab, src, dst, pass);
 }
-void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *imgs, const float *scratch,
-                     const float *mask, const unsigned short *maskIdx, int nmask, const double *atanLut, const int *bins,
+void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *imgs, const float *grid,
+                     const int *needTab, const float *coordTab, const float *mask, const unsigned short *maskIdx, int nmask, const double *atanLut, const int *bins,
                      const double *wts, int photoNorm, int rootsift, double maxBin, float *descF, uint8_t *descU8) {
   if (n <= 0) return;
   SiftConst sc;
   sc.nmask = nmask;
-  hipLaunchKernelGGL(k_describe, dim3(n), dim3(128), 0, s, jobs, n, imgs, scratch, mask, maskIdx, atanLut, bins, wts, sc,
+  hipLaunchKernelGGL(k_describe, dim3(n), dim3(128), 0, s, jobs, n, imgs, grid, needTab, coordTab, mask, maskIdx, atanLut, bins,
+                     wts, sc,
                      photoNorm, rootsift, maxBin, descF, descU8);
 }
 
