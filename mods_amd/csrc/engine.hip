@@ -763,7 +763,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
           j.a11 = (float)k.a11 * curr_sc; j.a12 = (float)k.a12 * curr_sc; j.a21 = (float)k.a21 * curr_sc; j.a22 = (float)k.a22 * curr_sc;
         }
         jobs.push_back(j);
-        pfxSample.push_back(pfxSample.back() + (j.P > 0 ? (j.P + 63) / 64 : 0));
+        pfxSample.push_back(pfxSample.back() + (j.P > 0 ? ((j.P + 63) / 64) * ((j.P + 127) / 128) : 0));  // 64 x SAMPLE_COLS tiles
         pfxRow.push_back(pfxRow.back() + (j.P > 0 ? (j.P * j.NC + 255) / 256 : 0));
         pfxCol.push_back(pfxCol.back() + (j.P > 0 ? (j.NC * j.NC + 255) / 256 : 0));
       }

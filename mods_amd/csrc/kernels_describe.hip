@@ -36,8 +36,13 @@ __global__ __launch_bounds__(64) void k_expand_tiles(const int *prefix, int nJob
 }
 
 // --- stage 1: interpolate(img, x, y, A, smoothed(P x P)) ---------------------------------------
-// One wavefront per 64 rows of one window.  Lane j walks row j left to right (sample coordinates are
-// f32 running sums); 32-column chunks are transposed through LDS so the stores are row-contiguous.
+// One wavefront per tile of 64 rows x SAMPLE_COLS columns of one window.  Lane j owns row j: it runs the f32
+// running sums of interpolate() (rx += a12 per row, WX += a11 per column -- cheap dependent adds) up to the
+// tile's first column and then walks the tile left to right; 32-column chunks are transposed through LDS so
+// the stores are row-contiguous.  Splitting long rows into column tiles keeps the longest serial walk at
+// SAMPLE_COLS gathers instead of P (up to ~500).
+constexpr int SAMPLE_COLS = 128;
+
 __global__ __launch_bounds__(64) void k_patch_sample(const DescJob *jobs, const int *tilePrefix, const int *tileJob,
                                                      const ImgRef *imgs, float *scratch) {
   const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -46,7 +51,11 @@ __global__ __launch_bounds__(64) void k_patch_sample(const DescJob *jobs, const 
   const int P = jb.P;
   if (P <= 0) return;
   const int lane = threadIdx.x;
-  const int row0 = (tile - tilePrefix[jid]) * 64;
+  const int local = tile - tilePrefix[jid];
+  const int ncolTiles = (P + SAMPLE_COLS - 1) / SAMPLE_COLS;
+  const int rowTile = local / ncolTiles, colTile = local - rowTile * ncolTiles;
+  const int row0 = rowTile * 64, col0 = colTile * SAMPLE_COLS;
+  const int colEnd = (col0 + SAMPLE_COLS) < P ? (col0 + SAMPLE_COLS) : P;
   const int row = row0 + lane;
   const ImgRef im = imgs[jb.img];
   __shared__ float tbuf[64 * 33];
@@ -58,11 +67,13 @@ __global__ __launch_bounds__(64) void k_patch_sample(const DescJob *jobs, const 
   for (int j = 0; j < nsteps; j++) { rx += jb.a12; ry += jb.a22; }
   float WX = rx - (float)half * jb.a11;
   float WY = ry - (float)half * jb.a21;
+  for (int i = 0; i < col0; i++) { WX += jb.a11; WY += jb.a21; }
   float *dst = scratch + jb.scratchOfs;
   const int rowsHere = (P - row0) < 64 ? (P - row0) : 64;
-  for (int c0 = 0; c0 < P; c0 += 32) {
-    const int nc = (P - c0) < 32 ? (P - c0) : 32;
+  for (int c0 = col0; c0 < colEnd; c0 += 32) {
+    const int nc = (colEnd - c0) < 32 ? (colEnd - c0) : 32;
     if (row < P) {
+#pragma unroll 4
       for (int i = 0; i < nc; i++) {
         tbuf[lane * 33 + i] = bilinear_tap(im.d, im.rows, im.cols, WX, WY, touch);
         WX += jb.a11;
@@ -112,6 +123,7 @@ __global__ __launch_bounds__(256) void k_patch_blur(const DescJob *jobs, const i
       }
     } else {
       v = 0.f;
+#pragma unroll 8
       for (int j = 0; j < n; j++) {
         int cc = c + j - R;
         cc = cc < 0 ? 0 : (cc > P - 1 ? P - 1 : cc);
@@ -128,6 +140,7 @@ __global__ __launch_bounds__(256) void k_patch_blur(const DescJob *jobs, const i
     if (n == 1) v = S[(size_t)r * NC + ci];
     else {
       v = k[R] * S[(size_t)r * NC + ci] + 0.f;
+#pragma unroll 4
       for (int j = 1; j <= R; j++) {
         int rp = r + j > P - 1 ? P - 1 : r + j, rm = r - j < 0 ? 0 : r - j;
         v = v + k[R + j] * (S[(size_t)rp * NC + ci] + S[(size_t)rm * NC + ci]);
@@ -191,6 +204,7 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
     const int *need = needTab + jb.needOfs;
     const int *map = need + NC;          // 41 x {idx0, idx1, x0, valid}
     const float *W = coordTab + jb.coordOfs;
+#pragma unroll 4
     for (int p = tid; p < NPX; p += 128) {
       const int r = p / PS, c = p - r * PS;
       float v = 0.f;

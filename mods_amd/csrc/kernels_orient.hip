@@ -45,6 +45,7 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
     }
   }
   __syncthreads();
+#pragma unroll 4
   for (int p = lane; p < PS * PS; p += 64) {
     const int r = p / PS, c = p - r * PS;
     patch[p] = bilinear_tap(im.d, im.rows, im.cols, bufX[r * PSP + c], bufY[r * PSP + c], touch);
