@@ -32,6 +32,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int BIG = 0x7fffffff;
 constexpr unsigned UBIG = 0xffffffffu;
 constexpr int TILES_PER_SPLIT_MAX = 512;   // 9 bits of local tile index in the packed key
+constexpr int TPS = 4;                     // train tiles staged per barrier (4 x 4 KB per LDS buffer)
 
 __global__ __launch_bounds__(256) void k_desc_norms(const uint8_t *d, int n, int *norms) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -66,6 +67,8 @@ MX_D int ratio_dmin(int d0i, double sqminratio) {
   return D;
 }
 MX_D bool lex_less(int da, int ia, int db, int ib) { return da < db || (da == db && ia < ib); }
+// median of three (folds to v_med3_u32): with m1 <= m2 the new second-smallest after seeing k is med3(m1, m2, k)
+MX_D unsigned umed3(unsigned a, unsigned b, unsigned c) { return min(max(a, b), max(min(a, b), c)); }
 
 // A fragment: 16 bytes [32*kb + 16*hi, +16) of a descriptor, u8 -> i8 (x - 128 == x ^ 0x80)
 MX_D v4i load_a(const uint8_t *base, int row, int kb, int hi) {
@@ -103,7 +106,7 @@ MX_D v4i read_b(const unsigned char *lds, int col, int kb, int hi) {
 // ---------------- sweep 1: per (query, split) top-2 -------------------------------------------------------
 __global__ __launch_bounds__(256) void k_match_sweep1(const uint8_t *d1, const int *norm1, const uint8_t *d2,
                                                       const int *norm2, MatchGeom g, int4 *partial) {
-  __shared__ __attribute__((aligned(16))) unsigned char tileBuf[2][4096];
+  __shared__ __attribute__((aligned(16))) unsigned char tileBuf[2][TPS * 4096];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 31, hi = lane >> 5;
   const int qb = blockIdx.x, sp = blockIdx.y;
@@ -112,37 +115,46 @@ __global__ __launch_bounds__(256) void k_match_sweep1(const uint8_t *d1, const i
   v4i a[4];
 #pragma unroll
   for (int kb = 0; kb < 4; kb++) a[kb] = load_a(d1, qrow, kb, hi);
-  int na[16];
+  // key(d, tile) = (d << 9) | tile with d = na + nb - 2 a'.b'  ==  ((na << 9) + ((nb << 9) | tile)) - (a'.b' << 10):
+  // one add, one 24-bit multiply-add, one min and one med3 per matrix element
+  int naS[16];
 #pragma unroll
-  for (int r = 0; r < 16; r++) na[r] = norm1[min(q0 + (r & 3) + 8 * (r >> 2) + 4 * hi, g.n1 - 1)];
+  for (int r = 0; r < 16; r++) naS[r] = norm1[min(q0 + (r & 3) + 8 * (r >> 2) + 4 * hi, g.n1 - 1)] << 9;
   const int ntilesAll = (g.n2 + 31) >> 5;
   const int tBeg = sp * g.tilesPerSplit, tEnd = min(tBeg + g.tilesPerSplit, ntilesAll);
   unsigned m1[16], m2[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) { m1[r] = UBIG; m2[r] = UBIG; }
-  if (tBeg < tEnd) stage_tile(d2, g.n2, tBeg, tileBuf[0], tid);
+  for (int q = 0; q < TPS; q++) if (tBeg + q < tEnd) stage_tile(d2, g.n2, tBeg + q, tileBuf[0] + q * 4096, tid);
   __syncthreads();
-  for (int t = tBeg; t < tEnd; t++) {
-    const int cur = (t - tBeg) & 1;
-    v4i nxt = {0, 0, 0, 0};
-    if (t + 1 < tEnd) nxt = fetch_tile(d2, g.n2, t + 1, tid);
-    v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int tg = tBeg; tg < tEnd; tg += TPS) {
+    const int cur = ((tg - tBeg) / TPS) & 1;
+    v4i nxt[TPS];
 #pragma unroll
-    for (int kb = 0; kb < 4; kb++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], read_b(tileBuf[cur], col, kb, hi), acc, 0, 0, 0);
-    const int trow = t * 32 + col;
-    if (trow < g.n2) {
-      const int nb = norm2[trow];
-      const unsigned lt = (unsigned)(t - tBeg);
+    for (int q = 0; q < TPS; q++) {
+      nxt[q] = (v4i){0, 0, 0, 0};
+      if (tg + TPS + q < tEnd) nxt[q] = fetch_tile(d2, g.n2, tg + TPS + q, tid);
+    }
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const unsigned d = (unsigned)(na[r] + nb - 2 * acc[r]);
-        const unsigned key = (d << 9) | lt;
-        const unsigned hi2 = max(m1[r], key);
-        m1[r] = min(m1[r], key);
-        m2[r] = min(m2[r], hi2);
+    for (int q = 0; q < TPS; q++) {
+      const int t = tg + q;
+      const unsigned char *tb = tileBuf[cur] + q * 4096;
+      v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int kb = 0; kb < 4; kb++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], read_b(tb, col, kb, hi), acc, 0, 0, 0);
+      const int trow = t * 32 + col;
+      if (t < tEnd && trow < g.n2) {
+        const int tileC = (norm2[trow] << 9) | (t - tBeg);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const unsigned key = (unsigned)(__mul24(acc[r], -1024) + (naS[r] + tileC));
+          m2[r] = umed3(m1[r], m2[r], key);
+          m1[r] = min(m1[r], key);
+        }
       }
     }
-    if (t + 1 < tEnd) put_tile(nxt, tileBuf[cur ^ 1], tid);
+#pragma unroll
+    for (int q = 0; q < TPS; q++) if (tg + TPS + q < tEnd) put_tile(nxt[q], tileBuf[cur ^ 1] + q * 4096, tid);
     __syncthreads();
   }
   // unpack and merge the per-lane top-2 over the 32 lanes that hold the same rows
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(256) void k_match_sweep2(const uint8_t *d1, const i
                                                       const int *norm2, MatchGeom g, const double *pos2,
                                                       double contrDistSq, const MatchRow *rows, const int *dmin,
                                                       const int *undecided, const int *nUndecided, int4 *partial2) {
-  __shared__ __attribute__((aligned(16))) unsigned char tileBuf[2][4096];
+  __shared__ __attribute__((aligned(16))) unsigned char tileBuf[2][TPS * 4096];
   const int nU = *nUndecided;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 31, hi = lane >> 5;
@@ -232,32 +244,43 @@ __global__ __launch_bounds__(256) void k_match_sweep2(const uint8_t *d1, const i
   int nless[16], nbad[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) { mj[r] = UBIG; nless[r] = 0; nbad[r] = 0; }
-  if (tBeg < tEnd) stage_tile(d2, g.n2, tBeg, tileBuf[0], tid);
+  for (int q = 0; q < TPS; q++) if (tBeg + q < tEnd) stage_tile(d2, g.n2, tBeg + q, tileBuf[0] + q * 4096, tid);
   __syncthreads();
-  for (int t = tBeg; t < tEnd; t++) {
-    const int cur = (t - tBeg) & 1;
-    v4i nxt = {0, 0, 0, 0};
-    if (t + 1 < tEnd) nxt = fetch_tile(d2, g.n2, t + 1, tid);
-    v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int tg = tBeg; tg < tEnd; tg += TPS) {
+    const int cur = ((tg - tBeg) / TPS) & 1;
+    v4i nxt[TPS];
 #pragma unroll
-    for (int kb = 0; kb < 4; kb++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], read_b(tileBuf[cur], col, kb, hi), acc, 0, 0, 0);
-    const int trow = t * 32 + col;
-    if (trow < g.n2) {
-      const int nb = norm2[trow];
-      const unsigned lt = (unsigned)(t - tBeg);
+    for (int q = 0; q < TPS; q++) {
+      nxt[q] = (v4i){0, 0, 0, 0};
+      if (tg + TPS + q < tEnd) nxt[q] = fetch_tile(d2, g.n2, tg + TPS + q, tid);
+    }
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int d = na[r] + nb - 2 * acc[r];
-        if (d >= dm[r]) mj[r] = min(mj[r], ((unsigned)d << 9) | lt);
-        else if (trow != t0[r]) {
-          nless[r]++;
-          // rare path: geometric consistency with NN0 (distanceSq, matching.cpp:174-179), f64
-          const double dx = pos2[2 * t0[r]] - pos2[2 * trow], dy = pos2[2 * t0[r] + 1] - pos2[2 * trow + 1];
-          if (dx * dx + dy * dy > contrDistSq) nbad[r]++;
+    for (int q = 0; q < TPS; q++) {
+      const int t = tg + q;
+      if (t >= tEnd) break;
+      const unsigned char *tb = tileBuf[cur] + q * 4096;
+      v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int kb = 0; kb < 4; kb++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], read_b(tb, col, kb, hi), acc, 0, 0, 0);
+      const int trow = t * 32 + col;
+      if (trow < g.n2) {
+        const int nb = norm2[trow];
+        const unsigned lt = (unsigned)(t - tBeg);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int d = na[r] + nb - 2 * acc[r];
+          if (d >= dm[r]) mj[r] = min(mj[r], ((unsigned)d << 9) | lt);
+          else if (trow != t0[r]) {
+            nless[r]++;
+            // rare path: geometric consistency with NN0 (distanceSq, matching.cpp:174-179), f64
+            const double dx = pos2[2 * t0[r]] - pos2[2 * trow], dy = pos2[2 * t0[r] + 1] - pos2[2 * trow + 1];
+            if (dx * dx + dy * dy > contrDistSq) nbad[r]++;
+          }
         }
       }
     }
-    if (t + 1 < tEnd) put_tile(nxt, tileBuf[cur ^ 1], tid);
+#pragma unroll
+    for (int q = 0; q < TPS; q++) if (tg + TPS + q < tEnd) put_tile(nxt[q], tileBuf[cur ^ 1] + q * 4096, tid);
     __syncthreads();
   }
 #pragma unroll
