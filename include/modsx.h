@@ -273,6 +273,22 @@ int modsx_match_pair_views(modsx_ctx *ctx, const modsx_image *img1, const modsx_
                            const modsx_view *views, int nviews, const modsx_pair_params *par,
                            modsx_pair_result *res);
 
+/* The iteration ladder of mods.cpp:229-415 (`for step < maxSteps && curr_matches < minMatches`), restricted to
+ * the HessianAffine + SIFT-family class with LO-RANSAC homography verification and doBeforeRANSAC = 1
+ * (config_iter_mods_cviu.ini).  Step k synthesises its views for both images, APPENDS the regions to the two
+ * image representations (AddRegions, imagerepresentation.cpp:552-600), re-matches everything accumulated so far
+ * (MatchImgReps clears and rebuilds the class' tentatives every step, correspondencebank.cpp:291-345) and
+ * verifies; the loop ends once n_verified >= min_matches.  match_ratio of a step (FGINNThreshold of that
+ * iteration's section) overrides par->match_ratio when > 0.  *steps_done = steps executed. */
+typedef struct modsx_ladder_step {
+  const modsx_view *views;
+  int nviews;
+  double match_ratio;
+} modsx_ladder_step;
+int modsx_match_ladder(modsx_ctx *ctx, const modsx_image *img1, const modsx_image *img2,
+                       const modsx_ladder_step *steps, int nsteps, int min_matches, const modsx_pair_params *par,
+                       modsx_pair_result *res, int *steps_done);
+
 /* Measurement hooks (no reference counterpart; the reference only keeps wall-clock TimeLog, structures.hpp:51-74).
  * modsx_profile(ctx, 1) brackets every kernel launch with HIP events on the ctx stream and accumulates, per kernel
  * class, GPU milliseconds, launch count and algorithmic work (bytes; flops for the matcher).  Classes in order:

@@ -65,6 +65,10 @@ def _view_array(views):
     return arr
 
 
+class LadderStep(C.Structure):
+    _fields_ = [("views", C.c_void_p), ("nviews", C.c_int), ("match_ratio", C.c_double)]
+
+
 class PairResult(C.Structure):
     _fields_ = [("n_regions1", C.c_int), ("n_regions2", C.c_int), ("n_tentatives", C.c_int), ("n_unique", C.c_int),
                 ("n_ransac_inliers", C.c_int), ("n_verified", C.c_int), ("ransac_samples", C.c_int),
@@ -80,7 +84,7 @@ EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "m
            "modsx_describe_regions", "modsx_match_fginn", "modsx_duplicate_filtering", "modsx_ransac_h",
            "modsx_loransac_h", "modsx_match_pair", "modsx_match_pairs", "modsx_pair_result_release",
            "modsx_set_vs_pars", "modsx_synth_view", "modsx_detect_describe_views", "modsx_match_fginn_device",
-           "modsx_match_pair_views", "modsx_last_timings", "modsx_profile",
+           "modsx_match_pair_views", "modsx_match_ladder", "modsx_last_timings", "modsx_profile",
            "modsx_kernel_stats"]
 
 KERNEL_CLASSES = ["blur_hess", "hessian", "resize", "nms_localize", "baumberg", "orientation", "patch_sample",
@@ -407,6 +411,22 @@ class Context(object):
         _check(lib().modsx_match_pair_views(self._c(), C.c_void_p(img1.h), C.c_void_p(img2.h), arr, len(views),
                                             C.byref(params), C.byref(res)), "match_pair_views")
         return _unpack_pair_result(res)
+
+    def match_ladder(self, img1, img2, steps, params, min_matches=10):
+        """steps: list of (views, match_ratio).  Returns (result dict, steps executed)."""
+        arr = (LadderStep * len(steps))()
+        keep = []
+        for i, (views, ratio) in enumerate(steps):
+            va = _view_array(views)
+            keep.append(va)
+            arr[i].views = C.cast(va, C.c_void_p)
+            arr[i].nviews = len(views)
+            arr[i].match_ratio = float(ratio)
+        res = PairResult()
+        done = C.c_int(0)
+        _check(lib().modsx_match_ladder(self._c(), C.c_void_p(img1.h), C.c_void_p(img2.h), arr, len(steps),
+                                        int(min_matches), C.byref(params), C.byref(res), C.byref(done)), "match_ladder")
+        return _unpack_pair_result(res), done.value
 
     def match_pair(self, img1, img2, params):
         res = PairResult()

@@ -393,6 +393,17 @@ int modsx_match_fginn_device(modsx_ctx *ctx, const void *dev_desc1_u8, int n1, c
   return (int)t.size();
 }
 
+int modsx_match_ladder(modsx_ctx *ctx, const modsx_image *img1, const modsx_image *img2,
+                       const modsx_ladder_step *steps, int nsteps, int min_matches, const modsx_pair_params *par,
+                       modsx_pair_result *res, int *steps_done) {
+  NEED(ctx); NEED(img1); NEED(img2); NEED(steps); NEED(par); NEED(res);
+  if (nsteps <= 0) { mx::set_error("modsx_match_ladder: nsteps"); return MODSX_ERR_ARG; }
+  for (int s = 0; s < nsteps; s++)
+    if (!steps[s].views || steps[s].nviews <= 0) { mx::set_error("modsx_match_ladder: empty step"); return MODSX_ERR_ARG; }
+  hipSetDevice(ctx->dev);
+  return match_ladder(ctx, img1, img2, steps, nsteps, min_matches, *par, res, steps_done);
+}
+
 int modsx_match_pair_views(modsx_ctx *ctx, const modsx_image *img1, const modsx_image *img2,
                            const modsx_view *views, int nviews, const modsx_pair_params *par,
                            modsx_pair_result *res) {

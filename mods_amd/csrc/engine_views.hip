@@ -264,44 +264,37 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
 }
 
 // AddRegionsToList (imagerepresentation.cpp:588-600): ids of each appended view block are shifted by the size
-// of the list so far
-static void rebase_ids(std::vector<modsx_region> &regs) {
+// of the list so far (`base` = regions already in the list from earlier ladder steps)
+static void rebase_ids(std::vector<modsx_region> &regs, size_t base = 0) {
   size_t start = 0;
-  while (start < regs.size()) {
+  const size_t n = regs.size();
+  while (start < n) {
     size_t end = start;
-    // a view block = maximal run produced by one view; orientation leaves id = 0 for every region of a view
-    // (synth-detection.cpp:854,889), so blocks are delimited by img_id changes
-    while (end < regs.size() && regs[end].img_id == regs[start].img_id) end++;
-    for (size_t i = start; i < end; i++) { regs[i].id += (int)start; regs[i].parent_id += (int)start; }
+    while (end < n && regs[end].img_id == regs[start].img_id) end++;
+    for (size_t i = start; i < end; i++) { regs[i].id += (int)(base + start); regs[i].parent_id += (int)(base + start); }
     start = end;
   }
 }
 
-int match_pair_views(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_view *views, int nv,
-                     const modsx_pair_params &pp, modsx_pair_result *res) {
+static void release_result_arrays(modsx_pair_result *res) {
+  free(res->tentatives); free(res->ransac_inlier); free(res->verified);
+  res->tentatives = nullptr; res->ransac_inlier = nullptr; res->verified = nullptr;
+}
+
+// Tentatives.MatchImgReps + DuplicateFiltering + LORANSACFiltering of one step (mods.cpp:287-342) on the regions
+// accumulated so far; the u8 descriptors of both sides are in c->descAllU8[side].
+static int match_and_verify(modsx_ctx *c, const std::vector<modsx_region> *regs, const modsx_pair_params &pp, double ratio,
+                            modsx_pair_result *res) {
+  release_result_arrays(res);
   memset(res, 0, sizeof *res);
   for (int i = 0; i < 9; i++) res->H[i] = -1;
-  const modsx_image *imgs[2] = {img1, img2};
-  std::vector<modsx_region> regs[2];
-  size_t cap = 1 << 16;
-  for (int side = 0; side < 2; side++) {
-    for (;;) {
-      if (!c->descAllU8[side].ensure(cap * 128) || !c->descAllF[side].ensure(cap * 512)) return MODSX_ERR_NOMEM;
-      int rc = detect_describe_views(c, imgs[side], views, nv, pp, 0, 1, regs[side], (float *)c->descAllF[side].p,
-                                     (uint8_t *)c->descAllU8[side].p, cap, nullptr, nullptr);
-      if (rc == MODSX_ERR_NOMEM && cap < ((size_t)1 << 24)) { cap *= 4; continue; }
-      if (rc) return rc;
-      break;
-    }
-    rebase_ids(regs[side]);
-  }
   res->n_regions1 = (int)regs[0].size();
   res->n_regions2 = (int)regs[1].size();
   std::vector<double> pos2(regs[1].size() * 2 + 2);
   for (size_t i = 0; i < regs[1].size(); i++) { pos2[2 * i] = regs[1][i].reproj_kp.x; pos2[2 * i + 1] = regs[1][i].reproj_kp.y; }
   std::vector<modsx_tentative> tents;
   int rc = match_device(c, (uint8_t *)c->descAllU8[0].p, res->n_regions1, (uint8_t *)c->descAllU8[1].p, res->n_regions2,
-                        pos2.data(), pp.match_ratio, pp.contradDist, pp.nn, tents);
+                        pos2.data(), ratio, pp.contradDist, pp.nn, tents);
   if (rc) return rc;
   res->n_tentatives = (int)tents.size();
   const int T0 = (int)tents.size();
@@ -337,6 +330,68 @@ int match_pair_views(modsx_ctx *c, const modsx_image *img1, const modsx_image *i
   res->n_verified = nvf < 0 ? 0 : nvf;
   for (int i = 0; i < T; i++) res->n_ransac_inliers += res->ransac_inlier[i];
   res->ransac_samples = dout[0]; res->ransac_lo = dout[1];
+  return MODSX_OK;
+}
+
+// Append the regions + u8 descriptors of one step's views to the accumulated lists of one image side
+// (SynthDetectDescribeKeypoints + AddRegions, imagerepresentation.cpp:603-2047).  The accumulator is
+// c->descAllU8[side]; it is re-allocated (device-to-device copy) when the step does not fit.
+static int accumulate_views(modsx_ctx *c, int side, const modsx_image *img, const modsx_view *views, int nv,
+                            const modsx_pair_params &pp, std::vector<modsx_region> &acc, size_t &cap) {
+  const size_t base = acc.size();
+  std::vector<modsx_region> step;
+  for (;;) {
+    if (c->descAllU8[side].cap < cap * 128) {
+      DevBuf bigger;
+      if (!bigger.ensure(cap * 128)) return MODSX_ERR_NOMEM;
+      if (base) {
+        MX_HIP(hipMemcpyAsync(bigger.p, c->descAllU8[side].p, base * 128, hipMemcpyDeviceToDevice, c->stream));
+        MX_HIP(hipStreamSynchronize(c->stream));
+      }
+      c->descAllU8[side].release();
+      c->descAllU8[side] = bigger;
+    }
+    int rc = detect_describe_views(c, img, views, nv, pp, 0, 1, step, nullptr, (uint8_t *)c->descAllU8[side].p + base * 128,
+                                   cap - base, nullptr, nullptr);
+    if (rc == MODSX_ERR_NOMEM && cap < ((size_t)1 << 24)) { cap *= 4; continue; }
+    if (rc) return rc;
+    break;
+  }
+  rebase_ids(step, base);
+  acc.insert(acc.end(), step.begin(), step.end());
+  return MODSX_OK;
+}
+
+int match_pair_views(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_view *views, int nv,
+                     const modsx_pair_params &pp, modsx_pair_result *res) {
+  modsx_ladder_step one;
+  one.views = views; one.nviews = nv; one.match_ratio = pp.match_ratio;
+  int done = 0;
+  return match_ladder(c, img1, img2, &one, 1, 0x7fffffff, pp, res, &done);
+}
+
+// The iteration loop of mods.cpp:229-415 (HessianAffine / SIFT-family class, LO-RANSAC homography verification,
+// duplicates filtered before RANSAC): every step adds its views' regions to both image representations,
+// re-matches everything accumulated so far, and the ladder stops once min_matches verified correspondences exist.
+int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_ladder_step *steps, int nsteps,
+                 int min_matches, const modsx_pair_params &pp, modsx_pair_result *res, int *steps_done) {
+  memset(res, 0, sizeof *res);
+  for (int i = 0; i < 9; i++) res->H[i] = -1;
+  const modsx_image *imgs[2] = {img1, img2};
+  std::vector<modsx_region> regs[2];
+  size_t cap[2] = {(size_t)1 << 16, (size_t)1 << 16};
+  int cur = 0, step = 0;
+  for (; step < nsteps && cur < min_matches; step++) {
+    for (int side = 0; side < 2; side++) {
+      int rc = accumulate_views(c, side, imgs[side], steps[step].views, steps[step].nviews, pp, regs[side], cap[side]);
+      if (rc) { release_result_arrays(res); return rc; }
+    }
+    const double ratio = steps[step].match_ratio > 0 ? steps[step].match_ratio : pp.match_ratio;
+    int rc = match_and_verify(c, regs, pp, ratio, res);
+    if (rc) { release_result_arrays(res); return rc; }
+    cur = res->n_verified;
+  }
+  if (steps_done) *steps_done = step;
   prof_collect(c);
   return MODSX_OK;
 }

@@ -132,3 +132,60 @@ def test_view_shard_path_world1_nccl(ctx, modsx, small_pair):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def _oracle_ladder(oracle, a, b, steps, min_matches, seed):
+    """mods.cpp:229-415 restated with the oracle's stage functions (test-side only)."""
+    acc = [[None, None], [None, None]]
+    out, done = None, 0
+    cur = 0
+    for views, ratio in steps:
+        if cur >= min_matches:
+            break
+        for side, img in enumerate((a, b)):
+            r, d = oracle.detect_describe_views(img, views)
+            if acc[side][0] is None:
+                acc[side] = [r, d]
+            else:
+                r = r.copy()
+                r["id"] += len(acc[side][0]); r["parent_id"] += len(acc[side][0])     # AddRegionsToList
+                acc[side] = [np.concatenate([acc[side][0], r]), np.concatenate([acc[side][1], d])]
+        (r1, d1), (r2, d2) = acc
+        pos2 = np.stack([r2["reproj_kp"]["x"], r2["reproj_kp"]["y"]], 1)
+        tent = oracle.match_fginn(d1, d2, pos2, ratio, 30.0)
+        pts = np.stack([r1["reproj_kp"]["x"][tent["q"]], r1["reproj_kp"]["y"][tent["q"]],
+                        r2["reproj_kp"]["x"][tent["t0"]], r2["reproj_kp"]["y"][tent["t0"]]], 1)
+        order, keep = oracle.duplicate_filtering(pts, tent["ratio"], 2.0, True)
+        sel = order[keep]
+        tu, pu = tent[sel], pts[sel]
+        rr = oracle.loransac_h(pu, laf_of(r1, tu["q"]), laf_of(r2, tu["t0"]), seed=seed)
+        cur = int(rr["keep"].sum())
+        out = dict(n_regions=(len(r1), len(r2)), n_tentatives=len(tent), tent=tu, rr=rr)
+        done += 1
+    return out, done
+
+
+@pytest.mark.parametrize("min_matches", [10, 10 ** 6])
+def test_iteration_ladder_matches_oracle(ctx, modsx, oracle, small_pair, min_matches):
+    """HessianAffine steps 4-6 of iters_mods_cviu.ini in miniature: the view sets of later steps are de-duplicated
+    against earlier ones (SetVSPars prev_par), regions accumulate, and the loop stops at minMatches."""
+    a, b, H = small_pair
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    prev_o, prev_m = [], []
+    steps_o, steps_m = [], []
+    for tilts, phi, ratio in (([1], 360.0, 0.8), ([1, 2], 360.0, 0.8), ([1, 2], 120.0, 0.85)):
+        vo = oracle.set_vs_pars([1.0], tilts, phi, 0.2, 1, prev_o)
+        vm = modsx.set_vs_pars([1.0], tilts, phi, 0.2, 1, prev_m)
+        assert len(vo) == len(vm) and len(vo) > 0
+        steps_o.append((vo, ratio)); steps_m.append((vm, ratio))
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    got, done = ctx.match_ladder(ia, ib, steps_m, modsx.default_pair_params(ransac_seed=6), min_matches=min_matches)
+    ia.free(); ib.free()
+    ref, done_ref = _oracle_ladder(oracle, a, b, steps_o, min_matches, 6)
+    assert done == done_ref and done == (1 if min_matches == 10 else 3)
+    assert got["n_regions"] == ref["n_regions"] and got["n_tentatives"] == ref["n_tentatives"]
+    for f in ref["tent"].dtype.names:
+        assert np.array_equal(got["tentatives"][f], ref["tent"][f]), f
+    assert np.array_equal(got["ransac_inlier"], ref["rr"]["inl"]) and np.array_equal(got["verified"], ref["rr"]["keep"])
+    assert np.abs(normH(got["H"]) - normH(ref["rr"]["H"])).max() < 1e-4
