@@ -102,6 +102,9 @@ typedef struct modsx_pair_params {
   double duplicateDist;                                  /* [DuplicateFiltering] :156-159, mode bestFGINN */
   double err_threshold, confidence; int max_samples; int localOptimization; double HLAFCoef; int doSymmCheck; /* [RANSAC] :162-170 */
   unsigned ransac_seed;
+  int useF;            /* RANSACPars::useF (matching.hpp:148): 1 = epipolar verification, exp_ransacFcustom + F_LAF_check */
+  double LAFCoef;      /* RANSACPars::LAFCoef, threshold of F_LAF_check = LAFCoef * err_threshold */
+  int errorType;       /* RANSAC_error_t: 0 SAMPSON, 1 SYMM_MAX, 2 SYMM_SUM (F path: 1 and 2 both select FDsSym) */
 } modsx_pair_params;
 
 typedef struct modsx_pair_result {
@@ -111,7 +114,8 @@ typedef struct modsx_pair_result {
   int n_ransac_inliers;          /* exp_ransacHcustom inliers */
   int n_verified;                /* after NaiveHCheck + H_LAF_check */
   int ransac_samples, ransac_lo;
-  double H[9];                   /* row-major, image 1 -> image 2 (LORANSACFiltering's H) */
+  double H[9];                   /* row-major, image 1 -> image 2 (LORANSACFiltering's H); with useF the
+                                  * fundamental matrix as exp_ransacFcustom returns it */
   /* malloc'd arrays (modsx_free): tentatives after duplicate filtering in RANSAC order,
    * inlier flags from RANSAC, flags after the LAF check */
   modsx_tentative *tentatives;
@@ -218,6 +222,23 @@ int modsx_loransac_h(const double *pts, const double *laf1, const double *laf2, 
                      double confidence, int max_samples, int localOptimization, double HLAFCoef, int doSymmCheck,
                      unsigned seed, double *H, double *Hraw, unsigned char *inl, unsigned char *keep,
                      int *data_out);
+
+/* int exp_ransacFcustom(double *u, int len, double th, double conf, int max_sam, double *F, unsigned char *inl,
+ *                       int *data_out, int do_lo, unsigned inlLimit, double **resids, double *H_best, int *Ih,
+ *                       exFDsPtr EXFDS1, FDsPtr FDS1, int doSymCheck)      degensac/exp_ranF.c:795-1192
+ * LO-RANSAC + DEGENSAC (plane-and-parallax) for the fundamental matrix; u [len][6] = x1 y1 1 x2 y2 1, th squared.
+ * error_type 0 = Sampson (FDs/exFDs), 1 = symmetric epipolar distance (FDsSym/exFDsSym), matching.cpp:821-846.
+ * F: 9 doubles as the reference returns them (x2^T F x1 = 0 with F read row-wise).  data_out: samples drawn,
+ * local optimisations, degenerate (H-consistent) samples handled.  `seed` replaces srand(time(NULL)).
+ * Returns the inlier count of the best model. */
+int modsx_ransac_f(const double *u, int len, double th, double conf, int max_sam, int do_lo, unsigned inl_limit,
+                   int error_type, int doSymCheck, unsigned seed, double *F, unsigned char *inl, int *data_out);
+
+/* LORANSACFiltering with RANSACPars::useF = 1 (matching.cpp:806-980): exp_ransacFcustom + F_LAF_check (:193-250,
+ * threshold LAFCoef * err_threshold).  Same argument layout as modsx_loransac_h.  Returns the verified count. */
+int modsx_loransac_f(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold,
+                     double confidence, int max_samples, int localOptimization, double LAFCoef, int doSymmCheck,
+                     int error_type, unsigned seed, double *F, unsigned char *inl, unsigned char *keep, int *data_out);
 
 /* One step of mods.cpp's iteration loop (:229-415) for an identity view: detect + orient + describe both
  * images, match, filter duplicates, verify.  Images and all intermediates stay in HBM between stages. */

@@ -44,7 +44,7 @@ class PairParams(C.Structure):
                 ("duplicateDist", C.c_double),
                 ("err_threshold", C.c_double), ("confidence", C.c_double), ("max_samples", C.c_int),
                 ("localOptimization", C.c_int), ("HLAFCoef", C.c_double), ("doSymmCheck", C.c_int),
-                ("ransac_seed", C.c_uint)]
+                ("ransac_seed", C.c_uint), ("useF", C.c_int), ("LAFCoef", C.c_double), ("errorType", C.c_int)]
 
 
 class View(C.Structure):
@@ -82,7 +82,7 @@ EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "m
            "modsx_detect_scalespace", "modsx_octave_levels", "modsx_gaussian_blur", "modsx_resize_half",
            "modsx_detect_affine_regions", "modsx_detect_orientation", "modsx_reproject_regions",
            "modsx_describe_regions", "modsx_match_fginn", "modsx_duplicate_filtering", "modsx_ransac_h",
-           "modsx_loransac_h", "modsx_match_pair", "modsx_match_pairs", "modsx_pair_result_release",
+           "modsx_loransac_h", "modsx_ransac_f", "modsx_loransac_f", "modsx_match_pair", "modsx_match_pairs", "modsx_pair_result_release",
            "modsx_set_vs_pars", "modsx_synth_view", "modsx_detect_describe_views", "modsx_match_fginn_device",
            "modsx_match_pair_views", "modsx_match_ladder", "modsx_last_timings", "modsx_profile",
            "modsx_kernel_stats"]
@@ -227,6 +227,25 @@ def loransac_h(pts, laf1, laf2, err_threshold=3.0, confidence=0.99, max_samples=
                "loransac_h")
     return dict(n=n, H=H.reshape(3, 3), Hraw=Hraw, inl=inl[:T].astype(bool), keep=keep[:T].astype(bool),
                 samples=int(dout[0]), lo_count=int(dout[1]), ori_rejects=int(dout[2]))
+
+
+def loransac_f(pts, laf1, laf2, err_threshold=4.0, confidence=0.99, max_samples=100000, lo=1, laf_coef=3.0,
+               sym_check=1, error_type=0, seed=1):
+    """LORANSACFiltering with useF = 1 (exp_ransacFcustom + F_LAF_check), host C++."""
+    pts = np.ascontiguousarray(pts, np.float64)
+    laf1 = np.ascontiguousarray(laf1, np.float64)
+    laf2 = np.ascontiguousarray(laf2, np.float64)
+    T = len(pts)
+    F = np.zeros(9)
+    inl = np.zeros(max(T, 1), np.uint8)
+    keep = np.zeros(max(T, 1), np.uint8)
+    dout = np.zeros(3, np.int32)
+    n = _check(lib().modsx_loransac_f(_p(pts), _p(laf1), _p(laf2), T, C.c_double(err_threshold),
+                                      C.c_double(confidence), int(max_samples), int(lo), C.c_double(laf_coef),
+                                      int(sym_check), int(error_type), C.c_uint(seed), _p(F), _p(inl), _p(keep),
+                                      _p(dout)), "loransac_f")
+    return dict(n=n, F=F.reshape(3, 3), inl=inl[:T].astype(bool), keep=keep[:T].astype(bool),
+                samples=int(dout[0]), lo_count=int(dout[1]), degen_count=int(dout[2]))
 
 
 def set_vs_pars(scale_set, tilt_set, phi_base, init_sigma=0.5, do_blur=1, prev=None):

@@ -62,6 +62,7 @@ void modsx_default_pair_params(modsx_pair_params *p) {
   p->err_threshold = 3.0; p->confidence = 0.99; p->max_samples = 100000; p->localOptimization = 1;
   p->HLAFCoef = 12.0; p->doSymmCheck = 1;
   p->ransac_seed = 1;
+  p->useF = 0; p->LAFCoef = 2.0; p->errorType = 0;
 }
 
 modsx_image *modsx_image_upload(modsx_ctx *ctx, const void *pixels, int rows, int cols, int channels, int dtype) {
@@ -255,6 +256,23 @@ int modsx_ransac_h(const double *u, int len, double th, double conf, int max_sam
                    int *data_out, int oriented_constraint, int doSymCheck, unsigned seed, double *score_J) {
   if (!u || !H || !inl || !data_out || len < 4) { mx::set_error("modsx_ransac_h: bad argument"); return MODSX_ERR_ARG; }
   return ransac_h(u, len, th, conf, max_sam, H, inl, data_out, oriented_constraint, doSymCheck, seed, score_J);
+}
+
+int modsx_ransac_f(const double *u, int len, double th, double conf, int max_sam, int do_lo, unsigned inl_limit,
+                   int error_type, int doSymCheck, unsigned seed, double *F, unsigned char *inl, int *data_out) {
+  if (!u || !F || !inl || !data_out || len < 8) { mx::set_error("modsx_ransac_f: bad argument"); return MODSX_ERR_ARG; }
+  return ransac_f(u, len, th, conf, max_sam, F, inl, data_out, do_lo, inl_limit, error_type, doSymCheck, seed);
+}
+
+int modsx_loransac_f(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold,
+                     double confidence, int max_samples, int localOptimization, double LAFCoef, int doSymmCheck,
+                     int error_type, unsigned seed, double *F, unsigned char *inl, unsigned char *keep, int *data_out) {
+  if (!pts || !laf1 || !laf2 || !F || !inl || !keep || !data_out || T < 0) {
+    mx::set_error("modsx_loransac_f: bad argument");
+    return MODSX_ERR_ARG;
+  }
+  return loransac_f(pts, laf1, laf2, T, err_threshold, confidence, max_samples, localOptimization, LAFCoef, doSymmCheck,
+                    error_type, seed, F, inl, keep, data_out);
 }
 
 int modsx_loransac_h(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold,

@@ -942,9 +942,15 @@ int match_pair(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, c
   for (int i = 0; i < T; i++) res->tentatives[i] = uniq[i];
   double Hraw[9];
   int dout[3] = {0, 0, 0};
-  int nv = loransac_h(p2.data(), l1.data(), l2.data(), T, pp.err_threshold, pp.confidence, pp.max_samples,
-                      pp.localOptimization, pp.HLAFCoef, pp.doSymmCheck, pp.ransac_seed, res->H, Hraw, res->ransac_inlier,
-                      res->verified, dout);
+  int nv;
+  if (pp.useF)
+    nv = loransac_f(p2.data(), l1.data(), l2.data(), T, pp.err_threshold, pp.confidence, pp.max_samples,
+                     pp.localOptimization, pp.LAFCoef, pp.doSymmCheck, pp.errorType, pp.ransac_seed, res->H,
+                     res->ransac_inlier, res->verified, dout);
+  else
+    nv = loransac_h(p2.data(), l1.data(), l2.data(), T, pp.err_threshold, pp.confidence, pp.max_samples,
+                        pp.localOptimization, pp.HLAFCoef, pp.doSymmCheck, pp.ransac_seed, res->H, Hraw, res->ransac_inlier,
+                        res->verified, dout);
   res->n_verified = nv < 0 ? 0 : nv;
   for (int i = 0; i < T; i++) res->n_ransac_inliers += res->ransac_inlier[i];
   res->ransac_samples = dout[0]; res->ransac_lo = dout[1];

@@ -49,6 +49,11 @@ int duplicate_filtering(const double *pts, const double *key, int T, double r, i
 int ransac_h(const double *u, int len, double th, double conf, int max_sam, double *H, unsigned char *inl, int *data_out,
              int oriented_constraint, int doSymCheck, unsigned seed0, double *scoreJ);
 void hds_sym(const double *u, const double *H, double *p, int len, bool takeMax);
+int ransac_f(const double *u, int len, double th, double conf, int max_sam, double *F, unsigned char *inl, int *data_out,
+             int do_lo, unsigned inlLimit, int error_type, int doSymCheck, unsigned seed0);
+int loransac_f(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold, double confidence,
+               int max_samples, int lo, double LAFCoef, int doSymmCheck, int error_type, unsigned seed, double *F,
+               unsigned char *inl, unsigned char *keep, int *data_out3);
 int loransac_h(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold,
                double confidence, int max_samples, int lo, double HLAFCoef, int doSymmCheck, unsigned seed, double *H,
                double *Hraw, unsigned char *inl, unsigned char *keep, int *data_out);

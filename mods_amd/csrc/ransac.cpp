@@ -15,372 +15,9 @@
 #include <vector>
 #include "engine_api.hpp"
 
+#include "ransac_common.hpp"
+
 namespace mx {
-
-// ---- glibc random_r TYPE_3 (srandom_r / random_r, stdlib/random_r.c) -------------------------
-struct GlibcRandom {
-  int32_t st[31];
-  int f, r;
-  void seed(unsigned s) {
-    if (s == 0) s = 1;
-    st[0] = (int32_t)s;
-    int32_t word = (int32_t)s;
-    for (int i = 1; i < 31; i++) {
-      long hi = word / 127773, lo = word % 127773;
-      long w = 16807 * lo - 2836 * hi;
-      if (w < 0) w += 2147483647;
-      word = (int32_t)w;
-      st[i] = word;
-    }
-    f = 3; r = 0;
-    for (int i = 0; i < 310; i++) next();
-  }
-  long next() {
-    uint32_t val = (uint32_t)st[f] + (uint32_t)st[r];
-    st[f] = (int32_t)val;
-    long result = (long)(val >> 1);
-    ++f;
-    if (f >= 31) { f = 0; ++r; }
-    else { ++r; if (r >= 31) r = 0; }
-    return result;
-  }
-};
-
-struct Score { unsigned I; double J; };
-
-// rtools.c:228-236
-static inline double trunc_quad(double epsilon, double thr) {
-  if (thr == 0) return 0;
-  if (epsilon >= thr * 9 / 4) return 0;
-  return 1 - (epsilon / (thr * 9 / 4));
-}
-static inline bool score_less(const Score &a, const Score &b) { return a.J < b.J; }  // SC_M, rtools.c:238-250
-// rtools.c:160-171
-static Score inlidxs(const double *err, int len, double th, int *inl) {
-  Score s = {0, 0};
-  for (int i = 0; i < len; ++i) {
-    s.J += trunc_quad(err[i], th);
-    if (err[i] <= th) { inl[s.I] = i; ++(s.I); }
-  }
-  return s;
-}
-// rtools.c:202-225
-static int nsamples(int ninl, int ptNum, int samsiz, double conf) {
-  const double EPS = 2.2204e-16;
-  const int MAXS = 1000000;
-  double a = 1, b = 1;
-  for (int i = 0; i < samsiz; i++) { a *= ninl - i; b *= ptNum - i; }
-  a = a / b;
-  if (a < EPS) return MAXS;
-  a = 1 - a;
-  if (a < EPS) return 1;
-  b = log(1 - conf) / log(a);
-  if (b > MAXS) return MAXS;
-  return (int)ceil(b);
-}
-
-// SuperFastHash, degensac/hash.c:4-54 (get16bits = little-endian 16-bit load)
-static uint32_t super_fast_hash(const char *data, int len) {
-  uint32_t hash = (uint32_t)len, tmp;
-  if (len <= 0 || data == 0) return 0;
-  auto g16 = [](const char *d) { return (uint32_t)(((uint32_t)((const uint8_t *)d)[1] << 8) + (uint32_t)((const uint8_t *)d)[0]); };
-  int rem = len & 3;
-  len >>= 2;
-  for (; len > 0; len--) {
-    hash += g16(data);
-    tmp = (g16(data + 2) << 11) ^ hash;
-    hash = (hash << 16) ^ tmp;
-    data += 4;
-    hash += hash >> 11;
-  }
-  switch (rem) {
-    case 3: hash += g16(data); hash ^= hash << 16; hash ^= ((uint32_t)(int32_t)(signed char)data[2]) << 18; hash += hash >> 11; break;
-    case 2: hash += g16(data); hash ^= hash << 11; hash += hash >> 17; break;
-    case 1: hash += (uint32_t)(int32_t)(signed char)*data; hash ^= hash << 10; hash += hash >> 1;
-  }
-  hash ^= hash << 3; hash += hash >> 5; hash ^= hash << 4; hash += hash >> 17; hash ^= hash << 25; hash += hash >> 6;
-  return hash;
-}
-// htInsert / htContains, degensac/hash.c:76-99 (64 chained buckets, newest first)
-struct HashTable {
-  struct Field { uint32_t hash; int length, iterID; };
-  std::vector<Field> b[64];
-  void insert(uint32_t hash, int length, int iterID) { b[hash % 64].push_back({hash, length, iterID}); }
-  int contains(uint32_t hash, int length, int iterID) const {
-    const std::vector<Field> &v = b[hash % 64];
-    for (size_t i = v.size(); i-- > 0;)
-      if (v[i].hash == hash && v[i].length == length && v[i].iterID == iterID) return iterID;
-    for (size_t i = v.size(); i-- > 0;)
-      if (v[i].hash == hash && v[i].length == length) return v[i].iterID;
-    return -1;
-  }
-};
-
-// det3, utools.c:196-202
-static double det3(const double *A) {
-  double r = (A[0] * A[4] * A[8] + A[2] * A[3] * A[7] + A[1] * A[5] * A[6]);
-  r -= (A[2] * A[4] * A[6] + A[0] * A[5] * A[7] + A[1] * A[3] * A[8]);
-  return r;
-}
-
-// nullspace (Gauss-Jordan with partial pivoting, row-wise matrix), utools.c:97-167
-static int nullspace(double *matrix, double *ns, int n, int *buffer) {
-  int *pnopivot = buffer, nonpivot = 0;
-  int *ppivot = buffer + n;
-  int i = 0, j, k, l, max;
-  double pivot, t;
-  const double tol = 1e-12;
-  for (j = 0; j < n; j++) {
-    pivot = fabs(matrix[n * i + j]); max = i;
-    for (k = i + 1; k < n; k++) {
-      t = fabs(matrix[n * k + j]);
-      if (pivot < t) { pivot = t; max = k; }
-    }
-    if (pivot < tol) {
-      *(pnopivot++) = j; nonpivot++;
-      for (k = i; k < n; k++) matrix[n * k + j] = 0;
-    } else {
-      *(ppivot++) = j;
-      for (k = j; k < n; k++) { t = matrix[i * n + k]; matrix[i * n + k] = matrix[max * n + k]; matrix[max * n + k] = t; }
-      pivot = matrix[i * n + j];
-      for (k = j; k < n; k++) matrix[i * n + k] /= pivot;
-      for (k = 0; k < i; k++) {
-        pivot = -matrix[k * n + j];
-        for (l = j; l < n; l++) matrix[k * n + l] += pivot * matrix[i * n + l];
-      }
-      for (k = i + 1; k < n; k++) {
-        pivot = matrix[k * n + j];
-        for (l = j; l < n; l++) matrix[k * n + l] -= pivot * matrix[i * n + l];
-      }
-      i++;
-    }
-  }
-  for (k = 0; k < nonpivot; k++) {
-    j = buffer[k];
-    for (l = 0; l < n - nonpivot; l++) ns[k * n + buffer[n + l]] = -matrix[l * n + j];
-    for (l = 0; l < nonpivot; l++) ns[k * n + buffer[l]] = (j == buffer[l]) ? 1 : 0;
-  }
-  return nonpivot;
-}
-
-// lin_hg: column-wise 2len x 9 linearisation of u' = H u, Htools.c:17-54.  Column c of the row pair of
-// point i: c = 3j -> (x'_j, 0), c = 3j+1 -> (0, x'_j), c = 3j+2 -> (-x x'_j, -y x'_j) with x' = (x2,y2,1),
-// i.e. h is the column-major 3x3.
-static void lin_hg(const double *u, double *dst, const int *inl, int len) {
-  const size_t len2 = 2 * (size_t)len;
-  for (int i = 0; i < len; i++) {
-    const double *s = u + 6 * inl[i];
-    double *r0 = dst + 2 * i, *r1 = dst + 2 * i + 1;
-    for (int j = 0; j < 3; j++) {
-      r0[(3 * j) * len2] = s[3 + j];
-      r0[(3 * j + 1) * len2] = 0;
-      r0[(3 * j + 2) * len2] = -s[0] * s[3 + j];
-      r1[(3 * j) * len2] = 0;
-      r1[(3 * j + 1) * len2] = s[3 + j];
-      r1[(3 * j + 2) * len2] = -s[1] * s[3 + j];
-    }
-  }
-}
-
-// normu, utools.c:7-52
-static void normu(const double *u, const int *inl, int len, double *A1, double *A2) {
-  for (int j = 0; j < 3; j++) { A1[j] = 0; A2[j] = 0; }
-  for (int j = 0; j < len; j++) {
-    const double *p = u + 6 * inl[j];
-    A1[1] += p[0]; A1[2] += p[1];
-    A2[1] += p[3]; A2[2] += p[4];
-  }
-  if (len > 0)
-    for (int i = 1; i < 3; i++) { A1[i] /= len; A2[i] /= len; }
-  for (int j = 0; j < len; j++) {
-    const double *p = u + 6 * inl[j];
-    double a = p[0] - A1[1], b = p[1] - A1[2];
-    A1[0] += sqrt(a * a + b * b);
-    a = p[3] - A2[1]; b = p[4] - A2[2];
-    A2[0] += sqrt(a * a + b * b);
-  }
-  if (A1[0] != 0) A1[0] = len * sqrt(2) / A1[0];
-  if (A2[0] != 0) A2[0] = len * sqrt(2) / A2[0];
-  A1[1] *= -A1[0]; A1[2] *= -A1[0];
-  A2[1] *= -A2[0]; A2[2] *= -A2[0];
-}
-
-// lin_hgN: row-wise 2len x 9 normalised linearisation, Htools.c:56-96
-static void lin_hgN(const double *u, double *p, const int *inl, int len, const double *A1, const double *A2) {
-  double a[3], b[3];
-  a[2] = 1; b[2] = 1;
-  for (int i = 0; i < len; i++) {
-    const double *s = u + 6 * inl[i];
-    a[0] = s[0] * A1[0] + A1[1];
-    a[1] = s[1] * A1[0] + A1[2];
-    b[0] = s[3] * A2[0] + A2[1];
-    b[1] = s[4] * A2[0] + A2[2];
-    double *r0 = p + (size_t)18 * i, *r1 = r0 + 9;
-    for (int j = 0; j < 3; j++) {
-      r0[3 * j] = b[j]; r0[3 * j + 1] = 0; r0[3 * j + 2] = -a[0] * b[j];
-      r1[3 * j] = 0; r1[3 * j + 1] = b[j]; r1[3 * j + 2] = -a[1] * b[j];
-    }
-  }
-}
-
-// cov_mat, utools.c:170-183: Cv[i][j] = sum_k Z[k][i] * Z[k][j].  The row loop is hoisted outside so the 45
-// running sums advance together; each individual sum still adds its terms in row order k = 0, 1, ...
-static void cov_mat(double *Cv, const double *Z, int len, int siz) {
-  double acc[9][9];
-  for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) acc[i][j] = 0;
-  for (int k = 0; k < len; k++) {
-    const double *z = Z + (size_t)k * siz;
-    for (int i = 0; i < siz; i++) {
-      const double zi = z[i];
-      for (int j = 0; j <= i; j++) acc[i][j] += zi * z[j];
-    }
-  }
-  for (int i = 0; i < siz; i++)
-    for (int j = 0; j <= i; j++) { Cv[siz * i + j] = acc[i][j]; Cv[i + siz * j] = acc[i][j]; }
-}
-
-// eigenvector of the smallest eigenvalue of a symmetric 9x9 (stands in for lap_eig = dsyev_, whose
-// first returned column is that vector: lapwrap.c:62-97, Htools.c:118-121)
-static void smallest_eigvec9(const double *C, double *v) {
-  const int n = 9;
-  double A[81], V[81];
-  memcpy(A, C, sizeof A);
-  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) V[i * n + j] = (i == j);
-  for (int sweep = 0; sweep < 100; sweep++) {
-    double off = 0, diag = 0;
-    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) (i == j ? diag : off) += A[i * n + j] * A[i * n + j];
-    if (off <= 1e-32 * diag || off == 0) break;
-    for (int p = 0; p < n - 1; p++)
-      for (int q = p + 1; q < n; q++) {
-        double apq = A[p * n + q];
-        if (apq == 0) continue;
-        double theta = (A[q * n + q] - A[p * n + p]) / (2 * apq);
-        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
-        double cs = 1 / sqrt(t * t + 1), sn = t * cs;
-        for (int k = 0; k < n; k++) {
-          double akp = A[k * n + p], akq = A[k * n + q];
-          A[k * n + p] = cs * akp - sn * akq;
-          A[k * n + q] = sn * akp + cs * akq;
-        }
-        for (int k = 0; k < n; k++) {
-          double apk = A[p * n + k], aqk = A[q * n + k];
-          A[p * n + k] = cs * apk - sn * aqk;
-          A[q * n + k] = sn * apk + cs * aqk;
-        }
-        for (int k = 0; k < n; k++) {
-          double vkp = V[k * n + p], vkq = V[k * n + q];
-          V[k * n + p] = cs * vkp - sn * vkq;
-          V[k * n + q] = sn * vkp + cs * vkq;
-        }
-      }
-  }
-  int best = 0;
-  for (int i = 1; i < n; i++) if (A[i * n + i] < A[best * n + best]) best = i;
-  for (int k = 0; k < n; k++) v[k] = V[k * n + best];
-}
-
-// denormH, utools.c:74-92 (F[] is the 3x3 in the _f1.._f9 order = F[0..8])
-static void denormH(double *F, const double *A1, const double *A2) {
-  double r = A2[0], x = A2[1], y = A2[2];
-  F[6] += x * F[0] + y * F[3];
-  F[7] += x * F[1] + y * F[4];
-  F[8] += x * F[2] + y * F[5];
-  F[0] *= r; F[1] *= r; F[2] *= r;
-  F[3] *= r; F[4] *= r; F[5] *= r;
-  r = 1 / A1[0]; x = -A1[1] * r; y = -A1[2] * r;
-  for (int i = 0; i < 9; i += 3) {
-    F[i] = r * F[i] + x * F[i + 2];
-    F[i + 1] = r * F[i + 1] + y * F[i + 2];
-  }
-}
-
-// u2h, Htools.c:98-130
-static void u2h(const double *u, const int *inl, int len, double *H, double *buffer) {
-  if (len < 4) return;
-  if (len == 4) {
-    // Exact 4-point solution = null vector of the 8 x 9 system.  (The reference transposes its 8-row
-    // column-wise buffer as if it were 9 x 9 and thereby reads 9 uninitialised stack doubles,
-    // Htools.c:105-113; that cannot be reproduced, so the intended null space is computed.)
-    double C[72], M[81], V[81];
-    int nb[18];
-    lin_hg(u, C, inl, len);
-    for (int r = 0; r < 8; r++) for (int c = 0; c < 9; c++) M[r * 9 + c] = C[c * 8 + r];
-    for (int i = 72; i < 81; ++i) M[i] = 0.0;
-    memset(V, 0, sizeof V);
-    nullspace(M, V, 9, nb);
-    memcpy(H, V, 9 * sizeof(double));
-    return;
-  }
-  double A1[3], A2[3], V[81], ev[9];
-  double *Z = buffer;
-  normu(u, inl, len, A1, A2);
-  lin_hgN(u, Z, inl, len, A1, A2);
-  cov_mat(V, Z, 2 * len, 9);
-  smallest_eigvec9(V, ev);
-  memcpy(H, ev, 9 * sizeof(double));
-  denormH(H, A1, A2);
-}
-
-// pinvJ + HDs (Sampson error), Htools.c:132-196
-// `lin` is the same linearisation as lin_hg() but stored row-major (18 doubles per point: the 9 entries of
-// row 2i, then of row 2i+1) -- identical products in identical order, contiguous in memory.
-static void HDs(const double *lin, const double *u, const double *H, double *p, int len) {
-  for (int i = 0; i < len; i++) {
-    double r1 = 0, r2 = 0;
-    const double *l = lin + (size_t)18 * i;
-    for (int j = 0; j < 9; j++) { r1 += H[j] * l[j]; r2 += H[j] * l[9 + j]; }
-    double a = H[0] - H[2] * u[0];
-    double b = H[3] - H[5] * u[0];
-    double c = -H[8] - H[2] * u[3] - H[5] * u[4];
-    double d = H[1] - H[2] * u[1];
-    double e = H[4] - H[5] * u[1];
-    double pJ[8];
-    {
-      double a2 = a * a, b2 = b * b, c2 = c * c, d2 = d * d, e2 = e * e;
-      double c2pd2 = c2 + d2, ab = a * b, de = d * e;
-      double Q = c * (c2pd2 + e2);
-      pJ[0] = -b * de + a * (c2 + e2);
-      pJ[1] = b * c2pd2 - a * de;
-      pJ[2] = Q;
-      pJ[3] = -c * (a * d + b * e);
-      pJ[4] = d * (b2 + c2) - ab * e;
-      pJ[5] = -ab * d + e * (a2 + c2);
-      pJ[6] = pJ[3];
-      pJ[7] = c * (a2 + b2 + c2);
-      double N = a * pJ[0] + b * pJ[1] + c * pJ[2];
-      for (int q = 0; q < 8; q++) pJ[q] /= N;
-    }
-    double acc = 0;
-    for (int j = 0; j < 4; j++) {
-      double t = pJ[j] * r1 + pJ[j + 4] * r2;
-      acc += t * t;
-    }
-    *p++ = acc;
-    u += 6;
-  }
-}
-
-// minv for n = 3 (matutls/minv.c) is a generic LU inverse; the symmetric transfer check only needs a
-// 3x3 inverse of H^T, computed here by the same LU-with-partial-pivoting scheme in closed form.
-static bool inv3_lu(const double *M, double *Out) {
-  double a[3][6];
-  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { a[i][j] = M[i * 3 + j]; a[i][3 + j] = (i == j); }
-  for (int c = 0; c < 3; c++) {
-    int piv = c;
-    for (int r = c + 1; r < 3; r++) if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
-    if (a[piv][c] == 0) return false;
-    if (piv != c) for (int k = 0; k < 6; k++) { double t = a[c][k]; a[c][k] = a[piv][k]; a[piv][k] = t; }
-    double d = a[c][c];
-    for (int k = 0; k < 6; k++) a[c][k] /= d;
-    for (int r = 0; r < 3; r++) {
-      if (r == c) continue;
-      double f = a[r][c];
-      for (int k = 0; k < 6; k++) a[r][k] -= f * a[c][k];
-    }
-  }
-  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Out[i * 3 + j] = a[i][3 + j];
-  return true;
-}
 
 // HDsSym / HDsSymMax, Htools.c:199-279
 void hds_sym(const double *u, const double *H, double *p, int len, bool takeMax) {
@@ -400,24 +37,6 @@ void hds_sym(const double *u, const double *H, double *p, int len, bool takeMax)
     *p++ = takeMax ? (d1 < d2 ? d2 : d1) : d1 + d2;
     u += 6;
   }
-}
-
-// all_Hori_valid, Htools.c:543-570
-static int all_hori_valid(const double *us, const int *idx) {
-  auto cross = [](double *o, const double *a, const double *b) {
-    o[0] = a[1] * b[2] - a[2] * b[1];
-    o[1] = a[2] * b[0] - a[0] * b[2];
-    o[2] = a[0] * b[1] - a[1] * b[0];
-  };
-  const double *a = us + 6 * idx[0], *b = us + 6 * idx[1], *c = us + 6 * idx[2], *d = us + 6 * idx[3];
-  double p[3], q[3];
-  cross(p, a, b); cross(q, a + 3, b + 3);
-  if ((p[0] * c[0] + p[1] * c[1] + p[2] * c[2]) * (q[0] * c[3] + q[1] * c[4] + q[2] * c[5]) < 0) return 0;
-  if ((p[0] * d[0] + p[1] * d[1] + p[2] * d[2]) * (q[0] * d[3] + q[1] * d[4] + q[2] * d[5]) < 0) return 0;
-  cross(p, c, d); cross(q, c + 3, d + 3);
-  if ((p[0] * a[0] + p[1] * a[1] + p[2] * a[2]) * (q[0] * a[3] + q[1] * a[4] + q[2] * a[5]) < 0) return 0;
-  if ((p[0] * b[0] + p[1] * b[1] + p[2] * b[2]) * (q[0] * b[3] + q[1] * b[4] + q[2] * b[5]) < 0) return 0;
-  return 1;
 }
 
 struct Ransac {

@@ -148,6 +148,10 @@ int orc_loransac_h(const double *pts /*T*4*/, const double *laf1 /*T*5: a11 a12 
                    double *H /*9 row-major img1->img2*/, double *Hraw /*9 as returned*/,
                    unsigned char *inl /*T ransac inliers*/, unsigned char *keep /*T after LAF check*/,
                    int *data_out /*3*/);
+int orc_loransac_f(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold,
+                   double confidence, int max_samples, int lo, double LAFCoef, int doSymmCheck, int error_type,
+                   unsigned seed, double *F /*9 as exp_ransacFcustom returns it*/, unsigned char *inl,
+                   unsigned char *keep /*after F_LAF_check*/, int *data_out3);
 
 #ifdef __cplusplus
 }

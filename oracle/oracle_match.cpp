@@ -61,6 +61,11 @@ typedef void (*HDsidxPtr)(const double *, const double *, const double *, double
 typedef RefScore (*ransacH_fn)(double *u, int len, double th, double conf, int max_sam, double *H,
                                unsigned char *inl, int iter_type, int *data_out, int oriented_constraint,
                                unsigned inlLimit, double **resids, HDsPtr, HDsiPtr, HDsidxPtr, int doSymCheck);
+typedef void (*FDsPtr)(const double *, const double *, double *, int);
+typedef void (*exFDsPtr)(const double *, const double *, double *, double *, int);
+typedef int (*ransacF_fn)(double *u, int len, double th, double conf, int max_sam, double *F, unsigned char *inl,
+                          int *data_out, int do_lo, unsigned inlLimit, double **resids, double *H_best, int *Ih,
+                          exFDsPtr, FDsPtr, int doSymCheck);
 typedef void (*set_seed_fn)(unsigned);
 
 static void *g_ref = nullptr;
@@ -69,6 +74,9 @@ static HDsPtr g_HDs = nullptr, g_HDsSymMax = nullptr;
 static HDsiPtr g_HDsi = nullptr;
 static HDsidxPtr g_HDsidx = nullptr;
 static set_seed_fn g_set_seed = nullptr;
+static ransacF_fn g_ransacF = nullptr;
+static FDsPtr g_FDs = nullptr, g_FDsSym = nullptr;
+static exFDsPtr g_exFDs = nullptr, g_exFDsSym = nullptr;
 
 static bool load_ref() {
   if (g_ref) return true;
@@ -88,7 +96,12 @@ static bool load_ref() {
   g_HDsidx = (HDsidxPtr)dlsym(g_ref, "HDsidx");
   g_HDsSymMax = (HDsPtr)dlsym(g_ref, "HDsSymMax");
   g_set_seed = (set_seed_fn)dlsym(g_ref, "modsx_ref_set_seed");
-  if (!g_ransacH || !g_HDs || !g_HDsi || !g_HDsidx || !g_HDsSymMax || !g_set_seed) {
+  g_ransacF = (ransacF_fn)dlsym(g_ref, "exp_ransacFcustom");
+  g_FDs = (FDsPtr)dlsym(g_ref, "FDs");
+  g_FDsSym = (FDsPtr)dlsym(g_ref, "FDsSym");
+  g_exFDs = (exFDsPtr)dlsym(g_ref, "exFDs");
+  g_exFDsSym = (exFDsPtr)dlsym(g_ref, "exFDsSym");
+  if (!g_ransacF || !g_FDs || !g_FDsSym || !g_exFDs || !g_exFDsSym || !g_ransacH || !g_HDs || !g_HDsi || !g_HDsidx || !g_HDsSymMax || !g_set_seed) {
     dlclose(g_ref);
     g_ref = nullptr;
     return false;
@@ -253,6 +266,56 @@ int orc_loransac_h(const double *pts, const double *laf1, const double *laf2, in
       if (!(sumErr > affErr)) kept.push_back(i);
     }
   } else kept = ril;
+  if ((int)kept.size() < 8) kept.clear();
+  for (int i : kept) keep[i] = 1;
+  return (int)kept.size();
+}
+/* LORANSACFiltering with useF = 1, matching/matching.cpp:806-980: the reference's exp_ransacFcustom (oracle/_ref,
+ * fixed seed through ref_shim.c) followed by F_LAF_check (:193-250, k_sigma = 3).  error_type 0 = SAMPSON
+ * (FDs / exFDs), otherwise FDsSym / exFDsSym (:821-846).  data_out3: samples, LO runs, unused. */
+int orc_loransac_f(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold,
+                   double confidence, int max_samples, int lo, double LAFCoef, int doSymmCheck, int error_type,
+                   unsigned seed, double *F, unsigned char *inl, unsigned char *keep, int *data_out3) {
+  for (int i = 0; i < T; i++) { inl[i] = 0; keep[i] = 0; }
+  for (int i = 0; i < 9; i++) F[i] = 0;
+  data_out3[0] = data_out3[1] = data_out3[2] = 0;
+  if (!load_ref()) return -1;
+  if (T < 8) return 0;
+  std::vector<double> u2((size_t)T * 6);
+  for (int i = 0; i < T; i++) {
+    u2[6 * i] = pts[4 * i]; u2[6 * i + 1] = pts[4 * i + 1]; u2[6 * i + 2] = 1.;
+    u2[6 * i + 3] = pts[4 * i + 2]; u2[6 * i + 4] = pts[4 * i + 3]; u2[6 * i + 5] = 1.;
+  }
+  std::vector<int> data_out((size_t)T * 18 + 18);
+  double *resids = nullptr;
+  double HinF[9];
+  int I_H = 0;
+  FDsPtr fds = error_type == 0 ? g_FDs : g_FDsSym;
+  exFDsPtr exfds = error_type == 0 ? g_exFDs : g_exFDsSym;
+  g_set_seed(seed);
+  g_ransacF(u2.data(), T, err_threshold * err_threshold, confidence, max_samples, F, inl, data_out.data(), lo, 0,
+            &resids, HinF, &I_H, exfds, fds, doSymmCheck);
+  free(resids);
+  data_out3[0] = data_out[0]; data_out3[1] = data_out[1];
+  const double affErr = LAFCoef * err_threshold;
+  std::vector<int> kept;
+  for (int i = 0; i < T; i++) {
+    if (!inl[i]) continue;
+    if (affErr > 0) {
+      double u[18], err[3];
+      const double *A = laf1 + 5 * i, *B = laf2 + 5 * i;
+      u[0] = pts[4 * i]; u[1] = pts[4 * i + 1]; u[2] = 1.0;
+      u[3] = pts[4 * i + 2]; u[4] = pts[4 * i + 3]; u[5] = 1.0;
+      u[6] = u[0] + 3.0 * A[1] * A[4]; u[7] = u[1] + 3.0 * A[3] * A[4]; u[8] = 1.0;
+      u[9] = u[3] + 3.0 * B[1] * B[4]; u[10] = u[4] + 3.0 * B[3] * B[4]; u[11] = 1.0;
+      u[12] = u[0] + 3.0 * A[0] * A[4]; u[13] = u[1] + 3.0 * A[2] * A[4]; u[14] = 1.0;
+      u[15] = u[3] + 3.0 * B[0] * B[4]; u[16] = u[4] + 3.0 * B[2] * B[4]; u[17] = 1.0;
+      fds(u, F, err, 3);
+      const double sumErr = sqrt(err[0]) + sqrt(err[1]) + sqrt(err[2]);
+      if (sumErr > affErr) continue;
+    }
+    kept.push_back(i);
+  }
   if ((int)kept.size() < 8) kept.clear();
   for (int i : kept) keep[i] = 1;
   return (int)kept.size();

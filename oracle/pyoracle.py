@@ -273,6 +273,24 @@ def loransac_h(pts, laf1, laf2, err_threshold=3.0, confidence=0.99, max_samples=
                 samples=int(dout[0]), lo_count=int(dout[1]), ori_rejects=int(dout[2]))
 
 
+def loransac_f(pts, laf1, laf2, err_threshold=4.0, confidence=0.99, max_samples=100000, lo=1, laf_coef=3.0,
+               sym_check=1, error_type=0, seed=1):
+    """LORANSACFiltering with useF = 1 (the reference's exp_ransacFcustom from oracle/_ref + F_LAF_check)."""
+    pts = np.ascontiguousarray(pts, np.float64)
+    laf1 = np.ascontiguousarray(laf1, np.float64)
+    laf2 = np.ascontiguousarray(laf2, np.float64)
+    T = len(pts)
+    F = np.zeros(9)
+    inl = np.zeros(max(T, 1), np.uint8)
+    keep = np.zeros(max(T, 1), np.uint8)
+    dout = np.zeros(3, np.int32)
+    n = lib().orc_loransac_f(_p(pts), _p(laf1), _p(laf2), T, C.c_double(err_threshold), C.c_double(confidence),
+                             max_samples, lo, C.c_double(laf_coef), sym_check, error_type, C.c_uint(seed), _p(F),
+                             _p(inl), _p(keep), _p(dout))
+    return dict(n=n, F=F.reshape(3, 3), inl=inl[:T].astype(bool), keep=keep[:T].astype(bool),
+                samples=int(dout[0]), lo_count=int(dout[1]))
+
+
 def warp_affine(img, M6, drows, dcols, border=128.0):
     img = _f32(img)
     M6 = np.ascontiguousarray(M6, np.float64).reshape(6)

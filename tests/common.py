@@ -43,6 +43,33 @@ def synth_corr(T, frac, noise=0.7, seed=0):
     return np.c_[p1, p2], laf, H
 
 
+def synth_two_view(seed, n_in=300, n_out=150, planar_frac=0.0, noise=0.5):
+    """Correspondences of a 3-D point cloud seen by two cameras (+ uniform outliers).  planar_frac of the inliers lie
+    on one plane, which drives exp_ransacFcustom through its DEGENSAC (plane-and-parallax) branch."""
+    rng = np.random.default_rng(seed)
+    K = np.array([[800., 0, 512], [0, 800, 384], [0, 0, 1]])
+    X = np.stack([rng.uniform(-4, 4, n_in), rng.uniform(-3, 3, n_in), rng.uniform(6, 14, n_in)], 1)
+    npl = int(planar_frac * n_in)
+    if npl:
+        X[:npl, 2] = 10.0 + 0.15 * X[:npl, 0]
+    ang = 0.25
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    t = np.array([-1.5, 0.1, 0.3])
+    p1 = (K @ X.T).T
+    p1 = p1[:, :2] / p1[:, 2:]
+    X2 = (R @ X.T).T + t
+    p2 = (K @ X2.T).T
+    p2 = p2[:, :2] / p2[:, 2:]
+    p1 += rng.normal(0, noise, p1.shape)
+    p2 += rng.normal(0, noise, p2.shape)
+    o1 = np.stack([rng.uniform(0, 1024, n_out), rng.uniform(0, 768, n_out)], 1)
+    o2 = np.stack([rng.uniform(0, 1024, n_out), rng.uniform(0, 768, n_out)], 1)
+    pts = np.concatenate([np.concatenate([p1, p2], 1), np.concatenate([o1, o2], 1)])
+    pts = pts[rng.permutation(len(pts))]
+    laf = np.tile(np.array([1., 0, 0, 1, 3.0]), (len(pts), 1))
+    return pts, laf
+
+
 def normH(H):
     H = np.asarray(H, float).reshape(3, 3)
     return H / H[2, 2]

@@ -173,6 +173,28 @@ def test_pair_end_to_end_identical_inliers(ctx, modsx, oracle, small_pair):
     ia.free(); ib.free()
 
 
+def test_pair_end_to_end_epipolar_verification(ctx, modsx, oracle, small_pair):
+    """RANSACPars::useF = 1 (config 5 of BASELINE.json): the same pair verified by exp_ransacFcustom + F_LAF_check.
+    The scene is planar, so DEGENSAC's plane-and-parallax branch is what runs."""
+    a, b, _ = small_pair
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    got = ctx.match_pair(ia, ib, modsx.default_pair_params(ransac_seed=3, useF=1, LAFCoef=2.0, err_threshold=4.0))
+    ia.free(); ib.free()
+    ref = oracle_pair(oracle, a, b, seed=3)
+    _check_tents(got["tentatives"], ref["uniq"])
+    tu = ref["uniq"]
+    rr = oracle.loransac_f(ref["pts"], laf_of(ref["r1"], tu["q"]), laf_of(ref["r2"], tu["t0"]), err_threshold=4.0,
+                           laf_coef=2.0, seed=3)
+    assert np.array_equal(got["ransac_inlier"], rr["inl"]) and np.array_equal(got["verified"], rr["keep"])
+    assert got["n_verified"] == rr["n"] and got["ransac_samples"] == rr["samples"] and rr["n"] > 50
+    Fa, Fb = rr["F"] / np.linalg.norm(rr["F"]), got["H"] / np.linalg.norm(got["H"])
+    if (Fa * Fb).sum() < 0:
+        Fb = -Fb
+    assert np.abs(Fa - Fb).max() < 1e-6
+
+
 def test_cat_pair_golden_counts(ctx, modsx, cat_pair):
     cat, cat2, _ = cat_pair
     i1, i2 = ctx.upload(cat), ctx.upload(cat2)

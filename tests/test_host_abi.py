@@ -7,7 +7,7 @@ import re
 import numpy as np
 import pytest
 
-from common import synth_corr, normH, same_records
+from common import synth_corr, synth_two_view, normH, same_records
 from conftest import HAS_GPU, ROOT
 
 
@@ -90,6 +90,39 @@ def test_loransac_edge_cases(modsx, oracle):
         pts, laf, _ = synth_corr(40, 0.0, seed=3)              # pure outliers
         a, b = oracle.loransac_h(pts, laf, laf, seed=5), modsx.loransac_h(pts, laf, laf, seed=5)
         assert np.array_equal(a["inl"], b["inl"]) and a["n"] == b["n"] and a["samples"] == b["samples"]
+
+
+@pytest.mark.parametrize("planar_frac", [0.0, 0.6, 1.0])
+@pytest.mark.parametrize("error_type", [0, 1])
+def test_loransac_f_matches_reference_degensac(modsx, oracle, planar_frac, error_type):
+    """G3: the host F-matrix LO-RANSAC / DEGENSAC against the reference's own exp_ransacFcustom (oracle/_ref):
+    identical sample count, LO count, inlier set and LAF-checked set for fixed seeds; F within 1e-9."""
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    for seed in (1, 2, 3, 4):
+        pts, laf = synth_two_view(seed, planar_frac=planar_frac)
+        a = oracle.loransac_f(pts, laf, laf, seed=seed, error_type=error_type)
+        b = modsx.loransac_f(pts, laf, laf, seed=seed, error_type=error_type)
+        assert (a["n"], a["samples"], a["lo_count"]) == (b["n"], b["samples"], b["lo_count"])
+        assert np.array_equal(a["inl"], b["inl"]) and np.array_equal(a["keep"], b["keep"])
+        assert a["inl"].sum() > 250
+        Fa, Fb = a["F"] / np.linalg.norm(a["F"]), b["F"] / np.linalg.norm(b["F"])
+        if (Fa * Fb).sum() < 0:
+            Fb = -Fb
+        assert np.abs(Fa - Fb).max() < 1e-9
+
+
+def test_loransac_f_edge_cases(modsx, oracle):
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    pts, laf = synth_two_view(9, n_in=5, n_out=2)          # fewer than MIN_POINTS
+    assert modsx.loransac_f(pts, laf, laf)["n"] == 0
+    for n_in, n_out, seed in ((12, 3, 5), (40, 60, 6), (30, 0, 7)):
+        pts, laf = synth_two_view(seed, n_in=n_in, n_out=n_out)
+        a = oracle.loransac_f(pts, laf, laf, seed=seed, max_samples=5000)
+        b = modsx.loransac_f(pts, laf, laf, seed=seed, max_samples=5000)
+        assert (a["n"], a["samples"], a["lo_count"]) == (b["n"], b["samples"], b["lo_count"])
+        assert np.array_equal(a["inl"], b["inl"]) and np.array_equal(a["keep"], b["keep"])
 
 
 def test_glibc_prng_restatement(modsx):
