@@ -179,10 +179,9 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
   if (k >= n) return;
   const int tid = threadIdx.x;
   __shared__ __attribute__((aligned(16))) float patch[NPX];
-  __shared__ __attribute__((aligned(16))) float bufA[PS * PSP];   // WX, later wc0 = (float)(w0[c] * val)
-  __shared__ __attribute__((aligned(16))) float bufB[PS * PSP];   // WY, later wc1 = (float)(w1[c] * val)
-  __shared__ __attribute__((aligned(16))) float bufC[PS * PSP];   // compacted masked values, later wo1
-  __shared__ __attribute__((aligned(16))) unsigned char sbo0[PS * PSP];
+  __shared__ __attribute__((aligned(16))) float bufA[PS * PSP];   // WX (direct branch), compacted masked values, later val
+  __shared__ __attribute__((aligned(16))) float bufB[PS * PSP];   // WY (direct branch), later o = orientation bin coordinate
+  __shared__ double slut[256];   // ATAN_LUT (2 KB) next to the CU
   __shared__ float swr0[PS], swr1[PS];
   __shared__ double swc0[PS], swc1[PS];
   __shared__ __attribute__((aligned(16))) double vec[128];
@@ -191,6 +190,7 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
   __shared__ double sfac;
   __shared__ int schanged;
   const DescJob jb = jobs[k];
+  for (int i = tid; i < 256; i += 128) slut[i] = atanLut[i];
   if (tid < PS) {
     swr0[tid] = (float)wTab[tid]; swr1[tid] = (float)wTab[PS + tid];   // const float wr0 = w0[r] (siftdesc.cpp:79-81)
     swc0[tid] = wTab[tid]; swc1[tid] = wTab[PS + tid];
@@ -250,31 +250,30 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
   // -- photometricallyNormalize (helpers.cpp:666-715): f32 running sums over the masked pixels
   if (photoNorm) {
     const int nm = sc.nmask, nm4 = (nm + 3) & ~3;
-    for (int i = tid; i < nm4; i += 128) bufC[i] = i < nm ? patch[maskIdx[i]] : 0.f;
+    for (int i = tid; i < nm4; i += 128) bufA[i] = i < nm ? patch[maskIdx[i]] : 0.f;
     __syncthreads();
     if (tid == 0) {
       float sum = 0.f;
-      const float4 *v4 = reinterpret_cast<const float4 *>(bufC);
+      const float4 *v4 = reinterpret_cast<const float4 *>(bufA);
       const int full = nm >> 2;
 #pragma unroll 8
       for (int i = 0; i < full; i++) { const float4 v = v4[i]; sum += v.x; sum += v.y; sum += v.z; sum += v.w; }
-      for (int i = full * 4; i < nm; i++) sum += bufC[i];
-      float gsum = 0.f;
-      for (int i = 0; i < nm; i++) gsum += 1.0f;   // gsum++ per masked pixel (exact in f32)
+      for (int i = full * 4; i < nm; i++) sum += bufA[i];
+      const float gsum = (float)nm;   // gsum++ per masked pixel: every partial count < 2^24 is exact in f32
       sstat[0] = sum / gsum;
       sstat[1] = gsum;
     }
     __syncthreads();
     const float mean = sstat[0], gsum = sstat[1];
-    for (int i = tid; i < nm4; i += 128) { const float d = mean - bufC[i]; bufC[i] = i < nm ? d * d : 0.f; }
+    for (int i = tid; i < nm4; i += 128) { const float d = mean - bufA[i]; bufA[i] = i < nm ? d * d : 0.f; }
     __syncthreads();
     if (tid == 0) {
       float var = 0.f;
-      const float4 *v4 = reinterpret_cast<const float4 *>(bufC);
+      const float4 *v4 = reinterpret_cast<const float4 *>(bufA);
       const int full = nm >> 2;
 #pragma unroll 8
       for (int i = 0; i < full; i++) { const float4 v = v4[i]; var += v.x; var += v.y; var += v.z; var += v.w; }
-      for (int i = full * 4; i < nm; i++) var += bufC[i];
+      for (int i = full * 4; i < nm; i++) var += bufA[i];
       sstat[1] = sqrtf(var / gsum);
     }
     __syncthreads();
@@ -302,21 +301,21 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
     else if (r == PS - 1) yg = patch[p] - patch[p - PS];
     else yg = patch[p + PS] - patch[p - PS];
     const float g = sqrtf(xg * xg + yg * yg);
-    const float ori = atan2lut(atanLut, yg, xg);
+    const float ori = atan2lut(slut, yg, xg);
     const float val = (float)(0.0 + (1.0 * (double)mask[p]) * (double)g);
     const float o = (float)((double)8.0f * ((double)ori + TWO_PI) / TWO_PI);
-    const int bo0 = (int)o;
     const int q = r * PSP + c;
-    bufC[q] = o - (float)bo0;                      // wo1
-    sbo0[q] = (unsigned char)(bo0 % 8);
-    bufA[q] = (float)(swc0[c] * (double)val);      // wc0
-    bufB[q] = (float)(swc1[c] * (double)val);      // wc1
+    bufA[q] = val;     // the column weights wc0 / wc1 = (float)(w[c] * val) are formed in the gather
+    bufB[q] = o;       // bo0 = (int)o, wo1 = o - bo0 likewise
   }
   __syncthreads();
   // -- samplePatch: bin t gathers its 16x16 pixel block in raster order
   {
     const int rb = tid >> 5, cb = (tid >> 3) & 3, ob = tid & 7;
     double acc = 0.0;
+    double wcol[16];   // w1[c] for the first eight columns of the block, w0[c] for the last eight
+#pragma unroll
+    for (int j = 0; j < 16; j++) wcol[j] = j < 8 ? swc1[8 * cb + j] : swc0[8 * cb + j];
 #pragma unroll 1
     for (int rr = 0; rr < 16; rr++) {
       const int r = 8 * rb + rr;
@@ -325,18 +324,20 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
 #pragma unroll
       for (int seg = 0; seg < 4; seg++) {
         const int q = q0 + 4 * seg;
-        const float4 wc = seg < 2 ? *reinterpret_cast<const float4 *>(bufB + q) : *reinterpret_cast<const float4 *>(bufA + q);
-        const float4 w1v = *reinterpret_cast<const float4 *>(bufC + q);
-        const unsigned bo = *reinterpret_cast<const unsigned *>(sbo0 + q);
-        const float wcs[4] = {wc.x, wc.y, wc.z, wc.w};
-        const float wos[4] = {w1v.x, w1v.y, w1v.z, w1v.w};
+        const float4 vv = *reinterpret_cast<const float4 *>(bufA + q);
+        const float4 ov = *reinterpret_cast<const float4 *>(bufB + q);
+        const float vals[4] = {vv.x, vv.y, vv.z, vv.w};
+        const float os[4] = {ov.x, ov.y, ov.z, ov.w};
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-          const int b0 = (bo >> (8 * e)) & 0xff;
+          const float o = os[e];
+          const int bo0 = (int)o;
+          const int b0 = bo0 % 8;
           const int b1 = (b0 + 1) & 7;
-          const float wo1 = wos[e];
+          const float wo1 = o - (float)bo0;
           const float wo0 = 1.0f - wo1;
-          const float v = wr * wcs[e];
+          const float wcv = (float)(wcol[4 * seg + e] * (double)vals[e]);
+          const float v = wr * wcv;
           if (v > 0) {
             if (b0 == ob) acc += (double)(v * wo0);
             else if (b1 == ob) acc += (double)(v * wo1);

@@ -20,11 +20,12 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
   const int k = blockIdx.x;
   if (k >= n) return;
   const int lane = threadIdx.x;
-  __shared__ __attribute__((aligned(16))) float patch[PS * PS];
-  __shared__ __attribute__((aligned(16))) float bufX[PS * PSP];   // WX, later the histogram weights
-  __shared__ __attribute__((aligned(16))) float bufY[PS * PSP];   // WY
+  __shared__ __attribute__((aligned(16))) float bufX[PS * PSP];   // WX, then the patch (same padded layout)
+  __shared__ __attribute__((aligned(16))) float bufY[PS * PSP];   // WY, then the histogram weights
   __shared__ __attribute__((aligned(16))) unsigned char sbin[PS * PSP];
+  __shared__ double slut[256];                                     // ATAN_LUT (2 KB) next to the CU
   __shared__ float hist[40];
+  for (int i = lane; i < 256; i += 64) slut[i] = atanLut[i];
   const OriJob jb = jobs[k];
   const ImgRef im = imgs[jb.img];
   const int half = PS >> 1;
@@ -45,10 +46,11 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
     }
   }
   __syncthreads();
+  // each lane replaces the coordinate it just consumed by the sample, so the patch reuses bufX
 #pragma unroll 4
   for (int p = lane; p < PS * PS; p += 64) {
-    const int r = p / PS, c = p - r * PS;
-    patch[p] = bilinear_tap(im.d, im.rows, im.cols, bufX[r * PSP + c], bufY[r * PSP + c], touch);
+    const int r = p / PS, c = p - r * PS, q = r * PSP + c;
+    bufX[q] = bilinear_tap(im.d, im.rows, im.cols, bufX[q], bufY[q], touch);
   }
   __syncthreads();
   const float PIf = float(M_PI);
@@ -57,19 +59,18 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
     unsigned char bin = 255;
     float w = 0.f;
     if (r >= 1 && r < PS - 1 && c >= 1 && c < PS - 1) {
-      const int q = r * PS + c;
-      const float xg = patch[q + 1] - patch[q - 1];
-      const float yg = patch[q + PS] - patch[q - PS];
+      const float xg = bufX[p + 1] - bufX[p - 1];
+      const float yg = bufX[p + PSP] - bufX[p - PSP];
       const float mag = sqrtf(xg * xg + yg * yg);
-      const float ori = atan2lut(atanLut, yg, xg);
-      const float m = orimask[q];
+      const float ori = atan2lut(slut, yg, xg);
+      const float m = orimask[r * PS + c];
       if (m > 0 && mag > 1.0f) {
         bin = (unsigned char)(int)(36 * (ori / PIf + 1.0f) / 2.0f);
         w = mag * m;
       }
     }
     sbin[p] = bin;
-    bufX[p] = w;
+    bufY[p] = w;
   }
   __syncthreads();
   // lane b owns histogram bin b and adds its pixels in raster order (f32 running sum of the reference)
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
 #pragma unroll 1
     for (int r = 1; r < PS - 1; r++) {
       const unsigned *b4 = reinterpret_cast<const unsigned *>(sbin + r * PSP);
-      const float4 *w4 = reinterpret_cast<const float4 *>(bufX + r * PSP);
+      const float4 *w4 = reinterpret_cast<const float4 *>(bufY + r * PSP);
 #pragma unroll
       for (int g = 0; g < PSP / 4; g++) {
         const unsigned b = b4[g];
@@ -92,39 +93,34 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
     hist[lane] = h;
   }
   __syncthreads();
-  if (lane == 0) {
-    const int nb = 36;
-    for (int it = 0; it < 6; it++) {
-      float first = hist[0], prev = hist[nb - 1];
-      for (int i = 0; i < nb - 1; i++) {
-        float cur = hist[i];
-        hist[i] = prev + cur + hist[i + 1];
-        prev = cur;
-      }
-      hist[nb - 1] = prev + hist[nb - 1] + first;
-    }
-    float thresh = 0.0f;
-    for (int i = 0; i < nb; i++) if (hist[i] > thresh) thresh = hist[i];
-    thresh = (float)((double)thresh * th);
-    if (doHalf) {
-      for (int i = 0; i < nb / 2; i++) { hist[i] += hist[i + nb / 2]; hist[i + nb / 2] = 0; }
-    }
-    OriOut o;
-    o.n = 0;
-    int npeaks = 0;  // number of peaks found so far (peak_values.size())
-    // peaks in the order (35,0,1), (i-1,i,i+1) for i = 1..34, (34,35,0); the reference keeps the first
-    // min(maxAngles, #peaks) of them -- every recorded peak already satisfies hist[b] >= thresh.
-    for (int q = 0; q < nb; q++) {
-      const int b = q, a = (q == 0) ? nb - 1 : q - 1, c = (q == nb - 1) ? 0 : q + 1;
-      if (hist[b] >= thresh && hist[b] > hist[a] && hist[b] > hist[c]) {
-        if (npeaks < maxAngles && o.n < 7) {
-          float pp = (hist[a] - hist[c]) / (hist[a] - 2.0f * hist[b] + hist[c]) / 2.0f;
-          o.ang[o.n++] = 2.0f * PIf * ((float)b + 0.5f + pp) / (float)nb - PIf;
-        }
-        npeaks++;
-      }
-    }
-    out[k] = o;
+  // 6 passes of the circular [1 1 1] smoothing: the in-place loop of the reference (synth-detection.cpp:795-809) only
+  // ever reads not-yet-updated neighbours, i.e. new[i] = (old[i-1] + old[i]) + old[i+1]; one lane per bin.
+  const int nb = 36;
+  float hv = lane < nb ? hist[lane] : 0.f;
+  for (int it = 0; it < 6; it++) {
+    const float left = __shfl(hv, lane == 0 ? nb - 1 : lane - 1);
+    const float right = __shfl(hv, lane == nb - 1 ? 0 : lane + 1);
+    hv = left + hv + right;
+  }
+  float mx = lane < nb ? hv : 0.f;   // thresh starts at 0 and takes every larger bin: a maximum, order free
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  const float thresh = (float)((double)(mx > 0.f ? mx : 0.f) * th);
+  if (doHalf) {
+    const float other = __shfl(hv, lane < nb / 2 ? lane + nb / 2 : lane);
+    if (lane < nb / 2) hv += other;
+    else if (lane < nb) hv = 0.f;
+  }
+  const float ha = __shfl(hv, lane == 0 ? nb - 1 : lane - 1);
+  const float hc = __shfl(hv, lane == nb - 1 ? 0 : lane + 1);
+  const bool peak = lane < nb && hv >= thresh && hv > ha && hv > hc;
+  const unsigned long long peaks = __ballot(peak);
+  // the reference keeps the first min(maxAngles, #peaks) peaks in bin order (35,0,1), (i-1,i,i+1), (34,35,0)
+  const int rank = __popcll(peaks & ((1ull << lane) - 1ull));
+  if (lane == 0) out[k].n = min(min(__popcll(peaks), maxAngles), 7);
+  if (peak && rank < maxAngles && rank < 7) {
+    const float pp = (ha - hc) / (ha - 2.0f * hv + hc) / 2.0f;
+    out[k].ang[rank] = 2.0f * PIf * ((float)lane + 0.5f + pp) / (float)nb - PIf;
   }
 }
 
