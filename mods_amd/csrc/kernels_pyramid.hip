@@ -15,78 +15,100 @@ namespace mx {
 
 // ---------------------------------------------------------------------------------------
 // Fused separable Gaussian blur (+ optional Hessian response of the blurred tile).
-// Tile: 64 x 32 outputs per 256-thread workgroup, staged through LDS:
-//   src  (TH+2+2R) x (TW+2+2R)   clamped (replicate) input tile
-//   tmp  (TH+2+2R) x (TW+2)      row-filtered
-//   blr  (TH+2)    x (TW+2)      blurred tile incl. the 1-px ring the 3x3 Hessian needs
-// Row pass accumulates taps left to right (cv RowFilter, ksize > 5) or centre + symmetric
-// pairs (SymmRowSmallFilter, ksize <= 5); column pass is centre + (below + above) * k
-// (SymmColumnFilter) -- the same f32 operation order as the CPU filter engine.
+// Tile: 64 x 32 outputs per 256-thread workgroup, staged through LDS (R = ksize / 2 is a template
+// parameter, so every tap loop is unrolled and the taps sit in SGPRs):
+//   src  (36+2R) x (68+2R)   clamped (replicate) input tile, row stride 84
+//   tmp  (36+2R) x 68        row-filtered
+//   blr  36 x 68             blurred tile incl. the 1-px ring the 3x3 Hessian needs (aliases src)
+// Each thread produces 4 neighbouring outputs per pass from one register window (4 + 2R inputs), which cuts
+// the LDS reads per output from 2R+1 to (4+2R)/4.  Row pass accumulates taps left to right (cv RowFilter,
+// ksize > 5) or centre + symmetric pairs (SymmRowSmallFilter, ksize <= 5); column pass is centre +
+// (below + above) * k (SymmColumnFilter) -- per output the same f32 operation order as the CPU filter engine.
 // ---------------------------------------------------------------------------------------
 constexpr int TW = 64, TH = 32, RMAX = 8;
-constexpr int SRC_W = TW + 2 + 2 * RMAX, SRC_H = TH + 2 + 2 * RMAX;
+constexpr int TMP_W = TW + 4;                 // 66 needed columns rounded up to a multiple of 4
+constexpr int BLR_H = TH + 4;                 // 34 needed rows rounded up to a multiple of 4
+constexpr int SRC_W = TMP_W + 2 * RMAX, SRC_H = BLR_H + 2 * RMAX;
 
+template <int R>
 __global__ __launch_bounds__(256) void k_blur_hess(BlurBatch batch) {
   const BlurJob jb = batch.j[blockIdx.z];
   const int rows = jb.rows, cols = jb.cols;
   const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
   if (tx0 >= cols || ty0 >= rows) return;
-  const int R = batch.n >> 1;
-  const int n = batch.n;
-  __shared__ float src[SRC_H * SRC_W];
-  __shared__ float tmp[SRC_H * (TW + 2)];
-  __shared__ float blr[(TH + 2) * (TW + 2)];
+  constexpr int n = 2 * R + 1;
+  constexpr int sh = BLR_H + 2 * R, sw = TMP_W + 2 * R;
+  __shared__ __attribute__((aligned(16))) float src[SRC_H * SRC_W];   // later reused as blr
+  __shared__ __attribute__((aligned(16))) float tmp[SRC_H * TMP_W];
+  float *blr = src;
   const int tid = threadIdx.x;
-  const int sh = TH + 2 + 2 * R, sw = TW + 2 + 2 * R;
   // stage 1: clamped input tile
   for (int i = tid; i < sh * sw; i += 256) {
-    int ly = i / sw, lx = i - ly * sw;
+    const int ly = i / sw, lx = i - ly * sw;
     int gy = ty0 - 1 - R + ly, gx = tx0 - 1 - R + lx;
     gy = gy < 0 ? 0 : (gy > rows - 1 ? rows - 1 : gy);
     gx = gx < 0 ? 0 : (gx > cols - 1 ? cols - 1 : gx);
     src[ly * SRC_W + lx] = jb.src[(size_t)gy * cols + gx];
   }
   __syncthreads();
-  // stage 2: row filter
-  const int tw2 = TW + 2;
-  for (int i = tid; i < sh * tw2; i += 256) {
-    int ly = i / tw2, lx = i - ly * tw2;
-    const float *S = src + ly * SRC_W + lx;  // taps S[0..n-1], centre at S[R]
-    float v;
-    if (n <= 5) {
-      v = S[R] * batch.k[R];
-      for (int j = 1; j <= R; j++) v = v + (S[R - j] + S[R + j]) * batch.k[R + j];
-    } else {
-      v = 0.f;
-      for (int j = 0; j < n; j++) v = v + S[j] * batch.k[j];
+  // stage 2: row filter, 4 outputs per thread
+  for (int i = tid; i < sh * (TMP_W / 4); i += 256) {
+    const int ly = i / (TMP_W / 4), g = i - ly * (TMP_W / 4);
+    const float *S = src + ly * SRC_W + 4 * g;   // output x reads S[x .. x + 2R], centre S[x + R]
+    float w[4 + 2 * R];
+#pragma unroll
+    for (int q = 0; q < (4 + 2 * R) / 4; q++) {
+      const float4 t = *reinterpret_cast<const float4 *>(S + 4 * q);
+      w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
     }
-    tmp[ly * tw2 + lx] = v;
+#pragma unroll
+    for (int q = ((4 + 2 * R) / 4) * 4; q < 4 + 2 * R; q++) w[q] = S[q];
+    float v[4];
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+      if (n <= 5) {
+        v[o] = w[o + R] * batch.k[R];
+#pragma unroll
+        for (int j = 1; j <= R; j++) v[o] = v[o] + (w[o + R - j] + w[o + R + j]) * batch.k[R + j];
+      } else {
+        v[o] = 0.f;
+#pragma unroll
+        for (int j = 0; j < n; j++) v[o] = v[o] + w[o + j] * batch.k[j];
+      }
+    }
+    *reinterpret_cast<float4 *>(tmp + ly * TMP_W + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
   }
   __syncthreads();
-  // stage 3: column filter -> blurred tile with 1-px ring
-  const int bh = TH + 2;
-  for (int i = tid; i < bh * tw2; i += 256) {
-    int ly = i / tw2, lx = i - ly * tw2;
-    const float *S = tmp + (ly + R) * tw2 + lx;
-    float v = batch.k[R] * S[0] + 0.f;
-    for (int j = 1; j <= R; j++) v = v + batch.k[R + j] * (S[j * tw2] + S[-j * tw2]);
-    blr[ly * tw2 + lx] = v;
+  // stage 3: column filter -> blurred tile with 1-px ring, 4 output rows per thread
+  for (int i = tid; i < (BLR_H / 4) * TMP_W; i += 256) {
+    const int gy = i / TMP_W, lx = i - gy * TMP_W;
+    const float *S = tmp + (4 * gy) * TMP_W + lx;   // output row y reads rows y .. y + 2R, centre y + R
+    float w[4 + 2 * R];
+#pragma unroll
+    for (int q = 0; q < 4 + 2 * R; q++) w[q] = S[q * TMP_W];
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+      float v = batch.k[R] * w[o + R] + 0.f;
+#pragma unroll
+      for (int j = 1; j <= R; j++) v = v + batch.k[R + j] * (w[o + R + j] + w[o + R - j]);
+      blr[(4 * gy + o) * TMP_W + lx] = v;
+    }
   }
   __syncthreads();
   // stage 4: write blur and response
   const float norm2 = jb.norm * jb.norm;
   for (int i = tid; i < TH * TW; i += 256) {
-    int ly = i / TW, lx = i - ly * TW;
-    int gy = ty0 + ly, gx = tx0 + lx;
+    const int ly = i / TW, lx = i - ly * TW;
+    const int gy = ty0 + ly, gx = tx0 + lx;
     if (gy >= rows || gx >= cols) continue;
-    const float *B = blr + (ly + 1) * tw2 + (lx + 1);
+    const float *B = blr + (ly + 1) * TMP_W + (lx + 1);
     jb.blur[(size_t)gy * cols + gx] = B[0];
     if (jb.resp) {
       float o = 0.f;
       if (gy >= 1 && gy < rows - 1 && gx >= 1 && gx < cols - 1) {
-        const float v11 = B[-tw2 - 1], v12 = B[-tw2], v13 = B[-tw2 + 1];
+        const float v11 = B[-TMP_W - 1], v12 = B[-TMP_W], v13 = B[-TMP_W + 1];
         const float v21 = B[-1], v22 = B[0], v23 = B[1];
-        const float v31 = B[tw2 - 1], v32 = B[tw2], v33 = B[tw2 + 1];
+        const float v31 = B[TMP_W - 1], v32 = B[TMP_W], v33 = B[TMP_W + 1];
         float Lxx = (v21 - 2 * v22 + v23);
         float Lyy = (v12 - 2 * v22 + v32);
         float Lxy = (v13 - v11 + v31 - v33) / 4.0f;
@@ -253,7 +275,16 @@ __global__ void k_gray_f32(const float *src, float *dst, size_t n, int channels)
 
 void launch_blur_hess(hipStream_t s, const BlurBatch &b, int nj, int maxRows, int maxCols) {
   dim3 grid((maxCols + TW - 1) / TW, (maxRows + TH - 1) / TH, nj);
-  hipLaunchKernelGGL(k_blur_hess, grid, dim3(256), 0, s, b);
+  switch (b.n >> 1) {
+    case 1: hipLaunchKernelGGL(k_blur_hess<1>, grid, dim3(256), 0, s, b); break;
+    case 2: hipLaunchKernelGGL(k_blur_hess<2>, grid, dim3(256), 0, s, b); break;
+    case 3: hipLaunchKernelGGL(k_blur_hess<3>, grid, dim3(256), 0, s, b); break;
+    case 4: hipLaunchKernelGGL(k_blur_hess<4>, grid, dim3(256), 0, s, b); break;
+    case 5: hipLaunchKernelGGL(k_blur_hess<5>, grid, dim3(256), 0, s, b); break;
+    case 6: hipLaunchKernelGGL(k_blur_hess<6>, grid, dim3(256), 0, s, b); break;
+    case 7: hipLaunchKernelGGL(k_blur_hess<7>, grid, dim3(256), 0, s, b); break;
+    default: hipLaunchKernelGGL(k_blur_hess<8>, grid, dim3(256), 0, s, b); break;
+  }
 }
 void launch_hessian(hipStream_t s, const BlurBatch &b, int nj, int maxRows, int maxCols) {
   dim3 grid((maxCols + 63) / 64, (maxRows + 3) / 4, nj);
