@@ -661,14 +661,23 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
   int rc = upload_img_refs(c, imgs, n);
   if (rc) return rc;
   const size_t ARENA_FLOATS = (size_t)192 << 20;  // 768 MiB per arena per chunk
+  DescOut outs;
+  memset(&outs, 0, sizeof outs);
   for (int i = 0; i < n; i++) {
     const size_t nr = regs[i].size();
     float *outF = devF ? devF[i] : nullptr;
     uint8_t *outU8 = devU8 ? devU8[i] : nullptr;
     if (!outF) { if (!c->descF[i].ensure(std::max<size_t>(1, nr) * 128 * 4)) return MODSX_ERR_NOMEM; outF = (float *)c->descF[i].p; }
     if (!outU8) { if (!c->descU8[i].ensure(std::max<size_t>(1, nr) * 128)) return MODSX_ERR_NOMEM; outU8 = (uint8_t *)c->descU8[i].p; }
-    size_t done = 0;
-    while (done < nr) {
+    outs.f[i] = outF; outs.u8[i] = outU8;
+  }
+  // the regions of all images of the batch go through one launch set per chunk (a chunk ends when the window arena is
+  // full); region order inside an image is kept, outIdx addresses the image's own descriptor buffer
+  int curImg = 0;
+  size_t curReg = 0;
+  while (curImg < n && regs[curImg].empty()) curImg++;
+  while (curImg < n) {
+    {
       std::vector<DescJob> jobs;
       std::vector<int> pfxSample(1, 0), pfxRow(1, 0), pfxCol(1, 0);
       std::vector<float> taps, coordTab;
@@ -676,12 +685,16 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       struct PInfo { int tapOfs, ksize, needOfs, NC, coordOfs, touch; };
       std::map<int, PInfo> pinfo;  // per window size P
       size_t arenaA = 0, arenaB = 0, arenaC = 0;
-      size_t r = done;
-      for (; r < nr; r++) {
+      bool full = false;
+      int i = curImg;
+      size_t r = curReg;
+      for (; i < n && !full; i++, r = 0) {
+      for (; r < regs[i].size(); r++) {
         const modsx_keypoint &k = regs[i][r].det_kp;
         DescJob j;
         memset(&j, 0, sizeof j);
         j.img = i;
+        j.outIdx = (int)r;
         j.x = (float)k.x; j.y = (float)k.y;
         if (!fast) {
           float mrScale = (float)ceil(k.s * mrSize);
@@ -743,7 +756,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
             }
             const PInfo &pi = it->second;
             size_t needA = (size_t)P * P;
-            if (arenaA + needA > ARENA_FLOATS && !jobs.empty()) break;
+            if (arenaA + needA > ARENA_FLOATS && !jobs.empty()) { full = true; break; }
             j.P = P;
             j.a11 = (float)k.a11; j.a12 = (float)k.a12; j.a21 = (float)k.a21; j.a22 = (float)k.a22;
             j.tapOfs = pi.tapOfs; j.ksize = pi.ksize; j.NC = pi.NC; j.needOfs = pi.needOfs; j.coordOfs = pi.coordOfs;
@@ -767,6 +780,10 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
         pfxRow.push_back(pfxRow.back() + (j.P > 0 ? (j.P * j.NC + 255) / 256 : 0));
         pfxCol.push_back(pfxCol.back() + (j.P > 0 ? (j.NC * j.NC + 255) / 256 : 0));
       }
+      if (full) break;
+      }
+      // (i, r) = first region that did not fit, or i == n
+      if (full) { curImg = i; curReg = r; } else { curImg = n; curReg = 0; }
       const size_t nj = jobs.size();
       if (!c->descJobs.ensure(nj * sizeof(DescJob)) || !c->tilePrefix.ensure((nj + 1) * 12) ||
           !c->taps.ensure(std::max<size_t>(1, taps.size()) * 4) || !c->needTab.ensure(std::max<size_t>(1, needTab.size()) * 4) ||
@@ -799,15 +816,18 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       ProfScope psd(c, K_DESCRIBE, (double)arenaC * 4 + (double)nj * (128 * 5));
       launch_describe(s, dj, (int)nj, (ImgRef *)c->imgRefs.p, (float *)c->scratchC.p, (int *)c->needTab.p, (float *)c->coordTab.p,
                       c->dSiftMask, c->dSiftMaskIdx, c->nSiftMask, c->dAtan,
-                      c->dSiftBins, c->dSiftW, photoNorm, descType == MODSX_DESC_ROOT_SIFT, maxBin,
-                      outF + done * 128, outU8 + done * 128);
+                      c->dSiftBins, c->dSiftW, photoNorm, descType == MODSX_DESC_ROOT_SIFT, maxBin, outs);
       MX_HIP(hipStreamSynchronize(s));  // jobs/taps/prefix are host vectors reused by the next chunk
-      done = r;
     }
-    if (descHost && descHost[i] && nr) {
-      MX_HIP(hipMemcpyAsync(descHost[i], outF, nr * 128 * 4, hipMemcpyDeviceToHost, s));
-      MX_HIP(hipStreamSynchronize(s));
-    }
+  }
+  if (descHost) {
+    bool any = false;
+    for (int i = 0; i < n; i++)
+      if (descHost[i] && !regs[i].empty()) {
+        MX_HIP(hipMemcpyAsync(descHost[i], outs.f[i], regs[i].size() * 128 * 4, hipMemcpyDeviceToHost, s));
+        any = true;
+      }
+    if (any) MX_HIP(hipStreamSynchronize(s));
   }
   MX_HIP(hipGetLastError());
   return MODSX_OK;

@@ -78,11 +78,14 @@ struct DescJob {
   int needOfs;        // offset into the int table: NC needed indices, then 41 x {idx of x0, idx of x0+1, valid}
   int coordOfs;       // offset into the float table: 41 sample coordinates WX_i (= WY_j)
   int touch;          // interpolate()'s border branch for the 41x41 resampling
+  int outIdx;         // index of the region in its image's descriptor buffers
+  int pad0;
   unsigned long long scratchOfs;    // float offset of this region's P x P window (arena A)
   unsigned long long rowOfs;        // float offset of its P x NC row-filtered block (arena B)
   unsigned long long gridOfs;       // float offset of its NC x NC blurred grid (arena C)
 };
 struct ImgRef { const float *d; int rows, cols, pad; };
+struct DescOut { float *f[MAXB]; uint8_t *u8[MAXB]; };   // per image of the batch: [n][128] f32 and u8 descriptors
 
 // view synthesis
 struct WarpJob {
@@ -165,7 +168,7 @@ void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix
 void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *imgs, const float *grid,
                      const int *needTab, const float *coordTab,
                      const float *mask, const unsigned short *maskIdx, int nmask, const double *atanLut, const int *bins,
-                     const double *wts, int photoNorm, int rootsift, double maxBin, float *descF, uint8_t *descU8);
+                     const double *wts, int photoNorm, int rootsift, double maxBin, const DescOut &outs);
 void launch_warp_affine(hipStream_t s, const WarpJob &jb);
 void launch_blur_pass(hipStream_t s, const float *src, float *dst, int rows, int cols, const float *taps, int n, int pass);
 size_t match_workspace_bytes(int n1, int n2, int *S_out, int *tilesPerSplit_out);

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
                                                   const float *mask, const unsigned short *maskIdx,
                                                   const double *atanLut, const int *binTab, const double *wTab,
                                                   SiftConst sc, int photoNorm, int rootsift, double maxBin,
-                                                  float *descF, uint8_t *descU8) {
+                                                  DescOut outs) {
   const int k = blockIdx.x;
   if (k >= n) return;
   const int tid = threadIdx.x;
@@ -390,8 +390,8 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
     else b = (int)((double)512.0f * vec[tid] + 0.5);
     b = b < 255 ? b : 255;
     b = b > 0 ? b : 0;
-    descF[(size_t)k * 128 + tid] = (float)b;
-    descU8[(size_t)k * 128 + tid] = (uint8_t)b;
+    outs.f[jb.img][(size_t)jb.outIdx * 128 + tid] = (float)b;
+    outs.u8[jb.img][(size_t)jb.outIdx * 128 + tid] = (uint8_t)b;
   }
 }
 
@@ -411,13 +411,13 @@ void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix
 }
 void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *imgs, const float *grid,
                      const int *needTab, const float *coordTab, const float *mask, const unsigned short *maskIdx, int nmask, const double *atanLut, const int *bins,
-                     const double *wts, int photoNorm, int rootsift, double maxBin, float *descF, uint8_t *descU8) {
+                     const double *wts, int photoNorm, int rootsift, double maxBin, const DescOut &outs) {
   if (n <= 0) return;
   SiftConst sc;
   sc.nmask = nmask;
   hipLaunchKernelGGL(k_describe, dim3(n), dim3(128), 0, s, jobs, n, imgs, grid, needTab, coordTab, mask, maskIdx, atanLut, bins,
                      wts, sc,
-                     photoNorm, rootsift, maxBin, descF, descU8);
+                     photoNorm, rootsift, maxBin, outs);
 }
 
 }  // namespace mx
