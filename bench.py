@@ -51,11 +51,11 @@ def cpu_baseline(rows, cols, seed, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=15)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=768)
     ap.add_argument("--cols", type=int, default=1024)
-    ap.add_argument("--batch", type=int, default=32, help="pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="pairs per step per GPU")
     ap.add_argument("--workers", type=int, default=16, help="contexts (thread + stream) per GPU")
     ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic pairs cycled through the batch")
     ap.add_argument("--tilts", type=str, default="", help="e.g. 1,2,3,4,6: synthesise views (configs[2]); default 1 view")

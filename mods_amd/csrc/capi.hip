@@ -302,13 +302,19 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
   std::atomic<int> next(0), failed(0);
   std::string firstErr;
   std::mutex *mu = new std::mutex();
+  // every context takes up to MAXB / 2 pairs at a time and runs their 2g images as one batch; the group shrinks so
+  // that all contexts get work when the batch is small
+  int group = (n_pairs + n_ctx - 1) / n_ctx;
+  if (group > mx::MAXB / 2) group = mx::MAXB / 2;
+  if (group < 1) group = 1;
   auto worker = [&](int w) {
     modsx_ctx *c = ctxs[w];
     hipSetDevice(c->dev);
     for (;;) {
-      int i = next.fetch_add(1);
+      int i = next.fetch_add(group);
       if (i >= n_pairs) break;
-      int rc = match_pair(c, imgs1[i], imgs2[i], *par, &results[i]);
+      const int g = (n_pairs - i) < group ? (n_pairs - i) : group;
+      int rc = match_pair_group(c, imgs1 + i, imgs2 + i, g, *par, &results[i]);
       if (rc) {
         std::lock_guard<std::mutex> g(*mu);
         if (!failed.exchange(rc)) firstErr = mx::last_error();
@@ -316,7 +322,8 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
     }
   };
   std::vector<std::thread> th;
-  const int nw = n_ctx < n_pairs ? n_ctx : n_pairs;
+  const int ngroups = (n_pairs + group - 1) / group;
+  const int nw = n_ctx < ngroups ? n_ctx : ngroups;
   for (int w = 1; w < nw; w++) th.emplace_back(worker, w);
   if (nw > 0) worker(0);
   for (auto &t : th) t.join();

@@ -660,7 +660,11 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
   hipStream_t s = c->stream;
   int rc = upload_img_refs(c, imgs, n);
   if (rc) return rc;
-  const size_t ARENA_FLOATS = (size_t)192 << 20;  // 768 MiB per arena per chunk
+  // Window arena per chunk.  Measured on MI355X with 16 contexts: throughput is flat up to 256 MiB per context and
+  // halves from 384 MiB on (the three arenas of all contexts stop fitting the 256 MiB Infinity Cache working set),
+  // so a batch is cut into chunks of 192 MiB of windows.  MODSX_ARENA_MB overrides it for experiments.
+  static const size_t arenaMB = getenv("MODSX_ARENA_MB") ? (size_t)atol(getenv("MODSX_ARENA_MB")) : 192;
+  const size_t ARENA_FLOATS = std::max<size_t>(arenaMB, 16) << 18;  // MiB -> floats
   DescOut outs;
   memset(&outs, 0, sizeof outs);
   for (int i = 0; i < n; i++) {
@@ -897,48 +901,15 @@ int match_host_desc(modsx_ctx *c, const float *desc1, int n1, const float *desc2
 // ------------------------------------------------------------------------------------------------
 // one step of the mods.cpp loop for an identity view
 // ------------------------------------------------------------------------------------------------
-int match_pair(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_pair_params &pp,
-               modsx_pair_result *res) {
-  memset(res, 0, sizeof *res);
-  for (int i = 0; i < 9; i++) res->H[i] = -1;
-  const modsx_image *imgs[2] = {img1, img2};
-  const double t0 = now_ms();
-  std::vector<modsx_keypoint> kps[2];
-  int rc = detect_keypoints_batch(c, imgs, 2, pp.det, nullptr, nullptr, kps);
-  if (rc) return rc;
-  std::vector<modsx_region> regs[2], oriented[2];
-  for (int i = 0; i < 2; i++) {
-    regs[i].resize(kps[i].size());
-    detect_affine_regions(kps[i].data(), (int)kps[i].size(), 0, MODSX_DET_HESSIAN, regs[i].data());
-  }
-  const double t1 = now_ms();
-  rc = detect_orientation_batch(c, imgs, 2, regs, pp.ori_mrSize, pp.ori_patchSize, 0, pp.ori_maxAngles, pp.ori_threshold,
-                                0, oriented);
-  if (rc) return rc;
-  const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  for (int i = 0; i < 2; i++) {
-    int m = reproject_regions(oriented[i].data(), (int)oriented[i].size(), eye, imgs[i]->cols, imgs[i]->rows);
-    oriented[i].resize(m);
-  }
-  const double t2 = now_ms();
-  rc = describe_batch(c, imgs, 2, oriented, pp.desc_mrSize, pp.desc_patchSize, 0, pp.desc_photoNorm, pp.desc_type,
-                      pp.desc_maxBinValue, nullptr, nullptr, nullptr);
-  if (rc) return rc;
-  const double t3 = now_ms();
-  res->n_regions1 = (int)oriented[0].size();
-  res->n_regions2 = (int)oriented[1].size();
-  std::vector<double> pos2(oriented[1].size() * 2 + 2);
-  for (size_t i = 0; i < oriented[1].size(); i++) { pos2[2 * i] = oriented[1][i].reproj_kp.x; pos2[2 * i + 1] = oriented[1][i].reproj_kp.y; }
-  std::vector<modsx_tentative> tents;
-  rc = match_device(c, (uint8_t *)c->descU8[0].p, res->n_regions1, (uint8_t *)c->descU8[1].p, res->n_regions2,
-                    pos2.data(), pp.match_ratio, pp.contradDist, pp.nn, tents);
-  if (rc) return rc;
-  const double t4 = now_ms();
+// DuplicateFiltering + LORANSACFiltering on the tentatives of one pair (mods.cpp:300-342, doBeforeRANSAC = 1).
+// Fills the counters, H and the three malloc'd arrays of `res` (which must not own arrays yet).
+void verify_tentatives(const std::vector<modsx_region> &r1, const std::vector<modsx_region> &r2,
+                       const std::vector<modsx_tentative> &tents, const modsx_pair_params &pp, modsx_pair_result *res) {
   res->n_tentatives = (int)tents.size();
   const int T0 = (int)tents.size();
   std::vector<double> pts((size_t)T0 * 4 + 4), key(T0 + 1);
   for (int i = 0; i < T0; i++) {
-    const modsx_keypoint &a = oriented[0][tents[i].q].reproj_kp, &b = oriented[1][tents[i].t0].reproj_kp;
+    const modsx_keypoint &a = r1[tents[i].q].reproj_kp, &b = r2[tents[i].t0].reproj_kp;
     pts[4 * i] = a.x; pts[4 * i + 1] = a.y; pts[4 * i + 2] = b.x; pts[4 * i + 3] = b.y;
     key[i] = tents[i].ratio;
   }
@@ -951,7 +922,7 @@ int match_pair(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, c
   res->n_unique = T;
   std::vector<double> p2((size_t)T * 4 + 4), l1((size_t)T * 5 + 5), l2((size_t)T * 5 + 5);
   for (int i = 0; i < T; i++) {
-    const modsx_keypoint &a = oriented[0][uniq[i].q].reproj_kp, &b = oriented[1][uniq[i].t0].reproj_kp;
+    const modsx_keypoint &a = r1[uniq[i].q].reproj_kp, &b = r2[uniq[i].t0].reproj_kp;
     p2[4 * i] = a.x; p2[4 * i + 1] = a.y; p2[4 * i + 2] = b.x; p2[4 * i + 3] = b.y;
     l1[5 * i] = a.a11; l1[5 * i + 1] = a.a12; l1[5 * i + 2] = a.a21; l1[5 * i + 3] = a.a22; l1[5 * i + 4] = a.s;
     l2[5 * i] = b.a11; l2[5 * i + 1] = b.a12; l2[5 * i + 2] = b.a21; l2[5 * i + 3] = b.a22; l2[5 * i + 4] = b.s;
@@ -965,20 +936,81 @@ int match_pair(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, c
   int nv;
   if (pp.useF)
     nv = loransac_f(p2.data(), l1.data(), l2.data(), T, pp.err_threshold, pp.confidence, pp.max_samples,
-                     pp.localOptimization, pp.LAFCoef, pp.doSymmCheck, pp.errorType, pp.ransac_seed, res->H,
-                     res->ransac_inlier, res->verified, dout);
+                    pp.localOptimization, pp.LAFCoef, pp.doSymmCheck, pp.errorType, pp.ransac_seed, res->H,
+                    res->ransac_inlier, res->verified, dout);
   else
     nv = loransac_h(p2.data(), l1.data(), l2.data(), T, pp.err_threshold, pp.confidence, pp.max_samples,
-                        pp.localOptimization, pp.HLAFCoef, pp.doSymmCheck, pp.ransac_seed, res->H, Hraw, res->ransac_inlier,
-                        res->verified, dout);
+                    pp.localOptimization, pp.HLAFCoef, pp.doSymmCheck, pp.ransac_seed, res->H, Hraw, res->ransac_inlier,
+                    res->verified, dout);
   res->n_verified = nv < 0 ? 0 : nv;
+  res->n_ransac_inliers = 0;
   for (int i = 0; i < T; i++) res->n_ransac_inliers += res->ransac_inlier[i];
   res->ransac_samples = dout[0]; res->ransac_lo = dout[1];
+}
+
+// One step of mods.cpp's loop (identity view) for G <= MAXB / 2 independent pairs at once: the 2G images go through
+// detection, orientation and description as ONE batch (one launch set, blockIdx.z / job tables select the image), then
+// each pair is matched and verified.  Results are those of G separate calls.
+int match_pair_group(modsx_ctx *c, const modsx_image *const *imgs1, const modsx_image *const *imgs2, int G,
+                     const modsx_pair_params &pp, modsx_pair_result *res) {
+  if (G < 1 || 2 * G > MAXB) { set_error("match_pair_group: group size"); return MODSX_ERR_ARG; }
+  for (int g = 0; g < G; g++) {
+    memset(&res[g], 0, sizeof res[g]);
+    for (int i = 0; i < 9; i++) res[g].H[i] = -1;
+  }
+  const int n = 2 * G;
+  const modsx_image *imgs[MAXB];
+  for (int g = 0; g < G; g++) { imgs[2 * g] = imgs1[g]; imgs[2 * g + 1] = imgs2[g]; }
+  const double t0 = now_ms();
+  std::vector<modsx_keypoint> kps[MAXB];
+  int rc = detect_keypoints_batch(c, imgs, n, pp.det, nullptr, nullptr, kps);
+  if (rc) return rc;
+  std::vector<modsx_region> regs[MAXB], oriented[MAXB];
+  for (int i = 0; i < n; i++) {
+    regs[i].resize(kps[i].size());
+    detect_affine_regions(kps[i].data(), (int)kps[i].size(), 0, MODSX_DET_HESSIAN, regs[i].data());
+  }
+  const double t1 = now_ms();
+  rc = detect_orientation_batch(c, imgs, n, regs, pp.ori_mrSize, pp.ori_patchSize, 0, pp.ori_maxAngles, pp.ori_threshold,
+                                0, oriented);
+  if (rc) return rc;
+  const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int i = 0; i < n; i++) {
+    int m = reproject_regions(oriented[i].data(), (int)oriented[i].size(), eye, imgs[i]->cols, imgs[i]->rows);
+    oriented[i].resize(m);
+  }
+  const double t2 = now_ms();
+  rc = describe_batch(c, imgs, n, oriented, pp.desc_mrSize, pp.desc_patchSize, 0, pp.desc_photoNorm, pp.desc_type,
+                      pp.desc_maxBinValue, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  const double t3 = now_ms();
+  double tMatch = 0, tVerify = 0;
+  for (int g = 0; g < G; g++) {
+    const std::vector<modsx_region> &ra = oriented[2 * g], &rb = oriented[2 * g + 1];
+    const double m0 = now_ms();
+    res[g].n_regions1 = (int)ra.size();
+    res[g].n_regions2 = (int)rb.size();
+    std::vector<double> pos2(rb.size() * 2 + 2);
+    for (size_t i = 0; i < rb.size(); i++) { pos2[2 * i] = rb[i].reproj_kp.x; pos2[2 * i + 1] = rb[i].reproj_kp.y; }
+    std::vector<modsx_tentative> tents;
+    rc = match_device(c, (uint8_t *)c->descU8[2 * g].p, res[g].n_regions1, (uint8_t *)c->descU8[2 * g + 1].p,
+                      res[g].n_regions2, pos2.data(), pp.match_ratio, pp.contradDist, pp.nn, tents);
+    if (rc) return rc;
+    const double m1 = now_ms();
+    verify_tentatives(ra, rb, tents, pp, &res[g]);
+    tMatch += m1 - m0; tVerify += now_ms() - m1;
+  }
   const double t5 = now_ms();
   prof_collect(c);
-  c->timings[0] = t1 - t0; c->timings[1] = t2 - t1; c->timings[2] = t3 - t2; c->timings[3] = t4 - t3;
-  c->timings[4] = t5 - t4; c->timings[5] = t5 - t0;
+  // per-stage wall time of the group, divided by the number of pairs it carried
+  c->timings[0] = (t1 - t0) / G; c->timings[1] = (t2 - t1) / G; c->timings[2] = (t3 - t2) / G; c->timings[3] = tMatch / G;
+  c->timings[4] = tVerify / G; c->timings[5] = (t5 - t0) / G;
   return MODSX_OK;
+}
+
+int match_pair(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_pair_params &pp,
+               modsx_pair_result *res) {
+  return match_pair_group(c, &img1, &img2, 1, pp, res);
 }
 
 }  // namespace mx

@@ -40,6 +40,10 @@ int match_device(modsx_ctx *c, const uint8_t *d1, int n1, const uint8_t *d2, int
                  double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out);
 int match_host_desc(modsx_ctx *c, const float *desc1, int n1, const float *desc2, int n2, const double *pos2,
                     double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out);
+void verify_tentatives(const std::vector<modsx_region> &r1, const std::vector<modsx_region> &r2,
+                       const std::vector<modsx_tentative> &tents, const modsx_pair_params &pp, modsx_pair_result *res);
+int match_pair_group(modsx_ctx *c, const modsx_image *const *imgs1, const modsx_image *const *imgs2, int G,
+                     const modsx_pair_params &pp, modsx_pair_result *res);
 int match_pair(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_pair_params &pp,
                modsx_pair_result *res);
 

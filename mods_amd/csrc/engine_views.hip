@@ -296,46 +296,7 @@ static int match_and_verify(modsx_ctx *c, const std::vector<modsx_region> *regs,
   int rc = match_device(c, (uint8_t *)c->descAllU8[0].p, res->n_regions1, (uint8_t *)c->descAllU8[1].p, res->n_regions2,
                         pos2.data(), ratio, pp.contradDist, pp.nn, tents);
   if (rc) return rc;
-  res->n_tentatives = (int)tents.size();
-  const int T0 = (int)tents.size();
-  std::vector<double> pts((size_t)T0 * 4 + 4), key(T0 + 1);
-  for (int i = 0; i < T0; i++) {
-    const modsx_keypoint &a = regs[0][tents[i].q].reproj_kp, &b = regs[1][tents[i].t0].reproj_kp;
-    pts[4 * i] = a.x; pts[4 * i + 1] = a.y; pts[4 * i + 2] = b.x; pts[4 * i + 3] = b.y;
-    key[i] = tents[i].ratio;
-  }
-  std::vector<int> order(T0 + 1);
-  std::vector<unsigned char> keepd(T0 + 1);
-  duplicate_filtering(pts.data(), key.data(), T0, pp.duplicateDist, 1, order.data(), keepd.data());
-  std::vector<modsx_tentative> uniq;
-  for (int i = 0; i < T0; i++) if (keepd[i]) uniq.push_back(tents[order[i]]);
-  const int T = (int)uniq.size();
-  res->n_unique = T;
-  std::vector<double> p2((size_t)T * 4 + 4), l1((size_t)T * 5 + 5), l2((size_t)T * 5 + 5);
-  for (int i = 0; i < T; i++) {
-    const modsx_keypoint &a = regs[0][uniq[i].q].reproj_kp, &b = regs[1][uniq[i].t0].reproj_kp;
-    p2[4 * i] = a.x; p2[4 * i + 1] = a.y; p2[4 * i + 2] = b.x; p2[4 * i + 3] = b.y;
-    l1[5 * i] = a.a11; l1[5 * i + 1] = a.a12; l1[5 * i + 2] = a.a21; l1[5 * i + 3] = a.a22; l1[5 * i + 4] = a.s;
-    l2[5 * i] = b.a11; l2[5 * i + 1] = b.a12; l2[5 * i + 2] = b.a21; l2[5 * i + 3] = b.a22; l2[5 * i + 4] = b.s;
-  }
-  res->tentatives = (modsx_tentative *)malloc(sizeof(modsx_tentative) * std::max(1, T));
-  res->ransac_inlier = (unsigned char *)calloc(std::max(1, T), 1);
-  res->verified = (unsigned char *)calloc(std::max(1, T), 1);
-  for (int i = 0; i < T; i++) res->tentatives[i] = uniq[i];
-  double Hraw[9];
-  int dout[3] = {0, 0, 0};
-  int nvf;
-  if (pp.useF)
-    nvf = loransac_f(p2.data(), l1.data(), l2.data(), T, pp.err_threshold, pp.confidence, pp.max_samples,
-                     pp.localOptimization, pp.LAFCoef, pp.doSymmCheck, pp.errorType, pp.ransac_seed, res->H,
-                     res->ransac_inlier, res->verified, dout);
-  else
-    nvf = loransac_h(p2.data(), l1.data(), l2.data(), T, pp.err_threshold, pp.confidence, pp.max_samples,
-                         pp.localOptimization, pp.HLAFCoef, pp.doSymmCheck, pp.ransac_seed, res->H, Hraw, res->ransac_inlier,
-                         res->verified, dout);
-  res->n_verified = nvf < 0 ? 0 : nvf;
-  for (int i = 0; i < T; i++) res->n_ransac_inliers += res->ransac_inlier[i];
-  res->ransac_samples = dout[0]; res->ransac_lo = dout[1];
+  verify_tentatives(regs[0], regs[1], tents, pp, res);
   return MODSX_OK;
 }
 
