@@ -350,8 +350,17 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
   for (int i = 0; i < n; i++) maxOct = std::max(maxOct, c->pyr[i].nOct);
   for (int o = 0; o < maxOct; o++) {
     int nj = 0, mr = 0, mc = 0;
+    auto flush = [&]() {
+      if (!nj) return;
+      double px = 0;
+      for (int q = 0; q < nj; q++) px += (double)nb.j[q].rows * nb.j[q].cols;
+      ProfScope ps(c, K_NMS, px * 12);
+      launch_nms(s, nb, nj, mr, mc, (Candidate *)c->cand.p, (unsigned *)c->counter.p, CAND_CAP);
+      nj = 0; mr = 0; mc = 0;
+    };
     for (int i = 0; i < n; i++) {
       if (c->pyr[i].nOct <= o) continue;
+      if (nj + p.numberOfScales > NMS_MAXJ) flush();
       Octave &oc = c->pyr[i].oct[o];
       for (int l = 1; l <= p.numberOfScales; l++) {
         NmsJob &j = nb.j[nj++];
@@ -360,10 +369,7 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
         mr = std::max(mr, oc.rows); mc = std::max(mc, oc.cols);
       }
     }
-    double px = 0;
-    for (int q = 0; q < nj; q++) px += (double)nb.j[q].rows * nb.j[q].cols;
-    ProfScope ps(c, K_NMS, px * 12);
-    launch_nms(s, nb, nj, mr, mc, (Candidate *)c->cand.p, (unsigned *)c->counter.p, CAND_CAP);
+    flush();
   }
   if (!c->hMisc.ensure(64)) return MODSX_ERR_NOMEM;
   MX_HIP(hipMemcpyAsync(c->hMisc.p, c->counter.p, 4, hipMemcpyDeviceToHost, s));

@@ -12,8 +12,8 @@
 namespace mx {
 
 // ---- device job descriptors (passed by value in kernel arguments) ----------------------
-constexpr int MAXB = 8;        // images per batched pyramid launch
-constexpr int NMS_MAXJ = 48;   // (image, octave, level) jobs per NMS launch
+constexpr int MAXB = 8;        // images per batched launch set (16 measured slower: per-context footprint)
+constexpr int NMS_MAXJ = 48;   // (image, level) jobs per NMS launch (flushed when full)
 constexpr int MAX_TAPS = 17;   // pyramid kernels: ksize <= 17
 
 struct BlurJob {

@@ -1,8 +1,8 @@
 #!/bin/bash
 # throughput sweep over (workers, batch); prints workers batch pairs/s
-for wb in "16 32" "16 64" "8 32" "12 48" "24 96" "6 24"; do
+for wb in "16 64" "16 128" "8 64" "12 96" "24 96"; do
   set -- $wb
-  timeout 300 python bench.py --no-cpu-baseline --workers $1 --batch $2 --steps 10 2>/dev/null > /tmp/o.json
+  timeout 300 python bench.py --no-cpu-baseline --workers $1 --batch $2 --steps 8 2>/dev/null > /tmp/o.json
   python - <<'PY'
 import json
 d = json.loads(open('/tmp/o.json').read().strip().splitlines()[-1])
