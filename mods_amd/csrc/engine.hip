@@ -163,7 +163,7 @@ void ctx_destroy(modsx_ctx *c) {
   hipSetDevice(c->dev);
   hipStreamSynchronize(c->stream);
   for (int i = 0; i < MAXB; i++) c->pyr[i].store.release();
-  DevBuf *bufs[] = {&c->cand, &c->counter, &c->affJobs, &c->affOut, &c->oriJobs, &c->oriOut, &c->descJobs, &c->tilePrefix,
+  DevBuf *bufs[] = {&c->nmsJobs, &c->cand, &c->counter, &c->affJobs, &c->affOut, &c->oriJobs, &c->oriOut, &c->descJobs, &c->tilePrefix,
                     &c->taps, &c->imgRefs, &c->scratchA, &c->scratchB, &c->descAllF[0], &c->descAllF[1], &c->descAllU8[0],
                     &c->descAllU8[1], &c->pos2, &c->matchRows, &c->matchWork, &c->misc, &c->scratchC, &c->needTab, &c->coordTab, &c->tileJob, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps};
   for (DevBuf *b : bufs) b->release();
@@ -348,28 +348,53 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
   nb.posTh = posTh; nb.negTh = negTh; nb.finalTh = finalTh; nb.border = p.border;
   int maxOct = 0;
   for (int i = 0; i < n; i++) maxOct = std::max(maxOct, c->pyr[i].nOct);
-  for (int o = 0; o < maxOct; o++) {
-    int nj = 0, mr = 0, mc = 0;
-    auto flush = [&]() {
-      if (!nj) return;
-      double px = 0;
-      for (int q = 0; q < nj; q++) px += (double)nb.j[q].rows * nb.j[q].cols;
+  // all (image, octave, level) scans of the batch in one launch (NMS_MAXJ jobs at most per launch)
+  std::vector<NmsJob> hjobs;
+  std::vector<int> hpfx(1, 0);
+  double px = 0;
+  auto flush = [&]() -> int {
+    const int nj = (int)hjobs.size();
+    if (!nj) return MODSX_OK;
+    const size_t jobBytes = (size_t)nj * sizeof(NmsJob), pfxBytes = (size_t)(nj + 1) * 4;
+    if (!c->nmsJobs.ensure(jobBytes + pfxBytes + 64)) return MODSX_ERR_NOMEM;
+    MX_HIP(hipMemcpyAsync(c->nmsJobs.p, hjobs.data(), jobBytes, hipMemcpyHostToDevice, s));
+    MX_HIP(hipMemcpyAsync((char *)c->nmsJobs.p + jobBytes, hpfx.data(), pfxBytes, hipMemcpyHostToDevice, s));
+    {
       ProfScope ps(c, K_NMS, px * 12);
-      launch_nms(s, nb, nj, mr, mc, (Candidate *)c->cand.p, (unsigned *)c->counter.p, CAND_CAP);
-      nj = 0; mr = 0; mc = 0;
-    };
+      launch_nms(s, nb, (const NmsJob *)c->nmsJobs.p, (const int *)((char *)c->nmsJobs.p + jobBytes), nj, hpfx.back(),
+                 (Candidate *)c->cand.p, (unsigned *)c->counter.p, CAND_CAP);
+    }
+    MX_HIP(hipStreamSynchronize(s));   // the host tables are reused by the next flush
+    hjobs.clear(); hpfx.assign(1, 0); px = 0;
+    return MODSX_OK;
+  };
+  for (int o = 0; o < maxOct; o++)
     for (int i = 0; i < n; i++) {
       if (c->pyr[i].nOct <= o) continue;
-      if (nj + p.numberOfScales > NMS_MAXJ) flush();
       Octave &oc = c->pyr[i].oct[o];
+      const int w = oc.cols - 2 * p.border, h = oc.rows - 2 * p.border;
+      if (w <= 0 || h <= 0) continue;
+      if ((int)hjobs.size() + p.numberOfScales > NMS_MAXJ) { int rcf = flush(); if (rcf) return rcf; }
       for (int l = 1; l <= p.numberOfScales; l++) {
-        NmsJob &j = nb.j[nj++];
+        NmsJob j;
         j.low = oc.resp[l - 1]; j.cur = oc.resp[l]; j.high = oc.resp[l + 1]; j.blur = oc.blur[l];
-        j.rows = oc.rows; j.cols = oc.cols; j.img = i; j.octave = o; j.level = l;
-        mr = std::max(mr, oc.rows); mc = std::max(mc, oc.cols);
+        j.rows = oc.rows; j.cols = oc.cols; j.img = i; j.octave = o; j.level = l; j.pad = 0;
+        hjobs.push_back(j);
+        hpfx.push_back(hpfx.back() + ((w + 63) / 64) * ((h + 3) / 4));
+        px += (double)oc.rows * oc.cols;
       }
     }
-    flush();
+  const bool pendingJobs = !hjobs.empty();
+  if (pendingJobs) {
+    // last flush: no extra synchronisation, the counter read-back below waits for the launch
+    const int nj = (int)hjobs.size();
+    const size_t jobBytes = (size_t)nj * sizeof(NmsJob), pfxBytes = (size_t)(nj + 1) * 4;
+    if (!c->nmsJobs.ensure(jobBytes + pfxBytes + 64)) return MODSX_ERR_NOMEM;
+    MX_HIP(hipMemcpyAsync(c->nmsJobs.p, hjobs.data(), jobBytes, hipMemcpyHostToDevice, s));
+    MX_HIP(hipMemcpyAsync((char *)c->nmsJobs.p + jobBytes, hpfx.data(), pfxBytes, hipMemcpyHostToDevice, s));
+    ProfScope ps(c, K_NMS, px * 12);
+    launch_nms(s, nb, (const NmsJob *)c->nmsJobs.p, (const int *)((char *)c->nmsJobs.p + jobBytes), nj, hpfx.back(),
+               (Candidate *)c->cand.p, (unsigned *)c->counter.p, CAND_CAP);
   }
   if (!c->hMisc.ensure(64)) return MODSX_ERR_NOMEM;
   MX_HIP(hipMemcpyAsync(c->hMisc.p, c->counter.p, 4, hipMemcpyDeviceToHost, s));

@@ -13,7 +13,7 @@ namespace mx {
 
 // ---- device job descriptors (passed by value in kernel arguments) ----------------------
 constexpr int MAXB = 8;        // images per batched launch set (16 measured slower: per-context footprint)
-constexpr int NMS_MAXJ = 48;   // (image, level) jobs per NMS launch (flushed when full)
+constexpr int NMS_MAXJ = 1024; // (image, octave, level) jobs per NMS launch (flushed when full)
 constexpr int MAX_TAPS = 17;   // pyramid kernels: ksize <= 17
 
 struct BlurJob {
@@ -39,11 +39,10 @@ struct NmsJob {
   const float *low, *cur, *high, *blur;
   int rows, cols, img, octave, level, pad;
 };
-struct NmsBatch {
+struct NmsBatch {   // thresholds of one scan; the (image, octave, level) jobs and their tile prefix live in device memory
   float posTh, negTh, finalTh;
   int border;
   double edgeScoreThreshold;
-  NmsJob j[NMS_MAXJ];
 };
 struct Candidate {
   int img, octave, level, type;
@@ -153,7 +152,7 @@ void rectify(double &a11, double &a12, double &a21, double &a22);
 void launch_blur_hess(hipStream_t s, const BlurBatch &b, int nj, int maxRows, int maxCols);
 void launch_hessian(hipStream_t s, const BlurBatch &b, int nj, int maxRows, int maxCols);
 void launch_resize_half(hipStream_t s, const ResizeBatch &b, int nj, int maxRows, int maxCols);
-void launch_nms(hipStream_t s, const NmsBatch &b, int nj, int maxRows, int maxCols, Candidate *out, unsigned *counter,
+void launch_nms(hipStream_t s, const NmsBatch &b, const NmsJob *jobs, const int *tilePrefix, int nj, int nTiles, Candidate *out, unsigned *counter,
                 unsigned cap);
 void launch_gray(hipStream_t s, const void *src, float *dst, size_t n, int channels, int dtype);
 void launch_baumberg(hipStream_t s, const AffJob *jobs, AffOut *out, int n, const float *mask, int W, int maxIter,
@@ -201,7 +200,7 @@ struct modsx_ctx {
   int dev;
   hipStream_t stream;
   mx::Pyramid pyr[mx::MAXB];
-  mx::DevBuf cand, counter, affJobs, affOut, oriJobs, oriOut, descJobs, tilePrefix, taps, imgRefs, scratchA, scratchB,
+  mx::DevBuf nmsJobs, cand, counter, affJobs, affOut, oriJobs, oriOut, descJobs, tilePrefix, taps, imgRefs, scratchA, scratchB,
       descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps, scratchC, needTab, coordTab, tileJob;
   mx::PinBuf hCand, hAff, hOri, hDesc, hMisc;
   // constant tables on device

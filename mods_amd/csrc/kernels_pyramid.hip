@@ -193,10 +193,27 @@ MX_D bool is_min9(float val, const float *p, int cols) {
   return ok;
 }
 
-__global__ __launch_bounds__(256) void k_nms_localize(NmsBatch batch, Candidate *out, unsigned *counter, unsigned cap) {
-  const NmsJob jb = batch.j[blockIdx.z];
+// One launch scans every (image, octave, level) of a batch: the 64 x 4 pixel tiles of all jobs are numbered
+// consecutively (tilePrefix) and a workgroup finds its job by a binary search in LDS.  A candidate's path is a chain of
+// ~10 dependent memory round trips (3 x 9-neighbour tests, <= 5 Newton steps), which is what a launch lasts however few
+// pixels it covers -- hence one launch instead of one per octave.
+__global__ __launch_bounds__(256) void k_nms_localize(NmsBatch batch, const NmsJob *jobs, const int *tilePrefix, int nj,
+                                                      Candidate *out, unsigned *counter, unsigned cap) {
+  __shared__ int spfx[NMS_MAXJ + 1];
+  for (int i = threadIdx.x; i <= nj; i += 256) spfx[i] = tilePrefix[i];
+  __syncthreads();
+  const int tile = blockIdx.x;
+  int lo = 0, hi = nj - 1;
+  while (lo < hi) {   // last job whose first tile is <= tile
+    const int mid = (lo + hi + 1) >> 1;
+    if (spfx[mid] <= tile) lo = mid; else hi = mid - 1;
+  }
+  const NmsJob jb = jobs[lo];
   const int rows = jb.rows, cols = jb.cols, B = batch.border;
-  int c = B + blockIdx.x * 64 + (threadIdx.x & 63), r = B + blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int local = tile - spfx[lo];
+  const int tilesX = (cols - 2 * B + 63) / 64;
+  const int by = local / tilesX, bx = local - by * tilesX;
+  int c = B + bx * 64 + (threadIdx.x & 63), r = B + by * 4 + (threadIdx.x >> 6);
   if (r >= rows - B || c >= cols - B) return;
   const size_t off = (size_t)r * cols + c;
   const float v0 = jb.cur[off];
@@ -294,12 +311,10 @@ void launch_resize_half(hipStream_t s, const ResizeBatch &b, int nj, int maxRows
   dim3 grid((maxCols + 63) / 64, (maxRows + 3) / 4, nj);
   hipLaunchKernelGGL(k_resize_half, grid, dim3(256), 0, s, b);
 }
-void launch_nms(hipStream_t s, const NmsBatch &b, int nj, int maxRows, int maxCols, Candidate *out, unsigned *counter,
-                unsigned cap) {
-  int w = maxCols - 2 * b.border, h = maxRows - 2 * b.border;
-  if (w <= 0 || h <= 0 || nj <= 0) return;
-  dim3 grid((w + 63) / 64, (h + 3) / 4, nj);
-  hipLaunchKernelGGL(k_nms_localize, grid, dim3(256), 0, s, b, out, counter, cap);
+void launch_nms(hipStream_t s, const NmsBatch &b, const NmsJob *jobs, const int *tilePrefix, int nj, int nTiles, Candidate *out,
+                unsigned *counter, unsigned cap) {
+  if (nj <= 0 || nTiles <= 0) return;
+  hipLaunchKernelGGL(k_nms_localize, dim3(nTiles), dim3(256), 0, s, b, jobs, tilePrefix, nj, out, counter, cap);
 }
 void launch_gray(hipStream_t s, const void *src, float *dst, size_t n, int channels, int dtype) {
   dim3 grid((unsigned)((n + 255) / 256));
