@@ -225,3 +225,30 @@ def test_full_size_pair_properties(ctx, modsx, oracle):
     again = ctx.match_pair(ia, ib, modsx.default_pair_params(ransac_seed=5))                # idempotent
     assert np.array_equal(again["ransac_inlier"], got["ransac_inlier"]) and np.array_equal(again["H"], got["H"])
     ia.free(); ib.free()
+
+
+def test_grouped_pairs_equal_single_pairs(modsx, small_pair):
+    """modsx_match_pairs runs up to four pairs (eight images, mixed sizes) as one batch per context; every result
+    must be the one modsx_match_pair returns for that pair alone."""
+    from mods_amd import synthetic
+    a, b, _ = small_pair
+    a2, b2, _ = synthetic.make_pair(rows=200, cols=272, nblobs=260, seed=31)
+    a3, b3, _ = synthetic.make_pair(rows=256, cols=256, nblobs=300, seed=32)
+    ctxs = [modsx.Context(0), modsx.Context(0)]
+    hosts = [(a, b), (a2, b2), (a3, b3), (b, a), (a2, b3[:200, :]), (a, b), (b2, a2)]
+    dev = [(ctxs[0].upload(x), ctxs[0].upload(y)) for x, y in hosts]
+    par = modsx.default_pair_params(ransac_seed=9)
+    singles = [ctxs[0].match_pair(x, y, par) for x, y in dev]
+    for nctx in (1, 2):
+        got = modsx.match_pairs(ctxs[:nctx], [x for x, _ in dev], [y for _, y in dev], par)
+        assert len(got) == len(singles)
+        for g, s in zip(got, singles):
+            assert g["n_regions"] == s["n_regions"] and g["n_tentatives"] == s["n_tentatives"]
+            assert g["n_verified"] == s["n_verified"] and g["ransac_samples"] == s["ransac_samples"]
+            for f in s["tentatives"].dtype.names:
+                assert np.array_equal(g["tentatives"][f], s["tentatives"][f]), f
+            assert np.array_equal(g["verified"], s["verified"]) and np.array_equal(g["H"], s["H"])
+    for x, y in dev:
+        x.free(); y.free()
+    for c in ctxs:
+        c.close()
