@@ -31,14 +31,15 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int BIG = 0x7fffffff;
 constexpr unsigned UBIG = 0xffffffffu;
-constexpr int TILES_PER_SPLIT_MAX = 512;   // 9 bits of local tile index in the packed key
+constexpr int TILES_PER_SPLIT_MAX = 256;   // 8 bits of local tile index in the packed key of sweep 1
 constexpr int TPS = 4;                     // train tiles staged per barrier (4 x 4 KB per LDS buffer)
 
-__global__ __launch_bounds__(256) void k_desc_norms(const uint8_t *d, int n, int *norms) {
+// norms[i] = |d_i - 128|^2; normS[i] (optional) = |d_i - 128|^2 + 2 sum(d_i - 128), the column constant of sweep 1
+__global__ __launch_bounds__(256) void k_desc_norms(const uint8_t *d, int n, int *norms, int *normS) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const v4i *p = reinterpret_cast<const v4i *>(d + (size_t)i * 128);
-  int s = 0;
+  int s = 0, lin = 0;
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     const v4i v = p[q];
@@ -46,10 +47,11 @@ __global__ __launch_bounds__(256) void k_desc_norms(const uint8_t *d, int n, int
     for (int w = 0; w < 4; w++) {
       const int x = v[w] ^ 0x80808080;
 #pragma unroll
-      for (int b = 0; b < 4; b++) { const int e = (int)(signed char)((x >> (8 * b)) & 0xff); s += e * e; }
+      for (int b = 0; b < 4; b++) { const int e = (int)(signed char)((x >> (8 * b)) & 0xff); s += e * e; lin += e; }
     }
   }
   norms[i] = s;
+  if (normS) normS[i] = s + 2 * lin;
 }
 
 MX_D bool ratio_pass(float d0, float d, double sqminratio) {
@@ -69,11 +71,20 @@ MX_D int ratio_dmin(int d0i, double sqminratio) {
 MX_D bool lex_less(int da, int ia, int db, int ib) { return da < db || (da == db && ia < ib); }
 // median of three (folds to v_med3_u32): with m1 <= m2 the new second-smallest after seeing k is med3(m1, m2, k)
 MX_D unsigned umed3(unsigned a, unsigned b, unsigned c) { return min(max(a, b), max(min(a, b), c)); }
+MX_D int imed3(int a, int b, int c) { return min(max(a, b), max(min(a, b), c)); }
 
 // A fragment: 16 bytes [32*kb + 16*hi, +16) of a descriptor, u8 -> i8 (x - 128 == x ^ 0x80)
 MX_D v4i load_a(const uint8_t *base, int row, int kb, int hi) {
   v4i v = *reinterpret_cast<const v4i *>(base + (size_t)row * 128 + 32 * kb + 16 * hi);
   v[0] ^= 0x80808080; v[1] ^= 0x80808080; v[2] ^= 0x80808080; v[3] ^= 0x80808080;
+  return v;
+}
+
+// the query fragment of sweep 1: a'' = 127 - a = -(a - 128) - 1 (u8 -> i8 by x ^ 0x7f), so that
+// a''.b' = -(a'.b') - sum(b') and the distance key needs no negation of the accumulator
+MX_D v4i load_a_neg(const uint8_t *base, int row, int kb, int hi) {
+  v4i v = *reinterpret_cast<const v4i *>(base + (size_t)row * 128 + 32 * kb + 16 * hi);
+  v[0] ^= 0x7f7f7f7f; v[1] ^= 0x7f7f7f7f; v[2] ^= 0x7f7f7f7f; v[3] ^= 0x7f7f7f7f;
   return v;
 }
 
@@ -105,7 +116,7 @@ MX_D v4i read_b(const unsigned char *lds, int col, int kb, int hi) {
 
 // ---------------- sweep 1: per (query, split) top-2 -------------------------------------------------------
 __global__ __launch_bounds__(256) void k_match_sweep1(const uint8_t *d1, const int *norm1, const uint8_t *d2,
-                                                      const int *norm2, MatchGeom g, int4 *partial) {
+                                                      const int *normS2, MatchGeom g, int4 *partial) {
   __shared__ __attribute__((aligned(16))) unsigned char tileBuf[2][TPS * 4096];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 31, hi = lane >> 5;
@@ -114,17 +125,16 @@ __global__ __launch_bounds__(256) void k_match_sweep1(const uint8_t *d1, const i
   const int qrow = min(q0 + col, g.n1 - 1);
   v4i a[4];
 #pragma unroll
-  for (int kb = 0; kb < 4; kb++) a[kb] = load_a(d1, qrow, kb, hi);
-  // key(d, tile) = (d << 9) | tile with d = na + nb - 2 a'.b'  ==  ((na << 9) + ((nb << 9) | tile)) - (a'.b' << 10):
-  // one add, one 24-bit multiply-add, one min and one med3 per matrix element
-  int naS[16];
-#pragma unroll
-  for (int r = 0; r < 16; r++) naS[r] = norm1[min(q0 + (r & 3) + 8 * (r >> 2) + 4 * hi, g.n1 - 1)] << 9;
+  for (int kb = 0; kb < 4; kb++) a[kb] = load_a_neg(d1, qrow, kb, hi);
+  // Per row the query norm na is a constant, so the running top-2 is kept on
+  //   key = ((nb - 2 a'.b') << 8) | tile = (acc << 9) + (((nb + 2 sum b') << 8) | tile)   with acc = a''.b',
+  // i.e. ONE v_lshl_add, one signed min and one signed med3 per matrix element; |nb - 2 a'.b'| < 2^23, so the key
+  // fits an int32 with 8 tile bits (tilesPerSplit <= 256).
   const int ntilesAll = (g.n2 + 31) >> 5;
   const int tBeg = sp * g.tilesPerSplit, tEnd = min(tBeg + g.tilesPerSplit, ntilesAll);
-  unsigned m1[16], m2[16];
+  int m1[16], m2[16];
 #pragma unroll
-  for (int r = 0; r < 16; r++) { m1[r] = UBIG; m2[r] = UBIG; }
+  for (int r = 0; r < 16; r++) { m1[r] = BIG; m2[r] = BIG; }
   for (int q = 0; q < TPS; q++) if (tBeg + q < tEnd) stage_tile(d2, g.n2, tBeg + q, tileBuf[0] + q * 4096, tid);
   __syncthreads();
   for (int tg = tBeg; tg < tEnd; tg += TPS) {
@@ -144,11 +154,11 @@ __global__ __launch_bounds__(256) void k_match_sweep1(const uint8_t *d1, const i
       for (int kb = 0; kb < 4; kb++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], read_b(tb, col, kb, hi), acc, 0, 0, 0);
       const int trow = t * 32 + col;
       if (t < tEnd && trow < g.n2) {
-        const int tileC = (norm2[trow] << 9) | (t - tBeg);
+        const int tileC = (normS2[trow] << 8) | (t - tBeg);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          const unsigned key = (unsigned)(__mul24(acc[r], -1024) + (naS[r] + tileC));
-          m2[r] = umed3(m1[r], m2[r], key);
+          const int key = (acc[r] << 9) + tileC;
+          m2[r] = imed3(m1[r], m2[r], key);
           m1[r] = min(m1[r], key);
         }
       }
@@ -160,8 +170,9 @@ __global__ __launch_bounds__(256) void k_match_sweep1(const uint8_t *d1, const i
   // unpack and merge the per-lane top-2 over the 32 lanes that hold the same rows
 #pragma unroll
   for (int r = 0; r < 16; r++) {
-    int d0 = m1[r] == UBIG ? BIG : (int)(m1[r] >> 9), i0 = m1[r] == UBIG ? BIG : (tBeg + (int)(m1[r] & 511)) * 32 + col;
-    int dd1 = m2[r] == UBIG ? BIG : (int)(m2[r] >> 9), i1 = m2[r] == UBIG ? BIG : (tBeg + (int)(m2[r] & 511)) * 32 + col;
+    const int na = norm1[min(q0 + (r & 3) + 8 * (r >> 2) + 4 * hi, g.n1 - 1)];
+    int d0 = m1[r] == BIG ? BIG : (m1[r] >> 8) + na, i0 = m1[r] == BIG ? BIG : (tBeg + (m1[r] & 255)) * 32 + col;
+    int dd1 = m2[r] == BIG ? BIG : (m2[r] >> 8) + na, i1 = m2[r] == BIG ? BIG : (tBeg + (m2[r] & 255)) * 32 + col;
 #pragma unroll
     for (int m = 16; m >= 1; m >>= 1) {
       const int od0 = __shfl_xor(d0, m), oi0 = __shfl_xor(i0, m), od1 = __shfl_xor(dd1, m), oi1 = __shfl_xor(i1, m);
@@ -330,7 +341,7 @@ size_t match_workspace_bytes(int n1, int n2, int *S_out, int *tilesPerSplit_out)
   if (S < 1) S = 1;
   *S_out = S; *tilesPerSplit_out = tps;
   size_t bytes = 0;
-  bytes += (size_t)(n1 + n2) * 4 + 256;          // norms
+  bytes += (size_t)(n1 + 2 * (size_t)n2) * 4 + 768;  // norms (+ the sweep-1 column constants of the trains)
   bytes += (size_t)n1 * S * 16 * 2 + 256;        // partial, partial2
   bytes += (size_t)n1 * 4 * 2 + 256;             // dmin, undecided
   bytes += 256;                                  // counter
@@ -345,15 +356,15 @@ void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, i
   match_workspace_bytes(n1, n2, &g.S, &g.tilesPerSplit);
   char *w = (char *)workspace;
   auto take = [&](size_t bytes) { char *p = w; w += (bytes + 255) & ~(size_t)255; return p; };
-  int *norm1 = (int *)take((size_t)n1 * 4), *norm2 = (int *)take((size_t)n2 * 4);
+  int *norm1 = (int *)take((size_t)n1 * 4), *norm2 = (int *)take((size_t)n2 * 4), *normS2 = (int *)take((size_t)n2 * 4);
   int4 *partial = (int4 *)take((size_t)n1 * g.S * 16), *partial2 = (int4 *)take((size_t)n1 * g.S * 16);
   int *dmin = (int *)take((size_t)n1 * 4), *undecided = (int *)take((size_t)n1 * 4);
   int *counter = (int *)take(64);
   hipMemsetAsync(counter, 0, 4, s);
-  hipLaunchKernelGGL(k_desc_norms, dim3((n1 + 255) / 256), dim3(256), 0, s, d1, n1, norm1);
-  hipLaunchKernelGGL(k_desc_norms, dim3((n2 + 255) / 256), dim3(256), 0, s, d2, n2, norm2);
+  hipLaunchKernelGGL(k_desc_norms, dim3((n1 + 255) / 256), dim3(256), 0, s, d1, n1, norm1, (int *)nullptr);
+  hipLaunchKernelGGL(k_desc_norms, dim3((n2 + 255) / 256), dim3(256), 0, s, d2, n2, norm2, normS2);
   const dim3 grid((n1 + 127) / 128, g.S);
-  hipLaunchKernelGGL(k_match_sweep1, grid, dim3(256), 0, s, d1, norm1, d2, norm2, g, partial);
+  hipLaunchKernelGGL(k_match_sweep1, grid, dim3(256), 0, s, d1, norm1, d2, normS2, g, partial);
   hipLaunchKernelGGL(k_match_decide, dim3((n1 + 255) / 256), dim3(256), 0, s, partial, g, pos2, sqminratio, contrDistSq,
                      rows, dmin, undecided, counter);
   hipLaunchKernelGGL(k_match_sweep2, grid, dim3(256), 0, s, d1, norm1, d2, norm2, g, pos2, contrDistSq, rows, dmin,
