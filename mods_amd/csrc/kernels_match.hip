@@ -135,36 +135,59 @@ __global__ __launch_bounds__(256) void k_match_sweep1(const uint8_t *d1, const i
   int m1[16], m2[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) { m1[r] = BIG; m2[r] = BIG; }
-  for (int q = 0; q < TPS; q++) if (tBeg + q < tEnd) stage_tile(d2, g.n2, tBeg + q, tileBuf[0] + q * 4096, tid);
+  // tiles past the end of the split are staged as zeros (b' = 0 => acc = 0) and get the column constant BIG, so
+  // their keys are BIG and the tile loop needs no branches
+  const int NOTILE = 0x3fffffff >> 5;   // fetch_tile sees a row index >= n2 and returns zeros
+  for (int q = 0; q < TPS; q++) stage_tile(d2, g.n2, tBeg + q < tEnd ? tBeg + q : NOTILE, tileBuf[0] + q * 4096, tid);
   __syncthreads();
   for (int tg = tBeg; tg < tEnd; tg += TPS) {
     const int cur = ((tg - tBeg) / TPS) & 1;
     v4i nxt[TPS];
 #pragma unroll
+    for (int q = 0; q < TPS; q++) nxt[q] = fetch_tile(d2, g.n2, tg + TPS + q < tEnd ? tg + TPS + q : NOTILE, tid);
+    int tileC[TPS];
+#pragma unroll
     for (int q = 0; q < TPS; q++) {
-      nxt[q] = (v4i){0, 0, 0, 0};
-      if (tg + TPS + q < tEnd) nxt[q] = fetch_tile(d2, g.n2, tg + TPS + q, tid);
+      const int t = tg + q, trow = t * 32 + col;
+      tileC[q] = (t < tEnd && trow < g.n2) ? ((normS2[trow] << 8) | (t - tBeg)) : BIG;
+    }
+    // software pipeline inside a wave: the four MFMAs of tile q are issued between the four quarters of the top-2
+    // update of tile q - 1, so the VALU work runs in the shadow of the matrix pipe
+    v16i accP = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    {
+      const unsigned char *tb = tileBuf[cur];
+#pragma unroll
+      for (int kb = 0; kb < 4; kb++) accP = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], read_b(tb, col, kb, hi), accP, 0, 0, 0);
     }
 #pragma unroll
-    for (int q = 0; q < TPS; q++) {
-      const int t = tg + q;
+    for (int q = 1; q < TPS; q++) {
       const unsigned char *tb = tileBuf[cur] + q * 4096;
-      v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      v4i bf[4];
 #pragma unroll
-      for (int kb = 0; kb < 4; kb++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], read_b(tb, col, kb, hi), acc, 0, 0, 0);
-      const int trow = t * 32 + col;
-      if (t < tEnd && trow < g.n2) {
-        const int tileC = (normS2[trow] << 8) | (t - tBeg);
+      for (int kb = 0; kb < 4; kb++) bf[kb] = read_b(tb, col, kb, hi);
+      v16i accN = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int key = (acc[r] << 9) + tileC;
+      for (int kb = 0; kb < 4; kb++) {
+        accN = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], bf[kb], accN, 0, 0, 0);
+#pragma unroll
+        for (int r = 4 * kb; r < 4 * kb + 4; r++) {
+          const int key = (accP[r] << 9) + tileC[q - 1];
           m2[r] = imed3(m1[r], m2[r], key);
           m1[r] = min(m1[r], key);
         }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA ...
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);  // ... then the 12 VALU ops of a quarter update
       }
+      accP = accN;
     }
 #pragma unroll
-    for (int q = 0; q < TPS; q++) if (tg + TPS + q < tEnd) put_tile(nxt[q], tileBuf[cur ^ 1] + q * 4096, tid);
+    for (int r = 0; r < 16; r++) {
+      const int key = (accP[r] << 9) + tileC[TPS - 1];
+      m2[r] = imed3(m1[r], m2[r], key);
+      m1[r] = min(m1[r], key);
+    }
+#pragma unroll
+    for (int q = 0; q < TPS; q++) put_tile(nxt[q], tileBuf[cur ^ 1] + q * 4096, tid);
     __syncthreads();
   }
   // unpack and merge the per-lane top-2 over the 32 lanes that hold the same rows
