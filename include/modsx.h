@@ -35,7 +35,10 @@ enum { MODSX_FIXED_TH = 0, MODSX_RELATIVE_TH = 1, MODSX_FIXED_REG_NUMBER = 2, MO
        MODSX_NOT_LESS_THAN_REGIONS = 4 };
 /* detector_type / descriptor_type, detectors/structures.hpp:17-38, 75-96 */
 enum { MODSX_DET_HESSIAN = 0 };
-enum { MODSX_DESC_SIFT = 0, MODSX_DESC_ROOT_SIFT = 1 };
+/* descriptor types of SIFTDescriptor::operator() (matching/siftdesc.cpp:399-442).  The half variants fold opposite
+ * orientation bins into 64 values; their rows keep the 128 stride with entries 64..127 zero, which leaves every
+ * L2 distance unchanged, so the matcher needs no second layout. */
+enum { MODSX_DESC_SIFT = 0, MODSX_DESC_ROOT_SIFT = 1, MODSX_DESC_HALF_SIFT = 2, MODSX_DESC_HALF_ROOT_SIFT = 3 };
 /* ScaleSpaceDetector point types, affinedetectors/pyramid.h:32-36 */
 enum { MODSX_HESSIAN_DARK = 0, MODSX_HESSIAN_BRIGHT = 1, MODSX_HESSIAN_SADDLE = 2 };
 

@@ -222,7 +222,7 @@ int modsx_describe_regions(modsx_ctx *ctx, const modsx_image *img, const modsx_r
                            float *desc) {
   NEED(ctx); NEED(img);
   if (n < 0 || (n > 0 && (!regs || !desc))) { mx::set_error("modsx_describe_regions: bad argument"); return MODSX_ERR_ARG; }
-  if (desc_type != MODSX_DESC_SIFT && desc_type != MODSX_DESC_ROOT_SIFT) { mx::set_error("descriptor type"); return MODSX_ERR_ARG; }
+  if (desc_type < MODSX_DESC_SIFT || desc_type > MODSX_DESC_HALF_ROOT_SIFT) { mx::set_error("descriptor type"); return MODSX_ERR_ARG; }
   hipSetDevice(ctx->dev);
   std::vector<modsx_region> v[1];
   v[0].assign(regs, regs + n);

@@ -851,7 +851,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       ProfScope psd(c, K_DESCRIBE, (double)arenaC * 4 + (double)nj * (128 * 5));
       launch_describe(s, dj, (int)nj, (ImgRef *)c->imgRefs.p, (float *)c->scratchC.p, (int *)c->needTab.p, (float *)c->coordTab.p,
                       c->dSiftMask, c->dSiftMaskIdx, c->nSiftMask, c->dAtan,
-                      c->dSiftBins, c->dSiftW, photoNorm, descType == MODSX_DESC_ROOT_SIFT, maxBin, outs);
+                      c->dSiftBins, c->dSiftW, photoNorm, descType, maxBin, outs);
       MX_HIP(hipStreamSynchronize(s));  // jobs/taps/prefix are host vectors reused by the next chunk
     }
   }

@@ -167,7 +167,7 @@ void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix
 void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *imgs, const float *grid,
                      const int *needTab, const float *coordTab,
                      const float *mask, const unsigned short *maskIdx, int nmask, const double *atanLut, const int *bins,
-                     const double *wts, int photoNorm, int rootsift, double maxBin, const DescOut &outs);
+                     const double *wts, int photoNorm, int descType, double maxBin, const DescOut &outs);
 void launch_warp_affine(hipStream_t s, const WarpJob &jb);
 void launch_blur_pass(hipStream_t s, const float *src, float *dst, int rows, int cols, const float *taps, int n, int pass);
 size_t match_workspace_bytes(int n1, int n2, int *S_out, int *tilesPerSplit_out);

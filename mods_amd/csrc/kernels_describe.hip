@@ -173,7 +173,7 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
                                                   const int *needTab, const float *coordTab,
                                                   const float *mask, const unsigned short *maskIdx,
                                                   const double *atanLut, const int *binTab, const double *wTab,
-                                                  SiftConst sc, int photoNorm, int rootsift, double maxBin,
+                                                  SiftConst sc, int photoNorm, int descType, double maxBin,
                                                   DescOut outs) {
   const int k = blockIdx.x;
   if (k >= n) return;
@@ -348,6 +348,16 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
     vec[tid] = acc;
   }
   __syncthreads();
+  const bool rootsift = (descType & 1) != 0;
+  if (descType >= 2) {
+    // HalfSIFT / HalfRootSIFT (siftdesc.cpp:412-433): opposite orientation bins are folded before the norm.  The upper
+    // 64 entries become +0, which every later sum, clip and quantisation leaves untouched.
+    const int sb = tid >> 2, j = tid & 3;
+    const double h = tid < 64 ? vec[sb * 8 + j] + vec[sb * 8 + j + 4] : 0.0;
+    __syncthreads();
+    vec[tid] = h;
+    __syncthreads();
+  }
   // -- normalize / clip / renormalize (siftdesc.cpp:136-158, 199-221, 247-262)
   for (int pass = 0; pass < 2; pass++) {
     if (tid < 32) {
@@ -411,13 +421,13 @@ void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix
 }
 void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *imgs, const float *grid,
                      const int *needTab, const float *coordTab, const float *mask, const unsigned short *maskIdx, int nmask, const double *atanLut, const int *bins,
-                     const double *wts, int photoNorm, int rootsift, double maxBin, const DescOut &outs) {
+                     const double *wts, int photoNorm, int descType, double maxBin, const DescOut &outs) {
   if (n <= 0) return;
   SiftConst sc;
   sc.nmask = nmask;
   hipLaunchKernelGGL(k_describe, dim3(n), dim3(128), 0, s, jobs, n, imgs, grid, needTab, coordTab, mask, maskIdx, atanLut, bins,
                      wts, sc,
-                     photoNorm, rootsift, maxBin, outs);
+                     photoNorm, descType, maxBin, outs);
 }
 
 }  // namespace mx

@@ -156,7 +156,13 @@ struct Sift {
       }
     }
   }
-  void compute(const Img &patch, bool rootsift, float *desc) {
+  /* type: 0 SIFT, 1 RootSIFT, 2 HalfSIFT, 3 HalfRootSIFT (operator(), siftdesc.cpp:399-442).  The half variants
+   * skip the norm of the 128-bin histogram (doNorm = false), fold opposite orientation bins
+   * (half[i*4+j] = vec[i*8+j] + vec[i*8+j+4]) and normalise the 64-vector; desc[64..127] are written 0.
+   * NOTE: SIFTnorm's clip loop runs to the MEMBER vec.size() = 128 on the 64-element half vector
+   * (siftdesc.cpp:250-254), an out-of-bounds read/write in the reference; the loop is restated over the 64 entries. */
+  void compute(const Img &patch, int type, float *desc) {
+    const bool rootsift = (type & 1) != 0, half = type >= 2;
     const int w = patch.cols, h = patch.rows;
     Img grad(h, w), ori(h, w);
     for (int r = 0; r < h; ++r)
@@ -173,6 +179,14 @@ struct Sift {
       }
     for (auto &x : vec) x = 0;
     sample_patch(grad, ori);
+    std::vector<double> full;
+    if (half) {
+      full = vec;
+      std::vector<double> hv(64);
+      for (int i = 0, b = 0; i < 16; i++)
+        for (int j = 0; j < 4; j++) hv[b++] = full[i * 8 + j] + full[i * 8 + j + 4];
+      vec = hv;
+    }
     normalize(vec);
     bool changed = false;
     for (size_t i = 0; i < vec.size(); i++)
@@ -193,6 +207,10 @@ struct Sift {
       }
     }
     for (size_t i = 0; i < vec.size(); i++) desc[i] = (float)vec[i];
+    if (half) {
+      for (int i = 64; i < 128; i++) desc[i] = 0.f;
+      vec.assign(128, 0.0);
+    }
   }
 };
 
@@ -335,7 +353,7 @@ void orc_describe_patch(float *patch41, int photoNorm, int rootsift, double maxB
   Img p(41, 41, patch41);
   Sift sift(maxBinValue);
   if (photoNorm) photometrically_normalize(p, sift.mask);
-  sift.compute(p, rootsift != 0, desc);
+  sift.compute(p, rootsift, desc);
   memcpy(patch41, p.v.data(), p.v.size() * 4);
 }
 
@@ -346,7 +364,7 @@ void orc_describe_regions(const float *img_, int rows, int cols, const orc_regio
   for (int i = 0; i < n; i++) {
     extract_patch(img, regs[i].det_kp, mrSize, patchSize, fast != 0, patch);
     if (photoNorm) photometrically_normalize(patch, sift.mask);
-    sift.compute(patch, rootsift != 0, desc + (size_t)i * 128);
+    sift.compute(patch, rootsift, desc + (size_t)i * 128);
   }
 }
 }

@@ -107,11 +107,13 @@ def test_orientation_and_description_bit_exact(ctx, modsx, oracle, small_pair):
         assert len(ref) > 20 and same_records(got, ref.view(modsx.REGION))
     ro = oracle.detect_orientation(img, regs)
     rr = oracle.reproject_regions(ro, np.eye(3), img.shape[1], img.shape[0])
-    for rootsift in (1, 0):
+    for rootsift in (1, 0, 3, 2):      # RootSIFT, SIFT, HalfRootSIFT, HalfSIFT (siftdesc.cpp:399-442)
         for photo in (1, 0):
             ref = oracle.describe_regions(img, rr, rootsift=rootsift, photo_norm=photo)
             got = ctx.describe_regions(im, rr.view(modsx.REGION), desc_type=rootsift, photo_norm=photo)
             assert np.array_equal(got, ref), (rootsift, photo, int((got != ref).any(1).sum()), len(ref))
+            if rootsift >= 2:
+                assert not got[:, 64:].any() and got[:, :64].any()
     # fast extraction branch (synth-detection.hpp:232-253) and a tiny-scale region (direct branch, i2p <= 0.4)
     ref = oracle.describe_regions(img, rr, fast=1)
     got = ctx.describe_regions(im, rr.view(modsx.REGION), fast=1)
