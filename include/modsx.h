@@ -313,6 +313,23 @@ int modsx_match_ladder(modsx_ctx *ctx, const modsx_image *img1, const modsx_imag
                        const modsx_ladder_step *steps, int nsteps, int min_matches, const modsx_pair_params *par,
                        modsx_pair_result *res, int *steps_done);
 
+/* Key files: void ImageRepresentation::SaveRegions(std::string fname, int mode) / LoadRegions(std::string fname)
+ * (imagerepresentation.cpp:2139-2215; mods.cpp:236-241 reads them instead of detecting when read_pre_extracted is
+ * set).  Text format, one (detector, descriptor) class after the other; files are byte-identical to the reference's
+ * for the same lists.  A class = the AffineRegionVector of RegionVectorMap[det_name][desc_name]: n regions, their
+ * descriptors as n rows of `stride` floats of which the first `dim` are written. */
+typedef struct modsx_region_class {
+  const char *det_name, *desc_name;
+  const modsx_region *regs;
+  const float *desc;
+  int n, dim, stride;
+} modsx_region_class;
+int modsx_save_regions(const char *path, const modsx_region_class *classes, int nclasses);
+/* Loads the class (det_name, desc_name) -- NULL / "" = the first class in the file.  regs and desc ([n][*dim]) are
+ * malloc'd (modsx_free); found_det / found_desc (optional, >= 64 bytes) receive the names.  Returns n. */
+int modsx_load_regions(const char *path, const char *det_name, const char *desc_name, modsx_region **regs, float **desc,
+                       int *dim, char *found_det, char *found_desc);
+
 /* Measurement hooks (no reference counterpart; the reference only keeps wall-clock TimeLog, structures.hpp:51-74).
  * modsx_profile(ctx, 1) brackets every kernel launch with HIP events on the ctx stream and accumulates, per kernel
  * class, GPU milliseconds, launch count and algorithmic work (bytes; flops for the matcher).  Classes in order:

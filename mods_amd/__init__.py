@@ -84,7 +84,7 @@ EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "m
            "modsx_describe_regions", "modsx_match_fginn", "modsx_duplicate_filtering", "modsx_ransac_h",
            "modsx_loransac_h", "modsx_ransac_f", "modsx_loransac_f", "modsx_match_pair", "modsx_match_pairs", "modsx_pair_result_release",
            "modsx_set_vs_pars", "modsx_synth_view", "modsx_detect_describe_views", "modsx_match_fginn_device",
-           "modsx_match_pair_views", "modsx_match_ladder", "modsx_last_timings", "modsx_profile",
+           "modsx_match_pair_views", "modsx_match_ladder", "modsx_save_regions", "modsx_load_regions", "modsx_last_timings", "modsx_profile",
            "modsx_kernel_stats"]
 
 KERNEL_CLASSES = ["blur_hess", "hessian", "resize", "nms_localize", "baumberg", "orientation", "patch_sample",
@@ -246,6 +246,37 @@ def loransac_f(pts, laf1, laf2, err_threshold=4.0, confidence=0.99, max_samples=
                                       _p(dout)), "loransac_f")
     return dict(n=n, F=F.reshape(3, 3), inl=inl[:T].astype(bool), keep=keep[:T].astype(bool),
                 samples=int(dout[0]), lo_count=int(dout[1]), degen_count=int(dout[2]))
+
+
+class RegionClass(C.Structure):
+    _fields_ = [("det_name", C.c_char_p), ("desc_name", C.c_char_p), ("regs", C.c_void_p), ("desc", C.c_void_p),
+                ("n", C.c_int), ("dim", C.c_int), ("stride", C.c_int)]
+
+
+def save_regions(path, classes):
+    """ImageRepresentation::SaveRegions: classes = [(det_name, desc_name, regs (REGION), desc [n, stride] f32, dim)]."""
+    arr = (RegionClass * len(classes))()
+    keep = []
+    for i, (det, dn, regs, desc, dim) in enumerate(classes):
+        regs = np.ascontiguousarray(regs, REGION)
+        desc = np.ascontiguousarray(desc, np.float32).reshape(len(regs), -1) if len(regs) else np.zeros((0, max(dim, 1)), np.float32)
+        keep += [regs, desc]
+        arr[i].det_name, arr[i].desc_name = det.encode(), dn.encode()
+        arr[i].regs, arr[i].desc = regs.ctypes.data, desc.ctypes.data
+        arr[i].n, arr[i].dim, arr[i].stride = len(regs), dim, desc.shape[1]
+    _check(lib().modsx_save_regions(path.encode(), arr, len(classes)), "save_regions")
+
+
+def load_regions(path, det_name="", desc_name=""):
+    """ImageRepresentation::LoadRegions for one class: returns (det_name, desc_name, regs, desc [n, dim])."""
+    regs, desc = C.c_void_p(), C.c_void_p()
+    dim = C.c_int(0)
+    fd, fs = C.create_string_buffer(64), C.create_string_buffer(64)
+    n = _check(lib().modsx_load_regions(path.encode(), det_name.encode(), desc_name.encode(), C.byref(regs), C.byref(desc),
+                                        C.byref(dim), fd, fs), "load_regions")
+    r = _take(regs, n, REGION)
+    d = _take(desc, n * dim.value, np.dtype(np.float32)).reshape(n, dim.value)
+    return fd.value.decode(), fs.value.decode(), r, d
 
 
 def set_vs_pars(scale_set, tilt_set, phi_base, init_sigma=0.5, do_blur=1, prev=None):

@@ -438,6 +438,36 @@ int modsx_match_pair_views(modsx_ctx *ctx, const modsx_image *img1, const modsx_
   return match_pair_views(ctx, img1, img2, views, nviews, *par, res);
 }
 
+int modsx_save_regions(const char *path, const modsx_region_class *classes, int nclasses) {
+  if (!path || !classes || nclasses <= 0) { mx::set_error("modsx_save_regions: bad argument"); return MODSX_ERR_ARG; }
+  for (int i = 0; i < nclasses; i++) {
+    const modsx_region_class &c = classes[i];
+    if (!c.det_name || !c.desc_name || c.n < 0 || c.dim < 0 || c.stride < c.dim || (c.n > 0 && (!c.regs || (c.dim > 0 && !c.desc)))) {
+      mx::set_error("modsx_save_regions: bad class");
+      return MODSX_ERR_ARG;
+    }
+  }
+  return save_regions(path, classes, nclasses);
+}
+
+int modsx_load_regions(const char *path, const char *det_name, const char *desc_name, modsx_region **regs, float **desc,
+                       int *dim, char *found_det, char *found_desc) {
+  if (!path || !regs || !desc || !dim) { mx::set_error("modsx_load_regions: bad argument"); return MODSX_ERR_ARG; }
+  std::vector<modsx_region> r;
+  std::vector<float> d;
+  std::string fd, fs;
+  int rc = load_regions(path, det_name, desc_name, r, d, dim, &fd, &fs);
+  if (rc) return rc;
+  *regs = (modsx_region *)malloc(sizeof(modsx_region) * std::max<size_t>(1, r.size()));
+  *desc = (float *)malloc(sizeof(float) * std::max<size_t>(1, d.size()));
+  if (!*regs || !*desc) { free(*regs); free(*desc); mx::set_error("out of memory"); return MODSX_ERR_NOMEM; }
+  if (!r.empty()) memcpy(*regs, r.data(), sizeof(modsx_region) * r.size());
+  if (!d.empty()) memcpy(*desc, d.data(), sizeof(float) * d.size());
+  if (found_det) { strncpy(found_det, fd.c_str(), 63); found_det[63] = 0; }
+  if (found_desc) { strncpy(found_desc, fs.c_str(), 63); found_desc[63] = 0; }
+  return (int)r.size();
+}
+
 int modsx_profile(modsx_ctx *ctx, int enable) {
   NEED(ctx);
   prof_reset(ctx, enable != 0);

@@ -139,3 +139,62 @@ def test_glibc_prng_restatement(modsx):
     libc.srand(42)
     first = [libc.random() for _ in range(3)]
     assert first[0] == 71876166 and first[1] == 708592740        # glibc srand(42) known answers
+
+
+def _keyfile_text(classes):
+    """The key-file text SaveRegions writes (imagerepresentation.cpp:2139-2175, saveAR/saveKP :35-38, :89-99), restated
+    with C's %g (what ostream << double prints at the default precision)."""
+    g = lambda v: "%g" % v
+    def kp(k):
+        return (" ".join([g(k["x"]), g(k["y"]), g(k["a11"]), g(k["a12"]), g(k["a21"]), g(k["a22"])]) + " " +
+                g(k["pyramid_scale"]) + " %d " % k["octave_number"] + g(k["s"]) + " %d " % k["sub_type"])
+    dets = sorted({c[0] for c in classes})
+    out = ["%d\n" % len(dets)]
+    for det in dets:
+        cl = sorted([c for c in classes if c[0] == det], key=lambda c: c[1])
+        out.append("%s %d\n" % (det, len(cl)))
+        for _, dn, regs, desc, dim in cl:
+            out.append("%s %d\n" % (dn, len(regs)))
+            if len(regs):
+                out.append("%d\n" % dim)
+            for r, d in zip(regs, desc):
+                out.append("%d %d %d %d " % (r["id"], r["img_id"], r["img_reproj_id"], r["parent_id"]) + kp(r["det_kp"]) +
+                           kp(r["reproj_kp"]) + " %d " % dim + "".join(g(v) + " " for v in d[:dim]) + "\n")
+    return "".join(out)
+
+
+def test_key_file_round_trip(modsx, tmp_path):
+    rs = np.random.RandomState(3)
+    def regions(n):
+        r = np.zeros(n, modsx.REGION)
+        for side in ("det_kp", "reproj_kp"):
+            for f in ("x", "y", "a11", "a12", "a21", "a22", "s", "pyramid_scale"):
+                r[side][f] = rs.uniform(-3, 900, n) * rs.choice([1.0, 1e-3, 1e4], n)
+            r[side]["octave_number"] = rs.randint(0, 6, n)
+            r[side]["sub_type"] = rs.randint(0, 3, n)
+        r["id"] = np.arange(n); r["parent_id"] = rs.randint(0, max(n, 1), n); r["img_id"] = rs.randint(0, 9, n)
+        r["img_reproj_id"] = 0
+        return r
+    r1, r2, r3 = regions(37), regions(5), regions(0)
+    d1 = rs.randint(0, 256, (37, 128)).astype(np.float32)
+    d2 = np.zeros((5, 128), np.float32); d2[:, :64] = rs.randint(0, 256, (5, 64))
+    classes = [("HessianAffine", "RootSIFT", r1, d1, 128), ("HessianAffine", "HalfRootSIFT", r2, d2, 64),
+               ("MSER", "RootSIFT", r3, np.zeros((0, 128), np.float32), 128)]
+    path = str(tmp_path / "keys.txt")
+    modsx.save_regions(path, classes)
+    assert open(path).read() == _keyfile_text(classes)           # byte-identical to the reference's writer
+    det, dn, lr, ld = modsx.load_regions(path, "HessianAffine", "RootSIFT")
+    assert (det, dn, len(lr)) == ("HessianAffine", "RootSIFT", 37) and np.array_equal(ld, d1)
+    for side in ("det_kp", "reproj_kp"):
+        for f in ("x", "y", "a11", "a12", "a21", "a22", "s", "pyramid_scale"):
+            assert np.allclose(lr[side][f], r1[side][f], rtol=1e-5, atol=0)    # 6 significant digits survive
+        assert np.array_equal(lr[side]["octave_number"], r1[side]["octave_number"])
+    assert np.array_equal(lr["id"], r1["id"]) and np.array_equal(lr["parent_id"], r1["parent_id"])
+    det, dn, lr, ld = modsx.load_regions(path, "HessianAffine", "HalfRootSIFT")
+    assert ld.shape == (5, 64) and np.array_equal(ld, d2[:, :64])
+    det, dn, lr, ld = modsx.load_regions(path)                     # first class of the file (maps iterate sorted)
+    assert (det, dn) == ("HessianAffine", "HalfRootSIFT")
+    with pytest.raises(RuntimeError):
+        modsx.load_regions(path, "DoG", "SIFT")
+    with pytest.raises(RuntimeError):
+        modsx.load_regions(str(tmp_path / "missing.txt"))
