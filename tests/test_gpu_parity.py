@@ -114,6 +114,13 @@ def test_orientation_and_description_bit_exact(ctx, modsx, oracle, small_pair):
             assert np.array_equal(got, ref), (rootsift, photo, int((got != ref).any(1).sum()), len(ref))
             if rootsift >= 2:
                 assert not got[:, 64:].any() and got[:, :64].any()
+    # large windows: blur kernels of 33..128 taps (second ring size) and beyond 128 taps (materialised fallback)
+    big = rr[:8].copy()
+    for side in ("det_kp", "reproj_kp"):
+        big[side]["s"] = [14.0, 20.0, 33.0, 41.5, 56.0, 60.0, 75.0, 7.0]
+    ref = oracle.describe_regions(img, big)
+    got = ctx.describe_regions(im, big.view(modsx.REGION))
+    assert np.array_equal(got, ref), int((got != ref).any(1).sum())
     # fast extraction branch (synth-detection.hpp:232-253) and a tiny-scale region (direct branch, i2p <= 0.4)
     ref = oracle.describe_regions(img, rr, fast=1)
     got = ctx.describe_regions(im, rr.view(modsx.REGION), fast=1)
