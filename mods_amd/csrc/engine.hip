@@ -812,8 +812,8 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
         }
         jobs.push_back(j);
         pfxSample.push_back(pfxSample.back() + (j.P > 0 ? ((j.P + 63) / 64) * ((j.P + 127) / 128) : 0));  // 64 x SAMPLE_COLS tiles
-        pfxRow.push_back(pfxRow.back() + (j.P > 0 ? (j.P * j.NC + 255) / 256 : 0));
-        pfxCol.push_back(pfxCol.back() + (j.P > 0 ? (j.NC * j.NC + 255) / 256 : 0));
+        pfxRow.push_back(pfxRow.back() + (j.P > 0 ? (j.P * j.NC + 1023) / 1024 : 0));   // BLUR_TILE outputs per workgroup
+        pfxCol.push_back(pfxCol.back() + (j.P > 0 ? (j.NC * j.NC + 1023) / 1024 : 0));
       }
       if (full) break;
       }

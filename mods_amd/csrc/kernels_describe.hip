@@ -96,6 +96,11 @@ __global__ __launch_bounds__(64) void k_patch_sample(const DescJob *jobs, const 
 //                                                                         SymmRowSmallFilter when ksize <= 5)
 //   pass 1 filters the columns only at those rows:      NC x NC outputs  (SymmColumnFilter: centre + (below+above)*k)
 // Every output is the same sum of the same terms in the same order as in the full blur.
+// A workgroup forms BLUR_TILE outputs (4 per thread): the start of a workgroup is a chain of dependent loads (tile ->
+// job -> needed column -> inputs) that lasts longer than the arithmetic of 256 outputs, so fewer, fatter workgroups
+// run faster; the taps are parked in LDS so that a tap costs one vector load, not two.
+constexpr int BLUR_TILE = 1024, BLUR_TAPS = 128;
+
 __global__ __launch_bounds__(256) void k_patch_blur(const DescJob *jobs, const int *tilePrefix, const int *tileJob,
                                                     const float *taps, const int *needTab, const float *src,
                                                     float *dst, int pass) {
@@ -104,49 +109,78 @@ __global__ __launch_bounds__(256) void k_patch_blur(const DescJob *jobs, const i
   const DescJob jb = jobs[jid];
   const int P = jb.P, NC = jb.NC;
   if (P <= 0) return;
-  const int e = (tile - tilePrefix[jid]) * 256 + threadIdx.x;
   const int n = jb.ksize, R = n >> 1;
-  const float *k = taps + jb.tapOfs;
-  const int *need = needTab + jb.needOfs;
+  __shared__ float sk[BLUR_TAPS];
+  __shared__ int sneed[96];
+  const float *kg = taps + jb.tapOfs;
+  const bool ldsTaps = n <= BLUR_TAPS;
+  if (ldsTaps) for (int i = threadIdx.x; i < n; i += 256) sk[i] = kg[i];
+  if (threadIdx.x < NC) sneed[threadIdx.x] = needTab[jb.needOfs + threadIdx.x];
+  __syncthreads();
+  const int e0 = (tile - tilePrefix[jid]) * BLUR_TILE + threadIdx.x;
   if (pass == 0) {
-    if (e >= P * NC) return;
-    const int r = e / NC, ci = e - r * NC;
-    const int c = need[ci];
-    const float *row = src + jb.scratchOfs + (size_t)r * P;
-    float v;
-    if (n == 1) v = row[c];
-    else if (n <= 5) {
-      v = row[c] * k[R];
-      for (int j = 1; j <= R; j++) {
-        int cm = c - j < 0 ? 0 : c - j, cp = c + j > P - 1 ? P - 1 : c + j;
-        v = v + (row[cm] + row[cp]) * k[R + j];
-      }
-    } else {
-      v = 0.f;
+    const float *A = src + jb.scratchOfs;
+#pragma unroll 1
+    for (int q = 0; q < BLUR_TILE / 256; q++) {
+      const int e = e0 + q * 256;
+      if (e >= P * NC) break;
+      const int r = e / NC, ci = e - r * NC;
+      const int c = sneed[ci];
+      const float *row = A + (size_t)r * P;
+      float v;
+      if (n == 1) v = row[c];
+      else if (n <= 5) {
+        v = row[c] * sk[R];
+        for (int j = 1; j <= R; j++) {
+          int cm = c - j < 0 ? 0 : c - j, cp = c + j > P - 1 ? P - 1 : c + j;
+          v = v + (row[cm] + row[cp]) * sk[R + j];
+        }
+      } else if (ldsTaps) {
+        v = 0.f;
 #pragma unroll 8
-      for (int j = 0; j < n; j++) {
-        int cc = c + j - R;
-        cc = cc < 0 ? 0 : (cc > P - 1 ? P - 1 : cc);
-        v = v + row[cc] * k[j];
+        for (int j = 0; j < n; j++) {
+          int cc = c + j - R;
+          cc = cc < 0 ? 0 : (cc > P - 1 ? P - 1 : cc);
+          v = v + row[cc] * sk[j];
+        }
+      } else {
+        v = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < n; j++) {
+          int cc = c + j - R;
+          cc = cc < 0 ? 0 : (cc > P - 1 ? P - 1 : cc);
+          v = v + row[cc] * kg[j];
+        }
       }
+      dst[jb.rowOfs + e] = v;
     }
-    dst[jb.rowOfs + e] = v;
   } else {
-    if (e >= NC * NC) return;
-    const int ri = e / NC, ci = e - ri * NC;
-    const int r = need[ri];
     const float *S = src + jb.rowOfs;   // P x NC
-    float v;
-    if (n == 1) v = S[(size_t)r * NC + ci];
-    else {
-      v = k[R] * S[(size_t)r * NC + ci] + 0.f;
+#pragma unroll 1
+    for (int q = 0; q < BLUR_TILE / 256; q++) {
+      const int e = e0 + q * 256;
+      if (e >= NC * NC) break;
+      const int ri = e / NC, ci = e - ri * NC;
+      const int r = sneed[ri];
+      float v;
+      if (n == 1) v = S[(size_t)r * NC + ci];
+      else if (ldsTaps) {
+        v = sk[R] * S[(size_t)r * NC + ci] + 0.f;
 #pragma unroll 4
-      for (int j = 1; j <= R; j++) {
-        int rp = r + j > P - 1 ? P - 1 : r + j, rm = r - j < 0 ? 0 : r - j;
-        v = v + k[R + j] * (S[(size_t)rp * NC + ci] + S[(size_t)rm * NC + ci]);
+        for (int j = 1; j <= R; j++) {
+          int rp = r + j > P - 1 ? P - 1 : r + j, rm = r - j < 0 ? 0 : r - j;
+          v = v + sk[R + j] * (S[(size_t)rp * NC + ci] + S[(size_t)rm * NC + ci]);
+        }
+      } else {
+        v = kg[R] * S[(size_t)r * NC + ci] + 0.f;
+#pragma unroll 4
+        for (int j = 1; j <= R; j++) {
+          int rp = r + j > P - 1 ? P - 1 : r + j, rm = r - j < 0 ? 0 : r - j;
+          v = v + kg[R + j] * (S[(size_t)rp * NC + ci] + S[(size_t)rm * NC + ci]);
+        }
       }
+      dst[jb.gridOfs + e] = v;
     }
-    dst[jb.gridOfs + e] = v;
   }
 }
 

@@ -6,10 +6,24 @@ import sys
 
 def main(db_path, out_path, note=""):
     db = sqlite3.connect(db_path)
-    rows = db.execute(
+    raw = db.execute(
         "select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(vgpr_count), "
         "max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(workgroup_x), max(grid_x) "
         "from kernels group by name order by sum(duration) desc").fetchall()
+    # template instantiations (k_blur_hess<R>, ...) are reported as one kernel
+    import re
+    merged = {}
+    for r in raw:
+        key = re.sub(r"<.*", "", re.sub(r"^void ", "", r[0].split("(")[0]))
+        m = merged.get(key)
+        if m is None:
+            merged[key] = [key] + list(r[1:])
+        else:
+            m[1] += r[1]; m[2] += r[2]; m[4] = min(m[4], r[4]); m[5] = max(m[5], r[5])
+            for q in (6, 7, 8, 9, 10, 11):
+                m[q] = max(m[q] or 0, r[q] or 0)
+            m[3] = m[2] / m[1]
+    rows = sorted(merged.values(), key=lambda r: -r[2])
     total = sum(r[2] for r in rows) or 1
     with open(out_path, "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats summary (durations in microseconds)\n")
