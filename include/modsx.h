@@ -34,7 +34,7 @@ typedef enum modsx_status {
 enum { MODSX_FIXED_TH = 0, MODSX_RELATIVE_TH = 1, MODSX_FIXED_REG_NUMBER = 2, MODSX_RELATIVE_REG_NUMBER = 3,
        MODSX_NOT_LESS_THAN_REGIONS = 4 };
 /* detector_type / descriptor_type, detectors/structures.hpp:17-38, 75-96 */
-enum { MODSX_DET_HESSIAN = 0 };
+enum { MODSX_DET_HESSIAN = 0, MODSX_DET_MSER = 3 };   /* detector_type, detectors/structures.hpp:16-19 */
 /* descriptor types of SIFTDescriptor::operator() (matching/siftdesc.cpp:399-442).  The half variants fold opposite
  * orientation bins into 64 values; their rows keep the 128 stride with entries 64..127 zero, which leaves every
  * L2 distance unchanged, so the matcher needs no second layout. */
@@ -82,6 +82,18 @@ typedef struct modsx_hessaff_params {
 
 /* scale-space keypoint before affine adaptation: the arguments of
  * KeypointCallback::onKeypointDetected, affinedetectors/pyramid.h:23-27 */
+/* == struct extrema::ExtremaParams (the fields DetectMSERs reads), detectors/mser/extrema/extremaParams.h:49-82;
+ * defaults of modsx_default_mser_params = [MSER] of build/config_iter_mods_cviu.ini:4-12 */
+typedef struct modsx_mser_params {
+  int min_size;          /* minimum region size in pixels */
+  double max_area;       /* maximum region area relative to the image */
+  double min_margin;     /* stability margin in grey levels (the detector threshold) */
+  int relative;          /* margin relative to the grey level */
+  int mode;              /* detection_mode_t, MODSX_FIXED_TH ... */
+  int reg_number;
+  float rel_threshold, rel_reg_number;
+} modsx_mser_params;
+
 typedef struct modsx_sskp {
   int octave, level, r0, c0, r, c, type, pad;
   float b0, b1, b2, val;
@@ -108,6 +120,8 @@ typedef struct modsx_pair_params {
   int useF;            /* RANSACPars::useF (matching.hpp:148): 1 = epipolar verification, exp_ransacFcustom + F_LAF_check */
   double LAFCoef;      /* RANSACPars::LAFCoef, threshold of F_LAF_check = LAFCoef * err_threshold */
   int errorType;       /* RANSAC_error_t: 0 SAMPSON, 1 SYMM_MAX, 2 SYMM_SUM (F path: 1 and 2 both select FDsSym) */
+  int detector;        /* MODSX_DET_HESSIAN (det) or MODSX_DET_MSER (mser): which detector the view loop runs */
+  modsx_mser_params mser;
 } modsx_pair_params;
 
 typedef struct modsx_pair_result {
@@ -174,6 +188,20 @@ int modsx_resize_half(modsx_ctx *ctx, const modsx_image *img, float *out, int *o
 
 /* template DetectAffineRegions<>: scale by sqrt|det A| and rectify, synth-detection.hpp:93-126 (host math) */
 int modsx_detect_affine_regions(const modsx_keypoint *kps, int n, int img_id, int det_type, modsx_region *out);
+
+/* int DetectMSERs(cv::Mat &input, std::vector<AffineKeypoint> &out1, extrema::ExtremaParams params,
+ *                 ScalePyramid &scale_pyramid, const double tilt, const double zoom)
+ *                                            detectors/mser/extrema/extrema.h:11, extrema.cpp:284-473 (doOnNormal)
+ * MSER+ (sub_type 21) then MSER- (sub_type 20) of one view: x, y = centroid, A = covariance^(1/2), s = 1,
+ * response = margin.  The view is truncated to u8 on the device; the component tree itself is sequential host code
+ * (as in the reference).  PARITY UNPINNED (the reference's MSER sources cannot be built in this image): checked against
+ * an independent CPU restatement only.  *out is malloc'd (modsx_free).  Returns the number of keypoints. */
+void modsx_default_mser_params(modsx_mser_params *p);
+int modsx_detect_msers(modsx_ctx *ctx, const modsx_image *img, const modsx_mser_params *par, double tilt, double zoom,
+                       modsx_keypoint **out);
+/* the same on a host u8 image (what DetectMSERs builds at extrema.cpp:395-403); needs no device */
+int modsx_detect_msers_u8(const unsigned char *gray, int rows, int cols, const modsx_mser_params *par, double tilt,
+                          double zoom, modsx_keypoint **out);
 
 /* int DetectOrientation(AffineRegionList &in, AffineRegionList &out, SynthImage &img, double mrSize,
  *                       int patchSize, int doHalfSIFT, int maxAngNum, double th, bool addUpRight)

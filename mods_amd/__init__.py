@@ -34,6 +34,11 @@ class HessAffParams(C.Structure):
                 ("affInitialSigma", C.c_float), ("doBaumberg", C.c_int)]
 
 
+class MserParams(C.Structure):
+    _fields_ = [("min_size", C.c_int), ("max_area", C.c_double), ("min_margin", C.c_double), ("relative", C.c_int),
+                ("mode", C.c_int), ("reg_number", C.c_int), ("rel_threshold", C.c_float), ("rel_reg_number", C.c_float)]
+
+
 class PairParams(C.Structure):
     _fields_ = [("det", HessAffParams),
                 ("ori_mrSize", C.c_double), ("ori_patchSize", C.c_int), ("ori_maxAngles", C.c_int),
@@ -44,7 +49,8 @@ class PairParams(C.Structure):
                 ("duplicateDist", C.c_double),
                 ("err_threshold", C.c_double), ("confidence", C.c_double), ("max_samples", C.c_int),
                 ("localOptimization", C.c_int), ("HLAFCoef", C.c_double), ("doSymmCheck", C.c_int),
-                ("ransac_seed", C.c_uint), ("useF", C.c_int), ("LAFCoef", C.c_double), ("errorType", C.c_int)]
+                ("ransac_seed", C.c_uint), ("useF", C.c_int), ("LAFCoef", C.c_double), ("errorType", C.c_int),
+                ("detector", C.c_int), ("mser", MserParams)]
 
 
 class View(C.Structure):
@@ -84,7 +90,7 @@ EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "m
            "modsx_describe_regions", "modsx_match_fginn", "modsx_duplicate_filtering", "modsx_ransac_h",
            "modsx_loransac_h", "modsx_ransac_f", "modsx_loransac_f", "modsx_match_pair", "modsx_match_pairs", "modsx_pair_result_release",
            "modsx_set_vs_pars", "modsx_synth_view", "modsx_detect_describe_views", "modsx_match_fginn_device",
-           "modsx_match_pair_views", "modsx_match_ladder", "modsx_save_regions", "modsx_load_regions", "modsx_last_timings", "modsx_profile",
+           "modsx_match_pair_views", "modsx_match_ladder", "modsx_save_regions", "modsx_load_regions", "modsx_default_mser_params", "modsx_detect_msers", "modsx_detect_msers_u8", "modsx_last_timings", "modsx_profile",
            "modsx_kernel_stats"]
 
 KERNEL_CLASSES = ["blur_hess", "hessian", "resize", "nms_localize", "baumberg", "orientation", "patch_sample",
@@ -147,6 +153,24 @@ def default_hessaff_params(**kw):
     for k, v in kw.items():
         setattr(p, k, v)
     return p
+
+
+def default_mser_params(**kw):
+    p = MserParams()
+    lib().modsx_default_mser_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def detect_msers_u8(gray, params=None, tilt=1.0, zoom=1.0):
+    """DetectMSERs on a host u8 image (no device needed)."""
+    params = params or default_mser_params()
+    g = np.ascontiguousarray(gray, np.uint8)
+    out = C.c_void_p()
+    n = _check(lib().modsx_detect_msers_u8(_p(g), g.shape[0], g.shape[1], C.byref(params), C.c_double(tilt),
+                                           C.c_double(zoom), C.byref(out)), "detect_msers_u8")
+    return _take(out, n, KEYPOINT)
 
 
 def default_pair_params(**kw):
@@ -461,6 +485,13 @@ class Context(object):
         _check(lib().modsx_match_pair_views(self._c(), C.c_void_p(img1.h), C.c_void_p(img2.h), arr, len(views),
                                             C.byref(params), C.byref(res)), "match_pair_views")
         return _unpack_pair_result(res)
+
+    def detect_msers(self, img, params=None, tilt=1.0, zoom=1.0):
+        params = params or default_mser_params()
+        out = C.c_void_p()
+        n = _check(lib().modsx_detect_msers(self._c(), C.c_void_p(img.h), C.byref(params), C.c_double(tilt),
+                                            C.c_double(zoom), C.byref(out)), "detect_msers")
+        return _take(out, n, KEYPOINT)
 
     def match_ladder(self, img1, img2, steps, params, min_matches=10):
         """steps: list of (views, match_ratio).  Returns (result dict, steps executed)."""

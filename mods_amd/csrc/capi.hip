@@ -51,6 +51,7 @@ void modsx_default_hessaff_params(modsx_hessaff_params *p) {
   p->doBaumberg = 1;
 }
 
+void modsx_default_mser_params(modsx_mser_params *p);
 void modsx_default_pair_params(modsx_pair_params *p) {
   memset(p, 0, sizeof *p);
   modsx_default_hessaff_params(&p->det);
@@ -63,6 +64,8 @@ void modsx_default_pair_params(modsx_pair_params *p) {
   p->HLAFCoef = 12.0; p->doSymmCheck = 1;
   p->ransac_seed = 1;
   p->useF = 0; p->LAFCoef = 2.0; p->errorType = 0;
+  p->detector = MODSX_DET_HESSIAN;
+  modsx_default_mser_params(&p->mser);
 }
 
 modsx_image *modsx_image_upload(modsx_ctx *ctx, const void *pixels, int rows, int cols, int channels, int dtype) {
@@ -436,6 +439,48 @@ int modsx_match_pair_views(modsx_ctx *ctx, const modsx_image *img1, const modsx_
   if (nviews <= 0) { mx::set_error("modsx_match_pair_views: nviews"); return MODSX_ERR_ARG; }
   hipSetDevice(ctx->dev);
   return match_pair_views(ctx, img1, img2, views, nviews, *par, res);
+}
+
+void modsx_default_mser_params(modsx_mser_params *p) {
+  // build/config_iter_mods_cviu.ini:4-12; extremaParams.h:66-82
+  memset(p, 0, sizeof *p);
+  p->min_size = 30; p->max_area = 0.05; p->min_margin = 8; p->relative = 0;
+  p->mode = MODSX_FIXED_TH; p->reg_number = 500; p->rel_threshold = -1; p->rel_reg_number = -1;
+}
+
+int modsx_detect_msers(modsx_ctx *ctx, const modsx_image *img, const modsx_mser_params *par, double tilt, double zoom,
+                       modsx_keypoint **out) {
+  NEED(ctx); NEED(img); NEED(par); NEED(out);
+  if (par->min_size < 1 || !(par->max_area > 0)) { mx::set_error("modsx_detect_msers: parameters"); return MODSX_ERR_ARG; }
+  hipSetDevice(ctx->dev);
+  const size_t n = (size_t)img->rows * img->cols;
+  if (!ctx->misc.ensure(n + 16)) return MODSX_ERR_NOMEM;
+  launch_trunc_u8(ctx->stream, img->d, (uint8_t *)ctx->misc.p, n);
+  std::vector<uint8_t> host(n);
+  MX_HIP(hipMemcpyAsync(host.data(), ctx->misc.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  MX_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<modsx_keypoint> k;
+  int rc = detect_msers_host(host.data(), img->rows, img->cols, *par, tilt, zoom, k);
+  if (rc) return rc;
+  *out = (modsx_keypoint *)malloc(sizeof(modsx_keypoint) * std::max<size_t>(1, k.size()));
+  if (!*out) { mx::set_error("out of memory"); return MODSX_ERR_NOMEM; }
+  if (!k.empty()) memcpy(*out, k.data(), sizeof(modsx_keypoint) * k.size());
+  return (int)k.size();
+}
+
+int modsx_detect_msers_u8(const unsigned char *gray, int rows, int cols, const modsx_mser_params *par, double tilt,
+                          double zoom, modsx_keypoint **out) {
+  if (!gray || !par || !out || rows <= 0 || cols <= 0 || par->min_size < 1 || !(par->max_area > 0)) {
+    mx::set_error("modsx_detect_msers_u8: bad argument");
+    return MODSX_ERR_ARG;
+  }
+  std::vector<modsx_keypoint> k;
+  int rc = detect_msers_host(gray, rows, cols, *par, tilt, zoom, k);
+  if (rc) return rc;
+  *out = (modsx_keypoint *)malloc(sizeof(modsx_keypoint) * std::max<size_t>(1, k.size()));
+  if (!*out) { mx::set_error("out of memory"); return MODSX_ERR_NOMEM; }
+  if (!k.empty()) memcpy(*out, k.data(), sizeof(modsx_keypoint) * k.size());
+  return (int)k.size();
 }
 
 int modsx_save_regions(const char *path, const modsx_region_class *classes, int nclasses) {

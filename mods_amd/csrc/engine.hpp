@@ -159,6 +159,7 @@ void launch_baumberg(hipStream_t s, const AffJob *jobs, AffOut *out, int n, cons
                      float convTh, float affInitialSigma);
 void launch_orientation(hipStream_t s, const OriJob *jobs, OriOut *out, int n, const ImgRef *imgs, const float *orimask,
                         const double *atanLut, int doHalf, double th, int maxAngles);
+void launch_trunc_u8(hipStream_t s, const float *src, uint8_t *dst, size_t n);
 void launch_expand_tiles(hipStream_t s, const int *prefix, int nJobs, int *tileJob);
 void launch_patch_sample(hipStream_t s, const DescJob *jobs, const int *tilePrefix, const int *tileJob, int nTiles,
                          const ImgRef *imgs, float *scratch);

@@ -57,6 +57,8 @@ void hds_sym(const double *u, const double *H, double *p, int len, bool takeMax)
 int save_regions(const char *path, const modsx_region_class *classes, int nclasses);
 int load_regions(const char *path, const char *det_name, const char *desc_name, std::vector<modsx_region> &regs,
                  std::vector<float> &desc, int *dim, std::string *found_det, std::string *found_desc);
+int detect_msers_host(const uint8_t *u8, int rows, int cols, const modsx_mser_params &par, double tilt, double zoom,
+                      std::vector<modsx_keypoint> &out);
 int ransac_f(const double *u, int len, double th, double conf, int max_sam, double *F, unsigned char *inl, int *data_out,
              int do_lo, unsigned inlLimit, int error_type, int doSymCheck, unsigned seed0);
 int loransac_f(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold, double confidence,

@@ -217,11 +217,27 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
     }
     std::vector<modsx_keypoint> kps[MAXB];
     std::vector<modsx_region> r0[MAXB], ro[MAXB];
-    if (!rc) rc = detect_keypoints_batch(c, cimg, n, pp.det, tilts, zooms, kps);
     if (!rc) {
+      if (pp.detector == MODSX_DET_MSER) {
+        // DetectAffineRegions(temp_img1, temp_kp1, det_par.MSERParam, DET_MSER, DetectMSERs), imagerepresentation.cpp:1037:
+        // u8 truncation of every view on the device, one D2H of bytes, the component trees on host threads' time
+        std::vector<uint8_t> host;
+        for (int i = 0; i < n && !rc; i++) {
+          const size_t npx = (size_t)cimg[i]->rows * cimg[i]->cols;
+          if (!c->misc.ensure(npx + 16)) { rc = MODSX_ERR_NOMEM; break; }
+          launch_trunc_u8(c->stream, cimg[i]->d, (uint8_t *)c->misc.p, npx);
+          host.resize(npx);
+          if (hipMemcpyAsync(host.data(), c->misc.p, npx, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+              hipStreamSynchronize(c->stream) != hipSuccess) { set_error("MSER view download failed"); rc = MODSX_ERR_DEVICE; break; }
+          rc = detect_msers_host(host.data(), cimg[i]->rows, cimg[i]->cols, pp.mser, tilts[i], zooms[i], kps[i]);
+        }
+      } else rc = detect_keypoints_batch(c, cimg, n, pp.det, tilts, zooms, kps);
+    }
+    if (!rc) {
+      const int detType = pp.detector == MODSX_DET_MSER ? MODSX_DET_MSER : MODSX_DET_HESSIAN;
       for (int i = 0; i < n; i++) {
         r0[i].resize(kps[i].size());
-        detect_affine_regions(kps[i].data(), (int)kps[i].size(), ident[i] ? 0 : take[g0 + i], MODSX_DET_HESSIAN, r0[i].data());
+        detect_affine_regions(kps[i].data(), (int)kps[i].size(), ident[i] ? 0 : take[g0 + i], detType, r0[i].data());
       }
       rc = detect_orientation_batch(c, cimg, n, r0, pp.ori_mrSize, pp.ori_patchSize, 0, pp.ori_maxAngles, pp.ori_threshold,
                                     0, ro);

@@ -316,6 +316,22 @@ void launch_nms(hipStream_t s, const NmsBatch &b, const NmsJob *jobs, const int 
   if (nj <= 0 || nTiles <= 0) return;
   hipLaunchKernelGGL(k_nms_localize, dim3(nTiles), dim3(256), 0, s, b, jobs, tilePrefix, nj, out, counter, cap);
 }
+// *ptr = (unsigned char)*in_ptr of DetectMSERs (extrema.cpp:401-403): f32 -> u8 by truncation, 4 pixels per thread
+__global__ void k_trunc_u8(const float *src, uint8_t *dst, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const float4 v = *reinterpret_cast<const float4 *>(src + i);
+    const unsigned p = (unsigned)(uint8_t)v.x | ((unsigned)(uint8_t)v.y << 8) | ((unsigned)(uint8_t)v.z << 16) | ((unsigned)(uint8_t)v.w << 24);
+    *reinterpret_cast<unsigned *>(dst + i) = p;
+  } else {
+    for (size_t k = i; k < n; k++) dst[k] = (uint8_t)src[k];
+  }
+}
+void launch_trunc_u8(hipStream_t s, const float *src, uint8_t *dst, size_t n) {
+  if (!n) return;
+  const size_t threads = (n + 3) / 4;
+  hipLaunchKernelGGL(k_trunc_u8, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, src, dst, n);
+}
 void launch_gray(hipStream_t s, const void *src, float *dst, size_t n, int channels, int dtype) {
   dim3 grid((unsigned)((n + 255) / 256));
   if (dtype == 0) hipLaunchKernelGGL(k_gray_u8, grid, dim3(256), 0, s, (const uint8_t *)src, dst, n, channels);

@@ -153,6 +153,13 @@ int orc_loransac_f(const double *pts, const double *laf1, const double *laf2, in
                    unsigned seed, double *F /*9 as exp_ransacFcustom returns it*/, unsigned char *inl,
                    unsigned char *keep /*after F_LAF_check*/, int *data_out3);
 
+/* DetectMSERs (6-arg overload, doOnNormal branch), detectors/mser/extrema/extrema.cpp:284-473 -- PARITY UNPINNED,
+ * see oracle_mser.cpp.  mode: 0 FIXED_TH, 1 RELATIVE_TH, 2 FIXED_REG_NUMBER, 3 RELATIVE_REG_NUMBER,
+ * 4 NOT_LESS_THAN_REGIONS.  Writes min(count, cap) keypoints, returns count. */
+int orc_detect_msers(const float *img, int rows, int cols, int min_size, double max_area, double min_margin, int relative,
+                     int mode, int reg_number, double rel_threshold, double rel_reg_number, double tilt, double zoom,
+                     orc_keypoint *out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -255,6 +255,22 @@ def ref_available():
     return bool(lib().orc_ref_available())
 
 
+def detect_msers(img, min_size=30, max_area=0.05, min_margin=8.0, relative=0, mode=0, reg_number=500, rel_threshold=-1.0,
+                 rel_reg_number=-1.0, tilt=1.0, zoom=1.0):
+    """DetectMSERs (extrema.cpp:284-473, doOnNormal); defaults = [MSER] of config_iter_mods_cviu.ini.  PARITY UNPINNED."""
+    img = _f32(img)
+    cap = 1 << 16
+    while True:
+        out = np.zeros(cap, KEYPOINT)
+        n = lib().orc_detect_msers(_p(img), img.shape[0], img.shape[1], int(min_size), C.c_double(max_area),
+                                   C.c_double(min_margin), int(relative), int(mode), int(reg_number),
+                                   C.c_double(rel_threshold), C.c_double(rel_reg_number), C.c_double(tilt),
+                                   C.c_double(zoom), _p(out), cap)
+        if n <= cap:
+            return out[:n].copy()
+        cap = n
+
+
 def loransac_h(pts, laf1, laf2, err_threshold=3.0, confidence=0.99, max_samples=100000, lo=1, hlaf_coef=12.0,
                sym_check=1, seed=1):
     pts = np.ascontiguousarray(pts, np.float64)
@@ -340,7 +356,7 @@ def set_vs_pars(scale_set, tilt_set, phi_base, init_sigma=0.5, do_blur=1, prev=N
     return [make_view(par[i].tilt, par[i].phi, par[i].zoom, par[i].InitSigma, par[i].doBlur) for i in range(n)]
 
 
-def detect_describe_views(gray, views, params=None, ori=(1.0, 41, 1, 0.8), desc=(5.1962, 41, 0, 1, 1, 0.2)):
+def detect_describe_views(gray, views, params=None, ori=(1.0, 41, 1, 0.8), desc=(5.1962, 41, 0, 1, 1, 0.2), mser=None):
     """The HessianAffine branch of SynthDetectDescribeKeypoints (imagerepresentation.cpp:603-2047) for one
     descriptor: per view synthesise, detect, orient, reproject, describe; concatenate in view order with
     AddRegionsToList id re-basing (:588-600).  Returns (regions, descriptors)."""
@@ -350,8 +366,13 @@ def detect_describe_views(gray, views, params=None, ori=(1.0, 41, 1, 0.8), desc=
     size = 0
     for vi, v in enumerate(views):
         img, H, ident = synth_view(gray, v)
-        k = detect_hessaff(img, params, tilt=abs(v.tilt) if not ident else 1.0, zoom=v.zoom if not ident else 1.0)
-        regs = detect_affine_regions(k, img_id=0 if ident else vi)
+        vt, vz = (abs(v.tilt) if not ident else 1.0), (v.zoom if not ident else 1.0)
+        if mser is not None:   # DetectAffineRegions(..., DET_MSER, DetectMSERs), imagerepresentation.cpp:1037
+            k = detect_msers(img, tilt=vt, zoom=vz, **mser)
+            regs = detect_affine_regions(k, img_id=0 if ident else vi, det_type=3)
+        else:
+            k = detect_hessaff(img, params, tilt=vt, zoom=vz)
+            regs = detect_affine_regions(k, img_id=0 if ident else vi)
         ro = detect_orientation(img, regs, mr_size=ori[0], patch_size=ori[1], max_ang=ori[2], th=ori[3])
         rr = reproject_regions(ro, H.reshape(9), gray.shape[1], gray.shape[0])
         d = describe_regions(img, rr, mr_size=desc[0], patch_size=desc[1], fast=desc[2], photo_norm=desc[3],

@@ -189,3 +189,22 @@ def test_iteration_ladder_matches_oracle(ctx, modsx, oracle, small_pair, min_mat
         assert np.array_equal(got["tentatives"][f], ref["tent"][f]), f
     assert np.array_equal(got["ransac_inlier"], ref["rr"]["inl"]) and np.array_equal(got["verified"], ref["rr"]["keep"])
     assert np.abs(normH(got["H"]) - normH(ref["rr"]["H"])).max() < 1e-4
+
+
+def test_mser_device_path_and_view_loop(ctx, modsx, oracle, small_pair):
+    """E1/E2 behind the device boundary: u8 truncation on the GPU, component tree on the host; then the MSER class of
+    the per-view loop (synthesise, DetectMSERs, orient, reproject, describe) against the oracle-side loop."""
+    a = small_pair[0]
+    im = ctx.upload(a)
+    got = ctx.detect_msers(im)
+    ref = oracle.detect_msers(a)
+    assert len(ref) > 100 and same_records(got, ref.view(modsx.KEYPOINT))
+    vo, vm = _views(oracle, modsx, [1, 2], 360.0, sigma=0.8)
+    mser_kw = dict(min_size=30, max_area=0.05, min_margin=8.0)
+    par = modsx.default_pair_params(detector=3, ori_mrSize=5.1962)
+    regs, desc = ctx.detect_describe_views(im, vm, par)
+    r_ref, d_ref = oracle.detect_describe_views(a, vo, ori=(5.1962, 41, 1, 0.8), mser=mser_kw)
+    im.free()
+    assert len(r_ref) > 100 and len(regs) == len(r_ref)
+    assert same_records(regs, r_ref.view(modsx.REGION)) and np.array_equal(desc, d_ref)
+    assert set(np.unique(regs["type"])) == {3}
