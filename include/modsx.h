@@ -331,11 +331,16 @@ int modsx_match_pair_views(modsx_ctx *ctx, const modsx_image *img1, const modsx_
  * image representations (AddRegions, imagerepresentation.cpp:552-600), re-matches everything accumulated so far
  * (MatchImgReps clears and rebuilds the class' tentatives every step, correspondencebank.cpp:291-345) and
  * verifies; the loop ends once n_verified >= min_matches.  match_ratio of a step (FGINNThreshold of that
- * iteration's section) overrides par->match_ratio when > 0.  *steps_done = steps executed. */
+ * iteration's section) overrides par->match_ratio when > 0.  *steps_done = steps executed.
+ * Two detector classes are kept apart as in the reference (separate_detectors): a step adds regions to, and re-matches,
+ * only the class of its own detector; the other class keeps its tentatives (CorrespondenceBank, correspondencebank.cpp:
+ * 180-218) and GetCorresponcesVector() concatenates HessianAffine before MSER (map order).  Region indices of the result
+ * refer to the concatenation [HessianAffine regions, MSER regions] of each image. */
 typedef struct modsx_ladder_step {
   const modsx_view *views;
   int nviews;
   double match_ratio;
+  int detector;      /* MODSX_DET_HESSIAN (0) or MODSX_DET_MSER: the [HessianAffineN] / [MSERN] section this step comes from */
 } modsx_ladder_step;
 int modsx_match_ladder(modsx_ctx *ctx, const modsx_image *img1, const modsx_image *img2,
                        const modsx_ladder_step *steps, int nsteps, int min_matches, const modsx_pair_params *par,

@@ -72,7 +72,7 @@ def _view_array(views):
 
 
 class LadderStep(C.Structure):
-    _fields_ = [("views", C.c_void_p), ("nviews", C.c_int), ("match_ratio", C.c_double)]
+    _fields_ = [("views", C.c_void_p), ("nviews", C.c_int), ("match_ratio", C.c_double), ("detector", C.c_int)]
 
 
 class PairResult(C.Structure):
@@ -494,15 +494,17 @@ class Context(object):
         return _take(out, n, KEYPOINT)
 
     def match_ladder(self, img1, img2, steps, params, min_matches=10):
-        """steps: list of (views, match_ratio).  Returns (result dict, steps executed)."""
+        """steps: list of (views, match_ratio[, detector]).  Returns (result dict, steps executed)."""
         arr = (LadderStep * len(steps))()
         keep = []
-        for i, (views, ratio) in enumerate(steps):
+        for i, st in enumerate(steps):
+            views, ratio = st[0], st[1]
             va = _view_array(views)
             keep.append(va)
             arr[i].views = C.cast(va, C.c_void_p)
             arr[i].nviews = len(views)
             arr[i].match_ratio = float(ratio)
+            arr[i].detector = int(st[2]) if len(st) > 2 else 0
         res = PairResult()
         done = C.c_int(0)
         _check(lib().modsx_match_ladder(self._c(), C.c_void_p(img1.h), C.c_void_p(img2.h), arr, len(steps),

@@ -165,7 +165,7 @@ void ctx_destroy(modsx_ctx *c) {
   for (int i = 0; i < MAXB; i++) c->pyr[i].store.release();
   DevBuf *bufs[] = {&c->nmsJobs, &c->cand, &c->counter, &c->affJobs, &c->affOut, &c->oriJobs, &c->oriOut, &c->descJobs, &c->tilePrefix,
                     &c->taps, &c->imgRefs, &c->scratchA, &c->scratchB, &c->descAllF[0], &c->descAllF[1], &c->descAllU8[0],
-                    &c->descAllU8[1], &c->pos2, &c->matchRows, &c->matchWork, &c->misc, &c->scratchC, &c->needTab, &c->coordTab, &c->tileJob, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps};
+                    &c->descAllU8[1], &c->descAllU8b[0], &c->descAllU8b[1], &c->pos2, &c->matchRows, &c->matchWork, &c->misc, &c->scratchC, &c->needTab, &c->coordTab, &c->tileJob, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps};
   for (DevBuf *b : bufs) b->release();
   for (int i = 0; i < MAXB; i++) { c->descF[i].release(); c->descU8[i].release(); }
   PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc};

@@ -297,45 +297,38 @@ static void release_result_arrays(modsx_pair_result *res) {
   res->tentatives = nullptr; res->ransac_inlier = nullptr; res->verified = nullptr;
 }
 
-// Tentatives.MatchImgReps + DuplicateFiltering + LORANSACFiltering of one step (mods.cpp:287-342) on the regions
-// accumulated so far; the u8 descriptors of both sides are in c->descAllU8[side].
-static int match_and_verify(modsx_ctx *c, const std::vector<modsx_region> *regs, const modsx_pair_params &pp, double ratio,
-                            modsx_pair_result *res) {
-  release_result_arrays(res);
-  memset(res, 0, sizeof *res);
-  for (int i = 0; i < 9; i++) res->H[i] = -1;
-  res->n_regions1 = (int)regs[0].size();
-  res->n_regions2 = (int)regs[1].size();
-  std::vector<double> pos2(regs[1].size() * 2 + 2);
-  for (size_t i = 0; i < regs[1].size(); i++) { pos2[2 * i] = regs[1][i].reproj_kp.x; pos2[2 * i + 1] = regs[1][i].reproj_kp.y; }
+// One detector class of the pair (separate_detectors of MatchImgReps): its accumulated regions per image, the device
+// buffers that hold their u8 descriptors, and the tentatives of its last match.
+struct LadderClass {
+  std::vector<modsx_region> regs[2];
+  size_t cap[2] = {(size_t)1 << 16, (size_t)1 << 16};
+  DevBuf *buf[2] = {nullptr, nullptr};
   std::vector<modsx_tentative> tents;
-  int rc = match_device(c, (uint8_t *)c->descAllU8[0].p, res->n_regions1, (uint8_t *)c->descAllU8[1].p, res->n_regions2,
-                        pos2.data(), ratio, pp.contradDist, pp.nn, tents);
-  if (rc) return rc;
-  verify_tentatives(regs[0], regs[1], tents, pp, res);
-  return MODSX_OK;
-}
+};
 
 // Append the regions + u8 descriptors of one step's views to the accumulated lists of one image side
-// (SynthDetectDescribeKeypoints + AddRegions, imagerepresentation.cpp:603-2047).  The accumulator is
-// c->descAllU8[side]; it is re-allocated (device-to-device copy) when the step does not fit.
-static int accumulate_views(modsx_ctx *c, int side, const modsx_image *img, const modsx_view *views, int nv,
-                            const modsx_pair_params &pp, std::vector<modsx_region> &acc, size_t &cap) {
+// (SynthDetectDescribeKeypoints + AddRegions, imagerepresentation.cpp:603-2047).  The accumulator is re-allocated
+// (device-to-device copy) when the step does not fit.
+static int accumulate_views(modsx_ctx *c, LadderClass &k, int side, const modsx_image *img, const modsx_view *views, int nv,
+                            const modsx_pair_params &pp) {
+  std::vector<modsx_region> &acc = k.regs[side];
+  DevBuf &buf = *k.buf[side];
+  size_t &cap = k.cap[side];
   const size_t base = acc.size();
   std::vector<modsx_region> step;
   for (;;) {
-    if (c->descAllU8[side].cap < cap * 128) {
+    if (buf.cap < cap * 128) {
       DevBuf bigger;
       if (!bigger.ensure(cap * 128)) return MODSX_ERR_NOMEM;
       if (base) {
-        MX_HIP(hipMemcpyAsync(bigger.p, c->descAllU8[side].p, base * 128, hipMemcpyDeviceToDevice, c->stream));
+        MX_HIP(hipMemcpyAsync(bigger.p, buf.p, base * 128, hipMemcpyDeviceToDevice, c->stream));
         MX_HIP(hipStreamSynchronize(c->stream));
       }
-      c->descAllU8[side].release();
-      c->descAllU8[side] = bigger;
+      buf.release();
+      buf = bigger;
     }
-    int rc = detect_describe_views(c, img, views, nv, pp, 0, 1, step, nullptr, (uint8_t *)c->descAllU8[side].p + base * 128,
-                                   cap - base, nullptr, nullptr);
+    int rc = detect_describe_views(c, img, views, nv, pp, 0, 1, step, nullptr, (uint8_t *)buf.p + base * 128, cap - base, nullptr,
+                                   nullptr);
     if (rc == MODSX_ERR_NOMEM && cap < ((size_t)1 << 24)) { cap *= 4; continue; }
     if (rc) return rc;
     break;
@@ -348,30 +341,58 @@ static int accumulate_views(modsx_ctx *c, int side, const modsx_image *img, cons
 int match_pair_views(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_view *views, int nv,
                      const modsx_pair_params &pp, modsx_pair_result *res) {
   modsx_ladder_step one;
-  one.views = views; one.nviews = nv; one.match_ratio = pp.match_ratio;
+  one.views = views; one.nviews = nv; one.match_ratio = pp.match_ratio; one.detector = pp.detector;
   int done = 0;
   return match_ladder(c, img1, img2, &one, 1, 0x7fffffff, pp, res, &done);
 }
 
-// The iteration loop of mods.cpp:229-415 (HessianAffine / SIFT-family class, LO-RANSAC homography verification,
-// duplicates filtered before RANSAC): every step adds its views' regions to both image representations,
-// re-matches everything accumulated so far, and the ladder stops once min_matches verified correspondences exist.
+// The iteration loop of mods.cpp:229-415 (HessianAffine and MSER classes with SIFT-family descriptors, LO-RANSAC
+// verification, duplicates filtered before RANSAC): every step adds its views' regions to both image representations,
+// re-matches the class it extended, and the ladder stops once min_matches verified correspondences exist.
 int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_ladder_step *steps, int nsteps,
                  int min_matches, const modsx_pair_params &pp, modsx_pair_result *res, int *steps_done) {
   memset(res, 0, sizeof *res);
   for (int i = 0; i < 9; i++) res->H[i] = -1;
   const modsx_image *imgs[2] = {img1, img2};
-  std::vector<modsx_region> regs[2];
-  size_t cap[2] = {(size_t)1 << 16, (size_t)1 << 16};
+  LadderClass cls[2];   // 0 = HessianAffine, 1 = MSER: the order GetCorresponcesVector("All", "All") walks the map
+  for (int s = 0; s < 2; s++) { cls[0].buf[s] = &c->descAllU8[s]; cls[1].buf[s] = &c->descAllU8b[s]; }
   int cur = 0, step = 0;
   for (; step < nsteps && cur < min_matches; step++) {
+    LadderClass &k = cls[steps[step].detector == MODSX_DET_MSER ? 1 : 0];
+    modsx_pair_params ps = pp;
+    ps.detector = steps[step].detector == MODSX_DET_MSER ? MODSX_DET_MSER : MODSX_DET_HESSIAN;
     for (int side = 0; side < 2; side++) {
-      int rc = accumulate_views(c, side, imgs[side], steps[step].views, steps[step].nviews, pp, regs[side], cap[side]);
+      int rc = accumulate_views(c, k, side, imgs[side], steps[step].views, steps[step].nviews, ps);
       if (rc) { release_result_arrays(res); return rc; }
     }
+    // Tentatives.MatchImgReps (correspondencebank.cpp:291-345): clear and re-match the class of this step
     const double ratio = steps[step].match_ratio > 0 ? steps[step].match_ratio : pp.match_ratio;
-    int rc = match_and_verify(c, regs, pp, ratio, res);
-    if (rc) { release_result_arrays(res); return rc; }
+    {
+      std::vector<double> pos2(k.regs[1].size() * 2 + 2);
+      for (size_t i = 0; i < k.regs[1].size(); i++) { pos2[2 * i] = k.regs[1][i].reproj_kp.x; pos2[2 * i + 1] = k.regs[1][i].reproj_kp.y; }
+      int rc = match_device(c, (uint8_t *)k.buf[0]->p, (int)k.regs[0].size(), (uint8_t *)k.buf[1]->p, (int)k.regs[1].size(),
+                            pos2.data(), ratio, pp.contradDist, pp.nn, k.tents);
+      if (rc) { release_result_arrays(res); return rc; }
+    }
+    // GetCorresponcesVector(): HessianAffine tentatives, then MSER; indices re-based onto the concatenated lists
+    std::vector<modsx_region> all[2];
+    std::vector<modsx_tentative> tents;
+    for (int q = 0; q < 2; q++) {
+      const int o1 = (int)all[0].size(), o2 = (int)all[1].size();
+      for (int s = 0; s < 2; s++) all[s].insert(all[s].end(), cls[q].regs[s].begin(), cls[q].regs[s].end());
+      for (modsx_tentative t : cls[q].tents) {
+        t.q += o1; t.t0 += o2;
+        if (t.t1 >= 0) t.t1 += o2;
+        if (t.tj >= 0) t.tj += o2;
+        tents.push_back(t);
+      }
+    }
+    release_result_arrays(res);
+    memset(res, 0, sizeof *res);
+    for (int i = 0; i < 9; i++) res->H[i] = -1;
+    res->n_regions1 = (int)all[0].size();
+    res->n_regions2 = (int)all[1].size();
+    verify_tentatives(all[0], all[1], tents, pp, res);
     cur = res->n_verified;
   }
   if (steps_done) *steps_done = step;

@@ -134,25 +134,42 @@ def test_view_shard_path_world1_nccl(ctx, modsx, small_pair):
             dist.destroy_process_group()
 
 
-def _oracle_ladder(oracle, a, b, steps, min_matches, seed):
-    """mods.cpp:229-415 restated with the oracle's stage functions (test-side only)."""
-    acc = [[None, None], [None, None]]
-    out, done = None, 0
-    cur = 0
-    for views, ratio in steps:
+def _oracle_ladder(oracle, a, b, steps, min_matches, seed, ori_mr=1.0):
+    """mods.cpp:229-415 restated with the oracle's stage functions (test-side only).  steps: (views, ratio[, detector]);
+    the two detector classes keep their own region lists and tentatives (CorrespondenceBank), HessianAffine first."""
+    mser_kw = dict(min_size=30, max_area=0.05, min_margin=8.0)
+    cls = {0: dict(acc=[[None, None], [None, None]], tent=None), 3: dict(acc=[[None, None], [None, None]], tent=None)}
+    out, done, cur = None, 0, 0
+    for st in steps:
         if cur >= min_matches:
             break
+        views, ratio = st[0], st[1]
+        det = st[2] if len(st) > 2 else 0
+        k = cls[det]
         for side, img in enumerate((a, b)):
-            r, d = oracle.detect_describe_views(img, views)
-            if acc[side][0] is None:
-                acc[side] = [r, d]
+            r, d = oracle.detect_describe_views(img, views, ori=(ori_mr, 41, 1, 0.8), mser=mser_kw if det == 3 else None)
+            if k["acc"][side][0] is None:
+                k["acc"][side] = [r, d]
             else:
                 r = r.copy()
-                r["id"] += len(acc[side][0]); r["parent_id"] += len(acc[side][0])     # AddRegionsToList
-                acc[side] = [np.concatenate([acc[side][0], r]), np.concatenate([acc[side][1], d])]
-        (r1, d1), (r2, d2) = acc
+                r["id"] += len(k["acc"][side][0]); r["parent_id"] += len(k["acc"][side][0])     # AddRegionsToList
+                k["acc"][side] = [np.concatenate([k["acc"][side][0], r]), np.concatenate([k["acc"][side][1], d])]
+        (r1, d1), (r2, d2) = k["acc"]
         pos2 = np.stack([r2["reproj_kp"]["x"], r2["reproj_kp"]["y"]], 1)
-        tent = oracle.match_fginn(d1, d2, pos2, ratio, 30.0)
+        k["tent"] = oracle.match_fginn(d1, d2, pos2, ratio, 30.0)
+        R1, R2, T = [], [], []
+        o1 = o2 = 0
+        for dkey in (0, 3):
+            kk = cls[dkey]
+            if kk["acc"][0][0] is None:
+                continue
+            t = kk["tent"].copy()
+            t["q"] += o1
+            for f in ("t0", "t1", "tj"):
+                t[f] = np.where(t[f] >= 0, t[f] + o2, t[f])
+            T.append(t); R1.append(kk["acc"][0][0]); R2.append(kk["acc"][1][0])
+            o1 += len(kk["acc"][0][0]); o2 += len(kk["acc"][1][0])
+        r1, r2, tent = np.concatenate(R1), np.concatenate(R2), np.concatenate(T)
         pts = np.stack([r1["reproj_kp"]["x"][tent["q"]], r1["reproj_kp"]["y"][tent["q"]],
                         r2["reproj_kp"]["x"][tent["t0"]], r2["reproj_kp"]["y"][tent["t0"]]], 1)
         order, keep = oracle.duplicate_filtering(pts, tent["ratio"], 2.0, True)
@@ -208,3 +225,29 @@ def test_mser_device_path_and_view_loop(ctx, modsx, oracle, small_pair):
     assert len(r_ref) > 100 and len(regs) == len(r_ref)
     assert same_records(regs, r_ref.view(modsx.REGION)) and np.array_equal(desc, d_ref)
     assert set(np.unique(regs["type"])) == {3}
+
+
+def test_mixed_mser_hessaff_ladder_matches_oracle(ctx, modsx, oracle, small_pair):
+    """iters_mods_cviu.ini in miniature: an MSER step, then HessianAffine steps; the classes keep separate region lists
+    and tentatives, the verified set comes from their concatenation (HessianAffine first)."""
+    a, b, H = small_pair
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    prev_o, prev_m, steps_o, steps_m = {0: [], 3: []}, {0: [], 3: []}, [], []
+    for det, tilts, phi, sigma, ratio in ((3, [1], 360.0, 0.8, 0.85), (0, [1], 360.0, 0.2, 0.8), (3, [1, 3], 360.0, 0.8, 0.8),
+                                          (0, [1, 2], 360.0, 0.2, 0.8)):
+        vo = oracle.set_vs_pars([1.0], tilts, phi, sigma, 1, prev_o[det])
+        vm = modsx.set_vs_pars([1.0], tilts, phi, sigma, 1, prev_m[det])
+        assert len(vo) == len(vm) and len(vo) > 0
+        steps_o.append((vo, ratio, det)); steps_m.append((vm, ratio, det))
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    got, done = ctx.match_ladder(ia, ib, steps_m, modsx.default_pair_params(ransac_seed=8), min_matches=10 ** 6)
+    ia.free(); ib.free()
+    ref, done_ref = _oracle_ladder(oracle, a, b, steps_o, 10 ** 6, 8)
+    assert done == done_ref == 4
+    assert got["n_regions"] == ref["n_regions"] and got["n_tentatives"] == ref["n_tentatives"]
+    for f in ref["tent"].dtype.names:
+        assert np.array_equal(got["tentatives"][f], ref["tent"][f]), f
+    assert np.array_equal(got["ransac_inlier"], ref["rr"]["inl"]) and np.array_equal(got["verified"], ref["rr"]["keep"])
+    assert np.abs(normH(got["H"]) - normH(ref["rr"]["H"])).max() < 1e-4
+    assert np.abs(normH(got["H"]) - H).max() < 1.5
