@@ -251,3 +251,53 @@ def test_mixed_mser_hessaff_ladder_matches_oracle(ctx, modsx, oracle, small_pair
     assert np.array_equal(got["ransac_inlier"], ref["rr"]["inl"]) and np.array_equal(got["verified"], ref["rr"]["keep"])
     assert np.abs(normH(got["H"]) - normH(ref["rr"]["H"])).max() < 1e-4
     assert np.abs(normH(got["H"]) - H).max() < 1.5
+
+
+def test_cat_pair_full_ladder_stops_early_on_ground_truth(ctx, modsx, cat_pair):
+    """The HessianAffine / MSER part of build/iters_mods_cviu.ini on the reference's example pair: [MSER2] (scales 1,
+    0.25, 0.125), [MSER3] (tilts 1, 3, 6, 9), [HessianAffine4..6] (tilts 1, 2, 4, 6, 8; phi 360, 120, 60), minMatches 10.
+    The ladder must stop as soon as 10 verified correspondences exist and they must obey the shipped ground truth."""
+    cat, cat2, Hgt = cat_pair
+    i1, i2 = ctx.upload(cat), ctx.upload(cat2)
+    prev = {0: [], 3: []}
+    steps = []
+    for det, scales, tilts, phi, sigma, ratio in ((3, [1, 0.25, 0.125], [1], 360.0, 0.8, 0.85),
+                                                 (3, [1, 0.25, 0.125], [1, 3, 6, 9], 360.0, 0.8, 0.8),
+                                                 (0, [1], [1, 2, 4, 6, 8], 360.0, 0.2, 0.8),
+                                                 (0, [1], [1, 2, 4, 6, 8], 120.0, 0.2, 0.8),
+                                                 (0, [1], [1, 2, 4, 6, 8], 60.0, 0.2, 0.8)):
+        v = modsx.set_vs_pars(scales, tilts, phi, sigma, 1, prev[det])
+        if v:
+            steps.append((v, ratio, det))
+    par = modsx.default_pair_params(ransac_seed=3, ori_mrSize=5.1962)
+    got, done = ctx.match_ladder(i1, i2, steps, par, min_matches=10)
+    full, done_full = ctx.match_ladder(i1, i2, steps[:done], par, min_matches=10 ** 6)
+    i1.free(); i2.free()
+    assert 1 <= done <= len(steps) and got["n_verified"] >= 10
+    assert done_full == done and full["n_verified"] == got["n_verified"]          # deterministic, stops exactly there
+    if done > 1:
+        i1, i2 = ctx.upload(cat), ctx.upload(cat2)
+        before, _ = ctx.match_ladder(i1, i2, steps[:done - 1], par, min_matches=10 ** 6)
+        i1.free(); i2.free()
+        assert before["n_verified"] < 10                                            # the previous step had not reached minMatches
+    # the verified correspondences obey the shipped ground-truth homography (cat.txt): rebuild the concatenated region
+    # lists (HessianAffine class first, then MSER, each in step order) the result indexes
+    i1, i2 = ctx.upload(cat), ctx.upload(cat2)
+    lists = {0: [[], []], 3: [[], []]}
+    for v, _, det in steps[:done]:
+        pd = modsx.default_pair_params(ransac_seed=3, ori_mrSize=5.1962, detector=det)
+        for side, im in enumerate((i1, i2)):
+            r, _ = ctx.detect_describe_views(im, v, pd, want_desc=False)
+            lists[det][side].append(r)
+    i1.free(); i2.free()
+    r1 = np.concatenate([r for det in (0, 3) for r in lists[det][0]] or [np.zeros(0, modsx.REGION)])
+    r2 = np.concatenate([r for det in (0, 3) for r in lists[det][1]] or [np.zeros(0, modsx.REGION)])
+    assert got["n_regions"] == (len(r1), len(r2))
+    t = got["tentatives"][got["verified"]]
+    p1 = np.stack([r1["reproj_kp"]["x"][t["q"]], r1["reproj_kp"]["y"][t["q"]], np.ones(len(t))], 1)
+    p2 = np.stack([r2["reproj_kp"]["x"][t["t0"]], r2["reproj_kp"]["y"][t["t0"]]], 1)
+    proj = p1 @ normH(Hgt).T
+    proj = proj[:, :2] / proj[:, 2:]
+    err = np.linalg.norm(proj - p2, axis=1)
+    # the scene is not exactly planar: the shipped H fits the matches to ~15 px
+    assert np.mean(err < 10.0) > 0.6 and err.max() < 30.0, (done, np.sort(err)[-10:], len(err))
