@@ -261,3 +261,39 @@ def test_grouped_pairs_equal_single_pairs(modsx, small_pair):
         x.free(); y.free()
     for c in ctxs:
         c.close()
+
+
+def test_degenerate_inputs_do_not_break_the_path(ctx, modsx, oracle):
+    """Empty and ragged inputs: blank images (no keypoints), images smaller than the detector border, one-sided
+    emptiness, zero pairs, a 1-row image for MSER; every call returns the reference's (empty) result, none raises."""
+    blank = np.full((96, 128), 90, np.float32)
+    tiny = np.random.RandomState(1).uniform(0, 255, (9, 11)).astype(np.float32)
+    from mods_amd import synthetic
+    a, b, _ = synthetic.make_pair(rows=120, cols=160, nblobs=120, seed=5)
+    par = modsx.default_pair_params(ransac_seed=2)
+    ims = {k: ctx.upload(v) for k, v in dict(blank=blank, tiny=tiny, a=a, b=b).items()}
+    for x, y in (("blank", "blank"), ("blank", "a"), ("a", "blank"), ("tiny", "tiny"), ("tiny", "a")):
+        r = ctx.match_pair(ims[x], ims[y], par)
+        assert r["n_verified"] == 0 and r["n_tentatives"] == 0 and len(r["tentatives"]) == 0
+        assert r["n_regions"][0] == len(oracle_features(oracle, dict(blank=blank, tiny=tiny, a=a, b=b)[x])[2])
+    assert modsx.match_pairs([ctx], [], [], par) == []
+    assert len(ctx.detect_affine_keypoints(ims["blank"], modsx.default_hessaff_params())) == 0
+    assert len(ctx.detect_msers(ims["blank"])) == 0 and len(ctx.detect_msers(ims["tiny"])) == len(oracle.detect_msers(tiny))
+    views = modsx.set_vs_pars([1.0], [1, 2], 360.0, 0.2, 1, [])
+    regs, desc = ctx.detect_describe_views(ims["blank"], views, par)
+    assert len(regs) == 0 and desc.shape == (0, 128)
+    got, done = ctx.match_ladder(ims["blank"], ims["a"], [(views, 0.8)], par, min_matches=10)
+    assert done == 1 and got["n_verified"] == 0
+    for im in ims.values():
+        im.free()
+
+
+def test_full_hd_pair_runs(ctx, modsx):
+    """configs[4] geometry (1920x1080): sizes that are not multiples of any tile, > 10 k regions per image."""
+    from mods_amd import synthetic
+    a, b, H = synthetic.make_pair(rows=1079, cols=1919, nblobs=11000, seed=21)
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    r = ctx.match_pair(ia, ib, modsx.default_pair_params(ransac_seed=4))
+    ia.free(); ib.free()
+    assert min(r["n_regions"]) > 4000 and r["n_verified"] > 500
+    assert np.abs(normH(r["H"]) - H).max() < 1.0
