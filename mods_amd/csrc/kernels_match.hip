@@ -20,8 +20,11 @@
 // resident in registers for the whole sweep) and one of S contiguous ranges of train tiles (M is split so
 // that small N still fills the chip).  Train tiles (32 descriptors = 4 KB) are loaded with fully coalesced
 // 16-byte-per-lane reads, staged in a double-buffered LDS tile shared by the 4 waves, and read back as MFMA
-// B fragments with ds_read_b128.  Each lane keeps running minima for its 16 accumulator rows as packed
-// (distance << 9 | local tile) keys: one shift-or and one or two integer min per element.
+// B fragments with ds_read_b128.  Each lane keeps the running top-2 of its 16 accumulator rows as packed keys.  In
+// sweep 1 the query fragment is negated (a'' = 127 - a), so acc = -(a'.b') - sum(b') and
+// key = ((|b'|^2 - 2 a'.b') << 8) | local tile = (acc << 9) + column constant: one v_lshl_add, one v_min and one v_med3
+// per matrix element, with the accumulators in VGPRs (-amdgpu-mfma-vgpr-form) and the four MFMAs of tile q issued
+// between the quarters of the update of tile q - 1.  The query norm, constant per row, is added after the sweep.
 #include "engine.hpp"
 
 namespace mx {
