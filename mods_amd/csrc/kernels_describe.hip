@@ -212,9 +212,12 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
   const int k = blockIdx.x;
   if (k >= n) return;
   const int tid = threadIdx.x;
-  __shared__ __attribute__((aligned(16))) float patch[NPX];
+  // `patch` (unpadded 41 x 41) and `bufB` (padded rows) share one buffer: whatever replaces the patch is first staged
+  // in registers (14 values per thread) and written after a barrier
+  __shared__ __attribute__((aligned(16))) float patchB[PS * PSP];
+  float *const patch = patchB, *const bufB = patchB;
+  constexpr int PER_T = (NPX + 127) / 128;
   __shared__ __attribute__((aligned(16))) float bufA[PS * PSP];   // WX (direct branch), compacted masked values, later val
-  __shared__ __attribute__((aligned(16))) float bufB[PS * PSP];   // WY (direct branch), later o = orientation bin coordinate
   __shared__ double slut[256];   // ATAN_LUT (2 KB) next to the CU
   __shared__ float swr0[PS], swr1[PS];
   __shared__ double swc0[PS], swc1[PS];
@@ -275,9 +278,18 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
       }
     }
     __syncthreads();
-    for (int p = tid; p < NPX; p += 128) {
+    float sv[PER_T];
+#pragma unroll
+    for (int k = 0; k < PER_T; k++) {
+      const int p = tid + 128 * k;
       const int r = p / PS, c = p - r * PS;
-      patch[p] = bilinear_tap(src, srows, scols, bufA[r * PSP + c], bufB[r * PSP + c], touch);
+      sv[k] = p < NPX ? bilinear_tap(src, srows, scols, bufA[r * PSP + c], bufB[r * PSP + c], touch) : 0.f;
+    }
+    __syncthreads();   // every WY coordinate has been consumed; the samples may overwrite them
+#pragma unroll
+    for (int k = 0; k < PER_T; k++) {
+      const int p = tid + 128 * k;
+      if (p < NPX) patch[p] = sv[k];
     }
   }
   __syncthreads();
@@ -325,7 +337,12 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
   }
   // -- gradients, orientation, per-pixel weights (siftdesc.cpp:346-379, 73-131)
   const double TWO_PI = 6.28318530718;
-  for (int p = tid; p < NPX; p += 128) {
+  float ov[PER_T];
+#pragma unroll
+  for (int k = 0; k < PER_T; k++) {
+    const int p = tid + 128 * k;
+    ov[k] = 0.f;
+    if (p >= NPX) continue;
     const int r = p / PS, c = p - r * PS;
     float xg, yg;
     if (c == 0) xg = patch[p + 1] - patch[p];
@@ -337,10 +354,14 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
     const float g = sqrtf(xg * xg + yg * yg);
     const float ori = atan2lut(slut, yg, xg);
     const float val = (float)(0.0 + (1.0 * (double)mask[p]) * (double)g);
-    const float o = (float)((double)8.0f * ((double)ori + TWO_PI) / TWO_PI);
-    const int q = r * PSP + c;
-    bufA[q] = val;     // the column weights wc0 / wc1 = (float)(w[c] * val) are formed in the gather
-    bufB[q] = o;       // bo0 = (int)o, wo1 = o - bo0 likewise
+    ov[k] = (float)((double)8.0f * ((double)ori + TWO_PI) / TWO_PI);
+    bufA[r * PSP + c] = val;     // the column weights wc0 / wc1 = (float)(w[c] * val) are formed in the gather
+  }
+  __syncthreads();   // all gradients taken: the patch may be replaced by o (bo0 = (int)o, wo1 = o - bo0 in the gather)
+#pragma unroll
+  for (int k = 0; k < PER_T; k++) {
+    const int p = tid + 128 * k;
+    if (p < NPX) { const int r = p / PS, c = p - r * PS; bufB[r * PSP + c] = ov[k]; }
   }
   __syncthreads();
   // -- samplePatch: bin t gathers its 16x16 pixel block in raster order
