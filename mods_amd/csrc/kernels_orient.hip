@@ -5,7 +5,7 @@
 //   computeGradientMagnitudeAndOrientation + atan2LUTff     detectors/helpers.cpp:840-863, 160-207
 //   36-bin histogram of mag * circular Gauss mask, 6x circular smoothing, parabolic peaks,
 //   first maxAngles peaks in bin order.
-// Lane j walks row j of the patch (the f32 sample coordinates are running sums along a row);
+// Lane j walks row j of the patch (the f32 sample coordinates are running sums along a row) and takes its taps;
 // histogram bin b is accumulated by lane b scanning the pixels in raster order, which keeps
 // the reference's f32 summation order per bin.
 #include "engine.hpp"
@@ -20,45 +20,46 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
   const int k = blockIdx.x;
   if (k >= n) return;
   const int lane = threadIdx.x;
-  __shared__ __attribute__((aligned(16))) float bufX[PS * PSP];   // WX, then the patch (same padded layout)
-  __shared__ __attribute__((aligned(16))) float bufY[PS * PSP];   // WY, then the histogram weights
+  // 11 KB of LDS per region (14 regions resident per CU): the patch, later overwritten by the histogram weights, the
+  // bin indices and the ATAN_LUT
+  __shared__ __attribute__((aligned(16))) float bufX[PS * PSP];
   __shared__ __attribute__((aligned(16))) unsigned char sbin[PS * PSP];
-  __shared__ double slut[256];                                     // ATAN_LUT (2 KB) next to the CU
+  __shared__ double slut[256];
   __shared__ float hist[40];
   for (int i = lane; i < 256; i += 64) slut[i] = atanLut[i];
   const OriJob jb = jobs[k];
   const ImgRef im = imgs[jb.img];
   const int half = PS >> 1;
   const bool touch = check_borders(im.cols, im.rows, jb.x, jb.y, jb.a11, jb.a12, jb.a21, jb.a22, PS, PS);
-  // sample coordinates: the f32 running sums of interpolate() (helpers.cpp:563-585), one lane per row
+  // lane j owns row j of the patch: it runs the f32 running sums of interpolate() (helpers.cpp:563-585) along the row
+  // and takes the taps as it goes, four columns in flight
   if (lane < PS) {
     float rx = jb.x - (float)half * jb.a12;
     float ry = jb.y - (float)half * jb.a22;
     for (int j = 0; j < lane; j++) { rx += jb.a12; ry += jb.a22; }
     float WX = rx - (float)half * jb.a11;
     float WY = ry - (float)half * jb.a21;
-#pragma unroll 1
+    float *row = bufX + lane * PSP;
+#pragma unroll 4
     for (int i = 0; i < PS; i++) {
-      bufX[lane * PSP + i] = WX;
-      bufY[lane * PSP + i] = WY;
+      row[i] = bilinear_tap(im.d, im.rows, im.cols, WX, WY, touch);
       WX += jb.a11;
       WY += jb.a21;
     }
   }
   __syncthreads();
-  // each lane replaces the coordinate it just consumed by the sample, so the patch reuses bufX
-#pragma unroll 4
-  for (int p = lane; p < PS * PS; p += 64) {
-    const int r = p / PS, c = p - r * PS, q = r * PSP + c;
-    bufX[q] = bilinear_tap(im.d, im.rows, im.cols, bufX[q], bufY[q], touch);
-  }
-  __syncthreads();
   const float PIf = float(M_PI);
-  for (int p = lane; p < PS * PSP; p += 64) {
+  // gradients -> (bin, weight) per pixel, staged in registers so that the weights can take the patch's place
+  constexpr int PER_L = (PS * PSP + 63) / 64;
+  float wreg[PER_L];
+  unsigned char breg[PER_L];
+#pragma unroll
+  for (int q = 0; q < PER_L; q++) {
+    const int p = lane + 64 * q;
     const int r = p / PSP, c = p - r * PSP;
     unsigned char bin = 255;
     float w = 0.f;
-    if (r >= 1 && r < PS - 1 && c >= 1 && c < PS - 1) {
+    if (p < PS * PSP && r >= 1 && r < PS - 1 && c >= 1 && c < PS - 1) {
       const float xg = bufX[p + 1] - bufX[p - 1];
       const float yg = bufX[p + PSP] - bufX[p - PSP];
       const float mag = sqrtf(xg * xg + yg * yg);
@@ -69,8 +70,13 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
         w = mag * m;
       }
     }
-    sbin[p] = bin;
-    bufY[p] = w;
+    wreg[q] = w; breg[q] = bin;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < PER_L; q++) {
+    const int p = lane + 64 * q;
+    if (p < PS * PSP) { bufX[p] = wreg[q]; sbin[p] = breg[q]; }
   }
   __syncthreads();
   // lane b owns histogram bin b and adds its pixels in raster order (f32 running sum of the reference)
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
 #pragma unroll 1
     for (int r = 1; r < PS - 1; r++) {
       const unsigned *b4 = reinterpret_cast<const unsigned *>(sbin + r * PSP);
-      const float4 *w4 = reinterpret_cast<const float4 *>(bufY + r * PSP);
+      const float4 *w4 = reinterpret_cast<const float4 *>(bufX + r * PSP);
 #pragma unroll
       for (int g = 0; g < PSP / 4; g++) {
         const unsigned b = b4[g];
