@@ -744,6 +744,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
               PInfo pi;
               float sigma = 1.5f * i2p;
               pi.ksize = blur_ksize(sigma);
+              if (pi.ksize > 512) { set_error("descriptor window too large (blur kernel > 512 taps)"); return MODSX_ERR_ARG; }
               std::vector<float> kk = gaussian_kernel(pi.ksize, sigma);
               pi.tapOfs = (int)taps.size();
               taps.insert(taps.end(), kk.begin(), kk.end());

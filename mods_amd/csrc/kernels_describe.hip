@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64) void k_patch_sample(const DescJob *jobs, const 
 // A workgroup forms BLUR_TILE outputs (4 per thread): the start of a workgroup is a chain of dependent loads (tile ->
 // job -> needed column -> inputs) that lasts longer than the arithmetic of 256 outputs, so fewer, fatter workgroups
 // run faster; the taps are parked in LDS so that a tap costs one vector load, not two.
-constexpr int BLUR_TILE = 1024, BLUR_TAPS = 128;
+constexpr int BLUR_TILE = 1024, BLUR_TAPS = 512;   // ksize <= 512 is enforced by the host (windows up to ~2300 px)
 
 __global__ __launch_bounds__(256) void k_patch_blur(const DescJob *jobs, const int *tilePrefix, const int *tileJob,
                                                     const float *taps, const int *needTab, const float *src,
@@ -113,73 +113,94 @@ __global__ __launch_bounds__(256) void k_patch_blur(const DescJob *jobs, const i
   __shared__ float sk[BLUR_TAPS];
   __shared__ int sneed[96];
   const float *kg = taps + jb.tapOfs;
-  const bool ldsTaps = n <= BLUR_TAPS;
-  if (ldsTaps) for (int i = threadIdx.x; i < n; i += 256) sk[i] = kg[i];
+  for (int i = threadIdx.x; i < n; i += 256) sk[i] = kg[i];
   if (threadIdx.x < NC) sneed[threadIdx.x] = needTab[jb.needOfs + threadIdx.x];
   __syncthreads();
   const int e0 = (tile - tilePrefix[jid]) * BLUR_TILE + threadIdx.x;
+  constexpr int NQ = BLUR_TILE / 256;   // outputs per thread, advanced in lock-step over the taps so that NQ (x unroll)
+                                        // independent loads are in flight per thread: the kernel is bound by memory
+                                        // latency (VALU 7 %, waitcnt 68 % of the wave cycles), not by arithmetic
+  const float *kk = sk;
   if (pass == 0) {
     const float *A = src + jb.scratchOfs;
-#pragma unroll 1
-    for (int q = 0; q < BLUR_TILE / 256; q++) {
-      const int e = e0 + q * 256;
-      if (e >= P * NC) break;
+    const int total = P * NC;
+    const float *row[NQ];
+    int c[NQ];
+    float v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      int e = e0 + q * 256;
+      e = e < total ? e : total - 1;          // out-of-range slots repeat the last output and are not stored
       const int r = e / NC, ci = e - r * NC;
-      const int c = sneed[ci];
-      const float *row = A + (size_t)r * P;
-      float v;
-      if (n == 1) v = row[c];
-      else if (n <= 5) {
-        v = row[c] * sk[R];
-        for (int j = 1; j <= R; j++) {
-          int cm = c - j < 0 ? 0 : c - j, cp = c + j > P - 1 ? P - 1 : c + j;
-          v = v + (row[cm] + row[cp]) * sk[R + j];
-        }
-      } else if (ldsTaps) {
-        v = 0.f;
-#pragma unroll 8
-        for (int j = 0; j < n; j++) {
-          int cc = c + j - R;
-          cc = cc < 0 ? 0 : (cc > P - 1 ? P - 1 : cc);
-          v = v + row[cc] * sk[j];
-        }
-      } else {
-        v = 0.f;
-#pragma unroll 8
-        for (int j = 0; j < n; j++) {
-          int cc = c + j - R;
-          cc = cc < 0 ? 0 : (cc > P - 1 ? P - 1 : cc);
-          v = v + row[cc] * kg[j];
+      c[q] = sneed[ci];
+      row[q] = A + (size_t)r * P;
+    }
+    if (n == 1) {
+#pragma unroll
+      for (int q = 0; q < NQ; q++) v[q] = row[q][c[q]];
+    } else if (n <= 5) {
+#pragma unroll
+      for (int q = 0; q < NQ; q++) v[q] = row[q][c[q]] * kk[R];
+      for (int j = 1; j <= R; j++) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const int cm = c[q] - j < 0 ? 0 : c[q] - j, cp = c[q] + j > P - 1 ? P - 1 : c[q] + j;
+          v[q] = v[q] + (row[q][cm] + row[q][cp]) * kk[R + j];
         }
       }
-      dst[jb.rowOfs + e] = v;
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQ; q++) v[q] = 0.f;
+#pragma unroll 4
+      for (int j = 0; j < n; j++) {
+        const float kj = kk[j];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          int cc = c[q] + j - R;
+          cc = cc < 0 ? 0 : (cc > P - 1 ? P - 1 : cc);
+          v[q] = v[q] + row[q][cc] * kj;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int e = e0 + q * 256;
+      if (e < total) dst[jb.rowOfs + e] = v[q];
     }
   } else {
     const float *S = src + jb.rowOfs;   // P x NC
-#pragma unroll 1
-    for (int q = 0; q < BLUR_TILE / 256; q++) {
-      const int e = e0 + q * 256;
-      if (e >= NC * NC) break;
+    const int total = NC * NC;
+    const float *col[NQ];
+    int r[NQ];
+    float v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      int e = e0 + q * 256;
+      e = e < total ? e : total - 1;
       const int ri = e / NC, ci = e - ri * NC;
-      const int r = sneed[ri];
-      float v;
-      if (n == 1) v = S[(size_t)r * NC + ci];
-      else if (ldsTaps) {
-        v = sk[R] * S[(size_t)r * NC + ci] + 0.f;
-#pragma unroll 4
-        for (int j = 1; j <= R; j++) {
-          int rp = r + j > P - 1 ? P - 1 : r + j, rm = r - j < 0 ? 0 : r - j;
-          v = v + sk[R + j] * (S[(size_t)rp * NC + ci] + S[(size_t)rm * NC + ci]);
-        }
-      } else {
-        v = kg[R] * S[(size_t)r * NC + ci] + 0.f;
-#pragma unroll 4
-        for (int j = 1; j <= R; j++) {
-          int rp = r + j > P - 1 ? P - 1 : r + j, rm = r - j < 0 ? 0 : r - j;
-          v = v + kg[R + j] * (S[(size_t)rp * NC + ci] + S[(size_t)rm * NC + ci]);
+      r[q] = sneed[ri];
+      col[q] = S + ci;
+    }
+    if (n == 1) {
+#pragma unroll
+      for (int q = 0; q < NQ; q++) v[q] = col[q][(size_t)r[q] * NC];
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQ; q++) v[q] = kk[R] * col[q][(size_t)r[q] * NC] + 0.f;
+#pragma unroll 2
+      for (int j = 1; j <= R; j++) {
+        const float kj = kk[R + j];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const int rp = r[q] + j > P - 1 ? P - 1 : r[q] + j, rm = r[q] - j < 0 ? 0 : r[q] - j;
+          v[q] = v[q] + kj * (col[q][(size_t)rp * NC] + col[q][(size_t)rm * NC]);
         }
       }
-      dst[jb.gridOfs + e] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int e = e0 + q * 256;
+      if (e < total) dst[jb.gridOfs + e] = v[q];
     }
   }
 }
