@@ -150,10 +150,13 @@ def main():
     iso = {}
     if rank == 0:
         ctx.profile(True)
-        for i in range(min(args.batch, 8)):
-            if views is None:
-                ctx.match_pair(imgs1[i], imgs2[i], params)
-            else:
+        niso = min(args.batch, 8)
+        if views is None:
+            # same launch geometry as the timed region: 4 pairs (8 images) per launch set
+            for i0 in range(0, niso, 4):
+                mods_amd.match_pairs([ctx], imgs1[i0:min(i0 + 4, niso)], imgs2[i0:min(i0 + 4, niso)], params)
+        else:
+            for i in range(niso):
                 ctx.match_pair_views(imgs1[i], imgs2[i], views, params)
         ctx.synchronize()
         iso = {k: v for k, v in ctx.kernel_stats().items() if v["launches"]}
