@@ -165,7 +165,7 @@ void ctx_destroy(modsx_ctx *c) {
   for (int i = 0; i < MAXB; i++) c->pyr[i].store.release();
   DevBuf *bufs[] = {&c->nmsJobs, &c->cand, &c->counter, &c->affJobs, &c->affOut, &c->oriJobs, &c->oriOut, &c->descJobs, &c->tilePrefix,
                     &c->taps, &c->imgRefs, &c->scratchA, &c->scratchB, &c->descAllF[0], &c->descAllF[1], &c->descAllU8[0],
-                    &c->descAllU8[1], &c->descAllU8b[0], &c->descAllU8b[1], &c->pos2, &c->matchRows, &c->matchWork, &c->misc, &c->scratchC, &c->needTab, &c->coordTab, &c->tileJob, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps};
+                    &c->descAllU8[1], &c->descAllU8b[0], &c->descAllU8b[1], &c->pos2, &c->matchRows, &c->matchWork, &c->misc, &c->scratchC, &c->needTab, &c->coordTab, &c->tileJob, &c->blurTiles, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps};
   for (DevBuf *b : bufs) b->release();
   for (int i = 0; i < MAXB; i++) { c->descF[i].release(); c->descU8[i].release(); }
   PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc};
@@ -714,10 +714,10 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
   while (curImg < n) {
     {
       std::vector<DescJob> jobs;
-      std::vector<int> pfxSample(1, 0), pfxRow(1, 0), pfxCol(1, 0);
+      std::vector<int> pfxSample(1, 0), pfxRow(1, 0), pfxCol(1, 0), pfxRowL(1, 0), pfxColL(1, 0);
       std::vector<float> taps, coordTab;
       std::vector<int> needTab;
-      struct PInfo { int tapOfs, ksize, needOfs, NC, coordOfs, touch; };
+      struct PInfo { int tapOfs, ksize, needOfs, NC, coordOfs, touch, rows0, ro1; };
       std::map<int, PInfo> pinfo;  // per window size P
       size_t arenaA = 0, arenaB = 0, arenaC = 0;
       bool full = false;
@@ -788,6 +788,22 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
               }
               pi.coordOfs = (int)coordTab.size();
               coordTab.insert(coordTab.end(), W, W + 41);
+              {  // tile shapes of the LDS blur kernels: <= BLUR_OUT outputs and <= BLUR_LDS floats per workgroup
+                const int BLUR_LDS = 4992, R = pi.ksize >> 1, cap = 2048 / (2 * ((pi.NC + 1) / 2));
+                // the row filter pairs needed columns (2m, 2m+1); they are neighbours in the window by construction
+                // (x0, x0 + 1 of one sample, or a contiguous range) -- if ever not, the job takes the global-memory kernel
+                bool pairs = true;
+                for (int a = 0; a + 1 < pi.NC; a += 2) pairs = pairs && need[a + 1] == need[a] + 1;
+                pi.rows0 = pairs ? std::min(cap, BLUR_LDS / (P + 2 * R)) : 0;
+                if (pi.rows0 < 2) pi.rows0 = 0;
+                pi.ro1 = 0;
+                const int LS = pi.NC <= 64 ? 64 : 96;   // LDS row stride of the column filter
+                for (int ro = std::min(cap, pi.NC); ro >= 2 && !pi.ro1 && pi.NC <= 96; ro--) {
+                  int span = 0;
+                  for (int a = 0; a < pi.NC; a += ro) span = std::max(span, need[std::min(a + ro, pi.NC) - 1] - need[a] + 2 * R + 1);
+                  if (span * LS <= BLUR_LDS) pi.ro1 = ro;
+                }
+              }
               it = pinfo.insert({P, pi}).first;
             }
             const PInfo &pi = it->second;
@@ -796,7 +812,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
             j.P = P;
             j.a11 = (float)k.a11; j.a12 = (float)k.a12; j.a21 = (float)k.a21; j.a22 = (float)k.a22;
             j.tapOfs = pi.tapOfs; j.ksize = pi.ksize; j.NC = pi.NC; j.needOfs = pi.needOfs; j.coordOfs = pi.coordOfs;
-            j.touch = pi.touch;
+            j.touch = pi.touch; j.rows0 = pi.rows0; j.ro1 = pi.ro1;
             j.scratchOfs = arenaA; j.rowOfs = arenaB; j.gridOfs = arenaC;
             arenaA += needA; arenaB += (size_t)P * pi.NC; arenaC += (size_t)pi.NC * pi.NC;
           } else {
@@ -813,15 +829,18 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
         }
         jobs.push_back(j);
         pfxSample.push_back(pfxSample.back() + (j.P > 0 ? ((j.P + 63) / 64) * ((j.P + 127) / 128) : 0));  // 64 x SAMPLE_COLS tiles
-        pfxRow.push_back(pfxRow.back() + (j.P > 0 ? (j.P * j.NC + 1023) / 1024 : 0));   // BLUR_TILE outputs per workgroup
-        pfxCol.push_back(pfxCol.back() + (j.P > 0 ? (j.NC * j.NC + 1023) / 1024 : 0));
+        // the blur passes: LDS kernels where a tile fits, k_patch_blur (BLUR_TILE outputs per workgroup) otherwise
+        pfxRowL.push_back(pfxRowL.back() + (j.P > 0 && j.rows0 ? (j.P + j.rows0 - 1) / j.rows0 : 0));
+        pfxColL.push_back(pfxColL.back() + (j.P > 0 && j.ro1 ? (j.NC + j.ro1 - 1) / j.ro1 : 0));
+        pfxRow.push_back(pfxRow.back() + (j.P > 0 && !j.rows0 ? (j.P * j.NC + 1023) / 1024 : 0));
+        pfxCol.push_back(pfxCol.back() + (j.P > 0 && !j.ro1 ? (j.NC * j.NC + 1023) / 1024 : 0));
       }
       if (full) break;
       }
       // (i, r) = first region that did not fit, or i == n
       if (full) { curImg = i; curReg = r; } else { curImg = n; curReg = 0; }
       const size_t nj = jobs.size();
-      if (!c->descJobs.ensure(nj * sizeof(DescJob)) || !c->tilePrefix.ensure((nj + 1) * 12) ||
+      if (!c->descJobs.ensure(nj * sizeof(DescJob)) || !c->tilePrefix.ensure((nj + 1) * 20) ||
           !c->taps.ensure(std::max<size_t>(1, taps.size()) * 4) || !c->needTab.ensure(std::max<size_t>(1, needTab.size()) * 4) ||
           !c->coordTab.ensure(std::max<size_t>(1, coordTab.size()) * 4) ||
           !c->scratchA.ensure(std::max<size_t>(1, arenaA) * 4) || !c->scratchB.ensure(std::max<size_t>(1, arenaB) * 4) ||
@@ -829,7 +848,12 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
           !c->tileJob.ensure(((size_t)pfxSample.back() + pfxRow.back() + pfxCol.back() + 3) * 4))
         return MODSX_ERR_NOMEM;
       int *tjS = (int *)c->tileJob.p, *tjR = tjS + pfxSample.back(), *tjC = tjR + pfxRow.back();
+      if (!c->blurTiles.ensure(((size_t)pfxRowL.back() + pfxColL.back() + 1) * sizeof(BlurTile))) return MODSX_ERR_NOMEM;
+      BlurTile *btR = (BlurTile *)c->blurTiles.p, *btC = btR + pfxRowL.back();
       int *dPfxS = (int *)c->tilePrefix.p, *dPfxR = dPfxS + (nj + 1), *dPfxC = dPfxR + (nj + 1);
+      int *dPfxRL = dPfxC + (nj + 1), *dPfxCL = dPfxRL + (nj + 1);
+      MX_HIP(hipMemcpyAsync(dPfxRL, pfxRowL.data(), (nj + 1) * 4, hipMemcpyHostToDevice, s));
+      MX_HIP(hipMemcpyAsync(dPfxCL, pfxColL.data(), (nj + 1) * 4, hipMemcpyHostToDevice, s));
       MX_HIP(hipMemcpyAsync(c->descJobs.p, jobs.data(), nj * sizeof(DescJob), hipMemcpyHostToDevice, s));
       MX_HIP(hipMemcpyAsync(dPfxS, pfxSample.data(), (nj + 1) * 4, hipMemcpyHostToDevice, s));
       MX_HIP(hipMemcpyAsync(dPfxR, pfxRow.data(), (nj + 1) * 4, hipMemcpyHostToDevice, s));
@@ -844,9 +868,13 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       { ProfScope ps(c, K_PATCH_SAMPLE, (double)arenaA * 8);
         launch_patch_sample(s, dj, dPfxS, tjS, pfxSample.back(), (ImgRef *)c->imgRefs.p, (float *)c->scratchA.p); }
       { ProfScope ps(c, K_PATCH_BLUR, ((double)arenaA + arenaB) * 4);
+        launch_blur_lds(s, dj, dPfxRL, (int)nj, btR, pfxRowL.back(), (float *)c->taps.p, (int *)c->needTab.p, (float *)c->scratchA.p,
+                        (float *)c->scratchB.p, 0);
         launch_patch_blur(s, dj, dPfxR, tjR, pfxRow.back(), (float *)c->taps.p, (int *)c->needTab.p, (float *)c->scratchA.p,
                           (float *)c->scratchB.p, 0); }
       { ProfScope ps(c, K_PATCH_BLUR, ((double)arenaB + arenaC) * 4);
+        launch_blur_lds(s, dj, dPfxCL, (int)nj, btC, pfxColL.back(), (float *)c->taps.p, (int *)c->needTab.p, (float *)c->scratchB.p,
+                        (float *)c->scratchC.p, 1);
         launch_patch_blur(s, dj, dPfxC, tjC, pfxCol.back(), (float *)c->taps.p, (int *)c->needTab.p, (float *)c->scratchB.p,
                           (float *)c->scratchC.p, 1); }
       ProfScope psd(c, K_DESCRIBE, (double)arenaC * 4 + (double)nj * (128 * 5));

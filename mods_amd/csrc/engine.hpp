@@ -78,10 +78,16 @@ struct DescJob {
   int coordOfs;       // offset into the float table: 41 sample coordinates WX_i (= WY_j)
   int touch;          // interpolate()'s border branch for the 41x41 resampling
   int outIdx;         // index of the region in its image's descriptor buffers
-  int pad0;
+  int rows0;          // window rows per workgroup of the LDS row filter, 0 = this job goes through k_patch_blur
+  int ro1;            // needed rows per workgroup of the LDS column filter, 0 = k_patch_blur
   unsigned long long scratchOfs;    // float offset of this region's P x P window (arena A)
   unsigned long long rowOfs;        // float offset of its P x NC row-filtered block (arena B)
   unsigned long long gridOfs;       // float offset of its NC x NC blurred grid (arena C)
+};
+struct BlurTile {     // one workgroup of the LDS blur kernels
+  unsigned long long srcOfs, dstOfs;   // float offsets: first input row / first output of the tile
+  int P, NC, n, tapOfs, needOfs;
+  int first, count, lo, span, magic;  // rows pass: window rows [first, first+count); columns pass: needed rows, parked source rows [lo, lo+span); magic = ceil(2^20 / ceil(NC / 2))
 };
 struct ImgRef { const float *d; int rows, cols, pad; };
 struct DescOut { float *f[MAXB]; uint8_t *u8[MAXB]; };   // per image of the batch: [n][128] f32 and u8 descriptors
@@ -160,6 +166,8 @@ void launch_baumberg(hipStream_t s, const AffJob *jobs, AffOut *out, int n, cons
 void launch_orientation(hipStream_t s, const OriJob *jobs, OriOut *out, int n, const ImgRef *imgs, const float *orimask,
                         const double *atanLut, int doHalf, double th, int maxAngles);
 void launch_trunc_u8(hipStream_t s, const float *src, uint8_t *dst, size_t n);
+void launch_blur_lds(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
+                     const float *taps, const int *needTab, const float *src, float *dst, int pass);
 void launch_expand_tiles(hipStream_t s, const int *prefix, int nJobs, int *tileJob);
 void launch_patch_sample(hipStream_t s, const DescJob *jobs, const int *tilePrefix, const int *tileJob, int nTiles,
                          const ImgRef *imgs, float *scratch);
@@ -202,7 +210,7 @@ struct modsx_ctx {
   hipStream_t stream;
   mx::Pyramid pyr[mx::MAXB];
   mx::DevBuf nmsJobs, cand, counter, affJobs, affOut, oriJobs, oriOut, descJobs, tilePrefix, taps, imgRefs, scratchA, scratchB,
-      descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], descAllU8b[2], pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps, scratchC, needTab, coordTab, tileJob;
+      descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], descAllU8b[2], pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps, scratchC, needTab, coordTab, tileJob, blurTiles;
   mx::PinBuf hCand, hAff, hOri, hDesc, hMisc;
   // constant tables on device
   float *dSmmMask = nullptr;   // 19x19 computeGaussMask

@@ -35,13 +35,47 @@ __global__ __launch_bounds__(64) void k_expand_tiles(const int *prefix, int nJob
   for (int t = b + threadIdx.x; t < e; t += 64) tileJob[t] = j;
 }
 
+// tile descriptors of the LDS blur kernels: everything a workgroup needs in one 48-byte scalar load, so that its first
+// vector loads (the inputs it parks in LDS) are two dependent round trips from the launch instead of three
+__global__ __launch_bounds__(64) void k_expand_blur_tiles(const DescJob *jobs, const int *prefix, int nJobs, const int *needTab,
+                                                          BlurTile *tiles, int pass) {
+  const int j = blockIdx.x;
+  if (j >= nJobs) return;
+  const int b = prefix[j], e = prefix[j + 1];
+  if (b == e) return;
+  const DescJob jb = jobs[j];
+  const int R = jb.ksize >> 1;
+  for (int t = b + threadIdx.x; t < e; t += 64) {
+    BlurTile bt;
+    bt.P = jb.P; bt.NC = jb.NC; bt.n = jb.ksize; bt.tapOfs = jb.tapOfs; bt.needOfs = jb.needOfs;
+    { const int NP = (jb.NC + 1) >> 1; bt.magic = ((1 << 20) + NP - 1) / NP; }
+    if (pass == 0) {
+      const int r0 = (t - b) * jb.rows0;
+      bt.count = jb.P - r0 < jb.rows0 ? jb.P - r0 : jb.rows0;
+      bt.first = r0; bt.lo = 0; bt.span = bt.count;
+      bt.srcOfs = jb.scratchOfs + (size_t)r0 * jb.P;
+      bt.dstOfs = jb.rowOfs + (size_t)r0 * jb.NC;
+    } else {
+      const int ro0 = (t - b) * jb.ro1;
+      bt.count = jb.NC - ro0 < jb.ro1 ? jb.NC - ro0 : jb.ro1;
+      bt.first = ro0;
+      bt.lo = needTab[jb.needOfs + ro0] - R;
+      bt.span = needTab[jb.needOfs + ro0 + bt.count - 1] + R - bt.lo + 1;
+      bt.srcOfs = jb.rowOfs;
+      bt.dstOfs = jb.gridOfs + (size_t)ro0 * jb.NC;
+    }
+    tiles[t] = bt;
+  }
+}
+
 // --- stage 1: interpolate(img, x, y, A, smoothed(P x P)) ---------------------------------------
-// One wavefront per tile of 64 rows x SAMPLE_COLS columns of one window.  Lane j owns row j: it runs the f32
-// running sums of interpolate() (rx += a12 per row, WX += a11 per column -- cheap dependent adds) up to the
-// tile's first column and then walks the tile left to right; 32-column chunks are transposed through LDS so
-// the stores are row-contiguous.  Splitting long rows into column tiles keeps the longest serial walk at
-// SAMPLE_COLS gathers instead of P (up to ~500).
-constexpr int SAMPLE_COLS = 128;
+// One wavefront per tile of 64 rows x SAMPLE_COLS columns of one window.  The coordinates of a row are f32 running sums
+// (rx += a12 per row, WX += a11 per column) -- cheap, but serial along the row -- so lane j walks row j and parks the
+// (WX, WY) of SAMPLE_C columns in LDS; the bilinear taps are then taken with the lanes running ALONG the rows (16
+// neighbouring samples of 4 rows per instruction), so that a gather touches a handful of cache lines instead of 64 and
+// every lane works even when the tile has few rows; the stores are row-contiguous.  Splitting long rows into column
+// tiles keeps the longest serial walk at SAMPLE_COLS steps instead of P (up to ~2000).
+constexpr int SAMPLE_COLS = 128, SAMPLE_C = 16, SAMPLE_CP = SAMPLE_C + 1;
 
 __global__ __launch_bounds__(64) void k_patch_sample(const DescJob *jobs, const int *tilePrefix, const int *tileJob,
                                                      const ImgRef *imgs, float *scratch) {
@@ -58,7 +92,7 @@ __global__ __launch_bounds__(64) void k_patch_sample(const DescJob *jobs, const 
   const int colEnd = (col0 + SAMPLE_COLS) < P ? (col0 + SAMPLE_COLS) : P;
   const int row = row0 + lane;
   const ImgRef im = imgs[jb.img];
-  __shared__ float tbuf[64 * 33];
+  __shared__ float cx[64 * SAMPLE_CP], cy[64 * SAMPLE_CP];
   const int half = P >> 1;
   const bool touch = check_borders(im.cols, im.rows, jb.x, jb.y, jb.a11, jb.a12, jb.a21, jb.a22, P, P);
   float rx = jb.x - (float)half * jb.a12;
@@ -70,20 +104,24 @@ __global__ __launch_bounds__(64) void k_patch_sample(const DescJob *jobs, const 
   for (int i = 0; i < col0; i++) { WX += jb.a11; WY += jb.a21; }
   float *dst = scratch + jb.scratchOfs;
   const int rowsHere = (P - row0) < 64 ? (P - row0) : 64;
-  for (int c0 = col0; c0 < colEnd; c0 += 32) {
-    const int nc = (colEnd - c0) < 32 ? (colEnd - c0) : 32;
+  for (int c0 = col0; c0 < colEnd; c0 += SAMPLE_C) {
+    const int nc = (colEnd - c0) < SAMPLE_C ? (colEnd - c0) : SAMPLE_C;
     if (row < P) {
 #pragma unroll 4
       for (int i = 0; i < nc; i++) {
-        tbuf[lane * 33 + i] = bilinear_tap(im.d, im.rows, im.cols, WX, WY, touch);
+        cx[lane * SAMPLE_CP + i] = WX;
+        cy[lane * SAMPLE_CP + i] = WY;
         WX += jb.a11;
         WY += jb.a21;
       }
     }
     __syncthreads();
-    for (int e = lane; e < rowsHere * 32; e += 64) {
-      const int r = e >> 5, c = e & 31;
-      if (c < nc) dst[(size_t)(row0 + r) * P + c0 + c] = tbuf[r * 33 + c];
+    const int tot = rowsHere * SAMPLE_C;
+#pragma unroll 4
+    for (int e = lane; e < tot; e += 64) {
+      const int r = e / SAMPLE_C, c = e - r * SAMPLE_C;
+      if (c < nc)
+        dst[(size_t)(row0 + r) * P + c0 + c] = bilinear_tap(im.d, im.rows, im.cols, cx[r * SAMPLE_CP + c], cy[r * SAMPLE_CP + c], touch);
     }
     __syncthreads();
   }
@@ -205,6 +243,202 @@ __global__ __launch_bounds__(256) void k_patch_blur(const DescJob *jobs, const i
   }
 }
 
+// LDS variants of the two passes.  The global-memory kernel above spends most of its issue slots on addresses: per tap a
+// clamp, a 64-bit address and the load for one multiply and one add, and the vector ALUs (not the memory system) are what
+// saturates.  Here a workgroup first parks its inputs in LDS WITH the replicated border written out (the clamp is paid once
+// per input, not once per tap), after which a tap is one ds_read at an immediate offset, one multiply and one add; the taps
+// themselves are wave-uniform and come through the scalar cache.  Sums, terms and order are those of the kernel above.
+//   rows:  a tile is jb.rows0 consecutive window rows, each stored as R + P + R floats
+//   cols:  a tile is jb.ro1 consecutive needed rows; it parks the source rows need[first] - R .. need[last] + R
+// Jobs whose tile does not fit BLUR_LDS floats have rows0 / ro1 = 0 and go through k_patch_blur.
+constexpr int BLUR_LDS = 4992, BLUR_OUT = 2048, FILL_MLP = 20;   // 20 KB: 8 workgroups (the wave limit) per CU
+
+__global__ __launch_bounds__(256, 8) void k_blur_rows_lds(const BlurTile *__restrict__ tiles, const float *__restrict__ taps,
+                                                       const int *__restrict__ needTab, const float *__restrict__ src,
+                                                       float *__restrict__ dst) {
+  const BlurTile bt = tiles[xcd_swizzle(blockIdx.x, gridDim.x)];
+  const int P = bt.P, NC = bt.NC;
+  const int n = bt.n, R = n >> 1, RW = P + 2 * R;
+  __shared__ float win[BLUR_LDS + 2];   // + 2: the idle partner of an odd last column reads one word past its row
+  __shared__ int sneed[96];
+  const int nr = bt.count;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < NC) sneed[threadIdx.x] = needTab[bt.needOfs + threadIdx.x];
+  const float *A = src + bt.srcOfs;
+  // a wave parks rows wave, wave + 4, ...; the loads of up to FILL_MLP (row, 64-column chunk) steps are all issued before the
+  // first LDS write, so a typical tile pays ONE memory round trip for its inputs; (row, chunk) advance in scalar registers
+  {
+    const int xit = (RW + 63) >> 6;
+    int ri = wave, xi = 0;
+    while (ri < nr) {
+      float t[FILL_MLP];
+      int r1 = ri, x1 = xi;
+#pragma unroll
+      for (int u = 0; u < FILL_MLP; u++) {
+        const int x = lane + (x1 << 6);
+        int cc = x - R;
+        cc = cc < 0 ? 0 : (cc > P - 1 ? P - 1 : cc);
+        t[u] = (r1 < nr && x < RW) ? A[r1 * P + cc] : 0.f;
+        if (++x1 == xit) { x1 = 0; r1 += 4; }
+      }
+#pragma unroll
+      for (int u = 0; u < FILL_MLP; u++) {
+        const int x = lane + (xi << 6);
+        if (ri < nr && x < RW) win[ri * RW + x] = t[u];
+        if (++xi == xit) { xi = 0; ri += 4; }
+      }
+    }
+  }
+  __syncthreads();
+  // A thread forms 4 PAIRS of horizontally adjacent outputs (needed columns 2m, 2m+1 -- the host checks that such pairs are
+  // neighbours in the window, which the x0 / x0+1 construction gives): both members of a pair take tap j from adjacent LDS
+  // words, so a tap of a pair is one 2-word read, one packed multiply and one packed add.
+  const float *kg = taps + bt.tapOfs;
+  const int NP = (NC + 1) >> 1, total = nr * NP;
+  float *out = dst + bt.dstOfs;
+  constexpr int NQ = 4;
+  for (int base = threadIdx.x; base < total; base += 256 * NQ) {
+    int p[NQ];     // win[p[q] + j], win[p[q] + j + 1] = window columns need[2m] + j - R, + 1 of the pair's row
+    float v0[NQ], v1[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      int e = base + q * 256;
+      e = e < total ? e : total - 1;                                      // idle slots repeat the last pair, not stored
+      const int r = (int)(((unsigned)e * (unsigned)bt.magic) >> 20), m = e - r * NP;   // e / NP (exact for e < 4096, NP <= 96)
+      p[q] = r * RW + sneed[2 * m];
+    }
+    if (n == 1) {
+#pragma unroll
+      for (int q = 0; q < NQ; q++) { v0[q] = win[p[q]]; v1[q] = win[p[q] + 1]; }
+    } else if (n <= 5) {
+#pragma unroll
+      for (int q = 0; q < NQ; q++) { v0[q] = win[p[q] + R] * kg[R]; v1[q] = win[p[q] + R + 1] * kg[R]; }
+      for (int j = 1; j <= R; j++) {
+        const float kj = kg[R + j];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          v0[q] = v0[q] + (win[p[q] + R - j] + win[p[q] + R + j]) * kj;
+          v1[q] = v1[q] + (win[p[q] + R - j + 1] + win[p[q] + R + j + 1]) * kj;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQ; q++) v0[q] = v1[q] = 0.f;
+#pragma unroll 8
+      for (int j = 0; j < n; j++) {
+        const float kj = kg[j];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          v0[q] = v0[q] + win[p[q] + j] * kj;
+          v1[q] = v1[q] + win[p[q] + j + 1] * kj;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int e = base + q * 256;
+      if (e < total) {
+        const int r = (int)(((unsigned)e * (unsigned)bt.magic) >> 20), m = e - r * NP;
+        float *o = out + r * NC + 2 * m;
+        o[0] = v0[q];
+        if (2 * m + 1 < NC) o[1] = v1[q];
+      }
+    }
+  }
+}
+
+template <int LS>   // LDS row stride (floats), a compile-time constant so that tap j of a column is an immediate offset
+__device__ __forceinline__ void blur_cols_tile(const BlurTile &bt, float *win, int *sneed, const float *__restrict__ taps,
+                                               const int *__restrict__ needTab, const float *__restrict__ src,
+                                               float *__restrict__ dst) {
+  const int P = bt.P, NC = bt.NC;
+  const int n = bt.n, R = n >> 1;
+  const int ro0 = bt.first, nro = bt.count, lo = bt.lo, S = bt.span;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < NC) sneed[threadIdx.x] = needTab[bt.needOfs + threadIdx.x];
+  const float *T = src + bt.srcOfs;   // P x NC
+  {
+    const int xit = (NC + 63) >> 6;
+    int si = wave, xi = 0;
+    while (si < S) {
+      float t[FILL_MLP];
+      int s1 = si, x1 = xi;
+#pragma unroll
+      for (int u = 0; u < FILL_MLP; u++) {
+        const int x = lane + (x1 << 6);
+        int rr = lo + s1;
+        rr = rr < 0 ? 0 : (rr > P - 1 ? P - 1 : rr);
+        t[u] = (s1 < S && x < NC) ? T[rr * NC + x] : 0.f;
+        if (++x1 == xit) { x1 = 0; s1 += 4; }
+      }
+#pragma unroll
+      for (int u = 0; u < FILL_MLP; u++) {
+        const int x = lane + (xi << 6);
+        if (si < S && x < NC) win[si * LS + x] = t[u];
+        if (++xi == xit) { xi = 0; si += 4; }
+      }
+    }
+  }
+  __syncthreads();
+  // pairs of horizontally adjacent outputs again: (ri, 2m) and (ri, 2m+1) read adjacent LDS words in every parked row
+  const float *kg = taps + bt.tapOfs;
+  const int NP = (NC + 1) >> 1, total = nro * NP;
+  float *out = dst + bt.dstOfs;
+  constexpr int NQ = 4;
+  for (int base = threadIdx.x; base < total; base += 256 * NQ) {
+    int pc[NQ];
+    float2 v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      int e = base + q * 256;
+      e = e < total ? e : total - 1;
+      const int ri = (int)(((unsigned)e * (unsigned)bt.magic) >> 20), m = e - ri * NP;
+      pc[q] = (sneed[ro0 + ri] - lo) * LS + 2 * m;
+    }
+    if (n == 1) {
+#pragma unroll
+      for (int q = 0; q < NQ; q++) v[q] = *(const float2 *)&win[pc[q]];
+    } else {
+      const float kc = kg[R];
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        const float2 c = *(const float2 *)&win[pc[q]];
+        v[q].x = kc * c.x + 0.f; v[q].y = kc * c.y + 0.f;
+      }
+#pragma unroll 4
+      for (int j = 1; j <= R; j++) {
+        const float kj = kg[R + j];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const float2 a = *(const float2 *)&win[pc[q] + j * LS], b = *(const float2 *)&win[pc[q] - j * LS];
+          v[q].x = v[q].x + kj * (a.x + b.x);
+          v[q].y = v[q].y + kj * (a.y + b.y);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int e = base + q * 256;
+      if (e < total) {
+        const int ri = (int)(((unsigned)e * (unsigned)bt.magic) >> 20), m = e - ri * NP;
+        float *o = out + ri * NC + 2 * m;
+        o[0] = v[q].x;
+        if (2 * m + 1 < NC) o[1] = v[q].y;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 8) void k_blur_cols_lds(const BlurTile *__restrict__ tiles, const float *__restrict__ taps,
+                                                       const int *__restrict__ needTab, const float *__restrict__ src,
+                                                       float *__restrict__ dst) {
+  const BlurTile bt = tiles[xcd_swizzle(blockIdx.x, gridDim.x)];
+  __shared__ __attribute__((aligned(16))) float win[BLUR_LDS];
+  __shared__ int sneed[96];
+  if (bt.NC <= 64) blur_cols_tile<64>(bt, win, sneed, taps, needTab, src, dst);
+  else blur_cols_tile<96>(bt, win, sneed, taps, needTab, src, dst);
+}
+
 // --- stage 3: 41x41 patch, photometric normalisation, SIFT histogram ----------------------------
 // One 128-thread workgroup per region.  Everything order-dependent in the reference is kept in its
 // order but fed from LDS so that the serial chains are pure dependent adds:
@@ -240,6 +474,7 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
   constexpr int PER_T = (NPX + 127) / 128;
   __shared__ __attribute__((aligned(16))) float bufA[PS * PSP];   // WX (direct branch), compacted masked values, later val
   __shared__ double slut[256];   // ATAN_LUT (2 KB) next to the CU
+  __shared__ __attribute__((aligned(16))) unsigned char sb0[PS * PSP];   // orientation bin bo0 % 8 of every pixel
   __shared__ float swr0[PS], swr1[PS];
   __shared__ double swc0[PS], swc1[PS];
   __shared__ __attribute__((aligned(16))) double vec[128];
@@ -375,10 +610,13 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
     const float g = sqrtf(xg * xg + yg * yg);
     const float ori = atan2lut(slut, yg, xg);
     const float val = (float)(0.0 + (1.0 * (double)mask[p]) * (double)g);
-    ov[k] = (float)((double)8.0f * ((double)ori + TWO_PI) / TWO_PI);
+    const float o = (float)((double)8.0f * ((double)ori + TWO_PI) / TWO_PI);
+    const int bo0 = (int)o;
+    ov[k] = o - (float)bo0;              // wo1 (siftdesc.cpp:111-117), formed once per pixel instead of once per bin
+    sb0[r * PSP + c] = (unsigned char)(bo0 % 8);   // o >= 0, so bo0 % 8 is in 0..7
     bufA[r * PSP + c] = val;     // the column weights wc0 / wc1 = (float)(w[c] * val) are formed in the gather
   }
-  __syncthreads();   // all gradients taken: the patch may be replaced by o (bo0 = (int)o, wo1 = o - bo0 in the gather)
+  __syncthreads();   // all gradients taken: the patch may be replaced by wo1
 #pragma unroll
   for (int k = 0; k < PER_T; k++) {
     const int p = tid + 128 * k;
@@ -387,7 +625,7 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
   __syncthreads();
   // -- samplePatch: bin t gathers its 16x16 pixel block in raster order
   {
-    const int rb = tid >> 5, cb = (tid >> 3) & 3, ob = tid & 7;
+    const int rb = tid >> 5, cb = (tid >> 3) & 3, ob = tid & 7, obm = (ob + 7) & 7;
     double acc = 0.0;
     double wcol[16];   // w1[c] for the first eight columns of the block, w0[c] for the last eight
 #pragma unroll
@@ -401,23 +639,21 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
       for (int seg = 0; seg < 4; seg++) {
         const int q = q0 + 4 * seg;
         const float4 vv = *reinterpret_cast<const float4 *>(bufA + q);
-        const float4 ov = *reinterpret_cast<const float4 *>(bufB + q);
+        const float4 w1v = *reinterpret_cast<const float4 *>(bufB + q);
+        const unsigned b4 = *reinterpret_cast<const unsigned *>(sb0 + q);
         const float vals[4] = {vv.x, vv.y, vv.z, vv.w};
-        const float os[4] = {ov.x, ov.y, ov.z, ov.w};
+        const float w1s[4] = {w1v.x, w1v.y, w1v.z, w1v.w};
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-          const float o = os[e];
-          const int bo0 = (int)o;
-          const int b0 = bo0 % 8;
-          const int b1 = (b0 + 1) & 7;
-          const float wo1 = o - (float)bo0;
-          const float wo0 = 1.0f - wo1;
+          const int b0 = (int)((b4 >> (8 * e)) & 0xff);
+          const float wo1 = w1s[e];
           const float wcv = (float)(wcol[4 * seg + e] * (double)vals[e]);
           const float v = wr * wcv;
-          if (v > 0) {
-            if (b0 == ob) acc += (double)(v * wo0);
-            else if (b1 == ob) acc += (double)(v * wo1);
-          }
+          // bin b0 takes v * wo0, bin (b0 + 1) % 8 takes v * wo1, nothing when v <= 0; a term that does not belong to
+          // this thread's bin is added as +0.0, which leaves the (non-negative) f64 accumulator as it is
+          const bool m0 = b0 == ob, m1 = b0 == obm;
+          const float t = v * (m0 ? 1.0f - wo1 : wo1);
+          acc += (double)(((m0 || m1) && v > 0) ? t : 0.f);
         }
       }
     }
@@ -489,6 +725,13 @@ void launch_patch_sample(hipStream_t s, const DescJob *jobs, const int *tilePref
                          const ImgRef *imgs, float *scratch) {
   if (nTiles <= 0) return;
   hipLaunchKernelGGL(k_patch_sample, dim3(nTiles), dim3(64), 0, s, jobs, tilePrefix, tileJob, imgs, scratch);
+}
+void launch_blur_lds(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
+                     const float *taps, const int *needTab, const float *src, float *dst, int pass) {
+  if (nTiles <= 0) return;
+  hipLaunchKernelGGL(k_expand_blur_tiles, dim3(nJobs), dim3(64), 0, s, jobs, tilePrefix, nJobs, needTab, tiles, pass);
+  if (pass == 0) hipLaunchKernelGGL(k_blur_rows_lds, dim3(nTiles), dim3(256), 0, s, tiles, taps, needTab, src, dst);
+  else hipLaunchKernelGGL(k_blur_cols_lds, dim3(nTiles), dim3(256), 0, s, tiles, taps, needTab, src, dst);
 }
 void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix, const int *tileJob, int nTiles,
                        const float *taps, const int *needTab, const float *src, float *dst, int pass) {
