@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out
       }
     }
     __syncthreads();
-    for (int p = lane; p < WW; p += 64) simg[p] = bilinear_tap(jb.blur, jb.rows, jb.cols, pa[p], pb[p], touch);
+    for (int p = lane; p < WW; p += 64) simg[p] = bilinear_tap(as_global(jb.blur), jb.rows, jb.cols, pa[p], pb[p], touch);
     __syncthreads();
     for (int p = lane; p < WW; p += 64) {
       const int r = p / W, c = p - r * W;

@@ -75,7 +75,28 @@ __global__ __launch_bounds__(64) void k_expand_blur_tiles(const DescJob *jobs, c
 // neighbouring samples of 4 rows per instruction), so that a gather touches a handful of cache lines instead of 64 and
 // every lane works even when the tile has few rows; the stores are row-contiguous.  Splitting long rows into column
 // tiles keeps the longest serial walk at SAMPLE_COLS steps instead of P (up to ~2000).
-constexpr int SAMPLE_COLS = 128, SAMPLE_C = 16, SAMPLE_CP = SAMPLE_C + 1;
+
+constexpr int SAMPLE_COLS = 128, SAMPLE_C = 16, SAMPLE_CP = SAMPLE_C + 1, SAMPLE_B = 8;
+
+// the taps of one parked chunk: SAMPLE_B samples (4 gathers each) are in flight per lane; the border branch of
+// interpolate() is hoisted out of the loop so that the loads of a batch can be issued together
+template <bool TOUCH>
+__device__ __forceinline__ void sample_chunk(const ImgRef &im, const float *cx, const float *cy, float *dst, int P, int tot, int nc,
+                                             int lane) {
+  for (int e0 = lane; e0 < tot; e0 += 64 * SAMPLE_B) {
+    float v[SAMPLE_B];
+#pragma unroll
+    for (int u = 0; u < SAMPLE_B; u++) {
+      const int e = e0 + 64 * u, r = e / SAMPLE_C, c = e - r * SAMPLE_C;
+      v[u] = (e < tot && c < nc) ? bilinear_tap(as_global(im.d), im.rows, im.cols, cx[r * SAMPLE_CP + c], cy[r * SAMPLE_CP + c], TOUCH) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < SAMPLE_B; u++) {
+      const int e = e0 + 64 * u, r = e / SAMPLE_C, c = e - r * SAMPLE_C;
+      if (e < tot && c < nc) dst[(size_t)r * P + c] = v[u];
+    }
+  }
+}
 
 __global__ __launch_bounds__(64) void k_patch_sample(const DescJob *jobs, const int *tilePrefix, const int *tileJob,
                                                      const ImgRef *imgs, float *scratch) {
@@ -117,12 +138,8 @@ __global__ __launch_bounds__(64) void k_patch_sample(const DescJob *jobs, const 
     }
     __syncthreads();
     const int tot = rowsHere * SAMPLE_C;
-#pragma unroll 4
-    for (int e = lane; e < tot; e += 64) {
-      const int r = e / SAMPLE_C, c = e - r * SAMPLE_C;
-      if (c < nc)
-        dst[(size_t)(row0 + r) * P + c0 + c] = bilinear_tap(im.d, im.rows, im.cols, cx[r * SAMPLE_CP + c], cy[r * SAMPLE_CP + c], touch);
-    }
+    if (!touch) sample_chunk<false>(im, cx, cy, dst + (size_t)row0 * P + c0, P, tot, nc, lane);
+    else sample_chunk<true>(im, cx, cy, dst + (size_t)row0 * P + c0, P, tot, nc, lane);
     __syncthreads();
   }
 }
@@ -539,7 +556,7 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
     for (int k = 0; k < PER_T; k++) {
       const int p = tid + 128 * k;
       const int r = p / PS, c = p - r * PS;
-      sv[k] = p < NPX ? bilinear_tap(src, srows, scols, bufA[r * PSP + c], bufB[r * PSP + c], touch) : 0.f;
+      sv[k] = p < NPX ? bilinear_tap(as_global(src), srows, scols, bufA[r * PSP + c], bufB[r * PSP + c], touch) : 0.f;
     }
     __syncthreads();   // every WY coordinate has been consumed; the samples may overwrite them
 #pragma unroll

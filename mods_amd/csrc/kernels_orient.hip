@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
     float *row = bufX + lane * PSP;
 #pragma unroll 4
     for (int i = 0; i < PS; i++) {
-      row[i] = bilinear_tap(im.d, im.rows, im.cols, WX, WY, touch);
+      row[i] = bilinear_tap(as_global(im.d), im.rows, im.cols, WX, WY, touch);
       WX += jb.a11;
       WY += jb.a21;
     }

@@ -116,23 +116,31 @@ MX_HD bool check_borders(int orig_w, int orig_h, float ofsx, float ofsy, float a
   return touch;
 }
 
+#ifdef __HIPCC__
+typedef const float __attribute__((address_space(1))) *gcfloat_p;
+MX_HD gcfloat_p as_global(const float *p) { return (gcfloat_p)p; }
+#endif
+
 // one bilinear sample of interpolate(), detectors/helpers.cpp:566-616.
 // touch = false: the (int) truncation branch; touch = true: floor + bounds branch (0 outside).
-MX_HD float bilinear_tap(const float *im, int rows, int cols, float WX, float WY, bool touch) {
+// PT is `const float *` or, in kernels, the same pointer cast to the global address space (as_global): image pointers
+// that come out of job tables are generic to the compiler, which would otherwise emit FLAT loads for every tap.
+template <class PT>
+MX_HD float bilinear_tap(PT im, int rows, int cols, float WX, float WY, bool touch) {
   if (!touch) {
     int x = (int)WX, y = (int)WY;
     // the reference would fault on NaN / far out-of-range coordinates; keep device loads in bounds
     x = x < 0 ? 0 : (x > cols - 2 ? cols - 2 : x);
     y = y < 0 ? 0 : (y > rows - 2 ? rows - 2 : y);
     const float wx = WX - (float)x;
-    const float *R0 = im + (size_t)y * cols, *R1 = R0 + cols;
+    const PT R0 = im + (size_t)y * cols, R1 = R0 + cols;
     const float I1 = wx * (R0[x + 1] - R0[x]) + R0[x];
     return (WY - (float)y) * (wx * (R1[x + 1] - R1[x]) + R1[x] - I1) + I1;
   }
   const int x = (int)floorf(WX), y = (int)floorf(WY);
   if (WX >= 0 && WY >= 0 && x < cols - 1 && y < rows - 1) {
     const float wx = WX - (float)x;
-    const float *R0 = im + (size_t)y * cols, *R1 = R0 + cols;
+    const PT R0 = im + (size_t)y * cols, R1 = R0 + cols;
     const float I1 = wx * (R0[x + 1] - R0[x]) + R0[x];
     return (WY - (float)y) * (wx * (R1[x + 1] - R1[x]) + R1[x] - I1) + I1;
   }
