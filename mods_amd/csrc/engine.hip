@@ -359,10 +359,12 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
     if (!c->nmsJobs.ensure(jobBytes + pfxBytes + 64)) return MODSX_ERR_NOMEM;
     MX_HIP(hipMemcpyAsync(c->nmsJobs.p, hjobs.data(), jobBytes, hipMemcpyHostToDevice, s));
     MX_HIP(hipMemcpyAsync((char *)c->nmsJobs.p + jobBytes, hpfx.data(), pfxBytes, hipMemcpyHostToDevice, s));
+    if (!c->tileJob.ensure((size_t)hpfx.back() * 4 + 4)) return MODSX_ERR_NOMEM;
+    launch_expand_tiles(s, (const int *)((char *)c->nmsJobs.p + jobBytes), nj, (int *)c->tileJob.p);
     {
       ProfScope ps(c, K_NMS, px * 12);
-      launch_nms(s, nb, (const NmsJob *)c->nmsJobs.p, (const int *)((char *)c->nmsJobs.p + jobBytes), nj, hpfx.back(),
-                 (Candidate *)c->cand.p, (unsigned *)c->counter.p, CAND_CAP);
+      launch_nms(s, nb, (const NmsJob *)c->nmsJobs.p, (const int *)((char *)c->nmsJobs.p + jobBytes), (const int *)c->tileJob.p, nj,
+                 hpfx.back(), (Candidate *)c->cand.p, (unsigned *)c->counter.p, CAND_CAP);
     }
     MX_HIP(hipStreamSynchronize(s));   // the host tables are reused by the next flush
     hjobs.clear(); hpfx.assign(1, 0); px = 0;
@@ -380,7 +382,7 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
         j.low = oc.resp[l - 1]; j.cur = oc.resp[l]; j.high = oc.resp[l + 1]; j.blur = oc.blur[l];
         j.rows = oc.rows; j.cols = oc.cols; j.img = i; j.octave = o; j.level = l; j.pad = 0;
         hjobs.push_back(j);
-        hpfx.push_back(hpfx.back() + ((w + 63) / 64) * ((h + 3) / 4));
+        hpfx.push_back(hpfx.back() + ((w + 63) / 64) * ((h + NMS_TILE_ROWS - 1) / NMS_TILE_ROWS));
         px += (double)oc.rows * oc.cols;
       }
     }
@@ -392,9 +394,11 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
     if (!c->nmsJobs.ensure(jobBytes + pfxBytes + 64)) return MODSX_ERR_NOMEM;
     MX_HIP(hipMemcpyAsync(c->nmsJobs.p, hjobs.data(), jobBytes, hipMemcpyHostToDevice, s));
     MX_HIP(hipMemcpyAsync((char *)c->nmsJobs.p + jobBytes, hpfx.data(), pfxBytes, hipMemcpyHostToDevice, s));
+    if (!c->tileJob.ensure((size_t)hpfx.back() * 4 + 4)) return MODSX_ERR_NOMEM;
+    launch_expand_tiles(s, (const int *)((char *)c->nmsJobs.p + jobBytes), nj, (int *)c->tileJob.p);
     ProfScope ps(c, K_NMS, px * 12);
-    launch_nms(s, nb, (const NmsJob *)c->nmsJobs.p, (const int *)((char *)c->nmsJobs.p + jobBytes), nj, hpfx.back(),
-               (Candidate *)c->cand.p, (unsigned *)c->counter.p, CAND_CAP);
+    launch_nms(s, nb, (const NmsJob *)c->nmsJobs.p, (const int *)((char *)c->nmsJobs.p + jobBytes), (const int *)c->tileJob.p, nj,
+               hpfx.back(), (Candidate *)c->cand.p, (unsigned *)c->counter.p, CAND_CAP);
   }
   if (!c->hMisc.ensure(64)) return MODSX_ERR_NOMEM;
   MX_HIP(hipMemcpyAsync(c->hMisc.p, c->counter.p, 4, hipMemcpyDeviceToHost, s));

@@ -158,8 +158,9 @@ void rectify(double &a11, double &a12, double &a21, double &a22);
 void launch_blur_hess(hipStream_t s, const BlurBatch &b, int nj, int maxRows, int maxCols);
 void launch_hessian(hipStream_t s, const BlurBatch &b, int nj, int maxRows, int maxCols);
 void launch_resize_half(hipStream_t s, const ResizeBatch &b, int nj, int maxRows, int maxCols);
-void launch_nms(hipStream_t s, const NmsBatch &b, const NmsJob *jobs, const int *tilePrefix, int nj, int nTiles, Candidate *out, unsigned *counter,
-                unsigned cap);
+void launch_nms(hipStream_t s, const NmsBatch &b, const NmsJob *jobs, const int *tilePrefix, const int *tileJob, int nj,
+                int nTiles, Candidate *out, unsigned *counter, unsigned cap);
+constexpr int NMS_TILE_ROWS = 16;   // rows of a 64-column NMS tile (kernels_pyramid.hip: NMS_ROWS)
 void launch_gray(hipStream_t s, const void *src, float *dst, size_t n, int channels, int dtype);
 void launch_baumberg(hipStream_t s, const AffJob *jobs, AffOut *out, int n, const float *mask, int W, int maxIter,
                      float convTh, float affInitialSigma);

@@ -193,34 +193,17 @@ MX_D bool is_min9(float val, const float *p, int cols) {
   return ok;
 }
 
-// One launch scans every (image, octave, level) of a batch: the 64 x 4 pixel tiles of all jobs are numbered
-// consecutively (tilePrefix) and a workgroup finds its job by a binary search in LDS.  A candidate's path is a chain of
-// ~10 dependent memory round trips (3 x 9-neighbour tests, <= 5 Newton steps), which is what a launch lasts however few
-// pixels it covers -- hence one launch instead of one per octave.
-__global__ __launch_bounds__(256) void k_nms_localize(NmsBatch batch, const NmsJob *jobs, const int *tilePrefix, int nj,
-                                                      Candidate *out, unsigned *counter, unsigned cap) {
-  __shared__ int spfx[NMS_MAXJ + 1];
-  for (int i = threadIdx.x; i <= nj; i += 256) spfx[i] = tilePrefix[i];
-  __syncthreads();
-  const int tile = blockIdx.x;
-  int lo = 0, hi = nj - 1;
-  while (lo < hi) {   // last job whose first tile is <= tile
-    const int mid = (lo + hi + 1) >> 1;
-    if (spfx[mid] <= tile) lo = mid; else hi = mid - 1;
-  }
-  const NmsJob jb = jobs[lo];
-  const int rows = jb.rows, cols = jb.cols, B = batch.border;
-  const int local = tile - spfx[lo];
-  const int tilesX = (cols - 2 * B + 63) / 64;
-  const int by = local / tilesX, bx = local - by * tilesX;
-  int c = B + bx * 64 + (threadIdx.x & 63), r = B + by * 4 + (threadIdx.x >> 6);
-  if (r >= rows - B || c >= cols - B) return;
-  const size_t off = (size_t)r * cols + c;
-  const float v0 = jb.cur[off];
-  bool cand = false;
-  if (v0 > batch.posTh) cand = is_max9(v0, jb.cur + off, cols) && is_max9(v0, jb.low + off, cols) && is_max9(v0, jb.high + off, cols);
-  else if (v0 < batch.negTh) cand = is_min9(v0, jb.cur + off, cols) && is_min9(v0, jb.low + off, cols) && is_min9(v0, jb.high + off, cols);
-  if (!cand) return;
+// One launch scans every (image, octave, level) of a batch: the 64 x NMS_ROWS pixel tiles of all jobs are numbered
+// consecutively (tilePrefix, expanded to a tile -> job table once per launch).  A candidate's path is a chain of ~10
+// dependent memory round trips (3 x 9-neighbour tests, <= 5 Newton steps), which is what a launch lasts however few
+// pixels it covers -- hence one launch instead of one per octave.  Nearly every pixel fails the threshold test on its own
+// value, so the scan is a stream over the response planes: a thread first loads its NMS_ROWS / 4 pixels (independent
+// loads), then follows up the few that pass.
+constexpr int NMS_ROWS = 16, NMS_LW = 66;
+
+// sub-pixel localisation of one 3x3x3 extremum (pyramid.cpp:341-419): <= 5 Newton steps, edge / value tests, record
+MX_D void nms_refine(const NmsBatch &batch, const NmsJob &jb, int r, int c, Candidate *out, unsigned *counter, unsigned cap) {
+  const int rows = jb.rows, cols = jb.cols;
   const int r0 = r, c0 = c;
   float b[3] = {0.f, 0.f, 0.f};
   float val = 0.f;
@@ -271,6 +254,76 @@ __global__ __launch_bounds__(256) void k_nms_localize(NmsBatch batch, const NmsJ
   out[slot] = k;
 }
 
+__global__ __launch_bounds__(256) void k_nms_localize(NmsBatch batch, const NmsJob *__restrict__ jobs,
+                                                      const int *__restrict__ tilePrefix, const int *__restrict__ tileJob,
+                                                      Candidate *out, unsigned *counter, unsigned cap) {
+  const int tile = blockIdx.x;
+  const int jid = tileJob[tile];
+  const NmsJob jb = jobs[jid];
+  const int rows = jb.rows, cols = jb.cols, B = batch.border;
+  const int local = tile - tilePrefix[jid];
+  const int tilesX = (cols - 2 * B + 63) / 64;
+  const int by = local / tilesX, bx = local - by * tilesX;
+  const int r0 = B + by * NMS_ROWS, c0 = B + bx * 64;   // first pixel of the tile
+  // the tile and a one-pixel halo of the three response planes: LDS row i = image row r0 - 1 + i, column likewise
+  __shared__ float sp[3][NMS_ROWS + 2][NMS_LW];
+  {
+    const float *planes[3] = {jb.cur, jb.low, jb.high};
+    constexpr int NE = (NMS_ROWS + 2) * NMS_LW, PER = (NE + 255) / 256;
+    float t[3][PER];
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+      for (int u = 0; u < PER; u++) {
+        const int idx = threadIdx.x + 256 * u, rr = idx / NMS_LW, cc = idx - rr * NMS_LW;
+        int gr = r0 - 1 + rr, gc = c0 - 1 + cc;
+        gr = gr < 0 ? 0 : (gr > rows - 1 ? rows - 1 : gr);     // clamped positions are never part of a tested neighbourhood
+        gc = gc < 0 ? 0 : (gc > cols - 1 ? cols - 1 : gc);
+        t[pl][u] = idx < NE ? planes[pl][(size_t)gr * cols + gc] : 0.f;
+      }
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+      for (int u = 0; u < PER; u++) {
+        const int idx = threadIdx.x + 256 * u;
+        if (idx < NE) (&sp[pl][0][0])[idx] = t[pl][u];
+      }
+  }
+  __syncthreads();
+  // thread (lc, g) tests rows 4g .. 4g+3 of column lc.  `!(x > v0)` for the 27 values of the 3x3x3 block is max <= v0
+  // (v_max / v_min skip NaNs exactly like the failed comparisons do), and the 3x3 maxima of four consecutive rows share
+  // their row maxima, so a pixel costs ~35 VALU operations and no divergent loads.
+  const int lc = threadIdx.x & 63, g = threadIdx.x >> 6;
+  float mx[4], mn[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) { mx[j] = -INFINITY; mn[j] = INFINITY; }
+#pragma unroll
+  for (int pl = 0; pl < 3; pl++) {
+    float hmax[6], hmin[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const float a = sp[pl][4 * g + k][lc], b = sp[pl][4 * g + k][lc + 1], d = sp[pl][4 * g + k][lc + 2];
+      hmax[k] = fmaxf(fmaxf(a, b), d);
+      hmin[k] = fminf(fminf(a, b), d);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      mx[j] = fmaxf(mx[j], fmaxf(fmaxf(hmax[j], hmax[j + 1]), hmax[j + 2]));
+      mn[j] = fminf(mn[j], fminf(fminf(hmin[j], hmin[j + 1]), hmin[j + 2]));
+    }
+  }
+  const int c = c0 + lc;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int r = r0 + 4 * g + j;
+    const float v0 = sp[0][4 * g + j + 1][lc + 1];
+    bool cand = false;
+    if (v0 > batch.posTh) cand = mx[j] <= v0;
+    else if (v0 < batch.negTh) cand = mn[j] >= v0;
+    if (cand && r < rows - B && c < cols - B) nms_refine(batch, jb, r, c, out, counter, cap);
+  }
+}
+
 // (B+G+R)/3 of GenerateSynthImageCorr (synth-detection.cpp:253-262): a cv::MatExpr that OpenCV
 // evaluates as addWeighted(B+G, 1/3., R, 1/3., 0) in f64 for CV_32F.
 __global__ void k_gray_u8(const uint8_t *src, float *dst, size_t n, int channels) {
@@ -311,10 +364,10 @@ void launch_resize_half(hipStream_t s, const ResizeBatch &b, int nj, int maxRows
   dim3 grid((maxCols + 63) / 64, (maxRows + 3) / 4, nj);
   hipLaunchKernelGGL(k_resize_half, grid, dim3(256), 0, s, b);
 }
-void launch_nms(hipStream_t s, const NmsBatch &b, const NmsJob *jobs, const int *tilePrefix, int nj, int nTiles, Candidate *out,
-                unsigned *counter, unsigned cap) {
+void launch_nms(hipStream_t s, const NmsBatch &b, const NmsJob *jobs, const int *tilePrefix, const int *tileJob, int nj,
+                int nTiles, Candidate *out, unsigned *counter, unsigned cap) {
   if (nj <= 0 || nTiles <= 0) return;
-  hipLaunchKernelGGL(k_nms_localize, dim3(nTiles), dim3(256), 0, s, b, jobs, tilePrefix, nj, out, counter, cap);
+  hipLaunchKernelGGL(k_nms_localize, dim3(nTiles), dim3(256), 0, s, b, jobs, tilePrefix, tileJob, out, counter, cap);
 }
 // *ptr = (unsigned char)*in_ptr of DetectMSERs (extrema.cpp:401-403): f32 -> u8 by truncation, 4 pixels per thread
 __global__ void k_trunc_u8(const float *src, uint8_t *dst, size_t n) {
