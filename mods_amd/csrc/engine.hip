@@ -165,7 +165,7 @@ void ctx_destroy(modsx_ctx *c) {
   for (int i = 0; i < MAXB; i++) c->pyr[i].store.release();
   DevBuf *bufs[] = {&c->nmsJobs, &c->cand, &c->counter, &c->affJobs, &c->affOut, &c->oriJobs, &c->oriOut, &c->descJobs, &c->tilePrefix,
                     &c->taps, &c->imgRefs, &c->scratchA, &c->scratchB, &c->descAllF[0], &c->descAllF[1], &c->descAllU8[0],
-                    &c->descAllU8[1], &c->descAllU8b[0], &c->descAllU8b[1], &c->pos2, &c->matchRows, &c->matchWork, &c->misc, &c->scratchC, &c->needTab, &c->coordTab, &c->tileJob, &c->blurTiles, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps};
+                    &c->descAllU8[1], &c->descAllU8b[0], &c->descAllU8b[1], &c->pos2, &c->matchRows, &c->matchWork, &c->misc, &c->scratchC, &c->needTab, &c->coordTab, &c->tileJob, &c->blurTiles, &c->nmsQueue, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps};
   for (DevBuf *b : bufs) b->release();
   for (int i = 0; i < MAXB; i++) { c->descF[i].release(); c->descU8[i].release(); }
   PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc};
@@ -333,8 +333,8 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
   int rc = build_pyramids(c, imgs, n, p, false);
   if (rc) return rc;
   hipStream_t s = c->stream;
-  if (!c->cand.ensure((size_t)CAND_CAP * sizeof(Candidate))) return MODSX_ERR_NOMEM;
-  if (!c->counter.ensure(64)) return MODSX_ERR_NOMEM;
+  if (!c->cand.ensure((size_t)CAND_CAP * sizeof(Candidate)) || !c->nmsQueue.ensure((size_t)CAND_CAP * 16)) return MODSX_ERR_NOMEM;
+  if (!c->counter.ensure((NMS_QUEUES + 1) * 128)) return MODSX_ERR_NOMEM;
   MX_HIP(hipMemsetAsync(c->counter.p, 0, 4, s));
   // thresholds, affinedetectors/pyramid.h:47-67 (DET_HESSIAN)
   NmsBatch nb;
@@ -363,8 +363,10 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
     launch_expand_tiles(s, (const int *)((char *)c->nmsJobs.p + jobBytes), nj, (int *)c->tileJob.p);
     {
       ProfScope ps(c, K_NMS, px * 12);
+      MX_HIP(hipMemsetAsync((unsigned *)c->counter.p + 32, 0, NMS_QUEUES * 128, s));
       launch_nms(s, nb, (const NmsJob *)c->nmsJobs.p, (const int *)((char *)c->nmsJobs.p + jobBytes), (const int *)c->tileJob.p, nj,
-                 hpfx.back(), (Candidate *)c->cand.p, (unsigned *)c->counter.p, CAND_CAP);
+                 hpfx.back(), (int4 *)c->nmsQueue.p, (unsigned *)c->counter.p + 32, CAND_CAP, (Candidate *)c->cand.p,
+                 (unsigned *)c->counter.p, CAND_CAP);
     }
     MX_HIP(hipStreamSynchronize(s));   // the host tables are reused by the next flush
     hjobs.clear(); hpfx.assign(1, 0); px = 0;
@@ -397,8 +399,10 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
     if (!c->tileJob.ensure((size_t)hpfx.back() * 4 + 4)) return MODSX_ERR_NOMEM;
     launch_expand_tiles(s, (const int *)((char *)c->nmsJobs.p + jobBytes), nj, (int *)c->tileJob.p);
     ProfScope ps(c, K_NMS, px * 12);
+    MX_HIP(hipMemsetAsync((unsigned *)c->counter.p + 32, 0, NMS_QUEUES * 128, s));
     launch_nms(s, nb, (const NmsJob *)c->nmsJobs.p, (const int *)((char *)c->nmsJobs.p + jobBytes), (const int *)c->tileJob.p, nj,
-               hpfx.back(), (Candidate *)c->cand.p, (unsigned *)c->counter.p, CAND_CAP);
+               hpfx.back(), (int4 *)c->nmsQueue.p, (unsigned *)c->counter.p + 32, CAND_CAP, (Candidate *)c->cand.p,
+               (unsigned *)c->counter.p, CAND_CAP);
   }
   if (!c->hMisc.ensure(64)) return MODSX_ERR_NOMEM;
   MX_HIP(hipMemcpyAsync(c->hMisc.p, c->counter.p, 4, hipMemcpyDeviceToHost, s));

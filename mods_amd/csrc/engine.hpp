@@ -159,7 +159,8 @@ void launch_blur_hess(hipStream_t s, const BlurBatch &b, int nj, int maxRows, in
 void launch_hessian(hipStream_t s, const BlurBatch &b, int nj, int maxRows, int maxCols);
 void launch_resize_half(hipStream_t s, const ResizeBatch &b, int nj, int maxRows, int maxCols);
 void launch_nms(hipStream_t s, const NmsBatch &b, const NmsJob *jobs, const int *tilePrefix, const int *tileJob, int nj,
-                int nTiles, Candidate *out, unsigned *counter, unsigned cap);
+                int nTiles, int4 *queue, unsigned *qcount, unsigned qcap, Candidate *out, unsigned *counter, unsigned cap);
+constexpr int NMS_QUEUES = 64;      // sub-queues of the NMS extremum queue; counter k lives at counter[32 * (k + 1)]
 constexpr int NMS_TILE_ROWS = 16;   // rows of a 64-column NMS tile (kernels_pyramid.hip: NMS_ROWS)
 void launch_gray(hipStream_t s, const void *src, float *dst, size_t n, int channels, int dtype);
 void launch_baumberg(hipStream_t s, const AffJob *jobs, AffOut *out, int n, const float *mask, int W, int maxIter,
@@ -211,7 +212,7 @@ struct modsx_ctx {
   hipStream_t stream;
   mx::Pyramid pyr[mx::MAXB];
   mx::DevBuf nmsJobs, cand, counter, affJobs, affOut, oriJobs, oriOut, descJobs, tilePrefix, taps, imgRefs, scratchA, scratchB,
-      descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], descAllU8b[2], pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps, scratchC, needTab, coordTab, tileJob, blurTiles;
+      descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], descAllU8b[2], pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps, scratchC, needTab, coordTab, tileJob, blurTiles, nmsQueue;
   mx::PinBuf hCand, hAff, hOri, hDesc, hMisc;
   // constant tables on device
   float *dSmmMask = nullptr;   // 19x19 computeGaussMask

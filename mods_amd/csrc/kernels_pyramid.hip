@@ -199,7 +199,7 @@ MX_D bool is_min9(float val, const float *p, int cols) {
 // pixels it covers -- hence one launch instead of one per octave.  Nearly every pixel fails the threshold test on its own
 // value, so the scan is a stream over the response planes: a thread first loads its NMS_ROWS / 4 pixels (independent
 // loads), then follows up the few that pass.
-constexpr int NMS_ROWS = 16, NMS_LW = 66;
+constexpr int NMS_ROWS = 16, NMS_LW = 66, NMS_REFINE_BLOCKS = 16;   // refine blocks per sub-queue
 
 // sub-pixel localisation of one 3x3x3 extremum (pyramid.cpp:341-419): <= 5 Newton steps, edge / value tests, record
 MX_D void nms_refine(const NmsBatch &batch, const NmsJob &jb, int r, int c, Candidate *out, unsigned *counter, unsigned cap) {
@@ -256,7 +256,7 @@ MX_D void nms_refine(const NmsBatch &batch, const NmsJob &jb, int r, int c, Cand
 
 __global__ __launch_bounds__(256) void k_nms_localize(NmsBatch batch, const NmsJob *__restrict__ jobs,
                                                       const int *__restrict__ tilePrefix, const int *__restrict__ tileJob,
-                                                      Candidate *out, unsigned *counter, unsigned cap) {
+                                                      int4 *queue, unsigned *qcount, unsigned qcap) {
   const int tile = blockIdx.x;
   const int jid = tileJob[tile];
   const NmsJob jb = jobs[jid];
@@ -313,6 +313,13 @@ __global__ __launch_bounds__(256) void k_nms_localize(NmsBatch batch, const NmsJ
     }
   }
   const int c = c0 + lc;
+  // the tile's extrema are queued with ONE global atomic per workgroup (slots within the tile come from an LDS counter),
+  // and the queue is split into NMS_QUEUES sub-queues with counters 128 bytes apart: atomics on one address are served
+  // one after the other and would cost more than the scan itself
+  __shared__ unsigned scount, sbase;
+  if (threadIdx.x == 0) scount = 0;
+  __syncthreads();
+  unsigned slot[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int r = r0 + 4 * g + j;
@@ -320,8 +327,15 @@ __global__ __launch_bounds__(256) void k_nms_localize(NmsBatch batch, const NmsJ
     bool cand = false;
     if (v0 > batch.posTh) cand = mx[j] <= v0;
     else if (v0 < batch.negTh) cand = mn[j] >= v0;
-    if (cand && r < rows - B && c < cols - B) nms_refine(batch, jb, r, c, out, counter, cap);
+    slot[j] = (cand && r < rows - B && c < cols - B) ? atomicAdd(&scount, 1u) : 0xffffffffu;
   }
+  __syncthreads();
+  const unsigned sq = blockIdx.x % NMS_QUEUES, qsub = qcap / NMS_QUEUES;
+  if (threadIdx.x == 0) sbase = scount ? atomicAdd(qcount + 32 * sq, scount) : 0u;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    if (slot[j] != 0xffffffffu && sbase + slot[j] < qsub) queue[(size_t)sq * qsub + sbase + slot[j]] = make_int4(jid, r0 + 4 * g + j, c, 0);
 }
 
 // (B+G+R)/3 of GenerateSynthImageCorr (synth-detection.cpp:253-262): a cv::MatExpr that OpenCV
@@ -364,10 +378,27 @@ void launch_resize_half(hipStream_t s, const ResizeBatch &b, int nj, int maxRows
   dim3 grid((maxCols + 63) / 64, (maxRows + 3) / 4, nj);
   hipLaunchKernelGGL(k_resize_half, grid, dim3(256), 0, s, b);
 }
+
+// The extrema found by the scan are few and scattered (about one per wavefront), and each needs a chain of ~10 dependent
+// round trips: run inside the scan they would hold nearly every wavefront for the whole chain with one lane working.
+// The scan therefore only queues (job, row, column); this kernel refines one queued extremum per lane.
+__global__ __launch_bounds__(256) void k_nms_refine(NmsBatch batch, const NmsJob *__restrict__ jobs, const int4 *__restrict__ queue,
+                                                    const unsigned *__restrict__ qcount, unsigned qcap, Candidate *out,
+                                                    unsigned *counter, unsigned cap) {
+  const unsigned sq = blockIdx.y, qsub = qcap / NMS_QUEUES;
+  unsigned n = qcount[32 * sq];
+  n = n < qsub ? n : qsub;
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int4 q = queue[(size_t)sq * qsub + i];
+    nms_refine(batch, jobs[q.x], q.y, q.z, out, counter, cap);
+  }
+}
+
 void launch_nms(hipStream_t s, const NmsBatch &b, const NmsJob *jobs, const int *tilePrefix, const int *tileJob, int nj,
-                int nTiles, Candidate *out, unsigned *counter, unsigned cap) {
+                int nTiles, int4 *queue, unsigned *qcount, unsigned qcap, Candidate *out, unsigned *counter, unsigned cap) {
   if (nj <= 0 || nTiles <= 0) return;
-  hipLaunchKernelGGL(k_nms_localize, dim3(nTiles), dim3(256), 0, s, b, jobs, tilePrefix, tileJob, out, counter, cap);
+  hipLaunchKernelGGL(k_nms_localize, dim3(nTiles), dim3(256), 0, s, b, jobs, tilePrefix, tileJob, queue, qcount, qcap);
+  hipLaunchKernelGGL(k_nms_refine, dim3(NMS_REFINE_BLOCKS, NMS_QUEUES), dim3(256), 0, s, b, jobs, queue, qcount, qcap, out, counter, cap);
 }
 // *ptr = (unsigned char)*in_ptr of DetectMSERs (extrema.cpp:401-403): f32 -> u8 by truncation, 4 pixels per thread
 __global__ void k_trunc_u8(const float *src, uint8_t *dst, size_t n) {
