@@ -73,28 +73,34 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
     wreg[q] = w; breg[q] = bin;
   }
   __syncthreads();
+  // Only pixels inside the circular mask with a gradient above 1 vote (typically ~60 % of the 44 x 41 padded grid), so
+  // the (bin, weight) pairs are first compacted IN RASTER ORDER: pixel p = lane + 64 q, so chunk q precedes chunk q + 1
+  // and within a chunk lanes are ordered -- a ballot prefix keeps the order.
+  int nv = 0;   // wave-uniform
 #pragma unroll
   for (int q = 0; q < PER_L; q++) {
-    const int p = lane + 64 * q;
-    if (p < PS * PSP) { bufX[p] = wreg[q]; sbin[p] = breg[q]; }
+    const bool valid = breg[q] != 255;
+    const unsigned long long m = __ballot(valid);
+    const int pos = nv + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    if (valid) { bufX[pos] = wreg[q]; sbin[pos] = breg[q]; }
+    nv += __popcll(m);
   }
+  if (lane < 4) { bufX[nv + lane] = 0.f; sbin[nv + lane] = 255; }   // pad the last group of four
   __syncthreads();
   // lane b owns histogram bin b and adds its pixels in raster order (f32 running sum of the reference)
   if (lane < 36) {
     float h = 0.f;
-#pragma unroll 1
-    for (int r = 1; r < PS - 1; r++) {
-      const unsigned *b4 = reinterpret_cast<const unsigned *>(sbin + r * PSP);
-      const float4 *w4 = reinterpret_cast<const float4 *>(bufX + r * PSP);
-#pragma unroll
-      for (int g = 0; g < PSP / 4; g++) {
-        const unsigned b = b4[g];
-        const float4 w = w4[g];
-        if ((int)(b & 0xff) == lane) h += w.x;
-        if ((int)((b >> 8) & 0xff) == lane) h += w.y;
-        if ((int)((b >> 16) & 0xff) == lane) h += w.z;
-        if ((int)(b >> 24) == lane) h += w.w;
-      }
+    const unsigned *b4 = reinterpret_cast<const unsigned *>(sbin);
+    const float4 *w4 = reinterpret_cast<const float4 *>(bufX);
+    const int ng = (nv + 3) >> 2;
+#pragma unroll 4
+    for (int g = 0; g < ng; g++) {
+      const unsigned b = b4[g];
+      const float4 w = w4[g];
+      if ((int)(b & 0xff) == lane) h += w.x;
+      if ((int)((b >> 8) & 0xff) == lane) h += w.y;
+      if ((int)((b >> 16) & 0xff) == lane) h += w.z;
+      if ((int)(b >> 24) == lane) h += w.w;
     }
     hist[lane] = h;
   }

@@ -13,27 +13,29 @@
 
 namespace mx {
 
-// atan2LUTff, detectors/helpers.cpp:160-207; L = 256-entry f64 table (:30-72)
+// atan2LUTff, detectors/helpers.cpp:160-207; L = 256-entry f64 table (:30-72).
+// The reference is an eight-way branch on the signs of x, y and on |x| > |y|; every branch looks up
+// L[(int)(255.f * small / big)] and returns (float)(c +- L) with c in {0, +-pi/2, +-pi} (f32 constants widened to f64).
+// Written without branches -- one division, one look-up, selects -- because the eight paths of a wavefront would
+// otherwise run one after the other.  (float)(-L) and (float)(L) are kept as plain negation / identity so that the sign
+// of a zero result is the reference's.
 MX_HD float atan2lut(const double *L, float y, float x) {
   const float PI_2f = 1.57079632679489661923f, PIf = 3.14159265358979323846f;
-  if (x > 0.f) {
-    if (y > 0.f) {
-      if (x > y) return (float)L[(int)(255.f * y / x)];
-      return (float)((double)PI_2f - L[(int)(255.f * x / y)]);
-    }
-    float ay = fabsf(y);
-    if (x > ay) return (float)(-L[(int)(255.f * ay / x)]);
-    return (float)((double)(-PI_2f) + L[(int)(255.f * x / ay)]);
-  }
-  if (y > 0.f) {
-    float ax = fabsf(x);
-    if (ax > y) return (float)((double)PIf - L[(int)(255.f * y / ax)]);
-    return (float)((double)PI_2f + L[(int)(255.f * ax / y)]);
-  }
-  float ax = fabsf(x), ay = fabsf(y);
-  if (ax > ay) return (float)((double)(-PIf) + L[(int)(255.f * ay / ax)]);
-  if (x == 0.f) return 0.f;
-  return (float)((double)(-PI_2f) - L[(int)(255.f * ax / ay)]);
+  const float ax = fabsf(x), ay = fabsf(y);
+  const bool xp = x > 0.f, yp = y > 0.f, big = ax > ay;
+  const float num = big ? ay : ax, den = big ? ax : ay;
+  const float q = 255.f * num / den;           // NaN only for x = y = 0, which returns 0 below
+  int idx = (int)q;
+  idx = idx < 0 ? 0 : (idx > 255 ? 255 : idx);
+  const double Lv = L[idx];
+  // x>0,y>0: L | pi/2 - L      x>0,y<=0: -L | -pi/2 + L      x<=0,y>0: pi - L | pi/2 + L      x<=0,y<=0: -pi + L | -pi/2 - L
+  const bool neg = xp ? (yp ? !big : big) : (yp ? big : !big);
+  const double sL = neg ? -Lv : Lv;
+  double c;
+  if (big) c = xp ? 0.0 : (yp ? (double)PIf : (double)(-PIf));
+  else c = yp ? (double)PI_2f : (double)(-PI_2f);
+  const float r = (big && xp) ? (float)sL : (float)(c + sL);
+  return (!xp && !yp && !big && x == 0.f) ? 0.f : r;
 }
 
 // solveLinear3x3, detectors/helpers.cpp:309-368
