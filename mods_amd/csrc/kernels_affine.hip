@@ -13,8 +13,12 @@ namespace mx {
 
 constexpr int AW_MAX = 19;
 
-__global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out, int n, const float *mask, int W,
+// WT = window size when known at compile time (19, the default smmWindowSize), 0 = use the argument: the row / column of a
+// pixel is an integer division by W in three loops of every iteration, ~25 instructions each unless W is a constant
+template <int WT>
+__global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out, int n, const float *mask, int Warg,
                                                  int maxIter, float convTh, float affInitialSigma) {
+  const int W = WT ? WT : Warg;
   const int k = blockIdx.x;
   if (k >= n) return;
   const int lane = threadIdx.x;
@@ -103,7 +107,8 @@ __global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out
 void launch_baumberg(hipStream_t s, const AffJob *jobs, AffOut *out, int n, const float *mask, int W, int maxIter,
                      float convTh, float affInitialSigma) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_baumberg, dim3(n), dim3(64), 0, s, jobs, out, n, mask, W, maxIter, convTh, affInitialSigma);
+  if (W == 19) hipLaunchKernelGGL(k_baumberg<19>, dim3(n), dim3(64), 0, s, jobs, out, n, mask, W, maxIter, convTh, affInitialSigma);
+  else hipLaunchKernelGGL(k_baumberg<0>, dim3(n), dim3(64), 0, s, jobs, out, n, mask, W, maxIter, convTh, affInitialSigma);
 }
 
 }  // namespace mx
