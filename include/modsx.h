@@ -366,8 +366,8 @@ int modsx_load_regions(const char *path, const char *det_name, const char *desc_
 /* Measurement hooks (no reference counterpart; the reference only keeps wall-clock TimeLog, structures.hpp:51-74).
  * modsx_profile(ctx, 1) brackets every kernel launch with HIP events on the ctx stream and accumulates, per kernel
  * class, GPU milliseconds, launch count and algorithmic work (bytes; flops for the matcher).  Classes in order:
- * blur_hess, hessian, resize, nms_localize, baumberg, orientation, patch_sample, patch_blur, describe, match_fginn,
- * gray, warp_affine, view_blur.  modsx_kernel_stats returns the number of classes. */
+ * blur_hess, hessian, resize, nms_localize (scan + refine), baumberg, orientation, patch_sample, blur_rows, describe,
+ * match_fginn, gray, warp_affine, view_blur, blur_cols.  modsx_kernel_stats returns the number of classes. */
 int modsx_profile(modsx_ctx *ctx, int enable);
 int modsx_kernel_stats(modsx_ctx *ctx, double *ms, double *work, long *launches, int n);
 

@@ -94,7 +94,7 @@ EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "m
            "modsx_kernel_stats"]
 
 KERNEL_CLASSES = ["blur_hess", "hessian", "resize", "nms_localize", "baumberg", "orientation", "patch_sample",
-                  "patch_blur", "describe", "match_fginn", "gray", "warp_affine", "view_blur"]
+                  "blur_rows", "describe", "match_fginn", "gray", "warp_affine", "view_blur", "blur_cols"]
 
 
 def build(force=False):

@@ -797,7 +797,8 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
               pi.coordOfs = (int)coordTab.size();
               coordTab.insert(coordTab.end(), W, W + 41);
               {  // tile shapes of the LDS blur kernels: <= BLUR_OUT outputs and <= BLUR_LDS floats per workgroup
-                const int BLUR_LDS = 4992, R = pi.ksize >> 1, cap = 2048 / (2 * ((pi.NC + 1) / 2));
+                const int BLUR_LDS = 4992, BLUR_LDS_C = 9984, R = pi.ksize >> 1, NP2 = 2 * ((pi.NC + 1) / 2);
+                const int cap = 2048 / NP2, capC = 4096 / NP2;
                 // the row filter pairs needed columns (2m, 2m+1); they are neighbours in the window by construction
                 // (x0, x0 + 1 of one sample, or a contiguous range) -- if ever not, the job takes the global-memory kernel
                 bool pairs = true;
@@ -806,10 +807,10 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
                 if (pi.rows0 < 2) pi.rows0 = 0;
                 pi.ro1 = 0;
                 const int LS = pi.NC <= 64 ? 64 : 96;   // LDS row stride of the column filter
-                for (int ro = std::min(cap, pi.NC); ro >= 2 && !pi.ro1 && pi.NC <= 96; ro--) {
+                for (int ro = std::min(capC, pi.NC); ro >= 2 && !pi.ro1 && pi.NC <= 96; ro--) {
                   int span = 0;
                   for (int a = 0; a < pi.NC; a += ro) span = std::max(span, need[std::min(a + ro, pi.NC) - 1] - need[a] + 2 * R + 1);
-                  if (span * LS <= BLUR_LDS) pi.ro1 = ro;
+                  if (span * LS <= BLUR_LDS_C) pi.ro1 = ro;
                 }
               }
               it = pinfo.insert({P, pi}).first;
@@ -875,12 +876,12 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       launch_expand_tiles(s, dPfxC, (int)nj, tjC);
       { ProfScope ps(c, K_PATCH_SAMPLE, (double)arenaA * 8);
         launch_patch_sample(s, dj, dPfxS, tjS, pfxSample.back(), (ImgRef *)c->imgRefs.p, (float *)c->scratchA.p); }
-      { ProfScope ps(c, K_PATCH_BLUR, ((double)arenaA + arenaB) * 4);
+      { ProfScope ps(c, K_BLUR_ROWS, ((double)arenaA + arenaB) * 4);
         launch_blur_lds(s, dj, dPfxRL, (int)nj, btR, pfxRowL.back(), (float *)c->taps.p, (int *)c->needTab.p, (float *)c->scratchA.p,
                         (float *)c->scratchB.p, 0);
         launch_patch_blur(s, dj, dPfxR, tjR, pfxRow.back(), (float *)c->taps.p, (int *)c->needTab.p, (float *)c->scratchA.p,
                           (float *)c->scratchB.p, 0); }
-      { ProfScope ps(c, K_PATCH_BLUR, ((double)arenaB + arenaC) * 4);
+      { ProfScope ps(c, K_BLUR_COLS, ((double)arenaB + arenaC) * 4);
         launch_blur_lds(s, dj, dPfxCL, (int)nj, btC, pfxColL.back(), (float *)c->taps.p, (int *)c->needTab.p, (float *)c->scratchB.p,
                         (float *)c->scratchC.p, 1);
         launch_patch_blur(s, dj, dPfxC, tjC, pfxCol.back(), (float *)c->taps.p, (int *)c->needTab.p, (float *)c->scratchB.p,

@@ -188,8 +188,8 @@ void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, i
 }  // namespace mx
 
 namespace mx {
-enum KClass { K_BLUR_HESS = 0, K_HESSIAN, K_RESIZE, K_NMS, K_BAUMBERG, K_ORIENT, K_PATCH_SAMPLE, K_PATCH_BLUR, K_DESCRIBE,
-              K_MATCH, K_GRAY, K_WARP, K_VIEW_BLUR, K_NCLASS };
+enum KClass { K_BLUR_HESS = 0, K_HESSIAN, K_RESIZE, K_NMS, K_BAUMBERG, K_ORIENT, K_PATCH_SAMPLE, K_BLUR_ROWS, K_DESCRIBE,
+              K_MATCH, K_GRAY, K_WARP, K_VIEW_BLUR, K_BLUR_COLS, K_NCLASS };
 struct Profiler {
   bool enabled = false;
   std::vector<hipEvent_t> evA, evB;

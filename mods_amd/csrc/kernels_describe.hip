@@ -268,9 +268,11 @@ __global__ __launch_bounds__(256) void k_patch_blur(const DescJob *jobs, const i
 //   rows:  a tile is jb.rows0 consecutive window rows, each stored as R + P + R floats
 //   cols:  a tile is jb.ro1 consecutive needed rows; it parks the source rows need[first] - R .. need[last] + R
 // Jobs whose tile does not fit BLUR_LDS floats have rows0 / ro1 = 0 and go through k_patch_blur.
-constexpr int BLUR_LDS = 4992, BLUR_OUT = 2048, FILL_MLP = 20;   // 20 KB: 8 workgroups (the wave limit) per CU
+constexpr int BLUR_T = 256, BLUR_W = BLUR_T / 64;   // threads / waves per workgroup of the LDS blur kernels
+constexpr int BLUR_LDS = 4992, BLUR_OUT = 2048, FILL_MLP = 20;   // row filter: 20 KB, 8 workgroups per CU
+constexpr int BLUR_LDS_C = 9984;                               // column filter: fatter tiles re-read fewer halo rows
 
-__global__ __launch_bounds__(256, 8) void k_blur_rows_lds(const BlurTile *__restrict__ tiles, const float *__restrict__ taps,
+__global__ __launch_bounds__(BLUR_T, 8) void k_blur_rows_lds(const BlurTile *__restrict__ tiles, const float *__restrict__ taps,
                                                        const int *__restrict__ needTab, const float *__restrict__ src,
                                                        float *__restrict__ dst) {
   const BlurTile bt = tiles[xcd_swizzle(blockIdx.x, gridDim.x)];
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256, 8) void k_blur_rows_lds(const BlurTile *__rest
   __shared__ int sneed[96];
   const int nr = bt.count;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x < NC) sneed[threadIdx.x] = needTab[bt.needOfs + threadIdx.x];
+  for (int i = threadIdx.x; i < NC; i += BLUR_T) sneed[i] = needTab[bt.needOfs + i];
   const float *A = src + bt.srcOfs;
   // a wave parks rows wave, wave + 4, ...; the loads of up to FILL_MLP (row, 64-column chunk) steps are all issued before the
   // first LDS write, so a typical tile pays ONE memory round trip for its inputs; (row, chunk) advance in scalar registers
@@ -296,13 +298,13 @@ __global__ __launch_bounds__(256, 8) void k_blur_rows_lds(const BlurTile *__rest
         int cc = x - R;
         cc = cc < 0 ? 0 : (cc > P - 1 ? P - 1 : cc);
         t[u] = (r1 < nr && x < RW) ? A[r1 * P + cc] : 0.f;
-        if (++x1 == xit) { x1 = 0; r1 += 4; }
+        if (++x1 == xit) { x1 = 0; r1 += BLUR_W; }
       }
 #pragma unroll
       for (int u = 0; u < FILL_MLP; u++) {
         const int x = lane + (xi << 6);
         if (ri < nr && x < RW) win[ri * RW + x] = t[u];
-        if (++xi == xit) { xi = 0; ri += 4; }
+        if (++xi == xit) { xi = 0; ri += BLUR_W; }
       }
     }
   }
@@ -314,12 +316,12 @@ __global__ __launch_bounds__(256, 8) void k_blur_rows_lds(const BlurTile *__rest
   const int NP = (NC + 1) >> 1, total = nr * NP;
   float *out = dst + bt.dstOfs;
   constexpr int NQ = 4;
-  for (int base = threadIdx.x; base < total; base += 256 * NQ) {
+  for (int base = threadIdx.x; base < total; base += BLUR_T * NQ) {
     int p[NQ];     // win[p[q] + j], win[p[q] + j + 1] = window columns need[2m] + j - R, + 1 of the pair's row
     float v0[NQ], v1[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-      int e = base + q * 256;
+      int e = base + q * BLUR_T;
       e = e < total ? e : total - 1;                                      // idle slots repeat the last pair, not stored
       const int r = (int)(((unsigned)e * (unsigned)bt.magic) >> 20), m = e - r * NP;   // e / NP (exact for e < 4096, NP <= 96)
       p[q] = r * RW + sneed[2 * m];
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(256, 8) void k_blur_rows_lds(const BlurTile *__rest
     }
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-      const int e = base + q * 256;
+      const int e = base + q * BLUR_T;
       if (e < total) {
         const int r = (int)(((unsigned)e * (unsigned)bt.magic) >> 20), m = e - r * NP;
         float *o = out + r * NC + 2 * m;
@@ -372,7 +374,7 @@ __device__ __forceinline__ void blur_cols_tile(const BlurTile &bt, float *win, i
   const int n = bt.n, R = n >> 1;
   const int ro0 = bt.first, nro = bt.count, lo = bt.lo, S = bt.span;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x < NC) sneed[threadIdx.x] = needTab[bt.needOfs + threadIdx.x];
+  for (int i = threadIdx.x; i < NC; i += BLUR_T) sneed[i] = needTab[bt.needOfs + i];
   const float *T = src + bt.srcOfs;   // P x NC
   {
     const int xit = (NC + 63) >> 6;
@@ -386,13 +388,13 @@ __device__ __forceinline__ void blur_cols_tile(const BlurTile &bt, float *win, i
         int rr = lo + s1;
         rr = rr < 0 ? 0 : (rr > P - 1 ? P - 1 : rr);
         t[u] = (s1 < S && x < NC) ? T[rr * NC + x] : 0.f;
-        if (++x1 == xit) { x1 = 0; s1 += 4; }
+        if (++x1 == xit) { x1 = 0; s1 += BLUR_W; }
       }
 #pragma unroll
       for (int u = 0; u < FILL_MLP; u++) {
         const int x = lane + (xi << 6);
         if (si < S && x < NC) win[si * LS + x] = t[u];
-        if (++xi == xit) { xi = 0; si += 4; }
+        if (++xi == xit) { xi = 0; si += BLUR_W; }
       }
     }
   }
@@ -402,12 +404,12 @@ __device__ __forceinline__ void blur_cols_tile(const BlurTile &bt, float *win, i
   const int NP = (NC + 1) >> 1, total = nro * NP;
   float *out = dst + bt.dstOfs;
   constexpr int NQ = 4;
-  for (int base = threadIdx.x; base < total; base += 256 * NQ) {
+  for (int base = threadIdx.x; base < total; base += BLUR_T * NQ) {
     int pc[NQ];
     float2 v[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-      int e = base + q * 256;
+      int e = base + q * BLUR_T;
       e = e < total ? e : total - 1;
       const int ri = (int)(((unsigned)e * (unsigned)bt.magic) >> 20), m = e - ri * NP;
       pc[q] = (sneed[ro0 + ri] - lo) * LS + 2 * m;
@@ -435,7 +437,7 @@ __device__ __forceinline__ void blur_cols_tile(const BlurTile &bt, float *win, i
     }
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-      const int e = base + q * 256;
+      const int e = base + q * BLUR_T;
       if (e < total) {
         const int ri = (int)(((unsigned)e * (unsigned)bt.magic) >> 20), m = e - ri * NP;
         float *o = out + ri * NC + 2 * m;
@@ -446,11 +448,11 @@ __device__ __forceinline__ void blur_cols_tile(const BlurTile &bt, float *win, i
   }
 }
 
-__global__ __launch_bounds__(256, 8) void k_blur_cols_lds(const BlurTile *__restrict__ tiles, const float *__restrict__ taps,
+__global__ __launch_bounds__(BLUR_T) void k_blur_cols_lds(const BlurTile *__restrict__ tiles, const float *__restrict__ taps,
                                                        const int *__restrict__ needTab, const float *__restrict__ src,
                                                        float *__restrict__ dst) {
   const BlurTile bt = tiles[xcd_swizzle(blockIdx.x, gridDim.x)];
-  __shared__ __attribute__((aligned(16))) float win[BLUR_LDS];
+  __shared__ __attribute__((aligned(16))) float win[BLUR_LDS_C];
   __shared__ int sneed[96];
   if (bt.NC <= 64) blur_cols_tile<64>(bt, win, sneed, taps, needTab, src, dst);
   else blur_cols_tile<96>(bt, win, sneed, taps, needTab, src, dst);
@@ -747,8 +749,8 @@ void launch_blur_lds(hipStream_t s, const DescJob *jobs, const int *tilePrefix, 
                      const float *taps, const int *needTab, const float *src, float *dst, int pass) {
   if (nTiles <= 0) return;
   hipLaunchKernelGGL(k_expand_blur_tiles, dim3(nJobs), dim3(64), 0, s, jobs, tilePrefix, nJobs, needTab, tiles, pass);
-  if (pass == 0) hipLaunchKernelGGL(k_blur_rows_lds, dim3(nTiles), dim3(256), 0, s, tiles, taps, needTab, src, dst);
-  else hipLaunchKernelGGL(k_blur_cols_lds, dim3(nTiles), dim3(256), 0, s, tiles, taps, needTab, src, dst);
+  if (pass == 0) hipLaunchKernelGGL(k_blur_rows_lds, dim3(nTiles), dim3(BLUR_T), 0, s, tiles, taps, needTab, src, dst);
+  else hipLaunchKernelGGL(k_blur_cols_lds, dim3(nTiles), dim3(BLUR_T), 0, s, tiles, taps, needTab, src, dst);
 }
 void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix, const int *tileJob, int nTiles,
                        const float *taps, const int *needTab, const float *src, float *dst, int pass) {
