@@ -492,12 +492,13 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
   float *const patch = patchB, *const bufB = patchB;
   constexpr int PER_T = (NPX + 127) / 128;
   __shared__ __attribute__((aligned(16))) float bufA[PS * PSP];   // WX (direct branch), compacted masked values, later val
-  __shared__ double slut[256];   // ATAN_LUT (2 KB) next to the CU
+  __shared__ __attribute__((aligned(16))) double slut[256];   // ATAN_LUT (2 KB) next to the CU
   __shared__ __attribute__((aligned(16))) unsigned char sb0[PS * PSP];   // orientation bin bo0 % 8 of every pixel
-  __shared__ float swr0[PS], swr1[PS];
+  __shared__ float swr0[PS], swr1[PS], sfr[PS];
+  __shared__ int4 smap[PS];
   __shared__ double swc0[PS], swc1[PS];
-  __shared__ __attribute__((aligned(16))) double vec[128];
-  __shared__ __attribute__((aligned(16))) double part[32];
+  // the descriptor vector and its partial sums take the place of the ATAN_LUT, which is dead once the gradients are taken
+  double *const vec = slut, *const part = slut + 128;
   __shared__ float sstat[2];
   __shared__ double sfac;
   __shared__ int schanged;
@@ -513,22 +514,39 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
     // and columns idx(x0_i), idx(x0_i+1) with wx = WX_i - x0_i, wy = WY_j - y0_j -- the expression of helpers.cpp:575-577.
     const float *G = grid + jb.gridOfs;
     const int NC = jb.NC;
-    const int *need = needTab + jb.needOfs;
-    const int *map = need + NC;          // 41 x {idx0, idx1, x0, valid}
-    const float *W = coordTab + jb.coordOfs;
-#pragma unroll 4
-    for (int p = tid; p < NPX; p += 128) {
-      const int r = p / PS, c = p - r * PS;
-      float v = 0.f;
-      if (map[4 * r + 3] && map[4 * c + 3]) {
-        const int y0 = map[4 * r], y1 = map[4 * r + 1], x0 = map[4 * c], x1 = map[4 * c + 1];
-        const float wx = W[c] - (float)map[4 * c + 2];
-        const float wyd = W[r] - (float)map[4 * r + 2];
-        const float *R0 = G + (size_t)y0 * NC, *R1 = G + (size_t)y1 * NC;
-        const float I1 = wx * (R0[x1] - R0[x0]) + R0[x0];
-        v = wyd * (wx * (R1[x1] - R1[x0]) + R1[x0] - I1) + I1;
+    // the 41 x {idx0, idx1, x0, valid} table and the 41 coordinates are parked in LDS first, so that a sample's four grid
+    // loads depend on nothing but the job; all PER_T samples of a thread are then in flight together
+    if (tid < PS) {
+      const int *mp = needTab + jb.needOfs + NC + 4 * tid;
+      const int4 m = make_int4(mp[0], mp[1], mp[2], mp[3]);
+      smap[tid] = m;
+      sfr[tid] = coordTab[jb.coordOfs + tid] - (float)m.z;     // wx_i = WX_i - x0_i (= wy for rows)
+    }
+    __syncthreads();
+    float g00[PER_T], g01[PER_T], g10[PER_T], g11[PER_T];
+#pragma unroll
+    for (int k = 0; k < PER_T; k++) {
+      const int p = tid + 128 * k, pp = p < NPX ? p : NPX - 1;
+      const int r = pp / PS, c = pp - r * PS;
+      const int4 mr = smap[r], mc = smap[c];
+      const bool ok = mr.w && mc.w;
+      const float *R0 = G + (size_t)(ok ? mr.x : 0) * NC, *R1 = G + (size_t)(ok ? mr.y : 0) * NC;
+      const int x0 = ok ? mc.x : 0, x1 = ok ? mc.y : 0;
+      g00[k] = R0[x0]; g01[k] = R0[x1]; g10[k] = R1[x0]; g11[k] = R1[x1];
+    }
+#pragma unroll
+    for (int k = 0; k < PER_T; k++) {
+      const int p = tid + 128 * k;
+      if (p < NPX) {
+        const int r = p / PS, c = p - r * PS;
+        float v = 0.f;
+        if (smap[r].w && smap[c].w) {
+          const float wx = sfr[c], wyd = sfr[r];
+          const float I1 = wx * (g01[k] - g00[k]) + g00[k];
+          v = wyd * (wx * (g11[k] - g10[k]) + g10[k] - I1) + I1;
+        }
+        patch[p] = v;
       }
-      patch[p] = v;
     }
   } else {
     // -- direct branch (imageToPatchScale <= 0.4 or fast extraction): interpolate() straight from the view

@@ -1,5 +1,5 @@
 #!/bin/bash
-for m in 0 1; do
+for m in 0 1 2 3 4; do
   MODSX_DBG=$m bash tools/prof_single.sh
-  echo "mode $m: $(grep k_nms_localize gpurun_out/prof_single.txt)"
+  echo "mode $m: $(grep k_describe gpurun_out/prof_single.txt)"
 done
