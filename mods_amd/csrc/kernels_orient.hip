@@ -87,8 +87,11 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
   }
   if (lane < 4) { bufX[nv + lane] = 0.f; sbin[nv + lane] = 255; }   // pad the last group of four
   __syncthreads();
-  // lane b owns histogram bin b and adds its pixels in raster order (f32 running sum of the reference)
-  if (lane < 36) {
+  // lane b owns histogram bin b and adds its pixels in raster order (f32 running sum of the reference).  This loop is the
+  // kernel's largest stage and is bound by VALU issue, so a vote is two vector instructions: v_cmpx narrows EXEC to the
+  // one lane whose bin matches, the add then only happens there (bins 36..63 and the 255 of padding never match), and
+  // EXEC is reopened by a scalar move.  All 64 lanes of the workgroup's single wavefront are active here.
+  {
     float h = 0.f;
     const unsigned *b4 = reinterpret_cast<const unsigned *>(sbin);
     const float4 *w4 = reinterpret_cast<const float4 *>(bufX);
@@ -97,12 +100,24 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
     for (int g = 0; g < ng; g++) {
       const unsigned b = b4[g];
       const float4 w = w4[g];
-      if ((int)(b & 0xff) == lane) h += w.x;
-      if ((int)((b >> 8) & 0xff) == lane) h += w.y;
-      if ((int)((b >> 16) & 0xff) == lane) h += w.z;
-      if ((int)(b >> 24) == lane) h += w.w;
+      asm volatile(
+          "v_cmpx_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+          "v_add_f32_e32 %0, %0, %3\n\t"
+          "s_mov_b64 exec, -1\n\t"
+          "v_cmpx_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+          "v_add_f32_e32 %0, %0, %4\n\t"
+          "s_mov_b64 exec, -1\n\t"
+          "v_cmpx_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+          "v_add_f32_e32 %0, %0, %5\n\t"
+          "s_mov_b64 exec, -1\n\t"
+          "v_cmpx_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+          "v_add_f32_e32 %0, %0, %6\n\t"
+          "s_mov_b64 exec, -1"
+          : "+v"(h)
+          : "v"(b), "v"(lane), "v"(w.x), "v"(w.y), "v"(w.z), "v"(w.w)
+          : "vcc");
     }
-    hist[lane] = h;
+    if (lane < 36) hist[lane] = h;
   }
   __syncthreads();
   // 6 passes of the circular [1 1 1] smoothing: the in-place loop of the reference (synth-detection.cpp:795-809) only
