@@ -7,8 +7,8 @@
 //   SIFTDescriptor               matching/siftdesc.cpp:22-131 (bins, samplePatch), 136-278 (norms),
 //                                290-379 (gradients + atan2LUTff)
 // Data layout: every region owns a dense P x P f32 window in a scratch arena in HBM
-// (P = 2*ceil(s*mrSize)+3), written once by k_patch_sample, blurred by two separable passes
-// (arena A -> B -> A) and read once by k_describe, which resamples it to 41x41 in LDS.
+// (P = 2*ceil(s*mrSize)+3), written once by k_patch_sample, blurred by two separable passes at the rows / columns the
+// resampling needs (arena A -> B -> C) and read once by k_describe, which resamples it to 41x41 in LDS.
 #include "engine.hpp"
 
 namespace mx {
@@ -151,9 +151,10 @@ __global__ __launch_bounds__(64) void k_patch_sample(const DescJob *jobs, const 
 //                                                                         SymmRowSmallFilter when ksize <= 5)
 //   pass 1 filters the columns only at those rows:      NC x NC outputs  (SymmColumnFilter: centre + (below+above)*k)
 // Every output is the same sum of the same terms in the same order as in the full blur.
-// A workgroup forms BLUR_TILE outputs (4 per thread): the start of a workgroup is a chain of dependent loads (tile ->
-// job -> needed column -> inputs) that lasts longer than the arithmetic of 256 outputs, so fewer, fatter workgroups
-// run faster; the taps are parked in LDS so that a tap costs one vector load, not two.
+// k_patch_blur is the global-memory form of the two passes; since the LDS kernels below exist it only serves windows
+// whose tiles do not fit LDS.  A workgroup forms BLUR_TILE outputs (4 per thread): the start of a workgroup is a chain
+// of dependent loads (tile -> job -> needed column -> inputs) that lasts longer than the arithmetic of 256 outputs, so
+// fewer, fatter workgroups run faster; the taps are parked in LDS so that a tap costs one vector load, not two.
 constexpr int BLUR_TILE = 1024, BLUR_TAPS = 512;   // ksize <= 512 is enforced by the host (windows up to ~2300 px)
 
 __global__ __launch_bounds__(256) void k_patch_blur(const DescJob *jobs, const int *tilePrefix, const int *tileJob,
