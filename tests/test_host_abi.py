@@ -198,3 +198,20 @@ def test_key_file_round_trip(modsx, tmp_path):
         modsx.load_regions(path, "DoG", "SIFT")
     with pytest.raises(RuntimeError):
         modsx.load_regions(str(tmp_path / "missing.txt"))
+
+
+def test_atan2lut_branchfree(tmp_path):
+    """The branch-free atan2LUT of the kernels equals the reference's eight-way branch form bit for bit (host build)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "atan2lut_check")
+    subprocess.check_call([hipcc, "-O2", "-ffp-contract=off", "--offload-arch=gfx950", "-x", "hip",
+                           "-I", os.path.join(root, "mods_amd", "csrc"), "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "native", "atan2lut_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-500:]
+    assert "bad=0" in out.stdout
