@@ -906,43 +906,78 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
   return MODSX_OK;
 }
 
-// MatchFlannFGINN (matching/matching.cpp:357-461, linear index) on descriptors resident in HBM
-int match_device(modsx_ctx *c, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2Host,
-                 double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out) {
-  out.clear();
-  if (n1 == 0 || n2 == 0) return MODSX_OK;
+// MatchFlannFGINN (matching/matching.cpp:357-461, linear index) on descriptors resident in HBM, for nb <= MATCH_MAXB
+// independent (query set, train set) problems that share the kernel launches (blockIdx.z) and one synchronisation
+int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
+                       const double *const *pos2Host, double ratioT, double contradDist, int nn,
+                       std::vector<modsx_tentative> *out) {
+  if (nb < 1 || nb > MATCH_MAXB) { set_error("match_device_batch: batch size"); return MODSX_ERR_ARG; }
   hipStream_t s = c->stream;
   const double sqminratio = ratioT * ratioT, contrDistSq = contradDist * contradDist;
   if (!(sqminratio < 1.0)) { set_error("match ratio >= 1 (PDF mode of MatchFlannFGINN) is not supported"); return MODSX_ERR_ARG; }
-  int S_, tps_;
-  if (!c->pos2.ensure((size_t)n2 * 16) || !c->matchRows.ensure((size_t)n1 * sizeof(MatchRow)) ||
-      !c->matchWork.ensure(match_workspace_bytes(n1, n2, &S_, &tps_) + 4096))
-    return MODSX_ERR_NOMEM;
-  MX_HIP(hipMemcpyAsync(c->pos2.p, pos2Host, (size_t)n2 * 16, hipMemcpyHostToDevice, s));
-  {
-    ProfScope ps(c, K_MATCH, 2.0 * n1 * (double)n2 * 128);
-    launch_match(s, d1, n1, d2, n2, (const double *)c->pos2.p, sqminratio, contrDistSq, (MatchRow *)c->matchRows.p,
-                 c->matchWork.p);
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  size_t posOfs[MATCH_MAXB], rowOfs[MATCH_MAXB], workOfs[MATCH_MAXB], posB = 0, rowB = 0, workB = 0;
+  int live[MATCH_MAXB], nl = 0;
+  for (int i = 0; i < nb; i++) {
+    out[i].clear();
+    if (n1[i] <= 0 || n2[i] <= 0) continue;
+    int S_, tps_;
+    posOfs[nl] = posB; posB += up((size_t)n2[i] * 16);
+    rowOfs[nl] = rowB; rowB += up((size_t)n1[i] * sizeof(MatchRow));
+    workOfs[nl] = workB; workB += up(match_workspace_bytes(n1[i], n2[i], &S_, &tps_) + 4096);
+    live[nl++] = i;
   }
-  std::vector<MatchRow> rows(n1);
-  MX_HIP(hipMemcpyAsync(rows.data(), c->matchRows.p, (size_t)n1 * sizeof(MatchRow), hipMemcpyDeviceToHost, s));
+  if (!nl) return MODSX_OK;
+  if (!c->pos2.ensure(posB) || !c->matchRows.ensure(rowB) || !c->matchWork.ensure(workB)) return MODSX_ERR_NOMEM;
+  const uint8_t *pd1[MATCH_MAXB], *pd2[MATCH_MAXB];
+  const double *ppos[MATCH_MAXB];
+  MatchRow *prow[MATCH_MAXB];
+  void *pwork[MATCH_MAXB];
+  int pn1[MATCH_MAXB], pn2[MATCH_MAXB];
+  double work = 0;
+  for (int k = 0; k < nl; k++) {
+    const int i = live[k];
+    pd1[k] = d1[i]; pd2[k] = d2[i]; pn1[k] = n1[i]; pn2[k] = n2[i];
+    ppos[k] = (const double *)((char *)c->pos2.p + posOfs[k]);
+    prow[k] = (MatchRow *)((char *)c->matchRows.p + rowOfs[k]);
+    pwork[k] = (char *)c->matchWork.p + workOfs[k];
+    MX_HIP(hipMemcpyAsync((void *)ppos[k], pos2Host[i], (size_t)n2[i] * 16, hipMemcpyHostToDevice, s));
+    work += 2.0 * n1[i] * (double)n2[i] * 128;
+  }
+  {
+    ProfScope ps(c, K_MATCH, work);
+    launch_match_batch(s, nl, pd1, pn1, pd2, pn2, ppos, sqminratio, contrDistSq, prow, pwork);
+  }
+  std::vector<MatchRow> rows[MATCH_MAXB];
+  for (int k = 0; k < nl; k++) {
+    rows[k].resize(pn1[k]);
+    MX_HIP(hipMemcpyAsync(rows[k].data(), prow[k], (size_t)pn1[k] * sizeof(MatchRow), hipMemcpyDeviceToHost, s));
+  }
   MX_HIP(hipStreamSynchronize(s));
   MX_HIP(hipGetLastError());
-  out.reserve(n1 / 4 + 16);
-  for (int q = 0; q < n1; q++) {
-    const MatchRow &r = rows[q];
-    // rank of the first ratio-passing neighbour is nless+1; it must be <= nn-1 and every neighbour
-    // before it must lie within contradDist of NN0 (matching.cpp:435-457)
-    if (r.t0 < 0 || r.tj < 0 || r.nbad != 0 || r.nless > nn - 2) continue;
-    modsx_tentative t;
-    t.q = q; t.t0 = r.t0; t.tj = r.tj;
-    t.t1 = r.t1;
-    t.d1 = r.d0; t.d2 = r.dj; t.d2by2ndcl = r.d1;
-    double ratio = r.d0 / r.dj;  // f32 / f32, then widened (matching.cpp:437)
-    t.ratio = sqrt(ratio);
-    out.push_back(t);
+  for (int k = 0; k < nl; k++) {
+    std::vector<modsx_tentative> &o = out[live[k]];
+    o.reserve(pn1[k] / 4 + 16);
+    for (int q = 0; q < pn1[k]; q++) {
+      const MatchRow &r = rows[k][q];
+      // rank of the first ratio-passing neighbour is nless+1; it must be <= nn-1 and every neighbour
+      // before it must lie within contradDist of NN0 (matching.cpp:435-457)
+      if (r.t0 < 0 || r.tj < 0 || r.nbad != 0 || r.nless > nn - 2) continue;
+      modsx_tentative t;
+      t.q = q; t.t0 = r.t0; t.tj = r.tj;
+      t.t1 = r.t1;
+      t.d1 = r.d0; t.d2 = r.dj; t.d2by2ndcl = r.d1;
+      double ratio = r.d0 / r.dj;  // f32 / f32, then widened (matching.cpp:437)
+      t.ratio = sqrt(ratio);
+      o.push_back(t);
+    }
   }
   return MODSX_OK;
+}
+
+int match_device(modsx_ctx *c, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2Host,
+                 double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out) {
+  return match_device_batch(c, 1, &d1, &n1, &d2, &n2, &pos2Host, ratioT, contradDist, nn, &out);
 }
 
 static void desc_f32_to_u8(const float *f, size_t n, uint8_t *u) {
@@ -1054,6 +1089,39 @@ int match_pair_group(modsx_ctx *c, const modsx_image *const *imgs1, const modsx_
   if (rc) return rc;
   const double t3 = now_ms();
   double tMatch = 0, tVerify = 0;
+  // Matching and verification alternate pair by pair.  (match_device_batch can take the G problems in one launch set, which
+  // cuts the matcher's device time per pair from 0.07 to 0.024 ms, but measured end to end with 16 contexts it LOWERS the
+  // throughput by ~12 %: the contexts then alternate between a long GPU-only and a long host-only phase and fall in step.)
+  static const int batchedMatch = getenv("MODSX_MATCH_BATCH") ? atoi(getenv("MODSX_MATCH_BATCH")) : 0;
+  if (batchedMatch) {
+    std::vector<double> pos2v[MAXB / 2];
+    std::vector<modsx_tentative> tentsv[MAXB / 2];
+    const double m0 = now_ms();
+    const uint8_t *pd1[MAXB / 2], *pd2[MAXB / 2];
+    const double *ppos[MAXB / 2];
+    int pn1[MAXB / 2], pn2[MAXB / 2];
+    for (int g = 0; g < G; g++) {
+      const std::vector<modsx_region> &rb = oriented[2 * g + 1];
+      res[g].n_regions1 = (int)oriented[2 * g].size();
+      res[g].n_regions2 = (int)rb.size();
+      pos2v[g].resize(rb.size() * 2 + 2);
+      for (size_t i = 0; i < rb.size(); i++) { pos2v[g][2 * i] = rb[i].reproj_kp.x; pos2v[g][2 * i + 1] = rb[i].reproj_kp.y; }
+      pd1[g] = (uint8_t *)c->descU8[2 * g].p; pd2[g] = (uint8_t *)c->descU8[2 * g + 1].p;
+      pn1[g] = res[g].n_regions1; pn2[g] = res[g].n_regions2; ppos[g] = pos2v[g].data();
+    }
+    for (int g0 = 0; g0 < G; g0 += MATCH_MAXB) {
+      const int nbm = std::min(MATCH_MAXB, G - g0);
+      rc = match_device_batch(c, nbm, pd1 + g0, pn1 + g0, pd2 + g0, pn2 + g0, ppos + g0, pp.match_ratio, pp.contradDist, pp.nn,
+                              tentsv + g0);
+      if (rc) return rc;
+    }
+    tMatch = now_ms() - m0;
+    for (int g = 0; g < G; g++) {
+      const double m1 = now_ms();
+      verify_tentatives(oriented[2 * g], oriented[2 * g + 1], tentsv[g], pp, &res[g]);
+      tVerify += now_ms() - m1;
+    }
+  } else
   for (int g = 0; g < G; g++) {
     const std::vector<modsx_region> &ra = oriented[2 * g], &rb = oriented[2 * g + 1];
     const double m0 = now_ms();

@@ -184,6 +184,10 @@ void launch_blur_pass(hipStream_t s, const float *src, float *dst, int rows, int
 size_t match_workspace_bytes(int n1, int n2, int *S_out, int *tilesPerSplit_out);
 void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2,
                   double sqminratio, double contrDistSq, MatchRow *rows, void *workspace);
+constexpr int MATCH_MAXB = 4;   // independent matching problems per launch set (blockIdx.z)
+void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
+                        const double *const *pos2, double sqminratio, double contrDistSq, MatchRow *const *rows,
+                        void *const *workspace);
 
 }  // namespace mx
 

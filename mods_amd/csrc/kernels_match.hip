@@ -38,7 +38,7 @@ constexpr int TILES_PER_SPLIT_MAX = 256;   // 8 bits of local tile index in the 
 constexpr int TPS = 4;                     // train tiles staged per barrier (4 x 4 KB per LDS buffer)
 
 // norms[i] = |d_i - 128|^2; normS[i] (optional) = |d_i - 128|^2 + 2 sum(d_i - 128), the column constant of sweep 1
-__global__ __launch_bounds__(256) void k_desc_norms(const uint8_t *d, int n, int *norms, int *normS) {
+__device__ __forceinline__ void norms_body(const uint8_t *d, int n, int *norms, int *normS) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const v4i *p = reinterpret_cast<const v4i *>(d + (size_t)i * 128);
@@ -118,7 +118,7 @@ MX_D v4i read_b(const unsigned char *lds, int col, int kb, int hi) {
 }
 
 // ---------------- sweep 1: per (query, split) top-2 -------------------------------------------------------
-__global__ __launch_bounds__(256) void k_match_sweep1(const uint8_t *d1, const int *norm1, const uint8_t *d2,
+__device__ __forceinline__ void sweep1_body(const uint8_t *d1, const int *norm1, const uint8_t *d2,
                                                       const int *normS2, MatchGeom g, int4 *partial) {
   __shared__ __attribute__((aligned(16))) unsigned char tileBuf[2][TPS * 4096];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_match_sweep1(const uint8_t *d1, const i
 }
 
 // ---------------- decide: merge splits, j = 1 of the walk, compact the undecided queries --------------------
-__global__ __launch_bounds__(256) void k_match_decide(const int4 *partial, MatchGeom g, const double *pos2,
+__device__ __forceinline__ void decide_body(const int4 *partial, MatchGeom g, const double *pos2,
                                                       double sqminratio, double contrDistSq, MatchRow *rows, int *dmin,
                                                       int *undecided, int *nUndecided) {
   const int q = blockIdx.x * 256 + threadIdx.x;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void k_match_decide(const int4 *partial, Match
 }
 
 // ---------------- sweep 2 over the undecided queries ----------------------------------------------------------
-__global__ __launch_bounds__(256) void k_match_sweep2(const uint8_t *d1, const int *norm1, const uint8_t *d2,
+__device__ __forceinline__ void sweep2_body(const uint8_t *d1, const int *norm1, const uint8_t *d2,
                                                       const int *norm2, MatchGeom g, const double *pos2,
                                                       double contrDistSq, const MatchRow *rows, const int *dmin,
                                                       const int *undecided, const int *nUndecided, int4 *partial2) {
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void k_match_sweep2(const uint8_t *d1, const i
   }
 }
 
-__global__ __launch_bounds__(256) void k_match_finish(const int4 *partial2, MatchGeom g, const int *undecided,
+__device__ __forceinline__ void finish_body(const int4 *partial2, MatchGeom g, const int *undecided,
                                                       const int *nUndecided, MatchRow *rows) {
   const int u = blockIdx.x * 256 + threadIdx.x;
   if (u >= *nUndecided) return;
@@ -374,28 +374,77 @@ size_t match_workspace_bytes(int n1, int n2, int *S_out, int *tilesPerSplit_out)
   return bytes;
 }
 
+// ---- batched entry points: blockIdx.z selects one of up to MATCH_MAXB independent problems (the pairs of a launch set).
+// At 2-3 k descriptors per image a problem is six launches of ~10-20 us of mostly latency, so the problems of a batch
+// share the launches.
+struct MatchProblem {
+  const uint8_t *d1, *d2;
+  const double *pos2;
+  int *norm1, *norm2, *normS2, *dmin, *undecided, *counter;
+  int4 *partial, *partial2;
+  MatchRow *rows;
+  MatchGeom g;
+};
+struct MatchBatch { MatchProblem p[MATCH_MAXB]; };
+
+__global__ __launch_bounds__(256) void k_desc_norms(MatchBatch b) {
+  const MatchProblem &P = b.p[blockIdx.z];
+  if (blockIdx.y == 0) norms_body(P.d1, P.g.n1, P.norm1, (int *)nullptr);
+  else norms_body(P.d2, P.g.n2, P.norm2, P.normS2);
+}
+__global__ __launch_bounds__(256) void k_match_sweep1(MatchBatch b) {
+  const MatchProblem &P = b.p[blockIdx.z];
+  if ((int)blockIdx.x * 128 >= P.g.n1 || (int)blockIdx.y >= P.g.S) return;
+  sweep1_body(P.d1, P.norm1, P.d2, P.normS2, P.g, P.partial);
+}
+__global__ __launch_bounds__(256) void k_match_decide(MatchBatch b, double sqminratio, double contrDistSq) {
+  const MatchProblem &P = b.p[blockIdx.z];
+  decide_body(P.partial, P.g, P.pos2, sqminratio, contrDistSq, P.rows, P.dmin, P.undecided, P.counter);
+}
+__global__ __launch_bounds__(256) void k_match_sweep2(MatchBatch b, double contrDistSq) {
+  const MatchProblem &P = b.p[blockIdx.z];
+  if ((int)blockIdx.x * 128 >= P.g.n1 || (int)blockIdx.y >= P.g.S) return;
+  sweep2_body(P.d1, P.norm1, P.d2, P.norm2, P.g, P.pos2, contrDistSq, P.rows, P.dmin, P.undecided, P.counter, P.partial2);
+}
+__global__ __launch_bounds__(256) void k_match_finish(MatchBatch b) {
+  const MatchProblem &P = b.p[blockIdx.z];
+  finish_body(P.partial2, P.g, P.undecided, P.counter, P.rows);
+}
+
+// Problems with n1 == 0 or n2 == 0 must be left out by the caller.  workspace[i] holds match_workspace_bytes(n1[i], n2[i]).
+void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
+                        const double *const *pos2, double sqminratio, double contrDistSq, MatchRow *const *rows,
+                        void *const *workspace) {
+  if (nb <= 0) return;
+  MatchBatch b;
+  memset(&b, 0, sizeof b);
+  int maxN = 0, maxN1 = 0, maxS = 0;
+  for (int i = 0; i < nb; i++) {
+    MatchProblem &P = b.p[i];
+    P.g.n1 = n1[i]; P.g.n2 = n2[i];
+    match_workspace_bytes(n1[i], n2[i], &P.g.S, &P.g.tilesPerSplit);
+    char *w = (char *)workspace[i];
+    auto take = [&](size_t bytes) { char *p = w; w += (bytes + 255) & ~(size_t)255; return p; };
+    P.norm1 = (int *)take((size_t)n1[i] * 4); P.norm2 = (int *)take((size_t)n2[i] * 4); P.normS2 = (int *)take((size_t)n2[i] * 4);
+    P.partial = (int4 *)take((size_t)n1[i] * P.g.S * 16); P.partial2 = (int4 *)take((size_t)n1[i] * P.g.S * 16);
+    P.dmin = (int *)take((size_t)n1[i] * 4); P.undecided = (int *)take((size_t)n1[i] * 4);
+    P.counter = (int *)take(64);
+    P.d1 = d1[i]; P.d2 = d2[i]; P.pos2 = pos2[i]; P.rows = rows[i];
+    hipMemsetAsync(P.counter, 0, 4, s);
+    maxN = std::max(maxN, std::max(n1[i], n2[i])); maxN1 = std::max(maxN1, n1[i]); maxS = std::max(maxS, P.g.S);
+  }
+  hipLaunchKernelGGL(k_desc_norms, dim3((maxN + 255) / 256, 2, nb), dim3(256), 0, s, b);
+  const dim3 grid((maxN1 + 127) / 128, maxS, nb), gridQ((maxN1 + 255) / 256, 1, nb);
+  hipLaunchKernelGGL(k_match_sweep1, grid, dim3(256), 0, s, b);
+  hipLaunchKernelGGL(k_match_decide, gridQ, dim3(256), 0, s, b, sqminratio, contrDistSq);
+  hipLaunchKernelGGL(k_match_sweep2, grid, dim3(256), 0, s, b, contrDistSq);
+  hipLaunchKernelGGL(k_match_finish, gridQ, dim3(256), 0, s, b);
+}
+
 void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2,
                   double sqminratio, double contrDistSq, MatchRow *rows, void *workspace) {
   if (n1 <= 0 || n2 <= 0) return;
-  MatchGeom g;
-  g.n1 = n1; g.n2 = n2;
-  match_workspace_bytes(n1, n2, &g.S, &g.tilesPerSplit);
-  char *w = (char *)workspace;
-  auto take = [&](size_t bytes) { char *p = w; w += (bytes + 255) & ~(size_t)255; return p; };
-  int *norm1 = (int *)take((size_t)n1 * 4), *norm2 = (int *)take((size_t)n2 * 4), *normS2 = (int *)take((size_t)n2 * 4);
-  int4 *partial = (int4 *)take((size_t)n1 * g.S * 16), *partial2 = (int4 *)take((size_t)n1 * g.S * 16);
-  int *dmin = (int *)take((size_t)n1 * 4), *undecided = (int *)take((size_t)n1 * 4);
-  int *counter = (int *)take(64);
-  hipMemsetAsync(counter, 0, 4, s);
-  hipLaunchKernelGGL(k_desc_norms, dim3((n1 + 255) / 256), dim3(256), 0, s, d1, n1, norm1, (int *)nullptr);
-  hipLaunchKernelGGL(k_desc_norms, dim3((n2 + 255) / 256), dim3(256), 0, s, d2, n2, norm2, normS2);
-  const dim3 grid((n1 + 127) / 128, g.S);
-  hipLaunchKernelGGL(k_match_sweep1, grid, dim3(256), 0, s, d1, norm1, d2, normS2, g, partial);
-  hipLaunchKernelGGL(k_match_decide, dim3((n1 + 255) / 256), dim3(256), 0, s, partial, g, pos2, sqminratio, contrDistSq,
-                     rows, dmin, undecided, counter);
-  hipLaunchKernelGGL(k_match_sweep2, grid, dim3(256), 0, s, d1, norm1, d2, norm2, g, pos2, contrDistSq, rows, dmin,
-                     undecided, counter, partial2);
-  hipLaunchKernelGGL(k_match_finish, dim3((n1 + 255) / 256), dim3(256), 0, s, partial2, g, undecided, counter, rows);
+  launch_match_batch(s, 1, &d1, &n1, &d2, &n2, &pos2, sqminratio, contrDistSq, &rows, &workspace);
 }
 
 }  // namespace mx
