@@ -168,7 +168,7 @@ void ctx_destroy(modsx_ctx *c) {
                     &c->descAllU8[1], &c->descAllU8b[0], &c->descAllU8b[1], &c->pos2, &c->matchRows, &c->matchWork, &c->misc, &c->scratchC, &c->needTab, &c->coordTab, &c->tileJob, &c->blurTiles, &c->nmsQueue, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps};
   for (DevBuf *b : bufs) b->release();
   for (int i = 0; i < MAXB; i++) { c->descF[i].release(); c->descU8[i].release(); }
-  PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc};
+  PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc, &c->hNms};
   for (PinBuf *b : pins) b->release();
   hipFree(c->dSmmMask); hipFree(c->dOriMask); hipFree(c->dSiftMask); hipFree(c->dSiftMaskIdx); hipFree(c->dAtan); hipFree(c->dSiftBins);
   hipFree(c->dSiftW);
@@ -357,8 +357,10 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
     if (!nj) return MODSX_OK;
     const size_t jobBytes = (size_t)nj * sizeof(NmsJob), pfxBytes = (size_t)(nj + 1) * 4;
     if (!c->nmsJobs.ensure(jobBytes + pfxBytes + 64)) return MODSX_ERR_NOMEM;
-    MX_HIP(hipMemcpyAsync(c->nmsJobs.p, hjobs.data(), jobBytes, hipMemcpyHostToDevice, s));
-    MX_HIP(hipMemcpyAsync((char *)c->nmsJobs.p + jobBytes, hpfx.data(), pfxBytes, hipMemcpyHostToDevice, s));
+    if (!c->hNms.ensure(jobBytes + pfxBytes)) return MODSX_ERR_NOMEM;   // jobs + prefix: one pinned blob, one copy
+    memcpy(c->hNms.p, hjobs.data(), jobBytes);
+    memcpy((char *)c->hNms.p + jobBytes, hpfx.data(), pfxBytes);
+    MX_HIP(hipMemcpyAsync(c->nmsJobs.p, c->hNms.p, jobBytes + pfxBytes, hipMemcpyHostToDevice, s));
     if (!c->tileJob.ensure((size_t)hpfx.back() * 4 + 4)) return MODSX_ERR_NOMEM;
     launch_expand_tiles(s, (const int *)((char *)c->nmsJobs.p + jobBytes), nj, (int *)c->tileJob.p);
     {
@@ -394,8 +396,10 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
     const int nj = (int)hjobs.size();
     const size_t jobBytes = (size_t)nj * sizeof(NmsJob), pfxBytes = (size_t)(nj + 1) * 4;
     if (!c->nmsJobs.ensure(jobBytes + pfxBytes + 64)) return MODSX_ERR_NOMEM;
-    MX_HIP(hipMemcpyAsync(c->nmsJobs.p, hjobs.data(), jobBytes, hipMemcpyHostToDevice, s));
-    MX_HIP(hipMemcpyAsync((char *)c->nmsJobs.p + jobBytes, hpfx.data(), pfxBytes, hipMemcpyHostToDevice, s));
+    if (!c->hNms.ensure(jobBytes + pfxBytes)) return MODSX_ERR_NOMEM;   // jobs + prefix: one pinned blob, one copy
+    memcpy(c->hNms.p, hjobs.data(), jobBytes);
+    memcpy((char *)c->hNms.p + jobBytes, hpfx.data(), pfxBytes);
+    MX_HIP(hipMemcpyAsync(c->nmsJobs.p, c->hNms.p, jobBytes + pfxBytes, hipMemcpyHostToDevice, s));
     if (!c->tileJob.ensure((size_t)hpfx.back() * 4 + 4)) return MODSX_ERR_NOMEM;
     launch_expand_tiles(s, (const int *)((char *)c->nmsJobs.p + jobBytes), nj, (int *)c->tileJob.p);
     ProfScope ps(c, K_NMS, px * 12);
@@ -849,9 +853,13 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       // (i, r) = first region that did not fit, or i == n
       if (full) { curImg = i; curReg = r; } else { curImg = n; curReg = 0; }
       const size_t nj = jobs.size();
-      if (!c->descJobs.ensure(nj * sizeof(DescJob)) || !c->tilePrefix.ensure((nj + 1) * 20) ||
-          !c->taps.ensure(std::max<size_t>(1, taps.size()) * 4) || !c->needTab.ensure(std::max<size_t>(1, needTab.size()) * 4) ||
-          !c->coordTab.ensure(std::max<size_t>(1, coordTab.size()) * 4) ||
+      // the job table, the five tile prefixes and the three small tables travel as ONE pinned blob and one copy: nine
+      // separate uploads cost nine ~6 us copy kernels per chunk on the stream
+      auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+      const size_t oJobs = 0, oPfx = up16(nj * sizeof(DescJob)), pfxB = up16((nj + 1) * 4);
+      const size_t oTaps = oPfx + 5 * pfxB, oNeed = oTaps + up16(taps.size() * 4), oCoord = oNeed + up16(needTab.size() * 4);
+      const size_t blobB = oCoord + up16(coordTab.size() * 4) + 16;
+      if (!c->descJobs.ensure(blobB) || !c->hDesc.ensure(blobB) ||
           !c->scratchA.ensure(std::max<size_t>(1, arenaA) * 4) || !c->scratchB.ensure(std::max<size_t>(1, arenaB) * 4) ||
           !c->scratchC.ensure(std::max<size_t>(1, arenaC) * 4) ||
           !c->tileJob.ensure(((size_t)pfxSample.back() + pfxRow.back() + pfxCol.back() + 3) * 4))
@@ -859,17 +867,18 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       int *tjS = (int *)c->tileJob.p, *tjR = tjS + pfxSample.back(), *tjC = tjR + pfxRow.back();
       if (!c->blurTiles.ensure(((size_t)pfxRowL.back() + pfxColL.back() + 1) * sizeof(BlurTile))) return MODSX_ERR_NOMEM;
       BlurTile *btR = (BlurTile *)c->blurTiles.p, *btC = btR + pfxRowL.back();
-      int *dPfxS = (int *)c->tilePrefix.p, *dPfxR = dPfxS + (nj + 1), *dPfxC = dPfxR + (nj + 1);
-      int *dPfxRL = dPfxC + (nj + 1), *dPfxCL = dPfxRL + (nj + 1);
-      MX_HIP(hipMemcpyAsync(dPfxRL, pfxRowL.data(), (nj + 1) * 4, hipMemcpyHostToDevice, s));
-      MX_HIP(hipMemcpyAsync(dPfxCL, pfxColL.data(), (nj + 1) * 4, hipMemcpyHostToDevice, s));
-      MX_HIP(hipMemcpyAsync(c->descJobs.p, jobs.data(), nj * sizeof(DescJob), hipMemcpyHostToDevice, s));
-      MX_HIP(hipMemcpyAsync(dPfxS, pfxSample.data(), (nj + 1) * 4, hipMemcpyHostToDevice, s));
-      MX_HIP(hipMemcpyAsync(dPfxR, pfxRow.data(), (nj + 1) * 4, hipMemcpyHostToDevice, s));
-      MX_HIP(hipMemcpyAsync(dPfxC, pfxCol.data(), (nj + 1) * 4, hipMemcpyHostToDevice, s));
-      if (!taps.empty()) MX_HIP(hipMemcpyAsync(c->taps.p, taps.data(), taps.size() * 4, hipMemcpyHostToDevice, s));
-      if (!needTab.empty()) MX_HIP(hipMemcpyAsync(c->needTab.p, needTab.data(), needTab.size() * 4, hipMemcpyHostToDevice, s));
-      if (!coordTab.empty()) MX_HIP(hipMemcpyAsync(c->coordTab.p, coordTab.data(), coordTab.size() * 4, hipMemcpyHostToDevice, s));
+      char *hb = (char *)c->hDesc.p, *db = (char *)c->descJobs.p;
+      memcpy(hb + oJobs, jobs.data(), nj * sizeof(DescJob));
+      const std::vector<int> *pf[5] = {&pfxSample, &pfxRow, &pfxCol, &pfxRowL, &pfxColL};
+      for (int q = 0; q < 5; q++) memcpy(hb + oPfx + q * pfxB, pf[q]->data(), (nj + 1) * 4);
+      if (!taps.empty()) memcpy(hb + oTaps, taps.data(), taps.size() * 4);
+      if (!needTab.empty()) memcpy(hb + oNeed, needTab.data(), needTab.size() * 4);
+      if (!coordTab.empty()) memcpy(hb + oCoord, coordTab.data(), coordTab.size() * 4);
+      MX_HIP(hipMemcpyAsync(db, hb, blobB, hipMemcpyHostToDevice, s));
+      int *dPfxS = (int *)(db + oPfx), *dPfxR = (int *)(db + oPfx + pfxB), *dPfxC = (int *)(db + oPfx + 2 * pfxB);
+      int *dPfxRL = (int *)(db + oPfx + 3 * pfxB), *dPfxCL = (int *)(db + oPfx + 4 * pfxB);
+      float *dTaps = (float *)(db + oTaps), *dCoord = (float *)(db + oCoord);
+      int *dNeed = (int *)(db + oNeed);
       const DescJob *dj = (const DescJob *)c->descJobs.p;
       launch_expand_tiles(s, dPfxS, (int)nj, tjS);
       launch_expand_tiles(s, dPfxR, (int)nj, tjR);
@@ -877,20 +886,20 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       { ProfScope ps(c, K_PATCH_SAMPLE, (double)arenaA * 8);
         launch_patch_sample(s, dj, dPfxS, tjS, pfxSample.back(), (ImgRef *)c->imgRefs.p, (float *)c->scratchA.p); }
       { ProfScope ps(c, K_BLUR_ROWS, ((double)arenaA + arenaB) * 4);
-        launch_blur_lds(s, dj, dPfxRL, (int)nj, btR, pfxRowL.back(), (float *)c->taps.p, (int *)c->needTab.p, (float *)c->scratchA.p,
+        launch_blur_lds(s, dj, dPfxRL, (int)nj, btR, pfxRowL.back(), dTaps, dNeed, (float *)c->scratchA.p,
                         (float *)c->scratchB.p, 0);
-        launch_patch_blur(s, dj, dPfxR, tjR, pfxRow.back(), (float *)c->taps.p, (int *)c->needTab.p, (float *)c->scratchA.p,
+        launch_patch_blur(s, dj, dPfxR, tjR, pfxRow.back(), dTaps, dNeed, (float *)c->scratchA.p,
                           (float *)c->scratchB.p, 0); }
       { ProfScope ps(c, K_BLUR_COLS, ((double)arenaB + arenaC) * 4);
-        launch_blur_lds(s, dj, dPfxCL, (int)nj, btC, pfxColL.back(), (float *)c->taps.p, (int *)c->needTab.p, (float *)c->scratchB.p,
+        launch_blur_lds(s, dj, dPfxCL, (int)nj, btC, pfxColL.back(), dTaps, dNeed, (float *)c->scratchB.p,
                         (float *)c->scratchC.p, 1);
-        launch_patch_blur(s, dj, dPfxC, tjC, pfxCol.back(), (float *)c->taps.p, (int *)c->needTab.p, (float *)c->scratchB.p,
+        launch_patch_blur(s, dj, dPfxC, tjC, pfxCol.back(), dTaps, dNeed, (float *)c->scratchB.p,
                           (float *)c->scratchC.p, 1); }
       ProfScope psd(c, K_DESCRIBE, (double)arenaC * 4 + (double)nj * (128 * 5));
-      launch_describe(s, dj, (int)nj, (ImgRef *)c->imgRefs.p, (float *)c->scratchC.p, (int *)c->needTab.p, (float *)c->coordTab.p,
+      launch_describe(s, dj, (int)nj, (ImgRef *)c->imgRefs.p, (float *)c->scratchC.p, dNeed, dCoord,
                       c->dSiftMask, c->dSiftMaskIdx, c->nSiftMask, c->dAtan,
                       c->dSiftBins, c->dSiftW, photoNorm, descType, maxBin, outs);
-      MX_HIP(hipStreamSynchronize(s));  // jobs/taps/prefix are host vectors reused by the next chunk
+      MX_HIP(hipStreamSynchronize(s));  // the pinned blob is reused by the next chunk
     }
   }
   if (descHost) {
@@ -1056,7 +1065,7 @@ void verify_tentatives(const std::vector<modsx_region> &r1, const std::vector<mo
 // detection, orientation and description as ONE batch (one launch set, blockIdx.z / job tables select the image), then
 // each pair is matched and verified.  Results are those of G separate calls.
 int match_pair_group(modsx_ctx *c, const modsx_image *const *imgs1, const modsx_image *const *imgs2, int G,
-                     const modsx_pair_params &pp, modsx_pair_result *res) {
+                     const modsx_pair_params &pp, modsx_pair_result *res, std::vector<VerifyTask> *deferred) {
   if (G < 1 || 2 * G > MAXB) { set_error("match_pair_group: group size"); return MODSX_ERR_ARG; }
   for (int g = 0; g < G; g++) {
     memset(&res[g], 0, sizeof res[g]);
@@ -1089,11 +1098,9 @@ int match_pair_group(modsx_ctx *c, const modsx_image *const *imgs1, const modsx_
   if (rc) return rc;
   const double t3 = now_ms();
   double tMatch = 0, tVerify = 0;
-  // Matching and verification alternate pair by pair.  (match_device_batch can take the G problems in one launch set, which
-  // cuts the matcher's device time per pair from 0.07 to 0.024 ms, but measured end to end with 16 contexts it LOWERS the
-  // throughput by ~12 %: the contexts then alternate between a long GPU-only and a long host-only phase and fall in step.)
-  static const int batchedMatch = getenv("MODSX_MATCH_BATCH") ? atoi(getenv("MODSX_MATCH_BATCH")) : 0;
-  if (batchedMatch) {
+  // With a `deferred` list (modsx_match_pairs) the G matching problems share the matcher's launches and verification is
+  // handed to the caller's helper threads; otherwise matching and verification alternate pair by pair.
+  if (deferred) {
     std::vector<double> pos2v[MAXB / 2];
     std::vector<modsx_tentative> tentsv[MAXB / 2];
     const double m0 = now_ms();
@@ -1117,9 +1124,9 @@ int match_pair_group(modsx_ctx *c, const modsx_image *const *imgs1, const modsx_
     }
     tMatch = now_ms() - m0;
     for (int g = 0; g < G; g++) {
-      const double m1 = now_ms();
-      verify_tentatives(oriented[2 * g], oriented[2 * g + 1], tentsv[g], pp, &res[g]);
-      tVerify += now_ms() - m1;
+      deferred->emplace_back();
+      VerifyTask &t = deferred->back();
+      t.r1.swap(oriented[2 * g]); t.r2.swap(oriented[2 * g + 1]); t.tents.swap(tentsv[g]); t.res = &res[g];
     }
   } else
   for (int g = 0; g < G; g++) {

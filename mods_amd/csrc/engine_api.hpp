@@ -43,8 +43,17 @@ int match_host_desc(modsx_ctx *c, const float *desc1, int n1, const float *desc2
                     double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out);
 void verify_tentatives(const std::vector<modsx_region> &r1, const std::vector<modsx_region> &r2,
                        const std::vector<modsx_tentative> &tents, const modsx_pair_params &pp, modsx_pair_result *res);
+// A pair whose tentatives are matched but not yet verified: modsx_match_pairs hands these to helper threads so that a
+// context's stream is fed the next group while the host runs DuplicateFiltering + LO-RANSAC of this one.
+struct VerifyTask {
+  std::vector<modsx_region> r1, r2;
+  std::vector<modsx_tentative> tents;
+  modsx_pair_result *res = nullptr;
+};
+// deferred == nullptr: verification runs inline, pair by pair.  Otherwise the G matching problems share the matcher's
+// launches and one VerifyTask per pair is appended to *deferred instead of being verified.
 int match_pair_group(modsx_ctx *c, const modsx_image *const *imgs1, const modsx_image *const *imgs2, int G,
-                     const modsx_pair_params &pp, modsx_pair_result *res);
+                     const modsx_pair_params &pp, modsx_pair_result *res, std::vector<VerifyTask> *deferred = nullptr);
 int match_pair(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_pair_params &pp,
                modsx_pair_result *res);
 

@@ -1,6 +1,13 @@
 #!/bin/bash
-for cfg in "0 8 32" "0 12 48" "0 16 64" "0 20 80" "1 8 32" "1 12 48"; do
-  set -- $cfg
-  v=$(MODSX_MATCH_BATCH=$1 python bench.py --no-cpu-baseline --workers $2 --batch $3 --steps 12 2>/dev/null | tail -1 | python -c 'import sys,json; print(round(json.loads(sys.stdin.read())["value"],1))')
-  echo "batch=$1 workers=$2 pairs/step=$3: $v"
+cp mods_amd/libmodsx.so /tmp/new.so
+run() { python bench.py --no-cpu-baseline --steps 20 2>/dev/null | tail -1 | python -c 'import sys,json; print(round(json.loads(sys.stdin.read())["value"],1))'; }
+for rep in 1 2 3; do
+for v in old new; do
+  if [ $v = old ]; then cp mods_amd/libmodsx_old.so mods_amd/libmodsx.so; else cp /tmp/new.so mods_amd/libmodsx.so; fi
+  for q in default 8; do
+    if [ $q = default ]; then unset GPU_MAX_HW_QUEUES; else export GPU_MAX_HW_QUEUES=$q; fi
+    echo "$v queues=$q: $(run)"
+  done
 done
+done
+cp /tmp/new.so mods_amd/libmodsx.so
