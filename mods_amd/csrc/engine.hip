@@ -168,7 +168,7 @@ void ctx_destroy(modsx_ctx *c) {
                     &c->descAllU8[1], &c->descAllU8b[0], &c->descAllU8b[1], &c->pos2, &c->matchRows, &c->matchWork, &c->misc, &c->scratchC, &c->needTab, &c->coordTab, &c->tileJob, &c->blurTiles, &c->nmsQueue, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps};
   for (DevBuf *b : bufs) b->release();
   for (int i = 0; i < MAXB; i++) { c->descF[i].release(); c->descU8[i].release(); }
-  PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc, &c->hNms};
+  PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc, &c->hNms, &c->hMatch};
   for (PinBuf *b : pins) b->release();
   hipFree(c->dSmmMask); hipFree(c->dOriMask); hipFree(c->dSiftMask); hipFree(c->dSiftMaskIdx); hipFree(c->dAtan); hipFree(c->dSiftBins);
   hipFree(c->dSiftW);
@@ -621,19 +621,25 @@ int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n
       }
     }
   }
-  std::vector<OriOut> res(jobs.size());
+  const OriOut *res = nullptr;   // in the pinned staging buffer
   if (!jobs.empty()) {
     int rc = upload_img_refs(c, imgs, n);
     if (rc) return rc;
     hipStream_t s = c->stream;
     size_t nj = jobs.size();
-    if (!c->oriJobs.ensure(nj * sizeof(OriJob)) || !c->oriOut.ensure(nj * sizeof(OriOut))) return MODSX_ERR_NOMEM;
-    MX_HIP(hipMemcpyAsync(c->oriJobs.p, jobs.data(), nj * sizeof(OriJob), hipMemcpyHostToDevice, s));
+    if (!c->oriJobs.ensure(nj * sizeof(OriJob)) || !c->oriOut.ensure(nj * sizeof(OriOut)) ||
+        !c->hOri.ensure(nj * (sizeof(OriJob) + sizeof(OriOut))))
+      return MODSX_ERR_NOMEM;
+    // jobs up and results down through pinned memory: pageable transfers are staged and serialised by the runtime
+    memcpy(c->hOri.p, jobs.data(), nj * sizeof(OriJob));
+    OriOut *hres = (OriOut *)((char *)c->hOri.p + nj * sizeof(OriJob));
+    res = hres;
+    MX_HIP(hipMemcpyAsync(c->oriJobs.p, c->hOri.p, nj * sizeof(OriJob), hipMemcpyHostToDevice, s));
     int maxA = maxAngNum == -1 ? 7 : std::min(maxAngNum, 7);
     ProfScope ps(c, K_ORIENT, (double)nj * 41 * 41 * 4);
     launch_orientation(s, (OriJob *)c->oriJobs.p, (OriOut *)c->oriOut.p, (int)nj, (ImgRef *)c->imgRefs.p, c->dOriMask,
                        c->dAtan, doHalfSIFT, th, maxA);
-    MX_HIP(hipMemcpyAsync(res.data(), c->oriOut.p, nj * sizeof(OriOut), hipMemcpyDeviceToHost, s));
+    MX_HIP(hipMemcpyAsync(hres, c->oriOut.p, nj * sizeof(OriOut), hipMemcpyDeviceToHost, s));
     MX_HIP(hipStreamSynchronize(s));
   }
   size_t jk = 0;
@@ -937,7 +943,9 @@ int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int
     live[nl++] = i;
   }
   if (!nl) return MODSX_OK;
-  if (!c->pos2.ensure(posB) || !c->matchRows.ensure(rowB) || !c->matchWork.ensure(workB)) return MODSX_ERR_NOMEM;
+  if (!c->pos2.ensure(posB) || !c->matchRows.ensure(rowB) || !c->matchWork.ensure(workB) || !c->hMatch.ensure(posB + rowB))
+    return MODSX_ERR_NOMEM;
+  char *hpos = (char *)c->hMatch.p, *hrow = hpos + posB;   // pinned staging: positions up, rows down
   const uint8_t *pd1[MATCH_MAXB], *pd2[MATCH_MAXB];
   const double *ppos[MATCH_MAXB];
   MatchRow *prow[MATCH_MAXB];
@@ -950,18 +958,17 @@ int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int
     ppos[k] = (const double *)((char *)c->pos2.p + posOfs[k]);
     prow[k] = (MatchRow *)((char *)c->matchRows.p + rowOfs[k]);
     pwork[k] = (char *)c->matchWork.p + workOfs[k];
-    MX_HIP(hipMemcpyAsync((void *)ppos[k], pos2Host[i], (size_t)n2[i] * 16, hipMemcpyHostToDevice, s));
+    memcpy(hpos + posOfs[k], pos2Host[i], (size_t)n2[i] * 16);
     work += 2.0 * n1[i] * (double)n2[i] * 128;
   }
+  MX_HIP(hipMemcpyAsync(c->pos2.p, hpos, posB, hipMemcpyHostToDevice, s));
   {
     ProfScope ps(c, K_MATCH, work);
     launch_match_batch(s, nl, pd1, pn1, pd2, pn2, ppos, sqminratio, contrDistSq, prow, pwork);
   }
-  std::vector<MatchRow> rows[MATCH_MAXB];
-  for (int k = 0; k < nl; k++) {
-    rows[k].resize(pn1[k]);
-    MX_HIP(hipMemcpyAsync(rows[k].data(), prow[k], (size_t)pn1[k] * sizeof(MatchRow), hipMemcpyDeviceToHost, s));
-  }
+  MX_HIP(hipMemcpyAsync(hrow, c->matchRows.p, rowB, hipMemcpyDeviceToHost, s));
+  const MatchRow *rows[MATCH_MAXB];
+  for (int k = 0; k < nl; k++) rows[k] = (const MatchRow *)(hrow + rowOfs[k]);
   MX_HIP(hipStreamSynchronize(s));
   MX_HIP(hipGetLastError());
   for (int k = 0; k < nl; k++) {
