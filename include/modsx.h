@@ -280,6 +280,9 @@ void modsx_pair_result_release(modsx_pair_result *res);
 /* A batch of independent pairs, pipelined over n_ctx contexts (one host thread + one HIP stream each), the
  * counterpart of the reference's OpenMP parallelism over images / views (mods.cpp:255-271,
  * imagerepresentation.cpp:612-622): host-side bookkeeping of one pair overlaps device work of another.
+ * Every context takes up to 4 pairs at a time and runs their 8 images as one launch set; DuplicateFiltering +
+ * LO-RANSAC of a finished group run on helper threads (one per working context) while the context's thread feeds
+ * the next group to its stream.  Results are those of n_pairs modsx_match_pair calls.
  * All contexts must live on the device that holds the images.  Returns n_pairs. */
 int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *const *imgs1,
                       const modsx_image *const *imgs2, int n_pairs, const modsx_pair_params *par,
