@@ -38,8 +38,11 @@ __global__ __launch_bounds__(256) void k_blur_hess(BlurBatch batch) {
   if (tx0 >= cols || ty0 >= rows) return;
   constexpr int n = 2 * R + 1;
   constexpr int sh = BLR_H + 2 * R, sw = TMP_W + 2 * R;
-  __shared__ __attribute__((aligned(16))) float src[SRC_H * SRC_W];   // later reused as blr
-  __shared__ __attribute__((aligned(16))) float tmp[SRC_H * TMP_W];
+  // sized for this instantiation's halo: 25 KB (R = 4) .. 31.6 KB (R = 8), i.e. 6 workgroups per CU for the two
+  // smallest kernels of an octave instead of 5 -- octave 0 of a batch of 8 images is 3072 workgroups, two full rounds
+  constexpr int SW = (sw + 3) & ~3;   // row stride, rows stay 16-byte aligned
+  __shared__ __attribute__((aligned(16))) float src[sh * SW];   // later reused as blr
+  __shared__ __attribute__((aligned(16))) float tmp[sh * TMP_W];
   float *blr = src;
   const int tid = threadIdx.x;
   // stage 1: clamped input tile
@@ -48,13 +51,13 @@ __global__ __launch_bounds__(256) void k_blur_hess(BlurBatch batch) {
     int gy = ty0 - 1 - R + ly, gx = tx0 - 1 - R + lx;
     gy = gy < 0 ? 0 : (gy > rows - 1 ? rows - 1 : gy);
     gx = gx < 0 ? 0 : (gx > cols - 1 ? cols - 1 : gx);
-    src[ly * SRC_W + lx] = jb.src[(size_t)gy * cols + gx];
+    src[ly * SW + lx] = jb.src[(size_t)gy * cols + gx];
   }
   __syncthreads();
   // stage 2: row filter, 4 outputs per thread
   for (int i = tid; i < sh * (TMP_W / 4); i += 256) {
     const int ly = i / (TMP_W / 4), g = i - ly * (TMP_W / 4);
-    const float *S = src + ly * SRC_W + 4 * g;   // output x reads S[x .. x + 2R], centre S[x + R]
+    const float *S = src + ly * SW + 4 * g;   // output x reads S[x .. x + 2R], centre S[x + R]
     float w[4 + 2 * R];
 #pragma unroll
     for (int q = 0; q < (4 + 2 * R) / 4; q++) {
