@@ -39,18 +39,41 @@ __global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out
     const bool touch = check_borders(jb.cols, jb.rows, lx, ly, a11, a12, a21, a22, W, W);
     // sample coordinates: lane j runs the f32 running sums of row j (helpers.cpp:563-585) into LDS,
     // then all lanes take the bilinear taps
-    if (lane < W) {
-      float rx = lx - (float)half * a12;
-      float ry = ly - (float)half * a22;
-      for (int j = 0; j < lane; j++) { rx += a12; ry += a22; }
-      float WX = rx - (float)half * a11;
-      float WY = ry - (float)half * a21;
+    {
+      // row starts: ONE chain of running sums (the same for every lane, a12 / a22 are uniform), lane j keeps step j --
+      // no divergent loop; then lane j walks its row with the loop unrolled when the window size is a constant
+      float cxr = lx - (float)half * a12, cyr = ly - (float)half * a22;
+      float rx = cxr, ry = cyr;
+      if (WT) {
+#pragma unroll
+        for (int j = 1; j < (WT ? WT : 1); j++) {
+          cxr += a12; cyr += a22;
+          if (lane == j) { rx = cxr; ry = cyr; }
+        }
+      } else {
+        rx = lx - (float)half * a12; ry = ly - (float)half * a22;
+        for (int j = 0; j < lane && j < W; j++) { rx += a12; ry += a22; }
+      }
+      if (lane < W) {
+        float WX = rx - (float)half * a11;
+        float WY = ry - (float)half * a21;
+        if (WT) {
+#pragma unroll
+          for (int i = 0; i < (WT ? WT : 1); i++) {
+            pa[lane * W + i] = WX;
+            pb[lane * W + i] = WY;
+            WX += a11;
+            WY += a21;
+          }
+        } else {
 #pragma unroll 1
-      for (int i = 0; i < W; i++) {
-        pa[lane * W + i] = WX;
-        pb[lane * W + i] = WY;
-        WX += a11;
-        WY += a21;
+          for (int i = 0; i < W; i++) {
+            pa[lane * W + i] = WX;
+            pb[lane * W + i] = WY;
+            WX += a11;
+            WY += a21;
+          }
+        }
       }
     }
     __syncthreads();
