@@ -77,7 +77,31 @@ __global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out
       }
     }
     __syncthreads();
-    for (int p = lane; p < WW; p += 64) simg[p] = bilinear_tap(as_global(jb.blur), jb.rows, jb.cols, pa[p], pb[p], touch);
+    if (WT) {
+      // all six taps of a lane in flight together: one memory round trip per iteration instead of six
+      constexpr int PER = ((WT ? WT : 1) * (WT ? WT : 1) + 63) / 64;
+      float sv[PER];
+      if (!touch) {
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+          const int p = lane + 64 * u;
+          sv[u] = p < WW ? bilinear_tap(as_global(jb.blur), jb.rows, jb.cols, pa[p], pb[p], false) : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+          const int p = lane + 64 * u;
+          sv[u] = p < WW ? bilinear_tap(as_global(jb.blur), jb.rows, jb.cols, pa[p], pb[p], true) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PER; u++) {
+        const int p = lane + 64 * u;
+        if (p < WW) simg[p] = sv[u];
+      }
+    } else {
+      for (int p = lane; p < WW; p += 64) simg[p] = bilinear_tap(as_global(jb.blur), jb.rows, jb.cols, pa[p], pb[p], touch);
+    }
     __syncthreads();
     for (int p = lane; p < WW; p += 64) {
       const int r = p / W, c = p - r * W;
