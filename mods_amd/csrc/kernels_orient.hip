@@ -13,6 +13,7 @@
 namespace mx {
 
 constexpr int PS = 41, PSP = 44;   // PSP: padded row stride so rows start 16-byte aligned in LDS
+constexpr int ORI_B = 14;          // taps of a patch row in flight per lane
 
 __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *out, int n, const ImgRef *imgs,
                                                     const float *orimask, const double *atanLut, int doHalf,
@@ -33,18 +34,39 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
   const bool touch = check_borders(im.cols, im.rows, jb.x, jb.y, jb.a11, jb.a12, jb.a21, jb.a22, PS, PS);
   // lane j owns row j of the patch: it runs the f32 running sums of interpolate() (helpers.cpp:563-585) along the row
   // and takes the taps as it goes, four columns in flight
-  if (lane < PS) {
-    float rx = jb.x - (float)half * jb.a12;
-    float ry = jb.y - (float)half * jb.a22;
-    for (int j = 0; j < lane; j++) { rx += jb.a12; ry += jb.a22; }
-    float WX = rx - (float)half * jb.a11;
-    float WY = ry - (float)half * jb.a21;
-    float *row = bufX + lane * PSP;
-#pragma unroll 4
-    for (int i = 0; i < PS; i++) {
-      row[i] = bilinear_tap(as_global(im.d), im.rows, im.cols, WX, WY, touch);
-      WX += jb.a11;
-      WY += jb.a21;
+  {
+    // row starts: one chain of running sums, identical in every lane (a12 / a22 are uniform); lane j keeps step j
+    float cxr = jb.x - (float)half * jb.a12, cyr = jb.y - (float)half * jb.a22;
+    float rx = cxr, ry = cyr;
+#pragma unroll
+    for (int j = 1; j < PS; j++) {
+      cxr += jb.a12; cyr += jb.a22;
+      if (lane == j) { rx = cxr; ry = cyr; }
+    }
+    if (lane < PS) {
+      float WX = rx - (float)half * jb.a11;
+      float WY = ry - (float)half * jb.a21;
+      float *row = bufX + lane * PSP;
+      // ORI_B taps of the row in flight at a time (the coordinates are cheap dependent adds, the taps are not dependent)
+      for (int i0 = 0; i0 < PS; i0 += ORI_B) {
+        float t[ORI_B];
+        if (!touch) {
+#pragma unroll
+          for (int u = 0; u < ORI_B; u++) {
+            t[u] = i0 + u < PS ? bilinear_tap(as_global(im.d), im.rows, im.cols, WX, WY, false) : 0.f;
+            WX += jb.a11; WY += jb.a21;
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < ORI_B; u++) {
+            t[u] = i0 + u < PS ? bilinear_tap(as_global(im.d), im.rows, im.cols, WX, WY, true) : 0.f;
+            WX += jb.a11; WY += jb.a21;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < ORI_B; u++)
+          if (i0 + u < PS) row[i0 + u] = t[u];
+      }
     }
   }
   __syncthreads();
