@@ -13,7 +13,7 @@
 namespace mx {
 
 constexpr int PS = 41, PSP = 44;   // PSP: padded row stride so rows start 16-byte aligned in LDS
-constexpr int ORI_B = 14;          // taps of a patch row in flight per lane
+constexpr int ORI_B = 21;          // taps of a patch row in flight per lane
 
 __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *out, int n, const ImgRef *imgs,
                                                     const float *orimask, const double *atanLut, int doHalf,
