@@ -46,12 +46,23 @@ __global__ __launch_bounds__(256) void k_blur_hess(BlurBatch batch) {
   float *blr = src;
   const int tid = threadIdx.x;
   // stage 1: clamped input tile
-  for (int i = tid; i < sh * sw; i += 256) {
-    const int ly = i / sw, lx = i - ly * sw;
-    int gy = ty0 - 1 - R + ly, gx = tx0 - 1 - R + lx;
-    gy = gy < 0 ? 0 : (gy > rows - 1 ? rows - 1 : gy);
-    gx = gx < 0 ? 0 : (gx > cols - 1 ? cols - 1 : gx);
-    src[ly * SW + lx] = jb.src[(size_t)gy * cols + gx];
+  {   // all loads of a thread are issued before the first LDS write: one memory round trip for the tile
+    constexpr int PER = (sh * sw + 255) / 256;
+    float t[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+      const int i = tid + 256 * u, ii = i < sh * sw ? i : sh * sw - 1;
+      const int ly = ii / sw, lx = ii - ly * sw;
+      int gy = ty0 - 1 - R + ly, gx = tx0 - 1 - R + lx;
+      gy = gy < 0 ? 0 : (gy > rows - 1 ? rows - 1 : gy);
+      gx = gx < 0 ? 0 : (gx > cols - 1 ? cols - 1 : gx);
+      t[u] = jb.src[(size_t)gy * cols + gx];
+    }
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+      const int i = tid + 256 * u;
+      if (i < sh * sw) { const int ly = i / sw, lx = i - ly * sw; src[ly * SW + lx] = t[u]; }
+    }
   }
   __syncthreads();
   // stage 2: row filter, 4 outputs per thread
