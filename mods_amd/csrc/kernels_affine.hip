@@ -27,7 +27,14 @@ __global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out
   __shared__ __attribute__((aligned(16))) float pa[AW_MAX * AW_MAX + 3], pb[AW_MAX * AW_MAX + 3], pc[AW_MAX * AW_MAX + 3];
   const AffJob jb = jobs[k];
   const int WW = W * W, half = W >> 1;
-  for (int i = lane; i < WW; i += 64) smask[i] = mask[i];
+  {   // the window mask: independent loads, issued together
+    constexpr int PERM = (AW_MAX * AW_MAX + 63) / 64;
+    float t[PERM];
+#pragma unroll
+    for (int u = 0; u < PERM; u++) { const int i = lane + 64 * u; t[u] = i < WW ? mask[i] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < PERM; u++) { const int i = lane + 64 * u; if (i < WW) smask[i] = t[u]; }
+  }
   float u11 = 1.0f, u12 = 0.0f, u21 = 0.0f, u22 = 1.0f, l1 = 1.0f, l2 = 1.0f;
   float era = 0.0f, erb = 0.0f;
   const float lx = jb.x / jb.pixelDistance, ly = jb.y / jb.pixelDistance;

@@ -504,7 +504,7 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
   __shared__ double sfac;
   __shared__ int schanged;
   const DescJob jb = jobs[k];
-  for (int i = tid; i < 256; i += 128) slut[i] = atanLut[i];
+  { const double l0 = atanLut[tid], l1 = atanLut[tid + 128]; slut[tid] = l0; slut[tid + 128] = l1; }
   if (tid < PS) {
     swr0[tid] = (float)wTab[tid]; swr1[tid] = (float)wTab[PS + tid];   // const float wr0 = w0[r] (siftdesc.cpp:79-81)
     swc0[tid] = wTab[tid]; swc1[tid] = wTab[PS + tid];

@@ -27,7 +27,13 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
   __shared__ __attribute__((aligned(16))) unsigned char sbin[PS * PSP];
   __shared__ double slut[256];
   __shared__ float hist[40];
-  for (int i = lane; i < 256; i += 64) slut[i] = atanLut[i];
+  {   // ATAN_LUT: four independent loads per lane, issued together
+    double t[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) t[u] = atanLut[lane + 64 * u];
+#pragma unroll
+    for (int u = 0; u < 4; u++) slut[lane + 64 * u] = t[u];
+  }
   const OriJob jb = jobs[k];
   const ImgRef im = imgs[jb.img];
   const int half = PS >> 1;
