@@ -22,19 +22,18 @@ __global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out
   const int k = blockIdx.x;
   if (k >= n) return;
   const int lane = threadIdx.x;
-  __shared__ float smask[AW_MAX * AW_MAX];
-  __shared__ float simg[AW_MAX * AW_MAX];
+  // 4.4 KB of LDS per keypoint: the kernel is a chain of dependent phases per iteration (coordinates -> taps -> gradients ->
+  // 361 ordered adds -> Jacobi), so what it needs is many keypoints in flight per CU.  The window mask stays in registers
+  // (it is the same every iteration), and the sampled window shares its buffer with the third product array: the
+  // products are staged in registers and written after every lane has taken its gradients.
   __shared__ __attribute__((aligned(16))) float pa[AW_MAX * AW_MAX + 3], pb[AW_MAX * AW_MAX + 3], pc[AW_MAX * AW_MAX + 3];
+  float *const simg = pc;
   const AffJob jb = jobs[k];
   const int WW = W * W, half = W >> 1;
-  {   // the window mask: independent loads, issued together
-    constexpr int PERM = (AW_MAX * AW_MAX + 63) / 64;
-    float t[PERM];
+  constexpr int PERM = (AW_MAX * AW_MAX + 63) / 64;
+  float vmask[PERM];
 #pragma unroll
-    for (int u = 0; u < PERM; u++) { const int i = lane + 64 * u; t[u] = i < WW ? mask[i] : 0.f; }
-#pragma unroll
-    for (int u = 0; u < PERM; u++) { const int i = lane + 64 * u; if (i < WW) smask[i] = t[u]; }
-  }
+  for (int u = 0; u < PERM; u++) { const int i = lane + 64 * u; vmask[u] = i < WW ? mask[i] : 0.f; }
   float u11 = 1.0f, u12 = 0.0f, u21 = 0.0f, u22 = 1.0f, l1 = 1.0f, l2 = 1.0f;
   float era = 0.0f, erb = 0.0f;
   const float lx = jb.x / jb.pixelDistance, ly = jb.y / jb.pixelDistance;
@@ -110,20 +109,34 @@ __global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out
       for (int p = lane; p < WW; p += 64) simg[p] = bilinear_tap(as_global(jb.blur), jb.rows, jb.cols, pa[p], pb[p], touch);
     }
     __syncthreads();
-    for (int p = lane; p < WW; p += 64) {
-      const int r = p / W, c = p - r * W;
-      float gx, gy;
-      if (c == 0) gx = simg[p + 1] - simg[p];
-      else if (c == W - 1) gx = simg[p] - simg[p - 1];
-      else gx = simg[p + 1] - simg[p - 1];
-      if (r == 0) gy = simg[p + W] - simg[p];
-      else if (r == W - 1) gy = simg[p] - simg[p - W];
-      else gy = simg[p + W] - simg[p - W];
-      const float v = smask[p];
-      const float gxy = gx * gy;
-      pa[p] = gx * gx * v;
-      pb[p] = gxy * v;
-      pc[p] = gy * gy * v;
+    {
+      float qa[PERM], qb[PERM], qc[PERM];
+#pragma unroll
+      for (int u = 0; u < PERM; u++) {
+        const int p = lane + 64 * u;
+        qa[u] = qb[u] = qc[u] = 0.f;
+        if (p < WW) {
+          const int r = p / W, c = p - r * W;
+          float gx, gy;
+          if (c == 0) gx = simg[p + 1] - simg[p];
+          else if (c == W - 1) gx = simg[p] - simg[p - 1];
+          else gx = simg[p + 1] - simg[p - 1];
+          if (r == 0) gy = simg[p + W] - simg[p];
+          else if (r == W - 1) gy = simg[p] - simg[p - W];
+          else gy = simg[p + W] - simg[p - W];
+          const float v = vmask[u];
+          const float gxy = gx * gy;
+          qa[u] = gx * gx * v;
+          qb[u] = gxy * v;
+          qc[u] = gy * gy * v;
+        }
+      }
+      __syncthreads();   // every gradient is taken: pc may replace the window
+#pragma unroll
+      for (int u = 0; u < PERM; u++) {
+        const int p = lane + 64 * u;
+        if (p < WW) { pa[p] = qa[u]; pb[p] = qb[u]; pc[p] = qc[u]; }
+      }
     }
     __syncthreads();
     float acc = 0.f;
