@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Randomised end-to-end parity sweep (GPU box): many synthetic pairs of random size / content / blob density go through
+modsx_match_pair and through the oracle; region counts, descriptors' consequences (tentatives, field by field), duplicate
+filtering and -- where oracle/_ref is built -- RANSAC inliers and H must agree.  Not part of the pytest suites (the
+oracle needs ~0.1-1 s per pair); run as `python tools/fuzz_parity.py [n_pairs] [seed0]`."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import mods_amd  # noqa: E402
+from mods_amd import synthetic  # noqa: E402
+from common import oracle_pair, normH  # noqa: E402
+from oracle import pyoracle  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    mods_amd.build()
+    pyoracle.lib()
+    O = pyoracle
+    ctx = mods_amd.Context(0)
+    rs = np.random.RandomState(seed0)
+    bad = 0
+    corner = 0
+    t0 = time.time()
+    for i in range(n):
+        rows, cols = int(rs.randint(60, 420)), int(rs.randint(60, 520))
+        nbl = int(rs.randint(20, 700))
+        seed = int(rs.randint(1, 1 << 30))
+        a, b, _ = synthetic.make_pair(rows=rows, cols=cols, nblobs=nbl, seed=seed)
+        if i % 5 == 4:   # flat-ish / noisy variants
+            a = (a * 0.25 + 90).astype(np.float32)
+        if i % 7 == 6:
+            b = np.clip(b + rs.normal(0, 6, b.shape), 0, 255).astype(np.float32)
+        ia, ib = ctx.upload(a), ctx.upload(b)
+        rseed = int(rs.randint(1, 1000))
+        got = ctx.match_pair(ia, ib, mods_amd.default_pair_params(ransac_seed=rseed))
+        ref = oracle_pair(O, a, b, seed=rseed)
+        ok = got["n_regions"] == (len(ref["d1"]), len(ref["d2"])) and got["n_tentatives"] == len(ref["tent"]) \
+            and got["n_unique"] == len(ref["uniq"])
+        if ok:
+            for f in ref["uniq"].dtype.names:
+                ok = ok and np.array_equal(got["tentatives"][f], ref["uniq"][f])
+        if ok and ref.get("ransac") is not None:
+            rr = ref["ransac"]
+            okr = np.array_equal(got["ransac_inlier"], rr["inl"]) and np.array_equal(got["verified"], rr["keep"])
+            if okr and rr["n"] > 0:
+                okr = np.abs(normH(got["H"]) - normH(rr["H"])).max() < 1e-4
+            if not okr and min(int(rr["inl"].sum()), int(got["ransac_inlier"].sum())) <= 9:
+                # known corner: with 8-9 inliers the reference's local optimisation draws 4-point inner samples and its
+                # u2h reads uninitialised stack there (Htools.c:105-113); not reproducible, see DESIGN.md section 2
+                corner += 1
+            else:
+                ok = okr
+        if not ok:
+            bad += 1
+            print("MISMATCH pair %d: %dx%d blobs %d seed %d: regions %s vs %s, tentatives %d vs %d" %
+                  (i, rows, cols, nbl, seed, got["n_regions"], (len(ref["d1"]), len(ref["d2"])), got["n_tentatives"],
+                   len(ref["tent"])), flush=True)
+        ia.free(); ib.free()
+    print("fuzz: %d pairs, %d mismatches, %d RANSAC results in the reference's 4-point-u2h corner, %.1f s" %
+          (n, bad, corner, time.time() - t0))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
