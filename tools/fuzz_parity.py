@@ -2,7 +2,8 @@
 """Randomised end-to-end parity sweep (GPU box): many synthetic pairs of random size / content / blob density go through
 modsx_match_pair and through the oracle; region counts, descriptors' consequences (tentatives, field by field), duplicate
 filtering and -- where oracle/_ref is built -- RANSAC inliers and H must agree.  Not part of the pytest suites (the
-oracle needs ~0.1-1 s per pair); run as `python tools/fuzz_parity.py [n_pairs] [seed0]`."""
+oracle needs ~0.1-1 s per pair); run as `python tools/fuzz_parity.py [n_pairs] [seed0]`; `python tools/fuzz_parity.py views [n_images] [seed0]` sweeps the
+multi-view loop instead (random tilt sets / rotation steps / blur: regions and descriptors of every view, bit for bit)."""
 import os
 import sys
 import time
@@ -14,11 +15,43 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import mods_amd  # noqa: E402
 from mods_amd import synthetic  # noqa: E402
-from common import oracle_pair, normH  # noqa: E402
+from common import oracle_pair, normH, same_records  # noqa: E402
 from oracle import pyoracle  # noqa: E402
 
 
+def fuzz_views(n, seed0):
+    mods_amd.build()
+    pyoracle.lib()
+    O = pyoracle
+    ctx = mods_amd.Context(0)
+    rs = np.random.RandomState(seed0)
+    bad = 0
+    t0 = time.time()
+    tilt_sets = ([1, 2], [1, 3, 5], [1, 2, 4, 8], [2, 6], [1, 2, 3, 4, 6], [1.5, 2.5])
+    for i in range(n):
+        rows, cols = int(rs.randint(70, 320)), int(rs.randint(70, 400))
+        a, _, _ = synthetic.make_pair(rows=rows, cols=cols, nblobs=int(rs.randint(30, 500)), seed=int(rs.randint(1, 1 << 30)))
+        tilts = [float(t) for t in tilt_sets[int(rs.randint(len(tilt_sets)))]]
+        phi = float(rs.choice([360.0, 180.0, 72.0, 50.0]))
+        sigma = float(rs.choice([0.2, 0.5, 0.8]))
+        vo = O.set_vs_pars([1.0], tilts, phi, sigma, 1, [])
+        vm = mods_amd.set_vs_pars([1.0], tilts, phi, sigma, 1, [])
+        im = ctx.upload(a)
+        rr, dr = O.detect_describe_views(a, vo)
+        rg, dg = ctx.detect_describe_views(im, vm, mods_amd.default_pair_params())
+        ok = len(rr) == len(rg) and np.array_equal(dr, dg) and same_records(rg, rr.view(mods_amd.REGION))
+        if not ok:
+            bad += 1
+            print("MISMATCH image %d: %dx%d tilts %s phi %g sigma %g: regions %d vs %d" % (i, rows, cols, tilts, phi, sigma,
+                                                                                         len(rg), len(rr)), flush=True)
+        im.free()
+    print("fuzz views: %d images, %d mismatches, %.1f s" % (n, bad, time.time() - t0))
+    return 1 if bad else 0
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "views":
+        return fuzz_views(int(sys.argv[2]) if len(sys.argv) > 2 else 20, int(sys.argv[3]) if len(sys.argv) > 3 else 500)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     mods_amd.build()
