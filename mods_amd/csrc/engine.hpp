@@ -216,8 +216,8 @@ struct modsx_ctx {
   hipStream_t stream;
   mx::Pyramid pyr[mx::MAXB];
   mx::DevBuf nmsJobs, cand, counter, affJobs, affOut, oriJobs, oriOut, descJobs, tilePrefix, taps, imgRefs, scratchA, scratchB,
-      descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], descAllU8b[2], pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps, scratchC, needTab, coordTab, tileJob, blurTiles, nmsQueue;
-  mx::PinBuf hCand, hAff, hOri, hDesc, hMisc, hNms, hMatch;
+      descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], descAllU8b[2], pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps, viewImg[mx::MAXB], scratchC, needTab, coordTab, tileJob, blurTiles, nmsQueue;
+  mx::PinBuf hCand, hAff, hOri, hDesc, hMisc, hNms, hMatch, hViewTaps;
   // constant tables on device
   float *dSmmMask = nullptr;   // 19x19 computeGaussMask
   int smmW = 0;

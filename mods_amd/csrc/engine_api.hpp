@@ -27,7 +27,11 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
 struct ProfScopeFwd;
 int set_vs_pars(const double *scale_set, int ns, const double *tilt_set, int nt, double phi_base, double InitSigma,
                 int doBlur, modsx_view *par, int cap, modsx_view *prev, int *nprev, int cap_prev);
-int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx_image **out, double *H, int *identity);
+// slot < 0: the view is a fresh allocation owned by the returned image (public API).  slot in [0, MAXB): the view lives in
+// the context's pooled buffer `slot`, nothing is allocated or freed and the call does not synchronise the stream (the
+// per-view loop: hipMalloc / hipFree synchronise the whole device, i.e. every other context's stream as well).
+int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx_image **out, double *H, int *identity,
+               int slot = -1);
 int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_view *views, int nv,
                           const modsx_pair_params &pp, int view_begin, int view_step, std::vector<modsx_region> &regs,
                           float *devF, uint8_t *devU8, size_t devCapRegions, float *hostDesc, int *viewCounts);

@@ -60,7 +60,10 @@ static void invert_affine(const double *Min, double *M) {
   M[2] = b1; M[5] = b2;
 }
 
-int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx_image **out, double *H, int *identity) {
+constexpr size_t VIEW_TAPS = 1024;   // floats of anti-alias taps (x then y) per view slot
+
+int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx_image **out, double *H, int *identity,
+               int slot) {
   double tilt = v.tilt;
   const double phi = v.phi, zoom = v.zoom, InitSigma = v.InitSigma;
   int zoomed = 0;
@@ -142,10 +145,10 @@ int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx
   memset(&wj, 0, sizeof wj);
   wj.src = gray->d; wj.dst = t0; wj.srows = h; wj.scols = w; wj.drows = h_rot; wj.dcols = w_rot; wj.cval = 128.f;
   invert_affine(R, wj.M);
-  size_t slot;
-  prof_begin(c, K_WARP, ((double)w * h + (double)rotPx) * 4, &slot);
+  size_t pslot;
+  prof_begin(c, K_WARP, ((double)w * h + (double)rotPx) * 4, &pslot);
   launch_warp_affine(s, wj);
-  prof_end(c, slot);
+  prof_end(c, pslot);
   float *cur = t0;
   if (v.doBlur) {
     int kx = floor(2.0 * 3.0 * sigma_x + 1.0);
@@ -160,28 +163,39 @@ int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx
     std::vector<float> KY = (ky == kx && fabs(sigma_x - sigma_y) < 2.220446049250313e-16) ? KX : gaussian_kernel(ky, std::max(sigma_y, 0.));
     std::vector<float> taps(KX);
     taps.insert(taps.end(), KY.begin(), KY.end());
-    if (!c->viewTaps.ensure(taps.size() * 4)) return MODSX_ERR_NOMEM;
-    MX_HIP(hipMemcpyAsync(c->viewTaps.p, taps.data(), taps.size() * 4, hipMemcpyHostToDevice, s));
-    MX_HIP(hipStreamSynchronize(s));  // taps is a stack-scoped vector
-    prof_begin(c, K_VIEW_BLUR, (double)rotPx * 16, &slot);
-    launch_blur_pass(s, t0, t1, h_rot, w_rot, (float *)c->viewTaps.p, kx, 0);
-    launch_blur_pass(s, t1, t0, h_rot, w_rot, (float *)c->viewTaps.p + kx, ky, 1);
-    prof_end(c, slot);
+    // taps travel through a pinned slice of their own (VIEW_TAPS floats per view slot), so the upload needs no host wait
+    const size_t sl = slot < 0 ? 0 : (size_t)slot;
+    if (taps.size() > VIEW_TAPS) { set_error("view anti-alias kernel too large"); return MODSX_ERR_ARG; }
+    if (!c->viewTaps.ensure((size_t)MAXB * VIEW_TAPS * 4) || !c->hViewTaps.ensure((size_t)MAXB * VIEW_TAPS * 4)) return MODSX_ERR_NOMEM;
+    float *hT = (float *)c->hViewTaps.p + sl * VIEW_TAPS, *dT = (float *)c->viewTaps.p + sl * VIEW_TAPS;
+    memcpy(hT, taps.data(), taps.size() * 4);
+    MX_HIP(hipMemcpyAsync(dT, hT, taps.size() * 4, hipMemcpyHostToDevice, s));
+    prof_begin(c, K_VIEW_BLUR, (double)rotPx * 16, &pslot);
+    launch_blur_pass(s, t0, t1, h_rot, w_rot, dT, kx, 0);
+    launch_blur_pass(s, t1, t0, h_rot, w_rot, dT + kx, ky, 1);
+    prof_end(c, pslot);
     cur = t0;
   }
   modsx_image *im = new modsx_image();
-  im->rows = oh; im->cols = ow; im->owned = true; im->d = nullptr;
-  if (hipMalloc(&im->d, (size_t)ow * oh * 4) != hipSuccess) { delete im; set_error("hipMalloc view"); return MODSX_ERR_NOMEM; }
+  im->rows = oh; im->cols = ow; im->d = nullptr;
+  if (slot >= 0) {
+    if (!c->viewImg[slot].ensure((size_t)ow * oh * 4)) { delete im; return MODSX_ERR_NOMEM; }
+    im->d = (float *)c->viewImg[slot].p; im->owned = false;
+  } else {
+    im->owned = true;
+    if (hipMalloc(&im->d, (size_t)ow * oh * 4) != hipSuccess) { delete im; set_error("hipMalloc view"); return MODSX_ERR_NOMEM; }
+  }
   double Wz[6] = {0, 0, 0, 0, 0, 0};
   if (vertical_tilt) { Wz[0] = 1.0 / kH; Wz[4] = 1.0 / (tilt * kV); }
   else { Wz[0] = 1.0 / (tilt * kH); Wz[4] = 1.0 / kV; }
   memset(&wj, 0, sizeof wj);
   wj.src = cur; wj.dst = im->d; wj.srows = h_rot; wj.scols = w_rot; wj.drows = oh; wj.dcols = ow; wj.cval = 128.f;
   invert_affine(Wz, wj.M);
-  prof_begin(c, K_WARP, ((double)rotPx + (double)ow * oh) * 4, &slot);
+  prof_begin(c, K_WARP, ((double)rotPx + (double)ow * oh) * 4, &pslot);
   launch_warp_affine(s, wj);
-  prof_end(c, slot);
-  MX_HIP(hipStreamSynchronize(s));  // viewTmp is reused by the next view
+  prof_end(c, pslot);
+  // viewTmp is reused by the next view: stream order makes that safe on the device; only the public entry point waits
+  if (slot < 0) MX_HIP(hipStreamSynchronize(s));
   MX_HIP(hipGetLastError());
   *out = im;
   return MODSX_OK;
@@ -210,7 +224,7 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
     for (int i = 0; i < n; i++) vimg[i] = nullptr;
     for (int i = 0; i < n && !rc; i++) {
       const modsx_view &v = views[take[g0 + i]];
-      rc = synth_view(c, gray, v, &vimg[i], Hs[i], &ident[i]);
+      rc = synth_view(c, gray, v, &vimg[i], Hs[i], &ident[i], i);
       cimg[i] = vimg[i];
       tilts[i] = ident[i] ? 1.0 : fabs(v.tilt);   // SynthImage::tilt / zoom as GenerateSynthImageCorr leaves them
       zooms[i] = ident[i] ? 1.0 : v.zoom;
