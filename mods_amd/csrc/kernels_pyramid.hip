@@ -216,7 +216,8 @@ MX_D bool is_min9(float val, const float *p, int cols) {
 constexpr int NMS_ROWS = 16, NMS_LW = 66, NMS_REFINE_BLOCKS = 16;   // refine blocks per sub-queue
 
 // sub-pixel localisation of one 3x3x3 extremum (pyramid.cpp:341-419): <= 5 Newton steps, edge / value tests, record
-MX_D void nms_refine(const NmsBatch &batch, const NmsJob &jb, int r, int c, Candidate *out, unsigned *counter, unsigned cap) {
+// Returns true and fills `k` for an accepted extremum; the caller appends the records of a wavefront with one atomic.
+MX_D bool nms_refine(const NmsBatch &batch, const NmsJob &jb, int r, int c, Candidate &k) {
   const int rows = jb.rows, cols = jb.cols;
   const int r0 = r, c0 = c;
   float b[3] = {0.f, 0.f, 0.f};
@@ -233,7 +234,7 @@ MX_D void nms_refine(const NmsBatch &batch, const NmsJob &jb, int r, int c, Cand
     float dxy = 0.25f * (c2[c + 1] - c2[c - 1] - c0p[c + 1] + c0p[c - 1]);
     if (iter == 0) {
       float edgeScore = (dxx + dyy) * (dxx + dyy) / (dxx * dyy - dxy * dxy);
-      if ((double)edgeScore >= batch.edgeScoreThreshold || edgeScore < 0) return;
+      if ((double)edgeScore >= batch.edgeScoreThreshold || edgeScore < 0) return false;
     }
     float dxs = 0.25f * (h1[c + 1] - h1[c - 1] - l1[c + 1] + l1[c - 1]);
     float dys = 0.25f * (h2[c] - h0[c] - l2[c] + l0[c]);
@@ -243,15 +244,15 @@ MX_D void nms_refine(const NmsBatch &batch, const NmsJob &jb, int r, int c, Cand
     float ds = 0.5f * (h1[c] - l1[c]);
     b[0] = -dx; b[1] = -dy; b[2] = -ds;
     solve3(A, b);
-    if (isnan(b[0]) || isnan(b[1]) || isnan(b[2])) return;
+    if (isnan(b[0]) || isnan(b[1]) || isnan(b[2])) return false;
     val = c1[c] + 0.5f * (dx * b[0] + dy * b[1] + ds * b[2]);
-    if ((double)b[0] > 0.6) { if (c < cols - 3) nc++; else return; }
-    if ((double)b[1] > 0.6) { if (r < rows - 3) nr++; else return; }
-    if ((double)b[0] < -0.6) { if (c > 3) nc--; else return; }
-    if ((double)b[1] < -0.6) { if (r > 3) nr--; else return; }
+    if ((double)b[0] > 0.6) { if (c < cols - 3) nc++; else return false; }
+    if ((double)b[1] > 0.6) { if (r < rows - 3) nr++; else return false; }
+    if ((double)b[0] < -0.6) { if (c > 3) nc--; else return false; }
+    if ((double)b[1] < -0.6) { if (r > 3) nr--; else return false; }
     if (nr == r && nc == c) break;
   }
-  if (fabsf(b[0]) > 1.5f || fabsf(b[1]) > 1.5f || fabsf(b[2]) > 1.5f || fabsf(val) < batch.finalTh) return;
+  if (fabsf(b[0]) > 1.5f || fabsf(b[1]) > 1.5f || fabsf(b[2]) > 1.5f || fabsf(val) < batch.finalTh) return false;
   int type;
   if (val < 0) type = 2;
   else {
@@ -259,13 +260,10 @@ MX_D void nms_refine(const NmsBatch &batch, const NmsJob &jb, int r, int c, Cand
     float Lxx = (p[-1] - 2 * p[0] + p[1]);
     type = (Lxx < 0) ? 0 : 1;
   }
-  unsigned slot = atomicAdd(counter, 1u);
-  if (slot >= cap) return;
-  Candidate k;
   k.img = jb.img; k.octave = jb.octave; k.level = jb.level; k.type = type;
   k.r0 = r0; k.c0 = c0; k.r = r; k.c = c;
   k.b0 = b[0]; k.b1 = b[1]; k.b2 = b[2]; k.val = val;
-  out[slot] = k;
+  return true;
 }
 
 __global__ __launch_bounds__(256) void k_nms_localize(NmsBatch batch, const NmsJob *__restrict__ jobs,
@@ -311,6 +309,14 @@ __global__ __launch_bounds__(256) void k_nms_localize(NmsBatch batch, const NmsJ
   float mx[4], mn[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) { mx[j] = -INFINITY; mn[j] = INFINITY; }
+  // a wavefront none of whose 256 pixels passes the threshold on its own value (flat image areas) skips the stencil
+  bool any = false;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const float v0 = sp[0][4 * g + j + 1][lc + 1];
+    any = any || v0 > batch.posTh || v0 < batch.negTh;
+  }
+  if (__ballot(any))
 #pragma unroll
   for (int pl = 0; pl < 3; pl++) {
     float hmax[6], hmin[6];
@@ -402,9 +408,25 @@ __global__ __launch_bounds__(256) void k_nms_refine(NmsBatch batch, const NmsJob
   const unsigned sq = blockIdx.y, qsub = qcap / NMS_QUEUES;
   unsigned n = qcount[32 * sq];
   n = n < qsub ? n : qsub;
-  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const int4 q = queue[(size_t)sq * qsub + i];
-    nms_refine(batch, jobs[q.x], q.y, q.z, out, counter, cap);
+  const int lane = threadIdx.x & 63;
+  for (unsigned i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {   // wave-uniform trip count
+    const unsigned i = i0 + threadIdx.x;
+    Candidate k;
+    bool ok = false;
+    if (i < n) {
+      const int4 q = queue[(size_t)sq * qsub + i];
+      ok = nms_refine(batch, jobs[q.x], q.y, q.z, k);
+    }
+    // one atomic per wavefront: the accepted records take consecutive slots
+    const unsigned long long m = __ballot(ok);
+    if (m) {
+      unsigned base = 0;
+      const int leader = __ffsll((long long)m) - 1;
+      if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
+      base = __shfl(base, leader);
+      const unsigned slot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+      if (ok && slot < cap) out[slot] = k;
+    }
   }
 }
 
