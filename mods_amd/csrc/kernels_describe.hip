@@ -495,8 +495,13 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
   __shared__ __attribute__((aligned(16))) float bufA[PS * PSP];   // WX (direct branch), compacted masked values, later val
   __shared__ __attribute__((aligned(16))) double slut[256];   // ATAN_LUT (2 KB) next to the CU
   __shared__ __attribute__((aligned(16))) unsigned char sb0[PS * PSP];   // orientation bin bo0 % 8 of every pixel
-  __shared__ float swr0[PS], swr1[PS], sfr[PS];
-  __shared__ int4 smap[PS];
+  __shared__ float swr0[PS], swr1[PS];
+  // 1 KB used twice: the resampling table of the sampling stage (smap, sfr), later the per-step weighted values of the
+  // gather (sv)
+  __shared__ __attribute__((aligned(16))) unsigned char sraw[1024];
+  int4 *const smap = reinterpret_cast<int4 *>(sraw);
+  float *const sfr = reinterpret_cast<float *>(sraw + 672);
+  float(*const sv)[64] = reinterpret_cast<float(*)[64]>(sraw);
   __shared__ double swc0[PS], swc1[PS];
   // the descriptor vector and its partial sums take the place of the ATAN_LUT, which is dead once the gradients are taken
   double *const vec = slut, *const part = slut + 128;
@@ -665,35 +670,46 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
   {
     const int rb = tid >> 5, cb = (tid >> 3) & 3, ob = tid & 7, obm = (ob + 7) & 7;
     double acc = 0.0;
-    double wcol[16];   // w1[c] for the first eight columns of the block, w0[c] for the last eight
-#pragma unroll
-    for (int j = 0; j < 16; j++) wcol[j] = j < 8 ? swc1[8 * cb + j] : swc0[8 * cb + j];
+    // Step rr touches rows 8 rb + rr (rb = 0..3) with one row weight each; a pixel's column weight is w1[c] in the block
+    // whose first half holds column c and w0[c] in the block whose second half does.  The product
+    // wr * (float)(w[c] * val) is the same for the 8 orientation lanes of a bin block, so the 128 threads first form the
+    // 4 rows x (w1: columns 0..31, w0: columns 8..39) values of the step once (clamped to 0 when not > 0: such a pixel
+    // adds nothing in the reference, and +0.0 here) and the bins then read them.
 #pragma unroll 1
     for (int rr = 0; rr < 16; rr++) {
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int i = tid + 128 * u, rbi = i >> 6, vc = i & 63;
+        const int col = vc < 32 ? vc : vc - 24, r = 8 * rbi + rr;
+        const float wrr = rr < 8 ? swr1[r] : swr0[r];
+        const double wc = vc < 32 ? swc1[col] : swc0[col];
+        const float wcv = (float)(wc * (double)bufA[r * PSP + col]);
+        const float v = wrr * wcv;
+        sv[rbi][vc] = v > 0 ? v : 0.f;
+      }
+      __syncthreads();
       const int r = 8 * rb + rr;
-      const float wr = rr < 8 ? swr1[r] : swr0[r];
       const int q0 = r * PSP + 8 * cb;
 #pragma unroll
       for (int seg = 0; seg < 4; seg++) {
         const int q = q0 + 4 * seg;
-        const float4 vv = *reinterpret_cast<const float4 *>(bufA + q);
+        const float4 vv = *reinterpret_cast<const float4 *>(&sv[rb][(seg < 2 ? 0 : 24) + 8 * cb + 4 * seg]);
         const float4 w1v = *reinterpret_cast<const float4 *>(bufB + q);
         const unsigned b4 = *reinterpret_cast<const unsigned *>(sb0 + q);
-        const float vals[4] = {vv.x, vv.y, vv.z, vv.w};
+        const float vs[4] = {vv.x, vv.y, vv.z, vv.w};
         const float w1s[4] = {w1v.x, w1v.y, w1v.z, w1v.w};
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const int b0 = (int)((b4 >> (8 * e)) & 0xff);
           const float wo1 = w1s[e];
-          const float wcv = (float)(wcol[4 * seg + e] * (double)vals[e]);
-          const float v = wr * wcv;
-          // bin b0 takes v * wo0, bin (b0 + 1) % 8 takes v * wo1, nothing when v <= 0; a term that does not belong to
-          // this thread's bin is added as +0.0, which leaves the (non-negative) f64 accumulator as it is
+          // bin b0 takes v * wo0, bin (b0 + 1) % 8 takes v * wo1; a term that does not belong to this thread's bin is
+          // added as +0.0, which leaves the (non-negative) f64 accumulator as it is
           const bool m0 = b0 == ob, m1 = b0 == obm;
-          const float t = v * (m0 ? 1.0f - wo1 : wo1);
-          acc += (double)(((m0 || m1) && v > 0) ? t : 0.f);
+          const float t = vs[e] * (m0 ? 1.0f - wo1 : wo1);
+          acc += (double)((m0 || m1) ? t : 0.f);
         }
       }
+      __syncthreads();
     }
     vec[tid] = acc;
   }
