@@ -214,6 +214,10 @@ def main():
             roof["note_bound"] = ("this kernel's limiter is VALU issue (SQ_INSTS_VALU x 4 cycles over SIMD cycles = %s in "
                                   "profiles/, ordered f32/f64 sums per region), not HBM; the schema only offers hbm|mfma, "
                                   "so its HBM fraction is reported as is" % VALU_BOUND[name])
+        if name == "patch_sample":
+            roof["note_bound"] = ("HBM bytes are this kernel's algorithmic work, but its limiter is the texture addresser: "
+                                  "every lane of the 2 x 2 bilinear gathers is its own L1 access (TA busy 55-80 %, "
+                                  "2.8 L1 accesses per sample, profiles/ and DESIGN.md section 5)")
         roof["kernels_single_stream_ms_per_pair"] = {k: v["ms"] / min(args.batch, 8) for k, v in iso.items()}
         out = {
             "metric": "image-pairs/sec (1024x768, HessAff+RootSIFT, FGINN match, LO-RANSAC H)",
