@@ -335,7 +335,7 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
   hipStream_t s = c->stream;
   if (!c->cand.ensure((size_t)CAND_CAP * sizeof(Candidate)) || !c->nmsQueue.ensure((size_t)CAND_CAP * 16)) return MODSX_ERR_NOMEM;
   if (!c->counter.ensure((NMS_QUEUES + 1) * 128)) return MODSX_ERR_NOMEM;
-  MX_HIP(hipMemsetAsync(c->counter.p, 0, 4, s));
+  MX_HIP(hipMemsetAsync(c->counter.p, 0, 8, s));   // [0] accepted candidates, [1] extremum-queue overflow flag
   // thresholds, affinedetectors/pyramid.h:47-67 (DET_HESSIAN)
   NmsBatch nb;
   memset(&nb, 0, sizeof nb);
@@ -409,10 +409,10 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
                (unsigned *)c->counter.p, CAND_CAP);
   }
   if (!c->hMisc.ensure(64)) return MODSX_ERR_NOMEM;
-  MX_HIP(hipMemcpyAsync(c->hMisc.p, c->counter.p, 4, hipMemcpyDeviceToHost, s));
+  MX_HIP(hipMemcpyAsync(c->hMisc.p, c->counter.p, 8, hipMemcpyDeviceToHost, s));
   MX_HIP(hipStreamSynchronize(s));
   unsigned cnt = *(unsigned *)c->hMisc.p;
-  if (cnt > CAND_CAP) { set_error("candidate buffer overflow"); return MODSX_ERR_NOMEM; }
+  if (cnt > CAND_CAP || ((unsigned *)c->hMisc.p)[1]) { set_error("candidate buffer overflow"); return MODSX_ERR_NOMEM; }
   if (!c->hCand.ensure((size_t)std::max(1u, cnt) * sizeof(Candidate))) return MODSX_ERR_NOMEM;
   if (cnt) {
     MX_HIP(hipMemcpyAsync(c->hCand.p, c->cand.p, (size_t)cnt * sizeof(Candidate), hipMemcpyDeviceToHost, s));

@@ -268,7 +268,7 @@ MX_D bool nms_refine(const NmsBatch &batch, const NmsJob &jb, int r, int c, Cand
 
 __global__ __launch_bounds__(256) void k_nms_localize(NmsBatch batch, const NmsJob *__restrict__ jobs,
                                                       const int *__restrict__ tilePrefix, const int *__restrict__ tileJob,
-                                                      int4 *queue, unsigned *qcount, unsigned qcap) {
+                                                      int4 *queue, unsigned *qcount, unsigned qcap, unsigned *overflow) {
   const int tile = blockIdx.x;
   const int jid = tileJob[tile];
   const NmsJob jb = jobs[jid];
@@ -355,7 +355,10 @@ __global__ __launch_bounds__(256) void k_nms_localize(NmsBatch batch, const NmsJ
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < 4; j++)
-    if (slot[j] != 0xffffffffu && sbase + slot[j] < qsub) queue[(size_t)sq * qsub + sbase + slot[j]] = make_int4(jid, r0 + 4 * g + j, c, 0);
+    if (slot[j] != 0xffffffffu) {
+      if (sbase + slot[j] < qsub) queue[(size_t)sq * qsub + sbase + slot[j]] = make_int4(jid, r0 + 4 * g + j, c, 0);
+      else atomicOr(overflow, 1u);   // the host turns this into an error: dropping extrema silently would change the result
+    }
 }
 
 // (B+G+R)/3 of GenerateSynthImageCorr (synth-detection.cpp:253-262): a cv::MatExpr that OpenCV
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(256) void k_nms_refine(NmsBatch batch, const NmsJob
 void launch_nms(hipStream_t s, const NmsBatch &b, const NmsJob *jobs, const int *tilePrefix, const int *tileJob, int nj,
                 int nTiles, int4 *queue, unsigned *qcount, unsigned qcap, Candidate *out, unsigned *counter, unsigned cap) {
   if (nj <= 0 || nTiles <= 0) return;
-  hipLaunchKernelGGL(k_nms_localize, dim3(nTiles), dim3(256), 0, s, b, jobs, tilePrefix, tileJob, queue, qcount, qcap);
+  hipLaunchKernelGGL(k_nms_localize, dim3(nTiles), dim3(256), 0, s, b, jobs, tilePrefix, tileJob, queue, qcount, qcap, counter + 1);
   hipLaunchKernelGGL(k_nms_refine, dim3(NMS_REFINE_BLOCKS, NMS_QUEUES), dim3(256), 0, s, b, jobs, queue, qcount, qcap, out, counter, cap);
 }
 // *ptr = (unsigned char)*in_ptr of DetectMSERs (extrema.cpp:401-403): f32 -> u8 by truncation, 4 pixels per thread
