@@ -285,29 +285,22 @@ __global__ __launch_bounds__(BLUR_T, 8) void k_blur_rows_lds(const BlurTile *__r
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < NC; i += BLUR_T) sneed[i] = needTab[bt.needOfs + i];
   const float *A = src + bt.srcOfs;
-  // a wave parks rows wave, wave + 4, ...; the loads of up to FILL_MLP (row, 64-column chunk) steps are all issued before the
-  // first LDS write, so a typical tile pays ONE memory round trip for its inputs; (row, chunk) advance in scalar registers
+  // a wave parks rows wave, wave + 4, ... with direct global -> LDS loads (global_load_lds_dword: per-lane source address,
+  // destination = a wave-uniform LDS base + 4 * lane): no staging registers, no LDS write pass, and all of a tile's loads
+  // are in flight together
   {
-    const int xit = (RW + 63) >> 6;
-    int ri = wave, xi = 0;
-    while (ri < nr) {
-      float t[FILL_MLP];
-      int r1 = ri, x1 = xi;
-#pragma unroll
-      for (int u = 0; u < FILL_MLP; u++) {
-        const int x = lane + (x1 << 6);
+    typedef const float __attribute__((address_space(1))) *gptr;
+    typedef float __attribute__((address_space(3))) *lptr;
+    for (int ri = wave; ri < nr; ri += BLUR_W) {
+      const float *a = A + (size_t)ri * P;
+      for (int x0 = 0; x0 < RW; x0 += 64) {
+        const int x = x0 + lane;
         int cc = x - R;
         cc = cc < 0 ? 0 : (cc > P - 1 ? P - 1 : cc);
-        t[u] = (r1 < nr && x < RW) ? A[r1 * P + cc] : 0.f;
-        if (++x1 == xit) { x1 = 0; r1 += BLUR_W; }
-      }
-#pragma unroll
-      for (int u = 0; u < FILL_MLP; u++) {
-        const int x = lane + (xi << 6);
-        if (ri < nr && x < RW) win[ri * RW + x] = t[u];
-        if (++xi == xit) { xi = 0; ri += BLUR_W; }
+        if (x < RW) __builtin_amdgcn_global_load_lds((gptr)(a + cc), (lptr)(win + ri * RW + x0), 4, 0, 0);
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
   // A thread forms 4 PAIRS of horizontally adjacent outputs (needed columns 2m, 2m+1 -- the host checks that such pairs are
@@ -377,27 +370,19 @@ __device__ __forceinline__ void blur_cols_tile(const BlurTile &bt, float *win, i
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < NC; i += BLUR_T) sneed[i] = needTab[bt.needOfs + i];
   const float *T = src + bt.srcOfs;   // P x NC
-  {
-    const int xit = (NC + 63) >> 6;
-    int si = wave, xi = 0;
-    while (si < S) {
-      float t[FILL_MLP];
-      int s1 = si, x1 = xi;
-#pragma unroll
-      for (int u = 0; u < FILL_MLP; u++) {
-        const int x = lane + (x1 << 6);
-        int rr = lo + s1;
-        rr = rr < 0 ? 0 : (rr > P - 1 ? P - 1 : rr);
-        t[u] = (s1 < S && x < NC) ? T[rr * NC + x] : 0.f;
-        if (++x1 == xit) { x1 = 0; s1 += BLUR_W; }
-      }
-#pragma unroll
-      for (int u = 0; u < FILL_MLP; u++) {
-        const int x = lane + (xi << 6);
-        if (si < S && x < NC) win[si * LS + x] = t[u];
-        if (++xi == xit) { xi = 0; si += BLUR_W; }
+  {   // direct global -> LDS loads, one parked row (64-column chunk) per instruction
+    typedef const float __attribute__((address_space(1))) *gptr;
+    typedef float __attribute__((address_space(3))) *lptr;
+    for (int si = wave; si < S; si += BLUR_W) {
+      int rr = lo + si;
+      rr = rr < 0 ? 0 : (rr > P - 1 ? P - 1 : rr);
+      const float *a = T + (size_t)rr * NC;
+      for (int x0 = 0; x0 < NC; x0 += 64) {
+        const int x = x0 + lane;
+        if (x < NC) __builtin_amdgcn_global_load_lds((gptr)(a + x), (lptr)(win + si * LS + x0), 4, 0, 0);
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
   // pairs of horizontally adjacent outputs again: (ri, 2m) and (ri, 2m+1) read adjacent LDS words in every parked row
