@@ -27,7 +27,8 @@ typedef enum modsx_status {
   MODSX_ERR_ARG = -1,
   MODSX_ERR_DEVICE = -2,
   MODSX_ERR_NOMEM = -3,
-  MODSX_ERR_INTERNAL = -4
+  MODSX_ERR_INTERNAL = -4,
+  MODSX_ERR_CAPACITY = -5   /* a caller-provided (or pooled) output buffer is too small: retry with a larger one */
 } modsx_status;
 
 /* detection_mode_t, detectors/structures.hpp:11-15 */
@@ -224,7 +225,9 @@ int modsx_describe_regions(modsx_ctx *ctx, const modsx_image *img, const modsx_r
 /* int MatchFlannFGINN(const AffineRegionList &list1, const AffineRegionList &list2,
  *                     TentativeCorrespListExt &corresp, const MatchPars &par, const int nn = 50)
  * matching/matching.hpp:268-269, .cpp:357-461 with vector_matcher = linear, vector_dist = L2.
- * desc*: [n][128] f32 holding integers 0..255; pos2: [n2][2] reproj_kp x,y of list2. */
+ * desc*: [n][128] f32 holding integers 0..255 (anything else -- fractions, out-of-range values, NaN -- is refused with
+ * MODSX_ERR_ARG: the int8 matrix-core path is exact only on that domain); pos2: [n2][2] reproj_kp x,y of list2.
+ * A ratio >= 1 (the PDF branch, matching.cpp:397-428, unused by every shipped configuration) is refused as well. */
 int modsx_match_fginn(modsx_ctx *ctx, const float *desc1, int n1, const float *desc2, int n2, const double *pos2,
                       double ratio, double contradDist, int nn, modsx_tentative **out);
 

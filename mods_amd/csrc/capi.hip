@@ -304,6 +304,7 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
   NEED(ctxs); NEED(par); NEED(results);
   if (n_ctx <= 0 || n_pairs < 0 || (n_pairs > 0 && (!imgs1 || !imgs2))) { mx::set_error("modsx_match_pairs: bad argument"); return MODSX_ERR_ARG; }
   for (int i = 0; i < n_ctx; i++) NEED(ctxs[i]);
+  for (int i = 0; i < n_pairs; i++) memset(&results[i], 0, sizeof results[i]);   // no result owns arrays before its group ran
   std::atomic<int> next(0), failed(0);
   std::string firstErr;
   std::mutex *mu = new std::mutex();
@@ -340,6 +341,7 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
     hipSetDevice(c->dev);
     std::vector<mx::VerifyTask> tasks;
     for (;;) {
+      if (failed.load()) break;   // another group failed: the batch is lost, stop feeding the stream
       int i = next.fetch_add(group);
       if (i >= n_pairs) break;
       const int g = (n_pairs - i) < group ? (n_pairs - i) : group;
@@ -366,7 +368,12 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
   vq.cv.notify_all();
   for (auto &t : hth) t.join();
   delete mu;
-  if (failed.load()) { mx::set_error(firstErr); return failed.load(); }
+  if (failed.load()) {
+    // a failed batch returns no results: release what the successful groups already own
+    for (int i = 0; i < n_pairs; i++) modsx_pair_result_release(&results[i]);
+    mx::set_error(firstErr);
+    return failed.load();
+  }
   return n_pairs;
 }
 
@@ -409,26 +416,20 @@ int modsx_detect_describe_views(modsx_ctx *ctx, const modsx_image *img, const mo
   hipSetDevice(ctx->dev);
   std::vector<modsx_region> r;
   size_t cap = dev_desc_u8 ? (size_t)dev_cap : ((size_t)1 << 16);
+  std::vector<int> counts(nviews, 0);
   int rc;
   for (;;) {
     if (!ctx->descAllF[0].ensure(cap * 512)) return MODSX_ERR_NOMEM;
     uint8_t *du8 = (uint8_t *)dev_desc_u8;
     if (!du8) { if (!ctx->descAllU8[0].ensure(cap * 128)) return MODSX_ERR_NOMEM; du8 = (uint8_t *)ctx->descAllU8[0].p; }
     rc = detect_describe_views(ctx, img, views, nviews, *par, view_begin, view_step, r, (float *)ctx->descAllF[0].p, du8,
-                               cap, nullptr, view_counts);
-    if (rc == MODSX_ERR_NOMEM && !dev_desc_u8 && cap < ((size_t)1 << 24)) { cap *= 4; continue; }
+                               cap, nullptr, counts.data());
+    if (rc == MODSX_ERR_CAPACITY && !dev_desc_u8 && cap < ((size_t)1 << 24)) { cap *= 4; continue; }
     break;
   }
   if (rc) return rc;
-  if (view_step <= 1 && view_begin == 0) {
-    size_t start = 0;
-    while (start < r.size()) {
-      size_t end = start;
-      while (end < r.size() && r[end].img_id == r[start].img_id) end++;
-      for (size_t i = start; i < end; i++) { r[i].id += (int)start; r[i].parent_id += (int)start; }
-      start = end;
-    }
-  }
+  if (view_counts) memcpy(view_counts, counts.data(), sizeof(int) * nviews);
+  if (view_step <= 1 && view_begin == 0) rebase_ids(r, counts.data(), nviews, 0);
   if (desc) {
     *desc = (float *)malloc(std::max<size_t>(1, r.size()) * 512);
     if (!r.empty()) {
@@ -536,7 +537,9 @@ int modsx_load_regions(const char *path, const char *det_name, const char *desc_
   std::vector<modsx_region> r;
   std::vector<float> d;
   std::string fd, fs;
-  int rc = load_regions(path, det_name, desc_name, r, d, dim, &fd, &fs);
+  int rc;
+  try { rc = load_regions(path, det_name, desc_name, r, d, dim, &fd, &fs); }
+  catch (const std::exception &e) { mx::set_error(std::string("modsx_load_regions: ") + e.what()); return MODSX_ERR_NOMEM; }
   if (rc) return rc;
   *regs = (modsx_region *)malloc(sizeof(modsx_region) * std::max<size_t>(1, r.size()));
   *desc = (float *)malloc(sizeof(float) * std::max<size_t>(1, d.size()));

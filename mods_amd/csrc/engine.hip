@@ -930,16 +930,16 @@ int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int
   hipStream_t s = c->stream;
   const double sqminratio = ratioT * ratioT, contrDistSq = contradDist * contradDist;
   if (!(sqminratio < 1.0)) { set_error("match ratio >= 1 (PDF mode of MatchFlannFGINN) is not supported"); return MODSX_ERR_ARG; }
+  if (nn < 2) { set_error("match_device_batch: nn < 2"); return MODSX_ERR_ARG; }
   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
   size_t posOfs[MATCH_MAXB], rowOfs[MATCH_MAXB], workOfs[MATCH_MAXB], posB = 0, rowB = 0, workB = 0;
   int live[MATCH_MAXB], nl = 0;
   for (int i = 0; i < nb; i++) {
     out[i].clear();
     if (n1[i] <= 0 || n2[i] <= 0) continue;
-    int S_, tps_;
     posOfs[nl] = posB; posB += up((size_t)n2[i] * 16);
     rowOfs[nl] = rowB; rowB += up((size_t)n1[i] * sizeof(MatchRow));
-    workOfs[nl] = workB; workB += up(match_workspace_bytes(n1[i], n2[i], &S_, &tps_) + 4096);
+    workOfs[nl] = workB; workB += up(match_workspace_bytes(n1[i], n2[i], nn));
     live[nl++] = i;
   }
   if (!nl) return MODSX_OK;
@@ -964,7 +964,7 @@ int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int
   MX_HIP(hipMemcpyAsync(c->pos2.p, hpos, posB, hipMemcpyHostToDevice, s));
   {
     ProfScope ps(c, K_MATCH, work);
-    launch_match_batch(s, nl, pd1, pn1, pd2, pn2, ppos, sqminratio, contrDistSq, prow, pwork);
+    launch_match_batch(s, nl, pd1, pn1, pd2, pn2, ppos, sqminratio, contrDistSq, nn, prow, pwork);
   }
   MX_HIP(hipMemcpyAsync(hrow, c->matchRows.p, rowB, hipMemcpyDeviceToHost, s));
   const MatchRow *rows[MATCH_MAXB];
@@ -996,12 +996,18 @@ int match_device(modsx_ctx *c, const uint8_t *d1, int n1, const uint8_t *d2, int
   return match_device_batch(c, 1, &d1, &n1, &d2, &n2, &pos2Host, ratioT, contradDist, nn, &out);
 }
 
-static void desc_f32_to_u8(const float *f, size_t n, uint8_t *u) {
+// The matcher computes on u8: the reference's SIFT-family descriptors hold the integers 0..255
+// ((int)(512 v + 0.5) clamped, siftdesc.cpp:218-274).  Anything else (fractions, values out of range, NaN) would be
+// matched with different distances than FLANN's float L2, so it is refused instead of being truncated silently.
+static bool desc_f32_to_u8(const float *f, size_t n, uint8_t *u) {
+  bool ok = true;
   for (size_t i = 0; i < n; i++) {
-    float v = f[i];
-    int b = (int)v;
-    u[i] = (uint8_t)(b < 0 ? 0 : (b > 255 ? 255 : b));
+    const float v = f[i];
+    const int b = (v >= 0.f && v <= 255.f) ? (int)v : -1;
+    ok = ok && b >= 0 && (float)b == v;
+    u[i] = (uint8_t)(b < 0 ? 0 : b);
   }
+  return ok;
 }
 
 int match_host_desc(modsx_ctx *c, const float *desc1, int n1, const float *desc2, int n2, const double *pos2,
@@ -1009,8 +1015,10 @@ int match_host_desc(modsx_ctx *c, const float *desc1, int n1, const float *desc2
   out.clear();
   if (n1 == 0 || n2 == 0) return MODSX_OK;
   std::vector<uint8_t> u1((size_t)n1 * 128), u2((size_t)n2 * 128);
-  desc_f32_to_u8(desc1, u1.size(), u1.data());
-  desc_f32_to_u8(desc2, u2.size(), u2.data());
+  if (!desc_f32_to_u8(desc1, u1.size(), u1.data()) || !desc_f32_to_u8(desc2, u2.size(), u2.data())) {
+    set_error("modsx_match_fginn: descriptors must hold the integers 0..255 (SIFT-family quantisation)");
+    return MODSX_ERR_ARG;
+  }
   if (!c->descU8[0].ensure(u1.size()) || !c->descU8[1].ensure(u2.size())) return MODSX_ERR_NOMEM;
   MX_HIP(hipMemcpyAsync(c->descU8[0].p, u1.data(), u1.size(), hipMemcpyHostToDevice, c->stream));
   MX_HIP(hipMemcpyAsync(c->descU8[1].p, u2.data(), u2.size(), hipMemcpyHostToDevice, c->stream));

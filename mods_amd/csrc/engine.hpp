@@ -181,12 +181,12 @@ void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *im
                      const double *wts, int photoNorm, int descType, double maxBin, const DescOut &outs);
 void launch_warp_affine(hipStream_t s, const WarpJob &jb);
 void launch_blur_pass(hipStream_t s, const float *src, float *dst, int rows, int cols, const float *taps, int n, int pass);
-size_t match_workspace_bytes(int n1, int n2, int *S_out, int *tilesPerSplit_out);
+size_t match_workspace_bytes(int n1, int n2, int nn);
 void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2,
-                  double sqminratio, double contrDistSq, MatchRow *rows, void *workspace);
+                  double sqminratio, double contrDistSq, int nn, MatchRow *rows, void *workspace);
 constexpr int MATCH_MAXB = 4;   // independent matching problems per launch set (blockIdx.z)
 void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
-                        const double *const *pos2, double sqminratio, double contrDistSq, MatchRow *const *rows,
+                        const double *const *pos2, double sqminratio, double contrDistSq, int nn, MatchRow *const *rows,
                         void *const *workspace);
 
 }  // namespace mx

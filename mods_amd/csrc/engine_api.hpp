@@ -35,6 +35,7 @@ int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx
 int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_view *views, int nv,
                           const modsx_pair_params &pp, int view_begin, int view_step, std::vector<modsx_region> &regs,
                           float *devF, uint8_t *devU8, size_t devCapRegions, float *hostDesc, int *viewCounts);
+void rebase_ids(std::vector<modsx_region> &regs, const int *viewCounts, int nv, size_t base);
 int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_ladder_step *steps, int nsteps,
                  int min_matches, const modsx_pair_params &pp, modsx_pair_result *res, int *steps_done);
 int match_pair_views(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_view *views, int nv,

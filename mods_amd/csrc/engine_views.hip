@@ -267,7 +267,7 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
         dU[i] = devU8 ? devU8 + ofs * 128 : nullptr;
         ofs += m;
       }
-      if (ofs > devCapRegions && (devF || devU8)) { set_error("descriptor buffer too small"); rc = MODSX_ERR_NOMEM; }
+      if (ofs > devCapRegions && (devF || devU8)) { set_error("descriptor buffer too small"); rc = MODSX_ERR_CAPACITY; }
       if (!rc) rc = describe_batch(c, cimg, n, ro, pp.desc_mrSize, pp.desc_patchSize, 0, pp.desc_photoNorm, pp.desc_type,
                                    pp.desc_maxBinValue, nullptr, devF ? dF : nullptr, devU8 ? dU : nullptr);
       if (!rc) {
@@ -294,13 +294,12 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
 }
 
 // AddRegionsToList (imagerepresentation.cpp:588-600): ids of each appended view block are shifted by the size
-// of the list so far (`base` = regions already in the list from earlier ladder steps)
-static void rebase_ids(std::vector<modsx_region> &regs, size_t base = 0) {
+// of the list so far (`base` = regions already in the list from earlier ladder steps).  Block boundaries come from the
+// per-view counts of the loop, not from runs of equal img_id (every identity-like view carries img_id 0).
+void rebase_ids(std::vector<modsx_region> &regs, const int *viewCounts, int nv, size_t base) {
   size_t start = 0;
-  const size_t n = regs.size();
-  while (start < n) {
-    size_t end = start;
-    while (end < n && regs[end].img_id == regs[start].img_id) end++;
+  for (int v = 0; v < nv; v++) {
+    const size_t end = std::min(regs.size(), start + (size_t)viewCounts[v]);
     for (size_t i = start; i < end; i++) { regs[i].id += (int)(base + start); regs[i].parent_id += (int)(base + start); }
     start = end;
   }
@@ -330,6 +329,7 @@ static int accumulate_views(modsx_ctx *c, LadderClass &k, int side, const modsx_
   size_t &cap = k.cap[side];
   const size_t base = acc.size();
   std::vector<modsx_region> step;
+  std::vector<int> counts(std::max(1, nv), 0);
   for (;;) {
     if (buf.cap < cap * 128) {
       DevBuf bigger;
@@ -342,12 +342,12 @@ static int accumulate_views(modsx_ctx *c, LadderClass &k, int side, const modsx_
       buf = bigger;
     }
     int rc = detect_describe_views(c, img, views, nv, pp, 0, 1, step, nullptr, (uint8_t *)buf.p + base * 128, cap - base, nullptr,
-                                   nullptr);
-    if (rc == MODSX_ERR_NOMEM && cap < ((size_t)1 << 24)) { cap *= 4; continue; }
+                                   counts.data());
+    if (rc == MODSX_ERR_CAPACITY && cap < ((size_t)1 << 24)) { cap *= 4; continue; }   // only "buffer too small" grows it
     if (rc) return rc;
     break;
   }
-  rebase_ids(step, base);
+  rebase_ids(step, counts.data(), nv, base);
   acc.insert(acc.end(), step.begin(), step.end());
   return MODSX_OK;
 }

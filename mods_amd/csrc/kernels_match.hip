@@ -13,18 +13,30 @@
 //             d0 (the predicate is monotone); NNj = lex-min over d >= Dmin; nless = #{t != NN0 : d < Dmin};
 //             nbad = #{those farther than contradDist from NN0}
 //   accept  <=>  NNj exists, nbad == 0, nless <= nn-2          (rank of NNj is nless+1)
-// Distances come from the int8 matrix cores: with a' = a-128, b' = b-128 (both in [-128,127])
-// |a-b|^2 = |a'|^2 + |b'|^2 - 2 a'.b' exactly in int32;  a'.b' = v_mfma_i32_32x32x32_i8 over K = 128.
+// Distances come from the int8 matrix cores: with a'' = 127 - a, b' = b - 128 (both in [-128,127])
+//   |a-b|^2 - |a-128|^2 = (|b'|^2 + 2 sum b') + 2 a''.b'   exactly in int32;   a''.b' = v_mfma_i32_32x32x32_i8 over K = 128.
 //
-// Work decomposition: a 256-thread workgroup owns 128 queries (one 32-query A fragment set per wave,
-// resident in registers for the whole sweep) and one of S contiguous ranges of train tiles (M is split so
-// that small N still fills the chip).  Train tiles (32 descriptors = 4 KB) are loaded with fully coalesced
-// 16-byte-per-lane reads, staged in a double-buffered LDS tile shared by the 4 waves, and read back as MFMA
-// B fragments with ds_read_b128.  Each lane keeps the running top-2 of its 16 accumulator rows as packed keys.  In
-// sweep 1 the query fragment is negated (a'' = 127 - a), so acc = -(a'.b') - sum(b') and
-// key = ((|b'|^2 - 2 a'.b') << 8) | local tile = (acc << 9) + column constant: one v_lshl_add, one v_min and one v_med3
-// per matrix element, with the accumulators in VGPRs (-amdgpu-mfma-vgpr-form) and the four MFMAs of tile q issued
-// between the quarters of the update of tile q - 1.  The query norm, constant per row, is added after the sweep.
+// Work decomposition (gfx950: a plain VALU instruction costs 4 cycles per wavefront, a 32x32x32 int8 MFMA 32, so the
+// epilogue, not the matrix pipe, is what has to be made small):
+//  * TRAIN descriptors are the MFMA rows (A operand, streamed), QUERIES the columns (B operand, resident in VGPRs):
+//    a lane then owns ONE query per 32-query set and sees 16 trains (a "group": fixed tile, fixed lane half) per tile,
+//    so its running state is two keys, not 16 x 2, and the merge at the end is one lane exchange.
+//  * Per group the lane forms 16 keys (d - |a'|^2) << 8 | idx with one v_lshl_add each, reduces them with a v_min3 tree
+//    (8 ops) and feeds ONLY the group minimum to the running top-2 (v_med3 + v_min): 26 VALU per 4 MFMA instead of 48.
+//    The top-2 of group minima misses exactly one candidate -- the second-best INSIDE the group of the overall winner;
+//    k_match_decide recomputes the 15 other distances of NN0's group (dot4) and folds that candidate in.
+//  * idx = (tile in a 12-tile chunk + 1) << 4 | register: every 12 tiles the lane moves the indices of keys that
+//    changed into two index registers and clears the low byte, so older entries keep winning ties (ascending train
+//    index, as the reference's sort) and a split may be any number of tiles long.
+//  * k_match_pack rewrites the trains once as 4 KB tiles (b - 128, 16-byte slots XOR-swizzled so that the ds_read_b128
+//    fragment reads are conflict-free) plus the 32 per-train key constants of each tile; the sweeps then stage 4 tiles per
+//    barrier with direct global->LDS loads (no staging registers), double-buffered; a wave holds 2 x 32 queries, so every
+//    fragment read from LDS feeds two MFMA chains.
+//  * sweep 2 folds the threshold into the accumulator: srcC = -ceil((Dmin - |a'|^2) / 2) makes the same key relative to
+//    Dmin, a group without a sub-threshold train costs the same 26 instructions (its minimum feeds NNj), a group WITH
+//    one is queued as an 4-byte event (per-query slots, no contended counter) and k_match_events recomputes its 16
+//    distances exactly for nless / nbad / NNj.  A query with more than nn + 2 event groups has nless > nn - 2 whatever
+//    they contain and is rejected without being looked at further.
 #include "engine.hpp"
 
 namespace mx {
@@ -33,29 +45,13 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int BIG = 0x7fffffff;
-constexpr unsigned UBIG = 0xffffffffu;
-constexpr int TILES_PER_SPLIT_MAX = 256;   // 8 bits of local tile index in the packed key of sweep 1
-constexpr int TPS = 4;                     // train tiles staged per barrier (4 x 4 KB per LDS buffer)
-
-// norms[i] = |d_i - 128|^2; normS[i] (optional) = |d_i - 128|^2 + 2 sum(d_i - 128), the column constant of sweep 1
-__device__ __forceinline__ void norms_body(const uint8_t *d, int n, int *norms, int *normS) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const v4i *p = reinterpret_cast<const v4i *>(d + (size_t)i * 128);
-  int s = 0, lin = 0;
-#pragma unroll
-  for (int q = 0; q < 8; q++) {
-    const v4i v = p[q];
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-      const int x = v[w] ^ 0x80808080;
-#pragma unroll
-      for (int b = 0; b < 4; b++) { const int e = (int)(signed char)((x >> (8 * b)) & 0xff); s += e * e; lin += e; }
-    }
-  }
-  norms[i] = s;
-  if (normS) normS[i] = s + 2 * lin;
-}
+constexpr int NONE = 0x7fffff00;           // empty slot of a running minimum: larger than every real key, low byte 0
+constexpr int TPS = 4;                     // train tiles staged per barrier
+constexpr int CHUNK = 12;                  // tiles per index chunk (3 stages); tilesPerSplit is a multiple of it
+constexpr int QSETS = 2;                   // 32-query sets per wave
+constexpr int QPB = 4 * 32 * QSETS;        // queries per 256-thread workgroup
+constexpr int TILE_B = 4096, STAGE_B = TPS * TILE_B + TPS * 128;
+constexpr int MAXD = 128 * 255 * 255;      // largest possible squared distance
 
 MX_D bool ratio_pass(float d0, float d, double sqminratio) {
   const float r = d0 / d;            // f32 division as in `double ratio = distsRow[0]/distsRow[j]`
@@ -72,180 +68,257 @@ MX_D int ratio_dmin(int d0i, double sqminratio) {
   return D;
 }
 MX_D bool lex_less(int da, int ia, int db, int ib) { return da < db || (da == db && ia < ib); }
-// median of three (folds to v_med3_u32): with m1 <= m2 the new second-smallest after seeing k is med3(m1, m2, k)
-MX_D unsigned umed3(unsigned a, unsigned b, unsigned c) { return min(max(a, b), max(min(a, b), c)); }
 MX_D int imed3(int a, int b, int c) { return min(max(a, b), max(min(a, b), c)); }
-
-// A fragment: 16 bytes [32*kb + 16*hi, +16) of a descriptor, u8 -> i8 (x - 128 == x ^ 0x80)
-MX_D v4i load_a(const uint8_t *base, int row, int kb, int hi) {
-  v4i v = *reinterpret_cast<const v4i *>(base + (size_t)row * 128 + 32 * kb + 16 * hi);
-  v[0] ^= 0x80808080; v[1] ^= 0x80808080; v[2] ^= 0x80808080; v[3] ^= 0x80808080;
-  return v;
-}
-
-// the query fragment of sweep 1: a'' = 127 - a = -(a - 128) - 1 (u8 -> i8 by x ^ 0x7f), so that
-// a''.b' = -(a'.b') - sum(b') and the distance key needs no negation of the accumulator
-MX_D v4i load_a_neg(const uint8_t *base, int row, int kb, int hi) {
-  v4i v = *reinterpret_cast<const v4i *>(base + (size_t)row * 128 + 32 * kb + 16 * hi);
-  v[0] ^= 0x7f7f7f7f; v[1] ^= 0x7f7f7f7f; v[2] ^= 0x7f7f7f7f; v[3] ^= 0x7f7f7f7f;
-  return v;
-}
+MX_D int imin3(int a, int b, int c) { return min(min(a, b), c); }
 
 struct MatchGeom {
   int n1, n2, S, tilesPerSplit;
 };
 
-// stage one 32-descriptor tile (4 KB) into LDS: thread t copies bytes [16 t, 16 t + 16) of the tile.
-// fetch_tile issues the global load early (next tile, in flight during the MFMAs); put_tile parks it in LDS.
-MX_D v4i fetch_tile(const uint8_t *d2, int n2, int tile, int tid) {
-  const int row = tile * 32 + (tid >> 3);
-  v4i v = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};  // rows past the end: a' = 0
-  if (row < n2) v = *reinterpret_cast<const v4i *>(d2 + (size_t)tile * 4096 + (size_t)tid * 16);
+// register r of the 32x32 accumulator of lane half `hi` holds MFMA row 8 (r >> 2) + 4 hi + (r & 3)
+MX_D int row_of(int r, int hi) { return 8 * (r >> 2) + 4 * hi + (r & 3); }
+
+// ---------------- pack: norms, swizzled tiles, key constants -------------------------------------------------------
+// y = 0: norm1[i] = |q_i - 128|^2.   y = 1: one thread per train slot t < ntilesPadded * 32:
+//   tiles[t >> 5] row t & 31 = b - 128 in 16-byte slots, slot s stored at s ^ ((row >> 1) & 7)
+//   cst[t] = (|b'|^2 + 2 sum b') << 8 | ((tile % 12) + 1) << 4 | register of the row;   past the end: zeros / NONE | idx
+//   norm2[t] = |b'|^2
+__device__ __forceinline__ void pack_body(const uint8_t *d1, int n1, int *norm1, const uint8_t *d2, int n2, int slots,
+                                          unsigned char *tiles, int *cst, int *norm2) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.y == 0) {
+    if (i >= n1) return;
+    const v4i *p = reinterpret_cast<const v4i *>(d1 + (size_t)i * 128);
+    int s = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const v4i v = p[q];
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        const int x = v[w] ^ 0x80808080;
+#pragma unroll
+        for (int b = 0; b < 4; b++) { const int e = (int)(signed char)((x >> (8 * b)) & 0xff); s += e * e; }
+      }
+    }
+    norm1[i] = s;
+    return;
+  }
+  if (i >= slots) return;
+  const int tile = i >> 5, row = i & 31;
+  const int idx = (((tile % CHUNK) + 1) << 4) | (4 * (row >> 3) + (row & 3));
+  unsigned char *dst = tiles + (size_t)tile * TILE_B + row * 128;
+  const int sw = (row >> 1) & 7;
+  if (i >= n2) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) *reinterpret_cast<v4i *>(dst + ((q ^ sw) << 4)) = (v4i){0, 0, 0, 0};
+    cst[i] = NONE | idx;
+    return;
+  }
+  const v4i *p = reinterpret_cast<const v4i *>(d2 + (size_t)i * 128);
+  int s = 0, lin = 0;
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    v4i v = p[q];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      v[w] ^= 0x80808080;
+      const int x = v[w];
+#pragma unroll
+      for (int b = 0; b < 4; b++) { const int e = (int)(signed char)((x >> (8 * b)) & 0xff); s += e * e; lin += e; }
+    }
+    *reinterpret_cast<v4i *>(dst + ((q ^ sw) << 4)) = v;
+  }
+  norm2[i] = s;
+  cst[i] = ((s + 2 * lin) << 8) | idx;
+}
+
+// exact |a - b|^2 of two 128-byte descriptors: na + nb - 2 (a-128).(b-128), dot4 on the signed bytes
+MX_D int exact_dist(const uint8_t *a, int na, const uint8_t *b, int nb) {
+  const v4i *pa = reinterpret_cast<const v4i *>(a), *pb = reinterpret_cast<const v4i *>(b);
+  int dot = 0;
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const v4i x = pa[q], y = pb[q];
+#pragma unroll
+    for (int w = 0; w < 4; w++) dot = __builtin_amdgcn_sdot4(x[w] ^ 0x80808080, y[w] ^ 0x80808080, dot, false);
+  }
+  return na + nb - 2 * dot;
+}
+
+// ---------------- staging: 4 tiles + their constants, global -> LDS directly ------------------------------------------
+typedef const unsigned char __attribute__((address_space(1))) *gbptr;
+typedef unsigned char __attribute__((address_space(3))) *lbptr;
+MX_D void stage_group(const unsigned char *tiles, const int *cst, int g0, unsigned char *buf, int wave, int lane) {
+  const unsigned char *src = tiles + (size_t)g0 * TILE_B + lane * 16;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int chunk = wave + 4 * i;   // 1 KB per wave instruction
+    __builtin_amdgcn_global_load_lds((gbptr)(src + chunk * 1024), (lbptr)(buf + chunk * 1024), 16, 0, 0);
+  }
+  if (wave < 2)
+    __builtin_amdgcn_global_load_lds((gbptr)(reinterpret_cast<const unsigned char *>(cst + (size_t)g0 * 32) + wave * 256 + lane * 4),
+                                     (lbptr)(buf + TPS * TILE_B + wave * 256), 4, 0, 0);
+}
+MX_D v4i read_a(const unsigned char *tile, int row, int kb, int hi) {
+  const int slot = 2 * kb + hi;
+  return *reinterpret_cast<const v4i *>(tile + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+}
+// the query fragment: a'' = 127 - a = -(a - 128) - 1 (u8 -> i8 by x ^ 0x7f), bytes [32 kb + 16 hi, +16)
+MX_D v4i load_q(const uint8_t *base, int row, int kb, int hi) {
+  v4i v = *reinterpret_cast<const v4i *>(base + (size_t)row * 128 + 32 * kb + 16 * hi);
+  v[0] ^= 0x7f7f7f7f; v[1] ^= 0x7f7f7f7f; v[2] ^= 0x7f7f7f7f; v[3] ^= 0x7f7f7f7f;
   return v;
 }
-MX_D void put_tile(v4i v, unsigned char *lds, int tid) {
-  v[0] ^= 0x80808080; v[1] ^= 0x80808080; v[2] ^= 0x80808080; v[3] ^= 0x80808080;
-  // LDS image: row r at r*128, XOR-swizzled in 16-byte slots so the b128 fragment reads spread over banks
-  const int r = tid >> 3, slot = tid & 7;
-  *reinterpret_cast<v4i *>(lds + r * 128 + ((slot ^ (r & 7)) << 4)) = v;
+MX_D int tree_min16(const int *k) {
+  const int t0 = imin3(k[0], k[1], k[2]), t1 = imin3(k[3], k[4], k[5]), t2 = imin3(k[6], k[7], k[8]);
+  const int t3 = imin3(k[9], k[10], k[11]), t4 = imin3(k[12], k[13], k[14]);
+  return min(imin3(t0, t1, t2), imin3(t3, t4, k[15]));
 }
-MX_D void stage_tile(const uint8_t *d2, int n2, int tile, unsigned char *lds, int tid) {
-  put_tile(fetch_tile(d2, n2, tile, tid), lds, tid);
-}
-MX_D v4i read_b(const unsigned char *lds, int col, int kb, int hi) {
-  const int slot = 2 * kb + hi;
-  return *reinterpret_cast<const v4i *>(lds + col * 128 + ((slot ^ (col & 7)) << 4));
+// train index of a key of the current chunk (low byte = (tile in chunk + 1) << 4 | register)
+MX_D int decode_idx(int lb, int chunkTile0, int hi) {
+  return (chunkTile0 + (lb >> 4) - 1) * 32 + row_of(lb & 15, hi);
 }
 
-// ---------------- sweep 1: per (query, split) top-2 -------------------------------------------------------
-__device__ __forceinline__ void sweep1_body(const uint8_t *d1, const int *norm1, const uint8_t *d2,
-                                                      const int *normS2, MatchGeom g, int4 *partial) {
-  __shared__ __attribute__((aligned(16))) unsigned char tileBuf[2][TPS * 4096];
+// ---------------- sweep 1: per (query, split) top-2 of the group minima -------------------------------------------------
+__device__ __forceinline__ void sweep1_body(const uint8_t *d1, const int *norm1, const unsigned char *tiles, const int *cst,
+                                            MatchGeom g, int4 *partial) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[2][STAGE_B];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 31, hi = lane >> 5;
-  const int qb = blockIdx.x, sp = blockIdx.y;
-  const int q0 = qb * 128 + wave * 32;
-  const int qrow = min(q0 + col, g.n1 - 1);
-  v4i a[4];
+  const int sp = blockIdx.y;
+  const int q0 = blockIdx.x * QPB + wave * (32 * QSETS);
+  v4i bq[QSETS][4];
 #pragma unroll
-  for (int kb = 0; kb < 4; kb++) a[kb] = load_a_neg(d1, qrow, kb, hi);
-  // Per row the query norm na is a constant, so the running top-2 is kept on
-  //   key = ((nb - 2 a'.b') << 8) | tile = (acc << 9) + (((nb + 2 sum b') << 8) | tile)   with acc = a''.b',
-  // i.e. ONE v_lshl_add, one signed min and one signed med3 per matrix element; |nb - 2 a'.b'| < 2^23, so the key
-  // fits an int32 with 8 tile bits (tilesPerSplit <= 256).
-  const int ntilesAll = (g.n2 + 31) >> 5;
-  const int tBeg = sp * g.tilesPerSplit, tEnd = min(tBeg + g.tilesPerSplit, ntilesAll);
-  int m1[16], m2[16];
+  for (int s = 0; s < QSETS; s++) {
+    const int qrow = min(q0 + 32 * s + col, g.n1 - 1);
 #pragma unroll
-  for (int r = 0; r < 16; r++) { m1[r] = BIG; m2[r] = BIG; }
-  // tiles past the end of the split are staged as zeros (b' = 0 => acc = 0) and get the column constant BIG, so
-  // their keys are BIG and the tile loop needs no branches
-  const int NOTILE = 0x3fffffff >> 5;   // fetch_tile sees a row index >= n2 and returns zeros
-  for (int q = 0; q < TPS; q++) stage_tile(d2, g.n2, tBeg + q < tEnd ? tBeg + q : NOTILE, tileBuf[0] + q * 4096, tid);
-  __syncthreads();
-  for (int tg = tBeg; tg < tEnd; tg += TPS) {
-    const int cur = ((tg - tBeg) / TPS) & 1;
-    v4i nxt[TPS];
+    for (int kb = 0; kb < 4; kb++) bq[s][kb] = load_q(d1, qrow, kb, hi);
+  }
+  const int ntiles4 = (((g.n2 + 31) >> 5) + TPS - 1) & ~(TPS - 1);
+  const int tBeg = sp * g.tilesPerSplit, tEnd = min(tBeg + g.tilesPerSplit, ntiles4);
+  int m1[QSETS], m2[QSETS], i1[QSETS], i2[QSETS];
 #pragma unroll
-    for (int q = 0; q < TPS; q++) nxt[q] = fetch_tile(d2, g.n2, tg + TPS + q < tEnd ? tg + TPS + q : NOTILE, tid);
-    int tileC[TPS];
+  for (int s = 0; s < QSETS; s++) { m1[s] = NONE; m2[s] = NONE; i1[s] = -1; i2[s] = -1; }
+  auto flush = [&](int chunkTile0) {
+#pragma unroll
+    for (int s = 0; s < QSETS; s++) {
+      const int lb1 = m1[s] & 255, lb2 = m2[s] & 255;
+      const int n2i = lb2 ? decode_idx(lb2, chunkTile0, hi) : (lb1 ? i1[s] : i2[s]);
+      const int n1i = lb1 ? decode_idx(lb1, chunkTile0, hi) : i1[s];
+      i1[s] = n1i; i2[s] = n2i;
+      m1[s] &= ~255; m2[s] &= ~255;
+    }
+  };
+  if (tBeg < tEnd) stage_group(tiles, cst, tBeg, sm[0], wave, lane);
+  int it = 0;
+  for (int tg = tBeg; tg < tEnd; tg += TPS, it++) {
+    const unsigned char *buf = sm[it & 1];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tg + TPS < tEnd) stage_group(tiles, cst, tg + TPS, sm[(it & 1) ^ 1], wave, lane);
 #pragma unroll
     for (int q = 0; q < TPS; q++) {
-      const int t = tg + q, trow = t * 32 + col;
-      tileC[q] = (t < tEnd && trow < g.n2) ? ((normS2[trow] << 8) | (t - tBeg)) : BIG;
-    }
-    // software pipeline inside a wave: the four MFMAs of tile q are issued between the four quarters of the top-2
-    // update of tile q - 1, so the VALU work runs in the shadow of the matrix pipe
-    v16i accP = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    {
-      const unsigned char *tb = tileBuf[cur];
+      const unsigned char *tb = buf + q * TILE_B;
+      v4i af[4];
 #pragma unroll
-      for (int kb = 0; kb < 4; kb++) accP = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], read_b(tb, col, kb, hi), accP, 0, 0, 0);
-    }
+      for (int kb = 0; kb < 4; kb++) af[kb] = read_a(tb, col, kb, hi);
+      int C[16];
 #pragma unroll
-    for (int q = 1; q < TPS; q++) {
-      const unsigned char *tb = tileBuf[cur] + q * 4096;
-      v4i bf[4];
-#pragma unroll
-      for (int kb = 0; kb < 4; kb++) bf[kb] = read_b(tb, col, kb, hi);
-      v16i accN = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int kb = 0; kb < 4; kb++) {
-        accN = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], bf[kb], accN, 0, 0, 0);
-#pragma unroll
-        for (int r = 4 * kb; r < 4 * kb + 4; r++) {
-          const int key = (accP[r] << 9) + tileC[q - 1];
-          m2[r] = imed3(m1[r], m2[r], key);
-          m1[r] = min(m1[r], key);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA ...
-        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);  // ... then the 12 VALU ops of a quarter update
+      for (int gq = 0; gq < 4; gq++) {
+        const v4i c4 = *reinterpret_cast<const v4i *>(buf + TPS * TILE_B + q * 128 + (8 * gq + 4 * hi) * 4);
+        C[4 * gq] = c4[0]; C[4 * gq + 1] = c4[1]; C[4 * gq + 2] = c4[2]; C[4 * gq + 3] = c4[3];
       }
-      accP = accN;
-    }
+      v16i acc[QSETS];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int key = (accP[r] << 9) + tileC[TPS - 1];
-      m2[r] = imed3(m1[r], m2[r], key);
-      m1[r] = min(m1[r], key);
-    }
+      for (int s = 0; s < QSETS; s++) {
+        acc[s] = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int q = 0; q < TPS; q++) put_tile(nxt[q], tileBuf[cur ^ 1] + q * 4096, tid);
-    __syncthreads();
+        for (int kb = 0; kb < 4; kb++) acc[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[kb], bq[s][kb], acc[s], 0, 0, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < QSETS; s++) {
+        int k[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) k[r] = (acc[s][r] << 9) + C[r];
+        const int t = tree_min16(k);
+        m2[s] = imed3(m1[s], m2[s], t);
+        m1[s] = min(m1[s], t);
+      }
+    }
+    if ((it % (CHUNK / TPS)) == CHUNK / TPS - 1) flush(tg + TPS - CHUNK);
   }
-  // unpack and merge the per-lane top-2 over the 32 lanes that hold the same rows
+  if (it % (CHUNK / TPS)) flush(tBeg + (it / (CHUNK / TPS)) * CHUNK);
+  // the two lane halves of a query saw different rows: merge their sorted pairs, convert to distances, store
 #pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const int na = norm1[min(q0 + (r & 3) + 8 * (r >> 2) + 4 * hi, g.n1 - 1)];
-    int d0 = m1[r] == BIG ? BIG : (m1[r] >> 8) + na, i0 = m1[r] == BIG ? BIG : (tBeg + (m1[r] & 255)) * 32 + col;
-    int dd1 = m2[r] == BIG ? BIG : (m2[r] >> 8) + na, i1 = m2[r] == BIG ? BIG : (tBeg + (m2[r] & 255)) * 32 + col;
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) {
-      const int od0 = __shfl_xor(d0, m), oi0 = __shfl_xor(i0, m), od1 = __shfl_xor(dd1, m), oi1 = __shfl_xor(i1, m);
-      // merge two sorted pairs (d0,i0)<=(dd1,i1) and (od0,oi0)<=(od1,oi1)
-      if (lex_less(od0, oi0, d0, i0)) {
-        // other's best wins; second = min(mine best, other's second)
-        if (lex_less(od1, oi1, d0, i0)) { dd1 = od1; i1 = oi1; } else { dd1 = d0; i1 = i0; }
-        d0 = od0; i0 = oi0;
-      } else {
-        if (lex_less(od0, oi0, dd1, i1)) { dd1 = od0; i1 = oi0; }
-      }
-    }
-    if (col == 0) {
-      const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (q < g.n1) partial[(size_t)q * g.S + sp] = make_int4(d0, i0, dd1, i1);
-    }
+  for (int s = 0; s < QSETS; s++) {
+    const int q = q0 + 32 * s + col;
+    const int na = norm1[min(q, g.n1 - 1)];
+    int d0 = i1[s] < 0 ? BIG : (m1[s] >> 8) + na, j0 = i1[s] < 0 ? BIG : i1[s];
+    int dd1 = i2[s] < 0 ? BIG : (m2[s] >> 8) + na, j1 = i2[s] < 0 ? BIG : i2[s];
+    const int od0 = __shfl_xor(d0, 32), oj0 = __shfl_xor(j0, 32), od1 = __shfl_xor(dd1, 32), oj1 = __shfl_xor(j1, 32);
+    if (lex_less(od0, oj0, d0, j0)) {
+      if (lex_less(od1, oj1, d0, j0)) { dd1 = od1; j1 = oj1; } else { dd1 = d0; j1 = j0; }
+      d0 = od0; j0 = oj0;
+    } else if (lex_less(od0, oj0, dd1, j1)) { dd1 = od0; j1 = oj0; }
+    if (hi == 0 && q < g.n1) partial[(size_t)q * g.S + sp] = make_int4(d0, j0, dd1, j1);
   }
 }
 
-// ---------------- decide: merge splits, j = 1 of the walk, compact the undecided queries --------------------
-__device__ __forceinline__ void decide_body(const int4 *partial, MatchGeom g, const double *pos2,
-                                                      double sqminratio, double contrDistSq, MatchRow *rows, int *dmin,
-                                                      int *undecided, int *nUndecided) {
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= g.n1) return;
-  int d0 = BIG, i0 = BIG, d1 = BIG, i1 = BIG;
-  for (int s = 0; s < g.S; s++) {
-    const int4 p = partial[(size_t)q * g.S + s];
+// ---------------- decide: merge splits, the hidden candidate of NN0's group, j = 1 of the walk ---------------------------
+// 16 lanes per query.  sweep 1 ranks group minima, so the one candidate it cannot have seen is the second-best inside the
+// group (same tile, same lane half) of the overall winner: lane l recomputes the distance of that group's row l exactly.
+__device__ __forceinline__ void decide_body(const uint8_t *d1, const int *norm1, const uint8_t *d2, const int *norm2,
+                                            const int4 *partial, MatchGeom g, const double *pos2, double sqminratio,
+                                            double contrDistSq, MatchRow *rows, int *dmin, int *undecided, int *nUndecided) {
+  const int l = threadIdx.x & 15;
+  const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = q < g.n1;
+  const int qc = live ? q : g.n1 - 1;
+  int d0 = BIG, i0 = BIG, dd1 = BIG, j1 = BIG;
+  for (int s = l; s < g.S; s += 16) {
+    const int4 p = partial[(size_t)qc * g.S + s];
     if (lex_less(p.x, p.y, d0, i0)) {
-      if (lex_less(p.z, p.w, d0, i0)) { d1 = p.z; i1 = p.w; } else { d1 = d0; i1 = i0; }
+      if (lex_less(p.z, p.w, d0, i0)) { dd1 = p.z; j1 = p.w; } else { dd1 = d0; j1 = i0; }
       d0 = p.x; i0 = p.y;
-    } else if (lex_less(p.x, p.y, d1, i1)) { d1 = p.x; i1 = p.y; }
+    } else if (lex_less(p.x, p.y, dd1, j1)) { dd1 = p.x; j1 = p.y; }
   }
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) {
+    const int od0 = __shfl_xor(d0, m), oi0 = __shfl_xor(i0, m), od1 = __shfl_xor(dd1, m), oj1 = __shfl_xor(j1, m);
+    if (lex_less(od0, oi0, d0, i0)) {
+      if (lex_less(od1, oj1, d0, i0)) { dd1 = od1; j1 = oj1; } else { dd1 = d0; j1 = i0; }
+      d0 = od0; i0 = oi0;
+    } else if (lex_less(od0, oi0, dd1, j1)) { dd1 = od0; j1 = oi0; }
+  }
+  if (i0 != BIG) {
+    const int tile = i0 >> 5, hi = ((i0 & 31) >> 2) & 1;
+    const int t = tile * 32 + row_of(l, hi);
+    int hd = BIG, ht = BIG;
+    if (t < g.n2 && t != i0) { hd = exact_dist(d1 + (size_t)qc * 128, norm1[qc], d2 + (size_t)t * 128, norm2[t]); ht = t; }
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) {
+      const int od = __shfl_xor(hd, m), ot = __shfl_xor(ht, m);
+      if (lex_less(od, ot, hd, ht)) { hd = od; ht = ot; }
+    }
+    if (lex_less(hd, ht, dd1, j1)) { dd1 = hd; j1 = ht; }
+  }
+  if (!live || l) return;
   MatchRow o;
-  o.t0 = i0 == BIG ? -1 : i0; o.t1 = i1 == BIG ? -1 : i1; o.tj = -1; o.nless = 0; o.nbad = 0;
-  o.d0 = (float)d0; o.d1 = (float)d1; o.dj = 0.f;
+  o.t0 = i0 == BIG ? -1 : i0; o.t1 = j1 == BIG ? -1 : j1; o.tj = -1; o.nless = 0; o.nbad = 0;
+  o.d0 = (float)d0; o.d1 = (float)dd1; o.dj = 0.f;
   int dm = 0;
-  if (i0 != BIG && i1 != BIG) {
-    if (ratio_pass((float)d0, (float)d1, sqminratio)) { o.tj = i1; o.dj = (float)d1; }       // accepted at j = 1
+  if (i0 != BIG && j1 != BIG) {
+    if (ratio_pass((float)d0, (float)dd1, sqminratio)) { o.tj = j1; o.dj = (float)dd1; }       // accepted at j = 1
     else {
-      const double dx = pos2[2 * i0] - pos2[2 * i1], dy = pos2[2 * i0 + 1] - pos2[2 * i1 + 1];
+      const double dx = pos2[2 * i0] - pos2[2 * j1], dy = pos2[2 * i0 + 1] - pos2[2 * j1 + 1];
       if (dx * dx + dy * dy > contrDistSq) o.nbad = 1;                                      // first contradictive
       else {
         dm = ratio_dmin(d0, sqminratio);
-        const int slot = atomicAdd(nUndecided, 1);
-        undecided[slot] = q;
-        o.nless = -1;   // filled by sweep 2
+        if (dm <= MAXD) {          // otherwise no distance can pass the ratio test: the walk ends without a match
+          const int slot = atomicAdd(nUndecided, 1);
+          undecided[slot] = q;
+          o.nless = -1;   // filled by sweep 2
+        }
       }
     }
   }
@@ -253,198 +326,292 @@ __device__ __forceinline__ void decide_body(const int4 *partial, MatchGeom g, co
   dmin[q] = dm;
 }
 
-// ---------------- sweep 2 over the undecided queries ----------------------------------------------------------
-__device__ __forceinline__ void sweep2_body(const uint8_t *d1, const int *norm1, const uint8_t *d2,
-                                                      const int *norm2, MatchGeom g, const double *pos2,
-                                                      double contrDistSq, const MatchRow *rows, const int *dmin,
-                                                      const int *undecided, const int *nUndecided, int4 *partial2) {
-  __shared__ __attribute__((aligned(16))) unsigned char tileBuf[2][TPS * 4096];
+// ---------------- sweep 2 over the undecided queries ----------------------------------------------------------------
+__device__ __forceinline__ void sweep2_body(const uint8_t *d1, const int *norm1, const unsigned char *tiles, const int *cst,
+                                            MatchGeom g, const int *dmin, const int *undecided, const int *nUndecided,
+                                            int2 *partial2, int *evCount, int *ev, int evLimit) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[2][STAGE_B];
   const int nU = *nUndecided;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 31, hi = lane >> 5;
-  const int qb = blockIdx.x, sp = blockIdx.y;
-  if (qb * 128 >= nU) return;
-  const int u0 = qb * 128 + wave * 32;
-  const int qA = undecided[min(u0 + col, nU - 1)];
-  v4i a[4];
+  const int sp = blockIdx.y;
+  if ((int)blockIdx.x * QPB >= nU) return;
+  const int u0 = blockIdx.x * QPB + wave * (32 * QSETS);
+  v4i bq[QSETS][4];
+  v16i base[QSETS];
+  int thr[QSETS], dmo[QSETS];
 #pragma unroll
-  for (int kb = 0; kb < 4; kb++) a[kb] = load_a(d1, qA, kb, hi);
-  int na[16], dm[16], t0[16];
+  for (int s = 0; s < QSETS; s++) {
+    const int u = min(u0 + 32 * s + col, nU - 1);
+    const int qA = undecided[u];
 #pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const int q = undecided[min(u0 + (r & 3) + 8 * (r >> 2) + 4 * hi, nU - 1)];
-    na[r] = norm1[q]; dm[r] = dmin[q]; t0[r] = rows[q].t0;
+    for (int kb = 0; kb < 4; kb++) bq[s][kb] = load_q(d1, qA, kb, hi);
+    // key = (d - Dmin - odd) << 8 | idx with Dq = Dmin - |a'|^2, odd = Dq & 1: the accumulator starts at -ceil(Dq / 2)
+    const int Dm = dmin[qA], Dq = Dm - norm1[qA];
+    const int c = (Dq + 1) >> 1, odd = Dq & 1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) base[s][r] = -c;
+    thr[s] = -(odd << 8);     // d < Dmin  <=>  key < thr
+    dmo[s] = Dm + odd;
   }
-  const int ntilesAll = (g.n2 + 31) >> 5;
-  const int tBeg = sp * g.tilesPerSplit, tEnd = min(tBeg + g.tilesPerSplit, ntilesAll);
-  unsigned mj[16];
-  int nless[16], nbad[16];
+  const int ntiles = (g.n2 + 31) >> 5;
+  const int ntiles4 = (ntiles + TPS - 1) & ~(TPS - 1);
+  const int tBeg = sp * g.tilesPerSplit, tEnd = min(tBeg + g.tilesPerSplit, ntiles4);
+  int mj[QSETS], ij[QSETS];
 #pragma unroll
-  for (int r = 0; r < 16; r++) { mj[r] = UBIG; nless[r] = 0; nbad[r] = 0; }
-  for (int q = 0; q < TPS; q++) if (tBeg + q < tEnd) stage_tile(d2, g.n2, tBeg + q, tileBuf[0] + q * 4096, tid);
-  __syncthreads();
-  for (int tg = tBeg; tg < tEnd; tg += TPS) {
-    const int cur = ((tg - tBeg) / TPS) & 1;
-    v4i nxt[TPS];
+  for (int s = 0; s < QSETS; s++) { mj[s] = NONE; ij[s] = -1; }
+  auto flush = [&](int chunkTile0) {
 #pragma unroll
-    for (int q = 0; q < TPS; q++) {
-      nxt[q] = (v4i){0, 0, 0, 0};
-      if (tg + TPS + q < tEnd) nxt[q] = fetch_tile(d2, g.n2, tg + TPS + q, tid);
+    for (int s = 0; s < QSETS; s++) {
+      const int lb = mj[s] & 255;
+      if (lb) ij[s] = decode_idx(lb, chunkTile0, hi);
+      mj[s] &= ~255;
     }
+  };
+  if (tBeg < tEnd) stage_group(tiles, cst, tBeg, sm[0], wave, lane);
+  int it = 0;
+  for (int tg = tBeg; tg < tEnd; tg += TPS, it++) {
+    const unsigned char *buf = sm[it & 1];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tg + TPS < tEnd) stage_group(tiles, cst, tg + TPS, sm[(it & 1) ^ 1], wave, lane);
 #pragma unroll
     for (int q = 0; q < TPS; q++) {
-      const int t = tg + q;
-      if (t >= tEnd) break;
-      const unsigned char *tb = tileBuf[cur] + q * 4096;
-      v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      const int tile = tg + q;
+      const unsigned char *tb = buf + q * TILE_B;
+      v4i af[4];
 #pragma unroll
-      for (int kb = 0; kb < 4; kb++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb], read_b(tb, col, kb, hi), acc, 0, 0, 0);
-      const int trow = t * 32 + col;
-      if (trow < g.n2) {
-        const int nb = norm2[trow];
-        const unsigned lt = (unsigned)(t - tBeg);
+      for (int kb = 0; kb < 4; kb++) af[kb] = read_a(tb, col, kb, hi);
+      int C[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int d = na[r] + nb - 2 * acc[r];
-          if (d >= dm[r]) mj[r] = min(mj[r], ((unsigned)d << 9) | lt);
-          else if (trow != t0[r]) {
-            nless[r]++;
-            // rare path: geometric consistency with NN0 (distanceSq, matching.cpp:174-179), f64
-            const double dx = pos2[2 * t0[r]] - pos2[2 * trow], dy = pos2[2 * t0[r] + 1] - pos2[2 * trow + 1];
-            if (dx * dx + dy * dy > contrDistSq) nbad[r]++;
-          }
+      for (int gq = 0; gq < 4; gq++) {
+        const v4i c4 = *reinterpret_cast<const v4i *>(buf + TPS * TILE_B + q * 128 + (8 * gq + 4 * hi) * 4);
+        C[4 * gq] = c4[0]; C[4 * gq + 1] = c4[1]; C[4 * gq + 2] = c4[2]; C[4 * gq + 3] = c4[3];
+      }
+      v16i acc[QSETS];
+#pragma unroll
+      for (int s = 0; s < QSETS; s++) {
+        acc[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bq[s][0], base[s], 0, 0, 0);
+#pragma unroll
+        for (int kb = 1; kb < 4; kb++) acc[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[kb], bq[s][kb], acc[s], 0, 0, 0);
+      }
+      const int nvalid = g.n2 - tile * 32;   // wave-uniform; < 32 only for the last tile and the padding tiles
+#pragma unroll
+      for (int s = 0; s < QSETS; s++) {
+        int k[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) k[r] = (acc[s][r] << 9) + C[r];
+        if (nvalid < 32) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) if (row_of(r, hi) >= nvalid) k[r] = BIG;
         }
+        const int t = tree_min16(k);
+        if (t < thr[s]) {
+          // a train of this group is closer than Dmin: k_match_events takes the whole group (its non-event rows included)
+          const int u = u0 + 32 * s + col;
+          if (u < nU) {
+            const int old = atomicAdd(&evCount[u], 1);
+            if (old < evLimit) ev[(size_t)u * evLimit + old] = (tile << 1) | hi;
+          }
+        } else mj[s] = min(mj[s], t);
       }
     }
-#pragma unroll
-    for (int q = 0; q < TPS; q++) if (tg + TPS + q < tEnd) put_tile(nxt[q], tileBuf[cur ^ 1] + q * 4096, tid);
-    __syncthreads();
+    if ((it % (CHUNK / TPS)) == CHUNK / TPS - 1) flush(tg + TPS - CHUNK);
   }
+  if (it % (CHUNK / TPS)) flush(tBeg + (it / (CHUNK / TPS)) * CHUNK);
 #pragma unroll
-  for (int r = 0; r < 16; r++) {
-    int dj = mj[r] == UBIG ? BIG : (int)(mj[r] >> 9), ij = mj[r] == UBIG ? BIG : (tBeg + (int)(mj[r] & 511)) * 32 + col;
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) {
-      const int od = __shfl_xor(dj, m), oi = __shfl_xor(ij, m);
-      if (lex_less(od, oi, dj, ij)) { dj = od; ij = oi; }
-      nless[r] += __shfl_xor(nless[r], m);
-      nbad[r] += __shfl_xor(nbad[r], m);
-    }
-    if (col == 0) {
-      const int u = u0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (u < nU) partial2[(size_t)u * g.S + sp] = make_int4(dj, ij, nless[r], nbad[r]);
-    }
+  for (int s = 0; s < QSETS; s++) {
+    const int u = u0 + 32 * s + col;
+    int dj = ij[s] < 0 ? BIG : (mj[s] >> 8) + dmo[s], tj = ij[s] < 0 ? BIG : ij[s];
+    const int od = __shfl_xor(dj, 32), ot = __shfl_xor(tj, 32);
+    if (lex_less(od, ot, dj, tj)) { dj = od; tj = ot; }
+    if (hi == 0 && u < nU) partial2[(size_t)u * g.S + sp] = make_int2(dj, tj);
   }
 }
 
-__device__ __forceinline__ void finish_body(const int4 *partial2, MatchGeom g, const int *undecided,
-                                                      const int *nUndecided, MatchRow *rows) {
+// ---------------- events: the groups of sweep 2 that hold a train below Dmin, recomputed exactly ---------------------------
+// One wave per undecided query, four groups (16 rows each) per pass.  Output per query: nless, nbad and the lex-smallest
+// (d, t) with d >= Dmin among the rows of the event groups (the sweep left those groups out of its own minimum).
+__device__ __forceinline__ void events_body(const uint8_t *d1, const int *norm1, const uint8_t *d2, const int *norm2, MatchGeom g,
+                                            const double *pos2, double contrDistSq, const MatchRow *rows, const int *dmin,
+                                            const int *undecided, const int *nUndecided, const int *evCount, const int *ev,
+                                            int evLimit, int4 *evRes) {
+  const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= *nUndecided) return;
+  const int lane = threadIdx.x & 63, l = lane & 15, sub = lane >> 4;
+  const int q = undecided[u];
+  const int total = evCount[u];
+  if (total > evLimit) {   // more than nn + 2 groups with a sub-threshold train: nless > nn - 2 whatever they hold
+    if (lane == 0) evRes[u] = make_int4(evLimit, 0, BIG, BIG);
+    return;
+  }
+  const int t0 = rows[q].t0, Dm = dmin[q], na = norm1[q];
+  const double x0 = pos2[2 * t0], y0 = pos2[2 * t0 + 1];
+  int nless = 0, nbad = 0, dj = BIG, tj = BIG;
+  for (int b = 0; b < total; b += 4) {
+    const int e = b + sub;
+    if (e < total) {
+      const int rec = ev[(size_t)u * evLimit + e];
+      const int t = (rec >> 1) * 32 + row_of(l, rec & 1);
+      if (t < g.n2 && t != t0) {
+        const int d = exact_dist(d1 + (size_t)q * 128, na, d2 + (size_t)t * 128, norm2[t]);
+        if (d < Dm) {
+          nless++;
+          // geometric consistency with NN0 (distanceSq, matching.cpp:174-179), f64
+          const double dx = x0 - pos2[2 * t], dy = y0 - pos2[2 * t + 1];
+          if (dx * dx + dy * dy > contrDistSq) nbad++;
+        } else if (lex_less(d, t, dj, tj)) { dj = d; tj = t; }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    nless += __shfl_xor(nless, m);
+    nbad += __shfl_xor(nbad, m);
+    const int od = __shfl_xor(dj, m), ot = __shfl_xor(tj, m);
+    if (lex_less(od, ot, dj, tj)) { dj = od; tj = ot; }
+  }
+  if (lane == 0) evRes[u] = make_int4(nless, nbad, dj, tj);
+}
+
+__device__ __forceinline__ void finish_body(const int2 *partial2, const int4 *evRes, MatchGeom g, const int *undecided,
+                                            const int *nUndecided, MatchRow *rows) {
   const int u = blockIdx.x * 256 + threadIdx.x;
   if (u >= *nUndecided) return;
-  int dj = BIG, ij = BIG, nless = 0, nbad = 0;
+  const int4 e = evRes[u];
+  int dj = e.z, ij = e.w;
   for (int s = 0; s < g.S; s++) {
-    const int4 p = partial2[(size_t)u * g.S + s];
+    const int2 p = partial2[(size_t)u * g.S + s];
     if (lex_less(p.x, p.y, dj, ij)) { dj = p.x; ij = p.y; }
-    nless += p.z; nbad += p.w;
   }
   const int q = undecided[u];
   MatchRow o = rows[q];
   o.tj = ij == BIG ? -1 : ij;
   o.dj = (float)dj;
-  o.nless = nless; o.nbad = nbad;
+  o.nless = e.x; o.nbad = e.y;
   rows[q] = o;
 }
 
-size_t match_workspace_bytes(int n1, int n2, int *S_out, int *tilesPerSplit_out) {
-  const int nQB = (n1 + 127) / 128;
+// ---- workspace layout: ONE description used by the size query and by the launcher -------------------------------------------
+struct MatchLayout {
+  int S, tilesPerSplit, slots, evLimit;
+  size_t norm1, norm2, cst, tiles, partial, partial2, dmin, undecided, evCount, ev, evRes, counter, bytes;
+};
+static MatchLayout match_layout(int n1, int n2, int nn) {
+  MatchLayout L;
+  const int nQB = (n1 + QPB - 1) / QPB;
   const int ntiles = (n2 + 31) / 32;
-  int S = (768 + nQB - 1) / nQB;                 // aim at >= 3 workgroups per CU
-  if (S > ntiles / 4) S = ntiles / 4;           // at least 4 tiles per split
+  int S = (1024 + nQB - 1) / nQB;                 // aim at one full round of 4 workgroups per CU
+  if (S > ntiles / CHUNK) S = ntiles / CHUNK;     // at least one chunk per split
   if (S < 1) S = 1;
   int tps = (ntiles + S - 1) / S;
-  if (tps > TILES_PER_SPLIT_MAX) { tps = TILES_PER_SPLIT_MAX; }
+  tps = ((tps + CHUNK - 1) / CHUNK) * CHUNK;
   S = (ntiles + tps - 1) / tps;
   if (S < 1) S = 1;
-  *S_out = S; *tilesPerSplit_out = tps;
-  size_t bytes = 0;
-  bytes += (size_t)(n1 + 2 * (size_t)n2) * 4 + 768;  // norms (+ the sweep-1 column constants of the trains)
-  bytes += (size_t)n1 * S * 16 * 2 + 256;        // partial, partial2
-  bytes += (size_t)n1 * 4 * 2 + 256;             // dmin, undecided
-  bytes += 256;                                  // counter
-  return bytes;
+  L.S = S; L.tilesPerSplit = tps; L.slots = S * tps * 32;
+  L.evLimit = (nn < 2 ? 2 : (nn > 4094 ? 4094 : nn)) + 2;
+  size_t w = 0;
+  auto take = [&](size_t bytes) { const size_t o = w; w += (bytes + 255) & ~(size_t)255; return o; };
+  L.norm1 = take((size_t)n1 * 4);
+  L.norm2 = take((size_t)L.slots * 4);
+  L.cst = take((size_t)L.slots * 4);
+  L.tiles = take((size_t)L.slots * 128);
+  L.partial = take((size_t)n1 * S * 16);
+  L.partial2 = take((size_t)n1 * S * 8);
+  L.dmin = take((size_t)n1 * 4);
+  L.undecided = take((size_t)n1 * 4);
+  L.evCount = take((size_t)n1 * 4);
+  L.ev = take((size_t)n1 * L.evLimit * 4);
+  L.evRes = take((size_t)n1 * 16);
+  L.counter = take(64);
+  L.bytes = w;
+  return L;
 }
+size_t match_workspace_bytes(int n1, int n2, int nn) { return match_layout(n1, n2, nn).bytes; }
 
 // ---- batched entry points: blockIdx.z selects one of up to MATCH_MAXB independent problems (the pairs of a launch set).
-// At 2-3 k descriptors per image a problem is six launches of ~10-20 us of mostly latency, so the problems of a batch
-// share the launches.
 struct MatchProblem {
   const uint8_t *d1, *d2;
   const double *pos2;
-  int *norm1, *norm2, *normS2, *dmin, *undecided, *counter;
-  int4 *partial, *partial2;
+  int *norm1, *norm2, *cst, *dmin, *undecided, *counter, *evCount, *ev;
+  unsigned char *tiles;
+  int4 *partial, *evRes;
+  int2 *partial2;
   MatchRow *rows;
   MatchGeom g;
+  int slots, evLimit;
 };
 struct MatchBatch { MatchProblem p[MATCH_MAXB]; };
 
-__global__ __launch_bounds__(256) void k_desc_norms(MatchBatch b) {
+__global__ __launch_bounds__(256) void k_match_pack(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
-  if (blockIdx.y == 0) norms_body(P.d1, P.g.n1, P.norm1, (int *)nullptr);
-  else norms_body(P.d2, P.g.n2, P.norm2, P.normS2);
+  pack_body(P.d1, P.g.n1, P.norm1, P.d2, P.g.n2, P.slots, P.tiles, P.cst, P.norm2);
 }
-__global__ __launch_bounds__(256) void k_match_sweep1(MatchBatch b) {
+__global__ __launch_bounds__(256, 4) void k_match_sweep1(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
-  if ((int)blockIdx.x * 128 >= P.g.n1 || (int)blockIdx.y >= P.g.S) return;
-  sweep1_body(P.d1, P.norm1, P.d2, P.normS2, P.g, P.partial);
+  if ((int)blockIdx.x * QPB >= P.g.n1 || (int)blockIdx.y >= P.g.S) return;
+  sweep1_body(P.d1, P.norm1, P.tiles, P.cst, P.g, P.partial);
 }
 __global__ __launch_bounds__(256) void k_match_decide(MatchBatch b, double sqminratio, double contrDistSq) {
   const MatchProblem &P = b.p[blockIdx.z];
-  decide_body(P.partial, P.g, P.pos2, sqminratio, contrDistSq, P.rows, P.dmin, P.undecided, P.counter);
+  if ((int)blockIdx.x * 16 >= P.g.n1) return;
+  decide_body(P.d1, P.norm1, P.d2, P.norm2, P.partial, P.g, P.pos2, sqminratio, contrDistSq, P.rows, P.dmin, P.undecided,
+              P.counter);
 }
-__global__ __launch_bounds__(256) void k_match_sweep2(MatchBatch b, double contrDistSq) {
+__global__ __launch_bounds__(256, 4) void k_match_sweep2(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
-  if ((int)blockIdx.x * 128 >= P.g.n1 || (int)blockIdx.y >= P.g.S) return;
-  sweep2_body(P.d1, P.norm1, P.d2, P.norm2, P.g, P.pos2, contrDistSq, P.rows, P.dmin, P.undecided, P.counter, P.partial2);
+  if ((int)blockIdx.x * QPB >= P.g.n1 || (int)blockIdx.y >= P.g.S) return;
+  sweep2_body(P.d1, P.norm1, P.tiles, P.cst, P.g, P.dmin, P.undecided, P.counter, P.partial2, P.evCount, P.ev, P.evLimit);
+}
+__global__ __launch_bounds__(256) void k_match_events(MatchBatch b, double contrDistSq) {
+  const MatchProblem &P = b.p[blockIdx.z];
+  if ((int)blockIdx.x * 4 >= P.g.n1) return;
+  events_body(P.d1, P.norm1, P.d2, P.norm2, P.g, P.pos2, contrDistSq, P.rows, P.dmin, P.undecided, P.counter, P.evCount, P.ev,
+              P.evLimit, P.evRes);
 }
 __global__ __launch_bounds__(256) void k_match_finish(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
-  finish_body(P.partial2, P.g, P.undecided, P.counter, P.rows);
+  finish_body(P.partial2, P.evRes, P.g, P.undecided, P.counter, P.rows);
 }
 
-// Problems with n1 == 0 or n2 == 0 must be left out by the caller.  workspace[i] holds match_workspace_bytes(n1[i], n2[i]).
+// Problems with n1 == 0 or n2 == 0 must be left out by the caller.  workspace[i] holds match_workspace_bytes(n1[i], n2[i], nn).
 void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
-                        const double *const *pos2, double sqminratio, double contrDistSq, MatchRow *const *rows,
+                        const double *const *pos2, double sqminratio, double contrDistSq, int nn, MatchRow *const *rows,
                         void *const *workspace) {
   if (nb <= 0) return;
   MatchBatch b;
   memset(&b, 0, sizeof b);
-  int maxN = 0, maxN1 = 0, maxS = 0;
+  int maxN1 = 0, maxS = 0, maxSlots = 0;
   for (int i = 0; i < nb; i++) {
     MatchProblem &P = b.p[i];
-    P.g.n1 = n1[i]; P.g.n2 = n2[i];
-    match_workspace_bytes(n1[i], n2[i], &P.g.S, &P.g.tilesPerSplit);
+    const MatchLayout L = match_layout(n1[i], n2[i], nn);
+    P.g.n1 = n1[i]; P.g.n2 = n2[i]; P.g.S = L.S; P.g.tilesPerSplit = L.tilesPerSplit;
+    P.slots = L.slots; P.evLimit = L.evLimit;
     char *w = (char *)workspace[i];
-    auto take = [&](size_t bytes) { char *p = w; w += (bytes + 255) & ~(size_t)255; return p; };
-    P.norm1 = (int *)take((size_t)n1[i] * 4); P.norm2 = (int *)take((size_t)n2[i] * 4); P.normS2 = (int *)take((size_t)n2[i] * 4);
-    P.partial = (int4 *)take((size_t)n1[i] * P.g.S * 16); P.partial2 = (int4 *)take((size_t)n1[i] * P.g.S * 16);
-    P.dmin = (int *)take((size_t)n1[i] * 4); P.undecided = (int *)take((size_t)n1[i] * 4);
-    P.counter = (int *)take(64);
+    P.norm1 = (int *)(w + L.norm1); P.norm2 = (int *)(w + L.norm2); P.cst = (int *)(w + L.cst);
+    P.tiles = (unsigned char *)(w + L.tiles);
+    P.partial = (int4 *)(w + L.partial); P.partial2 = (int2 *)(w + L.partial2);
+    P.dmin = (int *)(w + L.dmin); P.undecided = (int *)(w + L.undecided);
+    P.evCount = (int *)(w + L.evCount); P.ev = (int *)(w + L.ev); P.evRes = (int4 *)(w + L.evRes);
+    P.counter = (int *)(w + L.counter);
     P.d1 = d1[i]; P.d2 = d2[i]; P.pos2 = pos2[i]; P.rows = rows[i];
     hipMemsetAsync(P.counter, 0, 4, s);
-    maxN = std::max(maxN, std::max(n1[i], n2[i])); maxN1 = std::max(maxN1, n1[i]); maxS = std::max(maxS, P.g.S);
+    hipMemsetAsync(P.evCount, 0, (size_t)n1[i] * 4, s);
+    maxN1 = std::max(maxN1, n1[i]); maxS = std::max(maxS, L.S); maxSlots = std::max(maxSlots, L.slots);
   }
-  hipLaunchKernelGGL(k_desc_norms, dim3((maxN + 255) / 256, 2, nb), dim3(256), 0, s, b);
-  const dim3 grid((maxN1 + 127) / 128, maxS, nb), gridQ((maxN1 + 255) / 256, 1, nb);
+  hipLaunchKernelGGL(k_match_pack, dim3((std::max(maxN1, maxSlots) + 255) / 256, 2, nb), dim3(256), 0, s, b);
+  const dim3 grid((maxN1 + QPB - 1) / QPB, maxS, nb);
   hipLaunchKernelGGL(k_match_sweep1, grid, dim3(256), 0, s, b);
-  hipLaunchKernelGGL(k_match_decide, gridQ, dim3(256), 0, s, b, sqminratio, contrDistSq);
-  hipLaunchKernelGGL(k_match_sweep2, grid, dim3(256), 0, s, b, contrDistSq);
-  hipLaunchKernelGGL(k_match_finish, gridQ, dim3(256), 0, s, b);
+  hipLaunchKernelGGL(k_match_decide, dim3((maxN1 + 15) / 16, 1, nb), dim3(256), 0, s, b, sqminratio, contrDistSq);
+  hipLaunchKernelGGL(k_match_sweep2, grid, dim3(256), 0, s, b);
+  hipLaunchKernelGGL(k_match_events, dim3((maxN1 + 3) / 4, 1, nb), dim3(256), 0, s, b, contrDistSq);
+  hipLaunchKernelGGL(k_match_finish, dim3((maxN1 + 255) / 256, 1, nb), dim3(256), 0, s, b);
 }
 
 void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2,
-                  double sqminratio, double contrDistSq, MatchRow *rows, void *workspace) {
+                  double sqminratio, double contrDistSq, int nn, MatchRow *rows, void *workspace) {
   if (n1 <= 0 || n2 <= 0) return;
-  launch_match_batch(s, 1, &d1, &n1, &d2, &n2, &pos2, sqminratio, contrDistSq, &rows, &workspace);
+  launch_match_batch(s, 1, &d1, &n1, &d2, &n2, &pos2, sqminratio, contrDistSq, nn, &rows, &workspace);
 }
 
 }  // namespace mx

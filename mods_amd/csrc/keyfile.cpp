@@ -72,23 +72,30 @@ int load_regions(const char *path, const char *det_name, const char *desc_name, 
   regs.clear(); desc.clear(); *dim = 0;
   std::ifstream f(path);
   if (!f.is_open()) { set_error(std::string("cannot open ") + path + " to load keypoints"); return MODSX_ERR_ARG; }
+  // counts come from the file: bound them before they size anything (a corrupt header must not reach reserve())
+  const int MAX_CLASSES = 1 << 12, MAX_KP = 1 << 26, MAX_DIM = 1 << 16;
+  auto bad = [&](const char *what) { set_error(std::string("malformed key file ") + path + ": " + what); return MODSX_ERR_ARG; };
   int ndet = 0;
   f >> ndet;
+  if (!f || ndet < 0 || ndet > MAX_CLASSES) return bad("detector count");
   bool taken = false;
-  for (int d = 0; d < ndet && f; d++) {
+  for (int d = 0; d < ndet; d++) {
     std::string det;
     int ndesc = 0;
     f >> det >> ndesc;
-    for (int q = 0; q < ndesc && f; q++) {
+    if (!f || ndesc < 0 || ndesc > MAX_CLASSES) return bad("descriptor class count");
+    for (int q = 0; q < ndesc; q++) {
       std::string dn;
       int nkp = 0, dsize = 0;
       f >> dn >> nkp;
+      if (!f || nkp < 0 || nkp > MAX_KP) return bad("region count");
       // SaveRegions omits the length line for an empty class (:2157-2161) while LoadRegions reads it unconditionally
       // (:2200-2201) and so mis-parses what follows an empty class; here the file is read the way it is written
       if (nkp > 0) f >> dsize;
+      if (!f || dsize < 0 || dsize > MAX_DIM) return bad("descriptor length");
       const bool want = !taken && (!det_name || !*det_name || det == det_name) && (!desc_name || !*desc_name || dn == desc_name);
       if (want) { taken = true; *dim = dsize; *found_det = det; *found_desc = dn; regs.reserve(nkp); desc.reserve((size_t)nkp * dsize); }
-      for (int i = 0; i < nkp && f; i++) {
+      for (int i = 0; i < nkp; i++) {
         modsx_region r;
         memset(&r, 0, sizeof r);
         f >> r.id >> r.img_id >> r.img_reproj_id;      // loadAR, :134-147
@@ -97,16 +104,17 @@ int load_regions(const char *path, const char *det_name, const char *desc_name, 
         load_kp(r.reproj_kp, f);
         int sz = 0;
         f >> sz;
+        if (!f || sz < 0 || sz > MAX_DIM) return bad("truncated or corrupt region record");
         for (int k = 0; k < sz; k++) {
           float v;
           f >> v;
           if (want && k < dsize) desc.push_back(v);
         }
+        if (!f) return bad("truncated descriptor");   // EOF inside a record is an error, not a short file
         if (want) { for (int k = sz; k < dsize; k++) desc.push_back(0.f); regs.push_back(r); }
       }
     }
   }
-  if (!f && !f.eof()) { set_error(std::string("malformed key file ") + path); return MODSX_ERR_ARG; }
   if (!taken) { set_error("requested detector/descriptor class not in the key file"); return MODSX_ERR_ARG; }
   return MODSX_OK;
 }
