@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmodsx.so")
+LIB_PATH = os.environ.get("MODSX_LIB", os.path.join(_HERE, "libmodsx.so"))   # MODSX_LIB: kernel experiments (tools/)
 
 KEYPOINT = np.dtype([("x", "f8"), ("y", "f8"), ("a11", "f8"), ("a12", "f8"), ("a21", "f8"), ("a22", "f8"),
                      ("s", "f8"), ("response", "f8"), ("octave_number", "i4"), ("pyramid_scale", "f8"),

@@ -930,7 +930,8 @@ int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int
   hipStream_t s = c->stream;
   const double sqminratio = ratioT * ratioT, contrDistSq = contradDist * contradDist;
   if (!(sqminratio < 1.0)) { set_error("match ratio >= 1 (PDF mode of MatchFlannFGINN) is not supported"); return MODSX_ERR_ARG; }
-  if (nn < 2) { set_error("match_device_batch: nn < 2"); return MODSX_ERR_ARG; }
+  // nn = neighbours the walk may look at (default 50, matching.hpp:268-269); the event lists of the device matcher hold up to 64 groups
+  if (nn < 2 || nn > 64) { set_error("match: nn must be in [2, 64]"); return MODSX_ERR_ARG; }
   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
   size_t posOfs[MATCH_MAXB], rowOfs[MATCH_MAXB], workOfs[MATCH_MAXB], posB = 0, rowB = 0, workB = 0;
   int live[MATCH_MAXB], nl = 0;
@@ -939,7 +940,7 @@ int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int
     if (n1[i] <= 0 || n2[i] <= 0) continue;
     posOfs[nl] = posB; posB += up((size_t)n2[i] * 16);
     rowOfs[nl] = rowB; rowB += up((size_t)n1[i] * sizeof(MatchRow));
-    workOfs[nl] = workB; workB += up(match_workspace_bytes(n1[i], n2[i], nn));
+    workOfs[nl] = workB; workB += up(match_workspace_bytes(n1[i], n2[i]));
     live[nl++] = i;
   }
   if (!nl) return MODSX_OK;

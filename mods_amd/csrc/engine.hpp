@@ -181,7 +181,7 @@ void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *im
                      const double *wts, int photoNorm, int descType, double maxBin, const DescOut &outs);
 void launch_warp_affine(hipStream_t s, const WarpJob &jb);
 void launch_blur_pass(hipStream_t s, const float *src, float *dst, int rows, int cols, const float *taps, int n, int pass);
-size_t match_workspace_bytes(int n1, int n2, int nn);
+size_t match_workspace_bytes(int n1, int n2);
 void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2,
                   double sqminratio, double contrDistSq, int nn, MatchRow *rows, void *workspace);
 constexpr int MATCH_MAXB = 4;   // independent matching problems per launch set (blockIdx.z)

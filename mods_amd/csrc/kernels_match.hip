@@ -32,11 +32,12 @@
 //    fragment reads are conflict-free) plus the 32 per-train key constants of each tile; the sweeps then stage 4 tiles per
 //    barrier with direct global->LDS loads (no staging registers), double-buffered; a wave holds 2 x 32 queries, so every
 //    fragment read from LDS feeds two MFMA chains.
-//  * sweep 2 folds the threshold into the accumulator: srcC = -ceil((Dmin - |a'|^2) / 2) makes the same key relative to
-//    Dmin, a group without a sub-threshold train costs the same 26 instructions (its minimum feeds NNj), a group WITH
-//    one is queued as an 4-byte event (per-query slots, no contended counter) and k_match_events recomputes its 16
-//    distances exactly for nless / nbad / NNj.  A query with more than nn + 2 event groups has nless > nn - 2 whatever
-//    they contain and is rejected without being looked at further.
+//  * sweep 2 is the same loop with another two-instruction update: d < Dmin <=> key < (Dmin - |a'|^2) << 8, so a group
+//    without a sub-threshold train feeds its minimum to NNj, and a group WITH one is logged as a 4-byte event in the
+//    lane's own slots (no atomics); k_match_events recomputes the 16 distances of every event group exactly for
+//    nless / nbad / NNj (and falls back to an exact scan of all trains when a lane ran out of slots).
+//  * inside a wave the four MFMAs of one (tile, query set) chain are issued between the quarters of the reduction of the
+//    previous chain, so the matrix pipe and the vector ALU overlap without relying on other waves being out of phase.
 #include "engine.hpp"
 
 namespace mx {
@@ -179,99 +180,204 @@ MX_D int decode_idx(int lb, int chunkTile0, int hi) {
   return (chunkTile0 + (lb >> 4) - 1) * 32 + row_of(lb & 15, hi);
 }
 
-// ---------------- sweep 1: per (query, split) top-2 of the group minima -------------------------------------------------
-__device__ __forceinline__ void sweep1_body(const uint8_t *d1, const int *norm1, const unsigned char *tiles, const int *cst,
-                                            MatchGeom g, int4 *partial) {
+// ---------------- the sweep: MODE 0 = per (query, split) top-2 of the group minima, MODE 1 = NNj + event groups ------------
+// One instruction stream per wave keeps both pipes busy: while the four MFMAs of a (tile, query set) chain run, the wave
+// reduces the accumulators of the previous chain (26 VALU), so the matrix pipe never waits for a whole wave to leave its
+// epilogue.  Fragments and key constants of the next tile are read from LDS one tile ahead (two register sets).
+constexpr int EVCAP = 16;                  // event slots per (undecided query, split, lane half); more -> exact fallback
+struct SweepArgs {
+  const uint8_t *d1;
+  const int *norm1;
+  const unsigned char *tiles;
+  const int *cst;
+  MatchGeom g;
+  int4 *partial;          // MODE 0
+  const int *dmin, *undecided, *nUndecided;   // MODE 1
+  int2 *partial2;
+  int *evCnt, *ev;
+};
+
+template <int MODE>
+__device__ __forceinline__ void sweep_body(const SweepArgs &A) {
   __shared__ __attribute__((aligned(16))) unsigned char sm[2][STAGE_B];
+  const MatchGeom g = A.g;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 31, hi = lane >> 5;
   const int sp = blockIdx.y;
+  const int nQ = MODE == 0 ? g.n1 : *A.nUndecided;
+  if ((int)blockIdx.x * QPB >= nQ) return;
   const int q0 = blockIdx.x * QPB + wave * (32 * QSETS);
   v4i bq[QSETS][4];
+  int mA[QSETS], mB[QSETS], iA[QSETS], iB[QSETS];   // MODE 0: m1, m2, i1, i2;  MODE 1: mj, threshold key, ij, event count
+  int qsel[QSETS];
 #pragma unroll
   for (int s = 0; s < QSETS; s++) {
-    const int qrow = min(q0 + 32 * s + col, g.n1 - 1);
+    const int u = min(q0 + 32 * s + col, nQ - 1);
+    qsel[s] = MODE == 0 ? u : A.undecided[u];
 #pragma unroll
-    for (int kb = 0; kb < 4; kb++) bq[s][kb] = load_q(d1, qrow, kb, hi);
+    for (int kb = 0; kb < 4; kb++) bq[s][kb] = load_q(A.d1, qsel[s], kb, hi);
+    mA[s] = NONE; iA[s] = -1;
+    if (MODE == 0) { mB[s] = NONE; iB[s] = -1; }
+    else { mB[s] = (A.dmin[qsel[s]] - A.norm1[qsel[s]]) << 8; iB[s] = 0; }   // d < Dmin  <=>  key < (Dmin - |a'|^2) << 8
   }
   const int ntiles4 = (((g.n2 + 31) >> 5) + TPS - 1) & ~(TPS - 1);
   const int tBeg = sp * g.tilesPerSplit, tEnd = min(tBeg + g.tilesPerSplit, ntiles4);
-  int m1[QSETS], m2[QSETS], i1[QSETS], i2[QSETS];
-#pragma unroll
-  for (int s = 0; s < QSETS; s++) { m1[s] = NONE; m2[s] = NONE; i1[s] = -1; i2[s] = -1; }
   auto flush = [&](int chunkTile0) {
 #pragma unroll
     for (int s = 0; s < QSETS; s++) {
-      const int lb1 = m1[s] & 255, lb2 = m2[s] & 255;
-      const int n2i = lb2 ? decode_idx(lb2, chunkTile0, hi) : (lb1 ? i1[s] : i2[s]);
-      const int n1i = lb1 ? decode_idx(lb1, chunkTile0, hi) : i1[s];
-      i1[s] = n1i; i2[s] = n2i;
-      m1[s] &= ~255; m2[s] &= ~255;
+      if (MODE == 0) {
+        const int lb1 = mA[s] & 255, lb2 = mB[s] & 255;
+        const int n2i = lb2 ? decode_idx(lb2, chunkTile0, hi) : (lb1 ? iA[s] : iB[s]);
+        const int n1i = lb1 ? decode_idx(lb1, chunkTile0, hi) : iA[s];
+        iA[s] = n1i; iB[s] = n2i;
+        mA[s] &= ~255; mB[s] &= ~255;
+      } else {
+        const int lb = mA[s] & 255;
+        if (lb) iA[s] = decode_idx(lb, chunkTile0, hi);
+        mA[s] &= ~255;
+      }
     }
   };
-  if (tBeg < tEnd) stage_group(tiles, cst, tBeg, sm[0], wave, lane);
+  // reduce one accumulator: 16 keys, v_min3 tree, then the running state
+  auto epilogue = [&](const v16i &acc, const int *C, int s, int tile) {
+    int k[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) k[r] = (acc[r] << 9) + C[r];
+    const int t = tree_min16(k);
+    if (MODE == 0) {
+      mB[s] = imed3(mA[s], mB[s], t);
+      mA[s] = min(mA[s], t);
+    } else if (t < mB[s]) {
+      // a train of this group is closer than Dmin: k_match_events takes the whole group (its other rows included)
+      const int u = q0 + 32 * s + col;
+      if (u < nQ) {
+        if (iB[s] < EVCAP) A.ev[(((size_t)u * g.S + sp) * 2 + hi) * EVCAP + iB[s]] = tile;
+        iB[s]++;
+      }
+    } else mA[s] = min(mA[s], t);
+  };
+  auto load_af = [&](const unsigned char *buf, int q, v4i *af) {
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) af[kb] = read_a(buf + q * TILE_B, col, kb, hi);
+  };
+  auto load_c = [&](const unsigned char *buf, int q, int *C) {
+#pragma unroll
+    for (int gq = 0; gq < 4; gq++) {
+      const v4i c4 = *reinterpret_cast<const v4i *>(buf + TPS * TILE_B + q * 128 + (8 * gq + 4 * hi) * 4);
+      C[4 * gq] = c4[0]; C[4 * gq + 1] = c4[1]; C[4 * gq + 2] = c4[2]; C[4 * gq + 3] = c4[3];
+    }
+  };
+  v4i af[2][4];
+  int C[2][16];
+  v16i acc0, acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // the pipeline starts with a neutral pending chain: zero accumulator, NONE constants -> keys that change nothing
+#pragma unroll
+  for (int r = 0; r < 16; r++) C[1][r] = NONE;
+  int pendTile = 0;
+  if (tBeg < tEnd) stage_group(A.tiles, A.cst, tBeg, sm[0], wave, lane);
   int it = 0;
   for (int tg = tBeg; tg < tEnd; tg += TPS, it++) {
     const unsigned char *buf = sm[it & 1];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tg + TPS < tEnd) stage_group(tiles, cst, tg + TPS, sm[(it & 1) ^ 1], wave, lane);
+#ifndef EXP_NODMA
+    if (tg + TPS < tEnd) stage_group(A.tiles, A.cst, tg + TPS, sm[(it & 1) ^ 1], wave, lane);
+#endif
+#ifdef EXP_NOLDS
+    if (it == 0) { load_af(buf, 0, af[0]); load_c(buf, 0, C[0]); load_af(buf, 1, af[1]); }
+#else
+    load_af(buf, 0, af[0]);
+    load_c(buf, 0, C[0]);
+#endif
 #pragma unroll
     for (int q = 0; q < TPS; q++) {
-      const unsigned char *tb = buf + q * TILE_B;
-      v4i af[4];
+      const int cur = q & 1;
+      // The fragment / constant reads of the NEXT tile are issued as a burst in front of each phase and fenced there
+      // (sched_barrier): left to the scheduler they sink to just before their first use and every MFMA waits for LDS.
+      // phase A: chain of (tile q, set 0) beside the reduction of the pending chain (previous tile, set 1)
+#ifndef EXP_NOLDS
+      if (q + 1 < TPS) load_af(buf, q + 1, af[cur ^ 1]);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int kb = 0; kb < 4; kb++) af[kb] = read_a(tb, col, kb, hi);
-      int C[16];
+      for (int kb = 0; kb < 4; kb++) acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[cur][kb], bq[0][kb], acc0, 0, 0, 0);
+      epilogue(acc1, C[cur ^ 1], 1, pendTile);
 #pragma unroll
-      for (int gq = 0; gq < 4; gq++) {
-        const v4i c4 = *reinterpret_cast<const v4i *>(buf + TPS * TILE_B + q * 128 + (8 * gq + 4 * hi) * 4);
-        C[4 * gq] = c4[0]; C[4 * gq + 1] = c4[1]; C[4 * gq + 2] = c4[2]; C[4 * gq + 3] = c4[3];
+      for (int kb = 0; kb < 4; kb++) {   // one MFMA, then a quarter of the reduction
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
       }
-      v16i acc[QSETS];
+      __builtin_amdgcn_sched_barrier(0);
+      // phase B: chain of (tile q, set 1) beside the reduction of (tile q, set 0)
+#ifndef EXP_NOLDS
+      if (q + 1 < TPS) load_c(buf, q + 1, C[cur ^ 1]);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      acc1 = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int s = 0; s < QSETS; s++) {
-        acc[s] = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int kb = 0; kb < 4; kb++) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[cur][kb], bq[1][kb], acc1, 0, 0, 0);
+      epilogue(acc0, C[cur], 0, tg + q);
 #pragma unroll
-        for (int kb = 0; kb < 4; kb++) acc[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[kb], bq[s][kb], acc[s], 0, 0, 0);
+      for (int kb = 0; kb < 4; kb++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
       }
-#pragma unroll
-      for (int s = 0; s < QSETS; s++) {
-        int k[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) k[r] = (acc[s][r] << 9) + C[r];
-        const int t = tree_min16(k);
-        m2[s] = imed3(m1[s], m2[s], t);
-        m1[s] = min(m1[s], t);
-      }
+      __builtin_amdgcn_sched_barrier(0);
+      pendTile = tg + q;
     }
-    if ((it % (CHUNK / TPS)) == CHUNK / TPS - 1) flush(tg + TPS - CHUNK);
+    if ((it % (CHUNK / TPS)) == CHUNK / TPS - 1) {
+      // end of an index chunk: drain the pending chain, then move the indices of changed keys out of the low byte
+      epilogue(acc1, C[1], 1, pendTile);
+      acc1 = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < 16; r++) C[1][r] = NONE;
+      flush(tg + TPS - CHUNK);
+    }
   }
-  if (it % (CHUNK / TPS)) flush(tBeg + (it / (CHUNK / TPS)) * CHUNK);
-  // the two lane halves of a query saw different rows: merge their sorted pairs, convert to distances, store
+  if (it % (CHUNK / TPS)) {
+    epilogue(acc1, C[1], 1, pendTile);
+    flush(tBeg + (it / (CHUNK / TPS)) * CHUNK);
+  }
+  // the two lane halves of a query saw different rows: merge, convert keys to distances, store
 #pragma unroll
   for (int s = 0; s < QSETS; s++) {
     const int q = q0 + 32 * s + col;
-    const int na = norm1[min(q, g.n1 - 1)];
-    int d0 = i1[s] < 0 ? BIG : (m1[s] >> 8) + na, j0 = i1[s] < 0 ? BIG : i1[s];
-    int dd1 = i2[s] < 0 ? BIG : (m2[s] >> 8) + na, j1 = i2[s] < 0 ? BIG : i2[s];
-    const int od0 = __shfl_xor(d0, 32), oj0 = __shfl_xor(j0, 32), od1 = __shfl_xor(dd1, 32), oj1 = __shfl_xor(j1, 32);
-    if (lex_less(od0, oj0, d0, j0)) {
-      if (lex_less(od1, oj1, d0, j0)) { dd1 = od1; j1 = oj1; } else { dd1 = d0; j1 = j0; }
-      d0 = od0; j0 = oj0;
-    } else if (lex_less(od0, oj0, dd1, j1)) { dd1 = od0; j1 = oj0; }
-    if (hi == 0 && q < g.n1) partial[(size_t)q * g.S + sp] = make_int4(d0, j0, dd1, j1);
+    const int na = A.norm1[qsel[s]];
+    if (MODE == 0) {
+      int d0 = iA[s] < 0 ? BIG : (mA[s] >> 8) + na, j0 = iA[s] < 0 ? BIG : iA[s];
+      int dd1 = iB[s] < 0 ? BIG : (mB[s] >> 8) + na, j1 = iB[s] < 0 ? BIG : iB[s];
+      const int od0 = __shfl_xor(d0, 32), oj0 = __shfl_xor(j0, 32), od1 = __shfl_xor(dd1, 32), oj1 = __shfl_xor(j1, 32);
+      if (lex_less(od0, oj0, d0, j0)) {
+        if (lex_less(od1, oj1, d0, j0)) { dd1 = od1; j1 = oj1; } else { dd1 = d0; j1 = j0; }
+        d0 = od0; j0 = oj0;
+      } else if (lex_less(od0, oj0, dd1, j1)) { dd1 = od0; j1 = oj0; }
+      if (hi == 0 && q < nQ) A.partial[(size_t)q * g.S + sp] = make_int4(d0, j0, dd1, j1);
+    } else {
+      int dj = iA[s] < 0 ? BIG : (mA[s] >> 8) + na, tj = iA[s] < 0 ? BIG : iA[s];
+      const int od = __shfl_xor(dj, 32), ot = __shfl_xor(tj, 32);
+      if (lex_less(od, ot, dj, tj)) { dj = od; tj = ot; }
+      if (q < nQ) {
+        A.evCnt[((size_t)q * g.S + sp) * 2 + hi] = iB[s];
+        if (hi == 0) A.partial2[(size_t)q * g.S + sp] = make_int2(dj, tj);
+      }
+    }
   }
 }
 
 // ---------------- decide: merge splits, the hidden candidate of NN0's group, j = 1 of the walk ---------------------------
 // 16 lanes per query.  sweep 1 ranks group minima, so the one candidate it cannot have seen is the second-best inside the
 // group (same tile, same lane half) of the overall winner: lane l recomputes the distance of that group's row l exactly.
+constexpr int DECIDE_Q = 64;   // queries per 1024-thread workgroup of k_match_decide
 __device__ __forceinline__ void decide_body(const uint8_t *d1, const int *norm1, const uint8_t *d2, const int *norm2,
                                             const int4 *partial, MatchGeom g, const double *pos2, double sqminratio,
                                             double contrDistSq, MatchRow *rows, int *dmin, int *undecided, int *nUndecided) {
+  // undecided queries are compacted with ONE global atomic per workgroup (a counter word takes ~90 atomics per us)
+  __shared__ int sList[DECIDE_Q], sCount, sBase;
+  if (threadIdx.x == 0) sCount = 0;
+  __syncthreads();
   const int l = threadIdx.x & 15;
-  const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int q = blockIdx.x * DECIDE_Q + (threadIdx.x >> 4);
   const bool live = q < g.n1;
   const int qc = live ? q : g.n1 - 1;
   int d0 = BIG, i0 = BIG, dd1 = BIG, j1 = BIG;
@@ -302,166 +408,117 @@ __device__ __forceinline__ void decide_body(const uint8_t *d1, const int *norm1,
     }
     if (lex_less(hd, ht, dd1, j1)) { dd1 = hd; j1 = ht; }
   }
-  if (!live || l) return;
-  MatchRow o;
-  o.t0 = i0 == BIG ? -1 : i0; o.t1 = j1 == BIG ? -1 : j1; o.tj = -1; o.nless = 0; o.nbad = 0;
-  o.d0 = (float)d0; o.d1 = (float)dd1; o.dj = 0.f;
-  int dm = 0;
-  if (i0 != BIG && j1 != BIG) {
-    if (ratio_pass((float)d0, (float)dd1, sqminratio)) { o.tj = j1; o.dj = (float)dd1; }       // accepted at j = 1
-    else {
-      const double dx = pos2[2 * i0] - pos2[2 * j1], dy = pos2[2 * i0 + 1] - pos2[2 * j1 + 1];
-      if (dx * dx + dy * dy > contrDistSq) o.nbad = 1;                                      // first contradictive
+  if (live && l == 0) {
+    MatchRow o;
+    o.t0 = i0 == BIG ? -1 : i0; o.t1 = j1 == BIG ? -1 : j1; o.tj = -1; o.nless = 0; o.nbad = 0;
+    o.d0 = (float)d0; o.d1 = (float)dd1; o.dj = 0.f;
+    int dm = 0;
+    if (i0 != BIG && j1 != BIG) {
+      if (ratio_pass((float)d0, (float)dd1, sqminratio)) { o.tj = j1; o.dj = (float)dd1; }       // accepted at j = 1
       else {
-        dm = ratio_dmin(d0, sqminratio);
-        if (dm <= MAXD) {          // otherwise no distance can pass the ratio test: the walk ends without a match
-          const int slot = atomicAdd(nUndecided, 1);
-          undecided[slot] = q;
-          o.nless = -1;   // filled by sweep 2
-        }
-      }
-    }
-  }
-  rows[q] = o;
-  dmin[q] = dm;
-}
-
-// ---------------- sweep 2 over the undecided queries ----------------------------------------------------------------
-__device__ __forceinline__ void sweep2_body(const uint8_t *d1, const int *norm1, const unsigned char *tiles, const int *cst,
-                                            MatchGeom g, const int *dmin, const int *undecided, const int *nUndecided,
-                                            int2 *partial2, int *evCount, int *ev, int evLimit) {
-  __shared__ __attribute__((aligned(16))) unsigned char sm[2][STAGE_B];
-  const int nU = *nUndecided;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int col = lane & 31, hi = lane >> 5;
-  const int sp = blockIdx.y;
-  if ((int)blockIdx.x * QPB >= nU) return;
-  const int u0 = blockIdx.x * QPB + wave * (32 * QSETS);
-  v4i bq[QSETS][4];
-  v16i base[QSETS];
-  int thr[QSETS], dmo[QSETS];
-#pragma unroll
-  for (int s = 0; s < QSETS; s++) {
-    const int u = min(u0 + 32 * s + col, nU - 1);
-    const int qA = undecided[u];
-#pragma unroll
-    for (int kb = 0; kb < 4; kb++) bq[s][kb] = load_q(d1, qA, kb, hi);
-    // key = (d - Dmin - odd) << 8 | idx with Dq = Dmin - |a'|^2, odd = Dq & 1: the accumulator starts at -ceil(Dq / 2)
-    const int Dm = dmin[qA], Dq = Dm - norm1[qA];
-    const int c = (Dq + 1) >> 1, odd = Dq & 1;
-#pragma unroll
-    for (int r = 0; r < 16; r++) base[s][r] = -c;
-    thr[s] = -(odd << 8);     // d < Dmin  <=>  key < thr
-    dmo[s] = Dm + odd;
-  }
-  const int ntiles = (g.n2 + 31) >> 5;
-  const int ntiles4 = (ntiles + TPS - 1) & ~(TPS - 1);
-  const int tBeg = sp * g.tilesPerSplit, tEnd = min(tBeg + g.tilesPerSplit, ntiles4);
-  int mj[QSETS], ij[QSETS];
-#pragma unroll
-  for (int s = 0; s < QSETS; s++) { mj[s] = NONE; ij[s] = -1; }
-  auto flush = [&](int chunkTile0) {
-#pragma unroll
-    for (int s = 0; s < QSETS; s++) {
-      const int lb = mj[s] & 255;
-      if (lb) ij[s] = decode_idx(lb, chunkTile0, hi);
-      mj[s] &= ~255;
-    }
-  };
-  if (tBeg < tEnd) stage_group(tiles, cst, tBeg, sm[0], wave, lane);
-  int it = 0;
-  for (int tg = tBeg; tg < tEnd; tg += TPS, it++) {
-    const unsigned char *buf = sm[it & 1];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tg + TPS < tEnd) stage_group(tiles, cst, tg + TPS, sm[(it & 1) ^ 1], wave, lane);
-#pragma unroll
-    for (int q = 0; q < TPS; q++) {
-      const int tile = tg + q;
-      const unsigned char *tb = buf + q * TILE_B;
-      v4i af[4];
-#pragma unroll
-      for (int kb = 0; kb < 4; kb++) af[kb] = read_a(tb, col, kb, hi);
-      int C[16];
-#pragma unroll
-      for (int gq = 0; gq < 4; gq++) {
-        const v4i c4 = *reinterpret_cast<const v4i *>(buf + TPS * TILE_B + q * 128 + (8 * gq + 4 * hi) * 4);
-        C[4 * gq] = c4[0]; C[4 * gq + 1] = c4[1]; C[4 * gq + 2] = c4[2]; C[4 * gq + 3] = c4[3];
-      }
-      v16i acc[QSETS];
-#pragma unroll
-      for (int s = 0; s < QSETS; s++) {
-        acc[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bq[s][0], base[s], 0, 0, 0);
-#pragma unroll
-        for (int kb = 1; kb < 4; kb++) acc[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[kb], bq[s][kb], acc[s], 0, 0, 0);
-      }
-      const int nvalid = g.n2 - tile * 32;   // wave-uniform; < 32 only for the last tile and the padding tiles
-#pragma unroll
-      for (int s = 0; s < QSETS; s++) {
-        int k[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) k[r] = (acc[s][r] << 9) + C[r];
-        if (nvalid < 32) {
-#pragma unroll
-          for (int r = 0; r < 16; r++) if (row_of(r, hi) >= nvalid) k[r] = BIG;
-        }
-        const int t = tree_min16(k);
-        if (t < thr[s]) {
-          // a train of this group is closer than Dmin: k_match_events takes the whole group (its non-event rows included)
-          const int u = u0 + 32 * s + col;
-          if (u < nU) {
-            const int old = atomicAdd(&evCount[u], 1);
-            if (old < evLimit) ev[(size_t)u * evLimit + old] = (tile << 1) | hi;
+        const double dx = pos2[2 * i0] - pos2[2 * j1], dy = pos2[2 * i0 + 1] - pos2[2 * j1 + 1];
+        if (dx * dx + dy * dy > contrDistSq) o.nbad = 1;                                      // first contradictive
+        else {
+          dm = ratio_dmin(d0, sqminratio);
+          if (dm <= MAXD) {          // otherwise no distance can pass the ratio test: the walk ends without a match
+            sList[atomicAdd(&sCount, 1)] = q;
+            o.nless = -1;   // filled by sweep 2
           }
-        } else mj[s] = min(mj[s], t);
+        }
       }
     }
-    if ((it % (CHUNK / TPS)) == CHUNK / TPS - 1) flush(tg + TPS - CHUNK);
+    rows[q] = o;
+    dmin[q] = dm;
   }
-  if (it % (CHUNK / TPS)) flush(tBeg + (it / (CHUNK / TPS)) * CHUNK);
-#pragma unroll
-  for (int s = 0; s < QSETS; s++) {
-    const int u = u0 + 32 * s + col;
-    int dj = ij[s] < 0 ? BIG : (mj[s] >> 8) + dmo[s], tj = ij[s] < 0 ? BIG : ij[s];
-    const int od = __shfl_xor(dj, 32), ot = __shfl_xor(tj, 32);
-    if (lex_less(od, ot, dj, tj)) { dj = od; tj = ot; }
-    if (hi == 0 && u < nU) partial2[(size_t)u * g.S + sp] = make_int2(dj, tj);
-  }
+  __syncthreads();
+  if (threadIdx.x == 0 && sCount) sBase = atomicAdd(nUndecided, sCount);
+  __syncthreads();
+  if ((int)threadIdx.x < sCount) undecided[sBase + threadIdx.x] = sList[threadIdx.x];
 }
 
 // ---------------- events: the groups of sweep 2 that hold a train below Dmin, recomputed exactly ---------------------------
-// One wave per undecided query, four groups (16 rows each) per pass.  Output per query: nless, nbad and the lex-smallest
-// (d, t) with d >= Dmin among the rows of the event groups (the sweep left those groups out of its own minimum).
+// One wave per undecided query; each 16-lane quarter walks the event lists of every fourth (split, lane half) stream, one
+// group (16 rows) at a time.  Output per query: nless, nbad and the lex-smallest (d, t) with d >= Dmin among the rows of the
+// event groups (the sweep left those groups out of its own minimum).  A stream that ran out of its EVCAP slots sends the
+// query to the exact fallback: every train, one per lane (low-entropy inputs with thousands of near-duplicates).
 __device__ __forceinline__ void events_body(const uint8_t *d1, const int *norm1, const uint8_t *d2, const int *norm2, MatchGeom g,
                                             const double *pos2, double contrDistSq, const MatchRow *rows, const int *dmin,
-                                            const int *undecided, const int *nUndecided, const int *evCount, const int *ev,
-                                            int evLimit, int4 *evRes) {
-  const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                            const int *undecided, const int *nUndecided, const int *evCnt, const int *ev,
+                                            int nn, int4 *evRes) {
+  __shared__ int sRec[4][64];           // per wave: the event groups of its query as (tile << 1 | lane half)
+  const int w = threadIdx.x >> 6;
+  const int u = blockIdx.x * 4 + w;
   if (u >= *nUndecided) return;
   const int lane = threadIdx.x & 63, l = lane & 15, sub = lane >> 4;
-  const int q = undecided[u];
-  const int total = evCount[u];
-  if (total > evLimit) {   // more than nn + 2 groups with a sub-threshold train: nless > nn - 2 whatever they hold
-    if (lane == 0) evRes[u] = make_int4(evLimit, 0, BIG, BIG);
+  const int nst = 2 * g.S;
+  // Every event group holds at least one train below Dmin and at most one of all those trains is NN0, so nn or more
+  // groups mean nless > nn - 2: the walk gives up (matching.cpp:435-457) and nothing has to be recomputed.  (Look-alike
+  // regions -- a thousand similar blobs -- produce exactly this, and would otherwise dominate the kernel.)
+  int total = 0;
+  for (int st = lane; st < nst; st += 64) total += evCnt[(size_t)u * nst + st];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) total += __shfl_xor(total, m);
+  if (total >= nn) {
+    if (lane == 0) evRes[u] = make_int4(nn, 0, BIG, BIG);
     return;
   }
+  const int q = undecided[u];
   const int t0 = rows[q].t0, Dm = dmin[q], na = norm1[q];
   const double x0 = pos2[2 * t0], y0 = pos2[2 * t0 + 1];
+  v4i qv[8];                            // the query, once
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    qv[i] = reinterpret_cast<const v4i *>(d1 + (size_t)q * 128)[i];
+    qv[i][0] ^= 0x80808080; qv[i][1] ^= 0x80808080; qv[i][2] ^= 0x80808080; qv[i][3] ^= 0x80808080;
+  }
   int nless = 0, nbad = 0, dj = BIG, tj = BIG;
-  for (int b = 0; b < total; b += 4) {
+  auto visit = [&](int t) {
+    if (t >= g.n2 || t == t0) return;
+    const v4i *pb = reinterpret_cast<const v4i *>(d2 + (size_t)t * 128);
+    int dot = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const v4i y = pb[i];
+#pragma unroll
+      for (int c = 0; c < 4; c++) dot = __builtin_amdgcn_sdot4(qv[i][c], y[c] ^ 0x80808080, dot, false);
+    }
+    const int d = na + norm2[t] - 2 * dot;
+    if (d < Dm) {
+      nless++;
+      // geometric consistency with NN0 (distanceSq, matching.cpp:174-179), f64
+      const double dx = x0 - pos2[2 * t], dy = y0 - pos2[2 * t + 1];
+      if (dx * dx + dy * dy > contrDistSq) nbad++;
+    } else if (lex_less(d, t, dj, tj)) { dj = d; tj = t; }
+  };
+  // gather the (fewer than nn <= 64) logged groups of all streams into one list; a stream that ran out of slots is
+  // rescanned exactly over its own tiles afterwards (its logged groups are then ignored); the groups it did not flag hold
+  // no train below Dmin and their candidates d >= Dmin are already in the sweep's minimum
+  int nrec = 0;
+  bool anyOver = false;
+  for (int s0 = 0; s0 < nst; s0 += 64) {
+    const int st = s0 + lane;
+    int c = st < nst ? evCnt[(size_t)u * nst + st] : 0;
+    const bool over = c > EVCAP;
+    anyOver = anyOver || __any(over);
+    if (over) c = 0;
+    int pre = c;   // inclusive scan over the lanes
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const int v = __shfl_up(pre, m); if (lane >= m) pre += v; }
+    const int base = nrec + pre - c;
+    for (int e = 0; e < c; e++)
+      if (base + e < 64) sRec[w][base + e] = (ev[((size_t)u * nst + st) * EVCAP + e] << 1) | (st & 1);
+    nrec += __shfl(pre, 63);
+  }
+  nrec = min(nrec, 64);
+  for (int b = 0; b < nrec; b += 4) {
     const int e = b + sub;
-    if (e < total) {
-      const int rec = ev[(size_t)u * evLimit + e];
-      const int t = (rec >> 1) * 32 + row_of(l, rec & 1);
-      if (t < g.n2 && t != t0) {
-        const int d = exact_dist(d1 + (size_t)q * 128, na, d2 + (size_t)t * 128, norm2[t]);
-        if (d < Dm) {
-          nless++;
-          // geometric consistency with NN0 (distanceSq, matching.cpp:174-179), f64
-          const double dx = x0 - pos2[2 * t], dy = y0 - pos2[2 * t + 1];
-          if (dx * dx + dy * dy > contrDistSq) nbad++;
-        } else if (lex_less(d, t, dj, tj)) { dj = d; tj = t; }
-      }
+    if (e < nrec) { const int rec = sRec[w][e]; visit((rec >> 1) * 32 + row_of(l, rec & 1)); }
+  }
+  if (anyOver) {
+    for (int st = 0; st < nst; st++) {
+      if (evCnt[(size_t)u * nst + st] <= EVCAP) continue;
+      const int tb = (st >> 1) * g.tilesPerSplit, te = min(tb + g.tilesPerSplit, (g.n2 + 31) >> 5);
+      for (int tile = tb + sub; tile < te; tile += 4) visit(tile * 32 + row_of(l, st & 1));
     }
   }
 #pragma unroll
@@ -494,14 +551,16 @@ __device__ __forceinline__ void finish_body(const int2 *partial2, const int4 *ev
 
 // ---- workspace layout: ONE description used by the size query and by the launcher -------------------------------------------
 struct MatchLayout {
-  int S, tilesPerSplit, slots, evLimit;
-  size_t norm1, norm2, cst, tiles, partial, partial2, dmin, undecided, evCount, ev, evRes, counter, bytes;
+  int S, tilesPerSplit, slots;
+  size_t norm1, norm2, cst, tiles, partial, partial2, dmin, undecided, evCnt, ev, evRes, counter, bytes;
 };
-static MatchLayout match_layout(int n1, int n2, int nn) {
+static MatchLayout match_layout(int n1, int n2) {
   MatchLayout L;
   const int nQB = (n1 + QPB - 1) / QPB;
   const int ntiles = (n2 + 31) / 32;
-  int S = (1024 + nQB - 1) / nQB;                 // aim at one full round of 4 workgroups per CU
+  // one round of workgroups: 3 per CU (the sweeps hold ~150 VGPRs) x 256 CUs; a second, partly filled round costs as much
+  // as the first.  Many query blocks (N > 196 k) simply take several rounds.
+  int S = 768 / nQB;
   if (S > ntiles / CHUNK) S = ntiles / CHUNK;     // at least one chunk per split
   if (S < 1) S = 1;
   int tps = (ntiles + S - 1) / S;
@@ -509,7 +568,6 @@ static MatchLayout match_layout(int n1, int n2, int nn) {
   S = (ntiles + tps - 1) / tps;
   if (S < 1) S = 1;
   L.S = S; L.tilesPerSplit = tps; L.slots = S * tps * 32;
-  L.evLimit = (nn < 2 ? 2 : (nn > 4094 ? 4094 : nn)) + 2;
   size_t w = 0;
   auto take = [&](size_t bytes) { const size_t o = w; w += (bytes + 255) & ~(size_t)255; return o; };
   L.norm1 = take((size_t)n1 * 4);
@@ -520,26 +578,26 @@ static MatchLayout match_layout(int n1, int n2, int nn) {
   L.partial2 = take((size_t)n1 * S * 8);
   L.dmin = take((size_t)n1 * 4);
   L.undecided = take((size_t)n1 * 4);
-  L.evCount = take((size_t)n1 * 4);
-  L.ev = take((size_t)n1 * L.evLimit * 4);
+  L.evCnt = take((size_t)n1 * S * 2 * 4);
+  L.ev = take((size_t)n1 * S * 2 * EVCAP * 4);
   L.evRes = take((size_t)n1 * 16);
   L.counter = take(64);
   L.bytes = w;
   return L;
 }
-size_t match_workspace_bytes(int n1, int n2, int nn) { return match_layout(n1, n2, nn).bytes; }
+size_t match_workspace_bytes(int n1, int n2) { return match_layout(n1, n2).bytes; }
 
 // ---- batched entry points: blockIdx.z selects one of up to MATCH_MAXB independent problems (the pairs of a launch set).
 struct MatchProblem {
   const uint8_t *d1, *d2;
   const double *pos2;
-  int *norm1, *norm2, *cst, *dmin, *undecided, *counter, *evCount, *ev;
+  int *norm1, *norm2, *cst, *dmin, *undecided, *counter, *evCnt, *ev;
   unsigned char *tiles;
   int4 *partial, *evRes;
   int2 *partial2;
   MatchRow *rows;
   MatchGeom g;
-  int slots, evLimit;
+  int slots;
 };
 struct MatchBatch { MatchProblem p[MATCH_MAXB]; };
 
@@ -547,34 +605,39 @@ __global__ __launch_bounds__(256) void k_match_pack(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
   pack_body(P.d1, P.g.n1, P.norm1, P.d2, P.g.n2, P.slots, P.tiles, P.cst, P.norm2);
 }
-__global__ __launch_bounds__(256, 4) void k_match_sweep1(MatchBatch b) {
+__global__ __launch_bounds__(256, 3) void k_match_sweep1(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
   if ((int)blockIdx.x * QPB >= P.g.n1 || (int)blockIdx.y >= P.g.S) return;
-  sweep1_body(P.d1, P.norm1, P.tiles, P.cst, P.g, P.partial);
+  SweepArgs A;
+  A.d1 = P.d1; A.norm1 = P.norm1; A.tiles = P.tiles; A.cst = P.cst; A.g = P.g; A.partial = P.partial;
+  sweep_body<0>(A);
 }
-__global__ __launch_bounds__(256) void k_match_decide(MatchBatch b, double sqminratio, double contrDistSq) {
+__global__ __launch_bounds__(1024) void k_match_decide(MatchBatch b, double sqminratio, double contrDistSq) {
   const MatchProblem &P = b.p[blockIdx.z];
-  if ((int)blockIdx.x * 16 >= P.g.n1) return;
+  if ((int)blockIdx.x * DECIDE_Q >= P.g.n1) return;
   decide_body(P.d1, P.norm1, P.d2, P.norm2, P.partial, P.g, P.pos2, sqminratio, contrDistSq, P.rows, P.dmin, P.undecided,
               P.counter);
 }
-__global__ __launch_bounds__(256, 4) void k_match_sweep2(MatchBatch b) {
+__global__ __launch_bounds__(256, 3) void k_match_sweep2(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
   if ((int)blockIdx.x * QPB >= P.g.n1 || (int)blockIdx.y >= P.g.S) return;
-  sweep2_body(P.d1, P.norm1, P.tiles, P.cst, P.g, P.dmin, P.undecided, P.counter, P.partial2, P.evCount, P.ev, P.evLimit);
+  SweepArgs A;
+  A.d1 = P.d1; A.norm1 = P.norm1; A.tiles = P.tiles; A.cst = P.cst; A.g = P.g;
+  A.dmin = P.dmin; A.undecided = P.undecided; A.nUndecided = P.counter; A.partial2 = P.partial2; A.evCnt = P.evCnt; A.ev = P.ev;
+  sweep_body<1>(A);
 }
-__global__ __launch_bounds__(256) void k_match_events(MatchBatch b, double contrDistSq) {
+__global__ __launch_bounds__(256) void k_match_events(MatchBatch b, double contrDistSq, int nn) {
   const MatchProblem &P = b.p[blockIdx.z];
   if ((int)blockIdx.x * 4 >= P.g.n1) return;
-  events_body(P.d1, P.norm1, P.d2, P.norm2, P.g, P.pos2, contrDistSq, P.rows, P.dmin, P.undecided, P.counter, P.evCount, P.ev,
-              P.evLimit, P.evRes);
+  events_body(P.d1, P.norm1, P.d2, P.norm2, P.g, P.pos2, contrDistSq, P.rows, P.dmin, P.undecided, P.counter, P.evCnt, P.ev,
+              nn, P.evRes);
 }
 __global__ __launch_bounds__(256) void k_match_finish(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
   finish_body(P.partial2, P.evRes, P.g, P.undecided, P.counter, P.rows);
 }
 
-// Problems with n1 == 0 or n2 == 0 must be left out by the caller.  workspace[i] holds match_workspace_bytes(n1[i], n2[i], nn).
+// Problems with n1 == 0 or n2 == 0 must be left out by the caller.  workspace[i] holds match_workspace_bytes(n1[i], n2[i]).
 void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
                         const double *const *pos2, double sqminratio, double contrDistSq, int nn, MatchRow *const *rows,
                         void *const *workspace) {
@@ -584,27 +647,26 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
   int maxN1 = 0, maxS = 0, maxSlots = 0;
   for (int i = 0; i < nb; i++) {
     MatchProblem &P = b.p[i];
-    const MatchLayout L = match_layout(n1[i], n2[i], nn);
+    const MatchLayout L = match_layout(n1[i], n2[i]);
     P.g.n1 = n1[i]; P.g.n2 = n2[i]; P.g.S = L.S; P.g.tilesPerSplit = L.tilesPerSplit;
-    P.slots = L.slots; P.evLimit = L.evLimit;
+    P.slots = L.slots;
     char *w = (char *)workspace[i];
     P.norm1 = (int *)(w + L.norm1); P.norm2 = (int *)(w + L.norm2); P.cst = (int *)(w + L.cst);
     P.tiles = (unsigned char *)(w + L.tiles);
     P.partial = (int4 *)(w + L.partial); P.partial2 = (int2 *)(w + L.partial2);
     P.dmin = (int *)(w + L.dmin); P.undecided = (int *)(w + L.undecided);
-    P.evCount = (int *)(w + L.evCount); P.ev = (int *)(w + L.ev); P.evRes = (int4 *)(w + L.evRes);
+    P.evCnt = (int *)(w + L.evCnt); P.ev = (int *)(w + L.ev); P.evRes = (int4 *)(w + L.evRes);
     P.counter = (int *)(w + L.counter);
     P.d1 = d1[i]; P.d2 = d2[i]; P.pos2 = pos2[i]; P.rows = rows[i];
     hipMemsetAsync(P.counter, 0, 4, s);
-    hipMemsetAsync(P.evCount, 0, (size_t)n1[i] * 4, s);
     maxN1 = std::max(maxN1, n1[i]); maxS = std::max(maxS, L.S); maxSlots = std::max(maxSlots, L.slots);
   }
   hipLaunchKernelGGL(k_match_pack, dim3((std::max(maxN1, maxSlots) + 255) / 256, 2, nb), dim3(256), 0, s, b);
   const dim3 grid((maxN1 + QPB - 1) / QPB, maxS, nb);
   hipLaunchKernelGGL(k_match_sweep1, grid, dim3(256), 0, s, b);
-  hipLaunchKernelGGL(k_match_decide, dim3((maxN1 + 15) / 16, 1, nb), dim3(256), 0, s, b, sqminratio, contrDistSq);
+  hipLaunchKernelGGL(k_match_decide, dim3((maxN1 + DECIDE_Q - 1) / DECIDE_Q, 1, nb), dim3(1024), 0, s, b, sqminratio, contrDistSq);
   hipLaunchKernelGGL(k_match_sweep2, grid, dim3(256), 0, s, b);
-  hipLaunchKernelGGL(k_match_events, dim3((maxN1 + 3) / 4, 1, nb), dim3(256), 0, s, b, contrDistSq);
+  hipLaunchKernelGGL(k_match_events, dim3((maxN1 + 3) / 4, 1, nb), dim3(256), 0, s, b, contrDistSq, nn);
   hipLaunchKernelGGL(k_match_finish, dim3((maxN1 + 255) / 256, 1, nb), dim3(256), 0, s, b);
 }
 
