@@ -1,14 +1,20 @@
 #!/usr/bin/env python3
-"""Benchmark of the MODS hot path on MI355X.
+"""Benchmark of the MODS hot path on MI355X (BASELINE.json: image-pairs/s + descriptors matched/s, 1024x768, HessAff+SIFT).
 
-A step = one pass of the path over one batch of --batch synthetic 1024x768 image pairs, 1 (identity)
-view each (BASELINE.json configs[1]): Hessian-Affine detection + Baumberg, dominant orientation,
-RootSIFT description of both images, brute-force FGINN matching, duplicate filtering, LO-RANSAC H.
-The batch is pipelined over --workers contexts (host thread + HIP stream each, modsx_match_pairs).
-All images are resident in HBM before the timed region.  With --gpus N every rank runs the same
-per-GPU workload on its own pairs (pairs shard with no data-path collective: weak scaling).
+A step = one pass of the path over one batch of synthetic 1024x768 image pairs: per image the affine view ladder
+(default TiltSet 1,2,4,6,8 at Phi 120 = 31 views, synth-detection.cpp:103-234) -> Hessian-Affine + Baumberg -> dominant
+orientation -> RootSIFT per view, then brute-force FGINN matching of the ~24 k x 24 k descriptors on the int8 matrix cores
+(matching.cpp:357-461), duplicate filtering and LO-RANSAC (H).  All images are resident in HBM before the timed region.
 
-Prints ONE JSON line (rank 0).
+  --config views31 (default) | views61 | views11 | views8 | views1 | wxbs      workload of the JSON line
+  --gpus N   one process per GPU (torch.distributed.run).  --shard views (default for N > 1): every pair's views are split
+             over the N ranks (view v -> rank v mod N), the region rows + u8 descriptors are all-gathered over RCCL/xGMI
+             inside the library (modsx_allgather_view_blocks) and the query rows of the match are split over the ranks;
+             the batch grows with N (weak scaling: per-GPU work fixed).  --shard pairs: independent pairs per rank.
+Rank 0 prints ONE JSON line: value = pairs/s of the whole job, `roofline` = the distance kernels (all k_match_*
+launches, sweep 2 included, on the descriptors of this run) against the int8 MFMA peak, `roofline_describe` = the
+describe stage against HBM with SURVEY section 8(d) bytes, `cpu_baseline` = the CPU oracle (restatement of the reference's
+CPU path) on the same workload with all host cores and with one, `parity` = GPU vs that CPU path on one pair of the run.
 """
 import argparse
 import json
@@ -21,52 +27,112 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 INT8_PEAK_TOPS = 5000.0      # dense int8 matrix peak (~2x the 2.5 PF bf16 dense peak)
-# profile class -> kernel name as rocprofv3 reports it (default "k_" + class)
-KERNEL_OF_CLASS = {"blur_rows": "k_blur_rows_lds", "blur_cols": "k_blur_cols_lds", "match_fginn": "k_match_sweep1"}
-# classes whose limiter is vector-ALU issue, with the VALU-busy fraction measured by the SQ counters (profiles/r01_pmc_sq.txt)
-VALU_BOUND = {"describe": "0.87", "orientation": "0.70", "baumberg": "0.72", "blur_rows": "0.94", "nms_localize": "0.93"}
+CONFIGS = {   # name -> (tilts, phi, detector mode, description)
+    "views1": ("1", 360.0, "configs[1]: 1 view"),
+    "views8": ("1,2,3,4,6", 360.0, "configs[2]: 8 affine-synth views (TiltSet 1,2,3,4,6, Phi 360)"),
+    "views11": ("1,2,4,6,8", 360.0, "11 views (TiltSet 1,2,4,6,8, Phi 360: iters_mods_cviu.ini HessianAffine step)"),
+    "views31": ("1,2,4,6,8", 120.0, "31 views (TiltSet 1,2,4,6,8, Phi 120)"),
+    "views61": ("1,2,4,6,8", 60.0, "61 views (TiltSet 1,2,4,6,8, Phi 60)"),
+}
 
 
-def cpu_baseline(rows, cols, seed, budget_s=20.0):
-    """The CPU oracle (a restatement of the reference's CPU path, kind 'port') on the same workload,
-    single thread, bounded to ~budget_s seconds."""
+def cpu_info():
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return model, os.cpu_count() or 1, usable
+
+
+def oracle_pair_views(O, a, b, views_o, params, threads, seed=1, query_cap=None, one_image=False):
+    """The CPU path (oracle = restatement of the reference) for one pair under a view ladder.  Parallel structure of the
+    reference: images x views in parallel (mods.cpp:255-271, imagerepresentation.cpp:612-622), here a thread pool over
+    (image, view) tasks (ctypes releases the GIL) + OpenMP over the query rows of the brute-force kNN."""
     import numpy as np
-    from mods_amd import synthetic
-    from oracle import pyoracle as O
+    import ctypes
+    from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from common import oracle_pair
-    a, b, _ = synthetic.make_pair(rows=rows, cols=cols, nblobs=int(4000 * rows * cols / (768.0 * 1024)), seed=seed)
-    n = 0
+    from common import laf_of
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(threads))
+    except OSError:
+        pass
     t0 = time.time()
-    ndesc = 0
-    while True:
-        r = oracle_pair(O, a, b, seed=1)
-        ndesc += len(r["d1"]) + len(r["d2"])
-        n += 1
-        if time.time() - t0 > budget_s * 0.6 or n >= 8:
-            break
-    dt = time.time() - t0
-    return {"value": n / dt, "unit": "image-pairs/s", "cores": 1, "kind": "port",
-            "sample": "%d full pair(s) of the same %dx%d workload in %.1f s, single thread; %d descriptors/pair"
-                      % (n, cols, rows, dt, ndesc // n),
-            "descriptors_per_s": ndesc / dt}
+    imgs = [a] if one_image else [a, b]
+
+    def one(task):
+        im, v = task
+        return O.detect_describe_views(imgs[im], [views_o[v]])
+    tasks = [(i, v) for i in range(len(imgs)) for v in range(len(views_o))]
+    if threads > 1:
+        with ThreadPoolExecutor(threads) as pool:
+            parts = list(pool.map(one, tasks))
+    else:
+        parts = [one(t) for t in tasks]
+    regs, desc = [], []
+    for i in range(len(imgs)):
+        rs, ds, size = [], [], 0
+        for v in range(len(views_o)):
+            r, d = parts[i * len(views_o) + v]
+            r = r.copy()
+            if v and len(r):      # the per-view call numbered its block from 0 and cannot know the view index
+                ident = abs(views_o[v].tilt - 1) <= 0.1 and abs(views_o[v].phi) <= 0.2 and abs(views_o[v].zoom - 1) <= 0.1
+                r["img_id"] = 0 if ident else v
+            r["id"] += size; r["parent_id"] += size
+            size += len(r)
+            rs.append(r); ds.append(d)
+        regs.append(np.concatenate(rs)); desc.append(np.concatenate(ds))
+    t1 = time.time()
+    out = dict(t_extract=t1 - t0, regs=regs, desc=desc)
+    if one_image:
+        return out
+    r1, r2, d1, d2 = regs[0], regs[1], desc[0], desc[1]
+    pos2 = np.stack([r2["reproj_kp"]["x"], r2["reproj_kp"]["y"]], 1)
+    nq = len(d1) if query_cap is None else min(query_cap, len(d1))
+    tent = O.match_fginn(d1[:nq], d2, pos2, params.match_ratio, params.contradDist)
+    t2 = time.time()
+    out.update(t_match=t2 - t1, n_match_queries=nq, tent=tent)
+    if query_cap is not None and nq < len(d1):
+        return out
+    pts = np.stack([r1["reproj_kp"]["x"][tent["q"]], r1["reproj_kp"]["y"][tent["q"]],
+                    r2["reproj_kp"]["x"][tent["t0"]], r2["reproj_kp"]["y"][tent["t0"]]], 1)
+    order, keep = O.duplicate_filtering(pts, tent["ratio"], params.duplicateDist, True)
+    sel = order[keep]
+    tu, pu = tent[sel], pts[sel]
+    res = None
+    if O.ref_available():
+        res = O.loransac_h(pu, laf_of(r1, tu["q"]), laf_of(r2, tu["t0"]), err_threshold=params.err_threshold,
+                           confidence=params.confidence, max_samples=params.max_samples, seed=seed)
+    t3 = time.time()
+    out.update(t_verify=t3 - t2, uniq=tu, pts=pu, ransac=res, total=t3 - t0, laf1=laf_of(r1, tu["q"]), laf2=laf_of(r2, tu["t0"]))
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=15)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=768)
     ap.add_argument("--cols", type=int, default=1024)
-    ap.add_argument("--batch", type=int, default=64, help="pairs per step per GPU")
+    ap.add_argument("--config", type=str, default="views31", choices=sorted(CONFIGS))
+    ap.add_argument("--tilts", type=str, default="", help="override the tilt set of --config, e.g. 1,2,3,4,6")
+    ap.add_argument("--phi", type=float, default=0.0)
+    ap.add_argument("--batch", type=int, default=0, help="pairs per step per GPU (default 16; 64 for views1)")
     ap.add_argument("--workers", type=int, default=16, help="contexts (thread + stream) per GPU")
-    ap.add_argument("--distinct", type=int, default=2, help="distinct synthetic pairs cycled through the batch")
-    ap.add_argument("--tilts", type=str, default="", help="e.g. 1,2,3,4,6: synthesise views (configs[2]); default 1 view")
-    ap.add_argument("--phi", type=float, default=360.0)
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs cycled through the batch")
     ap.add_argument("--init-sigma", type=float, default=0.2)
+    ap.add_argument("--shard", type=str, default="", choices=["", "pairs", "views"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-extra", action="store_true", help="skip the short 1/8/11-view runs reported under `extra`")
     args = ap.parse_args()
 
     import numpy as np
@@ -75,27 +141,41 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+    shard = args.shard or ("views" if world > 1 else "pairs")
 
     import mods_amd
     from mods_amd import synthetic
-    seed = 12345 + 1000 * rank
+    tilts, phi, cfg_desc = CONFIGS[args.config]
+    if args.tilts:
+        tilts, phi = args.tilts, (args.phi or 360.0)
+        cfg_desc = "tilts %s, phi %g" % (tilts, phi)
+    single_view = tilts == "1"
+    batch = args.batch or (64 if single_view else 16)
     nblobs = int(4000 * args.rows * args.cols / (768.0 * 1024))
     ctxs = [mods_amd.Context(local_rank) for _ in range(max(1, args.workers))]
     ctx = ctxs[0]
-    pairs_host = [synthetic.make_pair(rows=args.rows, cols=args.cols, nblobs=nblobs, seed=seed + 17 * i)
-                  for i in range(max(1, args.distinct))]
-    H = pairs_host[0][2]
-    dev = [(ctx.upload(a), ctx.upload(b)) for a, b, _ in pairs_host]
-    imgs1 = [dev[i % len(dev)][0] for i in range(args.batch)]
-    imgs2 = [dev[i % len(dev)][1] for i in range(args.batch)]
     params = mods_amd.default_pair_params(ransac_seed=1)
+    views = mods_amd.set_vs_pars([1.0], [float(t) for t in tilts.split(",")], phi, args.init_sigma, 1, [])
+
+    # pairs: with --shard views every rank holds every pair of the (N x larger) batch; otherwise its own pairs
+    comm = None
+    if shard == "views" and world > 1:
+        from mods_amd import distributed as D
+        comm = D.NativeComm(ctxs, dist)          # one RCCL communicator per context (stream), bootstrapped over torch
+        seed0, nbatch = 12345, batch * world
+    else:
+        seed0, nbatch = 12345 + 1000 * rank, batch
+    pairs_host = [synthetic.make_pair(rows=args.rows, cols=args.cols, nblobs=nblobs, seed=seed0 + 17 * i)
+                  for i in range(max(1, args.distinct))]
+    Hgt = pairs_host[0][2]
+    dev = [(ctx.upload(a), ctx.upload(b)) for a, b, _ in pairs_host]
+    imgs1 = [dev[i % len(dev)][0] for i in range(nbatch)]
+    imgs2 = [dev[i % len(dev)][1] for i in range(nbatch)]
 
     def barrier():
         for c in ctxs:
@@ -105,64 +185,65 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    views = None
-    if args.tilts:
-        views = mods_amd.set_vs_pars([1.0], [float(t) for t in args.tilts.split(",")], args.phi, args.init_sigma, 1, [])
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(len(ctxs))
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(len(ctxs))
 
-    def run_batch():
-        if views is None:
-            return mods_amd.match_pairs(ctxs, imgs1, imgs2, params)
+    def run_batch(vw=views, single=single_view, i1=imgs1, i2=imgs2, cx=ctxs):
+        if single:
+            return mods_amd.match_pairs(cx, i1, i2, params)
+
         # multi-view pairs: one python thread per context (ctypes releases the GIL inside the library)
         def work(w):
             out = []
-            for i in range(w, args.batch, len(ctxs)):
-                out.append((i, ctxs[w].match_pair_views(imgs1[i], imgs2[i], views, params)))
+            for i in range(w, len(i1), len(cx)):
+                if comm is not None:
+                    out.append((i, comm.match_pair_views_sharded(w, i1[i], i2[i], vw, params, owner=i % world)))
+                else:
+                    out.append((i, cx[w].match_pair_views(i1[i], i2[i], vw, params)))
             return out
-        res = [None] * args.batch
-        for part in pool.map(work, range(len(ctxs))):
+        res = [None] * len(i1)
+        for part in pool.map(work, range(len(cx))):
             for i, r in part:
                 res[i] = r
         return res
 
     for _ in range(args.warmup):
         results = run_batch()
-    # The timed region runs WITHOUT the per-launch event brackets (they cost ~5 % of the throughput); per-kernel times of
-    # the multi-stream regime come from PROF_STEPS extra, untimed steps right after it.
     barrier()
     t0 = time.perf_counter()
     ndesc = 0
     for _ in range(args.steps):
         results = run_batch()
         for r in results:
-            ndesc += r["n_regions"][0] + r["n_regions"][1]
+            if r is not None:
+                ndesc += r["n_regions"][0] + r["n_regions"][1]
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    res = results[0]
-    PROF_STEPS = 2
-    for c in ctxs:
-        c.profile(True)
-    for _ in range(PROF_STEPS):
-        run_batch()
-    barrier()
+    res = next(r for r in results if r is not None)
+
+    # ---- untimed legs (rank 0 reports them) -------------------------------------------------------------------------
+    # per-kernel time of the multi-stream regime: two extra steps with the event brackets on
+    PROF_STEPS = 1
     stats = {}
-    for c in ctxs:
-        for k, v in c.kernel_stats().items():
-            d = stats.setdefault(k, dict(ms=0.0, work=0.0, launches=0))
-            d["ms"] += v["ms"]; d["work"] += v["work"]; d["launches"] += v["launches"]
-        c.profile(False)
-    stage = ctx.last_timings()
-    # Roofline leg: the timed region runs --workers streams whose kernels time-slice the CUs, so an event pair
-    # there brackets queueing as well as execution.  The same pairs are therefore repeated on ONE stream right
-    # after the timed region and the per-kernel launch durations are taken from that pass (rank 0 only).
-    iso = {}
-    if rank == 0:
+    if rank == 0 or comm is not None:
+        for c in ctxs:
+            c.profile(True)
+        for _ in range(PROF_STEPS):
+            run_batch()
+        barrier() if comm is not None else [c.synchronize() for c in ctxs]
+        for c in ctxs:
+            for k, v in c.kernel_stats().items():
+                d = stats.setdefault(k, dict(ms=0.0, work=0.0, launches=0))
+                d["ms"] += v["ms"]; d["work"] += v["work"]; d["launches"] += v["launches"]
+            c.profile(False)
+    # Roofline leg: in the timed region the kernels of --workers streams time-slice the CUs, so an event pair there
+    # brackets queueing as well.  The same pairs are repeated on ONE stream and the launch durations come from that pass.
+    iso, niso = {}, 0
+    if rank == 0 and comm is None:
         ctx.profile(True)
-        niso = min(args.batch, 8)
-        if views is None:
-            # same launch geometry as the timed region: 4 pairs (8 images) per launch set
+        niso = min(nbatch, 8 if single_view else 4)
+        if single_view:
             for i0 in range(0, niso, 4):
                 mods_amd.match_pairs([ctx], imgs1[i0:min(i0 + 4, niso)], imgs2[i0:min(i0 + 4, niso)], params)
         else:
@@ -183,69 +264,158 @@ def main():
         ndesc_total = float(ndesc)
 
     if rank == 0:
-        pairs = world * args.steps * args.batch
+        pairs = args.steps * (nbatch if comm is not None else world * nbatch)
         value = pairs / elapsed
-        # dominant kernel class by GPU time of the single-stream pass (HIP events on the launch stream)
-        name, st = max(iso.items(), key=lambda kv: kv[1]["ms"])
-        per_launch_ms = st["ms"] / max(1, st["launches"])
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if views is None and (args.rows, args.cols) == (768, 1024) and os.path.exists(tfile):
-            # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-            # workload (gfx950 correction applied, see profiles/ and DESIGN.md); PMC cannot be sampled in-process
-            traffic = json.load(open(tfile)).get(KERNEL_OF_CLASS.get(name, "k_" + name))
-        if name == "match_fginn":
-            achieved = st["work"] / (st["ms"] * 1e-3) / 1e12 if st["ms"] > 0 else 0.0
-            roof = {"kernel": "k_match_fginn", "bound": "mfma", "achieved": achieved, "peak": INT8_PEAK_TOPS,
-                    "unit": "TFLOP/s", "frac": achieved / INT8_PEAK_TOPS, "traffic": traffic}
-        else:
-            achieved = st["work"] / (st["ms"] * 1e-3) / 1e9 if st["ms"] > 0 else 0.0
-            roof = {"kernel": KERNEL_OF_CLASS.get(name, "k_" + name), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic}
-        roof["avg_launch_ms"] = per_launch_ms
-        roof["algorithmic_work_per_launch"] = st["work"] / max(1, st["launches"])
-        tr = stats.get(name)
-        roof["timed_region_avg_launch_ms"] = tr["ms"] / max(1, tr["launches"]) if tr else None
-        roof["note"] = ("avg_launch_ms: HIP events on the launch stream, single-stream pass run right after the timed "
-                        "region (same pairs); timed_region_avg_launch_ms: the same brackets in two untimed steps of the "
-                        "multi-stream regime (the timed region itself runs without event brackets), where the kernels "
-                        "of %d streams time-slice the CUs" % len(ctxs))
-        if name in VALU_BOUND:
-            roof["note_bound"] = ("this kernel's limiter is VALU issue (SQ_INSTS_VALU x 4 cycles over SIMD cycles = %s in "
-                                  "profiles/, ordered f32/f64 sums per region), not HBM; the schema only offers hbm|mfma, "
-                                  "so its HBM fraction is reported as is" % VALU_BOUND[name])
-        if name == "patch_sample":
-            roof["note_bound"] = ("HBM bytes are this kernel's algorithmic work, but its limiter is the texture addresser: "
-                                  "every lane of the 2 x 2 bilinear gathers is its own L1 access (TA busy 55-80 %, "
-                                  "2.8 L1 accesses per sample, profiles/ and DESIGN.md section 5)")
-        roof["kernels_single_stream_ms_per_pair"] = {k: v["ms"] / min(args.batch, 8) for k, v in iso.items()}
         out = {
-            "metric": "image-pairs/sec (1024x768, HessAff+RootSIFT, FGINN match, LO-RANSAC H)",
+            "metric": "image-pairs/sec (1024x768, HessAff+RootSIFT over the affine view ladder, MFMA FGINN match, LO-RANSAC H)",
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("configs[1]: single %dx%d synthetic pair, 1 view, HessAff+RootSIFT, brute-force "
-                                    "FGINN match + LO-RANSAC H" % (args.cols, args.rows)) if views is None else
-                                   ("configs[2]: %dx%d synthetic pair, %d affine-synth views (tilts %s, phi %g), "
-                                    "HessAff+RootSIFT, MFMA distance matrix + FGINN, LO-RANSAC H"
-                                    % (args.cols, args.rows, len(views), args.tilts, args.phi)),
-                       "pairs_per_step_per_gpu": args.batch, "workers_per_gpu": len(ctxs),
-                       "parallelism": "pairs sharded over ranks, no collective"},
+            "vs_baseline": None, "dtype": "f32 (detect/describe) + u8 on the int8 matrix cores (distance matrix)", "data": "synthetic",
+            "config": {"workload": "%dx%d synthetic pair, %s = %d views per image, HessAff+RootSIFT, MFMA distance matrix + "
+                                   "FGINN, duplicate filter, LO-RANSAC H" % (args.cols, args.rows, cfg_desc, len(views)),
+                       "views": len(views), "pairs_per_step": nbatch if comm is not None else world * nbatch,
+                       "workers_per_gpu": len(ctxs), "distinct_pairs": len(dev),
+                       "parallelism": ("views of every pair sharded over %d ranks (v mod N), RCCL all-gather of region rows + u8 "
+                                       "descriptors, query rows of the match split over ranks" % world) if comm is not None else
+                                      "pairs sharded over ranks, no collective"},
             "descriptors_per_s": ndesc_total / elapsed,
             "descriptors_per_pair": ndesc_total / pairs,
             "result": {"regions": list(res["n_regions"]), "tentatives": res["n_tentatives"], "unique": res["n_unique"],
-                       "verified": res["n_verified"], "H_max_abs_err": float(np.abs(res["H"] / res["H"][2, 2] - H).max())},
-            "stage_ms_last_pair": stage,
-            "kernel_ms_per_pair": {k: v["ms"] / (PROF_STEPS * args.batch) for k, v in stats.items() if v["launches"]},
-            "roofline": roof,
+                       "verified": res["n_verified"],
+                       "H_vs_generator_max_abs": float(np.abs(res["H"] / res["H"][2, 2] - Hgt).max())},
+            "kernel_ms_per_pair_multi_stream": {k: v["ms"] / (PROF_STEPS * nbatch) for k, v in stats.items() if v["launches"]},
         }
+        if comm is not None:
+            out["rccl"] = comm.describe()
+        if iso:
+            per = {k: v["ms"] / niso for k, v in iso.items()}
+            out["kernels_single_stream_ms_per_pair"] = per
+            m = iso.get("match_fginn")
+            if m and m["launches"]:
+                n1, n2 = res["n_regions"]
+                ms = m["ms"] / m["launches"]
+                flops = m["work"] / m["launches"]
+                tf = flops / (ms * 1e-3) / 1e12
+                byts = (n1 + n2) * 128.0 + n1 * 32.0
+                out["roofline"] = {
+                    "kernel": "k_match_* (pack, sweep1, decide, sweep2, events, finish: every launch of one matching problem)",
+                    "bound": "mfma", "achieved": tf, "peak": INT8_PEAK_TOPS, "unit": "TFLOP/s", "frac": tf / INT8_PEAK_TOPS,
+                    "traffic": None, "avg_launch_ms": ms, "algorithmic_work_per_launch": flops, "N": n1, "M": n2,
+                    "hbm_view": {"compulsory_bytes": byts, "achieved_GBs": byts / (ms * 1e-3) / 1e9,
+                                 "frac_of_8TBs": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                    "binds": "mfma: 2*N*M*128 int8 ops against (N+M)*128 B is ~1e4 op/B, the kernel is compute-shaped; "
+                             "its limiter is VALU issue beside the MFMAs (DESIGN.md section 5)",
+                    "note": "HIP events on the launch stream around the six launches, single-stream pass over %d pairs of "
+                            "this run right after the timed region; N, M = regions of the last pair" % niso}
+                tfile = os.path.join(ROOT, "profiles", "pmc_traffic_r02.json")
+                if os.path.exists(tfile):
+                    out["roofline"]["traffic"] = json.load(open(tfile)).get("k_match_total_" + args.config)
+            dk = [iso.get(k) for k in ("patch_sample", "blur_rows", "blur_cols", "describe")]
+            if all(d and d["launches"] for d in dk):
+                ms = sum(d["ms"] for d in dk) / dk[0]["launches"]
+                byts = (dk[0]["work"] + dk[3]["work"]) / dk[0]["launches"]
+                out["roofline_describe"] = {
+                    "kernel": "describe stage: k_patch_sample + k_blur_rows_lds + k_blur_cols_lds + k_describe (one chunk = one launch of each)",
+                    "bound": "hbm", "achieved": byts / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms,
+                    "algorithmic_work_per_launch": byts,
+                    "note": "bytes per SURVEY section 8(d): (P+2)^2 x 4 B read + 128 B written per region; the limiter of these "
+                            "kernels is VALU issue / the texture addresser, not HBM (DESIGN.md section 5)"}
+        # ---- short runs of the other view counts (same timed-region rules, fewer steps) ---------------------------------
+        if not args.no_extra and comm is None and world == 1 and not args.tilts:
+            extra = {}
+            for name in ("views1", "views8", "views11"):
+                if name == args.config:
+                    continue
+                tl, ph, _ = CONFIGS[name]
+                vw = mods_amd.set_vs_pars([1.0], [float(t) for t in tl.split(",")], ph, args.init_sigma, 1, [])
+                nb = 64 if tl == "1" else 16
+                i1 = [dev[i % len(dev)][0] for i in range(nb)]
+                i2 = [dev[i % len(dev)][1] for i in range(nb)]
+                run_batch(vw, tl == "1", i1, i2)
+                for c in ctxs:
+                    c.synchronize()
+                ta = time.perf_counter()
+                nd, st = 0, 3
+                for _ in range(st):
+                    for r in run_batch(vw, tl == "1", i1, i2):
+                        nd += r["n_regions"][0] + r["n_regions"][1]
+                for c in ctxs:
+                    c.synchronize()
+                dt = time.perf_counter() - ta
+                extra[name] = {"views": len(vw), "pairs_per_s": st * nb / dt, "descriptors_per_pair": nd / (st * nb),
+                               "descriptors_per_s": nd / dt}
+            out["extra"] = extra
+        # ---- the CPU path on the same workload: parity of one pair of the run + the baseline timing ---------------------
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.rows, args.cols, seed, args.cpu_budget)
+            from oracle import pyoracle as O
+            model, ncpu, usable = cpu_info()
+            a, b, _ = pairs_host[0]
+            vo = O.set_vs_pars([1.0], [float(t) for t in tilts.split(",")], phi, args.init_sigma, 1, [])
+            O.detect_describe_views(a[:64, :64].copy(), vo[:1])     # lazy tables (single-threaded once)
+            full = oracle_pair_views(O, a, b, vo, params, threads=usable, seed=1)
+            got = ctx.match_pair_views(imgs1[0], imgs2[0], views, params)
+            par = {"pair": "pair 0 of the run, GPU path vs CPU oracle",
+                   "regions_identical": bool(got["n_regions"] == (len(full["regs"][0]), len(full["regs"][1]))),
+                   "tentatives_identical": bool(got["n_unique"] == len(full["uniq"]) and all(
+                       np.array_equal(got["tentatives"][f], full["uniq"][f]) for f in ("q", "t0", "tj", "t1", "d1", "d2", "ratio")))}
+            if full["ransac"] is not None:
+                par["inliers_identical"] = bool(np.array_equal(got["ransac_inlier"], full["ransac"]["inl"]))
+                Hc = np.asarray(full["ransac"]["H"], float).reshape(3, 3)
+                par["H_vs_cpu_max_abs"] = float(np.abs(got["H"] / got["H"][2, 2] - Hc / Hc[2, 2]).max())
+            out["parity"] = par
+            # one thread: a bounded sample (image A's views + 2048 query rows of the match), scaled to a full pair
+            s1 = oracle_pair_views(O, a, b, vo, params, threads=1, one_image=True)
+            try:
+                import ctypes
+                ctypes.CDLL("libgomp.so.1").omp_set_num_threads(1)
+            except OSError:
+                pass
+            nq = min(2048, len(full["desc"][0]))
+            pos2 = np.stack([full["regs"][1]["reproj_kp"]["x"], full["regs"][1]["reproj_kp"]["y"]], 1)
+            tm = time.time()
+            O.match_fginn(full["desc"][0][:nq], full["desc"][1], pos2, params.match_ratio, params.contradDist)
+            tm = time.time() - tm
+            n1 = len(full["desc"][0])
+            est = 2 * s1["t_extract"] + tm * n1 / nq + full["t_verify"]
+            base = {"value": 1.0 / full["total"], "unit": "image-pairs/s", "cores": usable, "kind": "port",
+                    "cpu_model": model, "host_logical_cpus": ncpu,
+                    "sample": "1 full pair of this workload (%d views per image, %d + %d regions) on %d threads in %.2f s: "
+                              "(image, view) tasks on a thread pool as the reference's OpenMP loops (mods.cpp:255-271, "
+                              "imagerepresentation.cpp:612-622), OpenMP over the query rows of the linear kNN; extract %.2f s, "
+                              "match %.2f s, duplicate filter + reference degensac %.2f s"
+                              % (len(views), len(full["regs"][0]), len(full["regs"][1]), usable, full["total"],
+                                 full["t_extract"], full["t_match"], full["t_verify"]),
+                    "descriptors_per_s": (len(full["regs"][0]) + len(full["regs"][1])) / full["total"],
+                    "single_thread": {"value": 1.0 / est, "unit": "image-pairs/s", "cores": 1,
+                                      "sample": "image A's %d views (%.1f s, doubled) + %d of %d query rows of the match (%.1f s, "
+                                                "scaled) + verification of the full pair (%.2f s) -> %.1f s per pair"
+                                                % (len(views), s1["t_extract"], nq, n1, tm, full["t_verify"], est)}}
+            # the one stage where the real reference runs here: degensac from oracle/_ref vs the product's host C++
+            if full["ransac"] is not None and len(full["pts"]) >= 8:
+                tr = time.time()
+                for _ in range(3):
+                    O.loransac_h(full["pts"], full["laf1"], full["laf2"], err_threshold=params.err_threshold,
+                                 confidence=params.confidence, max_samples=params.max_samples, seed=1)
+                tr = (time.time() - tr) / 3
+                tp = time.time()
+                for _ in range(3):
+                    mods_amd.loransac_h(full["pts"], full["laf1"], full["laf2"], err_threshold=params.err_threshold,
+                                        confidence=params.confidence, max_samples=params.max_samples, seed=1)
+                tp = (time.time() - tp) / 3
+                base["ransac_reference_vs_restatement"] = {
+                    "reference_degensac_ms": 1e3 * tr, "libmodsx_host_ms": 1e3 * tp, "ratio": tr / tp if tp > 0 else None,
+                    "tentatives": int(len(full["pts"])),
+                    "note": "LORANSACFiltering (H) on the tentatives of this pair: the reference's own degensac C sources "
+                            "(oracle/_ref, built in the build container) vs the restatement shipped in libmodsx"}
+            out["cpu_baseline"] = base
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
     for a_, b_ in dev:
         a_.free(); b_.free()
+    if comm is not None:
+        comm.close()
     for c in ctxs:
         c.close()
     if dist is not None:

@@ -889,19 +889,22 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       launch_expand_tiles(s, dPfxS, (int)nj, tjS);
       launch_expand_tiles(s, dPfxR, (int)nj, tjR);
       launch_expand_tiles(s, dPfxC, (int)nj, tjC);
-      { ProfScope ps(c, K_PATCH_SAMPLE, (double)arenaA * 8);
+      // algorithmic work of the describe STAGE per SURVEY section 8(d): the (P+2)^2 f32 window of every region read once
+      // (booked here) + 128 B written per region (booked on k_describe); the arenas between the four kernels are an
+      // artefact of the split and are not algorithmic bytes
+      { ProfScope ps(c, K_PATCH_SAMPLE, (double)arenaA * 4);
         launch_patch_sample(s, dj, dPfxS, tjS, pfxSample.back(), (ImgRef *)c->imgRefs.p, (float *)c->scratchA.p); }
-      { ProfScope ps(c, K_BLUR_ROWS, ((double)arenaA + arenaB) * 4);
+      { ProfScope ps(c, K_BLUR_ROWS, 0.0);
         launch_blur_lds(s, dj, dPfxRL, (int)nj, btR, pfxRowL.back(), dTaps, dNeed, (float *)c->scratchA.p,
                         (float *)c->scratchB.p, 0);
         launch_patch_blur(s, dj, dPfxR, tjR, pfxRow.back(), dTaps, dNeed, (float *)c->scratchA.p,
                           (float *)c->scratchB.p, 0); }
-      { ProfScope ps(c, K_BLUR_COLS, ((double)arenaB + arenaC) * 4);
+      { ProfScope ps(c, K_BLUR_COLS, 0.0);
         launch_blur_lds(s, dj, dPfxCL, (int)nj, btC, pfxColL.back(), dTaps, dNeed, (float *)c->scratchB.p,
                         (float *)c->scratchC.p, 1);
         launch_patch_blur(s, dj, dPfxC, tjC, pfxCol.back(), dTaps, dNeed, (float *)c->scratchB.p,
                           (float *)c->scratchC.p, 1); }
-      ProfScope psd(c, K_DESCRIBE, (double)arenaC * 4 + (double)nj * (128 * 5));
+      ProfScope psd(c, K_DESCRIBE, (double)nj * 128);
       launch_describe(s, dj, (int)nj, (ImgRef *)c->imgRefs.p, (float *)c->scratchC.p, dNeed, dCoord,
                       c->dSiftMask, c->dSiftMaskIdx, c->nSiftMask, c->dAtan,
                       c->dSiftBins, c->dSiftW, photoNorm, descType, maxBin, outs);

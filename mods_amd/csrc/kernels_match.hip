@@ -38,6 +38,7 @@
 //    nless / nbad / NNj (and falls back to an exact scan of all trains when a lane ran out of slots).
 //  * inside a wave the four MFMAs of one (tile, query set) chain are issued between the quarters of the reduction of the
 //    previous chain, so the matrix pipe and the vector ALU overlap without relying on other waves being out of phase.
+#include <type_traits>
 #include "engine.hpp"
 
 namespace mx {
@@ -49,7 +50,11 @@ constexpr int BIG = 0x7fffffff;
 constexpr int NONE = 0x7fffff00;           // empty slot of a running minimum: larger than every real key, low byte 0
 constexpr int TPS = 4;                     // train tiles staged per barrier
 constexpr int CHUNK = 12;                  // tiles per index chunk (3 stages); tilesPerSplit is a multiple of it
-constexpr int QSETS = 2;                   // 32-query sets per wave
+#ifndef MATCH_QSETS
+#define MATCH_QSETS 2
+#endif
+constexpr int QSETS = MATCH_QSETS;         // 32-query sets per wave (even)
+constexpr int SWEEP_WPS = QSETS >= 4 ? 2 : 3;   // waves per SIMD the sweeps are built for
 constexpr int QPB = 4 * 32 * QSETS;        // queries per 256-thread workgroup
 constexpr int TILE_B = 4096, STAGE_B = TPS * TILE_B + TPS * 128;
 constexpr int MAXD = 128 * 255 * 255;      // largest possible squared distance
@@ -269,7 +274,8 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &A) {
   };
   v4i af[2][4];
   int C[2][16];
-  v16i acc0, acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  v16i acc[2];
+  acc[1] = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   // the pipeline starts with a neutral pending chain: zero accumulator, NONE constants -> keys that change nothing
 #pragma unroll
   for (int r = 0; r < 16; r++) C[1][r] = NONE;
@@ -280,63 +286,49 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &A) {
     const unsigned char *buf = sm[it & 1];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#ifndef EXP_NODMA
     if (tg + TPS < tEnd) stage_group(A.tiles, A.cst, tg + TPS, sm[(it & 1) ^ 1], wave, lane);
-#endif
-#ifdef EXP_NOLDS
-    if (it == 0) { load_af(buf, 0, af[0]); load_c(buf, 0, C[0]); load_af(buf, 1, af[1]); }
-#else
     load_af(buf, 0, af[0]);
     load_c(buf, 0, C[0]);
-#endif
 #pragma unroll
     for (int q = 0; q < TPS; q++) {
       const int cur = q & 1;
-      // The fragment / constant reads of the NEXT tile are issued as a burst in front of each phase and fenced there
+      // Phase s of a tile: the chain of (tile q, set s) beside the reduction of the previous chain -- (tile q, set s - 1),
+      // or the last set of the previous tile.  QSETS is even, so the chains alternate between the two accumulators.
+      // The fragment / constant reads of the NEXT tile are issued as a burst in front of phases 0 and 1 and fenced there
       // (sched_barrier): left to the scheduler they sink to just before their first use and every MFMA waits for LDS.
-      // phase A: chain of (tile q, set 0) beside the reduction of the pending chain (previous tile, set 1)
-#ifndef EXP_NOLDS
-      if (q + 1 < TPS) load_af(buf, q + 1, af[cur ^ 1]);
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-      acc0 = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int kb = 0; kb < 4; kb++) acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[cur][kb], bq[0][kb], acc0, 0, 0, 0);
-      epilogue(acc1, C[cur ^ 1], 1, pendTile);
+      for (int s = 0; s < QSETS; s++) {
+        if (q + 1 < TPS) {
+          if (s == 0) load_af(buf, q + 1, af[cur ^ 1]);
+          if (s == 1) load_c(buf, q + 1, C[cur ^ 1]);     // C[cur ^ 1] was the pending chain's until phase 0 ended
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        v16i &an = acc[s & 1];
+        an = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int kb = 0; kb < 4; kb++) {   // one MFMA, then a quarter of the reduction
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+        for (int kb = 0; kb < 4; kb++) an = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[cur][kb], bq[s][kb], an, 0, 0, 0);
+        if (s == 0) epilogue(acc[1], C[cur ^ 1], QSETS - 1, pendTile);
+        else epilogue(acc[(s - 1) & 1], C[cur], s - 1, tg + q);
+#pragma unroll
+        for (int kb = 0; kb < 4; kb++) {   // one MFMA, then a quarter of the reduction
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      // phase B: chain of (tile q, set 1) beside the reduction of (tile q, set 0)
-#ifndef EXP_NOLDS
-      if (q + 1 < TPS) load_c(buf, q + 1, C[cur ^ 1]);
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-      acc1 = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int kb = 0; kb < 4; kb++) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[cur][kb], bq[1][kb], acc1, 0, 0, 0);
-      epilogue(acc0, C[cur], 0, tg + q);
-#pragma unroll
-      for (int kb = 0; kb < 4; kb++) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
       pendTile = tg + q;
     }
     if ((it % (CHUNK / TPS)) == CHUNK / TPS - 1) {
       // end of an index chunk: drain the pending chain, then move the indices of changed keys out of the low byte
-      epilogue(acc1, C[1], 1, pendTile);
-      acc1 = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      epilogue(acc[1], C[1], QSETS - 1, pendTile);
+      acc[1] = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int r = 0; r < 16; r++) C[1][r] = NONE;
       flush(tg + TPS - CHUNK);
     }
   }
   if (it % (CHUNK / TPS)) {
-    epilogue(acc1, C[1], 1, pendTile);
+    epilogue(acc[1], C[1], QSETS - 1, pendTile);
     flush(tBeg + (it / (CHUNK / TPS)) * CHUNK);
   }
   // the two lane halves of a query saw different rows: merge, convert keys to distances, store
@@ -560,7 +552,7 @@ static MatchLayout match_layout(int n1, int n2) {
   const int ntiles = (n2 + 31) / 32;
   // one round of workgroups: 3 per CU (the sweeps hold ~150 VGPRs) x 256 CUs; a second, partly filled round costs as much
   // as the first.  Many query blocks (N > 196 k) simply take several rounds.
-  int S = 768 / nQB;
+  int S = (256 * SWEEP_WPS) / nQB;
   if (S > ntiles / CHUNK) S = ntiles / CHUNK;     // at least one chunk per split
   if (S < 1) S = 1;
   int tps = (ntiles + S - 1) / S;
@@ -605,7 +597,7 @@ __global__ __launch_bounds__(256) void k_match_pack(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
   pack_body(P.d1, P.g.n1, P.norm1, P.d2, P.g.n2, P.slots, P.tiles, P.cst, P.norm2);
 }
-__global__ __launch_bounds__(256, 3) void k_match_sweep1(MatchBatch b) {
+__global__ __launch_bounds__(256, SWEEP_WPS) void k_match_sweep1(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
   if ((int)blockIdx.x * QPB >= P.g.n1 || (int)blockIdx.y >= P.g.S) return;
   SweepArgs A;
@@ -618,7 +610,7 @@ __global__ __launch_bounds__(1024) void k_match_decide(MatchBatch b, double sqmi
   decide_body(P.d1, P.norm1, P.d2, P.norm2, P.partial, P.g, P.pos2, sqminratio, contrDistSq, P.rows, P.dmin, P.undecided,
               P.counter);
 }
-__global__ __launch_bounds__(256, 3) void k_match_sweep2(MatchBatch b) {
+__global__ __launch_bounds__(256, SWEEP_WPS) void k_match_sweep2(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
   if ((int)blockIdx.x * QPB >= P.g.n1 || (int)blockIdx.y >= P.g.S) return;
   SweepArgs A;

@@ -16,11 +16,13 @@
 
 namespace orc {
 
-/* linear kNN: nn best (dist, idx) ascending; equal distances keep insertion (index) order */
+/* linear kNN: nn best (dist, idx) ascending; equal distances keep insertion (index) order.  Queries are independent:
+ * the loop runs under OpenMP (OMP_NUM_THREADS=1 for the single-thread baseline), the per-query arithmetic is unchanged. */
 void knn_linear(const float *d1, int n1, const float *d2, int n2, int dim, int nn, int *idx, float *dist) {
-  std::vector<float> bd(nn);
-  std::vector<int> bi(nn);
+#pragma omp parallel for schedule(dynamic, 16)
   for (int q = 0; q < n1; q++) {
+    std::vector<float> bd(nn);
+    std::vector<int> bi(nn);
     int count = 0;
     float worst = std::numeric_limits<float>::max();
     const float *a = d1 + (size_t)q * dim;
