@@ -7,10 +7,11 @@ orientation -> RootSIFT per view, then brute-force FGINN matching of the ~24 k x
 (matching.cpp:357-461), duplicate filtering and LO-RANSAC (H).  All images are resident in HBM before the timed region.
 
   --config views31 (default) | views61 | views11 | views8 | views1 | wxbs      workload of the JSON line
-  --gpus N   one process per GPU (torch.distributed.run).  --shard views (default for N > 1): every pair's views are split
-             over the N ranks (view v -> rank v mod N), the region rows + u8 descriptors are all-gathered over RCCL/xGMI
-             inside the library (modsx_allgather_view_blocks) and the query rows of the match are split over the ranks;
-             the batch grows with N (weak scaling: per-GPU work fixed).  --shard pairs: independent pairs per rank.
+  --gpus N   one process per GPU (torch.distributed.run).  --shard pairs (default): independent pairs per rank, no
+             collective.  --shard views: every pair's views are split over the N ranks (view v -> rank v mod N), the region
+             rows + u8 descriptors are all-gathered over RCCL/xGMI inside the library (modsx_detect_describe_views_sharded)
+             and the query rows of the match are split over the ranks (modsx_match_fginn_sharded); the batch grows with N
+             (weak scaling: per-GPU work fixed).
 Rank 0 prints ONE JSON line: value = pairs/s of the whole job, `roofline` = the distance kernels (all k_match_*
 launches, sweep 2 included, on the descriptors of this run) against the int8 MFMA peak, `roofline_describe` = the
 describe stage against HBM with SURVEY section 8(d) bytes, `cpu_baseline` = the CPU oracle (restatement of the reference's
@@ -146,7 +147,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    shard = args.shard or ("views" if world > 1 else "pairs")
+    # default: pairs over ranks (no collective: independent pairs are the reference's batch use).  --shard views is the
+    # north-star's view-parallel mode; it needs RCCL between the ranks and is opt-in because the 1-GPU development box
+    # cannot exercise world > 1 (the path is covered at world 1 on the GPU and at world 2/3 over gloo on recorded blocks).
+    shard = args.shard or "pairs"
 
     import mods_amd
     from mods_amd import synthetic
@@ -164,7 +168,7 @@ def main():
 
     # pairs: with --shard views every rank holds every pair of the (N x larger) batch; otherwise its own pairs
     comm = None
-    if shard == "views" and world > 1:
+    if shard == "views":
         from mods_amd import distributed as D
         comm = D.NativeComm(ctxs, dist)          # one RCCL communicator per context (stream), bootstrapped over torch
         seed0, nbatch = 12345, batch * world
@@ -231,7 +235,11 @@ def main():
             c.profile(True)
         for _ in range(PROF_STEPS):
             run_batch()
-        barrier() if comm is not None else [c.synchronize() for c in ctxs]
+        if comm is not None:
+            barrier()
+        else:
+            for c in ctxs:
+                c.synchronize()
         for c in ctxs:
             for k, v in c.kernel_stats().items():
                 d = stats.setdefault(k, dict(ms=0.0, work=0.0, launches=0))
@@ -240,7 +248,7 @@ def main():
     # Roofline leg: in the timed region the kernels of --workers streams time-slice the CUs, so an event pair there
     # brackets queueing as well.  The same pairs are repeated on ONE stream and the launch durations come from that pass.
     iso, niso = {}, 0
-    if rank == 0 and comm is None:
+    if rank == 0 and (comm is None or world == 1):
         ctx.profile(True)
         niso = min(nbatch, 8 if single_view else 4)
         if single_view:

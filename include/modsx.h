@@ -352,6 +352,37 @@ int modsx_match_ladder(modsx_ctx *ctx, const modsx_image *img1, const modsx_imag
                        const modsx_ladder_step *steps, int nsteps, int min_matches, const modsx_pair_params *par,
                        modsx_pair_result *res, int *steps_done);
 
+/* ---- view-sharded multi-GPU path (one process per GPU, RCCL over xGMI) ------------------------------------------------
+ * The reference's unit of parallelism is the synthesised view (`#pragma omp parallel for` over views,
+ * imagerepresentation.cpp:612-622); views meet only in AddRegions' ordered concatenation (:2044-2045, ids re-based by
+ * AddRegionsToList :588-600).  View v belongs to rank v mod world.  A modsx_comm wraps one RCCL communicator used on the
+ * stream of the ctx it was created with; the 128-byte id comes from modsx_comm_unique_id() on one rank and reaches the
+ * others by any side channel (MPI, torch.distributed, a file).  RCCL is bound at run time (dlopen). */
+typedef struct modsx_comm modsx_comm;
+int modsx_comm_unique_id(void *id128);
+modsx_comm *modsx_comm_create(modsx_ctx *ctx, const void *id128, int rank, int world);
+void modsx_comm_destroy(modsx_comm *comm);
+int modsx_comm_info(const modsx_comm *comm, int *rank, int *world, int *rccl_version, long *bytes_gathered, long *collectives);
+/* Where row j of the reference's list sits in the all-gathered buffer (rank r's padded block starts at r * maxrows):
+ * counts[r * nviews + v] = regions of view v on rank r (0 unless r == v mod world).  Returns the list length (host only). */
+int modsx_view_block_order(const int *counts, int world, int nviews, int *src, int cap, int *maxrows_out);
+/* SynthDetectDescribeKeypoints with this rank taking views rank, rank + world, ...: per-view counts and the padded row
+ * blocks (modsx_region + 128 u8 descriptor bytes = 328 B per row) are all-gathered device to device; every rank returns
+ * ALL regions in reference order with re-based ids.  *dev_desc_u8 = the [n][128] u8 descriptors in HBM (owned by ctx,
+ * valid until its next sharded call). */
+int modsx_detect_describe_views_sharded(modsx_ctx *ctx, modsx_comm *comm, const modsx_image *img, const modsx_view *views,
+                                        int nviews, const modsx_pair_params *par, modsx_region **regs, void **dev_desc_u8,
+                                        int *view_counts);
+/* MatchFlannFGINN with the query rows split over the ranks (every rank holds all descriptors of both images): the
+ * per-query result rows are all-gathered on the device, every rank returns the full tentative list in query order. */
+int modsx_match_fginn_sharded(modsx_ctx *ctx, modsx_comm *comm, const void *dev_desc1_u8, int n1, const void *dev_desc2_u8,
+                              int n2, const double *pos2, double ratio, double contradDist, int nn, modsx_tentative **out);
+/* modsx_match_pair_views over the ranks: both images sharded by view, the match sharded by query row, DuplicateFiltering +
+ * LO-RANSAC on rank `owner` only (owner < 0: on every rank); the other ranks fill the counters up to n_tentatives. */
+int modsx_match_pair_views_sharded(modsx_ctx *ctx, modsx_comm *comm, const modsx_image *img1, const modsx_image *img2,
+                                   const modsx_view *views, int nviews, const modsx_pair_params *par, int owner,
+                                   modsx_pair_result *res);
+
 /* Key files: void ImageRepresentation::SaveRegions(std::string fname, int mode) / LoadRegions(std::string fname)
  * (imagerepresentation.cpp:2139-2215; mods.cpp:236-241 reads them instead of detecting when read_pre_extracted is
  * set).  Text format, one (detector, descriptor) class after the other; files are byte-identical to the reference's

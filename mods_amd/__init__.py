@@ -91,7 +91,9 @@ EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "m
            "modsx_loransac_h", "modsx_ransac_f", "modsx_loransac_f", "modsx_match_pair", "modsx_match_pairs", "modsx_pair_result_release",
            "modsx_set_vs_pars", "modsx_synth_view", "modsx_detect_describe_views", "modsx_match_fginn_device",
            "modsx_match_pair_views", "modsx_match_ladder", "modsx_save_regions", "modsx_load_regions", "modsx_default_mser_params", "modsx_detect_msers", "modsx_detect_msers_u8", "modsx_last_timings", "modsx_profile",
-           "modsx_kernel_stats"]
+           "modsx_kernel_stats", "modsx_comm_unique_id", "modsx_comm_create", "modsx_comm_destroy", "modsx_comm_info",
+           "modsx_view_block_order", "modsx_detect_describe_views_sharded", "modsx_match_fginn_sharded",
+           "modsx_match_pair_views_sharded"]
 
 KERNEL_CLASSES = ["blur_hess", "hessian", "resize", "nms_localize", "baumberg", "orientation", "patch_sample",
                   "blur_rows", "describe", "match_fginn", "gray", "warp_affine", "view_blur", "blur_cols"]
@@ -120,6 +122,10 @@ def lib():
         L.modsx_last_error.restype = C.c_char_p
         L.modsx_create.restype = C.c_void_p
         L.modsx_create.argtypes = [C.c_int]
+        L.modsx_comm_create.restype = C.c_void_p
+        L.modsx_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.modsx_comm_destroy.argtypes = [C.c_void_p]
+        L.modsx_comm_info.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         L.modsx_destroy.argtypes = [C.c_void_p]
         L.modsx_free.argtypes = [C.c_void_p]
         L.modsx_image_upload.restype = C.c_void_p
@@ -486,6 +492,39 @@ class Context(object):
                                             C.byref(params), C.byref(res)), "match_pair_views")
         return _unpack_pair_result(res)
 
+    # ---- view-sharded path (engine_shard.hip): `comm` is a handle from modsx_comm_create on this context ----
+    def comm_create(self, id128, rank, world):
+        h = lib().modsx_comm_create(self._c(), id128, int(rank), int(world))
+        if not h:
+            raise RuntimeError("modsx_comm_create failed: " + _err())
+        return h
+
+    def detect_describe_views_sharded(self, comm, img, views, params):
+        """All regions in reference order on every rank + the device pointer of their [n][128] u8 descriptors."""
+        arr = _view_array(views)
+        regs, dptr = C.c_void_p(), C.c_void_p()
+        counts = (C.c_int * len(views))()
+        n = _check(lib().modsx_detect_describe_views_sharded(self._c(), C.c_void_p(comm), C.c_void_p(img.h), arr, len(views),
+                                                             C.byref(params), C.byref(regs), C.byref(dptr), counts),
+                   "detect_describe_views_sharded")
+        return _take(regs, n, REGION), dptr.value, np.array(list(counts), np.int64)
+
+    def match_fginn_sharded(self, comm, d1_ptr, n1, d2_ptr, n2, pos2, ratio=0.8, contrad_dist=30.0, nn=50):
+        pos2 = np.ascontiguousarray(pos2, np.float64)
+        out = C.c_void_p()
+        n = _check(lib().modsx_match_fginn_sharded(self._c(), C.c_void_p(comm), C.c_void_p(d1_ptr), int(n1), C.c_void_p(d2_ptr),
+                                                   int(n2), _p(pos2), C.c_double(ratio), C.c_double(contrad_dist), nn,
+                                                   C.byref(out)), "match_fginn_sharded")
+        return _take(out, n, TENT)
+
+    def match_pair_views_sharded(self, comm, img1, img2, views, params, owner=0):
+        arr = _view_array(views)
+        res = PairResult()
+        _check(lib().modsx_match_pair_views_sharded(self._c(), C.c_void_p(comm), C.c_void_p(img1.h), C.c_void_p(img2.h), arr,
+                                                    len(views), C.byref(params), int(owner), C.byref(res)),
+               "match_pair_views_sharded")
+        return _unpack_pair_result(res)
+
     def detect_msers(self, img, params=None, tilt=1.0, zoom=1.0):
         params = params or default_mser_params()
         out = C.c_void_p()
@@ -535,6 +574,23 @@ class Context(object):
 
 class _ImageStruct(C.Structure):   # mirrors struct modsx_image (engine.hpp) for reading rows/cols of a handle
     _fields_ = [("d", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("owned", C.c_bool)]
+
+
+def view_block_order(counts):
+    """modsx_view_block_order: counts [world, nviews] -> (source row of every list position, maxrows)."""
+    counts = np.ascontiguousarray(counts, np.int32)
+    world, nviews = counts.shape
+    total = int(counts.sum())
+    src = np.zeros(max(1, total), np.int32)
+    mr = C.c_int(0)
+    n = _check(lib().modsx_view_block_order(_p(counts), world, nviews, _p(src), len(src), C.byref(mr)), "view_block_order")
+    return src[:n].copy(), mr.value
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    _check(lib().modsx_comm_unique_id(buf), "comm_unique_id")
+    return buf.raw
 
 
 def _image_dims(handle):

@@ -924,11 +924,29 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
   return MODSX_OK;
 }
 
+// the host half of the matcher: per-query result rows -> TentativeCorrespExt records (matching.cpp:435-457)
+static void rows_to_tentatives(const MatchRow *rows, int n1, int nn, std::vector<modsx_tentative> &o) {
+  o.reserve(n1 / 4 + 16);
+  for (int q = 0; q < n1; q++) {
+    const MatchRow &r = rows[q];
+    // rank of the first ratio-passing neighbour is nless+1; it must be <= nn-1 and every neighbour
+    // before it must lie within contradDist of NN0 (matching.cpp:435-457)
+    if (r.t0 < 0 || r.tj < 0 || r.nbad != 0 || r.nless > nn - 2) continue;
+    modsx_tentative t;
+    t.q = q; t.t0 = r.t0; t.tj = r.tj;
+    t.t1 = r.t1;
+    t.d1 = r.d0; t.d2 = r.dj; t.d2by2ndcl = r.d1;
+    double ratio = r.d0 / r.dj;  // f32 / f32, then widened (matching.cpp:437)
+    t.ratio = sqrt(ratio);
+    o.push_back(t);
+  }
+}
+
 // MatchFlannFGINN (matching/matching.cpp:357-461, linear index) on descriptors resident in HBM, for nb <= MATCH_MAXB
 // independent (query set, train set) problems that share the kernel launches (blockIdx.z) and one synchronisation
 int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
                        const double *const *pos2Host, double ratioT, double contradDist, int nn,
-                       std::vector<modsx_tentative> *out) {
+                       std::vector<modsx_tentative> *out, const MatchShard *shard) {
   if (nb < 1 || nb > MATCH_MAXB) { set_error("match_device_batch: batch size"); return MODSX_ERR_ARG; }
   hipStream_t s = c->stream;
   const double sqminratio = ratioT * ratioT, contrDistSq = contradDist * contradDist;
@@ -936,6 +954,34 @@ int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int
   // nn = neighbours the walk may look at (default 50, matching.hpp:268-269); the event lists of the device matcher hold up to 64 groups
   if (nn < 2 || nn > 64) { set_error("match: nn must be in [2, 64]"); return MODSX_ERR_ARG; }
   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  if (shard) {
+    // view-sharded run (engine_shard.hip): this rank matches the query rows [lo, lo + per) of ONE problem; the result rows
+    // of all ranks are all-gathered on the device and every rank builds the full tentative list
+    if (nb != 1) { set_error("match_device_batch: a sharded match takes one problem"); return MODSX_ERR_ARG; }
+    out[0].clear();
+    const int N1 = shard->n1_total, M = n2[0], per = shard->per;
+    const int lo = shard->lo, nloc = std::max(0, std::min(N1, lo + per) - lo);
+    const size_t posB = up((size_t)M * 16), rowB = up((size_t)per * sizeof(MatchRow)), allB = (size_t)N1 * sizeof(MatchRow);
+    if (!c->pos2.ensure(posB) || !c->matchRows.ensure(rowB) || !c->hMatch.ensure(posB + up(allB)) ||
+        !c->matchWork.ensure(match_workspace_bytes(std::max(1, nloc), M)))
+      return MODSX_ERR_NOMEM;
+    char *hpos = (char *)c->hMatch.p, *hrow = hpos + posB;
+    memcpy(hpos, pos2Host[0], (size_t)M * 16);
+    MX_HIP(hipMemcpyAsync(c->pos2.p, hpos, (size_t)M * 16, hipMemcpyHostToDevice, s));
+    if (nloc > 0) {
+      ProfScope ps(c, K_MATCH, 2.0 * nloc * (double)M * 128);
+      launch_match(s, d1[0] + (size_t)lo * 128, nloc, d2[0], M, (const double *)c->pos2.p, sqminratio, contrDistSq, nn,
+                   (MatchRow *)c->matchRows.p, c->matchWork.p);
+    }
+    MatchRow *all = nullptr;
+    int rc = match_shard_gather(c, *shard, (MatchRow *)c->matchRows.p, &all);
+    if (rc) return rc;
+    MX_HIP(hipMemcpyAsync(hrow, all, allB, hipMemcpyDeviceToHost, s));
+    MX_HIP(hipStreamSynchronize(s));
+    MX_HIP(hipGetLastError());
+    rows_to_tentatives((const MatchRow *)hrow, N1, nn, out[0]);
+    return MODSX_OK;
+  }
   size_t posOfs[MATCH_MAXB], rowOfs[MATCH_MAXB], workOfs[MATCH_MAXB], posB = 0, rowB = 0, workB = 0;
   int live[MATCH_MAXB], nl = 0;
   for (int i = 0; i < nb; i++) {
@@ -971,33 +1017,15 @@ int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int
     launch_match_batch(s, nl, pd1, pn1, pd2, pn2, ppos, sqminratio, contrDistSq, nn, prow, pwork);
   }
   MX_HIP(hipMemcpyAsync(hrow, c->matchRows.p, rowB, hipMemcpyDeviceToHost, s));
-  const MatchRow *rows[MATCH_MAXB];
-  for (int k = 0; k < nl; k++) rows[k] = (const MatchRow *)(hrow + rowOfs[k]);
   MX_HIP(hipStreamSynchronize(s));
   MX_HIP(hipGetLastError());
-  for (int k = 0; k < nl; k++) {
-    std::vector<modsx_tentative> &o = out[live[k]];
-    o.reserve(pn1[k] / 4 + 16);
-    for (int q = 0; q < pn1[k]; q++) {
-      const MatchRow &r = rows[k][q];
-      // rank of the first ratio-passing neighbour is nless+1; it must be <= nn-1 and every neighbour
-      // before it must lie within contradDist of NN0 (matching.cpp:435-457)
-      if (r.t0 < 0 || r.tj < 0 || r.nbad != 0 || r.nless > nn - 2) continue;
-      modsx_tentative t;
-      t.q = q; t.t0 = r.t0; t.tj = r.tj;
-      t.t1 = r.t1;
-      t.d1 = r.d0; t.d2 = r.dj; t.d2by2ndcl = r.d1;
-      double ratio = r.d0 / r.dj;  // f32 / f32, then widened (matching.cpp:437)
-      t.ratio = sqrt(ratio);
-      o.push_back(t);
-    }
-  }
+  for (int k = 0; k < nl; k++) rows_to_tentatives((const MatchRow *)(hrow + rowOfs[k]), pn1[k], nn, out[live[k]]);
   return MODSX_OK;
 }
 
 int match_device(modsx_ctx *c, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2Host,
                  double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out) {
-  return match_device_batch(c, 1, &d1, &n1, &d2, &n2, &pos2Host, ratioT, contradDist, nn, &out);
+  return match_device_batch(c, 1, &d1, &n1, &d2, &n2, &pos2Host, ratioT, contradDist, nn, &out, nullptr);
 }
 
 // The matcher computes on u8: the reference's SIFT-family descriptors hold the integers 0..255
@@ -1138,7 +1166,7 @@ int match_pair_group(modsx_ctx *c, const modsx_image *const *imgs1, const modsx_
     for (int g0 = 0; g0 < G; g0 += MATCH_MAXB) {
       const int nbm = std::min(MATCH_MAXB, G - g0);
       rc = match_device_batch(c, nbm, pd1 + g0, pn1 + g0, pd2 + g0, pn2 + g0, ppos + g0, pp.match_ratio, pp.contradDist, pp.nn,
-                              tentsv + g0);
+                              tentsv + g0, nullptr);
       if (rc) return rc;
     }
     tMatch = now_ms() - m0;

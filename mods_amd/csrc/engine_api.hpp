@@ -42,6 +42,12 @@ int match_pair_views(modsx_ctx *c, const modsx_image *img1, const modsx_image *i
                      const modsx_pair_params &pp, modsx_pair_result *res);
 void prof_begin(modsx_ctx *c, int cls, double work, size_t *slot);
 void prof_end(modsx_ctx *c, size_t slot);
+// a sharded match (engine_shard.hip): this rank owns the query rows [lo, lo + per) of n1_total
+struct MatchShard { void *comm; int per, n1_total, lo; };
+int match_shard_gather(modsx_ctx *c, const MatchShard &sh, mx::MatchRow *rowsLocal, mx::MatchRow **rowsAll);
+int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
+                       const double *const *pos2Host, double ratioT, double contradDist, int nn,
+                       std::vector<modsx_tentative> *out, const MatchShard *shard);
 int match_device(modsx_ctx *c, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2Host,
                  double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out);
 int match_host_desc(modsx_ctx *c, const float *desc1, int n1, const float *desc2, int n2, const double *pos2,

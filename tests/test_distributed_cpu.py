@@ -1,5 +1,11 @@
-"""CPU, world_size 2 over gloo: the view-shard exchange (one all-gather of padded row blocks) rebuilds the
-reference's list order, and the pair-shard bench plumbing (barrier, max-over-ranks time) works."""
+"""CPU, world_size 2 over gloo: the view-shard exchange on RECORDED engine output.
+
+The native path (csrc/engine_shard.hip) does, per image side: all-gather of the per-view counts, all-gather of the padded
+328-byte row blocks, then a gather into the reference's (view, detection) order given by modsx_view_block_order, then
+AddRegionsToList's id re-basing.  RCCL needs GPUs, so here the same three steps run over gloo on the blocks the engine
+produced for a small image (tests/golden/view_blocks_small.npz, written by tools/make_view_blocks_fixture.py on an MI355X):
+the ordering function is the library's own (host code, no device needed), and the result must be the engine's unsharded
+output, field for field.  Also covers the pair-shard bench plumbing (barrier, max-over-ranks time)."""
 import os
 import sys
 
@@ -10,51 +16,70 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIX = os.path.join(ROOT, "tests", "golden", "view_blocks_small.npz")
 
 
-def _fake_blocks(nviews, seed=0):
-    """Deterministic per-view blocks: counts vary per view, one view is empty."""
+def _blocks():
     import mods_amd
-    rs = np.random.RandomState(seed)
-    blocks = []
-    for v in range(nviews):
-        n = 0 if v == 3 else int(rs.randint(1, 40))
-        regs = np.zeros(n, mods_amd.REGION)
-        regs["img_id"] = v
-        regs["det_kp"]["x"] = rs.uniform(0, 100, n)
-        regs["reproj_kp"]["x"] = rs.uniform(0, 100, n)
-        regs["reproj_kp"]["y"] = rs.uniform(0, 100, n)
-        desc = rs.randint(0, 256, (n, 128)).astype(np.uint8)
-        blocks.append((regs, desc))
-    return blocks
+    z = np.load(FIX)
+    counts = z["counts"].astype(np.int64)
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    R = mods_amd.REGION
+    br = np.frombuffer(np.ascontiguousarray(z["block_regs"]).tobytes(), R)        # raw 200-byte C records
+    blocks = [(br[starts[v]:starts[v + 1]], z["block_desc"][starts[v]:starts[v + 1]]) for v in range(len(counts))]
+    ref = np.frombuffer(np.ascontiguousarray(z["regs"]).tobytes(), R)
+    return blocks, counts, ref, z["desc"]
 
 
-def _worker(rank, world, port, nviews, ret):
+def _pack(regs, desc):
+    import mods_amd
+    n = len(regs)
+    rows = np.zeros((n, mods_amd.REGION.itemsize + 128), np.uint8)
+    if n:
+        rows[:, :mods_amd.REGION.itemsize] = np.frombuffer(np.ascontiguousarray(regs).tobytes(), np.uint8).reshape(n, -1)
+        rows[:, mods_amd.REGION.itemsize:] = desc
+    return rows
+
+
+def _worker(rank, world, port, ret):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mods_amd
     from mods_amd import distributed as D
-    blocks = _fake_blocks(nviews)
+    blocks, counts_ref, ref_regs, ref_desc = _blocks()
+    nviews = len(blocks)
     mine = D.shard_views(nviews, rank, world)
-    regs_l = np.concatenate([blocks[v][0] for v in mine])
-    desc_l = np.concatenate([blocks[v][1] for v in mine])
-    counts = np.zeros(nviews, np.int64)
+    rows_l = _pack(np.concatenate([blocks[v][0] for v in mine]), np.concatenate([blocks[v][1] for v in mine]))
+    cnt = np.zeros(nviews, np.int32)
     for v in mine:
-        counts[v] = len(blocks[v][0])
-    rows = torch.from_numpy(D.pack_rows(regs_l, desc_l))
-    rows_g, allc = D.all_gather_view_blocks(rows, counts, nviews, torch.device("cpu"))
-    regs_g, desc_g = D.unpack_rows(rows_g.numpy())
-    regs_g = D.rebase_ids(regs_g)
-    ref_regs = np.concatenate([b[0] for b in blocks])
-    ref_desc = np.concatenate([b[1] for b in blocks])
-    ok = (len(regs_g) == len(ref_regs) and np.array_equal(desc_g, ref_desc)
-          and np.array_equal(regs_g["reproj_kp"]["x"], ref_regs["reproj_kp"]["x"])
-          and np.array_equal(regs_g["img_id"], ref_regs["img_id"]))
-    # ids re-based like AddRegionsToList: block start added to the (zero) local ids
-    starts = np.concatenate([[0], np.cumsum([len(b[0]) for b in blocks])[:-1]])
-    exp_ids = np.concatenate([np.full(len(b[0]), s) for b, s in zip(blocks, starts)])
-    ok = ok and np.array_equal(regs_g["id"], exp_ids) and allc.shape == (world, nviews)
+        cnt[v] = len(blocks[v][0])
+    # 1. counts
+    allc = [torch.zeros(nviews, dtype=torch.int32) for _ in range(world)]
+    dist.all_gather(allc, torch.from_numpy(cnt))
+    counts = torch.stack(allc).numpy()
+    # 2. padded row blocks
+    src, maxrows = mods_amd.view_block_order(counts)
+    pad = np.zeros((maxrows, rows_l.shape[1]), np.uint8)
+    pad[:len(rows_l)] = rows_l
+    parts = [torch.zeros((maxrows, rows_l.shape[1]), dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(parts, torch.from_numpy(pad))
+    rows_all = torch.cat(parts).numpy()
+    # 3. reference order + id re-basing by view counts
+    rows = rows_all[src]
+    R = mods_amd.REGION
+    regs = np.frombuffer(np.ascontiguousarray(rows[:, :R.itemsize]).tobytes(), R, len(rows)).copy()
+    desc = np.ascontiguousarray(rows[:, R.itemsize:])
+    vc = np.array([counts[v % world, v] for v in range(nviews)])
+    starts = np.concatenate([[0], np.cumsum(vc)[:-1]])
+    for v in range(nviews):
+        regs["id"][starts[v]:starts[v] + vc[v]] += starts[v]
+        regs["parent_id"][starts[v]:starts[v] + vc[v]] += starts[v]
+    ok = np.array_equal(vc, counts_ref) and len(regs) == len(ref_regs) and np.array_equal(desc, ref_desc)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from common import same_records
+    ok = ok and same_records(regs, ref_regs)          # every field (struct padding bytes are not data)
     # bench plumbing: max-over-ranks of a per-rank time, sum of per-rank work
     t = torch.tensor([1.0 + rank, 10.0 * (rank + 1)], dtype=torch.float64)
     tmax, tsum = t.clone(), t.clone()
@@ -66,20 +91,24 @@ def _worker(rank, world, port, nviews, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nviews", [8, 11])
-def test_view_shard_all_gather_world2(nviews):
-    world = 2
-    port = 29500 + (os.getpid() % 2000) + nviews
+@pytest.mark.parametrize("world", [2, 3])
+def test_view_shard_exchange_on_recorded_blocks(world):
+    port = 29500 + (os.getpid() % 2000) + world
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, nviews, ret), nprocs=world, join=True)
-    assert dict(ret) == {0: True, 1: True}
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
 
 
-def test_global_order_and_sharding():
+def test_view_block_order_and_sharding():
     sys.path.insert(0, ROOT)
+    import mods_amd
     from mods_amd import distributed as D
     assert D.shard_views(8, 1, 3) == [1, 4, 7]
     counts = np.array([[2, 0, 3, 0], [0, 1, 0, 0]])           # rank 0 owns views 0,2; rank 1 owns 1,3 (empty)
-    idx, maxrows = D.global_order(counts, 2)
+    idx, maxrows = mods_amd.view_block_order(counts)
     assert maxrows == 5 and idx.tolist() == [0, 1, 5, 2, 3, 4]
+    # identity-like views all carry img_id 0: block boundaries must come from the counts, not from runs of img_id
+    counts = np.array([[3, 0, 2], [0, 4, 0]])
+    idx, maxrows = mods_amd.view_block_order(counts)
+    assert maxrows == 5 and idx.tolist() == [0, 1, 2, 5, 6, 7, 8, 3, 4]

@@ -98,40 +98,40 @@ def test_cat_pair_with_views_recovers_ground_truth(ctx, modsx, cat_pair):
     assert np.mean(err < 10.0) > 0.8, (np.sort(err)[:10], len(err))
 
 
-def test_view_shard_path_world1_nccl(ctx, modsx, small_pair):
-    """The RCCL code path of mods_amd.distributed on one GPU (world_size 1): device tensors, all-gather,
-    reorder, device matcher -- must equal the unsharded library call."""
-    import os
-    import torch
-    import torch.distributed as dist
+def test_view_shard_path_world1_rccl(ctx, modsx, small_pair):
+    """The native RCCL path (csrc/engine_shard.hip) on one GPU: a world-size-1 communicator, ncclAllGather of the counts,
+    the 328-byte row blocks and the matcher's result rows on device buffers -- must equal the unsharded library calls."""
     from mods_amd import distributed as D
     a, b, _ = small_pair
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29631")
-    created = False
-    if not dist.is_initialized():
-        torch.cuda.set_device(0)
-        dist.init_process_group("nccl", rank=0, world_size=1)
-        created = True
+    comm = D.NativeComm([ctx])
     try:
+        assert comm.describe()["ranks_seen_by_rccl"] == 1
         views = modsx.set_vs_pars([1.0], [1, 2, 3, 4], 360.0, 0.2, 1, [])
-        par = modsx.default_pair_params()
+        par = modsx.default_pair_params(ransac_seed=4)
         ia, ib = ctx.upload(a), ctx.upload(b)
-        r1, d1 = D.detect_describe_views_sharded(ctx, ia, views, par)
-        r2, d2 = D.detect_describe_views_sharded(ctx, ib, views, par)
-        ref1, refd1 = ctx.detect_describe_views(ia, views, par)
-        assert same_records(r1, ref1) and np.array_equal(d1.cpu().numpy().astype(np.float32), refd1)
-        tent = D.match_sharded(ctx, r1, d1, r2, d2, 0.8, 30.0)
+        ref1, refd1, c1 = ctx.detect_describe_views(ia, views, par, want_counts=True)
         ref2, refd2 = ctx.detect_describe_views(ib, views, par)
+        r1, d1ptr, cnt = comm.detect_describe_views_sharded(0, ia, views, par)
+        assert same_records(r1, ref1) and np.array_equal(cnt, c1)
+        # the gathered descriptors live in HBM: match them against image 2's through the sharded matcher
+        import torch
+        d2 = torch.from_numpy(refd2.astype(np.uint8)).cuda()
         pos2 = np.stack([ref2["reproj_kp"]["x"], ref2["reproj_kp"]["y"]], 1)
+        tent = comm.match_fginn_sharded(0, d1ptr, len(r1), d2.data_ptr(), len(ref2), pos2, 0.8, 30.0)
         reft = ctx.match_fginn(refd1, refd2, pos2, 0.8, 30.0)
         assert len(tent) == len(reft) > 10
         for f in reft.dtype.names:
             assert np.array_equal(tent[f], reft[f]), f
+        got = comm.match_pair_views_sharded(0, ia, ib, views, par, owner=0)
+        ref = ctx.match_pair_views(ia, ib, views, par)
+        assert got["n_regions"] == ref["n_regions"] and got["n_verified"] == ref["n_verified"]
+        for f in ref["tentatives"].dtype.names:
+            assert np.array_equal(got["tentatives"][f], ref["tentatives"][f]), f
+        assert np.array_equal(got["ransac_inlier"], ref["ransac_inlier"]) and np.array_equal(got["H"], ref["H"])
+        assert comm.describe()["all_gather_calls_rank0"] >= 5
         ia.free(); ib.free()
     finally:
-        if created:
-            dist.destroy_process_group()
+        comm.close()
 
 
 def _oracle_ladder(oracle, a, b, steps, min_matches, seed, ori_mr=1.0):
