@@ -34,7 +34,13 @@ CONFIGS = {   # name -> (tilts, phi, detector mode, description)
     "views11": ("1,2,4,6,8", 360.0, "11 views (TiltSet 1,2,4,6,8, Phi 360: iters_mods_cviu.ini HessianAffine step)"),
     "views31": ("1,2,4,6,8", 120.0, "31 views (TiltSet 1,2,4,6,8, Phi 120)"),
     "views61": ("1,2,4,6,8", 60.0, "61 views (TiltSet 1,2,4,6,8, Phi 60)"),
+    # configs[4]: 1920x1080 pairs with the parameter set of config_iter_mods_cviu_wxbs.ini (NotLessThanRegions 2000, maxAngles 5
+    # on the 5.1962 region, HalfRootSIFT, contradDist 10, duplicateDist 3, err_threshold 4, max_samples 1e6), H then F
+    "wxbs": ("1", 360.0, "configs[4]: WxBS parameter set, identity view"),
 }
+WXBS = dict(mode=4, threshold=5.3333, reg_number=2000, ori_mrSize=5.1962, ori_maxAngles=5, ori_threshold=0.8, desc_mrSize=5.1962,
+            desc_photoNorm=1, desc_type=3, desc_maxBinValue=0.2, match_ratio=0.8, contradDist=10.0, duplicateDist=3.0,
+            err_threshold=4.0, confidence=0.99, max_samples=1000000, localOptimization=1, LAFCoef=3.0, HLAFCoef=13.0, doSymmCheck=1)
 
 
 def cpu_info():
@@ -155,6 +161,9 @@ def main():
     import mods_amd
     from mods_amd import synthetic
     tilts, phi, cfg_desc = CONFIGS[args.config]
+    wxbs = args.config == "wxbs"
+    if wxbs:
+        args.rows, args.cols = 1080, 1920
     if args.tilts:
         tilts, phi = args.tilts, (args.phi or 360.0)
         cfg_desc = "tilts %s, phi %g" % (tilts, phi)
@@ -163,7 +172,7 @@ def main():
     nblobs = int(4000 * args.rows * args.cols / (768.0 * 1024))
     ctxs = [mods_amd.Context(local_rank) for _ in range(max(1, args.workers))]
     ctx = ctxs[0]
-    params = mods_amd.default_pair_params(ransac_seed=1)
+    params = mods_amd.default_pair_params(ransac_seed=1, **(WXBS if wxbs else {}))
     views = mods_amd.set_vs_pars([1.0], [float(t) for t in tilts.split(",")], phi, args.init_sigma, 1, [])
 
     # pairs: with --shard views every rank holds every pair of the (N x larger) batch; otherwise its own pairs
@@ -225,6 +234,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     res = next(r for r in results if r is not None)
+    verify_timed = mods_amd.last_batch_verify() if single_view else None   # host share of the last batch of the timed region
 
     # ---- untimed legs (rank 0 reports them) -------------------------------------------------------------------------
     # per-kernel time of the multi-stream regime: two extra steps with the event brackets on
@@ -329,8 +339,28 @@ def main():
                     "algorithmic_work_per_launch": byts,
                     "note": "bytes per SURVEY section 8(d): (P+2)^2 x 4 B read + 128 B written per region; the limiter of these "
                             "kernels is VALU issue / the texture addresser, not HBM (DESIGN.md section 5)"}
+        if wxbs:
+            # H verification was the timed region; the same batch with epipolar verification, and the host share of both
+            vms, vn, vth = verify_timed
+            hshare = {"verify_ms_per_pair": vms / max(1, vn), "helper_threads": vth}
+            pF = mods_amd.default_pair_params(ransac_seed=1, useF=1, **WXBS)
+            mods_amd.match_pairs(ctxs, imgs1, imgs2, pF)
+            ta = time.perf_counter()
+            stF = 3
+            for _ in range(stF):
+                rF = mods_amd.match_pairs(ctxs, imgs1, imgs2, pF)
+            dtF = time.perf_counter() - ta
+            fms, fn, fth = mods_amd.last_batch_verify()
+            out["wxbs"] = {
+                "H": {"pairs_per_s": value, **hshare,
+                      "host_ransac_share_of_wall": (vms / max(1, vn)) / max(1, vth) / (1e3 / value) * 1.0},
+                "F": {"pairs_per_s": stF * nbatch / dtF, "verify_ms_per_pair": fms / max(1, fn), "helper_threads": fth,
+                      "verified_last_pair": rF[0]["n_verified"],
+                      "host_ransac_share_of_wall": (fms / max(1, fn)) / max(1, fth) / (dtF / (stF * nbatch) * 1e3)},
+                "note": "DuplicateFiltering + LO-RANSAC run on helper threads beside the device pipeline; share = per-pair verify "
+                        "time / helper threads / per-pair wall time (the fraction of the wall the helpers are busy)"}
         # ---- short runs of the other view counts (same timed-region rules, fewer steps) ---------------------------------
-        if not args.no_extra and comm is None and world == 1 and not args.tilts:
+        if not args.no_extra and comm is None and world == 1 and not args.tilts and not wxbs:
             extra = {}
             for name in ("views1", "views8", "views11"):
                 if name == args.config:
@@ -355,7 +385,7 @@ def main():
                                "descriptors_per_s": nd / dt}
             out["extra"] = extra
         # ---- the CPU path on the same workload: parity of one pair of the run + the baseline timing ---------------------
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not wxbs:
             from oracle import pyoracle as O
             model, ncpu, usable = cpu_info()
             a, b, _ = pairs_host[0]

@@ -291,6 +291,9 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
                       const modsx_image *const *imgs2, int n_pairs, const modsx_pair_params *par,
                       modsx_pair_result *results);
 
+/* host share of the last modsx_match_pairs call: wall time of DuplicateFiltering + LO-RANSAC summed over its pairs (ms),
+ * the pairs verified and the helper threads that ran them (measurement hook) */
+int modsx_last_batch_verify(double *sum_ms, int *pairs, int *threads);
 /* per-stage time of the last modsx_match_pair in ms: detect, orient, describe, match, verify, total */
 int modsx_last_timings(modsx_ctx *ctx, double *ms6);
 

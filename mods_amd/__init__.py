@@ -91,7 +91,7 @@ EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "m
            "modsx_loransac_h", "modsx_ransac_f", "modsx_loransac_f", "modsx_match_pair", "modsx_match_pairs", "modsx_pair_result_release",
            "modsx_set_vs_pars", "modsx_synth_view", "modsx_detect_describe_views", "modsx_match_fginn_device",
            "modsx_match_pair_views", "modsx_match_ladder", "modsx_save_regions", "modsx_load_regions", "modsx_default_mser_params", "modsx_detect_msers", "modsx_detect_msers_u8", "modsx_last_timings", "modsx_profile",
-           "modsx_kernel_stats", "modsx_comm_unique_id", "modsx_comm_create", "modsx_comm_destroy", "modsx_comm_info",
+           "modsx_kernel_stats", "modsx_last_batch_verify", "modsx_comm_unique_id", "modsx_comm_create", "modsx_comm_destroy", "modsx_comm_info",
            "modsx_view_block_order", "modsx_detect_describe_views_sharded", "modsx_match_fginn_sharded",
            "modsx_match_pair_views_sharded"]
 
@@ -574,6 +574,13 @@ class Context(object):
 
 class _ImageStruct(C.Structure):   # mirrors struct modsx_image (engine.hpp) for reading rows/cols of a handle
     _fields_ = [("d", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("owned", C.c_bool)]
+
+
+def last_batch_verify():
+    """(summed ms of DuplicateFiltering + LO-RANSAC, pairs, helper threads) of the last match_pairs call."""
+    ms, n, t = C.c_double(), C.c_int(), C.c_int()
+    lib().modsx_last_batch_verify(C.byref(ms), C.byref(n), C.byref(t))
+    return ms.value, n.value, t.value
 
 
 def view_block_order(counts):

@@ -1,6 +1,7 @@
 // capi.hip -- the extern "C" boundary declared in include/modsx.h.
 #include <math.h>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <thread>
 #include <condition_variable>
@@ -20,6 +21,11 @@ static T *to_malloc(const std::vector<T> &v) {
   if (p && !v.empty()) memcpy(p, v.data(), sizeof(T) * v.size());
   return p;
 }
+
+// host share of the last modsx_match_pairs call: summed wall time of DuplicateFiltering + LO-RANSAC over its pairs, and
+// the number of helper threads that ran them
+static std::atomic<long> g_verifyUs(0);
+static std::atomic<int> g_verifyThreads(0), g_verifyPairs(0);
 
 extern "C" {
 
@@ -333,7 +339,10 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
         t = std::move(vq.q.front());
         vq.q.pop_front();
       }
+      const auto v0 = std::chrono::steady_clock::now();
       mx::verify_tentatives(t.r1, t.r2, t.tents, pp, t.res);
+      g_verifyUs += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - v0).count();
+      g_verifyPairs++;
     }
   };
   auto worker = [&](int w) {
@@ -360,6 +369,7 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
   std::vector<std::thread> th, hth;
   const int ngroups = (n_pairs + group - 1) / group;
   const int nw = n_ctx < ngroups ? n_ctx : ngroups;
+  g_verifyUs = 0; g_verifyPairs = 0; g_verifyThreads = nw;
   for (int w = 0; w < nw; w++) hth.emplace_back(helper);
   for (int w = 1; w < nw; w++) th.emplace_back(worker, w);
   if (nw > 0) worker(0);
@@ -381,6 +391,13 @@ void modsx_pair_result_release(modsx_pair_result *res) {
   if (!res) return;
   free(res->tentatives); free(res->ransac_inlier); free(res->verified);
   res->tentatives = nullptr; res->ransac_inlier = nullptr; res->verified = nullptr;
+}
+
+int modsx_last_batch_verify(double *sum_ms, int *pairs, int *threads) {
+  if (sum_ms) *sum_ms = g_verifyUs.load() / 1000.0;
+  if (pairs) *pairs = g_verifyPairs.load();
+  if (threads) *threads = g_verifyThreads.load();
+  return MODSX_OK;
 }
 
 int modsx_last_timings(modsx_ctx *ctx, double *ms6) {

@@ -298,3 +298,68 @@ def test_full_hd_pair_runs(ctx, modsx):
     ia.free(); ib.free()
     assert min(r["n_regions"]) > 4000 and r["n_verified"] > 500
     assert np.abs(normH(r["H"]) - H).max() < 1.0
+
+
+def _wxbs_params(modsx, seed, useF):
+    """config_iter_mods_cviu_wxbs.ini: [HessianAffine] :13-27, [DominantOrientation] :102-108, [SIFTDescriptor] :109-118 with the
+    HalfRootSIFT class of iters_mods_cviu_wxbs.ini:35,48,61, [Matching] contradDist :173, [DuplicateFiltering] :179-182,
+    [RANSAC] :185-194."""
+    return modsx.default_pair_params(
+        mode=4, threshold=5.3333, reg_number=2000,                 # NotLessThanRegions / 2000
+        ori_mrSize=5.1962, ori_maxAngles=5, ori_threshold=0.8,
+        desc_mrSize=5.1962, desc_photoNorm=1, desc_type=3, desc_maxBinValue=0.2,  # HalfRootSIFT
+        match_ratio=0.8, contradDist=10.0, duplicateDist=3.0,
+        err_threshold=4.0, confidence=0.99, max_samples=1000000, localOptimization=1, LAFCoef=3.0, HLAFCoef=13.0,
+        doSymmCheck=1, useF=useF, ransac_seed=seed)
+
+
+def _wxbs_oracle(O, a, b):
+    p = O.default_params(mode=4, threshold=5.3333, reg_number=2000)
+    feats = []
+    for g in (a, b):
+        k = O.detect_hessaff(g, p)
+        r = O.detect_affine_regions(k)
+        ro = O.detect_orientation(g, r, mr_size=5.1962, max_ang=5, th=0.8)
+        rr = O.reproject_regions(ro, np.eye(3), g.shape[1], g.shape[0])
+        feats.append((rr, O.describe_regions(g, rr, mr_size=5.1962, rootsift=3)))
+    (r1, d1), (r2, d2) = feats
+    pos2 = np.stack([r2["reproj_kp"]["x"], r2["reproj_kp"]["y"]], 1)
+    tent = O.match_fginn(d1, d2, pos2, 0.8, 10.0)
+    pts = np.stack([r1["reproj_kp"]["x"][tent["q"]], r1["reproj_kp"]["y"][tent["q"]],
+                    r2["reproj_kp"]["x"][tent["t0"]], r2["reproj_kp"]["y"][tent["t0"]]], 1)
+    order, keep = O.duplicate_filtering(pts, tent["ratio"], 3.0, True)
+    sel = order[keep]
+    return r1, r2, tent[sel], pts[sel]
+
+
+def test_wxbs_config_full_hd_pair_h_and_f(ctx, modsx, oracle):
+    """configs[4] of BASELINE.json end to end on one 1920x1080 pair with the WxBS parameter set (NotLessThanRegions 2000,
+    maxAngles 5 on the 5.1962 measurement region, HalfRootSIFT, contradDist 10, duplicateDist 3, err_threshold 4,
+    max_samples 1e6) against the CPU oracle: region counts, the de-duplicated tentative list field by field, and for both
+    verification types (H: exp_ransacHcustom + H_LAF_check 13, F: exp_ransacFcustom + DEGENSAC + F_LAF_check 3) the RANSAC
+    inlier flags, the verified set and the model."""
+    from mods_amd import synthetic
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    a, b, H = synthetic.make_pair(rows=1080, cols=1920, nblobs=3000, seed=77)
+    r1, r2, tu, pu = _wxbs_oracle(oracle, a, b)
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    for useF in (0, 1):
+        got = ctx.match_pair(ia, ib, _wxbs_params(modsx, 5, useF))
+        assert got["n_regions"] == (len(r1), len(r2)) and min(got["n_regions"]) >= 2000
+        _check_tents(got["tentatives"], tu)
+        if useF:
+            rr = oracle.loransac_f(pu, laf_of(r1, tu["q"]), laf_of(r2, tu["t0"]), err_threshold=4.0, max_samples=1000000,
+                                   laf_coef=3.0, seed=5)
+            Fa, Fb = rr["F"] / np.linalg.norm(rr["F"]), got["H"] / np.linalg.norm(got["H"])
+            if (Fa * Fb).sum() < 0:
+                Fb = -Fb
+            assert np.abs(Fa - Fb).max() < 1e-6
+        else:
+            rr = oracle.loransac_h(pu, laf_of(r1, tu["q"]), laf_of(r2, tu["t0"]), err_threshold=4.0, max_samples=1000000,
+                                   hlaf_coef=13.0, seed=5)
+            assert np.abs(normH(got["H"]) - normH(rr["H"])).max() < 1e-4
+            assert np.abs(normH(got["H"]) - H).max() < 1.0
+        assert np.array_equal(got["ransac_inlier"], rr["inl"]) and np.array_equal(got["verified"], rr["keep"])
+        assert got["n_verified"] > 200
+    ia.free(); ib.free()
