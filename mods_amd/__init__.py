@@ -94,6 +94,9 @@ EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "m
            "modsx_kernel_stats", "modsx_last_batch_verify", "modsx_comm_unique_id", "modsx_comm_create", "modsx_comm_destroy", "modsx_comm_info",
            "modsx_view_block_order", "modsx_detect_describe_views_sharded", "modsx_match_fginn_sharded",
            "modsx_match_pair_views_sharded"]
+# include/modsx_degensac.h: the reference's own verification symbols (link-time drop-in for libdegensac)
+EXPORTS_DEGENSAC = ["exp_ransacHcustom", "exp_ransacFcustom", "HDs", "HDsi", "HDsidx", "FDs", "FDsSym", "exFDs", "exFDsSym",
+                    "modsx_ransac_set_seed"]
 
 KERNEL_CLASSES = ["blur_hess", "hessian", "resize", "nms_localize", "baumberg", "orientation", "patch_sample",
                   "blur_rows", "describe", "match_fginn", "gray", "warp_affine", "view_blur", "blur_cols"]

@@ -317,7 +317,7 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
   // every context takes up to MAXB / 2 pairs at a time and runs their 2g images as one batch; the group shrinks so
   // that all contexts get work when the batch is small
   int group = (n_pairs + n_ctx - 1) / n_ctx;
-  if (group > mx::MAXB / 2) group = mx::MAXB / 2;
+  if (group > mx::PAIR_GROUP) group = mx::PAIR_GROUP;
   if (group < 1) group = 1;
   // Verification (DuplicateFiltering + LO-RANSAC, ~1.4 ms of host time per pair against ~0.9 ms of device time) runs on
   // helper threads, one per working context: the context's own thread goes straight on to the next group, so its

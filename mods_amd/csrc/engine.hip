@@ -1113,7 +1113,7 @@ void verify_tentatives(const std::vector<modsx_region> &r1, const std::vector<mo
 // each pair is matched and verified.  Results are those of G separate calls.
 int match_pair_group(modsx_ctx *c, const modsx_image *const *imgs1, const modsx_image *const *imgs2, int G,
                      const modsx_pair_params &pp, modsx_pair_result *res, std::vector<VerifyTask> *deferred) {
-  if (G < 1 || 2 * G > MAXB) { set_error("match_pair_group: group size"); return MODSX_ERR_ARG; }
+  if (G < 1 || G > PAIR_GROUP || 2 * G > MAXB) { set_error("match_pair_group: group size"); return MODSX_ERR_ARG; }
   for (int g = 0; g < G; g++) {
     memset(&res[g], 0, sizeof res[g]);
     for (int i = 0; i < 9; i++) res[g].H[i] = -1;

@@ -12,7 +12,11 @@
 namespace mx {
 
 // ---- device job descriptors (passed by value in kernel arguments) ----------------------
-constexpr int MAXB = 8;        // images per batched launch set (16 measured slower: per-context footprint)
+#ifndef MODSX_MAXB
+#define MODSX_MAXB 8
+#endif
+constexpr int MAXB = MODSX_MAXB;   // images (views) per batched launch set
+constexpr int PAIR_GROUP = 4;      // identity-view pairs per launch set of modsx_match_pairs (8 images; 16 measured slower)
 constexpr int NMS_MAXJ = 1024; // (image, octave, level) jobs per NMS launch (flushed when full)
 constexpr int MAX_TAPS = 17;   // pyramid kernels: ksize <= 17
 

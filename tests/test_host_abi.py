@@ -22,6 +22,34 @@ def test_library_exports_every_declared_symbol(modsx):
     assert L.modsx_version() == 100
 
 
+def test_degensac_symbols_are_exported_and_link(modsx, tmp_path):
+    """include/modsx_degensac.h: the reference's own verification symbols (exp_ransacHcustom, exp_ransacFcustom, HDs, ...)
+    with the reference's signatures.  A plain C program that links -lmodsx like an application that used to link
+    libdegensac calls them with LORANSACFiltering's argument list (tests/native/test_shim.c) and gets the results of
+    modsx_ransac_h / modsx_ransac_f for the same seed; a foreign error-function pointer is refused."""
+    import shutil
+    import subprocess
+    hdr = open(os.path.join(ROOT, "include", "modsx_degensac.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(const double|\b(exp_ransac[A-Za-z]+|modsx_ransac_set_seed)\s*\(", hdr))
+    names = {a or b for a, b in declared}
+    assert names == set(modsx.EXPORTS_DEGENSAC)
+    L = modsx.lib()
+    for name in sorted(names):
+        assert hasattr(L, name), name
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    exe = str(tmp_path / "test_shim")
+    libdir = os.path.join(ROOT, "mods_amd")
+    subprocess.check_call([cc, "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "test_shim.c"),
+                           "-o", exe, "-L" + libdir, "-lmodsx", "-lm", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("OK "), (out.stdout, out.stderr)
+    nh, nf = (int(x) for x in out.stdout.split()[1:3])
+    assert nh > 200 and nf > 200
+
+
 def test_struct_layouts_match_reference_structs(modsx):
     # AffineKeypoint is 8 doubles + int + double + int (88 B); AffineRegion = 5 ints + 2 keypoints
     assert modsx.KEYPOINT.itemsize == 88 and modsx.REGION.itemsize == 200
