@@ -106,6 +106,16 @@ struct WarpJob {
   int pad;
 };
 
+// one non-identity view of a batched synthesis (kernels_views.hip): src -R-> rot -blur (through tmp)-> rot -W-> dst
+struct ViewJob {
+  const float *src;
+  float *rot, *tmp, *dst;
+  int srows, scols, rrows, rcols, drows, dcols;
+  int kx, ky, tapOfs, doBlur;
+  int tileA, tileB;   // first 64 x 4 tile of this view in the rotated-image / output-image tile lists
+  double R[6], W[6];  // inverse maps of the two cv::warpAffine calls (f64, inverted on the host)
+};
+
 // matching
 struct MatchRow {     // per-query result of the device matcher
   int t0, t1, tj, nless, nbad;
@@ -185,6 +195,8 @@ void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *im
                      const double *wts, int photoNorm, int descType, double maxBin, const DescOut &outs);
 void launch_warp_affine(hipStream_t s, const WarpJob &jb);
 void launch_blur_pass(hipStream_t s, const float *src, float *dst, int rows, int cols, const float *taps, int n, int pass);
+void launch_views_warp(hipStream_t s, const ViewJob *jobs, int n, int tiles, int stage);
+void launch_views_blur(hipStream_t s, const ViewJob *jobs, int n, int tiles, const float *taps, int pass);
 size_t match_workspace_bytes(int n1, int n2);
 void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2,
                   double sqminratio, double contrDistSq, int nn, MatchRow *rows, void *workspace);
@@ -220,8 +232,8 @@ struct modsx_ctx {
   hipStream_t stream;
   mx::Pyramid pyr[mx::MAXB];
   mx::DevBuf nmsJobs, cand, counter, affJobs, affOut, oriJobs, oriOut, descJobs, tilePrefix, taps, imgRefs, scratchA, scratchB,
-      descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], descAllU8b[2], pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps, viewImg[mx::MAXB], scratchC, needTab, coordTab, tileJob, blurTiles, nmsQueue;
-  mx::PinBuf hCand, hAff, hOri, hDesc, hMisc, hNms, hMatch, hViewTaps;
+      descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], descAllU8b[2], pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps, viewJobs, viewImg[mx::MAXB], scratchC, needTab, coordTab, tileJob, blurTiles, nmsQueue;
+  mx::PinBuf hCand, hAff, hOri, hDesc, hMisc, hNms, hMatch, hViewTaps, hViewJobs;
   // constant tables on device
   float *dSmmMask = nullptr;   // 19x19 computeGaussMask
   int smmW = 0;

@@ -60,10 +60,17 @@ static void invert_affine(const double *Min, double *M) {
   M[2] = b1; M[5] = b2;
 }
 
-constexpr size_t VIEW_TAPS = 1024;   // floats of anti-alias taps (x then y) per view slot
+// host half of GenerateSynthImageCorr (synth-detection.cpp:236-430) for one view: homography, sizes, the inverse maps of the
+// two warps and the anti-alias taps
+struct ViewPlan {
+  int identity = 0;
+  double H[9];
+  int w_rot = 0, h_rot = 0, ow = 0, oh = 0, doBlur = 0, kx = 1, ky = 1;
+  double Rinv[6], Winv[6];
+  std::vector<float> taps;   // kx taps, then ky taps
+};
 
-int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx_image **out, double *H, int *identity,
-               int slot) {
+static int plan_view(const modsx_image *gray, const modsx_view &v, ViewPlan &P) {
   double tilt = v.tilt;
   const double phi = v.phi, zoom = v.zoom, InitSigma = v.InitSigma;
   int zoomed = 0;
@@ -72,17 +79,15 @@ int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx
   if (fabs(zoom - 1.0f) >= 0.05) zoomed = 1;
   const int w = gray->cols, h = gray->rows;
   int wS1 = (int)(w * zoom), hS1 = (int)(h * zoom);
-  *out = nullptr;
+  double *H = P.H;
   if ((fabs(tilt - 1.) <= 0.1) && (fabs(phi) <= 0.2) && (fabs(zoom - 1.) <= 0.1)) {  // original image, :278-289
     const double E[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     for (int i = 0; i < 9; i++) H[i] = E[i];
-    *identity = 1;
-    modsx_image *im = new modsx_image();
-    im->d = gray->d; im->rows = h; im->cols = w; im->owned = false;
-    *out = im;
+    P.identity = 1;
+    P.ow = w; P.oh = h;
     return MODSX_OK;
   }
-  *identity = 0;
+  P.identity = 0;
   double d, d2, w_new, h_new;
   double kV = 1., kH = 1.;
   if (zoomed) { kV = (double)w / (double)wS1; kH = (double)h / (double)hS1; }
@@ -120,36 +125,25 @@ int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx
   double sigma_aa_2 = zoomed ? InitSigma / (4.0 * zoom) : InitSigma / 2.0;
   double sigma_aa = InitSigma * tilt / (2.0 * zoom);
   double sigma_x = vertical_tilt ? sigma_aa_2 : sigma_aa, sigma_y = vertical_tilt ? sigma_aa : sigma_aa_2;
-  int w_rot, h_rot;
   double R[6];
   if (q1) {
-    w_rot = floor((0.5 + cos(phi) * w + sin(phi) * h));
-    h_rot = floor((0.5 + sin(phi) * w + cos(phi) * h));
+    P.w_rot = floor((0.5 + cos(phi) * w + sin(phi) * h));
+    P.h_rot = floor((0.5 + sin(phi) * w + cos(phi) * h));
     R[0] = cos(phi); R[1] = sin(phi); R[2] = 0;
     R[3] = -sin(phi); R[4] = cos(phi); R[5] = floor(0.5 + sin(phi) * w);
   } else {
-    w_rot = floor((0.5 - cos(phi) * w + sin(phi) * h));
-    h_rot = floor((0.5 + sin(phi) * w - cos(phi) * h));
+    P.w_rot = floor((0.5 - cos(phi) * w + sin(phi) * h));
+    P.h_rot = floor((0.5 + sin(phi) * w - cos(phi) * h));
     d = -floor(cos(phi) * w);
     d2 = floor(0.5 + (sin(phi) * w - cos(phi) * h));
     R[0] = cos(phi); R[1] = sin(phi); R[2] = d;
     R[3] = -sin(phi); R[4] = cos(phi); R[5] = d2;
   }
-  const int ow = (int)w_new, oh = (int)h_new;
-  if (w_rot <= 0 || h_rot <= 0 || ow <= 0 || oh <= 0) { set_error("degenerate synthesised view"); return MODSX_ERR_ARG; }
-  hipStream_t s = c->stream;
-  const size_t rotPx = (size_t)w_rot * h_rot;
-  if (!c->viewTmp[0].ensure(rotPx * 4) || !c->viewTmp[1].ensure(rotPx * 4)) return MODSX_ERR_NOMEM;
-  float *t0 = (float *)c->viewTmp[0].p, *t1 = (float *)c->viewTmp[1].p;
-  WarpJob wj;
-  memset(&wj, 0, sizeof wj);
-  wj.src = gray->d; wj.dst = t0; wj.srows = h; wj.scols = w; wj.drows = h_rot; wj.dcols = w_rot; wj.cval = 128.f;
-  invert_affine(R, wj.M);
-  size_t pslot;
-  prof_begin(c, K_WARP, ((double)w * h + (double)rotPx) * 4, &pslot);
-  launch_warp_affine(s, wj);
-  prof_end(c, pslot);
-  float *cur = t0;
+  P.ow = (int)w_new; P.oh = (int)h_new;
+  if (P.w_rot <= 0 || P.h_rot <= 0 || P.ow <= 0 || P.oh <= 0) { set_error("degenerate synthesised view"); return MODSX_ERR_ARG; }
+  invert_affine(R, P.Rinv);
+  P.doBlur = v.doBlur;
+  P.taps.clear();
   if (v.doBlur) {
     int kx = floor(2.0 * 3.0 * sigma_x + 1.0);
     if (kx % 2 == 0) kx++;
@@ -157,46 +151,98 @@ int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx
     int ky = floor(2.0 * 3.0 * sigma_y + 1.0);
     if (ky % 2 == 0) ky++;
     if (ky < 3) ky = 3;
-    if (h_rot == 1) ky = 1;
-    if (w_rot == 1) kx = 1;
+    if (P.h_rot == 1) ky = 1;
+    if (P.w_rot == 1) kx = 1;
     std::vector<float> KX = gaussian_kernel(kx, std::max(sigma_x, 0.));
     std::vector<float> KY = (ky == kx && fabs(sigma_x - sigma_y) < 2.220446049250313e-16) ? KX : gaussian_kernel(ky, std::max(sigma_y, 0.));
-    std::vector<float> taps(KX);
-    taps.insert(taps.end(), KY.begin(), KY.end());
-    // taps travel through a pinned slice of their own (VIEW_TAPS floats per view slot), so the upload needs no host wait
-    const size_t sl = slot < 0 ? 0 : (size_t)slot;
-    if (taps.size() > VIEW_TAPS) { set_error("view anti-alias kernel too large"); return MODSX_ERR_ARG; }
-    if (!c->viewTaps.ensure((size_t)MAXB * VIEW_TAPS * 4) || !c->hViewTaps.ensure((size_t)MAXB * VIEW_TAPS * 4)) return MODSX_ERR_NOMEM;
-    float *hT = (float *)c->hViewTaps.p + sl * VIEW_TAPS, *dT = (float *)c->viewTaps.p + sl * VIEW_TAPS;
-    memcpy(hT, taps.data(), taps.size() * 4);
-    MX_HIP(hipMemcpyAsync(dT, hT, taps.size() * 4, hipMemcpyHostToDevice, s));
-    prof_begin(c, K_VIEW_BLUR, (double)rotPx * 16, &pslot);
-    launch_blur_pass(s, t0, t1, h_rot, w_rot, dT, kx, 0);
-    launch_blur_pass(s, t1, t0, h_rot, w_rot, dT + kx, ky, 1);
-    prof_end(c, pslot);
-    cur = t0;
-  }
-  modsx_image *im = new modsx_image();
-  im->rows = oh; im->cols = ow; im->d = nullptr;
-  if (slot >= 0) {
-    if (!c->viewImg[slot].ensure((size_t)ow * oh * 4)) { delete im; return MODSX_ERR_NOMEM; }
-    im->d = (float *)c->viewImg[slot].p; im->owned = false;
-  } else {
-    im->owned = true;
-    if (hipMalloc(&im->d, (size_t)ow * oh * 4) != hipSuccess) { delete im; set_error("hipMalloc view"); return MODSX_ERR_NOMEM; }
+    P.kx = kx; P.ky = ky;
+    P.taps = KX;
+    P.taps.insert(P.taps.end(), KY.begin(), KY.end());
   }
   double Wz[6] = {0, 0, 0, 0, 0, 0};
   if (vertical_tilt) { Wz[0] = 1.0 / kH; Wz[4] = 1.0 / (tilt * kV); }
   else { Wz[0] = 1.0 / (tilt * kH); Wz[4] = 1.0 / kV; }
-  memset(&wj, 0, sizeof wj);
-  wj.src = cur; wj.dst = im->d; wj.srows = h_rot; wj.scols = w_rot; wj.drows = oh; wj.dcols = ow; wj.cval = 128.f;
-  invert_affine(Wz, wj.M);
-  prof_begin(c, K_WARP, ((double)rotPx + (double)ow * oh) * 4, &pslot);
-  launch_warp_affine(s, wj);
+  invert_affine(Wz, P.Winv);
+  return MODSX_OK;
+}
+
+// Synthesises n views of `gray` in four launches (rotate all, blur rows all, blur columns all, tilt/zoom all).  Outputs go to
+// dst[i] (device, P[i].ow x P[i].oh floats; ignored for identity views).  No host wait: the job table and the taps travel
+// through pinned staging that is only rewritten after the caller's next synchronisation of the stream.
+static int synth_views_batch(modsx_ctx *c, const modsx_image *gray, const ViewPlan *P, float *const *dst, int n) {
+  hipStream_t s = c->stream;
+  std::vector<ViewJob> jobs;
+  std::vector<float> taps;
+  size_t rotFloats = 0;
+  int tilesA = 0, tilesB = 0;
+  double wpx = 0, rpx = 0;
+  for (int i = 0; i < n; i++) {
+    if (P[i].identity) continue;
+    ViewJob j;
+    memset(&j, 0, sizeof j);
+    j.src = gray->d; j.srows = gray->rows; j.scols = gray->cols;
+    j.rrows = P[i].h_rot; j.rcols = P[i].w_rot; j.drows = P[i].oh; j.dcols = P[i].ow;
+    j.dst = dst[i];
+    j.doBlur = P[i].doBlur; j.kx = P[i].kx; j.ky = P[i].ky; j.tapOfs = (int)taps.size();
+    taps.insert(taps.end(), P[i].taps.begin(), P[i].taps.end());
+    for (int q = 0; q < 6; q++) { j.R[q] = P[i].Rinv[q]; j.W[q] = P[i].Winv[q]; }
+    j.tileA = tilesA; j.tileB = tilesB;
+    tilesA += ((j.rcols + 63) / 64) * ((j.rrows + 3) / 4);
+    tilesB += ((j.dcols + 63) / 64) * ((j.drows + 3) / 4);
+    j.rot = (float *)(uintptr_t)rotFloats;            // offsets first; the bases are added once the buffers exist
+    rotFloats += (size_t)j.rrows * j.rcols;
+    wpx += (double)gray->rows * gray->cols + 2.0 * j.rrows * j.rcols + (double)j.drows * j.dcols;
+    rpx += (double)j.rrows * j.rcols;
+    jobs.push_back(j);
+  }
+  if (jobs.empty()) return MODSX_OK;
+  const size_t jobB = jobs.size() * sizeof(ViewJob), tapB = std::max<size_t>(1, taps.size()) * 4;
+  if (!c->viewTmp[0].ensure(rotFloats * 4) || !c->viewTmp[1].ensure(rotFloats * 4) || !c->viewJobs.ensure(jobB + tapB + 64) ||
+      !c->hViewJobs.ensure(jobB + tapB + 64))
+    return MODSX_ERR_NOMEM;
+  for (ViewJob &j : jobs) {
+    const size_t o = (size_t)(uintptr_t)j.rot;
+    j.rot = (float *)c->viewTmp[0].p + o;
+    j.tmp = (float *)c->viewTmp[1].p + o;
+  }
+  char *hb = (char *)c->hViewJobs.p;
+  memcpy(hb, jobs.data(), jobB);
+  if (!taps.empty()) memcpy(hb + jobB, taps.data(), taps.size() * 4);
+  MX_HIP(hipMemcpyAsync(c->viewJobs.p, hb, jobB + tapB, hipMemcpyHostToDevice, s));
+  const ViewJob *dj = (const ViewJob *)c->viewJobs.p;
+  const float *dt = (const float *)((char *)c->viewJobs.p + jobB);
+  size_t pslot;
+  prof_begin(c, K_WARP, wpx * 4, &pslot);
+  launch_views_warp(s, dj, (int)jobs.size(), tilesA, 0);
   prof_end(c, pslot);
-  // viewTmp is reused by the next view: stream order makes that safe on the device; only the public entry point waits
-  if (slot < 0) MX_HIP(hipStreamSynchronize(s));
+  prof_begin(c, K_VIEW_BLUR, rpx * 16, &pslot);
+  launch_views_blur(s, dj, (int)jobs.size(), tilesA, dt, 0);
+  launch_views_blur(s, dj, (int)jobs.size(), tilesA, dt, 1);
+  prof_end(c, pslot);
+  prof_begin(c, K_WARP, 0, &pslot);
+  launch_views_warp(s, dj, (int)jobs.size(), tilesB, 1);
+  prof_end(c, pslot);
   MX_HIP(hipGetLastError());
+  return MODSX_OK;
+}
+
+// the public single-view form (modsx_synth_view): a fresh allocation owned by the returned image
+int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx_image **out, double *H, int *identity, int) {
+  *out = nullptr;
+  ViewPlan P;
+  int rc = plan_view(gray, v, P);
+  if (rc) return rc;
+  for (int i = 0; i < 9; i++) H[i] = P.H[i];
+  *identity = P.identity;
+  modsx_image *im = new modsx_image();
+  im->rows = P.oh; im->cols = P.ow;
+  if (P.identity) { im->d = gray->d; im->owned = false; *out = im; return MODSX_OK; }
+  im->owned = true; im->d = nullptr;
+  if (hipMalloc(&im->d, (size_t)P.ow * P.oh * 4) != hipSuccess) { delete im; set_error("hipMalloc view"); return MODSX_ERR_NOMEM; }
+  float *dst[1] = {im->d};
+  rc = synth_views_batch(c, gray, &P, dst, 1);
+  if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("view synthesis failed"); rc = MODSX_ERR_DEVICE; }
+  if (rc) { hipFree(im->d); delete im; return rc; }
   *out = im;
   return MODSX_OK;
 }
@@ -222,13 +268,26 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
     int ident[MAXB];
     int rc = MODSX_OK;
     for (int i = 0; i < n; i++) vimg[i] = nullptr;
+    ViewPlan plans[MAXB];
+    float *vdst[MAXB];
     for (int i = 0; i < n && !rc; i++) {
       const modsx_view &v = views[take[g0 + i]];
-      rc = synth_view(c, gray, v, &vimg[i], Hs[i], &ident[i], i);
-      cimg[i] = vimg[i];
+      rc = plan_view(gray, v, plans[i]);
+      if (rc) break;
+      for (int q = 0; q < 9; q++) Hs[i][q] = plans[i].H[q];
+      ident[i] = plans[i].identity;
+      modsx_image *im = new modsx_image();
+      im->rows = plans[i].oh; im->cols = plans[i].ow; im->owned = false;
+      if (ident[i]) im->d = gray->d;
+      else if (!c->viewImg[i].ensure((size_t)im->rows * im->cols * 4)) { delete im; rc = MODSX_ERR_NOMEM; break; }
+      else im->d = (float *)c->viewImg[i].p;
+      vdst[i] = im->d;
+      vimg[i] = im;
+      cimg[i] = im;
       tilts[i] = ident[i] ? 1.0 : fabs(v.tilt);   // SynthImage::tilt / zoom as GenerateSynthImageCorr leaves them
       zooms[i] = ident[i] ? 1.0 : v.zoom;
     }
+    if (!rc) rc = synth_views_batch(c, gray, plans, vdst, n);
     std::vector<modsx_keypoint> kps[MAXB];
     std::vector<modsx_region> r0[MAXB], ro[MAXB];
     if (!rc) {

@@ -9,8 +9,7 @@
 
 namespace mx {
 
-__global__ __launch_bounds__(256) void k_warp_affine(WarpJob jb) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+MX_D void warp_body(const WarpJob &jb, int x, int y) {
   if (x >= jb.dcols || y >= jb.drows) return;
   const int AB_SCALE = 1024;
   const int adelta = (int)rint(jb.M[0] * x * AB_SCALE), bdelta = (int)rint(jb.M[3] * x * AB_SCALE);
@@ -39,6 +38,9 @@ __global__ __launch_bounds__(256) void k_warp_affine(WarpJob jb) {
   }
   jb.dst[(size_t)y * jb.dcols + x] = out;
 }
+__global__ __launch_bounds__(256) void k_warp_affine(WarpJob jb) {
+  warp_body(jb, blockIdx.x * 64 + (threadIdx.x & 63), blockIdx.y * 4 + (threadIdx.x >> 6));
+}
 
 MX_D int reflect101(int p, int n) {
   if (n == 1) return 0;
@@ -48,9 +50,7 @@ MX_D int reflect101(int p, int n) {
 
 // one pass of a separable Gaussian with BORDER_REFLECT_101: pass 0 = rows (RowFilter / SymmRowSmallFilter order),
 // pass 1 = columns (SymmColumnFilter order)
-__global__ __launch_bounds__(256) void k_blur_pass(const float *src, float *dst, int rows, int cols, const float *taps,
-                                                   int n, int pass) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+MX_D void blur_body(const float *src, float *dst, int rows, int cols, const float *taps, int n, int pass, int x, int y) {
   if (x >= cols || y >= rows) return;
   const int R = n >> 1;
   float v;
@@ -71,6 +71,41 @@ __global__ __launch_bounds__(256) void k_blur_pass(const float *src, float *dst,
   }
   dst[(size_t)y * cols + x] = v;
 }
+__global__ __launch_bounds__(256) void k_blur_pass(const float *src, float *dst, int rows, int cols, const float *taps,
+                                                   int n, int pass) {
+  blur_body(src, dst, rows, cols, taps, n, pass, blockIdx.x * 64 + (threadIdx.x & 63), blockIdx.y * 4 + (threadIdx.x >> 6));
+}
+
+// ---- batched form: all views of a launch set in four launches (warp, blur rows, blur columns, warp) ---------------------------
+// A view of tilt t is 1/t of the image, 31 to 61 of them per image: launched one by one they are ~250 launches of 2-10 us
+// per pair.  Every block takes one 64 x 4 tile of one view; the view is found from the tile prefix carried by the jobs.
+MX_D int find_view(const ViewJob *jobs, int n, int tile, int stage) {
+  int j = 0;
+  while (j + 1 < n && tile >= (stage ? jobs[j + 1].tileB : jobs[j + 1].tileA)) j++;
+  return j;
+}
+__global__ __launch_bounds__(256) void k_views_warp(const ViewJob *jobs, int n, int stage) {
+  const int j = find_view(jobs, n, blockIdx.x, stage);
+  const ViewJob &v = jobs[j];
+  WarpJob jb;
+  if (stage == 0) { jb.src = v.src; jb.dst = v.rot; jb.srows = v.srows; jb.scols = v.scols; jb.drows = v.rrows; jb.dcols = v.rcols; }
+  else { jb.src = v.rot; jb.dst = v.dst; jb.srows = v.rrows; jb.scols = v.rcols; jb.drows = v.drows; jb.dcols = v.dcols; }
+#pragma unroll
+  for (int i = 0; i < 6; i++) jb.M[i] = stage ? v.W[i] : v.R[i];
+  jb.cval = 128.f;
+  const int t = blockIdx.x - (stage ? v.tileB : v.tileA), tx = (jb.dcols + 63) / 64;
+  warp_body(jb, (t % tx) * 64 + (threadIdx.x & 63), (t / tx) * 4 + (threadIdx.x >> 6));
+}
+__global__ __launch_bounds__(256) void k_views_blur(const ViewJob *jobs, int n, const float *taps, int pass) {
+  const int j = find_view(jobs, n, blockIdx.x, 0);
+  const ViewJob &v = jobs[j];
+  if (!v.doBlur) return;
+  const int t = blockIdx.x - v.tileA, tx = (v.rcols + 63) / 64;
+  const float *src = pass ? v.tmp : v.rot;
+  float *dst = pass ? v.rot : v.tmp;
+  blur_body(src, dst, v.rrows, v.rcols, taps + v.tapOfs + (pass ? v.kx : 0), pass ? v.ky : v.kx, pass, (t % tx) * 64 + (threadIdx.x & 63),
+            (t / tx) * 4 + (threadIdx.x >> 6));
+}
 
 void launch_warp_affine(hipStream_t s, const WarpJob &jb) {
   dim3 grid((jb.dcols + 63) / 64, (jb.drows + 3) / 4);
@@ -79,6 +114,12 @@ void launch_warp_affine(hipStream_t s, const WarpJob &jb) {
 void launch_blur_pass(hipStream_t s, const float *src, float *dst, int rows, int cols, const float *taps, int n, int pass) {
   dim3 grid((cols + 63) / 64, (rows + 3) / 4);
   hipLaunchKernelGGL(k_blur_pass, grid, dim3(256), 0, s, src, dst, rows, cols, taps, n, pass);
+}
+void launch_views_warp(hipStream_t s, const ViewJob *jobs, int n, int tiles, int stage) {
+  if (tiles > 0) hipLaunchKernelGGL(k_views_warp, dim3(tiles), dim3(256), 0, s, jobs, n, stage);
+}
+void launch_views_blur(hipStream_t s, const ViewJob *jobs, int n, int tiles, const float *taps, int pass) {
+  if (tiles > 0) hipLaunchKernelGGL(k_views_blur, dim3(tiles), dim3(256), 0, s, jobs, n, taps, pass);
 }
 
 }  // namespace mx
