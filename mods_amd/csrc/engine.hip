@@ -832,8 +832,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
             j.a11 = (float)k.a11; j.a12 = (float)k.a12; j.a21 = (float)k.a21; j.a22 = (float)k.a22;
             j.tapOfs = pi.tapOfs; j.ksize = pi.ksize; j.NC = pi.NC; j.needOfs = pi.needOfs; j.coordOfs = pi.coordOfs;
             j.touch = pi.touch; j.rows0 = pi.rows0; j.ro1 = pi.ro1;
-            j.scratchOfs = arenaA; j.rowOfs = arenaB; j.gridOfs = arenaC;
-            arenaA += needA; arenaB += (size_t)P * pi.NC; arenaC += (size_t)pi.NC * pi.NC;
+            arenaA += needA;
           } else {
             j.P = 0;
             j.a11 = (float)k.a11 * i2p; j.a12 = (float)k.a12 * i2p; j.a21 = (float)k.a21 * i2p; j.a22 = (float)k.a22 * i2p;
@@ -847,6 +846,28 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
           j.a11 = (float)k.a11 * curr_sc; j.a12 = (float)k.a12 * curr_sc; j.a21 = (float)k.a21 * curr_sc; j.a22 = (float)k.a22 * curr_sc;
         }
         jobs.push_back(j);
+      }
+      if (full) break;
+      }
+      // (i, r) = first region that did not fit, or i == n
+      if (full) { curImg = i; curReg = r; } else { curImg = n; curReg = 0; }
+      const size_t nj = jobs.size();
+      // Launch order of the chunk: by image, then by 64-pixel row band, then by x.  The sampling kernel hands every XCD one
+      // contiguous eighth of this order (kernels_describe.hip: xcd_chunk), i.e. one part of the images; outIdx keeps every
+      // descriptor at its region's place, so the reference's list order is untouched.
+      std::sort(jobs.begin(), jobs.end(), [](const DescJob &a, const DescJob &b) {
+        if (a.img != b.img) return a.img < b.img;
+        const int ya = (int)a.y >> 6, yb = (int)b.y >> 6;
+        if (ya != yb) return ya < yb;
+        if (a.x != b.x) return a.x < b.x;
+        return a.outIdx < b.outIdx;
+      });
+      arenaA = 0;
+      for (DescJob &j : jobs) {
+        if (j.P > 0) {
+          j.scratchOfs = arenaA; j.rowOfs = arenaB; j.gridOfs = arenaC;
+          arenaA += (size_t)j.P * j.P; arenaB += (size_t)j.P * j.NC; arenaC += (size_t)j.NC * j.NC;
+        }
         pfxSample.push_back(pfxSample.back() + (j.P > 0 ? ((j.P + 63) / 64) * ((j.P + 127) / 128) : 0));  // 64 x SAMPLE_COLS tiles
         // the blur passes: LDS kernels where a tile fits, k_patch_blur (BLUR_TILE outputs per workgroup) otherwise
         pfxRowL.push_back(pfxRowL.back() + (j.P > 0 && j.rows0 ? (j.P + j.rows0 - 1) / j.rows0 : 0));
@@ -854,11 +875,6 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
         pfxRow.push_back(pfxRow.back() + (j.P > 0 && !j.rows0 ? (j.P * j.NC + 1023) / 1024 : 0));
         pfxCol.push_back(pfxCol.back() + (j.P > 0 && !j.ro1 ? (j.NC * j.NC + 1023) / 1024 : 0));
       }
-      if (full) break;
-      }
-      // (i, r) = first region that did not fit, or i == n
-      if (full) { curImg = i; curReg = r; } else { curImg = n; curReg = 0; }
-      const size_t nj = jobs.size();
       // the job table, the five tile prefixes and the three small tables travel as ONE pinned blob and one copy: nine
       // separate uploads cost nine ~6 us copy kernels per chunk on the stream
       auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };

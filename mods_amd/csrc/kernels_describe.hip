@@ -26,6 +26,15 @@ MX_D int xcd_swizzle(int b, int n) {
   return sg * SG + xcd * G + k;
 }
 
+// The sampling kernel is the one stage whose inputs (the images) are shared between regions.  Its tile list is sorted by
+// (image, 64-px row band, x) on the host and XCD x takes the x-th CONTIGUOUS eighth of it (block b runs on XCD b % 8 and is
+// that XCD's (b / 8)-th block), so an XCD's L2 holds only its part of the images instead of all of them: without this every
+// L2 pulled its own copy of every image (FETCH_SIZE ~10x the image bytes).  The grid is 8 * ceil(n / 8) blocks.
+MX_D int xcd_chunk(int b, int n) {
+  const int per = (n + 7) >> 3;
+  return (b & 7) * per + (b >> 3);
+}
+
 // tile -> job table: a per-workgroup binary search over the prefix array costs ~12 dependent L2 round trips,
 // longer than the useful work of a 256-element tile, so the prefix array is expanded once per launch set
 __global__ __launch_bounds__(64) void k_expand_tiles(const int *prefix, int nJobs, int *tileJob) {
@@ -99,8 +108,9 @@ __device__ __forceinline__ void sample_chunk(const ImgRef &im, const float *cx, 
 }
 
 __global__ __launch_bounds__(64) void k_patch_sample(const DescJob *jobs, const int *tilePrefix, const int *tileJob,
-                                                     const ImgRef *imgs, float *scratch) {
-  const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+                                                     const ImgRef *imgs, float *scratch, int nTiles) {
+  const int tile = xcd_chunk(blockIdx.x, nTiles);
+  if (tile >= nTiles) return;
   const int jid = tileJob[tile];
   const DescJob jb = jobs[jid];
   const int P = jb.P;
@@ -763,7 +773,7 @@ void launch_expand_tiles(hipStream_t s, const int *prefix, int nJobs, int *tileJ
 void launch_patch_sample(hipStream_t s, const DescJob *jobs, const int *tilePrefix, const int *tileJob, int nTiles,
                          const ImgRef *imgs, float *scratch) {
   if (nTiles <= 0) return;
-  hipLaunchKernelGGL(k_patch_sample, dim3(nTiles), dim3(64), 0, s, jobs, tilePrefix, tileJob, imgs, scratch);
+  hipLaunchKernelGGL(k_patch_sample, dim3(8 * ((nTiles + 7) / 8)), dim3(64), 0, s, jobs, tilePrefix, tileJob, imgs, scratch, nTiles);
 }
 void launch_blur_lds(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
                      const float *taps, const int *needTab, const float *src, float *dst, int pass) {
