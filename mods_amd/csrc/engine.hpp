@@ -13,9 +13,9 @@ namespace mx {
 
 // ---- device job descriptors (passed by value in kernel arguments) ----------------------
 #ifndef MODSX_MAXB
-#define MODSX_MAXB 8
+#define MODSX_MAXB 16
 #endif
-constexpr int MAXB = MODSX_MAXB;   // images (views) per batched launch set
+constexpr int MAXB = MODSX_MAXB;   // images (views) per batched launch set: 8 / 16 / 32 measured 121 / 125 / 120 pairs/s at 31 views
 constexpr int PAIR_GROUP = 4;      // identity-view pairs per launch set of modsx_match_pairs (8 images; 16 measured slower)
 constexpr int NMS_MAXJ = 1024; // (image, octave, level) jobs per NMS launch (flushed when full)
 constexpr int MAX_TAPS = 17;   // pyramid kernels: ksize <= 17
@@ -32,13 +32,15 @@ struct BlurBatch {
   int n;                 // ksize
   float k[MAX_TAPS];
   BlurJob j[MAXB];
+  int nj;                // jobs in use; tile0[i] = first tile of job i in the flat tile list of the launch (filled by the launcher)
+  int tile0[MAXB + 1];
 };
 struct ResizeJob {
   const float *src;
   float *dst;
   int srows, scols, drows, dcols;
 };
-struct ResizeBatch { ResizeJob j[MAXB]; };
+struct ResizeBatch { ResizeJob j[MAXB]; int nj; int tile0[MAXB + 1]; };
 struct NmsJob {
   const float *low, *cur, *high, *blur;
   int rows, cols, img, octave, level, pad;

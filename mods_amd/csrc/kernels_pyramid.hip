@@ -30,12 +30,22 @@ constexpr int TMP_W = TW + 4;                 // 66 needed columns rounded up to
 constexpr int BLR_H = TH + 4;                 // 34 needed rows rounded up to a multiple of 4
 constexpr int SRC_W = TMP_W + 2 * RMAX, SRC_H = BLR_H + 2 * RMAX;
 
+// The images of a launch set differ in size (a view of tilt t is 1/t of the image): a grid over the largest image would
+// launch four empty workgroups for every useful one.  The launch is a flat list of tiles; tile0[] says where each job's
+// tiles start (wave-uniform scan over at most MAXB entries of the kernel arguments).
+MX_D int find_job(const int *tile0, int nj, int t) {
+  int j = 0;
+  while (j + 1 < nj && t >= tile0[j + 1]) j++;
+  return j;
+}
+
 template <int R>
 __global__ __launch_bounds__(256) void k_blur_hess(BlurBatch batch) {
-  const BlurJob jb = batch.j[blockIdx.z];
+  const int ji = find_job(batch.tile0, batch.nj, blockIdx.x);
+  const BlurJob jb = batch.j[ji];
   const int rows = jb.rows, cols = jb.cols;
-  const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
-  if (tx0 >= cols || ty0 >= rows) return;
+  const int lt = blockIdx.x - batch.tile0[ji], ntx = (cols + TW - 1) / TW;
+  const int tx0 = (lt % ntx) * TW, ty0 = (lt / ntx) * TH;
   constexpr int n = 2 * R + 1;
   constexpr int sh = BLR_H + 2 * R, sw = TMP_W + 2 * R;
   // sized for this instantiation's halo: 25 KB (R = 4) .. 31.6 KB (R = 8), i.e. 6 workgroups per CU for the two
@@ -135,9 +145,11 @@ __global__ __launch_bounds__(256) void k_blur_hess(BlurBatch batch) {
 
 // HessianResponse of an existing level (first level of octaves >= 1), pyramid.cpp:223-281
 __global__ __launch_bounds__(256) void k_hessian(BlurBatch batch) {
-  const BlurJob jb = batch.j[blockIdx.z];
+  const int ji = find_job(batch.tile0, batch.nj, blockIdx.x);
+  const BlurJob jb = batch.j[ji];
   const int rows = jb.rows, cols = jb.cols;
-  const int gx = blockIdx.x * 64 + (threadIdx.x & 63), gy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int lt = blockIdx.x - batch.tile0[ji], ntx = (cols + 63) / 64;
+  const int gx = (lt % ntx) * 64 + (threadIdx.x & 63), gy = (lt / ntx) * 4 + (threadIdx.x >> 6);
   if (gx >= cols || gy >= rows) return;
   float o = 0.f;
   if (gy >= 1 && gy < rows - 1 && gx >= 1 && gx < cols - 1) {
@@ -156,8 +168,10 @@ __global__ __launch_bounds__(256) void k_hessian(BlurBatch batch) {
 // cv::resize(src, dst, Size(0,0), 0.5, 0.5, INTER_LINEAR) == area-fast 2x2 (pyramid.cpp:520):
 // full blocks ((s00+s01)+s10)+s11)*0.25f, partial blocks sum(available)/count.
 __global__ __launch_bounds__(256) void k_resize_half(ResizeBatch batch) {
-  const ResizeJob jb = batch.j[blockIdx.z];
-  const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int ji = find_job(batch.tile0, batch.nj, blockIdx.x);
+  const ResizeJob jb = batch.j[ji];
+  const int lt = blockIdx.x - batch.tile0[ji], ntx = (jb.dcols + 63) / 64;
+  const int dx = (lt % ntx) * 64 + (threadIdx.x & 63), dy = (lt / ntx) * 4 + (threadIdx.x >> 6);
   if (dx >= jb.dcols || dy >= jb.drows) return;
   const int sr = jb.srows, sc = jb.scols;
   const int sy0 = dy * 2, sx0 = dx * 2;
@@ -380,8 +394,18 @@ __global__ void k_gray_f32(const float *src, float *dst, size_t n, int channels)
   dst[i] = (float)((double)t * k + (double)src[3 * i + 2] * k + 0.0);
 }
 
-void launch_blur_hess(hipStream_t s, const BlurBatch &b, int nj, int maxRows, int maxCols) {
-  dim3 grid((maxCols + TW - 1) / TW, (maxRows + TH - 1) / TH, nj);
+static int fill_tiles(BlurBatch &b, int nj, int tw, int th) {
+  b.nj = nj;
+  int t = 0;
+  for (int i = 0; i < nj; i++) { b.tile0[i] = t; t += ((b.j[i].cols + tw - 1) / tw) * ((b.j[i].rows + th - 1) / th); }
+  b.tile0[nj] = t;
+  return t;
+}
+void launch_blur_hess(hipStream_t s, const BlurBatch &bin, int nj, int, int) {
+  BlurBatch b = bin;
+  const int tiles = fill_tiles(b, nj, TW, TH);
+  if (tiles <= 0) return;
+  dim3 grid(tiles);
   switch (b.n >> 1) {
     case 1: hipLaunchKernelGGL(k_blur_hess<1>, grid, dim3(256), 0, s, b); break;
     case 2: hipLaunchKernelGGL(k_blur_hess<2>, grid, dim3(256), 0, s, b); break;
@@ -393,13 +417,18 @@ void launch_blur_hess(hipStream_t s, const BlurBatch &b, int nj, int maxRows, in
     default: hipLaunchKernelGGL(k_blur_hess<8>, grid, dim3(256), 0, s, b); break;
   }
 }
-void launch_hessian(hipStream_t s, const BlurBatch &b, int nj, int maxRows, int maxCols) {
-  dim3 grid((maxCols + 63) / 64, (maxRows + 3) / 4, nj);
-  hipLaunchKernelGGL(k_hessian, grid, dim3(256), 0, s, b);
+void launch_hessian(hipStream_t s, const BlurBatch &bin, int nj, int, int) {
+  BlurBatch b = bin;
+  const int tiles = fill_tiles(b, nj, 64, 4);
+  if (tiles > 0) hipLaunchKernelGGL(k_hessian, dim3(tiles), dim3(256), 0, s, b);
 }
-void launch_resize_half(hipStream_t s, const ResizeBatch &b, int nj, int maxRows, int maxCols) {
-  dim3 grid((maxCols + 63) / 64, (maxRows + 3) / 4, nj);
-  hipLaunchKernelGGL(k_resize_half, grid, dim3(256), 0, s, b);
+void launch_resize_half(hipStream_t s, const ResizeBatch &bin, int nj, int, int) {
+  ResizeBatch b = bin;
+  b.nj = nj;
+  int t = 0;
+  for (int i = 0; i < nj; i++) { b.tile0[i] = t; t += ((b.j[i].dcols + 63) / 64) * ((b.j[i].drows + 3) / 4); }
+  b.tile0[nj] = t;
+  if (t > 0) hipLaunchKernelGGL(k_resize_half, dim3(t), dim3(256), 0, s, b);
 }
 
 // The extrema found by the scan are few and scattered (about one per wavefront), and each needs a chain of ~10 dependent
