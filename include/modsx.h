@@ -35,7 +35,7 @@ typedef enum modsx_status {
 enum { MODSX_FIXED_TH = 0, MODSX_RELATIVE_TH = 1, MODSX_FIXED_REG_NUMBER = 2, MODSX_RELATIVE_REG_NUMBER = 3,
        MODSX_NOT_LESS_THAN_REGIONS = 4 };
 /* detector_type / descriptor_type, detectors/structures.hpp:17-38, 75-96 */
-enum { MODSX_DET_HESSIAN = 0, MODSX_DET_MSER = 3 };   /* detector_type, detectors/structures.hpp:16-19 */
+enum { MODSX_DET_HESSIAN = 0, MODSX_DET_DOG = 1, MODSX_DET_HARRIS = 2, MODSX_DET_MSER = 3 };   /* detector_type, detectors/structures.hpp:16-19 */
 /* descriptor types of SIFTDescriptor::operator() (matching/siftdesc.cpp:399-442).  The half variants fold opposite
  * orientation bins into 64 values; their rows keep the 128 stride with entries 64..127 zero, which leaves every
  * L2 distance unchanged, so the matcher needs no second layout. */
@@ -186,6 +186,13 @@ int modsx_octave_levels(modsx_ctx *ctx, const modsx_image *img, const modsx_hess
  * cv::resize(.., 0.5, 0.5, INTER_LINEAR) (pyramid.cpp:520) */
 int modsx_gaussian_blur(modsx_ctx *ctx, const modsx_image *img, float sigma, float *out);
 int modsx_resize_half(modsx_ctx *ctx, const modsx_image *img, float *out, int *orows, int *ocols);
+
+/* stage tap: Mat ScaleSpaceDetector::Response(const Mat &inputImage, float norm), affinedetectors/pyramid.cpp:132-175, for
+ * DetectorType MODSX_DET_HESSIAN (HessianResponse :223-281), MODSX_DET_DOG (dogResponse :176-181: the input minus its
+ * gaussianBlur with sigma = norm) and MODSX_DET_HARRIS (HarrisResponse :283-305: gradients, three blurred products,
+ * det - 0.04 trace^2).  out: rows*cols f32.  The scale-space loop of modsx_detect_affine_keypoints itself runs the
+ * Hessian response only (the shipped configurations use HessianAffine and MSER); the other two are provided as kernels. */
+int modsx_response(modsx_ctx *ctx, const modsx_image *img, int detector_type, float norm, float *out);
 
 /* template DetectAffineRegions<>: scale by sqrt|det A| and rectify, synth-detection.hpp:93-126 (host math) */
 int modsx_detect_affine_regions(const modsx_keypoint *kps, int n, int img_id, int det_type, modsx_region *out);

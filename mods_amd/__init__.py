@@ -85,7 +85,7 @@ class PairResult(C.Structure):
 EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "modsx_destroy", "modsx_synchronize",
            "modsx_default_hessaff_params", "modsx_default_pair_params", "modsx_image_upload",
            "modsx_image_wrap_device", "modsx_image_free", "modsx_image_download", "modsx_detect_affine_keypoints",
-           "modsx_detect_scalespace", "modsx_octave_levels", "modsx_gaussian_blur", "modsx_resize_half",
+           "modsx_detect_scalespace", "modsx_octave_levels", "modsx_gaussian_blur", "modsx_resize_half", "modsx_response",
            "modsx_detect_affine_regions", "modsx_detect_orientation", "modsx_reproject_regions",
            "modsx_describe_regions", "modsx_match_fginn", "modsx_duplicate_filtering", "modsx_ransac_h",
            "modsx_loransac_h", "modsx_ransac_f", "modsx_loransac_f", "modsx_match_pair", "modsx_match_pairs", "modsx_pair_result_release",
@@ -392,6 +392,11 @@ class Context(object):
     def gaussian_blur(self, img, sigma):
         out = np.empty((img.rows, img.cols), np.float32)
         _check(lib().modsx_gaussian_blur(self._c(), C.c_void_p(img.h), C.c_float(sigma), _p(out)), "gaussian_blur")
+        return out
+
+    def response(self, img, detector_type, norm):
+        out = np.zeros((img.rows, img.cols), np.float32)
+        _check(lib().modsx_response(self._c(), C.c_void_p(img.h), int(detector_type), C.c_float(norm), _p(out)), "response")
         return out
 
     def resize_half(self, img):

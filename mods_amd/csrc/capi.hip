@@ -184,6 +184,62 @@ int modsx_gaussian_blur(modsx_ctx *ctx, const modsx_image *img, float sigma, flo
   return MODSX_OK;
 }
 
+// gaussianBlur(helpers.cpp:717-724) for any sigma (the tiled pyramid kernel stops at 17 taps): two generic passes, replicate border
+static int blur_any(modsx_ctx *c, const float *src, float *dst, float *tmp, float *dTaps, float *hTaps, int rows, int cols, float sigma) {
+  const int n = blur_ksize(sigma);
+  if (n == 1) { MX_HIP(hipMemcpyAsync(dst, src, (size_t)rows * cols * 4, hipMemcpyDeviceToDevice, c->stream)); return MODSX_OK; }
+  const int nx = cols == 1 ? 1 : n, ny = rows == 1 ? 1 : n;
+  std::vector<float> kx = gaussian_kernel(nx, sigma), ky = gaussian_kernel(ny, sigma);
+  memcpy(hTaps, kx.data(), nx * 4); memcpy(hTaps + nx, ky.data(), ny * 4);
+  MX_HIP(hipMemcpyAsync(dTaps, hTaps, (size_t)(nx + ny) * 4, hipMemcpyHostToDevice, c->stream));
+  launch_blur_pass(c->stream, src, tmp, rows, cols, dTaps, nx, 0, 1);
+  launch_blur_pass(c->stream, tmp, dst, rows, cols, dTaps + nx, ny, 1, 1);
+  return MODSX_OK;
+}
+
+int modsx_response(modsx_ctx *ctx, const modsx_image *img, int detector_type, float norm, float *out) {
+  NEED(ctx); NEED(img); NEED(out);
+  if (detector_type != MODSX_DET_HESSIAN && detector_type != MODSX_DET_DOG && detector_type != MODSX_DET_HARRIS) {
+    mx::set_error("modsx_response: detector type must be Hessian (0), DoG (1) or Harris (2)");
+    return MODSX_ERR_ARG;
+  }
+  hipSetDevice(ctx->dev);
+  hipStream_t s = ctx->stream;
+  const int rows = img->rows, cols = img->cols;
+  const size_t npx = (size_t)rows * cols;
+  const float sigma = detector_type == MODSX_DET_DOG ? norm : sqrtf((float)(0.6 * norm));
+  const int ntap = 2 * std::max(1, blur_ksize(sigma)) * 3 + 16;
+  if (ntap > 3 * 4096) { mx::set_error("modsx_response: blur kernel too large"); return MODSX_ERR_ARG; }
+  if (!ctx->scratchA.ensure(npx * 4 * 8) || !ctx->viewTaps.ensure((size_t)ntap * 4) || !ctx->hViewTaps.ensure((size_t)ntap * 4)) return MODSX_ERR_NOMEM;
+  float *buf = (float *)ctx->scratchA.p, *res = buf, *tmp = buf + npx, *a = buf + 2 * npx, *b = buf + 3 * npx, *cc = buf + 4 * npx;
+  float *ba = buf + 5 * npx, *bb = buf + 6 * npx, *bc = buf + 7 * npx;
+  float *dT = (float *)ctx->viewTaps.p, *hT = (float *)ctx->hViewTaps.p;
+  int rc = MODSX_OK;
+  if (detector_type == MODSX_DET_HESSIAN) {
+    BlurBatch bt;
+    memset(&bt, 0, sizeof bt);
+    bt.j[0].src = img->d; bt.j[0].resp = res; bt.j[0].rows = rows; bt.j[0].cols = cols; bt.j[0].norm = norm;
+    launch_hessian(s, bt, 1, rows, cols);
+  } else if (detector_type == MODSX_DET_DOG) {
+    rc = blur_any(ctx, img->d, a, tmp, dT, hT, rows, cols, sigma);
+    if (rc) return rc;
+    launch_sub(s, img->d, a, res, npx);
+  } else {
+    launch_grad_products(s, img->d, rows, cols, a, b, cc);
+    const int n = blur_ksize(sigma);
+    // the three blurs share the taps: separate slices of the staging buffer so no upload waits for a previous one
+    rc = blur_any(ctx, a, ba, tmp, dT, hT, rows, cols, sigma);
+    if (!rc) rc = blur_any(ctx, b, bb, tmp, dT + 2 * n + 2, hT + 2 * n + 2, rows, cols, sigma);
+    if (!rc) rc = blur_any(ctx, cc, bc, tmp, dT + 4 * n + 4, hT + 4 * n + 4, rows, cols, sigma);
+    if (rc) return rc;
+    launch_harris_combine(s, ba, bb, bc, (float)(0.6 * norm), res, npx);
+  }
+  MX_HIP(hipMemcpyAsync(out, res, npx * 4, hipMemcpyDeviceToHost, s));
+  MX_HIP(hipStreamSynchronize(s));
+  MX_HIP(hipGetLastError());
+  return MODSX_OK;
+}
+
 int modsx_resize_half(modsx_ctx *ctx, const modsx_image *img, float *out, int *orows, int *ocols) {
   NEED(ctx); NEED(img); NEED(orows); NEED(ocols);
   hipSetDevice(ctx->dev);

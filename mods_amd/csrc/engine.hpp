@@ -196,7 +196,10 @@ void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *im
                      const float *mask, const unsigned short *maskIdx, int nmask, const double *atanLut, const int *bins,
                      const double *wts, int photoNorm, int descType, double maxBin, const DescOut &outs);
 void launch_warp_affine(hipStream_t s, const WarpJob &jb);
-void launch_blur_pass(hipStream_t s, const float *src, float *dst, int rows, int cols, const float *taps, int n, int pass);
+void launch_blur_pass(hipStream_t s, const float *src, float *dst, int rows, int cols, const float *taps, int n, int pass, int border = 0);
+void launch_sub(hipStream_t s, const float *a, const float *b, float *o, size_t n);
+void launch_grad_products(hipStream_t s, const float *img, int rows, int cols, float *xx, float *yy, float *xy);
+void launch_harris_combine(hipStream_t s, const float *bxx, const float *byy, const float *bxy, float sigmasq, float *o, size_t n);
 void launch_views_warp(hipStream_t s, const ViewJob *jobs, int n, int tiles, int stage);
 void launch_views_blur(hipStream_t s, const ViewJob *jobs, int n, int tiles, const float *taps, int pass);
 size_t match_workspace_bytes(int n1, int n2);

@@ -50,7 +50,11 @@ MX_D int reflect101(int p, int n) {
 
 // one pass of a separable Gaussian with BORDER_REFLECT_101: pass 0 = rows (RowFilter / SymmRowSmallFilter order),
 // pass 1 = columns (SymmColumnFilter order)
-MX_D void blur_body(const float *src, float *dst, int rows, int cols, const float *taps, int n, int pass, int x, int y) {
+MX_D int border_idx(int p, int n, int border) {
+  if (border) return p < 0 ? 0 : (p > n - 1 ? n - 1 : p);
+  return reflect101(p, n);
+}
+MX_D void blur_body(const float *src, float *dst, int rows, int cols, const float *taps, int n, int pass, int x, int y, int border = 0) {
   if (x >= cols || y >= rows) return;
   const int R = n >> 1;
   float v;
@@ -59,21 +63,53 @@ MX_D void blur_body(const float *src, float *dst, int rows, int cols, const floa
     const float *row = src + (size_t)y * cols;
     if (n <= 5) {
       v = row[x] * taps[R];
-      for (int j = 1; j <= R; j++) v = v + (row[reflect101(x - j, cols)] + row[reflect101(x + j, cols)]) * taps[R + j];
+      for (int j = 1; j <= R; j++) v = v + (row[border_idx(x - j, cols, border)] + row[border_idx(x + j, cols, border)]) * taps[R + j];
     } else {
       v = 0.f;
-      for (int j = 0; j < n; j++) v = v + row[reflect101(x + j - R, cols)] * taps[j];
+      for (int j = 0; j < n; j++) v = v + row[border_idx(x + j - R, cols, border)] * taps[j];
     }
   } else {
     v = taps[R] * src[(size_t)y * cols + x] + 0.f;
     for (int j = 1; j <= R; j++)
-      v = v + taps[R + j] * (src[(size_t)reflect101(y + j, rows) * cols + x] + src[(size_t)reflect101(y - j, rows) * cols + x]);
+      v = v + taps[R + j] * (src[(size_t)border_idx(y + j, rows, border) * cols + x] + src[(size_t)border_idx(y - j, rows, border) * cols + x]);
   }
   dst[(size_t)y * cols + x] = v;
 }
 __global__ __launch_bounds__(256) void k_blur_pass(const float *src, float *dst, int rows, int cols, const float *taps,
-                                                   int n, int pass) {
-  blur_body(src, dst, rows, cols, taps, n, pass, blockIdx.x * 64 + (threadIdx.x & 63), blockIdx.y * 4 + (threadIdx.x >> 6));
+                                                   int n, int pass, int border) {
+  blur_body(src, dst, rows, cols, taps, n, pass, blockIdx.x * 64 + (threadIdx.x & 63), blockIdx.y * 4 + (threadIdx.x >> 6), border);
+}
+
+// ---- detector responses other than the Hessian (ScaleSpaceDetector::Response, pyramid.cpp:132-175) -------------------------
+// dogResponse (:176-181): in - blur(in).   computeGradient (helpers.cpp:779-797) + the three products of HarrisResponse
+// (:283-305).   harris_combine: dx2 = sigmasq * blur(LxLx) ..., R = (dx2 dy2 - dxdy dxdy) - (0.04f (dx2 + dy2)) (dx2 + dy2).
+__global__ __launch_bounds__(256) void k_sub(const float *a, const float *b, float *o, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) o[i] = a[i] - b[i];
+}
+__global__ __launch_bounds__(256) void k_grad_products(const float *img, int rows, int cols, float *xx, float *yy, float *xy) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (c >= cols || r >= rows) return;
+  const float *R = img + (size_t)r * cols;
+  float xg, yg;
+  if (cols == 1) xg = 0.f;
+  else if (c == 0) xg = R[c + 1] - R[c];
+  else if (c == cols - 1) xg = R[c] - R[c - 1];
+  else xg = R[c + 1] - R[c - 1];
+  if (rows == 1) yg = 0.f;
+  else if (r == 0) yg = R[cols + c] - R[c];
+  else if (r == rows - 1) yg = R[c] - R[c - cols];
+  else yg = R[cols + c] - R[c - cols];
+  const size_t i = (size_t)r * cols + c;
+  xx[i] = xg * xg; yy[i] = yg * yg; xy[i] = xg * yg;
+}
+__global__ __launch_bounds__(256) void k_harris_combine(const float *bxx, const float *byy, const float *bxy, float sigmasq, float *o, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float dx2 = bxx[i] * sigmasq, dy2 = byy[i] * sigmasq, dxdy = bxy[i] * sigmasq;
+  const float s = dx2 + dy2;
+  const float a = dx2 * dy2, b = dxdy * dxdy, c = (0.04f * s) * s;
+  o[i] = (a - b) - c;
 }
 
 // ---- batched form: all views of a launch set in four launches (warp, blur rows, blur columns, warp) ---------------------------
@@ -111,9 +147,18 @@ void launch_warp_affine(hipStream_t s, const WarpJob &jb) {
   dim3 grid((jb.dcols + 63) / 64, (jb.drows + 3) / 4);
   hipLaunchKernelGGL(k_warp_affine, grid, dim3(256), 0, s, jb);
 }
-void launch_blur_pass(hipStream_t s, const float *src, float *dst, int rows, int cols, const float *taps, int n, int pass) {
+void launch_blur_pass(hipStream_t s, const float *src, float *dst, int rows, int cols, const float *taps, int n, int pass, int border) {
   dim3 grid((cols + 63) / 64, (rows + 3) / 4);
-  hipLaunchKernelGGL(k_blur_pass, grid, dim3(256), 0, s, src, dst, rows, cols, taps, n, pass);
+  hipLaunchKernelGGL(k_blur_pass, grid, dim3(256), 0, s, src, dst, rows, cols, taps, n, pass, border);
+}
+void launch_sub(hipStream_t s, const float *a, const float *b, float *o, size_t n) {
+  hipLaunchKernelGGL(k_sub, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, o, n);
+}
+void launch_grad_products(hipStream_t s, const float *img, int rows, int cols, float *xx, float *yy, float *xy) {
+  hipLaunchKernelGGL(k_grad_products, dim3((cols + 63) / 64, (rows + 3) / 4), dim3(256), 0, s, img, rows, cols, xx, yy, xy);
+}
+void launch_harris_combine(hipStream_t s, const float *bxx, const float *byy, const float *bxy, float sigmasq, float *o, size_t n) {
+  hipLaunchKernelGGL(k_harris_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, bxx, byy, bxy, sigmasq, o, n);
 }
 void launch_views_warp(hipStream_t s, const ViewJob *jobs, int n, int tiles, int stage) {
   if (tiles > 0) hipLaunchKernelGGL(k_views_warp, dim3(tiles), dim3(256), 0, s, jobs, n, stage);

@@ -80,6 +80,7 @@ int  orc_blur_ksize(float sigma);
 void orc_gaussian_blur(const float *in, int rows, int cols, float sigma, float *out);
 void orc_resize_half(const float *in, int rows, int cols, float *out, int *orows, int *ocols);
 void orc_hessian_response(const float *in, int rows, int cols, float norm, float *out);
+void orc_response(const float *in, int rows, int cols, int detector_type, float norm, float *out);
 int  orc_interpolate(const float *im, int rows, int cols, float ofsx, float ofsy,
                      float a11, float a12, float a21, float a22, float *res, int rrows, int rcols);
 float orc_atan2lut(float y, float x);

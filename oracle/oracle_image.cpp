@@ -204,6 +204,59 @@ void hessian_response(const Img &in, float norm, Img &out) {
   out = dst;
 }
 
+/* ScaleSpaceDetector::dogResponse, affinedetectors/pyramid.cpp:176-181: input - gaussianBlur(input, norm) -- the blur
+ * sigma IS the norm argument (sigma^2 of the level at the call sites :475, :490). */
+void dog_response(const Img &in, float norm, Img &out) {
+  Img nb;
+  gaussian_blur(in, norm, nb);
+  Img dst(in.rows, in.cols);
+  for (size_t i = 0; i < dst.v.size(); i++) dst.v[i] = in.v[i] - nb.v[i];
+  out = dst;
+}
+
+/* computeGradient, detectors/helpers.cpp:779-797: central differences, one-sided at the frame */
+static void compute_gradient(const Img &img, Img &gx, Img &gy) {
+  const int width = img.cols, height = img.rows;
+  gx = Img(height, width); gy = Img(height, width);
+  for (int r = 0; r < height; r++)
+    for (int c = 0; c < width; c++) {
+      float xg, yg;
+      if (width == 1) xg = 0.f;
+      else if (c == 0) xg = img.row(r)[c + 1] - img.row(r)[c];
+      else if (c == width - 1) xg = img.row(r)[c] - img.row(r)[c - 1];
+      else xg = img.row(r)[c + 1] - img.row(r)[c - 1];
+      if (height == 1) yg = 0.f;
+      else if (r == 0) yg = img.row(r + 1)[c] - img.row(r)[c];
+      else if (r == height - 1) yg = img.row(r)[c] - img.row(r - 1)[c];
+      else yg = img.row(r + 1)[c] - img.row(r - 1)[c];
+      gx.row(r)[c] = xg; gy.row(r)[c] = yg;
+    }
+}
+
+/* ScaleSpaceDetector::HarrisResponse, affinedetectors/pyramid.cpp:283-305.  OpenCV 2.4 MatExpr arithmetic as read from the
+ * published semantics (PARITY UNPINNED like every cv:: call of the detector): Mat::mul and Mat - Mat are plain f32
+ * element operations, `sigmasq * Mat` is convertTo with the scale cast to float, `0.04 * A.mul(A)` folds the scale into
+ * multiply(): (0.04f * a) * a. */
+void harris_response(const Img &in, float norm, Img &out) {
+  const float sigmasq = (float)(0.6 * norm);
+  const float sigma = sqrtf(sigmasq);
+  Img Lx, Ly;
+  compute_gradient(in, Lx, Ly);
+  Img xx(in.rows, in.cols), yy(in.rows, in.cols), xy(in.rows, in.cols);
+  for (size_t i = 0; i < xx.v.size(); i++) { xx.v[i] = Lx.v[i] * Lx.v[i]; yy.v[i] = Ly.v[i] * Ly.v[i]; xy.v[i] = Lx.v[i] * Ly.v[i]; }
+  Img bxx, byy, bxy;
+  gaussian_blur(xx, sigma, bxx); gaussian_blur(yy, sigma, byy); gaussian_blur(xy, sigma, bxy);
+  Img dst(in.rows, in.cols);
+  const float k = 0.04f;
+  for (size_t i = 0; i < dst.v.size(); i++) {
+    const float dx2 = bxx.v[i] * sigmasq, dy2 = byy.v[i] * sigmasq, dxdy = bxy.v[i] * sigmasq;
+    const float s = dx2 + dy2;
+    const float a = dx2 * dy2, b = dxdy * dxdy, c = (k * s) * s;
+    dst.v[i] = (a - b) - c;
+  }
+  out = dst;
+}
+
 /* interpolateCheckBorders, detectors/helpers.cpp:524-549 */
 bool interpolate_check_borders(int orig_w, int orig_h, float ofsx, float ofsy, float a11, float a12,
                                float a21, float a22, int res_w, int res_h) {
@@ -339,6 +392,14 @@ void orc_resize_half(const float *in, int rows, int cols, float *out, int *orows
 void orc_hessian_response(const float *in, int rows, int cols, float norm, float *out) {
   Img a(rows, cols, in), b;
   hessian_response(a, norm, b);
+  memcpy(out, b.v.data(), b.v.size() * sizeof(float));
+}
+/* Response() of ScaleSpaceDetector for DetectorType 0 (Hessian), 1 (DoG), 2 (Harris): pyramid.cpp:132-175 */
+void orc_response(const float *in, int rows, int cols, int detector_type, float norm, float *out) {
+  Img a(rows, cols, in), b;
+  if (detector_type == 1) dog_response(a, norm, b);
+  else if (detector_type == 2) harris_response(a, norm, b);
+  else hessian_response(a, norm, b);
   memcpy(out, b.v.data(), b.v.size() * sizeof(float));
 }
 int orc_interpolate(const float *im, int rows, int cols, float ofsx, float ofsy, float a11, float a12,

@@ -151,6 +151,14 @@ def detect_scalespace(img, params, cap=400000):
     return out[:n].copy()
 
 
+def response(img, detector_type, norm):
+    """ScaleSpaceDetector::Response (pyramid.cpp:132-175): 0 Hessian, 1 DoG, 2 Harris."""
+    img = _f32(img)
+    out = np.zeros_like(img)
+    lib().orc_response(_p(img), img.shape[0], img.shape[1], int(detector_type), C.c_float(norm), _p(out))
+    return out
+
+
 def detect_hessaff(img, params, tilt=1.0, zoom=1.0, cap=400000):
     img = _f32(img)
     out = np.zeros(cap, KEYPOINT)

@@ -47,6 +47,20 @@ def test_gaussian_blur_bit_exact(ctx, oracle, shape, sigma):
     assert np.array_equal(got, oracle.gaussian_blur(img, sigma))
 
 
+@pytest.mark.parametrize("det", [0, 1, 2])
+@pytest.mark.parametrize("shape,norm", [((97, 131), 2.56), ((64, 64), 4.0637), ((33, 200), 10.24), ((240, 320), 1.0), ((5, 7), 2.56)])
+def test_detector_responses_bit_exact(ctx, oracle, det, shape, norm):
+    """ScaleSpaceDetector::Response for Hessian / DoG / Harris (pyramid.cpp:132-305) vs the oracle, every pixel (the Hessian
+    frame is written 0 on both sides).  norm = sigma^2 of a pyramid level as at the call sites (pyramid.cpp:475, 490)."""
+    rs = np.random.RandomState(det * 100 + shape[0])
+    img = np.floor(rs.uniform(0, 255, shape)).astype(np.float32)
+    im = ctx.upload(img)
+    got = ctx.response(im, det, norm)
+    im.free()
+    ref = oracle.response(img, det, norm)
+    assert np.array_equal(got, ref)
+
+
 @pytest.mark.parametrize("shape", [(96, 128), (97, 131), (75, 125), (38, 63), (13, 14)])
 def test_resize_half_bit_exact(ctx, oracle, shape):
     img = _rand_img(shape[0], shape[1], 4)
