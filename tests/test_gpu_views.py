@@ -74,6 +74,9 @@ def test_pair_views_end_to_end(ctx, modsx, oracle, small_pair):
     ia.free(); ib.free()
 
 
+CAT_CENTRE_TOL_PX, CAT_CORNER_TOL_PX = 15.0, 75.0   # transfer error of the recovered H against build/examples/cat.txt over the support of the matches
+
+
 def test_cat_pair_with_views_recovers_ground_truth(ctx, modsx, cat_pair):
     """The example pair of the reference (build/examples/cat.png, cat2.png) needs synthesised views; with the
     HessianAffine ladder of iters_mods_cviu.ini step 4 (TiltSet 1,2,4,6,8, Phi 360, initSigma 0.2) the verified
@@ -96,6 +99,18 @@ def test_cat_pair_with_views_recovers_ground_truth(ctx, modsx, cat_pair):
     err = np.linalg.norm(proj - p2, axis=1)
     # the verified correspondences obey the shipped ground-truth homography (cat.txt)
     assert np.mean(err < 10.0) > 0.8, (np.sort(err)[:10], len(err))
+    # and the recovered homography IS that mapping where it is supported by data: the corners of the bounding box of the
+    # verified points in image 1 land where cat.txt sends them (the one reference-held anchor of the whole detect ->
+    # describe -> match -> verify chain; the image corners themselves are an extrapolation of ~30 clustered matches of a
+    # non-planar scene and move by hundreds of pixels)
+    x0, y0, x1, y1 = p1[:, 0].min(), p1[:, 1].min(), p1[:, 0].max(), p1[:, 1].max()
+    cor = np.array([[x0, y0, 1], [x1, y0, 1], [x1, y1, 1], [x0, y1, 1], [(x0 + x1) / 2, (y0 + y1) / 2, 1]], float)
+    a = cor @ normH(got["H"]).T
+    b = cor @ normH(Hgt).T
+    cerr = np.linalg.norm(a[:, :2] / a[:, 2:] - b[:, :2] / b[:, 2:], axis=1)
+    print("cat support-box corners + centre vs cat.txt [px]:", np.round(cerr, 2), "box", np.round([x0, y0, x1, y1], 1))
+    # measured: corners 7 .. 53 px, centre 9.5 px (the support is a 62 x 324 px strip, so H is loosely constrained across it)
+    assert cerr[4] < CAT_CENTRE_TOL_PX and cerr[:4].max() < CAT_CORNER_TOL_PX, cerr
 
 
 def test_view_shard_path_world1_rccl(ctx, modsx, small_pair):
