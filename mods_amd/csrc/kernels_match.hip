@@ -151,6 +151,41 @@ MX_D int exact_dist(const uint8_t *a, int na, const uint8_t *b, int nb) {
   return na + nb - 2 * dot;
 }
 
+// Exact distances of one group (the 16 rows of tile `tile` that lane half `hi` of the sweeps owns) from query `qd`, by the
+// 16 lanes l = 0..15 of a quarter wave: lane l returns the distance of row row_of(l, hi).  Loads are coalesced: in step k
+// the lanes l < 8 read the eight 16-byte slices of row k, the lanes l >= 8 those of row k + 8 (two whole 128-byte rows per
+// step instead of sixteen scattered 16-byte pieces), partial dot products are summed over the eight lanes of a row.
+MX_D int group_dist16(const uint8_t *qd, int na, const uint8_t *d2, const int *norm2, int n2, int tile, int hi, int l, int *t_out) {
+  const int slice = l & 7, half = l >> 3;
+  v4i q = reinterpret_cast<const v4i *>(qd)[slice];
+  q[0] ^= 0x80808080; q[1] ^= 0x80808080; q[2] ^= 0x80808080; q[3] ^= 0x80808080;
+  int part[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int t = tile * 32 + row_of(k + 8 * half, hi);
+    v4i y = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+    if (t < n2) y = reinterpret_cast<const v4i *>(d2 + (size_t)t * 128)[slice];
+    int dot = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) dot = __builtin_amdgcn_sdot4(q[c], y[c] ^ 0x80808080, dot, false);
+    part[k] = dot;
+  }
+  // sum over the 8 lanes of a half row with three DPP adds (half-row mirror, quad reverse, quad pair swap): every lane ends
+  // with the total; integer sums, so the order is immaterial
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    part[k] += __builtin_amdgcn_update_dpp(0, part[k], 0x141, 0xf, 0xf, false);
+    part[k] += __builtin_amdgcn_update_dpp(0, part[k], 0x1B, 0xf, 0xf, false);
+    part[k] += __builtin_amdgcn_update_dpp(0, part[k], 0xB1, 0xf, 0xf, false);
+  }
+  int dot = part[0];
+#pragma unroll
+  for (int k = 1; k < 8; k++) dot = slice == k ? part[k] : dot;
+  const int t = tile * 32 + row_of(l, hi);
+  *t_out = t;
+  return t < n2 ? na + norm2[t] - 2 * dot : BIG;
+}
+
 // ---------------- staging: 4 tiles + their constants, global -> LDS directly ------------------------------------------
 typedef const unsigned char __attribute__((address_space(1))) *gbptr;
 typedef unsigned char __attribute__((address_space(3))) *lbptr;
@@ -390,9 +425,9 @@ __device__ __forceinline__ void decide_body(const uint8_t *d1, const int *norm1,
   }
   if (i0 != BIG) {
     const int tile = i0 >> 5, hi = ((i0 & 31) >> 2) & 1;
-    const int t = tile * 32 + row_of(l, hi);
-    int hd = BIG, ht = BIG;
-    if (t < g.n2 && t != i0) { hd = exact_dist(d1 + (size_t)qc * 128, norm1[qc], d2 + (size_t)t * 128, norm2[t]); ht = t; }
+    int ht;
+    int hd = group_dist16(d1 + (size_t)qc * 128, norm1[qc], d2, norm2, g.n2, tile, hi, l, &ht);
+    if (ht >= g.n2 || ht == i0) { hd = BIG; ht = BIG; }
 #pragma unroll
     for (int m = 8; m >= 1; m >>= 1) {
       const int od = __shfl_xor(hd, m), ot = __shfl_xor(ht, m);
@@ -457,24 +492,13 @@ __device__ __forceinline__ void events_body(const uint8_t *d1, const int *norm1,
   const int q = undecided[u];
   const int t0 = rows[q].t0, Dm = dmin[q], na = norm1[q];
   const double x0 = pos2[2 * t0], y0 = pos2[2 * t0 + 1];
-  v4i qv[8];                            // the query, once
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    qv[i] = reinterpret_cast<const v4i *>(d1 + (size_t)q * 128)[i];
-    qv[i][0] ^= 0x80808080; qv[i][1] ^= 0x80808080; qv[i][2] ^= 0x80808080; qv[i][3] ^= 0x80808080;
-  }
+  const uint8_t *qd = d1 + (size_t)q * 128;
   int nless = 0, nbad = 0, dj = BIG, tj = BIG;
-  auto visit = [&](int t) {
-    if (t >= g.n2 || t == t0) return;
-    const v4i *pb = reinterpret_cast<const v4i *>(d2 + (size_t)t * 128);
-    int dot = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const v4i y = pb[i];
-#pragma unroll
-      for (int c = 0; c < 4; c++) dot = __builtin_amdgcn_sdot4(qv[i][c], y[c] ^ 0x80808080, dot, false);
-    }
-    const int d = na + norm2[t] - 2 * dot;
+  // one group (tile, lane half) per quarter wave: lane l gets the exact distance of the group's row l
+  auto visit_group = [&](int tile, int hi, bool active) {
+    int t;
+    const int d = group_dist16(qd, na, d2, norm2, g.n2, active ? tile : 0, hi, l, &t);
+    if (!active || t >= g.n2 || t == t0) return;
     if (d < Dm) {
       nless++;
       // geometric consistency with NN0 (distanceSq, matching.cpp:174-179), f64
@@ -502,15 +526,16 @@ __device__ __forceinline__ void events_body(const uint8_t *d1, const int *norm1,
     nrec += __shfl(pre, 63);
   }
   nrec = min(nrec, 64);
-  for (int b = 0; b < nrec; b += 4) {
+  for (int b = 0; b < nrec; b += 4) {      // wave-uniform trip count: the quarter waves shuffle among their own lanes
     const int e = b + sub;
-    if (e < nrec) { const int rec = sRec[w][e]; visit((rec >> 1) * 32 + row_of(l, rec & 1)); }
+    const int rec = e < nrec ? sRec[w][e] : 0;
+    visit_group(rec >> 1, rec & 1, e < nrec);
   }
   if (anyOver) {
     for (int st = 0; st < nst; st++) {
       if (evCnt[(size_t)u * nst + st] <= EVCAP) continue;
       const int tb = (st >> 1) * g.tilesPerSplit, te = min(tb + g.tilesPerSplit, (g.n2 + 31) >> 5);
-      for (int tile = tb + sub; tile < te; tile += 4) visit(tile * 32 + row_of(l, st & 1));
+      for (int tile = tb; tile < te; tile += 4) visit_group(tile + sub, st & 1, tile + sub < te);
     }
   }
 #pragma unroll
