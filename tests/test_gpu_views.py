@@ -113,6 +113,27 @@ def test_cat_pair_with_views_recovers_ground_truth(ctx, modsx, cat_pair):
     assert cerr[4] < CAT_CENTRE_TOL_PX and cerr[:4].max() < CAT_CORNER_TOL_PX, cerr
 
 
+def test_match_fginn_full_size_multi_view_descriptors(ctx, modsx, oracle):
+    """The distance kernels at the north-star size: the ~24 k x 24 k descriptors of a 1024x768 pair under the 31-view ladder
+    (TiltSet 1,2,4,6,8, Phi 120) -- the same blob seen in 10-20 views, so most matched queries go through sweep 2 and the
+    event kernel -- against the oracle's exact linear kNN + FGINN walk (OpenMP over the queries), every tentative field."""
+    from mods_amd import synthetic
+    a, b, _ = synthetic.make_pair(rows=768, cols=1024, nblobs=4000, seed=12345)
+    views = modsx.set_vs_pars([1.0], [1, 2, 4, 6, 8], 120.0, 0.2, 1, [])
+    par = modsx.default_pair_params()
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    r1, d1 = ctx.detect_describe_views(ia, views, par)
+    r2, d2 = ctx.detect_describe_views(ib, views, par)
+    ia.free(); ib.free()
+    assert len(d1) > 20000 and len(d2) > 20000
+    pos2 = np.stack([r2["reproj_kp"]["x"], r2["reproj_kp"]["y"]], 1)
+    got = ctx.match_fginn(d1, d2, pos2, 0.8, 30.0)
+    ref = oracle.match_fginn(d1, d2, pos2, 0.8, 30.0)
+    assert len(ref) > 10000 and len(got) == len(ref)
+    for f in ref.dtype.names:
+        assert np.array_equal(got[f], ref[f]), f
+
+
 def test_view_shard_path_world1_rccl(ctx, modsx, small_pair):
     """The native RCCL path (csrc/engine_shard.hip) on one GPU: a world-size-1 communicator, ncclAllGather of the counts,
     the 328-byte row blocks and the matcher's result rows on device buffers -- must equal the unsharded library calls."""
