@@ -177,6 +177,38 @@ def test_match_fginn_ties_ranks_and_ragged_sizes(ctx, oracle):
     assert len(ctx.match_fginn(np.zeros((0, 128)), np.zeros((4, 128)), np.zeros((4, 2)))) == 0
 
 
+def test_match_fginn_clustered_near_duplicates_and_split_ranges(ctx, oracle):
+    """The paths of the device matcher that small real pairs do not reach: several splits of the train range (n2 > 768),
+    index chunks of 12 tiles, runs of up to 40 near-duplicate trains of one query packed into ONE (split, lane-half) stream
+    (more than the 16 event slots of a stream with fewer than nn groups in total -> the exact rescan of that stream), exact
+    distance ties across tiles and lane halves, walks that end at rank nn - 1 / nn, and a query block boundary (n1 > 256)."""
+    rs = np.random.RandomState(31)
+    for n1, n2, kmax in ((300, 2100, 40), (40, 5000, 25), (513, 1000, 12)):
+        base = rs.randint(0, 90, (n2, 128)).astype(np.float32)
+        d2 = base.copy()
+        d1 = rs.randint(0, 90, (n1, 128)).astype(np.float32)
+        pos2 = rs.uniform(0, 2000, (n2, 2))
+        for q in range(0, n1, 3):
+            k = int(rs.randint(2, kmax))
+            start = int(rs.randint(0, n2 - k))
+            near = np.clip(d1[q][None, :] + rs.randint(-2, 3, (k, 128)), 0, 255)
+            d2[start:start + k] = near                     # contiguous: same tiles, same stream
+            pos2[start:start + k] = pos2[start] + rs.uniform(-3, 3, (k, 2))
+            if q % 6 == 0:
+                d2[start + k - 1] = d2[start]               # an exact tie inside the run
+        # one near-duplicate per tile, always in the same lane half, over 20 consecutive tiles of the first split: 20 event
+        # groups in ONE stream (> 16 slots) but fewer than nn in total -> the stream is rescanned exactly
+        for q in (1, 4, 7):
+            t0 = 32 * (q % 3)
+            for j in range(20):
+                t = t0 + 32 * j + 1
+                if t < n2:
+                    d2[t] = np.clip(d1[q] + rs.randint(-2, 3, 128), 0, 255)
+                    pos2[t] = pos2[t0 + 1] + rs.uniform(-3, 3, 2)
+        for ratio, cd, nn in ((0.8, 30.0, 50), (0.9, 30.0, 20), (0.8, 2.0, 50)):
+            _check_tents(ctx.match_fginn(d1, d2, pos2, ratio, cd, nn), oracle.match_fginn(d1, d2, pos2, ratio, cd, nn))
+
+
 def test_pair_end_to_end_identical_inliers(ctx, modsx, oracle, small_pair):
     a, b, H = small_pair
     if not oracle.ref_available():
