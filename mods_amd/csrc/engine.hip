@@ -160,6 +160,7 @@ modsx_ctx *ctx_create(int device_id) {
 
 void ctx_destroy(modsx_ctx *c) {
   if (!c) return;
+  if (c->peer) { ctx_destroy(c->peer); c->peer = nullptr; }
   hipSetDevice(c->dev);
   hipStreamSynchronize(c->stream);
   for (int i = 0; i < MAXB; i++) c->pyr[i].store.release();

@@ -252,4 +252,5 @@ struct modsx_ctx {
   hipEvent_t ev[8];
   double timings[6];
   mx::Profiler prof;
+  modsx_ctx *peer = nullptr;   // second stream + buffers, created on demand: the two images of a multi-view pair run side by side
 };

@@ -9,6 +9,8 @@
 // (the shard of one GPU); the caller gathers the per-view blocks afterwards.
 #include <math.h>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include "engine_api.hpp"
 
 namespace mx {
@@ -429,14 +431,45 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
   const modsx_image *imgs[2] = {img1, img2};
   LadderClass cls[2];   // 0 = HessianAffine, 1 = MSER: the order GetCorresponcesVector("All", "All") walks the map
   for (int s = 0; s < 2; s++) { cls[0].buf[s] = &c->descAllU8[s]; cls[1].buf[s] = &c->descAllU8b[s]; }
+  static std::atomic<int> active(0);
+  struct Guard { std::atomic<int> &a; ~Guard() { a.fetch_sub(1); } } guard{active};
+  const bool alone = active.fetch_add(1) == 0;
   int cur = 0, step = 0;
   for (; step < nsteps && cur < min_matches; step++) {
     LadderClass &k = cls[steps[step].detector == MODSX_DET_MSER ? 1 : 0];
     modsx_pair_params ps = pp;
     ps.detector = steps[step].detector == MODSX_DET_MSER ? MODSX_DET_MSER : MODSX_DET_HESSIAN;
-    for (int side = 0; side < 2; side++) {
-      int rc = accumulate_views(c, k, side, imgs[side], steps[step].views, steps[step].nviews, ps);
-      if (rc) { release_result_arrays(res); return rc; }
+    {
+      // The two images are independent until the match (mods.cpp:255-271 runs them in two OpenMP threads): image 2 goes
+      // through a peer context (own stream, own scratch) on a second host thread, so the host bookkeeping of one image
+      // overlaps the kernels of the other (31 views: 42 -> 32 ms per pair).  Only when this is the one ladder running in the
+      // process: with many contexts at work the GPU is already full and the extra streams and scratch cost throughput
+      // (16 workers: 123 -> 77 pairs/s).  MODSX_PAIR_SERIAL=1 keeps one stream (measurements).
+      static const bool serialEnv = getenv("MODSX_PAIR_SERIAL") != nullptr;
+      const bool serial = serialEnv || !alone;
+      int rc0 = MODSX_OK, rc1 = MODSX_OK;
+      std::string err1;
+      if (!serial && !c->peer) c->peer = ctx_create(c->dev);
+      if (!serial && c->peer) {
+        modsx_ctx *pc = c->peer;
+        prof_reset(pc, c->prof.enabled);
+        std::thread t([&]() {
+          hipSetDevice(pc->dev);
+          rc1 = accumulate_views(pc, k, 1, imgs[1], steps[step].views, steps[step].nviews, ps);
+          if (rc1) err1 = last_error();
+        });
+        rc0 = accumulate_views(c, k, 0, imgs[0], steps[step].views, steps[step].nviews, ps);
+        t.join();
+        if (c->prof.enabled) {   // the peer's kernels belong to this call
+          prof_collect(pc);
+          for (int q = 0; q < K_NCLASS; q++) { c->prof.ms[q] += pc->prof.ms[q]; c->prof.work[q] += pc->prof.work[q]; c->prof.launches[q] += pc->prof.launches[q]; }
+        }
+        if (!rc0 && rc1) set_error(err1);
+      } else {
+        rc0 = accumulate_views(c, k, 0, imgs[0], steps[step].views, steps[step].nviews, ps);
+        if (!rc0) rc1 = accumulate_views(c, k, 1, imgs[1], steps[step].views, steps[step].nviews, ps);
+      }
+      if (rc0 || rc1) { release_result_arrays(res); return rc0 ? rc0 : rc1; }
     }
     // Tentatives.MatchImgReps (correspondencebank.cpp:291-345): clear and re-match the class of this step
     const double ratio = steps[step].match_ratio > 0 ? steps[step].match_ratio : pp.match_ratio;
