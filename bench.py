@@ -449,7 +449,14 @@ def main():
             out["cpu_baseline"] = base
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        # RCCL writes a version banner through C stdio, which would otherwise be flushed at exit, after this line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     for a_, b_ in dev:
         a_.free(); b_.free()
     if comm is not None:
