@@ -175,6 +175,17 @@ def test_match_fginn_ties_ranks_and_ragged_sizes(ctx, oracle):
         for ratio, cd in ((0.8, 30.0), (0.95, 80.0), (0.8, 5.0)):
             _check_tents(ctx.match_fginn(d1, d2, pos2, ratio, cd), oracle.match_fginn(d1, d2, pos2, ratio, cd))
     assert len(ctx.match_fginn(np.zeros((0, 128)), np.zeros((4, 128)), np.zeros((4, 2)))) == 0
+    # outside the domain the int8 path is exact on (integers 0..255), and for the branches that are not built, the call
+    # fails loudly instead of returning something else than the reference would
+    d = rs.randint(0, 255, (8, 128)).astype(np.float32)
+    p2 = rs.uniform(0, 60, (8, 2))
+    for bad in (d + 0.5, d - 300.0, np.where(np.arange(128) == 3, np.nan, d)):
+        with pytest.raises(RuntimeError):
+            ctx.match_fginn(bad.astype(np.float32), d, p2)
+    with pytest.raises(RuntimeError):
+        ctx.match_fginn(d, d, p2, ratio=1.2)          # the "PDF" branch of MatchFlannFGINN (matching.cpp:397-428)
+    with pytest.raises(RuntimeError):
+        ctx.match_fginn(d, d, p2, nn=100)
 
 
 def test_match_fginn_clustered_near_duplicates_and_split_ranges(ctx, oracle):

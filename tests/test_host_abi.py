@@ -222,6 +222,17 @@ def test_key_file_round_trip(modsx, tmp_path):
     assert ld.shape == (5, 64) and np.array_equal(ld, d2[:, :64])
     det, dn, lr, ld = modsx.load_regions(path)                     # first class of the file (maps iterate sorted)
     assert (det, dn) == ("HessianAffine", "HalfRootSIFT")
+    # malformed input is an error code, never an exception across the C boundary: a truncated file (EOF inside a record),
+    # absurd counts in the header, a missing class
+    text = open(path).read()
+    bad = str(tmp_path / "bad.txt")
+    for broken in (text[: len(text) // 2], text.replace("RootSIFT 37", "RootSIFT -5", 1), text.replace("RootSIFT 37", "RootSIFT 2000000000", 1),
+                   "999999999\n", ""):
+        open(bad, "w").write(broken)
+        with pytest.raises(RuntimeError):
+            modsx.load_regions(bad, "HessianAffine", "RootSIFT")
+    with pytest.raises(RuntimeError):
+        modsx.load_regions(path, "HessianAffine", "NoSuchDescriptor")
     with pytest.raises(RuntimeError):
         modsx.load_regions(path, "DoG", "SIFT")
     with pytest.raises(RuntimeError):
