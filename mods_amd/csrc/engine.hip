@@ -6,6 +6,7 @@
 // order-dependent bookkeeping (detection order, first-come octaveMap claims, std::sort) and the few
 // libm transcendentals (powf / cos / sin / exp) so they are evaluated by the same libm as on the CPU path.
 #include <math.h>
+#include <stdio.h>
 #include <algorithm>
 #include <chrono>
 #include <map>
@@ -539,6 +540,13 @@ int detect_keypoints_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, 
     MX_HIP(hipStreamSynchronize(s));
   } else {
     for (size_t i = 0; i < total; i++) { ho[i].u11 = 1; ho[i].u12 = 0; ho[i].u21 = 0; ho[i].u22 = 1; ho[i].ok = 1; ho[i].iters = 0; }
+  }
+  if (getenv("MODSX_DEBUG_BAUMBERG")) {   // iteration histogram of the launch (development aid)
+    long hist[2][20] = {{0}};
+    for (size_t i = 0; i < total; i++) hist[ho[i].ok ? 1 : 0][std::min(19, std::max(0, ho[i].iters))]++;
+    fprintf(stderr, "baumberg %zu keypoints; iterations (failed | converged):", total);
+    for (int q = 0; q < 18; q++) fprintf(stderr, " %d:%ld|%ld", q, hist[0][q], hist[1][q]);
+    fprintf(stderr, "\n");
   }
   k = 0;
   for (int i = 0; i < n; i++) {

@@ -13,8 +13,37 @@ namespace mx {
 
 constexpr int AW_MAX = 19;
 
+// invSqrt (kmath.hpp inv_sqrt, detectors/helpers.cpp:463-502) for a whole wavefront that holds the same (a, b, c) in every
+// lane: the two independent 1/sqrt of the rotated diagonal, and the two divisions by their geometric mean, run in lanes
+// 0 and 1 side by side instead of one after the other in every lane (f64 sqrt and division are ~25 half-rate
+// instructions each).  Every operation has the operands and the order of the scalar form.
+MX_D void inv_sqrt_wave(int lane, float &a, float &b, float &c, float &l1, float &l2) {
+  double t, r;
+  if (b != 0) {
+    r = double(c - a) / (2 * b);
+    if (r >= 0) t = 1.0 / (r + sqrt(1 + r * r));
+    else t = -1.0 / (-r + sqrt(1 + r * r));
+    r = 1.0 / sqrt(1 + t * t);
+    t = t * r;
+  } else { r = 1; t = 0; }
+  const bool odd = lane & 1;
+  // even lanes: r*r*a - 2*r*t*b + t*t*c       odd lanes: t*t*a + 2*r*t*b + r*r*c
+  const double rr = r * r, tt = t * t, m = 2 * r * t * b;
+  const double first = (odd ? tt : rr) * a, last = (odd ? rr : tt) * c;
+  double w = 1.0 / sqrt((odd ? first + m : first - m) + last);
+  double x = __shfl(w, 0), z = __shfl(w, 1);
+  const double d = sqrt(x * z);
+  w = (odd ? z : x) / d;
+  x = __shfl(w, 0); z = __shfl(w, 1);
+  if (x < z) { l1 = float(z); l2 = float(x); } else { l1 = float(x); l2 = float(z); }
+  a = float(r * r * x + t * t * z);
+  b = float(-r * t * x + t * r * z);
+  c = float(t * t * x + r * r * z);
+}
+
 // WT = window size when known at compile time (19, the default smmWindowSize), 0 = use the argument: the row / column of a
-// pixel is an integer division by W in three loops of every iteration, ~25 instructions each unless W is a constant
+// pixel is an integer division by W, done once per keypoint (the LDS offsets of a pixel's four gradient neighbours do not
+// change between iterations)
 template <int WT>
 __global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out, int n, const float *mask, int Warg,
                                                  int maxIter, float convTh, float affInitialSigma) {
@@ -23,21 +52,41 @@ __global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out
   if (k >= n) return;
   const int lane = threadIdx.x;
   // 4.4 KB of LDS per keypoint: the kernel is a chain of dependent phases per iteration (coordinates -> taps -> gradients ->
-  // 361 ordered adds -> Jacobi), so what it needs is many keypoints in flight per CU.  The window mask stays in registers
-  // (it is the same every iteration), and the sampled window shares its buffer with the third product array: the
-  // products are staged in registers and written after every lane has taken its gradients.
+  // 361 ordered adds -> Jacobi) and it is bound by vector-instruction issue (VALU busy ~90 %), so what counts is the number
+  // of instructions per iteration (~1750; it was ~2150 with per-pixel edge branches in the gradient, 64-bit tap addresses
+  // and the Jacobi step's two 1/sqrt in sequence).  The window mask and the neighbour offsets stay in registers (126 VGPRs,
+  // 4 waves per SIMD: capping the registers for more waves only adds spills and is slower), and the sampled window shares
+  // its buffer with the third product array: the products are staged in registers and written after every lane has taken
+  // its gradients.
+  // Tried and dropped: G keypoints per workgroup with the serial phases (ordered sums, Jacobi) of all G run side by side in
+  // the lanes of one wavefront -- half the instructions per keypoint, but a keypoint still owns a wavefront and 4.4 KB of
+  // LDS, so no more keypoints are in flight per CU, the group iterates in lock-step to its slowest member, and the launch
+  // was 5-25 % slower for G = 2..16.
   __shared__ __attribute__((aligned(16))) float pa[AW_MAX * AW_MAX + 3], pb[AW_MAX * AW_MAX + 3], pc[AW_MAX * AW_MAX + 3];
   float *const simg = pc;
   const AffJob jb = jobs[k];
   const int WW = W * W, half = W >> 1;
   constexpr int PERM = (AW_MAX * AW_MAX + 63) / 64;
   float vmask[PERM];
+  int pp[PERM], oxp[PERM], oxm[PERM], oyp[PERM], oym[PERM];   // pixel (clamped to the window) and its gradient neighbours
 #pragma unroll
-  for (int u = 0; u < PERM; u++) { const int i = lane + 64 * u; vmask[u] = i < WW ? mask[i] : 0.f; }
+  for (int u = 0; u < PERM; u++) {
+    const int i = lane + 64 * u;
+    vmask[u] = i < WW ? mask[i] : 0.f;
+    const int p = i < WW ? i : WW - 1;
+    const int r = p / W, c = p - r * W;
+    pp[u] = p;
+    // computeGradient (helpers.cpp:779-797): one-sided differences on the window's frame, central ones inside
+    oxp[u] = c == W - 1 ? p : p + 1;
+    oxm[u] = c == 0 ? p : p - 1;
+    oyp[u] = r == W - 1 ? p : p + W;
+    oym[u] = r == 0 ? p : p - W;
+  }
   float u11 = 1.0f, u12 = 0.0f, u21 = 0.0f, u22 = 1.0f, l1 = 1.0f, l2 = 1.0f;
   float era = 0.0f, erb = 0.0f;
   const float lx = jb.x / jb.pixelDistance, ly = jb.y / jb.pixelDistance;
   const float ratio = jb.s / (affInitialSigma * jb.pixelDistance);
+  const gcfloat_p img = as_global(jb.blur);
   int ok = 0, l = 0;
   __syncthreads();
   for (l = 0; l < maxIter; l++) {
@@ -46,18 +95,14 @@ __global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out
     // sample coordinates: lane j runs the f32 running sums of row j (helpers.cpp:563-585) into LDS,
     // then all lanes take the bilinear taps
     {
-      // row starts: ONE chain of running sums (the same for every lane, a12 / a22 are uniform), lane j keeps step j --
-      // no divergent loop; then lane j walks its row with the loop unrolled when the window size is a constant
-      float cxr = lx - (float)half * a12, cyr = ly - (float)half * a22;
-      float rx = cxr, ry = cyr;
+      // row starts: lane j takes j steps of the running sum (a12 / a22 are uniform, the loop is not divergent: a lane
+      // that has its row start sits out the remaining steps), then walks its row
+      float rx = lx - (float)half * a12, ry = ly - (float)half * a22;
       if (WT) {
 #pragma unroll
-        for (int j = 1; j < (WT ? WT : 1); j++) {
-          cxr += a12; cyr += a22;
-          if (lane == j) { rx = cxr; ry = cyr; }
-        }
+        for (int j = 1; j < (WT ? WT : 1); j++)
+          if (lane >= j) { rx += a12; ry += a22; }
       } else {
-        rx = lx - (float)half * a12; ry = ly - (float)half * a22;
         for (int j = 0; j < lane && j < W; j++) { rx += a12; ry += a22; }
       }
       if (lane < W) {
@@ -83,53 +128,33 @@ __global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out
       }
     }
     __syncthreads();
-    if (WT) {
-      // all six taps of a lane in flight together: one memory round trip per iteration instead of six
-      constexpr int PER = ((WT ? WT : 1) * (WT ? WT : 1) + 63) / 64;
-      float sv[PER];
+    {
+      // all six taps of a lane in flight together (no per-tap branch: slots past the window repeat its last pixel and
+      // are not stored): one memory round trip per iteration instead of six
+      float sv[PERM];
       if (!touch) {
 #pragma unroll
-        for (int u = 0; u < PER; u++) {
-          const int p = lane + 64 * u;
-          sv[u] = p < WW ? bilinear_tap(as_global(jb.blur), jb.rows, jb.cols, pa[p], pb[p], false) : 0.f;
-        }
+        for (int u = 0; u < PERM; u++) sv[u] = bilinear_tap(img, jb.rows, jb.cols, pa[pp[u]], pb[pp[u]], false);
       } else {
 #pragma unroll
-        for (int u = 0; u < PER; u++) {
-          const int p = lane + 64 * u;
-          sv[u] = p < WW ? bilinear_tap(as_global(jb.blur), jb.rows, jb.cols, pa[p], pb[p], true) : 0.f;
-        }
+        for (int u = 0; u < PERM; u++) sv[u] = bilinear_tap_touch_select(img, jb.rows, jb.cols, pa[pp[u]], pb[pp[u]]);
       }
 #pragma unroll
-      for (int u = 0; u < PER; u++) {
-        const int p = lane + 64 * u;
-        if (p < WW) simg[p] = sv[u];
-      }
-    } else {
-      for (int p = lane; p < WW; p += 64) simg[p] = bilinear_tap(as_global(jb.blur), jb.rows, jb.cols, pa[p], pb[p], touch);
+      for (int u = 0; u < PERM; u++)
+        if (lane + 64 * u < WW) simg[lane + 64 * u] = sv[u];
     }
     __syncthreads();
     {
       float qa[PERM], qb[PERM], qc[PERM];
 #pragma unroll
       for (int u = 0; u < PERM; u++) {
-        const int p = lane + 64 * u;
-        qa[u] = qb[u] = qc[u] = 0.f;
-        if (p < WW) {
-          const int r = p / W, c = p - r * W;
-          float gx, gy;
-          if (c == 0) gx = simg[p + 1] - simg[p];
-          else if (c == W - 1) gx = simg[p] - simg[p - 1];
-          else gx = simg[p + 1] - simg[p - 1];
-          if (r == 0) gy = simg[p + W] - simg[p];
-          else if (r == W - 1) gy = simg[p] - simg[p - W];
-          else gy = simg[p + W] - simg[p - W];
-          const float v = vmask[u];
-          const float gxy = gx * gy;
-          qa[u] = gx * gx * v;
-          qb[u] = gxy * v;
-          qc[u] = gy * gy * v;
-        }
+        const float gx = simg[oxp[u]] - simg[oxm[u]];
+        const float gy = simg[oyp[u]] - simg[oym[u]];
+        const float v = vmask[u];
+        const float gxy = gx * gy;
+        qa[u] = gx * gx * v;
+        qb[u] = gxy * v;
+        qc[u] = gy * gy * v;
       }
       __syncthreads();   // every gradient is taken: pc may replace the window
 #pragma unroll
@@ -147,10 +172,10 @@ __global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out
 #pragma unroll 6
       for (int i = 0; i < full; i++) { const float4 v = a4[i]; acc += v.x; acc += v.y; acc += v.z; acc += v.w; }
       for (int i = full * 4; i < WW; i++) acc += arr[i];
+      acc /= (float)WW;
     }
     float a = __shfl(acc, 0), b = __shfl(acc, 1), c = __shfl(acc, 2);
-    a /= (float)WW; b /= (float)WW; c /= (float)WW;
-    inv_sqrt(a, b, c, l1, l2);
+    inv_sqrt_wave(lane, a, b, c, l1, l2);
     if ((a != a) || (b != b) || (c != c)) break;
     erb = era;
     era = (float)(1.0 - (double)(l2 / l1));

@@ -127,26 +127,40 @@ MX_HD gcfloat_p as_global(const float *p) { return (gcfloat_p)p; }
 // touch = false: the (int) truncation branch; touch = true: floor + bounds branch (0 outside).
 // PT is `const float *` or, in kernels, the same pointer cast to the global address space (as_global): image pointers
 // that come out of job tables are generic to the compiler, which would otherwise emit FLAT loads for every tap.
+// Addressing: the four neighbours are read at 32-bit BYTE offsets from the (wave-uniform) image base -- one 24-bit
+// multiply, an add and a shift per tap, and the loads take the scalar base + vector offset form; the 64-bit
+// multiply-add per row pointer this replaces was a third of the instructions of a tap.  An image level is far below
+// 2^30 pixels (rows, cols < 2^24 is checked where images are created).
 template <class PT>
-MX_HD float bilinear_tap(PT im, int rows, int cols, float WX, float WY, bool touch) {
+MX_D float bilinear_blend(PT im, int cols, int x, int y, float WX, float WY) {
+  const unsigned off = (__umul24((unsigned)y, (unsigned)cols) + (unsigned)x) << 2;
+  typedef const char __attribute__((address_space(1))) *gbyte_p;
+  const PT R0 = (PT)((gbyte_p)im + off), R1 = (PT)((gbyte_p)(im + cols) + off);   // both bases are wave-uniform
+  const float wx = WX - (float)x;
+  const float I1 = wx * (R0[1] - R0[0]) + R0[0];
+  return (WY - (float)y) * (wx * (R1[1] - R1[0]) + R1[0] - I1) + I1;
+}
+template <class PT>
+MX_D float bilinear_tap(PT im, int rows, int cols, float WX, float WY, bool touch) {
   if (!touch) {
     int x = (int)WX, y = (int)WY;
     // the reference would fault on NaN / far out-of-range coordinates; keep device loads in bounds
-    x = x < 0 ? 0 : (x > cols - 2 ? cols - 2 : x);
-    y = y < 0 ? 0 : (y > rows - 2 ? rows - 2 : y);
-    const float wx = WX - (float)x;
-    const PT R0 = im + (size_t)y * cols, R1 = R0 + cols;
-    const float I1 = wx * (R0[x + 1] - R0[x]) + R0[x];
-    return (WY - (float)y) * (wx * (R1[x + 1] - R1[x]) + R1[x] - I1) + I1;
+    x = min(max(x, 0), cols - 2);
+    y = min(max(y, 0), rows - 2);
+    return bilinear_blend(im, cols, x, y, WX, WY);
   }
   const int x = (int)floorf(WX), y = (int)floorf(WY);
-  if (WX >= 0 && WY >= 0 && x < cols - 1 && y < rows - 1) {
-    const float wx = WX - (float)x;
-    const PT R0 = im + (size_t)y * cols, R1 = R0 + cols;
-    const float I1 = wx * (R0[x + 1] - R0[x]) + R0[x];
-    return (WY - (float)y) * (wx * (R1[x + 1] - R1[x]) + R1[x] - I1) + I1;
-  }
+  if (WX >= 0 && WY >= 0 && x < cols - 1 && y < rows - 1) return bilinear_blend(im, cols, x, y, WX, WY);
   return 0.f;
+}
+// the same sample without a divergent branch (all the taps of a lane can then be issued together): out-of-image
+// coordinates read a clamped address and select 0
+template <class PT>
+MX_D float bilinear_tap_touch_select(PT im, int rows, int cols, float WX, float WY) {
+  const int x = (int)floorf(WX), y = (int)floorf(WY);
+  const bool in = WX >= 0 && WY >= 0 && x < cols - 1 && y < rows - 1;
+  const float v = bilinear_blend(im, cols, in ? x : 0, in ? y : 0, WX, WY);
+  return in ? v : 0.f;
 }
 
 }  // namespace mx

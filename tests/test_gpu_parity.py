@@ -110,6 +110,22 @@ def test_affine_keypoints_bit_exact(ctx, modsx, oracle, small_pair, mode, regn):
         assert same_records(got, ref.view(modsx.KEYPOINT))
 
 
+@pytest.mark.parametrize("kw", [dict(smmWindowSize=15), dict(smmWindowSize=11, maxIterations=5), dict(maxIterations=1),
+                                dict(maxIterations=7, convergenceThreshold=0.01), dict(convergenceThreshold=0.3)])
+def test_baumberg_parameter_variants_bit_exact(ctx, modsx, oracle, small_pair, kw):
+    """AffineShape::findAffineShape (affine.cpp:26-169) away from the defaults: other second-moment windows (the
+    single-keypoint kernel), iteration caps that cut adaptation short and looser / tighter convergence (the grouped kernel's
+    lock-step exits)."""
+    img = small_pair[0]
+    im = ctx.upload(img)
+    got = ctx.detect_affine_keypoints(im, modsx.default_hessaff_params(**kw))
+    im.free()
+    ref = oracle.detect_hessaff(img, oracle.default_params(**kw))
+    assert same_records(got, ref.view(modsx.KEYPOINT))
+    if kw.get("maxIterations", 16) > 1:
+        assert len(ref) > 20
+
+
 def test_orientation_and_description_bit_exact(ctx, modsx, oracle, small_pair):
     img = small_pair[0]
     im = ctx.upload(img)
