@@ -101,9 +101,29 @@ static double now_ms() {
 static int upload_tables(modsx_ctx *c) {
   const int PS = 41;
   std::vector<float> m(PS * PS);
-  MX_HIP(hipMalloc(&c->dOriMask, PS * PS * 4));
   circular_gauss_mask(m.data(), PS, PS / 3.0f);  // EstimateDominantAnglesFunctor ctor, synth-detection.cpp:757-762
-  MX_HIP(hipMemcpy(c->dOriMask, m.data(), PS * PS * 4, hipMemcpyHostToDevice));
+  {
+    // the pixels that can vote (mask > 0; all lie inside the 1-pixel frame the gradient needs), raster order, as indices
+    // into k_orientation's 44-column patch
+    const int PSP = 44;
+    std::vector<unsigned short> idx;
+    std::vector<float> w;
+    for (int r = 1; r < PS - 1; r++)
+      for (int q = 1; q < PS - 1; q++)
+        if (m[r * PS + q] > 0) { idx.push_back((unsigned short)(r * PSP + q)); w.push_back(m[r * PS + q]); }
+    for (int r = 0; r < PS; r++)
+      for (int q = 0; q < PS; q++)
+        if ((r == 0 || q == 0 || r == PS - 1 || q == PS - 1) && m[r * PS + q] > 0) {
+          set_error("orientation mask reaches the patch frame");
+          return MODSX_ERR_ARG;
+        }
+    if ((int)idx.size() > ORI_NV) { set_error("orientation voting list exceeds ORI_NV"); return MODSX_ERR_ARG; }
+    while ((int)idx.size() < ORI_NV) { idx.push_back((unsigned short)(PSP + 1)); w.push_back(0.f); }
+    MX_HIP(hipMalloc(&c->dOriMask, ORI_NV * 4));
+    MX_HIP(hipMalloc(&c->dOriIdx, ORI_NV * 2));
+    MX_HIP(hipMemcpy(c->dOriMask, w.data(), ORI_NV * 4, hipMemcpyHostToDevice));
+    MX_HIP(hipMemcpy(c->dOriIdx, idx.data(), ORI_NV * 2, hipMemcpyHostToDevice));
+  }
   MX_HIP(hipMalloc(&c->dSiftMask, PS * PS * 4));
   circular_gauss_mask(m.data(), PS, 0);          // SIFTDescriptor ctor / DescribeRegions, siftdesc.h:87
   MX_HIP(hipMemcpy(c->dSiftMask, m.data(), PS * PS * 4, hipMemcpyHostToDevice));
@@ -172,7 +192,7 @@ void ctx_destroy(modsx_ctx *c) {
   for (int i = 0; i < MAXB; i++) { c->descF[i].release(); c->descU8[i].release(); c->viewImg[i].release(); }
   PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc, &c->hNms, &c->hMatch, &c->hViewTaps, &c->hViewJobs};
   for (PinBuf *b : pins) b->release();
-  hipFree(c->dSmmMask); hipFree(c->dOriMask); hipFree(c->dSiftMask); hipFree(c->dSiftMaskIdx); hipFree(c->dAtan); hipFree(c->dSiftBins);
+  hipFree(c->dSmmMask); hipFree(c->dOriMask); hipFree(c->dOriIdx); hipFree(c->dSiftMask); hipFree(c->dSiftMaskIdx); hipFree(c->dAtan); hipFree(c->dSiftBins);
   hipFree(c->dSiftW);
   for (int i = 0; i < 8; i++) hipEventDestroy(c->ev[i]);
   hipStreamDestroy(c->stream);
@@ -646,8 +666,8 @@ int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n
     MX_HIP(hipMemcpyAsync(c->oriJobs.p, c->hOri.p, nj * sizeof(OriJob), hipMemcpyHostToDevice, s));
     int maxA = maxAngNum == -1 ? 7 : std::min(maxAngNum, 7);
     ProfScope ps(c, K_ORIENT, (double)nj * 41 * 41 * 4);
-    launch_orientation(s, (OriJob *)c->oriJobs.p, (OriOut *)c->oriOut.p, (int)nj, (ImgRef *)c->imgRefs.p, c->dOriMask,
-                       c->dAtan, doHalfSIFT, th, maxA);
+    launch_orientation(s, (OriJob *)c->oriJobs.p, (OriOut *)c->oriOut.p, (int)nj, (ImgRef *)c->imgRefs.p, c->dOriIdx,
+                       c->dOriMask, c->dAtan, doHalfSIFT, th, maxA);
     MX_HIP(hipMemcpyAsync(hres, c->oriOut.p, nj * sizeof(OriOut), hipMemcpyDeviceToHost, s));
     MX_HIP(hipStreamSynchronize(s));
   }

@@ -181,7 +181,9 @@ constexpr int NMS_TILE_ROWS = 16;   // rows of a 64-column NMS tile (kernels_pyr
 void launch_gray(hipStream_t s, const void *src, float *dst, size_t n, int channels, int dtype);
 void launch_baumberg(hipStream_t s, const AffJob *jobs, AffOut *out, int n, const float *mask, int W, int maxIter,
                      float convTh, float affInitialSigma);
-void launch_orientation(hipStream_t s, const OriJob *jobs, OriOut *out, int n, const ImgRef *imgs, const float *orimask,
+constexpr int ORI_NV = 1280;   // entries of the orientation kernel's voting-pixel list (1245 under the mask, padded)
+void launch_orientation(hipStream_t s, const OriJob *jobs, OriOut *out, int n, const ImgRef *imgs,
+                        const unsigned short *maskIdx, const float *maskW,
                         const double *atanLut, int doHalf, double th, int maxAngles);
 void launch_trunc_u8(hipStream_t s, const float *src, uint8_t *dst, size_t n);
 void launch_blur_lds(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
@@ -242,7 +244,8 @@ struct modsx_ctx {
   // constant tables on device
   float *dSmmMask = nullptr;   // 19x19 computeGaussMask
   int smmW = 0;
-  float *dOriMask = nullptr;   // 41x41 circular mask, sigma = 41/3
+  float *dOriMask = nullptr;   // values of the 41x41 circular mask (sigma = 41/3) at the ORI_NV listed pixels
+  unsigned short *dOriIdx = nullptr;   // their index in the kernel's padded 44-column patch, raster order
   float *dSiftMask = nullptr;  // 41x41 circular mask, sigma2 = 0.9 r^2
   unsigned short *dSiftMaskIdx = nullptr;  // raster-ordered indices of the pixels with mask > 0
   int nSiftMask = 0;

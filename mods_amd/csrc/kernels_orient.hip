@@ -16,8 +16,8 @@ constexpr int PS = 41, PSP = 44;   // PSP: padded row stride so rows start 16-by
 constexpr int ORI_B = 21;          // taps of a patch row in flight per lane
 
 __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *out, int n, const ImgRef *imgs,
-                                                    const float *orimask, const double *atanLut, int doHalf,
-                                                    double th, int maxAngles) {
+                                                    const unsigned short *maskIdx, const float *maskW,
+                                                    const double *atanLut, int doHalf, double th, int maxAngles) {
   const int k = blockIdx.x;
   if (k >= n) return;
   const int lane = threadIdx.x;
@@ -77,33 +77,34 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
   }
   __syncthreads();
   const float PIf = float(M_PI);
-  // gradients -> (bin, weight) per pixel, staged in registers so that the weights can take the patch's place
-  constexpr int PER_L = (PS * PSP + 63) / 64;
+  // gradients -> (bin, weight) per pixel, staged in registers so that the weights can take the patch's place.  Only the
+  // pixels under the circular mask can vote (mask > 0: a disc of radius 20, 1245 of the 1681 pixels, all of them interior),
+  // so the wave walks the host-built raster-ordered list of those pixels (padded LDS index + mask value, padded with
+  // mask 0 to ORI_NV entries) instead of the whole 44 x 41 grid: 20 passes instead of 29 of the kernel's most expensive
+  // per-pixel code (IEEE sqrt, two IEEE divisions, the f64 look-up).
+  constexpr int PER_L = ORI_NV / 64;
   float wreg[PER_L];
   unsigned char breg[PER_L];
 #pragma unroll
   for (int q = 0; q < PER_L; q++) {
-    const int p = lane + 64 * q;
-    const int r = p / PSP, c = p - r * PSP;
+    const int e = lane + 64 * q;
+    const int p = maskIdx[e];
+    const float m = maskW[e];
+    const float xg = bufX[p + 1] - bufX[p - 1];
+    const float yg = bufX[p + PSP] - bufX[p - PSP];
+    const float mag = sqrtf(xg * xg + yg * yg);
+    const float ori = atan2lut(slut, yg, xg);
     unsigned char bin = 255;
     float w = 0.f;
-    if (p < PS * PSP && r >= 1 && r < PS - 1 && c >= 1 && c < PS - 1) {
-      const float xg = bufX[p + 1] - bufX[p - 1];
-      const float yg = bufX[p + PSP] - bufX[p - PSP];
-      const float mag = sqrtf(xg * xg + yg * yg);
-      const float ori = atan2lut(slut, yg, xg);
-      const float m = orimask[r * PS + c];
-      if (m > 0 && mag > 1.0f) {
-        bin = (unsigned char)(int)(36 * (ori / PIf + 1.0f) / 2.0f);
-        w = mag * m;
-      }
+    if (m > 0 && mag > 1.0f) {
+      bin = (unsigned char)(int)(36 * (ori / PIf + 1.0f) / 2.0f);
+      w = mag * m;
     }
     wreg[q] = w; breg[q] = bin;
   }
   __syncthreads();
-  // Only pixels inside the circular mask with a gradient above 1 vote (typically ~60 % of the 44 x 41 padded grid), so
-  // the (bin, weight) pairs are first compacted IN RASTER ORDER: pixel p = lane + 64 q, so chunk q precedes chunk q + 1
-  // and within a chunk lanes are ordered -- a ballot prefix keeps the order.
+  // Only pixels with a gradient above 1 vote, so the (bin, weight) pairs are first compacted IN RASTER ORDER: list entry
+  // e = lane + 64 q, so chunk q precedes chunk q + 1 and within a chunk lanes are ordered -- a ballot prefix keeps the order.
   int nv = 0;   // wave-uniform
 #pragma unroll
   for (int q = 0; q < PER_L; q++) {
@@ -116,9 +117,10 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
   if (lane < 4) { bufX[nv + lane] = 0.f; sbin[nv + lane] = 255; }   // pad the last group of four
   __syncthreads();
   // lane b owns histogram bin b and adds its pixels in raster order (f32 running sum of the reference).  This loop is the
-  // kernel's largest stage and is bound by VALU issue, so a vote is two vector instructions: v_cmpx narrows EXEC to the
-  // one lane whose bin matches, the add then only happens there (bins 36..63 and the 255 of padding never match), and
-  // EXEC is reopened by a scalar move.  All 64 lanes of the workgroup's single wavefront are active here.
+  // kernel's largest stage and is bound by VALU issue, so a vote is ONE vector instruction: the four bins of a group are
+  // wave-uniform (every lane reads the same LDS word), so they go to a scalar register once per group and the scalar unit
+  // -- which issues beside the vector unit -- opens EXEC for exactly lane `bin` (s_bfe + s_lshl of 1) before each add.
+  // The 255 of padding selects lane 63, whose sum is never read.  All 64 lanes of the single wavefront are active here.
   {
     float h = 0.f;
     const unsigned *b4 = reinterpret_cast<const unsigned *>(sbin);
@@ -126,24 +128,26 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
     const int ng = (nv + 3) >> 2;
 #pragma unroll 4
     for (int g = 0; g < ng; g++) {
-      const unsigned b = b4[g];
+      const unsigned b = __builtin_amdgcn_readfirstlane(b4[g]);
       const float4 w = w4[g];
+      unsigned t;
       asm volatile(
-          "v_cmpx_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+          "s_bfe_u32 %1, %2, 0x60000\n\t"
+          "s_lshl_b64 exec, 1, %1\n\t"
           "v_add_f32_e32 %0, %0, %3\n\t"
-          "s_mov_b64 exec, -1\n\t"
-          "v_cmpx_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+          "s_bfe_u32 %1, %2, 0x60008\n\t"
+          "s_lshl_b64 exec, 1, %1\n\t"
           "v_add_f32_e32 %0, %0, %4\n\t"
-          "s_mov_b64 exec, -1\n\t"
-          "v_cmpx_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+          "s_bfe_u32 %1, %2, 0x60010\n\t"
+          "s_lshl_b64 exec, 1, %1\n\t"
           "v_add_f32_e32 %0, %0, %5\n\t"
-          "s_mov_b64 exec, -1\n\t"
-          "v_cmpx_eq_u32_sdwa vcc, %1, %2 src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+          "s_bfe_u32 %1, %2, 0x60018\n\t"
+          "s_lshl_b64 exec, 1, %1\n\t"
           "v_add_f32_e32 %0, %0, %6\n\t"
           "s_mov_b64 exec, -1"
-          : "+v"(h)
-          : "v"(b), "v"(lane), "v"(w.x), "v"(w.y), "v"(w.z), "v"(w.w)
-          : "vcc");
+          : "+v"(h), "=&s"(t)
+          : "s"(b), "v"(w.x), "v"(w.y), "v"(w.z), "v"(w.w)
+          : "scc");
     }
     if (lane < 36) hist[lane] = h;
   }
@@ -180,9 +184,10 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
 }
 
 void launch_orientation(hipStream_t s, const OriJob *jobs, OriOut *out, int n, const ImgRef *imgs,
-                          const float *orimask, const double *atanLut, int doHalf, double th, int maxAngles) {
+                          const unsigned short *maskIdx, const float *maskW, const double *atanLut, int doHalf, double th,
+                          int maxAngles) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_orientation, dim3(n), dim3(64), 0, s, jobs, out, n, imgs, orimask, atanLut, doHalf, th,
+  hipLaunchKernelGGL(k_orientation, dim3(n), dim3(64), 0, s, jobs, out, n, imgs, maskIdx, maskW, atanLut, doHalf, th,
                      maxAngles);
 }
 
