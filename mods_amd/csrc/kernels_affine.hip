@@ -61,7 +61,10 @@ __global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out
   // Tried and dropped: G keypoints per workgroup with the serial phases (ordered sums, Jacobi) of all G run side by side in
   // the lanes of one wavefront -- half the instructions per keypoint, but a keypoint still owns a wavefront and 4.4 KB of
   // LDS, so no more keypoints are in flight per CU, the group iterates in lock-step to its slowest member, and the launch
-  // was 5-25 % slower for G = 2..16.
+  // was 5-25 % slower for G = 2..16.  Likewise two or three keypoint slots per wavefront (parallel phases one after the
+  // other, serial phases side by side in lanes 0-5, finished slots refilled from the wavefront's chunk of the job list):
+  // 17 % fewer vector instructions, bit-exact, but the same time in the pipeline's launches (343 vs 348 us) -- with 4 waves
+  // per SIMD the dependent 361-add chains bound the launch, not the issue slots they leave free.
   __shared__ __attribute__((aligned(16))) float pa[AW_MAX * AW_MAX + 3], pb[AW_MAX * AW_MAX + 3], pc[AW_MAX * AW_MAX + 3];
   float *const simg = pc;
   const AffJob jb = jobs[k];
