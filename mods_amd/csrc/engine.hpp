@@ -115,6 +115,7 @@ struct ViewJob {
   int srows, scols, rrows, rcols, drows, dcols;
   int kx, ky, tapOfs, doBlur;
   int tileA, tileB;   // first 64 x 4 tile of this view in the rotated-image / output-image tile lists
+  int tileF, fused;   // fused rotate + blur: first VF_TW x VF_TH tile of this view (views with a blur whose halo fits)
   double R[6], W[6];  // inverse maps of the two cv::warpAffine calls (f64, inverted on the host)
 };
 
@@ -204,6 +205,8 @@ void launch_grad_products(hipStream_t s, const float *img, int rows, int cols, f
 void launch_harris_combine(hipStream_t s, const float *bxx, const float *byy, const float *bxy, float sigmasq, float *o, size_t n);
 void launch_views_warp(hipStream_t s, const ViewJob *jobs, int n, int tiles, int stage);
 void launch_views_blur(hipStream_t s, const ViewJob *jobs, int n, int tiles, const float *taps, int pass);
+constexpr int VF_TW = 128, VF_TH = 16, VF_RX = 32, VF_RY = 2;   // tile of the fused rotate + blur kernel and the largest halo it takes
+void launch_views_rotblur(hipStream_t s, const ViewJob *jobs, int n, int tiles, const float *taps, int maxRx, int maxRy);
 size_t match_workspace_bytes(int n1, int n2);
 void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2,
                   double sqminratio, double contrDistSq, int nn, MatchRow *rows, void *workspace);

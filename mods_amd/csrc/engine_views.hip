@@ -176,7 +176,7 @@ static int synth_views_batch(modsx_ctx *c, const modsx_image *gray, const ViewPl
   std::vector<ViewJob> jobs;
   std::vector<float> taps;
   size_t rotFloats = 0;
-  int tilesA = 0, tilesB = 0;
+  int tilesA = 0, tilesB = 0, tilesF = 0, maxRx = 0, maxRy = 0;
   double wpx = 0, rpx = 0;
   for (int i = 0; i < n; i++) {
     if (P[i].identity) continue;
@@ -188,8 +188,14 @@ static int synth_views_batch(modsx_ctx *c, const modsx_image *gray, const ViewPl
     j.doBlur = P[i].doBlur; j.kx = P[i].kx; j.ky = P[i].ky; j.tapOfs = (int)taps.size();
     taps.insert(taps.end(), P[i].taps.begin(), P[i].taps.end());
     for (int q = 0; q < 6; q++) { j.R[q] = P[i].Rinv[q]; j.W[q] = P[i].Winv[q]; }
-    j.tileA = tilesA; j.tileB = tilesB;
-    tilesA += ((j.rcols + 63) / 64) * ((j.rrows + 3) / 4);
+    j.tileA = tilesA; j.tileB = tilesB; j.tileF = tilesF;
+    // rotate + blur in one launch when the halo of the two filters fits the fused kernel's tile (every default view does)
+    j.fused = j.doBlur && (j.kx >> 1) <= VF_RX && (j.ky >> 1) <= VF_RY;
+    if (j.fused) {
+      tilesF += ((j.rcols + VF_TW - 1) / VF_TW) * ((j.rrows + VF_TH - 1) / VF_TH);
+      maxRx = std::max(maxRx, j.kx >> 1); maxRy = std::max(maxRy, j.ky >> 1);
+    } else
+      tilesA += ((j.rcols + 63) / 64) * ((j.rrows + 3) / 4);
     tilesB += ((j.dcols + 63) / 64) * ((j.drows + 3) / 4);
     j.rot = (float *)(uintptr_t)rotFloats;            // offsets first; the bases are added once the buffers exist
     rotFloats += (size_t)j.rrows * j.rcols;
@@ -218,6 +224,7 @@ static int synth_views_batch(modsx_ctx *c, const modsx_image *gray, const ViewPl
   launch_views_warp(s, dj, (int)jobs.size(), tilesA, 0);
   prof_end(c, pslot);
   prof_begin(c, K_VIEW_BLUR, rpx * 16, &pslot);
+  launch_views_rotblur(s, dj, (int)jobs.size(), tilesF, dt, maxRx, maxRy);
   launch_views_blur(s, dj, (int)jobs.size(), tilesA, dt, 0);
   launch_views_blur(s, dj, (int)jobs.size(), tilesA, dt, 1);
   prof_end(c, pslot);

@@ -9,34 +9,49 @@
 
 namespace mx {
 
-MX_D void warp_body(const WarpJob &jb, int x, int y) {
-  if (x >= jb.dcols || y >= jb.drows) return;
+// cv::warpAffine's fixed-point inverse map: adelta / bdelta depend on x only, X0 / Y0 on y only (OpenCV tabulates the
+// former per column and forms the latter per row)
+MX_D void warp_xterm(const double *M, int x, int &adelta, int &bdelta) {
   const int AB_SCALE = 1024;
-  const int adelta = (int)rint(jb.M[0] * x * AB_SCALE), bdelta = (int)rint(jb.M[3] * x * AB_SCALE);
-  const int X0 = (int)rint((jb.M[1] * y + jb.M[2]) * AB_SCALE) + 16;
-  const int Y0 = (int)rint((jb.M[4] * y + jb.M[5]) * AB_SCALE) + 16;
+  adelta = (int)rint(M[0] * x * AB_SCALE); bdelta = (int)rint(M[3] * x * AB_SCALE);
+}
+MX_D void warp_yterm(const double *M, int y, int &X0, int &Y0) {
+  const int AB_SCALE = 1024;
+  X0 = (int)rint((M[1] * y + M[2]) * AB_SCALE) + 16;
+  Y0 = (int)rint((M[4] * y + M[5]) * AB_SCALE) + 16;
+}
+MX_D float warp_fetch(const float *src, int sh, int sw, float cval, int adelta, int bdelta, int X0, int Y0) {
   const int X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
   int sx = X >> 5, sy = Y >> 5;
   sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx);
   sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
   const float fx = (float)(X & 31) * (1.f / 32), fy = (float)(Y & 31) * (1.f / 32);
   const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
-  const int sw = jb.scols, sh = jb.srows;
   float out;
   if (sx >= 0 && sx < sw - 1 && sy >= 0 && sy < sh - 1) {
-    const float *S = jb.src + (size_t)sy * sw + sx;
+    const float *S = src + (size_t)sy * sw + sx;
     out = S[0] * w0 + S[1] * w1 + S[sw] * w2 + S[sw + 1] * w3;
   } else if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) {
-    out = jb.cval;
+    out = cval;
   } else {
     const bool x0 = sx >= 0 && sx < sw, x1 = sx + 1 >= 0 && sx + 1 < sw, y0 = sy >= 0 && sy < sh, y1 = sy + 1 >= 0 && sy + 1 < sh;
-    const float v0 = (x0 && y0) ? jb.src[(size_t)sy * sw + sx] : jb.cval;
-    const float v1 = (x1 && y0) ? jb.src[(size_t)sy * sw + sx + 1] : jb.cval;
-    const float v2 = (x0 && y1) ? jb.src[(size_t)(sy + 1) * sw + sx] : jb.cval;
-    const float v3 = (x1 && y1) ? jb.src[(size_t)(sy + 1) * sw + sx + 1] : jb.cval;
+    const float v0 = (x0 && y0) ? src[(size_t)sy * sw + sx] : cval;
+    const float v1 = (x1 && y0) ? src[(size_t)sy * sw + sx + 1] : cval;
+    const float v2 = (x0 && y1) ? src[(size_t)(sy + 1) * sw + sx] : cval;
+    const float v3 = (x1 && y1) ? src[(size_t)(sy + 1) * sw + sx + 1] : cval;
     out = v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
   }
-  jb.dst[(size_t)y * jb.dcols + x] = out;
+  return out;
+}
+MX_D float warp_value(const float *src, int sh, int sw, const double *M, float cval, int x, int y) {
+  int ad, bd, X0, Y0;
+  warp_xterm(M, x, ad, bd);
+  warp_yterm(M, y, X0, Y0);
+  return warp_fetch(src, sh, sw, cval, ad, bd, X0, Y0);
+}
+MX_D void warp_body(const WarpJob &jb, int x, int y) {
+  if (x >= jb.dcols || y >= jb.drows) return;
+  jb.dst[(size_t)y * jb.dcols + x] = warp_value(jb.src, jb.srows, jb.scols, jb.M, jb.cval, x, y);
 }
 __global__ __launch_bounds__(256) void k_warp_affine(WarpJob jb) {
   warp_body(jb, blockIdx.x * 64 + (threadIdx.x & 63), blockIdx.y * 4 + (threadIdx.x >> 6));
@@ -117,7 +132,7 @@ __global__ __launch_bounds__(256) void k_harris_combine(const float *bxx, const 
 // per pair.  Every block takes one 64 x 4 tile of one view; the view is found from the tile prefix carried by the jobs.
 MX_D int find_view(const ViewJob *jobs, int n, int tile, int stage) {
   int j = 0;
-  while (j + 1 < n && tile >= (stage ? jobs[j + 1].tileB : jobs[j + 1].tileA)) j++;
+  while (j + 1 < n && tile >= (stage == 2 ? jobs[j + 1].tileF : (stage ? jobs[j + 1].tileB : jobs[j + 1].tileA))) j++;
   return j;
 }
 __global__ __launch_bounds__(256) void k_views_warp(const ViewJob *jobs, int n, int stage) {
@@ -143,6 +158,74 @@ __global__ __launch_bounds__(256) void k_views_blur(const ViewJob *jobs, int n, 
             (t / tx) * 4 + (threadIdx.x >> 6));
 }
 
+// Rotate + anti-alias blur of a view in ONE launch.  The three-launch form writes the rotated image, reads it for the row
+// filter, writes the row-filtered image, reads it for the column filter and writes the result over the rotated image: four
+// passes over 1-2 Mpx per view, 16-31 views per image, in kernels that wait on memory.  Here a workgroup owns a
+// VF_TW x VF_TH tile of the blurred rotated image: it evaluates cv::warpAffine at the tile's pixels plus the halo the two
+// filters reach (BORDER_REFLECT_101 of the ROTATED image: a halo pixel outside it is the rotation evaluated at the mirrored
+// coordinate, the value the separate launches read back), filters the rows of all TH + 2 Ry lines in LDS, then the columns,
+// and stores the tile.  Every value is the same f32 the separate launches pass through memory; sums, terms and order are
+// those of blur_body.
+__global__ __launch_bounds__(256) void k_views_rotblur(const ViewJob *jobs, int n, const float *taps, int wFloats) {
+  extern __shared__ float smem[];
+  const int j = find_view(jobs, n, blockIdx.x, 2);
+  const ViewJob &v = jobs[j];
+  const int Rx = v.kx >> 1, Ry = v.ky >> 1;
+  const int t = blockIdx.x - v.tileF, tx = (v.rcols + VF_TW - 1) / VF_TW;
+  const int x0 = (t % tx) * VF_TW, y0 = (t / tx) * VF_TH;
+  const int WW = VF_TW + 2 * Rx, HH = VF_TH + 2 * Ry;
+  float *const Wt = smem, *const Tt = smem + wFloats;
+  const int lane = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int xEnd = min(VF_TW, v.rcols - x0) + 2 * Rx, yEnd = min(VF_TH, v.rrows - y0) + 2 * Ry;   // what the tile's outputs reach
+  {
+    constexpr int NX = (VF_TW + 2 * VF_RX + 63) / 64;   // columns of the haloed tile per lane
+    int ad[NX], bd[NX];
+#pragma unroll
+    for (int u = 0; u < NX; u++) warp_xterm(v.R, reflect101(x0 - Rx + lane + 64 * u, v.rcols), ad[u], bd[u]);
+    for (int ly = ty; ly < yEnd; ly += 4) {
+      int X0, Y0;
+      warp_yterm(v.R, reflect101(y0 - Ry + ly, v.rrows), X0, Y0);
+#pragma unroll
+      for (int u = 0; u < NX; u++) {
+        const int lx = lane + 64 * u;
+        if (lx < xEnd) Wt[ly * WW + lx] = warp_fetch(v.src, v.srows, v.scols, 128.f, ad[u], bd[u], X0, Y0);
+      }
+    }
+  }
+  __syncthreads();
+  const float *kxT = taps + v.tapOfs, *kyT = kxT + v.kx;
+  const int nx = v.kx, ny = v.ky, xOut = xEnd - 2 * Rx, yOut = yEnd - 2 * Ry;
+  for (int ly = ty; ly < yEnd; ly += 4) {
+    const float *row = Wt + ly * WW + Rx;
+    for (int lx = lane; lx < xOut; lx += 64) {
+      float r;
+      if (nx == 1) r = row[lx];
+      else if (nx <= 5) {
+        r = row[lx] * kxT[Rx];
+        for (int q = 1; q <= Rx; q++) r = r + (row[lx - q] + row[lx + q]) * kxT[Rx + q];
+      } else {
+        r = 0.f;
+        for (int q = 0; q < nx; q++) r = r + row[lx + q - Rx] * kxT[q];
+      }
+      Tt[ly * VF_TW + lx] = r;
+    }
+  }
+  __syncthreads();
+  for (int ly = ty; ly < yOut; ly += 4) {
+    const float *col = Tt + (ly + Ry) * VF_TW;
+    float *out = v.rot + (size_t)(y0 + ly) * v.rcols + x0;
+    for (int lx = lane; lx < xOut; lx += 64) {
+      float r;
+      if (ny == 1) r = col[lx];
+      else {
+        r = kyT[Ry] * col[lx] + 0.f;
+        for (int q = 1; q <= Ry; q++) r = r + kyT[Ry + q] * (col[lx + q * VF_TW] + col[lx - q * VF_TW]);
+      }
+      out[lx] = r;
+    }
+  }
+}
+
 void launch_warp_affine(hipStream_t s, const WarpJob &jb) {
   dim3 grid((jb.dcols + 63) / 64, (jb.drows + 3) / 4);
   hipLaunchKernelGGL(k_warp_affine, grid, dim3(256), 0, s, jb);
@@ -165,6 +248,11 @@ void launch_views_warp(hipStream_t s, const ViewJob *jobs, int n, int tiles, int
 }
 void launch_views_blur(hipStream_t s, const ViewJob *jobs, int n, int tiles, const float *taps, int pass) {
   if (tiles > 0) hipLaunchKernelGGL(k_views_blur, dim3(tiles), dim3(256), 0, s, jobs, n, taps, pass);
+}
+void launch_views_rotblur(hipStream_t s, const ViewJob *jobs, int n, int tiles, const float *taps, int maxRx, int maxRy) {
+  if (tiles <= 0) return;
+  const int wFloats = (VF_TH + 2 * maxRy) * (VF_TW + 2 * maxRx), tFloats = (VF_TH + 2 * maxRy) * VF_TW;
+  hipLaunchKernelGGL(k_views_rotblur, dim3(tiles), dim3(256), (size_t)(wFloats + tFloats) * 4, s, jobs, n, taps, wFloats);
 }
 
 }  // namespace mx
