@@ -174,6 +174,7 @@ modsx_ctx *ctx_create(int device_id) {
   c->dev = device_id;
   if (hipStreamCreate(&c->stream) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
   for (int i = 0; i < 8; i++) hipEventCreate(&c->ev[i]);
+  for (int i = 0; i < 2; i++) hipEventCreateWithFlags(&c->descEv[i], hipEventDisableTiming);
   for (int i = 0; i < 6; i++) c->timings[i] = 0;
   if (upload_tables(c) != MODSX_OK) { delete c; return nullptr; }
   return c;
@@ -195,6 +196,8 @@ void ctx_destroy(modsx_ctx *c) {
   hipFree(c->dSmmMask); hipFree(c->dOriMask); hipFree(c->dOriIdx); hipFree(c->dSiftMask); hipFree(c->dSiftMaskIdx); hipFree(c->dAtan); hipFree(c->dSiftBins);
   hipFree(c->dSiftW);
   for (int i = 0; i < 8; i++) hipEventDestroy(c->ev[i]);
+  for (int i = 0; i < 2; i++) hipEventDestroy(c->descEv[i]);
+  c->hDescB.release();
   hipStreamDestroy(c->stream);
   delete c;
 }
@@ -440,24 +443,54 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
     MX_HIP(hipMemcpyAsync(c->hCand.p, c->cand.p, (size_t)cnt * sizeof(Candidate), hipMemcpyDeviceToHost, s));
     MX_HIP(hipStreamSynchronize(s));
   }
-  Candidate *cd = (Candidate *)c->hCand.p;
-  // the reference visits (octave, level, row, col) in this order (pyramid.cpp:438-451, 490-498, 564-571)
-  std::sort(cd, cd + cnt, [](const Candidate &a, const Candidate &b) {
-    if (a.img != b.img) return a.img < b.img;
-    if (a.octave != b.octave) return a.octave < b.octave;
-    if (a.level != b.level) return a.level < b.level;
-    if (a.r0 != b.r0) return a.r0 < b.r0;
-    return a.c0 < b.c0;
-  });
-  const SigmaPlan sp = make_sigma_plan(p);
-  for (int i = 0; i < n; i++) out[i].clear();
-  std::unordered_set<unsigned long long> claimed;  // octaveMap(r,c) per (image, octave), pyramid.cpp:414-418
-  claimed.reserve(cnt * 2 + 16);
+  const Candidate *cd = (const Candidate *)c->hCand.p;
+  // the reference visits (octave, level, row, col) in this order (pyramid.cpp:438-451, 490-498, 564-571): an LSD radix sort
+  // of one 64-bit key per candidate (the comparison sort of the 48-byte records was 2/3 of the host time of a launch set)
+  std::vector<uint64_t> &keys = c->candKeys, &keys2 = c->candKeys2;
+  std::vector<uint32_t> &order = c->candOrder, &order2 = c->candOrder2;
+  keys.resize(cnt); keys2.resize(cnt); order.resize(cnt); order2.resize(cnt);
   for (unsigned k = 0; k < cnt; k++) {
     const Candidate &q = cd[k];
-    unsigned long long key = ((unsigned long long)q.img << 58) | ((unsigned long long)q.octave << 52) |
-                             ((unsigned long long)q.r << 26) | (unsigned long long)q.c;
-    if (!claimed.insert(key).second) continue;
+    if ((unsigned)q.img >= 64u || (unsigned)q.octave >= 32u || (unsigned)q.level >= 32u || (unsigned)q.r0 >= (1u << 24) ||
+        (unsigned)q.c0 >= (1u << 24) || (unsigned)q.r >= (1u << 24) || (unsigned)q.c >= (1u << 24)) {
+      set_error("candidate outside the sort key's range");
+      return MODSX_ERR_DEVICE;
+    }
+    keys[k] = ((uint64_t)q.img << 58) | ((uint64_t)q.octave << 53) | ((uint64_t)q.level << 48) | ((uint64_t)q.r0 << 24) | (uint64_t)q.c0;
+    order[k] = k;
+  }
+  {
+    constexpr int BITS = 11, NB = 1 << BITS;
+    uint32_t hist[NB];
+    for (int shift = 0; shift < 64; shift += BITS) {
+      memset(hist, 0, sizeof hist);
+      for (unsigned k = 0; k < cnt; k++) hist[(keys[k] >> shift) & (NB - 1)]++;
+      if (cnt && hist[(keys[0] >> shift) & (NB - 1)] == cnt) continue;   // this digit is the same in every key
+      uint32_t sum = 0;
+      for (int b = 0; b < NB; b++) { const uint32_t h = hist[b]; hist[b] = sum; sum += h; }
+      for (unsigned k = 0; k < cnt; k++) {
+        const uint32_t d = hist[(keys[k] >> shift) & (NB - 1)]++;
+        keys2[d] = keys[k]; order2[d] = order[k];
+      }
+      keys.swap(keys2); order.swap(order2);
+    }
+  }
+  const SigmaPlan sp = make_sigma_plan(p);
+  for (int i = 0; i < n; i++) out[i].clear();
+  // octaveMap(r,c) per (image, octave), pyramid.cpp:414-418: the first candidate in detection order that lands on a pixel
+  // claims it.  Open addressing over a power-of-two table (key + 1, 0 = empty).
+  size_t tabSize = 64;
+  while (tabSize < (size_t)cnt * 2 + 16) tabSize <<= 1;
+  std::vector<uint64_t> &claimed = c->candClaim;
+  claimed.assign(tabSize, 0);
+  for (unsigned kk = 0; kk < cnt; kk++) {
+    const Candidate &q = cd[order[kk]];
+    const uint64_t key = (((uint64_t)q.img << 53) | ((uint64_t)q.octave << 48) | ((uint64_t)q.r << 24) | (uint64_t)q.c) + 1;
+    size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & (tabSize - 1);
+    bool taken = false;
+    while (claimed[h]) { if (claimed[h] == key) { taken = true; break; } h = (h + 1) & (tabSize - 1); }
+    if (taken) continue;
+    claimed[h] = key;
     const float pixelDistance = c->pyr[q.img].oct[q.octave].pixelDistance;
     const float curScale = sp.curSigma[q.level];
     float scale = curScale * powf(2.0f, q.b2 / p.numberOfScales);
@@ -561,13 +594,6 @@ int detect_keypoints_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, 
   } else {
     for (size_t i = 0; i < total; i++) { ho[i].u11 = 1; ho[i].u12 = 0; ho[i].u21 = 0; ho[i].u22 = 1; ho[i].ok = 1; ho[i].iters = 0; }
   }
-  if (getenv("MODSX_DEBUG_BAUMBERG")) {   // iteration histogram of the launch (development aid)
-    long hist[2][20] = {{0}};
-    for (size_t i = 0; i < total; i++) hist[ho[i].ok ? 1 : 0][std::min(19, std::max(0, ho[i].iters))]++;
-    fprintf(stderr, "baumberg %zu keypoints; iterations (failed | converged):", total);
-    for (int q = 0; q < 18; q++) fprintf(stderr, " %d:%ld|%ld", q, hist[0][q], hist[1][q]);
-    fprintf(stderr, "\n");
-  }
   k = 0;
   for (int i = 0; i < n; i++) {
     for (const modsx_sskp &q : ss[i]) {
@@ -627,12 +653,16 @@ int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n
   double mrScale = (double)mrSize;
   int patchImageSize = 2 * int(mrScale) + 1;
   double imageToPatchScale = double(patchImageSize) / (double)patchSize;
-  struct Ref { int img, idx; };
-  std::vector<Ref> refs;
   std::vector<OriJob> jobs;
   std::vector<char> passed[MAXB];
+  {
+    size_t tot = 0;
+    for (int i = 0; i < n; i++) tot += in[i].size();
+    jobs.reserve(tot);
+  }
   for (int i = 0; i < n; i++) {
     passed[i].assign(in[i].size(), 0);
+    out[i].reserve(in[i].size() + in[i].size() / 4);
     for (size_t r = 0; r < in[i].size(); r++) {
       const modsx_keypoint &k = in[i][r].det_kp;
       if (check_borders_host(imgs[i]->cols, imgs[i]->rows, (float)k.x, (float)k.y, (float)k.a11, (float)k.a12,
@@ -646,7 +676,6 @@ int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n
         j.a11 = (float)k.a11 * curr_sc; j.a12 = (float)k.a12 * curr_sc;
         j.a21 = (float)k.a21 * curr_sc; j.a22 = (float)k.a22 * curr_sc;
         jobs.push_back(j);
-        refs.push_back({i, (int)r});
       }
     }
   }
@@ -755,7 +784,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
   }
   // the regions of all images of the batch go through one launch set per chunk (a chunk ends when the window arena is
   // full); region order inside an image is kept, outIdx addresses the image's own descriptor buffer
-  int curImg = 0;
+  int curImg = 0, chunkNo = 0;
   size_t curReg = 0;
   while (curImg < n && regs[curImg].empty()) curImg++;
   while (curImg < n) {
@@ -884,13 +913,37 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       // Launch order of the chunk: by image, then by 64-pixel row band, then by x.  The sampling kernel hands every XCD one
       // contiguous eighth of this order (kernels_describe.hip: xcd_chunk), i.e. one part of the images; outIdx keeps every
       // descriptor at its region's place, so the reference's list order is untouched.
-      std::sort(jobs.begin(), jobs.end(), [](const DescJob &a, const DescJob &b) {
-        if (a.img != b.img) return a.img < b.img;
-        const int ya = (int)a.y >> 6, yb = (int)b.y >> 6;
-        if (ya != yb) return ya < yb;
-        if (a.x != b.x) return a.x < b.x;
-        return a.outIdx < b.outIdx;
-      });
+      // (a stable LSD radix sort of one key per job: jobs are generated in (image, outIdx) order, which breaks the ties)
+      {
+        std::vector<uint64_t> key(nj), key2(nj);
+        std::vector<uint32_t> ord(nj), ord2(nj);
+        for (size_t q = 0; q < nj; q++) {
+          const DescJob &a = jobs[q];
+          uint32_t xb;
+          memcpy(&xb, &a.x, 4);
+          xb = (xb & 0x80000000u) ? ~xb : (xb | 0x80000000u);             // f32 -> order-preserving u32
+          const uint32_t band = (uint32_t)(((int)a.y >> 6) + (1 << 20)) & 0x3fffffu;
+          key[q] = ((uint64_t)(uint32_t)a.img << 54) | ((uint64_t)band << 32) | xb;
+          ord[q] = (uint32_t)q;
+        }
+        constexpr int BITS = 11, NB = 1 << BITS;
+        uint32_t hist[NB];
+        for (int shift = 0; shift < 64; shift += BITS) {
+          memset(hist, 0, sizeof hist);
+          for (size_t q = 0; q < nj; q++) hist[(key[q] >> shift) & (NB - 1)]++;
+          if (nj && hist[(key[0] >> shift) & (NB - 1)] == nj) continue;
+          uint32_t sum = 0;
+          for (int b = 0; b < NB; b++) { const uint32_t h = hist[b]; hist[b] = sum; sum += h; }
+          for (size_t q = 0; q < nj; q++) {
+            const uint32_t d = hist[(key[q] >> shift) & (NB - 1)]++;
+            key2[d] = key[q]; ord2[d] = ord[q];
+          }
+          key.swap(key2); ord.swap(ord2);
+        }
+        std::vector<DescJob> sorted(nj);
+        for (size_t q = 0; q < nj; q++) sorted[q] = jobs[ord[q]];
+        jobs.swap(sorted);
+      }
       arenaA = 0;
       for (DescJob &j : jobs) {
         if (j.P > 0) {
@@ -910,7 +963,11 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       const size_t oJobs = 0, oPfx = up16(nj * sizeof(DescJob)), pfxB = up16((nj + 1) * 4);
       const size_t oTaps = oPfx + 5 * pfxB, oNeed = oTaps + up16(taps.size() * 4), oCoord = oNeed + up16(needTab.size() * 4);
       const size_t blobB = oCoord + up16(coordTab.size() * 4) + 16;
-      if (!c->descJobs.ensure(blobB) || !c->hDesc.ensure(blobB) ||
+      // two staging blobs in turn: the copy of chunk k may still be in flight while chunk k + 1 is being prepared
+      const int slot = chunkNo & 1;
+      PinBuf &hblob = slot ? c->hDescB : c->hDesc;
+      if (c->descEvPending[slot]) { MX_HIP(hipEventSynchronize(c->descEv[slot])); c->descEvPending[slot] = false; }
+      if (!c->descJobs.ensure(blobB) || !hblob.ensure(blobB) ||
           !c->scratchA.ensure(std::max<size_t>(1, arenaA) * 4) || !c->scratchB.ensure(std::max<size_t>(1, arenaB) * 4) ||
           !c->scratchC.ensure(std::max<size_t>(1, arenaC) * 4) ||
           !c->tileJob.ensure(((size_t)pfxSample.back() + pfxRow.back() + pfxCol.back() + 3) * 4))
@@ -918,7 +975,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       int *tjS = (int *)c->tileJob.p, *tjR = tjS + pfxSample.back(), *tjC = tjR + pfxRow.back();
       if (!c->blurTiles.ensure(((size_t)pfxRowL.back() + pfxColL.back() + 1) * sizeof(BlurTile))) return MODSX_ERR_NOMEM;
       BlurTile *btR = (BlurTile *)c->blurTiles.p, *btC = btR + pfxRowL.back();
-      char *hb = (char *)c->hDesc.p, *db = (char *)c->descJobs.p;
+      char *hb = (char *)hblob.p, *db = (char *)c->descJobs.p;
       memcpy(hb + oJobs, jobs.data(), nj * sizeof(DescJob));
       const std::vector<int> *pf[5] = {&pfxSample, &pfxRow, &pfxCol, &pfxRowL, &pfxColL};
       for (int q = 0; q < 5; q++) memcpy(hb + oPfx + q * pfxB, pf[q]->data(), (nj + 1) * 4);
@@ -926,6 +983,8 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       if (!needTab.empty()) memcpy(hb + oNeed, needTab.data(), needTab.size() * 4);
       if (!coordTab.empty()) memcpy(hb + oCoord, coordTab.data(), coordTab.size() * 4);
       MX_HIP(hipMemcpyAsync(db, hb, blobB, hipMemcpyHostToDevice, s));
+      MX_HIP(hipEventRecord(c->descEv[slot], s));
+      c->descEvPending[slot] = true;
       int *dPfxS = (int *)(db + oPfx), *dPfxR = (int *)(db + oPfx + pfxB), *dPfxC = (int *)(db + oPfx + 2 * pfxB);
       int *dPfxRL = (int *)(db + oPfx + 3 * pfxB), *dPfxCL = (int *)(db + oPfx + 4 * pfxB);
       float *dTaps = (float *)(db + oTaps), *dCoord = (float *)(db + oCoord);
@@ -953,9 +1012,11 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       launch_describe(s, dj, (int)nj, (ImgRef *)c->imgRefs.p, (float *)c->scratchC.p, dNeed, dCoord,
                       c->dSiftMask, c->dSiftMaskIdx, c->nSiftMask, c->dAtan,
                       c->dSiftBins, c->dSiftW, photoNorm, descType, maxBin, outs);
-      MX_HIP(hipStreamSynchronize(s));  // the pinned blob is reused by the next chunk
+      chunkNo++;
     }
   }
+  MX_HIP(hipStreamSynchronize(s));   // callers read the descriptor buffers and reuse the staging blobs
+  c->descEvPending[0] = c->descEvPending[1] = false;
   if (descHost) {
     bool any = false;
     for (int i = 0; i < n; i++)

@@ -243,10 +243,15 @@ struct modsx_ctx {
   mx::Pyramid pyr[mx::MAXB];
   mx::DevBuf nmsJobs, cand, counter, affJobs, affOut, oriJobs, oriOut, descJobs, tilePrefix, taps, imgRefs, scratchA, scratchB,
       descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], descAllU8b[2], pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps, viewJobs, viewImg[mx::MAXB], scratchC, needTab, coordTab, tileJob, blurTiles, nmsQueue;
+  mx::PinBuf hDescB;           // second staging blob of describe_batch: chunk k + 1 is prepared while chunk k runs
+  hipEvent_t descEv[2];
+  bool descEvPending[2] = {false, false};
   mx::PinBuf hCand, hAff, hOri, hDesc, hMisc, hNms, hMatch, hViewTaps, hViewJobs;
   // constant tables on device
   float *dSmmMask = nullptr;   // 19x19 computeGaussMask
   int smmW = 0;
+  std::vector<uint64_t> candKeys, candKeys2, candClaim;   // detection-order sort + octaveMap claim scratch (host)
+  std::vector<uint32_t> candOrder, candOrder2;
   float *dOriMask = nullptr;   // values of the 41x41 circular mask (sigma = 41/3) at the ORI_NV listed pixels
   unsigned short *dOriIdx = nullptr;   // their index in the kernel's padded 44-column patch, raster order
   float *dSiftMask = nullptr;  // 41x41 circular mask, sigma2 = 0.9 r^2

@@ -296,7 +296,12 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
       tilts[i] = ident[i] ? 1.0 : fabs(v.tilt);   // SynthImage::tilt / zoom as GenerateSynthImageCorr leaves them
       zooms[i] = ident[i] ? 1.0 : v.zoom;
     }
+    auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const bool tim = getenv("MODSX_HOST_TIMING") != nullptr;
+    double t0 = tnow();
     if (!rc) rc = synth_views_batch(c, gray, plans, vdst, n);
+    if (tim) hipStreamSynchronize(c->stream);
+    double t1 = tnow();
     std::vector<modsx_keypoint> kps[MAXB];
     std::vector<modsx_region> r0[MAXB], ro[MAXB];
     if (!rc) {
@@ -315,6 +320,7 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
         }
       } else rc = detect_keypoints_batch(c, cimg, n, pp.det, tilts, zooms, kps);
     }
+    double t2 = tnow(), t3 = t2, t4 = t2;
     if (!rc) {
       const int detType = pp.detector == MODSX_DET_MSER ? MODSX_DET_MSER : MODSX_DET_HESSIAN;
       for (int i = 0; i < n; i++) {
@@ -324,6 +330,7 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
       rc = detect_orientation_batch(c, cimg, n, r0, pp.ori_mrSize, pp.ori_patchSize, 0, pp.ori_maxAngles, pp.ori_threshold,
                                     0, ro);
     }
+    t3 = tnow();
     if (!rc) {
       float *dF[MAXB];
       uint8_t *dU[MAXB];
@@ -354,6 +361,8 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
         hipStreamSynchronize(c->stream);
       }
     }
+    t4 = tnow();
+    if (tim) fprintf(stderr, "set of %d views: synth %.2f detect %.2f orient %.2f describe %.2f ms\n", n, t1 - t0, t2 - t1, t3 - t2, t4 - t3);
     for (int i = 0; i < n; i++)
       if (vimg[i]) { if (vimg[i]->owned && vimg[i]->d) hipFree(vimg[i]->d); delete vimg[i]; }
     if (rc) return rc;
