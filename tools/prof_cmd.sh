@@ -10,3 +10,4 @@ DB=$(find /tmp/rpc_$tag -name "*.db" | head -1)
 python $R/tools/rocprof_summary.py $DB $R/gpurun_out/prof/cmd_$tag.txt "$*" > /dev/null
 echo "== $tag: $(grep -v rocprofv3 /tmp/rpc_$tag.log | tail -1 | cut -c1-100)"
 grep -h "$filt" $R/gpurun_out/prof/cmd_$tag.txt
+[ -n "$TIMELINE" ] && python $R/tools/rocprof_timeline.py $DB $TIMELINE > $R/gpurun_out/prof/timeline_$tag.txt
