@@ -873,6 +873,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
                 for (int a = 0; a + 1 < pi.NC; a += 2) pairs = pairs && need[a + 1] == need[a] + 1;
                 pi.rows0 = pairs ? std::min(cap, BLUR_LDS / (P + 2 * R)) : 0;
                 if (pi.rows0 < 2) pi.rows0 = 0;
+                if (pi.rows0 > 32 && pi.rows0 < 48) pi.rows0 = 32;   // the fused sampling kernel parks 16 columns x <= 32 rows or 8 x <= 64
                 pi.ro1 = 0;
                 const int LS = pi.NC <= 64 ? 64 : 96;   // LDS row stride of the column filter
                 for (int ro = std::min(capC, pi.NC); ro >= 2 && !pi.ro1 && pi.NC <= 96; ro--) {
@@ -944,13 +945,17 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
         for (size_t q = 0; q < nj; q++) sorted[q] = jobs[ord[q]];
         jobs.swap(sorted);
       }
-      arenaA = 0;
+      const size_t windowFloats = arenaA;   // all P x P windows of the chunk: its size limit and its algorithmic bytes
+      arenaA = 0;                           // arena A itself only holds the windows that do not take the fused kernel
       for (DescJob &j : jobs) {
         if (j.P > 0) {
           j.scratchOfs = arenaA; j.rowOfs = arenaB; j.gridOfs = arenaC;
-          arenaA += (size_t)j.P * j.P; arenaB += (size_t)j.P * j.NC; arenaC += (size_t)j.NC * j.NC;
+          if (!j.rows0) arenaA += (size_t)j.P * j.P;
+          arenaB += (size_t)j.P * j.NC; arenaC += (size_t)j.NC * j.NC;
         }
-        pfxSample.push_back(pfxSample.back() + (j.P > 0 ? ((j.P + 63) / 64) * ((j.P + 127) / 128) : 0));  // 64 x SAMPLE_COLS tiles
+        // windows whose row tile fits LDS are sampled by the fused sample + row-filter kernel (arena A is not touched); the
+        // others go through k_patch_sample (64 x SAMPLE_COLS tiles) and the global-memory row filter
+        pfxSample.push_back(pfxSample.back() + (j.P > 0 && !j.rows0 ? ((j.P + 63) / 64) * ((j.P + 127) / 128) : 0));
         // the blur passes: LDS kernels where a tile fits, k_patch_blur (BLUR_TILE outputs per workgroup) otherwise
         pfxRowL.push_back(pfxRowL.back() + (j.P > 0 && j.rows0 ? (j.P + j.rows0 - 1) / j.rows0 : 0));
         pfxColL.push_back(pfxColL.back() + (j.P > 0 && j.ro1 ? (j.NC + j.ro1 - 1) / j.ro1 : 0));
@@ -996,11 +1001,10 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       // algorithmic work of the describe STAGE per SURVEY section 8(d): the (P+2)^2 f32 window of every region read once
       // (booked here) + 128 B written per region (booked on k_describe); the arenas between the four kernels are an
       // artefact of the split and are not algorithmic bytes
-      { ProfScope ps(c, K_PATCH_SAMPLE, (double)arenaA * 4);
+      { ProfScope ps(c, K_PATCH_SAMPLE, (double)windowFloats * 4);
+        launch_sample_rows(s, dj, dPfxRL, (int)nj, btR, pfxRowL.back(), (ImgRef *)c->imgRefs.p, dTaps, dNeed, (float *)c->scratchB.p);
         launch_patch_sample(s, dj, dPfxS, tjS, pfxSample.back(), (ImgRef *)c->imgRefs.p, (float *)c->scratchA.p); }
       { ProfScope ps(c, K_BLUR_ROWS, 0.0);
-        launch_blur_lds(s, dj, dPfxRL, (int)nj, btR, pfxRowL.back(), dTaps, dNeed, (float *)c->scratchA.p,
-                        (float *)c->scratchB.p, 0);
         launch_patch_blur(s, dj, dPfxR, tjR, pfxRow.back(), dTaps, dNeed, (float *)c->scratchA.p,
                           (float *)c->scratchB.p, 0); }
       { ProfScope ps(c, K_BLUR_COLS, 0.0);

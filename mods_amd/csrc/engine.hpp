@@ -93,6 +93,7 @@ struct DescJob {
 struct BlurTile {     // one workgroup of the LDS blur kernels
   unsigned long long srcOfs, dstOfs;   // float offsets: first input row / first output of the tile
   int P, NC, n, tapOfs, needOfs;
+  int job, pad;                        // index of the tile's DescJob (the fused sample + row-filter kernel reads its affine frame)
   int first, count, lo, span, magic;  // rows pass: window rows [first, first+count); columns pass: needed rows, parked source rows [lo, lo+span); magic = ceil(2^20 / ceil(NC / 2))
 };
 struct ImgRef { const float *d; int rows, cols, pad; };
@@ -187,6 +188,8 @@ void launch_orientation(hipStream_t s, const OriJob *jobs, OriOut *out, int n, c
                         const unsigned short *maskIdx, const float *maskW,
                         const double *atanLut, int doHalf, double th, int maxAngles);
 void launch_trunc_u8(hipStream_t s, const float *src, uint8_t *dst, size_t n);
+void launch_sample_rows(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
+                        const ImgRef *imgs, const float *taps, const int *needTab, float *dst);
 void launch_blur_lds(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
                      const float *taps, const int *needTab, const float *src, float *dst, int pass);
 void launch_expand_tiles(hipStream_t s, const int *prefix, int nJobs, int *tileJob);

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(64) void k_expand_blur_tiles(const DescJob *jobs, c
   for (int t = b + threadIdx.x; t < e; t += 64) {
     BlurTile bt;
     bt.P = jb.P; bt.NC = jb.NC; bt.n = jb.ksize; bt.tapOfs = jb.tapOfs; bt.needOfs = jb.needOfs;
+    bt.job = j; bt.pad = 0;
     { const int NP = (jb.NC + 1) >> 1; bt.magic = ((1 << 20) + NP - 1) / NP; }
     if (pass == 0) {
       const int r0 = (t - b) * jb.rows0;
@@ -283,36 +284,10 @@ constexpr int BLUR_T = 256, BLUR_W = BLUR_T / 64;   // threads / waves per workg
 constexpr int BLUR_LDS = 4992, BLUR_OUT = 2048, FILL_MLP = 20;   // row filter: 20 KB, 8 workgroups per CU
 constexpr int BLUR_LDS_C = 9984;                               // column filter: fatter tiles re-read fewer halo rows
 
-__global__ __launch_bounds__(BLUR_T, 8) void k_blur_rows_lds(const BlurTile *__restrict__ tiles, const float *__restrict__ taps,
-                                                       const int *__restrict__ needTab, const float *__restrict__ src,
-                                                       float *__restrict__ dst) {
-  const BlurTile bt = tiles[xcd_swizzle(blockIdx.x, gridDim.x)];
-  const int P = bt.P, NC = bt.NC;
-  const int n = bt.n, R = n >> 1, RW = P + 2 * R;
-  __shared__ float win[BLUR_LDS + 2];   // + 2: the idle partner of an odd last column reads one word past its row
-  __shared__ int sneed[96];
-  const int nr = bt.count;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < NC; i += BLUR_T) sneed[i] = needTab[bt.needOfs + i];
-  const float *A = src + bt.srcOfs;
-  // a wave parks rows wave, wave + 4, ... with direct global -> LDS loads (global_load_lds_dword: per-lane source address,
-  // destination = a wave-uniform LDS base + 4 * lane): no staging registers, no LDS write pass, and all of a tile's loads
-  // are in flight together
-  {
-    typedef const float __attribute__((address_space(1))) *gptr;
-    typedef float __attribute__((address_space(3))) *lptr;
-    for (int ri = wave; ri < nr; ri += BLUR_W) {
-      const float *a = A + (size_t)ri * P;
-      for (int x0 = 0; x0 < RW; x0 += 64) {
-        const int x = x0 + lane;
-        int cc = x - R;
-        cc = cc < 0 ? 0 : (cc > P - 1 ? P - 1 : cc);
-        if (x < RW) __builtin_amdgcn_global_load_lds((gptr)(a + cc), (lptr)(win + ri * RW + x0), 4, 0, 0);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
+// the row filter proper, on a tile parked in LDS as nr rows of R + P + R floats (replicated border written out)
+__device__ __forceinline__ void blur_rows_from_lds(const BlurTile &bt, const float *win, const int *sneed, const float *__restrict__ taps,
+                                                   float *__restrict__ dst) {
+  const int NC = bt.NC, n = bt.n, R = n >> 1, RW = bt.P + 2 * R, nr = bt.count;
   // A thread forms 4 PAIRS of horizontally adjacent outputs (needed columns 2m, 2m+1 -- the host checks that such pairs are
   // neighbours in the window, which the x0 / x0+1 construction gives): both members of a pair take tap j from adjacent LDS
   // words, so a tap of a pair is one 2-word read, one packed multiply and one packed add.
@@ -368,6 +343,140 @@ __global__ __launch_bounds__(BLUR_T, 8) void k_blur_rows_lds(const BlurTile *__r
       }
     }
   }
+}
+
+__global__ __launch_bounds__(BLUR_T, 8) void k_blur_rows_lds(const BlurTile *__restrict__ tiles, const float *__restrict__ taps,
+                                                       const int *__restrict__ needTab, const float *__restrict__ src,
+                                                       float *__restrict__ dst) {
+  const BlurTile bt = tiles[xcd_swizzle(blockIdx.x, gridDim.x)];
+  const int P = bt.P, NC = bt.NC;
+  const int n = bt.n, R = n >> 1, RW = P + 2 * R;
+  __shared__ float win[BLUR_LDS + 2];   // + 2: the idle partner of an odd last column reads one word past its row
+  __shared__ int sneed[96];
+  const int nr = bt.count;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < NC; i += BLUR_T) sneed[i] = needTab[bt.needOfs + i];
+  const float *A = src + bt.srcOfs;
+  // a wave parks rows wave, wave + 4, ... with direct global -> LDS loads (global_load_lds_dword: per-lane source address,
+  // destination = a wave-uniform LDS base + 4 * lane): no staging registers, no LDS write pass, and all of a tile's loads
+  // are in flight together
+  {
+    typedef const float __attribute__((address_space(1))) *gptr;
+    typedef float __attribute__((address_space(3))) *lptr;
+    for (int ri = wave; ri < nr; ri += BLUR_W) {
+      const float *a = A + (size_t)ri * P;
+      for (int x0 = 0; x0 < RW; x0 += 64) {
+        const int x = x0 + lane;
+        int cc = x - R;
+        cc = cc < 0 ? 0 : (cc > P - 1 ? P - 1 : cc);
+        if (x < RW) __builtin_amdgcn_global_load_lds((gptr)(a + cc), (lptr)(win + ri * RW + x0), 4, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  blur_rows_from_lds(bt, win, sneed, taps, dst);
+}
+
+// Stage 1 + the row pass of stage 2 in one launch: a workgroup SAMPLES its tile of window rows (interpolate(), the f32
+// running-sum coordinates of k_patch_sample) straight into the LDS tile of the row filter and filters it there, so the
+// P x P window never exists in HBM (arena A was written once and read once per region: 2 x 4 P^2 bytes, the largest
+// traffic item of the describe stage).  Lane j of a wave walks row j of the tile over the wave's QUARTER of the columns
+// (its coordinates start with col0 dependent adds, as for the column tiles of k_patch_sample) and parks SR_C columns at a
+// time; the taps are then taken with the lanes running along the rows.  Coordinates, taps, filter sums: term for term those
+// of k_patch_sample + k_blur_rows_lds.
+// A wave parks C columns of up to 64 rows at a time in its 64 x 9 words of coordinates: C = 8 for tiles of more than 32 rows,
+// C = 16 for tiles of up to 32 rows (the host keeps row tiles out of the 33..48 range), so that a lane has 8 samples --
+// 16 loads -- in flight either way.
+constexpr int SR_WORDS = 64 * 9;
+
+template <bool TOUCH, int C>
+__device__ __forceinline__ void sample_chunk_lds(const ImgRef &im, const float *cx, const float *cy, float *dst, int RW, int tot, int nc,
+                                                 int lane) {
+  constexpr int CP = C + 1, PER = 8;   // tot <= 64 * PER
+  float v[PER];
+#pragma unroll
+  for (int u = 0; u < PER; u++) {
+    const int e = lane + 64 * u, r = e / C, c = e - r * C;
+    v[u] = (e < tot && c < nc) ? bilinear_tap(as_global(im.d), im.rows, im.cols, cx[r * CP + c], cy[r * CP + c], TOUCH) : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < PER; u++) {
+    const int e = lane + 64 * u, r = e / C, c = e - r * C;
+    if (e < tot && c < nc) dst[r * RW + c] = v[u];
+  }
+}
+
+template <int C>
+__device__ __forceinline__ void sample_rows_tile(const BlurTile &bt, const DescJob &jb, const ImgRef &im, float *win, float *cx, float *cy,
+                                                 int lane, int wave) {
+  constexpr int CP = C + 1, RG = C == 8 ? 64 : 32;   // rows per pass of the wave
+  const int P = bt.P, R = bt.n >> 1, RW = P + 2 * R, nr = bt.count, r0 = bt.first;
+  const int half = P >> 1;
+  const bool touch = check_borders(im.cols, im.rows, jb.x, jb.y, jb.a11, jb.a12, jb.a21, jb.a22, P, P);
+  const int cper = (P + BLUR_W - 1) / BLUR_W, cb = wave * cper, ce = (cb + cper) < P ? (cb + cper) : P;
+  for (int rb = 0; rb < nr; rb += RG) {
+    const bool active = lane < RG && rb + lane < nr;
+    const int row = r0 + rb + lane;
+    float rx = jb.x - (float)half * jb.a12;
+    float ry = jb.y - (float)half * jb.a22;
+    const int nsteps = active ? row : 0;
+    for (int j = 0; j < nsteps; j++) { rx += jb.a12; ry += jb.a22; }
+    float WX = rx - (float)half * jb.a11;
+    float WY = ry - (float)half * jb.a21;
+    for (int i = 0; i < cb; i++) { WX += jb.a11; WY += jb.a21; }
+    const int rowsHere = (nr - rb) < RG ? (nr - rb) : RG;
+    for (int c0 = cb; c0 < ce; c0 += C) {
+      const int nc = (ce - c0) < C ? (ce - c0) : C;
+      if (active) {
+#pragma unroll
+        for (int i = 0; i < C; i++) {
+          if (i < nc) {
+            cx[lane * CP + i] = WX;
+            cy[lane * CP + i] = WY;
+            WX += jb.a11;
+            WY += jb.a21;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float *d = win + rb * RW + R + c0;
+      if (!touch) sample_chunk_lds<false, C>(im, cx, cy, d, RW, rowsHere * C, nc, lane);
+      else sample_chunk_lds<true, C>(im, cx, cy, d, RW, rowsHere * C, nc, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLUR_T, 4) void k_sample_rows_lds(const BlurTile *__restrict__ tiles, const DescJob *__restrict__ jobs,
+                                                         const ImgRef *__restrict__ imgs, const float *__restrict__ taps,
+                                                         const int *__restrict__ needTab, float *__restrict__ dst, int nTiles) {
+  const int ti = xcd_chunk(blockIdx.x, nTiles);   // tiles follow the (image, row band, x) order of the jobs: one part of the images per XCD
+  if (ti >= nTiles) return;
+  const BlurTile bt = tiles[ti];
+  const DescJob jb = jobs[bt.job];
+  const int P = bt.P, NC = bt.NC;
+  const int n = bt.n, R = n >> 1, RW = P + 2 * R;
+  __shared__ float win[BLUR_LDS + 2];
+  __shared__ int sneed[96];
+  __shared__ float cxs[BLUR_W][SR_WORDS], cys[BLUR_W][SR_WORDS];
+  const int nr = bt.count;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < NC; i += BLUR_T) sneed[i] = needTab[bt.needOfs + i];
+  const ImgRef im = imgs[jb.img];
+  if (nr <= 32) sample_rows_tile<16>(bt, jb, im, win, cxs[wave], cys[wave], lane, wave);
+  else sample_rows_tile<8>(bt, jb, im, win, cxs[wave], cys[wave], lane, wave);
+  __syncthreads();
+  // replicated border: R copies of the first and of the last sample of every row
+  for (int i = threadIdx.x; i < nr * 2 * R; i += BLUR_T) {
+    const int ri = i / (2 * R), k = i - ri * 2 * R;
+    float *rowp = win + ri * RW;
+    if (k < R) rowp[k] = rowp[R];
+    else rowp[P + k] = rowp[R + P - 1];
+  }
+  __syncthreads();
+  blur_rows_from_lds(bt, win, sneed, taps, dst);
 }
 
 template <int LS>   // LDS row stride (floats), a compile-time constant so that tap j of a column is an immediate offset
@@ -774,6 +883,12 @@ void launch_patch_sample(hipStream_t s, const DescJob *jobs, const int *tilePref
                          const ImgRef *imgs, float *scratch) {
   if (nTiles <= 0) return;
   hipLaunchKernelGGL(k_patch_sample, dim3(8 * ((nTiles + 7) / 8)), dim3(64), 0, s, jobs, tilePrefix, tileJob, imgs, scratch, nTiles);
+}
+void launch_sample_rows(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
+                        const ImgRef *imgs, const float *taps, const int *needTab, float *dst) {
+  if (nTiles <= 0) return;
+  hipLaunchKernelGGL(k_expand_blur_tiles, dim3(nJobs), dim3(64), 0, s, jobs, tilePrefix, nJobs, needTab, tiles, 0);
+  hipLaunchKernelGGL(k_sample_rows_lds, dim3(8 * ((nTiles + 7) / 8)), dim3(BLUR_T), 0, s, tiles, jobs, imgs, taps, needTab, dst, nTiles);
 }
 void launch_blur_lds(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
                      const float *taps, const int *needTab, const float *src, float *dst, int pass) {
