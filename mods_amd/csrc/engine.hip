@@ -188,7 +188,7 @@ void ctx_destroy(modsx_ctx *c) {
   for (int i = 0; i < MAXB; i++) c->pyr[i].store.release();
   DevBuf *bufs[] = {&c->nmsJobs, &c->cand, &c->counter, &c->affJobs, &c->affOut, &c->oriJobs, &c->oriOut, &c->descJobs, &c->tilePrefix,
                     &c->taps, &c->imgRefs, &c->scratchA, &c->scratchB, &c->descAllF[0], &c->descAllF[1], &c->descAllU8[0],
-                    &c->descAllU8[1], &c->descAllU8b[0], &c->descAllU8b[1], &c->pos2, &c->matchRows, &c->matchWork, &c->misc, &c->scratchC, &c->needTab, &c->coordTab, &c->tileJob, &c->blurTiles, &c->nmsQueue, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps, &c->viewJobs};
+                    &c->descAllU8[1], &c->descAllU8b[0], &c->descAllU8b[1], &c->pos2, &c->matchRows, &c->matchWork, &c->misc, &c->scratchC, &c->needTab, &c->coordTab, &c->tileJob, &c->blurTiles, &c->nmsQueue, &c->rowStarts, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps, &c->viewJobs};
   for (DevBuf *b : bufs) b->release();
   for (int i = 0; i < MAXB; i++) { c->descF[i].release(); c->descU8[i].release(); c->viewImg[i].release(); }
   PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc, &c->hNms, &c->hMatch, &c->hViewTaps, &c->hViewJobs};
@@ -947,10 +947,12 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       }
       const size_t windowFloats = arenaA;   // all P x P windows of the chunk: its size limit and its algorithmic bytes
       arenaA = 0;                           // arena A itself only holds the windows that do not take the fused kernel
+      size_t rowStarts = 0;                 // the fused ones get their P row starts (float2) instead
       for (DescJob &j : jobs) {
         if (j.P > 0) {
-          j.scratchOfs = arenaA; j.rowOfs = arenaB; j.gridOfs = arenaC;
-          if (!j.rows0) arenaA += (size_t)j.P * j.P;
+          j.rowOfs = arenaB; j.gridOfs = arenaC;
+          if (!j.rows0) { j.scratchOfs = arenaA; arenaA += (size_t)j.P * j.P; }
+          else { j.scratchOfs = rowStarts; rowStarts += (size_t)j.P; }
           arenaB += (size_t)j.P * j.NC; arenaC += (size_t)j.NC * j.NC;
         }
         // windows whose row tile fits LDS are sampled by the fused sample + row-filter kernel (arena A is not touched); the
@@ -974,7 +976,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       if (c->descEvPending[slot]) { MX_HIP(hipEventSynchronize(c->descEv[slot])); c->descEvPending[slot] = false; }
       if (!c->descJobs.ensure(blobB) || !hblob.ensure(blobB) ||
           !c->scratchA.ensure(std::max<size_t>(1, arenaA) * 4) || !c->scratchB.ensure(std::max<size_t>(1, arenaB) * 4) ||
-          !c->scratchC.ensure(std::max<size_t>(1, arenaC) * 4) ||
+          !c->scratchC.ensure(std::max<size_t>(1, arenaC) * 4) || !c->rowStarts.ensure(std::max<size_t>(1, rowStarts) * 8) ||
           !c->tileJob.ensure(((size_t)pfxSample.back() + pfxRow.back() + pfxCol.back() + 3) * 4))
         return MODSX_ERR_NOMEM;
       int *tjS = (int *)c->tileJob.p, *tjR = tjS + pfxSample.back(), *tjC = tjR + pfxRow.back();
@@ -1002,7 +1004,8 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       // (booked here) + 128 B written per region (booked on k_describe); the arenas between the four kernels are an
       // artefact of the split and are not algorithmic bytes
       { ProfScope ps(c, K_PATCH_SAMPLE, (double)windowFloats * 4);
-        launch_sample_rows(s, dj, dPfxRL, (int)nj, btR, pfxRowL.back(), (ImgRef *)c->imgRefs.p, dTaps, dNeed, (float *)c->scratchB.p);
+        launch_sample_rows(s, dj, dPfxRL, (int)nj, btR, pfxRowL.back(), (ImgRef *)c->imgRefs.p, dTaps, dNeed, (float *)c->scratchB.p,
+                           (float2 *)c->rowStarts.p);
         launch_patch_sample(s, dj, dPfxS, tjS, pfxSample.back(), (ImgRef *)c->imgRefs.p, (float *)c->scratchA.p); }
       { ProfScope ps(c, K_BLUR_ROWS, 0.0);
         launch_patch_blur(s, dj, dPfxR, tjR, pfxRow.back(), dTaps, dNeed, (float *)c->scratchA.p,

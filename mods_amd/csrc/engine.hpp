@@ -86,7 +86,8 @@ struct DescJob {
   int outIdx;         // index of the region in its image's descriptor buffers
   int rows0;          // window rows per workgroup of the LDS row filter, 0 = this job goes through k_patch_blur
   int ro1;            // needed rows per workgroup of the LDS column filter, 0 = k_patch_blur
-  unsigned long long scratchOfs;    // float offset of this region's P x P window (arena A)
+  unsigned long long scratchOfs;    // float offset of this region's P x P window (arena A); for windows that take the fused
+                                    // sample + row-filter kernel: float2 offset of its P row starts
   unsigned long long rowOfs;        // float offset of its P x NC row-filtered block (arena B)
   unsigned long long gridOfs;       // float offset of its NC x NC blurred grid (arena C)
 };
@@ -189,7 +190,7 @@ void launch_orientation(hipStream_t s, const OriJob *jobs, OriOut *out, int n, c
                         const double *atanLut, int doHalf, double th, int maxAngles);
 void launch_trunc_u8(hipStream_t s, const float *src, uint8_t *dst, size_t n);
 void launch_sample_rows(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
-                        const ImgRef *imgs, const float *taps, const int *needTab, float *dst);
+                        const ImgRef *imgs, const float *taps, const int *needTab, float *dst, float2 *rowStarts);
 void launch_blur_lds(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
                      const float *taps, const int *needTab, const float *src, float *dst, int pass);
 void launch_expand_tiles(hipStream_t s, const int *prefix, int nJobs, int *tileJob);
@@ -245,7 +246,7 @@ struct modsx_ctx {
   hipStream_t stream;
   mx::Pyramid pyr[mx::MAXB];
   mx::DevBuf nmsJobs, cand, counter, affJobs, affOut, oriJobs, oriOut, descJobs, tilePrefix, taps, imgRefs, scratchA, scratchB,
-      descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], descAllU8b[2], pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps, viewJobs, viewImg[mx::MAXB], scratchC, needTab, coordTab, tileJob, blurTiles, nmsQueue;
+      descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], descAllU8b[2], pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps, viewJobs, viewImg[mx::MAXB], scratchC, needTab, coordTab, tileJob, blurTiles, nmsQueue, rowStarts;
   mx::PinBuf hDescB;           // second staging blob of describe_batch: chunk k + 1 is prepared while chunk k runs
   hipEvent_t descEv[2];
   bool descEvPending[2] = {false, false};

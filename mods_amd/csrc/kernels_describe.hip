@@ -47,13 +47,21 @@ __global__ __launch_bounds__(64) void k_expand_tiles(const int *prefix, int nJob
 // tile descriptors of the LDS blur kernels: everything a workgroup needs in one 48-byte scalar load, so that its first
 // vector loads (the inputs it parks in LDS) are two dependent round trips from the launch instead of three
 __global__ __launch_bounds__(64) void k_expand_blur_tiles(const DescJob *jobs, const int *prefix, int nJobs, const int *needTab,
-                                                          BlurTile *tiles, int pass) {
+                                                          BlurTile *tiles, int pass, float2 *rowStart) {
   const int j = blockIdx.x;
   if (j >= nJobs) return;
   const int b = prefix[j], e = prefix[j + 1];
   if (b == e) return;
   const DescJob jb = jobs[j];
   const int R = jb.ksize >> 1;
+  if (rowStart && threadIdx.x == 63) {
+    // row starts of interpolate() (rx += a12, ry += a22 per row, helpers.cpp:563-566): one serial chain per window, run
+    // here once instead of by every row tile of the fused sampling kernel (a tile of a large window is a few rows only)
+    float2 *rs = rowStart + jb.scratchOfs;
+    const int half = jb.P >> 1;
+    float rx = jb.x - (float)half * jb.a12, ry = jb.y - (float)half * jb.a22;
+    for (int r = 0; r < jb.P; r++) { rs[r] = make_float2(rx, ry); rx += jb.a12; ry += jb.a22; }
+  }
   for (int t = b + threadIdx.x; t < e; t += 64) {
     BlurTile bt;
     bt.P = jb.P; bt.NC = jb.NC; bt.n = jb.ksize; bt.tapOfs = jb.tapOfs; bt.needOfs = jb.needOfs;
@@ -408,8 +416,8 @@ __device__ __forceinline__ void sample_chunk_lds(const ImgRef &im, const float *
 }
 
 template <int C>
-__device__ __forceinline__ void sample_rows_tile(const BlurTile &bt, const DescJob &jb, const ImgRef &im, float *win, float *cx, float *cy,
-                                                 int lane, int wave) {
+__device__ __forceinline__ void sample_rows_tile(const BlurTile &bt, const DescJob &jb, const ImgRef &im, const float2 *rowStart,
+                                                 float *win, float *cx, float *cy, int lane, int wave) {
   constexpr int CP = C + 1, RG = C == 8 ? 64 : 32;   // rows per pass of the wave
   const int P = bt.P, R = bt.n >> 1, RW = P + 2 * R, nr = bt.count, r0 = bt.first;
   const int half = P >> 1;
@@ -417,13 +425,9 @@ __device__ __forceinline__ void sample_rows_tile(const BlurTile &bt, const DescJ
   const int cper = (P + BLUR_W - 1) / BLUR_W, cb = wave * cper, ce = (cb + cper) < P ? (cb + cper) : P;
   for (int rb = 0; rb < nr; rb += RG) {
     const bool active = lane < RG && rb + lane < nr;
-    const int row = r0 + rb + lane;
-    float rx = jb.x - (float)half * jb.a12;
-    float ry = jb.y - (float)half * jb.a22;
-    const int nsteps = active ? row : 0;
-    for (int j = 0; j < nsteps; j++) { rx += jb.a12; ry += jb.a22; }
-    float WX = rx - (float)half * jb.a11;
-    float WY = ry - (float)half * jb.a21;
+    const float2 rs = rowStart[active ? r0 + rb + lane : r0];   // the running sums of the window's rows (k_expand_blur_tiles)
+    float WX = rs.x - (float)half * jb.a11;
+    float WY = rs.y - (float)half * jb.a21;
     for (int i = 0; i < cb; i++) { WX += jb.a11; WY += jb.a21; }
     const int rowsHere = (nr - rb) < RG ? (nr - rb) : RG;
     for (int c0 = cb; c0 < ce; c0 += C) {
@@ -450,7 +454,8 @@ __device__ __forceinline__ void sample_rows_tile(const BlurTile &bt, const DescJ
 
 __global__ __launch_bounds__(BLUR_T, 4) void k_sample_rows_lds(const BlurTile *__restrict__ tiles, const DescJob *__restrict__ jobs,
                                                          const ImgRef *__restrict__ imgs, const float *__restrict__ taps,
-                                                         const int *__restrict__ needTab, float *__restrict__ dst, int nTiles) {
+                                                         const int *__restrict__ needTab, float *__restrict__ dst, int nTiles,
+                                                         const float2 *__restrict__ rowStarts) {
   const int ti = xcd_chunk(blockIdx.x, nTiles);   // tiles follow the (image, row band, x) order of the jobs: one part of the images per XCD
   if (ti >= nTiles) return;
   const BlurTile bt = tiles[ti];
@@ -465,8 +470,9 @@ __global__ __launch_bounds__(BLUR_T, 4) void k_sample_rows_lds(const BlurTile *_
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int i = threadIdx.x; i < NC; i += BLUR_T) sneed[i] = needTab[bt.needOfs + i];
   const ImgRef im = imgs[jb.img];
-  if (nr <= 32) sample_rows_tile<16>(bt, jb, im, win, cxs[wave], cys[wave], lane, wave);
-  else sample_rows_tile<8>(bt, jb, im, win, cxs[wave], cys[wave], lane, wave);
+  const float2 *rowStart = rowStarts + jb.scratchOfs;
+  if (nr <= 32) sample_rows_tile<16>(bt, jb, im, rowStart, win, cxs[wave], cys[wave], lane, wave);
+  else sample_rows_tile<8>(bt, jb, im, rowStart, win, cxs[wave], cys[wave], lane, wave);
   __syncthreads();
   // replicated border: R copies of the first and of the last sample of every row
   for (int i = threadIdx.x; i < nr * 2 * R; i += BLUR_T) {
@@ -885,15 +891,16 @@ void launch_patch_sample(hipStream_t s, const DescJob *jobs, const int *tilePref
   hipLaunchKernelGGL(k_patch_sample, dim3(8 * ((nTiles + 7) / 8)), dim3(64), 0, s, jobs, tilePrefix, tileJob, imgs, scratch, nTiles);
 }
 void launch_sample_rows(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
-                        const ImgRef *imgs, const float *taps, const int *needTab, float *dst) {
+                        const ImgRef *imgs, const float *taps, const int *needTab, float *dst, float2 *rowStarts) {
   if (nTiles <= 0) return;
-  hipLaunchKernelGGL(k_expand_blur_tiles, dim3(nJobs), dim3(64), 0, s, jobs, tilePrefix, nJobs, needTab, tiles, 0);
-  hipLaunchKernelGGL(k_sample_rows_lds, dim3(8 * ((nTiles + 7) / 8)), dim3(BLUR_T), 0, s, tiles, jobs, imgs, taps, needTab, dst, nTiles);
+  hipLaunchKernelGGL(k_expand_blur_tiles, dim3(nJobs), dim3(64), 0, s, jobs, tilePrefix, nJobs, needTab, tiles, 0, rowStarts);
+  hipLaunchKernelGGL(k_sample_rows_lds, dim3(8 * ((nTiles + 7) / 8)), dim3(BLUR_T), 0, s, tiles, jobs, imgs, taps, needTab, dst, nTiles,
+                     rowStarts);
 }
 void launch_blur_lds(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
                      const float *taps, const int *needTab, const float *src, float *dst, int pass) {
   if (nTiles <= 0) return;
-  hipLaunchKernelGGL(k_expand_blur_tiles, dim3(nJobs), dim3(64), 0, s, jobs, tilePrefix, nJobs, needTab, tiles, pass);
+  hipLaunchKernelGGL(k_expand_blur_tiles, dim3(nJobs), dim3(64), 0, s, jobs, tilePrefix, nJobs, needTab, tiles, pass, (float2 *)nullptr);
   if (pass == 0) hipLaunchKernelGGL(k_blur_rows_lds, dim3(nTiles), dim3(BLUR_T), 0, s, tiles, taps, needTab, src, dst);
   else hipLaunchKernelGGL(k_blur_cols_lds, dim3(nTiles), dim3(BLUR_T), 0, s, tiles, taps, needTab, src, dst);
 }
