@@ -337,12 +337,18 @@ def main():
                 ms = sum(d["ms"] for d in dk) / dk[0]["launches"]
                 byts = (dk[0]["work"] + dk[3]["work"]) / dk[0]["launches"]
                 out["roofline_describe"] = {
-                    "kernel": "describe stage: k_patch_sample + k_blur_rows_lds + k_blur_cols_lds + k_describe (one chunk = one launch of each)",
+                    "kernel": "describe stage: k_sample_rows_lds (sampling fused with the row filter; k_patch_sample + k_patch_blur for the few windows beyond LDS) + k_blur_cols_lds + k_describe (one chunk = one launch of each)",
                     "bound": "hbm", "achieved": byts / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms,
-                    "algorithmic_work_per_launch": byts,
+                    "algorithmic_work_per_launch": byts, "traffic": None,
                     "note": "bytes per SURVEY section 8(d): (P+2)^2 x 4 B read + 128 B written per region; the limiter of these "
                             "kernels is VALU issue / the texture addresser, not HBM (DESIGN.md section 5)"}
+            tfile = os.path.join(ROOT, "profiles", "pmc_traffic_r02.json")
+            if "roofline_describe" in out and os.path.exists(tfile):
+                t = json.load(open(tfile))
+                # HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE, rocprofv3 --pmc, separate passes) of one launch of each kernel of the stage
+                out["roofline_describe"]["traffic"] = sum(t.get(k, 0) for k in ("k_sample_rows_lds", "k_patch_sample", "k_blur_rows_lds",
+                                                                                "k_patch_blur", "k_blur_cols_lds", "k_describe")) or None
         if wxbs:
             # H verification was the timed region; the same batch with epipolar verification, and the host share of both
             vms, vn, vth = verify_timed
