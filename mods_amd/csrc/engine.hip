@@ -873,7 +873,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
                 for (int a = 0; a + 1 < pi.NC; a += 2) pairs = pairs && need[a + 1] == need[a] + 1;
                 pi.rows0 = pairs ? std::min(cap, BLUR_LDS / (P + 2 * R)) : 0;
                 if (pi.rows0 < 2) pi.rows0 = 0;
-                if (pi.rows0 > 32 && pi.rows0 < 48) pi.rows0 = 32;   // the fused sampling kernel parks 16 columns x <= 32 rows or 8 x <= 64
+                if (pi.rows0 > 32 && pi.rows0 < 48 && pi.rows0 < P) pi.rows0 = 32;   // the fused sampling kernel parks 16 columns x <= 32 rows or 8 x <= 64
                 pi.ro1 = 0;
                 const int LS = pi.NC <= 64 ? 64 : 96;   // LDS row stride of the column filter
                 for (int ro = std::min(capC, pi.NC); ro >= 2 && !pi.ro1 && pi.NC <= 96; ro--) {
@@ -881,6 +881,9 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
                   for (int a = 0; a < pi.NC; a += ro) span = std::max(span, need[std::min(a + ro, pi.NC) - 1] - need[a] + 2 * R + 1);
                   if (span * LS <= BLUR_LDS_C) pi.ro1 = ro;
                 }
+                // a window that is one row tile, with <= 64 needed columns and <= 80 block rows (kernels_describe.hip: FC_LS,
+                // FC_ROWS): the fused sampling kernel runs the column filter too
+                if (pi.rows0 >= P && pi.NC <= 64 && P + 2 * R <= 80) pi.ro1 = -1;
               }
               it = pinfo.insert({P, pi}).first;
             }
@@ -960,9 +963,9 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
         pfxSample.push_back(pfxSample.back() + (j.P > 0 && !j.rows0 ? ((j.P + 63) / 64) * ((j.P + 127) / 128) : 0));
         // the blur passes: LDS kernels where a tile fits, k_patch_blur (BLUR_TILE outputs per workgroup) otherwise
         pfxRowL.push_back(pfxRowL.back() + (j.P > 0 && j.rows0 ? (j.P + j.rows0 - 1) / j.rows0 : 0));
-        pfxColL.push_back(pfxColL.back() + (j.P > 0 && j.ro1 ? (j.NC + j.ro1 - 1) / j.ro1 : 0));
+        pfxColL.push_back(pfxColL.back() + (j.P > 0 && j.ro1 > 0 ? (j.NC + j.ro1 - 1) / j.ro1 : 0));
         pfxRow.push_back(pfxRow.back() + (j.P > 0 && !j.rows0 ? (j.P * j.NC + 1023) / 1024 : 0));
-        pfxCol.push_back(pfxCol.back() + (j.P > 0 && !j.ro1 ? (j.NC * j.NC + 1023) / 1024 : 0));
+        pfxCol.push_back(pfxCol.back() + (j.P > 0 && j.ro1 == 0 ? (j.NC * j.NC + 1023) / 1024 : 0));
       }
       // the job table, the five tile prefixes and the three small tables travel as ONE pinned blob and one copy: nine
       // separate uploads cost nine ~6 us copy kernels per chunk on the stream
@@ -1005,7 +1008,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       // artefact of the split and are not algorithmic bytes
       { ProfScope ps(c, K_PATCH_SAMPLE, (double)windowFloats * 4);
         launch_sample_rows(s, dj, dPfxRL, (int)nj, btR, pfxRowL.back(), (ImgRef *)c->imgRefs.p, dTaps, dNeed, (float *)c->scratchB.p,
-                           (float2 *)c->rowStarts.p);
+                           (float2 *)c->rowStarts.p, (float *)c->scratchC.p);
         launch_patch_sample(s, dj, dPfxS, tjS, pfxSample.back(), (ImgRef *)c->imgRefs.p, (float *)c->scratchA.p); }
       { ProfScope ps(c, K_BLUR_ROWS, 0.0);
         launch_patch_blur(s, dj, dPfxR, tjR, pfxRow.back(), dTaps, dNeed, (float *)c->scratchA.p,

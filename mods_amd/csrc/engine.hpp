@@ -85,7 +85,8 @@ struct DescJob {
   int touch;          // interpolate()'s border branch for the 41x41 resampling
   int outIdx;         // index of the region in its image's descriptor buffers
   int rows0;          // window rows per workgroup of the LDS row filter, 0 = this job goes through k_patch_blur
-  int ro1;            // needed rows per workgroup of the LDS column filter, 0 = k_patch_blur
+  int ro1;            // needed rows per workgroup of the LDS column filter, 0 = k_patch_blur, -1 = the fused sampling kernel
+                      // filters the columns too (small window: whole row tile + row-filtered block fit its LDS)
   unsigned long long scratchOfs;    // float offset of this region's P x P window (arena A); for windows that take the fused
                                     // sample + row-filter kernel: float2 offset of its P row starts
   unsigned long long rowOfs;        // float offset of its P x NC row-filtered block (arena B)
@@ -190,7 +191,7 @@ void launch_orientation(hipStream_t s, const OriJob *jobs, OriOut *out, int n, c
                         const double *atanLut, int doHalf, double th, int maxAngles);
 void launch_trunc_u8(hipStream_t s, const float *src, uint8_t *dst, size_t n);
 void launch_sample_rows(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
-                        const ImgRef *imgs, const float *taps, const int *needTab, float *dst, float2 *rowStarts);
+                        const ImgRef *imgs, const float *taps, const int *needTab, float *dst, float2 *rowStarts, float *dstGrid);
 void launch_blur_lds(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
                      const float *taps, const int *needTab, const float *src, float *dst, int pass);
 void launch_expand_tiles(hipStream_t s, const int *prefix, int nJobs, int *tileJob);

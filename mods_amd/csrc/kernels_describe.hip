@@ -293,15 +293,15 @@ constexpr int BLUR_LDS = 4992, BLUR_OUT = 2048, FILL_MLP = 20;   // row filter: 
 constexpr int BLUR_LDS_C = 9984;                               // column filter: fatter tiles re-read fewer halo rows
 
 // the row filter proper, on a tile parked in LDS as nr rows of R + P + R floats (replicated border written out)
+// (dst = the tile's place in arena B, row stride NC; or, for the fully fused small windows, an LDS block of row stride ostride)
 __device__ __forceinline__ void blur_rows_from_lds(const BlurTile &bt, const float *win, const int *sneed, const float *__restrict__ taps,
-                                                   float *__restrict__ dst) {
+                                                   float *__restrict__ out, int ostride) {
   const int NC = bt.NC, n = bt.n, R = n >> 1, RW = bt.P + 2 * R, nr = bt.count;
   // A thread forms 4 PAIRS of horizontally adjacent outputs (needed columns 2m, 2m+1 -- the host checks that such pairs are
   // neighbours in the window, which the x0 / x0+1 construction gives): both members of a pair take tap j from adjacent LDS
   // words, so a tap of a pair is one 2-word read, one packed multiply and one packed add.
   const float *kg = taps + bt.tapOfs;
   const int NP = (NC + 1) >> 1, total = nr * NP;
-  float *out = dst + bt.dstOfs;
   constexpr int NQ = 4;
   for (int base = threadIdx.x; base < total; base += BLUR_T * NQ) {
     int p[NQ];     // win[p[q] + j], win[p[q] + j + 1] = window columns need[2m] + j - R, + 1 of the pair's row
@@ -345,9 +345,62 @@ __device__ __forceinline__ void blur_rows_from_lds(const BlurTile &bt, const flo
       const int e = base + q * BLUR_T;
       if (e < total) {
         const int r = (int)(((unsigned)e * (unsigned)bt.magic) >> 20), m = e - r * NP;
-        float *o = out + r * NC + 2 * m;
+        float *o = out + r * ostride + 2 * m;
         o[0] = v0[q];
         if (2 * m + 1 < NC) o[1] = v1[q];
+      }
+    }
+  }
+}
+
+// the column filter proper on source rows parked in LDS from row `lo` on (row stride LS, replicated border rows written
+// out): needed rows ro0 .. ro0 + nro - 1, all NC columns; out = first output of the tile (row stride NC)
+template <int LS>
+__device__ __forceinline__ void blur_cols_from_lds(int NC, int n, int ro0, int nro, int lo, int magic, const float *win, const int *sneed,
+                                                   const float *__restrict__ kg, float *__restrict__ out) {
+  const int R = n >> 1;
+  // pairs of horizontally adjacent outputs again: (ri, 2m) and (ri, 2m+1) read adjacent LDS words in every parked row
+  const int NP = (NC + 1) >> 1, total = nro * NP;
+  constexpr int NQ = 4;
+  for (int base = threadIdx.x; base < total; base += BLUR_T * NQ) {
+    int pc[NQ];
+    float2 v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      int e = base + q * BLUR_T;
+      e = e < total ? e : total - 1;
+      const int ri = (int)(((unsigned)e * (unsigned)magic) >> 20), m = e - ri * NP;
+      pc[q] = (sneed[ro0 + ri] - lo) * LS + 2 * m;
+    }
+    if (n == 1) {
+#pragma unroll
+      for (int q = 0; q < NQ; q++) v[q] = *(const float2 *)&win[pc[q]];
+    } else {
+      const float kc = kg[R];
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        const float2 c = *(const float2 *)&win[pc[q]];
+        v[q].x = kc * c.x + 0.f; v[q].y = kc * c.y + 0.f;
+      }
+#pragma unroll 4
+      for (int j = 1; j <= R; j++) {
+        const float kj = kg[R + j];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const float2 a = *(const float2 *)&win[pc[q] + j * LS], b = *(const float2 *)&win[pc[q] - j * LS];
+          v[q].x = v[q].x + kj * (a.x + b.x);
+          v[q].y = v[q].y + kj * (a.y + b.y);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int e = base + q * BLUR_T;
+      if (e < total) {
+        const int ri = (int)(((unsigned)e * (unsigned)magic) >> 20), m = e - ri * NP;
+        float *o = out + ri * NC + 2 * m;
+        o[0] = v[q].x;
+        if (2 * m + 1 < NC) o[1] = v[q].y;
       }
     }
   }
@@ -383,7 +436,7 @@ __global__ __launch_bounds__(BLUR_T, 8) void k_blur_rows_lds(const BlurTile *__r
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  blur_rows_from_lds(bt, win, sneed, taps, dst);
+  blur_rows_from_lds(bt, win, sneed, taps, dst + bt.dstOfs, NC);
 }
 
 // Stage 1 + the row pass of stage 2 in one launch: a workgroup SAMPLES its tile of window rows (interpolate(), the f32
@@ -397,6 +450,8 @@ __global__ __launch_bounds__(BLUR_T, 8) void k_blur_rows_lds(const BlurTile *__r
 // C = 16 for tiles of up to 32 rows (the host keeps row tiles out of the 33..48 range), so that a lane has 8 samples --
 // 16 loads -- in flight either way.
 constexpr int SR_WORDS = 64 * 9;
+constexpr int FC_LS = 64, FC_ROWS = 80;   // fully fused small windows: NC <= FC_LS needed columns, P + 2 R <= FC_ROWS block rows
+MX_D int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 
 template <bool TOUCH, int C>
 __device__ __forceinline__ void sample_chunk_lds(const ImgRef &im, const float *cx, const float *cy, float *dst, int RW, int tot, int nc,
@@ -455,7 +510,7 @@ __device__ __forceinline__ void sample_rows_tile(const BlurTile &bt, const DescJ
 __global__ __launch_bounds__(BLUR_T, 4) void k_sample_rows_lds(const BlurTile *__restrict__ tiles, const DescJob *__restrict__ jobs,
                                                          const ImgRef *__restrict__ imgs, const float *__restrict__ taps,
                                                          const int *__restrict__ needTab, float *__restrict__ dst, int nTiles,
-                                                         const float2 *__restrict__ rowStarts) {
+                                                         const float2 *__restrict__ rowStarts, float *__restrict__ dstGrid) {
   const int ti = xcd_chunk(blockIdx.x, nTiles);   // tiles follow the (image, row band, x) order of the jobs: one part of the images per XCD
   if (ti >= nTiles) return;
   const BlurTile bt = tiles[ti];
@@ -464,15 +519,19 @@ __global__ __launch_bounds__(BLUR_T, 4) void k_sample_rows_lds(const BlurTile *_
   const int n = bt.n, R = n >> 1, RW = P + 2 * R;
   __shared__ float win[BLUR_LDS + 2];
   __shared__ int sneed[96];
-  __shared__ float cxs[BLUR_W][SR_WORDS], cys[BLUR_W][SR_WORDS];
+  // coordinates of the sampling phase (2 x 4 waves x 64 x 9 words); afterwards, for a small window that is here as a whole
+  // (DescJob::ro1 < 0), the row-filtered block with its replicated border rows, which the column filter then reads in place
+  __shared__ __attribute__((aligned(16))) float aux[FC_ROWS * FC_LS];
+  static_assert(FC_ROWS * FC_LS >= 2 * BLUR_W * SR_WORDS, "aux holds the sampling coordinates");
+  float *const cxw = aux + wave_id() * SR_WORDS, *const cyw = aux + (BLUR_W + wave_id()) * SR_WORDS;
   const int nr = bt.count;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int i = threadIdx.x; i < NC; i += BLUR_T) sneed[i] = needTab[bt.needOfs + i];
   const ImgRef im = imgs[jb.img];
   const float2 *rowStart = rowStarts + jb.scratchOfs;
-  if (nr <= 32) sample_rows_tile<16>(bt, jb, im, rowStart, win, cxs[wave], cys[wave], lane, wave);
-  else sample_rows_tile<8>(bt, jb, im, rowStart, win, cxs[wave], cys[wave], lane, wave);
+  if (nr <= 32) sample_rows_tile<16>(bt, jb, im, rowStart, win, cxw, cyw, lane, wave);
+  else sample_rows_tile<8>(bt, jb, im, rowStart, win, cxw, cyw, lane, wave);
   __syncthreads();
   // replicated border: R copies of the first and of the last sample of every row
   for (int i = threadIdx.x; i < nr * 2 * R; i += BLUR_T) {
@@ -482,7 +541,18 @@ __global__ __launch_bounds__(BLUR_T, 4) void k_sample_rows_lds(const BlurTile *_
     else rowp[P + k] = rowp[R + P - 1];
   }
   __syncthreads();
-  blur_rows_from_lds(bt, win, sneed, taps, dst);
+  if (jb.ro1 >= 0) { blur_rows_from_lds(bt, win, sneed, taps, dst + bt.dstOfs, NC); return; }
+  // the whole (small) window is here: its row-filtered block stays in LDS and the column filter follows at once -- arena B
+  // is not touched either
+  blur_rows_from_lds(bt, win, sneed, taps, aux + R * FC_LS, FC_LS);
+  __syncthreads();
+  for (int i = threadIdx.x; i < R * FC_LS; i += BLUR_T) {   // replicated border rows above and below
+    const int k = i / FC_LS, x = i - k * FC_LS;
+    aux[k * FC_LS + x] = aux[R * FC_LS + x];
+    aux[(R + P + k) * FC_LS + x] = aux[(R + P - 1) * FC_LS + x];
+  }
+  __syncthreads();
+  blur_cols_from_lds<FC_LS>(NC, n, 0, NC, -R, bt.magic, aux, sneed, taps + bt.tapOfs, dstGrid + jb.gridOfs);
 }
 
 template <int LS>   // LDS row stride (floats), a compile-time constant so that tap j of a column is an immediate offset
@@ -490,7 +560,7 @@ __device__ __forceinline__ void blur_cols_tile(const BlurTile &bt, float *win, i
                                                const int *__restrict__ needTab, const float *__restrict__ src,
                                                float *__restrict__ dst) {
   const int P = bt.P, NC = bt.NC;
-  const int n = bt.n, R = n >> 1;
+  const int n = bt.n;
   const int ro0 = bt.first, nro = bt.count, lo = bt.lo, S = bt.span;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < NC; i += BLUR_T) sneed[i] = needTab[bt.needOfs + i];
@@ -510,53 +580,7 @@ __device__ __forceinline__ void blur_cols_tile(const BlurTile &bt, float *win, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  // pairs of horizontally adjacent outputs again: (ri, 2m) and (ri, 2m+1) read adjacent LDS words in every parked row
-  const float *kg = taps + bt.tapOfs;
-  const int NP = (NC + 1) >> 1, total = nro * NP;
-  float *out = dst + bt.dstOfs;
-  constexpr int NQ = 4;
-  for (int base = threadIdx.x; base < total; base += BLUR_T * NQ) {
-    int pc[NQ];
-    float2 v[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-      int e = base + q * BLUR_T;
-      e = e < total ? e : total - 1;
-      const int ri = (int)(((unsigned)e * (unsigned)bt.magic) >> 20), m = e - ri * NP;
-      pc[q] = (sneed[ro0 + ri] - lo) * LS + 2 * m;
-    }
-    if (n == 1) {
-#pragma unroll
-      for (int q = 0; q < NQ; q++) v[q] = *(const float2 *)&win[pc[q]];
-    } else {
-      const float kc = kg[R];
-#pragma unroll
-      for (int q = 0; q < NQ; q++) {
-        const float2 c = *(const float2 *)&win[pc[q]];
-        v[q].x = kc * c.x + 0.f; v[q].y = kc * c.y + 0.f;
-      }
-#pragma unroll 4
-      for (int j = 1; j <= R; j++) {
-        const float kj = kg[R + j];
-#pragma unroll
-        for (int q = 0; q < NQ; q++) {
-          const float2 a = *(const float2 *)&win[pc[q] + j * LS], b = *(const float2 *)&win[pc[q] - j * LS];
-          v[q].x = v[q].x + kj * (a.x + b.x);
-          v[q].y = v[q].y + kj * (a.y + b.y);
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-      const int e = base + q * BLUR_T;
-      if (e < total) {
-        const int ri = (int)(((unsigned)e * (unsigned)bt.magic) >> 20), m = e - ri * NP;
-        float *o = out + ri * NC + 2 * m;
-        o[0] = v[q].x;
-        if (2 * m + 1 < NC) o[1] = v[q].y;
-      }
-    }
-  }
+  blur_cols_from_lds<LS>(NC, n, ro0, nro, lo, bt.magic, win, sneed, taps + bt.tapOfs, dst + bt.dstOfs);
 }
 
 __global__ __launch_bounds__(BLUR_T) void k_blur_cols_lds(const BlurTile *__restrict__ tiles, const float *__restrict__ taps,
@@ -891,11 +915,11 @@ void launch_patch_sample(hipStream_t s, const DescJob *jobs, const int *tilePref
   hipLaunchKernelGGL(k_patch_sample, dim3(8 * ((nTiles + 7) / 8)), dim3(64), 0, s, jobs, tilePrefix, tileJob, imgs, scratch, nTiles);
 }
 void launch_sample_rows(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
-                        const ImgRef *imgs, const float *taps, const int *needTab, float *dst, float2 *rowStarts) {
+                        const ImgRef *imgs, const float *taps, const int *needTab, float *dst, float2 *rowStarts, float *dstGrid) {
   if (nTiles <= 0) return;
   hipLaunchKernelGGL(k_expand_blur_tiles, dim3(nJobs), dim3(64), 0, s, jobs, tilePrefix, nJobs, needTab, tiles, 0, rowStarts);
   hipLaunchKernelGGL(k_sample_rows_lds, dim3(8 * ((nTiles + 7) / 8)), dim3(BLUR_T), 0, s, tiles, jobs, imgs, taps, needTab, dst, nTiles,
-                     rowStarts);
+                     rowStarts, dstGrid);
 }
 void launch_blur_lds(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
                      const float *taps, const int *needTab, const float *src, float *dst, int pass) {
