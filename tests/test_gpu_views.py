@@ -13,14 +13,17 @@ def _views(oracle, modsx, tilts, phi, sigma=0.2):
     return vo, vm
 
 
-@pytest.mark.parametrize("tilt,phi,zoom,sigma", [(2.0, 0.0, 1.0, 0.2), (4.0, np.pi / 2, 1.0, 0.2), (6.0, 2 * np.pi / 3, 1.0, 0.5),
-                                                 (3.0, 0.0, 0.5, 0.5), (-2.0, 0.0, 1.0, 0.5), (8.0, 1.0, 1.0, 0.5),
-                                                 (1.0, 0.0, 0.7, 0.5), (1.0, 0.0, 1.0, 0.5)])
-def test_synth_view_bit_exact(ctx, modsx, oracle, small_pair, tilt, phi, zoom, sigma):
+@pytest.mark.parametrize("tilt,phi,zoom,sigma,blur", [
+    (2.0, 0.0, 1.0, 0.2, 1), (4.0, np.pi / 2, 1.0, 0.2, 1), (6.0, 2 * np.pi / 3, 1.0, 0.5, 1), (3.0, 0.0, 0.5, 0.5, 1),
+    (-2.0, 0.0, 1.0, 0.5, 1), (8.0, 1.0, 1.0, 0.5, 1), (1.0, 0.0, 0.7, 0.5, 1), (1.0, 0.0, 1.0, 0.5, 1),
+    # beyond the fused rotate + blur kernel's halo (the separate launches): a tall column filter (vertical tilt), a row
+    # filter of 73 taps; the widest halo the fused kernel takes (49 taps); no blur at all
+    (-6.0, 0.3, 1.0, 0.8, 1), (8.0, 0.7, 1.0, 3.0, 1), (8.0, 2.0, 1.0, 2.0, 1), (4.0, 1.2, 1.0, 0.5, 0)])
+def test_synth_view_bit_exact(ctx, modsx, oracle, small_pair, tilt, phi, zoom, sigma, blur):
     a = small_pair[0]
     im = ctx.upload(a)
-    vo = oracle.make_view(tilt, phi, zoom, sigma, 1)
-    vm = modsx.make_view(tilt, phi, zoom, sigma, 1)
+    vo = oracle.make_view(tilt, phi, zoom, sigma, blur)
+    vm = modsx.make_view(tilt, phi, zoom, sigma, blur)
     ref, Href, ident_ref = oracle.synth_view(a, vo)
     got, H, ident = ctx.synth_view(im, vm)
     assert ident == ident_ref and np.array_equal(H, Href)
