@@ -144,10 +144,12 @@ def test_orientation_and_description_bit_exact(ctx, modsx, oracle, small_pair):
             assert np.array_equal(got, ref), (rootsift, photo, int((got != ref).any(1).sum()), len(ref))
             if rootsift >= 2:
                 assert not got[:, 64:].any() and got[:, :64].any()
-    # large windows: blur kernels of 33..128 taps (second ring size) and beyond 128 taps (materialised fallback)
-    big = rr[:8].copy()
+    # large windows: row tiles of a few rows in the fused sampling kernel (blur kernels of 33..170 taps), a window whose row
+    # tile does not fit LDS at all (s = 200: 2083 px wide, 459 taps -> k_patch_sample + the global-memory filter), and a
+    # small one that is column-filtered in the sampling kernel too
+    big = rr[:9].copy()
     for side in ("det_kp", "reproj_kp"):
-        big[side]["s"] = [14.0, 20.0, 33.0, 41.5, 56.0, 60.0, 75.0, 7.0]
+        big[side]["s"] = [14.0, 20.0, 33.0, 41.5, 56.0, 60.0, 75.0, 7.0, 200.0]
     ref = oracle.describe_regions(img, big)
     got = ctx.describe_regions(im, big.view(modsx.REGION))
     assert np.array_equal(got, ref), int((got != ref).any(1).sum())
