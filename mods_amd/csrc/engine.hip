@@ -1000,9 +1000,10 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       float *dTaps = (float *)(db + oTaps), *dCoord = (float *)(db + oCoord);
       int *dNeed = (int *)(db + oNeed);
       const DescJob *dj = (const DescJob *)c->descJobs.p;
-      launch_expand_tiles(s, dPfxS, (int)nj, tjS);
-      launch_expand_tiles(s, dPfxR, (int)nj, tjR);
-      launch_expand_tiles(s, dPfxC, (int)nj, tjC);
+      // tile -> job tables of the global-memory fallbacks: most chunks have no such tiles at all
+      if (pfxSample.back()) launch_expand_tiles(s, dPfxS, (int)nj, tjS);
+      if (pfxRow.back()) launch_expand_tiles(s, dPfxR, (int)nj, tjR);
+      if (pfxCol.back()) launch_expand_tiles(s, dPfxC, (int)nj, tjC);
       // algorithmic work of the describe STAGE per SURVEY section 8(d): the (P+2)^2 f32 window of every region read once
       // (booked here) + 128 B written per region (booked on k_describe); the arenas between the four kernels are an
       // artefact of the split and are not algorithmic bytes
