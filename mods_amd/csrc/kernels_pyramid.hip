@@ -25,10 +25,11 @@ namespace mx {
 // ksize > 5) or centre + symmetric pairs (SymmRowSmallFilter, ksize <= 5); column pass is centre +
 // (below + above) * k (SymmColumnFilter) -- per output the same f32 operation order as the CPU filter engine.
 // ---------------------------------------------------------------------------------------
-constexpr int TW = 64, TH = 32, RMAX = 8;
+constexpr int TW = 64, RMAX = 8;
 constexpr int TMP_W = TW + 4;                 // 66 needed columns rounded up to a multiple of 4
-constexpr int BLR_H = TH + 4;                 // 34 needed rows rounded up to a multiple of 4
-constexpr int SRC_W = TMP_W + 2 * RMAX, SRC_H = BLR_H + 2 * RMAX;
+// The tile height is a template parameter: 32 rows for the large levels (less halo per output), 16 rows when a whole launch
+// is under two rounds of 32-row tiles (small octaves: twice the workgroups, shorter per-workgroup chains; 6 % of the
+// pyramid's time).  BLR_H = TH + 4: the TH + 2 needed rows rounded up to a multiple of 4.
 
 // The images of a launch set differ in size (a view of tilt t is 1/t of the image): a grid over the largest image would
 // launch four empty workgroups for every useful one.  The launch is a flat list of tiles; tile0[] says where each job's
@@ -39,8 +40,9 @@ MX_D int find_job(const int *tile0, int nj, int t) {
   return j;
 }
 
-template <int R>
+template <int R, int TH>
 __global__ __launch_bounds__(256) void k_blur_hess(BlurBatch batch) {
+  constexpr int BLR_H = TH + 4;
   const int ji = find_job(batch.tile0, batch.nj, blockIdx.x);
   const BlurJob jb = batch.j[ji];
   const int rows = jb.rows, cols = jb.cols;
@@ -401,21 +403,28 @@ static int fill_tiles(BlurBatch &b, int nj, int tw, int th) {
   b.tile0[nj] = t;
   return t;
 }
-void launch_blur_hess(hipStream_t s, const BlurBatch &bin, int nj, int, int) {
-  BlurBatch b = bin;
-  const int tiles = fill_tiles(b, nj, TW, TH);
-  if (tiles <= 0) return;
+template <int TH>
+static void launch_blur_hess_th(hipStream_t s, const BlurBatch &b, int tiles) {
   dim3 grid(tiles);
   switch (b.n >> 1) {
-    case 1: hipLaunchKernelGGL(k_blur_hess<1>, grid, dim3(256), 0, s, b); break;
-    case 2: hipLaunchKernelGGL(k_blur_hess<2>, grid, dim3(256), 0, s, b); break;
-    case 3: hipLaunchKernelGGL(k_blur_hess<3>, grid, dim3(256), 0, s, b); break;
-    case 4: hipLaunchKernelGGL(k_blur_hess<4>, grid, dim3(256), 0, s, b); break;
-    case 5: hipLaunchKernelGGL(k_blur_hess<5>, grid, dim3(256), 0, s, b); break;
-    case 6: hipLaunchKernelGGL(k_blur_hess<6>, grid, dim3(256), 0, s, b); break;
-    case 7: hipLaunchKernelGGL(k_blur_hess<7>, grid, dim3(256), 0, s, b); break;
-    default: hipLaunchKernelGGL(k_blur_hess<8>, grid, dim3(256), 0, s, b); break;
+    case 1: hipLaunchKernelGGL((k_blur_hess<1, TH>), grid, dim3(256), 0, s, b); break;
+    case 2: hipLaunchKernelGGL((k_blur_hess<2, TH>), grid, dim3(256), 0, s, b); break;
+    case 3: hipLaunchKernelGGL((k_blur_hess<3, TH>), grid, dim3(256), 0, s, b); break;
+    case 4: hipLaunchKernelGGL((k_blur_hess<4, TH>), grid, dim3(256), 0, s, b); break;
+    case 5: hipLaunchKernelGGL((k_blur_hess<5, TH>), grid, dim3(256), 0, s, b); break;
+    case 6: hipLaunchKernelGGL((k_blur_hess<6, TH>), grid, dim3(256), 0, s, b); break;
+    case 7: hipLaunchKernelGGL((k_blur_hess<7, TH>), grid, dim3(256), 0, s, b); break;
+    default: hipLaunchKernelGGL((k_blur_hess<8, TH>), grid, dim3(256), 0, s, b); break;
   }
+}
+void launch_blur_hess(hipStream_t s, const BlurBatch &bin, int nj, int, int) {
+  BlurBatch b = bin;
+  int tiles = fill_tiles(b, nj, TW, 32);
+  if (tiles <= 0) return;
+  // under two rounds of workgroups (5-6 per CU x 256 CUs) the 16-row tile is faster
+  if (tiles >= 2560) { launch_blur_hess_th<32>(s, b, tiles); return; }
+  tiles = fill_tiles(b, nj, TW, 16);
+  launch_blur_hess_th<16>(s, b, tiles);
 }
 void launch_hessian(hipStream_t s, const BlurBatch &bin, int nj, int, int) {
   BlurBatch b = bin;
