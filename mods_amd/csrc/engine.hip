@@ -312,6 +312,7 @@ int build_pyramids(modsx_ctx *c, const modsx_image *const *imgs, int n, const mo
         ResizeJob &r = rb.j[nj];
         r.src = pv.blur[p.numberOfScales]; r.dst = oc.blur[0];
         r.srows = pv.rows; r.scols = pv.cols; r.drows = oc.rows; r.dcols = oc.cols;
+        r.resp = oc.resp[0]; r.norm = sp.curSigma[0] * sp.curSigma[0];   // resize + Hessian of the new level in one launch
         BlurJob &j = bb.j[nj++];
         j.src = oc.blur[0]; j.blur = nullptr; j.resp = oc.resp[0]; j.rows = oc.rows; j.cols = oc.cols;
         j.norm = sp.curSigma[0] * sp.curSigma[0];
@@ -320,8 +321,7 @@ int build_pyramids(modsx_ctx *c, const modsx_image *const *imgs, int n, const mo
       if (nj) {
         double spx = 0, dpx = 0;
         for (int q = 0; q < nj; q++) { spx += (double)rb.j[q].srows * rb.j[q].scols; dpx += (double)rb.j[q].drows * rb.j[q].dcols; }
-        { ProfScope ps(c, K_RESIZE, (spx + dpx) * 4); launch_resize_half(s, rb, nj, mr, mc); }
-        { ProfScope ps(c, K_HESSIAN, dpx * 8); launch_hessian(s, bb, nj, mr, mc); }
+        { ProfScope ps(c, K_RESIZE, (spx + dpx) * 4 + dpx * 4); launch_resize_half(s, rb, nj, mr, mc); }
       }
     }
     if (!nj) continue;

@@ -38,7 +38,10 @@ struct BlurBatch {
 struct ResizeJob {
   const float *src;
   float *dst;
+  float *resp;   // not null: the Hessian response of the resized level is written too (norm = its sigma^2)
   int srows, scols, drows, dcols;
+  float norm;
+  int pad;
 };
 struct ResizeBatch { ResizeJob j[MAXB]; int nj; int tile0[MAXB + 1]; };
 struct NmsJob {

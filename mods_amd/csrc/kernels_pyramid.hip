@@ -169,18 +169,12 @@ __global__ __launch_bounds__(256) void k_hessian(BlurBatch batch) {
 
 // cv::resize(src, dst, Size(0,0), 0.5, 0.5, INTER_LINEAR) == area-fast 2x2 (pyramid.cpp:520):
 // full blocks ((s00+s01)+s10)+s11)*0.25f, partial blocks sum(available)/count.
-__global__ __launch_bounds__(256) void k_resize_half(ResizeBatch batch) {
-  const int ji = find_job(batch.tile0, batch.nj, blockIdx.x);
-  const ResizeJob jb = batch.j[ji];
-  const int lt = blockIdx.x - batch.tile0[ji], ntx = (jb.dcols + 63) / 64;
-  const int dx = (lt % ntx) * 64 + (threadIdx.x & 63), dy = (lt / ntx) * 4 + (threadIdx.x >> 6);
-  if (dx >= jb.dcols || dy >= jb.drows) return;
-  const int sr = jb.srows, sc = jb.scols;
+MX_D float resize_half_px(const float *src, int sr, int sc, int dx, int dy) {
   const int sy0 = dy * 2, sx0 = dx * 2;
   float out;
   if (sy0 >= sr) out = 0.f;
   else if (sy0 + 2 <= sr && dx < sc / 2) {
-    const float *S = jb.src + (size_t)sy0 * sc + sx0;
+    const float *S = src + (size_t)sy0 * sc + sx0;
     float sum = 0.f;
     sum = sum + (((S[0] + S[1]) + S[sc]) + S[sc + 1]);
     out = sum * 0.25f;
@@ -190,13 +184,40 @@ __global__ __launch_bounds__(256) void k_resize_half(ResizeBatch batch) {
       if (sy0 + sy >= sr) break;
       for (int sx = 0; sx < 2; sx++) {
         if (sx0 + sx >= sc) break;
-        sum += jb.src[(size_t)(sy0 + sy) * sc + sx0 + sx];
+        sum += src[(size_t)(sy0 + sy) * sc + sx0 + sx];
         count++;
       }
     }
     out = (sx0 >= sc) ? 0.f : sum / (float)count;
   }
-  jb.dst[(size_t)dy * jb.dcols + dx] = out;
+  return out;
+}
+// First level of an octave >= 1: the 2 x 2 resize and, in the same launch, the Hessian response of the resized level
+// (HessianResponse, pyramid.cpp:223-281; the expression of k_hessian) -- a thread forms the 3 x 3 resized values its
+// response needs itself (the same f32 values its neighbours store), which saves a launch per octave.
+__global__ __launch_bounds__(256) void k_resize_half(ResizeBatch batch) {
+  const int ji = find_job(batch.tile0, batch.nj, blockIdx.x);
+  const ResizeJob jb = batch.j[ji];
+  const int lt = blockIdx.x - batch.tile0[ji], ntx = (jb.dcols + 63) / 64;
+  const int dx = (lt % ntx) * 64 + (threadIdx.x & 63), dy = (lt / ntx) * 4 + (threadIdx.x >> 6);
+  if (dx >= jb.dcols || dy >= jb.drows) return;
+  const int sr = jb.srows, sc = jb.scols, rows = jb.drows, cols = jb.dcols;
+  const float v22 = resize_half_px(jb.src, sr, sc, dx, dy);
+  jb.dst[(size_t)dy * cols + dx] = v22;
+  if (!jb.resp) return;
+  float o = 0.f;
+  if (dy >= 1 && dy < rows - 1 && dx >= 1 && dx < cols - 1) {
+    const float v11 = resize_half_px(jb.src, sr, sc, dx - 1, dy - 1), v12 = resize_half_px(jb.src, sr, sc, dx, dy - 1),
+                v13 = resize_half_px(jb.src, sr, sc, dx + 1, dy - 1);
+    const float v21 = resize_half_px(jb.src, sr, sc, dx - 1, dy), v23 = resize_half_px(jb.src, sr, sc, dx + 1, dy);
+    const float v31 = resize_half_px(jb.src, sr, sc, dx - 1, dy + 1), v32 = resize_half_px(jb.src, sr, sc, dx, dy + 1),
+                v33 = resize_half_px(jb.src, sr, sc, dx + 1, dy + 1);
+    float Lxx = (v21 - 2 * v22 + v23);
+    float Lyy = (v12 - 2 * v22 + v32);
+    float Lxy = (v13 - v11 + v31 - v33) / 4.0f;
+    o = (Lxx * Lyy - Lxy * Lxy) * (jb.norm * jb.norm);
+  }
+  jb.resp[(size_t)dy * cols + dx] = o;
 }
 
 // ---------------------------------------------------------------------------------------
