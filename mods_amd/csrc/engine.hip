@@ -360,7 +360,9 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
   hipStream_t s = c->stream;
   if (!c->cand.ensure((size_t)CAND_CAP * sizeof(Candidate)) || !c->nmsQueue.ensure((size_t)CAND_CAP * 16)) return MODSX_ERR_NOMEM;
   if (!c->counter.ensure((NMS_QUEUES + 1) * 128)) return MODSX_ERR_NOMEM;
-  MX_HIP(hipMemsetAsync(c->counter.p, 0, 8, s));   // [0] accepted candidates, [1] extremum-queue overflow flag
+  // [0] accepted candidates, [1] extremum-queue overflow flag, from word 32 on the sub-queue counters: one fill for the lot
+  MX_HIP(hipMemsetAsync(c->counter.p, 0, 128 + NMS_QUEUES * 128, s));
+  bool queuesClean = true;   // the sub-queue counters are zero (no scan has run since the fill)
   // thresholds, affinedetectors/pyramid.h:47-67 (DET_HESSIAN)
   NmsBatch nb;
   memset(&nb, 0, sizeof nb);
@@ -390,7 +392,8 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
     launch_expand_tiles(s, (const int *)((char *)c->nmsJobs.p + jobBytes), nj, (int *)c->tileJob.p);
     {
       ProfScope ps(c, K_NMS, px * 12);
-      MX_HIP(hipMemsetAsync((unsigned *)c->counter.p + 32, 0, NMS_QUEUES * 128, s));
+      if (!queuesClean) MX_HIP(hipMemsetAsync((unsigned *)c->counter.p + 32, 0, NMS_QUEUES * 128, s));
+      queuesClean = false;
       launch_nms(s, nb, (const NmsJob *)c->nmsJobs.p, (const int *)((char *)c->nmsJobs.p + jobBytes), (const int *)c->tileJob.p, nj,
                  hpfx.back(), (int4 *)c->nmsQueue.p, (unsigned *)c->counter.p + 32, CAND_CAP, (Candidate *)c->cand.p,
                  (unsigned *)c->counter.p, CAND_CAP);
@@ -428,7 +431,7 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
     if (!c->tileJob.ensure((size_t)hpfx.back() * 4 + 4)) return MODSX_ERR_NOMEM;
     launch_expand_tiles(s, (const int *)((char *)c->nmsJobs.p + jobBytes), nj, (int *)c->tileJob.p);
     ProfScope ps(c, K_NMS, px * 12);
-    MX_HIP(hipMemsetAsync((unsigned *)c->counter.p + 32, 0, NMS_QUEUES * 128, s));
+    if (!queuesClean) MX_HIP(hipMemsetAsync((unsigned *)c->counter.p + 32, 0, NMS_QUEUES * 128, s));
     launch_nms(s, nb, (const NmsJob *)c->nmsJobs.p, (const int *)((char *)c->nmsJobs.p + jobBytes), (const int *)c->tileJob.p, nj,
                hpfx.back(), (int4 *)c->nmsQueue.p, (unsigned *)c->counter.p + 32, CAND_CAP, (Candidate *)c->cand.p,
                (unsigned *)c->counter.p, CAND_CAP);
