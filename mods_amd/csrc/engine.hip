@@ -1010,16 +1010,17 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       // algorithmic work of the describe STAGE per SURVEY section 8(d): the (P+2)^2 f32 window of every region read once
       // (booked here) + 128 B written per region (booked on k_describe); the arenas between the four kernels are an
       // artefact of the split and are not algorithmic bytes
+      if (pfxRowL.back() + pfxColL.back())
+        launch_expand_blur_tiles(s, dj, dPfxRL, dPfxCL, (int)nj, dNeed, btR, btC, (float2 *)c->rowStarts.p);
       { ProfScope ps(c, K_PATCH_SAMPLE, (double)windowFloats * 4);
-        launch_sample_rows(s, dj, dPfxRL, (int)nj, btR, pfxRowL.back(), (ImgRef *)c->imgRefs.p, dTaps, dNeed, (float *)c->scratchB.p,
-                           (float2 *)c->rowStarts.p, (float *)c->scratchC.p);
+        launch_sample_rows(s, dj, btR, pfxRowL.back(), (ImgRef *)c->imgRefs.p, dTaps, dNeed, (float *)c->scratchB.p,
+                           (const float2 *)c->rowStarts.p, (float *)c->scratchC.p);
         launch_patch_sample(s, dj, dPfxS, tjS, pfxSample.back(), (ImgRef *)c->imgRefs.p, (float *)c->scratchA.p); }
       { ProfScope ps(c, K_BLUR_ROWS, 0.0);
         launch_patch_blur(s, dj, dPfxR, tjR, pfxRow.back(), dTaps, dNeed, (float *)c->scratchA.p,
                           (float *)c->scratchB.p, 0); }
       { ProfScope ps(c, K_BLUR_COLS, 0.0);
-        launch_blur_lds(s, dj, dPfxCL, (int)nj, btC, pfxColL.back(), dTaps, dNeed, (float *)c->scratchB.p,
-                        (float *)c->scratchC.p, 1);
+        launch_blur_cols(s, btC, pfxColL.back(), dTaps, dNeed, (float *)c->scratchB.p, (float *)c->scratchC.p);
         launch_patch_blur(s, dj, dPfxC, tjC, pfxCol.back(), dTaps, dNeed, (float *)c->scratchB.p,
                           (float *)c->scratchC.p, 1); }
       ProfScope psd(c, K_DESCRIBE, (double)nj * 128);

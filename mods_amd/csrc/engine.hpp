@@ -193,10 +193,12 @@ void launch_orientation(hipStream_t s, const OriJob *jobs, OriOut *out, int n, c
                         const unsigned short *maskIdx, const float *maskW,
                         const double *atanLut, int doHalf, double th, int maxAngles);
 void launch_trunc_u8(hipStream_t s, const float *src, uint8_t *dst, size_t n);
-void launch_sample_rows(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
-                        const ImgRef *imgs, const float *taps, const int *needTab, float *dst, float2 *rowStarts, float *dstGrid);
-void launch_blur_lds(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
-                     const float *taps, const int *needTab, const float *src, float *dst, int pass);
+void launch_expand_blur_tiles(hipStream_t s, const DescJob *jobs, const int *prefixRows, const int *prefixCols, int nJobs,
+                              const int *needTab, BlurTile *tilesRows, BlurTile *tilesCols, float2 *rowStarts);
+void launch_sample_rows(hipStream_t s, const DescJob *jobs, const BlurTile *tiles, int nTiles, const ImgRef *imgs, const float *taps,
+                        const int *needTab, float *dst, const float2 *rowStarts, float *dstGrid);
+void launch_blur_cols(hipStream_t s, const BlurTile *tiles, int nTiles, const float *taps, const int *needTab, const float *src,
+                      float *dst);
 void launch_expand_tiles(hipStream_t s, const int *prefix, int nJobs, int *tileJob);
 void launch_patch_sample(hipStream_t s, const DescJob *jobs, const int *tilePrefix, const int *tileJob, int nTiles,
                          const ImgRef *imgs, float *scratch);

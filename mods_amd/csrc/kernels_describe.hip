@@ -46,15 +46,18 @@ __global__ __launch_bounds__(64) void k_expand_tiles(const int *prefix, int nJob
 
 // tile descriptors of the LDS blur kernels: everything a workgroup needs in one 48-byte scalar load, so that its first
 // vector loads (the inputs it parks in LDS) are two dependent round trips from the launch instead of three
-__global__ __launch_bounds__(64) void k_expand_blur_tiles(const DescJob *jobs, const int *prefix, int nJobs, const int *needTab,
-                                                          BlurTile *tiles, int pass, float2 *rowStart) {
-  const int j = blockIdx.x;
+// (blockIdx.y = pass: 0 = the row tiles of the fused sampling kernel, 1 = the tiles of the column filter)
+__global__ __launch_bounds__(64) void k_expand_blur_tiles(const DescJob *jobs, const int *prefix0, const int *prefix1, int nJobs,
+                                                          const int *needTab, BlurTile *tiles0, BlurTile *tiles1, float2 *rowStart) {
+  const int j = blockIdx.x, pass = blockIdx.y;
   if (j >= nJobs) return;
+  const int *prefix = pass ? prefix1 : prefix0;
+  BlurTile *tiles = pass ? tiles1 : tiles0;
   const int b = prefix[j], e = prefix[j + 1];
   if (b == e) return;
   const DescJob jb = jobs[j];
   const int R = jb.ksize >> 1;
-  if (rowStart && threadIdx.x == 63) {
+  if (pass == 0 && threadIdx.x == 63) {
     // row starts of interpolate() (rx += a12, ry += a22 per row, helpers.cpp:563-566): one serial chain per window, run
     // here once instead of by every row tile of the fused sampling kernel (a tile of a large window is a few rows only)
     float2 *rs = rowStart + jb.scratchOfs;
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(256) void k_patch_blur(const DescJob *jobs, const i
 //   cols:  a tile is jb.ro1 consecutive needed rows; it parks the source rows need[first] - R .. need[last] + R
 // Jobs whose tile does not fit BLUR_LDS floats have rows0 / ro1 = 0 and go through k_patch_blur.
 constexpr int BLUR_T = 256, BLUR_W = BLUR_T / 64;   // threads / waves per workgroup of the LDS blur kernels
-constexpr int BLUR_LDS = 4992, BLUR_OUT = 2048, FILL_MLP = 20;   // row filter: 20 KB, 8 workgroups per CU
+constexpr int BLUR_LDS = 4992;   // row tile of the fused sampling + row-filter kernel: 20 KB
 constexpr int BLUR_LDS_C = 9984;                               // column filter: fatter tiles re-read fewer halo rows
 
 // the row filter proper, on a tile parked in LDS as nr rows of R + P + R floats (replicated border written out)
@@ -404,39 +407,6 @@ __device__ __forceinline__ void blur_cols_from_lds(int NC, int n, int ro0, int n
       }
     }
   }
-}
-
-__global__ __launch_bounds__(BLUR_T, 8) void k_blur_rows_lds(const BlurTile *__restrict__ tiles, const float *__restrict__ taps,
-                                                       const int *__restrict__ needTab, const float *__restrict__ src,
-                                                       float *__restrict__ dst) {
-  const BlurTile bt = tiles[xcd_swizzle(blockIdx.x, gridDim.x)];
-  const int P = bt.P, NC = bt.NC;
-  const int n = bt.n, R = n >> 1, RW = P + 2 * R;
-  __shared__ float win[BLUR_LDS + 2];   // + 2: the idle partner of an odd last column reads one word past its row
-  __shared__ int sneed[96];
-  const int nr = bt.count;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < NC; i += BLUR_T) sneed[i] = needTab[bt.needOfs + i];
-  const float *A = src + bt.srcOfs;
-  // a wave parks rows wave, wave + 4, ... with direct global -> LDS loads (global_load_lds_dword: per-lane source address,
-  // destination = a wave-uniform LDS base + 4 * lane): no staging registers, no LDS write pass, and all of a tile's loads
-  // are in flight together
-  {
-    typedef const float __attribute__((address_space(1))) *gptr;
-    typedef float __attribute__((address_space(3))) *lptr;
-    for (int ri = wave; ri < nr; ri += BLUR_W) {
-      const float *a = A + (size_t)ri * P;
-      for (int x0 = 0; x0 < RW; x0 += 64) {
-        const int x = x0 + lane;
-        int cc = x - R;
-        cc = cc < 0 ? 0 : (cc > P - 1 ? P - 1 : cc);
-        if (x < RW) __builtin_amdgcn_global_load_lds((gptr)(a + cc), (lptr)(win + ri * RW + x0), 4, 0, 0);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
-  blur_rows_from_lds(bt, win, sneed, taps, dst + bt.dstOfs, NC);
 }
 
 // Stage 1 + the row pass of stage 2 in one launch: a workgroup SAMPLES its tile of window rows (interpolate(), the f32
@@ -606,7 +576,6 @@ __global__ __launch_bounds__(BLUR_T) void k_blur_cols_lds(const BlurTile *__rest
 //     same for columns -- this is precomputeBinsAndWeights (siftdesc.cpp:22-71) for 4 spatial bins
 //     and patch 41, where step = 5/40 makes xi = i/8.
 constexpr int PS = 41, NPX = PS * PS, PSP = 44;  // PSP: padded row stride (16-byte aligned rows)
-constexpr int NMASK_MAX = 1300;
 
 struct SiftConst {
   int nmask;   // number of pixels with mask > 0
@@ -914,19 +883,20 @@ void launch_patch_sample(hipStream_t s, const DescJob *jobs, const int *tilePref
   if (nTiles <= 0) return;
   hipLaunchKernelGGL(k_patch_sample, dim3(8 * ((nTiles + 7) / 8)), dim3(64), 0, s, jobs, tilePrefix, tileJob, imgs, scratch, nTiles);
 }
-void launch_sample_rows(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
-                        const ImgRef *imgs, const float *taps, const int *needTab, float *dst, float2 *rowStarts, float *dstGrid) {
+void launch_expand_blur_tiles(hipStream_t s, const DescJob *jobs, const int *prefixRows, const int *prefixCols, int nJobs,
+                              const int *needTab, BlurTile *tilesRows, BlurTile *tilesCols, float2 *rowStarts) {
+  if (nJobs > 0) hipLaunchKernelGGL(k_expand_blur_tiles, dim3(nJobs, 2), dim3(64), 0, s, jobs, prefixRows, prefixCols, nJobs, needTab,
+                                    tilesRows, tilesCols, rowStarts);
+}
+void launch_sample_rows(hipStream_t s, const DescJob *jobs, const BlurTile *tiles, int nTiles, const ImgRef *imgs, const float *taps,
+                        const int *needTab, float *dst, const float2 *rowStarts, float *dstGrid) {
   if (nTiles <= 0) return;
-  hipLaunchKernelGGL(k_expand_blur_tiles, dim3(nJobs), dim3(64), 0, s, jobs, tilePrefix, nJobs, needTab, tiles, 0, rowStarts);
   hipLaunchKernelGGL(k_sample_rows_lds, dim3(8 * ((nTiles + 7) / 8)), dim3(BLUR_T), 0, s, tiles, jobs, imgs, taps, needTab, dst, nTiles,
                      rowStarts, dstGrid);
 }
-void launch_blur_lds(hipStream_t s, const DescJob *jobs, const int *tilePrefix, int nJobs, BlurTile *tiles, int nTiles,
-                     const float *taps, const int *needTab, const float *src, float *dst, int pass) {
-  if (nTiles <= 0) return;
-  hipLaunchKernelGGL(k_expand_blur_tiles, dim3(nJobs), dim3(64), 0, s, jobs, tilePrefix, nJobs, needTab, tiles, pass, (float2 *)nullptr);
-  if (pass == 0) hipLaunchKernelGGL(k_blur_rows_lds, dim3(nTiles), dim3(BLUR_T), 0, s, tiles, taps, needTab, src, dst);
-  else hipLaunchKernelGGL(k_blur_cols_lds, dim3(nTiles), dim3(BLUR_T), 0, s, tiles, taps, needTab, src, dst);
+void launch_blur_cols(hipStream_t s, const BlurTile *tiles, int nTiles, const float *taps, const int *needTab, const float *src,
+                      float *dst) {
+  if (nTiles > 0) hipLaunchKernelGGL(k_blur_cols_lds, dim3(nTiles), dim3(BLUR_T), 0, s, tiles, taps, needTab, src, dst);
 }
 void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix, const int *tileJob, int nTiles,
                        const float *taps, const int *needTab, const float *src, float *dst, int pass) {

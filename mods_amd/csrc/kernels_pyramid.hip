@@ -25,7 +25,7 @@ namespace mx {
 // ksize > 5) or centre + symmetric pairs (SymmRowSmallFilter, ksize <= 5); column pass is centre +
 // (below + above) * k (SymmColumnFilter) -- per output the same f32 operation order as the CPU filter engine.
 // ---------------------------------------------------------------------------------------
-constexpr int TW = 64, RMAX = 8;
+constexpr int TW = 64;
 constexpr int TMP_W = TW + 4;                 // 66 needed columns rounded up to a multiple of 4
 // The tile height is a template parameter: 32 rows for the large levels (less halo per output), 16 rows when a whole launch
 // is under two rounds of 32-row tiles (small octaves: twice the workgroups, shorter per-workgroup chains; 6 % of the

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_views_rotblur(const ViewJob *jobs, int 
   const int Rx = v.kx >> 1, Ry = v.ky >> 1;
   const int t = blockIdx.x - v.tileF, tx = (v.rcols + VF_TW - 1) / VF_TW;
   const int x0 = (t % tx) * VF_TW, y0 = (t / tx) * VF_TH;
-  const int WW = VF_TW + 2 * Rx, HH = VF_TH + 2 * Ry;
+  const int WW = VF_TW + 2 * Rx;
   float *const Wt = smem, *const Tt = smem + wFloats;
   const int lane = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int xEnd = min(VF_TW, v.rcols - x0) + 2 * Rx, yEnd = min(VF_TH, v.rrows - y0) + 2 * Ry;   // what the tile's outputs reach
