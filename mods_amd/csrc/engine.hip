@@ -638,12 +638,16 @@ void detect_affine_regions(const modsx_keypoint *kps, int n, int img_id, int det
 static const double K_SIGMA = 2 * 3.0 * sqrt(3.0);  // synth-detection.cpp:28
 
 static int upload_img_refs(modsx_ctx *c, const modsx_image *const *imgs, int n) {
+  const bool fresh = !c->imgRefs.p;
   if (!c->imgRefs.ensure(MAXB * sizeof(ImgRef))) return MODSX_ERR_NOMEM;
   ImgRef refs[MAXB];
   memset(refs, 0, sizeof refs);
   for (int i = 0; i < n; i++) { refs[i].d = imgs[i]->d; refs[i].rows = imgs[i]->rows; refs[i].cols = imgs[i]->cols; }
+  // orientation and description of a launch set name the same images: the table on the device is already right
+  if (!fresh && memcmp(refs, c->imgRefsHost, sizeof refs) == 0) return MODSX_OK;
   MX_HIP(hipMemcpyAsync(c->imgRefs.p, refs, sizeof refs, hipMemcpyHostToDevice, c->stream));
   MX_HIP(hipStreamSynchronize(c->stream));  // refs[] is a stack buffer
+  memcpy(c->imgRefsHost, refs, sizeof refs);
   return MODSX_OK;
 }
 
