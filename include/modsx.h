@@ -164,6 +164,7 @@ void modsx_default_pair_params(modsx_pair_params *p);
 /* Image upload.  dtype 0 = u8, 1 = f32; channels 1 or 3 (BGR as cv::imread gives).  3-channel input is
  * converted with the reference's (B+G+R)/3 rule: GenerateSynthImageCorr, synth-detection.cpp:253-262
  * (identity view: out_img.pixels = gray, :278-289). */
+/* images are limited to 16384 px per side and 64 Mpx (32-bit pixel addressing in the samplers); larger ones are refused */
 modsx_image *modsx_image_upload(modsx_ctx *ctx, const void *pixels, int rows, int cols, int channels, int dtype);
 /* wrap pixels that already live in HBM (f32, 1 channel, dense rows); not owned */
 modsx_image *modsx_image_wrap_device(modsx_ctx *ctx, const float *dev_pixels, int rows, int cols);

@@ -76,11 +76,23 @@ void modsx_default_pair_params(modsx_pair_params *p) {
   modsx_default_mser_params(&p->mser);
 }
 
+// the samplers address a pixel by a 24-bit row x column product and a 32-bit byte offset from the image base (kmath.hpp,
+// bilinear_tap); views and pyramid levels are never larger than the image they come from by more than the rotation's
+// bounding box (< 2x per side), so the bound is taken with that margin
+static bool image_size_ok(int rows, int cols) {
+  if (rows > 16384 || cols > 16384 || (long long)rows * cols > (1ll << 26)) {
+    mx::set_error("image larger than 16384 px per side / 64 Mpx is not supported");
+    return false;
+  }
+  return true;
+}
+
 modsx_image *modsx_image_upload(modsx_ctx *ctx, const void *pixels, int rows, int cols, int channels, int dtype) {
   if (!ctx || !pixels || rows <= 0 || cols <= 0 || (channels != 1 && channels != 3) || (dtype != 0 && dtype != 1)) {
     mx::set_error("modsx_image_upload: bad argument");
     return nullptr;
   }
+  if (!image_size_ok(rows, cols)) return nullptr;
   hipSetDevice(ctx->dev);
   const size_t n = (size_t)rows * cols;
   const size_t inBytes = n * channels * (dtype == 0 ? 1 : 4);
@@ -98,6 +110,7 @@ modsx_image *modsx_image_upload(modsx_ctx *ctx, const void *pixels, int rows, in
 
 modsx_image *modsx_image_wrap_device(modsx_ctx *ctx, const float *dev_pixels, int rows, int cols) {
   if (!ctx || !dev_pixels || rows <= 0 || cols <= 0) { mx::set_error("modsx_image_wrap_device: bad argument"); return nullptr; }
+  if (!image_size_ok(rows, cols)) return nullptr;
   modsx_image *im = new modsx_image();
   im->d = const_cast<float *>(dev_pixels); im->rows = rows; im->cols = cols; im->owned = false;
   return im;

@@ -130,7 +130,7 @@ MX_HD gcfloat_p as_global(const float *p) { return (gcfloat_p)p; }
 // Addressing: the four neighbours are read at 32-bit BYTE offsets from the (wave-uniform) image base -- one 24-bit
 // multiply, an add and a shift per tap, and the loads take the scalar base + vector offset form; the 64-bit
 // multiply-add per row pointer this replaces was a third of the instructions of a tap.  An image level is far below
-// 2^30 pixels (rows, cols < 2^24 is checked where images are created).
+// 2^30 pixels (images are limited to 16384 px per side / 64 Mpx where they are created, capi.hip image_size_ok).
 template <class PT>
 MX_D float bilinear_blend(PT im, int cols, int x, int y, float WX, float WY) {
   const unsigned off = (__umul24((unsigned)y, (unsigned)cols) + (unsigned)x) << 2;

@@ -362,6 +362,11 @@ def test_degenerate_inputs_do_not_break_the_path(ctx, modsx, oracle):
     assert done == 1 and got["n_verified"] == 0
     for im in ims.values():
         im.free()
+    # beyond the samplers' 32-bit pixel addressing: refused, not mis-sampled
+    with pytest.raises(RuntimeError):
+        ctx.upload(np.zeros((2, 16385), np.uint8))
+    with pytest.raises(RuntimeError):
+        ctx.wrap_device(1 << 20, 16384, 8192)
 
 
 def test_full_hd_pair_runs(ctx, modsx):
