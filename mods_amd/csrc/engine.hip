@@ -136,6 +136,25 @@ static int upload_tables(modsx_ctx *c) {
   }
   MX_HIP(hipMalloc(&c->dAtan, 256 * 8));
   MX_HIP(hipMemcpy(c->dAtan, atan_lut_host(), 256 * 8, hipMemcpyHostToDevice));
+  {
+    // What the gradient stages need of atan2LUTff's angle is a function of it: the histogram bin (orientation) and the
+    // fractional SIFT orientation bin (description).  The angle takes 8 x 256 values (kmath.hpp: atan2lut_case / _value) and
+    // 0 in the special case (entry 2048), so both functions are tabulated here with the kernels' own expressions.
+    std::vector<unsigned char> obin(ATAN_CASES);
+    std::vector<float> so(ATAN_CASES);
+    const double *L = atan_lut_host();
+    const float PIf = float(M_PI);
+    const double TWO_PI = 6.28318530718;
+    for (int e = 0; e < ATAN_CASES; e++) {
+      const float ori = e < 2048 ? atan2lut_value(L, e >> 8, e & 255) : 0.f;
+      obin[e] = (unsigned char)(int)(36 * (ori / PIf + 1.0f) / 2.0f);          // synth-detection.cpp:781-786 as in k_orientation
+      so[e] = (float)((double)8.0f * ((double)ori + TWO_PI) / TWO_PI);         // siftdesc.cpp:103-110 as in k_describe
+    }
+    MX_HIP(hipMalloc(&c->dOriBinTab, ATAN_CASES));
+    MX_HIP(hipMemcpy(c->dOriBinTab, obin.data(), ATAN_CASES, hipMemcpyHostToDevice));
+    MX_HIP(hipMalloc(&c->dSiftOTab, ATAN_CASES * 4));
+    MX_HIP(hipMemcpy(c->dSiftOTab, so.data(), ATAN_CASES * 4, hipMemcpyHostToDevice));
+  }
   // precomputeBinsAndWeights, matching/siftdesc.cpp:22-71 (spatialBins 4, orientationBins 8, patch 41)
   int bins[2 * PS];
   double w[2 * PS];
@@ -193,7 +212,7 @@ void ctx_destroy(modsx_ctx *c) {
   for (int i = 0; i < MAXB; i++) { c->descF[i].release(); c->descU8[i].release(); c->viewImg[i].release(); }
   PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc, &c->hNms, &c->hMatch, &c->hViewTaps, &c->hViewJobs};
   for (PinBuf *b : pins) b->release();
-  hipFree(c->dSmmMask); hipFree(c->dOriMask); hipFree(c->dOriIdx); hipFree(c->dSiftMask); hipFree(c->dSiftMaskIdx); hipFree(c->dAtan); hipFree(c->dSiftBins);
+  hipFree(c->dSmmMask); hipFree(c->dOriMask); hipFree(c->dOriIdx); hipFree(c->dSiftMask); hipFree(c->dSiftMaskIdx); hipFree(c->dAtan); hipFree(c->dOriBinTab); hipFree(c->dSiftOTab); hipFree(c->dSiftBins);
   hipFree(c->dSiftW);
   for (int i = 0; i < 8; i++) hipEventDestroy(c->ev[i]);
   for (int i = 0; i < 2; i++) hipEventDestroy(c->descEv[i]);
@@ -703,7 +722,7 @@ int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n
     int maxA = maxAngNum == -1 ? 7 : std::min(maxAngNum, 7);
     ProfScope ps(c, K_ORIENT, (double)nj * 41 * 41 * 4);
     launch_orientation(s, (OriJob *)c->oriJobs.p, (OriOut *)c->oriOut.p, (int)nj, (ImgRef *)c->imgRefs.p, c->dOriIdx,
-                       c->dOriMask, c->dAtan, doHalfSIFT, th, maxA);
+                       c->dOriMask, c->dOriBinTab, doHalfSIFT, th, maxA);
     MX_HIP(hipMemcpyAsync(hres, c->oriOut.p, nj * sizeof(OriOut), hipMemcpyDeviceToHost, s));
     MX_HIP(hipStreamSynchronize(s));
   }
@@ -1029,7 +1048,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
                           (float *)c->scratchC.p, 1); }
       ProfScope psd(c, K_DESCRIBE, (double)nj * 128);
       launch_describe(s, dj, (int)nj, (ImgRef *)c->imgRefs.p, (float *)c->scratchC.p, dNeed, dCoord,
-                      c->dSiftMask, c->dSiftMaskIdx, c->nSiftMask, c->dAtan,
+                      c->dSiftMask, c->dSiftMaskIdx, c->nSiftMask, c->dSiftOTab,
                       c->dSiftBins, c->dSiftW, photoNorm, descType, maxBin, outs);
       chunkNo++;
     }

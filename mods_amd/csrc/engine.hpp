@@ -188,10 +188,11 @@ constexpr int NMS_TILE_ROWS = 16;   // rows of a 64-column NMS tile (kernels_pyr
 void launch_gray(hipStream_t s, const void *src, float *dst, size_t n, int channels, int dtype);
 void launch_baumberg(hipStream_t s, const AffJob *jobs, AffOut *out, int n, const float *mask, int W, int maxIter,
                      float convTh, float affInitialSigma);
+constexpr int ATAN_CASES = 2048 + 64;   // 8 x 256 (sign / octant bits, table index) values of atan2LUTff's angle + the special case (entry 2048), padded
 constexpr int ORI_NV = 1280;   // entries of the orientation kernel's voting-pixel list (1245 under the mask, padded)
 void launch_orientation(hipStream_t s, const OriJob *jobs, OriOut *out, int n, const ImgRef *imgs,
                         const unsigned short *maskIdx, const float *maskW,
-                        const double *atanLut, int doHalf, double th, int maxAngles);
+                        const unsigned char *binTab, int doHalf, double th, int maxAngles);
 void launch_trunc_u8(hipStream_t s, const float *src, uint8_t *dst, size_t n);
 void launch_expand_blur_tiles(hipStream_t s, const DescJob *jobs, const int *prefixRows, const int *prefixCols, int nJobs,
                               const int *needTab, BlurTile *tilesRows, BlurTile *tilesCols, float2 *rowStarts);
@@ -206,7 +207,7 @@ void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix
                        const float *taps, const int *needTab, const float *src, float *dst, int pass);
 void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *imgs, const float *grid,
                      const int *needTab, const float *coordTab,
-                     const float *mask, const unsigned short *maskIdx, int nmask, const double *atanLut, const int *bins,
+                     const float *mask, const unsigned short *maskIdx, int nmask, const float *oTab, const int *bins,
                      const double *wts, int photoNorm, int descType, double maxBin, const DescOut &outs);
 void launch_warp_affine(hipStream_t s, const WarpJob &jb);
 void launch_blur_pass(hipStream_t s, const float *src, float *dst, int rows, int cols, const float *taps, int n, int pass, int border = 0);
@@ -269,6 +270,8 @@ struct modsx_ctx {
   unsigned short *dSiftMaskIdx = nullptr;  // raster-ordered indices of the pixels with mask > 0
   int nSiftMask = 0;
   double *dAtan = nullptr;
+  unsigned char *dOriBinTab = nullptr;   // histogram bin of every atan2LUT angle (ATAN_CASES entries)
+  float *dSiftOTab = nullptr;            // fractional SIFT orientation bin of every atan2LUT angle
   int *dSiftBins = nullptr;    // bin0[41], bin1[41]
   double *dSiftW = nullptr;    // w0[41], w1[41]
   hipEvent_t ev[8];

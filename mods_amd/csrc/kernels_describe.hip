@@ -584,7 +584,7 @@ struct SiftConst {
 __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, const ImgRef *imgs, const float *grid,
                                                   const int *needTab, const float *coordTab,
                                                   const float *mask, const unsigned short *maskIdx,
-                                                  const double *atanLut, const int *binTab, const double *wTab,
+                                                  const float *oTab, const int *binTab, const double *wTab,
                                                   SiftConst sc, int photoNorm, int descType, double maxBin,
                                                   DescOut outs) {
   const int k = blockIdx.x;
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
   float *const patch = patchB, *const bufB = patchB;
   constexpr int PER_T = (NPX + 127) / 128;
   __shared__ __attribute__((aligned(16))) float bufA[PS * PSP];   // WX (direct branch), compacted masked values, later val
-  __shared__ __attribute__((aligned(16))) double slut[256];   // ATAN_LUT (2 KB) next to the CU
+  __shared__ __attribute__((aligned(16))) double slut[256];   // the descriptor vector and its partial sums (2 KB)
   __shared__ __attribute__((aligned(16))) unsigned char sb0[PS * PSP];   // orientation bin bo0 % 8 of every pixel
   __shared__ float swr0[PS], swr1[PS];
   // 1 KB used twice: the resampling table of the sampling stage (smap, sfr), later the per-step weighted values of the
@@ -612,7 +612,6 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
   __shared__ double sfac;
   __shared__ int schanged;
   const DescJob jb = jobs[k];
-  { const double l0 = atanLut[tid], l1 = atanLut[tid + 128]; slut[tid] = l0; slut[tid + 128] = l1; }
   if (tid < PS) {
     swr0[tid] = (float)wTab[tid]; swr1[tid] = (float)wTab[PS + tid];   // const float wr0 = w0[r] (siftdesc.cpp:79-81)
     swc0[tid] = wTab[tid]; swc1[tid] = wTab[PS + tid];
@@ -738,7 +737,6 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
     __syncthreads();
   }
   // -- gradients, orientation, per-pixel weights (siftdesc.cpp:346-379, 73-131)
-  const double TWO_PI = 6.28318530718;
   float ov[PER_T];
 #pragma unroll
   for (int k = 0; k < PER_T; k++) {
@@ -754,9 +752,15 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
     else if (r == PS - 1) yg = patch[p] - patch[p - PS];
     else yg = patch[p + PS] - patch[p - PS];
     const float g = sqrtf(xg * xg + yg * yg);
-    const float ori = atan2lut(slut, yg, xg);
-    const float val = (float)(0.0 + (1.0 * (double)mask[p]) * (double)g);
-    const float o = (float)((double)8.0f * ((double)ori + TWO_PI) / TWO_PI);
+    // o = (float)(8 * (ori + 2 pi) / (2 pi)) of ori = atan2LUTff(yg, xg) (siftdesc.cpp:103-110): the angle takes one of 8 x 256 + 1
+    // values, so o comes from a table built with that f64 expression (engine.hip: upload_tables) -- no f64 look-up, add and
+    // division per pixel
+    int code, idx;
+    const bool special = atan2lut_case(yg, xg, code, idx);
+    // val = (float)(0.0 + (1.0 * (double)mask) * (double)g) in the reference: the f64 product of two f32 values is exact (48
+    // significant bits), so rounding it to f32 IS the f32 product; mask, g >= 0, so the + 0.0 changes nothing
+    const float val = mask[p] * g;
+    const float o = oTab[special ? 2048 : code * 256 + idx];
     const int bo0 = (int)o;
     ov[k] = o - (float)bo0;              // wo1 (siftdesc.cpp:111-117), formed once per pixel instead of once per bin
     sb0[r * PSP + c] = (unsigned char)(bo0 % 8);   // o >= 0, so bo0 % 8 is in 0..7
@@ -904,12 +908,12 @@ void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix
   hipLaunchKernelGGL(k_patch_blur, dim3(nTiles), dim3(256), 0, s, jobs, tilePrefix, tileJob, taps, needTab, src, dst, pass);
 }
 void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *imgs, const float *grid,
-                     const int *needTab, const float *coordTab, const float *mask, const unsigned short *maskIdx, int nmask, const double *atanLut, const int *bins,
+                     const int *needTab, const float *coordTab, const float *mask, const unsigned short *maskIdx, int nmask, const float *oTab, const int *bins,
                      const double *wts, int photoNorm, int descType, double maxBin, const DescOut &outs) {
   if (n <= 0) return;
   SiftConst sc;
   sc.nmask = nmask;
-  hipLaunchKernelGGL(k_describe, dim3(n), dim3(128), 0, s, jobs, n, imgs, grid, needTab, coordTab, mask, maskIdx, atanLut, bins,
+  hipLaunchKernelGGL(k_describe, dim3(n), dim3(128), 0, s, jobs, n, imgs, grid, needTab, coordTab, mask, maskIdx, oTab, bins,
                      wts, sc,
                      photoNorm, descType, maxBin, outs);
 }

@@ -17,22 +17,24 @@ constexpr int ORI_B = 21;          // taps of a patch row in flight per lane
 
 __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *out, int n, const ImgRef *imgs,
                                                     const unsigned short *maskIdx, const float *maskW,
-                                                    const double *atanLut, int doHalf, double th, int maxAngles) {
+                                                    const unsigned char *binTab, int doHalf, double th, int maxAngles) {
   const int k = blockIdx.x;
   if (k >= n) return;
   const int lane = threadIdx.x;
   // 11 KB of LDS per region (14 regions resident per CU): the patch, later overwritten by the histogram weights, the
-  // bin indices and the ATAN_LUT
+  // bin indices and the bin of every atan2LUT angle
   __shared__ __attribute__((aligned(16))) float bufX[PS * PSP];
   __shared__ __attribute__((aligned(16))) unsigned char sbin[PS * PSP];
-  __shared__ double slut[256];
+  __shared__ __attribute__((aligned(16))) unsigned char sbt[ATAN_CASES];
   __shared__ float hist[40];
-  {   // ATAN_LUT: four independent loads per lane, issued together
-    double t[4];
+  static_assert(ATAN_CASES == 33 * 64, "one 4-byte word per lane and step");
+  {   // the bin table: independent loads per lane, issued together
+    unsigned t[9];
 #pragma unroll
-    for (int u = 0; u < 4; u++) t[u] = atanLut[lane + 64 * u];
+    for (int u = 0; u < 9; u++) t[u] = lane + 64 * u < ATAN_CASES / 4 ? reinterpret_cast<const unsigned *>(binTab)[lane + 64 * u] : 0u;
 #pragma unroll
-    for (int u = 0; u < 4; u++) slut[lane + 64 * u] = t[u];
+    for (int u = 0; u < 9; u++)
+      if (lane + 64 * u < ATAN_CASES / 4) reinterpret_cast<unsigned *>(sbt)[lane + 64 * u] = t[u];
   }
   const OriJob jb = jobs[k];
   const ImgRef im = imgs[jb.img];
@@ -93,11 +95,14 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
     const float xg = bufX[p + 1] - bufX[p - 1];
     const float yg = bufX[p + PSP] - bufX[p - PSP];
     const float mag = sqrtf(xg * xg + yg * yg);
-    const float ori = atan2lut(slut, yg, xg);
+    // bin = (int)(36 * (ori / pi + 1) / 2) of ori = atan2LUTff(yg, xg): the angle takes one of 8 x 256 + 1 values, so the
+    // bin comes from a table built with that expression (engine.hip: upload_tables) -- no f64 look-up, no division by pi
+    int code, idx;
+    const bool special = atan2lut_case(yg, xg, code, idx);
     unsigned char bin = 255;
     float w = 0.f;
     if (m > 0 && mag > 1.0f) {
-      bin = (unsigned char)(int)(36 * (ori / PIf + 1.0f) / 2.0f);
+      bin = sbt[special ? 2048 : code * 256 + idx];
       w = mag * m;
     }
     wreg[q] = w; breg[q] = bin;
@@ -184,10 +189,10 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
 }
 
 void launch_orientation(hipStream_t s, const OriJob *jobs, OriOut *out, int n, const ImgRef *imgs,
-                          const unsigned short *maskIdx, const float *maskW, const double *atanLut, int doHalf, double th,
+                          const unsigned short *maskIdx, const float *maskW, const unsigned char *binTab, int doHalf, double th,
                           int maxAngles) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_orientation, dim3(n), dim3(64), 0, s, jobs, out, n, imgs, maskIdx, maskW, atanLut, doHalf, th,
+  hipLaunchKernelGGL(k_orientation, dim3(n), dim3(64), 0, s, jobs, out, n, imgs, maskIdx, maskW, binTab, doHalf, th,
                      maxAngles);
 }
 

@@ -19,14 +19,24 @@ namespace mx {
 // Written without branches -- one division, one look-up, selects -- because the eight paths of a wavefront would
 // otherwise run one after the other.  (float)(-L) and (float)(L) are kept as plain negation / identity so that the sign
 // of a zero result is the reference's.
-MX_HD float atan2lut(const double *L, float y, float x) {
-  const float PI_2f = 1.57079632679489661923f, PIf = 3.14159265358979323846f;
+// Split in two so that a kernel that only needs a FUNCTION of the angle can tabulate it: the result depends on (y, x) only
+// through the table index, three sign / octant bits and one special case, 8 x 256 + 1 possible values in all.
+//   atan2lut_case:  code = xp << 2 | yp << 1 | big, idx = clamped table index; returns true for the special case
+//                   (x == 0 with y <= 0: the reference returns 0 there)
+//   atan2lut_value: the angle of (code, idx)
+MX_HD bool atan2lut_case(float y, float x, int &code, int &idx) {
   const float ax = fabsf(x), ay = fabsf(y);
   const bool xp = x > 0.f, yp = y > 0.f, big = ax > ay;
   const float num = big ? ay : ax, den = big ? ax : ay;
-  const float q = 255.f * num / den;           // NaN only for x = y = 0, which returns 0 below
-  int idx = (int)q;
-  idx = idx < 0 ? 0 : (idx > 255 ? 255 : idx);
+  const float q = 255.f * num / den;           // NaN only for x = y = 0, which is the special case
+  int i = (int)q;
+  idx = i < 0 ? 0 : (i > 255 ? 255 : i);
+  code = (xp ? 4 : 0) | (yp ? 2 : 0) | (big ? 1 : 0);
+  return !xp && !yp && !big && x == 0.f;
+}
+MX_HD float atan2lut_value(const double *L, int code, int idx) {
+  const float PI_2f = 1.57079632679489661923f, PIf = 3.14159265358979323846f;
+  const bool xp = code & 4, yp = code & 2, big = code & 1;
   const double Lv = L[idx];
   // x>0,y>0: L | pi/2 - L      x>0,y<=0: -L | -pi/2 + L      x<=0,y>0: pi - L | pi/2 + L      x<=0,y<=0: -pi + L | -pi/2 - L
   const bool neg = xp ? (yp ? !big : big) : (yp ? big : !big);
@@ -34,8 +44,13 @@ MX_HD float atan2lut(const double *L, float y, float x) {
   double c;
   if (big) c = xp ? 0.0 : (yp ? (double)PIf : (double)(-PIf));
   else c = yp ? (double)PI_2f : (double)(-PI_2f);
-  const float r = (big && xp) ? (float)sL : (float)(c + sL);
-  return (!xp && !yp && !big && x == 0.f) ? 0.f : r;
+  return (big && xp) ? (float)sL : (float)(c + sL);
+}
+MX_HD float atan2lut(const double *L, float y, float x) {
+  int code, idx;
+  const bool special = atan2lut_case(y, x, code, idx);
+  const float r = atan2lut_value(L, code, idx);
+  return special ? 0.f : r;
 }
 
 // solveLinear3x3, detectors/helpers.cpp:309-368
