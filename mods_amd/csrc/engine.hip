@@ -173,6 +173,8 @@ static int upload_tables(modsx_ctx *c) {
     if (b1 >= spatialBins) { b1 = spatialBins - 1; w1 = 0; }
     bins[i] = b0 * orientationBins; bins[PS + i] = b1 * orientationBins;
     w[i] = w0; w[PS + i] = w1;
+    // k_describe forms (float)(w * (double)val) as an f32 product, which is the same number when w is an f32 value
+    if ((double)(float)w0 != w0 || (double)(float)w1 != w1) { set_error("SIFT spatial weights are not f32 values"); return MODSX_ERR_ARG; }
   }
   MX_HIP(hipMalloc(&c->dSiftBins, sizeof bins));
   MX_HIP(hipMemcpy(c->dSiftBins, bins, sizeof bins, hipMemcpyHostToDevice));

@@ -605,7 +605,6 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
   int4 *const smap = reinterpret_cast<int4 *>(sraw);
   float *const sfr = reinterpret_cast<float *>(sraw + 672);
   float(*const sv)[64] = reinterpret_cast<float(*)[64]>(sraw);
-  __shared__ double swc0[PS], swc1[PS];
   // the descriptor vector and its partial sums take the place of the ATAN_LUT, which is dead once the gradients are taken
   double *const vec = slut, *const part = slut + 128;
   __shared__ float sstat[2];
@@ -614,7 +613,6 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
   const DescJob jb = jobs[k];
   if (tid < PS) {
     swr0[tid] = (float)wTab[tid]; swr1[tid] = (float)wTab[PS + tid];   // const float wr0 = w0[r] (siftdesc.cpp:79-81)
-    swc0[tid] = wTab[tid]; swc1[tid] = wTab[PS + tid];
   }
   if (jb.P > 0) {
     // interpolate(smoothed, P/2, P/2, i2p, 0, 0, i2p, patch) (synth-detection.hpp:211-212) on the compact blurred grid:
@@ -744,13 +742,10 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
     ov[k] = 0.f;
     if (p >= NPX) continue;
     const int r = p / PS, c = p - r * PS;
-    float xg, yg;
-    if (c == 0) xg = patch[p + 1] - patch[p];
-    else if (c == PS - 1) xg = patch[p] - patch[p - 1];
-    else xg = patch[p + 1] - patch[p - 1];
-    if (r == 0) yg = patch[p + PS] - patch[p];
-    else if (r == PS - 1) yg = patch[p] - patch[p - PS];
-    else yg = patch[p + PS] - patch[p - PS];
+    // one-sided differences on the patch's frame, central ones inside (siftdesc.cpp:346-360): the neighbour that does not
+    // exist is the pixel itself -- no per-pixel branch
+    const float xg = patch[c == PS - 1 ? p : p + 1] - patch[c == 0 ? p : p - 1];
+    const float yg = patch[r == PS - 1 ? p : p + PS] - patch[r == 0 ? p : p - PS];
     const float g = sqrtf(xg * xg + yg * yg);
     // o = (float)(8 * (ori + 2 pi) / (2 pi)) of ori = atan2LUTff(yg, xg) (siftdesc.cpp:103-110): the angle takes one of 8 x 256 + 1
     // values, so o comes from a table built with that f64 expression (engine.hip: upload_tables) -- no f64 look-up, add and
@@ -763,7 +758,7 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
     const float o = oTab[special ? 2048 : code * 256 + idx];
     const int bo0 = (int)o;
     ov[k] = o - (float)bo0;              // wo1 (siftdesc.cpp:111-117), formed once per pixel instead of once per bin
-    sb0[r * PSP + c] = (unsigned char)(bo0 % 8);   // o >= 0, so bo0 % 8 is in 0..7
+    sb0[r * PSP + c] = (unsigned char)(bo0 & 7);   // o >= 4 (ori >= -pi), so bo0 % 8 = bo0 & 7
     bufA[r * PSP + c] = val;     // the column weights wc0 / wc1 = (float)(w[c] * val) are formed in the gather
   }
   __syncthreads();   // all gradients taken: the patch may be replaced by wo1
@@ -789,8 +784,9 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
         const int i = tid + 128 * u, rbi = i >> 6, vc = i & 63;
         const int col = vc < 32 ? vc : vc - 24, r = 8 * rbi + rr;
         const float wrr = rr < 8 ? swr1[r] : swr0[r];
-        const double wc = vc < 32 ? swc1[col] : swc0[col];
-        const float wcv = (float)(wc * (double)bufA[r * PSP + col]);
+        // wc0 / wc1 = (float)(w[c] * (double)val) in the reference: the weights are multiples of 1/8 (exact in f32, checked
+        // where the table is built), so the f64 product is exact and its rounding to f32 is the f32 product
+        const float wcv = (vc < 32 ? swr1[col] : swr0[col]) * bufA[r * PSP + col];
         const float v = wrr * wcv;
         sv[rbi][vc] = v > 0 ? v : 0.f;
       }
