@@ -61,10 +61,8 @@ __global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out
   // Tried and dropped: G keypoints per workgroup with the serial phases (ordered sums, Jacobi) of all G run side by side in
   // the lanes of one wavefront -- half the instructions per keypoint, but a keypoint still owns a wavefront and 4.4 KB of
   // LDS, so no more keypoints are in flight per CU, the group iterates in lock-step to its slowest member, and the launch
-  // was 5-25 % slower for G = 2..16.  Likewise two or three keypoint slots per wavefront (parallel phases one after the
-  // other, serial phases side by side in lanes 0-5, finished slots refilled from the wavefront's chunk of the job list):
-  // 17 % fewer vector instructions, bit-exact, but the same time in the pipeline's launches (343 vs 348 us) -- with 4 waves
-  // per SIMD the dependent 361-add chains bound the launch, not the issue slots they leave free.
+  // was 5-25 % slower for G = 2..16.  Two keypoint slots per WAVEFRONT (k_baumberg_stream below) is what the default
+  // window size runs: no faster as a launch, but 17 % fewer vector instructions.
   __shared__ __attribute__((aligned(16))) float pa[AW_MAX * AW_MAX + 3], pb[AW_MAX * AW_MAX + 3], pc[AW_MAX * AW_MAX + 3];
   float *const simg = pc;
   const AffJob jb = jobs[k];
@@ -199,10 +197,222 @@ __global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K keypoints in flight per wavefront (19 x 19 window), streamed from the wavefront's own chunk of the job list.
+// An iteration of k_baumberg is ~1200 vector instructions of which ~640 are work for a handful of lanes -- the 3 x 361
+// ordered adds of the second-moment sums (3 lanes) and the f64 Jacobi step with the convergence tests (1 lane's worth) --
+// and an instruction costs the same issue slot with 3 active lanes as with 64.  Here a wavefront has K keypoint SLOTS: it
+// samples, differentiates and multiplies the windows of the live slots one after the other (the lane-parallel phases,
+// unchanged) and then runs their serial phases SIDE BY SIDE: lane 3q + c sums chain c of slot q, lanes 2q and 2q + 1 run
+// slot q's Jacobi step (its two independent 1/sqrt and divisions one in each lane of the pair) and keep its state.  A slot
+// whose keypoint stops writes the result and takes the next keypoint of the chunk, so the slots stay full although the
+// iteration counts differ (2 .. 16); iterations of different keypoints are independent, so which slot or wavefront runs a
+// keypoint changes nothing.  Operands and order of every f32 / f64 operation are those of k_baumberg.
+// On its own the launch is no faster than k_baumberg (the dependent chains bound it); it issues 17 % fewer vector
+// instructions, and vector issue is what the pipeline's concurrent streams compete for.
+MX_D void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // LDS hand-over inside one wavefront
+
+template <int K>
+__global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffOut *out, int n, const float *mask, int chunk,
+                                                        int maxIter, float convTh, float affInitialSigma) {
+  constexpr int W = AW_MAX, WW = W * W, half = W >> 1, CH = AW_MAX * AW_MAX + 3;
+  constexpr int PERM = (WW + 63) / 64;
+  __shared__ __attribute__((aligned(16))) float buf[K][3][CH];
+  const int lane = threadIdx.x;
+  float vmask[PERM];
+  int pp[PERM], oxp[PERM], oxm[PERM], oyp[PERM], oym[PERM];   // pixel (clamped to the window) and its gradient neighbours
+#pragma unroll
+  for (int u = 0; u < PERM; u++) {
+    const int i = lane + 64 * u;
+    vmask[u] = i < WW ? mask[i] : 0.f;
+    const int p = i < WW ? i : WW - 1;
+    const int r = p / W, c = p - r * W;
+    pp[u] = p;
+    oxp[u] = c == W - 1 ? p : p + 1;
+    oxm[u] = c == 0 ? p : p - 1;
+    oyp[u] = r == W - 1 ? p : p + W;
+    oym[u] = r == 0 ? p : p - W;
+  }
+  // serial side: lanes 2q, 2q + 1 keep the state of slot q
+  const int kq = lane >> 1;
+  const bool slotLane = lane < 2 * K;
+  float u11 = 1.0f, u12 = 0.0f, u21 = 0.0f, u22 = 1.0f, l1 = 1.0f, l2 = 1.0f, era = 0.0f, erb = 0.0f, ratio = 0.f;
+  int ok = 0, it = 0, kidx = -1;
+  int next = blockIdx.x * chunk;                                       // wave-uniform: next keypoint of the chunk
+  const int end = min(next + chunk, n);
+  bool live = false;
+  if (maxIter <= 0) {   // no iteration at all: identity shape, not converged (the loop of the reference does not run)
+    for (int i = next + lane; i < end; i += 64) { AffOut o; o.u11 = 1; o.u12 = 0; o.u21 = 0; o.u22 = 1; o.ok = 0; o.iters = 0; out[i] = o; }
+    return;
+  }
+  for (;;) {
+    // refill: every idle slot takes the next keypoint of the chunk, in slot order
+    {
+      const bool want = slotLane && !live;
+      const unsigned long long wm = __ballot(want && !(lane & 1));           // one bit per idle slot (its even lane)
+      const int rank = __popcll(wm & ((1ull << (lane & ~1)) - 1ull));
+      const int cand = next + rank;
+      if (want && cand < end) {
+        kidx = cand;
+        const AffJob sj = jobs[cand];
+        ratio = sj.s / (affInitialSigma * sj.pixelDistance);
+        u11 = 1.0f; u12 = 0.0f; u21 = 0.0f; u22 = 1.0f; l1 = 1.0f; l2 = 1.0f; era = 0.0f; erb = 0.0f;
+        ok = 0; it = 0;
+        live = true;
+      }
+      next = min(next + __popcll(wm), end);
+    }
+    const unsigned long long liveMask = __ballot(live);
+    if (!liveMask) break;
+    const float A11 = u11 * ratio, A12 = u12 * ratio, A21 = u21 * ratio, A22 = u22 * ratio;
+#pragma unroll
+    for (int q = 0; q < K; q++) {
+      if (!((liveMask >> (2 * q)) & 1)) continue;
+      const AffJob jb = jobs[__shfl(kidx, 2 * q)];
+      const float lx = jb.x / jb.pixelDistance, ly = jb.y / jb.pixelDistance;
+      const gcfloat_p img = as_global(jb.blur);
+      float *const pa = buf[q][0], *const pb = buf[q][1], *const pc = buf[q][2];
+      float *const simg = pc;
+      const float a11 = __shfl(A11, 2 * q), a12 = __shfl(A12, 2 * q), a21 = __shfl(A21, 2 * q), a22 = __shfl(A22, 2 * q);
+      const bool touch = check_borders(jb.cols, jb.rows, lx, ly, a11, a12, a21, a22, W, W);
+      {
+        // sample coordinates: lane j runs the f32 running sums of row j (helpers.cpp:563-585) into LDS
+        float rx = lx - (float)half * a12, ry = ly - (float)half * a22;
+#pragma unroll
+        for (int j = 1; j < W; j++)
+          if (lane >= j) { rx += a12; ry += a22; }
+        if (lane < W) {
+          float WX = rx - (float)half * a11;
+          float WY = ry - (float)half * a21;
+#pragma unroll
+          for (int i = 0; i < W; i++) {
+            pa[lane * W + i] = WX;
+            pb[lane * W + i] = WY;
+            WX += a11;
+            WY += a21;
+          }
+        }
+      }
+      wave_lds_sync();
+      {
+        // all six taps of a lane in flight together; slots past the window repeat its last pixel and are not stored
+        float sv[PERM];
+        if (!touch) {
+#pragma unroll
+          for (int u = 0; u < PERM; u++) sv[u] = bilinear_tap(img, jb.rows, jb.cols, pa[pp[u]], pb[pp[u]], false);
+        } else {
+#pragma unroll
+          for (int u = 0; u < PERM; u++) sv[u] = bilinear_tap_touch_select(img, jb.rows, jb.cols, pa[pp[u]], pb[pp[u]]);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int u = 0; u < PERM; u++)
+          if (lane + 64 * u < WW) simg[lane + 64 * u] = sv[u];
+      }
+      wave_lds_sync();
+      {
+        float qa[PERM], qb[PERM], qc[PERM];
+#pragma unroll
+        for (int u = 0; u < PERM; u++) {
+          const float gx = simg[oxp[u]] - simg[oxm[u]];
+          const float gy = simg[oyp[u]] - simg[oym[u]];
+          const float v = vmask[u];
+          const float gxy = gx * gy;
+          qa[u] = gx * gx * v;
+          qb[u] = gxy * v;
+          qc[u] = gy * gy * v;
+        }
+        wave_lds_sync();   // every gradient is taken: pc may replace the window
+#pragma unroll
+        for (int u = 0; u < PERM; u++) {
+          const int p = lane + 64 * u;
+          if (p < WW) { pa[p] = qa[u]; pb[p] = qb[u]; pc[p] = qc[u]; }
+        }
+      }
+    }
+    wave_lds_sync();
+    float acc = 0.f;
+    if (lane < 3 * K) {
+      const int q3 = lane / 3, ch = lane - 3 * q3;
+      const float *arr = buf[q3][ch];
+      const float4 *a4 = reinterpret_cast<const float4 *>(arr);
+#pragma unroll 6
+      for (int i = 0; i < WW / 4; i++) { const float4 v = a4[i]; acc += v.x; acc += v.y; acc += v.z; acc += v.w; }
+      acc += arr[WW - 1];
+      acc /= (float)WW;
+    }
+    float a = __shfl(acc, 3 * kq), b = __shfl(acc, 3 * kq + 1), c = __shfl(acc, 3 * kq + 2);
+    if (live) {
+      {   // invSqrt, helpers.cpp:463-502 (inv_sqrt_wave with the partner lane in the place of lanes 0 / 1)
+        double t, r;
+        if (b != 0) {
+          r = double(c - a) / (2 * b);
+          if (r >= 0) t = 1.0 / (r + sqrt(1 + r * r));
+          else t = -1.0 / (-r + sqrt(1 + r * r));
+          r = 1.0 / sqrt(1 + t * t);
+          t = t * r;
+        } else { r = 1; t = 0; }
+        const bool odd = lane & 1;
+        const double rr = r * r, tt = t * t, m = 2 * r * t * b;
+        const double first = (odd ? tt : rr) * a, last = (odd ? rr : tt) * c;
+        double w = 1.0 / sqrt((odd ? first + m : first - m) + last);
+        double x = __shfl(w, lane & ~1), z = __shfl(w, lane | 1);
+        const double d = sqrt(x * z);
+        w = (odd ? z : x) / d;
+        x = __shfl(w, lane & ~1); z = __shfl(w, lane | 1);
+        if (x < z) { l1 = float(z); l2 = float(x); } else { l1 = float(x); l2 = float(z); }
+        a = float(r * r * x + t * t * z);
+        b = float(-r * t * x + t * r * z);
+        c = float(t * t * x + r * r * z);
+      }
+      bool stop = false;
+      int iters = it;                                 // the value of the reference's loop counter at a break
+      if ((a != a) || (b != b) || (c != c)) stop = true;
+      else {
+        erb = era;
+        era = (float)(1.0 - (double)(l2 / l1));
+        const float u11t = u11, u12t = u12;
+        u11 = a * u11t + b * u21;
+        u12 = a * u12t + b * u22;
+        u21 = b * u11t + c * u21;
+        u22 = b * u12t + c * u22;
+        if (!eigenvalues(u11, u12, u21, u22, l1, l2)) stop = true;
+        else if ((l1 / l2 > 6) || (l2 / l1 > 6)) stop = true;
+        else if (era < convTh && erb < convTh) { ok = 1; stop = true; }
+      }
+      it++;
+      if (!stop && it >= maxIter) { stop = true; iters = maxIter; }
+      if (stop) {
+        live = false;
+        if (!(lane & 1)) {
+          AffOut o;
+          o.u11 = u11; o.u12 = u12; o.u21 = u21; o.u22 = u22; o.ok = ok; o.iters = iters;
+          out[kidx] = o;
+        }
+      }
+    }
+  }
+}
+
+#ifndef MODSX_BAUMBERG_K
+#define MODSX_BAUMBERG_K 2
+#endif
+#ifndef MODSX_BAUMBERG_CHUNK
+#define MODSX_BAUMBERG_CHUNK 8
+#endif
+
 void launch_baumberg(hipStream_t s, const AffJob *jobs, AffOut *out, int n, const float *mask, int W, int maxIter,
                      float convTh, float affInitialSigma) {
   if (n <= 0) return;
-  if (W == 19) hipLaunchKernelGGL(k_baumberg<19>, dim3(n), dim3(64), 0, s, jobs, out, n, mask, W, maxIter, convTh, affInitialSigma);
+  constexpr int K = MODSX_BAUMBERG_K;
+  if (W == 19 && K > 1) {
+    // chunk per wavefront: long enough to keep the slots full across keypoints of different iteration counts, short enough
+    // for >= 4 rounds of wavefronts over the chip (256 CUs x 16 resident) so that the tail of the launch stays short
+    int chunk = n / 16384;
+    chunk = chunk < K ? K : (chunk > MODSX_BAUMBERG_CHUNK ? MODSX_BAUMBERG_CHUNK : chunk);
+    hipLaunchKernelGGL(k_baumberg_stream<K>, dim3((n + chunk - 1) / chunk), dim3(64), 0, s, jobs, out, n, mask, chunk, maxIter, convTh,
+                       affInitialSigma);
+  } else if (W == 19) hipLaunchKernelGGL(k_baumberg<19>, dim3(n), dim3(64), 0, s, jobs, out, n, mask, W, maxIter, convTh, affInitialSigma);
   else hipLaunchKernelGGL(k_baumberg<0>, dim3(n), dim3(64), 0, s, jobs, out, n, mask, W, maxIter, convTh, affInitialSigma);
 }
 
