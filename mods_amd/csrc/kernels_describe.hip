@@ -581,35 +581,52 @@ struct SiftConst {
   int nmask;   // number of pixels with mask > 0
 };
 
-__global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, const ImgRef *imgs, const float *grid,
+// DR regions per workgroup, 128 threads (two wavefronts) each.  The regions run side by side and meet at the same barriers;
+// what they share is the instruction stream of the serial chains: the 2 x 1257 ordered adds of the photometric
+// normalisation (and the 128 of the RootSIFT L1 norm) are run by lanes 0 .. DR-1 of wavefront 0, one region per lane, so a
+// chain costs its issue slots once per workgroup instead of once per region (a quarter of the kernel's vector instructions
+// were these one-lane chains).  LDS per region is unchanged, so the same number of regions is resident per CU.
+#ifndef MODSX_DESCRIBE_REGIONS
+#define MODSX_DESCRIBE_REGIONS 2
+#endif
+constexpr int DR = MODSX_DESCRIBE_REGIONS;
+
+__global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int n, const ImgRef *imgs, const float *grid,
                                                   const int *needTab, const float *coordTab,
                                                   const float *mask, const unsigned short *maskIdx,
                                                   const float *oTab, const int *binTab, const double *wTab,
                                                   SiftConst sc, int photoNorm, int descType, double maxBin,
                                                   DescOut outs) {
-  const int k = blockIdx.x;
-  if (k >= n) return;
-  const int tid = threadIdx.x;
+  const int tidw = threadIdx.x;                                    // thread of the workgroup
+  const int reg = __builtin_amdgcn_readfirstlane(tidw >> 7);       // region of the workgroup (a wavefront is inside one region)
+  const int tid = tidw & 127;                                      // thread of the region
+  const int kreal = blockIdx.x * DR + reg;
+  const bool alive = kreal < n;                                    // a region past the end repeats the last one and stores nothing
+  const int k = alive ? kreal : n - 1;
   // `patch` (unpadded 41 x 41) and `bufB` (padded rows) share one buffer: whatever replaces the patch is first staged
   // in registers (14 values per thread) and written after a barrier
-  __shared__ __attribute__((aligned(16))) float patchB[PS * PSP];
-  float *const patch = patchB, *const bufB = patchB;
+  __shared__ __attribute__((aligned(16))) float patchB_[DR][PS * PSP];
+  float *const patch = patchB_[reg], *const bufB = patchB_[reg];
   constexpr int PER_T = (NPX + 127) / 128;
-  __shared__ __attribute__((aligned(16))) float bufA[PS * PSP];   // WX (direct branch), compacted masked values, later val
-  __shared__ __attribute__((aligned(16))) double slut[256];   // the descriptor vector and its partial sums (2 KB)
-  __shared__ __attribute__((aligned(16))) unsigned char sb0[PS * PSP];   // orientation bin bo0 % 8 of every pixel
-  __shared__ float swr0[PS], swr1[PS];
+  __shared__ __attribute__((aligned(16))) float bufA_[DR][PS * PSP];   // WX (direct branch), compacted masked values, later val
+  float *const bufA = bufA_[reg];
+  __shared__ __attribute__((aligned(16))) double slut_[DR][256];   // the descriptor vector and its partial sums (2 KB)
+  __shared__ __attribute__((aligned(16))) unsigned char sb0_[DR][PS * PSP];   // orientation bin bo0 % 8 of every pixel
+  unsigned char *const sb0 = sb0_[reg];
+  __shared__ float swr0_[DR][PS], swr1_[DR][PS];
+  float *const swr0 = swr0_[reg], *const swr1 = swr1_[reg];
   // 1 KB used twice: the resampling table of the sampling stage (smap, sfr), later the per-step weighted values of the
   // gather (sv)
-  __shared__ __attribute__((aligned(16))) unsigned char sraw[1024];
+  __shared__ __attribute__((aligned(16))) unsigned char sraw_[DR][1024];
+  unsigned char *const sraw = sraw_[reg];
   int4 *const smap = reinterpret_cast<int4 *>(sraw);
   float *const sfr = reinterpret_cast<float *>(sraw + 672);
   float(*const sv)[64] = reinterpret_cast<float(*)[64]>(sraw);
-  // the descriptor vector and its partial sums take the place of the ATAN_LUT, which is dead once the gradients are taken
-  double *const vec = slut, *const part = slut + 128;
-  __shared__ float sstat[2];
-  __shared__ double sfac;
-  __shared__ int schanged;
+  double *const vec = slut_[reg], *const part = slut_[reg] + 128;
+  __shared__ float sstat_[DR][2];
+  float *const sstat = sstat_[reg];
+  __shared__ double sfac_[DR];
+  __shared__ int schanged_[DR];
   const DescJob jb = jobs[k];
   if (tid < PS) {
     swr0[tid] = (float)wTab[tid]; swr1[tid] = (float)wTab[PS + tid];   // const float wr0 = w0[r] (siftdesc.cpp:79-81)
@@ -640,6 +657,7 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
       const int x0 = ok ? mc.x : 0, x1 = ok ? mc.y : 0;
       g00[k] = R0[x0]; g01[k] = R0[x1]; g10[k] = R1[x0]; g11[k] = R1[x1];
     }
+    __syncthreads();   // (the direct branch of another region of the workgroup has a barrier here)
 #pragma unroll
     for (int k = 0; k < PER_T; k++) {
       const int p = tid + 128 * k;
@@ -697,29 +715,31 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
     const int nm = sc.nmask, nm4 = (nm + 3) & ~3;
     for (int i = tid; i < nm4; i += 128) bufA[i] = i < nm ? patch[maskIdx[i]] : 0.f;
     __syncthreads();
-    if (tid == 0) {
+    if (tidw < DR) {   // lane q of wavefront 0 runs region q's chain
       float sum = 0.f;
-      const float4 *v4 = reinterpret_cast<const float4 *>(bufA);
+      const float *vals = bufA_[tidw];
+      const float4 *v4 = reinterpret_cast<const float4 *>(vals);
       const int full = nm >> 2;
 #pragma unroll 8
       for (int i = 0; i < full; i++) { const float4 v = v4[i]; sum += v.x; sum += v.y; sum += v.z; sum += v.w; }
-      for (int i = full * 4; i < nm; i++) sum += bufA[i];
+      for (int i = full * 4; i < nm; i++) sum += vals[i];
       const float gsum = (float)nm;   // gsum++ per masked pixel: every partial count < 2^24 is exact in f32
-      sstat[0] = sum / gsum;
-      sstat[1] = gsum;
+      sstat_[tidw][0] = sum / gsum;
+      sstat_[tidw][1] = gsum;
     }
     __syncthreads();
-    const float mean = sstat[0], gsum = sstat[1];
+    const float mean = sstat[0];
     for (int i = tid; i < nm4; i += 128) { const float d = mean - bufA[i]; bufA[i] = i < nm ? d * d : 0.f; }
     __syncthreads();
-    if (tid == 0) {
+    if (tidw < DR) {
       float var = 0.f;
-      const float4 *v4 = reinterpret_cast<const float4 *>(bufA);
+      const float *vals = bufA_[tidw];
+      const float4 *v4 = reinterpret_cast<const float4 *>(vals);
       const int full = nm >> 2;
 #pragma unroll 8
       for (int i = 0; i < full; i++) { const float4 v = v4[i]; var += v.x; var += v.y; var += v.z; var += v.w; }
-      for (int i = full * 4; i < nm; i++) var += bufA[i];
-      sstat[1] = sqrtf(var / gsum);
+      for (int i = full * 4; i < nm; i++) var += vals[i];
+      sstat_[tidw][1] = sqrtf(var / sstat_[tidw][1]);
     }
     __syncthreads();
     const float var = sstat[1];
@@ -827,41 +847,44 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
     vec[tid] = h;
     __syncthreads();
   }
-  // -- normalize / clip / renormalize (siftdesc.cpp:136-158, 199-221, 247-262)
+  // -- normalize / clip / renormalize (siftdesc.cpp:136-158, 199-221, 247-262).  The reference leaves after the first pass
+  // when nothing was clipped; here such a region sits out the second pass (the regions of a workgroup share the barriers).
+  bool active = true;
   for (int pass = 0; pass < 2; pass++) {
-    if (tid < 32) {
+    if (tid < 32 && active) {
       const double s0 = vec[4 * tid] * vec[4 * tid], s1 = vec[4 * tid + 1] * vec[4 * tid + 1],
                    s2 = vec[4 * tid + 2] * vec[4 * tid + 2], s3 = vec[4 * tid + 3] * vec[4 * tid + 3];
       part[tid] = s0 + s1 + s2 + s3;
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && active) {
       double len = 0.0;
 #pragma unroll
       for (int i = 0; i < 32; i++) len += part[i];
       len = sqrt(len);
-      sfac = 1.0 / len;
-      schanged = 0;
+      sfac_[reg] = 1.0 / len;
+      schanged_[reg] = 0;
     }
     __syncthreads();
-    vec[tid] *= sfac;
+    if (active) vec[tid] *= sfac_[reg];
     __syncthreads();
     if (pass == 0) {
-      if (vec[tid] > maxBin) { vec[tid] = maxBin; schanged = 1; }
+      if (vec[tid] > maxBin) { vec[tid] = maxBin; schanged_[reg] = 1; }
       __syncthreads();
-      if (!schanged) break;
+      if (!schanged_[reg]) active = false;
     }
   }
   __syncthreads();
   if (rootsift) {
-    if (tid == 0) {
+    if (tidw < DR) {   // lane q of wavefront 0: the L1 norm of region q, in index order
+      const double *vq = slut_[tidw];
       double sum = 0.;
 #pragma unroll 16
-      for (int i = 0; i < 128; i++) sum += fabs(vec[i]);
-      sfac = sum;
+      for (int i = 0; i < 128; i++) sum += fabs(vq[i]);
+      sfac_[tidw] = sum;
     }
     __syncthreads();
-    vec[tid] = sqrt(vec[tid] / sfac);
+    vec[tid] = sqrt(vec[tid] / sfac_[reg]);
   }
   {
     int b;
@@ -869,8 +892,10 @@ __global__ __launch_bounds__(128) void k_describe(const DescJob *jobs, int n, co
     else b = (int)((double)512.0f * vec[tid] + 0.5);
     b = b < 255 ? b : 255;
     b = b > 0 ? b : 0;
-    outs.f[jb.img][(size_t)jb.outIdx * 128 + tid] = (float)b;
-    outs.u8[jb.img][(size_t)jb.outIdx * 128 + tid] = (uint8_t)b;
+    if (alive) {
+      outs.f[jb.img][(size_t)jb.outIdx * 128 + tid] = (float)b;
+      outs.u8[jb.img][(size_t)jb.outIdx * 128 + tid] = (uint8_t)b;
+    }
   }
 }
 
@@ -909,7 +934,7 @@ void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *im
   if (n <= 0) return;
   SiftConst sc;
   sc.nmask = nmask;
-  hipLaunchKernelGGL(k_describe, dim3(n), dim3(128), 0, s, jobs, n, imgs, grid, needTab, coordTab, mask, maskIdx, oTab, bins,
+  hipLaunchKernelGGL(k_describe, dim3((n + DR - 1) / DR), dim3(128 * DR), 0, s, jobs, n, imgs, grid, needTab, coordTab, mask, maskIdx, oTab, bins,
                      wts, sc,
                      photoNorm, descType, maxBin, outs);
 }
