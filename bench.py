@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark of the MODS hot path on MI355X (BASELINE.json: image-pairs/s + descriptors matched/s, 1024x768, HessAff+SIFT).
 
-A step = one pass of the path over one batch of synthetic 1024x768 image pairs: per image the affine view ladder
+A step = one pass of the path over one batch of 64 synthetic 1024x768 image pairs per GPU (16 contexts take the pairs of a
+step from a shared counter): per image the affine view ladder
 (default TiltSet 1,2,4,6,8 at Phi 120 = 31 views, synth-detection.cpp:103-234) -> Hessian-Affine + Baumberg -> dominant
 orientation -> RootSIFT per view, then brute-force FGINN matching of the ~24 k x 24 k descriptors on the int8 matrix cores
 (matching.cpp:357-461), duplicate filtering and LO-RANSAC (H).  All images are resident in HBM before the timed region.
@@ -18,6 +19,8 @@ describe stage against HBM with SURVEY section 8(d) bytes, `cpu_baseline` = the 
 CPU path) on the same workload with all host cores and with one, `parity` = GPU vs that CPU path on one pair of the run.
 """
 import argparse
+import itertools
+import threading
 import json
 import os
 import sys
@@ -133,7 +136,7 @@ def main():
     ap.add_argument("--config", type=str, default="views31", choices=sorted(CONFIGS))
     ap.add_argument("--tilts", type=str, default="", help="override the tilt set of --config, e.g. 1,2,3,4,6")
     ap.add_argument("--phi", type=float, default=0.0)
-    ap.add_argument("--batch", type=int, default=0, help="pairs per step per GPU (default 16; 64 for views1)")
+    ap.add_argument("--batch", type=int, default=0, help="pairs per step per GPU (default 64)")
     ap.add_argument("--blobs", type=int, default=0, help="blobs per 1024x768 of the synthetic scene (0 = per config)")
     ap.add_argument("--workers", type=int, default=16, help="contexts (thread + stream) per GPU")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs cycled through the batch")
@@ -169,7 +172,7 @@ def main():
         tilts, phi = args.tilts, (args.phi or 360.0)
         cfg_desc = "tilts %s, phi %g" % (tilts, phi)
     single_view = tilts == "1"
-    batch = args.batch or (64 if single_view else 16)
+    batch = args.batch or 64
     # blob density of the synthetic scene: 4000 per 1024x768 for configs[1] (comparable with round 1), 5500 for the
     # multi-view configs so that the 31-view default carries the >= 50 k descriptors per pair the north star is quoted on
     blobs = args.blobs or (4000 if (single_view or wxbs) else 5500)
@@ -209,15 +212,26 @@ def main():
         if single:
             return mods_amd.match_pairs(cx, i1, i2, params)
 
-        # multi-view pairs: one python thread per context (ctypes releases the GIL inside the library)
+        # multi-view pairs: one python thread per context (ctypes releases the GIL inside the library).  The contexts take the
+        # pairs of the step from a shared counter, so that the step ends at most one pair after its last pair was started
+        # (with a static pair -> context map the step waited for the context with the most expensive pairs: 15 % of the
+        # GPU's time was idle at step boundaries).  The view-sharded mode keeps the static map: every rank must meet the
+        # others' collectives in the same order.
+        nxt = itertools.count()
+        lock = threading.Lock()
+
         def work(w):
             out = []
-            for i in range(w, len(i1), len(cx)):
-                if comm is not None:
+            if comm is not None:
+                for i in range(w, len(i1), len(cx)):
                     out.append((i, comm.match_pair_views_sharded(w, i1[i], i2[i], vw, params, owner=i % world)))
-                else:
-                    out.append((i, cx[w].match_pair_views(i1[i], i2[i], vw, params)))
-            return out
+                return out
+            while True:
+                with lock:
+                    i = next(nxt)
+                if i >= len(i1):
+                    return out
+                out.append((i, cx[w].match_pair_views(i1[i], i2[i], vw, params)))
         res = [None] * len(i1)
         for part in pool.map(work, range(len(cx))):
             for i, r in part:
@@ -377,7 +391,7 @@ def main():
                     continue
                 tl, ph, _ = CONFIGS[name]
                 vw = mods_amd.set_vs_pars([1.0], [float(t) for t in tl.split(",")], ph, args.init_sigma, 1, [])
-                nb = 64 if tl == "1" else 16
+                nb = 64
                 i1 = [dev[i % len(dev)][0] for i in range(nb)]
                 i2 = [dev[i % len(dev)][1] for i in range(nb)]
                 run_batch(vw, tl == "1", i1, i2)
