@@ -13,9 +13,9 @@ namespace mx {
 
 // ---- device job descriptors (passed by value in kernel arguments) ----------------------
 #ifndef MODSX_MAXB
-#define MODSX_MAXB 16
+#define MODSX_MAXB 32
 #endif
-constexpr int MAXB = MODSX_MAXB;   // images (views) per batched launch set: 8 / 16 / 32 measured 121 / 125 / 120 pairs/s at 31 views
+constexpr int MAXB = MODSX_MAXB;   // images (views) per batched launch set: 8 / 16 / 32 measured 150 / 157 / 159 pairs/s at 31 views
 constexpr int PAIR_GROUP = 4;      // identity-view pairs per launch set of modsx_match_pairs (8 images; 16 measured slower)
 constexpr int NMS_MAXJ = 1024; // (image, octave, level) jobs per NMS launch (flushed when full)
 constexpr int MAX_TAPS = 17;   // pyramid kernels: ksize <= 17
