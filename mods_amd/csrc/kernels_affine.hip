@@ -237,6 +237,7 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
   const int kq = lane >> 1;
   const bool slotLane = lane < 2 * K;
   float u11 = 1.0f, u12 = 0.0f, u21 = 0.0f, u22 = 1.0f, l1 = 1.0f, l2 = 1.0f, era = 0.0f, erb = 0.0f, ratio = 0.f;
+  float slx = 0.f, sly = 0.f;   // the keypoint's position in its pyramid level (x / pixelDistance): formed once per keypoint
   int ok = 0, it = 0, kidx = -1;
   int next = blockIdx.x * chunk;                                       // wave-uniform: next keypoint of the chunk
   const int end = min(next + chunk, n);
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
         kidx = cand;
         const AffJob sj = jobs[cand];
         ratio = sj.s / (affInitialSigma * sj.pixelDistance);
+        slx = sj.x / sj.pixelDistance; sly = sj.y / sj.pixelDistance;
         u11 = 1.0f; u12 = 0.0f; u21 = 0.0f; u22 = 1.0f; l1 = 1.0f; l2 = 1.0f; era = 0.0f; erb = 0.0f;
         ok = 0; it = 0;
         live = true;
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
     for (int q = 0; q < K; q++) {
       if (!((liveMask >> (2 * q)) & 1)) continue;
       const AffJob jb = jobs[__shfl(kidx, 2 * q)];
-      const float lx = jb.x / jb.pixelDistance, ly = jb.y / jb.pixelDistance;
+      const float lx = __shfl(slx, 2 * q), ly = __shfl(sly, 2 * q);
       const gcfloat_p img = as_global(jb.blur);
       float *const pa = buf[q][0], *const pb = buf[q][1], *const pc = buf[q][2];
       float *const simg = pc;

@@ -43,14 +43,12 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
   // lane j owns row j of the patch: it runs the f32 running sums of interpolate() (helpers.cpp:563-585) along the row
   // and takes the taps as it goes, four columns in flight
   {
-    // row starts: one chain of running sums, identical in every lane (a12 / a22 are uniform); lane j keeps step j
-    float cxr = jb.x - (float)half * jb.a12, cyr = jb.y - (float)half * jb.a22;
-    float rx = cxr, ry = cyr;
+    // row starts: lane j takes j steps of the running sum (a12 / a22 are uniform: a lane that has its row start sits out
+    // the remaining steps)
+    float rx = jb.x - (float)half * jb.a12, ry = jb.y - (float)half * jb.a22;
 #pragma unroll
-    for (int j = 1; j < PS; j++) {
-      cxr += jb.a12; cyr += jb.a22;
-      if (lane == j) { rx = cxr; ry = cyr; }
-    }
+    for (int j = 1; j < PS; j++)
+      if (lane >= j) { rx += jb.a12; ry += jb.a22; }
     if (lane < PS) {
       float WX = rx - (float)half * jb.a11;
       float WY = ry - (float)half * jb.a21;
