@@ -115,22 +115,26 @@ MX_HD bool eigenvalues(float a, float b, float c, float d, float &l1, float &l2)
   return true;
 }
 
-// interpolateCheckBorders, detectors/helpers.cpp:524-549
+// interpolateCheckBorders, detectors/helpers.cpp:524-549: true when a corner of the sampled window has
+// floor(x) <= 0 || floor(y) <= 0 || ceil(x) >= width || ceil(y) >= height.  For the integer-valued bounds these are
+// x < 1, y < 1, x > width - 1, y > height - 1 (a NaN corner is false either way), so the four corners reduce to the extrema
+// of their coordinates: no floor / ceil per corner.
 MX_HD bool check_borders(int orig_w, int orig_h, float ofsx, float ofsy, float a11, float a12, float a21, float a22,
                          int res_w, int res_h) {
   const int width = orig_w - 2, height = orig_h - 2;
   const float hw = (float)ceil((double)(float)res_w / 2.0);
   const float hh = (float)ceil((double)(float)res_h / 2.0);
-  bool touch = false;
+  float xmin = 0.f, xmax = 0.f, ymin = 0.f, ymax = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const float xs = (i < 2) ? -hw : hw;
     const float ys = (i & 1) ? hh : -hh;
-    float imx = ofsx + xs * a11 + ys * a12;
-    float imy = ofsy + xs * a21 + ys * a22;
-    if (floorf(imx) <= 0 || floorf(imy) <= 0 || ceilf(imx) >= width || ceilf(imy) >= height) touch = true;
+    const float imx = ofsx + xs * a11 + ys * a12;
+    const float imy = ofsy + xs * a21 + ys * a22;
+    if (i == 0) { xmin = xmax = imx; ymin = ymax = imy; }
+    else { xmin = fminf(xmin, imx); xmax = fmaxf(xmax, imx); ymin = fminf(ymin, imy); ymax = fmaxf(ymax, imy); }
   }
-  return touch;
+  return xmin < 1.f || ymin < 1.f || xmax > (float)(width - 1) || ymax > (float)(height - 1);
 }
 
 #ifdef __HIPCC__
