@@ -6,9 +6,11 @@
 //   photometricallyNormalize     detectors/helpers.cpp:666-715
 //   SIFTDescriptor               matching/siftdesc.cpp:22-131 (bins, samplePatch), 136-278 (norms),
 //                                290-379 (gradients + atan2LUTff)
-// Data layout: every region owns a dense P x P f32 window in a scratch arena in HBM
-// (P = 2*ceil(s*mrSize)+3), written once by k_patch_sample, blurred by two separable passes at the rows / columns the
-// resampling needs (arena A -> B -> C) and read once by k_describe, which resamples it to 41x41 in LDS.
+// Data layout: a region's P x P f32 window (P = 2*ceil(s*mrSize)+3) is sampled one row tile at a time into LDS and
+// row-filtered there at the columns the resampling needs (k_sample_rows_lds -> arena B, P x NC), column-filtered at the
+// needed rows (k_blur_cols_lds -> arena C, NC x NC; small windows: in the sampling kernel itself) and read once by
+// k_describe, which resamples it to 41x41 in LDS.  Windows whose row tile does not fit LDS take k_patch_sample (arena A)
+// and the global-memory filter k_patch_blur.
 #include "engine.hpp"
 
 namespace mx {
@@ -415,7 +417,7 @@ __device__ __forceinline__ void blur_cols_from_lds(int NC, int n, int ro0, int n
 // traffic item of the describe stage).  Lane j of a wave walks row j of the tile over the wave's QUARTER of the columns
 // (its coordinates start with col0 dependent adds, as for the column tiles of k_patch_sample) and parks SR_C columns at a
 // time; the taps are then taken with the lanes running along the rows.  Coordinates, taps, filter sums: term for term those
-// of k_patch_sample + k_blur_rows_lds.
+// of k_patch_sample + the row filter.
 // A wave parks C columns of up to 64 rows at a time in its 64 x 9 words of coordinates: C = 8 for tiles of more than 32 rows,
 // C = 16 for tiles of up to 32 rows (the host keeps row tiles out of the 33..48 range), so that a lane has 8 samples --
 // 16 loads -- in flight either way.
