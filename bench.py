@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs cycled through the batch")
     ap.add_argument("--init-sigma", type=float, default=0.2)
     ap.add_argument("--shard", type=str, default="", choices=["", "pairs", "views"])
+    ap.add_argument("--batch-api", action="store_true", help="multi-view configs: run a step as ONE modsx_match_pairs_views call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the short 1/8/11-view runs reported under `extra`")
     args = ap.parse_args()
@@ -211,6 +212,10 @@ def main():
     def run_batch(vw=views, single=single_view, i1=imgs1, i2=imgs2, cx=ctxs):
         if single:
             return mods_amd.match_pairs(cx, i1, i2, params)
+        if comm is None and args.batch_api:
+            # the library's own batch loop (modsx_match_pairs_views): 4-5 % below the persistent python threads of the default
+            # path, whose threads are not re-created per step
+            return mods_amd.match_pairs_views(cx, i1, i2, vw, params, arrays=False)
 
         # multi-view pairs: one python thread per context (ctypes releases the GIL inside the library).  The contexts take the
         # pairs of the step from a shared counter, so that the step ends at most one pair after its last pair was started

@@ -299,7 +299,15 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
                       const modsx_image *const *imgs2, int n_pairs, const modsx_pair_params *par,
                       modsx_pair_result *results);
 
-/* host share of the last modsx_match_pairs call: wall time of DuplicateFiltering + LO-RANSAC summed over its pairs (ms),
+/* The same for multi-view pairs (mods.cpp's loop over image pairs with one view list per image, as modsx_match_pair_views
+ * per pair): every context takes one pair at a time off a shared counter; DuplicateFiltering + LO-RANSAC of a matched pair
+ * run on helper threads while the context goes on to the next pair.  Results are those of n_pairs modsx_match_pair_views
+ * calls.  Returns n_pairs. */
+int modsx_match_pairs_views(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *const *imgs1,
+                            const modsx_image *const *imgs2, int n_pairs, const modsx_view *views, int n_views,
+                            const modsx_pair_params *par, modsx_pair_result *results);
+
+/* host share of the last modsx_match_pairs / modsx_match_pairs_views call: wall time of DuplicateFiltering + LO-RANSAC summed over its pairs (ms),
  * the pairs verified and the helper threads that ran them (measurement hook) */
 int modsx_last_batch_verify(double *sum_ms, int *pairs, int *threads);
 /* per-stage time of the last modsx_match_pair in ms: detect, orient, describe, match, verify, total */

@@ -88,7 +88,7 @@ EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "m
            "modsx_detect_scalespace", "modsx_octave_levels", "modsx_gaussian_blur", "modsx_resize_half", "modsx_response",
            "modsx_detect_affine_regions", "modsx_detect_orientation", "modsx_reproject_regions",
            "modsx_describe_regions", "modsx_match_fginn", "modsx_duplicate_filtering", "modsx_ransac_h",
-           "modsx_loransac_h", "modsx_ransac_f", "modsx_loransac_f", "modsx_match_pair", "modsx_match_pairs", "modsx_pair_result_release",
+           "modsx_loransac_h", "modsx_ransac_f", "modsx_loransac_f", "modsx_match_pair", "modsx_match_pairs", "modsx_match_pairs_views", "modsx_pair_result_release",
            "modsx_set_vs_pars", "modsx_synth_view", "modsx_detect_describe_views", "modsx_match_fginn_device",
            "modsx_match_pair_views", "modsx_match_ladder", "modsx_save_regions", "modsx_load_regions", "modsx_default_mser_params", "modsx_detect_msers", "modsx_detect_msers_u8", "modsx_last_timings", "modsx_profile",
            "modsx_kernel_stats", "modsx_last_batch_verify", "modsx_comm_unique_id", "modsx_comm_create", "modsx_comm_destroy", "modsx_comm_info",
@@ -624,10 +624,23 @@ def match_pairs(ctxs, imgs1, imgs2, params):
     return [_unpack_pair_result(res[i]) for i in range(n)]
 
 
-def _unpack_pair_result(res):
+def match_pairs_views(ctxs, imgs1, imgs2, views, params, arrays=True):
+    """modsx_match_pairs_views: a batch of multi-view pairs over several contexts, verification on helper threads.
+    arrays=False returns the counts and H only (the tentative / flag arrays are released without being copied out)."""
+    n = len(imgs1)
+    carr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    a1 = (C.c_void_p * n)(*[im.h for im in imgs1])
+    a2 = (C.c_void_p * n)(*[im.h for im in imgs2])
+    arr = _view_array(views)
+    res = (PairResult * n)()
+    _check(lib().modsx_match_pairs_views(carr, len(ctxs), a1, a2, n, arr, len(views), C.byref(params), res), "match_pairs_views")
+    return [_unpack_pair_result(res[i], arrays) for i in range(n)]
+
+
+def _unpack_pair_result(res, arrays=True):
     if True:
-        T = res.n_unique
-        out = dict(n_regions=(res.n_regions1, res.n_regions2), n_tentatives=res.n_tentatives, n_unique=T,
+        T = res.n_unique if arrays else 0
+        out = dict(n_regions=(res.n_regions1, res.n_regions2), n_tentatives=res.n_tentatives, n_unique=res.n_unique,
                    n_ransac_inliers=res.n_ransac_inliers, n_verified=res.n_verified,
                    ransac_samples=res.ransac_samples, ransac_lo=res.ransac_lo,
                    H=np.array(list(res.H)).reshape(3, 3))

@@ -456,6 +456,82 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
   return n_pairs;
 }
 
+// modsx_match_pairs for multi-view pairs: every context takes one pair at a time (the pairs come off a shared counter), runs
+// the view loop of both images and the match, and hands the tentatives to a helper thread for DuplicateFiltering +
+// LO-RANSAC while its own thread goes on to the next pair -- a 31-view pair carries ~12 k tentatives and ~10 ms of host
+// verification, during which the context's stream would otherwise sit idle.
+int modsx_match_pairs_views(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *const *imgs1, const modsx_image *const *imgs2,
+                            int n_pairs, const modsx_view *views, int n_views, const modsx_pair_params *par,
+                            modsx_pair_result *results) {
+  NEED(ctxs); NEED(par); NEED(results); NEED(views);
+  if (n_ctx <= 0 || n_views <= 0 || n_pairs < 0 || (n_pairs > 0 && (!imgs1 || !imgs2))) {
+    mx::set_error("modsx_match_pairs_views: bad argument");
+    return MODSX_ERR_ARG;
+  }
+  for (int i = 0; i < n_ctx; i++) NEED(ctxs[i]);
+  for (int i = 0; i < n_pairs; i++) memset(&results[i], 0, sizeof results[i]);
+  std::atomic<int> next(0), failed(0);
+  std::string firstErr;
+  std::mutex mu;
+  struct Queue {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<mx::VerifyTask> q;
+    bool done = false;
+  } vq;
+  const modsx_pair_params pp = *par;
+  auto helper = [&]() {
+    for (;;) {
+      mx::VerifyTask t;
+      {
+        std::unique_lock<std::mutex> lk(vq.m);
+        vq.cv.wait(lk, [&] { return vq.done || !vq.q.empty(); });
+        if (vq.q.empty()) return;
+        t = std::move(vq.q.front());
+        vq.q.pop_front();
+      }
+      const auto v0 = std::chrono::steady_clock::now();
+      mx::verify_tentatives(t.r1, t.r2, t.tents, pp, t.res);
+      g_verifyUs += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - v0).count();
+      g_verifyPairs++;
+    }
+  };
+  auto worker = [&](int w) {
+    modsx_ctx *c = ctxs[w];
+    hipSetDevice(c->dev);
+    for (;;) {
+      if (failed.load()) break;
+      const int i = next.fetch_add(1);
+      if (i >= n_pairs) break;
+      mx::VerifyTask task;
+      const int rc = mx::match_pair_views(c, imgs1[i], imgs2[i], views, n_views, pp, &results[i], &task);
+      if (rc) {
+        std::lock_guard<std::mutex> g(mu);
+        if (!failed.exchange(rc)) firstErr = mx::last_error();
+        continue;
+      }
+      { std::lock_guard<std::mutex> lk(vq.m); vq.q.push_back(std::move(task)); }
+      vq.cv.notify_one();
+    }
+  };
+  std::vector<std::thread> th, hth;
+  const int nw = n_ctx < n_pairs ? n_ctx : n_pairs;
+  g_verifyUs = 0; g_verifyPairs = 0; g_verifyThreads = nw;
+  for (int w = 0; w < nw; w++) hth.emplace_back(helper);
+  for (int w = 1; w < nw; w++) th.emplace_back(worker, w);
+  if (nw > 0) worker(0);
+  for (auto &t : th) t.join();
+  { std::lock_guard<std::mutex> lk(vq.m); vq.done = true; }
+  vq.cv.notify_all();
+  for (auto &t : hth) t.join();
+  if (failed.load()) {
+    for (int i = 0; i < n_pairs; i++) modsx_pair_result_release(&results[i]);
+    mx::set_error(firstErr);
+    return failed.load();
+  }
+  return n_pairs;
+}
+
 void modsx_pair_result_release(modsx_pair_result *res) {
   if (!res) return;
   free(res->tentatives); free(res->ransac_inlier); free(res->verified);

@@ -36,10 +36,12 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
                           const modsx_pair_params &pp, int view_begin, int view_step, std::vector<modsx_region> &regs,
                           float *devF, uint8_t *devU8, size_t devCapRegions, float *hostDesc, int *viewCounts);
 void rebase_ids(std::vector<modsx_region> &regs, const int *viewCounts, int nv, size_t base);
+struct VerifyTask;
+// defer != nullptr (one-step ladders only): the tentatives are matched and handed back unverified
 int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_ladder_step *steps, int nsteps,
-                 int min_matches, const modsx_pair_params &pp, modsx_pair_result *res, int *steps_done);
+                 int min_matches, const modsx_pair_params &pp, modsx_pair_result *res, int *steps_done, VerifyTask *defer = nullptr);
 int match_pair_views(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_view *views, int nv,
-                     const modsx_pair_params &pp, modsx_pair_result *res);
+                     const modsx_pair_params &pp, modsx_pair_result *res, VerifyTask *defer = nullptr);
 void prof_begin(modsx_ctx *c, int cls, double work, size_t *slot);
 void prof_end(modsx_ctx *c, size_t slot);
 // a sharded match (engine_shard.hip): this rank owns the query rows [lo, lo + per) of n1_total

@@ -430,18 +430,19 @@ static int accumulate_views(modsx_ctx *c, LadderClass &k, int side, const modsx_
 }
 
 int match_pair_views(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_view *views, int nv,
-                     const modsx_pair_params &pp, modsx_pair_result *res) {
+                     const modsx_pair_params &pp, modsx_pair_result *res, VerifyTask *defer) {
   modsx_ladder_step one;
   one.views = views; one.nviews = nv; one.match_ratio = pp.match_ratio; one.detector = pp.detector;
   int done = 0;
-  return match_ladder(c, img1, img2, &one, 1, 0x7fffffff, pp, res, &done);
+  return match_ladder(c, img1, img2, &one, 1, 0x7fffffff, pp, res, &done, defer);
 }
 
 // The iteration loop of mods.cpp:229-415 (HessianAffine and MSER classes with SIFT-family descriptors, LO-RANSAC
 // verification, duplicates filtered before RANSAC): every step adds its views' regions to both image representations,
 // re-matches the class it extended, and the ladder stops once min_matches verified correspondences exist.
 int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_ladder_step *steps, int nsteps,
-                 int min_matches, const modsx_pair_params &pp, modsx_pair_result *res, int *steps_done) {
+                 int min_matches, const modsx_pair_params &pp, modsx_pair_result *res, int *steps_done, VerifyTask *defer) {
+  if (defer && nsteps != 1) { set_error("deferred verification needs a one-step ladder"); return MODSX_ERR_ARG; }
   memset(res, 0, sizeof *res);
   for (int i = 0; i < 9; i++) res->H[i] = -1;
   const modsx_image *imgs[2] = {img1, img2};
@@ -514,6 +515,11 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
     for (int i = 0; i < 9; i++) res->H[i] = -1;
     res->n_regions1 = (int)all[0].size();
     res->n_regions2 = (int)all[1].size();
+    if (defer) {   // the caller runs DuplicateFiltering + LO-RANSAC elsewhere (modsx_match_pairs_views: helper threads)
+      defer->r1 = std::move(all[0]); defer->r2 = std::move(all[1]); defer->tents = std::move(tents); defer->res = res;
+      step++;
+      break;
+    }
     verify_tentatives(all[0], all[1], tents, pp, res);
     cur = res->n_verified;
   }

@@ -340,3 +340,27 @@ def test_cat_pair_full_ladder_stops_early_on_ground_truth(ctx, modsx, cat_pair):
     err = np.linalg.norm(proj - p2, axis=1)
     # the scene is not exactly planar: the shipped H fits the matches to ~15 px
     assert np.mean(err < 10.0) > 0.6 and err.max() < 30.0, (done, np.sort(err)[-10:], len(err))
+
+
+def test_match_pairs_views_equals_single_calls(modsx, small_pair):
+    """modsx_match_pairs_views (contexts take pairs off a counter, verification on helper threads) returns what
+    modsx_match_pair_views returns pair by pair."""
+    a, b, _ = small_pair
+    ctxs = [modsx.Context(0) for _ in range(3)]
+    views = modsx.set_vs_pars([1.0], [1, 2, 3], 360.0, 0.2, 1, [])
+    par = modsx.default_pair_params(ransac_seed=9)
+    ims = [(ctxs[0].upload(a), ctxs[0].upload(b)), (ctxs[0].upload(b), ctxs[0].upload(a))]
+    i1 = [ims[i % 2][0] for i in range(7)]
+    i2 = [ims[i % 2][1] for i in range(7)]
+    got = modsx.match_pairs_views(ctxs, i1, i2, views, par)
+    light = modsx.match_pairs_views(ctxs, i1, i2, views, par, arrays=False)
+    for i in range(7):
+        ref = ctxs[0].match_pair_views(i1[i], i2[i], views, par)
+        for k in ("n_regions", "n_tentatives", "n_unique", "n_ransac_inliers", "n_verified", "ransac_samples"):
+            assert got[i][k] == ref[k] and light[i][k] == ref[k], k
+        assert np.array_equal(got[i]["H"], ref["H"]) and np.array_equal(got[i]["verified"], ref["verified"])
+        assert same_records(got[i]["tentatives"], ref["tentatives"])
+    assert modsx.match_pairs_views(ctxs, [], [], views, par) == []
+    for x, y in ims:
+        x.free(); y.free()
+
