@@ -339,14 +339,14 @@ def main():
                 tf = flops / (ms * 1e-3) / 1e12
                 byts = (n1 + n2) * 128.0 + n1 * 32.0
                 out["roofline"] = {
-                    "kernel": "k_match_* (pack, sweep1, decide, sweep2, events, finish: every launch of one matching problem)",
+                    "kernel": "k_match_* (pack, sweep1, decide, sweep2, events: every launch of one matching problem)",
                     "bound": "mfma", "achieved": tf, "peak": INT8_PEAK_TOPS, "unit": "TFLOP/s", "frac": tf / INT8_PEAK_TOPS,
                     "traffic": None, "avg_launch_ms": ms, "algorithmic_work_per_launch": flops, "N": n1, "M": n2,
                     "hbm_view": {"compulsory_bytes": byts, "achieved_GBs": byts / (ms * 1e-3) / 1e9,
                                  "frac_of_8TBs": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                     "binds": "mfma: 2*N*M*128 int8 ops against (N+M)*128 B is ~1e4 op/B, the kernel is compute-shaped; "
                              "its limiter is VALU issue beside the MFMAs (DESIGN.md section 5)",
-                    "note": "HIP events on the launch stream around the six launches, single-stream pass over %d pairs of "
+                    "note": "HIP events on the launch stream around the five launches, single-stream pass over %d pairs of "
                             "this run right after the timed region; N, M = regions of the last pair" % niso}
                 tfile = os.path.join(ROOT, "profiles", "pmc_traffic_r02.json")
                 if os.path.exists(tfile):

@@ -469,9 +469,9 @@ __device__ __forceinline__ void decide_body(const uint8_t *d1, const int *norm1,
 // event groups (the sweep left those groups out of its own minimum).  A stream that ran out of its EVCAP slots sends the
 // query to the exact fallback: every train, one per lane (low-entropy inputs with thousands of near-duplicates).
 __device__ __forceinline__ void events_body(const uint8_t *d1, const int *norm1, const uint8_t *d2, const int *norm2, MatchGeom g,
-                                            const double *pos2, double contrDistSq, const MatchRow *rows, const int *dmin,
+                                            const double *pos2, double contrDistSq, MatchRow *rows, const int *dmin,
                                             const int *undecided, const int *nUndecided, const int *evCnt, const int *ev,
-                                            int nn, int4 *evRes) {
+                                            int nn, const int2 *partial2) {
   __shared__ int sRec[4][64];           // per wave: the event groups of its query as (tile << 1 | lane half)
   const int w = threadIdx.x >> 6;
   const int u = blockIdx.x * 4 + w;
@@ -485,11 +485,28 @@ __device__ __forceinline__ void events_body(const uint8_t *d1, const int *norm1,
   for (int st = lane; st < nst; st += 64) total += evCnt[(size_t)u * nst + st];
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) total += __shfl_xor(total, m);
-  if (total >= nn) {
-    if (lane == 0) evRes[u] = make_int4(nn, 0, BIG, BIG);
-    return;
-  }
   const int q = undecided[u];
+  // the last step of the walk for this query: NNj = the lex-smallest of the event groups' candidate and the splits' minima of
+  // sweep 2, then the row gets tj / dj / nless / nbad (this used to be a launch of its own)
+  auto finish = [&](int nlessF, int nbadF, int djF, int tjF) {
+    for (int sp = lane; sp < g.S; sp += 64) {
+      const int2 p = partial2[(size_t)u * g.S + sp];
+      if (lex_less(p.x, p.y, djF, tjF)) { djF = p.x; tjF = p.y; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const int od = __shfl_xor(djF, m), ot = __shfl_xor(tjF, m);
+      if (lex_less(od, ot, djF, tjF)) { djF = od; tjF = ot; }
+    }
+    if (lane == 0) {
+      MatchRow o = rows[q];
+      o.tj = tjF == BIG ? -1 : tjF;
+      o.dj = (float)djF;
+      o.nless = nlessF; o.nbad = nbadF;
+      rows[q] = o;
+    }
+  };
+  if (total >= nn) { finish(nn, 0, BIG, BIG); return; }
   const int t0 = rows[q].t0, Dm = dmin[q], na = norm1[q];
   const double x0 = pos2[2 * t0], y0 = pos2[2 * t0 + 1];
   const uint8_t *qd = d1 + (size_t)q * 128;
@@ -545,25 +562,7 @@ __device__ __forceinline__ void events_body(const uint8_t *d1, const int *norm1,
     const int od = __shfl_xor(dj, m), ot = __shfl_xor(tj, m);
     if (lex_less(od, ot, dj, tj)) { dj = od; tj = ot; }
   }
-  if (lane == 0) evRes[u] = make_int4(nless, nbad, dj, tj);
-}
-
-__device__ __forceinline__ void finish_body(const int2 *partial2, const int4 *evRes, MatchGeom g, const int *undecided,
-                                            const int *nUndecided, MatchRow *rows) {
-  const int u = blockIdx.x * 256 + threadIdx.x;
-  if (u >= *nUndecided) return;
-  const int4 e = evRes[u];
-  int dj = e.z, ij = e.w;
-  for (int s = 0; s < g.S; s++) {
-    const int2 p = partial2[(size_t)u * g.S + s];
-    if (lex_less(p.x, p.y, dj, ij)) { dj = p.x; ij = p.y; }
-  }
-  const int q = undecided[u];
-  MatchRow o = rows[q];
-  o.tj = ij == BIG ? -1 : ij;
-  o.dj = (float)dj;
-  o.nless = e.x; o.nbad = e.y;
-  rows[q] = o;
+  finish(nless, nbad, dj, tj);
 }
 
 // ---- workspace layout: ONE description used by the size query and by the launcher -------------------------------------------
@@ -647,13 +646,8 @@ __global__ __launch_bounds__(256) void k_match_events(MatchBatch b, double contr
   const MatchProblem &P = b.p[blockIdx.z];
   if ((int)blockIdx.x * 4 >= P.g.n1) return;
   events_body(P.d1, P.norm1, P.d2, P.norm2, P.g, P.pos2, contrDistSq, P.rows, P.dmin, P.undecided, P.counter, P.evCnt, P.ev,
-              nn, P.evRes);
+              nn, P.partial2);
 }
-__global__ __launch_bounds__(256) void k_match_finish(MatchBatch b) {
-  const MatchProblem &P = b.p[blockIdx.z];
-  finish_body(P.partial2, P.evRes, P.g, P.undecided, P.counter, P.rows);
-}
-
 // Problems with n1 == 0 or n2 == 0 must be left out by the caller.  workspace[i] holds match_workspace_bytes(n1[i], n2[i]).
 void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
                         const double *const *pos2, double sqminratio, double contrDistSq, int nn, MatchRow *const *rows,
@@ -684,7 +678,6 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
   hipLaunchKernelGGL(k_match_decide, dim3((maxN1 + DECIDE_Q - 1) / DECIDE_Q, 1, nb), dim3(1024), 0, s, b, sqminratio, contrDistSq);
   hipLaunchKernelGGL(k_match_sweep2, grid, dim3(256), 0, s, b);
   hipLaunchKernelGGL(k_match_events, dim3((maxN1 + 3) / 4, 1, nb), dim3(256), 0, s, b, contrDistSq, nn);
-  hipLaunchKernelGGL(k_match_finish, dim3((maxN1 + 255) / 256, 1, nb), dim3(256), 0, s, b);
 }
 
 void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2,
