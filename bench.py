@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--config", type=str, default="views31", choices=sorted(CONFIGS))
     ap.add_argument("--tilts", type=str, default="", help="override the tilt set of --config, e.g. 1,2,3,4,6")
     ap.add_argument("--phi", type=float, default=0.0)
-    ap.add_argument("--batch", type=int, default=0, help="pairs per step per GPU (default 64)")
+    ap.add_argument("--batch", type=int, default=0, help="pairs per step per GPU (default 64; 256 for views1, 128 for wxbs)")
     ap.add_argument("--blobs", type=int, default=0, help="blobs per 1024x768 of the synthetic scene (0 = per config)")
     ap.add_argument("--workers", type=int, default=16, help="contexts (thread + stream) per GPU")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs cycled through the batch")
@@ -173,7 +173,9 @@ def main():
         tilts, phi = args.tilts, (args.phi or 360.0)
         cfg_desc = "tilts %s, phi %g" % (tilts, phi)
     single_view = tilts == "1"
-    batch = args.batch or 64
+    # a step ends with the verification of its last pairs while the GPU drains: configs[1] (45 ms per 64 pairs) and
+    # configs[4] take longer steps so that this tail stays a few per cent of the step
+    batch = args.batch or (128 if wxbs else 256 if single_view else 64)
     # blob density of the synthetic scene: 4000 per 1024x768 for configs[1] (comparable with round 1), 5500 for the
     # multi-view configs so that the 31-view default carries the >= 50 k descriptors per pair the north star is quoted on
     blobs = args.blobs or (4000 if (single_view or wxbs) else 5500)
@@ -396,7 +398,7 @@ def main():
                     continue
                 tl, ph, _ = CONFIGS[name]
                 vw = mods_amd.set_vs_pars([1.0], [float(t) for t in tl.split(",")], ph, args.init_sigma, 1, [])
-                nb = 64
+                nb = 256 if tl == "1" else 64
                 i1 = [dev[i % len(dev)][0] for i in range(nb)]
                 i2 = [dev[i % len(dev)][1] for i in range(nb)]
                 run_batch(vw, tl == "1", i1, i2)
