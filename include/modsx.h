@@ -28,7 +28,9 @@ typedef enum modsx_status {
   MODSX_ERR_DEVICE = -2,
   MODSX_ERR_NOMEM = -3,
   MODSX_ERR_INTERNAL = -4,
-  MODSX_ERR_CAPACITY = -5   /* a caller-provided (or pooled) output buffer is too small: retry with a larger one */
+  MODSX_ERR_CAPACITY = -5,  /* a caller-provided (or pooled) output buffer is too small: retry with a larger one */
+  MODSX_ERR_TIMEOUT = -6    /* view-sharded path: a collective did not complete within the communicator's deadline (a peer rank
+                               is missing or failed); the communicator is dead, destroy it and create a new one */
 } modsx_status;
 
 /* detection_mode_t, detectors/structures.hpp:11-15 */
@@ -374,19 +376,41 @@ int modsx_match_ladder(modsx_ctx *ctx, const modsx_image *img1, const modsx_imag
 /* ---- view-sharded multi-GPU path (one process per GPU, RCCL over xGMI) ------------------------------------------------
  * The reference's unit of parallelism is the synthesised view (`#pragma omp parallel for` over views,
  * imagerepresentation.cpp:612-622); views meet only in AddRegions' ordered concatenation (:2044-2045, ids re-based by
- * AddRegionsToList :588-600).  View v belongs to rank v mod world.  A modsx_comm wraps one RCCL communicator used on the
- * stream of the ctx it was created with; the 128-byte id comes from modsx_comm_unique_id() on one rank and reaches the
- * others by any side channel (MPI, torch.distributed, a file).  RCCL is bound at run time (dlopen). */
+ * AddRegionsToList :588-600).  View v belongs to rank v mod world.  A modsx_comm is ONE communicator per rank; the
+ * 128-byte id comes from modsx_comm_unique_id() (RCCL, bound at run time with dlopen) or modsx_comm_loopback_id() on one
+ * rank and reaches the others by any side channel (MPI, torch.distributed, a file, a shared variable).
+ *   Lanes.  The contexts (host thread + stream) of a rank that use the communicator at the same time are its LANES:
+ * modsx_comm_set_lanes(n) once, modsx_comm_attach(comm, ctx, lane) per context, one thread per lane.  Collectives are issued
+ * in strict round-robin lane order, the same sequence on every rank: lane k of every rank must make the same sharded
+ * calls in the same order, and every lane the same number of them per round (modsx_comm_lane_done() takes a lane that
+ * has finished out of the rotation, modsx_comm_reset_lanes() puts all of them back at a quiescent point).
+ *   Errors are collective: a failure on one rank (bad view, out of memory, ...) is carried in the exchanged headers and
+ * every rank returns it from the same call; no rank is left waiting.  A collective that does not complete within the
+ * deadline (modsx_comm_set_timeout, env MODSX_COMM_TIMEOUT_MS, default 30000) aborts the communicator: the call and all
+ * later ones on it return MODSX_ERR_TIMEOUT.
+ *   The loopback transport runs `world` ranks inside ONE process on ONE device (one context + host thread per rank): the
+ * all-gather is `world` device-to-device copies behind an event handshake, everything above it is the code the RCCL
+ * transport runs.  It exists so that world > 1 is testable on a single GPU. */
 typedef struct modsx_comm modsx_comm;
 int modsx_comm_unique_id(void *id128);
+int modsx_comm_loopback_id(void *id128, int world);
 modsx_comm *modsx_comm_create(modsx_ctx *ctx, const void *id128, int rank, int world);
 void modsx_comm_destroy(modsx_comm *comm);
+int modsx_comm_set_lanes(modsx_comm *comm, int nlanes);
+int modsx_comm_attach(modsx_comm *comm, modsx_ctx *ctx, int lane);
+int modsx_comm_lane_done(modsx_comm *comm, int lane);
+int modsx_comm_reset_lanes(modsx_comm *comm);
+int modsx_comm_set_timeout(modsx_comm *comm, int milliseconds);
 int modsx_comm_info(const modsx_comm *comm, int *rank, int *world, int *rccl_version, long *bytes_gathered, long *collectives);
+/* out[0..n): collectives issued, bytes gathered, block-size retries, agreement collectives, lanes, loopback (0/1), dead (0/1).
+ * Returns the number of statistics available. */
+int modsx_comm_stats(const modsx_comm *comm, long *out, int n);
 /* Where row j of the reference's list sits in the all-gathered buffer (rank r's padded block starts at r * maxrows):
  * counts[r * nviews + v] = regions of view v on rank r (0 unless r == v mod world).  Returns the list length (host only). */
 int modsx_view_block_order(const int *counts, int world, int nviews, int *src, int cap, int *maxrows_out);
-/* SynthDetectDescribeKeypoints with this rank taking views rank, rank + world, ...: per-view counts and the padded row
- * blocks (modsx_region + 128 u8 descriptor bytes = 328 B per row) are all-gathered device to device; every rank returns
+/* SynthDetectDescribeKeypoints with this rank taking views rank, rank + world, ...: one all-gather of padded blocks
+ * (header with the per-view counts + rows of modsx_region + 128 u8 descriptor bytes = 328 B), device to device; the
+ * reference's order is rebuilt on the device from the gathered headers; every rank returns
  * ALL regions in reference order with re-based ids.  *dev_desc_u8 = the [n][128] u8 descriptors in HBM (owned by ctx,
  * valid until its next sharded call). */
 int modsx_detect_describe_views_sharded(modsx_ctx *ctx, modsx_comm *comm, const modsx_image *img, const modsx_view *views,
@@ -401,6 +425,13 @@ int modsx_match_fginn_sharded(modsx_ctx *ctx, modsx_comm *comm, const void *dev_
 int modsx_match_pair_views_sharded(modsx_ctx *ctx, modsx_comm *comm, const modsx_image *img1, const modsx_image *img2,
                                    const modsx_view *views, int nviews, const modsx_pair_params *par, int owner,
                                    modsx_pair_result *res);
+/* modsx_match_ladder over the ranks (configs[3]: the iteration ladder with every step's views sharded): each step's
+ * regions are exchanged and appended to the accumulated lists on every rank, the match is sharded by query row, and every
+ * rank runs DuplicateFiltering + LO-RANSAC on the same tentatives with the same seed, so all ranks take the min_matches
+ * exit at the same step without a collective.  Results are identical on every rank and equal to modsx_match_ladder's. */
+int modsx_match_ladder_sharded(modsx_ctx *ctx, modsx_comm *comm, const modsx_image *img1, const modsx_image *img2,
+                               const modsx_ladder_step *steps, int nsteps, int min_matches, const modsx_pair_params *par,
+                               modsx_pair_result *res, int *steps_done);
 
 /* Key files: void ImageRepresentation::SaveRegions(std::string fname, int mode) / LoadRegions(std::string fname)
  * (imagerepresentation.cpp:2139-2215; mods.cpp:236-241 reads them instead of detecting when read_pre_extracted is

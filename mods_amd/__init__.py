@@ -93,7 +93,8 @@ EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "m
            "modsx_match_pair_views", "modsx_match_ladder", "modsx_save_regions", "modsx_load_regions", "modsx_default_mser_params", "modsx_detect_msers", "modsx_detect_msers_u8", "modsx_last_timings", "modsx_profile",
            "modsx_kernel_stats", "modsx_last_batch_verify", "modsx_comm_unique_id", "modsx_comm_create", "modsx_comm_destroy", "modsx_comm_info",
            "modsx_view_block_order", "modsx_detect_describe_views_sharded", "modsx_match_fginn_sharded",
-           "modsx_match_pair_views_sharded"]
+           "modsx_match_pair_views_sharded", "modsx_match_ladder_sharded", "modsx_comm_loopback_id", "modsx_comm_set_lanes",
+           "modsx_comm_attach", "modsx_comm_lane_done", "modsx_comm_reset_lanes", "modsx_comm_set_timeout", "modsx_comm_stats"]
 # include/modsx_degensac.h: the reference's own verification symbols (link-time drop-in for libdegensac)
 EXPORTS_DEGENSAC = ["exp_ransacHcustom", "exp_ransacFcustom", "HDs", "HDsi", "HDsidx", "FDs", "FDsSym", "exFDs", "exFDsSym",
                     "modsx_ransac_set_seed"]
@@ -129,6 +130,13 @@ def lib():
         L.modsx_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.modsx_comm_destroy.argtypes = [C.c_void_p]
         L.modsx_comm_info.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        L.modsx_comm_loopback_id.argtypes = [C.c_void_p, C.c_int]
+        L.modsx_comm_set_lanes.argtypes = [C.c_void_p, C.c_int]
+        L.modsx_comm_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.modsx_comm_lane_done.argtypes = [C.c_void_p, C.c_int]
+        L.modsx_comm_reset_lanes.argtypes = [C.c_void_p]
+        L.modsx_comm_set_timeout.argtypes = [C.c_void_p, C.c_int]
+        L.modsx_comm_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.modsx_destroy.argtypes = [C.c_void_p]
         L.modsx_free.argtypes = [C.c_void_p]
         L.modsx_image_upload.restype = C.c_void_p
@@ -540,8 +548,9 @@ class Context(object):
                                             C.c_double(zoom), C.byref(out)), "detect_msers")
         return _take(out, n, KEYPOINT)
 
-    def match_ladder(self, img1, img2, steps, params, min_matches=10):
-        """steps: list of (views, match_ratio[, detector]).  Returns (result dict, steps executed)."""
+    def match_ladder(self, img1, img2, steps, params, min_matches=10, comm=None):
+        """steps: list of (views, match_ratio[, detector]).  Returns (result dict, steps executed).  comm: a communicator
+        handle => modsx_match_ladder_sharded (every step's views sharded over the ranks)."""
         arr = (LadderStep * len(steps))()
         keep = []
         for i, st in enumerate(steps):
@@ -554,8 +563,13 @@ class Context(object):
             arr[i].detector = int(st[2]) if len(st) > 2 else 0
         res = PairResult()
         done = C.c_int(0)
-        _check(lib().modsx_match_ladder(self._c(), C.c_void_p(img1.h), C.c_void_p(img2.h), arr, len(steps),
-                                        int(min_matches), C.byref(params), C.byref(res), C.byref(done)), "match_ladder")
+        if comm is not None:
+            _check(lib().modsx_match_ladder_sharded(self._c(), C.c_void_p(comm), C.c_void_p(img1.h), C.c_void_p(img2.h), arr,
+                                                    len(steps), int(min_matches), C.byref(params), C.byref(res),
+                                                    C.byref(done)), "match_ladder_sharded")
+        else:
+            _check(lib().modsx_match_ladder(self._c(), C.c_void_p(img1.h), C.c_void_p(img2.h), arr, len(steps),
+                                            int(min_matches), C.byref(params), C.byref(res), C.byref(done)), "match_ladder")
         return _unpack_pair_result(res), done.value
 
     def match_pair(self, img1, img2, params):
@@ -606,6 +620,22 @@ def comm_unique_id():
     buf = C.create_string_buffer(128)
     _check(lib().modsx_comm_unique_id(buf), "comm_unique_id")
     return buf.raw
+
+
+def comm_loopback_id(world):
+    """Id of an in-process communicator group: `world` ranks of THIS process on one device (one context + thread each)."""
+    buf = C.create_string_buffer(128)
+    _check(lib().modsx_comm_loopback_id(buf, int(world)), "comm_loopback_id")
+    return buf.raw
+
+
+COMM_STATS = ["collectives", "bytes_gathered", "block_retries", "agreements", "lanes", "loopback", "dead"]
+
+
+def comm_stats(comm):
+    out = (C.c_long * len(COMM_STATS))()
+    lib().modsx_comm_stats(C.c_void_p(comm), out, len(COMM_STATS))
+    return dict(zip(COMM_STATS, list(out)))
 
 
 def _image_dims(handle):

@@ -1107,25 +1107,33 @@ int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int
     out[0].clear();
     const int N1 = shard->n1_total, M = n2[0], per = shard->per;
     const int lo = shard->lo, nloc = std::max(0, std::min(N1, lo + per) - lo);
-    const size_t posB = up((size_t)M * 16), rowB = up((size_t)per * sizeof(MatchRow)), allB = (size_t)N1 * sizeof(MatchRow);
-    if (!c->pos2.ensure(posB) || !c->matchRows.ensure(rowB) || !c->hMatch.ensure(posB + up(allB)) ||
-        !c->matchWork.ensure(match_workspace_bytes(std::max(1, nloc), M)))
-      return MODSX_ERR_NOMEM;
-    char *hpos = (char *)c->hMatch.p, *hrow = hpos + posB;
-    memcpy(hpos, pos2Host[0], (size_t)M * 16);
-    MX_HIP(hipMemcpyAsync(c->pos2.p, hpos, (size_t)M * 16, hipMemcpyHostToDevice, s));
-    if (nloc > 0) {
-      ProfScope ps(c, K_MATCH, 2.0 * nloc * (double)M * 128);
-      launch_match(s, d1[0] + (size_t)lo * 128, nloc, d2[0], M, (const double *)c->pos2.p, sqminratio, contrDistSq, nn,
-                   (MatchRow *)c->matchRows.p, c->matchWork.p);
-    }
-    MatchRow *all = nullptr;
-    int rc = match_shard_gather(c, *shard, (MatchRow *)c->matchRows.p, &all);
+    MatchRow *blk = nullptr;
+    int rc = match_shard_begin(c, *shard, &blk);          // the lane's blocks (growth agreed by all ranks)
     if (rc) return rc;
-    MX_HIP(hipMemcpyAsync(hrow, all, allB, hipMemcpyDeviceToHost, s));
-    MX_HIP(hipStreamSynchronize(s));
-    MX_HIP(hipGetLastError());
-    rows_to_tentatives((const MatchRow *)hrow, N1, nn, out[0]);
+    // from here to the all-gather nothing returns: a local failure travels in the block header
+    int lrc = MODSX_OK;
+    const int world = shard->world;
+    const size_t posB = up((size_t)M * 16), allB = (size_t)world * (per + 1) * sizeof(MatchRow);
+    if (!c->pos2.ensure(posB) || !c->hMatch.ensure(posB + up(allB)) || !c->matchWork.ensure(match_workspace_bytes(std::max(1, nloc), M)))
+      lrc = MODSX_ERR_NOMEM;
+    char *hpos = (char *)c->hMatch.p, *hrow = hpos ? hpos + posB : nullptr;
+    if (!lrc) {
+      memcpy(hpos, pos2Host[0], (size_t)M * 16);
+      if (hipMemcpyAsync(c->pos2.p, hpos, (size_t)M * 16, hipMemcpyHostToDevice, s) != hipSuccess) { set_error("sharded match: upload failed"); lrc = MODSX_ERR_DEVICE; }
+    }
+    if (!lrc && nloc > 0) {
+      ProfScope ps(c, K_MATCH, 2.0 * nloc * (double)M * 128);
+      launch_match(s, d1[0] + (size_t)lo * 128, nloc, d2[0], M, (const double *)c->pos2.p, sqminratio, contrDistSq, nn, blk + 1, c->matchWork.p);
+    }
+    rc = match_shard_gather(c, *shard, lrc, lrc ? nullptr : (MatchRow *)hrow);
+    if (rc) return rc;
+    // rank r's rows sit behind its header row; the last ranks may hold fewer rows, or none
+    std::vector<MatchRow> rows((size_t)N1);
+    for (int r = 0; r < world; r++) {
+      const int rlo = std::min(N1, r * per), rn = std::min(N1, rlo + per) - rlo;
+      if (rn > 0) memcpy(rows.data() + rlo, (const MatchRow *)hrow + (size_t)r * (per + 1) + 1, (size_t)rn * sizeof(MatchRow));
+    }
+    rows_to_tentatives(rows.data(), N1, nn, out[0]);
     return MODSX_OK;
   }
   size_t posOfs[MATCH_MAXB], rowOfs[MATCH_MAXB], workOfs[MATCH_MAXB], posB = 0, rowB = 0, workB = 0;

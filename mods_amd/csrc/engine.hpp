@@ -277,5 +277,6 @@ struct modsx_ctx {
   hipEvent_t ev[8];
   double timings[6];
   mx::Profiler prof;
+  int shardLane = 0;           // lane of the rank's communicator this context issues its collectives on (engine_shard.hip)
   modsx_ctx *peer = nullptr;   // second stream + buffers, created on demand: the two images of a multi-view pair run side by side
 };

@@ -4,6 +4,8 @@
 #include <vector>
 #include "engine.hpp"
 
+struct modsx_comm;
+
 namespace mx {
 const char *last_error();
 void prof_collect(modsx_ctx *c);
@@ -39,14 +41,23 @@ void rebase_ids(std::vector<modsx_region> &regs, const int *viewCounts, int nv, 
 struct VerifyTask;
 // defer != nullptr (one-step ladders only): the tentatives are matched and handed back unverified
 int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_ladder_step *steps, int nsteps,
-                 int min_matches, const modsx_pair_params &pp, modsx_pair_result *res, int *steps_done, VerifyTask *defer = nullptr);
+                 int min_matches, const modsx_pair_params &pp, modsx_pair_result *res, int *steps_done, VerifyTask *defer = nullptr,
+                 modsx_comm *comm = nullptr, int owner = -1);
 int match_pair_views(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_view *views, int nv,
                      const modsx_pair_params &pp, modsx_pair_result *res, VerifyTask *defer = nullptr);
 void prof_begin(modsx_ctx *c, int cls, double work, size_t *slot);
 void prof_end(modsx_ctx *c, size_t slot);
 // a sharded match (engine_shard.hip): this rank owns the query rows [lo, lo + per) of n1_total
-struct MatchShard { void *comm; int per, n1_total, lo; };
-int match_shard_gather(modsx_ctx *c, const MatchShard &sh, mx::MatchRow *rowsLocal, mx::MatchRow **rowsAll);
+struct MatchShard { void *comm; int world, per, n1_total, lo; };
+// the lane's (per + 1)-row blocks (header row + result rows), grown by agreement; then header + all-gather + download + wait
+int match_shard_begin(modsx_ctx *c, const MatchShard &sh, mx::MatchRow **blk);
+int match_shard_gather(modsx_ctx *c, const MatchShard &sh, int local_rc, mx::MatchRow *host);
+int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *img, const modsx_view *views, int nv,
+                                  const modsx_pair_params &pp, std::vector<modsx_region> &regs, DevBuf &descAcc, size_t base,
+                                  int *viewCounts);
+int comm_rank(const modsx_comm *cm);
+int match_sharded(modsx_ctx *c, modsx_comm *cm, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2Host,
+                  double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out);
 int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
                        const double *const *pos2Host, double ratioT, double contradDist, int nn,
                        std::vector<modsx_tentative> *out, const MatchShard *shard);

@@ -3,34 +3,65 @@
 // Reference unit of parallelism: the synthesised views of an image are independent from GenerateSynthImageCorr through
 // DescribeRegions (the `#pragma omp parallel for` over views, imagerepresentation.cpp:612-622) and meet only in the ordered
 // concatenation of AddRegions (:2044-2045, ids re-based by AddRegionsToList :588-600).  Here view v belongs to rank
-// v mod world; ONE exchange step per image side rebuilds the reference's list on every rank:
-//   ncclAllGather of the per-view counts (nviews ints per rank), then ncclAllGather of the padded row blocks
-//   (row = modsx_region, 200 B, + the 128 u8 descriptor bytes = 328 B), both on the context's stream, device to device
-//   (xGMI between the GPUs of a node); a gather kernel then writes regions and descriptors in (view, detection) order.
+// v mod world; ONE collective per image side rebuilds the reference's list on every rank:
+//   every rank packs a BLOCK = header {magic, rc, rows, views, per-view counts} + its rows (row = modsx_region, 200 B, + the
+//   128 u8 descriptor bytes = 328 B) padded to the lane's agreed block size; one all-gather of the blocks on the context's
+//   stream, device to device (xGMI between the GPUs of a node); a kernel reads the W headers on the device and writes
+//   regions and descriptors in (view, detection) order.  The host learns the counts from the same download that brings the
+//   regions back.  A block that turns out too small (a rank had more rows than the agreed size) is seen by every rank in
+//   the headers: all of them grow the block size alike and repeat the exchange.
 // Matching splits the QUERY rows (rank r takes [r n1 / W, (r+1) n1 / W) against all of image 2); the per-query result rows
-// of the device matcher (32 B each) are all-gathered before the host turns them into tentatives, so every rank ends with
-// the full list in query order and no host object crosses ranks.  DuplicateFiltering + LO-RANSAC run on the owner rank.
+// of the device matcher (32 B each, behind a header row) are all-gathered before the host turns them into tentatives, so
+// every rank ends with the full list in query order and no host object crosses ranks.  DuplicateFiltering + LO-RANSAC run on
+// the owner rank (or on every rank: same input, same seed, same result -- how the sharded ladder agrees on its early exit).
 //
-// RCCL is bound at run time (dlopen; an already loaded librccl -- e.g. the one torch ships -- is reused), so libmodsx has
-// no link-time dependency on it and single-GPU users never load it.
+// What keeps W ranks from hanging each other:
+//  * ONE communicator per rank.  The contexts (host thread + stream) of a rank are LANES of that communicator; collectives
+//    are issued in strict round-robin lane order (lane 0's k-th, lane 1's k-th, ...), which is the same sequence on every
+//    rank whatever the thread timing -- collectives of one communicator must be issued in one global order, and several
+//    communicators per device can deadlock in the hardware queues.
+//  * Error agreement.  A rank-local failure before a collective travels IN the collective (the `rc` of the header); every
+//    rank returns the same error at the same point and none is left waiting.  Buffers a rank needs in order to take part
+//    (the blocks themselves) grow only at points every rank derives from the gathered headers, followed by a 4-byte
+//    all-gather of the allocation results.
+//  * A watchdog.  Every wait on a collective has a deadline (MODSX_COMM_TIMEOUT_MS, default 30 s): past it the
+//    communicator is aborted (ncclCommAbort), marked dead, and every call on it returns MODSX_ERR_TIMEOUT.
+//
+// Transports: RCCL, bound at run time (dlopen; an already loaded librccl -- e.g. the one torch ships -- is reused), so
+// libmodsx has no link-time dependency on it and single-GPU users never load it; and LOOPBACK: W ranks inside one process
+// on one device (one host thread per rank), the all-gather being W device-to-device copies between the ranks' buffers
+// behind an event handshake.  Everything above the transport -- blocks, headers, device-side ordering, id re-basing, the
+// query-row split, lanes, agreement, watchdog -- is the same code, which is how W = 2, 3, 8 are tested on a 1-GPU box.
 #include <dlfcn.h>
+#include <unistd.h>
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <rccl/rccl.h>
 #include "engine_api.hpp"
 
 namespace mx {
+
+using Clock = std::chrono::steady_clock;
 
 struct RcclApi {
   void *h = nullptr;
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GetVersion)(int *) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 static RcclApi g_rccl;
+static std::mutex g_rcclMu;
 static bool rccl_load() {
+  std::lock_guard<std::mutex> lk(g_rcclMu);
   if (g_rccl.h) return true;
   const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void *h = nullptr;
@@ -42,41 +73,204 @@ static bool rccl_load() {
   a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
   a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
   a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+  a.CommAbort = (decltype(a.CommAbort))dlsym(h, "ncclCommAbort");
   a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
   a.GetVersion = (decltype(a.GetVersion))dlsym(h, "ncclGetVersion");
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
-  if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.GetVersion || !a.GetErrorString) {
+  if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.CommAbort || !a.AllGather || !a.GetVersion || !a.GetErrorString) {
     set_error("librccl lacks an expected symbol");
     return false;
   }
   g_rccl = a;
   return true;
 }
-#define MX_NCCL(expr)                                                                                   \
-  do {                                                                                                  \
-    ncclResult_t r_ = (expr);                                                                           \
-    if (r_ != ncclSuccess) {                                                                            \
-      mx::set_error(std::string(#expr) + ": " + g_rccl.GetErrorString(r_));                            \
-      return MODSX_ERR_DEVICE;                                                                          \
-    }                                                                                                   \
-  } while (0)
+
+// ---- loopback transport: W ranks of one process on one device ---------------------------------------------------------
+constexpr char LOOP_MAGIC[8] = {'M', 'X', 'L', 'O', 'O', 'P', '0', '1'};
+struct LoopGroup {
+  int world = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0, joined = 0;
+  long gen = 0;
+  bool dead = false;
+  struct Slot { const void *send = nullptr; void *recv = nullptr; size_t bytes = 0; hipEvent_t ready = nullptr, done = nullptr; };
+  std::vector<Slot> slots;
+  // all ranks of the group meet here; false = a rank did not show up within the deadline (the group is dead from then on)
+  bool barrier(int timeout_ms) {
+    std::unique_lock<std::mutex> lk(mu);
+    if (dead) return false;
+    const long g0 = gen;
+    if (++arrived == world) { arrived = 0; gen++; cv.notify_all(); return true; }
+    const auto deadline = Clock::now() + std::chrono::milliseconds(timeout_ms);
+    while (gen == g0 && !dead)
+      if (cv.wait_until(lk, deadline) == std::cv_status::timeout && gen == g0) { dead = true; cv.notify_all(); }
+    return gen != g0 && !dead;
+  }
+  void kill() { std::lock_guard<std::mutex> lk(mu); dead = true; cv.notify_all(); }
+};
+static std::mutex g_loopMu;
+static std::map<uint64_t, std::shared_ptr<LoopGroup>> g_loopGroups;
+static uint64_t g_loopNext = 1;
+
+struct ShardLane {
+  DevBuf blkLocal, blkAll, regsIn, regsOut, mLocal, mAll, rcDev, order;
+  PinBuf hRegs, hHdr, hRc;
+  size_t capBlock = 0;    // agreed: bytes of one region block the lane's buffers hold (blkLocal; blkAll = world x)
+  size_t capMatch = 0;    // agreed: bytes of one match block (mLocal; mAll = world x)
+  int guessRows = 0;      // agreed: rows per block of the next exchange (a function of the headers gathered so far)
+  size_t lastN = 0;       // local: list length of the last exchange (sizes the speculative region download)
+  bool retired = false;
+};
 
 }  // namespace mx
 
 struct modsx_comm {
-  ncclComm_t comm = nullptr;
-  int rank = 0, world = 1, version = 0;
-  mx::DevBuf rowsLocal, rowsAll, regsDev, cntDev, matchAll;
-  mx::PinBuf hRegs, hCnt;
-  long bytes_gathered = 0, collectives = 0;
+  // transport
+  ncclComm_t nccl = nullptr;
+  std::shared_ptr<mx::LoopGroup> loop;
+  int rank = 0, world = 1, version = 0, dev = 0;
+  int timeout_ms = 30000;
+  // lanes: the contexts of this rank, collectives issued round-robin
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<mx::ShardLane> lanes;
+  int turn = 0;
+  bool dead = false;
+  std::string deadWhy;
+  long bytes_gathered = 0, collectives = 0, retries = 0, agreements = 0;
 };
 
 namespace mx {
 
 constexpr int REG_B = (int)sizeof(modsx_region), ROW_B = REG_B + 128;
 static_assert(sizeof(modsx_region) == 200, "region rows are 200 + 128 bytes on the wire");
+constexpr int HDR_MAGIC = 0x4D585348;   // "MXSH"
+constexpr int HDR_FIXED = 4;            // ints before the per-view counts: magic, rc, rows, views
+static int hdr_bytes(int nv) { return ((HDR_FIXED + nv) * 4 + 63) & ~63; }
 
-// rows[i] = region i (REG_B bytes, 8-byte words) followed by its 128 descriptor bytes (16-byte words)
+static void comm_kill(modsx_comm *cm, const std::string &why) {
+  {
+    std::lock_guard<std::mutex> lk(cm->mu);
+    if (cm->dead) return;
+    cm->dead = true;
+    cm->deadWhy = why;
+    cm->cv.notify_all();
+  }
+  if (cm->loop) cm->loop->kill();
+  if (cm->nccl) { g_rccl.CommAbort(cm->nccl); cm->nccl = nullptr; }
+}
+static int comm_dead_rc(modsx_comm *cm) {
+  set_error("communicator is dead (" + cm->deadWhy + "): a collective timed out or failed; destroy it and create a new one");
+  return MODSX_ERR_TIMEOUT;
+}
+
+// round-robin issue order over the lanes that are still active
+static int turn_begin(modsx_comm *cm, int lane) {
+  std::unique_lock<std::mutex> lk(cm->mu);
+  const auto deadline = Clock::now() + std::chrono::milliseconds(cm->timeout_ms);
+  while (!cm->dead && cm->turn != lane) {
+    if (cm->cv.wait_until(lk, deadline) == std::cv_status::timeout && cm->turn != lane && !cm->dead) {
+      lk.unlock();
+      comm_kill(cm, "lane " + std::to_string(lane) + " waited " + std::to_string(cm->timeout_ms) + " ms for its turn (lane " +
+                        std::to_string(cm->turn) + " never issued its collective)");
+      return comm_dead_rc(cm);
+    }
+  }
+  if (cm->dead) { lk.unlock(); return comm_dead_rc(cm); }
+  return MODSX_OK;
+}
+static void turn_advance_locked(modsx_comm *cm) {
+  const int L = (int)cm->lanes.size();
+  for (int k = 1; k <= L; k++) {
+    const int t = (cm->turn + k) % L;
+    if (!cm->lanes[t].retired) { cm->turn = t; break; }
+  }
+  cm->cv.notify_all();
+}
+static void turn_end(modsx_comm *cm) {
+  std::lock_guard<std::mutex> lk(cm->mu);
+  turn_advance_locked(cm);
+}
+
+// wait for the stream with the watchdog's deadline
+static int comm_wait(modsx_comm *cm, hipStream_t s) {
+  const auto t0 = Clock::now();
+  const auto deadline = t0 + std::chrono::milliseconds(cm->timeout_ms);
+  for (;;) {
+    hipError_t e = hipStreamQuery(s);
+    if (e == hipSuccess) return MODSX_OK;
+    if (e != hipErrorNotReady) { set_error(std::string("sharded path: ") + hipGetErrorString(e)); comm_kill(cm, "device error"); return MODSX_ERR_DEVICE; }
+    if (cm->dead) return comm_dead_rc(cm);
+    const auto now = Clock::now();
+    if (now > deadline) {
+      comm_kill(cm, "a collective did not complete within " + std::to_string(cm->timeout_ms) + " ms (a peer rank is missing)");
+      return comm_dead_rc(cm);
+    }
+    if (now - t0 > std::chrono::microseconds(200)) usleep(50); else std::this_thread::yield();
+  }
+}
+
+// the transport: enqueue an all-gather of `bytes` per rank on stream s (this rank's turn is held by the caller)
+static int transport_all_gather(modsx_comm *cm, const void *send, void *recv, size_t bytes, hipStream_t s) {
+  if (cm->dead) return comm_dead_rc(cm);
+  if (cm->nccl) {
+    ncclResult_t r = g_rccl.AllGather(send, recv, bytes, ncclUint8, cm->nccl, s);
+    if (r != ncclSuccess) {
+      set_error(std::string("ncclAllGather: ") + g_rccl.GetErrorString(r));
+      comm_kill(cm, "ncclAllGather failed");
+      return MODSX_ERR_DEVICE;
+    }
+  } else {
+    LoopGroup &g = *cm->loop;
+    const int W = cm->world, R = cm->rank;
+    LoopGroup::Slot &me = g.slots[R];
+    me.send = send; me.recv = recv; me.bytes = bytes;
+    MX_HIP(hipEventRecord(me.ready, s));
+    if (!g.barrier(cm->timeout_ms)) { comm_kill(cm, "loopback: a rank did not reach the collective"); return comm_dead_rc(cm); }
+    for (int p = 0; p < W; p++)
+      if (g.slots[p].bytes != bytes) { comm_kill(cm, "loopback: ranks disagree on the size of a collective"); return comm_dead_rc(cm); }
+    for (int p = 0; p < W; p++) {
+      MX_HIP(hipStreamWaitEvent(s, g.slots[p].ready, 0));
+      if (bytes) MX_HIP(hipMemcpyAsync((char *)recv + (size_t)p * bytes, g.slots[p].send, bytes, hipMemcpyDeviceToDevice, s));
+    }
+    MX_HIP(hipEventRecord(me.done, s));
+    if (!g.barrier(cm->timeout_ms)) { comm_kill(cm, "loopback: a rank left the collective"); return comm_dead_rc(cm); }
+    for (int p = 0; p < W; p++) MX_HIP(hipStreamWaitEvent(s, g.slots[p].done, 0));   // my send buffer is free once every peer copied it
+  }
+  cm->bytes_gathered += (long)bytes * cm->world;
+  cm->collectives++;
+  return MODSX_OK;
+}
+static int ordered_all_gather(modsx_comm *cm, int lane, const void *send, void *recv, size_t bytes, hipStream_t s) {
+  int rc = turn_begin(cm, lane);
+  if (rc) return rc;
+  rc = transport_all_gather(cm, send, recv, bytes, s);
+  turn_end(cm);
+  return rc;
+}
+
+// every rank contributes the result of a local step (an allocation); all of them get the first failure in rank order
+static int comm_agree(modsx_comm *cm, int lane, hipStream_t s, int local_rc) {
+  ShardLane &L = cm->lanes[lane];
+  int *h = (int *)L.hRc.p, *d = (int *)L.rcDev.p;
+  h[0] = local_rc;
+  MX_HIP(hipMemcpyAsync(d, h, 4, hipMemcpyHostToDevice, s));
+  int rc = ordered_all_gather(cm, lane, d, d + 16, 4, s);
+  if (rc) return rc;
+  MX_HIP(hipMemcpyAsync(h + 16, d + 16, (size_t)cm->world * 4, hipMemcpyDeviceToHost, s));
+  rc = comm_wait(cm, s);
+  if (rc) return rc;
+  cm->agreements++;
+  for (int r = 0; r < cm->world; r++)
+    if (h[16 + r]) {
+      if (r != cm->rank || !local_rc) set_error("rank " + std::to_string(r) + " of the sharded call failed (" + std::to_string(h[16 + r]) + ")");
+      return h[16 + r];
+    }
+  return MODSX_OK;
+}
+
+// block = header + rows; rows[i] = region i (REG_B bytes, 8-byte words) followed by its 128 descriptor bytes
 __global__ void k_pack_rows(const unsigned char *regs, const unsigned char *desc, int n, unsigned char *rows) {
   const int i = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
   if (i >= n) return;
@@ -84,17 +278,40 @@ __global__ void k_pack_rows(const unsigned char *regs, const unsigned char *desc
   if (l < REG_B / 8) reinterpret_cast<uint64_t *>(dst)[l] = reinterpret_cast<const uint64_t *>(regs + (size_t)i * REG_B)[l];
   if (l < 16) reinterpret_cast<uint64_t *>(dst + REG_B)[l] = reinterpret_cast<const uint64_t *>(desc + (size_t)i * 128)[l];
 }
-// out row j comes from gathered row src[j]; split back into the region array and the descriptor matrix
-__global__ void k_unpack_rows(const unsigned char *rowsAll, const int *src, int n, unsigned char *regs, unsigned char *desc) {
-  const int j = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
-  if (j >= n) return;
-  const unsigned char *s = rowsAll + (size_t)src[j] * ROW_B;
-  if (l < REG_B / 8) reinterpret_cast<uint64_t *>(regs + (size_t)j * REG_B)[l] = reinterpret_cast<const uint64_t *>(s)[l];
-  if (l < 16) reinterpret_cast<uint64_t *>(desc + (size_t)j * 128)[l] = reinterpret_cast<const uint64_t *>(s + REG_B)[l];
+
+// The reference's order from the gathered blocks, on the device: view v is rank v mod W's, at that rank's running offset;
+// its rows go to the list position the views before it fill (AddRegions' concatenation).  One 32-lane group per row slot
+// (rank r, row i < G); every workgroup rebuilds the two small prefix tables from the W headers in LDS.
+constexpr int SHARD_MAXV = 1024, SHARD_MAXW = 64;
+__global__ __launch_bounds__(256) void k_unpack_blocks(const unsigned char *all, int W, int nv, int G, size_t blockB, int hdrB,
+                                                       unsigned char *regs, unsigned char *desc, size_t cap) {
+  __shared__ int viewStart[SHARD_MAXV], runStart[SHARD_MAXV], cnt[SHARD_MAXV], run[SHARD_MAXW];
+  for (int v = threadIdx.x; v < nv; v += 256) {
+    const int *h = reinterpret_cast<const int *>(all + (size_t)(v % W) * blockB);
+    cnt[v] = h[HDR_FIXED + v];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int r = 0; r < W; r++) run[r] = 0;
+    int tot = 0;
+    for (int v = 0; v < nv; v++) { const int r = v % W; viewStart[v] = tot; runStart[v] = run[r]; run[r] += cnt[v]; tot += cnt[v]; }
+  }
+  __syncthreads();
+  const long slot = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int l = threadIdx.x & 31;
+  const int r = (int)(slot / G), i = (int)(slot % G);
+  if (r >= W || i >= min(run[r], G)) return;
+  int v = r;
+  while (v + W < nv && runStart[v + W] <= i) v += W;     // views of rank r in ascending order; an empty one shares its start with the next
+  const size_t j = (size_t)viewStart[v] + (i - runStart[v]);
+  if (j >= cap) return;
+  const unsigned char *s = all + (size_t)r * blockB + hdrB + (size_t)i * ROW_B;
+  if (l < REG_B / 8) reinterpret_cast<uint64_t *>(regs + j * REG_B)[l] = reinterpret_cast<const uint64_t *>(s)[l];
+  if (l < 16) reinterpret_cast<uint64_t *>(desc + j * 128)[l] = reinterpret_cast<const uint64_t *>(s + REG_B)[l];
 }
 
-// Position of every row of the reference's list inside the all-gathered buffer: view v is rank v mod W's, at that rank's
-// running offset; rank r's block starts at r * maxrows.  counts[r * nviews + v].  Returns the list length.
+// Position of every row of the reference's list inside the all-gathered buffer (the host statement of what
+// k_unpack_blocks computes; tests compare the two): counts[r * nviews + v].  Returns the list length.
 int view_block_order(const int *counts, int world, int nviews, int maxrows, std::vector<int> &src) {
   src.clear();
   std::vector<int> run(world, 0);
@@ -106,116 +323,203 @@ int view_block_order(const int *counts, int world, int nviews, int maxrows, std:
   return (int)src.size();
 }
 
-// The sharded SynthDetectDescribeKeypoints: regions of ALL views in reference order on every rank (ids re-based),
-// u8 descriptors in `descOut` (device, grown as needed).
+int comm_rank(const modsx_comm *cm) { return cm->rank; }
+
+static int lane_of(modsx_ctx *c, modsx_comm *cm) {
+  const int lane = c->shardLane;
+  return lane >= 0 && lane < (int)cm->lanes.size() ? lane : 0;
+}
+
+// grow a device buffer keeping its first `keep` bytes (the accumulated descriptors of earlier ladder steps)
+static int grow_keep(hipStream_t s, DevBuf &b, size_t keep, size_t bytes) {
+  if (b.cap >= bytes) return MODSX_OK;
+  DevBuf bigger;
+  if (!bigger.ensure(bytes)) return MODSX_ERR_NOMEM;
+  if (keep && b.p) {
+    MX_HIP(hipMemcpyAsync(bigger.p, b.p, keep, hipMemcpyDeviceToDevice, s));
+    MX_HIP(hipStreamSynchronize(s));
+  }
+  b.release();
+  b = bigger;
+  return MODSX_OK;
+}
+
+// The sharded SynthDetectDescribeKeypoints + AddRegions: the regions of ALL views of this step in reference order on every
+// rank (ids re-based onto a list that already holds `base` regions), their u8 descriptors appended at row `base` of descAcc.
 int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *img, const modsx_view *views, int nv,
-                                  const modsx_pair_params &pp, std::vector<modsx_region> &regs, DevBuf &descOut, int *viewCounts) {
+                                  const modsx_pair_params &pp, std::vector<modsx_region> &regs, DevBuf &descAcc, size_t base,
+                                  int *viewCounts) {
+  regs.clear();
+  if (cm->dead) return comm_dead_rc(cm);
+  if (nv < 1 || nv > SHARD_MAXV || cm->world > SHARD_MAXW) { set_error("sharded path: at most 1024 views and 64 ranks"); return MODSX_ERR_ARG; }
   hipStream_t s = c->stream;
-  const int W = cm->world, R = cm->rank;
+  const int W = cm->world, R = cm->rank, lane = lane_of(c, cm);
+  ShardLane &L = cm->lanes[lane];
+  // 1. this rank's views.  A failure here does not return: it travels in the header, so that no rank waits for this one.
   std::vector<modsx_region> local;
   std::vector<int> cnt(nv, 0);
+  int lrc = MODSX_OK;
+  std::string lerr;
   size_t cap = (size_t)1 << 15;
   for (;;) {
-    if (!c->descAllU8b[0].ensure(cap * 128)) return MODSX_ERR_NOMEM;
-    int rc = detect_describe_views(c, img, views, nv, pp, R, W, local, nullptr, (uint8_t *)c->descAllU8b[0].p, cap, nullptr,
-                                   cnt.data());
-    if (rc == MODSX_ERR_CAPACITY && cap < ((size_t)1 << 24)) { cap *= 4; continue; }
-    if (rc) return rc;
+    if (!c->descAllU8b[1].ensure(cap * 128)) { lrc = MODSX_ERR_NOMEM; break; }
+    lrc = detect_describe_views(c, img, views, nv, pp, R, W, local, nullptr, (uint8_t *)c->descAllU8b[1].p, cap, nullptr, cnt.data());
+    if (lrc == MODSX_ERR_CAPACITY && cap < ((size_t)1 << 24)) { cap *= 4; continue; }
     break;
   }
+  if (lrc) { lerr = last_error(); local.clear(); std::fill(cnt.begin(), cnt.end(), 0); }
   const int nloc = (int)local.size();
-  // 1. counts of every rank
-  if (!cm->cntDev.ensure((size_t)(W + 1) * nv * 4) || !cm->hCnt.ensure((size_t)(W + 1) * nv * 4)) return MODSX_ERR_NOMEM;
-  int *hc = (int *)cm->hCnt.p, *dc = (int *)cm->cntDev.p;
-  memcpy(hc, cnt.data(), (size_t)nv * 4);
-  MX_HIP(hipMemcpyAsync(dc, hc, (size_t)nv * 4, hipMemcpyHostToDevice, s));
-  MX_NCCL(g_rccl.AllGather(dc, dc + nv, nv, ncclInt32, cm->comm, s));
-  MX_HIP(hipMemcpyAsync(hc + nv, dc + nv, (size_t)W * nv * 4, hipMemcpyDeviceToHost, s));
-  // 2. local rows = region + descriptor (regions go up once; descriptors never left the device)
-  if (!cm->hRegs.ensure((size_t)std::max(1, nloc) * REG_B) || !cm->regsDev.ensure((size_t)std::max(1, nloc) * REG_B)) return MODSX_ERR_NOMEM;
-  if (nloc) {
-    memcpy(cm->hRegs.p, local.data(), (size_t)nloc * REG_B);
-    MX_HIP(hipMemcpyAsync(cm->regsDev.p, cm->hRegs.p, (size_t)nloc * REG_B, hipMemcpyHostToDevice, s));
+  const int hdrB = hdr_bytes(nv);
+  if (!L.guessRows) L.guessRows = 4096;
+  for (int attempt = 0;; attempt++) {
+    const int G = L.guessRows;
+    const size_t blockB = (size_t)hdrB + (size_t)G * ROW_B;
+    // 2. buffers a rank needs to take part grow at points every rank computes alike, and the outcome is agreed
+    if (blockB > L.capBlock) {
+      int arc = MODSX_OK;
+      if (!L.blkLocal.ensure(blockB) || !L.blkAll.ensure(blockB * W)) arc = MODSX_ERR_NOMEM;
+      arc = comm_agree(cm, lane, s, arc);
+      if (arc) return arc;
+      L.capBlock = blockB;
+    }
+    // 3. everything else this rank needs: a failure is reported through the header
+    const size_t rowsCap = (size_t)W * G;
+    if (!L.hHdr.ensure((size_t)hdrB * (W + 1))) { comm_kill(cm, "no pinned memory for a block header"); return MODSX_ERR_NOMEM; }
+    if (!lrc) {
+      if (!L.regsIn.ensure((size_t)std::max(1, nloc) * REG_B) || !L.hRegs.ensure(std::max((size_t)std::max(1, nloc), rowsCap) * REG_B) ||
+          !L.regsOut.ensure(rowsCap * REG_B) || grow_keep(s, descAcc, base * 128, (base + rowsCap) * 128) != MODSX_OK) {
+        lrc = MODSX_ERR_NOMEM; lerr = "sharded path: out of memory";
+      }
+    }
+    int *hh = (int *)L.hHdr.p;
+    memset(hh, 0, hdrB);
+    hh[0] = HDR_MAGIC; hh[1] = lrc; hh[2] = lrc ? 0 : nloc; hh[3] = nv;
+    if (!lrc) memcpy(hh + HDR_FIXED, cnt.data(), (size_t)nv * 4);
+    MX_HIP(hipMemcpyAsync(L.blkLocal.p, hh, hdrB, hipMemcpyHostToDevice, s));
+    const int npack = lrc ? 0 : std::min(nloc, G);
+    if (npack) {
+      memcpy(L.hRegs.p, local.data(), (size_t)npack * REG_B);
+      MX_HIP(hipMemcpyAsync(L.regsIn.p, L.hRegs.p, (size_t)npack * REG_B, hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(k_pack_rows, dim3((npack + 7) / 8), dim3(256), 0, s, (const unsigned char *)L.regsIn.p,
+                         (const unsigned char *)c->descAllU8b[1].p, npack, (unsigned char *)L.blkLocal.p + hdrB);
+    }
+    // 4. the exchange: one all-gather of the blocks
+    int rc = ordered_all_gather(cm, lane, L.blkLocal.p, L.blkAll.p, blockB, s);
+    if (rc) return rc;
+    // 5. headers down; reference order on the device; a first guess of the regions down with the same wait
+    MX_HIP(hipMemcpy2DAsync((char *)L.hHdr.p + hdrB, hdrB, L.blkAll.p, blockB, hdrB, W, hipMemcpyDeviceToHost, s));
+    size_t got = 0;
+    if (!lrc) {
+      hipLaunchKernelGGL(k_unpack_blocks, dim3((unsigned)((rowsCap + 7) / 8)), dim3(256), 0, s, (const unsigned char *)L.blkAll.p, W, nv, G,
+                         blockB, hdrB, (unsigned char *)L.regsOut.p, (unsigned char *)descAcc.p + base * 128, rowsCap);
+      got = std::min(rowsCap, L.lastN + L.lastN / 4 + 256);
+      MX_HIP(hipMemcpyAsync(L.hRegs.p, L.regsOut.p, got * REG_B, hipMemcpyDeviceToHost, s));
+    }
+    rc = comm_wait(cm, s);
+    if (rc) return rc;
+    MX_HIP(hipGetLastError());
+    // 6. what every rank sees alike: a failed rank, or a block that was too small
+    int maxrows = 0;
+    size_t N = 0;
+    std::vector<int> vc(nv, 0);
+    for (int r = 0; r < W; r++) {
+      const int *h = (const int *)((char *)L.hHdr.p + (size_t)hdrB * (r + 1));
+      if (h[0] != HDR_MAGIC || h[3] != nv) { comm_kill(cm, "a gathered block header is malformed (ranks out of step)"); return comm_dead_rc(cm); }
+      if (h[1]) {
+        if (r == R) set_error(lerr); else set_error("rank " + std::to_string(r) + " failed in the sharded detect / describe (" + std::to_string(h[1]) + ")");
+        return h[1];
+      }
+      maxrows = std::max(maxrows, h[2]);
+      for (int v = r; v < nv; v += W) { vc[v] = h[HDR_FIXED + v]; N += (size_t)vc[v]; }
+    }
+    if (maxrows > G) {        // every rank takes this branch together
+      L.guessRows = maxrows + maxrows / 4 + 64;
+      cm->retries++;
+      if (attempt > 2) { comm_kill(cm, "block size does not converge"); return comm_dead_rc(cm); }
+      continue;
+    }
+    L.guessRows = std::max(G, maxrows + maxrows / 4 + 64);
+    L.lastN = N;
+    if (viewCounts) for (int v = 0; v < nv; v++) viewCounts[v] = vc[v];
+    regs.resize(N);
+    if (N > got) {           // the speculative download was short (first call, or a much larger image)
+      MX_HIP(hipMemcpyAsync((char *)L.hRegs.p + got * REG_B, (char *)L.regsOut.p + got * REG_B, (N - got) * REG_B, hipMemcpyDeviceToHost, s));
+      rc = comm_wait(cm, s);
+      if (rc) return rc;
+    }
+    if (N) memcpy(regs.data(), L.hRegs.p, N * REG_B);
+    rebase_ids(regs, vc.data(), nv, base);
+    return MODSX_OK;
   }
-  MX_HIP(hipStreamSynchronize(s));
-  const int *all = hc + nv;
-  int maxrows = 0;
-  for (int r = 0; r < W; r++) {
-    int t = 0;
-    for (int v = 0; v < nv; v++) t += all[r * nv + v];
-    maxrows = std::max(maxrows, t);
-  }
-  std::vector<int> src;
-  const int N = view_block_order(all, W, nv, maxrows, src);
-  if (viewCounts) for (int v = 0; v < nv; v++) viewCounts[v] = all[(v % W) * nv + v];
-  regs.resize(N);
-  if (!N) return MODSX_OK;
-  if (!cm->rowsLocal.ensure((size_t)maxrows * ROW_B) || !cm->rowsAll.ensure((size_t)W * maxrows * ROW_B)) return MODSX_ERR_NOMEM;
-  if (nloc) hipLaunchKernelGGL(k_pack_rows, dim3((nloc + 7) / 8), dim3(256), 0, s, (const unsigned char *)cm->regsDev.p,
-                               (const unsigned char *)c->descAllU8b[0].p, nloc, (unsigned char *)cm->rowsLocal.p);
-  // 3. the exchange: one all-gather of the padded blocks
-  MX_NCCL(g_rccl.AllGather(cm->rowsLocal.p, cm->rowsAll.p, (size_t)maxrows * ROW_B, ncclUint8, cm->comm, s));
-  cm->bytes_gathered += (long)W * maxrows * ROW_B; cm->collectives += 2;
-  // 4. reference order on the device; regions come down, descriptors stay
-  if (!c->misc.ensure((size_t)N * 4) || !descOut.ensure((size_t)N * 128) || !cm->regsDev.ensure((size_t)N * REG_B) ||
-      !cm->hRegs.ensure((size_t)N * REG_B)) return MODSX_ERR_NOMEM;
-  MX_HIP(hipMemcpyAsync(c->misc.p, src.data(), (size_t)N * 4, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_unpack_rows, dim3((N + 7) / 8), dim3(256), 0, s, (const unsigned char *)cm->rowsAll.p, (const int *)c->misc.p, N,
-                     (unsigned char *)cm->regsDev.p, (unsigned char *)descOut.p);
-  MX_HIP(hipMemcpyAsync(cm->hRegs.p, cm->regsDev.p, (size_t)N * REG_B, hipMemcpyDeviceToHost, s));
-  MX_HIP(hipStreamSynchronize(s));   // also keeps `src` alive until the upload is done
-  MX_HIP(hipGetLastError());
-  memcpy(regs.data(), cm->hRegs.p, (size_t)N * REG_B);
-  std::vector<int> vc(nv);
-  for (int v = 0; v < nv; v++) vc[v] = all[(v % W) * nv + v];
-  rebase_ids(regs, vc.data(), nv, 0);
-  return MODSX_OK;
 }
 
 // MatchFlannFGINN with the query rows split over the ranks (d1 / d2 hold ALL descriptors on every rank)
 int match_sharded(modsx_ctx *c, modsx_comm *cm, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2Host,
                   double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out) {
   out.clear();
-  if (n1 <= 0 || n2 <= 0) return MODSX_OK;
+  if (cm->dead) return comm_dead_rc(cm);
+  if (n1 <= 0 || n2 <= 0) return MODSX_OK;   // the same on every rank: nobody issues a collective
   const int W = cm->world, R = cm->rank;
   const int per = (n1 + W - 1) / W;                 // rows per rank (the last ranks may hold fewer or none)
-  const int lo = std::min(n1, R * per), hi = std::min(n1, lo + per);
+  const int lo = std::min(n1, R * per);
   MatchShard sh;
-  sh.comm = cm; sh.per = per; sh.n1_total = n1; sh.lo = lo;
+  sh.comm = cm; sh.world = W; sh.per = per; sh.n1_total = n1; sh.lo = lo;
   return match_device_batch(c, 1, &d1, &n1, &d2, &n2, &pos2Host, ratioT, contradDist, nn, &out, &sh);
 }
 
-// called by match_device_batch between the matcher launches and the D2H of the result rows
-int match_shard_gather(modsx_ctx *c, const MatchShard &sh, MatchRow *rowsLocal, MatchRow **rowsAll) {
+// match_device_batch, sharded branch, step 1: the lane's blocks ((per + 1) result rows: a header row, then the rows of this
+// rank's queries).  Growth is agreed; *blk = the local block.
+int match_shard_begin(modsx_ctx *c, const MatchShard &sh, MatchRow **blk) {
   modsx_comm *cm = (modsx_comm *)sh.comm;
-  const size_t blk = (size_t)sh.per * sizeof(MatchRow);
-  if (!cm->matchAll.ensure(blk * cm->world)) return MODSX_ERR_NOMEM;
-  MX_NCCL(g_rccl.AllGather(rowsLocal, cm->matchAll.p, blk, ncclUint8, cm->comm, c->stream));
-  cm->bytes_gathered += (long)blk * cm->world; cm->collectives++;
-  *rowsAll = (MatchRow *)cm->matchAll.p;
+  const int lane = lane_of(c, cm);
+  ShardLane &L = cm->lanes[lane];
+  const size_t blockB = (size_t)(sh.per + 1) * sizeof(MatchRow);
+  if (blockB > L.capMatch) {
+    int arc = MODSX_OK;
+    if (!L.mLocal.ensure(blockB) || !L.mAll.ensure(blockB * cm->world)) arc = MODSX_ERR_NOMEM;
+    arc = comm_agree(cm, lane, c->stream, arc);
+    if (arc) return arc;
+    L.capMatch = blockB;
+  }
+  *blk = (MatchRow *)L.mLocal.p;
   return MODSX_OK;
+}
+// step 2, after the matcher launches: header (with this rank's local result), all-gather, the gathered blocks to `host`
+// (world x (per + 1) rows), one wait.  Returns the agreed result: the first failure in rank order.
+int match_shard_gather(modsx_ctx *c, const MatchShard &sh, int local_rc, MatchRow *host) {
+  modsx_comm *cm = (modsx_comm *)sh.comm;
+  const int lane = lane_of(c, cm), W = cm->world;
+  ShardLane &L = cm->lanes[lane];
+  hipStream_t s = c->stream;
+  const size_t blockB = (size_t)(sh.per + 1) * sizeof(MatchRow);
+  static_assert(sizeof(MatchRow) == 32, "match rows are 32 bytes on the wire");
+  int *h = (int *)L.hRc.p + 64;
+  h[0] = HDR_MAGIC; h[1] = local_rc; h[2] = sh.per; h[3] = sh.n1_total;
+  MX_HIP(hipMemcpyAsync(L.mLocal.p, h, 16, hipMemcpyHostToDevice, s));
+  int rc = ordered_all_gather(cm, lane, L.mLocal.p, L.mAll.p, blockB, s);
+  if (rc) return rc;
+  if (host) MX_HIP(hipMemcpyAsync(host, L.mAll.p, blockB * W, hipMemcpyDeviceToHost, s));
+  else MX_HIP(hipMemcpy2DAsync((int *)L.hRc.p + 128, 16, L.mAll.p, blockB, 16, W, hipMemcpyDeviceToHost, s));
+  rc = comm_wait(cm, s);
+  if (rc) return rc;
+  MX_HIP(hipGetLastError());
+  for (int r = 0; r < W; r++) {
+    const int *g = host ? (const int *)((const char *)host + blockB * r) : (const int *)L.hRc.p + 128 + 4 * r;
+    if (g[0] != HDR_MAGIC || g[2] != sh.per || g[3] != sh.n1_total) { comm_kill(cm, "a gathered match block is malformed (ranks out of step)"); return comm_dead_rc(cm); }
+    if (g[1]) {
+      if (r != cm->rank) set_error("rank " + std::to_string(r) + " failed in the sharded match (" + std::to_string(g[1]) + ")");
+      return g[1];
+    }
+  }
+  return local_rc;
 }
 
 int match_pair_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *img1, const modsx_image *img2, const modsx_view *views,
                              int nv, const modsx_pair_params &pp, int owner, modsx_pair_result *res) {
-  memset(res, 0, sizeof *res);
-  for (int i = 0; i < 9; i++) res->H[i] = -1;
-  std::vector<modsx_region> r1, r2;
-  int rc = detect_describe_views_sharded(c, cm, img1, views, nv, pp, r1, c->descAllU8[0], nullptr);
-  if (rc) return rc;
-  rc = detect_describe_views_sharded(c, cm, img2, views, nv, pp, r2, c->descAllU8[1], nullptr);
-  if (rc) return rc;
-  res->n_regions1 = (int)r1.size(); res->n_regions2 = (int)r2.size();
-  std::vector<double> pos2(r2.size() * 2 + 2);
-  for (size_t i = 0; i < r2.size(); i++) { pos2[2 * i] = r2[i].reproj_kp.x; pos2[2 * i + 1] = r2[i].reproj_kp.y; }
-  std::vector<modsx_tentative> tents;
-  rc = match_sharded(c, cm, (uint8_t *)c->descAllU8[0].p, (int)r1.size(), (uint8_t *)c->descAllU8[1].p, (int)r2.size(), pos2.data(),
-                     pp.match_ratio, pp.contradDist, pp.nn, tents);
-  if (rc) return rc;
-  res->n_tentatives = (int)tents.size();
-  if (owner < 0 || owner == cm->rank) verify_tentatives(r1, r2, tents, pp, res);   // DuplicateFiltering + LO-RANSAC: sequential, tiny
-  prof_collect(c);
-  return MODSX_OK;
+  modsx_ladder_step one;
+  one.views = views; one.nviews = nv; one.match_ratio = pp.match_ratio; one.detector = pp.detector;
+  int done = 0;
+  return match_ladder(c, img1, img2, &one, 1, 0x7fffffff, pp, res, &done, nullptr, cm, owner);
 }
 
 }  // namespace mx
@@ -227,31 +531,130 @@ int modsx_comm_unique_id(void *id128) {
   if (!id128) { mx::set_error("modsx_comm_unique_id: null"); return MODSX_ERR_ARG; }
   if (!rccl_load()) return MODSX_ERR_DEVICE;
   ncclUniqueId id;
-  MX_NCCL(g_rccl.GetUniqueId(&id));
+  ncclResult_t r = g_rccl.GetUniqueId(&id);
+  if (r != ncclSuccess) { mx::set_error(std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r)); return MODSX_ERR_DEVICE; }
+  static_assert(sizeof id <= 128, "the id buffer of the C ABI is 128 bytes");
+  memset(id128, 0, 128);
   memcpy(id128, &id, sizeof id);
   return MODSX_OK;
 }
 
+int modsx_comm_loopback_id(void *id128, int world) {
+  if (!id128 || world < 1 || world > SHARD_MAXW) { mx::set_error("modsx_comm_loopback_id: bad argument"); return MODSX_ERR_ARG; }
+  std::lock_guard<std::mutex> lk(g_loopMu);
+  const uint64_t key = g_loopNext++;
+  auto g = std::make_shared<LoopGroup>();
+  g->world = world;
+  g->slots.resize(world);
+  g_loopGroups[key] = g;
+  memset(id128, 0, 128);
+  memcpy(id128, LOOP_MAGIC, 8);
+  memcpy((char *)id128 + 8, &key, 8);
+  return MODSX_OK;
+}
+
+static int comm_make_lanes(modsx_comm *cm, int n) {
+  cm->lanes.clear();
+  cm->lanes.resize(n);
+  int guess = 0;   // MODSX_SHARD_BLOCK_ROWS: rows of the first exchange's blocks (tests use a small value to reach the retry path)
+  if (const char *e = getenv("MODSX_SHARD_BLOCK_ROWS")) guess = std::max(1, atoi(e));
+  for (ShardLane &L : cm->lanes) L.guessRows = guess;
+  for (ShardLane &L : cm->lanes)
+    if (!L.rcDev.ensure(4 * (16 + SHARD_MAXW)) || !L.hRc.ensure(4 * (128 + 4 * SHARD_MAXW))) return MODSX_ERR_NOMEM;
+  cm->turn = 0;
+  return MODSX_OK;
+}
+
 modsx_comm *modsx_comm_create(modsx_ctx *ctx, const void *id128, int rank, int world) {
-  if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) { mx::set_error("modsx_comm_create: bad argument"); return nullptr; }
-  if (!rccl_load()) return nullptr;
+  if (!ctx || !id128 || world < 1 || world > SHARD_MAXW || rank < 0 || rank >= world) { mx::set_error("modsx_comm_create: bad argument"); return nullptr; }
   hipSetDevice(ctx->dev);
-  modsx_comm *cm = new modsx_comm();
-  cm->rank = rank; cm->world = world;
-  ncclUniqueId id;
-  memcpy(&id, id128, sizeof id);
-  ncclResult_t r = g_rccl.CommInitRank(&cm->comm, world, id, rank);
-  if (r != ncclSuccess) { mx::set_error(std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); delete cm; return nullptr; }
-  g_rccl.GetVersion(&cm->version);
-  return cm;
+  std::unique_ptr<modsx_comm> cm(new modsx_comm());
+  cm->rank = rank; cm->world = world; cm->dev = ctx->dev;
+  if (const char *e = getenv("MODSX_COMM_TIMEOUT_MS")) cm->timeout_ms = std::max(1, atoi(e));
+  if (!memcmp(id128, LOOP_MAGIC, 8)) {
+    uint64_t key;
+    memcpy(&key, (const char *)id128 + 8, 8);
+    std::lock_guard<std::mutex> lk(g_loopMu);
+    auto it = g_loopGroups.find(key);
+    if (it == g_loopGroups.end() || it->second->world != world) { mx::set_error("modsx_comm_create: unknown loopback group or wrong world size"); return nullptr; }
+    cm->loop = it->second;
+    LoopGroup::Slot &sl = cm->loop->slots[rank];
+    if (sl.ready) { mx::set_error("modsx_comm_create: loopback rank already taken"); return nullptr; }
+    if (hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
+      mx::set_error("modsx_comm_create: hipEventCreate failed");
+      return nullptr;
+    }
+    if (++cm->loop->joined == world) g_loopGroups.erase(it);   // complete: the id cannot be joined again
+  } else {
+    if (!rccl_load()) return nullptr;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclResult_t r = g_rccl.CommInitRank(&cm->nccl, world, id, rank);
+    if (r != ncclSuccess) { mx::set_error(std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); return nullptr; }
+    g_rccl.GetVersion(&cm->version);
+  }
+  if (comm_make_lanes(cm.get(), 1)) { if (cm->nccl) g_rccl.CommDestroy(cm->nccl); return nullptr; }
+  ctx->shardLane = 0;
+  return cm.release();
+}
+
+int modsx_comm_set_lanes(modsx_comm *cm, int nlanes) {
+  if (!cm || nlanes < 1 || nlanes > 256) { mx::set_error("modsx_comm_set_lanes: bad argument"); return MODSX_ERR_ARG; }
+  hipSetDevice(cm->dev);
+  std::lock_guard<std::mutex> lk(cm->mu);
+  for (ShardLane &L : cm->lanes) {
+    DevBuf *bufs[] = {&L.blkLocal, &L.blkAll, &L.regsIn, &L.regsOut, &L.mLocal, &L.mAll, &L.rcDev, &L.order};
+    for (DevBuf *b : bufs) b->release();
+    L.hRegs.release(); L.hHdr.release(); L.hRc.release();
+  }
+  return comm_make_lanes(cm, nlanes);
+}
+
+int modsx_comm_attach(modsx_comm *cm, modsx_ctx *ctx, int lane) {
+  if (!cm || !ctx || lane < 0 || lane >= (int)cm->lanes.size()) { mx::set_error("modsx_comm_attach: bad argument"); return MODSX_ERR_ARG; }
+  ctx->shardLane = lane;
+  return MODSX_OK;
+}
+
+int modsx_comm_lane_done(modsx_comm *cm, int lane) {
+  if (!cm || lane < 0 || lane >= (int)cm->lanes.size()) { mx::set_error("modsx_comm_lane_done: bad argument"); return MODSX_ERR_ARG; }
+  std::lock_guard<std::mutex> lk(cm->mu);
+  cm->lanes[lane].retired = true;
+  if (cm->turn == lane) turn_advance_locked(cm);
+  return MODSX_OK;
+}
+
+int modsx_comm_reset_lanes(modsx_comm *cm) {
+  if (!cm) { mx::set_error("modsx_comm_reset_lanes: null"); return MODSX_ERR_ARG; }
+  std::lock_guard<std::mutex> lk(cm->mu);
+  for (ShardLane &L : cm->lanes) L.retired = false;
+  cm->turn = 0;
+  cm->cv.notify_all();
+  return MODSX_OK;
+}
+
+int modsx_comm_set_timeout(modsx_comm *cm, int ms) {
+  if (!cm || ms < 1) { mx::set_error("modsx_comm_set_timeout: bad argument"); return MODSX_ERR_ARG; }
+  cm->timeout_ms = ms;
+  return MODSX_OK;
 }
 
 void modsx_comm_destroy(modsx_comm *cm) {
   if (!cm) return;
-  if (cm->comm) g_rccl.CommDestroy(cm->comm);
-  DevBuf *bufs[] = {&cm->rowsLocal, &cm->rowsAll, &cm->regsDev, &cm->cntDev, &cm->matchAll};
-  for (DevBuf *b : bufs) b->release();
-  cm->hRegs.release(); cm->hCnt.release();
+  hipSetDevice(cm->dev);
+  if (cm->nccl) { if (cm->dead) g_rccl.CommAbort(cm->nccl); else g_rccl.CommDestroy(cm->nccl); }
+  if (cm->loop) {
+    LoopGroup::Slot &sl = cm->loop->slots[cm->rank];
+    hipDeviceSynchronize();
+    if (sl.ready) hipEventDestroy(sl.ready);
+    if (sl.done) hipEventDestroy(sl.done);
+    sl.ready = sl.done = nullptr;
+  }
+  for (ShardLane &L : cm->lanes) {
+    DevBuf *bufs[] = {&L.blkLocal, &L.blkAll, &L.regsIn, &L.regsOut, &L.mLocal, &L.mAll, &L.rcDev, &L.order};
+    for (DevBuf *b : bufs) b->release();
+    L.hRegs.release(); L.hHdr.release(); L.hRc.release();
+  }
   delete cm;
 }
 
@@ -263,6 +666,14 @@ int modsx_comm_info(const modsx_comm *cm, int *rank, int *world, int *rccl_versi
   if (bytes_gathered) *bytes_gathered = cm->bytes_gathered;
   if (collectives) *collectives = cm->collectives;
   return MODSX_OK;
+}
+
+int modsx_comm_stats(const modsx_comm *cm, long *out, int n) {
+  if (!cm || !out) { mx::set_error("modsx_comm_stats: null"); return MODSX_ERR_ARG; }
+  const long v[] = {cm->collectives, cm->bytes_gathered, cm->retries, cm->agreements, (long)cm->lanes.size(), cm->loop ? 1L : 0L, cm->dead ? 1L : 0L};
+  const int m = (int)(sizeof v / sizeof v[0]);
+  for (int i = 0; i < n && i < m; i++) out[i] = v[i];
+  return m;
 }
 
 int modsx_view_block_order(const int *counts, int world, int nviews, int *src, int cap, int *maxrows_out) {
@@ -285,7 +696,7 @@ int modsx_detect_describe_views_sharded(modsx_ctx *ctx, modsx_comm *comm, const 
   if (!ctx || !comm || !img || !views || !par || !regs || nviews <= 0) { mx::set_error("modsx_detect_describe_views_sharded: bad argument"); return MODSX_ERR_ARG; }
   hipSetDevice(ctx->dev);
   std::vector<modsx_region> r;
-  int rc = detect_describe_views_sharded(ctx, comm, img, views, nviews, *par, r, ctx->descAllU8[0], view_counts);
+  int rc = detect_describe_views_sharded(ctx, comm, img, views, nviews, *par, r, ctx->descAllU8[0], 0, view_counts);
   if (rc) return rc;
   if (dev_desc_u8) *dev_desc_u8 = ctx->descAllU8[0].p;
   modsx_region *p = (modsx_region *)malloc(sizeof(modsx_region) * std::max<size_t>(1, r.size()));
@@ -315,6 +726,17 @@ int modsx_match_pair_views_sharded(modsx_ctx *ctx, modsx_comm *comm, const modsx
   if (!ctx || !comm || !img1 || !img2 || !views || !par || !res || nviews <= 0) { mx::set_error("modsx_match_pair_views_sharded: bad argument"); return MODSX_ERR_ARG; }
   hipSetDevice(ctx->dev);
   return match_pair_views_sharded(ctx, comm, img1, img2, views, nviews, *par, owner, res);
+}
+
+int modsx_match_ladder_sharded(modsx_ctx *ctx, modsx_comm *comm, const modsx_image *img1, const modsx_image *img2,
+                               const modsx_ladder_step *steps, int nsteps, int min_matches, const modsx_pair_params *par,
+                               modsx_pair_result *res, int *steps_done) {
+  if (!ctx || !comm || !img1 || !img2 || !steps || nsteps < 1 || !par || !res) { mx::set_error("modsx_match_ladder_sharded: bad argument"); return MODSX_ERR_ARG; }
+  for (int i = 0; i < nsteps; i++)
+    if (!steps[i].views || steps[i].nviews < 1) { mx::set_error("modsx_match_ladder_sharded: a step without views"); return MODSX_ERR_ARG; }
+  hipSetDevice(ctx->dev);
+  // every rank verifies (owner -1): same tentatives, same seed, same result -- the early exit needs no collective
+  return match_ladder(ctx, img1, img2, steps, nsteps, min_matches, *par, res, steps_done, nullptr, comm, -1);
 }
 
 }  // extern "C"

@@ -400,13 +400,19 @@ struct LadderClass {
 // (SynthDetectDescribeKeypoints + AddRegions, imagerepresentation.cpp:603-2047).  The accumulator is re-allocated
 // (device-to-device copy) when the step does not fit.
 static int accumulate_views(modsx_ctx *c, LadderClass &k, int side, const modsx_image *img, const modsx_view *views, int nv,
-                            const modsx_pair_params &pp) {
+                            const modsx_pair_params &pp, modsx_comm *cm) {
   std::vector<modsx_region> &acc = k.regs[side];
   DevBuf &buf = *k.buf[side];
   size_t &cap = k.cap[side];
   const size_t base = acc.size();
   std::vector<modsx_region> step;
   std::vector<int> counts(std::max(1, nv), 0);
+  if (cm) {   // view-sharded: this rank runs its views, the exchange appends the whole step in reference order (ids re-based)
+    int rc = detect_describe_views_sharded(c, cm, img, views, nv, pp, step, buf, base, counts.data());
+    if (rc) return rc;
+    acc.insert(acc.end(), step.begin(), step.end());
+    return MODSX_OK;
+  }
   for (;;) {
     if (buf.cap < cap * 128) {
       DevBuf bigger;
@@ -441,7 +447,8 @@ int match_pair_views(modsx_ctx *c, const modsx_image *img1, const modsx_image *i
 // verification, duplicates filtered before RANSAC): every step adds its views' regions to both image representations,
 // re-matches the class it extended, and the ladder stops once min_matches verified correspondences exist.
 int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_ladder_step *steps, int nsteps,
-                 int min_matches, const modsx_pair_params &pp, modsx_pair_result *res, int *steps_done, VerifyTask *defer) {
+                 int min_matches, const modsx_pair_params &pp, modsx_pair_result *res, int *steps_done, VerifyTask *defer,
+                 modsx_comm *cm, int owner) {
   if (defer && nsteps != 1) { set_error("deferred verification needs a one-step ladder"); return MODSX_ERR_ARG; }
   memset(res, 0, sizeof *res);
   for (int i = 0; i < 9; i++) res->H[i] = -1;
@@ -463,7 +470,7 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
       // process: with many contexts at work the GPU is already full and the extra streams and scratch cost throughput
       // (16 workers: 123 -> 77 pairs/s).  MODSX_PAIR_SERIAL=1 keeps one stream (measurements).
       static const bool serialEnv = getenv("MODSX_PAIR_SERIAL") != nullptr;
-      const bool serial = serialEnv || !alone;
+      const bool serial = serialEnv || !alone || cm;   // a sharded ladder issues its collectives from one thread, in one order
       int rc0 = MODSX_OK, rc1 = MODSX_OK;
       std::string err1;
       if (!serial && !c->peer) c->peer = ctx_create(c->dev);
@@ -472,10 +479,10 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
         prof_reset(pc, c->prof.enabled);
         std::thread t([&]() {
           hipSetDevice(pc->dev);
-          rc1 = accumulate_views(pc, k, 1, imgs[1], steps[step].views, steps[step].nviews, ps);
+          rc1 = accumulate_views(pc, k, 1, imgs[1], steps[step].views, steps[step].nviews, ps, nullptr);
           if (rc1) err1 = last_error();
         });
-        rc0 = accumulate_views(c, k, 0, imgs[0], steps[step].views, steps[step].nviews, ps);
+        rc0 = accumulate_views(c, k, 0, imgs[0], steps[step].views, steps[step].nviews, ps, nullptr);
         t.join();
         if (c->prof.enabled) {   // the peer's kernels belong to this call
           prof_collect(pc);
@@ -483,8 +490,8 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
         }
         if (!rc0 && rc1) set_error(err1);
       } else {
-        rc0 = accumulate_views(c, k, 0, imgs[0], steps[step].views, steps[step].nviews, ps);
-        if (!rc0) rc1 = accumulate_views(c, k, 1, imgs[1], steps[step].views, steps[step].nviews, ps);
+        rc0 = accumulate_views(c, k, 0, imgs[0], steps[step].views, steps[step].nviews, ps, cm);
+        if (!rc0) rc1 = accumulate_views(c, k, 1, imgs[1], steps[step].views, steps[step].nviews, ps, cm);
       }
       if (rc0 || rc1) { release_result_arrays(res); return rc0 ? rc0 : rc1; }
     }
@@ -493,8 +500,10 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
     {
       std::vector<double> pos2(k.regs[1].size() * 2 + 2);
       for (size_t i = 0; i < k.regs[1].size(); i++) { pos2[2 * i] = k.regs[1][i].reproj_kp.x; pos2[2 * i + 1] = k.regs[1][i].reproj_kp.y; }
-      int rc = match_device(c, (uint8_t *)k.buf[0]->p, (int)k.regs[0].size(), (uint8_t *)k.buf[1]->p, (int)k.regs[1].size(),
-                            pos2.data(), ratio, pp.contradDist, pp.nn, k.tents);
+      int rc = cm ? match_sharded(c, cm, (uint8_t *)k.buf[0]->p, (int)k.regs[0].size(), (uint8_t *)k.buf[1]->p, (int)k.regs[1].size(),
+                                  pos2.data(), ratio, pp.contradDist, pp.nn, k.tents)
+                  : match_device(c, (uint8_t *)k.buf[0]->p, (int)k.regs[0].size(), (uint8_t *)k.buf[1]->p, (int)k.regs[1].size(),
+                                 pos2.data(), ratio, pp.contradDist, pp.nn, k.tents);
       if (rc) { release_result_arrays(res); return rc; }
     }
     // GetCorresponcesVector(): HessianAffine tentatives, then MSER; indices re-based onto the concatenated lists
@@ -520,7 +529,10 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
       step++;
       break;
     }
-    verify_tentatives(all[0], all[1], tents, pp, res);
+    // a sharded single-step call may leave verification to the owner rank; a sharded ladder verifies on every rank (same
+    // tentatives, same seed => same count), which is how the ranks agree on the early exit without a collective
+    res->n_tentatives = (int)tents.size();
+    if (!cm || owner < 0 || owner == comm_rank(cm)) verify_tentatives(all[0], all[1], tents, pp, res);
     cur = res->n_verified;
   }
   if (steps_done) *steps_done = step;

@@ -87,3 +87,15 @@ def same_records(a, b):
         elif not np.array_equal(x, y):
             return False
     return True
+
+
+def dev_to_host(ptr, nbytes):
+    """Copy nbytes from a device pointer (e.g. the HBM-resident u8 descriptors of a sharded call) into a numpy array."""
+    import ctypes as C
+    import numpy as np
+    hip = C.CDLL("libamdhip64.so")
+    out = np.empty(int(nbytes), np.uint8)
+    hip.hipDeviceSynchronize()
+    rc = hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(int(nbytes)), 2)
+    assert rc == 0, rc
+    return out

@@ -1,0 +1,218 @@
+"""GPU: the native view-sharded path (csrc/engine_shard.hip) at world sizes > 1 on ONE device.
+
+The loopback transport runs W ranks inside this process (one host thread + context per rank); its all-gather is W
+device-to-device copies, everything above it -- blocks with headers, device-side reference order, id re-basing, the
+query-row split of the match, lanes, error agreement, watchdog -- is the code the RCCL transport runs.  Every result is
+compared with the unsharded library calls (which tests/test_gpu_views.py compares with the oracle)."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from common import dev_to_host, same_records
+
+pytestmark = pytest.mark.gpu
+
+
+def _views(modsx):
+    return modsx.set_vs_pars([1.0], [1, 2, 3, 4, 6], 360.0, 0.2, 1, [])      # 8 views
+
+
+def _same_pair_result(got, ref):
+    assert got["n_regions"] == ref["n_regions"] and got["n_tentatives"] == ref["n_tentatives"]
+    assert got["n_unique"] == ref["n_unique"] and got["n_verified"] == ref["n_verified"]
+    assert got["ransac_samples"] == ref["ransac_samples"]
+    assert same_records(got["tentatives"], ref["tentatives"])
+    assert np.array_equal(got["ransac_inlier"], ref["ransac_inlier"]) and np.array_equal(got["verified"], ref["verified"])
+    assert np.array_equal(got["H"], ref["H"])
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_equals_unsharded(ctx, modsx, small_pair, world):
+    """Regions (every field, re-based ids), per-view counts, the HBM-resident descriptors, the tentatives of the sharded
+    matcher and the whole pair result on every rank == the unsharded calls.  World 8 has as many ranks as views (one view per
+    rank, the identity view alone on rank 0); world 3 leaves ranks with unequal view counts and a ragged last query block."""
+    from mods_amd import distributed as D
+    a, b, _ = small_pair
+    views = _views(modsx)
+    par = modsx.default_pair_params(ransac_seed=4)
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    ref1, refd1, c1 = ctx.detect_describe_views(ia, views, par, want_counts=True)
+    ref2, refd2 = ctx.detect_describe_views(ib, views, par)
+    pos2 = np.stack([ref2["reproj_kp"]["x"], ref2["reproj_kp"]["y"]], 1)
+    reft = ctx.match_fginn(refd1, refd2, pos2, 0.8, 30.0)
+    ref = ctx.match_pair_views(ia, ib, views, par)
+    import torch
+    d2 = torch.from_numpy(refd2.astype(np.uint8)).cuda()
+
+    def rank_body(r, comm):
+        r1, d1ptr, cnt = comm.detect_describe_views_sharded(0, ia, views, par)
+        desc = dev_to_host(d1ptr, len(r1) * 128).reshape(-1, 128)
+        tent = comm.match_fginn_sharded(0, d1ptr, len(r1), d2.data_ptr(), len(ref2), pos2, 0.8, 30.0)
+        pair_all = comm.ctxs[0].match_pair_views_sharded(comm.comm, ia, ib, views, par, -1)     # every rank verifies
+        pair_own = comm.ctxs[0].match_pair_views_sharded(comm.comm, ia, ib, views, par, world - 1)
+        return r1, cnt, desc, tent, pair_all, pair_own, comm.describe()
+
+    out = D.run_loopback(world, rank_body)
+    for r, (r1, cnt, desc, tent, pair_all, pair_own, info) in enumerate(out):
+        assert same_records(r1, ref1), r
+        assert np.array_equal(cnt, c1)
+        assert np.array_equal(desc, refd1.astype(np.uint8)), r
+        assert same_records(tent, reft), r
+        _same_pair_result(pair_all, ref)
+        if r == world - 1:
+            _same_pair_result(pair_own, ref)
+        else:
+            assert pair_own["n_regions"] == ref["n_regions"] and pair_own["n_tentatives"] == ref["n_tentatives"]
+            assert pair_own["n_verified"] == 0
+        assert info["transport"] == "loopback" and info["ranks_seen_by_rccl"] == world
+        # one all-gather per image side and one per match (+ the agreed buffer growth of the first calls)
+        assert info["all_gather_calls_rank0"] == 1 + 1 + 2 * 3 + info["agreement_collectives"], info
+    ia.free(); ib.free()
+
+
+def test_sharded_block_retry_and_unbalanced_ranks(ctx, modsx, small_pair, monkeypatch):
+    """A first block size far below a rank's row count: every rank sees the overflow in the gathered headers, all grow alike
+    and repeat the exchange (and agree on the allocation)."""
+    from mods_amd import distributed as D
+    monkeypatch.setenv("MODSX_SHARD_BLOCK_ROWS", "7")
+    a, b, _ = small_pair
+    views = _views(modsx)
+    par = modsx.default_pair_params(ransac_seed=4)
+    ia = ctx.upload(a)
+    ref1, refd1, c1 = ctx.detect_describe_views(ia, views, par, want_counts=True)
+
+    def rank_body(r, comm):
+        r1, d1ptr, cnt = comm.detect_describe_views_sharded(0, ia, views, par)
+        r1b, d1ptrb, _ = comm.detect_describe_views_sharded(0, ia, views, par)      # second call: block size is known
+        return r1, dev_to_host(d1ptr, len(r1) * 128).reshape(-1, 128), r1b, comm.describe()
+
+    for r1, desc, r1b, info in D.run_loopback(3, rank_body):
+        assert same_records(r1, ref1) and same_records(r1b, ref1)
+        assert np.array_equal(desc, refd1.astype(np.uint8))
+        assert info["block_retries"] == 1 and info["agreement_collectives"] == 2
+    ia.free()
+
+
+def test_sharded_lanes_two_contexts_per_rank(ctx, modsx, small_pair):
+    """Two contexts per rank drive different pairs at the same time over ONE communicator: the round-robin lane order keeps
+    the collectives of the ranks in one sequence."""
+    import threading
+    from mods_amd import distributed as D
+    a, b, _ = small_pair
+    views = _views(modsx)[:5]
+    par = modsx.default_pair_params(ransac_seed=2)
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    refs = [ctx.match_pair_views(ia, ib, views, par), ctx.match_pair_views(ib, ia, views, par)]
+
+    def rank_body(r, comm):
+        res = [None, None]
+
+        def lane(w):
+            x, y = (ia, ib) if w == 0 else (ib, ia)
+            outs = []
+            for k in range(3):
+                outs.append(comm.ctxs[w].match_pair_views_sharded(comm.comm, x, y, views, par, -1))
+                if w == 1 and k == 0:
+                    time.sleep(0.05)     # lanes out of phase
+            res[w] = outs
+        th = [threading.Thread(target=lane, args=(w,)) for w in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return res
+
+    for res in D.run_loopback(2, rank_body, lanes=2):
+        for w in range(2):
+            for got in res[w]:
+                _same_pair_result(got, refs[w])
+    ia.free(); ib.free()
+
+
+def test_sharded_error_is_collective(ctx, modsx, small_pair):
+    """A view only rank 1 owns is degenerate: rank 1's failure travels in its block header, every rank returns the same
+    error from the same call, and the communicator keeps working."""
+    from mods_amd import distributed as D
+    a, b, _ = small_pair
+    good = _views(modsx)[:4]
+    bad = list(good)
+    bad[1] = modsx.make_view(1e9, 0.0, 1.0, 0.2, 1)
+    par = modsx.default_pair_params(ransac_seed=4)
+    ia = ctx.upload(a)
+    ref1, _ = ctx.detect_describe_views(ia, good, par)
+
+    def rank_body(r, comm):
+        t0 = time.time()
+        try:
+            comm.detect_describe_views_sharded(0, ia, bad, par)
+            err = None
+        except RuntimeError as e:
+            err = str(e)
+        r1, _, _ = comm.detect_describe_views_sharded(0, ia, good, par)
+        return err, time.time() - t0, r1
+
+    for r, (err, dt, r1) in enumerate(D.run_loopback(2, rank_body)):
+        assert err is not None and ("degenerate" in err if r == 1 else "rank 1" in err), (r, err)
+        assert dt < 20
+        assert same_records(r1, ref1)
+    ia.free()
+
+
+def test_sharded_watchdog_turns_a_missing_rank_into_an_error(ctx, modsx, small_pair):
+    """Rank 1 never makes the call: rank 0's collective hits the deadline, the communicator is aborted, and the call -- and
+    every later one -- returns MODSX_ERR_TIMEOUT instead of hanging."""
+    from mods_amd import distributed as D
+    a, _, _ = small_pair
+    views = _views(modsx)[:3]
+    par = modsx.default_pair_params()
+    ia = ctx.upload(a)
+
+    def rank_body(r, comm):
+        if r == 1:
+            return None
+        out = []
+        for _ in range(2):
+            t0 = time.time()
+            try:
+                comm.detect_describe_views_sharded(0, ia, views, par)
+                out.append((None, time.time() - t0))
+            except RuntimeError as e:
+                out.append((str(e), time.time() - t0))
+        return out, comm.describe()
+
+    res = D.run_loopback(2, rank_body, timeout_ms=1500)
+    (e1, t1), (e2, t2) = res[0][0]
+    assert e1 is not None and "dead" in e1 and 1.0 < t1 < 15.0, (e1, t1)
+    assert e2 is not None and "dead" in e2 and t2 < 1.0, (e2, t2)
+    ia.free()
+
+
+def test_sharded_ladder_equals_unsharded_ladder(ctx, modsx, small_pair):
+    """configs[3] in miniature over 3 ranks: an MSER step and two HessianAffine steps with cumulative view sets; all steps
+    forced, and the early exit taken at the same step on every rank."""
+    from mods_amd import distributed as D
+    a, b, _ = small_pair
+    prev = {0: [], 3: []}
+    steps = []
+    for det, scales, tilts, phi, sigma, ratio in ((3, [1, 0.5], [1], 360.0, 0.8, 0.85), (0, [1], [1, 2, 4], 360.0, 0.2, 0.8),
+                                                 (0, [1], [1, 2, 4], 120.0, 0.2, 0.8)):
+        v = modsx.set_vs_pars(scales, tilts, phi, sigma, 1, prev[det])
+        assert v
+        steps.append((v, ratio, det))
+    par = modsx.default_pair_params(ransac_seed=3)
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    ref_all, done_all = ctx.match_ladder(ia, ib, steps, par, min_matches=10 ** 6)
+    ref_early, done_early = ctx.match_ladder(ia, ib, steps, par, min_matches=10)
+    assert done_all == 3
+
+    def rank_body(r, comm):
+        return (comm.match_ladder_sharded(0, ia, ib, steps, par, min_matches=10 ** 6),
+                comm.match_ladder_sharded(0, ia, ib, steps, par, min_matches=10))
+
+    for (got_all, d_all), (got_early, d_early) in D.run_loopback(3, rank_body):
+        assert d_all == done_all and d_early == done_early
+        _same_pair_result(got_all, ref_all)
+        _same_pair_result(got_early, ref_early)
+    ia.free(); ib.free()
