@@ -237,7 +237,10 @@ int modsx_describe_regions(modsx_ctx *ctx, const modsx_image *img, const modsx_r
  * matching/matching.hpp:268-269, .cpp:357-461 with vector_matcher = linear, vector_dist = L2.
  * desc*: [n][128] f32 holding integers 0..255 (anything else -- fractions, out-of-range values, NaN -- is refused with
  * MODSX_ERR_ARG: the int8 matrix-core path is exact only on that domain); pos2: [n2][2] reproj_kp x,y of list2.
- * A ratio >= 1 (the PDF branch, matching.cpp:397-428, unused by every shipped configuration) is refused as well. */
+ * A ratio >= 1 (the PDF branch, matching.cpp:397-428, unused by every shipped configuration) is refused as well.
+ * nn must lie in [2, 64] (the reference takes any nn, default 50; the device walk logs at most 64 groups of trains per
+ * query): other values return MODSX_ERR_ARG on every match path, the sharded and fused ones included.
+ * Images must have at least 2 rows and 2 columns (modsx_image_upload / modsx_image_wrap_device refuse smaller ones). */
 int modsx_match_fginn(modsx_ctx *ctx, const float *desc1, int n1, const float *desc2, int n2, const double *pos2,
                       double ratio, double contradDist, int nn, modsx_tentative **out);
 
@@ -266,6 +269,18 @@ int modsx_loransac_h(const double *pts, const double *laf1, const double *laf2, 
                      double confidence, int max_samples, int localOptimization, double HLAFCoef, int doSymmCheck,
                      unsigned seed, double *H, double *Hraw, unsigned char *inl, unsigned char *keep,
                      int *data_out);
+
+/* The same two calls with RANSACPars::errorType (matching.cpp:821-846 picks the HDS1 / HDSi1 / HDSidx1 triple the whole
+ * of exp_ransacHcustom scores with): 0 SAMPSON = HDs, 1 SYMM_MAX = HDsSymMax, 2 SYMM_SUM = HDsSym (the RANSACPars
+ * default, matching.hpp:138-171).  modsx_ransac_h / modsx_loransac_h are error_type 0; modsx_pair_params.errorType
+ * selects it for the fused callers. */
+int modsx_ransac_h_errtype(const double *u, int len, double th, double conf, int max_sam, double *H, unsigned char *inl,
+                           int *data_out, int oriented_constraint, int doSymCheck, int error_type, unsigned seed,
+                           double *score_J);
+int modsx_loransac_h_errtype(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold,
+                             double confidence, int max_samples, int localOptimization, double HLAFCoef, int doSymmCheck,
+                             int error_type, unsigned seed, double *H, double *Hraw, unsigned char *inl,
+                             unsigned char *keep, int *data_out);
 
 /* int exp_ransacFcustom(double *u, int len, double th, double conf, int max_sam, double *F, unsigned char *inl,
  *                       int *data_out, int do_lo, unsigned inlLimit, double **resids, double *H_best, int *Ih,

@@ -21,6 +21,14 @@ typedef void (*exFDsPtr)(const double *, const double *, double *, double *, int
 void HDs(const double *lin, const double *u, const double *H, double *p, int len);
 void HDsi(const double *lin, const double *u6, const double *H, double *p, int len, int *pts, int ni);
 void HDsidx(const double *lin, const double *u6, const double *H, double *p, int len, int *idx, int siz);
+/* symmetric transfer error of a homography: sum (SYMM_SUM) and max (SYMM_MAX) of the two directions
+ * (Htools.c:199-279, 325-411, 458-535) -- the triples matching.cpp:834-846 takes the addresses of */
+void HDsSym(const double *lin, const double *u, const double *H, double *p, int len);
+void HDsSymMax(const double *lin, const double *u, const double *H, double *p, int len);
+void HDsiSym(const double *lin, const double *u6, const double *H, double *p, int len, int *pts, int ni);
+void HDsiSymMax(const double *lin, const double *u6, const double *H, double *p, int len, int *pts, int ni);
+void HDsSymidx(const double *lin, const double *mu, const double *H, double *p, int len, int *idx, int siz);
+void HDsSymidxMax(const double *lin, const double *mu, const double *H, double *p, int len, int *idx, int siz);
 /* Sampson / symmetric epipolar error of a fundamental matrix (Ftools.c:82-210) */
 void FDs(const double *u, const double *F, double *p, int len);
 void FDsSym(const double *u, const double *F, double *p, int len);

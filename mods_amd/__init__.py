@@ -88,7 +88,7 @@ EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "m
            "modsx_detect_scalespace", "modsx_octave_levels", "modsx_gaussian_blur", "modsx_resize_half", "modsx_response",
            "modsx_detect_affine_regions", "modsx_detect_orientation", "modsx_reproject_regions",
            "modsx_describe_regions", "modsx_match_fginn", "modsx_duplicate_filtering", "modsx_ransac_h",
-           "modsx_loransac_h", "modsx_ransac_f", "modsx_loransac_f", "modsx_match_pair", "modsx_match_pairs", "modsx_match_pairs_views", "modsx_pair_result_release",
+           "modsx_loransac_h", "modsx_ransac_h_errtype", "modsx_loransac_h_errtype", "modsx_ransac_f", "modsx_loransac_f", "modsx_match_pair", "modsx_match_pairs", "modsx_match_pairs_views", "modsx_pair_result_release",
            "modsx_set_vs_pars", "modsx_synth_view", "modsx_detect_describe_views", "modsx_match_fginn_device",
            "modsx_match_pair_views", "modsx_match_ladder", "modsx_save_regions", "modsx_load_regions", "modsx_default_mser_params", "modsx_detect_msers", "modsx_detect_msers_u8", "modsx_last_timings", "modsx_profile",
            "modsx_kernel_stats", "modsx_last_batch_verify", "modsx_comm_unique_id", "modsx_comm_create", "modsx_comm_destroy", "modsx_comm_info",
@@ -96,7 +96,8 @@ EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "m
            "modsx_match_pair_views_sharded", "modsx_match_ladder_sharded", "modsx_comm_loopback_id", "modsx_comm_set_lanes",
            "modsx_comm_attach", "modsx_comm_lane_done", "modsx_comm_reset_lanes", "modsx_comm_set_timeout", "modsx_comm_stats"]
 # include/modsx_degensac.h: the reference's own verification symbols (link-time drop-in for libdegensac)
-EXPORTS_DEGENSAC = ["exp_ransacHcustom", "exp_ransacFcustom", "HDs", "HDsi", "HDsidx", "FDs", "FDsSym", "exFDs", "exFDsSym",
+EXPORTS_DEGENSAC = ["exp_ransacHcustom", "exp_ransacFcustom", "HDs", "HDsi", "HDsidx", "HDsSym", "HDsiSym", "HDsSymidx",
+                    "HDsSymMax", "HDsiSymMax", "HDsSymidxMax", "FDs", "FDsSym", "exFDs", "exFDsSym",
                     "modsx_ransac_set_seed"]
 
 KERNEL_CLASSES = ["blur_hess", "hessian", "resize", "nms_localize", "baumberg", "orientation", "patch_sample",
@@ -253,7 +254,7 @@ def ransac_h(u, th, conf=0.99, max_sam=100000, oriented=1, sym_check=1, seed=1):
 
 
 def loransac_h(pts, laf1, laf2, err_threshold=3.0, confidence=0.99, max_samples=100000, lo=1, hlaf_coef=12.0,
-               sym_check=1, seed=1):
+               sym_check=1, seed=1, error_type=0):
     pts = np.ascontiguousarray(pts, np.float64)
     laf1 = np.ascontiguousarray(laf1, np.float64)
     laf2 = np.ascontiguousarray(laf2, np.float64)
@@ -262,10 +263,10 @@ def loransac_h(pts, laf1, laf2, err_threshold=3.0, confidence=0.99, max_samples=
     inl = np.zeros(max(T, 1), np.uint8)
     keep = np.zeros(max(T, 1), np.uint8)
     dout = np.zeros(3, np.int32)
-    n = _check(lib().modsx_loransac_h(_p(pts), _p(laf1), _p(laf2), T, C.c_double(err_threshold),
-                                      C.c_double(confidence), int(max_samples), int(lo), C.c_double(hlaf_coef),
-                                      int(sym_check), C.c_uint(seed), _p(H), _p(Hraw), _p(inl), _p(keep), _p(dout)),
-               "loransac_h")
+    n = _check(lib().modsx_loransac_h_errtype(_p(pts), _p(laf1), _p(laf2), T, C.c_double(err_threshold),
+                                              C.c_double(confidence), int(max_samples), int(lo), C.c_double(hlaf_coef),
+                                              int(sym_check), int(error_type), C.c_uint(seed), _p(H), _p(Hraw), _p(inl),
+                                              _p(keep), _p(dout)), "loransac_h")
     return dict(n=n, H=H.reshape(3, 3), Hraw=Hraw, inl=inl[:T].astype(bool), keep=keep[:T].astype(bool),
                 samples=int(dout[0]), lo_count=int(dout[1]), ori_rejects=int(dout[2]))
 

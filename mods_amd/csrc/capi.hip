@@ -80,6 +80,10 @@ void modsx_default_pair_params(modsx_pair_params *p) {
 // bilinear_tap); views and pyramid levels are never larger than the image they come from by more than the rotation's
 // bounding box (< 2x per side), so the bound is taken with that margin
 static bool image_size_ok(int rows, int cols) {
+  if (rows < 2 || cols < 2) {   // interpolate()'s clamp `min(max(x, 0), cols - 2)` needs two pixels per side (kmath.hpp bilinear_blend)
+    mx::set_error("images of fewer than 2 rows or 2 columns are not supported");
+    return false;
+  }
   if (rows > 16384 || cols > 16384 || (long long)rows * cols > (1ll << 26)) {
     mx::set_error("image larger than 16384 px per side / 64 Mpx is not supported");
     return false;
@@ -338,6 +342,12 @@ int modsx_ransac_h(const double *u, int len, double th, double conf, int max_sam
   return ransac_h(u, len, th, conf, max_sam, H, inl, data_out, oriented_constraint, doSymCheck, seed, score_J);
 }
 
+int modsx_ransac_h_errtype(const double *u, int len, double th, double conf, int max_sam, double *H, unsigned char *inl,
+                           int *data_out, int oriented_constraint, int doSymCheck, int error_type, unsigned seed, double *score_J) {
+  if (!u || !H || !inl || !data_out || len < 4 || error_type < 0 || error_type > 2) { mx::set_error("modsx_ransac_h_errtype: bad argument"); return MODSX_ERR_ARG; }
+  return ransac_h(u, len, th, conf, max_sam, H, inl, data_out, oriented_constraint, doSymCheck, seed, score_J, error_type);
+}
+
 int modsx_ransac_f(const double *u, int len, double th, double conf, int max_sam, int do_lo, unsigned inl_limit,
                    int error_type, int doSymCheck, unsigned seed, double *F, unsigned char *inl, int *data_out) {
   if (!u || !F || !inl || !data_out || len < 8) { mx::set_error("modsx_ransac_f: bad argument"); return MODSX_ERR_ARG; }
@@ -364,6 +374,18 @@ int modsx_loransac_h(const double *pts, const double *laf1, const double *laf2, 
   }
   return loransac_h(pts, laf1, laf2, T, err_threshold, confidence, max_samples, localOptimization, HLAFCoef, doSymmCheck,
                     seed, H, Hraw, inl, keep, data_out);
+}
+
+int modsx_loransac_h_errtype(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold,
+                             double confidence, int max_samples, int localOptimization, double HLAFCoef, int doSymmCheck,
+                             int error_type, unsigned seed, double *H, double *Hraw, unsigned char *inl, unsigned char *keep,
+                             int *data_out) {
+  if (T < 0 || !H || !Hraw || !data_out || (T > 0 && (!pts || !laf1 || !laf2 || !inl || !keep)) || error_type < 0 || error_type > 2) {
+    mx::set_error("modsx_loransac_h_errtype: bad argument");
+    return MODSX_ERR_ARG;
+  }
+  return loransac_h(pts, laf1, laf2, T, err_threshold, confidence, max_samples, localOptimization, HLAFCoef, doSymmCheck,
+                    seed, H, Hraw, inl, keep, data_out, error_type);
 }
 
 int modsx_match_pair(modsx_ctx *ctx, const modsx_image *img1, const modsx_image *img2, const modsx_pair_params *par,

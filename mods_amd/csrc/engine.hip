@@ -212,7 +212,7 @@ void ctx_destroy(modsx_ctx *c) {
                     &c->descAllU8[1], &c->descAllU8b[0], &c->descAllU8b[1], &c->pos2, &c->matchRows, &c->matchWork, &c->misc, &c->scratchC, &c->needTab, &c->coordTab, &c->tileJob, &c->blurTiles, &c->nmsQueue, &c->rowStarts, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps, &c->viewJobs};
   for (DevBuf *b : bufs) b->release();
   for (int i = 0; i < MAXB; i++) { c->descF[i].release(); c->descU8[i].release(); c->viewImg[i].release(); }
-  PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc, &c->hNms, &c->hMatch, &c->hViewTaps, &c->hViewJobs};
+  PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc, &c->hNms, &c->hMatch, &c->hViewTaps, &c->hViewJobs, &c->hMser};
   for (PinBuf *b : pins) b->release();
   hipFree(c->dSmmMask); hipFree(c->dOriMask); hipFree(c->dOriIdx); hipFree(c->dSiftMask); hipFree(c->dSiftMaskIdx); hipFree(c->dAtan); hipFree(c->dOriBinTab); hipFree(c->dSiftOTab); hipFree(c->dSiftBins);
   hipFree(c->dSiftW);
@@ -1255,7 +1255,7 @@ void verify_tentatives(const std::vector<modsx_region> &r1, const std::vector<mo
   else
     nv = loransac_h(p2.data(), l1.data(), l2.data(), T, pp.err_threshold, pp.confidence, pp.max_samples,
                     pp.localOptimization, pp.HLAFCoef, pp.doSymmCheck, pp.ransac_seed, res->H, Hraw, res->ransac_inlier,
-                    res->verified, dout);
+                    res->verified, dout, pp.errorType);
   res->n_verified = nv < 0 ? 0 : nv;
   res->n_ransac_inliers = 0;
   for (int i = 0; i < T; i++) res->n_ransac_inliers += res->ransac_inlier[i];

@@ -1,5 +1,6 @@
 // engine_api.hpp -- functions shared between engine.hip, ransac.cpp, filters.cpp and capi.hip.
 #pragma once
+#include <functional>
 #include <string>
 #include <vector>
 #include "engine.hpp"
@@ -85,13 +86,17 @@ int match_pair(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, c
 int duplicate_filtering(const double *pts, const double *key, int T, double r, int do_sort, int *order,
                         unsigned char *keep);
 int ransac_h(const double *u, int len, double th, double conf, int max_sam, double *H, unsigned char *inl, int *data_out,
-             int oriented_constraint, int doSymCheck, unsigned seed0, double *scoreJ);
+             int oriented_constraint, int doSymCheck, unsigned seed0, double *scoreJ, int error_type = 0);
 void hds_sym(const double *u, const double *H, double *p, int len, bool takeMax);
 int save_regions(const char *path, const modsx_region_class *classes, int nclasses);
 int load_regions(const char *path, const char *det_name, const char *desc_name, std::vector<modsx_region> &regs,
                  std::vector<float> &desc, int *dim, std::string *found_det, std::string *found_desc);
 int detect_msers_host(const uint8_t *u8, int rows, int cols, const modsx_mser_params &par, double tilt, double zoom,
                       std::vector<modsx_keypoint> &out);
+int detect_msers_views(const uint8_t *const *u8, const int *rows, const int *cols, int n, const modsx_mser_params &par,
+                       const double *tilts, const double *zooms, std::vector<modsx_keypoint> *out);
+// fn(0) .. fn(n - 1) on the process-wide host worker pool (MODSX_HOST_THREADS, default min(hardware threads, 64)) + the caller
+void host_parallel_for(int n, const std::function<void(int)> &fn);
 int ransac_f(const double *u, int len, double th, double conf, int max_sam, double *F, unsigned char *inl, int *data_out,
              int do_lo, unsigned inlLimit, int error_type, int doSymCheck, unsigned seed0);
 int loransac_f(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold, double confidence,
@@ -99,5 +104,5 @@ int loransac_f(const double *pts, const double *laf1, const double *laf2, int T,
                unsigned char *inl, unsigned char *keep, int *data_out3);
 int loransac_h(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold,
                double confidence, int max_samples, int lo, double HLAFCoef, int doSymmCheck, unsigned seed, double *H,
-               double *Hraw, unsigned char *inl, unsigned char *keep, int *data_out);
+               double *Hraw, unsigned char *inl, unsigned char *keep, int *data_out, int error_type = 0);
 }  // namespace mx

@@ -308,15 +308,19 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
       if (pp.detector == MODSX_DET_MSER) {
         // DetectAffineRegions(temp_img1, temp_kp1, det_par.MSERParam, DET_MSER, DetectMSERs), imagerepresentation.cpp:1037:
         // u8 truncation of every view on the device, one D2H of bytes, the component trees on host threads' time
-        std::vector<uint8_t> host;
-        for (int i = 0; i < n && !rc; i++) {
-          const size_t npx = (size_t)cimg[i]->rows * cimg[i]->cols;
-          if (!c->misc.ensure(npx + 16)) { rc = MODSX_ERR_NOMEM; break; }
-          launch_trunc_u8(c->stream, cimg[i]->d, (uint8_t *)c->misc.p, npx);
-          host.resize(npx);
-          if (hipMemcpyAsync(host.data(), c->misc.p, npx, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-              hipStreamSynchronize(c->stream) != hipSuccess) { set_error("MSER view download failed"); rc = MODSX_ERR_DEVICE; break; }
-          rc = detect_msers_host(host.data(), cimg[i]->rows, cimg[i]->cols, pp.mser, tilts[i], zooms[i], kps[i]);
+        // all views of the set in one buffer, ONE download; the 2 n (view, polarity) trees then run on the host pool
+        size_t ofs[MAXB + 1], tot = 0;
+        for (int i = 0; i < n; i++) { ofs[i] = tot; tot += ((size_t)cimg[i]->rows * cimg[i]->cols + 63) & ~(size_t)63; }
+        if (!c->misc.ensure(tot + 64) || !c->hMser.ensure(tot + 64)) rc = MODSX_ERR_NOMEM;
+        for (int i = 0; i < n && !rc; i++)
+          launch_trunc_u8(c->stream, cimg[i]->d, (uint8_t *)c->misc.p + ofs[i], (size_t)cimg[i]->rows * cimg[i]->cols);
+        if (!rc && (hipMemcpyAsync(c->hMser.p, c->misc.p, tot, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                    hipStreamSynchronize(c->stream) != hipSuccess)) { set_error("MSER view download failed"); rc = MODSX_ERR_DEVICE; }
+        if (!rc) {
+          const uint8_t *src[MAXB];
+          int vr[MAXB], vc[MAXB];
+          for (int i = 0; i < n; i++) { src[i] = (const uint8_t *)c->hMser.p + ofs[i]; vr[i] = cimg[i]->rows; vc[i] = cimg[i]->cols; }
+          rc = detect_msers_views(src, vr, vc, n, pp.mser, tilts, zooms, kps);
         }
       } else rc = detect_keypoints_batch(c, cimg, n, pp.det, tilts, zooms, kps);
     }

@@ -96,7 +96,7 @@ int duplicate_filtering(const double *pts, const double *key, int T, double r, i
 
 int loransac_h(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold,
                double confidence, int max_samples_, int lo, double HLAFCoef, int doSymmCheck, unsigned seed, double *H,
-               double *Hraw, unsigned char *inl, unsigned char *keep, int *data_out3) {
+               double *Hraw, unsigned char *inl, unsigned char *keep, int *data_out3, int error_type) {
   (void)lo;  // the reference ignores localOptimization on the H path (iter_type is the constant 4)
   for (int i = 0; i < T; i++) { inl[i] = 0; keep[i] = 0; }
   for (int i = 0; i < 9; i++) { H[i] = -1; Hraw[i] = 0; }
@@ -111,7 +111,7 @@ int loransac_h(const double *pts, const double *laf1, const double *laf2, int T,
   }
   double Hloran[9];
   ransac_h(u2.data(), T, err_threshold * err_threshold, confidence, max_samples, Hloran, inl, data_out3, 1, doSymmCheck,
-           seed, nullptr);
+           seed, nullptr, error_type);
   for (int i = 0; i < 9; i++) Hraw[i] = Hloran[i];
   double Ht[9] = {Hloran[0], Hloran[3], Hloran[6], Hloran[1], Hloran[4], Hloran[7], Hloran[2], Hloran[5], Hloran[8]};
   double Hinv[9];

@@ -134,23 +134,26 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
       const unsigned b = __builtin_amdgcn_readfirstlane(b4[g]);
       const float4 w = w4[g];
       unsigned t;
+      unsigned long long ex;   // the incoming EXEC is saved and restored (the block is entered with all 64 lanes of the
+                               // launch's single wavefront active, but nothing here depends on that)
       asm volatile(
-          "s_bfe_u32 %1, %2, 0x60000\n\t"
-          "s_lshl_b64 exec, 1, %1\n\t"
-          "v_add_f32_e32 %0, %0, %3\n\t"
-          "s_bfe_u32 %1, %2, 0x60008\n\t"
+          "s_mov_b64 %2, exec\n\t"
+          "s_bfe_u32 %1, %3, 0x60000\n\t"
           "s_lshl_b64 exec, 1, %1\n\t"
           "v_add_f32_e32 %0, %0, %4\n\t"
-          "s_bfe_u32 %1, %2, 0x60010\n\t"
+          "s_bfe_u32 %1, %3, 0x60008\n\t"
           "s_lshl_b64 exec, 1, %1\n\t"
           "v_add_f32_e32 %0, %0, %5\n\t"
-          "s_bfe_u32 %1, %2, 0x60018\n\t"
+          "s_bfe_u32 %1, %3, 0x60010\n\t"
           "s_lshl_b64 exec, 1, %1\n\t"
           "v_add_f32_e32 %0, %0, %6\n\t"
-          "s_mov_b64 exec, -1"
-          : "+v"(h), "=&s"(t)
+          "s_bfe_u32 %1, %3, 0x60018\n\t"
+          "s_lshl_b64 exec, 1, %1\n\t"
+          "v_add_f32_e32 %0, %0, %7\n\t"
+          "s_mov_b64 exec, %2"
+          : "+v"(h), "=&s"(t), "=&s"(ex)
           : "s"(b), "v"(w.x), "v"(w.y), "v"(w.z), "v"(w.w)
-          : "scc");
+          : "scc", "memory");
     }
     if (lane < 36) hist[lane] = h;
   }

@@ -28,6 +28,12 @@
 #include <stdint.h>
 #include <string.h>
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 #include "engine_api.hpp"
 
@@ -49,18 +55,21 @@ struct GrownRegion {
 struct Forest {
   int rows, cols, stride;
   const uint8_t *grey;                 // padded (rows + 2) x stride
-  std::vector<int> parent;             // -1 = pixel not seen yet
-  std::vector<int> smallArea, smallPerim, regionOf;   // per root: counters of a small component, or region index (>= 0)
+  // parent: -1 = pixel not seen yet (the hot array: four neighbour look-ups per pixel); node: per ROOT the counters of a small
+  // component, or the index of its region (>= 0) -- written when a pixel becomes a root, so it needs no clearing
+  struct Node { int area, perim, region; };
+  std::vector<Node> &node;
+  std::vector<int> &parent;
+  std::vector<int> &order;             // pixel offsets in (grey level, raster) order
   std::vector<GrownRegion> regions;    // promotion order = output order
+  Forest(std::vector<Node> &n, std::vector<int> &par, std::vector<int> &o) : node(n), parent(par), order(o) {}
   int minSize, promoteAt, maxSize;
   double minMargin;
   bool relative, inverted;
 
   int find(int p) {
-    int r = p;
-    while (parent[r] != r) r = parent[r];
-    while (parent[p] != r) { const int n = parent[p]; parent[p] = r; p = n; }
-    return r;
+    while (parent[p] != p) { const int g = parent[parent[p]]; parent[p] = g; p = g; }   // path halving
+    return p;
   }
 
   void thin_levels(GrownRegion &g) {
@@ -117,22 +126,23 @@ struct Forest {
   void promote(int root, int level) {
     GrownRegion g;
     g.born = g.last = level;
-    g.area = smallArea[root]; g.perimeter = smallPerim[root];
+    g.area = node[root].area; g.perimeter = node[root].perim;
     g.seed = root; g.kept = true;
     g.addArea.assign(256, 0); g.addPerim.assign(256, 0);
     g.addArea[level] = g.area; g.addPerim[level] = g.perimeter;
-    regionOf[root] = (int)regions.size();
-    regions.push_back(g);
+    node[root].region = (int)regions.size();
+    regions.push_back(std::move(g));
   }
 
   void add_pixel(int root, int ofs, int level, int touching) {
     parent[ofs] = root;
     const int dPerim = 4 - 2 * touching;
-    if (regionOf[root] < 0) {
-      smallArea[root]++; smallPerim[root] += dPerim;
-      if (smallArea[root] >= promoteAt) promote(root, level);
+    Node &R = node[root];
+    if (R.region < 0) {
+      R.area++; R.perim += dPerim;
+      if (R.area >= promoteAt) promote(root, level);
     } else {
-      GrownRegion &g = regions[regionOf[root]];
+      GrownRegion &g = regions[R.region];
       g.last = level; g.area++; g.perimeter += dPerim;
       g.addArea[level]++; g.addPerim[level] += dPerim;
     }
@@ -140,18 +150,19 @@ struct Forest {
 
   void run() {
     const size_t npx = (size_t)(rows + 2) * stride;
-    parent.assign(npx, -1);
-    smallArea.assign(npx, 0); smallPerim.assign(npx, 0); regionOf.assign(npx, -1);
+    node.resize(npx); parent.assign(npx, -1);
     // bin sort: offsets per grey level in raster order (sortPixels.cpp:76-125)
     std::vector<int> start(257, 0);
-    for (int r = 1; r <= rows; r++) for (int c = 1; c <= cols; c++) start[grey[(size_t)r * stride + c] + 1]++;
+    for (int r = 1; r <= rows; r++) { const uint8_t *g = grey + (size_t)r * stride; for (int c = 1; c <= cols; c++) start[g[c] + 1]++; }
     for (int l = 0; l < 256; l++) start[l + 1] += start[l];
-    std::vector<int> order((size_t)rows * cols), fill(start.begin(), start.end() - 1);
-    for (int r = 1; r <= rows; r++) for (int c = 1; c <= cols; c++) { const int o = r * stride + c; order[fill[grey[o]]++] = o; }
+    order.resize((size_t)rows * cols);
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    for (int r = 1; r <= rows; r++) { const uint8_t *g = grey + (size_t)r * stride; const int o0 = r * stride; for (int c = 1; c <= cols; c++) order[fill[g[c]]++] = o0 + c; }
     int lastRoot = -1;
     for (int level = 0; level < 256; level++)
       for (int k = start[level]; k < start[level + 1]; k++) {
         const int ofs = order[k];
+        if (k + 12 < start[256]) { const int f = order[k + 12]; __builtin_prefetch(&parent[f - stride]); __builtin_prefetch(&parent[f + stride]); }
         const int nb[4] = {ofs - stride, ofs - 1, ofs + 1, ofs + stride};
         int roots[4], nroots = 0, touching = 0;
         for (int q = 0; q < 4; q++) {
@@ -163,7 +174,7 @@ struct Forest {
           if (!dup) roots[nroots++] = r;
         }
         if (nroots == 0) {                       // a new component: area 1, perimeter 4
-          parent[ofs] = ofs; smallArea[ofs] = 1; smallPerim[ofs] = 4;
+          parent[ofs] = ofs; node[ofs] = Node{1, 4, -1};
           lastRoot = ofs;
           continue;
         }
@@ -172,8 +183,8 @@ struct Forest {
           unsigned bestPrev = 0;
           int grown = 0;
           for (int z = 0; z < nroots; z++)
-            if (regionOf[roots[z]] >= 0) {
-              const GrownRegion &g = regions[regionOf[roots[z]]];
+            if (node[roots[z]].region >= 0) {
+              const GrownRegion &g = regions[node[roots[z]].region];
               const unsigned prev = (unsigned)(g.area - g.addArea[level]);   // its size one level below
               grown++;
               if (prev > bestPrev) { bestPrev = prev; keep = roots[z]; }
@@ -182,11 +193,11 @@ struct Forest {
             const int r = roots[z];
             if (r == keep) continue;
             parent[r] = keep;
-            const int ri = regionOf[r];
-            const int a = ri < 0 ? smallArea[r] : regions[ri].area, b = ri < 0 ? smallPerim[r] : regions[ri].perimeter;
-            if (regionOf[keep] < 0) { smallArea[keep] += a; smallPerim[keep] += b; }
+            const int ri = node[r].region;
+            const int a = ri < 0 ? node[r].area : regions[ri].area, b = ri < 0 ? node[r].perim : regions[ri].perimeter;
+            if (node[keep].region < 0) { node[keep].area += a; node[keep].perim += b; }
             else {
-              GrownRegion &g = regions[regionOf[keep]];
+              GrownRegion &g = regions[node[keep].region];
               g.area += a; g.perimeter += b; g.addArea[level] += a; g.addPerim[level] += b;
             }
             if (ri >= 0 && grown) {
@@ -205,7 +216,7 @@ struct Forest {
       }
     if (rows > 0 && cols > 0) {
       const int root = find(stride + 1);
-      if (regionOf[root] >= 0) close_region(regions[regionOf[root]]);
+      if (node[root].region >= 0) close_region(regions[node[root].region]);
     }
     (void)lastRoot;
   }
@@ -213,30 +224,36 @@ struct Forest {
 
 struct RowRun { int line, c0, c1; };
 
-// row runs (raster order) of the 4-connected component of {grey <= level} that contains `seed`
-void component_runs(const uint8_t *grey, int rows, int cols, int stride, int seed, int level, std::vector<uint8_t> &mark,
-                    std::vector<int> &stack, std::vector<int> &pix, std::vector<RowRun> &runs) {
-  pix.clear(); stack.clear(); runs.clear();
-  auto ok = [&](int o) {
-    const int r = o / stride, c = o - r * stride;
-    return r >= 1 && r <= rows && c >= 1 && c <= cols && grey[o] <= level && !mark[o];
-  };
-  if (!ok(seed)) return;
-  mark[seed] = 1; stack.push_back(seed);
+// row runs (raster order) of the 4-connected component of {grey <= level} that contains `seed`: a span fill -- a pixel
+// taken off the stack is grown to its maximal horizontal span (which IS a row run of the component), the spans above and
+// below are seeded from it; the runs are then sorted by (line, first column).  `mark` is all-zero on entry and on exit.
+void component_runs(const uint8_t *grey, int stride, int seed, int level, std::vector<uint8_t> &mark, std::vector<int> &stack,
+                    std::vector<RowRun> &runs) {
+  stack.clear(); runs.clear();
+  // the padding frame holds 255 in `fence` terms: the caller guarantees level < 255 and a frame of 255s (see mser_polarity)
+  if (grey[seed] > level) return;
+  stack.push_back(seed);
   while (!stack.empty()) {
     const int o = stack.back(); stack.pop_back();
-    pix.push_back(o);
-    const int nb[4] = {o + stride, o - stride, o + 1, o - 1};
-    for (int q : nb) if (ok(q)) { mark[q] = 1; stack.push_back(q); }
+    if (mark[o]) continue;
+    int a = o, b = o;
+    while (grey[a - 1] <= level && !mark[a - 1]) a--;
+    while (grey[b + 1] <= level && !mark[b + 1]) b++;
+    memset(&mark[a], 1, (size_t)(b - a + 1));
+    const int line = a / stride;
+    runs.push_back({line - 1, a - line * stride - 1, b - line * stride - 1});
+    for (int dir = -1; dir <= 1; dir += 2) {
+      const int base = dir * stride;
+      bool in = false;
+      for (int q = a; q <= b; q++) {
+        const bool ok = grey[q + base] <= level && !mark[q + base];
+        if (ok && !in) stack.push_back(q + base);
+        in = ok;
+      }
+    }
   }
-  std::sort(pix.begin(), pix.end());
-  for (size_t i = 0; i < pix.size();) {
-    size_t j = i;
-    while (j + 1 < pix.size() && pix[j + 1] == pix[j] + 1) j++;
-    runs.push_back({pix[i] / stride - 1, pix[i] % stride - 1, pix[j] % stride - 1});
-    i = j + 1;
-  }
-  for (int o : pix) mark[o] = 0;
+  std::sort(runs.begin(), runs.end(), [](const RowRun &x, const RowRun &y) { return x.line != y.line ? x.line < y.line : x.c0 < y.c0; });
+  for (const RowRun &q : runs) memset(&mark[(size_t)(q.line + 1) * stride + q.c0 + 1], 0, (size_t)(q.c1 - q.c0 + 1));
 }
 
 // RLE2Ellipse, libExtrema.cpp:117-159: area moments of the unit-square pixels of the runs
@@ -282,73 +299,184 @@ void sym_sqrt(double c00, double c01, double c11, double A[4]) {
 
 }  // namespace
 
+// per-thread scratch of the component tree (12-16 bytes per pixel): reused from call to call, so that a worker thread does
+// not page in fresh memory for every view
+struct MserScratch {
+  std::vector<Forest::Node> node;
+  std::vector<int> parent, order, stack;
+  std::vector<uint8_t> grey, fence, mark;
+  std::vector<RowRun> runs;
+};
+static thread_local MserScratch t_scratch;
+
+// MSER+ (pol 0) or MSER- (pol 1: the inverted image, extremaInvertImage) of one view, in region / threshold order
+static void mser_polarity(const uint8_t *u8, int rows, int cols, const modsx_mser_params &par, double minMargin, int pol,
+                          std::vector<modsx_keypoint> &out) {
+  MserScratch &S = t_scratch;
+  const int stride = cols + 2;
+  const size_t npx = (size_t)(rows + 2) * stride;
+  // `grey`: the padded image the tree is built on (frame 0, never visited: only interior offsets are in `order`);
+  // `fence`: the same pixels inside a frame of 255, which stops the span fill of any threshold < 255 at the image border
+  S.grey.assign(npx, 0); S.fence.assign(npx, 255); S.mark.assign(npx, 0);
+  for (int r = 0; r < rows; r++) {
+    uint8_t *g = &S.grey[(size_t)(r + 1) * stride + 1], *f = &S.fence[(size_t)(r + 1) * stride + 1];
+    const uint8_t *src = u8 + (size_t)r * cols;
+    if (pol == 0) { memcpy(g, src, cols); memcpy(f, src, cols); }
+    else for (int c = 0; c < cols; c++) g[c] = f[c] = (uint8_t)(255 - src[c]);
+  }
+  Forest F(S.node, S.parent, S.order);
+  F.rows = rows; F.cols = cols; F.stride = stride; F.grey = S.grey.data();
+  F.minSize = par.min_size; F.promoteAt = std::min(10000, par.min_size);
+  F.maxSize = (int)((double)cols * rows * par.max_area);
+  F.minMargin = par.relative ? minMargin / 100.0 : minMargin;
+  F.relative = par.relative != 0; F.inverted = pol == 1;
+  F.run();
+  for (const GrownRegion &g : F.regions) {
+    if (!g.kept) continue;
+    for (const StableLevel &t : g.levels) {
+      if (t.thresh >= 255) continue;
+      component_runs(S.fence.data(), stride, g.seed, t.thresh, S.mark, S.stack, S.runs);
+      if (S.runs.empty()) continue;
+      double cx, cy, sxx, sxy, syy, A[4];
+      run_moments(S.runs, cx, cy, sxx, sxy, syy);
+      sym_sqrt(sxx, sxy, syy, A);
+      modsx_keypoint k;
+      memset(&k, 0, sizeof k);
+      k.x = cx; k.y = cy; k.a11 = A[0]; k.a12 = A[1]; k.a21 = A[2]; k.a22 = A[3];
+      k.s = 1.0; k.response = t.margin; k.sub_type = pol == 0 ? 21 : 20;
+      out.push_back(k);
+    }
+  }
+}
+
+// prepareKeysForExport, extrema.cpp:31-90 (same libstdc++ std::sort on the same sequence: MSER+ keys, then MSER-)
+static void mser_export(std::vector<modsx_keypoint> &out, const modsx_mser_params &par, double minMargin, double tilt, double zoom) {
+  int regNumber = par.reg_number;
+  if ((tilt > 2.0) || (zoom < 0.5)) regNumber = (int)floor(zoom * 2.0 * regNumber / tilt);
+  if (out.empty() || par.mode == MODSX_FIXED_TH) return;
+  auto byMargin = [](const modsx_keypoint &a, const modsx_keypoint &b) { return fabs(a.response) > fabs(b.response); };
+  std::sort(out.begin(), out.end(), byMargin);
+  const double top = fabs(out[0].response);
+  const int have = (int)out.size();
+  modsx_keypoint probe = out[0];
+  switch (par.mode) {
+    case MODSX_RELATIVE_TH:
+      probe.response = top * par.rel_threshold;
+      out.resize(std::lower_bound(out.begin(), out.end(), probe, byMargin) - out.begin());
+      break;
+    case MODSX_FIXED_REG_NUMBER:
+      if (regNumber < have && regNumber >= 0) out.resize(regNumber);
+      break;
+    case MODSX_RELATIVE_REG_NUMBER:
+      out.resize((size_t)std::max(0, (int)floor(par.rel_reg_number * (double)out.size())));
+      break;
+    case MODSX_NOT_LESS_THAN_REGIONS: {
+      probe.response = minMargin;
+      const int fixed = (int)(std::lower_bound(out.begin(), out.end(), probe, byMargin) - out.begin());
+      out.resize((size_t)std::max(0, fixed < regNumber ? std::min(regNumber, have) : std::min(fixed, have)));
+      break;
+    }
+    default: break;
+  }
+}
+
+// ---- host worker pool: the (view, polarity) component trees of a view set are independent (the reference runs one view
+// per OpenMP thread, imagerepresentation.cpp:612-622, with threadprivate MSER globals) -------------------------------------
+namespace {
+class HostPool {
+ public:
+  static HostPool &get() { static HostPool p; return p; }
+  // runs fn(0) .. fn(n - 1) on the workers (and on the caller), returns when all are done
+  void run(int n, const std::function<void(int)> &fn) {
+    if (n <= 0) return;
+    auto job = std::make_shared<Job>();
+    job->n = n; job->fn = &fn;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      jobs_.push_back(job);
+    }
+    cv_.notify_all();
+    work(*job);                    // the calling thread takes tasks too
+    std::unique_lock<std::mutex> lk(mu_);
+    job->done_cv.wait(lk, [&] { return job->finished == job->n; });
+  }
+ private:
+  struct Job { int n = 0, next = 0, finished = 0; const std::function<void(int)> *fn = nullptr; std::condition_variable done_cv; };
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<std::shared_ptr<Job>> jobs_;
+  std::vector<std::thread> threads_;
+  bool stop_ = false;
+  HostPool() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("MODSX_HOST_THREADS")) n = atoi(e);
+    n = std::max(0, std::min(n, 64) - 1);
+    for (int i = 0; i < n; i++) threads_.emplace_back([this] { loop(); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (std::thread &t : threads_) t.join();
+  }
+  void work(Job &j) {
+    for (;;) {
+      int i;
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (j.next >= j.n) return;
+        i = j.next++;
+        if (j.next >= j.n) for (auto it = jobs_.begin(); it != jobs_.end(); ++it) if (it->get() == &j) { jobs_.erase(it); break; }
+      }
+      (*j.fn)(i);
+      std::lock_guard<std::mutex> lk(mu_);
+      if (++j.finished == j.n) j.done_cv.notify_all();
+    }
+  }
+  void loop() {
+    for (;;) {
+      std::shared_ptr<Job> j;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || !jobs_.empty(); });
+        if (stop_) return;
+        j = jobs_.front();
+      }
+      work(*j);
+    }
+  }
+};
+}  // namespace
+
+void host_parallel_for(int n, const std::function<void(int)> &fn) { HostPool::get().run(n, fn); }
+
 // u8: rows x cols grey values (already truncated from the f32 view).  Appends nothing to `out` beyond the keypoints of
 // this view; returns MODSX_OK.
 int detect_msers_host(const uint8_t *u8, int rows, int cols, const modsx_mser_params &par, double tilt, double zoom,
                       std::vector<modsx_keypoint> &out) {
   out.clear();
   if (rows <= 0 || cols <= 0) return MODSX_OK;
-  int regNumber = par.reg_number;
-  if ((tilt > 2.0) || (zoom < 0.5)) regNumber = (int)floor(zoom * 2.0 * regNumber / tilt);
   const double minMargin = par.mode != MODSX_FIXED_TH ? 1.0 : par.min_margin;
-  const int stride = cols + 2;
-  std::vector<uint8_t> grey((size_t)(rows + 2) * stride, 0), mark((size_t)(rows + 2) * stride, 0);
-  for (int r = 0; r < rows; r++) memcpy(&grey[(size_t)(r + 1) * stride + 1], u8 + (size_t)r * cols, cols);
-  std::vector<int> stack, pix;
-  std::vector<RowRun> runs;
-  for (int pol = 0; pol < 2; pol++) {
-    if (pol == 1)
-      for (int r = 1; r <= rows; r++) for (int c = 1; c <= cols; c++) { uint8_t &v = grey[(size_t)r * stride + c]; v = 255 - v; }
-    Forest F;
-    F.rows = rows; F.cols = cols; F.stride = stride; F.grey = grey.data();
-    F.minSize = par.min_size; F.promoteAt = std::min(10000, par.min_size);
-    F.maxSize = (int)((double)cols * rows * par.max_area);
-    F.minMargin = par.relative ? minMargin / 100.0 : minMargin;
-    F.relative = par.relative != 0; F.inverted = pol == 1;
-    F.run();
-    for (const GrownRegion &g : F.regions) {
-      if (!g.kept) continue;
-      for (const StableLevel &t : g.levels) {
-        if (t.thresh >= 255) continue;
-        component_runs(grey.data(), rows, cols, stride, g.seed, t.thresh, mark, stack, pix, runs);
-        if (runs.empty()) continue;
-        double cx, cy, sxx, sxy, syy, A[4];
-        run_moments(runs, cx, cy, sxx, sxy, syy);
-        sym_sqrt(sxx, sxy, syy, A);
-        modsx_keypoint k;
-        memset(&k, 0, sizeof k);
-        k.x = cx; k.y = cy; k.a11 = A[0]; k.a12 = A[1]; k.a21 = A[2]; k.a22 = A[3];
-        k.s = 1.0; k.response = t.margin; k.sub_type = pol == 0 ? 21 : 20;
-        out.push_back(k);
-      }
-    }
-  }
-  // prepareKeysForExport, extrema.cpp:31-90 (same libstdc++ std::sort on the same sequence)
-  if (!out.empty() && par.mode != MODSX_FIXED_TH) {
-    auto byMargin = [](const modsx_keypoint &a, const modsx_keypoint &b) { return fabs(a.response) > fabs(b.response); };
-    std::sort(out.begin(), out.end(), byMargin);
-    const double top = fabs(out[0].response);
-    const int have = (int)out.size();
-    modsx_keypoint probe = out[0];
-    switch (par.mode) {
-      case MODSX_RELATIVE_TH:
-        probe.response = top * par.rel_threshold;
-        out.resize(std::lower_bound(out.begin(), out.end(), probe, byMargin) - out.begin());
-        break;
-      case MODSX_FIXED_REG_NUMBER:
-        if (regNumber < have && regNumber >= 0) out.resize(regNumber);
-        break;
-      case MODSX_RELATIVE_REG_NUMBER:
-        out.resize((size_t)std::max(0, (int)floor(par.rel_reg_number * (double)out.size())));
-        break;
-      case MODSX_NOT_LESS_THAN_REGIONS: {
-        probe.response = minMargin;
-        const int fixed = (int)(std::lower_bound(out.begin(), out.end(), probe, byMargin) - out.begin());
-        out.resize((size_t)std::max(0, fixed < regNumber ? std::min(regNumber, have) : std::min(fixed, have)));
-        break;
-      }
-      default: break;
-    }
+  for (int pol = 0; pol < 2; pol++) mser_polarity(u8, rows, cols, par, minMargin, pol, out);
+  mser_export(out, par, minMargin, tilt, zoom);
+  return MODSX_OK;
+}
+
+// The views of a set: 2 n independent (view, polarity) trees on the host pool, largest first; out[i] = DetectMSERs of view i
+int detect_msers_views(const uint8_t *const *u8, const int *rows, const int *cols, int n, const modsx_mser_params &par,
+                       const double *tilts, const double *zooms, std::vector<modsx_keypoint> *out) {
+  const double minMargin = par.mode != MODSX_FIXED_TH ? 1.0 : par.min_margin;
+  std::vector<std::vector<modsx_keypoint>> part((size_t)2 * n);
+  std::vector<int> task((size_t)2 * n);
+  for (int i = 0; i < 2 * n; i++) task[i] = i;
+  std::stable_sort(task.begin(), task.end(), [&](int a, int b) { return (long)rows[a / 2] * cols[a / 2] > (long)rows[b / 2] * cols[b / 2]; });
+  host_parallel_for(2 * n, [&](int k) {
+    const int t = task[k], v = t / 2;
+    if (rows[v] > 0 && cols[v] > 0) mser_polarity(u8[v], rows[v], cols[v], par, minMargin, t & 1, part[t]);
+  });
+  for (int v = 0; v < n; v++) {
+    out[v] = std::move(part[2 * v]);
+    out[v].insert(out[v].end(), part[2 * v + 1].begin(), part[2 * v + 1].end());
+    mser_export(out[v], par, minMargin, tilts[v], zooms[v]);
   }
   return MODSX_OK;
 }

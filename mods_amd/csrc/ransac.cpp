@@ -46,6 +46,11 @@ struct Ransac {
   double *errs[5];
   HashTable ht;
   GlibcRandom rng;
+  int errType = 0;   // the HDS1 the caller chose: 0 HDs (Sampson), 1 HDsSymMax, 2 HDsSym (matching.cpp:821-846)
+  void errf(const double *h, double *d) {
+    if (errType == 0) HDs(Zrow.data(), u, h, d, len);
+    else hds_sym(u, h, d, len, errType == 1);
+  }
 
   // randsubset, rtools.c:27-41
   int *randsubset(int *pool, int max_sz, int siz) {
@@ -69,7 +74,7 @@ struct Ransac {
     memcpy(h, H, sizeof h);  // defined start value; overwritten below since S.I >= 4
     u2h(u, inliers, S.I, h, buffer.data());
     for (int it = 0; it < steps; it++) {
-      HDs(Zrow.data(), u, h, d, len);
+      errf(h, d);
       Ss = inlidxs(d, len, th, inliers);
       uint32_t hash = super_fast_hash((const char *)inliers, (int)(Ss.I * sizeof(int)));
       int ret = ht.contains(hash, (int)Ss.I, iterID);
@@ -85,7 +90,7 @@ struct Ransac {
       u2h(u, inliers, S.I, h, buffer.data());
       ths -= dth;
     }
-    HDs(Zrow.data(), u, h, d, len);
+    errf(h, d);
     S = inlidxs(d, len, th, inliers);
     if (score_less(maxS, S)) {
       maxS = S;
@@ -108,7 +113,7 @@ struct Ransac {
     for (int i = 0; i < rep; i++) {
       int *sample = randsubset(inliers, ninl, ssiz);
       u2h(u, sample, ssiz, h, buffer.data());
-      HDs(Zrow.data(), u, h, errs[0], len);
+      errf(h, errs[0]);
       errs[4] = errs[0];
       S = iterH(intbuff.data(), th, 4 * th, 4, h, ++*iterID);
       if (score_less(maxS, S)) {
@@ -122,11 +127,11 @@ struct Ransac {
   }
 };
 
-// exp_ransacHcustom, exp_ranH.c:796-1236 (iter_type 4, HDs)
+// exp_ransacHcustom, exp_ranH.c:796-1236 (iter_type 4; HDS1 = HDs, HDsSymMax or HDsSym by error_type)
 int ransac_h(const double *u, int len, double th, double conf, int max_sam, double *H, unsigned char *inl, int *data_out,
-             int oriented_constraint, int doSymCheck, unsigned seed0, double *scoreJ) {
+             int oriented_constraint, int doSymCheck, unsigned seed0, double *scoreJ, int error_type) {
   Ransac R;
-  R.u = u; R.len = len;
+  R.u = u; R.len = len; R.errType = error_type;
   std::vector<int> pool(len), inliers(len);
   double M[81], sol[81], *h = sol;
   memset(sol, 0, sizeof sol);
@@ -182,7 +187,7 @@ int ransac_h(const double *u, int len, double th, double conf, int max_sam, doub
     d = R.errs[0];
     S = inlidxs(R.errs[4], len, 4 * th * 2, inliers.data());
     u2h(u, inliers.data(), S.I, h, R.buffer.data());
-    HDs(R.Zrow.data(), u, h, d, len);
+    R.errf(h, d);
     S = inlidxs(d, len, th, inliers.data());
     S = R.inHrani(inliers.data(), (int)S.I, th, h, 10, &iterID);
   };
@@ -212,7 +217,7 @@ int ransac_h(const double *u, int len, double th, double conf, int max_sam, doub
     double tol = tol_of(h);
     if (fabs(v / tol) < 10e-2) continue;
     d = R.errs[0];
-    HDs(R.Zrow.data(), u, h, d, len);
+    R.errf(h, d);
     S = score_of(d);
     int do_iterate;
     if (score_less(maxS, S)) {

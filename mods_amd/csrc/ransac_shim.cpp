@@ -9,7 +9,8 @@
 //                         exFDsPtr EXFDS1, FDsPtr FDS1, int doSymCheck)                         degensac/exp_ranF.h:67-72
 //
 // as LORANSACFiltering calls them (matching/matching.cpp:883, 891).  The error functions the caller passes are the
-// library's own HDs / HDsi / HDsidx (Sampson; degensac/Htools.c:158-196, 284-320, 418-456) and FDs / exFDs or
+// library's own HDs / HDsi / HDsidx (Sampson; degensac/Htools.c:158-196, 284-320, 418-456), HDsSym / HDsiSym / HDsSymidx
+// (SYMM_SUM, the RANSACPars default) or HDsSymMax / HDsiSymMax / HDsSymidxMax (SYMM_MAX) and FDs / exFDs or
 // FDsSym / exFDsSym (Ftools.c:82-210), exported here with the reference's signatures and data layout; they select the
 // error type of the restated RANSAC (ransac.cpp, ransac_f.cpp).  Foreign function pointers cannot be honoured by a
 // restatement and are refused loudly (zero inliers + modsx_last_error()), as is an iter_type other than 4.
@@ -79,6 +80,17 @@ void HDsidx(const double *lin, const double *u6, const double *H, double *p, int
   for (int i = 0; i < siz; i++) p[i] = sampson_h(lin, len, idx[i], u6 + 6 * idx[i], H);
 }
 
+/* symmetric transfer error, sum and max of the two directions (Htools.c:199-279, 325-411, 458-535); `lin` is unused */
+void HDsSym(const double *lin, const double *u, const double *H, double *p, int len) { (void)lin; mx::hds_sym(u, H, p, len, false); }
+void HDsSymMax(const double *lin, const double *u, const double *H, double *p, int len) { (void)lin; mx::hds_sym(u, H, p, len, true); }
+static void hds_sym_subset(const double *u6, const double *H, double *p, const int *pts, int ni, bool takeMax) {
+  for (int i = 0; i < ni; i++) mx::hds_sym(u6 + 6 * pts[i], H, p + i, 1, takeMax);
+}
+void HDsiSym(const double *lin, const double *u6, const double *H, double *p, int len, int *pts, int ni) { (void)lin; (void)len; hds_sym_subset(u6, H, p, pts, ni, false); }
+void HDsiSymMax(const double *lin, const double *u6, const double *H, double *p, int len, int *pts, int ni) { (void)lin; (void)len; hds_sym_subset(u6, H, p, pts, ni, true); }
+void HDsSymidx(const double *lin, const double *mu, const double *H, double *p, int len, int *idx, int siz) { (void)lin; (void)len; hds_sym_subset(mu, H, p, idx, siz, false); }
+void HDsSymidxMax(const double *lin, const double *mu, const double *H, double *p, int len, int *idx, int siz) { (void)lin; (void)len; hds_sym_subset(mu, H, p, idx, siz, true); }
+
 static inline void f_terms(const double *u, const double *F, double &r, double &a, double &b) {
   const double rxc = F[0] * u[3] + F[3] * u[4] + F[6], ryc = F[1] * u[3] + F[4] * u[4] + F[7];
   const double rwc = F[2] * u[3] + F[5] * u[4] + F[8];
@@ -119,8 +131,13 @@ Score exp_ransacHcustom(double *u, int len, double th, double conf, int max_sam,
   if (resids) *resids = alloc_resids(len);
   if (!u || !H || !inl || !data_out || len < 4) { mx::set_error("exp_ransacHcustom: bad argument"); return S; }
   memset(inl, 0, (size_t)len);
-  if (HDS1 != &HDs || HDSi1 != &HDsi || HDSidx1 != &HDsidx) {
-    mx::set_error("exp_ransacHcustom: only the library's Sampson error functions (HDs, HDsi, HDsidx) are supported");
+  int error_type;   // the three triples LORANSACFiltering can pass (matching.cpp:821-846)
+  if (HDS1 == &HDs && HDSi1 == &HDsi && HDSidx1 == &HDsidx) error_type = 0;
+  else if (HDS1 == &HDsSymMax && HDSi1 == &HDsiSymMax && HDSidx1 == &HDsSymidxMax) error_type = 1;
+  else if (HDS1 == &HDsSym && HDSi1 == &HDsiSym && HDSidx1 == &HDsSymidx) error_type = 2;
+  else {
+    mx::set_error("exp_ransacHcustom: only the library's own error functions are supported (HDs/HDsi/HDsidx, "
+                  "HDsSym/HDsiSym/HDsSymidx, HDsSymMax/HDsiSymMax/HDsSymidxMax)");
     return S;
   }
   if (iter_type != 4 || inlLimit != 0) {
@@ -128,7 +145,7 @@ Score exp_ransacHcustom(double *u, int len, double th, double conf, int max_sam,
     return S;
   }
   double J = 0;
-  const int n = mx::ransac_h(u, len, th, conf, max_sam, H, inl, data_out, oriented_constraint, doSymCheck, shim_seed(), &J);
+  const int n = mx::ransac_h(u, len, th, conf, max_sam, H, inl, data_out, oriented_constraint, doSymCheck, shim_seed(), &J, error_type);
   S.I = n < 0 ? 0u : (unsigned)n;
   S.J = J;
   return S;

@@ -148,7 +148,7 @@ int orc_loransac_h(const double *pts /*T*4*/, const double *laf1 /*T*5: a11 a12 
                    int lo, double HLAFCoef, int doSymmCheck, unsigned seed,
                    double *H /*9 row-major img1->img2*/, double *Hraw /*9 as returned*/,
                    unsigned char *inl /*T ransac inliers*/, unsigned char *keep /*T after LAF check*/,
-                   int *data_out /*3*/);
+                   int *data_out /*3*/, int error_type /*0 SAMPSON, 1 SYMM_MAX, 2 SYMM_SUM: matching.cpp:821-846*/);
 int orc_loransac_f(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold,
                    double confidence, int max_samples, int lo, double LAFCoef, int doSymmCheck, int error_type,
                    unsigned seed, double *F /*9 as exp_ransacFcustom returns it*/, unsigned char *inl,

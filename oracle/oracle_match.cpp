@@ -72,9 +72,9 @@ typedef void (*set_seed_fn)(unsigned);
 
 static void *g_ref = nullptr;
 static ransacH_fn g_ransacH = nullptr;
-static HDsPtr g_HDs = nullptr, g_HDsSymMax = nullptr;
-static HDsiPtr g_HDsi = nullptr;
-static HDsidxPtr g_HDsidx = nullptr;
+static HDsPtr g_HDs = nullptr, g_HDsSymMax = nullptr, g_HDsSym = nullptr;
+static HDsiPtr g_HDsi = nullptr, g_HDsiSym = nullptr, g_HDsiSymMax = nullptr;
+static HDsidxPtr g_HDsidx = nullptr, g_HDsSymidx = nullptr, g_HDsSymidxMax = nullptr;
 static set_seed_fn g_set_seed = nullptr;
 static ransacF_fn g_ransacF = nullptr;
 static FDsPtr g_FDs = nullptr, g_FDsSym = nullptr;
@@ -97,13 +97,19 @@ static bool load_ref() {
   g_HDsi = (HDsiPtr)dlsym(g_ref, "HDsi");
   g_HDsidx = (HDsidxPtr)dlsym(g_ref, "HDsidx");
   g_HDsSymMax = (HDsPtr)dlsym(g_ref, "HDsSymMax");
+  g_HDsSym = (HDsPtr)dlsym(g_ref, "HDsSym");
+  g_HDsiSym = (HDsiPtr)dlsym(g_ref, "HDsiSym");
+  g_HDsiSymMax = (HDsiPtr)dlsym(g_ref, "HDsiSymMax");
+  g_HDsSymidx = (HDsidxPtr)dlsym(g_ref, "HDsSymidx");
+  g_HDsSymidxMax = (HDsidxPtr)dlsym(g_ref, "HDsSymidxMax");
   g_set_seed = (set_seed_fn)dlsym(g_ref, "modsx_ref_set_seed");
   g_ransacF = (ransacF_fn)dlsym(g_ref, "exp_ransacFcustom");
   g_FDs = (FDsPtr)dlsym(g_ref, "FDs");
   g_FDsSym = (FDsPtr)dlsym(g_ref, "FDsSym");
   g_exFDs = (exFDsPtr)dlsym(g_ref, "exFDs");
   g_exFDsSym = (exFDsPtr)dlsym(g_ref, "exFDsSym");
-  if (!g_ransacF || !g_FDs || !g_FDsSym || !g_exFDs || !g_exFDsSym || !g_ransacH || !g_HDs || !g_HDsi || !g_HDsidx || !g_HDsSymMax || !g_set_seed) {
+  if (!g_ransacF || !g_FDs || !g_FDsSym || !g_exFDs || !g_exFDsSym || !g_ransacH || !g_HDs || !g_HDsi || !g_HDsidx || !g_HDsSymMax || !g_set_seed || !g_HDsSym || !g_HDsiSym ||
+      !g_HDsiSymMax || !g_HDsSymidx || !g_HDsSymidxMax) {
     dlclose(g_ref);
     g_ref = nullptr;
     return false;
@@ -203,7 +209,7 @@ int orc_ref_available(void) { return load_ref() ? 1 : 0; }
  * time() for exp_ranH.c only).  errorType = SAMPSON (config_iter_mods_cviu.ini:164). */
 int orc_loransac_h(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold,
                    double confidence, int max_samples_, int lo, double HLAFCoef, int doSymmCheck, unsigned seed,
-                   double *H, double *Hraw, unsigned char *inl, unsigned char *keep, int *data_out3) {
+                   double *H, double *Hraw, unsigned char *inl, unsigned char *keep, int *data_out3, int error_type) {
   (void)lo;
   for (int i = 0; i < T; i++) { inl[i] = 0; keep[i] = 0; }
   for (int i = 0; i < 9; i++) { H[i] = -1; Hraw[i] = 0; }
@@ -221,7 +227,9 @@ int orc_loransac_h(const double *pts, const double *laf1, const double *laf2, in
   double Hloran[9];
   g_set_seed(seed);
   g_ransacH(u2.data(), T, err_threshold * err_threshold, confidence, max_samples, Hloran, inl, 4, data_out.data(), 1,
-            0, &resids, g_HDs, g_HDsi, g_HDsidx, doSymmCheck);
+            0, &resids, error_type == 0 ? g_HDs : error_type == 1 ? g_HDsSymMax : g_HDsSym,
+            error_type == 0 ? g_HDsi : error_type == 1 ? g_HDsiSymMax : g_HDsiSym,
+            error_type == 0 ? g_HDsidx : error_type == 1 ? g_HDsSymidxMax : g_HDsSymidx, doSymmCheck);   /* matching.cpp:821-846 */
   free(resids);
   data_out3[0] = data_out[0]; data_out3[1] = data_out[1]; data_out3[2] = data_out[2];
   for (int i = 0; i < 9; i++) Hraw[i] = Hloran[i];

@@ -280,7 +280,7 @@ def detect_msers(img, min_size=30, max_area=0.05, min_margin=8.0, relative=0, mo
 
 
 def loransac_h(pts, laf1, laf2, err_threshold=3.0, confidence=0.99, max_samples=100000, lo=1, hlaf_coef=12.0,
-               sym_check=1, seed=1):
+               sym_check=1, seed=1, error_type=0):
     pts = np.ascontiguousarray(pts, np.float64)
     laf1 = np.ascontiguousarray(laf1, np.float64)
     laf2 = np.ascontiguousarray(laf2, np.float64)
@@ -292,7 +292,7 @@ def loransac_h(pts, laf1, laf2, err_threshold=3.0, confidence=0.99, max_samples=
     dout = np.zeros(3, np.int32)
     n = lib().orc_loransac_h(_p(pts), _p(laf1), _p(laf2), T, C.c_double(err_threshold), C.c_double(confidence),
                              max_samples, lo, C.c_double(hlaf_coef), sym_check, C.c_uint(seed), _p(H), _p(Hraw),
-                             _p(inl), _p(keep), _p(dout))
+                             _p(inl), _p(keep), _p(dout), int(error_type))
     return dict(n=n, H=H.reshape(3, 3), Hraw=Hraw, inl=inl[:T].astype(bool), keep=keep[:T].astype(bool),
                 samples=int(dout[0]), lo_count=int(dout[1]), ori_rejects=int(dout[2]))
 

@@ -38,6 +38,31 @@ int main(void) {
   Score Sbad = exp_ransacHcustom(u, T, 9.0, 0.99, 1000, H, inl2, 4, data_out, 1, 0, &resids, (HDsPtr)&FDs, &HDsi, &HDsidx, 1);
   free(resids);
   if (Sbad.I != 0) { printf("FAIL foreign pointer accepted\n"); return 1; }
+  /* --- the errorType switch of LORANSACFiltering (matching.cpp:821-846) takes the address of every one of these; the
+   * SYMM_SUM triple is the RANSACPars default (matching.hpp) and SYMM_MAX the other symmetric choice --- */
+  {
+    HDsPtr hds[3] = {&HDs, &HDsSymMax, &HDsSym};
+    HDsiPtr hdsi[3] = {&HDsi, &HDsiSymMax, &HDsiSym};
+    HDsidxPtr hdsidx[3] = {&HDsidx, &HDsSymidxMax, &HDsSymidx};
+    for (int et = 1; et < 3; et++) {
+      Score Se = exp_ransacHcustom(u, T, 9.0, 0.99, 100000, H, inl, 4, data_out, 1, 0, &resids, hds[et], hdsi[et], hdsidx[et], 1);
+      free(resids);
+      const int ne = modsx_ransac_h_errtype(u, T, 9.0, 0.99, 100000, H2, inl2, d3, 1, 1, et, 5, &J);
+      if ((int)Se.I != ne || ne < T / 2 || memcmp(inl, inl2, T) || memcmp(H, H2, sizeof H)) { printf("FAIL H errtype %d: %u %d\n", et, Se.I, ne); return 1; }
+      /* the subset forms agree with the full form */
+      double pall[400], psub[3];
+      int idx[3] = {1, 7, 399};
+      hds[et](NULL, u, H, pall, T);
+      hdsi[et](NULL, u, H, psub, T, idx, 3);
+      if (psub[0] != pall[1] || psub[1] != pall[7] || psub[2] != pall[399]) { printf("FAIL HDsi errtype %d\n", et); return 1; }
+      hdsidx[et](NULL, u, H, psub, T, idx, 3);
+      if (psub[0] != pall[1] || psub[1] != pall[7] || psub[2] != pall[399]) { printf("FAIL HDsidx errtype %d\n", et); return 1; }
+    }
+    /* a mixed triple is refused */
+    Score Smix = exp_ransacHcustom(u, T, 9.0, 0.99, 1000, H, inl2, 4, data_out, 1, 0, &resids, &HDsSym, &HDsi, &HDsidx, 1);
+    free(resids);
+    if (Smix.I != 0) { printf("FAIL mixed triple accepted\n"); return 1; }
+  }
   /* --- F, exactly as matching.cpp:876-885 --- */
   double F[9], F2[9], HinF[9];
   int I_H = 0;

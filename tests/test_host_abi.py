@@ -108,6 +108,23 @@ def test_loransac_h_matches_reference_degensac(modsx, oracle, T, frac, seed):
         assert np.abs(normH(a["H"]) - normH(b["H"])).max() < 1e-4
 
 
+@pytest.mark.parametrize("error_type", [1, 2])
+def test_loransac_h_symmetric_error_types_match_reference_degensac(modsx, oracle, error_type):
+    """RANSACPars::errorType SYMM_MAX (1) and SYMM_SUM (2, the default of matching.hpp and what config_iter_cviu.ini's
+    'Samspon' typo selects): exp_ransacHcustom scores with HDsSymMax / HDsSym throughout (matching.cpp:821-846)."""
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    for T, frac, seed in ((500, 0.66, 1), (200, 0.3, 2), (1500, 0.9, 3), (60, 0.5, 4), (30, 0.5, 5), (2000, 0.15, 7)):
+        pts, laf, H = synth_corr(T, frac, seed=seed)
+        for rseed in (1, 12345):
+            a = oracle.loransac_h(pts, laf, laf, seed=rseed, error_type=error_type)
+            b = modsx.loransac_h(pts, laf, laf, seed=rseed, error_type=error_type)
+            assert (a["samples"], a["lo_count"], a["ori_rejects"]) == (b["samples"], b["lo_count"], b["ori_rejects"])
+            assert np.array_equal(a["inl"], b["inl"]) and np.array_equal(a["keep"], b["keep"]) and a["n"] == b["n"]
+            assert np.abs(normH(a["H"]) - normH(b["H"])).max() < 1e-4
+        assert a["inl"].sum() > 0.5 * frac * T
+
+
 def test_loransac_edge_cases(modsx, oracle):
     pts, laf, _ = synth_corr(7, 1.0, seed=1)
     r = modsx.loransac_h(pts, laf, laf)
