@@ -209,7 +209,7 @@ void ctx_destroy(modsx_ctx *c) {
   for (int i = 0; i < MAXB; i++) c->pyr[i].store.release();
   DevBuf *bufs[] = {&c->nmsJobs, &c->cand, &c->counter, &c->affJobs, &c->affOut, &c->oriJobs, &c->oriOut, &c->descJobs, &c->tilePrefix,
                     &c->taps, &c->imgRefs, &c->scratchA, &c->scratchB, &c->descAllF[0], &c->descAllF[1], &c->descAllU8[0],
-                    &c->descAllU8[1], &c->descAllU8b[0], &c->descAllU8b[1], &c->pos2, &c->matchRows, &c->matchWork, &c->misc, &c->scratchC, &c->needTab, &c->coordTab, &c->tileJob, &c->blurTiles, &c->nmsQueue, &c->rowStarts, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps, &c->viewJobs};
+                    &c->descAllU8[1], &c->descAllU8b[0], &c->descAllU8b[1], &c->shardLocal, &c->pos2, &c->matchRows, &c->matchWork, &c->misc, &c->scratchC, &c->needTab, &c->coordTab, &c->tileJob, &c->blurTiles, &c->nmsQueue, &c->rowStarts, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps, &c->viewJobs};
   for (DevBuf *b : bufs) b->release();
   for (int i = 0; i < MAXB; i++) { c->descF[i].release(); c->descU8[i].release(); c->viewImg[i].release(); }
   PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc, &c->hNms, &c->hMatch, &c->hViewTaps, &c->hViewJobs, &c->hMser};

@@ -253,7 +253,7 @@ struct modsx_ctx {
   hipStream_t stream;
   mx::Pyramid pyr[mx::MAXB];
   mx::DevBuf nmsJobs, cand, counter, affJobs, affOut, oriJobs, oriOut, descJobs, tilePrefix, taps, imgRefs, scratchA, scratchB,
-      descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], descAllU8b[2], pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps, viewJobs, viewImg[mx::MAXB], scratchC, needTab, coordTab, tileJob, blurTiles, nmsQueue, rowStarts;
+      descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], descAllU8b[2], shardLocal, pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps, viewJobs, viewImg[mx::MAXB], scratchC, needTab, coordTab, tileJob, blurTiles, nmsQueue, rowStarts;
   mx::ImgRef imgRefsHost[mx::MAXB];   // what imgRefs holds on the device
   mx::PinBuf hDescB;           // second staging blob of describe_batch: chunk k + 1 is prepared while chunk k runs
   hipEvent_t descEv[2];

@@ -362,8 +362,8 @@ int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
   std::string lerr;
   size_t cap = (size_t)1 << 15;
   for (;;) {
-    if (!c->descAllU8b[1].ensure(cap * 128)) { lrc = MODSX_ERR_NOMEM; break; }
-    lrc = detect_describe_views(c, img, views, nv, pp, R, W, local, nullptr, (uint8_t *)c->descAllU8b[1].p, cap, nullptr, cnt.data());
+    if (!c->shardLocal.ensure(cap * 128)) { lrc = MODSX_ERR_NOMEM; break; }
+    lrc = detect_describe_views(c, img, views, nv, pp, R, W, local, nullptr, (uint8_t *)c->shardLocal.p, cap, nullptr, cnt.data());
     if (lrc == MODSX_ERR_CAPACITY && cap < ((size_t)1 << 24)) { cap *= 4; continue; }
     break;
   }
@@ -401,7 +401,7 @@ int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
       memcpy(L.hRegs.p, local.data(), (size_t)npack * REG_B);
       MX_HIP(hipMemcpyAsync(L.regsIn.p, L.hRegs.p, (size_t)npack * REG_B, hipMemcpyHostToDevice, s));
       hipLaunchKernelGGL(k_pack_rows, dim3((npack + 7) / 8), dim3(256), 0, s, (const unsigned char *)L.regsIn.p,
-                         (const unsigned char *)c->descAllU8b[1].p, npack, (unsigned char *)L.blkLocal.p + hdrB);
+                         (const unsigned char *)c->shardLocal.p, npack, (unsigned char *)L.blkLocal.p + hdrB);
     }
     // 4. the exchange: one all-gather of the blocks
     int rc = ordered_all_gather(cm, lane, L.blkLocal.p, L.blkAll.p, blockB, s);

@@ -364,15 +364,16 @@ def set_vs_pars(scale_set, tilt_set, phi_base, init_sigma=0.5, do_blur=1, prev=N
     return [make_view(par[i].tilt, par[i].phi, par[i].zoom, par[i].InitSigma, par[i].doBlur) for i in range(n)]
 
 
-def detect_describe_views(gray, views, params=None, ori=(1.0, 41, 1, 0.8), desc=(5.1962, 41, 0, 1, 1, 0.2), mser=None):
+def detect_describe_views(gray, views, params=None, ori=(1.0, 41, 1, 0.8), desc=(5.1962, 41, 0, 1, 1, 0.2), mser=None, threads=1):
     """The HessianAffine branch of SynthDetectDescribeKeypoints (imagerepresentation.cpp:603-2047) for one
     descriptor: per view synthesise, detect, orient, reproject, describe; concatenate in view order with
-    AddRegionsToList id re-basing (:588-600).  Returns (regions, descriptors)."""
+    AddRegionsToList id re-basing (:588-600).  Returns (regions, descriptors).  threads > 1: the views run on a thread
+    pool (the reference's `#pragma omp parallel for` over views, :612-622; ctypes releases the GIL), same result."""
     gray = _f32(gray)
     params = params or default_params()
-    all_regs, all_desc = [], []
-    size = 0
-    for vi, v in enumerate(views):
+
+    def one(job):
+        vi, v = job
         img, H, ident = synth_view(gray, v)
         vt, vz = (abs(v.tilt) if not ident else 1.0), (v.zoom if not ident else 1.0)
         if mser is not None:   # DetectAffineRegions(..., DET_MSER, DetectMSERs), imagerepresentation.cpp:1037
@@ -385,7 +386,18 @@ def detect_describe_views(gray, views, params=None, ori=(1.0, 41, 1, 0.8), desc=
         rr = reproject_regions(ro, H.reshape(9), gray.shape[1], gray.shape[0])
         d = describe_regions(img, rr, mr_size=desc[0], patch_size=desc[1], fast=desc[2], photo_norm=desc[3],
                              rootsift=desc[4], max_bin=desc[5])
-        rr = rr.copy()
+        return rr.copy(), d
+
+    jobs = list(enumerate(views))
+    if threads > 1 and len(jobs) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(threads) as pool:
+            parts = list(pool.map(one, jobs))
+    else:
+        parts = [one(j) for j in jobs]
+    all_regs, all_desc = [], []
+    size = 0
+    for rr, d in parts:
         rr["id"] += size
         rr["parent_id"] += size
         size += len(rr)

@@ -216,3 +216,26 @@ def test_sharded_ladder_equals_unsharded_ladder(ctx, modsx, small_pair):
         _same_pair_result(got_all, ref_all)
         _same_pair_result(got_early, ref_early)
     ia.free(); ib.free()
+
+
+def test_configs3_full_cviu_ladder_sharded_over_8_ranks(ctx, modsx):
+    """configs[3] with its view sharding: every step of the iters_mods_cviu.ini ladder (27 MSER + 61 HessianAffine views per
+    image, all steps forced) on the 1024x768 pair with the views of each step split over 8 ranks; every rank ends with the
+    result of the unsharded ladder (which test_gpu_views.py compares with the oracle)."""
+    from mods_amd import distributed as D, synthetic
+    from test_gpu_views import _cviu_ladder
+    a, b, _ = synthetic.make_pair(rows=768, cols=1024, nblobs=4000, seed=12345)
+    _, steps = _cviu_ladder(None, modsx)
+    par = modsx.default_pair_params(ransac_seed=3, ori_mrSize=5.1962)
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    ref, done = ctx.match_ladder(ia, ib, steps, par, min_matches=10 ** 6)
+    assert done == 5 and ref["n_regions"][0] > 50000
+
+    def rank_body(r, comm):
+        return comm.match_ladder_sharded(0, ia, ib, steps, par, min_matches=10 ** 6), comm.describe()
+
+    for got, info in D.run_loopback(8, rank_body):
+        assert got[1] == 5
+        _same_pair_result(got[0], ref)
+        assert info["ranks_seen_by_rccl"] == 8 and info["all_gather_calls_rank0"] >= 5 * 3
+    ia.free(); ib.free()

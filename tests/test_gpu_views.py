@@ -173,7 +173,7 @@ def test_view_shard_path_world1_rccl(ctx, modsx, small_pair):
         comm.close()
 
 
-def _oracle_ladder(oracle, a, b, steps, min_matches, seed, ori_mr=1.0):
+def _oracle_ladder(oracle, a, b, steps, min_matches, seed, ori_mr=1.0, threads=1):
     """mods.cpp:229-415 restated with the oracle's stage functions (test-side only).  steps: (views, ratio[, detector]);
     the two detector classes keep their own region lists and tentatives (CorrespondenceBank), HessianAffine first."""
     mser_kw = dict(min_size=30, max_area=0.05, min_margin=8.0)
@@ -186,7 +186,8 @@ def _oracle_ladder(oracle, a, b, steps, min_matches, seed, ori_mr=1.0):
         det = st[2] if len(st) > 2 else 0
         k = cls[det]
         for side, img in enumerate((a, b)):
-            r, d = oracle.detect_describe_views(img, views, ori=(ori_mr, 41, 1, 0.8), mser=mser_kw if det == 3 else None)
+            r, d = oracle.detect_describe_views(img, views, ori=(ori_mr, 41, 1, 0.8), mser=mser_kw if det == 3 else None,
+                                                threads=threads)
             if k["acc"][side][0] is None:
                 k["acc"][side] = [r, d]
             else:
@@ -290,6 +291,50 @@ def test_mixed_mser_hessaff_ladder_matches_oracle(ctx, modsx, oracle, small_pair
     assert np.array_equal(got["ransac_inlier"], ref["rr"]["inl"]) and np.array_equal(got["verified"], ref["rr"]["keep"])
     assert np.abs(normH(got["H"]) - normH(ref["rr"]["H"])).max() < 1e-4
     assert np.abs(normH(got["H"]) - H).max() < 1.5
+
+
+def _cviu_ladder(oracle, modsx):
+    """[MSER2], [MSER3], [HessianAffine4..6] of build/iters_mods_cviu.ini: view sets of both sides, later steps de-duplicated
+    against the earlier ones of their detector (SetVSPars prev_par)."""
+    prev_o, prev_m, steps_o, steps_m = {0: [], 3: []}, {0: [], 3: []}, [], []
+    for det, scales, tilts, phi, sigma, ratio in ((3, [1, 0.25, 0.125], [1], 360.0, 0.8, 0.85),
+                                                 (3, [1, 0.25, 0.125], [1, 3, 6, 9], 360.0, 0.8, 0.8),
+                                                 (0, [1], [1, 2, 4, 6, 8], 360.0, 0.2, 0.8),
+                                                 (0, [1], [1, 2, 4, 6, 8], 120.0, 0.2, 0.8),
+                                                 (0, [1], [1, 2, 4, 6, 8], 60.0, 0.2, 0.8)):
+        vm = modsx.set_vs_pars(scales, tilts, phi, sigma, 1, prev_m[det])
+        steps_m.append((vm, ratio, det))
+        if oracle is not None:
+            vo = oracle.set_vs_pars(scales, tilts, phi, sigma, 1, prev_o[det])
+            assert len(vo) == len(vm) and len(vo) > 0
+            steps_o.append((vo, ratio, det))
+    return steps_o, steps_m
+
+
+def test_configs3_full_cviu_ladder_all_steps_matches_oracle(ctx, modsx, oracle):
+    """configs[3] in its stated form on one GPU: the 1024x768 synthetic pair through ALL MSER and HessianAffine steps of
+    iters_mods_cviu.ini (minMatches forced high): 27 MSER views and 61 HessianAffine views per image accumulate, every step
+    re-matches its class; region counts, every tentative, the RANSAC inlier set, the verified set and H == the CPU oracle's
+    loop (whose views run on a thread pool, as the reference's OpenMP loop does)."""
+    import os
+    from mods_amd import synthetic
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    a, b, _ = synthetic.make_pair(rows=768, cols=1024, nblobs=4000, seed=12345)
+    steps_o, steps_m = _cviu_ladder(oracle, modsx)
+    assert [len(v) for v, _, _ in steps_m] == [3, 24, 11, 20, 30]        # 27 MSER views, 61 HessianAffine views
+    par = modsx.default_pair_params(ransac_seed=3, ori_mrSize=5.1962)
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    got, done = ctx.match_ladder(ia, ib, steps_m, par, min_matches=10 ** 6)
+    ia.free(); ib.free()
+    ref, done_ref = _oracle_ladder(oracle, a, b, steps_o, 10 ** 6, 3, ori_mr=5.1962, threads=min(64, os.cpu_count() or 1))
+    assert done == done_ref == 5
+    assert got["n_regions"] == ref["n_regions"] and got["n_regions"][0] > 50000
+    assert got["n_tentatives"] == ref["n_tentatives"] and len(ref["tent"]) > 5000
+    for f in ref["tent"].dtype.names:
+        assert np.array_equal(got["tentatives"][f], ref["tent"][f]), f
+    assert np.array_equal(got["ransac_inlier"], ref["rr"]["inl"]) and np.array_equal(got["verified"], ref["rr"]["keep"])
+    assert np.abs(normH(got["H"]) - normH(ref["rr"]["H"])).max() < 1e-4
 
 
 def test_cat_pair_full_ladder_stops_early_on_ground_truth(ctx, modsx, cat_pair):
