@@ -8,11 +8,16 @@ orientation -> RootSIFT per view, then brute-force FGINN matching of the ~24 k x
 (matching.cpp:357-461), duplicate filtering and LO-RANSAC (H).  All images are resident in HBM before the timed region.
 
   --config views31 (default) | views61 | views11 | views8 | views1 | wxbs      workload of the JSON line
+  --config ladder    configs[3] on one GPU: every MSER and HessianAffine step of build/iters_mods_cviu.ini (27 MSER + 61
+             HessianAffine views per image, minMatches forced high so that all steps run), with the MSER host share
   --gpus N   one process per GPU (torch.distributed.run).  --shard pairs (default): independent pairs per rank, no
-             collective.  --shard views: every pair's views are split over the N ranks (view v -> rank v mod N), the region
-             rows + u8 descriptors are all-gathered over RCCL/xGMI inside the library (modsx_detect_describe_views_sharded)
-             and the query rows of the match are split over the ranks (modsx_match_fginn_sharded); the batch grows with N
-             (weak scaling: per-GPU work fixed).
+             collective; with N > 1 the same line carries `scaling_views`, the north-star's view-parallel mode measured
+             right after: every pair's views are split over the N ranks (view v -> rank v mod N), the region rows + u8
+             descriptors are all-gathered over RCCL/xGMI inside the library (modsx_detect_describe_views_sharded) and the
+             query rows of the match are split over the ranks; the batch grows with N (weak scaling: per-GPU work fixed).
+             --shard views makes that mode the headline value instead.
+  --loopback W   one GPU: the view-sharded path with W in-process ranks (loopback transport: the all-gather is W
+             device-to-device copies, everything else is the code the RCCL transport runs), workers / W lanes per rank
 Rank 0 prints ONE JSON line: value = pairs/s of the whole job, `roofline` = the distance kernels (all k_match_*
 launches, sweep 2 included, on the descriptors of this run) against the int8 MFMA peak, `roofline_describe` = the
 describe stage against HBM with SURVEY section 8(d) bytes, `cpu_baseline` = the CPU oracle (restatement of the reference's
@@ -40,7 +45,21 @@ CONFIGS = {   # name -> (tilts, phi, detector mode, description)
     # configs[4]: 1920x1080 pairs with the parameter set of config_iter_mods_cviu_wxbs.ini (NotLessThanRegions 2000, maxAngles 5
     # on the 5.1962 region, HalfRootSIFT, contradDist 10, duplicateDist 3, err_threshold 4, max_samples 1e6), H then F
     "wxbs": ("1", 360.0, "configs[4]: WxBS parameter set, identity view"),
+    "ladder": ("1,2,4,6,8", 60.0, "configs[3]: iters_mods_cviu.ini, all MSER + HessianAffine steps (27 + 61 views per image)"),
 }
+# [MSER2], [MSER3], [HessianAffine4..6] of build/iters_mods_cviu.ini: detector, ScaleSet, TiltSet, Phi, initSigma, FGINN ratio
+CVIU_LADDER = ((3, [1, 0.25, 0.125], [1], 360.0, 0.8, 0.85), (3, [1, 0.25, 0.125], [1, 3, 6, 9], 360.0, 0.8, 0.8),
+               (0, [1], [1, 2, 4, 6, 8], 360.0, 0.2, 0.8), (0, [1], [1, 2, 4, 6, 8], 120.0, 0.2, 0.8),
+               (0, [1], [1, 2, 4, 6, 8], 60.0, 0.2, 0.8))
+
+
+def cviu_ladder_steps(M, only=None):
+    prev, steps = {0: [], 3: []}, []
+    for det, scales, tilts, phi, sigma, ratio in CVIU_LADDER:
+        v = M.set_vs_pars(scales, tilts, phi, sigma, 1, prev[det])
+        if v and (only is None or det == only):
+            steps.append((v, ratio, det))
+    return steps
 WXBS = dict(mode=4, threshold=5.3333, reg_number=2000, ori_mrSize=5.1962, ori_maxAngles=5, ori_threshold=0.8, desc_mrSize=5.1962,
             desc_photoNorm=1, desc_type=3, desc_maxBinValue=0.2, match_ratio=0.8, contradDist=10.0, duplicateDist=3.0,
             err_threshold=4.0, confidence=0.99, max_samples=1000000, localOptimization=1, LAFCoef=3.0, HLAFCoef=13.0, doSymmCheck=1)
@@ -126,6 +145,69 @@ def oracle_pair_views(O, a, b, views_o, params, threads, seed=1, query_cap=None,
     return out
 
 
+class ShardGroup:
+    """The view-sharded mode of a step.  RCCL: this process is one rank, its contexts are the lanes of ONE communicator.
+    Loopback (one GPU): W in-process ranks, each with its own contexts / lanes.  Pair i of a step runs on lane i % lanes of
+    EVERY rank (static map: all ranks must issue the collectives of a lane in the same order); rank i % world verifies."""
+
+    def __init__(self, mods_amd, device, lanes, dist=None, loopback=0, ctxs=None):
+        from mods_amd import distributed as D
+        self.lanes = lanes
+        if loopback:
+            self.world = loopback
+            uid = mods_amd.comm_loopback_id(loopback)
+            self.ctxs = [[mods_amd.Context(device) for _ in range(lanes)] for _ in range(loopback)]
+            self.comms = [D.NativeComm(self.ctxs[r], rank=r, world=loopback, uid=uid) for r in range(loopback)]
+            self.own_ctxs = True
+        else:
+            self.world = dist.get_world_size() if dist is not None else 1
+            self.ctxs = [list(ctxs[:lanes])]
+            self.comms = [D.NativeComm(self.ctxs[0], dist)]
+            self.own_ctxs = False
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(len(self.comms) * lanes)
+
+    def step(self, i1, i2, views, params):
+        for cm in self.comms:
+            cm.reset_lanes()
+
+        def work(job):
+            k, w = job
+            cm = self.comms[k]
+            out = []
+            try:
+                for i in range(w, len(i1), self.lanes):
+                    out.append((i, cm.match_pair_views_sharded(w, i1[i], i2[i], views, params, owner=i % self.world)))
+            finally:
+                cm.lane_done(w)
+            return out
+        res = [None] * len(i1)
+        for part in self.pool.map(work, [(k, w) for k in range(len(self.comms)) for w in range(self.lanes)]):
+            for i, r in part:
+                if r is not None:
+                    res[i] = r
+        return res
+
+    def synchronize(self):
+        for cs in self.ctxs:
+            for c in cs:
+                c.synchronize()
+
+    def describe(self):
+        d = self.comms[0].describe()
+        d["ranks_in_this_process"] = len(self.comms)
+        return d
+
+    def close(self):
+        self.pool.shutdown()
+        for cm in self.comms:
+            cm.close()
+        if self.own_ctxs:
+            for cs in self.ctxs:
+                for c in cs:
+                    c.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,15 +218,17 @@ def main():
     ap.add_argument("--config", type=str, default="views31", choices=sorted(CONFIGS))
     ap.add_argument("--tilts", type=str, default="", help="override the tilt set of --config, e.g. 1,2,3,4,6")
     ap.add_argument("--phi", type=float, default=0.0)
-    ap.add_argument("--batch", type=int, default=0, help="pairs per step per GPU (default 64; 256 for views1, 128 for wxbs)")
+    ap.add_argument("--batch", type=int, default=0, help="pairs per step per GPU (default 64; 256 for views1, 128 for wxbs, 32 for ladder)")
     ap.add_argument("--blobs", type=int, default=0, help="blobs per 1024x768 of the synthetic scene (0 = per config)")
     ap.add_argument("--workers", type=int, default=16, help="contexts (thread + stream) per GPU")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs cycled through the batch")
     ap.add_argument("--init-sigma", type=float, default=0.2)
     ap.add_argument("--shard", type=str, default="", choices=["", "pairs", "views"])
+    ap.add_argument("--loopback", type=int, default=0, help="one GPU: W in-process ranks of the view-sharded path")
+    ap.add_argument("--no-scaling-views", action="store_true", help="N > 1: skip the view-sharded second measurement")
     ap.add_argument("--batch-api", action="store_true", help="multi-view configs: run a step as ONE modsx_match_pairs_views call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the short 1/8/11-view runs reported under `extra`")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short 1/8/11-view and 4000-blob runs reported under `extra`")
     args = ap.parse_args()
 
     import numpy as np
@@ -158,15 +242,19 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    # default: pairs over ranks (no collective: independent pairs are the reference's batch use).  --shard views is the
-    # north-star's view-parallel mode; it needs RCCL between the ranks and is opt-in because the 1-GPU development box
-    # cannot exercise world > 1 (the path is covered at world 1 on the GPU and at world 2/3 over gloo on recorded blocks).
+    # headline: pairs over ranks (no collective: independent pairs are the reference's batch use); the north star's
+    # view-parallel mode is measured in the same run when N > 1 (`scaling_views`), or as the headline with --shard views
     shard = args.shard or "pairs"
+    if args.loopback:
+        if world > 1:
+            raise SystemExit("--loopback is a one-process mode")
+        shard = "views"
 
     import mods_amd
     from mods_amd import synthetic
     tilts, phi, cfg_desc = CONFIGS[args.config]
     wxbs = args.config == "wxbs"
+    ladder = args.config == "ladder"
     if wxbs:
         args.rows, args.cols = 1080, 1920
     if args.tilts:
@@ -175,34 +263,45 @@ def main():
     single_view = tilts == "1"
     # a step ends with the verification of its last pairs while the GPU drains: configs[1] (45 ms per 64 pairs) and
     # configs[4] take longer steps so that this tail stays a few per cent of the step
-    batch = args.batch or (128 if wxbs else 256 if single_view else 64)
-    # blob density of the synthetic scene: 4000 per 1024x768 for configs[1] (comparable with round 1), 5500 for the
-    # multi-view configs so that the 31-view default carries the >= 50 k descriptors per pair the north star is quoted on
-    blobs = args.blobs or (4000 if (single_view or wxbs) else 5500)
+    batch = args.batch or (128 if wxbs else 256 if single_view else 32 if ladder else 64)
+    # blob density of the synthetic scene: 4000 per 1024x768 for configs[1], [3], [4]; 5500 for
+    # the multi-view headline so that the 31-view default carries the >= 50 k descriptors per pair the north star is quoted
+    # on (the 4000-blob figure of the same configuration is reported under `extra`)
+    blobs = args.blobs or (4000 if (single_view or wxbs or ladder) else 5500)
     nblobs = int(blobs * args.rows * args.cols / (768.0 * 1024))
     ctxs = [mods_amd.Context(local_rank) for _ in range(max(1, args.workers))]
     ctx = ctxs[0]
-    params = mods_amd.default_pair_params(ransac_seed=1, **(WXBS if wxbs else {}))
+    pkw = dict(WXBS) if wxbs else dict(ori_mrSize=5.1962) if ladder else {}
+    params = mods_amd.default_pair_params(ransac_seed=1, **pkw)
     views = mods_amd.set_vs_pars([1.0], [float(t) for t in tilts.split(",")], phi, args.init_sigma, 1, [])
+    lsteps = cviu_ladder_steps(mods_amd) if ladder else None
 
-    # pairs: with --shard views every rank holds every pair of the (N x larger) batch; otherwise its own pairs
-    comm = None
+    def make_images(seed0, count, nb):
+        host = [synthetic.make_pair(rows=args.rows, cols=args.cols, nblobs=nb, seed=seed0 + 17 * i) for i in range(max(1, count))]
+        devp = [(ctx.upload(a), ctx.upload(b)) for a, b, _ in host]
+        return host, devp
+
+    # pairs: in the view-sharded mode every rank holds every pair of the (N x larger) batch; otherwise its own pairs
+    views_world = args.loopback or world
     if shard == "views":
-        from mods_amd import distributed as D
-        comm = D.NativeComm(ctxs, dist)          # one RCCL communicator per context (stream), bootstrapped over torch
-        seed0, nbatch = 12345, batch * world
+        seed0, nbatch = 12345, batch * views_world
     else:
         seed0, nbatch = 12345 + 1000 * rank, batch
-    pairs_host = [synthetic.make_pair(rows=args.rows, cols=args.cols, nblobs=nblobs, seed=seed0 + 17 * i)
-                  for i in range(max(1, args.distinct))]
+    pairs_host, dev = make_images(seed0, args.distinct, nblobs)
     Hgt = pairs_host[0][2]
-    dev = [(ctx.upload(a), ctx.upload(b)) for a, b, _ in pairs_host]
     imgs1 = [dev[i % len(dev)][0] for i in range(nbatch)]
     imgs2 = [dev[i % len(dev)][1] for i in range(nbatch)]
 
-    def barrier():
+    group = None
+    if shard == "views":
+        lanes = max(1, len(ctxs) // args.loopback) if args.loopback else len(ctxs)
+        group = ShardGroup(mods_amd, local_rank, lanes, dist=dist, loopback=args.loopback, ctxs=ctxs)
+
+    def barrier(g=None):
         for c in ctxs:
             c.synchronize()
+        if g is not None:
+            g.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -211,10 +310,12 @@ def main():
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(len(ctxs))
 
-    def run_batch(vw=views, single=single_view, i1=imgs1, i2=imgs2, cx=ctxs):
+    def run_batch(vw=views, single=single_view, i1=imgs1, i2=imgs2, cx=ctxs, g=group, steps_l=lsteps):
+        if g is not None:
+            return g.step(i1, i2, vw, params)
         if single:
             return mods_amd.match_pairs(cx, i1, i2, params)
-        if comm is None and args.batch_api:
+        if args.batch_api and steps_l is None:
             # the library's own batch loop (modsx_match_pairs_views): 4-5 % below the persistent python threads of the default
             # path, whose threads are not re-created per step
             return mods_amd.match_pairs_views(cx, i1, i2, vw, params, arrays=False)
@@ -222,59 +323,91 @@ def main():
         # multi-view pairs: one python thread per context (ctypes releases the GIL inside the library).  The contexts take the
         # pairs of the step from a shared counter, so that the step ends at most one pair after its last pair was started
         # (with a static pair -> context map the step waited for the context with the most expensive pairs: 15 % of the
-        # GPU's time was idle at step boundaries).  The view-sharded mode keeps the static map: every rank must meet the
-        # others' collectives in the same order.
+        # GPU's time was idle at step boundaries).
         nxt = itertools.count()
         lock = threading.Lock()
 
         def work(w):
             out = []
-            if comm is not None:
-                for i in range(w, len(i1), len(cx)):
-                    out.append((i, comm.match_pair_views_sharded(w, i1[i], i2[i], vw, params, owner=i % world)))
-                return out
             while True:
                 with lock:
                     i = next(nxt)
                 if i >= len(i1):
                     return out
-                out.append((i, cx[w].match_pair_views(i1[i], i2[i], vw, params)))
+                if steps_l is not None:
+                    out.append((i, cx[w].match_ladder(i1[i], i2[i], steps_l, params, min_matches=10 ** 6)[0]))
+                else:
+                    out.append((i, cx[w].match_pair_views(i1[i], i2[i], vw, params)))
         res = [None] * len(i1)
         for part in pool.map(work, range(len(cx))):
             for i, r in part:
                 res[i] = r
         return res
 
-    for _ in range(args.warmup):
-        results = run_batch()
-    barrier()
-    t0 = time.perf_counter()
-    ndesc = 0
-    for _ in range(args.steps):
-        results = run_batch()
-        for r in results:
-            if r is not None:
-                ndesc += r["n_regions"][0] + r["n_regions"][1]
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    res = next(r for r in results if r is not None)
+    def timed(run, warmup, steps, g=None):
+        results = None
+        for _ in range(warmup):
+            results = run()
+        barrier(g)
+        t0 = time.perf_counter()
+        nd = 0
+        for _ in range(steps):
+            results = run()
+            for r in results:
+                if r is not None:
+                    nd += r["n_regions"][0] + r["n_regions"][1]
+        barrier(g)
+        return time.perf_counter() - t0, nd, results
+
+    def reduce_over_ranks(elapsed, nd):
+        if dist is None:
+            return elapsed, float(nd)
+        t = torch.tensor([elapsed, float(nd)], device="cuda", dtype=torch.float64)
+        tmax, tsum = t.clone(), t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        return float(tmax[0]), float(tsum[1])
+
+    elapsed, ndesc, results = timed(run_batch, args.warmup, args.steps, group)
+    res = next((r for r in results if r is not None), None)
     verify_timed = mods_amd.last_batch_verify() if single_view else None   # host share of the last batch of the timed region
+    elapsed, ndesc_total = reduce_over_ranks(elapsed, ndesc)
+    if res is None:   # view-sharded: this rank verified none of the last step's pairs
+        res = {"n_regions": (0, 0), "n_tentatives": 0, "n_unique": 0, "n_verified": 0, "H": np.eye(3)}
+
+    # ---- N > 1: the north star's view-parallel mode, measured right after the pair-sharded headline -------------------
+    scaling_views = None
+    if world > 1 and group is None and not args.no_scaling_views and not single_view and not ladder:
+        try:
+            vhost, vdev = make_images(12345, args.distinct, nblobs)       # every rank holds every pair
+            nb_v = batch * world
+            v1 = [vdev[i % len(vdev)][0] for i in range(nb_v)]
+            v2 = [vdev[i % len(vdev)][1] for i in range(nb_v)]
+            vg = ShardGroup(mods_amd, local_rank, len(ctxs), dist=dist, ctxs=ctxs)
+            el_v, nd_v, res_v = timed(lambda: vg.step(v1, v2, views, params), max(1, args.warmup), args.steps, vg)
+            el_v, nd_v = reduce_over_ranks(el_v, nd_v)
+            scaling_views = {"value": args.steps * nb_v / el_v, "unit": "image-pairs/s", "ms_per_step": 1e3 * el_v / args.steps,
+                             "pairs_per_step": nb_v, "descriptors_per_s": nd_v / el_v, "scaling": "weak",
+                             "parallelism": "views of every pair sharded over %d ranks (view v -> rank v mod N), one RCCL all-gather of "
+                                            "header + region rows + u8 descriptors per image side, query rows of the match split over "
+                                            "the ranks, verification on rank pair mod N" % world,
+                             "rccl": vg.describe()}
+            vg.close()
+            for a_, b_ in vdev:
+                a_.free(); b_.free()
+        except Exception as e:       # noqa: BLE001 -- reported in the JSON line, the headline stands
+            scaling_views = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- untimed legs (rank 0 reports them) -------------------------------------------------------------------------
-    # per-kernel time of the multi-stream regime: two extra steps with the event brackets on
+    # per-kernel time of the multi-stream regime: an extra step with the event brackets on
     PROF_STEPS = 1
     stats = {}
-    if rank == 0 or comm is not None:
+    if (rank == 0 and group is None) or (group is not None and not args.loopback):
         for c in ctxs:
             c.profile(True)
         for _ in range(PROF_STEPS):
             run_batch()
-        if comm is not None:
-            barrier()
-        else:
-            for c in ctxs:
-                c.synchronize()
+        barrier(group) if group is not None else [c.synchronize() for c in ctxs]
         for c in ctxs:
             for k, v in c.kernel_stats().items():
                 d = stats.setdefault(k, dict(ms=0.0, work=0.0, launches=0))
@@ -282,8 +415,8 @@ def main():
             c.profile(False)
     # Roofline leg: in the timed region the kernels of --workers streams time-slice the CUs, so an event pair there
     # brackets queueing as well.  The same pairs are repeated on ONE stream and the launch durations come from that pass.
-    iso, niso = {}, 0
-    if rank == 0 and (comm is None or world == 1):
+    iso, niso, mroof = {}, 0, None
+    if rank == 0 and (group is None or views_world == 1 or args.loopback):
         ctx.profile(True)
         niso = min(nbatch, 8 if single_view else 4)
         if single_view:
@@ -295,32 +428,36 @@ def main():
         ctx.synchronize()
         iso = {k: v for k, v in ctx.kernel_stats().items() if v["launches"]}
         ctx.profile(False)
-    if dist is not None:
-        t = torch.tensor([elapsed, float(ndesc)], device="cuda", dtype=torch.float64)
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0])
-        ndesc_total = float(tsum[1])
-    else:
-        ndesc_total = float(ndesc)
+        if not single_view:
+            # the matcher's roofline: ONE pair (pair 0), repeated; N, M and the work all come from that pair
+            ctx.profile(True)
+            REP = 5
+            for _ in range(REP):
+                r0 = ctx.match_pair_views(imgs1[0], imgs2[0], views, params)
+            ctx.synchronize()
+            m = ctx.kernel_stats().get("match_fginn")
+            ctx.profile(False)
+            if m and m["launches"]:
+                mroof = (m["ms"] / m["launches"], r0["n_regions"][0], r0["n_regions"][1], m["launches"])
 
     if rank == 0:
-        pairs = args.steps * (nbatch if comm is not None else world * nbatch)
+        pairs = args.steps * (nbatch if group is not None else world * nbatch)
         value = pairs / elapsed
         out = {
             "metric": "image-pairs/sec (1024x768, HessAff+RootSIFT over the affine view ladder, MFMA FGINN match, LO-RANSAC H)",
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (detect/describe) + u8 on the int8 matrix cores (distance matrix)", "data": "synthetic",
-            "config": {"workload": "%dx%d synthetic pair, %s = %d views per image, HessAff+RootSIFT, MFMA distance matrix + "
-                                   "FGINN, duplicate filter, LO-RANSAC H" % (args.cols, args.rows, cfg_desc, len(views)),
-                       "views": len(views), "pairs_per_step": nbatch if comm is not None else world * nbatch,
-                       "workers_per_gpu": len(ctxs), "distinct_pairs": len(dev),
-                       "parallelism": ("views of every pair sharded over %d ranks (v mod N), RCCL all-gather of region rows + u8 "
-                                       "descriptors, query rows of the match split over ranks" % world) if comm is not None else
-                                      "pairs sharded over ranks, no collective"},
+            "config": {"workload": ("%dx%d synthetic pair, %s, MSER + HessAff, RootSIFT, MFMA distance matrix + FGINN per class, duplicate "
+                                    "filter, LO-RANSAC H after every step" % (args.cols, args.rows, cfg_desc)) if ladder else
+                                   ("%dx%d synthetic pair, %s = %d views per image, HessAff+RootSIFT, MFMA distance matrix + "
+                                    "FGINN, duplicate filter, LO-RANSAC H" % (args.cols, args.rows, cfg_desc, len(views))),
+                       "views": len(views), "pairs_per_step": nbatch if group is not None else world * nbatch,
+                       "workers_per_gpu": len(ctxs), "distinct_pairs": len(dev), "blobs_per_1024x768": blobs,
+                       "parallelism": ("views of every pair sharded over %d ranks (v mod N), one all-gather of header + region rows + u8 "
+                                       "descriptors per image side (%s), query rows of the match split over ranks"
+                                       % (views_world, "loopback transport, all ranks on this GPU" if args.loopback else "RCCL"))
+                                      if group is not None else "pairs sharded over ranks, no collective"},
             "descriptors_per_s": ndesc_total / elapsed,
             "descriptors_per_pair": ndesc_total / pairs,
             "result": {"regions": list(res["n_regions"]), "tentatives": res["n_tentatives"], "unique": res["n_unique"],
@@ -328,31 +465,48 @@ def main():
                        "H_vs_generator_max_abs": float(np.abs(res["H"] / res["H"][2, 2] - Hgt).max())},
             "kernel_ms_per_pair_multi_stream": {k: v["ms"] / (PROF_STEPS * nbatch) for k, v in stats.items() if v["launches"]},
         }
-        if comm is not None:
-            out["rccl"] = comm.describe()
+        if group is not None:
+            out["rccl"] = group.describe()
+        if scaling_views is not None:
+            out["scaling_views"] = scaling_views
         if iso:
             per = {k: v["ms"] / niso for k, v in iso.items()}
             out["kernels_single_stream_ms_per_pair"] = per
-            m = iso.get("match_fginn")
-            if m and m["launches"]:
-                n1, n2 = res["n_regions"]
-                ms = m["ms"] / m["launches"]
+            if mroof is None and iso.get("match_fginn", {}).get("launches"):
+                m = iso["match_fginn"]      # configs[1] / [4]: launch sets of 4 small problems; per launch set
+                mroof = (m["ms"] / m["launches"], None, None, m["launches"])
                 flops = m["work"] / m["launches"]
+            if mroof is not None:
+                ms, n1, n2, nl = mroof
+                if n1 is not None:
+                    flops = 2.0 * n1 * n2 * 128
                 tf = flops / (ms * 1e-3) / 1e12
-                byts = (n1 + n2) * 128.0 + n1 * 32.0
                 out["roofline"] = {
-                    "kernel": "k_match_* (pack, sweep1, decide, sweep2, events: every launch of one matching problem)",
+                    "kernel": "k_match_* (every launch of one matching problem: pack, sweep 1, sweep 2, walk)",
                     "bound": "mfma", "achieved": tf, "peak": INT8_PEAK_TOPS, "unit": "TFLOP/s", "frac": tf / INT8_PEAK_TOPS,
                     "traffic": None, "avg_launch_ms": ms, "algorithmic_work_per_launch": flops, "N": n1, "M": n2,
-                    "hbm_view": {"compulsory_bytes": byts, "achieved_GBs": byts / (ms * 1e-3) / 1e9,
-                                 "frac_of_8TBs": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                     "binds": "mfma: 2*N*M*128 int8 ops against (N+M)*128 B is ~1e4 op/B, the kernel is compute-shaped; "
                              "its limiter is VALU issue beside the MFMAs (DESIGN.md section 5)",
-                    "note": "HIP events on the launch stream around the five launches, single-stream pass over %d pairs of "
-                            "this run right after the timed region; N, M = regions of the last pair" % niso}
-                tfile = os.path.join(ROOT, "profiles", "pmc_traffic_r02.json")
-                if os.path.exists(tfile):
-                    out["roofline"]["traffic"] = json.load(open(tfile)).get("k_match_total_" + args.config)
+                    "note": ("HIP events on the launch stream around the launches of ONE matching problem -- pair 0 of this run, "
+                             "%d repetitions on one stream right after the timed region; N, M, the work and the time all belong "
+                             "to that pair" % nl) if n1 is not None else
+                            "HIP events on the launch stream; one launch set = up to 4 small problems, work = their sum"}
+                if n1 is not None:
+                    byts = (n1 + n2) * 128.0 + n1 * 32.0
+                    out["roofline"]["hbm_view"] = {"compulsory_bytes": byts, "achieved_GBs": byts / (ms * 1e-3) / 1e9,
+                                                   "frac_of_8TBs": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            tfile, tsrc = None, None
+            for tag in ("r03", "r02"):
+                cand = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % tag)
+                if os.path.exists(cand):
+                    tfile, tsrc = cand, "profiles/pmc_traffic_%s.json" % tag
+                    break
+            tj = json.load(open(tfile)) if tfile else {}
+            if "roofline" in out and tj:
+                out["roofline"]["traffic"] = tj.get("k_match_total_views31")
+                out["roofline"]["traffic_source"] = ("%s: FETCH_SIZE x2 + WRITE_SIZE of the k_match_* kernels from separate rocprofv3 --pmc "
+                                                     "passes over tools/bench_match.py at %s (a committed profile, not measured in this run)"
+                                                     % (tsrc, tj.get("k_match_problem", "24.1 k x 23.6 k real 31-view descriptors")))
             dk = [iso.get(k) for k in ("patch_sample", "blur_rows", "blur_cols", "describe")]
             if all(d and d["launches"] for d in dk):
                 ms = sum(d["ms"] for d in dk) / dk[0]["launches"]
@@ -364,12 +518,11 @@ def main():
                     "algorithmic_work_per_launch": byts, "traffic": None,
                     "note": "bytes per SURVEY section 8(d): (P+2)^2 x 4 B read + 128 B written per region; the limiter of these "
                             "kernels is VALU issue / the texture addresser, not HBM (DESIGN.md section 5)"}
-            tfile = os.path.join(ROOT, "profiles", "pmc_traffic_r02.json")
-            if "roofline_describe" in out and os.path.exists(tfile):
-                t = json.load(open(tfile))
-                # HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE, rocprofv3 --pmc, separate passes) of one launch of each kernel of the stage
-                out["roofline_describe"]["traffic"] = sum(t.get(k, 0) for k in ("k_sample_rows_lds", "k_patch_sample", "k_blur_rows_lds",
-                                                                                "k_patch_blur", "k_blur_cols_lds", "k_describe")) or None
+                if tj:
+                    # HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE, rocprofv3 --pmc, separate passes) of one launch of each kernel of the stage
+                    out["roofline_describe"]["traffic"] = sum(tj.get(k, 0) for k in ("k_sample_rows_lds", "k_patch_sample", "k_blur_rows_lds",
+                                                                                     "k_patch_blur", "k_blur_cols_lds", "k_describe")) or None
+                    out["roofline_describe"]["traffic_source"] = "%s (a committed profile of the one-stream 31-view run)" % tsrc
         if wxbs:
             # H verification was the timed region; the same batch with epipolar verification, and the host share of both
             vms, vn, vth = verify_timed
@@ -390,8 +543,30 @@ def main():
                       "host_ransac_share_of_wall": (fms / max(1, fn)) / max(1, fth) / (dtF / (stF * nbatch) * 1e3)},
                 "note": "DuplicateFiltering + LO-RANSAC run on helper threads beside the device pipeline; share = per-pair verify "
                         "time / helper threads / per-pair wall time (the fraction of the wall the helpers are busy)"}
+        if ladder:
+            # where a ladder's time goes: the MSER steps alone and the HessianAffine steps alone (throughput, same contexts), and
+            # one pair on an otherwise idle GPU step by step (latency)
+            lad = {"steps": [{"detector": "MSER" if d == 3 else "HessianAffine", "views": len(v), "match_ratio": r} for v, r, d in lsteps]}
+            for name, det in (("mser_steps_only", 3), ("hessaff_steps_only", 0)):
+                st = cviu_ladder_steps(mods_amd, only=det)
+                el, nd, _ = timed(lambda st=st: run_batch(steps_l=st), 1, 2)
+                lad[name] = {"pairs_per_s": 2 * nbatch / el, "descriptors_per_pair": nd / (2 * nbatch), "views_per_image": sum(len(v) for v, _, _ in st)}
+            lat = []
+            ctx.match_ladder(imgs1[0], imgs2[0], lsteps, params, min_matches=10 ** 6)
+            for k in range(1, len(lsteps) + 1):
+                ta = time.perf_counter()
+                for _ in range(3):
+                    ctx.match_ladder(imgs1[0], imgs2[0], lsteps[:k], params, min_matches=10 ** 6)
+                lat.append((time.perf_counter() - ta) / 3 * 1e3)
+            lad["one_pair_idle_gpu_ms_cumulative_by_step"] = lat
+            lad["one_pair_idle_gpu_ms_by_step"] = [lat[0]] + [lat[k] - lat[k - 1] for k in range(1, len(lat))]
+            lad["host_threads"] = os.environ.get("MODSX_HOST_THREADS", "min(hardware threads, 64)")
+            lad["note"] = ("the component trees of the MSER steps run on the host worker pool ((view, polarity) tasks) while other "
+                           "contexts keep the device busy; mser_steps_only / hessaff_steps_only are the same contexts on a ladder cut to "
+                           "that detector's steps")
+            out["ladder"] = lad
         # ---- short runs of the other view counts (same timed-region rules, fewer steps) ---------------------------------
-        if not args.no_extra and comm is None and world == 1 and not args.tilts and not wxbs:
+        if not args.no_extra and group is None and world == 1 and not args.tilts and not wxbs and not ladder:
             extra = {}
             for name in ("views1", "views8", "views11"):
                 if name == args.config:
@@ -401,22 +576,22 @@ def main():
                 nb = 256 if tl == "1" else 64
                 i1 = [dev[i % len(dev)][0] for i in range(nb)]
                 i2 = [dev[i % len(dev)][1] for i in range(nb)]
-                run_batch(vw, tl == "1", i1, i2)
-                for c in ctxs:
-                    c.synchronize()
-                ta = time.perf_counter()
-                nd, st = 0, 3
-                for _ in range(st):
-                    for r in run_batch(vw, tl == "1", i1, i2):
-                        nd += r["n_regions"][0] + r["n_regions"][1]
-                for c in ctxs:
-                    c.synchronize()
-                dt = time.perf_counter() - ta
-                extra[name] = {"views": len(vw), "pairs_per_s": st * nb / dt, "descriptors_per_pair": nd / (st * nb),
-                               "descriptors_per_s": nd / dt}
+                el, nd, _ = timed(lambda: run_batch(vw, tl == "1", i1, i2), 1, 3)
+                extra[name] = {"views": len(vw), "pairs_per_s": 3 * nb / el, "descriptors_per_pair": nd / (3 * nb),
+                               "descriptors_per_s": nd / el, "blobs_per_1024x768": blobs}
+            if not args.blobs and not single_view:
+                # the scene of SURVEY section 8(d) item 2 (4000 blobs per 1024x768) under the headline's view ladder
+                h4, d4 = make_images(12345, args.distinct, int(4000 * args.rows * args.cols / (768.0 * 1024)))
+                i1 = [d4[i % len(d4)][0] for i in range(nbatch)]
+                i2 = [d4[i % len(d4)][1] for i in range(nbatch)]
+                el, nd, _ = timed(lambda: run_batch(views, False, i1, i2), 1, 3)
+                extra["%s_4000_blobs" % args.config] = {"views": len(views), "pairs_per_s": 3 * nbatch / el, "descriptors_per_pair": nd / (3 * nbatch),
+                                                        "descriptors_per_s": nd / el, "blobs_per_1024x768": 4000}
+                for a_, b_ in d4:
+                    a_.free(); b_.free()
             out["extra"] = extra
         # ---- the CPU path on the same workload: parity of one pair of the run + the baseline timing ---------------------
-        if world == 1 and not args.no_cpu_baseline and not wxbs:
+        if world == 1 and not args.no_cpu_baseline and not wxbs and not ladder and group is None:
             from oracle import pyoracle as O
             model, ncpu, usable = cpu_info()
             a, b, _ = pairs_host[0]
@@ -490,8 +665,8 @@ def main():
         print(json.dumps(out), flush=True)
     for a_, b_ in dev:
         a_.free(); b_.free()
-    if comm is not None:
-        comm.close()
+    if group is not None:
+        group.close()
     for c in ctxs:
         c.close()
     if dist is not None:

@@ -214,7 +214,7 @@ MX_D void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <int K>
 __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffOut *out, int n, const float *mask, int chunk,
-                                                        int maxIter, float convTh, float affInitialSigma) {
+                                                        int nchunks, int maxIter, float convTh, float affInitialSigma) {
   constexpr int W = AW_MAX, WW = W * W, half = W >> 1, CH = AW_MAX * AW_MAX + 3;
   constexpr int PERM = (WW + 63) / 64;
   __shared__ __attribute__((aligned(16))) float buf[K][3][CH];
@@ -239,7 +239,10 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
   float u11 = 1.0f, u12 = 0.0f, u21 = 0.0f, u22 = 1.0f, l1 = 1.0f, l2 = 1.0f, era = 0.0f, erb = 0.0f, ratio = 0.f;
   float slx = 0.f, sly = 0.f;   // the keypoint's position in its pyramid level (x / pixelDistance): formed once per keypoint
   int ok = 0, it = 0, kidx = -1;
-  int next = blockIdx.x * chunk;                                       // wave-uniform: next keypoint of the chunk
+  // the job list is image-major in detection order (octave, level, row, column): XCD x takes the x-th contiguous eighth of
+  // the chunks, so that the blur planes a keypoint's windows read stay in ONE L2 (round 2: 1.03 GB fetched per launch, every
+  // window a miss)
+  int next = min(xcd_chunk(blockIdx.x, nchunks) * chunk, n);           // wave-uniform: next keypoint of the chunk
   const int end = min(next + chunk, n);
   bool live = false;
   if (maxIter <= 0) {   // no iteration at all: identity shape, not converged (the loop of the reference does not run)
@@ -412,8 +415,9 @@ void launch_baumberg(hipStream_t s, const AffJob *jobs, AffOut *out, int n, cons
     // for >= 4 rounds of wavefronts over the chip (256 CUs x 16 resident) so that the tail of the launch stays short
     int chunk = n / 16384;
     chunk = chunk < K ? K : (chunk > MODSX_BAUMBERG_CHUNK ? MODSX_BAUMBERG_CHUNK : chunk);
-    hipLaunchKernelGGL(k_baumberg_stream<K>, dim3((n + chunk - 1) / chunk), dim3(64), 0, s, jobs, out, n, mask, chunk, maxIter, convTh,
-                       affInitialSigma);
+    const int nchunks = (n + chunk - 1) / chunk;
+    hipLaunchKernelGGL(k_baumberg_stream<K>, dim3(8 * ((nchunks + 7) / 8)), dim3(64), 0, s, jobs, out, n, mask, chunk, nchunks, maxIter,
+                       convTh, affInitialSigma);
   } else if (W == 19) hipLaunchKernelGGL(k_baumberg<19>, dim3(n), dim3(64), 0, s, jobs, out, n, mask, W, maxIter, convTh, affInitialSigma);
   else hipLaunchKernelGGL(k_baumberg<0>, dim3(n), dim3(64), 0, s, jobs, out, n, mask, W, maxIter, convTh, affInitialSigma);
 }

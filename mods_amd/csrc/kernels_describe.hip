@@ -32,10 +32,7 @@ MX_D int xcd_swizzle(int b, int n) {
 // (image, 64-px row band, x) on the host and XCD x takes the x-th CONTIGUOUS eighth of it (block b runs on XCD b % 8 and is
 // that XCD's (b / 8)-th block), so an XCD's L2 holds only its part of the images instead of all of them: without this every
 // L2 pulled its own copy of every image (FETCH_SIZE ~10x the image bytes).  The grid is 8 * ceil(n / 8) blocks.
-MX_D int xcd_chunk(int b, int n) {
-  const int per = (n + 7) >> 3;
-  return (b & 7) * per + (b >> 3);
-}
+// (xcd_chunk lives in kmath.hpp: the Baumberg and orientation kernels use it for their image-major job lists too)
 
 // tile -> job table: a per-workgroup binary search over the prefix array costs ~12 dependent L2 round trips,
 // longer than the useful work of a 256-element tile, so the prefix array is expanded once per launch set

@@ -18,7 +18,7 @@ constexpr int ORI_B = 21;          // taps of a patch row in flight per lane
 __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *out, int n, const ImgRef *imgs,
                                                     const unsigned short *maskIdx, const float *maskW,
                                                     const unsigned char *binTab, int doHalf, double th, int maxAngles) {
-  const int k = blockIdx.x;
+  const int k = xcd_chunk(blockIdx.x, n);   // regions are listed image by image: one part of the views per XCD's L2
   if (k >= n) return;
   const int lane = threadIdx.x;
   // 11 KB of LDS per region (14 regions resident per CU): the patch, later overwritten by the histogram weights, the
@@ -193,7 +193,7 @@ void launch_orientation(hipStream_t s, const OriJob *jobs, OriOut *out, int n, c
                           const unsigned short *maskIdx, const float *maskW, const unsigned char *binTab, int doHalf, double th,
                           int maxAngles) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_orientation, dim3(n), dim3(64), 0, s, jobs, out, n, imgs, maskIdx, maskW, binTab, doHalf, th,
+  hipLaunchKernelGGL(k_orientation, dim3(8 * ((n + 7) / 8)), dim3(64), 0, s, jobs, out, n, imgs, maskIdx, maskW, binTab, doHalf, th,
                      maxAngles);
 }
 

@@ -40,6 +40,13 @@ MX_D int find_job(const int *tile0, int nj, int t) {
   return j;
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));   // two f32 lanes of the packed ALU (v_pk_mul_f32 / v_pk_add_f32)
+
+// Vector issue is what the pipeline's concurrent streams compete for, so both filter passes run on the packed f32 ALU: two
+// outputs per instruction, each with the operand order and rounding of the scalar form (no contraction, IEEE mul and add).
+//   row pass     pairs the SAME column of two neighbouring ROWS: the input tile is parked row-pair interleaved
+//                (src2[pair][x] = {row 2 pair, row 2 pair + 1}), so a thread's register window is already made of pairs;
+//   column pass  pairs two neighbouring COLUMNS of the row-filtered tile (an aligned 8-byte LDS read per window element).
 template <int R, int TH>
 __global__ __launch_bounds__(256) void k_blur_hess(BlurBatch batch) {
   constexpr int BLR_H = TH + 4;
@@ -50,10 +57,11 @@ __global__ __launch_bounds__(256) void k_blur_hess(BlurBatch batch) {
   const int tx0 = (lt % ntx) * TW, ty0 = (lt / ntx) * TH;
   constexpr int n = 2 * R + 1;
   constexpr int sh = BLR_H + 2 * R, sw = TMP_W + 2 * R;
+  static_assert(sh % 2 == 0, "the input tile is parked as row pairs");
   // sized for this instantiation's halo: 25 KB (R = 4) .. 31.6 KB (R = 8), i.e. 6 workgroups per CU for the two
   // smallest kernels of an octave instead of 5 -- octave 0 of a batch of 8 images is 3072 workgroups, two full rounds
-  constexpr int SW = (sw + 3) & ~3;   // row stride, rows stay 16-byte aligned
-  __shared__ __attribute__((aligned(16))) float src[sh * SW];   // later reused as blr
+  constexpr int SW = (sw + 3) & ~3;   // pairs per pair-row: a pair-row is 2 SW floats, 16-byte aligned
+  __shared__ __attribute__((aligned(16))) float src[sh * SW];   // (sh / 2) pair-rows x SW pairs; later reused as blr
   __shared__ __attribute__((aligned(16))) float tmp[sh * TMP_W];
   float *blr = src;
   const int tid = threadIdx.x;
@@ -73,23 +81,21 @@ __global__ __launch_bounds__(256) void k_blur_hess(BlurBatch batch) {
 #pragma unroll
     for (int u = 0; u < PER; u++) {
       const int i = tid + 256 * u;
-      if (i < sh * sw) { const int ly = i / sw, lx = i - ly * sw; src[ly * SW + lx] = t[u]; }
+      if (i < sh * sw) { const int ly = i / sw, lx = i - ly * sw; src[(ly >> 1) * (2 * SW) + 2 * lx + (ly & 1)] = t[u]; }
     }
   }
   __syncthreads();
-  // stage 2: row filter, 4 outputs per thread
-  for (int i = tid; i < sh * (TMP_W / 4); i += 256) {
-    const int ly = i / (TMP_W / 4), g = i - ly * (TMP_W / 4);
-    const float *S = src + ly * SW + 4 * g;   // output x reads S[x .. x + 2R], centre S[x + R]
-    float w[4 + 2 * R];
+  // stage 2: row filter, 4 outputs of 2 rows per thread
+  for (int i = tid; i < (sh / 2) * (TMP_W / 4); i += 256) {
+    const int lp = i / (TMP_W / 4), g = i - lp * (TMP_W / 4);
+    const f2 *S = reinterpret_cast<const f2 *>(src) + lp * SW + 4 * g;   // output x reads S[x .. x + 2R], centre S[x + R]
+    f2 w[4 + 2 * R];
 #pragma unroll
-    for (int q = 0; q < (4 + 2 * R) / 4; q++) {
-      const float4 t = *reinterpret_cast<const float4 *>(S + 4 * q);
-      w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
+    for (int q = 0; q < (4 + 2 * R) / 2; q++) {
+      const float4 t = *reinterpret_cast<const float4 *>(S + 2 * q);
+      w[2 * q] = (f2){t.x, t.y}; w[2 * q + 1] = (f2){t.z, t.w};
     }
-#pragma unroll
-    for (int q = ((4 + 2 * R) / 4) * 4; q < 4 + 2 * R; q++) w[q] = S[q];
-    float v[4];
+    f2 v[4];
 #pragma unroll
     for (int o = 0; o < 4; o++) {
       if (n <= 5) {
@@ -97,27 +103,28 @@ __global__ __launch_bounds__(256) void k_blur_hess(BlurBatch batch) {
 #pragma unroll
         for (int j = 1; j <= R; j++) v[o] = v[o] + (w[o + R - j] + w[o + R + j]) * batch.k[R + j];
       } else {
-        v[o] = 0.f;
+        v[o] = (f2){0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < n; j++) v[o] = v[o] + w[o + j] * batch.k[j];
       }
     }
-    *reinterpret_cast<float4 *>(tmp + ly * TMP_W + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4 *>(tmp + (2 * lp) * TMP_W + 4 * g) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+    *reinterpret_cast<float4 *>(tmp + (2 * lp + 1) * TMP_W + 4 * g) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
   }
   __syncthreads();
-  // stage 3: column filter -> blurred tile with 1-px ring, 4 output rows per thread
-  for (int i = tid; i < (BLR_H / 4) * TMP_W; i += 256) {
-    const int gy = i / TMP_W, lx = i - gy * TMP_W;
+  // stage 3: column filter -> blurred tile with 1-px ring, 4 output rows of 2 columns per thread
+  for (int i = tid; i < (BLR_H / 4) * (TMP_W / 2); i += 256) {
+    const int gy = i / (TMP_W / 2), lx = 2 * (i - gy * (TMP_W / 2));
     const float *S = tmp + (4 * gy) * TMP_W + lx;   // output row y reads rows y .. y + 2R, centre y + R
-    float w[4 + 2 * R];
+    f2 w[4 + 2 * R];
 #pragma unroll
-    for (int q = 0; q < 4 + 2 * R; q++) w[q] = S[q * TMP_W];
+    for (int q = 0; q < 4 + 2 * R; q++) w[q] = *reinterpret_cast<const f2 *>(S + q * TMP_W);
 #pragma unroll
     for (int o = 0; o < 4; o++) {
-      float v = batch.k[R] * w[o + R] + 0.f;
+      f2 v = w[o + R] * batch.k[R] + (f2){0.f, 0.f};
 #pragma unroll
-      for (int j = 1; j <= R; j++) v = v + batch.k[R + j] * (w[o + R + j] + w[o + R - j]);
-      blr[(4 * gy + o) * TMP_W + lx] = v;
+      for (int j = 1; j <= R; j++) v = v + (w[o + R + j] + w[o + R - j]) * batch.k[R + j];
+      *reinterpret_cast<f2 *>(blr + (4 * gy + o) * TMP_W + lx) = v;
     }
   }
   __syncthreads();

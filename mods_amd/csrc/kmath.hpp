@@ -150,6 +150,17 @@ MX_HD gcfloat_p as_global(const float *p) { return (gcfloat_p)p; }
 // multiply, an add and a shift per tap, and the loads take the scalar base + vector offset form; the 64-bit
 // multiply-add per row pointer this replaces was a third of the instructions of a tap.  An image level is far below
 // 2^30 pixels (images are limited to 16384 px per side / 64 Mpx where they are created, capi.hip image_size_ok).
+
+// Workgroups are dispatched round-robin over the 8 XCDs (block b runs on XCD b % 8 and is that XCD's (b / 8)-th block), each
+// XCD with its own L2.  For a work list whose neighbours share input (jobs sorted by image, level, position): logical item
+// (b & 7) * ceil(n / 8) + (b >> 3), i.e. XCD x takes the x-th CONTIGUOUS eighth of the list and its L2 holds one part of the
+// images instead of all of them.  The grid is 8 * ceil(n / 8) blocks; results >= n have no work.  Placement only changes
+// speed: the mapping is a bijection whatever XCD a block really runs on.
+MX_D int xcd_chunk(int b, int n) {
+  const int per = (n + 7) >> 3;
+  return (b & 7) * per + (b >> 3);
+}
+
 template <class PT>
 MX_D float bilinear_blend(PT im, int cols, int x, int y, float WX, float WY) {
   const unsigned off = (__umul24((unsigned)y, (unsigned)cols) + (unsigned)x) << 2;

@@ -42,13 +42,13 @@ void hds_sym(const double *u, const double *H, double *p, int len, bool takeMax)
 struct Ransac {
   const double *u;
   int len;
-  std::vector<double> Z, Zrow, buffer, err;
+  std::vector<double> buffer, err;
   double *errs[5];
   HashTable ht;
   GlibcRandom rng;
   int errType = 0;   // the HDS1 the caller chose: 0 HDs (Sampson), 1 HDsSymMax, 2 HDsSym (matching.cpp:821-846)
   void errf(const double *h, double *d) {
-    if (errType == 0) HDs(Zrow.data(), u, h, d, len);
+    if (errType == 0) HDs(nullptr, u, h, d, len);
     else hds_sym(u, h, d, len, errType == 1);
   }
 
@@ -143,14 +143,8 @@ int ransac_h(const double *u, int len, double th, double conf, int max_sam, doub
   for (int i = 0; i < 9; i++) H[i] = 0;
   R.rng.seed(seed0);
   for (int i = 0; i < len; i++) pool[i] = i;
-  R.Z.resize((size_t)len * 18);
-  lin_hg(u, R.Z.data(), pool.data(), len);
-  R.Zrow.resize((size_t)len * 18);
-  for (int i = 0; i < len; i++)
-    for (int c = 0; c < 9; c++) {
-      R.Zrow[(size_t)18 * i + c] = R.Z[(size_t)c * 2 * len + 2 * i];
-      R.Zrow[(size_t)18 * i + 9 + c] = R.Z[(size_t)c * 2 * len + 2 * i + 1];
-    }
+  // the reference linearises all points once (lin_hg into Z) and reads Z for the samples and inside HDs; both re-form the few
+  // products they need from u instead -- the same values -- which saves building and streaming 144 bytes per point
   R.buffer.resize((size_t)len * 18);
   R.err.assign((size_t)len * 4, 0.0);
   std::vector<double> d_check(len);
@@ -164,7 +158,12 @@ int ransac_h(const double *u, int len, double th, double conf, int max_sam, doub
 
   auto score_of = [&](const double *dd) {
     Score s = {0, 0};
-    for (int j = 0; j < len; j++) { if (dd[j] <= th) s.I++; s.J += trunc_quad(dd[j], th); }
+    double term[256];
+    for (int j0 = 0; j0 < len; j0 += 256) {      // terms in a vectorisable loop, the f64 sum in point order
+      const int m = len - j0 < 256 ? len - j0 : 256;
+      for (int j = 0; j < m; j++) term[j] = trunc_quad(dd[j0 + j], th);
+      for (int j = 0; j < m; j++) { if (dd[j0 + j] <= th) s.I++; s.J += term[j]; }
+    }
     return s;
   };
   auto sym_bad = [&](const double *hh) {
@@ -200,12 +199,11 @@ int ransac_h(const double *u, int len, double th, double conf, int max_sam, doub
       int s = (int)(R.rng.next() % (len - i));
       int j = len - i - 1;
       int q = pool[s]; pool[s] = pool[j]; pool[j] = q;
-      const double *src = R.Z.data() + 2 * q;
+      const double *sq = u + 6 * q;     // the row pair of point q, lin_hg (Htools.c:17-47)
       double *p = M + i * 18;
-      for (int c = 0; c < 9; c++) {
-        p[c] = src[0];
-        p[9 + c] = src[1];
-        src += 2 * len;
+      for (int j = 0; j < 3; j++) {
+        p[3 * j] = sq[3 + j]; p[3 * j + 1] = 0; p[3 * j + 2] = -sq[0] * sq[3 + j];
+        p[9 + 3 * j] = 0; p[9 + 3 * j + 1] = sq[3 + j]; p[9 + 3 * j + 2] = -sq[1] * sq[3 + j];
       }
     }
     seed = (unsigned)R.rng.next();

@@ -49,11 +49,18 @@ static inline double trunc_quad(double epsilon, double thr) {
 }
 static inline bool score_less(const Score &a, const Score &b) { return a.J < b.J; }  // SC_M, rtools.c:238-250
 // rtools.c:160-171
+// The score is a running f64 sum in point order (kept); the terms are independent, so they are formed block-wise in a loop
+// the compiler vectorises (one division per point) and added afterwards.
 static inline Score inlidxs(const double *err, int len, double th, int *inl) {
   Score s = {0, 0};
-  for (int i = 0; i < len; ++i) {
-    s.J += trunc_quad(err[i], th);
-    if (err[i] <= th) { inl[s.I] = i; ++(s.I); }
+  double term[256];
+  for (int i0 = 0; i0 < len; i0 += 256) {
+    const int m = len - i0 < 256 ? len - i0 : 256;
+    for (int i = 0; i < m; ++i) term[i] = trunc_quad(err[i0 + i], th);
+    for (int i = 0; i < m; ++i) {
+      s.J += term[i];
+      if (err[i0 + i] <= th) { inl[s.I] = i0 + i; ++(s.I); }
+    }
   }
   return s;
 }
@@ -232,6 +239,24 @@ static inline void cov_mat(double *Cv, const double *Z, int len, int siz) {
     for (int j = 0; j <= i; j++) { Cv[siz * i + j] = acc[i][j]; Cv[i + siz * j] = acc[i][j]; }
 }
 
+// cov_mat for the 2len x 9 matrix lin_hgN builds: row 2i is zero in columns 1, 4, 7 and row 2i + 1 in columns 0, 3, 6 (exact
+// zeros by construction).  A product with such a zero is +-0 and adding +-0 to a running sum that starts at +0 never changes
+// it (x + -x is +0 in round-to-nearest), so those 24 of the 45 products per row are left out; every sum still takes its
+// remaining terms in row order.
+static inline void cov_mat_hgN(double *Cv, const double *Z, int npts) {
+  double acc[9][9];
+  for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) acc[i][j] = 0;
+  static const int nz0[6] = {0, 2, 3, 5, 6, 8}, nz1[6] = {1, 2, 4, 5, 7, 8};
+  for (int k = 0; k < npts; k++) {
+    const double *z = Z + (size_t)18 * k;
+    for (int a = 0; a < 6; a++) { const int i = nz0[a]; const double zi = z[i]; for (int b = 0; b <= a; b++) acc[i][nz0[b]] += zi * z[nz0[b]]; }
+    z += 9;
+    for (int a = 0; a < 6; a++) { const int i = nz1[a]; const double zi = z[i]; for (int b = 0; b <= a; b++) acc[i][nz1[b]] += zi * z[nz1[b]]; }
+  }
+  for (int i = 0; i < 9; i++)
+    for (int j = 0; j <= i; j++) { Cv[9 * i + j] = acc[i][j]; Cv[i + 9 * j] = acc[i][j]; }
+}
+
 // eigenvector of the smallest eigenvalue of a symmetric 9x9 (stands in for lap_eig = dsyev_, whose
 // first returned column is that vector: lapwrap.c:62-97, Htools.c:118-121)
 static inline void smallest_eigvec9(const double *C, double *v) {
@@ -308,20 +333,69 @@ static inline void u2h(const double *u, const int *inl, int len, double *H, doub
   double *Z = buffer;
   normu(u, inl, len, A1, A2);
   lin_hgN(u, Z, inl, len, A1, A2);
-  cov_mat(V, Z, 2 * len, 9);
+  cov_mat_hgN(V, Z, len);
   smallest_eigvec9(V, ev);
   memcpy(H, ev, 9 * sizeof(double));
   denormH(H, A1, A2);
 }
 
 // pinvJ + HDs (Sampson error), Htools.c:132-196
-// `lin` is the same linearisation as lin_hg() but stored row-major (18 doubles per point: the 9 entries of
-// row 2i, then of row 2i+1) -- identical products in identical order, contiguous in memory.
+// `lin` (the reference's argument: the linearisation lin_hg() builds from the same u) is not read: its entries are
+// re-formed from u -- identical products in identical order.
+// Four points per step on 256-bit vectors (two 128-bit halves without AVX): every lane runs the scalar expression of its own
+// point -- same operations, same order, IEEE add / mul / div, no contraction -- so the values are those of the scalar loop.
+typedef double hds_v4 __attribute__((vector_size(32)));
+static inline hds_v4 hds_ld4(const double *p, size_t stride) { return (hds_v4){p[0], p[stride], p[2 * stride], p[3 * stride]}; }
 static inline void HDs(const double *lin, const double *u, const double *H, double *p, int len) {
-  for (int i = 0; i < len; i++) {
+  (void)lin;
+  int i = 0;
+  for (; i + 4 <= len; i += 4) {
+    const double *uu = u + (size_t)6 * i;
+    const hds_v4 u0 = hds_ld4(uu, 6), u1 = hds_ld4(uu + 1, 6), u3 = hds_ld4(uu + 3, 6), u4 = hds_ld4(uu + 4, 6), u5 = hds_ld4(uu + 5, 6);
+    // the linearisation of the point (lin_hg: x'_j, 0, -x x'_j / 0, x'_j, -y x'_j) is re-formed from u -- the same products,
+    // rounded the same way -- instead of being streamed from the 144-byte row of `lin` (the loop is memory-bound otherwise)
+    const hds_v4 zero = {0, 0, 0, 0};
+    const hds_v4 xs[3] = {u3, u4, u5};
+    hds_v4 r1 = zero, r2 = zero;
+    for (int j = 0; j < 3; j++) {
+      r1 += H[3 * j] * xs[j]; r1 += H[3 * j + 1] * zero; r1 += H[3 * j + 2] * (-u0 * xs[j]);
+      r2 += H[3 * j] * zero; r2 += H[3 * j + 1] * xs[j]; r2 += H[3 * j + 2] * (-u1 * xs[j]);
+    }
+    const hds_v4 a = H[0] - H[2] * u0;
+    const hds_v4 b = H[3] - H[5] * u0;
+    const hds_v4 c = -H[8] - H[2] * u3 - H[5] * u4;
+    const hds_v4 d = H[1] - H[2] * u1;
+    const hds_v4 e = H[4] - H[5] * u1;
+    hds_v4 pJ[8];
+    {
+      const hds_v4 a2 = a * a, b2 = b * b, c2 = c * c, d2 = d * d, e2 = e * e;
+      const hds_v4 c2pd2 = c2 + d2, ab = a * b, de = d * e;
+      const hds_v4 Q = c * (c2pd2 + e2);
+      pJ[0] = -b * de + a * (c2 + e2);
+      pJ[1] = b * c2pd2 - a * de;
+      pJ[2] = Q;
+      pJ[3] = -c * (a * d + b * e);
+      pJ[4] = d * (b2 + c2) - ab * e;
+      pJ[5] = -ab * d + e * (a2 + c2);
+      pJ[6] = pJ[3];
+      pJ[7] = c * (a2 + b2 + c2);
+      const hds_v4 N = a * pJ[0] + b * pJ[1] + c * pJ[2];
+      for (int q = 0; q < 8; q++) pJ[q] /= N;
+    }
+    hds_v4 acc = {0, 0, 0, 0};
+    for (int j = 0; j < 4; j++) {
+      const hds_v4 t = pJ[j] * r1 + pJ[j + 4] * r2;
+      acc += t * t;
+    }
+    p[i] = acc[0]; p[i + 1] = acc[1]; p[i + 2] = acc[2]; p[i + 3] = acc[3];
+  }
+  u += (size_t)6 * i; p += i;
+  for (; i < len; i++) {
     double r1 = 0, r2 = 0;
-    const double *l = lin + (size_t)18 * i;
-    for (int j = 0; j < 9; j++) { r1 += H[j] * l[j]; r2 += H[j] * l[9 + j]; }
+    for (int j = 0; j < 3; j++) {
+      r1 += H[3 * j] * u[3 + j]; r1 += H[3 * j + 1] * 0.0; r1 += H[3 * j + 2] * (-u[0] * u[3 + j]);
+      r2 += H[3 * j] * 0.0; r2 += H[3 * j + 1] * u[3 + j]; r2 += H[3 * j + 2] * (-u[1] * u[3 + j]);
+    }
     double a = H[0] - H[2] * u[0];
     double b = H[3] - H[5] * u[0];
     double c = -H[8] - H[2] * u[3] - H[5] * u[4];
