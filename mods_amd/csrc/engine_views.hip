@@ -463,7 +463,10 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
   struct Guard { std::atomic<int> &a; ~Guard() { a.fetch_sub(1); } } guard{active};
   const bool alone = active.fetch_add(1) == 0;
   int cur = 0, step = 0;
+  auto tnowL = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const bool timL = getenv("MODSX_HOST_TIMING") != nullptr;
   for (; step < nsteps && cur < min_matches; step++) {
+    const double tL0 = tnowL();
     LadderClass &k = cls[steps[step].detector == MODSX_DET_MSER ? 1 : 0];
     modsx_pair_params ps = pp;
     ps.detector = steps[step].detector == MODSX_DET_MSER ? MODSX_DET_MSER : MODSX_DET_HESSIAN;
@@ -499,6 +502,7 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
       }
       if (rc0 || rc1) { release_result_arrays(res); return rc0 ? rc0 : rc1; }
     }
+    const double tL1 = tnowL();
     // Tentatives.MatchImgReps (correspondencebank.cpp:291-345): clear and re-match the class of this step
     const double ratio = steps[step].match_ratio > 0 ? steps[step].match_ratio : pp.match_ratio;
     {
@@ -510,6 +514,7 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
                                  pos2.data(), ratio, pp.contradDist, pp.nn, k.tents);
       if (rc) { release_result_arrays(res); return rc; }
     }
+    const double tL2 = tnowL();
     // GetCorresponcesVector(): HessianAffine tentatives, then MSER; indices re-based onto the concatenated lists
     std::vector<modsx_region> all[2];
     std::vector<modsx_tentative> tents;
@@ -535,9 +540,11 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
     }
     // a sharded single-step call may leave verification to the owner rank; a sharded ladder verifies on every rank (same
     // tentatives, same seed => same count), which is how the ranks agree on the early exit without a collective
+    const double tL3 = tnowL();
     res->n_tentatives = (int)tents.size();
     if (!cm || owner < 0 || owner == comm_rank(cm)) verify_tentatives(all[0], all[1], tents, pp, res);
     cur = res->n_verified;
+    if (timL) fprintf(stderr, "ladder step %d: views %.2f match %.2f lists %.2f verify %.2f ms\n", step, tL1 - tL0, tL2 - tL1, tL3 - tL2, tnowL() - tL3);
   }
   if (steps_done) *steps_done = step;
   prof_collect(c);

@@ -158,6 +158,69 @@ __global__ __launch_bounds__(256) void k_views_blur(const ViewJob *jobs, int n, 
             (t / tx) * 4 + (threadIdx.x >> 6));
 }
 
+// the two filter passes of k_views_rotblur over its LDS tiles; N = compile-time tap count (0: runtime nx / ny)
+template <int N>
+MX_D void vf_rows(const float *Wt, float *Tt, const float *kxT, int WW, int Rx, int lane, int ty, int xOut, int yEnd, int nxRt) {
+  constexpr int NK = N ? N : 1;
+  float k[NK];
+#pragma unroll
+  for (int q = 0; q < NK; q++) k[q] = N ? kxT[q] : 0.f;
+  for (int ly = ty; ly < yEnd; ly += 4) {
+    const float *row = Wt + ly * WW + Rx;
+    for (int lx = lane; lx < xOut; lx += 64) {
+      float r;
+      if (N == 1) r = row[lx];
+      else if (N == 3 || N == 5) {
+        constexpr int R = N >> 1;
+        r = row[lx] * k[R];
+#pragma unroll
+        for (int q = 1; q <= R; q++) r = r + (row[lx - q] + row[lx + q]) * k[R + q];
+      } else if (N > 5) {
+        constexpr int R = N >> 1;
+        r = 0.f;
+#pragma unroll
+        for (int q = 0; q < N; q++) r = r + row[lx + q - R] * k[q];
+      } else {
+        const int nx = nxRt;
+        if (nx <= 5) {
+          r = row[lx] * kxT[Rx];
+          for (int q = 1; q <= Rx; q++) r = r + (row[lx - q] + row[lx + q]) * kxT[Rx + q];
+        } else {
+          r = 0.f;
+          for (int q = 0; q < nx; q++) r = r + row[lx + q - Rx] * kxT[q];
+        }
+      }
+      Tt[ly * VF_TW + lx] = r;
+    }
+  }
+}
+template <int N>
+MX_D void vf_cols(const float *Tt, float *outBase, const float *kyT, int rcols, int Ry, int lane, int ty, int xOut, int yOut, int nyRt) {
+  constexpr int NK = N ? N : 1;
+  float k[NK];
+#pragma unroll
+  for (int q = 0; q < NK; q++) k[q] = N ? kyT[q] : 0.f;
+  for (int ly = ty; ly < yOut; ly += 4) {
+    const float *col = Tt + (ly + Ry) * VF_TW;
+    float *out = outBase + (size_t)ly * rcols;
+    for (int lx = lane; lx < xOut; lx += 64) {
+      float r;
+      if (N == 1) r = col[lx];
+      else if (N > 1) {
+        constexpr int R = N >> 1;
+        r = k[R] * col[lx] + 0.f;
+#pragma unroll
+        for (int q = 1; q <= R; q++) r = r + k[R + q] * (col[lx + q * VF_TW] + col[lx - q * VF_TW]);
+      } else {
+        (void)nyRt;
+        r = kyT[Ry] * col[lx] + 0.f;
+        for (int q = 1; q <= Ry; q++) r = r + kyT[Ry + q] * (col[lx + q * VF_TW] + col[lx - q * VF_TW]);
+      }
+      out[lx] = r;
+    }
+  }
+}
+
 // Rotate + anti-alias blur of a view in ONE launch.  The three-launch form writes the rotated image, reads it for the row
 // filter, writes the row-filtered image, reads it for the column filter and writes the result over the rotated image: four
 // passes over 1-2 Mpx per view, 16-31 views per image, in kernels that wait on memory.  Here a workgroup owns a
@@ -195,34 +258,25 @@ __global__ __launch_bounds__(256) void k_views_rotblur(const ViewJob *jobs, int 
   __syncthreads();
   const float *kxT = taps + v.tapOfs, *kyT = kxT + v.kx;
   const int nx = v.kx, ny = v.ky, xOut = xEnd - 2 * Rx, yOut = yEnd - 2 * Ry;
-  for (int ly = ty; ly < yEnd; ly += 4) {
-    const float *row = Wt + ly * WW + Rx;
-    for (int lx = lane; lx < xOut; lx += 64) {
-      float r;
-      if (nx == 1) r = row[lx];
-      else if (nx <= 5) {
-        r = row[lx] * kxT[Rx];
-        for (int q = 1; q <= Rx; q++) r = r + (row[lx - q] + row[lx + q]) * kxT[Rx + q];
-      } else {
-        r = 0.f;
-        for (int q = 0; q < nx; q++) r = r + row[lx + q - Rx] * kxT[q];
-      }
-      Tt[ly * VF_TW + lx] = r;
-    }
+  // The filter sizes of a view are wave-uniform and small (3 .. 13 taps for every default view): one switch per pass picks a
+  // fully unrolled body with the taps in registers; other sizes take the runtime loop.  Terms and order are blur_body's.
+  switch (nx) {
+    case 1: vf_rows<1>(Wt, Tt, kxT, WW, Rx, lane, ty, xOut, yEnd, nx); break;
+    case 3: vf_rows<3>(Wt, Tt, kxT, WW, Rx, lane, ty, xOut, yEnd, nx); break;
+    case 5: vf_rows<5>(Wt, Tt, kxT, WW, Rx, lane, ty, xOut, yEnd, nx); break;
+    case 7: vf_rows<7>(Wt, Tt, kxT, WW, Rx, lane, ty, xOut, yEnd, nx); break;
+    case 9: vf_rows<9>(Wt, Tt, kxT, WW, Rx, lane, ty, xOut, yEnd, nx); break;
+    case 11: vf_rows<11>(Wt, Tt, kxT, WW, Rx, lane, ty, xOut, yEnd, nx); break;
+    case 13: vf_rows<13>(Wt, Tt, kxT, WW, Rx, lane, ty, xOut, yEnd, nx); break;
+    default: vf_rows<0>(Wt, Tt, kxT, WW, Rx, lane, ty, xOut, yEnd, nx); break;
   }
   __syncthreads();
-  for (int ly = ty; ly < yOut; ly += 4) {
-    const float *col = Tt + (ly + Ry) * VF_TW;
-    float *out = v.rot + (size_t)(y0 + ly) * v.rcols + x0;
-    for (int lx = lane; lx < xOut; lx += 64) {
-      float r;
-      if (ny == 1) r = col[lx];
-      else {
-        r = kyT[Ry] * col[lx] + 0.f;
-        for (int q = 1; q <= Ry; q++) r = r + kyT[Ry + q] * (col[lx + q * VF_TW] + col[lx - q * VF_TW]);
-      }
-      out[lx] = r;
-    }
+  float *const outBase = v.rot + (size_t)y0 * v.rcols + x0;
+  switch (ny) {
+    case 1: vf_cols<1>(Tt, outBase, kyT, v.rcols, Ry, lane, ty, xOut, yOut, ny); break;
+    case 3: vf_cols<3>(Tt, outBase, kyT, v.rcols, Ry, lane, ty, xOut, yOut, ny); break;
+    case 5: vf_cols<5>(Tt, outBase, kyT, v.rcols, Ry, lane, ty, xOut, yOut, ny); break;
+    default: vf_cols<0>(Tt, outBase, kyT, v.rcols, Ry, lane, ty, xOut, yOut, ny); break;
   }
 }
 
