@@ -1,8 +1,9 @@
 #!/bin/bash
-# Regenerates the round-2 files of profiles/ on the GPU box (run through gpurun; output lands in gpurun_out/profiles, copy
+# Regenerates the files of one round (ROUND_TAG, default r03) of profiles/ on the GPU box (run through gpurun; output lands in gpurun_out/profiles, copy
 # what is to be judged into profiles/).  Kernel-trace summaries and counter passes are separate rocprofv3 runs; counter
 # passes use --kernel-trace only.
 R=$GRAFT_REPO_ROOT
+TAG=${ROUND_TAG:-r03}
 OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -16,33 +17,33 @@ run() { # tag, rocprof args..., -- command
 }
 # 1. the default bench (31 views, 16 streams): durations include time-slicing between the streams
 DB=$(run def --kernel-trace --stats -d /tmp/rp_def -o p -- python $R/bench.py --no-cpu-baseline --no-extra)
-python $R/tools/rocprof_summary.py $DB $OUT/r02_kernel_stats_default.txt "python bench.py --no-cpu-baseline --no-extra  (default workload: 31 views per image, 16 workers x 16 pairs/step; kernels of the 16 streams overlap, durations include time-slicing)" > /dev/null
+python $R/tools/rocprof_summary.py $DB $OUT/${TAG}_kernel_stats_default.txt "python bench.py --no-cpu-baseline --no-extra  (default workload: 31 views per image, 16 workers x 16 pairs/step; kernels of the 16 streams overlap, durations include time-slicing)" > /dev/null
 # 2. one stream, same workload: the durations the roofline objects of bench.py are compared with
 DB=$(run one --kernel-trace --stats -d /tmp/rp_one -o p -- python $R/bench.py $ONE)
-python $R/tools/rocprof_summary.py $DB $OUT/r02_kernel_stats_single_stream.txt "python bench.py $ONE  (31 views per image, one stream)" > /dev/null
+python $R/tools/rocprof_summary.py $DB $OUT/${TAG}_kernel_stats_single_stream.txt "python bench.py $ONE  (31 views per image, one stream)" > /dev/null
 DB=$(run one1 --kernel-trace --stats -d /tmp/rp_one1 -o p -- python $R/bench.py $ONE1)
-python $R/tools/rocprof_summary.py $DB $OUT/r02_kernel_stats_views1_single_stream.txt "python bench.py $ONE1  (configs[1]: 1 view, one stream, 4 pairs per launch set -- comparable with r01_kernel_stats_single_stream.txt)" > /dev/null
+python $R/tools/rocprof_summary.py $DB $OUT/${TAG}_kernel_stats_views1_single_stream.txt "python bench.py $ONE1  (configs[1]: 1 view, one stream, 4 pairs per launch set -- comparable with r01_kernel_stats_single_stream.txt)" > /dev/null
 # 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes
 DBF=$(run fetch --kernel-trace --pmc FETCH_SIZE -d /tmp/rp_fetch -o p -- python $R/bench.py $ONE)
 DBW=$(run write --kernel-trace --pmc WRITE_SIZE -d /tmp/rp_write -o p -- python $R/bench.py $ONE)
-python $R/tools/pmc_summary.py $DBF $DBW $OUT/r02_pmc_hbm.txt "python bench.py $ONE (31 views, one stream)" > /dev/null
+python $R/tools/pmc_summary.py $DBF $DBW $OUT/${TAG}_pmc_hbm.txt "python bench.py $ONE (31 views, one stream)" > /dev/null
 DBF=$(run fetch1 --kernel-trace --pmc FETCH_SIZE -d /tmp/rp_fetch1 -o p -- python $R/bench.py $ONE1)
 DBW=$(run write1 --kernel-trace --pmc WRITE_SIZE -d /tmp/rp_write1 -o p -- python $R/bench.py $ONE1)
-python $R/tools/pmc_summary.py $DBF $DBW $OUT/r02_pmc_hbm_views1.txt "python bench.py $ONE1 (configs[1], one stream, 4 pairs per launch set: comparable with r01_pmc_hbm.txt)" > /dev/null
+python $R/tools/pmc_summary.py $DBF $DBW $OUT/${TAG}_pmc_hbm_views1.txt "python bench.py $ONE1 (configs[1], one stream, 4 pairs per launch set: comparable with r01_pmc_hbm.txt)" > /dev/null
 # 4. SQ counters
 DBS=$(run sq --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/rp_sq -o p -- python $R/bench.py $ONE)
-python $R/tools/pmc_counters.py $DBS $OUT/r02_pmc_sq.txt "python bench.py $ONE (31 views, one stream); GRBM_GUI_ACTIVE is summed over the 8 XCDs" > /dev/null
+python $R/tools/pmc_counters.py $DBS $OUT/${TAG}_pmc_sq.txt "python bench.py $ONE (31 views, one stream); GRBM_GUI_ACTIVE is summed over the 8 XCDs" > /dev/null
 # 5. the matcher alone on real descriptors: 8 views (10 k x 10 k), 8 views doubled (20 k x 20 k), 31 views (24 k x 24 k), doubled (48 k)
 for spec in "m10k:" "m20k:--rep 2" "m24k:--tilts 1,2,4,6,8 --phi 120" "m48k:--tilts 1,2,4,6,8 --phi 120 --rep 2"; do
   tag=${spec%%:*}; a=${spec#*:}
   DB=$(run $tag --kernel-trace --stats -d /tmp/rp_$tag -o p -- python $R/tools/bench_match.py $a --reps 10)
-  python $R/tools/rocprof_summary.py $DB $OUT/r02_match_$tag.txt "python tools/bench_match.py $a --reps 10   $(tail -1 /tmp/rp_$tag.log | cut -c1-220)" > /dev/null
+  python $R/tools/rocprof_summary.py $DB $OUT/${TAG}_match_$tag.txt "python tools/bench_match.py $a --reps 10   $(tail -1 /tmp/rp_$tag.log | cut -c1-220)" > /dev/null
 done
 DBM=$(run msq --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d /tmp/rp_msq -o p -- python $R/tools/bench_match.py --tilts 1,2,4,6,8 --phi 120 --reps 3)
-python $R/tools/pmc_counters.py $DBM $OUT/r02_match_pmc_sq.txt "python tools/bench_match.py --tilts 1,2,4,6,8 --phi 120 --reps 3 (24 k x 24 k real descriptors)" > /dev/null
+python $R/tools/pmc_counters.py $DBM $OUT/${TAG}_match_pmc_sq.txt "python tools/bench_match.py --tilts 1,2,4,6,8 --phi 120 --reps 3 (24 k x 24 k real descriptors)" > /dev/null
 DBF=$(run mf --kernel-trace --pmc FETCH_SIZE -d /tmp/rp_mf -o p -- python $R/tools/bench_match.py --tilts 1,2,4,6,8 --phi 120 --reps 3)
 DBW=$(run mw --kernel-trace --pmc WRITE_SIZE -d /tmp/rp_mw -o p -- python $R/tools/bench_match.py --tilts 1,2,4,6,8 --phi 120 --reps 3)
-python $R/tools/pmc_summary.py $DBF $DBW $OUT/r02_match_pmc_hbm.txt "python tools/bench_match.py --tilts 1,2,4,6,8 --phi 120 --reps 3 (24 k x 24 k real descriptors)" > /dev/null
+python $R/tools/pmc_summary.py $DBF $DBW $OUT/${TAG}_match_pmc_hbm.txt "python tools/bench_match.py --tilts 1,2,4,6,8 --phi 120 --reps 3 (24 k x 24 k real descriptors)" > /dev/null
 python - <<PY
 import json, re
 def table(path):
@@ -54,9 +55,12 @@ def table(path):
             k = re.sub(r"<.*", "", p[0].replace("void ", "").strip())
             rows[k] = max(rows.get(k, 0), int(float(p[3]) + float(p[4])))   # fetch x2 + write; templates: the largest instantiation
     return rows
-t = table("$OUT/r02_pmc_hbm.txt")
-m = table("$OUT/r02_match_pmc_hbm.txt")
+t = table("$OUT/${TAG}_pmc_hbm.txt")
+m = table("$OUT/${TAG}_match_pmc_hbm.txt")
 t["k_match_total_views31"] = sum(v for k, v in m.items() if k.startswith("k_match_"))
-json.dump(dict(sorted(t.items())), open("$OUT/pmc_traffic_r02.json", "w"), indent=1)
+hdr = open("$OUT/${TAG}_match_m24k.txt").read()
+mm = re.search(r"N=(\d+) M=(\d+)", hdr)
+t["k_match_problem"] = ("%s x %s real 31-view descriptors (tools/bench_match.py --tilts 1,2,4,6,8 --phi 120)" % (mm.group(1), mm.group(2))) if mm else "24 k x 24 k real 31-view descriptors"
+json.dump(dict(sorted(t.items())), open("$OUT/pmc_traffic_${TAG}.json", "w"), indent=1)
 PY
 ls -la $OUT
