@@ -81,6 +81,35 @@ struct MatchGeom {
   int n1, n2, S, tilesPerSplit;
 };
 
+// Sweep 2 runs over the UNDECIDED queries only, whose number the host does not know at launch time.  With sweep 1's splits it
+// would be a handful of query blocks x S long splits -- a sixth of the machine busy for as long as a whole sweep 1 workgroup
+// takes (41 us of the 165 at 24 k x 24 k, where 15 % of the queries are undecided).  Every workgroup therefore derives the
+// split geometry from the device-side count: the NW workgroups of the launch are dealt out as (query block, split) with as
+// many splits as fill the machine once.  k_match_events uses the same function.
+constexpr int SWEEP2_NW = 256 * SWEEP_WPS;    // one round of workgroups
+struct Sweep2Geom { int nQB, S, tilesPerSplit; };
+MX_HD Sweep2Geom sweep2_geom(int nUnd, int n2) {
+  Sweep2Geom G;
+  const int ntiles = (n2 + 31) >> 5;
+  G.nQB = (nUnd + QPB - 1) / QPB;
+  int S = G.nQB > 0 ? SWEEP2_NW / G.nQB : 1;
+  if (S > ntiles / CHUNK) S = ntiles / CHUNK;     // at least one index chunk per split
+  if (S < 1) S = 1;
+  int tps = (ntiles + S - 1) / S;
+  tps = ((tps + CHUNK - 1) / CHUNK) * CHUNK;
+  S = (ntiles + tps - 1) / tps;
+  G.S = S < 1 ? 1 : S;
+  G.tilesPerSplit = tps;
+  return G;
+}
+// entries of the per-(undecided query, split) arrays of sweep 2, whatever the count turns out to be
+static size_t sweep2_entries(int n1, int n2) {
+  const int ntiles = (n2 + 31) >> 5;
+  const size_t smax = (size_t)std::max(1, ntiles / CHUNK);
+  const size_t a = std::max<size_t>((size_t)n1, (size_t)SWEEP2_NW * QPB);   // nQB * S <= NW while S > 1; S = 1 beyond
+  return std::min(a, (size_t)n1 * smax) + QPB;
+}
+
 // register r of the 32x32 accumulator of lane half `hi` holds MFMA row 8 (r >> 2) + 4 hi + (r & 3)
 MX_D int row_of(int r, int hi) { return 8 * (r >> 2) + 4 * hi + (r & 3); }
 
@@ -243,10 +272,16 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &A) {
   const MatchGeom g = A.g;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 31, hi = lane >> 5;
-  const int sp = blockIdx.y;
   const int nQ = MODE == 0 ? g.n1 : *A.nUndecided;
-  if ((int)blockIdx.x * QPB >= nQ) return;
-  const int q0 = blockIdx.x * QPB + wave * (32 * QSETS);
+  int sp, qb, S, tilesPerSplit;
+  if (MODE == 0) { sp = blockIdx.y; qb = blockIdx.x; S = g.S; tilesPerSplit = g.tilesPerSplit; }
+  else {
+    const Sweep2Geom G2 = sweep2_geom(nQ, g.n2);
+    S = G2.S; tilesPerSplit = G2.tilesPerSplit;
+    qb = (int)blockIdx.x / S; sp = (int)blockIdx.x - qb * S;
+  }
+  if (qb * QPB >= nQ) return;
+  const int q0 = qb * QPB + wave * (32 * QSETS);
   v4i bq[QSETS][4];
   int mA[QSETS], mB[QSETS], iA[QSETS], iB[QSETS];   // MODE 0: m1, m2, i1, i2;  MODE 1: mj, threshold key, ij, event count
   int qsel[QSETS];
@@ -261,7 +296,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &A) {
     else { mB[s] = (A.dmin[qsel[s]] - A.norm1[qsel[s]]) << 8; iB[s] = 0; }   // d < Dmin  <=>  key < (Dmin - |a'|^2) << 8
   }
   const int ntiles4 = (((g.n2 + 31) >> 5) + TPS - 1) & ~(TPS - 1);
-  const int tBeg = sp * g.tilesPerSplit, tEnd = min(tBeg + g.tilesPerSplit, ntiles4);
+  const int tBeg = sp * tilesPerSplit, tEnd = min(tBeg + tilesPerSplit, ntiles4);
   auto flush = [&](int chunkTile0) {
 #pragma unroll
     for (int s = 0; s < QSETS; s++) {
@@ -291,7 +326,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &A) {
       // a train of this group is closer than Dmin: k_match_events takes the whole group (its other rows included)
       const int u = q0 + 32 * s + col;
       if (u < nQ) {
-        if (iB[s] < EVCAP) A.ev[(((size_t)u * g.S + sp) * 2 + hi) * EVCAP + iB[s]] = tile;
+        if (iB[s] < EVCAP) A.ev[(((size_t)u * S + sp) * 2 + hi) * EVCAP + iB[s]] = tile;
         iB[s]++;
       }
     } else mA[s] = min(mA[s], t);
@@ -379,14 +414,14 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &A) {
         if (lex_less(od1, oj1, d0, j0)) { dd1 = od1; j1 = oj1; } else { dd1 = d0; j1 = j0; }
         d0 = od0; j0 = oj0;
       } else if (lex_less(od0, oj0, dd1, j1)) { dd1 = od0; j1 = oj0; }
-      if (hi == 0 && q < nQ) A.partial[(size_t)q * g.S + sp] = make_int4(d0, j0, dd1, j1);
+      if (hi == 0 && q < nQ) A.partial[(size_t)q * S + sp] = make_int4(d0, j0, dd1, j1);
     } else {
       int dj = iA[s] < 0 ? BIG : (mA[s] >> 8) + na, tj = iA[s] < 0 ? BIG : iA[s];
       const int od = __shfl_xor(dj, 32), ot = __shfl_xor(tj, 32);
       if (lex_less(od, ot, dj, tj)) { dj = od; tj = ot; }
       if (q < nQ) {
-        A.evCnt[((size_t)q * g.S + sp) * 2 + hi] = iB[s];
-        if (hi == 0) A.partial2[(size_t)q * g.S + sp] = make_int2(dj, tj);
+        A.evCnt[((size_t)q * S + sp) * 2 + hi] = iB[s];
+        if (hi == 0) A.partial2[(size_t)q * S + sp] = make_int2(dj, tj);
       }
     }
   }
@@ -475,9 +510,12 @@ __device__ __forceinline__ void events_body(const uint8_t *d1, const int *norm1,
   __shared__ int sRec[4][64];           // per wave: the event groups of its query as (tile << 1 | lane half)
   const int w = threadIdx.x >> 6;
   const int u = blockIdx.x * 4 + w;
-  if (u >= *nUndecided) return;
+  const int nUnd = *nUndecided;
+  if (u >= nUnd) return;
   const int lane = threadIdx.x & 63, l = lane & 15, sub = lane >> 4;
-  const int nst = 2 * g.S;
+  const Sweep2Geom G2 = sweep2_geom(nUnd, g.n2);      // the splits sweep 2 chose for this count
+  const int S2 = G2.S;
+  const int nst = 2 * S2;
   // Every event group holds at least one train below Dmin and at most one of all those trains is NN0, so nn or more
   // groups mean nless > nn - 2: the walk gives up (matching.cpp:435-457) and nothing has to be recomputed.  (Look-alike
   // regions -- a thousand similar blobs -- produce exactly this, and would otherwise dominate the kernel.)
@@ -489,8 +527,8 @@ __device__ __forceinline__ void events_body(const uint8_t *d1, const int *norm1,
   // the last step of the walk for this query: NNj = the lex-smallest of the event groups' candidate and the splits' minima of
   // sweep 2, then the row gets tj / dj / nless / nbad (this used to be a launch of its own)
   auto finish = [&](int nlessF, int nbadF, int djF, int tjF) {
-    for (int sp = lane; sp < g.S; sp += 64) {
-      const int2 p = partial2[(size_t)u * g.S + sp];
+    for (int sp = lane; sp < S2; sp += 64) {
+      const int2 p = partial2[(size_t)u * S2 + sp];
       if (lex_less(p.x, p.y, djF, tjF)) { djF = p.x; tjF = p.y; }
     }
 #pragma unroll
@@ -551,7 +589,7 @@ __device__ __forceinline__ void events_body(const uint8_t *d1, const int *norm1,
   if (anyOver) {
     for (int st = 0; st < nst; st++) {
       if (evCnt[(size_t)u * nst + st] <= EVCAP) continue;
-      const int tb = (st >> 1) * g.tilesPerSplit, te = min(tb + g.tilesPerSplit, (g.n2 + 31) >> 5);
+      const int tb = (st >> 1) * G2.tilesPerSplit, te = min(tb + G2.tilesPerSplit, (g.n2 + 31) >> 5);
       for (int tile = tb; tile < te; tile += 4) visit_group(tile + sub, st & 1, tile + sub < te);
     }
   }
@@ -591,11 +629,12 @@ static MatchLayout match_layout(int n1, int n2) {
   L.cst = take((size_t)L.slots * 4);
   L.tiles = take((size_t)L.slots * 128);
   L.partial = take((size_t)n1 * S * 16);
-  L.partial2 = take((size_t)n1 * S * 8);
+  const size_t e2 = sweep2_entries(n1, n2);
+  L.partial2 = take(e2 * 8);
   L.dmin = take((size_t)n1 * 4);
   L.undecided = take((size_t)n1 * 4);
-  L.evCnt = take((size_t)n1 * S * 2 * 4);
-  L.ev = take((size_t)n1 * S * 2 * EVCAP * 4);
+  L.evCnt = take(e2 * 2 * 4);
+  L.ev = take(e2 * 2 * EVCAP * 4);
   L.evRes = take((size_t)n1 * 16);
   L.counter = take(64);
   L.bytes = w;
@@ -636,7 +675,6 @@ __global__ __launch_bounds__(1024) void k_match_decide(MatchBatch b, double sqmi
 }
 __global__ __launch_bounds__(256, SWEEP_WPS) void k_match_sweep2(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
-  if ((int)blockIdx.x * QPB >= P.g.n1 || (int)blockIdx.y >= P.g.S) return;
   SweepArgs A;
   A.d1 = P.d1; A.norm1 = P.norm1; A.tiles = P.tiles; A.cst = P.cst; A.g = P.g;
   A.dmin = P.dmin; A.undecided = P.undecided; A.nUndecided = P.counter; A.partial2 = P.partial2; A.evCnt = P.evCnt; A.ev = P.ev;
@@ -676,7 +714,9 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
   const dim3 grid((maxN1 + QPB - 1) / QPB, maxS, nb);
   hipLaunchKernelGGL(k_match_sweep1, grid, dim3(256), 0, s, b);
   hipLaunchKernelGGL(k_match_decide, dim3((maxN1 + DECIDE_Q - 1) / DECIDE_Q, 1, nb), dim3(1024), 0, s, b, sqminratio, contrDistSq);
-  hipLaunchKernelGGL(k_match_sweep2, grid, dim3(256), 0, s, b);
+  // sweep 2: one round of workgroups dealt out on the device as (undecided block, split); more only if there could be more
+  // undecided query blocks than that
+  hipLaunchKernelGGL(k_match_sweep2, dim3(std::max(SWEEP2_NW, (maxN1 + QPB - 1) / QPB), 1, nb), dim3(256), 0, s, b);
   hipLaunchKernelGGL(k_match_events, dim3((maxN1 + 3) / 4, 1, nb), dim3(256), 0, s, b, contrDistSq, nn);
 }
 
