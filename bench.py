@@ -608,6 +608,18 @@ def main():
                                                         "descriptors_per_s": nd / el, "blobs_per_1024x768": 4000}
                 for a_, b_ in d4:
                     a_.free(); b_.free()
+                # configs[2] with a scene dense enough that the per-view costs (synthesis, pyramid) are amortised over more regions:
+                # 8 views, 16000 blobs per 1024x768 -- the configuration in which the path delivers its most descriptors per second
+                h8, d8 = make_images(12345, args.distinct, int(16000 * args.rows * args.cols / (768.0 * 1024)))
+                tl, ph, _ = CONFIGS["views8"]
+                vw = mods_amd.set_vs_pars([1.0], [float(t) for t in tl.split(",")], ph, args.init_sigma, 1, [])
+                i1 = [d8[i % len(d8)][0] for i in range(64)]
+                i2 = [d8[i % len(d8)][1] for i in range(64)]
+                el, nd, _ = timed(lambda: run_batch(vw, False, i1, i2), 1, 3)
+                extra["views8_16000_blobs"] = {"views": len(vw), "pairs_per_s": 3 * 64 / el, "descriptors_per_pair": nd / (3 * 64),
+                                               "descriptors_per_s": nd / el, "blobs_per_1024x768": 16000}
+                for a_, b_ in d8:
+                    a_.free(); b_.free()
             out["extra"] = extra
         # ---- the CPU path on the same workload: parity of one pair of the run + the baseline timing ---------------------
         if world == 1 and not args.no_cpu_baseline and not wxbs and not ladder and group is None:
