@@ -37,7 +37,8 @@ python $R/tools/pmc_counters.py $DBS $OUT/${TAG}_pmc_sq.txt "python bench.py $ON
 for spec in "m10k:" "m20k:--rep 2" "m24k:--tilts 1,2,4,6,8 --phi 120" "m48k:--tilts 1,2,4,6,8 --phi 120 --rep 2"; do
   tag=${spec%%:*}; a=${spec#*:}
   DB=$(run $tag --kernel-trace --stats -d /tmp/rp_$tag -o p -- python $R/tools/bench_match.py $a --reps 10)
-  python $R/tools/rocprof_summary.py $DB $OUT/${TAG}_match_$tag.txt "python tools/bench_match.py $a --reps 10   $(tail -1 /tmp/rp_$tag.log | cut -c1-220)" > /dev/null
+  grep -h "N=" /tmp/rp_$tag.log | tail -1 > /tmp/rp_$tag.line
+  python $R/tools/rocprof_summary.py $DB $OUT/${TAG}_match_$tag.txt "python tools/bench_match.py $a --reps 10   $(cut -c1-220 /tmp/rp_$tag.line)" > /dev/null
 done
 DBM=$(run msq --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d /tmp/rp_msq -o p -- python $R/tools/bench_match.py --tilts 1,2,4,6,8 --phi 120 --reps 3)
 python $R/tools/pmc_counters.py $DBM $OUT/${TAG}_match_pmc_sq.txt "python tools/bench_match.py --tilts 1,2,4,6,8 --phi 120 --reps 3 (24 k x 24 k real descriptors)" > /dev/null
@@ -58,7 +59,7 @@ def table(path):
 t = table("$OUT/${TAG}_pmc_hbm.txt")
 m = table("$OUT/${TAG}_match_pmc_hbm.txt")
 t["k_match_total_views31"] = sum(v for k, v in m.items() if k.startswith("k_match_"))
-hdr = open("$OUT/${TAG}_match_m24k.txt").read()
+hdr = open("/tmp/rp_m24k.line").read()
 mm = re.search(r"N=(\d+) M=(\d+)", hdr)
 t["k_match_problem"] = ("%s x %s real 31-view descriptors (tools/bench_match.py --tilts 1,2,4,6,8 --phi 120)" % (mm.group(1), mm.group(2))) if mm else "24 k x 24 k real 31-view descriptors"
 json.dump(dict(sorted(t.items())), open("$OUT/pmc_traffic_${TAG}.json", "w"), indent=1)
