@@ -91,6 +91,13 @@ void prof_reset(modsx_ctx *c, bool enable) {
   for (int i = 0; i < K_NCLASS; i++) { p.ms[i] = 0; p.work[i] = 0; p.launches[i] = 0; }
 }
 
+// MODSX_HOST_TIMING=2: wall time of the host phases between the launches of a set (stderr)
+struct HostMark {
+  bool on; double t;
+  HostMark() : on(getenv("MODSX_HOST_TIMING") && atoi(getenv("MODSX_HOST_TIMING")) >= 2), t(0) { if (on) t = now(); }
+  static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  void mark(const char *what) { if (!on) return; const double n = now(); fprintf(stderr, "  host %-28s %.3f ms\n", what, n - t); t = n; }
+};
 static double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -467,67 +474,70 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
     MX_HIP(hipMemcpyAsync(c->hCand.p, c->cand.p, (size_t)cnt * sizeof(Candidate), hipMemcpyDeviceToHost, s));
     MX_HIP(hipStreamSynchronize(s));
   }
+  HostMark hm;
   const Candidate *cd = (const Candidate *)c->hCand.p;
-  // the reference visits (octave, level, row, col) in this order (pyramid.cpp:438-451, 490-498, 564-571): an LSD radix sort
-  // of one 64-bit key per candidate (the comparison sort of the 48-byte records was 2/3 of the host time of a launch set)
-  std::vector<uint64_t> &keys = c->candKeys, &keys2 = c->candKeys2;
-  std::vector<uint32_t> &order = c->candOrder, &order2 = c->candOrder2;
-  keys.resize(cnt); keys2.resize(cnt); order.resize(cnt); order2.resize(cnt);
+  // The reference visits (octave, level, row, col) in this order per image (pyramid.cpp:438-451, 490-498, 564-571) and the
+  // first candidate in that order that lands on a pixel of an octave claims it (octaveMap, :414-418).  Images are
+  // independent: the candidates are bucketed by image once, then every image sorts one 64-bit key per candidate, applies the
+  // claim through a small open-addressing table and builds its keypoints -- one task per image on the host pool.
   for (unsigned k = 0; k < cnt; k++) {
     const Candidate &q = cd[k];
-    if ((unsigned)q.img >= 64u || (unsigned)q.octave >= 32u || (unsigned)q.level >= 32u || (unsigned)q.r0 >= (1u << 24) ||
+    if ((unsigned)q.img >= (unsigned)n || (unsigned)q.octave >= 32u || (unsigned)q.level >= 32u || (unsigned)q.r0 >= (1u << 24) ||
         (unsigned)q.c0 >= (1u << 24) || (unsigned)q.r >= (1u << 24) || (unsigned)q.c >= (1u << 24)) {
       set_error("candidate outside the sort key's range");
       return MODSX_ERR_DEVICE;
     }
-    keys[k] = ((uint64_t)q.img << 58) | ((uint64_t)q.octave << 53) | ((uint64_t)q.level << 48) | ((uint64_t)q.r0 << 24) | (uint64_t)q.c0;
-    order[k] = k;
   }
+  std::vector<uint32_t> &byImg = c->candOrder;
+  std::vector<uint32_t> imgStart(n + 1, 0);
+  byImg.resize(cnt);
+  for (unsigned k = 0; k < cnt; k++) imgStart[cd[k].img + 1]++;
+  for (int i = 0; i < n; i++) imgStart[i + 1] += imgStart[i];
   {
-    constexpr int BITS = 11, NB = 1 << BITS;
-    uint32_t hist[NB];
-    for (int shift = 0; shift < 64; shift += BITS) {
-      memset(hist, 0, sizeof hist);
-      for (unsigned k = 0; k < cnt; k++) hist[(keys[k] >> shift) & (NB - 1)]++;
-      if (cnt && hist[(keys[0] >> shift) & (NB - 1)] == cnt) continue;   // this digit is the same in every key
-      uint32_t sum = 0;
-      for (int b = 0; b < NB; b++) { const uint32_t h = hist[b]; hist[b] = sum; sum += h; }
-      for (unsigned k = 0; k < cnt; k++) {
-        const uint32_t d = hist[(keys[k] >> shift) & (NB - 1)]++;
-        keys2[d] = keys[k]; order2[d] = order[k];
-      }
-      keys.swap(keys2); order.swap(order2);
-    }
+    std::vector<uint32_t> fill(imgStart.begin(), imgStart.end() - 1);
+    for (unsigned k = 0; k < cnt; k++) byImg[fill[cd[k].img]++] = k;
   }
+  hm.mark("cand bucket by image");
   const SigmaPlan sp = make_sigma_plan(p);
-  for (int i = 0; i < n; i++) out[i].clear();
-  // octaveMap(r,c) per (image, octave), pyramid.cpp:414-418: the first candidate in detection order that lands on a pixel
-  // claims it.  Open addressing over a power-of-two table (key + 1, 0 = empty).
-  size_t tabSize = 64;
-  while (tabSize < (size_t)cnt * 2 + 16) tabSize <<= 1;
-  std::vector<uint64_t> &claimed = c->candClaim;
-  claimed.assign(tabSize, 0);
-  for (unsigned kk = 0; kk < cnt; kk++) {
-    const Candidate &q = cd[order[kk]];
-    const uint64_t key = (((uint64_t)q.img << 53) | ((uint64_t)q.octave << 48) | ((uint64_t)q.r << 24) | (uint64_t)q.c) + 1;
-    size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & (tabSize - 1);
-    bool taken = false;
-    while (claimed[h]) { if (claimed[h] == key) { taken = true; break; } h = (h + 1) & (tabSize - 1); }
-    if (taken) continue;
-    claimed[h] = key;
-    const float pixelDistance = c->pyr[q.img].oct[q.octave].pixelDistance;
-    const float curScale = sp.curSigma[q.level];
-    float scale = curScale * powf(2.0f, q.b2 / p.numberOfScales);
-    modsx_sskp kp;
-    kp.octave = q.octave; kp.level = q.level; kp.r0 = q.r0; kp.c0 = q.c0; kp.r = q.r; kp.c = q.c; kp.type = q.type;
-    kp.pad = 0;
-    kp.b0 = q.b0; kp.b1 = q.b1; kp.b2 = q.b2; kp.val = q.val;
-    kp.x = pixelDistance * (q.c + q.b0);
-    kp.y = pixelDistance * (q.r + q.b1);
-    kp.s = pixelDistance * scale;
-    kp.pixelDistance = pixelDistance;
-    out[q.img].push_back(kp);
-  }
+  host_parallel_light(n, [&](int img) {
+    std::vector<modsx_sskp> &dst = out[img];
+    dst.clear();
+    const uint32_t *idx = byImg.data() + imgStart[img];
+    const size_t m = imgStart[img + 1] - imgStart[img];
+    if (!m) return;
+    std::vector<std::pair<uint64_t, uint32_t>> order(m);
+    for (size_t k = 0; k < m; k++) {
+      const Candidate &q = cd[idx[k]];
+      order[k] = {((uint64_t)q.octave << 53) | ((uint64_t)q.level << 48) | ((uint64_t)q.r0 << 24) | (uint64_t)q.c0, idx[k]};
+    }
+    std::sort(order.begin(), order.end());      // keys are unique: one candidate per (octave, level, pixel)
+    size_t tabSize = 64;
+    while (tabSize < m * 2 + 16) tabSize <<= 1;
+    std::vector<uint64_t> claimed(tabSize, 0);  // key + 1, 0 = empty
+    dst.reserve(m);
+    for (size_t kk = 0; kk < m; kk++) {
+      const Candidate &q = cd[order[kk].second];
+      const uint64_t key = (((uint64_t)q.octave << 48) | ((uint64_t)q.r << 24) | (uint64_t)q.c) + 1;
+      size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & (tabSize - 1);
+      bool taken = false;
+      while (claimed[h]) { if (claimed[h] == key) { taken = true; break; } h = (h + 1) & (tabSize - 1); }
+      if (taken) continue;
+      claimed[h] = key;
+      const float pixelDistance = c->pyr[q.img].oct[q.octave].pixelDistance;
+      const float curScale = sp.curSigma[q.level];
+      float scale = curScale * powf(2.0f, q.b2 / p.numberOfScales);
+      modsx_sskp kp;
+      kp.octave = q.octave; kp.level = q.level; kp.r0 = q.r0; kp.c0 = q.c0; kp.r = q.r; kp.c = q.c; kp.type = q.type;
+      kp.pad = 0;
+      kp.b0 = q.b0; kp.b1 = q.b1; kp.b2 = q.b2; kp.val = q.val;
+      kp.x = pixelDistance * (q.c + q.b0);
+      kp.y = pixelDistance * (q.r + q.b1);
+      kp.s = pixelDistance * scale;
+      kp.pixelDistance = pixelDistance;
+      dst.push_back(kp);
+    }
+  });
+  hm.mark("octaveMap claim + sskp");
   return MODSX_OK;
 }
 
@@ -588,6 +598,7 @@ int detect_keypoints_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, 
   std::vector<modsx_sskp> ss[MAXB];
   int rc = detect_scalespace_batch(c, imgs, n, p, ss);
   if (rc) return rc;
+  HostMark hm;
   rc = ensure_smm_mask(c, p.smmWindowSize);
   if (rc) return rc;
   size_t total = 0;
@@ -599,8 +610,11 @@ int detect_keypoints_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, 
   if (!c->affJobs.ensure(total * sizeof(AffJob)) || !c->affOut.ensure(total * sizeof(AffOut))) return MODSX_ERR_NOMEM;
   AffJob *hj = (AffJob *)c->hAff.p;
   AffOut *ho = (AffOut *)((char *)c->hAff.p + total * sizeof(AffJob));
-  size_t k = 0;
-  for (int i = 0; i < n; i++)
+  size_t first[MAXB + 1];   // image i's keypoints are jobs first[i] .. first[i + 1]
+  first[0] = 0;
+  for (int i = 0; i < n; i++) first[i + 1] = first[i] + ss[i].size();
+  host_parallel_light(n, [&](int i) {
+    size_t k = first[i];
     for (const modsx_sskp &q : ss[i]) {
       const Octave &oc = c->pyr[i].oct[q.octave];
       AffJob &j = hj[k++];
@@ -608,6 +622,8 @@ int detect_keypoints_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, 
       j.rows = oc.rows; j.cols = oc.cols;
       j.x = q.x; j.y = q.y; j.s = q.s; j.pixelDistance = q.pixelDistance;
     }
+  });
+  hm.mark("AffJob build");
   if (p.doBaumberg) {
     MX_HIP(hipMemcpyAsync(c->affJobs.p, hj, total * sizeof(AffJob), hipMemcpyHostToDevice, s));
     ProfScope ps(c, K_BAUMBERG, (double)total * 361 * 4 * 2);
@@ -618,8 +634,10 @@ int detect_keypoints_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, 
   } else {
     for (size_t i = 0; i < total; i++) { ho[i].u11 = 1; ho[i].u12 = 0; ho[i].u21 = 0; ho[i].u22 = 1; ho[i].ok = 1; ho[i].iters = 0; }
   }
-  k = 0;
-  for (int i = 0; i < n; i++) {
+  hm.mark("baumberg launch + wait");
+  host_parallel_light(n, [&](int i) {
+    size_t k = first[i];
+    out[i].reserve(ss[i].size());
     for (const modsx_sskp &q : ss[i]) {
       const AffOut &a = ho[k++];
       if (!a.ok) continue;
@@ -635,7 +653,8 @@ int detect_keypoints_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, 
     const double tilt = tilts ? tilts[i] : 1.0, zoom = zooms ? zooms[i] : 1.0;
     if ((tilt > 2.0) || (zoom < 0.5)) pe.reg_number = (int)floor(zoom * (double)pe.reg_number / tilt);
     prepare_keys_for_export(out[i], pe);
-  }
+  });
+  hm.mark("keypoints + export");
   return MODSX_OK;
 }
 
@@ -681,16 +700,14 @@ int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n
   double mrScale = (double)mrSize;
   int patchImageSize = 2 * int(mrScale) + 1;
   double imageToPatchScale = double(patchImageSize) / (double)patchSize;
+  HostMark hm;
   std::vector<OriJob> jobs;
   std::vector<char> passed[MAXB];
-  {
-    size_t tot = 0;
-    for (int i = 0; i < n; i++) tot += in[i].size();
-    jobs.reserve(tot);
-  }
-  for (int i = 0; i < n; i++) {
+  std::vector<OriJob> jobsOf[MAXB];     // per image, then concatenated: the images are independent (one pool task each)
+  host_parallel_light(n, [&](int i) {
     passed[i].assign(in[i].size(), 0);
-    out[i].reserve(in[i].size() + in[i].size() / 4);
+    jobsOf[i].clear();
+    jobsOf[i].reserve(in[i].size());
     for (size_t r = 0; r < in[i].size(); r++) {
       const modsx_keypoint &k = in[i][r].det_kp;
       if (check_borders_host(imgs[i]->cols, imgs[i]->rows, (float)k.x, (float)k.y, (float)k.a11, (float)k.a12,
@@ -703,10 +720,16 @@ int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n
         j.img = i; j.x = (float)k.x; j.y = (float)k.y;
         j.a11 = (float)k.a11 * curr_sc; j.a12 = (float)k.a12 * curr_sc;
         j.a21 = (float)k.a21 * curr_sc; j.a22 = (float)k.a22 * curr_sc;
-        jobs.push_back(j);
+        jobsOf[i].push_back(j);
       }
     }
-  }
+  });
+  size_t jobStart[MAXB + 1];
+  jobStart[0] = 0;
+  for (int i = 0; i < n; i++) jobStart[i + 1] = jobStart[i] + jobsOf[i].size();
+  jobs.resize(jobStart[n]);
+  host_parallel_light(n, [&](int i) { if (!jobsOf[i].empty()) memcpy(jobs.data() + jobStart[i], jobsOf[i].data(), jobsOf[i].size() * sizeof(OriJob)); });
+  hm.mark("orientation jobs");
   const OriOut *res = nullptr;   // in the pinned staging buffer
   if (!jobs.empty()) {
     int rc = upload_img_refs(c, imgs, n);
@@ -728,8 +751,11 @@ int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n
     MX_HIP(hipMemcpyAsync(hres, c->oriOut.p, nj * sizeof(OriOut), hipMemcpyDeviceToHost, s));
     MX_HIP(hipStreamSynchronize(s));
   }
-  size_t jk = 0;
-  for (int i = 0; i < n; i++) {
+  hm.mark("orientation launch + wait");
+  host_parallel_light(n, [&](int i) {
+    size_t jk = jobStart[i];
+    out[i].clear();
+    out[i].reserve(in[i].size() + in[i].size() / 4);
     for (size_t r = 0; r < in[i].size(); r++) {
       if (!passed[i][r]) continue;
       modsx_region base = in[i][r];
@@ -750,7 +776,8 @@ int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n
       }
       if (addUpRight) out[i].push_back(base);
     }
-  }
+  });
+  hm.mark("rotated regions");
   return MODSX_OK;
 }
 
@@ -812,6 +839,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
   }
   // the regions of all images of the batch go through one launch set per chunk (a chunk ends when the window arena is
   // full); region order inside an image is kept, outIdx addresses the image's own descriptor buffer
+  HostMark hm;
   int curImg = 0, chunkNo = 0;
   size_t curReg = 0;
   while (curImg < n && regs[curImg].empty()) curImg++;
@@ -941,6 +969,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       }
       // (i, r) = first region that did not fit, or i == n
       if (full) { curImg = i; curReg = r; } else { curImg = n; curReg = 0; }
+      hm.mark("desc jobs");
       const size_t nj = jobs.size();
       // Launch order of the chunk: by image, then by 64-pixel row band, then by x.  The sampling kernel hands every XCD one
       // contiguous eighth of this order (kernels_describe.hip: xcd_chunk), i.e. one part of the images; outIdx keeps every
@@ -976,6 +1005,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
         for (size_t q = 0; q < nj; q++) sorted[q] = jobs[ord[q]];
         jobs.swap(sorted);
       }
+      hm.mark("desc job sort");
       const size_t windowFloats = arenaA;   // all P x P windows of the chunk: its size limit and its algorithmic bytes
       arenaA = 0;                           // arena A itself only holds the windows that do not take the fused kernel
       size_t rowStarts = 0;                 // the fused ones get their P row starts (float2) instead
@@ -1020,6 +1050,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       if (!taps.empty()) memcpy(hb + oTaps, taps.data(), taps.size() * 4);
       if (!needTab.empty()) memcpy(hb + oNeed, needTab.data(), needTab.size() * 4);
       if (!coordTab.empty()) memcpy(hb + oCoord, coordTab.data(), coordTab.size() * 4);
+      hm.mark("desc tables + blob");
       MX_HIP(hipMemcpyAsync(db, hb, blobB, hipMemcpyHostToDevice, s));
       MX_HIP(hipEventRecord(c->descEv[slot], s));
       c->descEvPending[slot] = true;
@@ -1055,7 +1086,9 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       chunkNo++;
     }
   }
+  hm.mark("desc launches");
   MX_HIP(hipStreamSynchronize(s));   // callers read the descriptor buffers and reuse the staging blobs
+  hm.mark("desc wait");
   c->descEvPending[0] = c->descEvPending[1] = false;
   if (descHost) {
     bool any = false;

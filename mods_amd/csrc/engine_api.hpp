@@ -96,7 +96,10 @@ int detect_msers_host(const uint8_t *u8, int rows, int cols, const modsx_mser_pa
 int detect_msers_views(const uint8_t *const *u8, const int *rows, const int *cols, int n, const modsx_mser_params &par,
                        const double *tilts, const double *zooms, std::vector<modsx_keypoint> *out);
 // fn(0) .. fn(n - 1) on the process-wide host worker pool (MODSX_HOST_THREADS, default min(hardware threads, 64)) + the caller
-void host_parallel_for(int n, const std::function<void(int)> &fn);
+void host_parallel_for(int n, const std::function<void(int)> &fn, bool light = false);
+void host_set_enter();
+void host_set_leave();
+inline void host_parallel_light(int n, const std::function<void(int)> &fn) { host_parallel_for(n, fn, true); }
 int ransac_f(const double *u, int len, double th, double conf, int max_sam, double *F, unsigned char *inl, int *data_out,
              int do_lo, unsigned inlLimit, int error_type, int doSymCheck, unsigned seed0);
 int loransac_f(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold, double confidence,

@@ -266,6 +266,7 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
   regs.clear();
   if (viewCounts) for (int v = 0; v < nv; v++) viewCounts[v] = 0;
   if (view_step < 1) view_step = 1;
+  struct SetScope { SetScope() { host_set_enter(); } ~SetScope() { host_set_leave(); } } setScope;
   std::vector<int> take;
   for (int v = view_begin; v < nv; v += view_step) take.push_back(v);
   size_t total = 0;
@@ -298,6 +299,8 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
     }
     auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const bool tim = getenv("MODSX_HOST_TIMING") != nullptr;
+    const bool tim2 = tim && atoi(getenv("MODSX_HOST_TIMING")) >= 2;
+    double tq = 0;
     double t0 = tnow();
     if (!rc) rc = synth_views_batch(c, gray, plans, vdst, n);
     if (tim) hipStreamSynchronize(c->stream);
@@ -327,28 +330,34 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
     double t2 = tnow(), t3 = t2, t4 = t2;
     if (!rc) {
       const int detType = pp.detector == MODSX_DET_MSER ? MODSX_DET_MSER : MODSX_DET_HESSIAN;
-      for (int i = 0; i < n; i++) {
+      host_parallel_light(n, [&](int i) {
         r0[i].resize(kps[i].size());
         detect_affine_regions(kps[i].data(), (int)kps[i].size(), ident[i] ? 0 : take[g0 + i], detType, r0[i].data());
-      }
+      });
       rc = detect_orientation_batch(c, cimg, n, r0, pp.ori_mrSize, pp.ori_patchSize, 0, pp.ori_maxAngles, pp.ori_threshold,
                                     0, ro);
     }
     t3 = tnow();
+    tq = t3;
     if (!rc) {
       float *dF[MAXB];
       uint8_t *dU[MAXB];
       size_t ofs = total;
-      for (int i = 0; i < n; i++) {
+      host_parallel_light(n, [&](int i) {
         int m = reproject_regions(ro[i].data(), (int)ro[i].size(), Hs[i], gray->cols, gray->rows);
         ro[i].resize(m);
+      });
+      for (int i = 0; i < n; i++) {
+        const int m = (int)ro[i].size();
         dF[i] = devF ? devF + ofs * 128 : nullptr;
         dU[i] = devU8 ? devU8 + ofs * 128 : nullptr;
         ofs += m;
       }
+      if (tim2) { fprintf(stderr, "  host %-28s %.3f ms\n", "reproject", tnow() - tq); tq = tnow(); }
       if (ofs > devCapRegions && (devF || devU8)) { set_error("descriptor buffer too small"); rc = MODSX_ERR_CAPACITY; }
       if (!rc) rc = describe_batch(c, cimg, n, ro, pp.desc_mrSize, pp.desc_patchSize, 0, pp.desc_photoNorm, pp.desc_type,
                                    pp.desc_maxBinValue, nullptr, devF ? dF : nullptr, devU8 ? dU : nullptr);
+      if (tim2) tq = tnow();
       if (!rc) {
         for (int i = 0; i < n; i++) {
           if (hostDesc && !ro[i].empty()) {
@@ -359,10 +368,17 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
             }
           }
           if (viewCounts) viewCounts[take[g0 + i]] = (int)ro[i].size();
-          regs.insert(regs.end(), ro[i].begin(), ro[i].end());
-          total += ro[i].size();
+        }
+        {   // the set's regions behind the list, one copy task per view
+          size_t at[MAXB + 1];
+          at[0] = regs.size();
+          for (int i = 0; i < n; i++) at[i + 1] = at[i] + ro[i].size();
+          regs.resize(at[n]);
+          host_parallel_light(n, [&](int i) { if (!ro[i].empty()) memcpy(regs.data() + at[i], ro[i].data(), ro[i].size() * sizeof(modsx_region)); });
+          total += at[n] - at[0];
         }
         hipStreamSynchronize(c->stream);
+        if (tim2) fprintf(stderr, "  host %-28s %.3f ms\n", "region list append", tnow() - tq);
       }
     }
     t4 = tnow();

@@ -28,6 +28,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -386,22 +387,27 @@ namespace {
 class HostPool {
  public:
   static HostPool &get() { static HostPool p; return p; }
-  // runs fn(0) .. fn(n - 1) on the workers (and on the caller), returns when all are done
+  // runs fn(0) .. fn(n - 1) on the workers and on the caller, returns when all are done.  Tasks are handed out by an atomic
+  // counter; only as many workers as there are tasks are woken.
   void run(int n, const std::function<void(int)> &fn) {
     if (n <= 0) return;
+    if (n == 1 || threads_.empty()) { for (int i = 0; i < n; i++) fn(i); return; }
     auto job = std::make_shared<Job>();
     job->n = n; job->fn = &fn;
     {
       std::lock_guard<std::mutex> lk(mu_);
       jobs_.push_back(job);
     }
-    cv_.notify_all();
+    const int wake = std::min(n - 1, (int)threads_.size());
+    for (int k = 0; k < wake; k++) cv_.notify_one();
     work(*job);                    // the calling thread takes tasks too
-    std::unique_lock<std::mutex> lk(mu_);
-    job->done_cv.wait(lk, [&] { return job->finished == job->n; });
+    for (int spin = 0; job->done.load(std::memory_order_acquire) < n; spin++)
+      if (spin > 64) std::this_thread::yield();
+    std::lock_guard<std::mutex> lk(mu_);
+    for (auto it = jobs_.begin(); it != jobs_.end(); ++it) if (it->get() == job.get()) { jobs_.erase(it); break; }
   }
  private:
-  struct Job { int n = 0, next = 0, finished = 0; const std::function<void(int)> *fn = nullptr; std::condition_variable done_cv; };
+  struct Job { int n = 0; std::atomic<int> next{0}, done{0}; const std::function<void(int)> *fn = nullptr; };
   std::mutex mu_;
   std::condition_variable cv_;
   std::deque<std::shared_ptr<Job>> jobs_;
@@ -418,36 +424,52 @@ class HostPool {
     cv_.notify_all();
     for (std::thread &t : threads_) t.join();
   }
-  void work(Job &j) {
+  static void work(Job &j) {
+    int mine = 0;
     for (;;) {
-      int i;
-      {
-        std::lock_guard<std::mutex> lk(mu_);
-        if (j.next >= j.n) return;
-        i = j.next++;
-        if (j.next >= j.n) for (auto it = jobs_.begin(); it != jobs_.end(); ++it) if (it->get() == &j) { jobs_.erase(it); break; }
-      }
+      const int i = j.next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= j.n) break;
       (*j.fn)(i);
-      std::lock_guard<std::mutex> lk(mu_);
-      if (++j.finished == j.n) j.done_cv.notify_all();
+      mine++;
     }
+    if (mine) j.done.fetch_add(mine, std::memory_order_release);
   }
   void loop() {
     for (;;) {
       std::shared_ptr<Job> j;
       {
         std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return stop_ || !jobs_.empty(); });
-        if (stop_) return;
-        j = jobs_.front();
+        for (;;) {
+          if (stop_) return;
+          while (!jobs_.empty() && jobs_.front()->next.load(std::memory_order_relaxed) >= jobs_.front()->n) jobs_.pop_front();
+          if (!jobs_.empty()) { j = jobs_.front(); break; }
+          cv_.wait(lk);
+        }
       }
       work(*j);
     }
   }
 };
+std::atomic<int> g_setsInFlight(0);
 }  // namespace
 
-void host_parallel_for(int n, const std::function<void(int)> &fn) { HostPool::get().run(n, fn); }
+// a launch set is being driven by the calling thread (detect_describe_views): how many are decides whether their short
+// host loops may use the pool
+void host_set_enter() { g_setsInFlight.fetch_add(1); }
+void host_set_leave() { g_setsInFlight.fetch_sub(1); }
+
+// fn(0) .. fn(n - 1) in parallel.  light = true marks the short per-view loops of a launch set (hundreds of microseconds of
+// work): they go to the pool only while at most two launch sets are in flight -- a single pair, or its two images side by side; with
+// many contexts at work every host core already has a context's own loop to run and the loops stay where they are.
+void host_parallel_for(int n, const std::function<void(int)> &fn, bool light) {
+  if (light) {
+    static const bool off = getenv("MODSX_HOST_SERIAL") != nullptr;
+    if (g_setsInFlight.load() > 2 || off) { for (int i = 0; i < n; i++) fn(i); return; }
+    HostPool::get().run(n, fn);
+    return;
+  }
+  HostPool::get().run(n, fn);
+}
 
 // u8: rows x cols grey values (already truncated from the f32 view).  Appends nothing to `out` beyond the keypoints of
 // this view; returns MODSX_OK.
