@@ -1252,6 +1252,7 @@ int match_host_desc(modsx_ctx *c, const float *desc1, int n1, const float *desc2
 // Fills the counters, H and the three malloc'd arrays of `res` (which must not own arrays yet).
 void verify_tentatives(const std::vector<modsx_region> &r1, const std::vector<modsx_region> &r2,
                        const std::vector<modsx_tentative> &tents, const modsx_pair_params &pp, modsx_pair_result *res) {
+  HostMark hm;
   res->n_tentatives = (int)tents.size();
   const int T0 = (int)tents.size();
   std::vector<double> pts((size_t)T0 * 4 + 4), key(T0 + 1);
@@ -1260,9 +1261,11 @@ void verify_tentatives(const std::vector<modsx_region> &r1, const std::vector<mo
     pts[4 * i] = a.x; pts[4 * i + 1] = a.y; pts[4 * i + 2] = b.x; pts[4 * i + 3] = b.y;
     key[i] = tents[i].ratio;
   }
+  hm.mark("verify: points");
   std::vector<int> order(T0 + 1);
   std::vector<unsigned char> keepd(T0 + 1);
   duplicate_filtering(pts.data(), key.data(), T0, pp.duplicateDist, 1, order.data(), keepd.data());
+  hm.mark("verify: duplicate filter");
   std::vector<modsx_tentative> uniq;
   for (int i = 0; i < T0; i++) if (keepd[i]) uniq.push_back(tents[order[i]]);
   const int T = (int)uniq.size();
@@ -1278,6 +1281,7 @@ void verify_tentatives(const std::vector<modsx_region> &r1, const std::vector<mo
   res->ransac_inlier = (unsigned char *)calloc(std::max(1, T), 1);
   res->verified = (unsigned char *)calloc(std::max(1, T), 1);
   for (int i = 0; i < T; i++) res->tentatives[i] = uniq[i];
+  hm.mark("verify: unique lists");
   double Hraw[9];
   int dout[3] = {0, 0, 0};
   int nv;
@@ -1289,6 +1293,7 @@ void verify_tentatives(const std::vector<modsx_region> &r1, const std::vector<mo
     nv = loransac_h(p2.data(), l1.data(), l2.data(), T, pp.err_threshold, pp.confidence, pp.max_samples,
                     pp.localOptimization, pp.HLAFCoef, pp.doSymmCheck, pp.ransac_seed, res->H, Hraw, res->ransac_inlier,
                     res->verified, dout, pp.errorType);
+  hm.mark("verify: lo-ransac + checks");
   res->n_verified = nv < 0 ? 0 : nv;
   res->n_ransac_inliers = 0;
   for (int i = 0; i < T; i++) res->n_ransac_inliers += res->ransac_inlier[i];

@@ -39,8 +39,9 @@ int duplicate_filtering(const double *pts, const double *key, int T, double r, i
   std::vector<char> uniq(T, 1);
   double maxx = minx, maxy = miny;
   for (int i = 0; i < T; i++) { maxx = std::max(maxx, P[4 * (size_t)i]); maxy = std::max(maxy, P[4 * (size_t)i + 1]); }
-  // cell edge >= r (so +-1 cell covers the radius); coarser cells keep the grid small
-  const double cell_sz = std::max(r, std::max(maxx - minx, maxy - miny) / 96.0);
+  // cell edge >= r (so +-1 cell covers the radius) and at most 1024 cells per side.  Multi-view tentatives cluster -- a dozen per
+  // scene point -- so cells of the radius itself matter: with 96 cells per side the pass was 2 ms of a 12 k-tentative pair
+  const double cell_sz = std::max(r, std::max(maxx - minx, maxy - miny) / 1024.0);
   const double gw = (maxx - minx) / cell_sz, gh = (maxy - miny) / cell_sz;
   if (!finite || T < 64 || gw > 8192 || gh > 8192) {
     for (int i = 0; i < T; i++) {

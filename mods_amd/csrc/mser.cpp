@@ -458,6 +458,7 @@ std::atomic<int> g_setsInFlight(0);
 void host_set_enter() { g_setsInFlight.fetch_add(1); }
 void host_set_leave() { g_setsInFlight.fetch_sub(1); }
 
+
 // fn(0) .. fn(n - 1) in parallel.  light = true marks the short per-view loops of a launch set (hundreds of microseconds of
 // work): they go to the pool only while at most two launch sets are in flight -- a single pair, or its two images side by side; with
 // many contexts at work every host core already has a context's own loop to run and the loops stay where they are.
