@@ -465,7 +465,8 @@ void host_set_leave() { g_setsInFlight.fetch_sub(1); }
 void host_parallel_for(int n, const std::function<void(int)> &fn, bool light) {
   if (light) {
     static const bool off = getenv("MODSX_HOST_SERIAL") != nullptr;
-    if (g_setsInFlight.load() > 2 || off) { for (int i = 0; i < n; i++) fn(i); return; }
+    static const int maxSets = getenv("MODSX_LIGHT_SETS") ? atoi(getenv("MODSX_LIGHT_SETS")) : 2;
+    if (g_setsInFlight.load() > maxSets || off) { for (int i = 0; i < n; i++) fn(i); return; }
     HostPool::get().run(n, fn);
     return;
   }
