@@ -50,12 +50,17 @@ constexpr int BIG = 0x7fffffff;
 constexpr int NONE = 0x7fffff00;           // empty slot of a running minimum: larger than every real key, low byte 0
 constexpr int TPS = 4;                     // train tiles staged per barrier
 constexpr int CHUNK = 12;                  // tiles per index chunk (3 stages); tilesPerSplit is a multiple of it
-#ifndef MATCH_QSETS
-#define MATCH_QSETS 2
-#endif
-constexpr int QSETS = MATCH_QSETS;         // 32-query sets per wave (even)
-constexpr int SWEEP_WPS = QSETS >= 4 ? 2 : 3;   // waves per SIMD the sweeps are built for
-constexpr int QPB = 4 * 32 * QSETS;        // queries per 256-thread workgroup
+// 32-query sets per wave (QS, even): 2 for most problems -- 3 wavefronts per SIMD --, 4 when both sides hold >= 40 k descriptors:
+// every LDS fragment read then feeds four MFMA chains (half the LDS bytes per matrix instruction) at 2 wavefronts per SIMD
+// (round 3: 0.392 against 0.402 ms at 46 k x 45 k, 0.155 against 0.151 ms at 24 k x 24 k, -25 % at 10 k; selected per problem)
+constexpr int sweep_wps(int qs) { return qs >= 4 ? 2 : 3; }   // waves per SIMD the sweeps are built for
+constexpr int qpb_of(int qs) { return 4 * 32 * qs; }          // queries per 256-thread workgroup
+constexpr int QPB_MAX = qpb_of(4), NW_MAX = 256 * 3;
+static int match_qsets(int nb, int n1, int n2) {
+  static const int forced = getenv("MODSX_MATCH_QSETS") ? atoi(getenv("MODSX_MATCH_QSETS")) : 0;
+  if (forced == 2 || forced == 4) return forced;
+  return (nb == 1 && n1 >= 40000 && n2 >= 40000) ? 4 : 2;
+}
 constexpr int TILE_B = 4096, STAGE_B = TPS * TILE_B + TPS * 128;
 constexpr int MAXD = 128 * 255 * 255;      // largest possible squared distance
 
@@ -78,7 +83,7 @@ MX_D int imed3(int a, int b, int c) { return min(max(a, b), max(min(a, b), c)); 
 MX_D int imin3(int a, int b, int c) { return min(min(a, b), c); }
 
 struct MatchGeom {
-  int n1, n2, S, tilesPerSplit;
+  int n1, n2, S, tilesPerSplit, qs;
 };
 
 // Sweep 2 runs over the UNDECIDED queries only, whose number the host does not know at launch time.  With sweep 1's splits it
@@ -86,11 +91,11 @@ struct MatchGeom {
 // takes (41 us of the 165 at 24 k x 24 k, where 15 % of the queries are undecided).  Every workgroup therefore derives the
 // split geometry from the device-side count: the NW workgroups of the launch are dealt out as (query block, split) with as
 // many splits as fill the machine once.  k_match_events uses the same function.
-constexpr int SWEEP2_NW = 256 * SWEEP_WPS;    // one round of workgroups
 struct Sweep2Geom { int nQB, S, tilesPerSplit; };
-MX_HD Sweep2Geom sweep2_geom(int nUnd, int n2) {
+MX_HD Sweep2Geom sweep2_geom(int nUnd, int n2, int qs) {
   Sweep2Geom G;
   const int ntiles = (n2 + 31) >> 5;
+  const int QPB = qpb_of(qs), SWEEP2_NW = 256 * sweep_wps(qs);    // one round of workgroups
   G.nQB = (nUnd + QPB - 1) / QPB;
   int S = G.nQB > 0 ? SWEEP2_NW / G.nQB : 1;
   if (S > ntiles / CHUNK) S = ntiles / CHUNK;     // at least one index chunk per split
@@ -106,8 +111,8 @@ MX_HD Sweep2Geom sweep2_geom(int nUnd, int n2) {
 static size_t sweep2_entries(int n1, int n2) {
   const int ntiles = (n2 + 31) >> 5;
   const size_t smax = (size_t)std::max(1, ntiles / CHUNK);
-  const size_t a = std::max<size_t>((size_t)n1, (size_t)SWEEP2_NW * QPB);   // nQB * S <= NW while S > 1; S = 1 beyond
-  return std::min(a, (size_t)n1 * smax) + QPB;
+  const size_t a = std::max<size_t>((size_t)n1, (size_t)NW_MAX * QPB_MAX);   // nQB * S <= NW while S > 1; S = 1 beyond
+  return std::min(a, (size_t)n1 * smax) + QPB_MAX;
 }
 
 // register r of the 32x32 accumulator of lane half `hi` holds MFMA row 8 (r >> 2) + 4 hi + (r & 3)
@@ -266,8 +271,9 @@ struct SweepArgs {
   int *evCnt, *ev;
 };
 
-template <int MODE>
+template <int MODE, int QSETS>
 __device__ __forceinline__ void sweep_body(const SweepArgs &A) {
+  constexpr int QPB = qpb_of(QSETS);
   __shared__ __attribute__((aligned(16))) unsigned char sm[2][STAGE_B];
   const MatchGeom g = A.g;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -276,7 +282,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &A) {
   int sp, qb, S, tilesPerSplit;
   if (MODE == 0) { sp = blockIdx.y; qb = blockIdx.x; S = g.S; tilesPerSplit = g.tilesPerSplit; }
   else {
-    const Sweep2Geom G2 = sweep2_geom(nQ, g.n2);
+    const Sweep2Geom G2 = sweep2_geom(nQ, g.n2, QSETS);
     S = G2.S; tilesPerSplit = G2.tilesPerSplit;
     qb = (int)blockIdx.x / S; sp = (int)blockIdx.x - qb * S;
   }
@@ -513,7 +519,7 @@ __device__ __forceinline__ void events_body(const uint8_t *d1, const int *norm1,
   const int nUnd = *nUndecided;
   if (u >= nUnd) return;
   const int lane = threadIdx.x & 63, l = lane & 15, sub = lane >> 4;
-  const Sweep2Geom G2 = sweep2_geom(nUnd, g.n2);      // the splits sweep 2 chose for this count
+  const Sweep2Geom G2 = sweep2_geom(nUnd, g.n2, g.qs);      // the splits sweep 2 chose for this count
   const int S2 = G2.S;
   const int nst = 2 * S2;
   // Every event group holds at least one train below Dmin and at most one of all those trains is NN0, so nn or more
@@ -608,13 +614,14 @@ struct MatchLayout {
   int S, tilesPerSplit, slots;
   size_t norm1, norm2, cst, tiles, partial, partial2, dmin, undecided, evCnt, ev, evRes, counter, bytes;
 };
-static MatchLayout match_layout(int n1, int n2) {
+static MatchLayout match_layout(int n1, int n2, int qs) {
   MatchLayout L;
+  const int QPB = qpb_of(qs);
   const int nQB = (n1 + QPB - 1) / QPB;
   const int ntiles = (n2 + 31) / 32;
   // one round of workgroups: 3 per CU (the sweeps hold ~150 VGPRs) x 256 CUs; a second, partly filled round costs as much
   // as the first.  Many query blocks (N > 196 k) simply take several rounds.
-  int S = (256 * SWEEP_WPS) / nQB;
+  int S = (256 * sweep_wps(qs)) / nQB;
   if (S > ntiles / CHUNK) S = ntiles / CHUNK;     // at least one chunk per split
   if (S < 1) S = 1;
   int tps = (ntiles + S - 1) / S;
@@ -640,7 +647,8 @@ static MatchLayout match_layout(int n1, int n2) {
   L.bytes = w;
   return L;
 }
-size_t match_workspace_bytes(int n1, int n2) { return match_layout(n1, n2).bytes; }
+// the larger of the two geometries: the caller sizes the workspace before the launcher picks one
+size_t match_workspace_bytes(int n1, int n2) { return std::max(match_layout(n1, n2, 2).bytes, match_layout(n1, n2, 4).bytes); }
 
 // ---- batched entry points: blockIdx.z selects one of up to MATCH_MAXB independent problems (the pairs of a launch set).
 struct MatchProblem {
@@ -660,12 +668,13 @@ __global__ __launch_bounds__(256) void k_match_pack(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
   pack_body(P.d1, P.g.n1, P.norm1, P.d2, P.g.n2, P.slots, P.tiles, P.cst, P.norm2);
 }
-__global__ __launch_bounds__(256, SWEEP_WPS) void k_match_sweep1(MatchBatch b) {
+template <int QS>
+__global__ __launch_bounds__(256, sweep_wps(QS)) void k_match_sweep1(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
-  if ((int)blockIdx.x * QPB >= P.g.n1 || (int)blockIdx.y >= P.g.S) return;
+  if ((int)blockIdx.x * qpb_of(QS) >= P.g.n1 || (int)blockIdx.y >= P.g.S) return;
   SweepArgs A;
   A.d1 = P.d1; A.norm1 = P.norm1; A.tiles = P.tiles; A.cst = P.cst; A.g = P.g; A.partial = P.partial;
-  sweep_body<0>(A);
+  sweep_body<0, QS>(A);
 }
 __global__ __launch_bounds__(1024) void k_match_decide(MatchBatch b, double sqminratio, double contrDistSq) {
   const MatchProblem &P = b.p[blockIdx.z];
@@ -673,12 +682,13 @@ __global__ __launch_bounds__(1024) void k_match_decide(MatchBatch b, double sqmi
   decide_body(P.d1, P.norm1, P.d2, P.norm2, P.partial, P.g, P.pos2, sqminratio, contrDistSq, P.rows, P.dmin, P.undecided,
               P.counter);
 }
-__global__ __launch_bounds__(256, SWEEP_WPS) void k_match_sweep2(MatchBatch b) {
+template <int QS>
+__global__ __launch_bounds__(256, sweep_wps(QS)) void k_match_sweep2(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
   SweepArgs A;
   A.d1 = P.d1; A.norm1 = P.norm1; A.tiles = P.tiles; A.cst = P.cst; A.g = P.g;
   A.dmin = P.dmin; A.undecided = P.undecided; A.nUndecided = P.counter; A.partial2 = P.partial2; A.evCnt = P.evCnt; A.ev = P.ev;
-  sweep_body<1>(A);
+  sweep_body<1, QS>(A);
 }
 __global__ __launch_bounds__(256) void k_match_events(MatchBatch b, double contrDistSq, int nn) {
   const MatchProblem &P = b.p[blockIdx.z];
@@ -694,10 +704,11 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
   MatchBatch b;
   memset(&b, 0, sizeof b);
   int maxN1 = 0, maxS = 0, maxSlots = 0;
+  const int qs = match_qsets(nb, n1[0], n2[0]);
   for (int i = 0; i < nb; i++) {
     MatchProblem &P = b.p[i];
-    const MatchLayout L = match_layout(n1[i], n2[i]);
-    P.g.n1 = n1[i]; P.g.n2 = n2[i]; P.g.S = L.S; P.g.tilesPerSplit = L.tilesPerSplit;
+    const MatchLayout L = match_layout(n1[i], n2[i], qs);
+    P.g.n1 = n1[i]; P.g.n2 = n2[i]; P.g.S = L.S; P.g.tilesPerSplit = L.tilesPerSplit; P.g.qs = qs;
     P.slots = L.slots;
     char *w = (char *)workspace[i];
     P.norm1 = (int *)(w + L.norm1); P.norm2 = (int *)(w + L.norm2); P.cst = (int *)(w + L.cst);
@@ -711,12 +722,16 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
     maxN1 = std::max(maxN1, n1[i]); maxS = std::max(maxS, L.S); maxSlots = std::max(maxSlots, L.slots);
   }
   hipLaunchKernelGGL(k_match_pack, dim3((std::max(maxN1, maxSlots) + 255) / 256, 2, nb), dim3(256), 0, s, b);
+  const int QPB = qpb_of(qs), NW2 = 256 * sweep_wps(qs);
   const dim3 grid((maxN1 + QPB - 1) / QPB, maxS, nb);
-  hipLaunchKernelGGL(k_match_sweep1, grid, dim3(256), 0, s, b);
+  if (qs == 4) hipLaunchKernelGGL(k_match_sweep1<4>, grid, dim3(256), 0, s, b);
+  else hipLaunchKernelGGL(k_match_sweep1<2>, grid, dim3(256), 0, s, b);
   hipLaunchKernelGGL(k_match_decide, dim3((maxN1 + DECIDE_Q - 1) / DECIDE_Q, 1, nb), dim3(1024), 0, s, b, sqminratio, contrDistSq);
   // sweep 2: one round of workgroups dealt out on the device as (undecided block, split); more only if there could be more
   // undecided query blocks than that
-  hipLaunchKernelGGL(k_match_sweep2, dim3(std::max(SWEEP2_NW, (maxN1 + QPB - 1) / QPB), 1, nb), dim3(256), 0, s, b);
+  const dim3 grid2(std::max(NW2, (maxN1 + QPB - 1) / QPB), 1, nb);
+  if (qs == 4) hipLaunchKernelGGL(k_match_sweep2<4>, grid2, dim3(256), 0, s, b);
+  else hipLaunchKernelGGL(k_match_sweep2<2>, grid2, dim3(256), 0, s, b);
   hipLaunchKernelGGL(k_match_events, dim3((maxN1 + 3) / 4, 1, nb), dim3(256), 0, s, b, contrDistSq, nn);
 }
 
