@@ -839,7 +839,24 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
   }
   // the regions of all images of the batch go through one launch set per chunk (a chunk ends when the window arena is
   // full); region order inside an image is kept, outIdx addresses the image's own descriptor buffer
+  // The window size of every region, once for the whole batch (one pool task per image): P = patchImageSize + 2 of the
+  // smoothed branch, 0 for the direct branch (imageToPatchScale <= 0.4, or fast extraction)
   HostMark hm;
+  std::vector<int> winP[MAXB];
+  host_parallel_light(n, [&](int i) {
+    winP[i].resize(regs[i].size());
+    for (size_t r = 0; r < regs[i].size(); r++) {
+      int P = 0;
+      if (!fast) {
+        const modsx_keypoint &k = regs[i][r].det_kp;
+        float mrScale = (float)ceil(k.s * mrSize);
+        int patchImageSize = 2 * int(mrScale) + 1;
+        float i2p = float(patchImageSize) / float(patchSize);
+        if (i2p > 0.4) P = patchImageSize + 2;
+      }
+      winP[i][r] = P;
+    }
+  });
   int curImg = 0, chunkNo = 0;
   size_t curReg = 0;
   while (curImg < n && regs[curImg].empty()) curImg++;
@@ -853,120 +870,141 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       std::map<int, PInfo> pinfo;  // per window size P
       size_t arenaA = 0, arenaB = 0, arenaC = 0;
       bool full = false;
-      int i = curImg;
-      size_t r = curReg;
-      for (; i < n && !full; i++, r = 0) {
-      for (; r < regs[i].size(); r++) {
-        const modsx_keypoint &k = regs[i][r].det_kp;
-        DescJob j;
-        memset(&j, 0, sizeof j);
-        j.img = i;
-        j.outIdx = (int)r;
-        j.x = (float)k.x; j.y = (float)k.y;
-        if (!fast) {
-          float mrScale = (float)ceil(k.s * mrSize);
-          int patchImageSize = 2 * int(mrScale) + 1;
-          float i2p = float(patchImageSize) / float(patchSize);
-          j.i2p = i2p;
-          if (i2p > 0.4) {
-            patchImageSize += 2;
-            const int P = patchImageSize;
-            auto it = pinfo.find(P);
-            if (it == pinfo.end()) {
-              PInfo pi;
-              float sigma = 1.5f * i2p;
-              pi.ksize = blur_ksize(sigma);
-              if (pi.ksize > 512) { set_error("descriptor window too large (blur kernel > 512 taps)"); return MODSX_ERR_ARG; }
-              std::vector<float> kk = gaussian_kernel(pi.ksize, sigma);
-              pi.tapOfs = (int)taps.size();
-              taps.insert(taps.end(), kk.begin(), kk.end());
-              // coordinates of interpolate(smoothed, P/2, P/2, i2p, 0, 0, i2p, patch41): f32 running sums
-              // (helpers.cpp:563-585); rows and columns run the same recurrence (a12 = a21 = 0, ofsx = ofsy)
-              const float o = (float)(P >> 1);
-              pi.touch = check_borders_host(P, P, o, o, i2p, 0.f, 0.f, i2p, 41, 41) ? 1 : 0;
-              float W[41];
-              {
-                float rx = o - (float)20 * 0.f;
-                float WX = rx - (float)20 * i2p;
-                for (int q = 0; q < 41; q++) { W[q] = WX; WX += i2p; }
-              }
-              int x0[41], valid[41];
-              std::vector<int> need;
-              for (int q = 0; q < 41; q++) {
-                if (!pi.touch) {
-                  int x = (int)W[q];
-                  x = x < 0 ? 0 : (x > P - 2 ? P - 2 : x);
-                  x0[q] = x; valid[q] = 1;
-                } else {
-                  int x = (int)floorf(W[q]);
-                  valid[q] = (W[q] >= 0 && x < P - 1) ? 1 : 0;
-                  x0[q] = valid[q] ? x : 0;
-                }
-                if (valid[q]) { need.push_back(x0[q]); need.push_back(x0[q] + 1); }
-              }
-              std::sort(need.begin(), need.end());
-              need.erase(std::unique(need.begin(), need.end()), need.end());
-              if (need.empty()) need.push_back(0);
-              pi.NC = (int)need.size();
-              pi.needOfs = (int)needTab.size();
-              needTab.insert(needTab.end(), need.begin(), need.end());
-              for (int q = 0; q < 41; q++) {
-                int i0 = 0, i1 = 0;
-                if (valid[q]) {
-                  i0 = (int)(std::lower_bound(need.begin(), need.end(), x0[q]) - need.begin());
-                  i1 = (int)(std::lower_bound(need.begin(), need.end(), x0[q] + 1) - need.begin());
-                }
-                needTab.push_back(i0); needTab.push_back(i1); needTab.push_back(x0[q]); needTab.push_back(valid[q]);
-              }
-              pi.coordOfs = (int)coordTab.size();
-              coordTab.insert(coordTab.end(), W, W + 41);
-              {  // tile shapes of the LDS blur kernels: <= BLUR_OUT outputs and <= BLUR_LDS floats per workgroup
-                const int BLUR_LDS = 4992, BLUR_LDS_C = 9984, R = pi.ksize >> 1, NP2 = 2 * ((pi.NC + 1) / 2);
-                const int cap = 2048 / NP2, capC = 4096 / NP2;
-                // the row filter pairs needed columns (2m, 2m+1); they are neighbours in the window by construction
-                // (x0, x0 + 1 of one sample, or a contiguous range) -- if ever not, the job takes the global-memory kernel
-                bool pairs = true;
-                for (int a = 0; a + 1 < pi.NC; a += 2) pairs = pairs && need[a + 1] == need[a] + 1;
-                pi.rows0 = pairs ? std::min(cap, BLUR_LDS / (P + 2 * R)) : 0;
-                if (pi.rows0 < 2) pi.rows0 = 0;
-                if (pi.rows0 > 32 && pi.rows0 < 48 && pi.rows0 < P) pi.rows0 = 32;   // the fused sampling kernel parks 16 columns x <= 32 rows or 8 x <= 64
-                pi.ro1 = 0;
-                const int LS = pi.NC <= 64 ? 64 : 96;   // LDS row stride of the column filter
-                for (int ro = std::min(capC, pi.NC); ro >= 2 && !pi.ro1 && pi.NC <= 96; ro--) {
-                  int span = 0;
-                  for (int a = 0; a < pi.NC; a += ro) span = std::max(span, need[std::min(a + ro, pi.NC) - 1] - need[a] + 2 * R + 1);
-                  if (span * LS <= BLUR_LDS_C) pi.ro1 = ro;
-                }
-                // a window that is one row tile, with <= 64 needed columns and <= 80 block rows (kernels_describe.hip: FC_LS,
-                // FC_ROWS): the fused sampling kernel runs the column filter too
-                if (pi.rows0 >= P && pi.NC <= 64 && P + 2 * R <= 80) pi.ro1 = -1;
-              }
-              it = pinfo.insert({P, pi}).first;
-            }
-            const PInfo &pi = it->second;
-            size_t needA = (size_t)P * P;
-            if (arenaA + needA > ARENA_FLOATS && !jobs.empty()) { full = true; break; }
-            j.P = P;
-            j.a11 = (float)k.a11; j.a12 = (float)k.a12; j.a21 = (float)k.a21; j.a22 = (float)k.a22;
-            j.tapOfs = pi.tapOfs; j.ksize = pi.ksize; j.NC = pi.NC; j.needOfs = pi.needOfs; j.coordOfs = pi.coordOfs;
-            j.touch = pi.touch; j.rows0 = pi.rows0; j.ro1 = pi.ro1;
-            arenaA += needA;
-          } else {
-            j.P = 0;
-            j.a11 = (float)k.a11 * i2p; j.a12 = (float)k.a12 * i2p; j.a21 = (float)k.a21 * i2p; j.a22 = (float)k.a22 * i2p;
-          }
-        } else {
-          double mrScale = (double)mrSize * k.s;
-          int patchImageSize = 2 * int(mrScale) + 1;
-          double i2pd = double(patchImageSize) / (double)patchSize;
-          float curr_sc = i2pd;
-          j.P = 0; j.i2p = curr_sc;
-          j.a11 = (float)k.a11 * curr_sc; j.a12 = (float)k.a12 * curr_sc; j.a21 = (float)k.a21 * curr_sc; j.a22 = (float)k.a22 * curr_sc;
+      // the tables of a window size (taps, needed columns, sample coordinates, tile shapes), built when the size first appears
+      auto make_pinfo = [&](int P, PInfo &pi) -> int {
+        const float i2p = float(P - 2) / float(patchSize);
+        float sigma = 1.5f * i2p;
+        pi.ksize = blur_ksize(sigma);
+        if (pi.ksize > 512) { set_error("descriptor window too large (blur kernel > 512 taps)"); return MODSX_ERR_ARG; }
+        std::vector<float> kk = gaussian_kernel(pi.ksize, sigma);
+        pi.tapOfs = (int)taps.size();
+        taps.insert(taps.end(), kk.begin(), kk.end());
+        // coordinates of interpolate(smoothed, P/2, P/2, i2p, 0, 0, i2p, patch41): f32 running sums
+        // (helpers.cpp:563-585); rows and columns run the same recurrence (a12 = a21 = 0, ofsx = ofsy)
+        const float o = (float)(P >> 1);
+        pi.touch = check_borders_host(P, P, o, o, i2p, 0.f, 0.f, i2p, 41, 41) ? 1 : 0;
+        float W[41];
+        {
+          float rx = o - (float)20 * 0.f;
+          float WX = rx - (float)20 * i2p;
+          for (int q = 0; q < 41; q++) { W[q] = WX; WX += i2p; }
         }
-        jobs.push_back(j);
+        int x0[41], valid[41];
+        std::vector<int> need;
+        for (int q = 0; q < 41; q++) {
+          if (!pi.touch) {
+            int x = (int)W[q];
+            x = x < 0 ? 0 : (x > P - 2 ? P - 2 : x);
+            x0[q] = x; valid[q] = 1;
+          } else {
+            int x = (int)floorf(W[q]);
+            valid[q] = (W[q] >= 0 && x < P - 1) ? 1 : 0;
+            x0[q] = valid[q] ? x : 0;
+          }
+          if (valid[q]) { need.push_back(x0[q]); need.push_back(x0[q] + 1); }
+        }
+        std::sort(need.begin(), need.end());
+        need.erase(std::unique(need.begin(), need.end()), need.end());
+        if (need.empty()) need.push_back(0);
+        pi.NC = (int)need.size();
+        pi.needOfs = (int)needTab.size();
+        needTab.insert(needTab.end(), need.begin(), need.end());
+        for (int q = 0; q < 41; q++) {
+          int i0 = 0, i1 = 0;
+          if (valid[q]) {
+            i0 = (int)(std::lower_bound(need.begin(), need.end(), x0[q]) - need.begin());
+            i1 = (int)(std::lower_bound(need.begin(), need.end(), x0[q] + 1) - need.begin());
+          }
+          needTab.push_back(i0); needTab.push_back(i1); needTab.push_back(x0[q]); needTab.push_back(valid[q]);
+        }
+        pi.coordOfs = (int)coordTab.size();
+        coordTab.insert(coordTab.end(), W, W + 41);
+        {  // tile shapes of the LDS blur kernels: <= BLUR_OUT outputs and <= BLUR_LDS floats per workgroup
+          const int BLUR_LDS = 4992, BLUR_LDS_C = 9984, R = pi.ksize >> 1, NP2 = 2 * ((pi.NC + 1) / 2);
+          const int cap = 2048 / NP2, capC = 4096 / NP2;
+          // the row filter pairs needed columns (2m, 2m+1); they are neighbours in the window by construction
+          // (x0, x0 + 1 of one sample, or a contiguous range) -- if ever not, the job takes the global-memory kernel
+          bool pairs = true;
+          for (int a = 0; a + 1 < pi.NC; a += 2) pairs = pairs && need[a + 1] == need[a] + 1;
+          pi.rows0 = pairs ? std::min(cap, BLUR_LDS / (P + 2 * R)) : 0;
+          if (pi.rows0 < 2) pi.rows0 = 0;
+          if (pi.rows0 > 32 && pi.rows0 < 48 && pi.rows0 < P) pi.rows0 = 32;   // the fused sampling kernel parks 16 columns x <= 32 rows or 8 x <= 64
+          pi.ro1 = 0;
+          const int LS = pi.NC <= 64 ? 64 : 96;   // LDS row stride of the column filter
+          for (int ro = std::min(capC, pi.NC); ro >= 2 && !pi.ro1 && pi.NC <= 96; ro--) {
+            int span = 0;
+            for (int a = 0; a < pi.NC; a += ro) span = std::max(span, need[std::min(a + ro, pi.NC) - 1] - need[a] + 2 * R + 1);
+            if (span * LS <= BLUR_LDS_C) pi.ro1 = ro;
+          }
+          // a window that is one row tile, with <= 64 needed columns and <= 80 block rows (kernels_describe.hip: FC_LS,
+          // FC_ROWS): the fused sampling kernel runs the column filter too
+          if (pi.rows0 >= P && pi.NC <= 64 && P + 2 * R <= 80) pi.ro1 = -1;
+        }
+        return MODSX_OK;
+      };
+      // which regions this chunk takes (a light sequential walk over the window sizes), then the job records in parallel
+      size_t beg[MAXB], end[MAXB], at[MAXB + 1];
+      for (int q = 0; q < n; q++) { beg[q] = end[q] = 0; }
+      int i = curImg;
+      size_t r = curReg, count = 0;
+      for (; i < n && !full; i++, r = 0) {
+        beg[i] = r;
+        for (; r < regs[i].size(); r++) {
+          const int P = winP[i][r];
+          if (P > 0) {
+            if (pinfo.find(P) == pinfo.end()) {
+              PInfo pi;
+              const int prc = make_pinfo(P, pi);
+              if (prc) return prc;
+              pinfo.insert({P, pi});
+            }
+            const size_t needA = (size_t)P * P;
+            if (arenaA + needA > ARENA_FLOATS && count) { full = true; break; }
+            arenaA += needA;
+          }
+          count++;
+        }
+        end[i] = r;
+        if (full) break;
       }
-      if (full) break;
-      }
+      at[0] = 0;
+      for (int q = 0; q < n; q++) at[q + 1] = at[q] + (end[q] - beg[q]);
+      jobs.resize(count);
+      host_parallel_light(n, [&](int q) {
+        for (size_t rr = beg[q]; rr < end[q]; rr++) {
+          const modsx_keypoint &k = regs[q][rr].det_kp;
+          DescJob j;
+          memset(&j, 0, sizeof j);
+          j.img = q;
+          j.outIdx = (int)rr;
+          j.x = (float)k.x; j.y = (float)k.y;
+          if (!fast) {
+            float mrScale = (float)ceil(k.s * mrSize);
+            int patchImageSize = 2 * int(mrScale) + 1;
+            float i2p = float(patchImageSize) / float(patchSize);
+            j.i2p = i2p;
+            const int P = winP[q][rr];
+            if (P > 0) {
+              const PInfo &pi = pinfo.find(P)->second;
+              j.P = P;
+              j.a11 = (float)k.a11; j.a12 = (float)k.a12; j.a21 = (float)k.a21; j.a22 = (float)k.a22;
+              j.tapOfs = pi.tapOfs; j.ksize = pi.ksize; j.NC = pi.NC; j.needOfs = pi.needOfs; j.coordOfs = pi.coordOfs;
+              j.touch = pi.touch; j.rows0 = pi.rows0; j.ro1 = pi.ro1;
+            } else {
+              j.P = 0;
+              j.a11 = (float)k.a11 * i2p; j.a12 = (float)k.a12 * i2p; j.a21 = (float)k.a21 * i2p; j.a22 = (float)k.a22 * i2p;
+            }
+          } else {
+            double mrScale = (double)mrSize * k.s;
+            int patchImageSize = 2 * int(mrScale) + 1;
+            double i2pd = double(patchImageSize) / (double)patchSize;
+            float curr_sc = i2pd;
+            j.P = 0; j.i2p = curr_sc;
+            j.a11 = (float)k.a11 * curr_sc; j.a12 = (float)k.a12 * curr_sc; j.a21 = (float)k.a21 * curr_sc; j.a22 = (float)k.a22 * curr_sc;
+          }
+          jobs[at[q] + (rr - beg[q])] = j;
+        }
+      });
       // (i, r) = first region that did not fit, or i == n
       if (full) { curImg = i; curReg = r; } else { curImg = n; curReg = 0; }
       hm.mark("desc jobs");
@@ -1313,6 +1351,7 @@ int match_pair_group(modsx_ctx *c, const modsx_image *const *imgs1, const modsx_
   const int n = 2 * G;
   const modsx_image *imgs[MAXB];
   for (int g = 0; g < G; g++) { imgs[2 * g] = imgs1[g]; imgs[2 * g + 1] = imgs2[g]; }
+  struct SetScope { SetScope() { host_set_enter(); } ~SetScope() { host_set_leave(); } } setScope;   // a launch set in flight (host pool policy)
   const double t0 = now_ms();
   std::vector<modsx_keypoint> kps[MAXB];
   int rc = detect_keypoints_batch(c, imgs, n, pp.det, nullptr, nullptr, kps);
