@@ -464,13 +464,19 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
                hpfx.back(), (int4 *)c->nmsQueue.p, (unsigned *)c->counter.p + 32, CAND_CAP, (Candidate *)c->cand.p,
                (unsigned *)c->counter.p, CAND_CAP);
   }
+  // the count and the candidates come down behind ONE wait: the records are copied speculatively, as many as the context's
+  // last set had (+ 1/4); a set that holds more costs a second copy for the rest
   if (!c->hMisc.ensure(64)) return MODSX_ERR_NOMEM;
+  const size_t spec = std::min<size_t>(CAND_CAP, c->lastCandCount + c->lastCandCount / 4 + 1024);
+  if (!c->hCand.ensure(spec * sizeof(Candidate))) return MODSX_ERR_NOMEM;
   MX_HIP(hipMemcpyAsync(c->hMisc.p, c->counter.p, 8, hipMemcpyDeviceToHost, s));
+  MX_HIP(hipMemcpyAsync(c->hCand.p, c->cand.p, spec * sizeof(Candidate), hipMemcpyDeviceToHost, s));
   MX_HIP(hipStreamSynchronize(s));
   unsigned cnt = *(unsigned *)c->hMisc.p;
   if (cnt > CAND_CAP || ((unsigned *)c->hMisc.p)[1]) { set_error("candidate buffer overflow"); return MODSX_ERR_NOMEM; }
-  if (!c->hCand.ensure((size_t)std::max(1u, cnt) * sizeof(Candidate))) return MODSX_ERR_NOMEM;
-  if (cnt) {
+  c->lastCandCount = cnt;
+  if (cnt > spec) {
+    if (!c->hCand.ensure((size_t)cnt * sizeof(Candidate))) return MODSX_ERR_NOMEM;   // (re-allocation loses the first part: copy all)
     MX_HIP(hipMemcpyAsync(c->hCand.p, c->cand.p, (size_t)cnt * sizeof(Candidate), hipMemcpyDeviceToHost, s));
     MX_HIP(hipStreamSynchronize(s));
   }

@@ -277,6 +277,7 @@ struct modsx_ctx {
   hipEvent_t ev[8];
   double timings[6];
   mx::Profiler prof;
+  size_t lastCandCount = 0;    // scale-space candidates of the context's last launch set (sizes the speculative download)
   int shardLane = 0;           // lane of the rank's communicator this context issues its collectives on (engine_shard.hip)
   modsx_ctx *peer = nullptr;   // second stream + buffers, created on demand: the two images of a multi-view pair run side by side
 };
