@@ -621,7 +621,12 @@ static MatchLayout match_layout(int n1, int n2, int qs) {
   const int ntiles = (n2 + 31) / 32;
   // one round of workgroups: 3 per CU (the sweeps hold ~150 VGPRs) x 256 CUs; a second, partly filled round costs as much
   // as the first.  Many query blocks (N > 196 k) simply take several rounds.
+#ifdef MATCH_TRACE
+  static const int nwEnv = getenv("MODSX_MATCH_NW") ? atoi(getenv("MODSX_MATCH_NW")) : 0;   // workgroups per round, to trace 1 / 2 / 3 per CU
+  int S = (nwEnv > 0 ? nwEnv : 256 * sweep_wps(qs)) / nQB;
+#else
   int S = (256 * sweep_wps(qs)) / nQB;
+#endif
   if (S > ntiles / CHUNK) S = ntiles / CHUNK;     // at least one chunk per split
   if (S < 1) S = 1;
   int tps = (ntiles + S - 1) / S;
@@ -668,13 +673,32 @@ __global__ __launch_bounds__(256) void k_match_pack(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
   pack_body(P.d1, P.g.n1, P.norm1, P.d2, P.g.n2, P.slots, P.tiles, P.cst, P.norm2);
 }
+#ifdef MATCH_TRACE
+// debugging aid (tools/trace_match.py): when and where every workgroup of the last k_match_sweep1 launch ran
+__device__ unsigned long long g_mtrace[16384][4];
+#endif
 template <int QS>
 __global__ __launch_bounds__(256, sweep_wps(QS)) void k_match_sweep1(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
   if ((int)blockIdx.x * qpb_of(QS) >= P.g.n1 || (int)blockIdx.y >= P.g.S) return;
+#ifdef MATCH_TRACE
+  const int wg = blockIdx.x + gridDim.x * blockIdx.y;
+  if (threadIdx.x == 0 && wg < 16384) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_mtrace[wg][0] = wall_clock64();
+    g_mtrace[wg][2] = ((unsigned long long)xcc << 32) | hw;
+    g_mtrace[wg][3] = __builtin_readcyclecounter();
+  }
+#endif
   SweepArgs A;
   A.d1 = P.d1; A.norm1 = P.norm1; A.tiles = P.tiles; A.cst = P.cst; A.g = P.g; A.partial = P.partial;
   sweep_body<0, QS>(A);
+#ifdef MATCH_TRACE
+  __syncthreads();
+  if (threadIdx.x == 0 && wg < 16384) { g_mtrace[wg][1] = wall_clock64(); g_mtrace[wg][3] = __builtin_readcyclecounter() - g_mtrace[wg][3]; }
+#endif
 }
 __global__ __launch_bounds__(1024) void k_match_decide(MatchBatch b, double sqminratio, double contrDistSq) {
   const MatchProblem &P = b.p[blockIdx.z];
@@ -742,3 +766,9 @@ void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, i
 }
 
 }  // namespace mx
+
+#ifdef MATCH_TRACE
+extern "C" __attribute__((visibility("default"))) int modsx_debug_match_trace(unsigned long long *out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mx::g_mtrace), (size_t)n * 32, 0, hipMemcpyDeviceToHost);
+}
+#endif
