@@ -88,6 +88,8 @@ int duplicate_filtering(const double *pts, const double *key, int T, double r, i
 int ransac_h(const double *u, int len, double th, double conf, int max_sam, double *H, unsigned char *inl, int *data_out,
              int oriented_constraint, int doSymCheck, unsigned seed0, double *scoreJ, int error_type = 0);
 void hds_sym(const double *u, const double *H, double *p, int len, bool takeMax);
+void hds_sym_setup(const double *H, double *Hinv, double *H1);                 // hds_sym = setup + with
+void hds_sym_with(const double *u, const double *Hinv, const double *H1, double *p, int len, bool takeMax);
 int save_regions(const char *path, const modsx_region_class *classes, int nclasses);
 int load_regions(const char *path, const char *det_name, const char *desc_name, std::vector<modsx_region> &regs,
                  std::vector<float> &desc, int *dim, std::string *found_det, std::string *found_desc);

@@ -4,6 +4,8 @@
 //   NaiveHCheck                              matching/matching.cpp:1171-1200
 //   H_LAF_check                              matching/matching.cpp:251-309
 #include <math.h>
+#include <stdint.h>
+#include <string.h>
 #include <algorithm>
 #include "engine_api.hpp"
 
@@ -13,35 +15,65 @@ namespace mx {
 // pass; the same libstdc++ introsort on the same key sequence yields the same permutation.
 int duplicate_filtering(const double *pts, const double *key, int T, double r, int do_sort, int *order,
                         unsigned char *keep) {
-  struct E { double key; int i; };
-  std::vector<E> v(T);
-  for (int i = 0; i < T; i++) { v[i].key = key ? key[i] : 0; v[i].i = i; }
   if (r <= 0) {
     for (int i = 0; i < T; i++) { order[i] = i; keep[i] = 1; }
     return T;
   }
-  if (do_sort) std::sort(v.begin(), v.end(), [](E a, E b) { return fabs(a.key) < fabs(b.key); });
+  // sorted position -> tentative.  The permutation std::sort produces depends only on the outcomes of its comparisons, so
+  // the elements may be anything that compares the same way.  The ratios are f32 quotients widened to f64 (29 zero bits at
+  // the bottom of the mantissa): |key| then fits, with the index below it, into one 64-bit word whose top 35 bits order
+  // like the doubles do -- half the bytes to move and an integer comparison.  Anything else (a key with low mantissa bits,
+  // a NaN -- for which the double comparison is false both ways) takes the 16-byte elements.
+  struct E { double key; int i; };
+  static thread_local std::vector<E> v;
+  static thread_local std::vector<uint64_t> w;
+  bool packed = do_sort && key && T < (1 << 29);
+  if (packed) {
+    w.resize(T);
+    for (int i = 0; i < T; i++) {
+      uint64_t bits;
+      memcpy(&bits, &key[i], 8);
+      bits &= ~(1ull << 63);                                   // fabs
+      if ((bits & ((1ull << 29) - 1)) || bits > 0x7ff0000000000000ull) { packed = false; break; }
+      w[i] = bits | (uint64_t)i;
+    }
+  }
+  if (packed) {
+    std::sort(w.begin(), w.end(), [](uint64_t a, uint64_t b) { return (a >> 29) < (b >> 29); });
+    for (int i = 0; i < T; i++) order[i] = (int)(w[i] & ((1u << 29) - 1));
+  } else {
+    v.resize(T);
+    for (int i = 0; i < T; i++) { v[i].key = key ? key[i] : 0; v[i].i = i; }
+    if (do_sort) std::sort(v.begin(), v.end(), [](E a, E b) { return fabs(a.key) < fabs(b.key); });
+    for (int i = 0; i < T; i++) order[i] = v[i].i;
+  }
   const double r_sq = r * r;
   // Same greedy pass as the reference's O(T^2) double loop (matching.cpp:3017-3036), with a uniform grid
   // over the image-1 coordinates so that only tentatives within +-1 cell (cell = r) of i are visited;
   // the visiting order inside the j-loop is irrelevant to the result (j is only ever flagged, and a j is
   // flagged by the first unflagged i < j that is within r in both images -- the flag itself is all that
   // later iterations observe).
-  std::vector<double> P((size_t)T * 4);
-  double minx = 0, miny = 0;
+  static thread_local std::vector<double> P;
+  static thread_local std::vector<char> uniq;
+  P.resize((size_t)T * 4);
+  double minx = 0, miny = 0, maxx = 0, maxy = 0;
   bool finite = true;
   for (int i = 0; i < T; i++) {
-    const double *p = pts + 4 * v[i].i;
+    const double *p = pts + 4 * order[i];
     for (int q = 0; q < 4; q++) { P[4 * (size_t)i + q] = p[q]; finite = finite && std::isfinite(p[q]); }
-    if (i == 0 || p[0] < minx) minx = p[0];
-    if (i == 0 || p[1] < miny) miny = p[1];
+    if (i == 0) { minx = maxx = p[0]; miny = maxy = p[1]; }
+    if (p[0] < minx) minx = p[0];
+    if (p[1] < miny) miny = p[1];
+    if (p[0] > maxx) maxx = p[0];
+    if (p[1] > maxy) maxy = p[1];
   }
-  std::vector<char> uniq(T, 1);
-  double maxx = minx, maxy = miny;
-  for (int i = 0; i < T; i++) { maxx = std::max(maxx, P[4 * (size_t)i]); maxy = std::max(maxy, P[4 * (size_t)i + 1]); }
-  // cell edge >= r (so +-1 cell covers the radius) and at most 1024 cells per side.  Multi-view tentatives cluster -- a dozen per
-  // scene point -- so cells of the radius itself matter: with 96 cells per side the pass was 2 ms of a 12 k-tentative pair
-  const double cell_sz = std::max(r, std::max(maxx - minx, maxy - miny) / 1024.0);
+  uniq.assign(T, 1);
+  // cell edge a little above r (two points within r of each other are then in the same or in adjacent cells whatever the
+  // rounding of the cell index: the index only has to be monotone and to move by at most one over a distance r) and at most
+  // 1024 cells per side.  Multi-view tentatives cluster -- a dozen per scene point -- so cells of the radius itself matter:
+  // with 96 cells per side the pass was 2 ms of a 12 k-tentative pair
+  const double cell_sz = std::max(r * 1.001, std::max(maxx - minx, maxy - miny) / 1024.0);
+  const double inv_cell = 1.0 / cell_sz;
   const double gw = (maxx - minx) / cell_sz, gh = (maxy - miny) / cell_sz;
   if (!finite || T < 64 || gw > 8192 || gh > 8192) {
     for (int i = 0; i < T; i++) {
@@ -59,39 +91,34 @@ int duplicate_filtering(const double *pts, const double *key, int T, double r, i
       }
     }
   } else {
-    const int GW = (int)gw + 2, GH = (int)gh + 2;
-    std::vector<int> cellOf(T), start((size_t)GW * GH + 1, 0), items(T);
-    for (int i = 0; i < T; i++) {
-      int cx = (int)((P[4 * (size_t)i] - minx) / cell_sz), cy = (int)((P[4 * (size_t)i + 1] - miny) / cell_sz);
-      cellOf[i] = cy * GW + cx;
-      start[cellOf[i] + 1]++;
-    }
-    for (size_t q = 1; q < start.size(); q++) start[q] += start[q - 1];
-    std::vector<int> fill(start.begin(), start.end() - 1);
-    for (int i = 0; i < T; i++) items[fill[cellOf[i]]++] = i;  // ascending i inside each cell
-    for (int i = 0; i < T; i++) {
-      if (!uniq[i]) continue;
-      const double *p1 = &P[4 * (size_t)i];
-      const int cx = cellOf[i] % GW, cy = cellOf[i] / GW;
-      for (int yy = std::max(0, cy - 1); yy <= std::min(GH - 1, cy + 1); yy++)
-        for (int xx = std::max(0, cx - 1); xx <= std::min(GW - 1, cx + 1); xx++) {
-          const int cell = yy * GW + xx;
-          for (int q = start[cell]; q < start[cell + 1]; q++) {
-            const int j = items[q];
-            if (j <= i || !uniq[j]) continue;
-            const double *p2 = &P[4 * (size_t)j];
+    // The same outcome, one tentative at a time: j is dropped iff a KEPT i < j lies within r of it in both images (a dropped
+    // i flags nothing, and whether i is kept is settled before any j > i is looked at).  So only kept tentatives enter the
+    // grid -- a list per cell, threaded through next[] -- and the look-up of j stops at the first hit.
+    const int GW = (int)gw + 3, GH = (int)gh + 3;
+    static thread_local std::vector<int> head, next;
+    head.assign((size_t)GW * GH, -1);
+    next.resize(T);
+    for (int j = 0; j < T; j++) {
+      const double *p2 = &P[4 * (size_t)j];
+      const int cx = (int)((p2[0] - minx) * inv_cell), cy = (int)((p2[1] - miny) * inv_cell);
+      bool hit = false;
+      for (int yy = std::max(0, cy - 1); yy <= std::min(GH - 1, cy + 1) && !hit; yy++)
+        for (int xx = std::max(0, cx - 1); xx <= std::min(GW - 1, cx + 1) && !hit; xx++)
+          for (int i = head[yy * GW + xx]; i >= 0; i = next[i]) {
+            const double *p1 = &P[4 * (size_t)i];
             double dx = p1[0] - p2[0], dy = p1[1] - p2[1];
-            double d1 = dx * dx + dy * dy;
+            const double d1 = dx * dx + dy * dy;
             if (d1 > r_sq) continue;
             dx = p1[2] - p2[2]; dy = p1[3] - p2[3];
-            double d2 = dx * dx + dy * dy;
-            if (d2 <= r_sq) uniq[j] = 0;
+            const double d2 = dx * dx + dy * dy;
+            if (d2 <= r_sq) { hit = true; break; }
           }
-        }
+      if (hit) uniq[j] = 0;
+      else { const int c = cy * GW + cx; next[j] = head[c]; head[c] = j; }
     }
   }
   int kept = 0;
-  for (int i = 0; i < T; i++) { order[i] = v[i].i; keep[i] = uniq[i]; kept += uniq[i]; }
+  for (int i = 0; i < T; i++) { keep[i] = uniq[i]; kept += uniq[i]; }
   return kept;
 }
 
@@ -140,6 +167,8 @@ int loransac_h(const double *pts, const double *laf1, const double *laf2, int T,
   const double affErr = 3.0 * HLAFCoef * err_threshold;
   std::vector<int> kept;
   if (affErr > 0) {
+    double HsT[9], Hs1[9];
+    hds_sym_setup(Hloran, HsT, Hs1);
     for (int i : ril) {
       double u[18], err[3];
       const double *A = laf1 + 5 * i, *B = laf2 + 5 * i;
@@ -149,7 +178,7 @@ int loransac_h(const double *pts, const double *laf1, const double *laf2, int T,
       u[9] = u[3] + 3.0 * B[1] * B[4]; u[10] = u[4] + 3.0 * B[3] * B[4]; u[11] = 1.0;
       u[12] = u[0] + 3.0 * A[0] * A[4]; u[13] = u[1] + 3.0 * A[2] * A[4]; u[14] = 1.0;
       u[15] = u[3] + 3.0 * B[0] * B[4]; u[16] = u[4] + 3.0 * B[2] * B[4]; u[17] = 1.0;
-      hds_sym(u, Hloran, err, 3, true);
+      hds_sym_with(u, HsT, Hs1, err, 3, true);
       double sumErr = sqrt(err[0] + err[1] + err[2]);
       if (!(sumErr > affErr)) kept.push_back(i);
     }

@@ -19,10 +19,15 @@
 
 namespace mx {
 
-// HDsSym / HDsSymMax, Htools.c:199-279
-void hds_sym(const double *u, const double *H, double *p, int len, bool takeMax) {
-  double Hinv[9] = {H[0], H[3], H[6], H[1], H[4], H[7], H[2], H[5], H[8]}, H1[9];
-  if (!inv3_lu(Hinv, H1)) memcpy(H1, Hinv, sizeof H1);  // minv leaves the matrix on a singular pivot
+// HDsSym / HDsSymMax, Htools.c:199-279.  The reference inverts H inside every call; hds_sym_setup + hds_sym_with are the same
+// call split in two for callers that evaluate many small point sets against one H (the LAF check of the verifier: three
+// points per call) -- the inverse of the same matrix is the same nine doubles every time.
+void hds_sym_setup(const double *H, double *Hinv, double *H1) {
+  const double Ht[9] = {H[0], H[3], H[6], H[1], H[4], H[7], H[2], H[5], H[8]};
+  memcpy(Hinv, Ht, sizeof Ht);
+  if (!inv3_lu(Hinv, H1)) memcpy(H1, Hinv, sizeof Ht);  // minv leaves the matrix on a singular pivot
+}
+void hds_sym_with(const double *u, const double *Hinv, const double *H1, double *p, int len, bool takeMax) {
   for (int i = 0; i < len; i++) {
     double a = H1[6] * u[0] + H1[7] * u[1] + H1[8];
     double b = Hinv[6] * u[3] + Hinv[7] * u[4] + Hinv[8];
@@ -37,6 +42,11 @@ void hds_sym(const double *u, const double *H, double *p, int len, bool takeMax)
     *p++ = takeMax ? (d1 < d2 ? d2 : d1) : d1 + d2;
     u += 6;
   }
+}
+void hds_sym(const double *u, const double *H, double *p, int len, bool takeMax) {
+  double Hinv[9], H1[9];
+  hds_sym_setup(H, Hinv, H1);
+  hds_sym_with(u, Hinv, H1, p, len, takeMax);
 }
 
 struct Ransac {
@@ -70,7 +80,7 @@ struct Ransac {
     double dth = (ths - th) / (steps);
     maxS = inlidxs(errs[4], len, th, inliers);
     if (maxS.I < 4) return S;
-    S = inlidxs(errs[4], len, th * 2, inliers);
+    S.I = inl_list(errs[4], len, th * 2, inliers);   // only the count and the indices of these wider sets are read
     memcpy(h, H, sizeof h);  // defined start value; overwritten below since S.I >= 4
     u2h(u, inliers, S.I, h, buffer.data());
     for (int it = 0; it < steps; it++) {
@@ -80,7 +90,7 @@ struct Ransac {
       int ret = ht.contains(hash, (int)Ss.I, iterID);
       if (ret != -1 && ret != iterID) { S.I = 0; S.J = 0; return S; }
       if (ret == -1) ht.insert(hash, (int)Ss.I, iterID);
-      S = inlidxs(d, len, ths * 2, inliers);
+      S.I = inl_list(d, len, ths * 2, inliers);
       if (score_less(maxS, Ss)) {
         maxS = Ss;
         errs[1] = errs[0]; errs[0] = d; d = errs[1];
@@ -145,7 +155,7 @@ int ransac_h(const double *u, int len, double th, double conf, int max_sam, doub
   for (int i = 0; i < len; i++) pool[i] = i;
   // the reference linearises all points once (lin_hg into Z) and reads Z for the samples and inside HDs; both re-form the few
   // products they need from u instead -- the same values -- which saves building and streaming 144 bytes per point
-  R.buffer.resize((size_t)len * 18);
+  // (u2h no longer builds the 2len x 9 matrix: no buffer)
   R.err.assign((size_t)len * 4, 0.0);
   std::vector<double> d_check(len);
   for (int i = 0; i < 4; i++) R.errs[i] = R.err.data() + (size_t)i * len;
@@ -184,10 +194,10 @@ int ransac_h(const double *u, int len, double th, double conf, int max_sam, doub
   };
   auto local_opt = [&]() {  // case 4 with __LSQ_BEFORE_LO__
     d = R.errs[0];
-    S = inlidxs(R.errs[4], len, 4 * th * 2, inliers.data());
+    S.I = inl_list(R.errs[4], len, 4 * th * 2, inliers.data());
     u2h(u, inliers.data(), S.I, h, R.buffer.data());
     R.errf(h, d);
-    S = inlidxs(d, len, th, inliers.data());
+    S.I = inl_list(d, len, th, inliers.data());
     S = R.inHrani(inliers.data(), (int)S.I, th, h, 10, &iterID);
   };
 

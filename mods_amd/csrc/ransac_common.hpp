@@ -54,15 +54,23 @@ static inline bool score_less(const Score &a, const Score &b) { return a.J < b.J
 static inline Score inlidxs(const double *err, int len, double th, int *inl) {
   Score s = {0, 0};
   double term[256];
+  unsigned cnt = 0;
   for (int i0 = 0; i0 < len; i0 += 256) {
     const int m = len - i0 < 256 ? len - i0 : 256;
     for (int i = 0; i < m; ++i) term[i] = trunc_quad(err[i0 + i], th);
-    for (int i = 0; i < m; ++i) {
-      s.J += term[i];
-      if (err[i0 + i] <= th) { inl[s.I] = i0 + i; ++(s.I); }
-    }
+    for (int i = 0; i < m; ++i) s.J += term[i];
+    // the index list without a branch per point (a third of the points are outliers in no particular order): the slot is
+    // written every time and kept when the point is an inlier; inl[] has len entries and cnt <= i0 + i
+    for (int i = 0; i < m; ++i) { inl[cnt] = i0 + i; cnt += err[i0 + i] <= th; }
   }
+  s.I = cnt;
   return s;
+}
+// the same list where the caller reads only the count and the indices (S.I of exp_iterHcustom's 2 * th sets): no score sum
+static inline unsigned inl_list(const double *err, int len, double th, int *inl) {
+  unsigned cnt = 0;
+  for (int i = 0; i < len; ++i) { inl[cnt] = i; cnt += err[i] <= th; }
+  return cnt;
 }
 // rtools.c:202-225
 static inline int nsamples(int ninl, int ptNum, int samsiz, double conf) {
@@ -312,6 +320,66 @@ static inline void denormH(double *F, const double *A1, const double *A2) {
   }
 }
 
+// lin_hgN + cov_mat_hgN in one pass, without the 2len x 9 matrix in memory: the 45 sums of Z^T Z, each with its terms in row
+// order (row 2i of point i, then row 2i + 1).  With b = (b0, b1, 1) the normalised image-2 point and n0 = -a0, n1 = -a1 the
+// negated normalised image-1 coordinates, row 2i holds b in columns 0, 3, 6 and n0 * b in columns 2, 5, 8; row 2i + 1 holds b
+// in columns 1, 4, 7 and n1 * b in columns 2, 5, 8 (lin_hgN above; products with the structural zeros are left out as in
+// cov_mat_hgN).  So
+//   * the b x b block is the same sequence of terms for both rows: entries (0|3|6, 0|3|6) and (1|4|7, 1|4|7) are one sum,
+//   * the cross blocks (2|5|8, 0|3|6) and (2|5|8, 1|4|7) are (n0 b) x b and (n1 b) x b,
+//   * the (2|5|8, 2|5|8) block takes the row-2i term and then the row-(2i+1) term of every point.
+// Each product is formed from the same two factors as Z[k][i] * Z[k][j] (multiplication commutes exactly), 1 * x and x * 1
+// are x, and every sum adds its terms in the reference's order: the matrix is bit-identical to cov_mat(lin_hgN(...)).
+typedef double cov_v4 __attribute__((vector_size(32)));
+static inline void cov_hgN_fused(double *Cv, const double *u, const int *inl, int len, const double *A1, const double *A2) {
+  const cov_v4 zero = {0, 0, 0, 0};
+  cov_v4 BB = zero;                     // b0 b0, b1 b0, b1 b1, b0 (= 1 * b0)
+  double sB1 = 0, sOne = 0;             // b1 (= 1 * b1), 1 * 1
+  cov_v4 X0[3] = {zero, zero, zero};    // row 2i:     b0 * C0, b1 * C0, 1 * C0 with C0 = (n0 b0, n0 b1, n0, -)
+  cov_v4 X1[3] = {zero, zero, zero};    // row 2i + 1: the same with n1
+  cov_v4 S1 = zero;                     // (2,2) (5,2) (5,5) (8,2)
+  double s85 = 0, s88 = 0;              // (8,5) (8,8)
+  const double a1s = A1[0], a1x = A1[1], a1y = A1[2], a2s = A2[0], a2x = A2[1], a2y = A2[2];
+  for (int i = 0; i < len; i++) {
+    const double *s = u + 6 * inl[i];
+    const double a0 = s[0] * a1s + a1x, a1 = s[1] * a1s + a1y;
+    const double b0 = s[3] * a2s + a2x, b1 = s[4] * a2s + a2y;
+    const double n0 = -a0, n1 = -a1;
+    const cov_v4 Bv = {b0, b1, 1.0, 0.0};
+    const cov_v4 C0 = (cov_v4){n0, n0, n0, 0.0} * Bv, C1 = (cov_v4){n1, n1, n1, 0.0} * Bv;   // n * 1 = n
+    BB += (cov_v4){b0, b1, b1, 1.0} * (cov_v4){b0, b0, b1, b0};
+    sB1 += b1; sOne += 1.0;
+    const cov_v4 vb0 = {b0, b0, b0, b0}, vb1 = {b1, b1, b1, b1};
+    X0[0] += vb0 * C0; X0[1] += vb1 * C0; X0[2] += C0;
+    X1[0] += vb0 * C1; X1[1] += vb1 * C1; X1[2] += C1;
+    // the shared block: z2 z2, z5 z2, z5 z5, z8 z2 | z8 z5, z8 z8 -- row 2i first
+    const cov_v4 L0 = {C0[0], C0[1], C0[1], C0[2]}, R0 = {C0[0], C0[0], C0[1], C0[0]};
+    const cov_v4 L1 = {C1[0], C1[1], C1[1], C1[2]}, R1 = {C1[0], C1[0], C1[1], C1[0]};
+    S1 += L0 * R0;
+    S1 += L1 * R1;
+    s85 += C0[2] * C0[1]; s85 += C1[2] * C1[1];
+    s88 += C0[2] * C0[2]; s88 += C1[2] * C1[2];
+  }
+  double acc[9][9];
+  for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) acc[i][j] = 0;
+  for (int o = 0; o < 2; o++) {          // columns 0,3,6 (row 2i) and 1,4,7 (row 2i + 1)
+    const int c0 = o, c1 = 3 + o, c2 = 6 + o;
+    acc[c0][c0] = BB[0]; acc[c1][c0] = BB[1]; acc[c1][c1] = BB[2];
+    acc[c2][c0] = BB[3]; acc[c2][c1] = sB1; acc[c2][c2] = sOne;
+    const cov_v4 *X = o ? X1 : X0;
+    // b_l * (n b_k): entry (max, min) of columns (2 | 5 | 8)[k] and c_l
+    const int cc[3] = {2, 5, 8}, cb[3] = {c0, c1, c2};
+    for (int l = 0; l < 3; l++)
+      for (int k = 0; k < 3; k++) {
+        const int i = cc[k] > cb[l] ? cc[k] : cb[l], j = cc[k] > cb[l] ? cb[l] : cc[k];
+        acc[i][j] = X[l][k];
+      }
+  }
+  acc[2][2] = S1[0]; acc[5][2] = S1[1]; acc[5][5] = S1[2]; acc[8][2] = S1[3]; acc[8][5] = s85; acc[8][8] = s88;
+  for (int i = 0; i < 9; i++)
+    for (int j = 0; j <= i; j++) { Cv[9 * i + j] = acc[i][j]; Cv[i + 9 * j] = acc[i][j]; }
+}
+
 // u2h, Htools.c:98-130
 static inline void u2h(const double *u, const int *inl, int len, double *H, double *buffer) {
   if (len < 4) return;
@@ -330,10 +398,9 @@ static inline void u2h(const double *u, const int *inl, int len, double *H, doub
     return;
   }
   double A1[3], A2[3], V[81], ev[9];
-  double *Z = buffer;
+  (void)buffer;
   normu(u, inl, len, A1, A2);
-  lin_hgN(u, Z, inl, len, A1, A2);
-  cov_mat_hgN(V, Z, len);
+  cov_hgN_fused(V, u, inl, len, A1, A2);
   smallest_eigvec9(V, ev);
   memcpy(H, ev, 9 * sizeof(double));
   denormH(H, A1, A2);

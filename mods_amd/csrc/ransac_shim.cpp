@@ -84,7 +84,9 @@ void HDsidx(const double *lin, const double *u6, const double *H, double *p, int
 void HDsSym(const double *lin, const double *u, const double *H, double *p, int len) { (void)lin; mx::hds_sym(u, H, p, len, false); }
 void HDsSymMax(const double *lin, const double *u, const double *H, double *p, int len) { (void)lin; mx::hds_sym(u, H, p, len, true); }
 static void hds_sym_subset(const double *u6, const double *H, double *p, const int *pts, int ni, bool takeMax) {
-  for (int i = 0; i < ni; i++) mx::hds_sym(u6 + 6 * pts[i], H, p + i, 1, takeMax);
+  double HT[9], H1[9];
+  mx::hds_sym_setup(H, HT, H1);
+  for (int i = 0; i < ni; i++) mx::hds_sym_with(u6 + 6 * pts[i], HT, H1, p + i, 1, takeMax);
 }
 void HDsiSym(const double *lin, const double *u6, const double *H, double *p, int len, int *pts, int ni) { (void)lin; (void)len; hds_sym_subset(u6, H, p, pts, ni, false); }
 void HDsiSymMax(const double *lin, const double *u6, const double *H, double *p, int len, int *pts, int ni) { (void)lin; (void)len; hds_sym_subset(u6, H, p, pts, ni, true); }
