@@ -190,23 +190,42 @@ static inline void lin_hg(const double *u, double *dst, const int *inl, int len)
   }
 }
 
-// normu, utools.c:7-52
+// normu, utools.c:7-52.  The two sums of distances keep their order; the distances themselves (two square roots per point)
+// are formed four points at a time in front of the additions.
 static inline void normu(const double *u, const int *inl, int len, double *A1, double *A2) {
+  typedef double nv4 __attribute__((vector_size(32)));
   for (int j = 0; j < 3; j++) { A1[j] = 0; A2[j] = 0; }
-  for (int j = 0; j < len; j++) {
-    const double *p = u + 6 * inl[j];
-    A1[1] += p[0]; A1[2] += p[1];
-    A2[1] += p[3]; A2[2] += p[4];
+  {
+    double x1 = 0, y1 = 0, x2 = 0, y2 = 0;    // in registers: A1 / A2 may alias u to the compiler, a store and a load per addition
+    for (int j = 0; j < len; j++) {
+      const double *p = u + 6 * inl[j];
+      x1 += p[0]; y1 += p[1];
+      x2 += p[3]; y2 += p[4];
+    }
+    A1[1] = x1; A1[2] = y1; A2[1] = x2; A2[2] = y2;
   }
   if (len > 0)
     for (int i = 1; i < 3; i++) { A1[i] /= len; A2[i] /= len; }
-  for (int j = 0; j < len; j++) {
+  const nv4 m1x = {A1[1], A1[1], A1[1], A1[1]}, m1y = {A1[2], A1[2], A1[2], A1[2]};
+  const nv4 m2x = {A2[1], A2[1], A2[1], A2[1]}, m2y = {A2[2], A2[2], A2[2], A2[2]};
+  double s1 = A1[0], s2 = A2[0];
+  int j = 0;
+  for (; j + 4 <= len; j += 4) {
+    const double *p0 = u + 6 * inl[j], *p1 = u + 6 * inl[j + 1], *p2 = u + 6 * inl[j + 2], *p3 = u + 6 * inl[j + 3];
+    const nv4 ax = (nv4){p0[0], p1[0], p2[0], p3[0]} - m1x, ay = (nv4){p0[1], p1[1], p2[1], p3[1]} - m1y;
+    const nv4 bx = (nv4){p0[3], p1[3], p2[3], p3[3]} - m2x, by = (nv4){p0[4], p1[4], p2[4], p3[4]} - m2y;
+    nv4 q1 = ax * ax + ay * ay, q2 = bx * bx + by * by;
+    for (int k = 0; k < 4; k++) { q1[k] = sqrt(q1[k]); q2[k] = sqrt(q2[k]); }   // one vsqrtpd each
+    for (int k = 0; k < 4; k++) { s1 += q1[k]; s2 += q2[k]; }
+  }
+  for (; j < len; j++) {
     const double *p = u + 6 * inl[j];
     double a = p[0] - A1[1], b = p[1] - A1[2];
-    A1[0] += sqrt(a * a + b * b);
+    s1 += sqrt(a * a + b * b);
     a = p[3] - A2[1]; b = p[4] - A2[2];
-    A2[0] += sqrt(a * a + b * b);
+    s2 += sqrt(a * a + b * b);
   }
+  A1[0] = s1; A2[0] = s2;
   if (A1[0] != 0) A1[0] = len * sqrt(2) / A1[0];
   if (A2[0] != 0) A2[0] = len * sqrt(2) / A2[0];
   A1[1] *= -A1[0]; A1[2] *= -A1[0];
@@ -412,50 +431,67 @@ static inline void u2h(const double *u, const int *inl, int len, double *H, doub
 // Four points per step on 256-bit vectors (two 128-bit halves without AVX): every lane runs the scalar expression of its own
 // point -- same operations, same order, IEEE add / mul / div, no contraction -- so the values are those of the scalar loop.
 typedef double hds_v4 __attribute__((vector_size(32)));
+typedef double hds_v8 __attribute__((vector_size(64)));
 static inline hds_v4 hds_ld4(const double *p, size_t stride) { return (hds_v4){p[0], p[stride], p[2 * stride], p[3 * stride]}; }
+__attribute__((target("avx512f"), always_inline)) static inline hds_v8 hds_ld8(const double *p, size_t stride) {
+  return (hds_v8){p[0], p[stride], p[2 * stride], p[3 * stride], p[4 * stride], p[5 * stride], p[6 * stride], p[7 * stride]};
+}
+// the vector loop of HDs for W points per step: every lane runs the scalar expression of its own point.
+// the linearisation of a point (lin_hg: x'_j, 0, -x x'_j / 0, x'_j, -y x'_j) is re-formed from u -- the same products,
+// rounded the same way -- instead of being streamed from the 144-byte row of `lin` (the loop is memory-bound otherwise)
+#define HDS_VECTOR_LOOP(V, W, LD, ZERO) \
+  for (; i + W <= len; i += W) { \
+    const double *uu = u + (size_t)6 * i; \
+    const V u0 = LD(uu, 6), u1 = LD(uu + 1, 6), u3 = LD(uu + 3, 6), u4 = LD(uu + 4, 6), u5 = LD(uu + 5, 6); \
+    const V zero = ZERO; \
+    const V xs[3] = {u3, u4, u5}; \
+    V r1 = zero, r2 = zero; \
+    for (int j = 0; j < 3; j++) { \
+      r1 += H[3 * j] * xs[j]; r1 += H[3 * j + 1] * zero; r1 += H[3 * j + 2] * (-u0 * xs[j]); \
+      r2 += H[3 * j] * zero; r2 += H[3 * j + 1] * xs[j]; r2 += H[3 * j + 2] * (-u1 * xs[j]); \
+    } \
+    const V a = H[0] - H[2] * u0; \
+    const V b = H[3] - H[5] * u0; \
+    const V c = -H[8] - H[2] * u3 - H[5] * u4; \
+    const V d = H[1] - H[2] * u1; \
+    const V e = H[4] - H[5] * u1; \
+    V pJ[8]; \
+    { \
+      const V a2 = a * a, b2 = b * b, c2 = c * c, d2 = d * d, e2 = e * e; \
+      const V c2pd2 = c2 + d2, ab = a * b, de = d * e; \
+      const V Q = c * (c2pd2 + e2); \
+      pJ[0] = -b * de + a * (c2 + e2); \
+      pJ[1] = b * c2pd2 - a * de; \
+      pJ[2] = Q; \
+      pJ[3] = -c * (a * d + b * e); \
+      pJ[4] = d * (b2 + c2) - ab * e; \
+      pJ[5] = -ab * d + e * (a2 + c2); \
+      pJ[6] = pJ[3]; \
+      pJ[7] = c * (a2 + b2 + c2); \
+      const V N = a * pJ[0] + b * pJ[1] + c * pJ[2]; \
+      for (int q = 0; q < 8; q++) pJ[q] /= N; \
+    } \
+    V acc = ZERO; \
+    for (int j = 0; j < 4; j++) { \
+      const V t = pJ[j] * r1 + pJ[j + 4] * r2; \
+      acc += t * t; \
+    } \
+    for (int k = 0; k < W; k++) p[i + k] = acc[k]; \
+  }
+// eight points per step where the CPU has 512-bit vectors (the seven divisions per point are what the loop costs)
+__attribute__((target("avx512f"))) static inline int hds_loop8(const double *u, const double *H, double *p, int len) {
+  int i = 0;
+  HDS_VECTOR_LOOP(hds_v8, 8, hds_ld8, ((hds_v8){0, 0, 0, 0, 0, 0, 0, 0}))
+  return i;
+}
 static inline void HDs(const double *lin, const double *u, const double *H, double *p, int len) {
   (void)lin;
   int i = 0;
-  for (; i + 4 <= len; i += 4) {
-    const double *uu = u + (size_t)6 * i;
-    const hds_v4 u0 = hds_ld4(uu, 6), u1 = hds_ld4(uu + 1, 6), u3 = hds_ld4(uu + 3, 6), u4 = hds_ld4(uu + 4, 6), u5 = hds_ld4(uu + 5, 6);
-    // the linearisation of the point (lin_hg: x'_j, 0, -x x'_j / 0, x'_j, -y x'_j) is re-formed from u -- the same products,
-    // rounded the same way -- instead of being streamed from the 144-byte row of `lin` (the loop is memory-bound otherwise)
-    const hds_v4 zero = {0, 0, 0, 0};
-    const hds_v4 xs[3] = {u3, u4, u5};
-    hds_v4 r1 = zero, r2 = zero;
-    for (int j = 0; j < 3; j++) {
-      r1 += H[3 * j] * xs[j]; r1 += H[3 * j + 1] * zero; r1 += H[3 * j + 2] * (-u0 * xs[j]);
-      r2 += H[3 * j] * zero; r2 += H[3 * j + 1] * xs[j]; r2 += H[3 * j + 2] * (-u1 * xs[j]);
-    }
-    const hds_v4 a = H[0] - H[2] * u0;
-    const hds_v4 b = H[3] - H[5] * u0;
-    const hds_v4 c = -H[8] - H[2] * u3 - H[5] * u4;
-    const hds_v4 d = H[1] - H[2] * u1;
-    const hds_v4 e = H[4] - H[5] * u1;
-    hds_v4 pJ[8];
-    {
-      const hds_v4 a2 = a * a, b2 = b * b, c2 = c * c, d2 = d * d, e2 = e * e;
-      const hds_v4 c2pd2 = c2 + d2, ab = a * b, de = d * e;
-      const hds_v4 Q = c * (c2pd2 + e2);
-      pJ[0] = -b * de + a * (c2 + e2);
-      pJ[1] = b * c2pd2 - a * de;
-      pJ[2] = Q;
-      pJ[3] = -c * (a * d + b * e);
-      pJ[4] = d * (b2 + c2) - ab * e;
-      pJ[5] = -ab * d + e * (a2 + c2);
-      pJ[6] = pJ[3];
-      pJ[7] = c * (a2 + b2 + c2);
-      const hds_v4 N = a * pJ[0] + b * pJ[1] + c * pJ[2];
-      for (int q = 0; q < 8; q++) pJ[q] /= N;
-    }
-    hds_v4 acc = {0, 0, 0, 0};
-    for (int j = 0; j < 4; j++) {
-      const hds_v4 t = pJ[j] * r1 + pJ[j + 4] * r2;
-      acc += t * t;
-    }
-    p[i] = acc[0]; p[i + 1] = acc[1]; p[i + 2] = acc[2]; p[i + 3] = acc[3];
-  }
+#if defined(__x86_64__)
+  static const bool wide = __builtin_cpu_supports("avx512f");
+  if (wide) i = hds_loop8(u, H, p, len);
+#endif
+  HDS_VECTOR_LOOP(hds_v4, 4, hds_ld4, ((hds_v4){0, 0, 0, 0}))
   u += (size_t)6 * i; p += i;
   for (; i < len; i++) {
     double r1 = 0, r2 = 0;
