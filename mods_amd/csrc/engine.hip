@@ -511,12 +511,27 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
     const uint32_t *idx = byImg.data() + imgStart[img];
     const size_t m = imgStart[img + 1] - imgStart[img];
     if (!m) return;
-    std::vector<std::pair<uint64_t, uint32_t>> order(m);
+    // keys are unique (one candidate per (octave, level, pixel)), so the order is the same whatever sorts them: an LSD radix
+    // sort of (key, index), 11 bits per pass, passes whose digit is the same for every key left out
+    static thread_local std::vector<std::pair<uint64_t, uint32_t>> order, order2;
+    order.resize(m); order2.resize(m);
     for (size_t k = 0; k < m; k++) {
       const Candidate &q = cd[idx[k]];
       order[k] = {((uint64_t)q.octave << 53) | ((uint64_t)q.level << 48) | ((uint64_t)q.r0 << 24) | (uint64_t)q.c0, idx[k]};
     }
-    std::sort(order.begin(), order.end());      // keys are unique: one candidate per (octave, level, pixel)
+    {
+      constexpr int BITS = 11, NB = 1 << BITS;
+      uint32_t hist[NB];
+      for (int shift = 0; shift < 58; shift += BITS) {
+        memset(hist, 0, sizeof hist);
+        for (size_t k = 0; k < m; k++) hist[(order[k].first >> shift) & (NB - 1)]++;
+        if (hist[(order[0].first >> shift) & (NB - 1)] == m) continue;
+        uint32_t sum = 0;
+        for (int b = 0; b < NB; b++) { const uint32_t h = hist[b]; hist[b] = sum; sum += h; }
+        for (size_t k = 0; k < m; k++) order2[hist[(order[k].first >> shift) & (NB - 1)]++] = order[k];
+        order.swap(order2);
+      }
+    }
     size_t tabSize = 64;
     while (tabSize < m * 2 + 16) tabSize <<= 1;
     std::vector<uint64_t> claimed(tabSize, 0);  // key + 1, 0 = empty
@@ -1024,16 +1039,17 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
         std::vector<uint32_t> ord(nj), ord2(nj);
         for (size_t q = 0; q < nj; q++) {
           const DescJob &a = jobs[q];
-          uint32_t xb;
-          memcpy(&xb, &a.x, 4);
-          xb = (xb & 0x80000000u) ? ~xb : (xb | 0x80000000u);             // f32 -> order-preserving u32
-          const uint32_t band = (uint32_t)(((int)a.y >> 6) + (1 << 20)) & 0x3fffffu;
-          key[q] = ((uint64_t)(uint32_t)a.img << 54) | ((uint64_t)band << 32) | xb;
+          // the order only places neighbouring windows on neighbouring workgroups (no result depends on it): whole pixels
+          // are enough, and a 32-bit key is three passes instead of six
+          const int xi = (int)a.x, yb = (int)a.y >> 6;
+          const uint32_t x16 = (uint32_t)(xi < 0 ? 0 : (xi > 65535 ? 65535 : xi));
+          const uint32_t band = (uint32_t)(yb < 0 ? 0 : (yb > 1023 ? 1023 : yb));
+          key[q] = ((uint64_t)(uint32_t)a.img << 26) | ((uint64_t)band << 16) | x16;
           ord[q] = (uint32_t)q;
         }
         constexpr int BITS = 11, NB = 1 << BITS;
         uint32_t hist[NB];
-        for (int shift = 0; shift < 64; shift += BITS) {
+        for (int shift = 0; shift < 33; shift += BITS) {
           memset(hist, 0, sizeof hist);
           for (size_t q = 0; q < nj; q++) hist[(key[q] >> shift) & (NB - 1)]++;
           if (nj && hist[(key[0] >> shift) & (NB - 1)] == nj) continue;

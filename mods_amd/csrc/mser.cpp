@@ -35,6 +35,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <chrono>
 #include <vector>
 #include "engine_api.hpp"
 
@@ -398,7 +399,10 @@ class HostPool {
       std::lock_guard<std::mutex> lk(mu_);
       jobs_.push_back(job);
     }
-    const int wake = std::min(n - 1, (int)threads_.size());
+    epoch_.fetch_add(1, std::memory_order_release);      // workers that are still looking around take it from here
+    // only sleeping workers need a wake-up, and a futex wake is microseconds of the caller's time each: the short loops of a
+    // launch set follow one another within tens of microseconds, which the workers bridge spinning (loop())
+    const int wake = std::min(std::min(n - 1, (int)threads_.size()), sleepers_.load(std::memory_order_acquire));
     for (int k = 0; k < wake; k++) cv_.notify_one();
     work(*job);                    // the calling thread takes tasks too
     for (int spin = 0; job->done.load(std::memory_order_acquire) < n; spin++)
@@ -412,10 +416,13 @@ class HostPool {
   std::condition_variable cv_;
   std::deque<std::shared_ptr<Job>> jobs_;
   std::vector<std::thread> threads_;
+  std::atomic<int> epoch_{0}, sleepers_{0};
+  int spinUs_ = 150;
   bool stop_ = false;
   HostPool() {
     int n = (int)std::thread::hardware_concurrency();
     if (const char *e = getenv("MODSX_HOST_THREADS")) n = atoi(e);
+    if (const char *e = getenv("MODSX_HOST_SPIN_US")) spinUs_ = atoi(e);
     n = std::max(0, std::min(n, 64) - 1);
     for (int i = 0; i < n; i++) threads_.emplace_back([this] { loop(); });
   }
@@ -434,19 +441,38 @@ class HostPool {
     }
     if (mine) j.done.fetch_add(mine, std::memory_order_release);
   }
+  // the first job that still has tasks to hand out (finished ones are dropped from the front); mu_ held
+  std::shared_ptr<Job> front_job() {
+    while (!jobs_.empty() && jobs_.front()->next.load(std::memory_order_relaxed) >= jobs_.front()->n) jobs_.pop_front();
+    return jobs_.empty() ? nullptr : jobs_.front();
+  }
   void loop() {
     for (;;) {
       std::shared_ptr<Job> j;
+      const int seen = epoch_.load(std::memory_order_acquire);
       {
-        std::unique_lock<std::mutex> lk(mu_);
-        for (;;) {
-          if (stop_) return;
-          while (!jobs_.empty() && jobs_.front()->next.load(std::memory_order_relaxed) >= jobs_.front()->n) jobs_.pop_front();
-          if (!jobs_.empty()) { j = jobs_.front(); break; }
-          cv_.wait(lk);
+        std::lock_guard<std::mutex> lk(mu_);
+        if (stop_) return;
+        j = front_job();
+      }
+      if (j) { work(*j); continue; }
+      // nothing to do: watch the epoch for a while before going to sleep (a job pushed after `seen` was read changes it; one
+      // pushed before is found by the look under the lock below)
+      bool fresh = false;
+      if (spinUs_ > 0) {
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spinUs_);
+        for (int it = 0;; it++) {
+          if (epoch_.load(std::memory_order_acquire) != seen) { fresh = true; break; }
+          __builtin_ia32_pause();
+          if ((it & 63) == 63 && std::chrono::steady_clock::now() >= until) break;
         }
       }
-      work(*j);
+      if (fresh) continue;
+      std::unique_lock<std::mutex> lk(mu_);
+      sleepers_.fetch_add(1, std::memory_order_acq_rel);
+      cv_.wait(lk, [&] { return stop_ || front_job() != nullptr; });
+      sleepers_.fetch_sub(1, std::memory_order_acq_rel);
+      if (stop_) return;
     }
   }
 };
