@@ -232,7 +232,8 @@ static inline void normu(const double *u, const int *inl, int len, double *A1, d
   A2[1] *= -A2[0]; A2[2] *= -A2[0];
 }
 
-// lin_hgN: row-wise 2len x 9 normalised linearisation, Htools.c:56-96
+// lin_hgN: row-wise 2len x 9 normalised linearisation, Htools.c:56-96.  (lin_hgN and cov_mat_hgN are no longer called: u2h
+// forms the same sums without the matrix, cov_hgN_fused below; they stay as the plain statement of what it computes.)
 static inline void lin_hgN(const double *u, double *p, const int *inl, int len, const double *A1, const double *A2) {
   double a[3], b[3];
   a[2] = 1; b[2] = 1;
