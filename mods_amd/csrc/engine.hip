@@ -941,7 +941,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
         pi.coordOfs = (int)coordTab.size();
         coordTab.insert(coordTab.end(), W, W + 41);
         {  // tile shapes of the LDS blur kernels: <= BLUR_OUT outputs and <= BLUR_LDS floats per workgroup
-          const int BLUR_LDS = 4992, BLUR_LDS_C = 9984, R = pi.ksize >> 1, NP2 = 2 * ((pi.NC + 1) / 2);
+          const int BLUR_LDS = 4992, BLUR_LDS_C = MODSX_BLUR_LDS_C, R = pi.ksize >> 1, NP2 = 2 * ((pi.NC + 1) / 2);
           const int cap = 2048 / NP2, capC = 4096 / NP2;
           // the row filter pairs needed columns (2m, 2m+1); they are neighbours in the window by construction
           // (x0, x0 + 1 of one sample, or a contiguous range) -- if ever not, the job takes the global-memory kernel

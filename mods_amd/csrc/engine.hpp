@@ -221,6 +221,10 @@ void launch_views_rotblur(hipStream_t s, const ViewJob *jobs, int n, int tiles, 
 size_t match_workspace_bytes(int n1, int n2);
 void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2,
                   double sqminratio, double contrDistSq, int nn, MatchRow *rows, void *workspace);
+// LDS floats of a column-filter workgroup (kernels_describe.hip k_blur_cols_lds; engine.hip sizes the tiles with the same number)
+#ifndef MODSX_BLUR_LDS_C
+#define MODSX_BLUR_LDS_C 9984
+#endif
 constexpr int MATCH_MAXB = 4;   // independent matching problems per launch set (blockIdx.z)
 void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
                         const double *const *pos2, double sqminratio, double contrDistSq, int nn, MatchRow *const *rows,

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void k_patch_blur(const DescJob *jobs, const i
 // Jobs whose tile does not fit BLUR_LDS floats have rows0 / ro1 = 0 and go through k_patch_blur.
 constexpr int BLUR_T = 256, BLUR_W = BLUR_T / 64;   // threads / waves per workgroup of the LDS blur kernels
 constexpr int BLUR_LDS = 4992;   // row tile of the fused sampling + row-filter kernel: 20 KB
-constexpr int BLUR_LDS_C = 9984;                               // column filter: fatter tiles re-read fewer halo rows
+constexpr int BLUR_LDS_C = MODSX_BLUR_LDS_C;                               // column filter: fatter tiles re-read fewer halo rows
 
 // the row filter proper, on a tile parked in LDS as nr rows of R + P + R floats (replicated border written out)
 // (dst = the tile's place in arena B, row stride NC; or, for the fully fused small windows, an LDS block of row stride ostride)
