@@ -1,4 +1,4 @@
-# usage: _ab.sh out.log lib1 lib2 ...   (default bench, 5 steps, alternating)
+# usage: ab_bench.sh out.log lib1 lib2 ...  (variants built by tools/build_variant.sh; "main" = mods_amd/libmodsx.so)   (default bench, 5 steps, alternating)
 out=$1; shift
 mkdir -p $(dirname $out)
 for rep in 1 2; do
