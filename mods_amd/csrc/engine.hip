@@ -941,7 +941,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
         pi.coordOfs = (int)coordTab.size();
         coordTab.insert(coordTab.end(), W, W + 41);
         {  // tile shapes of the LDS blur kernels: <= BLUR_OUT outputs and <= BLUR_LDS floats per workgroup
-          const int BLUR_LDS = 4992, BLUR_LDS_C = MODSX_BLUR_LDS_C, R = pi.ksize >> 1, NP2 = 2 * ((pi.NC + 1) / 2);
+          const int BLUR_LDS = MODSX_SR_WIN, BLUR_LDS_C = MODSX_BLUR_LDS_C, R = pi.ksize >> 1, NP2 = 2 * ((pi.NC + 1) / 2);
           const int cap = 2048 / NP2, capC = 4096 / NP2;
           // the row filter pairs needed columns (2m, 2m+1); they are neighbours in the window by construction
           // (x0, x0 + 1 of one sample, or a contiguous range) -- if ever not, the job takes the global-memory kernel
@@ -949,7 +949,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
           for (int a = 0; a + 1 < pi.NC; a += 2) pairs = pairs && need[a + 1] == need[a] + 1;
           pi.rows0 = pairs ? std::min(cap, BLUR_LDS / (P + 2 * R)) : 0;
           if (pi.rows0 < 2) pi.rows0 = 0;
-          if (pi.rows0 > 32 && pi.rows0 < 48 && pi.rows0 < P) pi.rows0 = 32;   // the fused sampling kernel parks 16 columns x <= 32 rows or 8 x <= 64
+          if (pi.rows0 > 32 && pi.rows0 < 48 && pi.rows0 < P) pi.rows0 = 32;   // the fused sampling kernel parks 8 columns x <= 32 rows or 4 x <= 64 (MODSX_SR_HALF)
           pi.ro1 = 0;
           const int LS = pi.NC <= 64 ? 64 : 96;   // LDS row stride of the column filter
           for (int ro = std::min(capC, pi.NC); ro >= 2 && !pi.ro1 && pi.NC <= 96; ro--) {
@@ -959,7 +959,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
           }
           // a window that is one row tile, with <= 64 needed columns and <= 80 block rows (kernels_describe.hip: FC_LS,
           // FC_ROWS): the fused sampling kernel runs the column filter too
-          if (pi.rows0 >= P && pi.NC <= 64 && P + 2 * R <= 80) pi.ro1 = -1;
+          if (pi.rows0 >= P && pi.NC <= 64 && P + 2 * R <= MODSX_FC_ROWS) pi.ro1 = -1;
         }
         return MODSX_OK;
       };

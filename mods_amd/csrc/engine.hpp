@@ -221,6 +221,19 @@ void launch_views_rotblur(hipStream_t s, const ViewJob *jobs, int n, int tiles, 
 size_t match_workspace_bytes(int n1, int n2);
 void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2,
                   double sqminratio, double contrDistSq, int nn, MatchRow *rows, void *workspace);
+// Shapes of the fused sampling + row-filter kernel (kernels_describe.hip k_sample_rows_lds; engine.hip sizes the tiles with the
+// same numbers): LDS floats of the sampled row tile, block rows of a fully fused small window, whether a wave parks 4 / 8
+// columns of coordinates at a time (1) or 8 / 16 (0), and the workgroups per CU the kernel is built for
+// The kernel's time follows its residency far more than its tile shapes: with 4 workgroups per CU (20 KB tile + 20 KB of
+// coordinates / fused block) it took 1.9 ms per 31-view pair on one stream, padded to 3 per CU 3.4 ms, and at 6 / 7 / 8 per CU
+// 1.33 / 1.18 / 1.13 ms (175 -> 179 / 179.5 / 180.5 pairs/s), although fewer windows are then small enough for the fused
+// column pass (the separate column filter grows from 0.69 to 0.86 ms).
+#ifndef MODSX_SR_WIN
+#define MODSX_SR_WIN 2400
+#define MODSX_FC_ROWS 40
+#define MODSX_SR_HALF 1
+#define MODSX_SR_WGS 8
+#endif
 // LDS floats of a column-filter workgroup (kernels_describe.hip k_blur_cols_lds; engine.hip sizes the tiles with the same number)
 #ifndef MODSX_BLUR_LDS_C
 #define MODSX_BLUR_LDS_C 9984

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void k_patch_blur(const DescJob *jobs, const i
 //   cols:  a tile is jb.ro1 consecutive needed rows; it parks the source rows need[first] - R .. need[last] + R
 // Jobs whose tile does not fit BLUR_LDS floats have rows0 / ro1 = 0 and go through k_patch_blur.
 constexpr int BLUR_T = 256, BLUR_W = BLUR_T / 64;   // threads / waves per workgroup of the LDS blur kernels
-constexpr int BLUR_LDS = 4992;   // row tile of the fused sampling + row-filter kernel: 20 KB
+constexpr int BLUR_LDS = MODSX_SR_WIN;   // row tile of the fused sampling + row-filter kernel: 20 KB
 constexpr int BLUR_LDS_C = MODSX_BLUR_LDS_C;                               // column filter: fatter tiles re-read fewer halo rows
 
 // the row filter proper, on a tile parked in LDS as nr rows of R + P + R floats (replicated border written out)
@@ -418,14 +418,15 @@ __device__ __forceinline__ void blur_cols_from_lds(int NC, int n, int ro0, int n
 // A wave parks C columns of up to 64 rows at a time in its 64 x 9 words of coordinates: C = 8 for tiles of more than 32 rows,
 // C = 16 for tiles of up to 32 rows (the host keeps row tiles out of the 33..48 range), so that a lane has 8 samples --
 // 16 loads -- in flight either way.
-constexpr int SR_WORDS = 64 * 9;
-constexpr int FC_LS = 64, FC_ROWS = 80;   // fully fused small windows: NC <= FC_LS needed columns, P + 2 R <= FC_ROWS block rows
+constexpr int SR_CW = MODSX_SR_HALF ? 4 : 8;      // columns parked per pass for tiles of more than 32 rows (twice that up to 32 rows)
+constexpr int SR_WORDS = 64 * (SR_CW + 1);
+constexpr int FC_LS = 64, FC_ROWS = MODSX_FC_ROWS;   // fully fused small windows: NC <= FC_LS needed columns, P + 2 R <= FC_ROWS block rows
 MX_D int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 
 template <bool TOUCH, int C>
 __device__ __forceinline__ void sample_chunk_lds(const ImgRef &im, const float *cx, const float *cy, float *dst, int RW, int tot, int nc,
                                                  int lane) {
-  constexpr int CP = C + 1, PER = 8;   // tot <= 64 * PER
+  constexpr int CP = C + 1, PER = SR_CW;   // tot <= 64 * PER (64 rows x SR_CW columns, or 32 x 2 SR_CW)
   float v[PER];
 #pragma unroll
   for (int u = 0; u < PER; u++) {
@@ -442,7 +443,7 @@ __device__ __forceinline__ void sample_chunk_lds(const ImgRef &im, const float *
 template <int C>
 __device__ __forceinline__ void sample_rows_tile(const BlurTile &bt, const DescJob &jb, const ImgRef &im, const float2 *rowStart,
                                                  float *win, float *cx, float *cy, int lane, int wave) {
-  constexpr int CP = C + 1, RG = C == 8 ? 64 : 32;   // rows per pass of the wave
+  constexpr int CP = C + 1, RG = C == SR_CW ? 64 : 32;   // rows per pass of the wave
   const int P = bt.P, R = bt.n >> 1, RW = P + 2 * R, nr = bt.count, r0 = bt.first;
   const int half = P >> 1;
   const bool touch = check_borders(im.cols, im.rows, jb.x, jb.y, jb.a11, jb.a12, jb.a21, jb.a22, P, P);
@@ -476,7 +477,7 @@ __device__ __forceinline__ void sample_rows_tile(const BlurTile &bt, const DescJ
   }
 }
 
-__global__ __launch_bounds__(BLUR_T, 4) void k_sample_rows_lds(const BlurTile *__restrict__ tiles, const DescJob *__restrict__ jobs,
+__global__ __launch_bounds__(BLUR_T, MODSX_SR_WGS) void k_sample_rows_lds(const BlurTile *__restrict__ tiles, const DescJob *__restrict__ jobs,
                                                          const ImgRef *__restrict__ imgs, const float *__restrict__ taps,
                                                          const int *__restrict__ needTab, float *__restrict__ dst, int nTiles,
                                                          const float2 *__restrict__ rowStarts, float *__restrict__ dstGrid) {
@@ -486,6 +487,10 @@ __global__ __launch_bounds__(BLUR_T, 4) void k_sample_rows_lds(const BlurTile *_
   const DescJob jb = jobs[bt.job];
   const int P = bt.P, NC = bt.NC;
   const int n = bt.n, R = n >> 1, RW = P + 2 * R;
+#ifdef MODSX_SAMPLE_PAD
+  __shared__ volatile char spad_[MODSX_SAMPLE_PAD];
+  if (threadIdx.x == 0) spad_[MODSX_SAMPLE_PAD - 1] = 1;
+#endif
   __shared__ float win[BLUR_LDS + 2];
   __shared__ int sneed[96];
   // coordinates of the sampling phase (2 x 4 waves x 64 x 9 words); afterwards, for a small window that is here as a whole
@@ -499,8 +504,8 @@ __global__ __launch_bounds__(BLUR_T, 4) void k_sample_rows_lds(const BlurTile *_
   for (int i = threadIdx.x; i < NC; i += BLUR_T) sneed[i] = needTab[bt.needOfs + i];
   const ImgRef im = imgs[jb.img];
   const float2 *rowStart = rowStarts + jb.scratchOfs;
-  if (nr <= 32) sample_rows_tile<16>(bt, jb, im, rowStart, win, cxw, cyw, lane, wave);
-  else sample_rows_tile<8>(bt, jb, im, rowStart, win, cxw, cyw, lane, wave);
+  if (nr <= 32) sample_rows_tile<2 * SR_CW>(bt, jb, im, rowStart, win, cxw, cyw, lane, wave);
+  else sample_rows_tile<SR_CW>(bt, jb, im, rowStart, win, cxw, cyw, lane, wave);
   __syncthreads();
   // replicated border: R copies of the first and of the last sample of every row
   for (int i = threadIdx.x; i < nr * 2 * R; i += BLUR_T) {
@@ -625,6 +630,10 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
   float *const sstat = sstat_[reg];
   __shared__ double sfac_[DR];
   __shared__ int schanged_[DR];
+#ifdef MODSX_DESCRIBE_PAD
+  __shared__ volatile char spad_[MODSX_DESCRIBE_PAD];
+  if (tidw == 0) spad_[MODSX_DESCRIBE_PAD - 1] = 1;
+#endif
   const DescJob jb = jobs[k];
   if (tid < PS) {
     swr0[tid] = (float)wTab[tid]; swr1[tid] = (float)wTab[PS + tid];   // const float wr0 = w0[r] (siftdesc.cpp:79-81)
