@@ -210,7 +210,9 @@ modsx_ctx *ctx_create(int device_id) {
 
 void ctx_destroy(modsx_ctx *c) {
   if (!c) return;
+  ctx_worker_stop(c);
   if (c->peer) { ctx_destroy(c->peer); c->peer = nullptr; }
+  if (c->half) { ctx_destroy(c->half); c->half = nullptr; }
   hipSetDevice(c->dev);
   hipStreamSynchronize(c->stream);
   for (int i = 0; i < MAXB; i++) c->pyr[i].store.release();

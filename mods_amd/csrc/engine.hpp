@@ -297,4 +297,7 @@ struct modsx_ctx {
   size_t lastCandCount = 0;    // scale-space candidates of the context's last launch set (sizes the speculative download)
   int shardLane = 0;           // lane of the rank's communicator this context issues its collectives on (engine_shard.hip)
   modsx_ctx *peer = nullptr;   // second stream + buffers, created on demand: the two images of a multi-view pair run side by side
+  modsx_ctx *half = nullptr;   // a lone pair: the second part of an image's views runs here (accumulate_views)
+  mx::DevBuf halfDesc;         // ... and writes its descriptors here until the first part's count is known
+  void *worker = nullptr;      // CtxWorker: the host thread that drives this context when it is a peer / half (engine_views.hip)
 };

@@ -38,6 +38,7 @@ int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx
 int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_view *views, int nv,
                           const modsx_pair_params &pp, int view_begin, int view_step, std::vector<modsx_region> &regs,
                           float *devF, uint8_t *devU8, size_t devCapRegions, float *hostDesc, int *viewCounts);
+void ctx_worker_stop(modsx_ctx *c);   // joins the context's host thread, if it has one (ctx_destroy)
 void rebase_ids(std::vector<modsx_region> &regs, const int *viewCounts, int nv, size_t base);
 struct VerifyTask;
 // defer != nullptr (one-step ladders only): the tentatives are matched and handed back unverified

@@ -10,6 +10,9 @@
 #include <math.h>
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include "engine_api.hpp"
 
@@ -419,14 +422,128 @@ struct LadderClass {
 // Append the regions + u8 descriptors of one step's views to the accumulated lists of one image side
 // (SynthDetectDescribeKeypoints + AddRegions, imagerepresentation.cpp:603-2047).  The accumulator is re-allocated
 // (device-to-device copy) when the step does not fit.
+// A peer / half context is driven by ONE host thread for as long as it lives: a thread spawned per call starts with a cold
+// allocator arena and fresh thread_local scratch every time (page faults worth milliseconds on some calls of a lone pair).
+struct CtxWorker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void()> task;
+  bool has = false, done = true, stop = false;
+};
+static void ctx_worker_post(modsx_ctx *c, std::function<void()> fn) {
+  if (!c->worker) {
+    CtxWorker *w = new CtxWorker();
+    c->worker = w;
+    const int dev = c->dev;
+    w->th = std::thread([w, dev] {
+      hipSetDevice(dev);
+      for (;;) {
+        std::function<void()> f;
+        {
+          std::unique_lock<std::mutex> lk(w->mu);
+          w->cv.wait(lk, [&] { return w->has || w->stop; });
+          if (w->stop) return;
+          f = std::move(w->task);
+          w->has = false;
+        }
+        f();
+        { std::lock_guard<std::mutex> lk(w->mu); w->done = true; }
+        w->cv.notify_all();
+      }
+    });
+  }
+  CtxWorker *w = (CtxWorker *)c->worker;
+  { std::lock_guard<std::mutex> lk(w->mu); w->task = std::move(fn); w->has = true; w->done = false; }
+  w->cv.notify_all();
+}
+static void ctx_worker_wait(modsx_ctx *c) {
+  CtxWorker *w = (CtxWorker *)c->worker;
+  if (!w) return;
+  std::unique_lock<std::mutex> lk(w->mu);
+  w->cv.wait(lk, [&] { return w->done; });
+}
+void ctx_worker_stop(modsx_ctx *c) {
+  CtxWorker *w = (CtxWorker *)c->worker;
+  if (!w) return;
+  { std::lock_guard<std::mutex> lk(w->mu); w->stop = true; }
+  w->cv.notify_all();
+  if (w->th.joinable()) w->th.join();
+  delete w;
+  c->worker = nullptr;
+}
+
+// split = true (a lone pair on an otherwise idle GPU): the views [m, nv) of the step run on a helper context -- its own
+// stream, scratch and host thread -- beside the views [0, m) on c; m balances the view areas.  A view's regions and
+// descriptors do not depend on which launch set it is part of, so the step is the concatenation of the two parts (the
+// second part's descriptors are moved behind the first's once its size is known).
 static int accumulate_views(modsx_ctx *c, LadderClass &k, int side, const modsx_image *img, const modsx_view *views, int nv,
-                            const modsx_pair_params &pp, modsx_comm *cm) {
+                            const modsx_pair_params &pp, modsx_comm *cm, bool split = false) {
   std::vector<modsx_region> &acc = k.regs[side];
   DevBuf &buf = *k.buf[side];
   size_t &cap = k.cap[side];
   const size_t base = acc.size();
   std::vector<modsx_region> step;
   std::vector<int> counts(std::max(1, nv), 0);
+  auto grow_buf = [&]() -> int {     // the accumulated descriptors of the class: cap regions, earlier steps' kept
+    if (buf.cap >= cap * 128) return MODSX_OK;
+    DevBuf bigger;
+    if (!bigger.ensure(cap * 128)) return MODSX_ERR_NOMEM;
+    if (base) {
+      MX_HIP(hipMemcpyAsync(bigger.p, buf.p, base * 128, hipMemcpyDeviceToDevice, c->stream));
+      MX_HIP(hipStreamSynchronize(c->stream));
+    }
+    buf.release();
+    buf = bigger;
+    return MODSX_OK;
+  };
+  static const bool noSplit = getenv("MODSX_PAIR_NOSPLIT") != nullptr;
+  static const double splitBias = getenv("MODSX_SPLIT_BIAS") ? atof(getenv("MODSX_SPLIT_BIAS")) : 0.25;   // a view's fixed cost, in untilted-view areas
+  if (split && !cm && !noSplit && nv >= 12) {
+    { const int rg = grow_buf(); if (rg) return rg; }
+    if (!c->half) c->half = ctx_create(c->dev);
+    modsx_ctx *h = c->half;
+    double tot = 0, run = 0;
+    std::vector<double> w(nv);
+    for (int v = 0; v < nv; v++) { const double t = fabs(views[v].tilt) > 1e-9 ? fabs(views[v].tilt) : 1.0; w[v] = views[v].zoom * views[v].zoom / t + splitBias; tot += w[v]; }
+    int m = 1;
+    for (; m < nv - 1; m++) { run += w[m - 1]; if (run + 0.5 * w[m] >= 0.5 * tot) break; }
+    if (h && buf.cap >= cap * 128 && h->halfDesc.ensure(cap * 128)) {
+      std::vector<modsx_region> stepB;
+      std::vector<int> countsB(nv, 0);
+      int rcA = MODSX_OK, rcB = MODSX_OK;
+      std::string errB;
+      prof_reset(h, c->prof.enabled);
+      ctx_worker_post(h, [&]() {
+        rcB = detect_describe_views(h, img, views, nv, pp, m, 1, stepB, nullptr, (uint8_t *)h->halfDesc.p, cap, nullptr, countsB.data());
+        if (rcB) errB = last_error();
+      });
+      rcA = detect_describe_views(c, img, views, m, pp, 0, 1, step, nullptr, (uint8_t *)buf.p + base * 128, cap - base, nullptr,
+                                  counts.data());
+      ctx_worker_wait(h);
+      if (c->prof.enabled) {
+        prof_collect(h);
+        for (int q = 0; q < K_NCLASS; q++) { c->prof.ms[q] += h->prof.ms[q]; c->prof.work[q] += h->prof.work[q]; c->prof.launches[q] += h->prof.launches[q]; }
+      }
+      if (!rcA && !rcB && base + step.size() + stepB.size() <= cap) {
+        if (!stepB.empty()) {
+          MX_HIP(hipMemcpyAsync((uint8_t *)buf.p + (base + step.size()) * 128, h->halfDesc.p, stepB.size() * 128, hipMemcpyDeviceToDevice,
+                                c->stream));
+          MX_HIP(hipStreamSynchronize(c->stream));
+        }
+        for (int v = m; v < nv; v++) counts[v] = countsB[v];
+        step.insert(step.end(), stepB.begin(), stepB.end());
+        rebase_ids(step, counts.data(), nv, base);
+        acc.insert(acc.end(), step.begin(), step.end());
+        return MODSX_OK;
+      }
+      if (rcA && rcA != MODSX_ERR_CAPACITY) return rcA;
+      if (rcB && rcB != MODSX_ERR_CAPACITY) { set_error(errB); return rcB; }
+      // a part did not fit: the one-context path below grows the buffer and runs the step again
+      step.clear();
+      std::fill(counts.begin(), counts.end(), 0);
+    }
+  }
   if (cm) {   // view-sharded: this rank runs its views, the exchange appends the whole step in reference order (ids re-based)
     int rc = detect_describe_views_sharded(c, cm, img, views, nv, pp, step, buf, base, counts.data());
     if (rc) return rc;
@@ -434,16 +551,7 @@ static int accumulate_views(modsx_ctx *c, LadderClass &k, int side, const modsx_
     return MODSX_OK;
   }
   for (;;) {
-    if (buf.cap < cap * 128) {
-      DevBuf bigger;
-      if (!bigger.ensure(cap * 128)) return MODSX_ERR_NOMEM;
-      if (base) {
-        MX_HIP(hipMemcpyAsync(bigger.p, buf.p, base * 128, hipMemcpyDeviceToDevice, c->stream));
-        MX_HIP(hipStreamSynchronize(c->stream));
-      }
-      buf.release();
-      buf = bigger;
-    }
+    { const int rg = grow_buf(); if (rg) return rg; }
     int rc = detect_describe_views(c, img, views, nv, pp, 0, 1, step, nullptr, (uint8_t *)buf.p + base * 128, cap - base, nullptr,
                                    counts.data());
     if (rc == MODSX_ERR_CAPACITY && cap < ((size_t)1 << 24)) { cap *= 4; continue; }   // only "buffer too small" grows it
@@ -500,13 +608,12 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
       if (!serial && c->peer) {
         modsx_ctx *pc = c->peer;
         prof_reset(pc, c->prof.enabled);
-        std::thread t([&]() {
-          hipSetDevice(pc->dev);
-          rc1 = accumulate_views(pc, k, 1, imgs[1], steps[step].views, steps[step].nviews, ps, nullptr);
+        ctx_worker_post(pc, [&]() {
+          rc1 = accumulate_views(pc, k, 1, imgs[1], steps[step].views, steps[step].nviews, ps, nullptr, true);
           if (rc1) err1 = last_error();
         });
-        rc0 = accumulate_views(c, k, 0, imgs[0], steps[step].views, steps[step].nviews, ps, nullptr);
-        t.join();
+        rc0 = accumulate_views(c, k, 0, imgs[0], steps[step].views, steps[step].nviews, ps, nullptr, true);
+        ctx_worker_wait(pc);
         if (c->prof.enabled) {   // the peer's kernels belong to this call
           prof_collect(pc);
           for (int q = 0; q < K_NCLASS; q++) { c->prof.ms[q] += pc->prof.ms[q]; c->prof.work[q] += pc->prof.work[q]; c->prof.launches[q] += pc->prof.launches[q]; }

@@ -417,7 +417,7 @@ class HostPool {
   std::deque<std::shared_ptr<Job>> jobs_;
   std::vector<std::thread> threads_;
   std::atomic<int> epoch_{0}, sleepers_{0};
-  int spinUs_ = 150;
+  int spinUs_ = 0;     // MODSX_HOST_SPIN_US: measured on a lone 31-view pair, 150 us of watching bought nothing in the median and cost outliers
   bool stop_ = false;
   HostPool() {
     int n = (int)std::thread::hardware_concurrency();
@@ -486,12 +486,12 @@ void host_set_leave() { g_setsInFlight.fetch_sub(1); }
 
 
 // fn(0) .. fn(n - 1) in parallel.  light = true marks the short per-view loops of a launch set (hundreds of microseconds of
-// work): they go to the pool only while at most two launch sets are in flight -- a single pair, or its two images side by side; with
+// work): they go to the pool only while at most four launch sets are in flight -- a single pair: its two images, each in two parts; with
 // many contexts at work every host core already has a context's own loop to run and the loops stay where they are.
 void host_parallel_for(int n, const std::function<void(int)> &fn, bool light) {
   if (light) {
     static const bool off = getenv("MODSX_HOST_SERIAL") != nullptr;
-    static const int maxSets = getenv("MODSX_LIGHT_SETS") ? atoi(getenv("MODSX_LIGHT_SETS")) : 2;
+    static const int maxSets = getenv("MODSX_LIGHT_SETS") ? atoi(getenv("MODSX_LIGHT_SETS")) : 4;
     if (g_setsInFlight.load() > maxSets || off) { for (int i = 0; i < n; i++) fn(i); return; }
     HostPool::get().run(n, fn);
     return;
