@@ -100,6 +100,7 @@ int detect_msers_views(const uint8_t *const *u8, const int *rows, const int *col
                        const double *tilts, const double *zooms, std::vector<modsx_keypoint> *out);
 // fn(0) .. fn(n - 1) on the process-wide host worker pool (MODSX_HOST_THREADS, default min(hardware threads, 64)) + the caller
 void host_parallel_for(int n, const std::function<void(int)> &fn, bool light = false);
+void host_light_pool(bool on);   // this thread's short host loops may use the pool regardless of the sets in flight
 void host_set_enter();
 void host_set_leave();
 inline void host_parallel_light(int n, const std::function<void(int)> &fn) { host_parallel_for(n, fn, true); }

@@ -481,18 +481,21 @@ std::atomic<int> g_setsInFlight(0);
 
 // a launch set is being driven by the calling thread (detect_describe_views): how many are decides whether their short
 // host loops may use the pool
+// the calling thread drives a part of a lone pair (accumulate_views): its short loops use the pool whatever the count says
+static thread_local bool t_lightPool = false;
+void host_light_pool(bool on) { t_lightPool = on; }
 void host_set_enter() { g_setsInFlight.fetch_add(1); }
 void host_set_leave() { g_setsInFlight.fetch_sub(1); }
 
 
 // fn(0) .. fn(n - 1) in parallel.  light = true marks the short per-view loops of a launch set (hundreds of microseconds of
-// work): they go to the pool only while at most four launch sets are in flight -- a single pair: its two images, each in two parts; with
+// work): they go to the pool only while at most two launch sets are in flight, or when the caller says so (the parts of a lone pair, host_light_pool); with
 // many contexts at work every host core already has a context's own loop to run and the loops stay where they are.
 void host_parallel_for(int n, const std::function<void(int)> &fn, bool light) {
   if (light) {
     static const bool off = getenv("MODSX_HOST_SERIAL") != nullptr;
-    static const int maxSets = getenv("MODSX_LIGHT_SETS") ? atoi(getenv("MODSX_LIGHT_SETS")) : 4;
-    if (g_setsInFlight.load() > maxSets || off) { for (int i = 0; i < n; i++) fn(i); return; }
+    static const int maxSets = getenv("MODSX_LIGHT_SETS") ? atoi(getenv("MODSX_LIGHT_SETS")) : 2;
+    if ((g_setsInFlight.load() > maxSets && !t_lightPool) || off) { for (int i = 0; i < n; i++) fn(i); return; }
     HostPool::get().run(n, fn);
     return;
   }
