@@ -679,7 +679,12 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
     // GetCorresponcesVector(): HessianAffine tentatives, then MSER; indices re-based onto the concatenated lists
     std::vector<modsx_region> all[2];
     std::vector<modsx_tentative> tents;
-    for (int q = 0; q < 2; q++) {
+    // one class only (no MSER step so far, or no HessianAffine one) and verification here: the class's own lists are the
+    // concatenation -- 2 x 5 MB of region records not copied per step of a 31-view pair
+    const int only = cls[1].regs[0].empty() && cls[1].regs[1].empty() ? 0 : (cls[0].regs[0].empty() && cls[0].regs[1].empty() ? 1 : -1);
+    const bool inPlace = only >= 0 && !defer;
+    if (inPlace) tents = cls[only].tents;
+    for (int q = 0; q < 2 && !inPlace; q++) {
       const int o1 = (int)all[0].size(), o2 = (int)all[1].size();
       for (int s = 0; s < 2; s++) all[s].insert(all[s].end(), cls[q].regs[s].begin(), cls[q].regs[s].end());
       for (modsx_tentative t : cls[q].tents) {
@@ -689,11 +694,12 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
         tents.push_back(t);
       }
     }
+    const std::vector<modsx_region> &list1 = inPlace ? cls[only].regs[0] : all[0], &list2 = inPlace ? cls[only].regs[1] : all[1];
     release_result_arrays(res);
     memset(res, 0, sizeof *res);
     for (int i = 0; i < 9; i++) res->H[i] = -1;
-    res->n_regions1 = (int)all[0].size();
-    res->n_regions2 = (int)all[1].size();
+    res->n_regions1 = (int)list1.size();
+    res->n_regions2 = (int)list2.size();
     if (defer) {   // the caller runs DuplicateFiltering + LO-RANSAC elsewhere (modsx_match_pairs_views: helper threads)
       defer->r1 = std::move(all[0]); defer->r2 = std::move(all[1]); defer->tents = std::move(tents); defer->res = res;
       step++;
@@ -703,7 +709,7 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
     // tentatives, same seed => same count), which is how the ranks agree on the early exit without a collective
     const double tL3 = tnowL();
     res->n_tentatives = (int)tents.size();
-    if (!cm || owner < 0 || owner == comm_rank(cm)) verify_tentatives(all[0], all[1], tents, pp, res);
+    if (!cm || owner < 0 || owner == comm_rank(cm)) verify_tentatives(list1, list2, tents, pp, res);
     cur = res->n_verified;
     if (timL) fprintf(stderr, "ladder step %d: views %.2f match %.2f lists %.2f verify %.2f ms\n", step, tL1 - tL0, tL2 - tL1, tL3 - tL2, tnowL() - tL3);
   }
