@@ -25,6 +25,8 @@ CPU path) on the same workload with all host cores and with one, `parity` = GPU 
 """
 import argparse
 import itertools
+import subprocess
+import tempfile
 import threading
 import json
 import os
@@ -378,14 +380,51 @@ def main():
     # ---- N > 1: the north star's view-parallel mode, measured right after the pair-sharded headline -------------------
     scaling_views = None
     views_hung = False
+    guard_flag = None
     if (world > 1 or os.environ.get("MODSX_BENCH_FORCE_VIEWS")) and group is None and not args.no_scaling_views and not single_view and not ladder:
         # The first contact of the RCCL transport with more than one rank must not cost the headline: the measurement runs
         # on a worker thread with a deadline.  Past it (a collective or the communicator bootstrap hangs) every rank reports
         # the pair-sharded line with the error and leaves through os._exit -- no clean-up that could block.
         box = {}
+        # ... and a crash must not either: RCCL with more than one rank has only ever run on the driver's node.  Rank 0 leaves
+        # the headline with a child process that shares its stdout and prints it if this process dies before its own line.
+        if rank == 0:
+            pairs0 = args.steps * world * nbatch
+            emergency = {
+                "metric": "image-pairs/sec (1024x768, HessAff+RootSIFT over the affine view ladder, MFMA FGINN match, LO-RANSAC H)",
+                "value": pairs0 / elapsed, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32 (detect/describe) + u8 on the int8 matrix cores (distance matrix)", "data": "synthetic",
+                "config": {"workload": "%dx%d synthetic pair, %s = %d views per image, HessAff+RootSIFT, MFMA distance matrix + FGINN, "
+                                       "duplicate filter, LO-RANSAC H" % (args.cols, args.rows, cfg_desc, len(views)),
+                           "views": len(views), "pairs_per_step": world * nbatch, "workers_per_gpu": len(ctxs),
+                           "parallelism": "pairs sharded over ranks, no collective"},
+                "descriptors_per_s": ndesc_total / elapsed,
+                "scaling_views": {"error": "the process ended during the untimed view-sharded leg; this line was left behind by rank 0 "
+                                           "before it started (the legs after it -- roofline, parity, kernel statistics -- did not run)"},
+            }
+            guard_dir = tempfile.mkdtemp(prefix="modsx_bench_")
+            guard_line, guard_flag = os.path.join(guard_dir, "line.json"), os.path.join(guard_dir, "printed")
+            with open(guard_line, "w") as f:
+                f.write(json.dumps(emergency))
+            guard_code = ("import os,sys,time\n"
+                          "pid=int(sys.argv[1])\n"
+                          "while True:\n"
+                          "    try: os.kill(pid,0)\n"
+                          "    except OSError: break\n"
+                          "    time.sleep(0.2)\n"
+                          "if not os.path.exists(sys.argv[3]): sys.stdout.write(open(sys.argv[2]).read()+'\\n'); sys.stdout.flush()\n")
+            try:
+                subprocess.Popen([sys.executable, "-c", guard_code, str(os.getpid()), guard_line, guard_flag], stdin=subprocess.DEVNULL,
+                                 start_new_session=True)
+            except OSError:
+                guard_flag = None
 
         def measure_views():
             try:
+                if os.environ.get("MODSX_BENCH_CRASH_IN_VIEWS"):   # test hook for the guard above
+                    import signal
+                    os.kill(os.getpid(), signal.SIGSEGV)
                 vhost, vdev = make_images(12345, args.distinct, nblobs)       # every rank holds every pair
                 nb_v = batch * world
                 v1 = [vdev[i % len(vdev)][0] for i in range(nb_v)]
@@ -693,6 +732,8 @@ def main():
         except OSError:
             pass
         sys.stdout.flush()
+        if guard_flag:
+            open(guard_flag, "w").close()     # from here on the line is this process's to print
         print(json.dumps(out), flush=True)
     if views_hung:
         sys.stdout.flush()
