@@ -42,6 +42,7 @@ enum { MODSX_DET_HESSIAN = 0, MODSX_DET_DOG = 1, MODSX_DET_HARRIS = 2, MODSX_DET
  * orientation bins into 64 values; their rows keep the 128 stride with entries 64..127 zero, which leaves every
  * L2 distance unchanged, so the matcher needs no second layout. */
 enum { MODSX_DESC_SIFT = 0, MODSX_DESC_ROOT_SIFT = 1, MODSX_DESC_HALF_SIFT = 2, MODSX_DESC_HALF_ROOT_SIFT = 3 };
+#define MODSX_MAX_DESC 4   /* descriptor classes one step can carry (the four SIFT-family types above) */
 /* ScaleSpaceDetector point types, affinedetectors/pyramid.h:32-36 */
 enum { MODSX_HESSIAN_DARK = 0, MODSX_HESSIAN_BRIGHT = 1, MODSX_HESSIAN_SADDLE = 2 };
 
@@ -125,6 +126,13 @@ typedef struct modsx_pair_params {
   int errorType;       /* RANSAC_error_t: 0 SAMPSON, 1 SYMM_MAX, 2 SYMM_SUM (F path: 1 and 2 both select FDsSym) */
   int detector;        /* MODSX_DET_HESSIAN (det) or MODSX_DET_MSER (mser): which detector the view loop runs */
   modsx_mser_params mser;
+  /* The `Descriptors=` / `FGINNThreshold=` lists of one [DetectorN] section (iters_mods_cviu_wxbs.ini:35-36: RootSIFT,
+   * HalfRootSIFT with 0.85, 0.8).  n_desc = 0: the one class {desc_type, match_ratio}.  n_desc = 1..4: the step carries these
+   * descriptor classes, each matched with its own ratio; desc_type / match_ratio are then ignored.  See "descriptor classes"
+   * at modsx_ladder_step. */
+  int n_desc;
+  int desc_types[MODSX_MAX_DESC];
+  double desc_ratios[MODSX_MAX_DESC];
 } modsx_pair_params;
 
 typedef struct modsx_pair_result {
@@ -379,13 +387,29 @@ int modsx_match_pair_views(modsx_ctx *ctx, const modsx_image *img1, const modsx_
  * iteration's section) overrides par->match_ratio when > 0.  *steps_done = steps executed.
  * Two detector classes are kept apart as in the reference (separate_detectors): a step adds regions to, and re-matches,
  * only the class of its own detector; the other class keeps its tentatives (CorrespondenceBank, correspondencebank.cpp:
- * 180-218) and GetCorresponcesVector() concatenates HessianAffine before MSER (map order).  Region indices of the result
- * refer to the concatenation [HessianAffine regions, MSER regions] of each image. */
+ * 180-218) and GetCorresponcesVector() concatenates HessianAffine before MSER (map order).
+ *   Descriptor classes (the WxBS ladder, iters_mods_cviu_wxbs.ini:35-41,48-54,61-67).  A step may carry several descriptors.
+ * The reference then keeps one region list per (detector, descriptor) -- RegionVectorMap[det][desc] -- and one tentative list
+ * per (descriptor, detector), each matched separately with the FGINNThreshold of its descriptor (MatchImgReps,
+ * correspondencebank.cpp:291-347).  All descriptors of a step are computed on ONE oriented region list: when any of them
+ * is a Half type the dominant orientations come from DetectOrientation(..., doHalfSIFT = true, ...) (opposite histogram
+ * bins folded, synth-detection.cpp:801-808) and every descriptor of the step -- RootSIFT included -- is described on that
+ * list (imagerepresentation.cpp:693-706, 1259-1264, 1288-1296).  The fused callers do exactly that: one orientation pass
+ * (Half-folded iff a Half type is present), one pass over the patches that emits every descriptor of the step.
+ *   GetCorresponcesVector("All", "All") walks std::map<descriptor name, std::map<detector name, list>> (correspondencebank.cpp:
+ * 117-179), i.e. the tentatives reach DuplicateFiltering / LO-RANSAC in the order HalfRootSIFT, HalfSIFT, RootSIFT, SIFT and,
+ * inside a descriptor, HessianAffine before MSER.  Region indices of the result refer to the concatenation of the per-class
+ * region lists of each image in that same order (with one descriptor class: [HessianAffine regions, MSER regions]). */
 typedef struct modsx_ladder_step {
   const modsx_view *views;
   int nviews;
   double match_ratio;
   int detector;      /* MODSX_DET_HESSIAN (0) or MODSX_DET_MSER: the [HessianAffineN] / [MSERN] section this step comes from */
+  /* the section's Descriptors / FGINNThreshold lists; n_desc = 0: par->n_desc / desc_types / desc_ratios (and, when those are
+   * empty too, the one class {par->desc_type, match_ratio}) */
+  int n_desc;
+  int desc_types[MODSX_MAX_DESC];
+  double desc_ratios[MODSX_MAX_DESC];
 } modsx_ladder_step;
 int modsx_match_ladder(modsx_ctx *ctx, const modsx_image *img1, const modsx_image *img2,
                        const modsx_ladder_step *steps, int nsteps, int min_matches, const modsx_pair_params *par,

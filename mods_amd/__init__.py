@@ -50,7 +50,8 @@ class PairParams(C.Structure):
                 ("err_threshold", C.c_double), ("confidence", C.c_double), ("max_samples", C.c_int),
                 ("localOptimization", C.c_int), ("HLAFCoef", C.c_double), ("doSymmCheck", C.c_int),
                 ("ransac_seed", C.c_uint), ("useF", C.c_int), ("LAFCoef", C.c_double), ("errorType", C.c_int),
-                ("detector", C.c_int), ("mser", MserParams)]
+                ("detector", C.c_int), ("mser", MserParams),
+                ("n_desc", C.c_int), ("desc_types", C.c_int * 4), ("desc_ratios", C.c_double * 4)]
 
 
 class View(C.Structure):
@@ -72,7 +73,8 @@ def _view_array(views):
 
 
 class LadderStep(C.Structure):
-    _fields_ = [("views", C.c_void_p), ("nviews", C.c_int), ("match_ratio", C.c_double), ("detector", C.c_int)]
+    _fields_ = [("views", C.c_void_p), ("nviews", C.c_int), ("match_ratio", C.c_double), ("detector", C.c_int),
+                ("n_desc", C.c_int), ("desc_types", C.c_int * 4), ("desc_ratios", C.c_double * 4)]
 
 
 class PairResult(C.Structure):
@@ -194,12 +196,22 @@ def detect_msers_u8(gray, params=None, tilt=1.0, zoom=1.0):
 def default_pair_params(**kw):
     p = PairParams()
     lib().modsx_default_pair_params(C.byref(p))
+    descs = kw.pop("descs", None)     # [(MODSX_DESC_* type, FGINN ratio), ...]: the step's Descriptors / FGINNThreshold lists
+    if descs is not None:
+        _set_descs(p, descs)
     for k, v in kw.items():
         if hasattr(p.det, k) and not hasattr(p, k):
             setattr(p.det, k, v)
         else:
             setattr(p, k, v)
     return p
+
+
+def _set_descs(obj, descs):
+    obj.n_desc = len(descs)
+    for i, (t, r) in enumerate(descs):
+        obj.desc_types[i] = int(t)
+        obj.desc_ratios[i] = float(r)
 
 
 def _take(ptr, n, dtype):
@@ -550,8 +562,9 @@ class Context(object):
         return _take(out, n, KEYPOINT)
 
     def match_ladder(self, img1, img2, steps, params, min_matches=10, comm=None):
-        """steps: list of (views, match_ratio[, detector]).  Returns (result dict, steps executed).  comm: a communicator
-        handle => modsx_match_ladder_sharded (every step's views sharded over the ranks)."""
+        """steps: list of (views, match_ratio[, detector[, descs]]); descs = [(descriptor type, FGINN ratio), ...] is the
+        section's Descriptors / FGINNThreshold lists (None: the parameter block's).  Returns (result dict, steps executed).
+        comm: a communicator handle => modsx_match_ladder_sharded (every step's views sharded over the ranks)."""
         arr = (LadderStep * len(steps))()
         keep = []
         for i, st in enumerate(steps):
@@ -562,6 +575,8 @@ class Context(object):
             arr[i].nviews = len(views)
             arr[i].match_ratio = float(ratio)
             arr[i].detector = int(st[2]) if len(st) > 2 else 0
+            if len(st) > 3 and st[3] is not None:
+                _set_descs(arr[i], st[3])
         res = PairResult()
         done = C.c_int(0)
         if comm is not None:

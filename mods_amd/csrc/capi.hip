@@ -452,7 +452,7 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
         vq.q.pop_front();
       }
       const auto v0 = std::chrono::steady_clock::now();
-      mx::verify_tentatives(t.r1, t.r2, t.tents, pp, t.res);
+      mx::verify_tentatives(t.l1, t.l2, t.tents, pp, t.res);
       g_verifyUs += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - v0).count();
       g_verifyPairs++;
     }
@@ -534,7 +534,7 @@ int modsx_match_pairs_views(modsx_ctx *const *ctxs, int n_ctx, const modsx_image
         vq.q.pop_front();
       }
       const auto v0 = std::chrono::steady_clock::now();
-      mx::verify_tentatives(t.r1, t.r2, t.tents, pp, t.res);
+      mx::verify_tentatives(t.l1, t.l2, t.tents, pp, t.res);
       g_verifyUs += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - v0).count();
       g_verifyPairs++;
     }

@@ -220,7 +220,9 @@ void ctx_destroy(modsx_ctx *c) {
                     &c->taps, &c->imgRefs, &c->scratchA, &c->scratchB, &c->descAllF[0], &c->descAllF[1], &c->descAllU8[0],
                     &c->descAllU8[1], &c->descAllU8b[0], &c->descAllU8b[1], &c->shardLocal, &c->pos2, &c->matchRows, &c->matchWork, &c->misc, &c->scratchC, &c->needTab, &c->coordTab, &c->tileJob, &c->blurTiles, &c->nmsQueue, &c->rowStarts, &c->viewTmp[0], &c->viewTmp[1], &c->viewTaps, &c->viewJobs};
   for (DevBuf *b : bufs) b->release();
-  for (int i = 0; i < MAXB; i++) { c->descF[i].release(); c->descU8[i].release(); c->viewImg[i].release(); }
+  for (int i = 0; i < MAXB; i++) { c->descF[i].release(); c->descU8[i].release(); c->viewImg[i].release(); for (int k = 0; k < 3; k++) c->descU8x[k][i].release(); }
+  for (int d = 0; d < 2; d++) for (int t = 0; t < 4; t++) for (int sd = 0; sd < 2; sd++) c->descCls[d][t][sd].release();
+  for (int t = 0; t < 4; t++) c->halfDesc[t].release();
   PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc, &c->hNms, &c->hMatch, &c->hViewTaps, &c->hViewJobs, &c->hMser};
   for (PinBuf *b : pins) b->release();
   hipFree(c->dSmmMask); hipFree(c->dOriMask); hipFree(c->dOriIdx); hipFree(c->dSiftMask); hipFree(c->dSiftMaskIdx); hipFree(c->dAtan); hipFree(c->dOriBinTab); hipFree(c->dSiftOTab); hipFree(c->dSiftBins);
@@ -700,6 +702,27 @@ void detect_affine_regions(const modsx_keypoint *kps, int n, int img_id, int det
 
 static const double K_SIGMA = 2 * 3.0 * sqrt(3.0);  // synth-detection.cpp:28
 
+// `Descriptors=` / `FGINNThreshold=` of the step: the step's own list, else the parameter block's, else {desc_type, match_ratio}
+// ord[0..n): the classes of ds in descriptor-NAME order, the outer key of CorrespondencesMapMap (correspondencebank.cpp:117-179):
+// "HalfRootSIFT" (3) < "HalfSIFT" (2) < "RootSIFT" (1) < "SIFT" (0)
+void desc_class_order(const DescSet &ds, int *ord) {
+  int m = 0;
+  for (int type = 3; type >= 0; type--)
+    for (int i = 0; i < ds.n; i++) if (ds.type[i] == type) ord[m++] = i;
+}
+int resolve_descs(const modsx_pair_params &pp, const modsx_ladder_step *st, DescSet &ds) {
+  const int ns = st ? st->n_desc : 0;
+  if (ns < 0 || ns > MODSX_MAX_DESC || pp.n_desc < 0 || pp.n_desc > MODSX_MAX_DESC) { set_error("n_desc must be 0..4"); return MODSX_ERR_ARG; }
+  if (ns > 0) { ds.n = ns; for (int i = 0; i < ns; i++) { ds.type[i] = st->desc_types[i]; ds.ratio[i] = st->desc_ratios[i]; } }
+  else if (pp.n_desc > 0) { ds.n = pp.n_desc; for (int i = 0; i < ds.n; i++) { ds.type[i] = pp.desc_types[i]; ds.ratio[i] = pp.desc_ratios[i]; } }
+  else { ds.n = 1; ds.type[0] = pp.desc_type; ds.ratio[0] = st && st->match_ratio > 0 ? st->match_ratio : pp.match_ratio; }
+  for (int i = 0; i < ds.n; i++) {
+    if (ds.type[i] < 0 || ds.type[i] > 3) { set_error("descriptor type must be 0..3 (SIFT, RootSIFT, HalfSIFT, HalfRootSIFT)"); return MODSX_ERR_ARG; }
+    for (int j = 0; j < i; j++) if (ds.type[j] == ds.type[i]) { set_error("a descriptor type is listed twice in one step"); return MODSX_ERR_ARG; }
+  }
+  return MODSX_OK;
+}
+
 static int upload_img_refs(modsx_ctx *c, const modsx_image *const *imgs, int n) {
   const bool fresh = !c->imgRefs.p;
   if (!c->imgRefs.ensure(MAXB * sizeof(ImgRef))) return MODSX_ERR_NOMEM;
@@ -753,25 +776,26 @@ int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n
   jobs.resize(jobStart[n]);
   host_parallel_light(n, [&](int i) { if (!jobsOf[i].empty()) memcpy(jobs.data() + jobStart[i], jobsOf[i].data(), jobsOf[i].size() * sizeof(OriJob)); });
   hm.mark("orientation jobs");
-  const OriOut *res = nullptr;   // in the pinned staging buffer
+  const float *res = nullptr;   // in the pinned staging buffer: (1 + maxA) words per job
+  const int maxA = maxAngNum < 0 ? ORI_MAX_PEAKS : std::min(maxAngNum, ORI_MAX_PEAKS);
+  const size_t oriB = (size_t)(1 + maxA) * 4;
   if (!jobs.empty()) {
     int rc = upload_img_refs(c, imgs, n);
     if (rc) return rc;
     hipStream_t s = c->stream;
     size_t nj = jobs.size();
-    if (!c->oriJobs.ensure(nj * sizeof(OriJob)) || !c->oriOut.ensure(nj * sizeof(OriOut)) ||
-        !c->hOri.ensure(nj * (sizeof(OriJob) + sizeof(OriOut))))
+    if (!c->oriJobs.ensure(nj * sizeof(OriJob)) || !c->oriOut.ensure(nj * oriB) ||
+        !c->hOri.ensure(nj * (sizeof(OriJob) + oriB)))
       return MODSX_ERR_NOMEM;
     // jobs up and results down through pinned memory: pageable transfers are staged and serialised by the runtime
     memcpy(c->hOri.p, jobs.data(), nj * sizeof(OriJob));
-    OriOut *hres = (OriOut *)((char *)c->hOri.p + nj * sizeof(OriJob));
+    float *hres = (float *)((char *)c->hOri.p + nj * sizeof(OriJob));
     res = hres;
     MX_HIP(hipMemcpyAsync(c->oriJobs.p, c->hOri.p, nj * sizeof(OriJob), hipMemcpyHostToDevice, s));
-    int maxA = maxAngNum == -1 ? 7 : std::min(maxAngNum, 7);
     ProfScope ps(c, K_ORIENT, (double)nj * 41 * 41 * 4);
-    launch_orientation(s, (OriJob *)c->oriJobs.p, (OriOut *)c->oriOut.p, (int)nj, (ImgRef *)c->imgRefs.p, c->dOriIdx,
+    launch_orientation(s, (OriJob *)c->oriJobs.p, (float *)c->oriOut.p, (int)nj, (ImgRef *)c->imgRefs.p, c->dOriIdx,
                        c->dOriMask, c->dOriBinTab, doHalfSIFT, th, maxA);
-    MX_HIP(hipMemcpyAsync(hres, c->oriOut.p, nj * sizeof(OriOut), hipMemcpyDeviceToHost, s));
+    MX_HIP(hipMemcpyAsync(hres, c->oriOut.p, nj * oriB, hipMemcpyDeviceToHost, s));
     MX_HIP(hipStreamSynchronize(s));
   }
   hm.mark("orientation launch + wait");
@@ -784,11 +808,13 @@ int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n
       modsx_region base = in[i][r];
       if (maxAngNum > 0) {
         base.id = 0;  // const_temp_region.id = count, count is never incremented (synth-detection.cpp:854,889)
-        const OriOut &o = res[jk++];
-        for (int a = 0; a < o.n; a++) {
+        const float *o = res + (jk++) * (size_t)(1 + maxA);
+        int on;
+        memcpy(&on, o, 4);
+        for (int a = 0; a < on; a++) {
           // `using namespace std` in synth-detection.cpp:30 => cos/sin(float) are the f32 overloads
-          double ci = cosf(-o.ang[a]);
-          double si = sinf(-o.ang[a]);
+          double ci = cosf(-o[1 + a]);
+          double si = sinf(-o[1 + a]);
           modsx_region t = base;
           t.det_kp.a11 = base.det_kp.a11 * ci - base.det_kp.a12 * si;
           t.det_kp.a12 = base.det_kp.a11 * si + base.det_kp.a12 * ci;
@@ -839,8 +865,12 @@ int reproject_regions(modsx_region *regs, int n, const double *H, int orig_w, in
 // (c->descF[i], c->descU8[i]); descHost[i] (optional) receives the f32 copy.
 int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const std::vector<modsx_region> *regs,
                    double mrSize, int patchSize, int fast, int photoNorm, int descType, double maxBin,
-                   float *const *descHost, float *const *devF, uint8_t *const *devU8) {
+                   float *const *descHost, float *const *devF, uint8_t *const *devU8, const DescSet *ds,
+                   uint8_t *const *const *devU8x) {
   if (patchSize != 41) { set_error("descriptor patchSize must be 41"); return MODSX_ERR_ARG; }
+  DescSet one;
+  if (!ds) { one.n = 1; one.type[0] = descType; ds = &one; }
+  if (ds->n < 1 || ds->n > MODSX_MAX_DESC) { set_error("describe: 1..4 descriptor classes"); return MODSX_ERR_ARG; }
   if (n > MAXB) { set_error("describe batch too large"); return MODSX_ERR_ARG; }
   hipStream_t s = c->stream;
   int rc = upload_img_refs(c, imgs, n);
@@ -859,6 +889,11 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
     if (!outF) { if (!c->descF[i].ensure(std::max<size_t>(1, nr) * 128 * 4)) return MODSX_ERR_NOMEM; outF = (float *)c->descF[i].p; }
     if (!outU8) { if (!c->descU8[i].ensure(std::max<size_t>(1, nr) * 128)) return MODSX_ERR_NOMEM; outU8 = (uint8_t *)c->descU8[i].p; }
     outs.f[i] = outF; outs.u8[i] = outU8;
+    for (int k = 1; k < ds->n; k++) {
+      uint8_t *o = devU8x && devU8x[k - 1] ? devU8x[k - 1][i] : nullptr;
+      if (!o) { if (!c->descU8x[k - 1][i].ensure(std::max<size_t>(1, nr) * 128)) return MODSX_ERR_NOMEM; o = (uint8_t *)c->descU8x[k - 1][i].p; }
+      outs.u8x[k - 1][i] = o;
+    }
   }
   // the regions of all images of the batch go through one launch set per chunk (a chunk ends when the window arena is
   // full); region order inside an image is kept, outIdx addresses the image's own descriptor buffer
@@ -1141,10 +1176,10 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
         launch_blur_cols(s, btC, pfxColL.back(), dTaps, dNeed, (float *)c->scratchB.p, (float *)c->scratchC.p);
         launch_patch_blur(s, dj, dPfxC, tjC, pfxCol.back(), dTaps, dNeed, (float *)c->scratchB.p,
                           (float *)c->scratchC.p, 1); }
-      ProfScope psd(c, K_DESCRIBE, (double)nj * 128);
+      ProfScope psd(c, K_DESCRIBE, (double)nj * 128 * ds->n);
       launch_describe(s, dj, (int)nj, (ImgRef *)c->imgRefs.p, (float *)c->scratchC.p, dNeed, dCoord,
                       c->dSiftMask, c->dSiftMaskIdx, c->nSiftMask, c->dSiftOTab,
-                      c->dSiftBins, c->dSiftW, photoNorm, descType, maxBin, outs);
+                      c->dSiftBins, c->dSiftW, photoNorm, ds->packed(), ds->n, maxBin, outs);
       chunkNo++;
     }
   }
@@ -1314,6 +1349,12 @@ int match_host_desc(modsx_ctx *c, const float *desc1, int n1, const float *desc2
 // Fills the counters, H and the three malloc'd arrays of `res` (which must not own arrays yet).
 void verify_tentatives(const std::vector<modsx_region> &r1, const std::vector<modsx_region> &r2,
                        const std::vector<modsx_tentative> &tents, const modsx_pair_params &pp, modsx_pair_result *res) {
+  RegList a, b;
+  a.add(r1); b.add(r2);
+  verify_tentatives(a, b, tents, pp, res);
+}
+void verify_tentatives(const RegList &r1, const RegList &r2, const std::vector<modsx_tentative> &tents,
+                       const modsx_pair_params &pp, modsx_pair_result *res) {
   HostMark hm;
   res->n_tentatives = (int)tents.size();
   const int T0 = (int)tents.size();
@@ -1386,7 +1427,12 @@ int match_pair_group(modsx_ctx *c, const modsx_image *const *imgs1, const modsx_
     detect_affine_regions(kps[i].data(), (int)kps[i].size(), 0, MODSX_DET_HESSIAN, regs[i].data());
   }
   const double t1 = now_ms();
-  rc = detect_orientation_batch(c, imgs, n, regs, pp.ori_mrSize, pp.ori_patchSize, 0, pp.ori_maxAngles, pp.ori_threshold,
+  // the step's descriptor classes: ONE oriented list (Half-folded orientation histogram iff a Half type is among them,
+  // imagerepresentation.cpp:693-706, 1259-1264, 1288-1296), one pass over the patches for all of them
+  DescSet ds;
+  rc = resolve_descs(pp, nullptr, ds);
+  if (rc) return rc;
+  rc = detect_orientation_batch(c, imgs, n, regs, pp.ori_mrSize, pp.ori_patchSize, ds.half() ? 1 : 0, pp.ori_maxAngles, pp.ori_threshold,
                                 0, oriented);
   if (rc) return rc;
   const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -1395,56 +1441,71 @@ int match_pair_group(modsx_ctx *c, const modsx_image *const *imgs1, const modsx_
     oriented[i].resize(m);
   }
   const double t2 = now_ms();
-  rc = describe_batch(c, imgs, n, oriented, pp.desc_mrSize, pp.desc_patchSize, 0, pp.desc_photoNorm, pp.desc_type,
-                      pp.desc_maxBinValue, nullptr, nullptr, nullptr);
+  rc = describe_batch(c, imgs, n, oriented, pp.desc_mrSize, pp.desc_patchSize, 0, pp.desc_photoNorm, ds.type[0],
+                      pp.desc_maxBinValue, nullptr, nullptr, nullptr, &ds);
   if (rc) return rc;
   const double t3 = now_ms();
   double tMatch = 0, tVerify = 0;
-  // With a `deferred` list (modsx_match_pairs) the G matching problems share the matcher's launches and verification is
-  // handed to the caller's helper threads; otherwise matching and verification alternate pair by pair.
-  if (deferred) {
-    std::vector<double> pos2v[MAXB / 2];
-    std::vector<modsx_tentative> tentsv[MAXB / 2];
-    const double m0 = now_ms();
+  // classes in the order GetCorresponcesVector("All", "All") walks them: descriptor NAME order (correspondencebank.cpp:117-179)
+  int ord[MODSX_MAX_DESC];
+  desc_class_order(ds, ord);
+  auto desc_of = [&](int k, int img) -> const uint8_t * { return (const uint8_t *)(k == 0 ? c->descU8[img].p : c->descU8x[k - 1][img].p); };
+  std::vector<double> pos2v[MAXB / 2];
+  std::vector<modsx_tentative> tentsv[MAXB / 2];
+  const double m0 = now_ms();
+  for (int g = 0; g < G; g++) {
+    const std::vector<modsx_region> &rb = oriented[2 * g + 1];
+    res[g].n_regions1 = (int)oriented[2 * g].size() * ds.n;
+    res[g].n_regions2 = (int)rb.size() * ds.n;
+    pos2v[g].resize(rb.size() * 2 + 2);
+    for (size_t i = 0; i < rb.size(); i++) { pos2v[g][2 * i] = rb[i].reproj_kp.x; pos2v[g][2 * i + 1] = rb[i].reproj_kp.y; }
+  }
+  // the G matching problems of a class share the matcher's launches; each class has its own FGINN threshold
+  for (int oi = 0; oi < ds.n; oi++) {
+    const int k = ord[oi];
     const uint8_t *pd1[MAXB / 2], *pd2[MAXB / 2];
     const double *ppos[MAXB / 2];
     int pn1[MAXB / 2], pn2[MAXB / 2];
+    std::vector<modsx_tentative> part[MAXB / 2];
     for (int g = 0; g < G; g++) {
-      const std::vector<modsx_region> &rb = oriented[2 * g + 1];
-      res[g].n_regions1 = (int)oriented[2 * g].size();
-      res[g].n_regions2 = (int)rb.size();
-      pos2v[g].resize(rb.size() * 2 + 2);
-      for (size_t i = 0; i < rb.size(); i++) { pos2v[g][2 * i] = rb[i].reproj_kp.x; pos2v[g][2 * i + 1] = rb[i].reproj_kp.y; }
-      pd1[g] = (uint8_t *)c->descU8[2 * g].p; pd2[g] = (uint8_t *)c->descU8[2 * g + 1].p;
-      pn1[g] = res[g].n_regions1; pn2[g] = res[g].n_regions2; ppos[g] = pos2v[g].data();
+      pd1[g] = desc_of(k, 2 * g); pd2[g] = desc_of(k, 2 * g + 1);
+      pn1[g] = (int)oriented[2 * g].size(); pn2[g] = (int)oriented[2 * g + 1].size(); ppos[g] = pos2v[g].data();
     }
     for (int g0 = 0; g0 < G; g0 += MATCH_MAXB) {
       const int nbm = std::min(MATCH_MAXB, G - g0);
-      rc = match_device_batch(c, nbm, pd1 + g0, pn1 + g0, pd2 + g0, pn2 + g0, ppos + g0, pp.match_ratio, pp.contradDist, pp.nn,
-                              tentsv + g0, nullptr);
+      rc = match_device_batch(c, nbm, pd1 + g0, pn1 + g0, pd2 + g0, pn2 + g0, ppos + g0, ds.ratio[k], pp.contradDist, pp.nn,
+                              part + g0, nullptr);
       if (rc) return rc;
     }
-    tMatch = now_ms() - m0;
     for (int g = 0; g < G; g++) {
+      const int o1 = oi * pn1[g], o2 = oi * pn2[g];
+      if (oi == 0) { tentsv[g].swap(part[g]); continue; }
+      for (modsx_tentative t : part[g]) {
+        t.q += o1; t.t0 += o2;
+        if (t.t1 >= 0) t.t1 += o2;
+        if (t.tj >= 0) t.tj += o2;
+        tentsv[g].push_back(t);
+      }
+    }
+  }
+  tMatch = now_ms() - m0;
+  for (int g = 0; g < G; g++) {
+    if (deferred) {   // modsx_match_pairs: verification is handed to the caller's helper threads
       deferred->emplace_back();
       VerifyTask &t = deferred->back();
-      t.r1.swap(oriented[2 * g]); t.r2.swap(oriented[2 * g + 1]); t.tents.swap(tentsv[g]); t.res = &res[g];
+      t.own.resize(2);
+      t.own[0].swap(oriented[2 * g]); t.own[1].swap(oriented[2 * g + 1]);
+      for (int oi = 0; oi < ds.n; oi++) { t.l1.add(t.own[0]); t.l2.add(t.own[1]); }
+      t.tents.swap(tentsv[g]); t.res = &res[g];
+    } else {
+      const double m1 = now_ms();
+      RegList l1, l2;
+      for (int oi = 0; oi < ds.n; oi++) { l1.add(oriented[2 * g]); l2.add(oriented[2 * g + 1]); }
+      const int nr1 = res[g].n_regions1, nr2 = res[g].n_regions2;
+      verify_tentatives(l1, l2, tentsv[g], pp, &res[g]);
+      res[g].n_regions1 = nr1; res[g].n_regions2 = nr2;
+      tVerify += now_ms() - m1;
     }
-  } else
-  for (int g = 0; g < G; g++) {
-    const std::vector<modsx_region> &ra = oriented[2 * g], &rb = oriented[2 * g + 1];
-    const double m0 = now_ms();
-    res[g].n_regions1 = (int)ra.size();
-    res[g].n_regions2 = (int)rb.size();
-    std::vector<double> pos2(rb.size() * 2 + 2);
-    for (size_t i = 0; i < rb.size(); i++) { pos2[2 * i] = rb[i].reproj_kp.x; pos2[2 * i + 1] = rb[i].reproj_kp.y; }
-    std::vector<modsx_tentative> tents;
-    rc = match_device(c, (uint8_t *)c->descU8[2 * g].p, res[g].n_regions1, (uint8_t *)c->descU8[2 * g + 1].p,
-                      res[g].n_regions2, pos2.data(), pp.match_ratio, pp.contradDist, pp.nn, tents);
-    if (rc) return rc;
-    const double m1 = now_ms();
-    verify_tentatives(ra, rb, tents, pp, &res[g]);
-    tMatch += m1 - m0; tVerify += now_ms() - m1;
   }
   const double t5 = now_ms();
   prof_collect(c);

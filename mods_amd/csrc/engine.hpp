@@ -72,7 +72,9 @@ struct OriJob {
   int img;
   float x, y, a11, a12, a21, a22;  // A * curr_sc, f32 (synth-detection.cpp:892-898)
 };
-struct OriOut { int n; float ang[7]; };
+// orientation results: (1 + maxA) 32-bit words per region -- the angle count, then the angles; maxA = min(maxAngles, 18), the
+// most strict local maxima a 36-bin circular histogram can have (so "all peaks", maxAngles = -1, loses none)
+constexpr int ORI_MAX_PEAKS = 18;
 
 // describe
 struct DescJob {
@@ -102,7 +104,8 @@ struct BlurTile {     // one workgroup of the LDS blur kernels
   int first, count, lo, span, magic;  // rows pass: window rows [first, first+count); columns pass: needed rows, parked source rows [lo, lo+span); magic = ceil(2^20 / ceil(NC / 2))
 };
 struct ImgRef { const float *d; int rows, cols, pad; };
-struct DescOut { float *f[MAXB]; uint8_t *u8[MAXB]; };   // per image of the batch: [n][128] f32 and u8 descriptors
+// per image of the batch: [n][128] f32 and u8 descriptors of the step's first descriptor class, u8 of up to three more
+struct DescOut { float *f[MAXB]; uint8_t *u8[MAXB]; uint8_t *u8x[3][MAXB]; };
 
 // view synthesis
 struct WarpJob {
@@ -190,7 +193,7 @@ void launch_baumberg(hipStream_t s, const AffJob *jobs, AffOut *out, int n, cons
                      float convTh, float affInitialSigma);
 constexpr int ATAN_CASES = 2048 + 64;   // 8 x 256 (sign / octant bits, table index) values of atan2LUTff's angle + the special case (entry 2048), padded
 constexpr int ORI_NV = 1280;   // entries of the orientation kernel's voting-pixel list (1245 under the mask, padded)
-void launch_orientation(hipStream_t s, const OriJob *jobs, OriOut *out, int n, const ImgRef *imgs,
+void launch_orientation(hipStream_t s, const OriJob *jobs, float *out, int n, const ImgRef *imgs,
                         const unsigned short *maskIdx, const float *maskW,
                         const unsigned char *binTab, int doHalf, double th, int maxAngles);
 void launch_trunc_u8(hipStream_t s, const float *src, uint8_t *dst, size_t n);
@@ -208,7 +211,7 @@ void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix
 void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *imgs, const float *grid,
                      const int *needTab, const float *coordTab,
                      const float *mask, const unsigned short *maskIdx, int nmask, const float *oTab, const int *bins,
-                     const double *wts, int photoNorm, int descType, double maxBin, const DescOut &outs);
+                     const double *wts, int photoNorm, int descTypes, int nOut, double maxBin, const DescOut &outs);
 void launch_warp_affine(hipStream_t s, const WarpJob &jb);
 void launch_blur_pass(hipStream_t s, const float *src, float *dst, int rows, int cols, const float *taps, int n, int pass, int border = 0);
 void launch_sub(hipStream_t s, const float *a, const float *b, float *o, size_t n);
@@ -270,7 +273,7 @@ struct modsx_ctx {
   hipStream_t stream;
   mx::Pyramid pyr[mx::MAXB];
   mx::DevBuf nmsJobs, cand, counter, affJobs, affOut, oriJobs, oriOut, descJobs, tilePrefix, taps, imgRefs, scratchA, scratchB,
-      descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], descAllU8b[2], shardLocal, pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps, viewJobs, viewImg[mx::MAXB], scratchC, needTab, coordTab, tileJob, blurTiles, nmsQueue, rowStarts;
+      descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], descAllU8b[2], descCls[2][4][2], descU8x[3][mx::MAXB], shardLocal, pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps, viewJobs, viewImg[mx::MAXB], scratchC, needTab, coordTab, tileJob, blurTiles, nmsQueue, rowStarts;
   mx::ImgRef imgRefsHost[mx::MAXB];   // what imgRefs holds on the device
   mx::PinBuf hDescB;           // second staging blob of describe_batch: chunk k + 1 is prepared while chunk k runs
   hipEvent_t descEv[2];
@@ -298,6 +301,6 @@ struct modsx_ctx {
   int shardLane = 0;           // lane of the rank's communicator this context issues its collectives on (engine_shard.hip)
   modsx_ctx *peer = nullptr;   // second stream + buffers, created on demand: the two images of a multi-view pair run side by side
   modsx_ctx *half = nullptr;   // a lone pair: the second part of an image's views runs here (accumulate_views)
-  mx::DevBuf halfDesc;         // ... and writes its descriptors here until the first part's count is known
+  mx::DevBuf halfDesc[4];      // ... and writes its descriptors (one buffer per descriptor class of the step) here until the first part's count is known
   void *worker = nullptr;      // CtxWorker: the host thread that drives this context when it is a peer / half (engine_views.hip)
 };

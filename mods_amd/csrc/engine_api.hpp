@@ -24,9 +24,25 @@ int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n
                              double mrSize, int patchSize, int doHalfSIFT, int maxAngNum, double th, int addUpRight,
                              std::vector<modsx_region> *out);
 int reproject_regions(modsx_region *regs, int n, const double *H, int orig_w, int orig_h);
+// The descriptor classes one step carries (modsx_pair_params / modsx_ladder_step n_desc, desc_types, desc_ratios resolved):
+// `Descriptors=` and `FGINNThreshold=` of a [DetectorN] section.  half(): the step orients with doHalfSIFT = true
+// (imagerepresentation.cpp:693-706, 1259-1264).
+struct DescSet {
+  int n = 1;
+  int type[MODSX_MAX_DESC] = {MODSX_DESC_ROOT_SIFT, 0, 0, 0};
+  double ratio[MODSX_MAX_DESC] = {0, 0, 0, 0};
+  bool forceHalf = false;   // a caller that takes only the first class of a longer list keeps the list's orientation mode
+  bool half() const { for (int i = 0; i < n; i++) if (type[i] >= 2) return true; return forceHalf; }
+  int packed() const { int p = 0; for (int i = 0; i < n; i++) p |= (type[i] & 15) << (4 * i); return p; }
+};
+// rc = MODSX_ERR_ARG for a type outside 0..3, a type listed twice or n_desc outside 0..4
+int resolve_descs(const modsx_pair_params &pp, const modsx_ladder_step *st, DescSet &ds);
+void desc_class_order(const DescSet &ds, int *ord);   // the classes in descriptor-name order (GetCorresponcesVector)
+// devU8x (optional): devU8x[k][i] receives the u8 descriptors of class k + 1 of image i (default: c->descU8x[k][i])
 int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const std::vector<modsx_region> *regs,
                    double mrSize, int patchSize, int fast, int photoNorm, int descType, double maxBin,
-                   float *const *descHost, float *const *devF, uint8_t *const *devU8);
+                   float *const *descHost, float *const *devF, uint8_t *const *devU8, const DescSet *ds = nullptr,
+                   uint8_t *const *const *devU8x = nullptr);
 struct ProfScopeFwd;
 int set_vs_pars(const double *scale_set, int ns, const double *tilt_set, int nt, double phi_base, double InitSigma,
                 int doBlur, modsx_view *par, int cap, modsx_view *prev, int *nprev, int cap_prev);
@@ -37,7 +53,8 @@ int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx
                int slot = -1);
 int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_view *views, int nv,
                           const modsx_pair_params &pp, int view_begin, int view_step, std::vector<modsx_region> &regs,
-                          float *devF, uint8_t *devU8, size_t devCapRegions, float *hostDesc, int *viewCounts);
+                          float *devF, uint8_t *devU8, size_t devCapRegions, float *hostDesc, int *viewCounts,
+                          const DescSet *ds = nullptr, uint8_t *const *devU8x = nullptr);
 void ctx_worker_stop(modsx_ctx *c);   // joins the context's host thread, if it has one (ctx_destroy)
 void rebase_ids(std::vector<modsx_region> &regs, const int *viewCounts, int nv, size_t base);
 struct VerifyTask;
@@ -55,8 +72,8 @@ struct MatchShard { void *comm; int world, per, n1_total, lo; };
 int match_shard_begin(modsx_ctx *c, const MatchShard &sh, mx::MatchRow **blk);
 int match_shard_gather(modsx_ctx *c, const MatchShard &sh, int local_rc, mx::MatchRow *host);
 int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *img, const modsx_view *views, int nv,
-                                  const modsx_pair_params &pp, std::vector<modsx_region> &regs, DevBuf &descAcc, size_t base,
-                                  int *viewCounts);
+                                  const modsx_pair_params &pp, const DescSet &ds, std::vector<modsx_region> &regs,
+                                  DevBuf *const *descAcc, const size_t *base, int *viewCounts);
 int comm_rank(const modsx_comm *cm);
 int match_sharded(modsx_ctx *c, modsx_comm *cm, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2Host,
                   double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out);
@@ -67,12 +84,33 @@ int match_device(modsx_ctx *c, const uint8_t *d1, int n1, const uint8_t *d2, int
                  double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out);
 int match_host_desc(modsx_ctx *c, const float *desc1, int n1, const float *desc2, int n2, const double *pos2,
                     double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out);
+// The region list a tentative's indices refer to: the per-class lists of one image in the order GetCorresponcesVector walks
+// the classes (descriptor name, then detector name), as segments -- two descriptor classes of one detector share their
+// regions, so the concatenation is never materialised.
+struct RegList {
+  const modsx_region *p[2 * MODSX_MAX_DESC];
+  size_t end[2 * MODSX_MAX_DESC];   // running end index of every segment
+  int n = 0;
+  void clear() { n = 0; }
+  void add(const modsx_region *q, size_t cnt) { p[n] = q; end[n] = (n ? end[n - 1] : 0) + cnt; n++; }
+  void add(const std::vector<modsx_region> &v) { add(v.data(), v.size()); }
+  size_t size() const { return n ? end[n - 1] : 0; }
+  const modsx_region &operator[](size_t i) const {
+    int k = 0;
+    while (i >= end[k]) k++;
+    return p[k][i - (k ? end[k - 1] : 0)];
+  }
+};
+void verify_tentatives(const RegList &r1, const RegList &r2, const std::vector<modsx_tentative> &tents,
+                       const modsx_pair_params &pp, modsx_pair_result *res);
 void verify_tentatives(const std::vector<modsx_region> &r1, const std::vector<modsx_region> &r2,
                        const std::vector<modsx_tentative> &tents, const modsx_pair_params &pp, modsx_pair_result *res);
 // A pair whose tentatives are matched but not yet verified: modsx_match_pairs hands these to helper threads so that a
-// context's stream is fed the next group while the host runs DuplicateFiltering + LO-RANSAC of this one.
+// context's stream is fed the next group while the host runs DuplicateFiltering + LO-RANSAC of this one.  The task owns the
+// region vectors its two lists point into (moving a vector keeps its heap block, so the segments stay valid).
 struct VerifyTask {
-  std::vector<modsx_region> r1, r2;
+  std::vector<std::vector<modsx_region>> own;
+  RegList l1, l2;
   std::vector<modsx_tentative> tents;
   modsx_pair_result *res = nullptr;
 };

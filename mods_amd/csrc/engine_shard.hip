@@ -143,8 +143,10 @@ struct modsx_comm {
 
 namespace mx {
 
-constexpr int REG_B = (int)sizeof(modsx_region), ROW_B = REG_B + 128;
-static_assert(sizeof(modsx_region) == 200, "region rows are 200 + 128 bytes on the wire");
+constexpr int REG_B = (int)sizeof(modsx_region);
+static_assert(sizeof(modsx_region) == 200, "region rows are 200 + 128 bytes per descriptor class on the wire");
+static inline __host__ __device__ int row_bytes(int nd) { return REG_B + 128 * nd; }   // nd = descriptor classes of the step
+struct DescPtrs { unsigned char *p[MODSX_MAX_DESC]; };
 constexpr int HDR_MAGIC = 0x4D585348;   // "MXSH"
 constexpr int HDR_FIXED = 4;            // ints before the per-view counts: magic, rc, rows, views
 static int hdr_bytes(int nv) { return ((HDR_FIXED + nv) * 4 + 63) & ~63; }
@@ -271,12 +273,13 @@ static int comm_agree(modsx_comm *cm, int lane, hipStream_t s, int local_rc) {
 }
 
 // block = header + rows; rows[i] = region i (REG_B bytes, 8-byte words) followed by its 128 descriptor bytes
-__global__ void k_pack_rows(const unsigned char *regs, const unsigned char *desc, int n, unsigned char *rows) {
+__global__ void k_pack_rows(const unsigned char *regs, DescPtrs desc, int nd, int n, unsigned char *rows) {
   const int i = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
   if (i >= n) return;
-  unsigned char *dst = rows + (size_t)i * ROW_B;
+  unsigned char *dst = rows + (size_t)i * row_bytes(nd);
   if (l < REG_B / 8) reinterpret_cast<uint64_t *>(dst)[l] = reinterpret_cast<const uint64_t *>(regs + (size_t)i * REG_B)[l];
-  if (l < 16) reinterpret_cast<uint64_t *>(dst + REG_B)[l] = reinterpret_cast<const uint64_t *>(desc + (size_t)i * 128)[l];
+  for (int k = 0; k < nd; k++)
+    if (l < 16) reinterpret_cast<uint64_t *>(dst + REG_B + 128 * k)[l] = reinterpret_cast<const uint64_t *>(desc.p[k] + (size_t)i * 128)[l];
 }
 
 // The reference's order from the gathered blocks, on the device: view v is rank v mod W's, at that rank's running offset;
@@ -284,7 +287,7 @@ __global__ void k_pack_rows(const unsigned char *regs, const unsigned char *desc
 // (rank r, row i < G); every workgroup rebuilds the two small prefix tables from the W headers in LDS.
 constexpr int SHARD_MAXV = 1024, SHARD_MAXW = 64;
 __global__ __launch_bounds__(256) void k_unpack_blocks(const unsigned char *all, int W, int nv, int G, size_t blockB, int hdrB,
-                                                       unsigned char *regs, unsigned char *desc, size_t cap) {
+                                                       unsigned char *regs, DescPtrs desc, int nd, size_t cap) {
   __shared__ int viewStart[SHARD_MAXV], runStart[SHARD_MAXV], cnt[SHARD_MAXV], run[SHARD_MAXW];
   for (int v = threadIdx.x; v < nv; v += 256) {
     const int *h = reinterpret_cast<const int *>(all + (size_t)(v % W) * blockB);
@@ -305,9 +308,10 @@ __global__ __launch_bounds__(256) void k_unpack_blocks(const unsigned char *all,
   while (v + W < nv && runStart[v + W] <= i) v += W;     // views of rank r in ascending order; an empty one shares its start with the next
   const size_t j = (size_t)viewStart[v] + (i - runStart[v]);
   if (j >= cap) return;
-  const unsigned char *s = all + (size_t)r * blockB + hdrB + (size_t)i * ROW_B;
+  const unsigned char *s = all + (size_t)r * blockB + hdrB + (size_t)i * row_bytes(nd);
   if (l < REG_B / 8) reinterpret_cast<uint64_t *>(regs + j * REG_B)[l] = reinterpret_cast<const uint64_t *>(s)[l];
-  if (l < 16) reinterpret_cast<uint64_t *>(desc + j * 128)[l] = reinterpret_cast<const uint64_t *>(s + REG_B)[l];
+  for (int k = 0; k < nd; k++)
+    if (l < 16) reinterpret_cast<uint64_t *>(desc.p[k] + j * 128)[l] = reinterpret_cast<const uint64_t *>(s + REG_B + 128 * k)[l];
 }
 
 // Position of every row of the reference's list inside the all-gathered buffer (the host statement of what
@@ -344,12 +348,14 @@ static int grow_keep(hipStream_t s, DevBuf &b, size_t keep, size_t bytes) {
   return MODSX_OK;
 }
 
-// The sharded SynthDetectDescribeKeypoints + AddRegions: the regions of ALL views of this step in reference order on every
-// rank (ids re-based onto a list that already holds `base` regions), their u8 descriptors appended at row `base` of descAcc.
+// The sharded SynthDetectDescribeKeypoints: the regions of ALL views of this step in reference order on every rank (ids local
+// to their view block: the caller re-bases them onto its lists, AddRegionsToList), the u8 descriptors of the step's
+// descriptor class k appended at row base[k] of *descAcc[k].
 int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *img, const modsx_view *views, int nv,
-                                  const modsx_pair_params &pp, std::vector<modsx_region> &regs, DevBuf &descAcc, size_t base,
-                                  int *viewCounts) {
+                                  const modsx_pair_params &pp, const DescSet &ds, std::vector<modsx_region> &regs,
+                                  DevBuf *const *descAcc, const size_t *base, int *viewCounts) {
   regs.clear();
+  const int nd = ds.n, ROW_B = row_bytes(nd);
   if (cm->dead) return comm_dead_rc(cm);
   if (nv < 1 || nv > SHARD_MAXV || cm->world > SHARD_MAXW) { set_error("sharded path: at most 1024 views and 64 ranks"); return MODSX_ERR_ARG; }
   hipStream_t s = c->stream;
@@ -362,8 +368,9 @@ int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
   std::string lerr;
   size_t cap = (size_t)1 << 15;
   for (;;) {
-    if (!c->shardLocal.ensure(cap * 128)) { lrc = MODSX_ERR_NOMEM; break; }
-    lrc = detect_describe_views(c, img, views, nv, pp, R, W, local, nullptr, (uint8_t *)c->shardLocal.p, cap, nullptr, cnt.data());
+    if (!c->shardLocal.ensure(cap * 128 * nd)) { lrc = MODSX_ERR_NOMEM; break; }   // class k at row k * cap
+    uint8_t *xs[3] = {(uint8_t *)c->shardLocal.p + cap * 128, (uint8_t *)c->shardLocal.p + 2 * cap * 128, (uint8_t *)c->shardLocal.p + 3 * cap * 128};
+    lrc = detect_describe_views(c, img, views, nv, pp, R, W, local, nullptr, (uint8_t *)c->shardLocal.p, cap, nullptr, cnt.data(), &ds, xs);
     if (lrc == MODSX_ERR_CAPACITY && cap < ((size_t)1 << 24)) { cap *= 4; continue; }
     break;
   }
@@ -387,9 +394,11 @@ int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
     if (!L.hHdr.ensure((size_t)hdrB * (W + 1))) { comm_kill(cm, "no pinned memory for a block header"); return MODSX_ERR_NOMEM; }
     if (!lrc) {
       if (!L.regsIn.ensure((size_t)std::max(1, nloc) * REG_B) || !L.hRegs.ensure(std::max((size_t)std::max(1, nloc), rowsCap) * REG_B) ||
-          !L.regsOut.ensure(rowsCap * REG_B) || grow_keep(s, descAcc, base * 128, (base + rowsCap) * 128) != MODSX_OK) {
+          !L.regsOut.ensure(rowsCap * REG_B)) {
         lrc = MODSX_ERR_NOMEM; lerr = "sharded path: out of memory";
       }
+      for (int k = 0; k < nd && !lrc; k++)
+        if (grow_keep(s, *descAcc[k], base[k] * 128, (base[k] + rowsCap) * 128) != MODSX_OK) { lrc = MODSX_ERR_NOMEM; lerr = "sharded path: out of memory"; }
     }
     int *hh = (int *)L.hHdr.p;
     memset(hh, 0, hdrB);
@@ -400,8 +409,10 @@ int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
     if (npack) {
       memcpy(L.hRegs.p, local.data(), (size_t)npack * REG_B);
       MX_HIP(hipMemcpyAsync(L.regsIn.p, L.hRegs.p, (size_t)npack * REG_B, hipMemcpyHostToDevice, s));
-      hipLaunchKernelGGL(k_pack_rows, dim3((npack + 7) / 8), dim3(256), 0, s, (const unsigned char *)L.regsIn.p,
-                         (const unsigned char *)c->shardLocal.p, npack, (unsigned char *)L.blkLocal.p + hdrB);
+      DescPtrs dp;
+      for (int k = 0; k < MODSX_MAX_DESC; k++) dp.p[k] = (unsigned char *)c->shardLocal.p + (size_t)k * cap * 128;
+      hipLaunchKernelGGL(k_pack_rows, dim3((npack + 7) / 8), dim3(256), 0, s, (const unsigned char *)L.regsIn.p, dp, nd, npack,
+                         (unsigned char *)L.blkLocal.p + hdrB);
     }
     // 4. the exchange: one all-gather of the blocks
     int rc = ordered_all_gather(cm, lane, L.blkLocal.p, L.blkAll.p, blockB, s);
@@ -410,8 +421,10 @@ int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
     MX_HIP(hipMemcpy2DAsync((char *)L.hHdr.p + hdrB, hdrB, L.blkAll.p, blockB, hdrB, W, hipMemcpyDeviceToHost, s));
     size_t got = 0;
     if (!lrc) {
+      DescPtrs dp;
+      for (int k = 0; k < MODSX_MAX_DESC; k++) dp.p[k] = k < nd ? (unsigned char *)descAcc[k]->p + base[k] * 128 : nullptr;
       hipLaunchKernelGGL(k_unpack_blocks, dim3((unsigned)((rowsCap + 7) / 8)), dim3(256), 0, s, (const unsigned char *)L.blkAll.p, W, nv, G,
-                         blockB, hdrB, (unsigned char *)L.regsOut.p, (unsigned char *)descAcc.p + base * 128, rowsCap);
+                         blockB, hdrB, (unsigned char *)L.regsOut.p, dp, nd, rowsCap);
       got = std::min(rowsCap, L.lastN + L.lastN / 4 + 256);
       MX_HIP(hipMemcpyAsync(L.hRegs.p, L.regsOut.p, got * REG_B, hipMemcpyDeviceToHost, s));
     }
@@ -448,7 +461,6 @@ int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
       if (rc) return rc;
     }
     if (N) memcpy(regs.data(), L.hRegs.p, N * REG_B);
-    rebase_ids(regs, vc.data(), nv, base);
     return MODSX_OK;
   }
 }
@@ -517,6 +529,7 @@ int match_shard_gather(modsx_ctx *c, const MatchShard &sh, int local_rc, MatchRo
 int match_pair_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *img1, const modsx_image *img2, const modsx_view *views,
                              int nv, const modsx_pair_params &pp, int owner, modsx_pair_result *res) {
   modsx_ladder_step one;
+  memset(&one, 0, sizeof one);
   one.views = views; one.nviews = nv; one.match_ratio = pp.match_ratio; one.detector = pp.detector;
   int done = 0;
   return match_ladder(c, img1, img2, &one, 1, 0x7fffffff, pp, res, &done, nullptr, cm, owner);
@@ -696,8 +709,19 @@ int modsx_detect_describe_views_sharded(modsx_ctx *ctx, modsx_comm *comm, const 
   if (!ctx || !comm || !img || !views || !par || !regs || nviews <= 0) { mx::set_error("modsx_detect_describe_views_sharded: bad argument"); return MODSX_ERR_ARG; }
   hipSetDevice(ctx->dev);
   std::vector<modsx_region> r;
-  int rc = detect_describe_views_sharded(ctx, comm, img, views, nviews, *par, r, ctx->descAllU8[0], 0, view_counts);
+  // the first descriptor class of par's list is the one returned (the orientation mode follows the whole list)
+  DescSet ds;
+  int rc = resolve_descs(*par, nullptr, ds);
   if (rc) return rc;
+  ds.forceHalf = ds.half();
+  ds.n = 1;
+  DevBuf *acc[1] = {&ctx->descAllU8[0]};
+  const size_t base0[1] = {0};
+  std::vector<int> counts(nviews, 0);
+  rc = detect_describe_views_sharded(ctx, comm, img, views, nviews, *par, ds, r, acc, base0, counts.data());
+  if (rc) return rc;
+  rebase_ids(r, counts.data(), nviews, 0);
+  if (view_counts) memcpy(view_counts, counts.data(), sizeof(int) * nviews);
   if (dev_desc_u8) *dev_desc_u8 = ctx->descAllU8[0].p;
   modsx_region *p = (modsx_region *)malloc(sizeof(modsx_region) * std::max<size_t>(1, r.size()));
   if (!r.empty()) memcpy(p, r.data(), sizeof(modsx_region) * r.size());

@@ -265,8 +265,16 @@ int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx
 // view block at devU8/devF (device, capacity devCapRegions) and optionally copied to hostDesc.
 int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_view *views, int nv,
                           const modsx_pair_params &pp, int view_begin, int view_step, std::vector<modsx_region> &regs,
-                          float *devF, uint8_t *devU8, size_t devCapRegions, float *hostDesc, int *viewCounts) {
+                          float *devF, uint8_t *devU8, size_t devCapRegions, float *hostDesc, int *viewCounts,
+                          const DescSet *dsIn, uint8_t *const *devU8x) {
   regs.clear();
+  // the step's descriptor classes: class 0 goes to devF / devU8 / hostDesc, class k >= 1 to devU8x[k - 1] (same capacity);
+  // without devU8x only class 0 is produced -- the orientation mode still follows the whole list
+  DescSet ds;
+  if (dsIn) ds = *dsIn;
+  else { const int rd = resolve_descs(pp, nullptr, ds); if (rd) return rd; }
+  const int oriHalf = ds.half() ? 1 : 0;
+  if (!devU8x) { ds.forceHalf = oriHalf != 0; ds.n = 1; }
   if (viewCounts) for (int v = 0; v < nv; v++) viewCounts[v] = 0;
   if (view_step < 1) view_step = 1;
   struct SetScope { SetScope() { host_set_enter(); } ~SetScope() { host_set_leave(); } } setScope;
@@ -337,7 +345,9 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
         r0[i].resize(kps[i].size());
         detect_affine_regions(kps[i].data(), (int)kps[i].size(), ident[i] ? 0 : take[g0 + i], detType, r0[i].data());
       });
-      rc = detect_orientation_batch(c, cimg, n, r0, pp.ori_mrSize, pp.ori_patchSize, 0, pp.ori_maxAngles, pp.ori_threshold,
+      // DetectOrientation(..., HalfSIFT_like_desc, ...): one oriented list for every descriptor of the step
+      // (imagerepresentation.cpp:1254-1268, 1288-1296)
+      rc = detect_orientation_batch(c, cimg, n, r0, pp.ori_mrSize, pp.ori_patchSize, oriHalf, pp.ori_maxAngles, pp.ori_threshold,
                                     0, ro);
     }
     t3 = tnow();
@@ -345,6 +355,7 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
     if (!rc) {
       float *dF[MAXB];
       uint8_t *dU[MAXB];
+      uint8_t *dUx[3][MAXB];
       size_t ofs = total;
       host_parallel_light(n, [&](int i) {
         int m = reproject_regions(ro[i].data(), (int)ro[i].size(), Hs[i], gray->cols, gray->rows);
@@ -354,12 +365,16 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
         const int m = (int)ro[i].size();
         dF[i] = devF ? devF + ofs * 128 : nullptr;
         dU[i] = devU8 ? devU8 + ofs * 128 : nullptr;
+        for (int k = 1; k < ds.n; k++) dUx[k - 1][i] = devU8x[k - 1] ? devU8x[k - 1] + ofs * 128 : nullptr;
         ofs += m;
       }
       if (tim2) { fprintf(stderr, "  host %-28s %.3f ms\n", "reproject", tnow() - tq); tq = tnow(); }
       if (ofs > devCapRegions && (devF || devU8)) { set_error("descriptor buffer too small"); rc = MODSX_ERR_CAPACITY; }
-      if (!rc) rc = describe_batch(c, cimg, n, ro, pp.desc_mrSize, pp.desc_patchSize, 0, pp.desc_photoNorm, pp.desc_type,
-                                   pp.desc_maxBinValue, nullptr, devF ? dF : nullptr, devU8 ? dU : nullptr);
+      if (!rc) {
+        uint8_t *const *xs[3] = {ds.n > 1 ? dUx[0] : nullptr, ds.n > 2 ? dUx[1] : nullptr, ds.n > 3 ? dUx[2] : nullptr};
+        rc = describe_batch(c, cimg, n, ro, pp.desc_mrSize, pp.desc_patchSize, 0, pp.desc_photoNorm, ds.type[0],
+                            pp.desc_maxBinValue, nullptr, devF ? dF : nullptr, devU8 ? dU : nullptr, &ds, xs);
+      }
       if (tim2) tq = tnow();
       if (!rc) {
         for (int i = 0; i < n; i++) {
@@ -410,8 +425,9 @@ static void release_result_arrays(modsx_pair_result *res) {
   res->tentatives = nullptr; res->ransac_inlier = nullptr; res->verified = nullptr;
 }
 
-// One detector class of the pair (separate_detectors of MatchImgReps): its accumulated regions per image, the device
-// buffers that hold their u8 descriptors, and the tentatives of its last match.
+// One (detector, descriptor) class of the pair -- RegionVectorMap[det][desc] of both ImageRepresentations and
+// CorrespondencesMapMap[desc][det] (imagerepresentation.cpp:552-600, correspondencebank.cpp:180-218): its accumulated regions
+// per image, the device buffers that hold their u8 descriptors, and the tentatives of its last match.
 struct LadderClass {
   std::vector<modsx_region> regs[2];
   size_t cap[2] = {(size_t)1 << 16, (size_t)1 << 16};
@@ -477,31 +493,54 @@ void ctx_worker_stop(modsx_ctx *c) {
 // stream, scratch and host thread -- beside the views [0, m) on c; m balances the view areas.  A view's regions and
 // descriptors do not depend on which launch set it is part of, so the step is the concatenation of the two parts (the
 // second part's descriptors are moved behind the first's once its size is known).
-static int accumulate_views(modsx_ctx *c, LadderClass &k, int side, const modsx_image *img, const modsx_view *views, int nv,
-                            const modsx_pair_params &pp, modsx_comm *cm, bool split = false) {
-  std::vector<modsx_region> &acc = k.regs[side];
-  DevBuf &buf = *k.buf[side];
-  size_t &cap = k.cap[side];
-  const size_t base = acc.size();
+static int accumulate_views(modsx_ctx *c, LadderClass *const *ks, const DescSet &ds, int side, const modsx_image *img,
+                            const modsx_view *views, int nv, const modsx_pair_params &pp, modsx_comm *cm, bool split = false) {
+  // ks[j] = the class of the step's j-th descriptor: all of them receive the step's regions (one oriented list for the
+  // whole step), each its own descriptors.  Their lists may differ in length (earlier steps may have carried other
+  // descriptors), so every class has its own base.
+  const int nd = ds.n;
+  size_t base[MODSX_MAX_DESC];
+  for (int j = 0; j < nd; j++) base[j] = ks[j]->regs[side].size();
   std::vector<modsx_region> step;
   std::vector<int> counts(std::max(1, nv), 0);
-  auto grow_buf = [&]() -> int {     // the accumulated descriptors of the class: cap regions, earlier steps' kept
-    if (buf.cap >= cap * 128) return MODSX_OK;
-    DevBuf bigger;
-    if (!bigger.ensure(cap * 128)) return MODSX_ERR_NOMEM;
-    if (base) {
-      MX_HIP(hipMemcpyAsync(bigger.p, buf.p, base * 128, hipMemcpyDeviceToDevice, c->stream));
-      MX_HIP(hipStreamSynchronize(c->stream));
+  auto grow_bufs = [&]() -> int {     // the accumulated descriptors of the classes: cap regions, earlier steps' kept
+    for (int j = 0; j < nd; j++) {
+      DevBuf &buf = *ks[j]->buf[side];
+      const size_t cap = ks[j]->cap[side];
+      if (buf.cap >= cap * 128) continue;
+      DevBuf bigger;
+      if (!bigger.ensure(cap * 128)) return MODSX_ERR_NOMEM;
+      if (base[j]) {
+        MX_HIP(hipMemcpyAsync(bigger.p, buf.p, base[j] * 128, hipMemcpyDeviceToDevice, c->stream));
+        MX_HIP(hipStreamSynchronize(c->stream));
+      }
+      buf.release();
+      buf = bigger;
     }
-    buf.release();
-    buf = bigger;
     return MODSX_OK;
+  };
+  auto room = [&]() { size_t r = (size_t)-1; for (int j = 0; j < nd; j++) r = std::min(r, ks[j]->cap[side] - base[j]); return r; };
+  auto dst = [&](int j, size_t row) { return (uint8_t *)ks[j]->buf[side]->p + (base[j] + row) * 128; };
+  // the step's regions behind every class's list, ids re-based onto that list (AddRegionsToList)
+  auto append = [&]() {
+    for (int j = 0; j < nd; j++) {
+      std::vector<modsx_region> &acc = ks[j]->regs[side];
+      const size_t at = acc.size();
+      acc.insert(acc.end(), step.begin(), step.end());
+      size_t start = 0;
+      for (int v = 0; v < nv; v++) {
+        const size_t end = std::min(step.size(), start + (size_t)counts[v]);
+        for (size_t i = start; i < end; i++) { acc[at + i].id += (int)(base[j] + start); acc[at + i].parent_id += (int)(base[j] + start); }
+        start = end;
+      }
+    }
   };
   static const bool noSplit = getenv("MODSX_PAIR_NOSPLIT") != nullptr;
   static const double splitBias = getenv("MODSX_SPLIT_BIAS") ? atof(getenv("MODSX_SPLIT_BIAS")) : 0.25;   // a view's fixed cost, in untilted-view areas
   static const int nParts = getenv("MODSX_PAIR_PARTS") ? std::max(1, std::min(8, atoi(getenv("MODSX_PAIR_PARTS")))) : 3;   // 31 views: 2 / 3 / 4 parts 13.7 / 12.8 / 13.1 ms per pair
   if (split && !cm && !noSplit && nParts > 1 && nv >= 6 * nParts) {
-    { const int rg = grow_buf(); if (rg) return rg; }
+    { const int rg = grow_bufs(); if (rg) return rg; }
+    const size_t cap = room();
     // part p = views [cut[p], cut[p + 1]): equal shares of the views' weights (area + a fixed cost per view)
     const int P = nParts;
     std::vector<double> w(nv);
@@ -526,11 +565,12 @@ static int accumulate_views(modsx_ctx *c, LadderClass &k, int side, const modsx_
       for (int p = 1; p < P && ready; p++) {
         if (!prev->half) prev->half = ctx_create(c->dev);
         hs[p] = prev->half;
-        ready = hs[p] && hs[p]->halfDesc.ensure(cap * 128);
+        ready = hs[p] != nullptr;
+        for (int j = 0; j < nd && ready; j++) ready = hs[p]->halfDesc[j].ensure(cap * 128);
         prev = hs[p];
       }
     }
-    if (ready && buf.cap >= cap * 128) {
+    if (ready) {
       std::vector<std::vector<modsx_region>> part(P);
       std::vector<std::vector<int>> cnt(P, std::vector<int>(nv, 0));
       std::vector<int> rcs(P, MODSX_OK);
@@ -540,14 +580,17 @@ static int accumulate_views(modsx_ctx *c, LadderClass &k, int side, const modsx_
         prof_reset(h, c->prof.enabled);
         ctx_worker_post(h, [&, p, h]() {
           host_light_pool(true);
-          rcs[p] = detect_describe_views(h, img, views, cut[p + 1], pp, cut[p], 1, part[p], nullptr, (uint8_t *)h->halfDesc.p, cap, nullptr,
-                                         cnt[p].data());
+          uint8_t *xs[3] = {(uint8_t *)h->halfDesc[1].p, (uint8_t *)h->halfDesc[2].p, (uint8_t *)h->halfDesc[3].p};
+          rcs[p] = detect_describe_views(h, img, views, cut[p + 1], pp, cut[p], 1, part[p], nullptr, (uint8_t *)h->halfDesc[0].p, cap, nullptr,
+                                         cnt[p].data(), &ds, xs);
           if (rcs[p]) errs[p] = last_error();
         });
       }
       host_light_pool(true);
-      rcs[0] = detect_describe_views(c, img, views, cut[1], pp, 0, 1, step, nullptr, (uint8_t *)buf.p + base * 128, cap - base, nullptr,
-                                     counts.data());
+      {
+        uint8_t *xs[3] = {nd > 1 ? dst(1, 0) : nullptr, nd > 2 ? dst(2, 0) : nullptr, nd > 3 ? dst(3, 0) : nullptr};
+        rcs[0] = detect_describe_views(c, img, views, cut[1], pp, 0, 1, step, nullptr, dst(0, 0), cap, nullptr, counts.data(), &ds, xs);
+      }
       host_light_pool(false);
       size_t total = step.size();
       bool ok = rcs[0] == MODSX_OK;
@@ -560,50 +603,55 @@ static int accumulate_views(modsx_ctx *c, LadderClass &k, int side, const modsx_
         ok = ok && rcs[p] == MODSX_OK;
         total += part[p].size();
       }
-      if (ok && base + total <= cap) {
-        size_t at = base + step.size();
+      if (ok && total <= cap) {
+        size_t at = step.size();
         for (int p = 1; p < P; p++) {
           if (!part[p].empty())
-            MX_HIP(hipMemcpyAsync((uint8_t *)buf.p + at * 128, hs[p]->halfDesc.p, part[p].size() * 128, hipMemcpyDeviceToDevice, c->stream));
+            for (int j = 0; j < nd; j++)
+              MX_HIP(hipMemcpyAsync(dst(j, at), hs[p]->halfDesc[j].p, part[p].size() * 128, hipMemcpyDeviceToDevice, c->stream));
           at += part[p].size();
           for (int v = cut[p]; v < cut[p + 1]; v++) counts[v] = cnt[p][v];
         }
         MX_HIP(hipStreamSynchronize(c->stream));
         step.reserve(total);
         for (int p = 1; p < P; p++) step.insert(step.end(), part[p].begin(), part[p].end());
-        rebase_ids(step, counts.data(), nv, base);
-        acc.insert(acc.end(), step.begin(), step.end());
+        append();
         return MODSX_OK;
       }
       for (int p = 0; p < P; p++)
         if (rcs[p] && rcs[p] != MODSX_ERR_CAPACITY) { if (p) set_error(errs[p]); return rcs[p]; }
-      // a part did not fit: the one-context path below grows the buffer and runs the step again
+      // a part did not fit: the one-context path below grows the buffers and runs the step again
       step.clear();
       std::fill(counts.begin(), counts.end(), 0);
     }
   }
   if (cm) {   // view-sharded: this rank runs its views, the exchange appends the whole step in reference order (ids re-based)
-    int rc = detect_describe_views_sharded(c, cm, img, views, nv, pp, step, buf, base, counts.data());
+    DevBuf *accs[MODSX_MAX_DESC];
+    for (int j = 0; j < nd; j++) accs[j] = ks[j]->buf[side];
+    int rc = detect_describe_views_sharded(c, cm, img, views, nv, pp, ds, step, accs, base, counts.data());
     if (rc) return rc;
-    acc.insert(acc.end(), step.begin(), step.end());
+    append();
     return MODSX_OK;
   }
   for (;;) {
-    { const int rg = grow_buf(); if (rg) return rg; }
-    int rc = detect_describe_views(c, img, views, nv, pp, 0, 1, step, nullptr, (uint8_t *)buf.p + base * 128, cap - base, nullptr,
-                                   counts.data());
-    if (rc == MODSX_ERR_CAPACITY && cap < ((size_t)1 << 24)) { cap *= 4; continue; }   // only "buffer too small" grows it
+    { const int rg = grow_bufs(); if (rg) return rg; }
+    uint8_t *xs[3] = {nd > 1 ? dst(1, 0) : nullptr, nd > 2 ? dst(2, 0) : nullptr, nd > 3 ? dst(3, 0) : nullptr};
+    int rc = detect_describe_views(c, img, views, nv, pp, 0, 1, step, nullptr, dst(0, 0), room(), nullptr, counts.data(), &ds, xs);
+    if (rc == MODSX_ERR_CAPACITY && ks[0]->cap[side] < ((size_t)1 << 24)) {   // only "buffer too small" grows them
+      for (int j = 0; j < nd; j++) ks[j]->cap[side] *= 4;
+      continue;
+    }
     if (rc) return rc;
     break;
   }
-  rebase_ids(step, counts.data(), nv, base);
-  acc.insert(acc.end(), step.begin(), step.end());
+  append();
   return MODSX_OK;
 }
 
 int match_pair_views(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_view *views, int nv,
                      const modsx_pair_params &pp, modsx_pair_result *res, VerifyTask *defer) {
   modsx_ladder_step one;
+  memset(&one, 0, sizeof one);
   one.views = views; one.nviews = nv; one.match_ratio = pp.match_ratio; one.detector = pp.detector;
   int done = 0;
   return match_ladder(c, img1, img2, &one, 1, 0x7fffffff, pp, res, &done, defer);
@@ -611,7 +659,8 @@ int match_pair_views(modsx_ctx *c, const modsx_image *img1, const modsx_image *i
 
 // The iteration loop of mods.cpp:229-415 (HessianAffine and MSER classes with SIFT-family descriptors, LO-RANSAC
 // verification, duplicates filtered before RANSAC): every step adds its views' regions to both image representations,
-// re-matches the class it extended, and the ladder stops once min_matches verified correspondences exist.
+// re-matches the (detector, descriptor) classes it extended, and the ladder stops once min_matches verified
+// correspondences exist.
 int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_ladder_step *steps, int nsteps,
                  int min_matches, const modsx_pair_params &pp, modsx_pair_result *res, int *steps_done, VerifyTask *defer,
                  modsx_comm *cm, int owner) {
@@ -619,8 +668,10 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
   memset(res, 0, sizeof *res);
   for (int i = 0; i < 9; i++) res->H[i] = -1;
   const modsx_image *imgs[2] = {img1, img2};
-  LadderClass cls[2];   // 0 = HessianAffine, 1 = MSER: the order GetCorresponcesVector("All", "All") walks the map
-  for (int s = 0; s < 2; s++) { cls[0].buf[s] = &c->descAllU8[s]; cls[1].buf[s] = &c->descAllU8b[s]; }
+  // cls[det][type]: det 0 = HessianAffine, 1 = MSER; type = MODSX_DESC_*.  GetCorresponcesVector("All", "All") walks
+  // descriptor names, then detector names (correspondencebank.cpp:117-179): types 3, 2, 1, 0, HessianAffine before MSER.
+  LadderClass cls[2][4];
+  for (int d = 0; d < 2; d++) for (int t = 0; t < 4; t++) for (int sd = 0; sd < 2; sd++) cls[d][t].buf[sd] = &c->descCls[d][t][sd];
   static std::atomic<int> active(0);
   struct Guard { std::atomic<int> &a; ~Guard() { a.fetch_sub(1); } } guard{active};
   const bool alone = active.fetch_add(1) == 0;
@@ -629,9 +680,13 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
   const bool timL = getenv("MODSX_HOST_TIMING") != nullptr;
   for (; step < nsteps && cur < min_matches; step++) {
     const double tL0 = tnowL();
-    LadderClass &k = cls[steps[step].detector == MODSX_DET_MSER ? 1 : 0];
+    const int det = steps[step].detector == MODSX_DET_MSER ? 1 : 0;
+    DescSet ds;
+    { const int rd = resolve_descs(pp, &steps[step], ds); if (rd) { release_result_arrays(res); return rd; } }
+    LadderClass *ks[MODSX_MAX_DESC];
+    for (int j = 0; j < ds.n; j++) ks[j] = &cls[det][ds.type[j]];
     modsx_pair_params ps = pp;
-    ps.detector = steps[step].detector == MODSX_DET_MSER ? MODSX_DET_MSER : MODSX_DET_HESSIAN;
+    ps.detector = det ? MODSX_DET_MSER : MODSX_DET_HESSIAN;
     {
       // The two images are independent until the match (mods.cpp:255-271 runs them in two OpenMP threads): image 2 goes
       // through a peer context (own stream, own scratch) on a second host thread, so the host bookkeeping of one image
@@ -647,10 +702,10 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
         modsx_ctx *pc = c->peer;
         prof_reset(pc, c->prof.enabled);
         ctx_worker_post(pc, [&]() {
-          rc1 = accumulate_views(pc, k, 1, imgs[1], steps[step].views, steps[step].nviews, ps, nullptr, true);
+          rc1 = accumulate_views(pc, ks, ds, 1, imgs[1], steps[step].views, steps[step].nviews, ps, nullptr, true);
           if (rc1) err1 = last_error();
         });
-        rc0 = accumulate_views(c, k, 0, imgs[0], steps[step].views, steps[step].nviews, ps, nullptr, true);
+        rc0 = accumulate_views(c, ks, ds, 0, imgs[0], steps[step].views, steps[step].nviews, ps, nullptr, true);
         ctx_worker_wait(pc);
         if (c->prof.enabled) {   // the peer's kernels belong to this call
           prof_collect(pc);
@@ -658,50 +713,64 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
         }
         if (!rc0 && rc1) set_error(err1);
       } else {
-        rc0 = accumulate_views(c, k, 0, imgs[0], steps[step].views, steps[step].nviews, ps, cm);
-        if (!rc0) rc1 = accumulate_views(c, k, 1, imgs[1], steps[step].views, steps[step].nviews, ps, cm);
+        rc0 = accumulate_views(c, ks, ds, 0, imgs[0], steps[step].views, steps[step].nviews, ps, cm);
+        if (!rc0) rc1 = accumulate_views(c, ks, ds, 1, imgs[1], steps[step].views, steps[step].nviews, ps, cm);
       }
       if (rc0 || rc1) { release_result_arrays(res); return rc0 ? rc0 : rc1; }
     }
     const double tL1 = tnowL();
-    // Tentatives.MatchImgReps (correspondencebank.cpp:291-345): clear and re-match the class of this step
-    const double ratio = steps[step].match_ratio > 0 ? steps[step].match_ratio : pp.match_ratio;
-    {
+    // Tentatives.MatchImgReps (correspondencebank.cpp:291-345): clear and re-match every (this detector, descriptor) class of
+    // the step, each with the FGINNThreshold of its descriptor
+    for (int j = 0; j < ds.n; j++) {
+      LadderClass &k = *ks[j];
       std::vector<double> pos2(k.regs[1].size() * 2 + 2);
       for (size_t i = 0; i < k.regs[1].size(); i++) { pos2[2 * i] = k.regs[1][i].reproj_kp.x; pos2[2 * i + 1] = k.regs[1][i].reproj_kp.y; }
       int rc = cm ? match_sharded(c, cm, (uint8_t *)k.buf[0]->p, (int)k.regs[0].size(), (uint8_t *)k.buf[1]->p, (int)k.regs[1].size(),
-                                  pos2.data(), ratio, pp.contradDist, pp.nn, k.tents)
+                                  pos2.data(), ds.ratio[j], pp.contradDist, pp.nn, k.tents)
                   : match_device(c, (uint8_t *)k.buf[0]->p, (int)k.regs[0].size(), (uint8_t *)k.buf[1]->p, (int)k.regs[1].size(),
-                                 pos2.data(), ratio, pp.contradDist, pp.nn, k.tents);
+                                 pos2.data(), ds.ratio[j], pp.contradDist, pp.nn, k.tents);
       if (rc) { release_result_arrays(res); return rc; }
     }
     const double tL2 = tnowL();
-    // GetCorresponcesVector(): HessianAffine tentatives, then MSER; indices re-based onto the concatenated lists
-    std::vector<modsx_region> all[2];
+    // GetCorresponcesVector(): the classes in map order; indices re-based onto the concatenation of their region lists
+    RegList l1, l2;
     std::vector<modsx_tentative> tents;
-    // one class only (no MSER step so far, or no HessianAffine one) and verification here: the class's own lists are the
-    // concatenation -- 2 x 5 MB of region records not copied per step of a 31-view pair
-    const int only = cls[1].regs[0].empty() && cls[1].regs[1].empty() ? 0 : (cls[0].regs[0].empty() && cls[0].regs[1].empty() ? 1 : -1);
-    const bool inPlace = only >= 0 && !defer;
-    if (inPlace) tents = cls[only].tents;
-    for (int q = 0; q < 2 && !inPlace; q++) {
-      const int o1 = (int)all[0].size(), o2 = (int)all[1].size();
-      for (int s = 0; s < 2; s++) all[s].insert(all[s].end(), cls[q].regs[s].begin(), cls[q].regs[s].end());
-      for (modsx_tentative t : cls[q].tents) {
-        t.q += o1; t.t0 += o2;
-        if (t.t1 >= 0) t.t1 += o2;
-        if (t.tj >= 0) t.tj += o2;
-        tents.push_back(t);
+    int nonEmpty = 0;
+    LadderClass *lastCls = nullptr;
+    for (int t = 3; t >= 0; t--)
+      for (int d = 0; d < 2; d++)
+        if (!cls[d][t].regs[0].empty() || !cls[d][t].regs[1].empty()) { nonEmpty++; lastCls = &cls[d][t]; }
+    if (nonEmpty == 1 && !defer) tents = lastCls->tents;   // one class: no copy of 12 k tentatives with re-based indices
+    for (int t = 3; t >= 0; t--)
+      for (int d = 0; d < 2; d++) {
+        LadderClass &k = cls[d][t];
+        if (k.regs[0].empty() && k.regs[1].empty()) continue;
+        const int o1 = (int)l1.size(), o2 = (int)l2.size();
+        l1.add(k.regs[0]); l2.add(k.regs[1]);
+        if (nonEmpty == 1 && !defer) continue;
+        for (modsx_tentative tt : k.tents) {
+          tt.q += o1; tt.t0 += o2;
+          if (tt.t1 >= 0) tt.t1 += o2;
+          if (tt.tj >= 0) tt.tj += o2;
+          tents.push_back(tt);
+        }
       }
-    }
-    const std::vector<modsx_region> &list1 = inPlace ? cls[only].regs[0] : all[0], &list2 = inPlace ? cls[only].regs[1] : all[1];
     release_result_arrays(res);
     memset(res, 0, sizeof *res);
     for (int i = 0; i < 9; i++) res->H[i] = -1;
-    res->n_regions1 = (int)list1.size();
-    res->n_regions2 = (int)list2.size();
+    res->n_regions1 = (int)l1.size();
+    res->n_regions2 = (int)l2.size();
     if (defer) {   // the caller runs DuplicateFiltering + LO-RANSAC elsewhere (modsx_match_pairs_views: helper threads)
-      defer->r1 = std::move(all[0]); defer->r2 = std::move(all[1]); defer->tents = std::move(tents); defer->res = res;
+      defer->l1.clear(); defer->l2.clear(); defer->own.clear();
+      defer->own.reserve(16);
+      for (int t = 3; t >= 0; t--)
+        for (int d = 0; d < 2; d++) {
+          LadderClass &k = cls[d][t];
+          if (k.regs[0].empty() && k.regs[1].empty()) continue;
+          defer->own.emplace_back(std::move(k.regs[0])); defer->l1.add(defer->own.back());
+          defer->own.emplace_back(std::move(k.regs[1])); defer->l2.add(defer->own.back());
+        }
+      defer->tents = std::move(tents); defer->res = res;
       step++;
       break;
     }
@@ -709,7 +778,7 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
     // tentatives, same seed => same count), which is how the ranks agree on the early exit without a collective
     const double tL3 = tnowL();
     res->n_tentatives = (int)tents.size();
-    if (!cm || owner < 0 || owner == comm_rank(cm)) verify_tentatives(list1, list2, tents, pp, res);
+    if (!cm || owner < 0 || owner == comm_rank(cm)) verify_tentatives(l1, l2, tents, pp, res);
     cur = res->n_verified;
     if (timL) fprintf(stderr, "ladder step %d: views %.2f match %.2f lists %.2f verify %.2f ms\n", step, tL1 - tL0, tL2 - tL1, tL3 - tL2, tnowL() - tL3);
   }

@@ -599,7 +599,7 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
                                                   const int *needTab, const float *coordTab,
                                                   const float *mask, const unsigned short *maskIdx,
                                                   const float *oTab, const int *binTab, const double *wTab,
-                                                  SiftConst sc, int photoNorm, int descType, double maxBin,
+                                                  SiftConst sc, int photoNorm, int descTypes, int nOut, double maxBin,
                                                   DescOut outs) {
   const int tidw = threadIdx.x;                                    // thread of the workgroup
   const int reg = __builtin_amdgcn_readfirstlane(tidw >> 7);       // region of the workgroup (a wavefront is inside one region)
@@ -858,6 +858,19 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
     if (gth) { vec[(rb * 4 + cb) * 8 + oa] = accA; vec[(rb * 4 + cb) * 8 + ob] = accB; }
   }
   __syncthreads();
+  // The descriptors of one step share everything up to here (SIFTDescriptor::operator(), siftdesc.cpp:401-442: RootSIFT and
+  // HalfRootSIFT run the same computeRootSiftDescriptor on the same patch and differ in the fold and the norm), so a step
+  // with several descriptor classes (iters_mods_cviu_wxbs.ini:35: RootSIFT, HalfRootSIFT) emits all of them from one
+  // histogram: output t has type (descTypes >> 4 t) & 15 and goes to outs.u8 (t = 0) or outs.u8x[t - 1].
+  const double rawBin = vec[tid];
+#pragma unroll 1
+  for (int ot = 0; ot < nOut; ot++) {
+  const int descType = (descTypes >> (4 * ot)) & 15;
+  if (ot) {
+    __syncthreads();
+    vec[tid] = rawBin;
+    __syncthreads();
+  }
   const bool rootsift = (descType & 1) != 0;
   if (descType >= 2) {
     // HalfSIFT / HalfRootSIFT (siftdesc.cpp:412-433): opposite orientation bins are folded before the norm.  The upper
@@ -914,10 +927,14 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
     b = b < 255 ? b : 255;
     b = b > 0 ? b : 0;
     if (alive) {
-      outs.f[jb.img][(size_t)jb.outIdx * 128 + tid] = (float)b;
-      outs.u8[jb.img][(size_t)jb.outIdx * 128 + tid] = (uint8_t)b;
+      if (ot == 0) {
+        outs.f[jb.img][(size_t)jb.outIdx * 128 + tid] = (float)b;
+        outs.u8[jb.img][(size_t)jb.outIdx * 128 + tid] = (uint8_t)b;
+      } else
+        outs.u8x[ot - 1][jb.img][(size_t)jb.outIdx * 128 + tid] = (uint8_t)b;
     }
   }
+  }   // ot
 }
 
 void launch_expand_tiles(hipStream_t s, const int *prefix, int nJobs, int *tileJob) {
@@ -951,13 +968,13 @@ void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix
 }
 void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *imgs, const float *grid,
                      const int *needTab, const float *coordTab, const float *mask, const unsigned short *maskIdx, int nmask, const float *oTab, const int *bins,
-                     const double *wts, int photoNorm, int descType, double maxBin, const DescOut &outs) {
+                     const double *wts, int photoNorm, int descTypes, int nOut, double maxBin, const DescOut &outs) {
   if (n <= 0) return;
   SiftConst sc;
   sc.nmask = nmask;
   hipLaunchKernelGGL(k_describe, dim3((n + DR - 1) / DR), dim3(128 * DR), 0, s, jobs, n, imgs, grid, needTab, coordTab, mask, maskIdx, oTab, bins,
                      wts, sc,
-                     photoNorm, descType, maxBin, outs);
+                     photoNorm, descTypes, nOut, maxBin, outs);
 }
 
 }  // namespace mx

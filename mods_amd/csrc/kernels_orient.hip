@@ -15,7 +15,7 @@ namespace mx {
 constexpr int PS = 41, PSP = 44;   // PSP: padded row stride so rows start 16-byte aligned in LDS
 constexpr int ORI_B = 21;          // taps of a patch row in flight per lane
 
-__global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *out, int n, const ImgRef *imgs,
+__global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, float *out, int n, const ImgRef *imgs,
                                                     const unsigned short *maskIdx, const float *maskW,
                                                     const unsigned char *binTab, int doHalf, double th, int maxAngles) {
   const int k = xcd_chunk(blockIdx.x, n);   // regions are listed image by image: one part of the views per XCD's L2
@@ -182,14 +182,15 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, OriOut *
   const unsigned long long peaks = __ballot(peak);
   // the reference keeps the first min(maxAngles, #peaks) peaks in bin order (35,0,1), (i-1,i,i+1), (34,35,0)
   const int rank = __popcll(peaks & ((1ull << lane) - 1ull));
-  if (lane == 0) out[k].n = min(min(__popcll(peaks), maxAngles), 7);
-  if (peak && rank < maxAngles && rank < 7) {
+  float *const o = out + (size_t)k * (1 + maxAngles);   // maxAngles <= ORI_MAX_PEAKS: the stride of the result records
+  if (lane == 0) o[0] = __int_as_float(min(__popcll(peaks), maxAngles));
+  if (peak && rank < maxAngles) {
     const float pp = (ha - hc) / (ha - 2.0f * hv + hc) / 2.0f;
-    out[k].ang[rank] = 2.0f * PIf * ((float)lane + 0.5f + pp) / (float)nb - PIf;
+    o[1 + rank] = 2.0f * PIf * ((float)lane + 0.5f + pp) / (float)nb - PIf;
   }
 }
 
-void launch_orientation(hipStream_t s, const OriJob *jobs, OriOut *out, int n, const ImgRef *imgs,
+void launch_orientation(hipStream_t s, const OriJob *jobs, float *out, int n, const ImgRef *imgs,
                           const unsigned short *maskIdx, const float *maskW, const unsigned char *binTab, int doHalf, double th,
                           int maxAngles) {
   if (n <= 0) return;

@@ -364,13 +364,20 @@ def set_vs_pars(scale_set, tilt_set, phi_base, init_sigma=0.5, do_blur=1, prev=N
     return [make_view(par[i].tilt, par[i].phi, par[i].zoom, par[i].InitSigma, par[i].doBlur) for i in range(n)]
 
 
-def detect_describe_views(gray, views, params=None, ori=(1.0, 41, 1, 0.8), desc=(5.1962, 41, 0, 1, 1, 0.2), mser=None, threads=1):
-    """The HessianAffine branch of SynthDetectDescribeKeypoints (imagerepresentation.cpp:603-2047) for one
-    descriptor: per view synthesise, detect, orient, reproject, describe; concatenate in view order with
-    AddRegionsToList id re-basing (:588-600).  Returns (regions, descriptors).  threads > 1: the views run on a thread
-    pool (the reference's `#pragma omp parallel for` over views, :612-622; ctypes releases the GIL), same result."""
+def detect_describe_views(gray, views, params=None, ori=(1.0, 41, 1, 0.8), desc=(5.1962, 41, 0, 1, 1, 0.2), mser=None, threads=1,
+                          descs=None):
+    """The HessianAffine / MSER branch of SynthDetectDescribeKeypoints (imagerepresentation.cpp:603-2047): per view
+    synthesise, detect, orient, reproject, describe; concatenate in view order with AddRegionsToList id re-basing
+    (:588-600).  Returns (regions, descriptors).  threads > 1: the views run on a thread pool (the reference's `#pragma omp
+    parallel for` over views, :612-622; ctypes releases the GIL), same result.
+    descs = the step's descriptor list (types 0 SIFT, 1 RootSIFT, 2 HalfSIFT, 3 HalfRootSIFT; default [desc[4]]): the
+    reference orients ONCE per step -- with doHalfSIFT = true as soon as one name contains "Half" (:693-706, 1259-1264) -- and
+    describes every descriptor of the step on that oriented list (:1288-1296).  With `descs` the second return value is the
+    list of descriptor arrays, one per entry."""
     gray = _f32(gray)
     params = params or default_params()
+    types = [desc[4]] if descs is None else list(descs)
+    half = 1 if any(t >= 2 for t in types) else 0
 
     def one(job):
         vi, v = job
@@ -382,10 +389,10 @@ def detect_describe_views(gray, views, params=None, ori=(1.0, 41, 1, 0.8), desc=
         else:
             k = detect_hessaff(img, params, tilt=vt, zoom=vz)
             regs = detect_affine_regions(k, img_id=0 if ident else vi)
-        ro = detect_orientation(img, regs, mr_size=ori[0], patch_size=ori[1], max_ang=ori[2], th=ori[3])
+        ro = detect_orientation(img, regs, mr_size=ori[0], patch_size=ori[1], half=half, max_ang=ori[2], th=ori[3])
         rr = reproject_regions(ro, H.reshape(9), gray.shape[1], gray.shape[0])
-        d = describe_regions(img, rr, mr_size=desc[0], patch_size=desc[1], fast=desc[2], photo_norm=desc[3],
-                             rootsift=desc[4], max_bin=desc[5])
+        d = [describe_regions(img, rr, mr_size=desc[0], patch_size=desc[1], fast=desc[2], photo_norm=desc[3],
+                              rootsift=t, max_bin=desc[5]) for t in types]
         return rr.copy(), d
 
     jobs = list(enumerate(views))
@@ -403,5 +410,6 @@ def detect_describe_views(gray, views, params=None, ori=(1.0, 41, 1, 0.8), desc=
         size += len(rr)
         all_regs.append(rr)
         all_desc.append(d)
-    return np.concatenate(all_regs) if all_regs else np.zeros(0, REGION), \
-        np.concatenate(all_desc) if all_desc else np.zeros((0, 128), np.float32)
+    regs = np.concatenate(all_regs) if all_regs else np.zeros(0, REGION)
+    per = [np.concatenate([d[k] for d in all_desc]) if all_desc else np.zeros((0, 128), np.float32) for k in range(len(types))]
+    return regs, (per if descs is not None else per[0])

@@ -99,3 +99,74 @@ def dev_to_host(ptr, nbytes):
     rc = hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(int(nbytes)), 2)
     assert rc == 0, rc
     return out
+
+
+DESC_NAME_ORDER = (3, 2, 1, 0)   # "HalfRootSIFT" < "HalfSIFT" < "RootSIFT" < "SIFT": the outer key of CorrespondencesMapMap
+DET_NAME_ORDER = (0, 3)          # "HessianAffine" < "MSER"
+
+
+def oracle_ladder(oracle, a, b, steps, min_matches, seed, ori=(1.0, 41, 1, 0.8), threads=1, hess=None, mser_kw=None,
+                  contrad=30.0, dup_dist=2.0, ransac=None, default_desc=1):
+    """mods.cpp:229-415 restated with the oracle's stage functions (test-side only).
+    steps: (views, ratio[, detector[, descs]]) with descs = [(descriptor type, FGINN ratio), ...] -- the Descriptors /
+    FGINNThreshold lists of the step's [DetectorN] section (default: one class {default_desc, ratio}).
+    Every (detector, descriptor) class keeps its own region lists (RegionVectorMap[det][desc], imagerepresentation.cpp:552-600)
+    and tentatives (CorrespondencesMapMap[desc][det], correspondencebank.cpp:180-218); a step orients once (Half-folded iff
+    one of its descriptors is a Half type) and describes all its descriptors on that list; MatchImgReps re-matches the classes
+    of the step's detector with the step's thresholds (:291-347); GetCorresponcesVector concatenates in map order (:117-179).
+    ransac: dict(kind="h"|"f", **kwargs of oracle.loransac_h / loransac_f)."""
+    mser_kw = mser_kw or dict(min_size=30, max_area=0.05, min_margin=8.0)
+    ransac = dict(ransac or dict(kind="h"))
+    kind = ransac.pop("kind", "h")
+    cls = {}   # (desc type, det) -> dict(acc=[[regs, desc], [regs, desc]], tent)
+    out, done, cur = None, 0, 0
+    for st in steps:
+        if cur >= min_matches:
+            break
+        views, ratio = st[0], st[1]
+        det = st[2] if len(st) > 2 else 0
+        descs = st[3] if len(st) > 3 and st[3] is not None else [(default_desc, ratio)]
+        types = [t for t, _ in descs]
+        for side, img in enumerate((a, b)):
+            r, ds = oracle.detect_describe_views(img, views, params=hess, ori=ori, mser=mser_kw if det == 3 else None,
+                                                 threads=threads, descs=types)
+            for t, d in zip(types, ds):
+                k = cls.setdefault((t, det), dict(acc=[[None, None], [None, None]], tent=None))
+                if k["acc"][side][0] is None:
+                    k["acc"][side] = [r.copy(), d]
+                else:
+                    rr = r.copy()
+                    rr["id"] += len(k["acc"][side][0]); rr["parent_id"] += len(k["acc"][side][0])     # AddRegionsToList
+                    k["acc"][side] = [np.concatenate([k["acc"][side][0], rr]), np.concatenate([k["acc"][side][1], d])]
+        for t, thr in descs:
+            k = cls[(t, det)]
+            (r1, d1), (r2, d2) = k["acc"]
+            pos2 = np.stack([r2["reproj_kp"]["x"], r2["reproj_kp"]["y"]], 1)
+            k["tent"] = oracle.match_fginn(d1, d2, pos2, thr, contrad)
+        R1, R2, T = [], [], []
+        o1 = o2 = 0
+        for t in DESC_NAME_ORDER:
+            for dkey in DET_NAME_ORDER:
+                kk = cls.get((t, dkey))
+                if kk is None:
+                    continue
+                tt = kk["tent"].copy()
+                tt["q"] += o1
+                for f in ("t0", "t1", "tj"):
+                    tt[f] = np.where(tt[f] >= 0, tt[f] + o2, tt[f])
+                T.append(tt); R1.append(kk["acc"][0][0]); R2.append(kk["acc"][1][0])
+                o1 += len(kk["acc"][0][0]); o2 += len(kk["acc"][1][0])
+        r1, r2, tent = np.concatenate(R1), np.concatenate(R2), np.concatenate(T)
+        pts = np.stack([r1["reproj_kp"]["x"][tent["q"]], r1["reproj_kp"]["y"][tent["q"]],
+                        r2["reproj_kp"]["x"][tent["t0"]], r2["reproj_kp"]["y"][tent["t0"]]], 1)
+        order, keep = oracle.duplicate_filtering(pts, tent["ratio"], dup_dist, True)
+        sel = order[keep]
+        tu, pu = tent[sel], pts[sel]
+        if kind == "f":
+            rr = oracle.loransac_f(pu, laf_of(r1, tu["q"]), laf_of(r2, tu["t0"]), seed=seed, **ransac)
+        else:
+            rr = oracle.loransac_h(pu, laf_of(r1, tu["q"]), laf_of(r2, tu["t0"]), seed=seed, **ransac)
+        cur = int(rr["keep"].sum())
+        out = dict(n_regions=(len(r1), len(r2)), n_tentatives=len(tent), tent=tu, rr=rr, r1=r1, r2=r2, pts=pu)
+        done += 1
+    return out, done

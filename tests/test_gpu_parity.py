@@ -163,6 +163,48 @@ def test_orientation_and_description_bit_exact(ctx, modsx, oracle, small_pair):
     im.free()
 
 
+@pytest.mark.parametrize("mr,max_ang", [(1.0, 1), (1.0, 5), (5.1962, 1), (5.1962, 5), (5.1962, 18)])
+def test_orientation_half_mode_bit_exact(ctx, modsx, oracle, small_pair, mr, max_ang):
+    """DetectOrientation(..., doHalfSIFT = true, ...) -- what the reference runs for every step whose descriptor list holds a
+    Half type (imagerepresentation.cpp:1259-1264): opposite bins of the smoothed 36-bin histogram are folded before the peak
+    search (synth-detection.cpp:801-808).  Both measurement regions of the shipped configs x maxAngles 1 / 5 / 18 (= every peak a 36-bin histogram can have); the folded
+    and the plain mode must also differ, or the test would not see the flag."""
+    differs = 0
+    for img in small_pair[:2]:
+        im = ctx.upload(img)
+        k = oracle.detect_hessaff(img, oracle.default_params())
+        regs = oracle.detect_affine_regions(k)
+        ref = oracle.detect_orientation(img, regs, mr_size=mr, half=1, max_ang=max_ang)
+        got = ctx.detect_orientation(im, regs.view(modsx.REGION), mr_size=mr, half=1, max_ang=max_ang)
+        plain = ctx.detect_orientation(im, regs.view(modsx.REGION), mr_size=mr, half=0, max_ang=max_ang)
+        im.free()
+        assert len(ref) > 20 and same_records(got, ref.view(modsx.REGION))
+        differs += int(len(plain) != len(got) or not same_records(plain, got))
+    assert differs > 0
+
+
+def test_step_descriptor_list_one_pass_equals_separate_calls(ctx, modsx, oracle, small_pair):
+    """A step with Descriptors = RootSIFT, HalfRootSIFT (iters_mods_cviu_wxbs.ini:35): the view loop orients once with the
+    Half-folded histogram and emits both descriptors from one pass over the patches; the first class it returns must be what
+    DescribeRegions gives on the Half-oriented list, for either order of the list and against the oracle-side loop."""
+    img = small_pair[0]
+    im = ctx.upload(img)
+    vo = oracle.set_vs_pars([1.0], [1, 2], 360.0, 0.2, 1, [])
+    vm = modsx.set_vs_pars([1.0], [1, 2], 360.0, 0.2, 1, [])
+    r_ref, d_ref = oracle.detect_describe_views(img, vo, ori=(5.1962, 41, 5, 0.8), descs=[1, 3])
+    for order in ([(1, 0.8), (3, 0.8)], [(3, 0.8), (1, 0.8)]):
+        par = modsx.default_pair_params(ori_mrSize=5.1962, ori_maxAngles=5, descs=order)
+        regs, desc = ctx.detect_describe_views(im, vm, par)
+        assert len(r_ref) > 100 and same_records(regs, r_ref.view(modsx.REGION))
+        assert np.array_equal(desc, d_ref[0] if order[0][0] == 1 else d_ref[1])
+    # a RootSIFT-only step on the same views orients WITHOUT the fold: other regions
+    par = modsx.default_pair_params(ori_mrSize=5.1962, ori_maxAngles=5)
+    regs1, _ = ctx.detect_describe_views(im, vm, par)
+    r1_ref, _ = oracle.detect_describe_views(img, vo, ori=(5.1962, 41, 5, 0.8))
+    assert same_records(regs1, r1_ref.view(modsx.REGION)) and len(regs1) != len(r_ref)
+    im.free()
+
+
 def _check_tents(a, b):
     assert len(a) == len(b)
     for f in a.dtype.names:
@@ -380,54 +422,76 @@ def test_full_hd_pair_runs(ctx, modsx):
     assert np.abs(normH(r["H"]) - H).max() < 1.0
 
 
-def _wxbs_params(modsx, seed, useF):
+WXBS_DESCS = [(1, 0.8), (3, 0.8)]    # Descriptors=RootSIFT,HalfRootSIFT; FGINNThreshold=0.8,0.8 ([HessianAffine4], iters_mods_cviu_wxbs.ini:61-62)
+
+
+def _wxbs_params(modsx, seed, useF, descs=WXBS_DESCS):
     """config_iter_mods_cviu_wxbs.ini: [HessianAffine] :13-27, [DominantOrientation] :102-108, [SIFTDescriptor] :109-118 with the
-    HalfRootSIFT class of iters_mods_cviu_wxbs.ini:35,48,61, [Matching] contradDist :173, [DuplicateFiltering] :179-182,
-    [RANSAC] :185-194."""
+    RootSIFT + HalfRootSIFT classes of iters_mods_cviu_wxbs.ini:35,48,61, [Matching] contradDist :173, [DuplicateFiltering]
+    :179-182, [RANSAC] :185-194."""
     return modsx.default_pair_params(
         mode=4, threshold=5.3333, reg_number=2000,                 # NotLessThanRegions / 2000
         ori_mrSize=5.1962, ori_maxAngles=5, ori_threshold=0.8,
-        desc_mrSize=5.1962, desc_photoNorm=1, desc_type=3, desc_maxBinValue=0.2,  # HalfRootSIFT
-        match_ratio=0.8, contradDist=10.0, duplicateDist=3.0,
+        desc_mrSize=5.1962, desc_photoNorm=1, desc_maxBinValue=0.2, descs=descs,
+        contradDist=10.0, duplicateDist=3.0,
         err_threshold=4.0, confidence=0.99, max_samples=1000000, localOptimization=1, LAFCoef=3.0, HLAFCoef=13.0,
         doSymmCheck=1, useF=useF, ransac_seed=seed)
 
 
-def _wxbs_oracle(O, a, b):
+def _wxbs_oracle(O, a, b, descs=WXBS_DESCS):
+    """One identity-view step of the WxBS ladder as the reference runs it (imagerepresentation.cpp:693-706, 1259-1264,
+    1288-1296; correspondencebank.cpp:291-347, 117-179): ONE oriented list per image -- doHalfSIFT = true because the step
+    carries HalfRootSIFT --, both descriptors on it, each class matched with its threshold, tentatives concatenated in
+    descriptor-name order (HalfRootSIFT before RootSIFT) with indices into the concatenated region lists."""
     p = O.default_params(mode=4, threshold=5.3333, reg_number=2000)
+    half = 1 if any(t >= 2 for t, _ in descs) else 0
     feats = []
     for g in (a, b):
         k = O.detect_hessaff(g, p)
         r = O.detect_affine_regions(k)
-        ro = O.detect_orientation(g, r, mr_size=5.1962, max_ang=5, th=0.8)
+        ro = O.detect_orientation(g, r, mr_size=5.1962, half=half, max_ang=5, th=0.8)
         rr = O.reproject_regions(ro, np.eye(3), g.shape[1], g.shape[0])
-        feats.append((rr, O.describe_regions(g, rr, mr_size=5.1962, rootsift=3)))
+        feats.append((rr, {t: O.describe_regions(g, rr, mr_size=5.1962, rootsift=t) for t, _ in descs}))
     (r1, d1), (r2, d2) = feats
     pos2 = np.stack([r2["reproj_kp"]["x"], r2["reproj_kp"]["y"]], 1)
-    tent = O.match_fginn(d1, d2, pos2, 0.8, 10.0)
-    pts = np.stack([r1["reproj_kp"]["x"][tent["q"]], r1["reproj_kp"]["y"][tent["q"]],
-                    r2["reproj_kp"]["x"][tent["t0"]], r2["reproj_kp"]["y"][tent["t0"]]], 1)
+    T, o1, o2 = [], 0, 0
+    for t in (3, 2, 1, 0):
+        thr = dict(descs).get(t)
+        if thr is None:
+            continue
+        tt = O.match_fginn(d1[t], d2[t], pos2, thr, 10.0).copy()
+        tt["q"] += o1
+        for f in ("t0", "t1", "tj"):
+            tt[f] = np.where(tt[f] >= 0, tt[f] + o2, tt[f])
+        T.append(tt)
+        o1 += len(r1); o2 += len(r2)
+    tent = np.concatenate(T)
+    R1, R2 = np.concatenate([r1] * len(descs)), np.concatenate([r2] * len(descs))
+    pts = np.stack([R1["reproj_kp"]["x"][tent["q"]], R1["reproj_kp"]["y"][tent["q"]],
+                    R2["reproj_kp"]["x"][tent["t0"]], R2["reproj_kp"]["y"][tent["t0"]]], 1)
     order, keep = O.duplicate_filtering(pts, tent["ratio"], 3.0, True)
     sel = order[keep]
-    return r1, r2, tent[sel], pts[sel]
+    return R1, R2, tent[sel], pts[sel], len(tent)
 
 
 def test_wxbs_config_full_hd_pair_h_and_f(ctx, modsx, oracle):
     """configs[4] of BASELINE.json end to end on one 1920x1080 pair with the WxBS parameter set (NotLessThanRegions 2000,
-    maxAngles 5 on the 5.1962 measurement region, HalfRootSIFT, contradDist 10, duplicateDist 3, err_threshold 4,
-    max_samples 1e6) against the CPU oracle: region counts, the de-duplicated tentative list field by field, and for both
-    verification types (H: exp_ransacHcustom + H_LAF_check 13, F: exp_ransacFcustom + DEGENSAC + F_LAF_check 3) the RANSAC
-    inlier flags, the verified set and the model."""
+    maxAngles 5 on the 5.1962 measurement region with the Half-folded orientation histogram, the RootSIFT and the HalfRootSIFT
+    class matched separately, contradDist 10, duplicateDist 3, err_threshold 4, max_samples 1e6) against the CPU oracle: region
+    counts, the de-duplicated tentative list field by field, and for both verification types (H: exp_ransacHcustom +
+    H_LAF_check 13, F: exp_ransacFcustom + DEGENSAC + F_LAF_check 3) the RANSAC inlier flags, the verified set and the model."""
     from mods_amd import synthetic
     if not oracle.ref_available():
         pytest.skip("oracle/_ref not built")
     a, b, H = synthetic.make_pair(rows=1080, cols=1920, nblobs=3000, seed=77)
-    r1, r2, tu, pu = _wxbs_oracle(oracle, a, b)
+    r1, r2, tu, pu, ntent = _wxbs_oracle(oracle, a, b)
     ia, ib = ctx.upload(a), ctx.upload(b)
     for useF in (0, 1):
         got = ctx.match_pair(ia, ib, _wxbs_params(modsx, 5, useF))
-        assert got["n_regions"] == (len(r1), len(r2)) and min(got["n_regions"]) >= 2000
+        assert got["n_regions"] == (len(r1), len(r2)) and min(got["n_regions"]) >= 4000     # two classes x >= 2000 regions
+        assert got["n_tentatives"] == ntent
         _check_tents(got["tentatives"], tu)
+        assert (tu["q"] >= len(r1) // 2).any() and (tu["q"] < len(r1) // 2).any()           # both classes survive the filter
         if useF:
             rr = oracle.loransac_f(pu, laf_of(r1, tu["q"]), laf_of(r2, tu["t0"]), err_threshold=4.0, max_samples=1000000,
                                    laf_coef=3.0, seed=5)

@@ -218,6 +218,30 @@ def test_sharded_ladder_equals_unsharded_ladder(ctx, modsx, small_pair):
     ia.free(); ib.free()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_wxbs_ladder_two_descriptor_classes(ctx, modsx, small_pair, world):
+    """The WxBS step structure through the exchange: a block row carries the region and BOTH descriptors of the step (200 +
+    2 x 128 B), the device-side ordering fills one accumulator per (detector, descriptor) class, and every class is matched
+    with its query rows split over the ranks; the result on every rank == the unsharded ladder (which test_gpu_views.py
+    compares with the oracle)."""
+    from mods_amd import distributed as D
+    from test_gpu_views import _wxbs_ladder, _wxbs_ladder_params
+    a, b, _ = small_pair
+    _, steps = _wxbs_ladder(None, modsx, which=(0, 2, 3))
+    par = _wxbs_ladder_params(modsx, 7, 0, 300, 120)
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    ref, done = ctx.match_ladder(ia, ib, steps, par, min_matches=10 ** 6)
+    assert done == 3 and ref["n_verified"] > 20
+
+    def rank_body(r, comm):
+        return comm.match_ladder_sharded(0, ia, ib, steps, par, min_matches=10 ** 6)
+
+    for got, d in D.run_loopback(world, rank_body):
+        assert d == 3
+        _same_pair_result(got, ref)
+    ia.free(); ib.free()
+
+
 def test_configs3_full_cviu_ladder_sharded_over_8_ranks(ctx, modsx):
     """configs[3] with its view sharding: every step of the iters_mods_cviu.ini ladder (27 MSER + 61 HessianAffine views per
     image, all steps forced) on the 1024x768 pair with the views of each step split over 8 ranks; every rank ends with the

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from common import laf_of, normH, same_records
+from common import laf_of, normH, oracle_ladder, same_records
 
 pytestmark = pytest.mark.gpu
 
@@ -174,52 +174,8 @@ def test_view_shard_path_world1_rccl(ctx, modsx, small_pair):
 
 
 def _oracle_ladder(oracle, a, b, steps, min_matches, seed, ori_mr=1.0, threads=1):
-    """mods.cpp:229-415 restated with the oracle's stage functions (test-side only).  steps: (views, ratio[, detector]);
-    the two detector classes keep their own region lists and tentatives (CorrespondenceBank), HessianAffine first."""
-    mser_kw = dict(min_size=30, max_area=0.05, min_margin=8.0)
-    cls = {0: dict(acc=[[None, None], [None, None]], tent=None), 3: dict(acc=[[None, None], [None, None]], tent=None)}
-    out, done, cur = None, 0, 0
-    for st in steps:
-        if cur >= min_matches:
-            break
-        views, ratio = st[0], st[1]
-        det = st[2] if len(st) > 2 else 0
-        k = cls[det]
-        for side, img in enumerate((a, b)):
-            r, d = oracle.detect_describe_views(img, views, ori=(ori_mr, 41, 1, 0.8), mser=mser_kw if det == 3 else None,
-                                                threads=threads)
-            if k["acc"][side][0] is None:
-                k["acc"][side] = [r, d]
-            else:
-                r = r.copy()
-                r["id"] += len(k["acc"][side][0]); r["parent_id"] += len(k["acc"][side][0])     # AddRegionsToList
-                k["acc"][side] = [np.concatenate([k["acc"][side][0], r]), np.concatenate([k["acc"][side][1], d])]
-        (r1, d1), (r2, d2) = k["acc"]
-        pos2 = np.stack([r2["reproj_kp"]["x"], r2["reproj_kp"]["y"]], 1)
-        k["tent"] = oracle.match_fginn(d1, d2, pos2, ratio, 30.0)
-        R1, R2, T = [], [], []
-        o1 = o2 = 0
-        for dkey in (0, 3):
-            kk = cls[dkey]
-            if kk["acc"][0][0] is None:
-                continue
-            t = kk["tent"].copy()
-            t["q"] += o1
-            for f in ("t0", "t1", "tj"):
-                t[f] = np.where(t[f] >= 0, t[f] + o2, t[f])
-            T.append(t); R1.append(kk["acc"][0][0]); R2.append(kk["acc"][1][0])
-            o1 += len(kk["acc"][0][0]); o2 += len(kk["acc"][1][0])
-        r1, r2, tent = np.concatenate(R1), np.concatenate(R2), np.concatenate(T)
-        pts = np.stack([r1["reproj_kp"]["x"][tent["q"]], r1["reproj_kp"]["y"][tent["q"]],
-                        r2["reproj_kp"]["x"][tent["t0"]], r2["reproj_kp"]["y"][tent["t0"]]], 1)
-        order, keep = oracle.duplicate_filtering(pts, tent["ratio"], 2.0, True)
-        sel = order[keep]
-        tu, pu = tent[sel], pts[sel]
-        rr = oracle.loransac_h(pu, laf_of(r1, tu["q"]), laf_of(r2, tu["t0"]), seed=seed)
-        cur = int(rr["keep"].sum())
-        out = dict(n_regions=(len(r1), len(r2)), n_tentatives=len(tent), tent=tu, rr=rr)
-        done += 1
-    return out, done
+    """the cviu parameter set through tests/common.py's oracle-side loop"""
+    return oracle_ladder(oracle, a, b, steps, min_matches, seed, ori=(ori_mr, 41, 1, 0.8), threads=threads)
 
 
 @pytest.mark.parametrize("min_matches", [10, 10 ** 6])
@@ -335,6 +291,105 @@ def test_configs3_full_cviu_ladder_all_steps_matches_oracle(ctx, modsx, oracle):
         assert np.array_equal(got["tentatives"][f], ref["tent"][f]), f
     assert np.array_equal(got["ransac_inlier"], ref["rr"]["inl"]) and np.array_equal(got["verified"], ref["rr"]["keep"])
     assert np.abs(normH(got["H"]) - normH(ref["rr"]["H"])).max() < 1e-4
+
+
+WXBS_STEPS = (   # [MSER2], [MSER3], [HessianAffine4..6] of build/iters_mods_cviu_wxbs.ini:30-75: Descriptors=RootSIFT,HalfRootSIFT
+    (3, [1, 0.25, 0.125], [1], 360.0, 0.8, [(1, 0.85), (3, 0.8)]),
+    (3, [1, 0.25, 0.125], [1, 3, 6, 9], 360.0, 0.8, [(1, 0.8), (3, 0.8)]),
+    (0, [1], [1, 2, 4, 6, 8], 360.0, 0.2, [(1, 0.8), (3, 0.8)]),
+    (0, [1], [1, 2, 4, 6, 8], 120.0, 0.2, [(1, 0.8), (3, 0.8)]),
+    (0, [1], [1, 2, 4, 6, 8], 60.0, 0.2, [(1, 0.9), (3, 0.9)]))
+
+
+def _wxbs_ladder(oracle, modsx, which=None):
+    prev_o, prev_m, steps_o, steps_m = {0: [], 3: []}, {0: [], 3: []}, [], []
+    for i, (det, scales, tilts, phi, sigma, descs) in enumerate(WXBS_STEPS):
+        vm = modsx.set_vs_pars(scales, tilts, phi, sigma, 1, prev_m[det])
+        vo = oracle.set_vs_pars(scales, tilts, phi, sigma, 1, prev_o[det]) if oracle is not None else None
+        if which is not None and i not in which:
+            continue
+        steps_m.append((vm, 0.0, det, descs))
+        if oracle is not None:
+            assert len(vo) == len(vm) and len(vo) > 0
+            steps_o.append((vo, 0.0, det, descs))
+    return steps_o, steps_m
+
+
+def _wxbs_ladder_params(modsx, seed, useF, reg_number=2000, mser_regs=500):
+    """config_iter_mods_cviu_wxbs.ini: [MSER] :4-12 (FixedRegNumber 500), [HessianAffine] :13-27 (NotLessThanRegions 2000),
+    [DominantOrientation] :102-108, [SIFTDescriptor] :109-118, contradDist :173, [DuplicateFiltering] :179-182, [RANSAC] :185-194"""
+    par = modsx.default_pair_params(
+        mode=4, threshold=5.3333, reg_number=reg_number, ori_mrSize=5.1962, ori_maxAngles=5, ori_threshold=0.8,
+        desc_mrSize=5.1962, desc_photoNorm=1, desc_maxBinValue=0.2, contradDist=10.0, duplicateDist=3.0,
+        err_threshold=4.0, confidence=0.99, max_samples=1000000, localOptimization=1, LAFCoef=3.0, HLAFCoef=13.0,
+        doSymmCheck=1, useF=useF, ransac_seed=seed)
+    par.mser.mode = 2
+    par.mser.reg_number = mser_regs
+    return par
+
+
+def _check_wxbs_ladder(oracle, modsx, ctx, a, b, steps_o, steps_m, useF, seed, min_matches, reg_number, mser_regs, threads=1):
+    par = _wxbs_ladder_params(modsx, seed, useF, reg_number, mser_regs)
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    got, done = ctx.match_ladder(ia, ib, steps_m, par, min_matches=min_matches)
+    ia.free(); ib.free()
+    rk = dict(kind="f", err_threshold=4.0, max_samples=1000000, laf_coef=3.0) if useF else \
+        dict(kind="h", err_threshold=4.0, max_samples=1000000, hlaf_coef=13.0)
+    ref, done_ref = oracle_ladder(oracle, a, b, steps_o, min_matches, seed, ori=(5.1962, 41, 5, 0.8), threads=threads,
+                                  hess=oracle.default_params(mode=4, threshold=5.3333, reg_number=reg_number),
+                                  mser_kw=dict(min_size=30, max_area=0.05, min_margin=8.0, mode=2, reg_number=mser_regs),
+                                  contrad=10.0, dup_dist=3.0, ransac=rk)
+    assert done == done_ref
+    assert got["n_regions"] == ref["n_regions"] and got["n_tentatives"] == ref["n_tentatives"]
+    for f in ref["tent"].dtype.names:
+        assert np.array_equal(got["tentatives"][f], ref["tent"][f]), f
+    assert np.array_equal(got["ransac_inlier"], ref["rr"]["inl"]) and np.array_equal(got["verified"], ref["rr"]["keep"])
+    if useF:
+        Fa, Fb = ref["rr"]["F"] / np.linalg.norm(ref["rr"]["F"]), got["H"] / np.linalg.norm(got["H"])
+        if (Fa * Fb).sum() < 0:
+            Fb = -Fb
+        assert np.abs(Fa - Fb).max() < 1e-6
+    else:
+        assert np.abs(normH(got["H"]) - normH(ref["rr"]["H"])).max() < 1e-4
+    return got, ref, done
+
+
+@pytest.mark.parametrize("useF", [0, 1])
+def test_wxbs_ladder_two_descriptor_classes_small(ctx, modsx, oracle, small_pair, useF):
+    """The WxBS ladder (iters_mods_cviu_wxbs.ini [MSER2], [MSER3], [HessianAffine4..6]) in its stated form on a small pair: every
+    step carries RootSIFT AND HalfRootSIFT, so it orients with the Half-folded histogram, keeps one region list and one
+    tentative list per (detector, descriptor), matches each with its own FGINN threshold (0.85 / 0.8 in [MSER2], 0.9 in
+    [HessianAffine6]) and verifies the concatenation in std::map order -- H (ver_type 0) and F (ver_type 2)."""
+    a, b, H = small_pair
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    steps_o, steps_m = _wxbs_ladder(oracle, modsx)
+    assert [len(v) for v, _, _, _ in steps_m] == [3, 24, 11, 20, 30]
+    got, ref, done = _check_wxbs_ladder(oracle, modsx, ctx, a, b, steps_o, steps_m, useF, 7, 10 ** 6, 300, 120)
+    assert done == 5 and got["n_verified"] > 30
+    n1 = got["n_regions"][0]
+    assert (got["tentatives"]["q"] < n1 // 2).any() and (got["tentatives"]["q"] >= n1 // 2).any()
+    if not useF:
+        assert np.abs(normH(got["H"]) - H).max() < 2.5
+    # minMatches = 15 (iters_mods_cviu_wxbs.ini:3): the same ladder stops as soon as the verified set is large enough
+    got2, ref2, done2 = _check_wxbs_ladder(oracle, modsx, ctx, a, b, steps_o, steps_m, useF, 7, 15, 300, 120)
+    assert done2 < 5
+
+
+def test_configs4_wxbs_ladder_full_size_both_classes(ctx, modsx, oracle):
+    """configs[4]'s ladder at full size: [MSER2], [HessianAffine4], [HessianAffine5] of iters_mods_cviu_wxbs.ini on the 1024x768
+    pair with the WxBS parameter set (3 MSER views, 31 HessianAffine views; two descriptor classes per detector = four
+    classes), every tentative, the inlier set, the verified set and H against the oracle's loop."""
+    import os
+    from mods_amd import synthetic
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    a, b, _ = synthetic.make_pair(rows=768, cols=1024, nblobs=4000, seed=12345)
+    steps_o, steps_m = _wxbs_ladder(oracle, modsx, which=(0, 2, 3))
+    assert [len(v) for v, _, _, _ in steps_m] == [3, 11, 20]
+    got, ref, done = _check_wxbs_ladder(oracle, modsx, ctx, a, b, steps_o, steps_m, 0, 3, 10 ** 6, 2000, 500,
+                                        threads=min(64, os.cpu_count() or 1))
+    assert done == 3 and got["n_regions"][0] > 40000 and len(ref["tent"]) > 3000
 
 
 def test_cat_pair_full_ladder_stops_early_on_ground_truth(ctx, modsx, cat_pair):
