@@ -35,6 +35,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# keep the host tables of a pair mapped between calls (modsx.h: opt-in, it changes malloc for the whole process -- this one is ours)
+os.environ.setdefault("MODSX_MALLOC_TUNE", "1")
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 INT8_PEAK_TOPS = 5000.0      # dense int8 matrix peak (~2x the 2.5 PF bf16 dense peak)
@@ -45,8 +47,9 @@ CONFIGS = {   # name -> (tilts, phi, detector mode, description)
     "views31": ("1,2,4,6,8", 120.0, "31 views (TiltSet 1,2,4,6,8, Phi 120)"),
     "views61": ("1,2,4,6,8", 60.0, "61 views (TiltSet 1,2,4,6,8, Phi 60)"),
     # configs[4]: 1920x1080 pairs with the parameter set of config_iter_mods_cviu_wxbs.ini (NotLessThanRegions 2000, maxAngles 5
-    # on the 5.1962 region, HalfRootSIFT, contradDist 10, duplicateDist 3, err_threshold 4, max_samples 1e6), H then F
-    "wxbs": ("1", 360.0, "configs[4]: WxBS parameter set, identity view"),
+    # on the 5.1962 region with the Half-folded orientation histogram, the RootSIFT and HalfRootSIFT classes of every WxBS step,
+    # contradDist 10, duplicateDist 3, err_threshold 4, max_samples 1e6), H then F
+    "wxbs": ("1", 360.0, "configs[4]: WxBS parameter set (RootSIFT + HalfRootSIFT classes), identity view"),
     "ladder": ("1,2,4,6,8", 60.0, "configs[3]: iters_mods_cviu.ini, all MSER + HessianAffine steps (27 + 61 views per image)"),
 }
 # [MSER2], [MSER3], [HessianAffine4..6] of build/iters_mods_cviu.ini: detector, ScaleSet, TiltSet, Phi, initSigma, FGINN ratio
@@ -62,8 +65,10 @@ def cviu_ladder_steps(M, only=None):
         if v and (only is None or det == only):
             steps.append((v, ratio, det))
     return steps
+# config_iter_mods_cviu_wxbs.ini + the step structure of iters_mods_cviu_wxbs.ini [HessianAffine4] (:56-62): Descriptors=RootSIFT,
+# HalfRootSIFT, FGINNThreshold=0.8,0.8 -- one Half-folded orientation pass, both descriptors, two classes matched separately
 WXBS = dict(mode=4, threshold=5.3333, reg_number=2000, ori_mrSize=5.1962, ori_maxAngles=5, ori_threshold=0.8, desc_mrSize=5.1962,
-            desc_photoNorm=1, desc_type=3, desc_maxBinValue=0.2, match_ratio=0.8, contradDist=10.0, duplicateDist=3.0,
+            desc_photoNorm=1, desc_maxBinValue=0.2, descs=[(1, 0.8), (3, 0.8)], contradDist=10.0, duplicateDist=3.0,
             err_threshold=4.0, confidence=0.99, max_samples=1000000, localOptimization=1, LAFCoef=3.0, HLAFCoef=13.0, doSymmCheck=1)
 
 
@@ -388,7 +393,7 @@ def main():
         box = {}
         # ... and a crash must not either: RCCL with more than one rank has only ever run on the driver's node.  Rank 0 leaves
         # the headline with a child process that shares its stdout and prints it if this process dies before its own line.
-        if rank == 0:
+        if rank == 0 and world > 1:   # never at --gpus 1: the N = 1 line has no leg that could take it away
             pairs0 = args.steps * world * nbatch
             emergency = {
                 "metric": "image-pairs/sec (1024x768, HessAff+RootSIFT over the affine view ladder, MFMA FGINN match, LO-RANSAC H)",

@@ -164,9 +164,9 @@ int modsx_version(void);
 const char *modsx_last_error(void);
 void modsx_free(void *p);
 
-/* The first call also raises glibc's mmap / trim thresholds (mallopt) so that the ~100 MB of host tables a pair allocates and
- * frees stay mapped between calls (1 ms of page faults per 31-view pair otherwise); MODSX_MALLOC_TUNE=0 in the environment
- * leaves the process's allocator settings alone. */
+/* With MODSX_MALLOC_TUNE=1 in the environment the first call also raises glibc's mmap / trim thresholds (mallopt) so that the
+ * ~100 MB of host tables a pair allocates and frees stay mapped between calls (1 ms of page faults per 31-view pair otherwise).
+ * Opt-in because it changes malloc for the whole host process. */
 modsx_ctx *modsx_create(int device_id);
 void modsx_destroy(modsx_ctx *ctx);
 int modsx_synchronize(modsx_ctx *ctx);

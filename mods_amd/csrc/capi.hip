@@ -37,13 +37,14 @@ void modsx_free(void *p) { free(p); }
 // The host stages of a pair allocate and release ~100 MB of job tables, region lists and tentative arrays per call.  With
 // glibc's defaults every block above 128 KB is its own mmap: fresh zero pages faulted in on first touch and unmapped on free --
 // about 1 ms of page faults per 31-view pair (measured: 16.3 -> 15.3 ms).  Once per process the thresholds are raised so that
-// such blocks come from, and return to, the heap and stay mapped.  MODSX_MALLOC_TUNE=0 leaves the allocator alone.
+// such blocks come from, and return to, the heap and stay mapped.  This changes malloc for the whole host process, so it is
+// OPT-IN: MODSX_MALLOC_TUNE=1 (bench.py and tools/latency.py set it; a host application decides for itself).
 static void tune_host_allocator() {
 #if defined(__GLIBC__)
   static std::once_flag once;
   std::call_once(once, [] {
     const char *e = getenv("MODSX_MALLOC_TUNE");
-    if (e && atoi(e) == 0) return;
+    if (!e || atoi(e) == 0) return;
     mallopt(M_MMAP_THRESHOLD, 1 << 30);
     mallopt(M_TRIM_THRESHOLD, 1 << 30);
     mallopt(M_TOP_PAD, 64 << 20);

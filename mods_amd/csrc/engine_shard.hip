@@ -35,6 +35,7 @@
 #include <dlfcn.h>
 #include <unistd.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <map>
@@ -94,8 +95,15 @@ struct LoopGroup {
   int arrived = 0, joined = 0;
   long gen = 0;
   bool dead = false;
-  struct Slot { const void *send = nullptr; void *recv = nullptr; size_t bytes = 0; hipEvent_t ready = nullptr, done = nullptr; };
+  // the events of a rank's slot belong to the GROUP: peers wait on them after the last barrier of a collective, so they are
+  // destroyed with the group (when the last rank has left), never by the rank that recorded them
+  struct Slot { const void *send = nullptr; void *recv = nullptr; size_t bytes = 0; hipEvent_t ready = nullptr, done = nullptr; bool taken = false; };
   std::vector<Slot> slots;
+  int dev = 0;
+  ~LoopGroup() {
+    hipSetDevice(dev);
+    for (Slot &sl : slots) { if (sl.ready) hipEventDestroy(sl.ready); if (sl.done) hipEventDestroy(sl.done); }
+  }
   // all ranks of the group meet here; false = a rank did not show up within the deadline (the group is dead from then on)
   bool barrier(int timeout_ms) {
     std::unique_lock<std::mutex> lk(mu);
@@ -130,14 +138,18 @@ struct modsx_comm {
   ncclComm_t nccl = nullptr;
   std::shared_ptr<mx::LoopGroup> loop;
   int rank = 0, world = 1, version = 0, dev = 0;
-  int timeout_ms = 30000;
+  std::atomic<int> timeout_ms{30000};       // deadline of a collective (the watchdog)
+  std::atomic<int> turn_timeout_ms{300000}; // deadline of a lane waiting for ITS TURN: the lane ahead may be in a long host stage
+                                            // (a full-size MSER step, a 10^6-sample RANSAC), which is not a hung collective
   // lanes: the contexts of this rank, collectives issued round-robin
   std::mutex mu;
   std::condition_variable cv;
   std::vector<mx::ShardLane> lanes;
   int turn = 0;
-  bool dead = false;
-  std::string deadWhy;
+  std::atomic<bool> dead{false};            // read without the lock by every lane and by the waits
+  std::string deadWhy;                      // written once, under mu, before dead is set
+  std::mutex issueMu;                       // serialises enqueueing on the RCCL communicator with its abort
+  bool aborted = false;                     // under issueMu: ncclCommAbort has run; nccl is never used again
   long bytes_gathered = 0, collectives = 0, retries = 0, agreements = 0;
 };
 
@@ -154,32 +166,42 @@ static int hdr_bytes(int nv) { return ((HDR_FIXED + nv) * 4 + 63) & ~63; }
 static void comm_kill(modsx_comm *cm, const std::string &why) {
   {
     std::lock_guard<std::mutex> lk(cm->mu);
-    if (cm->dead) return;
-    cm->dead = true;
+    if (cm->dead.load()) return;
     cm->deadWhy = why;
+    cm->dead.store(true);
     cm->cv.notify_all();
   }
   if (cm->loop) cm->loop->kill();
-  if (cm->nccl) { g_rccl.CommAbort(cm->nccl); cm->nccl = nullptr; }
+  else {
+    // abort once, and never while another lane is inside ncclAllGather on this communicator (issueMu); the handle stays set
+    // (modsx_comm_destroy frees what is left) but nothing enqueues on it again: transport_all_gather checks `aborted` under
+    // the same lock
+    std::lock_guard<std::mutex> lk(cm->issueMu);
+    if (!cm->aborted && cm->nccl) { g_rccl.CommAbort(cm->nccl); cm->aborted = true; }
+  }
 }
 static int comm_dead_rc(modsx_comm *cm) {
-  set_error("communicator is dead (" + cm->deadWhy + "): a collective timed out or failed; destroy it and create a new one");
+  std::string why;
+  { std::lock_guard<std::mutex> lk(cm->mu); why = cm->deadWhy; }
+  set_error("communicator is dead (" + why + "): a collective timed out or failed; destroy it and create a new one");
   return MODSX_ERR_TIMEOUT;
 }
 
 // round-robin issue order over the lanes that are still active
 static int turn_begin(modsx_comm *cm, int lane) {
   std::unique_lock<std::mutex> lk(cm->mu);
-  const auto deadline = Clock::now() + std::chrono::milliseconds(cm->timeout_ms);
-  while (!cm->dead && cm->turn != lane) {
-    if (cm->cv.wait_until(lk, deadline) == std::cv_status::timeout && cm->turn != lane && !cm->dead) {
+  const int tmo = std::max(cm->turn_timeout_ms.load(), cm->timeout_ms.load());
+  const auto deadline = Clock::now() + std::chrono::milliseconds(tmo);
+  while (!cm->dead.load() && cm->turn != lane) {
+    if (cm->cv.wait_until(lk, deadline) == std::cv_status::timeout && cm->turn != lane && !cm->dead.load()) {
+      const int ahead = cm->turn;
       lk.unlock();
-      comm_kill(cm, "lane " + std::to_string(lane) + " waited " + std::to_string(cm->timeout_ms) + " ms for its turn (lane " +
-                        std::to_string(cm->turn) + " never issued its collective)");
+      comm_kill(cm, "lane " + std::to_string(lane) + " waited " + std::to_string(tmo) + " ms for its turn (lane " +
+                        std::to_string(ahead) + " never issued its collective)");
       return comm_dead_rc(cm);
     }
   }
-  if (cm->dead) { lk.unlock(); return comm_dead_rc(cm); }
+  if (cm->dead.load()) { lk.unlock(); return comm_dead_rc(cm); }
   return MODSX_OK;
 }
 static void turn_advance_locked(modsx_comm *cm) {
@@ -198,15 +220,16 @@ static void turn_end(modsx_comm *cm) {
 // wait for the stream with the watchdog's deadline
 static int comm_wait(modsx_comm *cm, hipStream_t s) {
   const auto t0 = Clock::now();
-  const auto deadline = t0 + std::chrono::milliseconds(cm->timeout_ms);
+  const int tmo = cm->timeout_ms.load();
+  const auto deadline = t0 + std::chrono::milliseconds(tmo);
   for (;;) {
     hipError_t e = hipStreamQuery(s);
     if (e == hipSuccess) return MODSX_OK;
     if (e != hipErrorNotReady) { set_error(std::string("sharded path: ") + hipGetErrorString(e)); comm_kill(cm, "device error"); return MODSX_ERR_DEVICE; }
-    if (cm->dead) return comm_dead_rc(cm);
+    if (cm->dead.load()) return comm_dead_rc(cm);
     const auto now = Clock::now();
     if (now > deadline) {
-      comm_kill(cm, "a collective did not complete within " + std::to_string(cm->timeout_ms) + " ms (a peer rank is missing)");
+      comm_kill(cm, "a collective did not complete within " + std::to_string(tmo) + " ms (a peer rank is missing)");
       return comm_dead_rc(cm);
     }
     if (now - t0 > std::chrono::microseconds(200)) usleep(50); else std::this_thread::yield();
@@ -215,9 +238,14 @@ static int comm_wait(modsx_comm *cm, hipStream_t s) {
 
 // the transport: enqueue an all-gather of `bytes` per rank on stream s (this rank's turn is held by the caller)
 static int transport_all_gather(modsx_comm *cm, const void *send, void *recv, size_t bytes, hipStream_t s) {
-  if (cm->dead) return comm_dead_rc(cm);
-  if (cm->nccl) {
-    ncclResult_t r = g_rccl.AllGather(send, recv, bytes, ncclUint8, cm->nccl, s);
+  if (cm->dead.load()) return comm_dead_rc(cm);
+  if (!cm->loop) {     // the transport is chosen by what the communicator was created as, never by a handle that may change
+    ncclResult_t r;
+    {
+      std::lock_guard<std::mutex> lk(cm->issueMu);
+      if (cm->aborted || !cm->nccl) return comm_dead_rc(cm);
+      r = g_rccl.AllGather(send, recv, bytes, ncclUint8, cm->nccl, s);
+    }
     if (r != ncclSuccess) {
       set_error(std::string("ncclAllGather: ") + g_rccl.GetErrorString(r));
       comm_kill(cm, "ncclAllGather failed");
@@ -229,7 +257,7 @@ static int transport_all_gather(modsx_comm *cm, const void *send, void *recv, si
     LoopGroup::Slot &me = g.slots[R];
     me.send = send; me.recv = recv; me.bytes = bytes;
     MX_HIP(hipEventRecord(me.ready, s));
-    if (!g.barrier(cm->timeout_ms)) { comm_kill(cm, "loopback: a rank did not reach the collective"); return comm_dead_rc(cm); }
+    if (!g.barrier(cm->timeout_ms.load())) { comm_kill(cm, "loopback: a rank did not reach the collective"); return comm_dead_rc(cm); }
     for (int p = 0; p < W; p++)
       if (g.slots[p].bytes != bytes) { comm_kill(cm, "loopback: ranks disagree on the size of a collective"); return comm_dead_rc(cm); }
     for (int p = 0; p < W; p++) {
@@ -237,7 +265,7 @@ static int transport_all_gather(modsx_comm *cm, const void *send, void *recv, si
       if (bytes) MX_HIP(hipMemcpyAsync((char *)recv + (size_t)p * bytes, g.slots[p].send, bytes, hipMemcpyDeviceToDevice, s));
     }
     MX_HIP(hipEventRecord(me.done, s));
-    if (!g.barrier(cm->timeout_ms)) { comm_kill(cm, "loopback: a rank left the collective"); return comm_dead_rc(cm); }
+    if (!g.barrier(cm->timeout_ms.load())) { comm_kill(cm, "loopback: a rank left the collective"); return comm_dead_rc(cm); }
     for (int p = 0; p < W; p++) MX_HIP(hipStreamWaitEvent(s, g.slots[p].done, 0));   // my send buffer is free once every peer copied it
   }
   cm->bytes_gathered += (long)bytes * cm->world;
@@ -356,7 +384,7 @@ int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
                                   DevBuf *const *descAcc, const size_t *base, int *viewCounts) {
   regs.clear();
   const int nd = ds.n, ROW_B = row_bytes(nd);
-  if (cm->dead) return comm_dead_rc(cm);
+  if (cm->dead.load()) return comm_dead_rc(cm);
   if (nv < 1 || nv > SHARD_MAXV || cm->world > SHARD_MAXW) { set_error("sharded path: at most 1024 views and 64 ranks"); return MODSX_ERR_ARG; }
   hipStream_t s = c->stream;
   const int W = cm->world, R = cm->rank, lane = lane_of(c, cm);
@@ -469,7 +497,7 @@ int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
 int match_sharded(modsx_ctx *c, modsx_comm *cm, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2Host,
                   double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out) {
   out.clear();
-  if (cm->dead) return comm_dead_rc(cm);
+  if (cm->dead.load()) return comm_dead_rc(cm);
   if (n1 <= 0 || n2 <= 0) return MODSX_OK;   // the same on every rank: nobody issues a collective
   const int W = cm->world, R = cm->rank;
   const int per = (n1 + W - 1) / W;                 // rows per rank (the last ranks may hold fewer or none)
@@ -583,7 +611,8 @@ modsx_comm *modsx_comm_create(modsx_ctx *ctx, const void *id128, int rank, int w
   hipSetDevice(ctx->dev);
   std::unique_ptr<modsx_comm> cm(new modsx_comm());
   cm->rank = rank; cm->world = world; cm->dev = ctx->dev;
-  if (const char *e = getenv("MODSX_COMM_TIMEOUT_MS")) cm->timeout_ms = std::max(1, atoi(e));
+  if (const char *e = getenv("MODSX_COMM_TIMEOUT_MS")) cm->timeout_ms.store(std::max(1, atoi(e)));
+  cm->turn_timeout_ms.store(getenv("MODSX_COMM_TURN_TIMEOUT_MS") ? std::max(1, atoi(getenv("MODSX_COMM_TURN_TIMEOUT_MS"))) : 10 * cm->timeout_ms.load());
   if (!memcmp(id128, LOOP_MAGIC, 8)) {
     uint64_t key;
     memcpy(&key, (const char *)id128 + 8, 8);
@@ -591,12 +620,16 @@ modsx_comm *modsx_comm_create(modsx_ctx *ctx, const void *id128, int rank, int w
     auto it = g_loopGroups.find(key);
     if (it == g_loopGroups.end() || it->second->world != world) { mx::set_error("modsx_comm_create: unknown loopback group or wrong world size"); return nullptr; }
     cm->loop = it->second;
+    cm->loop->dev = ctx->dev;
     LoopGroup::Slot &sl = cm->loop->slots[rank];
-    if (sl.ready) { mx::set_error("modsx_comm_create: loopback rank already taken"); return nullptr; }
-    if (hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
-      mx::set_error("modsx_comm_create: hipEventCreate failed");
+    if (sl.taken) { mx::set_error("modsx_comm_create: loopback rank already taken"); return nullptr; }
+    if ((!sl.ready && hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming) != hipSuccess) ||
+        (!sl.done && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess)) {
+      mx::set_error("modsx_comm_create: hipEventCreate failed");     // the slot stays free; what was created is the group's
       return nullptr;
     }
+    if (comm_make_lanes(cm.get(), 1)) return nullptr;                 // before the slot is taken: a failure leaves it free
+    sl.taken = true;
     if (++cm->loop->joined == world) g_loopGroups.erase(it);   // complete: the id cannot be joined again
   } else {
     if (!rccl_load()) return nullptr;
@@ -606,7 +639,7 @@ modsx_comm *modsx_comm_create(modsx_ctx *ctx, const void *id128, int rank, int w
     if (r != ncclSuccess) { mx::set_error(std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); return nullptr; }
     g_rccl.GetVersion(&cm->version);
   }
-  if (comm_make_lanes(cm.get(), 1)) { if (cm->nccl) g_rccl.CommDestroy(cm->nccl); return nullptr; }
+  if (!cm->loop && comm_make_lanes(cm.get(), 1)) { if (cm->nccl) g_rccl.CommDestroy(cm->nccl); return nullptr; }
   ctx->shardLane = 0;
   return cm.release();
 }
@@ -648,20 +681,29 @@ int modsx_comm_reset_lanes(modsx_comm *cm) {
 
 int modsx_comm_set_timeout(modsx_comm *cm, int ms) {
   if (!cm || ms < 1) { mx::set_error("modsx_comm_set_timeout: bad argument"); return MODSX_ERR_ARG; }
-  cm->timeout_ms = ms;
+  cm->timeout_ms.store(ms);
+  // a lane may wait for its turn ten times as long as for a collective (a long host stage of the lane ahead is no hang);
+  // MODSX_COMM_TURN_TIMEOUT_MS overrides
+  cm->turn_timeout_ms.store(getenv("MODSX_COMM_TURN_TIMEOUT_MS") ? std::max(1, atoi(getenv("MODSX_COMM_TURN_TIMEOUT_MS"))) : (ms > 200000000 ? ms : 10 * ms));
   return MODSX_OK;
 }
 
 void modsx_comm_destroy(modsx_comm *cm) {
   if (!cm) return;
   hipSetDevice(cm->dev);
-  if (cm->nccl) { if (cm->dead) g_rccl.CommAbort(cm->nccl); else g_rccl.CommDestroy(cm->nccl); }
+  if (cm->nccl) {
+    std::lock_guard<std::mutex> lk(cm->issueMu);
+    if (cm->aborted) { /* ncclCommAbort already released the communicator */ }
+    else if (cm->dead.load()) g_rccl.CommAbort(cm->nccl);
+    else g_rccl.CommDestroy(cm->nccl);
+    cm->nccl = nullptr;
+  }
   if (cm->loop) {
-    LoopGroup::Slot &sl = cm->loop->slots[cm->rank];
+    // this rank's events stay with the group (peers may still be about to wait on them); the group's destructor releases them
+    // when the last rank drops its reference
     hipDeviceSynchronize();
-    if (sl.ready) hipEventDestroy(sl.ready);
-    if (sl.done) hipEventDestroy(sl.done);
-    sl.ready = sl.done = nullptr;
+    cm->loop->slots[cm->rank].taken = false;
+    cm->loop.reset();
   }
   for (ShardLane &L : cm->lanes) {
     DevBuf *bufs[] = {&L.blkLocal, &L.blkAll, &L.regsIn, &L.regsOut, &L.mLocal, &L.mAll, &L.rcDev, &L.order};
@@ -683,7 +725,7 @@ int modsx_comm_info(const modsx_comm *cm, int *rank, int *world, int *rccl_versi
 
 int modsx_comm_stats(const modsx_comm *cm, long *out, int n) {
   if (!cm || !out) { mx::set_error("modsx_comm_stats: null"); return MODSX_ERR_ARG; }
-  const long v[] = {cm->collectives, cm->bytes_gathered, cm->retries, cm->agreements, (long)cm->lanes.size(), cm->loop ? 1L : 0L, cm->dead ? 1L : 0L};
+  const long v[] = {cm->collectives, cm->bytes_gathered, cm->retries, cm->agreements, (long)cm->lanes.size(), cm->loop ? 1L : 0L, cm->dead.load() ? 1L : 0L};
   const int m = (int)(sizeof v / sizeof v[0]);
   for (int i = 0; i < n && i < m; i++) out[i] = v[i];
   return m;

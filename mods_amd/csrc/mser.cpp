@@ -420,7 +420,12 @@ class HostPool {
   int spinUs_ = 0;     // MODSX_HOST_SPIN_US: measured on a lone 31-view pair, 150 us of watching bought nothing in the median and cost outliers
   bool stop_ = false;
   HostPool() {
+    // default: the host's threads divided by the ranks that share it (torchrun / mpirun export the local world size: one
+    // process per GPU, 8 per node), capped by OMP_NUM_THREADS when the launcher set one; MODSX_HOST_THREADS overrides
     int n = (int)std::thread::hardware_concurrency();
+    for (const char *v : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MV2_COMM_WORLD_LOCAL_SIZE"})
+      if (const char *e = getenv(v)) { const int w = atoi(e); if (w > 1) { n = std::max(1, n / w); break; } }
+    if (const char *e = getenv("OMP_NUM_THREADS")) { const int o = atoi(e); if (o > 0) n = std::min(n, std::max(o, 4)); }
     if (const char *e = getenv("MODSX_HOST_THREADS")) n = atoi(e);
     if (const char *e = getenv("MODSX_HOST_SPIN_US")) spinUs_ = atoi(e);
     n = std::max(0, std::min(n, 64) - 1);

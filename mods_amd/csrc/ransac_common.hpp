@@ -404,16 +404,24 @@ static inline void cov_hgN_fused(double *Cv, const double *u, const int *inl, in
 static inline void u2h(const double *u, const int *inl, int len, double *H, double *buffer) {
   if (len < 4) return;
   if (len == 4) {
-    // Exact 4-point solution = null vector of the 8 x 9 system.  (The reference transposes its 8-row
-    // column-wise buffer as if it were 9 x 9 and thereby reads 9 uninitialised stack doubles,
-    // Htools.c:105-113; that cannot be reproduced, so the intended null space is computed.)
-    double C[72], M[81], V[81];
+    // The reference's 4-point branch (Htools.c:105-113) does NOT solve the 4-point problem: lin_hg fills its 9 x 9 buffer as
+    // an 8-row column-wise matrix (72 entries, stride 8), trnm transposes it as a 9 x 9 (stride 9), the last row is zeroed
+    // and the null space of THAT matrix becomes H; the nine entries lin_hg never wrote (Z2[72..80], which the transposition
+    // moves into the last column) are uninitialised stack.  The computation is repeated here operation for operation with
+    // those nine entries zero -- what the reference computes on a fresh stack.  The result is a homography unrelated to the
+    // sample either way (its last column is then zero: H = e8, every point maps to the origin), so an inner sample of four
+    // points -- a local optimisation that starts from 8 or 9 inliers -- never improves a model, in the reference as here.
+    // (Until round 4 the intended null space was solved instead: a better answer, but not the reference's -- 3.7 % of small
+    // pairs and 1 % of small epipolar problems then ended on another model.)
+    double Z2[81], V[81];
     int nb[18];
-    lin_hg(u, C, inl, len);
-    for (int r = 0; r < 8; r++) for (int c = 0; c < 9; c++) M[r * 9 + c] = C[c * 8 + r];
-    for (int i = 72; i < 81; ++i) M[i] = 0.0;
+    for (int i = 72; i < 81; ++i) Z2[i] = 0.0;   // the unwritten entries
+    lin_hg(u, Z2, inl, len);                      // column c of the 8-row matrix at Z2 + 8 c
+    for (int r = 0; r < 9; r++)                   // trnm(Z2, 9)
+      for (int c = r + 1; c < 9; c++) { const double t = Z2[r * 9 + c]; Z2[r * 9 + c] = Z2[c * 9 + r]; Z2[c * 9 + r] = t; }
+    for (int i = 72; i < 81; ++i) Z2[i] = 0.0;
     memset(V, 0, sizeof V);
-    nullspace(M, V, 9, nb);
+    nullspace(Z2, V, 9, nb);
     memcpy(H, V, 9 * sizeof(double));
     return;
   }

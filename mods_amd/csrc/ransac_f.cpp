@@ -14,6 +14,14 @@
 #include "engine_api.hpp"
 #include "ransac_common.hpp"
 
+// -DMODSX_TRACE_RANSAC: the trajectory of exp_ransacFcustom on stderr, in the format of the tracing build of the reference
+// (tools/trace_degensac.sh wraps the same call sites of exp_ranF.c through -D renames); for diffing the two, not shipped
+#ifdef MODSX_TRACE_RANSAC
+#include <cstdio>
+#define RTRACE(...) fprintf(stderr, __VA_ARGS__)
+#else
+#define RTRACE(...) ((void)0)
+#endif
 namespace mx {
 
 typedef void (*FdsFn)(const double *, const double *, double *, int);
@@ -213,20 +221,45 @@ static void lin_fmN(const double *u, double *p, const int *inl, int len, const d
       for (int l = 0; l < 3; l++) *p++ = a[l] * b[k];
   }
 }
-static inline double det3rows(const double *r0, const double *r1, const double *r2) {
-  return r0[0] * (r1[1] * r2[2] - r1[2] * r2[1]) - r0[1] * (r1[0] * r2[2] - r1[2] * r2[0]) +
-         r0[2] * (r1[0] * r2[1] - r1[1] * r2[0]);
+// slcm, Ftools.c:37-85: the cubic det(x A + (1 - x) B) = p0 x^3 + p1 x^2 + p2 x + p3; B leaves as A - B.
+// The roots feed the orientation test (all_ori_valid), a sign decision that is ill-conditioned whenever an epipolar line of the
+// sample is nearly horizontal: a relative 3e-13 in a root flipped it on a 31-tentative problem and sent the trajectory elsewhere.
+// The coefficients are therefore summed in the reference's term order -- the expansion it spells out, kept here as data: a term is
+// (+-c) x_i x_j [x_k] over x = (A row-wise, B row-wise), evaluated ((c x_i) x_j) x_k and added left to right; p1 and p2 end in
+// bracketed six-term sums times one more entry.  (An equivalent determinant form agreed to 1e-16 in the coefficients only.)
+struct CubicTerm { signed char c, i, j, k; };
+static inline double cubic_sum(const double *x, const CubicTerm *t, int n) {
+  double s = 0;
+  for (int q = 0; q < n; q++) {
+    const int c = t[q].c < 0 ? -t[q].c : t[q].c;
+    double v = c == 1 ? x[t[q].i] : (double)c * x[t[q].i];
+    v = v * x[t[q].j];
+    if (t[q].k >= 0) v = v * x[t[q].k];
+    if (q == 0) s = t[q].c < 0 ? -v : v;
+    else s = t[q].c < 0 ? s - v : s + v;
+  }
+  return s;
 }
-// slcm, Ftools.c:37-85: B becomes C = A - B and p holds the cubic det(C + x B) = p0 x^3 + p1 x^2 + p2 x + p3
-// (p0 = det B, p3 = det C, the mixed terms by multilinearity of the determinant in the rows)
 static void slcm(const double *A, double *B, double *p) {
-  double C[9];
-  for (int i = 0; i < 9; i++) C[i] = A[i] - B[i];
-  p[0] = det3rows(B, B + 3, B + 6);
-  p[1] = det3rows(C, B + 3, B + 6) + det3rows(B, C + 3, B + 6) + det3rows(B, B + 3, C + 6);
-  p[2] = det3rows(B, C + 3, C + 6) + det3rows(C, B + 3, C + 6) + det3rows(C, C + 3, B + 6);
-  p[3] = det3rows(C, C + 3, C + 6);
-  for (int i = 0; i < 9; i++) B[i] = C[i];
+  static const CubicTerm DETB[6] = {{-1, 11, 13, 15}, {1, 10, 14, 15}, {1, 11, 12, 16}, {-1, 9, 14, 16}, {-1, 10, 12, 17}, {1, 9, 13, 17}};
+  static const CubicTerm P1[18] = {{-1, 8, 10, 12}, {1, 7, 11, 12}, {1, 8, 9, 13}, {-1, 6, 11, 13}, {-1, 7, 9, 14}, {1, 6, 10, 14},
+                                   {1, 5, 10, 15}, {-1, 4, 11, 15}, {-1, 2, 13, 15}, {3, 11, 13, 15}, {1, 1, 14, 15}, {-3, 10, 14, 15},
+                                   {-1, 5, 9, 16}, {1, 3, 11, 16}, {1, 2, 12, 16}, {-3, 11, 12, 16}, {-1, 0, 14, 16}, {3, 9, 14, 16}};
+  static const CubicTerm P1G[6] = {{1, 4, 9, -1}, {-1, 3, 10, -1}, {-1, 1, 12, -1}, {3, 10, 12, -1}, {1, 0, 13, -1}, {-3, 9, 13, -1}};   // ... x B33
+  static const CubicTerm P2[24] = {{-1, 3, 8, 10}, {1, 3, 7, 11}, {1, 2, 7, 12}, {-1, 1, 8, 12}, {2, 8, 10, 12}, {-2, 7, 11, 12},
+                                   {-1, 2, 6, 13}, {1, 0, 8, 13}, {-2, 8, 9, 13}, {2, 6, 11, 13}, {1, 1, 6, 14}, {-1, 0, 7, 14},
+                                   {2, 7, 9, 14}, {-2, 6, 10, 14}, {2, 2, 13, 15}, {-3, 11, 13, 15}, {-2, 1, 14, 15}, {3, 10, 14, 15},
+                                   {1, 2, 3, 16}, {-2, 3, 11, 16}, {-2, 2, 12, 16}, {3, 11, 12, 16}, {2, 0, 14, 16}, {-3, 9, 14, 16}};
+  static const CubicTerm P2G1[6] = {{-1, 7, 9, -1}, {1, 6, 10, -1}, {1, 1, 15, -1}, {-2, 10, 15, -1}, {-1, 0, 16, -1}, {2, 9, 16, -1}};  // A23 x ...
+  static const CubicTerm P2G2[6] = {{-1, 1, 3, -1}, {2, 3, 10, -1}, {2, 1, 12, -1}, {-3, 10, 12, -1}, {-2, 0, 13, -1}, {3, 9, 13, -1}};   // ... x B33
+  static const CubicTerm P2G3[6] = {{1, 8, 9, -1}, {-1, 6, 11, -1}, {-1, 2, 15, -1}, {2, 11, 15, -1}, {1, 0, 17, -1}, {-2, 9, 17, -1}};   // A22 x ...
+  double x[18];
+  for (int i = 0; i < 9; i++) { x[i] = A[i]; x[9 + i] = B[i]; }
+  p[0] = cubic_sum(x, DETB, 6);
+  p[1] = cubic_sum(x, P1, 18) + cubic_sum(x, P1G, 6) * x[17];
+  p[2] = cubic_sum(x, P2, 24) + x[5] * cubic_sum(x, P2G1, 6) + cubic_sum(x, P2G2, 6) * x[17] + x[4] * cubic_sum(x, P2G3, 6);
+  for (int i = 0; i < 9; i++) { B[i] = A[i] - B[i]; x[9 + i] = B[i]; }
+  p[3] = cubic_sum(x, DETB, 6);
 }
 // rroots3, Ftools.c:216-261: real roots of po[0] x^3 + po[1] x^2 + po[2] x + po[3]
 static int rroots3(const double *po, double *r) {
@@ -441,6 +474,11 @@ static void dHDs(const double *H, const double *u, int len, double *Ds, std::vec
   HDs(lin.data(), u, H, Ds, len);
 }
 
+static inline Score tr_inlidxs(const double *err, int len, double th, int *inl) {   // inlidxs as called from exp_ranF.c
+  const Score s = inlidxs(err, len, th, inl);
+  RTRACE("S %u %.17g th %.3g\n", s.I, s.J, th);
+  return s;
+}
 struct RansacF {
   const double *u;
   int len;
@@ -784,15 +822,15 @@ struct RansacF {
       if (dc < 8) dc = 8;
       return dc;
     };
-    maxS = inlidxs(errs[4], len, th, inliers);
+    maxS = tr_inlidxs(errs[4], len, th, inliers);
     if (maxS.I < 8) return S;
-    S = inlidxs(errs[4], len, th * 2, inliers);
+    S = tr_inlidxs(errs[4], len, th * 2, inliers);
     unsigned dc = detached(S.I);
     if (dc >= S.I) u2f(u, inliers, (int)S.I, f, buffer.data());
     else u2f(u, randsubset(inliers, (int)S.I, (int)dc), (int)dc, f, buffer.data());
     for (int it = 0; it < iters; it++) {
       exfds(u, f, d, w.data(), len);
-      S = inlidxs(d, len, th, inliers);
+      S = tr_inlidxs(d, len, th, inliers);
       const uint32_t hash = super_fast_hash((const char *)inliers, (int)(S.I * sizeof(int)));
       const int ret = ht.contains(hash, (int)S.I, iterID);
       if (ret != -1 && ret != iterID) { S.I = 0; S.J = 0; return S; }
@@ -802,7 +840,7 @@ struct RansacF {
         errs[1] = errs[0]; errs[0] = d; d = errs[1];
         memcpy(F, f, sizeof f);
       }
-      Ss = inlidxs(d, len, ths * 2, inliers);
+      Ss = tr_inlidxs(d, len, ths * 2, inliers);
       if (Ss.I < 8) return maxS;
       dc = detached(Ss.I);
       if (dc >= Ss.I) u2fw(u, inliers, w.data(), (int)Ss.I, f, buffer.data());
@@ -810,7 +848,7 @@ struct RansacF {
       ths -= dth;
     }
     fds(u, f, d, len);
-    S = inlidxs(d, len, th, inliers);
+    S = tr_inlidxs(d, len, th, inliers);
     if (score_less(maxS, S)) {
       maxS = S;
       errs[1] = errs[0]; errs[0] = d;
@@ -879,6 +917,7 @@ int ransac_f(const double *u, int len, double th, double conf, int max_sam, doub
   auto degenerate_update = [&](unsigned I, double *fcur, double *derr_alt, int &new_max) {
     if (I > 6) {
       I = R.rFtH(inl, th, H, fcur);
+      RTRACE("rFtH %u F0 %.17g\n", I, fcur[0]);
       if (I > maxS.I) {
         R.fds(u, fcur, errs[3], len);
         maxS.I = I;
@@ -898,10 +937,10 @@ int ransac_f(const double *u, int len, double th, double conf, int max_sam, doub
   auto lsq_and_lo = [&](const double *base, int *sidx) {  // __LSQ_BEFORE_LO__ + exp_inFranicustom
     (void)sidx;
     d = errs[0];
-    S = inlidxs(base, len, 4 * th * 2, inliers.data());
+    S = tr_inlidxs(base, len, 4 * th * 2, inliers.data());
     u2f(u, inliers.data(), (int)S.I, f, R.buffer.data());
     R.fds(u, f, d, len);
-    S = inlidxs(d, len, th, inliers.data());
+    S = tr_inlidxs(d, len, th, inliers.data());
     S = R.inFrani(inliers.data(), (int)S.I, th, errs, f, &iterID, inlLimit);
   };
 
@@ -920,16 +959,18 @@ int ransac_f(const double *u, int len, double th, double conf, int max_sam, doub
     for (int i = 63; i < 81; ++i) A[i] = 0.0;
     memset(sol, 0, sizeof sol);
     const int nullsize = nullspace(A, f1, 9, nb);
+    RTRACE("null %d\n", nullsize);
     if (nullsize != 2) { last_i = 3; continue; }
     slcm(f1, f2, poly);
     const int nsol = rroots3(poly, roots);
+    RTRACE("roots %d %.17g\n", nsol, nsol ? roots[0] : 0.0);
     int new_max = 0, do_iterate = 0, LmaxI = 0, i;
     for (i = 0; i < nsol; i++) {
       for (int j = 0; j < 9; j++) f[j] = f1[j] * roots[i] + f2[j] * (1 - roots[i]);
-      if (!all_ori_valid(f, u, samidx, 7)) continue;
+      { const int ov = all_ori_valid(f, u, samidx, 7); RTRACE("ori %d\n", ov); if (!ov) continue; }
       d = errs[i];
       R.fds(u, f, d, len);
-      S = inlidxs(d, len, th, inliers.data());
+      S = tr_inlidxs(d, len, th, inliers.data());
       if ((int)S.I > LmaxI) LmaxI = (int)S.I;
       if (score_less(maxS, S)) {
         if (doSymCheck) {
@@ -950,12 +991,15 @@ int ransac_f(const double *u, int len, double th, double conf, int max_sam, doub
       }
       if (score_less(maxSs, S)) {
         maxSs = S;
-        if (R.checksample(f, u7, 3 * th, H)) {
+        const int cs = R.checksample(f, u7, 3 * th, H);
+        RTRACE("cs %d H0 %.17g\n", cs, H[0]);
+        if (cs) {
           dHDs(H, u, len, HDsv.data(), R.lin);
           unsigned I = 0;
           for (int j = 0; j < len; ++j) if (HDsv[j] < th * 3) ++I;
           if (I < 8) break;
           I = R.innerH(H, 16 * th, 10, inl);
+          RTRACE("innerH %u H0 %.17g\n", I, H[0]);
           degenerate_update(I, f, errs[i], new_max);
         } else {
           do_iterate = (do_lo > 0 && (no_sam > 50));
@@ -981,17 +1025,20 @@ int ransac_f(const double *u, int len, double th, double conf, int max_sam, doub
     }
     if (new_max) {
       const int new_sam = nsamples((int)maxS.I + 1, len, 7, conf);
+      RTRACE("nsamples %d %d -> %d\n", (int)maxS.I + 1, len, new_sam);
       if (new_sam < max_sam) max_sam = new_sam;
     }
   }
 
   if (do_lo && (!iter_cnt && !degen_cnt) && non_degen) {
     for (int i = 0; i < 7; i++) memcpy(u7 + 6 * i, u + 6 * samidxBest[i], 6 * sizeof(double));
-    if (R.checksample(FBest, u7, 3 * th, H)) {
+    const int csA = R.checksample(FBest, u7, 3 * th, H);
+    RTRACE("cs %d H0 %.17g\n", csA, H[0]);
+    if (csA) {
       dHDs(H, u, len, HDsv.data(), R.lin);
       unsigned I = 0;
       for (int j = 0; j < len; ++j) if (HDsv[j] < th * 3) ++I;
-      if (I >= 8) I = R.innerH(H, 16 * th, 10, inl);
+      if (I >= 8) { I = R.innerH(H, 16 * th, 10, inl); RTRACE("innerH %u H0 %.17g\n", I, H[0]); }
       int new_max = 0;
       degenerate_update(I, f, errs[last_i < 3 ? last_i : 3], new_max);
     } else {

@@ -1,3 +1,5 @@
+import os as _os
+_os.environ.setdefault("MODSX_MALLOC_TUNE", "1")   # modsx.h: opt-in allocator tuning
 import sys, time, numpy as np
 sys.path.insert(0, '.')
 import mods_amd

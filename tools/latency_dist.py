@@ -1,4 +1,6 @@
 """One 31-view pair repeated: the distribution of its wall time (single context, idle GPU)."""
+import os as _os
+_os.environ.setdefault("MODSX_MALLOC_TUNE", "1")   # modsx.h: opt-in allocator tuning
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np

@@ -1,4 +1,6 @@
 """One 31-view pair, repeated: for kernel-trace timelines of the single-pair (reference CLI) use."""
+import os as _os
+_os.environ.setdefault("MODSX_MALLOC_TUNE", "1")   # modsx.h: opt-in allocator tuning
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import mods_amd
