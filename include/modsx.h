@@ -235,6 +235,11 @@ int modsx_detect_orientation(modsx_ctx *ctx, const modsx_image *img, const modsx
 /* int ReprojectRegions(AffineRegionList &keypoints, double *H, int orig_w, int orig_h)
  * synth-detection.cpp:541-616; filters in place, returns the new count (host math) */
 int modsx_reproject_regions(modsx_region *regs, int n, const double *H, int orig_w, int orig_h);
+/* int ReprojectRegionsAndRemoveTouchBoundary(AffineRegionList &keypoints, double *H, int orig_w, int orig_h,
+ *                                            const double mrSize = 3.0*sqrt(3.0))        synth-detection.cpp:63-102, .hpp:68
+ * The same with the box mrSize * s instead of k_sigma * s: the un-oriented "None" list SynthDetectDescribeKeypoints keeps
+ * beside the described ones (imagerepresentation.cpp:1271-1272; what SaveRegions writes for regions without descriptors). */
+int modsx_reproject_regions_touch_boundary(modsx_region *regs, int n, const double *H, int orig_w, int orig_h, double mrSize);
 
 /* template DescribeRegions<SIFTDescriptor>(AffineRegionList&, SynthImage&, FuncType, double mrSize,
  *            int patchSize, bool fast_extraction, bool photoNorm)     synth-detection.hpp:169-255
@@ -469,8 +474,10 @@ int modsx_match_pair_views_sharded(modsx_ctx *ctx, modsx_comm *comm, const modsx
                                    modsx_pair_result *res);
 /* modsx_match_ladder over the ranks (configs[3]: the iteration ladder with every step's views sharded): each step's
  * regions are exchanged and appended to the accumulated lists on every rank, the match is sharded by query row, and every
- * rank runs DuplicateFiltering + LO-RANSAC on the same tentatives with the same seed, so all ranks take the min_matches
- * exit at the same step without a collective.  Results are identical on every rank and equal to modsx_match_ladder's. */
+ * rank runs DuplicateFiltering + LO-RANSAC on the same tentatives with the same seed; the verified count that decides the
+ * min_matches exit is all-gathered (4 bytes per rank and step) and the call fails on every rank (MODSX_ERR_INTERNAL) should
+ * the ranks ever disagree, so no rank can leave the loop alone.  Results are identical on every rank and equal to
+ * modsx_match_ladder's. */
 int modsx_match_ladder_sharded(modsx_ctx *ctx, modsx_comm *comm, const modsx_image *img1, const modsx_image *img2,
                                const modsx_ladder_step *steps, int nsteps, int min_matches, const modsx_pair_params *par,
                                modsx_pair_result *res, int *steps_done);

@@ -88,7 +88,7 @@ EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "m
            "modsx_default_hessaff_params", "modsx_default_pair_params", "modsx_image_upload",
            "modsx_image_wrap_device", "modsx_image_free", "modsx_image_download", "modsx_detect_affine_keypoints",
            "modsx_detect_scalespace", "modsx_octave_levels", "modsx_gaussian_blur", "modsx_resize_half", "modsx_response",
-           "modsx_detect_affine_regions", "modsx_detect_orientation", "modsx_reproject_regions",
+           "modsx_detect_affine_regions", "modsx_detect_orientation", "modsx_reproject_regions", "modsx_reproject_regions_touch_boundary",
            "modsx_describe_regions", "modsx_match_fginn", "modsx_duplicate_filtering", "modsx_ransac_h",
            "modsx_loransac_h", "modsx_ransac_h_errtype", "modsx_loransac_h_errtype", "modsx_ransac_f", "modsx_loransac_f", "modsx_match_pair", "modsx_match_pairs", "modsx_match_pairs_views", "modsx_pair_result_release",
            "modsx_set_vs_pars", "modsx_synth_view", "modsx_detect_describe_views", "modsx_match_fginn_device",
@@ -238,6 +238,14 @@ def reproject_regions(regs, H, w, h):
     regs = np.ascontiguousarray(regs, REGION).copy()
     H = np.ascontiguousarray(H, np.float64).reshape(9)
     n = _check(lib().modsx_reproject_regions(_p(regs), len(regs), _p(H), int(w), int(h)), "reproject_regions")
+    return regs[:n].copy()
+
+
+def reproject_regions_touch_boundary(regs, H, w, h, mr_size=3.0 * 3.0 ** 0.5):
+    regs = np.ascontiguousarray(regs, REGION).copy()
+    H = np.ascontiguousarray(H, np.float64).reshape(9)
+    n = _check(lib().modsx_reproject_regions_touch_boundary(_p(regs), len(regs), _p(H), int(w), int(h), C.c_double(mr_size)),
+               "reproject_regions_touch_boundary")
     return regs[:n].copy()
 
 

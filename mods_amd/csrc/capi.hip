@@ -323,6 +323,11 @@ int modsx_reproject_regions(modsx_region *regs, int n, const double *H, int orig
   return reproject_regions(regs, n, H, orig_w, orig_h);
 }
 
+int modsx_reproject_regions_touch_boundary(modsx_region *regs, int n, const double *H, int orig_w, int orig_h, double mrSize) {
+  if (n < 0 || (n > 0 && !regs) || !H) { mx::set_error("modsx_reproject_regions_touch_boundary: bad argument"); return MODSX_ERR_ARG; }
+  return reproject_regions_box(regs, n, H, orig_w, orig_h, mrSize);
+}
+
 int modsx_describe_regions(modsx_ctx *ctx, const modsx_image *img, const modsx_region *regs, int n, double mrSize,
                            int patchSize, int fast_extraction, int photoNorm, int desc_type, double maxBinValue,
                            float *desc) {

@@ -830,8 +830,12 @@ int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n
   return MODSX_OK;
 }
 
-// ReprojectRegions, synth-detection.cpp:541-616
+// ReprojectRegions, synth-detection.cpp:541-616 (box = k_sigma * s), and ReprojectRegionsAndRemoveTouchBoundary, :63-102
+// (box = mrSize * s, default 3 sqrt 3: the "None" list of imagerepresentation.cpp:1271-1272)
 int reproject_regions(modsx_region *regs, int n, const double *H, int orig_w, int orig_h) {
+  return reproject_regions_box(regs, n, H, orig_w, orig_h, K_SIGMA);
+}
+int reproject_regions_box(modsx_region *regs, int n, const double *H, int orig_w, int orig_h, double boxk) {
   double eyeTest = fabs(H[0] - 1.0) + fabs(H[1]) + fabs(H[2]) + fabs(H[3]) + fabs(H[4] - 1.0) + fabs(H[5]) + fabs(H[6]) +
                    fabs(H[7]) + fabs(H[8] - 1.0);
   double Hi[9];
@@ -854,7 +858,7 @@ int reproject_regions(modsx_region *regs, int n, const double *H, int orig_w, in
     const modsx_keypoint &k = regs[i].reproj_kp;
     if ((k.x < orig_w) && (k.y < orig_h) && (k.x > 0) && (k.y > 0)) {
       if (!check_borders_host(orig_w, orig_h, (float)k.x, (float)k.y, (float)k.a11, (float)k.a12, (float)k.a21,
-                              (float)k.a22, (int)(K_SIGMA * k.s), (int)(K_SIGMA * k.s)))
+                              (float)k.a22, (int)(boxk * k.s), (int)(boxk * k.s)))
         regs[m++] = regs[i];
     }
   }

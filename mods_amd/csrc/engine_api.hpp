@@ -24,6 +24,7 @@ int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n
                              double mrSize, int patchSize, int doHalfSIFT, int maxAngNum, double th, int addUpRight,
                              std::vector<modsx_region> *out);
 int reproject_regions(modsx_region *regs, int n, const double *H, int orig_w, int orig_h);
+int reproject_regions_box(modsx_region *regs, int n, const double *H, int orig_w, int orig_h, double boxk);
 // The descriptor classes one step carries (modsx_pair_params / modsx_ladder_step n_desc, desc_types, desc_ratios resolved):
 // `Descriptors=` and `FGINNThreshold=` of a [DetectorN] section.  half(): the step orients with doHalfSIFT = true
 // (imagerepresentation.cpp:693-706, 1259-1264).
@@ -75,6 +76,7 @@ int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
                                   const modsx_pair_params &pp, const DescSet &ds, std::vector<modsx_region> &regs,
                                   DevBuf *const *descAcc, const size_t *base, int *viewCounts);
 int comm_rank(const modsx_comm *cm);
+int comm_same_value(modsx_ctx *c, modsx_comm *cm, int value, const char *what);   // one 4-byte all-gather; an error on every rank when they differ
 int match_sharded(modsx_ctx *c, modsx_comm *cm, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2Host,
                   double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out);
 int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,

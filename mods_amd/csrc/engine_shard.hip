@@ -300,6 +300,30 @@ static int comm_agree(modsx_comm *cm, int lane, hipStream_t s, int local_rc) {
   return MODSX_OK;
 }
 
+// every rank contributes a value it must share with the others (the verified count that decides a ladder's early exit):
+// MODSX_OK when all ranks hold the same one, MODSX_ERR_INTERNAL -- on EVERY rank, from the same gathered data -- otherwise
+int comm_same_value(modsx_ctx *c, modsx_comm *cm, int value, const char *what) {
+  const int lane = c->shardLane >= 0 && c->shardLane < (int)cm->lanes.size() ? c->shardLane : 0;
+  ShardLane &L = cm->lanes[lane];
+  hipStream_t s = c->stream;
+  int *h = (int *)L.hRc.p, *d = (int *)L.rcDev.p;
+  h[0] = value;
+  MX_HIP(hipMemcpyAsync(d, h, 4, hipMemcpyHostToDevice, s));
+  int rc = ordered_all_gather(cm, lane, d, d + 16, 4, s);
+  if (rc) return rc;
+  MX_HIP(hipMemcpyAsync(h + 16, d + 16, (size_t)cm->world * 4, hipMemcpyDeviceToHost, s));
+  rc = comm_wait(cm, s);
+  if (rc) return rc;
+  cm->agreements++;
+  for (int r = 0; r < cm->world; r++)
+    if (h[16 + r] != h[16]) {
+      set_error(std::string("ranks disagree on ") + what + " (rank 0: " + std::to_string(h[16]) + ", rank " + std::to_string(r) + ": " +
+                std::to_string(h[16 + r]) + "): the hosts of the ranks do not compute the verification alike");
+      return MODSX_ERR_INTERNAL;
+    }
+  return MODSX_OK;
+}
+
 // block = header + rows; rows[i] = region i (REG_B bytes, 8-byte words) followed by its 128 descriptor bytes
 __global__ void k_pack_rows(const unsigned char *regs, DescPtrs desc, int nd, int n, unsigned char *rows) {
   const int i = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;

@@ -780,6 +780,13 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
     res->n_tentatives = (int)tents.size();
     if (!cm || owner < 0 || owner == comm_rank(cm)) verify_tentatives(l1, l2, tents, pp, res);
     cur = res->n_verified;
+    if (cm && owner < 0 && nsteps > 1) {
+      // the exit of a sharded ladder is AGREED, not assumed: one 4-byte all-gather of the verified count per step.  The ranks
+      // of a node share one host, so they compute the same count; a rank that did not (another CPU, another libm) would
+      // otherwise leave the loop at another step and hang the rest in the next exchange
+      const int ra = comm_same_value(c, cm, cur, "the verified count of a ladder step");
+      if (ra) { release_result_arrays(res); return ra; }
+    }
     if (timL) fprintf(stderr, "ladder step %d: views %.2f match %.2f lists %.2f verify %.2f ms\n", step, tL1 - tL0, tL2 - tL1, tL3 - tL2, tnowL() - tL3);
   }
   if (steps_done) *steps_done = step;

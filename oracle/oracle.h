@@ -122,6 +122,7 @@ int orc_detect_orientation(const float *img, int rows, int cols, const orc_regio
 int orc_dominant_angles(const float *patch, int patchSize, int doHalfSIFT, double th, int maxAngles,
                         float *angles, int cap);
 int orc_reproject_regions(orc_region *regs, int n, const double *H, int orig_w, int orig_h);
+int orc_reproject_regions_touch_boundary(orc_region *regs, int n, const double *H, int orig_w, int orig_h, double mrSize);
 /* descriptor: type 0 SIFT, 1 RootSIFT; desc is n*128 floats holding integers 0..255 */
 void orc_describe_regions(const float *img, int rows, int cols, const orc_region *regs, int n,
                           double mrSize, int patchSize, int fast, int photoNorm, int rootsift,

@@ -303,7 +303,16 @@ int orc_detect_orientation(const float *img_, int rows, int cols, const orc_regi
 
 /* ReprojectRegions, synth-detection.cpp:541-616.  H is original->view; the
    inverse is cv::invert(DECOMP_LU) == closed-form 3x3 adjugate. */
+static int reproject_regions_k(orc_region *regs, int n, const double *H, int orig_w, int orig_h, double boxk);
 int orc_reproject_regions(orc_region *regs, int n, const double *H, int orig_w, int orig_h) {
+  return reproject_regions_k(regs, n, H, orig_w, orig_h, K_SIGMA);
+}
+/* ReprojectRegionsAndRemoveTouchBoundary, synth-detection.cpp:63-102: the same with the box mrSize * s (default
+   3 sqrt 3 = k_sigma / 2, synth-detection.hpp:68) -- the "None" list of imagerepresentation.cpp:1271-1272 */
+int orc_reproject_regions_touch_boundary(orc_region *regs, int n, const double *H, int orig_w, int orig_h, double mrSize) {
+  return reproject_regions_k(regs, n, H, orig_w, orig_h, mrSize);
+}
+static int reproject_regions_k(orc_region *regs, int n, const double *H, int orig_w, int orig_h, double boxk) {
   double eyeTest = fabs(H[0] - 1.0) + fabs(H[1]) + fabs(H[2]) + fabs(H[3]) + fabs(H[4] - 1.0) + fabs(H[5]) +
                    fabs(H[6]) + fabs(H[7]) + fabs(H[8] - 1.0);
   double Hi[9];
@@ -334,8 +343,8 @@ int orc_reproject_regions(orc_region *regs, int n, const double *H, int orig_w, 
   for (int i = 0; i < n; i++) {
     const orc_keypoint &k = regs[i].reproj_kp;
     if ((k.x < orig_w) && (k.y < orig_h) && (k.x > 0) && (k.y > 0)) {
-      if (!interpolate_check_borders(orig_w, orig_h, k.x, k.y, k.a11, k.a12, k.a21, k.a22, (int)(K_SIGMA * k.s),
-                                     (int)(K_SIGMA * k.s)))
+      if (!interpolate_check_borders(orig_w, orig_h, k.x, k.y, k.a11, k.a12, k.a21, k.a22, (int)(boxk * k.s),
+                                     (int)(boxk * k.s)))
         regs[m++] = regs[i];
     }
   }

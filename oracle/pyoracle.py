@@ -208,6 +208,13 @@ def reproject_regions(regs, H, w, h):
     return regs[:n].copy()
 
 
+def reproject_regions_touch_boundary(regs, H, w, h, mr_size=3.0 * 3.0 ** 0.5):
+    regs = np.ascontiguousarray(regs, REGION).copy()
+    H = np.ascontiguousarray(H, np.float64).reshape(9)
+    n = lib().orc_reproject_regions_touch_boundary(_p(regs), len(regs), _p(H), w, h, C.c_double(mr_size))
+    return regs[:n].copy()
+
+
 def describe_regions(img, regs, mr_size=5.1962, patch_size=41, fast=0, photo_norm=1, rootsift=1, max_bin=0.2):
     img = _f32(img)
     regs = np.ascontiguousarray(regs, REGION)

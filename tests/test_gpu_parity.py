@@ -333,6 +333,68 @@ def test_cat_pair_golden_counts(ctx, modsx, cat_pair):
     i1.free(); i2.free()
 
 
+def test_cat_pair_every_stage_field_by_field(ctx, modsx, oracle, cat_pair):
+    """configs[0] on the one input whose grey values are not integers: cat.png / cat2.png are colour images, (B + G + R) / 3
+    leaves thirds (synth-detection.cpp:256-262), so every f32 rounding of the blur, the sampling and the Hessian actually
+    bites here (the synthetic images are floor'ed).  Every stage against the oracle, field by field: scale-space keypoints,
+    affine keypoints (FixedTh 255 / 414 and NotLessThanRegions 2000 / 2000), oriented regions, RootSIFT descriptors, the
+    tentatives of the pair; then the 11-view HessianAffine step of iters_mods_cviu.ini:56-62 (regions + descriptors of every
+    view of both images) and the pair through it."""
+    cat, cat2, _ = cat_pair
+    feats = []
+    for bgr in (cat, cat2):
+        g = oracle.gray_from_bgr(bgr)
+        assert np.abs(g * 3 - np.round(g * 3)).max() < 1e-3 and (np.abs(g - np.round(g)) > 0.2).any()      # thirds, not integers
+        im = ctx.upload(bgr)
+        ss_ref = oracle.detect_scalespace(g, oracle.default_params())
+        ss_got = ctx.detect_scalespace(im, modsx.default_hessaff_params())
+        assert len(ss_ref) > 200 and same_records(ss_got, ss_ref.view(modsx.SSKP))
+        for mode, n in ((0, None), (4, 2000)):
+            k_ref = oracle.detect_hessaff(g, oracle.default_params(mode=mode))
+            k_got = ctx.detect_affine_keypoints(im, modsx.default_hessaff_params(mode=mode))
+            assert same_records(k_got, k_ref.view(modsx.KEYPOINT)) and (n is None or len(k_ref) == n)
+        r = oracle.detect_affine_regions(k_ref)                       # the 2000 strongest
+        for mr, max_ang, half in ((1.0, 1, 0), (5.1962, 5, 1)):
+            ro = oracle.detect_orientation(g, r, mr_size=mr, max_ang=max_ang, half=half)
+            go = ctx.detect_orientation(im, r.view(modsx.REGION), mr_size=mr, max_ang=max_ang, half=half)
+            assert len(ro) > 1500 and same_records(go, ro.view(modsx.REGION))
+        ro = oracle.detect_orientation(g, r)
+        rr = oracle.reproject_regions(ro, np.eye(3), g.shape[1], g.shape[0])
+        for t in (1, 3):
+            d_ref = oracle.describe_regions(g, rr, rootsift=t)
+            d_got = ctx.describe_regions(im, rr.view(modsx.REGION), desc_type=t)
+            assert np.array_equal(d_got, d_ref), (t, int((d_got != d_ref).any(1).sum()))
+        feats.append((g, im, rr, oracle.describe_regions(g, rr)))
+    (g1, i1, r1, d1), (g2, i2, r2, d2) = feats
+    pos2 = np.stack([r2["reproj_kp"]["x"], r2["reproj_kp"]["y"]], 1)
+    _check_tents(ctx.match_fginn(d1, d2, pos2, 0.8, 30.0), oracle.match_fginn(d1, d2, pos2, 0.8, 30.0))
+    # the 11 views of [HessianAffine4]: TiltSet 1,2,4,6,8, Phi 360, initSigma 0.2
+    vo = oracle.set_vs_pars([1.0], [1, 2, 4, 6, 8], 360.0, 0.2, 1, [])
+    vm = modsx.set_vs_pars([1.0], [1, 2, 4, 6, 8], 360.0, 0.2, 1, [])
+    par = modsx.default_pair_params(ransac_seed=3)
+    import os
+    acc = []
+    for g, im in ((g1, i1), (g2, i2)):
+        r_ref, d_ref = oracle.detect_describe_views(g, vo, threads=min(16, os.cpu_count() or 1))
+        r_got, d_got = ctx.detect_describe_views(im, vm, par)
+        assert len(r_ref) > 1000 and same_records(r_got, r_ref.view(modsx.REGION)) and np.array_equal(d_got, d_ref)
+        acc.append((r_ref, d_ref))
+    (r1, d1), (r2, d2) = acc
+    pos2 = np.stack([r2["reproj_kp"]["x"], r2["reproj_kp"]["y"]], 1)
+    tent = oracle.match_fginn(d1, d2, pos2, 0.8, 30.0)
+    pts = np.stack([r1["reproj_kp"]["x"][tent["q"]], r1["reproj_kp"]["y"][tent["q"]],
+                    r2["reproj_kp"]["x"][tent["t0"]], r2["reproj_kp"]["y"][tent["t0"]]], 1)
+    order, keep = oracle.duplicate_filtering(pts, tent["ratio"], 2.0, True)
+    got = ctx.match_pair_views(i1, i2, vm, par)
+    assert got["n_tentatives"] == len(tent)
+    _check_tents(got["tentatives"], tent[order[keep]])
+    if oracle.ref_available():
+        tu, pu = tent[order[keep]], pts[order[keep]]
+        rr = oracle.loransac_h(pu, laf_of(r1, tu["q"]), laf_of(r2, tu["t0"]), seed=3)
+        assert np.array_equal(got["ransac_inlier"], rr["inl"]) and np.array_equal(got["verified"], rr["keep"])
+    i1.free(); i2.free()
+
+
 def test_full_size_pair_properties(ctx, modsx, oracle):
     """BASELINE config 1: one 1024x768 synthetic pair, 1 view.  Checked through size-independent properties
     plus a full oracle comparison of the (cheap) detection stage."""

@@ -267,11 +267,13 @@ def _cviu_ladder(oracle, modsx):
     return steps_o, steps_m
 
 
-def test_configs3_full_cviu_ladder_all_steps_matches_oracle(ctx, modsx, oracle):
+@pytest.mark.parametrize("ori_mr", [1.0, 5.1962])
+def test_configs3_full_cviu_ladder_all_steps_matches_oracle(ctx, modsx, oracle, ori_mr):
     """configs[3] in its stated form on one GPU: the 1024x768 synthetic pair through ALL MSER and HessianAffine steps of
     iters_mods_cviu.ini (minMatches forced high): 27 MSER views and 61 HessianAffine views per image accumulate, every step
     re-matches its class; region counts, every tentative, the RANSAC inlier set, the verified set and H == the CPU oracle's
-    loop (whose views run on a thread pool, as the reference's OpenMP loop does)."""
+    loop (whose views run on a thread pool, as the reference's OpenMP loop does).  ori_mr 1.0 is [DominantOrientation] mrSize of
+    config_iter_mods_cviu.ini:103 (the configuration the ladder ships with); 5.1962 is the WxBS file's value on the same ladder."""
     import os
     from mods_amd import synthetic
     if not oracle.ref_available():
@@ -279,13 +281,13 @@ def test_configs3_full_cviu_ladder_all_steps_matches_oracle(ctx, modsx, oracle):
     a, b, _ = synthetic.make_pair(rows=768, cols=1024, nblobs=4000, seed=12345)
     steps_o, steps_m = _cviu_ladder(oracle, modsx)
     assert [len(v) for v, _, _ in steps_m] == [3, 24, 11, 20, 30]        # 27 MSER views, 61 HessianAffine views
-    par = modsx.default_pair_params(ransac_seed=3, ori_mrSize=5.1962)
+    par = modsx.default_pair_params(ransac_seed=3, ori_mrSize=ori_mr)
     ia, ib = ctx.upload(a), ctx.upload(b)
     got, done = ctx.match_ladder(ia, ib, steps_m, par, min_matches=10 ** 6)
     ia.free(); ib.free()
-    ref, done_ref = _oracle_ladder(oracle, a, b, steps_o, 10 ** 6, 3, ori_mr=5.1962, threads=min(64, os.cpu_count() or 1))
+    ref, done_ref = _oracle_ladder(oracle, a, b, steps_o, 10 ** 6, 3, ori_mr=ori_mr, threads=min(64, os.cpu_count() or 1))
     assert done == done_ref == 5
-    assert got["n_regions"] == ref["n_regions"] and got["n_regions"][0] > 50000
+    assert got["n_regions"] == ref["n_regions"] and got["n_regions"][0] > 40000
     assert got["n_tentatives"] == ref["n_tentatives"] and len(ref["tent"]) > 5000
     for f in ref["tent"].dtype.names:
         assert np.array_equal(got["tentatives"][f], ref["tent"][f]), f

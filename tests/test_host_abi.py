@@ -79,6 +79,12 @@ def test_affine_regions_and_reproject_match_oracle(modsx, oracle):
         b = modsx.reproject_regions(rm, H, 1024, 768)
         assert same_records(a, b)
         assert 0 < len(a) < n
+        # ReprojectRegionsAndRemoveTouchBoundary (synth-detection.cpp:63-102): the "None" list, box mrSize * s (half of k_sigma)
+        for mr in (3.0 * 3.0 ** 0.5, 2.0, 9.0):
+            at = oracle.reproject_regions_touch_boundary(ro, H, 1024, 768, mr)
+            bt = modsx.reproject_regions_touch_boundary(rm, H, 1024, 768, mr)
+            assert same_records(at, bt) and 0 < len(at) < n
+        assert len(oracle.reproject_regions_touch_boundary(ro, H, 1024, 768)) > len(a)      # a smaller box keeps more regions
 
 
 def test_duplicate_filtering_matches_oracle(modsx, oracle):
