@@ -498,10 +498,12 @@ def main():
             for _ in range(REP):
                 r0 = ctx.match_pair_views(imgs1[0], imgs2[0], views, params)
             ctx.synchronize()
-            m = ctx.kernel_stats().get("match_fginn")
+            ks = ctx.kernel_stats()
+            m, m1 = ks.get("match_fginn"), ks.get("match_sweep1")
             ctx.profile(False)
             if m and m["launches"]:
-                mroof = (m["ms"] / m["launches"], r0["n_regions"][0], r0["n_regions"][1], m["launches"])
+                mroof = (m["ms"] / m["launches"], r0["n_regions"][0], r0["n_regions"][1], m["launches"],
+                         m1["ms"] / m1["launches"] if m1 and m1["launches"] else None)
 
     if rank == 0:
         pairs = args.steps * (nbatch if group is not None else world * nbatch)
@@ -537,10 +539,10 @@ def main():
             out["kernels_single_stream_ms_per_pair"] = per
             if mroof is None and iso.get("match_fginn", {}).get("launches"):
                 m = iso["match_fginn"]      # configs[1] / [4]: launch sets of 4 small problems; per launch set
-                mroof = (m["ms"] / m["launches"], None, None, m["launches"])
+                mroof = (m["ms"] / m["launches"], None, None, m["launches"], None)
                 flops = m["work"] / m["launches"]
             if mroof is not None:
-                ms, n1, n2, nl = mroof
+                ms, n1, n2, nl, ms1 = mroof
                 if n1 is not None:
                     flops = 2.0 * n1 * n2 * 128
                 tf = flops / (ms * 1e-3) / 1e12
@@ -558,8 +560,18 @@ def main():
                     byts = (n1 + n2) * 128.0 + n1 * 32.0
                     out["roofline"]["hbm_view"] = {"compulsory_bytes": byts, "achieved_GBs": byts / (ms * 1e-3) / 1e9,
                                                    "frac_of_8TBs": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                if ms1:
+                    tf1 = flops / (ms1 * 1e-3) / 1e12
+                    out["roofline_sweep1"] = {
+                        "kernel": "k_match_sweep1 alone: the one launch that carries the 2*N*M*128 contraction of the problem above "
+                                  "(sweep 2 repeats part of it for the undecided queries; pack / decide / events issue no MFMA)",
+                        "bound": "mfma", "achieved": tf1, "peak": INT8_PEAK_TOPS, "unit": "TFLOP/s", "frac": tf1 / INT8_PEAK_TOPS,
+                        "avg_launch_ms": ms1, "algorithmic_work_per_launch": flops, "traffic": None,
+                        "measured_ceilings_TOPs": {"mfma_only_descriptor_like_operands": 3800.0, "with_the_top2_reduction_VALU": 3000.0,
+                                                   "source": "profiles/r03_ubench_mfma.txt (tools/ubench/mfma_chain_sift, mfma_lds)"},
+                        "note": "HIP events on the launch stream around k_match_sweep1 of the same %d repetitions" % nl}
             tfile, tsrc = None, None
-            for tag in ("r03", "r02"):
+            for tag in ("r04", "r03", "r02"):
                 cand = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % tag)
                 if os.path.exists(cand):
                     tfile, tsrc = cand, "profiles/pmc_traffic_%s.json" % tag
@@ -583,9 +595,16 @@ def main():
                             "kernels is VALU issue / the texture addresser, not HBM (DESIGN.md section 5)"}
                 if tj:
                     # HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE, rocprofv3 --pmc, separate passes) of one launch of each kernel of the stage
-                    out["roofline_describe"]["traffic"] = sum(tj.get(k, 0) for k in ("k_sample_rows_lds", "k_patch_sample", "k_blur_rows_lds",
-                                                                                     "k_patch_blur", "k_blur_cols_lds", "k_describe")) or None
-                    out["roofline_describe"]["traffic_source"] = "%s (a committed profile of the one-stream 31-view run)" % tsrc
+                    # in the PROFILED run, whose chunks differ in size from this run's: scaled by the ratio of the two chunks'
+                    # algorithmic bytes so that traffic and algorithmic_work_per_launch describe the same launch
+                    tprof = sum(tj.get(k, 0) for k in ("k_sample_rows_lds", "k_patch_sample", "k_blur_rows_lds",
+                                                       "k_patch_blur", "k_blur_cols_lds", "k_describe")) or None
+                    aprof = tj.get("describe_chunk_algorithmic_bytes", 163.0e6)
+                    out["roofline_describe"]["traffic"] = tprof * byts / aprof if tprof else None
+                    out["roofline_describe"]["traffic_over_algorithmic"] = tprof / aprof if tprof else None
+                    out["roofline_describe"]["traffic_source"] = ("%s: %.0f MB per chunk of %.0f MB algorithmic bytes in the committed one-stream "
+                                                                  "31-view profile, scaled to this run's chunk (x %.3f)"
+                                                                  % (tsrc, (tprof or 0) / 1e6, aprof / 1e6, byts / aprof))
         if wxbs:
             # H verification was the timed region; the same batch with epipolar verification, and the host share of both
             vms, vn, vth = verify_timed

@@ -503,7 +503,8 @@ int modsx_load_regions(const char *path, const char *det_name, const char *desc_
  * modsx_profile(ctx, 1) brackets every kernel launch with HIP events on the ctx stream and accumulates, per kernel
  * class, GPU milliseconds, launch count and algorithmic work (bytes; flops for the matcher).  Classes in order:
  * blur_hess, hessian, resize, nms_localize (scan + refine), baumberg, orientation, patch_sample, blur_rows, describe,
- * match_fginn, gray, warp_affine, view_blur, blur_cols.  modsx_kernel_stats returns the number of classes. */
+ * match_fginn, gray, warp_affine, view_blur, blur_cols, match_sweep1 (the one k_match launch that carries the 2 N M 128
+ * contraction; also part of match_fginn).  modsx_kernel_stats returns the number of classes. */
 int modsx_profile(modsx_ctx *ctx, int enable);
 int modsx_kernel_stats(modsx_ctx *ctx, double *ms, double *work, long *launches, int n);
 

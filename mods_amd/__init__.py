@@ -103,7 +103,7 @@ EXPORTS_DEGENSAC = ["exp_ransacHcustom", "exp_ransacFcustom", "HDs", "HDsi", "HD
                     "modsx_ransac_set_seed"]
 
 KERNEL_CLASSES = ["blur_hess", "hessian", "resize", "nms_localize", "baumberg", "orientation", "patch_sample",
-                  "blur_rows", "describe", "match_fginn", "gray", "warp_affine", "view_blur", "blur_cols"]
+                  "blur_rows", "describe", "match_fginn", "gray", "warp_affine", "view_blur", "blur_cols", "match_sweep1"]
 
 
 def build(force=False):

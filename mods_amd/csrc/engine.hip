@@ -75,6 +75,22 @@ void prof_begin(modsx_ctx *c, int cls, double work, size_t *slot) {
   hipEventRecord(p.evA[*slot], c->stream);
 }
 void prof_end(modsx_ctx *c, size_t slot) { if (slot != (size_t)-1) hipEventRecord(c->prof.evB[slot], c->stream); }
+// a slot whose two events the caller records itself (around one launch inside a launch helper); false when profiling is off
+bool prof_reserve(modsx_ctx *c, int cls, double work, hipEvent_t *ev2) {
+  Profiler &p = c->prof;
+  if (!p.enabled) return false;
+  if (p.used == p.evA.size()) {
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    p.evA.push_back(a); p.evB.push_back(b); p.cls.push_back(0);
+  }
+  const size_t slot = p.used++;
+  p.cls[slot] = cls;
+  p.work[cls] += work;
+  p.launches[cls]++;
+  ev2[0] = p.evA[slot]; ev2[1] = p.evB[slot];
+  return true;
+}
 void prof_collect(modsx_ctx *c) {
   Profiler &p = c->prof;
   if (!p.enabled || !p.used) return;
@@ -1301,8 +1317,11 @@ int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int
   }
   MX_HIP(hipMemcpyAsync(c->pos2.p, hpos, posB, hipMemcpyHostToDevice, s));
   {
+    // K_MATCH = every launch of the problem(s); K_MATCH_SWEEP1 = the one launch that carries the 2 N M 128 contraction
+    hipEvent_t evS1[2];
+    const bool tS1 = prof_reserve(c, K_MATCH_SWEEP1, work, evS1);
     ProfScope ps(c, K_MATCH, work);
-    launch_match_batch(s, nl, pd1, pn1, pd2, pn2, ppos, sqminratio, contrDistSq, nn, prow, pwork);
+    launch_match_batch(s, nl, pd1, pn1, pd2, pn2, ppos, sqminratio, contrDistSq, nn, prow, pwork, tS1 ? evS1 : nullptr);
   }
   MX_HIP(hipMemcpyAsync(hrow, c->matchRows.p, rowB, hipMemcpyDeviceToHost, s));
   MX_HIP(hipStreamSynchronize(s));

@@ -244,13 +244,13 @@ void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, i
 constexpr int MATCH_MAXB = 4;   // independent matching problems per launch set (blockIdx.z)
 void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
                         const double *const *pos2, double sqminratio, double contrDistSq, int nn, MatchRow *const *rows,
-                        void *const *workspace);
+                        void *const *workspace, hipEvent_t *evSweep1 = nullptr);   // evSweep1: two events recorded around sweep 1
 
 }  // namespace mx
 
 namespace mx {
 enum KClass { K_BLUR_HESS = 0, K_HESSIAN, K_RESIZE, K_NMS, K_BAUMBERG, K_ORIENT, K_PATCH_SAMPLE, K_BLUR_ROWS, K_DESCRIBE,
-              K_MATCH, K_GRAY, K_WARP, K_VIEW_BLUR, K_BLUR_COLS, K_NCLASS };
+              K_MATCH, K_GRAY, K_WARP, K_VIEW_BLUR, K_BLUR_COLS, K_MATCH_SWEEP1, K_NCLASS };
 struct Profiler {
   bool enabled = false;
   std::vector<hipEvent_t> evA, evB;

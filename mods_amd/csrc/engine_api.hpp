@@ -67,6 +67,7 @@ int match_pair_views(modsx_ctx *c, const modsx_image *img1, const modsx_image *i
                      const modsx_pair_params &pp, modsx_pair_result *res, VerifyTask *defer = nullptr);
 void prof_begin(modsx_ctx *c, int cls, double work, size_t *slot);
 void prof_end(modsx_ctx *c, size_t slot);
+bool prof_reserve(modsx_ctx *c, int cls, double work, hipEvent_t *ev2);
 // a sharded match (engine_shard.hip): this rank owns the query rows [lo, lo + per) of n1_total
 struct MatchShard { void *comm; int world, per, n1_total, lo; };
 // the lane's (per + 1)-row blocks (header row + result rows), grown by agreement; then header + all-gather + download + wait

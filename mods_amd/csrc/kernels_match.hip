@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void k_match_events(MatchBatch b, double contr
 // Problems with n1 == 0 or n2 == 0 must be left out by the caller.  workspace[i] holds match_workspace_bytes(n1[i], n2[i]).
 void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
                         const double *const *pos2, double sqminratio, double contrDistSq, int nn, MatchRow *const *rows,
-                        void *const *workspace) {
+                        void *const *workspace, hipEvent_t *evSweep1) {
   if (nb <= 0) return;
   MatchBatch b;
   memset(&b, 0, sizeof b);
@@ -748,8 +748,10 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
   hipLaunchKernelGGL(k_match_pack, dim3((std::max(maxN1, maxSlots) + 255) / 256, 2, nb), dim3(256), 0, s, b);
   const int QPB = qpb_of(qs), NW2 = 256 * sweep_wps(qs);
   const dim3 grid((maxN1 + QPB - 1) / QPB, maxS, nb);
+  if (evSweep1) hipEventRecord(evSweep1[0], s);
   if (qs == 4) hipLaunchKernelGGL(k_match_sweep1<4>, grid, dim3(256), 0, s, b);
   else hipLaunchKernelGGL(k_match_sweep1<2>, grid, dim3(256), 0, s, b);
+  if (evSweep1) hipEventRecord(evSweep1[1], s);
   hipLaunchKernelGGL(k_match_decide, dim3((maxN1 + DECIDE_Q - 1) / DECIDE_Q, 1, nb), dim3(1024), 0, s, b, sqminratio, contrDistSq);
   // sweep 2: one round of workgroups dealt out on the device as (undecided block, split); more only if there could be more
   // undecided query blocks than that
@@ -762,7 +764,7 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
 void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2,
                   double sqminratio, double contrDistSq, int nn, MatchRow *rows, void *workspace) {
   if (n1 <= 0 || n2 <= 0) return;
-  launch_match_batch(s, 1, &d1, &n1, &d2, &n2, &pos2, sqminratio, contrDistSq, nn, &rows, &workspace);
+  launch_match_batch(s, 1, &d1, &n1, &d2, &n2, &pos2, sqminratio, contrDistSq, nn, &rows, &workspace, nullptr);
 }
 
 }  // namespace mx

@@ -3,7 +3,7 @@
 # what is to be judged into profiles/).  Kernel-trace summaries and counter passes are separate rocprofv3 runs; counter
 # passes use --kernel-trace only.
 R=$GRAFT_REPO_ROOT
-TAG=${ROUND_TAG:-r03}
+TAG=${ROUND_TAG:-r04}
 OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -61,6 +61,11 @@ m = table("$OUT/${TAG}_match_pmc_hbm.txt")
 t["k_match_total_views31"] = sum(v for k, v in m.items() if k.startswith("k_match_"))
 hdr = open("/tmp/rp_m24k.line").read()
 mm = re.search(r"N=(\d+) M=(\d+)", hdr)
+try:   # the describe chunk of the profiled run: its algorithmic bytes (bench.py's roofline_describe), so that a later run can scale the traffic to its own chunk
+    line = [l for l in open("/tmp/rp_fetch.log") if l.startswith("{")][-1]
+    t["describe_chunk_algorithmic_bytes"] = json.loads(line)["roofline_describe"]["algorithmic_work_per_launch"]
+except Exception as e:
+    print("no roofline_describe in the fetch pass:", e)
 t["k_match_problem"] = ("%s x %s real 31-view descriptors (tools/bench_match.py --tilts 1,2,4,6,8 --phi 120)" % (mm.group(1), mm.group(2))) if mm else "24 k x 24 k real 31-view descriptors"
 json.dump(dict(sorted(t.items())), open("$OUT/pmc_traffic_${TAG}.json", "w"), indent=1)
 PY
