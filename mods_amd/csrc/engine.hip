@@ -423,31 +423,39 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
   nb.posTh = posTh; nb.negTh = negTh; nb.finalTh = finalTh; nb.border = p.border;
   int maxOct = 0;
   for (int i = 0; i < n; i++) maxOct = std::max(maxOct, c->pyr[i].nOct);
-  // all (image, octave, level) scans of the batch in one launch (NMS_MAXJ jobs at most per launch)
+  // all (image, octave, level) scans of the batch in one launch (NMS_MAXJ jobs at most per launch).  With the shipped
+  // numberOfScales = 3 the tiles number OCTAVES and a tile scans the three levels of its octave in one pass over the five
+  // response planes (k_nms_localize_oct); otherwise a tile belongs to one level
+  const bool perOctave = p.numberOfScales == 3 && !getenv("MODSX_NMS_PER_LEVEL");
   std::vector<NmsJob> hjobs;
-  std::vector<int> hpfx(1, 0);
+  std::vector<int> hpfx(1, 0), hfirst;
   double px = 0;
-  auto flush = [&]() -> int {
+  auto flush = [&](bool last) -> int {
     const int nj = (int)hjobs.size();
     if (!nj) return MODSX_OK;
-    const size_t jobBytes = (size_t)nj * sizeof(NmsJob), pfxBytes = (size_t)(nj + 1) * 4;
-    if (!c->nmsJobs.ensure(jobBytes + pfxBytes + 64)) return MODSX_ERR_NOMEM;
-    if (!c->hNms.ensure(jobBytes + pfxBytes)) return MODSX_ERR_NOMEM;   // jobs + prefix: one pinned blob, one copy
+    const int np = (int)hpfx.size() - 1;     // tile groups: octaves or levels
+    const size_t jobBytes = (size_t)nj * sizeof(NmsJob), pfxBytes = (size_t)(np + 1) * 4, firstBytes = (size_t)std::max<size_t>(1, hfirst.size()) * 4;
+    if (!c->nmsJobs.ensure(jobBytes + pfxBytes + firstBytes + 64)) return MODSX_ERR_NOMEM;
+    if (!c->hNms.ensure(jobBytes + pfxBytes + firstBytes)) return MODSX_ERR_NOMEM;   // jobs + prefix (+ first level job of every octave): one pinned blob, one copy
     memcpy(c->hNms.p, hjobs.data(), jobBytes);
     memcpy((char *)c->hNms.p + jobBytes, hpfx.data(), pfxBytes);
-    MX_HIP(hipMemcpyAsync(c->nmsJobs.p, c->hNms.p, jobBytes + pfxBytes, hipMemcpyHostToDevice, s));
+    if (!hfirst.empty()) memcpy((char *)c->hNms.p + jobBytes + pfxBytes, hfirst.data(), hfirst.size() * 4);
+    MX_HIP(hipMemcpyAsync(c->nmsJobs.p, c->hNms.p, jobBytes + pfxBytes + firstBytes, hipMemcpyHostToDevice, s));
     if (!c->tileJob.ensure((size_t)hpfx.back() * 4 + 4)) return MODSX_ERR_NOMEM;
-    launch_expand_tiles(s, (const int *)((char *)c->nmsJobs.p + jobBytes), nj, (int *)c->tileJob.p);
+    const int *dPfx = (const int *)((char *)c->nmsJobs.p + jobBytes);
+    launch_expand_tiles(s, dPfx, np, (int *)c->tileJob.p);
     {
       ProfScope ps(c, K_NMS, px * 12);
       if (!queuesClean) MX_HIP(hipMemsetAsync((unsigned *)c->counter.p + 32, 0, NMS_QUEUES * 128, s));
       queuesClean = false;
-      launch_nms(s, nb, (const NmsJob *)c->nmsJobs.p, (const int *)((char *)c->nmsJobs.p + jobBytes), (const int *)c->tileJob.p, nj,
+      launch_nms(s, nb, (const NmsJob *)c->nmsJobs.p, dPfx, (const int *)c->tileJob.p, nj,
                  hpfx.back(), (int4 *)c->nmsQueue.p, (unsigned *)c->counter.p + 32, CAND_CAP, (Candidate *)c->cand.p,
-                 (unsigned *)c->counter.p, CAND_CAP);
+                 (unsigned *)c->counter.p, CAND_CAP, perOctave ? (const int *)((char *)c->nmsJobs.p + jobBytes + pfxBytes) : nullptr,
+                 p.numberOfScales);
     }
-    MX_HIP(hipStreamSynchronize(s));   // the host tables are reused by the next flush
-    hjobs.clear(); hpfx.assign(1, 0); px = 0;
+    // the host tables are reused by the next flush; after the last one the counter read-back below waits for the launch
+    if (!last) MX_HIP(hipStreamSynchronize(s));
+    hjobs.clear(); hpfx.assign(1, 0); hfirst.clear(); px = 0;
     return MODSX_OK;
   };
   for (int o = 0; o < maxOct; o++)
@@ -456,34 +464,19 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
       Octave &oc = c->pyr[i].oct[o];
       const int w = oc.cols - 2 * p.border, h = oc.rows - 2 * p.border;
       if (w <= 0 || h <= 0) continue;
-      if ((int)hjobs.size() + p.numberOfScales > NMS_MAXJ) { int rcf = flush(); if (rcf) return rcf; }
+      if ((int)hjobs.size() + p.numberOfScales > NMS_MAXJ) { int rcf = flush(false); if (rcf) return rcf; }
+      const int tiles = ((w + 63) / 64) * ((h + NMS_TILE_ROWS - 1) / NMS_TILE_ROWS);
+      if (perOctave) { hfirst.push_back((int)hjobs.size()); hpfx.push_back(hpfx.back() + tiles); }
       for (int l = 1; l <= p.numberOfScales; l++) {
         NmsJob j;
         j.low = oc.resp[l - 1]; j.cur = oc.resp[l]; j.high = oc.resp[l + 1]; j.blur = oc.blur[l];
         j.rows = oc.rows; j.cols = oc.cols; j.img = i; j.octave = o; j.level = l; j.pad = 0;
         hjobs.push_back(j);
-        hpfx.push_back(hpfx.back() + ((w + 63) / 64) * ((h + NMS_TILE_ROWS - 1) / NMS_TILE_ROWS));
+        if (!perOctave) hpfx.push_back(hpfx.back() + tiles);
         px += (double)oc.rows * oc.cols;
       }
     }
-  const bool pendingJobs = !hjobs.empty();
-  if (pendingJobs) {
-    // last flush: no extra synchronisation, the counter read-back below waits for the launch
-    const int nj = (int)hjobs.size();
-    const size_t jobBytes = (size_t)nj * sizeof(NmsJob), pfxBytes = (size_t)(nj + 1) * 4;
-    if (!c->nmsJobs.ensure(jobBytes + pfxBytes + 64)) return MODSX_ERR_NOMEM;
-    if (!c->hNms.ensure(jobBytes + pfxBytes)) return MODSX_ERR_NOMEM;   // jobs + prefix: one pinned blob, one copy
-    memcpy(c->hNms.p, hjobs.data(), jobBytes);
-    memcpy((char *)c->hNms.p + jobBytes, hpfx.data(), pfxBytes);
-    MX_HIP(hipMemcpyAsync(c->nmsJobs.p, c->hNms.p, jobBytes + pfxBytes, hipMemcpyHostToDevice, s));
-    if (!c->tileJob.ensure((size_t)hpfx.back() * 4 + 4)) return MODSX_ERR_NOMEM;
-    launch_expand_tiles(s, (const int *)((char *)c->nmsJobs.p + jobBytes), nj, (int *)c->tileJob.p);
-    ProfScope ps(c, K_NMS, px * 12);
-    if (!queuesClean) MX_HIP(hipMemsetAsync((unsigned *)c->counter.p + 32, 0, NMS_QUEUES * 128, s));
-    launch_nms(s, nb, (const NmsJob *)c->nmsJobs.p, (const int *)((char *)c->nmsJobs.p + jobBytes), (const int *)c->tileJob.p, nj,
-               hpfx.back(), (int4 *)c->nmsQueue.p, (unsigned *)c->counter.p + 32, CAND_CAP, (Candidate *)c->cand.p,
-               (unsigned *)c->counter.p, CAND_CAP);
-  }
+  { int rcf = flush(true); if (rcf) return rcf; }
   // the count and the candidates come down behind ONE wait: the records are copied speculatively, as many as the context's
   // last set had (+ 1/4); a set that holds more costs a second copy for the rest
   if (!c->hMisc.ensure(64)) return MODSX_ERR_NOMEM;

@@ -185,7 +185,8 @@ void launch_blur_hess(hipStream_t s, const BlurBatch &b, int nj, int maxRows, in
 void launch_hessian(hipStream_t s, const BlurBatch &b, int nj, int maxRows, int maxCols);
 void launch_resize_half(hipStream_t s, const ResizeBatch &b, int nj, int maxRows, int maxCols);
 void launch_nms(hipStream_t s, const NmsBatch &b, const NmsJob *jobs, const int *tilePrefix, const int *tileJob, int nj,
-                int nTiles, int4 *queue, unsigned *qcount, unsigned qcap, Candidate *out, unsigned *counter, unsigned cap);
+                int nTiles, int4 *queue, unsigned *qcount, unsigned qcap, Candidate *out, unsigned *counter, unsigned cap,
+                const int *octFirst = nullptr, int levelsPerOctave = 0);
 constexpr int NMS_QUEUES = 64;      // sub-queues of the NMS extremum queue; counter k lives at counter[32 * (k + 1)]
 constexpr int NMS_TILE_ROWS = 16;   // rows of a 64-column NMS tile (kernels_pyramid.hip: NMS_ROWS)
 void launch_gray(hipStream_t s, const void *src, float *dst, size_t n, int channels, int dtype);

@@ -405,6 +405,123 @@ __global__ __launch_bounds__(256) void k_nms_localize(NmsBatch batch, const NmsJ
     }
 }
 
+// The same scan with ONE pass per octave (findLevelKeypoints over levels 1 .. S of an octave, pyramid.cpp:432-452, 524-530):
+// a tile parks the S + 2 response planes of the octave once and every level takes its 3 x 3 x 3 extremum test from the
+// per-plane 3 x 3 maxima / minima, which are formed once per plane -- each response plane is fetched once instead of by three
+// level passes (535 -> ~300 MB per 31-view launch), and the stencil runs over S + 2 planes instead of 3 S.  `tileJob[tile]` is
+// the octave's entry in `first` / `tilePrefix`; its level jobs are jobs[first[o]] .. jobs[first[o] + S - 1] (consecutive
+// levels of one octave, as the host builds them), and the queue records name the level job, as the per-level scan's do.
+template <int S>
+__global__ __launch_bounds__(256) void k_nms_localize_oct(NmsBatch batch, const NmsJob *__restrict__ jobs, const int *__restrict__ first,
+                                                          const int *__restrict__ tilePrefix, const int *__restrict__ tileJob,
+                                                          int4 *queue, unsigned *qcount, unsigned qcap, unsigned *overflow) {
+  constexpr int NP = S + 2;
+  const int tile = blockIdx.x;
+  const int oj = tileJob[tile];
+  const int jid0 = first[oj];
+  const NmsJob jb = jobs[jid0];
+  const int rows = jb.rows, cols = jb.cols, B = batch.border;
+  const int local = tile - tilePrefix[oj];
+  const int tilesX = (cols - 2 * B + 63) / 64;
+  const int by = local / tilesX, bx = local - by * tilesX;
+  const int r0 = B + by * NMS_ROWS, c0 = B + bx * 64;
+  __shared__ float sp[NP][NMS_ROWS + 2][NMS_LW];
+  {
+    const float *planes[NP];
+    planes[0] = jb.low; planes[1] = jb.cur;
+#pragma unroll
+    for (int l = 0; l < S; l++) planes[2 + l] = jobs[jid0 + l].high;
+    constexpr int NE = (NMS_ROWS + 2) * NMS_LW, PER = (NE + 255) / 256;
+    // the (clamped) offsets of a thread's elements are the same in every plane
+    int ofs[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+      const int idx = threadIdx.x + 256 * u, rr = idx / NMS_LW, cc = idx - rr * NMS_LW;
+      int gr = r0 - 1 + rr, gc = c0 - 1 + cc;
+      gr = gr < 0 ? 0 : (gr > rows - 1 ? rows - 1 : gr);     // clamped positions are never part of a tested neighbourhood
+      gc = gc < 0 ? 0 : (gc > cols - 1 ? cols - 1 : gc);
+      ofs[u] = gr * cols + gc;
+    }
+    float t[NP][PER];
+#pragma unroll
+    for (int pl = 0; pl < NP; pl++)
+#pragma unroll
+      for (int u = 0; u < PER; u++) t[pl][u] = threadIdx.x + 256 * u < NE ? planes[pl][ofs[u]] : 0.f;
+#pragma unroll
+    for (int pl = 0; pl < NP; pl++)
+#pragma unroll
+      for (int u = 0; u < PER; u++) {
+        const int idx = threadIdx.x + 256 * u;
+        if (idx < NE) (&sp[pl][0][0])[idx] = t[pl][u];
+      }
+  }
+  __syncthreads();
+  const int lc = threadIdx.x & 63, g = threadIdx.x >> 6;
+  bool any = false;
+#pragma unroll
+  for (int l = 1; l <= S; l++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float v0 = sp[l][4 * g + j + 1][lc + 1];
+      any = any || v0 > batch.posTh || v0 < batch.negTh;
+    }
+  __shared__ unsigned scount, sbase;
+  if (threadIdx.x == 0) scount = 0;
+  unsigned slot[S][4];
+#pragma unroll
+  for (int l = 0; l < S; l++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) slot[l][j] = 0xffffffffu;
+  __syncthreads();
+  if (__ballot(any)) {
+    // 3 x 3 maximum / minimum of every plane at the thread's four pixels (rows 4g .. 4g + 3 of column lc)
+    float pmx[NP][4], pmn[NP][4];
+#pragma unroll
+    for (int pl = 0; pl < NP; pl++) {
+      float hmax[6], hmin[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const float a = sp[pl][4 * g + k][lc], b = sp[pl][4 * g + k][lc + 1], d = sp[pl][4 * g + k][lc + 2];
+        hmax[k] = fmaxf(fmaxf(a, b), d);
+        hmin[k] = fminf(fminf(a, b), d);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        pmx[pl][j] = fmaxf(fmaxf(hmax[j], hmax[j + 1]), hmax[j + 2]);
+        pmn[pl][j] = fminf(fminf(hmin[j], hmin[j + 1]), hmin[j + 2]);
+      }
+    }
+    const int c = c0 + lc;
+#pragma unroll
+    for (int l = 1; l <= S; l++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int r = r0 + 4 * g + j;
+        const float v0 = sp[l][4 * g + j + 1][lc + 1];
+        // `!(x > v0)` for the 27 values of the 3 x 3 x 3 block is max <= v0 (v_max / v_min skip NaNs exactly like the failed
+        // comparisons do); the plane order of the maximum is irrelevant
+        const float mx = fmaxf(fmaxf(pmx[l - 1][j], pmx[l][j]), pmx[l + 1][j]);
+        const float mn = fminf(fminf(pmn[l - 1][j], pmn[l][j]), pmn[l + 1][j]);
+        bool cand = false;
+        if (v0 > batch.posTh) cand = mx <= v0;
+        else if (v0 < batch.negTh) cand = mn >= v0;
+        if (cand && r < rows - B && c < cols - B) slot[l - 1][j] = atomicAdd(&scount, 1u);
+      }
+  }
+  __syncthreads();
+  const unsigned sq = blockIdx.x % NMS_QUEUES, qsub = qcap / NMS_QUEUES;
+  if (threadIdx.x == 0) sbase = scount ? atomicAdd(qcount + 32 * sq, scount) : 0u;
+  __syncthreads();
+#pragma unroll
+  for (int l = 0; l < S; l++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (slot[l][j] != 0xffffffffu) {
+        if (sbase + slot[l][j] < qsub) queue[(size_t)sq * qsub + sbase + slot[l][j]] = make_int4(jid0 + l, r0 + 4 * g + j, c0 + lc, 0);
+        else atomicOr(overflow, 1u);   // the host turns this into an error: dropping extrema silently would change the result
+      }
+}
+
 // (B+G+R)/3 of GenerateSynthImageCorr (synth-detection.cpp:253-262): a cv::MatExpr that OpenCV
 // evaluates as addWeighted(B+G, 1/3., R, 1/3., 0) in f64 for CV_32F.
 __global__ void k_gray_u8(const uint8_t *src, float *dst, size_t n, int channels) {
@@ -500,8 +617,14 @@ __global__ __launch_bounds__(256) void k_nms_refine(NmsBatch batch, const NmsJob
 }
 
 void launch_nms(hipStream_t s, const NmsBatch &b, const NmsJob *jobs, const int *tilePrefix, const int *tileJob, int nj,
-                int nTiles, int4 *queue, unsigned *qcount, unsigned qcap, Candidate *out, unsigned *counter, unsigned cap) {
+                int nTiles, int4 *queue, unsigned *qcount, unsigned qcap, Candidate *out, unsigned *counter, unsigned cap,
+                const int *octFirst, int levelsPerOctave) {
   if (nj <= 0 || nTiles <= 0) return;
+  // octFirst: the tiles number OCTAVES (tilePrefix / tileJob index `octFirst`), every octave holding levelsPerOctave consecutive
+  // level jobs; the one-pass-per-octave scan exists for the shipped numberOfScales = 3
+  if (octFirst && levelsPerOctave == 3)
+    hipLaunchKernelGGL(k_nms_localize_oct<3>, dim3(nTiles), dim3(256), 0, s, b, jobs, octFirst, tilePrefix, tileJob, queue, qcount, qcap, counter + 1);
+  else
   hipLaunchKernelGGL(k_nms_localize, dim3(nTiles), dim3(256), 0, s, b, jobs, tilePrefix, tileJob, queue, qcount, qcap, counter + 1);
   hipLaunchKernelGGL(k_nms_refine, dim3(NMS_REFINE_BLOCKS, NMS_QUEUES), dim3(256), 0, s, b, jobs, queue, qcount, qcap, out, counter, cap);
 }
