@@ -11,6 +11,7 @@
 #include <chrono>
 #include <map>
 #include <unordered_set>
+#include <mutex>
 #include "engine_api.hpp"
 
 namespace mx {
@@ -214,6 +215,20 @@ modsx_ctx *ctx_create(int device_id) {
   }
   if (device_id < 0 || device_id >= ndev) { set_error("device id out of range"); return nullptr; }
   if (hipSetDevice(device_id) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
+  {
+    // How a host thread waits for its stream.  The runtime's default spins on the completion signal: with one context per host
+    // thread that is one busy core per context for as long as the stream has work -- 16 contexts burn 16 cores, which is the
+    // whole CPU allowance of a container limited to 16 CPUs (the hosts this library is benchmarked on: cpu.max 1600000 100000),
+    // and the verification / component-tree threads then run into the cgroup's throttle (stalls of 60-90 ms per 100 ms period).
+    // MODSX_SYNC=block (default) waits on the interrupt instead; MODSX_SYNC=spin keeps the runtime's default.
+    static std::once_flag once;
+    std::call_once(once, [] {
+      const char *e = getenv("MODSX_SYNC");
+      if (e && !strcmp(e, "spin")) return;
+      hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+      (void)hipGetLastError();
+    });
+  }
   modsx_ctx *c = new modsx_ctx();
   c->dev = device_id;
   if (hipStreamCreate(&c->stream) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }

@@ -330,12 +330,14 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
           launch_trunc_u8(c->stream, cimg[i]->d, (uint8_t *)c->misc.p + ofs[i], (size_t)cimg[i]->rows * cimg[i]->cols);
         if (!rc && (hipMemcpyAsync(c->hMser.p, c->misc.p, tot, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
                     hipStreamSynchronize(c->stream) != hipSuccess)) { set_error("MSER view download failed"); rc = MODSX_ERR_DEVICE; }
+        const double tdl = tnow();
         if (!rc) {
           const uint8_t *src[MAXB];
           int vr[MAXB], vc[MAXB];
           for (int i = 0; i < n; i++) { src[i] = (const uint8_t *)c->hMser.p + ofs[i]; vr[i] = cimg[i]->rows; vc[i] = cimg[i]->cols; }
           rc = detect_msers_views(src, vr, vc, n, pp.mser, tilts, zooms, kps);
         }
+        if (tim) fprintf(stderr, "  mser set of %d views: u8 + download %.2f ms, component trees %.2f ms\n", n, tdl - t1, tnow() - tdl);
       } else rc = detect_keypoints_batch(c, cimg, n, pp.det, tilts, zooms, kps);
     }
     double t2 = tnow(), t3 = t2, t4 = t2;

@@ -527,10 +527,26 @@ int detect_msers_views(const uint8_t *const *u8, const int *rows, const int *col
   std::vector<int> task((size_t)2 * n);
   for (int i = 0; i < 2 * n; i++) task[i] = i;
   std::stable_sort(task.begin(), task.end(), [&](int a, int b) { return (long)rows[a / 2] * cols[a / 2] > (long)rows[b / 2] * cols[b / 2]; });
+  static const bool trace = getenv("MODSX_HOST_TIMING") && atoi(getenv("MODSX_HOST_TIMING")) >= 3;
+  auto nowms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  std::vector<double> tb(trace ? 2 * n : 0), te(trace ? 2 * n : 0);
+  std::vector<size_t> tid(trace ? 2 * n : 0);
+  const double t00 = trace ? nowms() : 0;
   host_parallel_for(2 * n, [&](int k) {
     const int t = task[k], v = t / 2;
+    if (trace) { tb[k] = nowms() - t00; tid[k] = std::hash<std::thread::id>()(std::this_thread::get_id()) % 1000; }
     if (rows[v] > 0 && cols[v] > 0) mser_polarity(u8[v], rows[v], cols[v], par, minMargin, t & 1, part[t]);
+    if (trace) te[k] = nowms() - t00;
   });
+  if (trace && nowms() - t00 > 30) {
+    std::string line = "  slow mser job (" + std::to_string(2 * n) + " tasks, " + std::to_string(nowms() - t00) + " ms): task start-end@thread px:";
+    for (int k = 0; k < 2 * n && k < 14; k++) {
+      char b[96];
+      snprintf(b, sizeof b, " %.1f-%.1f@%zu %dk", tb[k], te[k], tid[k], rows[task[k] / 2] * cols[task[k] / 2] / 1000);
+      line += b;
+    }
+    fprintf(stderr, "%s\n", line.c_str());
+  }
   for (int v = 0; v < n; v++) {
     out[v] = std::move(part[2 * v]);
     out[v].insert(out[v].end(), part[2 * v + 1].begin(), part[2 * v + 1].end());
