@@ -160,16 +160,20 @@ struct Forest {
     order.resize((size_t)rows * cols);
     std::vector<int> fill(start.begin(), start.end() - 1);
     for (int r = 1; r <= rows; r++) { const uint8_t *g = grey + (size_t)r * stride; const int o0 = r * stride; for (int c = 1; c <= cols; c++) order[fill[g[c]]++] = o0 + c; }
+    static const int PF = getenv("MODSX_MSER_PF") ? atoi(getenv("MODSX_MSER_PF")) : 12;
     int lastRoot = -1;
     for (int level = 0; level < 256; level++)
       for (int k = start[level]; k < start[level + 1]; k++) {
         const int ofs = order[k];
-        if (k + 12 < start[256]) { const int f = order[k + 12]; __builtin_prefetch(&parent[f - stride]); __builtin_prefetch(&parent[f + stride]); }
+        if (k + PF < start[256]) { const int f = order[k + PF]; __builtin_prefetch(&parent[f - stride]); __builtin_prefetch(&parent[f]); __builtin_prefetch(&parent[f + stride]); }
         const int nb[4] = {ofs - stride, ofs - 1, ofs + 1, ofs + stride};
         int roots[4], nroots = 0, touching = 0;
         for (int q = 0; q < 4; q++) {
-          if (parent[nb[q]] < 0) continue;
+          const int pq = parent[nb[q]];
+          if (pq < 0) continue;
           touching++;
+          // inside a component the neighbours already point at (or one step from) the root found for an earlier neighbour
+          if (nroots && (pq == roots[nroots - 1] || parent[pq] == roots[nroots - 1]) && parent[roots[nroots - 1]] == roots[nroots - 1]) continue;
           const int r = find(nb[q]);
           bool dup = false;
           for (int z = 0; z < nroots; z++) dup = dup || roots[z] == r;
