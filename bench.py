@@ -175,21 +175,30 @@ class ShardGroup:
         self.pool = ThreadPoolExecutor(len(self.comms) * lanes)
 
     def step(self, i1, i2, views, params):
+        """Chunks of k = world consecutive pairs go through ONE sharded call each (modsx_match_pairs_views_sharded: one exchange for
+        the 2 k image sides, one result all-gather): a rank's launch sets hold ~2 * 31 views whatever the world size, and the
+        collectives per pair fall with it.  Chunk j runs on lane j % lanes of every rank; pair g is verified by rank g % world."""
         for cm in self.comms:
             cm.reset_lanes()
+        k = max(1, min(8, self.world))
+        chunks = [(c0, min(len(i1), c0 + k)) for c0 in range(0, len(i1), k)]
 
         def work(job):
-            k, w = job
-            cm = self.comms[k]
+            r, w = job
+            cm = self.comms[r]
             out = []
             try:
-                for i in range(w, len(i1), self.lanes):
-                    out.append((i, cm.match_pair_views_sharded(w, i1[i], i2[i], views, params, owner=i % self.world)))
+                for j in range(w, len(chunks), self.lanes):
+                    c0, c1 = chunks[j]
+                    res = cm.match_pairs_views_sharded(w, i1[c0:c1], i2[c0:c1], views, params, owner_base=c0 % self.world, arrays=False)
+                    for g, rr in enumerate(res):
+                        if (c0 + g) % self.world == cm.rank:
+                            out.append((c0 + g, rr))
             finally:
                 cm.lane_done(w)
             return out
         res = [None] * len(i1)
-        for part in self.pool.map(work, [(k, w) for k in range(len(self.comms)) for w in range(self.lanes)]):
+        for part in self.pool.map(work, [(r, w) for r in range(len(self.comms)) for w in range(self.lanes)]):
             for i, r in part:
                 if r is not None:
                     res[i] = r

@@ -455,6 +455,23 @@ int modsx_comm_stats(const modsx_comm *comm, long *out, int n);
 /* Where row j of the reference's list sits in the all-gathered buffer (rank r's padded block starts at r * maxrows):
  * counts[r * nviews + v] = regions of view v on rank r (0 unless r == v mod world).  Returns the list length (host only). */
 int modsx_view_block_order(const int *counts, int world, int nviews, int *src, int cap, int *maxrows_out);
+/* The wire format of one exchange, stated on the host -- what the pack / ordering kernels of the sharded calls do on the device
+ * (the GPU tests compare the two byte for byte; the gloo CPU tests run world 2 and 3 over these functions without a device):
+ *   block = header {magic "MXSH", rc, rows, items, counts[items]} padded to 64 B, then rows of sizeof(modsx_region) + 128 * ndesc
+ *           bytes (the region, then its descriptor of every class of the step), padded to block_rows rows.
+ * Items = (image, view) pairs, f = image * nviews + view; item f belongs to rank f mod world.
+ * _bytes: size of a block.  _pack: this rank's block (counts[f] = 0 for items of other ranks; a block that is too small keeps
+ * the true row count in its header).  _unpack: the reference's list from the `world` gathered blocks; returns its length,
+ * MODSX_ERR_CAPACITY (*need_rows = the largest row count) when a block was too small, or the rc a rank's header carries. */
+long modsx_shard_block_bytes(int items, int block_rows, int ndesc);
+long modsx_shard_block_pack(const modsx_region *regs, const unsigned char *const *desc, int ndesc, int n, const int *counts, int items,
+                            int rc_local, int block_rows, void *block);
+long modsx_shard_blocks_unpack(const void *blocks, int world, int items, int block_rows, int ndesc, modsx_region *regs_out,
+                               unsigned char *const *desc_out, long cap, int *item_counts, int *need_rows);
+/* test hooks (need a device): the same two steps through the device kernels, outputs copied back to the host */
+long modsx_shard_device_pack(modsx_ctx *ctx, const modsx_region *regs, const unsigned char *const *desc, int ndesc, int n, void *rows_out);
+long modsx_shard_device_unpack(modsx_ctx *ctx, const void *blocks, int world, int items, int block_rows, int ndesc, modsx_region *regs_out,
+                               unsigned char *const *desc_out, double *pos_out, long cap);
 /* SynthDetectDescribeKeypoints with this rank taking views rank, rank + world, ...: one all-gather of padded blocks
  * (header with the per-view counts + rows of modsx_region + 128 u8 descriptor bytes = 328 B), device to device; the
  * reference's order is rebuilt on the device from the gathered headers; every rank returns
@@ -472,6 +489,15 @@ int modsx_match_fginn_sharded(modsx_ctx *ctx, modsx_comm *comm, const void *dev_
 int modsx_match_pair_views_sharded(modsx_ctx *ctx, modsx_comm *comm, const modsx_image *img1, const modsx_image *img2,
                                    const modsx_view *views, int nviews, const modsx_pair_params *par, int owner,
                                    modsx_pair_result *res);
+/* n_pairs (1..16) multi-view pairs in ONE sharded call -- what keeps the fixed costs of the exchange from growing with the world
+ * size: the views of all 2 n_pairs images form one item list (item f = image * nviews + view belongs to rank f mod world), so a
+ * rank's launch sets hold ~2 n_pairs nviews / world views whatever the world size; ONE all-gather moves the region rows +
+ * descriptors of every image side, the n_pairs matching problems of a descriptor class share ONE all-gather of result rows, and
+ * pair g is verified by rank (owner_base + g) mod world (owner_base < 0: by every rank; the other ranks fill the counters up to
+ * n_tentatives).  results[g] is what modsx_match_pair_views returns for pair g.  Returns n_pairs. */
+int modsx_match_pairs_views_sharded(modsx_ctx *ctx, modsx_comm *comm, const modsx_image *const *imgs1, const modsx_image *const *imgs2,
+                                    int n_pairs, const modsx_view *views, int nviews, const modsx_pair_params *par, int owner_base,
+                                    modsx_pair_result *results);
 /* modsx_match_ladder over the ranks (configs[3]: the iteration ladder with every step's views sharded): each step's
  * regions are exchanged and appended to the accumulated lists on every rank, the match is sharded by query row, and every
  * rank runs DuplicateFiltering + LO-RANSAC on the same tentatives with the same seed; the verified count that decides the

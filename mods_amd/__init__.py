@@ -95,8 +95,10 @@ EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "m
            "modsx_match_pair_views", "modsx_match_ladder", "modsx_save_regions", "modsx_load_regions", "modsx_default_mser_params", "modsx_detect_msers", "modsx_detect_msers_u8", "modsx_last_timings", "modsx_profile",
            "modsx_kernel_stats", "modsx_last_batch_verify", "modsx_comm_unique_id", "modsx_comm_create", "modsx_comm_destroy", "modsx_comm_info",
            "modsx_view_block_order", "modsx_detect_describe_views_sharded", "modsx_match_fginn_sharded",
-           "modsx_match_pair_views_sharded", "modsx_match_ladder_sharded", "modsx_comm_loopback_id", "modsx_comm_set_lanes",
-           "modsx_comm_attach", "modsx_comm_lane_done", "modsx_comm_reset_lanes", "modsx_comm_set_timeout", "modsx_comm_stats"]
+           "modsx_match_pair_views_sharded", "modsx_match_pairs_views_sharded", "modsx_match_ladder_sharded", "modsx_comm_loopback_id", "modsx_comm_set_lanes",
+           "modsx_comm_attach", "modsx_comm_lane_done", "modsx_comm_reset_lanes", "modsx_comm_set_timeout", "modsx_comm_stats",
+           "modsx_shard_block_bytes", "modsx_shard_block_pack", "modsx_shard_blocks_unpack", "modsx_shard_device_pack",
+           "modsx_shard_device_unpack"]
 # include/modsx_degensac.h: the reference's own verification symbols (link-time drop-in for libdegensac)
 EXPORTS_DEGENSAC = ["exp_ransacHcustom", "exp_ransacFcustom", "HDs", "HDsi", "HDsidx", "HDsSym", "HDsiSym", "HDsSymidx",
                     "HDsSymMax", "HDsiSymMax", "HDsSymidxMax", "FDs", "FDsSym", "exFDs", "exFDsSym",
@@ -562,6 +564,42 @@ class Context(object):
                "match_pair_views_sharded")
         return _unpack_pair_result(res)
 
+    def match_pairs_views_sharded(self, comm, imgs1, imgs2, views, params, owner_base=0, arrays=True):
+        """modsx_match_pairs_views_sharded: len(imgs1) <= 16 pairs in one sharded call; pair g is verified by rank
+        (owner_base + g) % world (owner_base < 0: by every rank).  Returns the list of per-pair results."""
+        n = len(imgs1)
+        a1 = (C.c_void_p * n)(*[im.h for im in imgs1])
+        a2 = (C.c_void_p * n)(*[im.h for im in imgs2])
+        arr = _view_array(views)
+        res = (PairResult * n)()
+        _check(lib().modsx_match_pairs_views_sharded(self._c(), C.c_void_p(comm), a1, a2, n, arr, len(views), C.byref(params),
+                                                     int(owner_base), res), "match_pairs_views_sharded")
+        return [_unpack_pair_result(res[i], arrays) for i in range(n)]
+
+    def shard_device_pack(self, regs, descs):
+        """k_pack_rows on host-provided regions + descriptors: the rows part of a block, [n, 200 + 128 * ndesc] u8."""
+        L = lib()
+        L.modsx_shard_device_pack.restype = C.c_long
+        regs = np.ascontiguousarray(regs, REGION)
+        descs = [np.ascontiguousarray(d, np.uint8) for d in descs]
+        out = np.zeros((len(regs), REGION.itemsize + 128 * len(descs)), np.uint8)
+        _check(L.modsx_shard_device_pack(self._c(), _p(regs), _ptr_array(descs), len(descs), len(regs), _p(out)), "shard_device_pack")
+        return out
+
+    def shard_device_unpack(self, blocks, world, items, block_rows, ndesc=1):
+        """k_unpack_blocks on gathered blocks: (regs [world * block_rows], [desc per class], pos [.., 2]) -- rows past the list's
+        end are zero."""
+        L = lib()
+        L.modsx_shard_device_unpack.restype = C.c_long
+        blocks = np.ascontiguousarray(blocks, np.uint8)
+        cap = world * block_rows
+        regs = np.zeros(cap, REGION)
+        descs = [np.zeros((cap, 128), np.uint8) for _ in range(ndesc)]
+        pos = np.zeros((cap, 2), np.float64)
+        _check(L.modsx_shard_device_unpack(self._c(), _p(blocks), int(world), int(items), int(block_rows), int(ndesc), _p(regs),
+                                           _ptr_array(descs), _p(pos), C.c_long(cap)), "shard_device_unpack")
+        return regs, descs, pos
+
     def detect_msers(self, img, params=None, tilt=1.0, zoom=1.0):
         params = params or default_mser_params()
         out = C.c_void_p()
@@ -638,6 +676,50 @@ def view_block_order(counts):
     mr = C.c_int(0)
     n = _check(lib().modsx_view_block_order(_p(counts), world, nviews, _p(src), len(src), C.byref(mr)), "view_block_order")
     return src[:n].copy(), mr.value
+
+
+def _ptr_array(arrs):
+    return (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+
+
+def shard_block_bytes(items, block_rows, ndesc=1):
+    L = lib()
+    L.modsx_shard_block_bytes.restype = C.c_long
+    return int(L.modsx_shard_block_bytes(int(items), int(block_rows), int(ndesc)))
+
+
+def shard_block_pack(regs, descs, counts, block_rows, rc_local=0):
+    """This rank's block of one exchange (host statement of the wire format): regs in item order, descs = list of [n, 128] u8
+    arrays (one per descriptor class), counts[f] per (image, view) item.  Returns the block as a uint8 array."""
+    L = lib()
+    L.modsx_shard_block_pack.restype = C.c_long
+    regs = np.ascontiguousarray(regs, REGION)
+    descs = [np.ascontiguousarray(d, np.uint8) for d in descs]
+    counts = np.ascontiguousarray(counts, np.int32)
+    out = np.zeros(shard_block_bytes(len(counts), block_rows, len(descs)), np.uint8)
+    n = _check(L.modsx_shard_block_pack(_p(regs), _ptr_array(descs), len(descs), len(regs), _p(counts), len(counts), int(rc_local),
+                                        int(block_rows), _p(out)), "shard_block_pack")
+    assert n == len(out)
+    return out
+
+
+def shard_blocks_unpack(blocks, world, items, block_rows, ndesc=1, cap=None):
+    """The reference's list from `world` gathered blocks (host): (regs, [desc per class], item_counts).  Raises on a failed rank;
+    returns (None, None, need_rows) when a block was too small."""
+    L = lib()
+    L.modsx_shard_blocks_unpack.restype = C.c_long
+    blocks = np.ascontiguousarray(blocks, np.uint8)
+    cap = int(cap if cap is not None else world * block_rows)
+    regs = np.zeros(max(1, cap), REGION)
+    descs = [np.zeros((max(1, cap), 128), np.uint8) for _ in range(ndesc)]
+    cnt = np.zeros(items, np.int32)
+    need = C.c_int(0)
+    n = L.modsx_shard_blocks_unpack(_p(blocks), int(world), int(items), int(block_rows), int(ndesc), _p(regs), _ptr_array(descs),
+                                    C.c_long(cap), _p(cnt), C.byref(need))
+    if n == -5:      # MODSX_ERR_CAPACITY
+        return None, None, need.value
+    _check(n, "shard_blocks_unpack")
+    return regs[:n].copy(), [d[:n].copy() for d in descs], cnt
 
 
 def comm_unique_id():

@@ -1229,7 +1229,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
 }
 
 // the host half of the matcher: per-query result rows -> TentativeCorrespExt records (matching.cpp:435-457)
-static void rows_to_tentatives(const MatchRow *rows, int n1, int nn, std::vector<modsx_tentative> &o) {
+void rows_to_tentatives(const MatchRow *rows, int n1, int nn, std::vector<modsx_tentative> &o) {
   o.reserve(n1 / 4 + 16);
   for (int q = 0; q < n1; q++) {
     const MatchRow &r = rows[q];

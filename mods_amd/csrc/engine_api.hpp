@@ -52,6 +52,11 @@ int set_vs_pars(const double *scale_set, int ns, const double *tilt_set, int nt,
 // per-view loop: hipMalloc / hipFree synchronise the whole device, i.e. every other context's stream as well).
 int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx_image **out, double *H, int *identity,
                int slot = -1);
+// the per-view loop over (source image, view) items: one launch set may mix the views of several images
+int detect_describe_items(modsx_ctx *c, const modsx_image *const *itemImg, const int *itemView, int nitems, const modsx_view *views,
+                          const modsx_pair_params &pp, std::vector<modsx_region> &regs,
+                          float *devF, uint8_t *devU8, size_t devCapRegions, float *hostDesc, int *itemCounts,
+                          const DescSet *ds = nullptr, uint8_t *const *devU8x = nullptr);
 int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_view *views, int nv,
                           const modsx_pair_params &pp, int view_begin, int view_step, std::vector<modsx_region> &regs,
                           float *devF, uint8_t *devU8, size_t devCapRegions, float *hostDesc, int *viewCounts,
@@ -76,7 +81,13 @@ int match_shard_gather(modsx_ctx *c, const MatchShard &sh, int local_rc, mx::Mat
 int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *img, const modsx_view *views, int nv,
                                   const modsx_pair_params &pp, const DescSet &ds, std::vector<modsx_region> &regs,
                                   DevBuf *const *descAcc, const size_t *base, int *viewCounts);
+int detect_describe_items_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *const *imgs, int nimg, const modsx_view *views,
+                                  int nviews, const modsx_pair_params &pp, const DescSet &ds, std::vector<modsx_region> &regs,
+                                  DevBuf *const *descAcc, const size_t *base, int *itemCounts, const unsigned char *wantImg = nullptr,
+                                  std::vector<size_t> *regStart = nullptr, double **devPos = nullptr);
+void rows_to_tentatives(const MatchRow *rows, int n1, int nn, std::vector<modsx_tentative> &o);
 int comm_rank(const modsx_comm *cm);
+int comm_world(const modsx_comm *cm);
 int comm_same_value(modsx_ctx *c, modsx_comm *cm, int value, const char *what);   // one 4-byte all-gather; an error on every rank when they differ
 int match_sharded(modsx_ctx *c, modsx_comm *cm, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2Host,
                   double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out);

@@ -122,12 +122,13 @@ static std::map<uint64_t, std::shared_ptr<LoopGroup>> g_loopGroups;
 static uint64_t g_loopNext = 1;
 
 struct ShardLane {
-  DevBuf blkLocal, blkAll, regsIn, regsOut, mLocal, mAll, rcDev, order;
+  DevBuf blkLocal, blkAll, regsIn, regsOut, mLocal, mAll, rcDev, order, posOut;
   PinBuf hRegs, hHdr, hRc;
   size_t capBlock = 0;    // agreed: bytes of one region block the lane's buffers hold (blkLocal; blkAll = world x)
   size_t capMatch = 0;    // agreed: bytes of one match block (mLocal; mAll = world x)
   int guessRows = 0;      // agreed: rows per block of the next exchange (a function of the headers gathered so far)
   size_t lastN = 0;       // local: list length of the last exchange (sizes the speculative region download)
+  size_t localCap = 0;    // local: region capacity the rank's own descriptor scratch needed last time (a too small first guess runs the views twice)
   bool retired = false;
 };
 
@@ -339,7 +340,7 @@ __global__ void k_pack_rows(const unsigned char *regs, DescPtrs desc, int nd, in
 // (rank r, row i < G); every workgroup rebuilds the two small prefix tables from the W headers in LDS.
 constexpr int SHARD_MAXV = 1024, SHARD_MAXW = 64;
 __global__ __launch_bounds__(256) void k_unpack_blocks(const unsigned char *all, int W, int nv, int G, size_t blockB, int hdrB,
-                                                       unsigned char *regs, DescPtrs desc, int nd, size_t cap) {
+                                                       unsigned char *regs, DescPtrs desc, int nd, size_t cap, double *pos, int posOfs) {
   __shared__ int viewStart[SHARD_MAXV], runStart[SHARD_MAXV], cnt[SHARD_MAXV], run[SHARD_MAXW];
   for (int v = threadIdx.x; v < nv; v += 256) {
     const int *h = reinterpret_cast<const int *>(all + (size_t)(v % W) * blockB);
@@ -362,6 +363,8 @@ __global__ __launch_bounds__(256) void k_unpack_blocks(const unsigned char *all,
   if (j >= cap) return;
   const unsigned char *s = all + (size_t)r * blockB + hdrB + (size_t)i * row_bytes(nd);
   if (l < REG_B / 8) reinterpret_cast<uint64_t *>(regs + j * REG_B)[l] = reinterpret_cast<const uint64_t *>(s)[l];
+  // reproj_kp.x, .y of every region as the matcher's pos2 array: ranks that do not verify a pair never bring its regions to the host
+  if (pos && l < 2) pos[2 * j + l] = reinterpret_cast<const double *>(s + posOfs)[l];
   for (int k = 0; k < nd; k++)
     if (l < 16) reinterpret_cast<uint64_t *>(desc.p[k] + j * 128)[l] = reinterpret_cast<const uint64_t *>(s + REG_B + 128 * k)[l];
 }
@@ -380,6 +383,7 @@ int view_block_order(const int *counts, int world, int nviews, int maxrows, std:
 }
 
 int comm_rank(const modsx_comm *cm) { return cm->rank; }
+int comm_world(const modsx_comm *cm) { return cm->world; }
 
 static int lane_of(modsx_ctx *c, modsx_comm *cm) {
   const int lane = c->shardLane;
@@ -406,10 +410,25 @@ static int grow_keep(hipStream_t s, DevBuf &b, size_t keep, size_t bytes) {
 int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *img, const modsx_view *views, int nv,
                                   const modsx_pair_params &pp, const DescSet &ds, std::vector<modsx_region> &regs,
                                   DevBuf *const *descAcc, const size_t *base, int *viewCounts) {
+  return detect_describe_items_sharded(c, cm, &img, 1, views, nv, pp, ds, regs, descAcc, base, viewCounts, nullptr, nullptr, nullptr);
+}
+// The same for the views of SEVERAL images in one exchange (the batched pair call: 2 k images of k pairs).  The (image, view)
+// items are numbered f = image * nviews + view and item f belongs to rank f mod world; a rank runs all its items as one
+// launch set sequence (detect_describe_items) and ONE all-gather moves every image side.  regs: all images in item order
+// (image, view, detection); itemCounts[f] = regions of item f.
+// wantImg (optional, nimg flags): only the regions of the flagged images come to the host -- `regs` is then the concatenation of
+// THOSE images' slices and regStart[j] .. regStart[j + 1] the slice of image j in it (empty for the others); without it `regs`
+// holds all images.  devPos (optional): receives the device array of (reproj x, y) of ALL regions in item order (the matcher's
+// pos2), valid until the lane's next exchange.
+int detect_describe_items_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *const *imgs, int nimg, const modsx_view *views,
+                                  int nviews, const modsx_pair_params &pp, const DescSet &ds, std::vector<modsx_region> &regs,
+                                  DevBuf *const *descAcc, const size_t *base, int *viewCounts, const unsigned char *wantImg,
+                                  std::vector<size_t> *regStart, double **devPos) {
   regs.clear();
+  const int nv = nimg * nviews;            // items: what the block headers call views
   const int nd = ds.n, ROW_B = row_bytes(nd);
   if (cm->dead.load()) return comm_dead_rc(cm);
-  if (nv < 1 || nv > SHARD_MAXV || cm->world > SHARD_MAXW) { set_error("sharded path: at most 1024 views and 64 ranks"); return MODSX_ERR_ARG; }
+  if (nimg < 1 || nviews < 1 || nv > SHARD_MAXV || cm->world > SHARD_MAXW) { set_error("sharded path: at most 1024 (image, view) items per exchange and 64 ranks"); return MODSX_ERR_ARG; }
   hipStream_t s = c->stream;
   const int W = cm->world, R = cm->rank, lane = lane_of(c, cm);
   ShardLane &L = cm->lanes[lane];
@@ -418,14 +437,22 @@ int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
   std::vector<int> cnt(nv, 0);
   int lrc = MODSX_OK;
   std::string lerr;
-  size_t cap = (size_t)1 << 15;
+  size_t cap = std::max<size_t>((size_t)1 << 15, L.localCap);
   for (;;) {
     if (!c->shardLocal.ensure(cap * 128 * nd)) { lrc = MODSX_ERR_NOMEM; break; }   // class k at row k * cap
     uint8_t *xs[3] = {(uint8_t *)c->shardLocal.p + cap * 128, (uint8_t *)c->shardLocal.p + 2 * cap * 128, (uint8_t *)c->shardLocal.p + 3 * cap * 128};
-    lrc = detect_describe_views(c, img, views, nv, pp, R, W, local, nullptr, (uint8_t *)c->shardLocal.p, cap, nullptr, cnt.data(), &ds, xs);
+    std::vector<const modsx_image *> myImg;
+    std::vector<int> myView, myItem;
+    for (int f = R; f < nv; f += W) { myImg.push_back(imgs[f / nviews]); myView.push_back(f % nviews); myItem.push_back(f); }
+    std::vector<int> myCnt(std::max<size_t>(1, myItem.size()), 0);
+    lrc = detect_describe_items(c, myImg.data(), myView.data(), (int)myItem.size(), views, pp, local, nullptr, (uint8_t *)c->shardLocal.p, cap,
+                                nullptr, myCnt.data(), &ds, xs);
+    std::fill(cnt.begin(), cnt.end(), 0);
+    for (size_t k = 0; k < myItem.size(); k++) cnt[myItem[k]] = myCnt[k];
     if (lrc == MODSX_ERR_CAPACITY && cap < ((size_t)1 << 24)) { cap *= 4; continue; }
     break;
   }
+  L.localCap = cap;
   if (lrc) { lerr = last_error(); local.clear(); std::fill(cnt.begin(), cnt.end(), 0); }
   const int nloc = (int)local.size();
   const int hdrB = hdr_bytes(nv);
@@ -446,7 +473,7 @@ int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
     if (!L.hHdr.ensure((size_t)hdrB * (W + 1))) { comm_kill(cm, "no pinned memory for a block header"); return MODSX_ERR_NOMEM; }
     if (!lrc) {
       if (!L.regsIn.ensure((size_t)std::max(1, nloc) * REG_B) || !L.hRegs.ensure(std::max((size_t)std::max(1, nloc), rowsCap) * REG_B) ||
-          !L.regsOut.ensure(rowsCap * REG_B)) {
+          !L.regsOut.ensure(rowsCap * REG_B) || (devPos && !L.posOut.ensure(rowsCap * 16))) {
         lrc = MODSX_ERR_NOMEM; lerr = "sharded path: out of memory";
       }
       for (int k = 0; k < nd && !lrc; k++)
@@ -476,9 +503,12 @@ int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
       DescPtrs dp;
       for (int k = 0; k < MODSX_MAX_DESC; k++) dp.p[k] = k < nd ? (unsigned char *)descAcc[k]->p + base[k] * 128 : nullptr;
       hipLaunchKernelGGL(k_unpack_blocks, dim3((unsigned)((rowsCap + 7) / 8)), dim3(256), 0, s, (const unsigned char *)L.blkAll.p, W, nv, G,
-                         blockB, hdrB, (unsigned char *)L.regsOut.p, dp, nd, rowsCap);
-      got = std::min(rowsCap, L.lastN + L.lastN / 4 + 256);
-      MX_HIP(hipMemcpyAsync(L.hRegs.p, L.regsOut.p, got * REG_B, hipMemcpyDeviceToHost, s));
+                         blockB, hdrB, (unsigned char *)L.regsOut.p, dp, nd, rowsCap, devPos ? (double *)L.posOut.p : nullptr,
+                         (int)offsetof(modsx_region, reproj_kp));
+      if (!wantImg) {     // all regions are wanted: a first guess comes down with the same wait as the headers
+        got = std::min(rowsCap, L.lastN + L.lastN / 4 + 256);
+        MX_HIP(hipMemcpyAsync(L.hRegs.p, L.regsOut.p, got * REG_B, hipMemcpyDeviceToHost, s));
+      }
     }
     rc = comm_wait(cm, s);
     if (rc) return rc;
@@ -506,6 +536,29 @@ int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
     L.guessRows = std::max(G, maxrows + maxrows / 4 + 64);
     L.lastN = N;
     if (viewCounts) for (int v = 0; v < nv; v++) viewCounts[v] = vc[v];
+    if (devPos) *devPos = (double *)L.posOut.p;
+    if (wantImg) {
+      // only the flagged images: their slices are known now (the counts came with the headers), one copy each, one more wait
+      std::vector<size_t> st(nimg + 1, 0), devStart(nimg + 1, 0);
+      for (int j = 0; j < nimg; j++) {
+        size_t n = 0;
+        for (int v = 0; v < nviews; v++) n += (size_t)vc[(size_t)j * nviews + v];
+        devStart[j + 1] = devStart[j] + n;
+        st[j + 1] = st[j] + (wantImg[j] ? n : 0);
+      }
+      regs.resize(st[nimg]);
+      bool any = false;
+      for (int j = 0; j < nimg; j++)
+        if (wantImg[j] && devStart[j + 1] > devStart[j]) {
+          MX_HIP(hipMemcpyAsync((char *)L.hRegs.p + st[j] * REG_B, (char *)L.regsOut.p + devStart[j] * REG_B,
+                                (devStart[j + 1] - devStart[j]) * REG_B, hipMemcpyDeviceToHost, s));
+          any = true;
+        }
+      if (any) { rc = comm_wait(cm, s); if (rc) return rc; }
+      if (st[nimg]) memcpy(regs.data(), L.hRegs.p, st[nimg] * REG_B);
+      if (regStart) *regStart = st;
+      return MODSX_OK;
+    }
     regs.resize(N);
     if (N > got) {           // the speculative download was short (first call, or a much larger image)
       MX_HIP(hipMemcpyAsync((char *)L.hRegs.p + got * REG_B, (char *)L.regsOut.p + got * REG_B, (N - got) * REG_B, hipMemcpyDeviceToHost, s));
@@ -576,6 +629,174 @@ int match_shard_gather(modsx_ctx *c, const MatchShard &sh, int local_rc, MatchRo
     }
   }
   return local_rc;
+}
+
+// MatchFlannFGINN for nb problems at once, each with its query rows split over the ranks: ONE all-gather moves the result rows of
+// all of them (block = header row + sum of the per-problem row shares), the problems share the matcher's launches four at a time.
+int match_sharded_batch(modsx_ctx *c, modsx_comm *cm, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2,
+                        const int *n2, const double *const *pos2Host, double ratioT, double contradDist, int nn,
+                        std::vector<modsx_tentative> *out, const double *const *pos2Dev) {
+  // pos2Dev (optional): the positions already live on the device (the exchange wrote them); pos2Host is then not read
+  for (int g = 0; g < nb; g++) out[g].clear();
+  if (cm->dead.load()) return comm_dead_rc(cm);
+  const double sqminratio = ratioT * ratioT, contrDistSq = contradDist * contradDist;
+  if (!(sqminratio < 1.0)) { set_error("match ratio >= 1 (PDF mode of MatchFlannFGINN) is not supported"); return MODSX_ERR_ARG; }
+  if (nn < 2 || nn > 64) { set_error("match: nn must be in [2, 64]"); return MODSX_ERR_ARG; }
+  const int W = cm->world, R = cm->rank;
+  hipStream_t s = c->stream;
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  // the row shares: every rank derives the same layout from the gathered counts
+  std::vector<int> per(nb), lo(nb), nloc(nb), off(nb);
+  int rowsTot = 0, n1Tot = 0;
+  size_t posB = 0, workB = 0;
+  std::vector<size_t> posOfs(nb), workOfs(nb);
+  for (int g = 0; g < nb; g++) {
+    const bool live = n1[g] > 0 && n2[g] > 0;
+    per[g] = live ? (n1[g] + W - 1) / W : 0;
+    lo[g] = std::min(n1[g], R * per[g]);
+    nloc[g] = live ? std::max(0, std::min(n1[g], lo[g] + per[g]) - lo[g]) : 0;
+    off[g] = 1 + rowsTot;
+    rowsTot += per[g]; n1Tot += live ? n1[g] : 0;
+    posOfs[g] = posB; posB += up((size_t)std::max(0, n2[g]) * 16);
+    workOfs[g] = workB; workB += up(match_workspace_bytes(std::max(1, nloc[g]), std::max(1, n2[g])));
+  }
+  if (rowsTot == 0) return MODSX_OK;       // the same on every rank: nobody issues a collective
+  MatchShard sh;
+  sh.comm = cm; sh.world = W; sh.per = rowsTot; sh.n1_total = n1Tot; sh.lo = 0;
+  MatchRow *blk = nullptr;
+  int rc = match_shard_begin(c, sh, &blk);
+  if (rc) return rc;
+  int lrc = MODSX_OK;
+  const size_t allB = (size_t)W * (rowsTot + 1) * sizeof(MatchRow);
+  if (!c->pos2.ensure(posB + 256) || !c->hMatch.ensure(posB + up(allB) + 256) || !c->matchWork.ensure(workB + 256)) lrc = MODSX_ERR_NOMEM;
+  char *hpos = (char *)c->hMatch.p, *hrow = hpos ? hpos + posB : nullptr;
+  if (!lrc && !pos2Dev) {
+    for (int g = 0; g < nb; g++) if (n2[g] > 0) memcpy(hpos + posOfs[g], pos2Host[g], (size_t)n2[g] * 16);
+    if (hipMemcpyAsync(c->pos2.p, hpos, posB, hipMemcpyHostToDevice, s) != hipSuccess) { set_error("sharded match: upload failed"); lrc = MODSX_ERR_DEVICE; }
+  }
+  if (!lrc) {
+    // live problems share the launches (blockIdx.z), MATCH_MAXB at a time
+    const uint8_t *pd1[MATCH_MAXB], *pd2[MATCH_MAXB];
+    const double *ppos[MATCH_MAXB];
+    MatchRow *prow[MATCH_MAXB];
+    void *pwork[MATCH_MAXB];
+    int pn1[MATCH_MAXB], pn2[MATCH_MAXB], k = 0;
+    double work = 0;
+    auto flush = [&]() {
+      if (!k) return;
+      size_t pslot;
+      prof_begin(c, K_MATCH, work, &pslot);
+      launch_match_batch(s, k, pd1, pn1, pd2, pn2, ppos, sqminratio, contrDistSq, nn, prow, pwork);
+      prof_end(c, pslot);
+      k = 0; work = 0;
+    };
+    for (int g = 0; g < nb; g++) {
+      if (nloc[g] <= 0) continue;
+      pd1[k] = d1[g] + (size_t)lo[g] * 128; pn1[k] = nloc[g]; pd2[k] = d2[g]; pn2[k] = n2[g];
+      ppos[k] = pos2Dev ? pos2Dev[g] : (const double *)((char *)c->pos2.p + posOfs[g]);
+      prow[k] = blk + off[g]; pwork[k] = (char *)c->matchWork.p + workOfs[g];
+      work += 2.0 * nloc[g] * (double)n2[g] * 128;
+      if (++k == MATCH_MAXB) flush();
+    }
+    flush();
+  }
+  rc = match_shard_gather(c, sh, lrc, lrc ? nullptr : (MatchRow *)hrow);
+  if (rc) return rc;
+  std::vector<MatchRow> rows;
+  for (int g = 0; g < nb; g++) {
+    if (per[g] <= 0) continue;
+    rows.resize((size_t)n1[g]);
+    for (int r = 0; r < W; r++) {
+      const int rlo = std::min(n1[g], r * per[g]), rn = std::min(n1[g], rlo + per[g]) - rlo;
+      if (rn > 0) memcpy(rows.data() + rlo, (const MatchRow *)hrow + (size_t)r * (rowsTot + 1) + off[g], (size_t)rn * sizeof(MatchRow));
+    }
+    rows_to_tentatives(rows.data(), n1[g], nn, out[g]);
+  }
+  return MODSX_OK;
+}
+
+// modsx_match_pairs_views_sharded: np pairs in ONE sharded call.  The views of all 2 np images are one item list (a rank's
+// launch sets are ~2 np nviews / world views again, whatever the world size), ONE exchange moves every image side, the np
+// matching problems of a descriptor class share ONE result all-gather, and pair g is verified by rank (owner_base + g) mod
+// world (owner_base < 0: by every rank).  Per pair the result is that of modsx_match_pair_views.
+int match_pairs_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *const *imgs1, const modsx_image *const *imgs2, int np,
+                              const modsx_view *views, int nv, const modsx_pair_params &pp, int owner_base, modsx_pair_result *results) {
+  for (int g = 0; g < np; g++) { memset(&results[g], 0, sizeof results[g]); for (int i = 0; i < 9; i++) results[g].H[i] = -1; }
+  DescSet ds;
+  int rc = resolve_descs(pp, nullptr, ds);
+  if (rc) return rc;
+  const int nimg = 2 * np;
+  std::vector<const modsx_image *> imgs(nimg);
+  for (int g = 0; g < np; g++) { imgs[2 * g] = imgs1[g]; imgs[2 * g + 1] = imgs2[g]; }
+  std::vector<modsx_region> regs;
+  std::vector<int> counts((size_t)nimg * nv, 0);
+  DevBuf *acc[MODSX_MAX_DESC];
+  size_t base0[MODSX_MAX_DESC] = {0, 0, 0, 0};
+  for (int k = 0; k < ds.n; k++) acc[k] = &c->descCls[0][k][0];      // scratch of this call: class slot k of the list
+  // the regions of a pair come to the host only on the rank that verifies it; the matcher's positions stay on the device
+  std::vector<unsigned char> want(nimg, 0);
+  for (int g = 0; g < np; g++) {
+    const bool mine = owner_base < 0 || (owner_base + g) % cm->world == cm->rank;
+    want[2 * g] = want[2 * g + 1] = mine ? 1 : 0;
+  }
+  std::vector<size_t> hs;      // slice of image j in `regs` (empty when not wanted)
+  double *devPos = nullptr;
+  rc = detect_describe_items_sharded(c, cm, imgs.data(), nimg, views, nv, pp, ds, regs, acc, base0, counts.data(), want.data(), &hs, &devPos);
+  if (rc) return rc;
+  // the slice of every image in the gathered (device) lists
+  std::vector<size_t> start(nimg + 1, 0);
+  for (int j = 0; j < nimg; j++) { size_t n = 0; for (int v = 0; v < nv; v++) n += (size_t)counts[(size_t)j * nv + v]; start[j + 1] = start[j] + n; }
+  // ids re-based per image (AddRegionsToList on a fresh representation)
+  for (int j = 0; j < nimg; j++) {
+    if (!want[j]) continue;
+    size_t at = hs[j];
+    for (int v = 0; v < nv; v++) {
+      const size_t cnt = (size_t)counts[(size_t)j * nv + v], rel = at - hs[j];
+      for (size_t i = 0; i < cnt; i++) { regs[at + i].id += (int)rel; regs[at + i].parent_id += (int)rel; }
+      at += cnt;
+    }
+  }
+  int ord[MODSX_MAX_DESC];
+  desc_class_order(ds, ord);
+  std::vector<std::vector<modsx_tentative>> tents(np);
+  std::vector<int> n1(np), n2(np);
+  std::vector<const double *> pdev(np);
+  for (int g = 0; g < np; g++) {
+    n1[g] = (int)(start[2 * g + 1] - start[2 * g]); n2[g] = (int)(start[2 * g + 2] - start[2 * g + 1]);
+    pdev[g] = devPos + 2 * start[2 * g + 1];
+  }
+  for (int oi = 0; oi < ds.n; oi++) {
+    const int k = ord[oi];
+    std::vector<const uint8_t *> d1(np), d2(np);
+    std::vector<std::vector<modsx_tentative>> part(np);
+    for (int g = 0; g < np; g++) {
+      d1[g] = (const uint8_t *)acc[k]->p + start[2 * g] * 128; d2[g] = (const uint8_t *)acc[k]->p + start[2 * g + 1] * 128;
+    }
+    rc = match_sharded_batch(c, cm, np, d1.data(), n1.data(), d2.data(), n2.data(), nullptr, ds.ratio[k], pp.contradDist, pp.nn, part.data(),
+                             pdev.data());
+    if (rc) return rc;
+    for (int g = 0; g < np; g++) {
+      const int o1 = oi * n1[g], o2 = oi * n2[g];
+      if (oi == 0) { tents[g].swap(part[g]); continue; }
+      for (modsx_tentative t : part[g]) {
+        t.q += o1; t.t0 += o2;
+        if (t.t1 >= 0) t.t1 += o2;
+        if (t.tj >= 0) t.tj += o2;
+        tents[g].push_back(t);
+      }
+    }
+  }
+  for (int g = 0; g < np; g++) {
+    modsx_pair_result *res = &results[g];
+    res->n_regions1 = n1[g] * ds.n; res->n_regions2 = n2[g] * ds.n;
+    res->n_tentatives = (int)tents[g].size();
+    if (owner_base >= 0 && (owner_base + g) % cm->world != cm->rank) continue;
+    RegList l1, l2;
+    for (int oi = 0; oi < ds.n; oi++) { l1.add(regs.data() + hs[2 * g], (size_t)n1[g]); l2.add(regs.data() + hs[2 * g + 1], (size_t)n2[g]); }
+    verify_tentatives(l1, l2, tents[g], pp, res);
+  }
+  prof_collect(c);
+  return MODSX_OK;
 }
 
 int match_pair_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *img1, const modsx_image *img2, const modsx_view *views,
@@ -673,7 +894,7 @@ int modsx_comm_set_lanes(modsx_comm *cm, int nlanes) {
   hipSetDevice(cm->dev);
   std::lock_guard<std::mutex> lk(cm->mu);
   for (ShardLane &L : cm->lanes) {
-    DevBuf *bufs[] = {&L.blkLocal, &L.blkAll, &L.regsIn, &L.regsOut, &L.mLocal, &L.mAll, &L.rcDev, &L.order};
+    DevBuf *bufs[] = {&L.blkLocal, &L.blkAll, &L.regsIn, &L.regsOut, &L.mLocal, &L.mAll, &L.rcDev, &L.order, &L.posOut};
     for (DevBuf *b : bufs) b->release();
     L.hRegs.release(); L.hHdr.release(); L.hRc.release();
   }
@@ -730,7 +951,7 @@ void modsx_comm_destroy(modsx_comm *cm) {
     cm->loop.reset();
   }
   for (ShardLane &L : cm->lanes) {
-    DevBuf *bufs[] = {&L.blkLocal, &L.blkAll, &L.regsIn, &L.regsOut, &L.mLocal, &L.mAll, &L.rcDev, &L.order};
+    DevBuf *bufs[] = {&L.blkLocal, &L.blkAll, &L.regsIn, &L.regsOut, &L.mLocal, &L.mAll, &L.rcDev, &L.order, &L.posOut};
     for (DevBuf *b : bufs) b->release();
     L.hRegs.release(); L.hHdr.release(); L.hRc.release();
   }
@@ -753,6 +974,125 @@ int modsx_comm_stats(const modsx_comm *cm, long *out, int n) {
   const int m = (int)(sizeof v / sizeof v[0]);
   for (int i = 0; i < n && i < m; i++) out[i] = v[i];
   return m;
+}
+
+/* The wire format of one exchange, stated on the host (what k_pack_rows / k_unpack_blocks do on the device; the GPU tests compare
+ * the two byte for byte, the gloo CPU tests run ranks over it without a device):
+ *   block = header {magic "MXSH", rc, rows, items, counts[items]} padded to 64 B, then `rows` records of
+ *           sizeof(modsx_region) + 128 * ndesc bytes (the region, then its descriptor of every class), then padding up to
+ *           block_rows records.
+ * modsx_shard_block_bytes: size of a block for `items` (image, view) items, block_rows rows and ndesc descriptor classes.
+ * modsx_shard_block_pack:  this rank's block from its regions (item order), descriptors (desc[k]: [n][128] u8 of class k) and
+ *                          per-item counts (counts[f] = 0 for items of other ranks); rows beyond block_rows are left out --
+ *                          the header still carries the true row count, which is how every rank sees that the block was too
+ *                          small.  Returns the bytes written.
+ * modsx_shard_blocks_unpack: the reference's list from the `world` gathered blocks: item f sits in the block of rank f mod world
+ *                          at that rank's running offset.  regs_out / desc_out[k]: capacity `cap` regions; item_counts: [items].
+ *                          Returns the list length, MODSX_ERR_CAPACITY (with *need_rows = the largest row count) when a block
+ *                          was too small, a rank's rc when its header carries one, MODSX_ERR_ARG on a malformed header. */
+long modsx_shard_block_bytes(int items, int block_rows, int ndesc) {
+  if (items < 1 || block_rows < 0 || ndesc < 1 || ndesc > MODSX_MAX_DESC) return MODSX_ERR_ARG;
+  return (long)hdr_bytes(items) + (long)block_rows * row_bytes(ndesc);
+}
+long modsx_shard_block_pack(const modsx_region *regs, const unsigned char *const *desc, int ndesc, int n, const int *counts, int items,
+                            int rc_local, int block_rows, void *block) {
+  if (!block || !counts || items < 1 || n < 0 || ndesc < 1 || ndesc > MODSX_MAX_DESC || (n > 0 && (!regs || !desc))) {
+    mx::set_error("modsx_shard_block_pack: bad argument");
+    return MODSX_ERR_ARG;
+  }
+  const int hdrB = hdr_bytes(items), ROW_B = row_bytes(ndesc);
+  unsigned char *b = (unsigned char *)block;
+  memset(b, 0, (size_t)hdrB + (size_t)block_rows * ROW_B);
+  int *h = (int *)b;
+  h[0] = HDR_MAGIC; h[1] = rc_local; h[2] = rc_local ? 0 : n; h[3] = items;
+  if (!rc_local) memcpy(h + HDR_FIXED, counts, (size_t)items * 4);
+  const int npack = rc_local ? 0 : std::min(n, block_rows);
+  for (int i = 0; i < npack; i++) {
+    unsigned char *row = b + hdrB + (size_t)i * ROW_B;
+    memcpy(row, regs + i, REG_B);
+    for (int k = 0; k < ndesc; k++) memcpy(row + REG_B + 128 * k, desc[k] + (size_t)i * 128, 128);
+  }
+  return (long)hdrB + (long)block_rows * ROW_B;
+}
+long modsx_shard_blocks_unpack(const void *blocks, int world, int items, int block_rows, int ndesc, modsx_region *regs_out,
+                               unsigned char *const *desc_out, long cap, int *item_counts, int *need_rows) {
+  if (!blocks || world < 1 || items < 1 || ndesc < 1 || ndesc > MODSX_MAX_DESC) { mx::set_error("modsx_shard_blocks_unpack: bad argument"); return MODSX_ERR_ARG; }
+  const int hdrB = hdr_bytes(items), ROW_B = row_bytes(ndesc);
+  const size_t blockB = (size_t)hdrB + (size_t)block_rows * ROW_B;
+  const unsigned char *all = (const unsigned char *)blocks;
+  int maxrows = 0;
+  for (int r = 0; r < world; r++) {
+    const int *h = (const int *)(all + r * blockB);
+    if (h[0] != HDR_MAGIC || h[3] != items) { mx::set_error("modsx_shard_blocks_unpack: malformed block header"); return MODSX_ERR_ARG; }
+    if (h[1]) { mx::set_error("rank " + std::to_string(r) + " reports a failure in its block header"); return h[1]; }
+    maxrows = std::max(maxrows, h[2]);
+  }
+  if (need_rows) *need_rows = maxrows;
+  if (maxrows > block_rows) { mx::set_error("modsx_shard_blocks_unpack: a block was too small (every rank sees this and repeats the exchange)"); return MODSX_ERR_CAPACITY; }
+  std::vector<int> run(world, 0);
+  long j = 0;
+  for (int f = 0; f < items; f++) {
+    const int r = f % world;
+    const int *h = (const int *)(all + r * blockB);
+    const int cnt = h[HDR_FIXED + f];
+    if (item_counts) item_counts[f] = cnt;
+    for (int i = 0; i < cnt; i++, j++) {
+      if (j >= cap) { mx::set_error("modsx_shard_blocks_unpack: output capacity"); return MODSX_ERR_CAPACITY; }
+      const unsigned char *row = all + r * blockB + hdrB + (size_t)(run[r] + i) * ROW_B;
+      if (regs_out) memcpy(regs_out + j, row, REG_B);
+      for (int k = 0; k < ndesc; k++) if (desc_out && desc_out[k]) memcpy(desc_out[k] + (size_t)j * 128, row + REG_B + 128 * k, 128);
+    }
+    run[r] += cnt;
+  }
+  return j;
+}
+/* test hook: the device kernels on host-provided data (needs a device): packs `n` regions + descriptors into a block with
+ * k_pack_rows, or orders `world` gathered blocks with k_unpack_blocks; outputs are copied back to the host */
+long modsx_shard_device_pack(modsx_ctx *ctx, const modsx_region *regs, const unsigned char *const *desc, int ndesc, int n, void *rows_out) {
+  if (!ctx || !regs || !desc || !rows_out || n < 1 || ndesc < 1 || ndesc > MODSX_MAX_DESC) { mx::set_error("modsx_shard_device_pack: bad argument"); return MODSX_ERR_ARG; }
+  hipSetDevice(ctx->dev);
+  hipStream_t s = ctx->stream;
+  DevBuf dr, dd, dout;
+  const int ROW_B = row_bytes(ndesc);
+  if (!dr.ensure((size_t)n * REG_B) || !dd.ensure((size_t)n * 128 * ndesc) || !dout.ensure((size_t)n * ROW_B)) return MODSX_ERR_NOMEM;
+  MX_HIP(hipMemcpyAsync(dr.p, regs, (size_t)n * REG_B, hipMemcpyHostToDevice, s));
+  DescPtrs dp;
+  for (int k = 0; k < MODSX_MAX_DESC; k++) dp.p[k] = nullptr;
+  for (int k = 0; k < ndesc; k++) {
+    dp.p[k] = (unsigned char *)dd.p + (size_t)k * n * 128;
+    MX_HIP(hipMemcpyAsync(dp.p[k], desc[k], (size_t)n * 128, hipMemcpyHostToDevice, s));
+  }
+  hipLaunchKernelGGL(k_pack_rows, dim3((n + 7) / 8), dim3(256), 0, s, (const unsigned char *)dr.p, dp, ndesc, n, (unsigned char *)dout.p);
+  MX_HIP(hipMemcpyAsync(rows_out, dout.p, (size_t)n * ROW_B, hipMemcpyDeviceToHost, s));
+  MX_HIP(hipStreamSynchronize(s));
+  dr.release(); dd.release(); dout.release();
+  return (long)n * ROW_B;
+}
+long modsx_shard_device_unpack(modsx_ctx *ctx, const void *blocks, int world, int items, int block_rows, int ndesc, modsx_region *regs_out,
+                               unsigned char *const *desc_out, double *pos_out, long cap) {
+  if (!ctx || !blocks || !regs_out || !desc_out || world < 1 || world > SHARD_MAXW || items < 1 || items > SHARD_MAXV || ndesc < 1 || ndesc > MODSX_MAX_DESC) {
+    mx::set_error("modsx_shard_device_unpack: bad argument");
+    return MODSX_ERR_ARG;
+  }
+  hipSetDevice(ctx->dev);
+  hipStream_t s = ctx->stream;
+  const int hdrB = hdr_bytes(items), ROW_B = row_bytes(ndesc);
+  const size_t blockB = (size_t)hdrB + (size_t)block_rows * ROW_B, rowsCap = (size_t)world * block_rows;
+  if ((size_t)cap < rowsCap) { mx::set_error("modsx_shard_device_unpack: cap must hold world * block_rows regions"); return MODSX_ERR_ARG; }
+  DevBuf din, dregs, ddesc, dpos;
+  if (!din.ensure(blockB * world) || !dregs.ensure(rowsCap * REG_B + 64) || !ddesc.ensure(rowsCap * 128 * ndesc + 64) || !dpos.ensure(rowsCap * 16 + 64)) return MODSX_ERR_NOMEM;
+  MX_HIP(hipMemcpyAsync(din.p, blocks, blockB * world, hipMemcpyHostToDevice, s));
+  MX_HIP(hipMemsetAsync(dregs.p, 0, rowsCap * REG_B, s));
+  DescPtrs dp;
+  for (int k = 0; k < MODSX_MAX_DESC; k++) dp.p[k] = k < ndesc ? (unsigned char *)ddesc.p + (size_t)k * rowsCap * 128 : nullptr;
+  hipLaunchKernelGGL(k_unpack_blocks, dim3((unsigned)((rowsCap + 7) / 8)), dim3(256), 0, s, (const unsigned char *)din.p, world, items, block_rows, blockB,
+                     hdrB, (unsigned char *)dregs.p, dp, ndesc, rowsCap, (double *)dpos.p, (int)offsetof(modsx_region, reproj_kp));
+  MX_HIP(hipMemcpyAsync(regs_out, dregs.p, rowsCap * REG_B, hipMemcpyDeviceToHost, s));
+  for (int k = 0; k < ndesc; k++) MX_HIP(hipMemcpyAsync(desc_out[k], dp.p[k], rowsCap * 128, hipMemcpyDeviceToHost, s));
+  if (pos_out) MX_HIP(hipMemcpyAsync(pos_out, dpos.p, rowsCap * 16, hipMemcpyDeviceToHost, s));
+  MX_HIP(hipStreamSynchronize(s));
+  din.release(); dregs.release(); ddesc.release(); dpos.release();
+  return (long)rowsCap;
 }
 
 int modsx_view_block_order(const int *counts, int world, int nviews, int *src, int cap, int *maxrows_out) {
@@ -816,6 +1156,20 @@ int modsx_match_pair_views_sharded(modsx_ctx *ctx, modsx_comm *comm, const modsx
   if (!ctx || !comm || !img1 || !img2 || !views || !par || !res || nviews <= 0) { mx::set_error("modsx_match_pair_views_sharded: bad argument"); return MODSX_ERR_ARG; }
   hipSetDevice(ctx->dev);
   return match_pair_views_sharded(ctx, comm, img1, img2, views, nviews, *par, owner, res);
+}
+
+int modsx_match_pairs_views_sharded(modsx_ctx *ctx, modsx_comm *comm, const modsx_image *const *imgs1, const modsx_image *const *imgs2,
+                                    int n_pairs, const modsx_view *views, int nviews, const modsx_pair_params *par, int owner_base,
+                                    modsx_pair_result *results) {
+  if (!ctx || !comm || !imgs1 || !imgs2 || !views || !par || !results || nviews <= 0 || n_pairs < 1 || n_pairs > 16) {
+    mx::set_error("modsx_match_pairs_views_sharded: bad argument (1..16 pairs per call)");
+    return MODSX_ERR_ARG;
+  }
+  for (int g = 0; g < n_pairs; g++) if (!imgs1[g] || !imgs2[g]) { mx::set_error("modsx_match_pairs_views_sharded: null image"); return MODSX_ERR_ARG; }
+  hipSetDevice(ctx->dev);
+  const int rc = match_pairs_views_sharded(ctx, comm, imgs1, imgs2, n_pairs, views, nviews, *par, owner_base, results);
+  if (rc) for (int g = 0; g < n_pairs; g++) modsx_pair_result_release(&results[g]);
+  return rc ? rc : n_pairs;
 }
 
 int modsx_match_ladder_sharded(modsx_ctx *ctx, modsx_comm *comm, const modsx_image *img1, const modsx_image *img2,

@@ -174,7 +174,7 @@ static int plan_view(const modsx_image *gray, const modsx_view &v, ViewPlan &P) 
 // Synthesises n views of `gray` in four launches (rotate all, blur rows all, blur columns all, tilt/zoom all).  Outputs go to
 // dst[i] (device, P[i].ow x P[i].oh floats; ignored for identity views).  No host wait: the job table and the taps travel
 // through pinned staging that is only rewritten after the caller's next synchronisation of the stream.
-static int synth_views_batch(modsx_ctx *c, const modsx_image *gray, const ViewPlan *P, float *const *dst, int n) {
+static int synth_views_batch(modsx_ctx *c, const modsx_image *const *grays, const ViewPlan *P, float *const *dst, int n) {
   hipStream_t s = c->stream;
   std::vector<ViewJob> jobs;
   std::vector<float> taps;
@@ -185,6 +185,7 @@ static int synth_views_batch(modsx_ctx *c, const modsx_image *gray, const ViewPl
     if (P[i].identity) continue;
     ViewJob j;
     memset(&j, 0, sizeof j);
+    const modsx_image *gray = grays[i];
     j.src = gray->d; j.srows = gray->rows; j.scols = gray->cols;
     j.rrows = P[i].h_rot; j.rcols = P[i].w_rot; j.drows = P[i].oh; j.dcols = P[i].ow;
     j.dst = dst[i];
@@ -252,20 +253,21 @@ int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx
   im->owned = true; im->d = nullptr;
   if (hipMalloc(&im->d, (size_t)P.ow * P.oh * 4) != hipSuccess) { delete im; set_error("hipMalloc view"); return MODSX_ERR_NOMEM; }
   float *dst[1] = {im->d};
-  rc = synth_views_batch(c, gray, &P, dst, 1);
+  rc = synth_views_batch(c, &gray, &P, dst, 1);
   if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("view synthesis failed"); rc = MODSX_ERR_DEVICE; }
   if (rc) { hipFree(im->d); delete im; return rc; }
   *out = im;
   return MODSX_OK;
 }
 
-// The per-view loop for views view_begin, view_begin+view_step, ... < nv.  Output regions carry
-// img_id = view index (0 for the identity view) and ids local to their view block; `viewCount[v]` gets the
-// number of described regions of view v (0 for views not taken).  Descriptors are written view block after
-// view block at devU8/devF (device, capacity devCapRegions) and optionally copied to hostDesc.
-int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_view *views, int nv,
-                          const modsx_pair_params &pp, int view_begin, int view_step, std::vector<modsx_region> &regs,
-                          float *devF, uint8_t *devU8, size_t devCapRegions, float *hostDesc, int *viewCounts,
+// The per-view loop over ITEMS = (source image, view) pairs, any mix of images in one launch set (the view-sharded path
+// batches the views a rank owns of several images / pairs: at world 8 a rank holds ~4 views per image, and launch sets of 4
+// views leave the device mostly idle).  Output regions carry img_id = view index (0 for the identity view) and ids local to
+// their item's block; `itemCounts[k]` gets the number of described regions of item k.  Descriptors are written item block
+// after item block at devU8/devF (device, capacity devCapRegions) and optionally copied to hostDesc.
+int detect_describe_items(modsx_ctx *c, const modsx_image *const *itemImg, const int *itemView, int nitems, const modsx_view *views,
+                          const modsx_pair_params &pp, std::vector<modsx_region> &regs,
+                          float *devF, uint8_t *devU8, size_t devCapRegions, float *hostDesc, int *itemCounts,
                           const DescSet *dsIn, uint8_t *const *devU8x) {
   regs.clear();
   // the step's descriptor classes: class 0 goes to devF / devU8 / hostDesc, class k >= 1 to devU8x[k - 1] (same capacity);
@@ -275,11 +277,10 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
   else { const int rd = resolve_descs(pp, nullptr, ds); if (rd) return rd; }
   const int oriHalf = ds.half() ? 1 : 0;
   if (!devU8x) { ds.forceHalf = oriHalf != 0; ds.n = 1; }
-  if (viewCounts) for (int v = 0; v < nv; v++) viewCounts[v] = 0;
-  if (view_step < 1) view_step = 1;
+  if (itemCounts) for (int k = 0; k < nitems; k++) itemCounts[k] = 0;
   struct SetScope { SetScope() { host_set_enter(); } ~SetScope() { host_set_leave(); } } setScope;
-  std::vector<int> take;
-  for (int v = view_begin; v < nv; v += view_step) take.push_back(v);
+  std::vector<int> take(nitems);
+  for (int k = 0; k < nitems; k++) take[k] = k;
   size_t total = 0;
   for (size_t g0 = 0; g0 < take.size(); g0 += MAXB) {
     const int n = (int)std::min<size_t>(MAXB, take.size() - g0);
@@ -291,8 +292,11 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
     for (int i = 0; i < n; i++) vimg[i] = nullptr;
     ViewPlan plans[MAXB];
     float *vdst[MAXB];
+    const modsx_image *gimg[MAXB];
     for (int i = 0; i < n && !rc; i++) {
-      const modsx_view &v = views[take[g0 + i]];
+      const modsx_image *gray = itemImg[take[g0 + i]];
+      gimg[i] = gray;
+      const modsx_view &v = views[itemView[take[g0 + i]]];
       rc = plan_view(gray, v, plans[i]);
       if (rc) break;
       for (int q = 0; q < 9; q++) Hs[i][q] = plans[i].H[q];
@@ -313,7 +317,7 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
     const bool tim2 = tim && atoi(getenv("MODSX_HOST_TIMING")) >= 2;
     double tq = 0;
     double t0 = tnow();
-    if (!rc) rc = synth_views_batch(c, gray, plans, vdst, n);
+    if (!rc) rc = synth_views_batch(c, gimg, plans, vdst, n);
     if (tim) hipStreamSynchronize(c->stream);
     double t1 = tnow();
     std::vector<modsx_keypoint> kps[MAXB];
@@ -345,7 +349,7 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
       const int detType = pp.detector == MODSX_DET_MSER ? MODSX_DET_MSER : MODSX_DET_HESSIAN;
       host_parallel_light(n, [&](int i) {
         r0[i].resize(kps[i].size());
-        detect_affine_regions(kps[i].data(), (int)kps[i].size(), ident[i] ? 0 : take[g0 + i], detType, r0[i].data());
+        detect_affine_regions(kps[i].data(), (int)kps[i].size(), ident[i] ? 0 : itemView[take[g0 + i]], detType, r0[i].data());
       });
       // DetectOrientation(..., HalfSIFT_like_desc, ...): one oriented list for every descriptor of the step
       // (imagerepresentation.cpp:1254-1268, 1288-1296)
@@ -360,7 +364,7 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
       uint8_t *dUx[3][MAXB];
       size_t ofs = total;
       host_parallel_light(n, [&](int i) {
-        int m = reproject_regions(ro[i].data(), (int)ro[i].size(), Hs[i], gray->cols, gray->rows);
+        int m = reproject_regions(ro[i].data(), (int)ro[i].size(), Hs[i], gimg[i]->cols, gimg[i]->rows);
         ro[i].resize(m);
       });
       for (int i = 0; i < n; i++) {
@@ -387,7 +391,7 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
               hipMemcpyAsync(hostDesc + total * 128, c->descF[i].p, ro[i].size() * 512, hipMemcpyDeviceToHost, c->stream);
             }
           }
-          if (viewCounts) viewCounts[take[g0 + i]] = (int)ro[i].size();
+          if (itemCounts) itemCounts[take[g0 + i]] = (int)ro[i].size();
         }
         {   // the set's regions behind the list, one copy task per view
           size_t at[MAXB + 1];
@@ -408,6 +412,24 @@ int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_vie
     if (rc) return rc;
   }
   return MODSX_OK;
+}
+
+// The per-view loop of ONE image for views view_begin, view_begin + view_step, ... < nv; `viewCounts[v]` gets the number of
+// described regions of view v (0 for views not taken).
+int detect_describe_views(modsx_ctx *c, const modsx_image *gray, const modsx_view *views, int nv,
+                          const modsx_pair_params &pp, int view_begin, int view_step, std::vector<modsx_region> &regs,
+                          float *devF, uint8_t *devU8, size_t devCapRegions, float *hostDesc, int *viewCounts,
+                          const DescSet *dsIn, uint8_t *const *devU8x) {
+  if (viewCounts) for (int v = 0; v < nv; v++) viewCounts[v] = 0;
+  if (view_step < 1) view_step = 1;
+  std::vector<const modsx_image *> im;
+  std::vector<int> vw;
+  for (int v = view_begin; v < nv; v += view_step) { im.push_back(gray); vw.push_back(v); }
+  std::vector<int> cnt(std::max<size_t>(1, vw.size()), 0);
+  const int rc = detect_describe_items(c, im.data(), vw.data(), (int)vw.size(), views, pp, regs, devF, devU8, devCapRegions, hostDesc,
+                                       cnt.data(), dsIn, devU8x);
+  if (viewCounts) for (size_t k = 0; k < vw.size(); k++) viewCounts[vw[k]] = cnt[k];
+  return rc;
 }
 
 // AddRegionsToList (imagerepresentation.cpp:588-600): ids of each appended view block are shifted by the size

@@ -52,6 +52,11 @@ class NativeComm:
         r = self.ctxs[w].match_pair_views_sharded(self.comm, img1, img2, views, params, owner)
         return r if owner < 0 or owner == self.rank else None
 
+    def match_pairs_views_sharded(self, w, imgs1, imgs2, views, params, owner_base=0, arrays=True):
+        """Up to 16 pairs in one sharded call on lane w: one exchange for all image sides, one result all-gather per descriptor
+        class; pair g is verified by rank (owner_base + g) % world.  Every rank gets the list of results (non-owners: counters only)."""
+        return self.ctxs[w].match_pairs_views_sharded(self.comm, imgs1, imgs2, views, params, owner_base, arrays)
+
     def match_ladder_sharded(self, w, img1, img2, steps, params, min_matches=10):
         return self.ctxs[w].match_ladder(img1, img2, steps, params, min_matches, comm=self.comm)
 

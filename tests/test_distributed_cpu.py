@@ -1,11 +1,15 @@
-"""CPU, world_size 2 over gloo: the view-shard exchange on RECORDED engine output.
+"""CPU, world sizes 2 and 3 over gloo: the view-shard exchange in the SHIPPED block format, on recorded engine output.
 
-The native path (csrc/engine_shard.hip) does, per image side: all-gather of the per-view counts, all-gather of the padded
-328-byte row blocks, then a gather into the reference's (view, detection) order given by modsx_view_block_order, then
-AddRegionsToList's id re-basing.  RCCL needs GPUs, so here the same three steps run over gloo on the blocks the engine
-produced for a small image (tests/golden/view_blocks_small.npz, written by tools/make_view_blocks_fixture.py on an MI355X):
-the ordering function is the library's own (host code, no device needed), and the result must be the engine's unsharded
-output, field for field.  Also covers the pair-shard bench plumbing (barrier, max-over-ranks time)."""
+One exchange of the native path (csrc/engine_shard.hip) = every rank packs a block (header {magic, rc, rows, items, per-item
+counts} + rows of region + descriptors, padded to the agreed block size), ONE all-gather of the blocks, then the reference's
+(image, view, detection) order is rebuilt from the gathered headers.  RCCL needs GPUs; here the ranks are gloo processes and the
+two data steps are the library's own host statements of the wire format -- modsx_shard_block_pack / modsx_shard_blocks_unpack,
+the functions the GPU tests hold the device kernels (k_pack_rows, k_unpack_blocks) against byte for byte.  Input: the per-view
+blocks the engine produced for a small image (tests/golden/view_blocks_small.npz, tools/make_view_blocks_fixture.py on an
+MI355X).  Covered: one image and a two-image item list (the batched pair call), one and two descriptor classes per row, the
+block-retry protocol (a first block size that is too small is seen by every rank in the headers; all grow alike and repeat), a
+failing rank (its rc travels in the header and every rank gets it), AddRegionsToList's id re-basing, and the bench plumbing
+(barrier, max-over-ranks time)."""
 import os
 import sys
 
@@ -31,55 +35,69 @@ def _blocks():
     return blocks, counts, ref, z["desc"]
 
 
-def _pack(regs, desc):
-    import mods_amd
-    n = len(regs)
-    rows = np.zeros((n, mods_amd.REGION.itemsize + 128), np.uint8)
-    if n:
-        rows[:, :mods_amd.REGION.itemsize] = np.frombuffer(np.ascontiguousarray(regs).tobytes(), np.uint8).reshape(n, -1)
-        rows[:, mods_amd.REGION.itemsize:] = desc
-    return rows
+def _exchange(mods_amd, rank, world, item_blocks, ndesc, first_rows, fail_rank=-1):
+    """One exchange as engine_shard.hip runs it: pack, all-gather, unpack; a block that was too small is repeated with the size every
+    rank derives from the gathered headers.  item_blocks[f] = (regs, desc) of item f.  Returns (regs, descs, counts, retries)."""
+    items = len(item_blocks)
+    mine = [f for f in range(items) if f % world == rank]
+    R = mods_amd.REGION
+    regs_l = np.concatenate([item_blocks[f][0] for f in mine]) if mine else np.zeros(0, R)
+    d0 = np.concatenate([item_blocks[f][1] for f in mine]) if mine else np.zeros((0, 128), np.uint8)
+    descs_l = [d0] + [np.ascontiguousarray(255 - d0) for _ in range(ndesc - 1)]      # class k > 0: a second, different descriptor
+    cnt = np.zeros(items, np.int32)
+    for f in mine:
+        cnt[f] = len(item_blocks[f][0])
+    rows, retries = first_rows, 0
+    while True:
+        blk = mods_amd.shard_block_pack(regs_l, descs_l, cnt, rows, rc_local=(-3 if rank == fail_rank else 0))
+        parts = [torch.zeros(len(blk), dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(blk))
+        allb = torch.cat(parts).numpy()
+        regs, descs, got = mods_amd.shard_blocks_unpack(allb, world, items, rows, ndesc)
+        if regs is None:                 # every rank sees the overflow in the same headers and takes the same new size
+            rows = got + got // 4 + 64
+            retries += 1
+            assert retries < 3
+            continue
+        return regs, descs, got, retries
+
+
+def _rebase(regs, counts):
+    starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    for v in range(len(counts)):
+        regs["id"][starts[v]:starts[v] + counts[v]] += starts[v]
+        regs["parent_id"][starts[v]:starts[v] + counts[v]] += starts[v]
+    return regs
 
 
 def _worker(rank, world, port, ret):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import mods_amd
-    from mods_amd import distributed as D
-    blocks, counts_ref, ref_regs, ref_desc = _blocks()
-    nviews = len(blocks)
-    mine = D.shard_views(nviews, rank, world)
-    rows_l = _pack(np.concatenate([blocks[v][0] for v in mine]), np.concatenate([blocks[v][1] for v in mine]))
-    cnt = np.zeros(nviews, np.int32)
-    for v in mine:
-        cnt[v] = len(blocks[v][0])
-    # 1. counts
-    allc = [torch.zeros(nviews, dtype=torch.int32) for _ in range(world)]
-    dist.all_gather(allc, torch.from_numpy(cnt))
-    counts = torch.stack(allc).numpy()
-    # 2. padded row blocks
-    src, maxrows = mods_amd.view_block_order(counts)
-    pad = np.zeros((maxrows, rows_l.shape[1]), np.uint8)
-    pad[:len(rows_l)] = rows_l
-    parts = [torch.zeros((maxrows, rows_l.shape[1]), dtype=torch.uint8) for _ in range(world)]
-    dist.all_gather(parts, torch.from_numpy(pad))
-    rows_all = torch.cat(parts).numpy()
-    # 3. reference order + id re-basing by view counts
-    rows = rows_all[src]
-    R = mods_amd.REGION
-    regs = np.frombuffer(np.ascontiguousarray(rows[:, :R.itemsize]).tobytes(), R, len(rows)).copy()
-    desc = np.ascontiguousarray(rows[:, R.itemsize:])
-    vc = np.array([counts[v % world, v] for v in range(nviews)])
-    starts = np.concatenate([[0], np.cumsum(vc)[:-1]])
-    for v in range(nviews):
-        regs["id"][starts[v]:starts[v] + vc[v]] += starts[v]
-        regs["parent_id"][starts[v]:starts[v] + vc[v]] += starts[v]
-    ok = np.array_equal(vc, counts_ref) and len(regs) == len(ref_regs) and np.array_equal(desc, ref_desc)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from common import same_records
-    ok = ok and same_records(regs, ref_regs)          # every field (struct padding bytes are not data)
+    blocks, counts_ref, ref_regs, ref_desc = _blocks()
+    nv = len(blocks)
+    ok = True
+    # 1. one image, one descriptor class, a first block size below every rank's row count: one retry, then the engine's list
+    regs, descs, cnt, retries = _exchange(mods_amd, rank, world, blocks, 1, first_rows=7)
+    ok = ok and retries == 1 and np.array_equal(cnt, counts_ref) and np.array_equal(descs[0], ref_desc)
+    ok = ok and same_records(_rebase(regs.copy(), cnt), ref_regs)
+    # 2. two images in one exchange (the batched pair call: items = image * nviews + view), two descriptor classes per row
+    two = blocks + blocks[::-1]
+    regs2, descs2, cnt2, retries2 = _exchange(mods_amd, rank, world, two, 2, first_rows=4096)
+    exp_regs = np.concatenate([b[0] for b in two]); exp_desc = np.concatenate([b[1] for b in two])
+    ok = ok and retries2 == 0 and np.array_equal(cnt2, [len(b[0]) for b in two])
+    ok = ok and same_records(regs2, exp_regs) and np.array_equal(descs2[0], exp_desc) and np.array_equal(descs2[1], 255 - exp_desc)
+    ok = ok and same_records(_rebase(regs2[:len(ref_regs)].copy(), cnt2[:nv]), ref_regs)        # image 0 of the item list
+    # 3. a failing rank: its rc travels in the header, every rank raises the same error from the same call
+    try:
+        _exchange(mods_amd, rank, world, blocks, 1, first_rows=4096, fail_rank=world - 1)
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "(-3)" in str(e)
     # bench plumbing: max-over-ranks of a per-rank time, sum of per-rank work
     t = torch.tensor([1.0 + rank, 10.0 * (rank + 1)], dtype=torch.float64)
     tmax, tsum = t.clone(), t.clone()
@@ -92,12 +110,50 @@ def _worker(rank, world, port, ret):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_view_shard_exchange_on_recorded_blocks(world):
+def test_view_shard_exchange_in_the_shipped_block_format(world):
     port = 29500 + (os.getpid() % 2000) + world
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_block_format_single_process():
+    """The host statement of the wire format without any transport: sizes, the header, a too-small block, capacity, and that the
+    ordering is the one modsx_view_block_order states."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import mods_amd
+    from common import same_records
+    blocks, counts_ref, ref_regs, ref_desc = _blocks()
+    nv, world = len(blocks), 3
+    assert mods_amd.shard_block_bytes(nv, 10, 1) == ((4 + nv) * 4 + 63) // 64 * 64 + 10 * 328
+    assert mods_amd.shard_block_bytes(nv, 10, 2) == ((4 + nv) * 4 + 63) // 64 * 64 + 10 * 456
+    allb, counts = [], np.zeros((world, nv), np.int32)
+    rows = int(max(sum(len(blocks[v][0]) for v in range(r, nv, world)) for r in range(world)))
+    for r in range(world):
+        mine = list(range(r, nv, world))
+        cnt = np.zeros(nv, np.int32)
+        for v in mine:
+            cnt[v] = counts[r, v] = len(blocks[v][0])
+        blk = mods_amd.shard_block_pack(np.concatenate([blocks[v][0] for v in mine]), [np.concatenate([blocks[v][1] for v in mine])], cnt, rows)
+        hdr = np.frombuffer(blk[:16].tobytes(), np.int32)
+        assert hdr[0] == 0x4D585348 and hdr[1] == 0 and hdr[2] == cnt.sum() and hdr[3] == nv
+        allb.append(blk)
+    regs, descs, cnt = mods_amd.shard_blocks_unpack(np.concatenate(allb), world, nv, rows, 1)
+    assert np.array_equal(cnt, counts_ref) and np.array_equal(descs[0], ref_desc)
+    # the same positions modsx_view_block_order names
+    src, maxrows = mods_amd.view_block_order(counts)
+    assert maxrows == rows
+    hdrB = mods_amd.shard_block_bytes(nv, 0, 1)
+    rows_all = np.concatenate([b[hdrB:].reshape(rows, 328) for b in allb])
+    by_order = np.frombuffer(np.ascontiguousarray(rows_all[src][:, :200]).tobytes(), mods_amd.REGION)
+    assert same_records(regs, by_order)          # field-wise (struct padding bytes are not data)
+    # too small a block: the header keeps the true count, the unpack reports what is needed
+    small = [mods_amd.shard_block_pack(np.concatenate([blocks[v][0] for v in range(r, nv, world)]),
+                                       [np.concatenate([blocks[v][1] for v in range(r, nv, world)])], counts[r], 5) for r in range(world)]
+    r_, d_, need = mods_amd.shard_blocks_unpack(np.concatenate(small), world, nv, 5, 1)
+    assert r_ is None and need == rows
 
 
 def test_view_block_order_and_sharding():

@@ -72,6 +72,88 @@ def test_sharded_equals_unsharded(ctx, modsx, small_pair, world):
     ia.free(); ib.free()
 
 
+@pytest.mark.parametrize("world,ndesc", [(2, 1), (3, 2), (8, 1)])
+def test_device_pack_and_order_kernels_equal_the_host_wire_format(ctx, modsx, small_pair, world, ndesc):
+    """k_pack_rows / k_unpack_blocks against modsx_shard_block_pack / modsx_shard_blocks_unpack (the host statement the gloo CPU
+    tests run ranks over): the rows a rank packs are the same bytes, and the device-side ordering of `world` gathered blocks gives
+    the same regions, descriptors (every class) and matcher positions as the host's."""
+    a = small_pair[0]
+    views = _views(modsx)
+    par = modsx.default_pair_params(ransac_seed=4)
+    ia = ctx.upload(a)
+    nv = len(views)
+    per_view = [ctx.detect_describe_views(ia, views, par, view_begin=v, view_step=nv) for v in range(nv)]
+    ia.free()
+    items = 2 * nv                        # two images' worth of items (the second: the views in reverse order)
+    blocks = per_view + per_view[::-1]
+    rows = 0
+    packs = []
+    for r in range(world):
+        mine = list(range(r, items, world))
+        regs = np.concatenate([blocks[f][0] for f in mine])
+        d0 = np.concatenate([blocks[f][1] for f in mine]).astype(np.uint8)
+        descs = [d0] + [np.ascontiguousarray(255 - d0)] * (ndesc - 1)
+        cnt = np.zeros(items, np.int32)
+        for f in mine:
+            cnt[f] = len(blocks[f][0])
+        packs.append((regs, descs, cnt))
+        rows = max(rows, len(regs))
+    allb = []
+    hdrB = modsx.shard_block_bytes(items, 0, ndesc)
+    for regs, descs, cnt in packs:
+        blk = modsx.shard_block_pack(regs, descs, cnt, rows)
+        dev_rows = ctx.shard_device_pack(regs, descs)
+        host_rows = blk[hdrB:].reshape(rows, -1)[:len(regs)]
+        # field-wise for the region part (struct padding is not data), bytes for the descriptors
+        assert same_records(np.frombuffer(np.ascontiguousarray(dev_rows[:, :200]).tobytes(), modsx.REGION),
+                            np.frombuffer(np.ascontiguousarray(host_rows[:, :200]).tobytes(), modsx.REGION))
+        assert np.array_equal(dev_rows[:, 200:], host_rows[:, 200:])
+        allb.append(blk)
+    allb = np.concatenate(allb)
+    h_regs, h_descs, h_cnt = modsx.shard_blocks_unpack(allb, world, items, rows, ndesc)
+    d_regs, d_descs, d_pos = ctx.shard_device_unpack(allb, world, items, rows, ndesc)
+    n = len(h_regs)
+    assert n == sum(len(b[0]) for b in blocks) and np.array_equal(h_cnt, [len(b[0]) for b in blocks])
+    assert same_records(d_regs[:n], h_regs)
+    for k in range(ndesc):
+        assert np.array_equal(d_descs[k][:n], h_descs[k])
+    assert np.array_equal(d_pos[:n, 0], h_regs["reproj_kp"]["x"]) and np.array_equal(d_pos[:n, 1], h_regs["reproj_kp"]["y"])
+
+
+@pytest.mark.parametrize("world,npairs", [(2, 3), (3, 5), (8, 4), (8, 1)])
+def test_batched_pairs_one_exchange_equals_single_pairs(ctx, modsx, small_pair, world, npairs):
+    """modsx_match_pairs_views_sharded: the views of all 2 n images travel in ONE exchange (items = (image, view), item f on rank
+    f mod world), the n matching problems in ONE result all-gather, pair g is verified on rank (1 + g) mod world.  Every pair's
+    result == modsx_match_pair_views of that pair (distinct pairs: the two images swapped, a cropped pair, ...), the call costs
+    2 data collectives whatever n, and non-owners carry the counters."""
+    from mods_amd import distributed as D
+    a, b, _ = small_pair
+    imgs = [a, b, a[:200, :300].copy(), b[:200, :300].copy(), np.ascontiguousarray(a[::-1]), b]
+    dev = [ctx.upload(x) for x in imgs]
+    pairs = [(0, 1), (1, 0), (2, 3), (4, 5), (0, 5)][:npairs]
+    views = _views(modsx)
+    par = modsx.default_pair_params(ransac_seed=4)
+    refs = [ctx.match_pair_views(dev[i], dev[j], views, par) for i, j in pairs]
+
+    def rank_body(r, comm):
+        before = comm.describe()["all_gather_calls_rank0"]
+        out = comm.match_pairs_views_sharded(0, [dev[i] for i, _ in pairs], [dev[j] for _, j in pairs], views, par, owner_base=1)
+        out2 = comm.match_pairs_views_sharded(0, [dev[i] for i, _ in pairs], [dev[j] for _, j in pairs], views, par, owner_base=-1)
+        info = comm.describe()
+        return out, out2, info["all_gather_calls_rank0"] - before - info["agreement_collectives"]
+
+    for r, (out, out2, ncoll) in enumerate(D.run_loopback(world, rank_body)):
+        assert ncoll <= 2 * 2 + 1, ncoll                     # per call: one exchange + one result all-gather (+ a block retry at most)
+        for g, ref in enumerate(refs):
+            _same_pair_result(out2[g], ref)
+            if (1 + g) % world == r:
+                _same_pair_result(out[g], ref)
+            else:
+                assert out[g]["n_regions"] == ref["n_regions"] and out[g]["n_tentatives"] == ref["n_tentatives"] and out[g]["n_verified"] == 0
+    for d in dev:
+        d.free()
+
+
 def test_sharded_block_retry_and_unbalanced_ranks(ctx, modsx, small_pair, monkeypatch):
     """A first block size far below a rank's row count: every rank sees the overflow in the gathered headers, all grow alike
     and repeat the exchange (and agree on the allocation)."""

@@ -1,5 +1,5 @@
 # usage: cpu_probe.sh "<env>" <bench args...>: pairs/s + host CPU seconds per pair + cgroup throttling of one bench run
-e="$1"; shift
+e="$1"; shift; [ "$e" = "-" ] && e="MODSX_NOOP=1"
 s0=$(grep -E "usage_usec|nr_throttled|throttled_usec" /sys/fs/cgroup/cpu.stat | awk '{print $2}' | tr '\n' ' ')
 out=$(env $e python bench.py --no-extra --no-cpu-baseline "$@" 2>/dev/null | tail -1)
 s1=$(grep -E "usage_usec|nr_throttled|throttled_usec" /sys/fs/cgroup/cpu.stat | awk '{print $2}' | tr '\n' ' ')
