@@ -254,6 +254,7 @@ void ctx_destroy(modsx_ctx *c) {
   for (int i = 0; i < MAXB; i++) { c->descF[i].release(); c->descU8[i].release(); c->viewImg[i].release(); for (int k = 0; k < 3; k++) c->descU8x[k][i].release(); }
   for (int d = 0; d < 2; d++) for (int t = 0; t < 4; t++) for (int sd = 0; sd < 2; sd++) c->descCls[d][t][sd].release();
   for (int t = 0; t < 4; t++) c->halfDesc[t].release();
+  c->candSort.release(); c->candOut.release();
   PinBuf *pins[] = {&c->hCand, &c->hAff, &c->hOri, &c->hDesc, &c->hMisc, &c->hNms, &c->hMatch, &c->hViewTaps, &c->hViewJobs, &c->hMser};
   for (PinBuf *b : pins) b->release();
   hipFree(c->dSmmMask); hipFree(c->dOriMask); hipFree(c->dOriIdx); hipFree(c->dSiftMask); hipFree(c->dSiftMaskIdx); hipFree(c->dAtan); hipFree(c->dOriBinTab); hipFree(c->dSiftOTab); hipFree(c->dSiftBins);
@@ -492,6 +493,85 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
       }
     }
   { int rcf = flush(true); if (rcf) return rcf; }
+  // MODSX_DEVICE_ORDER=1: detection order and the octaveMap claim on the device (kernels_cand.hip) -- the host receives the
+  // SURVIVING candidates in the reference's visiting order and only forms the scale (glibc powf) and the keypoint records.
+  // Built and bit-exact (tests/test_gpu_parity.py), but NOT the default: measured in round 4 it costs the 31-view bench 9 %
+  // (167 against 183.5 pairs/s) and a lone pair 0.5 ms (13.05 against 12.55 ms) -- key build, radix sort, two table fills, claim
+  // and compaction are six more small launches on every launch set's stream, while the host's radix sort + hash claim run on
+  // host cores that are otherwise idle and overlap the other contexts' device work.
+  static const bool deviceOrder = getenv("MODSX_DEVICE_ORDER") != nullptr && atoi(getenv("MODSX_DEVICE_ORDER")) != 0;
+  if (deviceOrder) {
+    if (!c->hMisc.ensure(64)) return MODSX_ERR_NOMEM;
+    for (int attempt = 0;; attempt++) {
+      // the sort runs over a host-chosen capacity (the device-side count is not known here): what the context's last set had
+      // (+ 1/4); a set that holds more is ordered again with its real count -- one more wait, as for the old download
+      const unsigned nsort = (unsigned)std::min<size_t>(CAND_CAP, attempt ? c->lastCandCount + 64 : c->lastCandCount + c->lastCandCount / 4 + 1024);
+      unsigned tabSize = 1024;
+      while (tabSize < 2 * nsort + 16) tabSize <<= 1;
+      auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+      const size_t tempB = cand_sort_temp_bytes(nsort);
+      const size_t oKeys = 0, oKeys2 = oKeys + up((size_t)nsort * 8), oIdx = oKeys2 + up((size_t)nsort * 8), oIdx2 = oIdx + up((size_t)nsort * 4),
+                   oSlot = oIdx2 + up((size_t)nsort * 4), oTabK = oSlot + up((size_t)nsort * 4), oTabR = oTabK + up((size_t)tabSize * 8),
+                   oTemp = oTabR + up((size_t)tabSize * 4), total = oTemp + up(tempB) + 256;
+      if (!c->candSort.ensure(total) || !c->candOut.ensure((size_t)nsort * sizeof(Candidate) + 64)) return MODSX_ERR_NOMEM;
+      char *w = (char *)c->candSort.p;
+      unsigned *survivors = (unsigned *)c->counter.p + 2;     // word 2 of the counter block (zeroed with it)
+      if (launch_cand_order(s, (const Candidate *)c->cand.p, (const unsigned *)c->counter.p, nsort, (unsigned long long *)(w + oKeys),
+                            (unsigned long long *)(w + oKeys2), (unsigned *)(w + oIdx), (unsigned *)(w + oIdx2), w + oTemp, tempB,
+                            (unsigned long long *)(w + oTabK), (unsigned *)(w + oTabR), tabSize, (unsigned *)(w + oSlot),
+                            (Candidate *)c->candOut.p, survivors)) { set_error("device-side detection order failed"); return MODSX_ERR_DEVICE; }
+      const size_t spec = std::min<size_t>(nsort, c->lastSurvivors + c->lastSurvivors / 4 + 1024);
+      if (!c->hCand.ensure(std::max<size_t>(spec, 1) * sizeof(Candidate))) return MODSX_ERR_NOMEM;
+      MX_HIP(hipMemcpyAsync(c->hMisc.p, c->counter.p, 12, hipMemcpyDeviceToHost, s));
+      MX_HIP(hipMemcpyAsync(c->hCand.p, c->candOut.p, spec * sizeof(Candidate), hipMemcpyDeviceToHost, s));
+      MX_HIP(hipStreamSynchronize(s));
+      const unsigned cnt = ((unsigned *)c->hMisc.p)[0], nsurv = ((unsigned *)c->hMisc.p)[2];
+      if (cnt > CAND_CAP || ((unsigned *)c->hMisc.p)[1]) { set_error("candidate buffer overflow"); return MODSX_ERR_NOMEM; }
+      c->lastCandCount = cnt;
+      if (cnt > nsort) {                       // the capacity was a guess and too small: once more with the count
+        if (attempt) { set_error("device-side detection order: capacity does not converge"); return MODSX_ERR_INTERNAL; }
+        continue;
+      }
+      c->lastSurvivors = nsurv;
+      if (nsurv > spec) {
+        if (!c->hCand.ensure((size_t)nsurv * sizeof(Candidate))) return MODSX_ERR_NOMEM;   // (re-allocation loses the first part: copy all)
+        MX_HIP(hipMemcpyAsync(c->hCand.p, c->candOut.p, (size_t)nsurv * sizeof(Candidate), hipMemcpyDeviceToHost, s));
+        MX_HIP(hipStreamSynchronize(s));
+      }
+      HostMark hm;
+      const Candidate *cd = (const Candidate *)c->hCand.p;
+      const SigmaPlan sp = make_sigma_plan(p);
+      // image-major, then (octave, level, row, column): one linear pass
+      std::vector<uint32_t> imgStart(n + 1, 0);
+      for (unsigned k = 0; k < nsurv; k++) {
+        if ((unsigned)cd[k].img >= (unsigned)n || (unsigned)cd[k].octave >= 32u) { set_error("candidate outside the image / octave range"); return MODSX_ERR_DEVICE; }
+        imgStart[cd[k].img + 1]++;
+      }
+      for (int i = 0; i < n; i++) imgStart[i + 1] += imgStart[i];
+      host_parallel_light(n, [&](int img) {
+        std::vector<modsx_sskp> &dst = out[img];
+        dst.clear();
+        dst.reserve(imgStart[img + 1] - imgStart[img]);
+        for (uint32_t k = imgStart[img]; k < imgStart[img + 1]; k++) {
+          const Candidate &q = cd[k];
+          const float pixelDistance = c->pyr[q.img].oct[q.octave].pixelDistance;
+          const float curScale = sp.curSigma[q.level];
+          float scale = curScale * powf(2.0f, q.b2 / p.numberOfScales);
+          modsx_sskp kp;
+          kp.octave = q.octave; kp.level = q.level; kp.r0 = q.r0; kp.c0 = q.c0; kp.r = q.r; kp.c = q.c; kp.type = q.type;
+          kp.pad = 0;
+          kp.b0 = q.b0; kp.b1 = q.b1; kp.b2 = q.b2; kp.val = q.val;
+          kp.x = pixelDistance * (q.c + q.b0);
+          kp.y = pixelDistance * (q.r + q.b1);
+          kp.s = pixelDistance * scale;
+          kp.pixelDistance = pixelDistance;
+          dst.push_back(kp);
+        }
+      });
+      hm.mark("sskp from ordered survivors");
+      return MODSX_OK;
+    }
+  }
   // the count and the candidates come down behind ONE wait: the records are copied speculatively, as many as the context's
   // last set had (+ 1/4); a set that holds more costs a second copy for the rest
   if (!c->hMisc.ensure(64)) return MODSX_ERR_NOMEM;

@@ -187,6 +187,10 @@ void launch_resize_half(hipStream_t s, const ResizeBatch &b, int nj, int maxRows
 void launch_nms(hipStream_t s, const NmsBatch &b, const NmsJob *jobs, const int *tilePrefix, const int *tileJob, int nj,
                 int nTiles, int4 *queue, unsigned *qcount, unsigned qcap, Candidate *out, unsigned *counter, unsigned cap,
                 const int *octFirst = nullptr, int levelsPerOctave = 0);
+size_t cand_sort_temp_bytes(unsigned nsort);
+int launch_cand_order(hipStream_t s, const Candidate *cand, const unsigned *counter, unsigned nsort, unsigned long long *keys,
+                      unsigned long long *keys2, unsigned *idx, unsigned *idx2, void *temp, size_t tempBytes, unsigned long long *tabKey,
+                      unsigned *tabRank, unsigned tabSize, unsigned *slotOf, Candidate *out, unsigned *outCount);
 constexpr int NMS_QUEUES = 64;      // sub-queues of the NMS extremum queue; counter k lives at counter[32 * (k + 1)]
 constexpr int NMS_TILE_ROWS = 16;   // rows of a 64-column NMS tile (kernels_pyramid.hip: NMS_ROWS)
 void launch_gray(hipStream_t s, const void *src, float *dst, size_t n, int channels, int dtype);
@@ -273,6 +277,8 @@ struct modsx_ctx {
   int dev;
   hipStream_t stream;
   mx::Pyramid pyr[mx::MAXB];
+  mx::DevBuf candSort, candOut;   // device-side detection order: keys / indices / hash table / temp storage, and the ordered survivors
+  size_t lastSurvivors = 0;
   mx::DevBuf nmsJobs, cand, counter, affJobs, affOut, oriJobs, oriOut, descJobs, tilePrefix, taps, imgRefs, scratchA, scratchB,
       descF[mx::MAXB], descU8[mx::MAXB], descAllF[2], descAllU8[2], descAllU8b[2], descCls[2][4][2], descU8x[3][mx::MAXB], shardLocal, pos2, matchRows, matchWork, misc, viewTmp[2], viewTaps, viewJobs, viewImg[mx::MAXB], scratchC, needTab, coordTab, tileJob, blurTiles, nmsQueue, rowStarts;
   mx::ImgRef imgRefsHost[mx::MAXB];   // what imgRefs holds on the device

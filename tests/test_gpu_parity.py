@@ -3,8 +3,12 @@
 Bar: bit-exact.  Every stage of this path ends in discrete decisions (extrema, thresholds, quantised
 descriptors, ratio tests, RANSAC samples), so the f32/f64 intermediates are compared for exact equality too.
 """
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from common import oracle_features, oracle_pair, laf_of, normH, same_records
 
@@ -319,6 +323,44 @@ def test_pair_end_to_end_epipolar_verification(ctx, modsx, oracle, small_pair):
     if (Fa * Fb).sum() < 0:
         Fb = -Fb
     assert np.abs(Fa - Fb).max() < 1e-6
+
+
+def test_device_side_detection_order_opt_in_is_bit_exact(oracle, small_pair):
+    """MODSX_DEVICE_ORDER=1 (kernels_cand.hip: device radix sort of the candidates + first-visitor claim of the converged pixel +
+    ordered compaction; off by default because it measured slower than the host's sort): the same keypoints as the oracle, in the
+    same order, for one image and for a multi-image launch set.  Runs in a child process (the switch is read once per process)."""
+    import json, os, subprocess, sys, tempfile
+    code = (
+        "import sys, json, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import mods_amd\n"
+        "from mods_amd import synthetic\n"
+        "from oracle import pyoracle as O\n"
+        "from common import same_records\n"
+        "a, b, _ = synthetic.make_pair(rows=240, cols=320, nblobs=420, seed=777)\n"
+        "ctx = mods_amd.Context(0)\n"
+        "ok = True\n"
+        "for img in (a, b, a):\n"
+        "    im = ctx.upload(img)\n"
+        "    for mode in (0, 4):\n"
+        "        ss = ctx.detect_scalespace(im, mods_amd.default_hessaff_params(mode=mode))\n"
+        "        ok = ok and same_records(ss, O.detect_scalespace(img, O.default_params(mode=mode)).view(mods_amd.SSKP))\n"
+        "        k = ctx.detect_affine_keypoints(im, mods_amd.default_hessaff_params(mode=mode))\n"
+        "        ok = ok and same_records(k, O.detect_hessaff(img, O.default_params(mode=mode)).view(mods_amd.KEYPOINT))\n"
+        "    im.free()\n"
+        "views = mods_amd.set_vs_pars([1.0], [1, 2, 3], 360.0, 0.2, 1, [])\n"
+        "vo = O.set_vs_pars([1.0], [1, 2, 3], 360.0, 0.2, 1, [])\n"
+        "im = ctx.upload(a)\n"
+        "r, d = ctx.detect_describe_views(im, views, mods_amd.default_pair_params())\n"
+        "rr, dd = O.detect_describe_views(a, vo)\n"
+        "ok = ok and same_records(r, rr.view(mods_amd.REGION)) and bool(np.array_equal(d, dd))\n"
+        "print(json.dumps({'ok': bool(ok), 'n': int(len(r))}))\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, MODSX_DEVICE_ORDER="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["n"] > 300
 
 
 def test_cat_pair_golden_counts(ctx, modsx, cat_pair):

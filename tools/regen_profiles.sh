@@ -7,6 +7,8 @@ TAG=${ROUND_TAG:-r04}
 OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# one context, one stream, whole launch sets: the lone-pair helpers (an image in three parts, image 2 on a peer context) are switched off
+export MODSX_PAIR_NOSPLIT=1 MODSX_PAIR_SERIAL=1
 ONE="--steps 2 --warmup 1 --workers 1 --batch 4 --no-cpu-baseline --no-extra"
 ONE1="--config views1 --steps 2 --warmup 1 --workers 1 --batch 8 --no-cpu-baseline --no-extra"
 run() { # tag, rocprof args..., -- command
