@@ -492,9 +492,12 @@ int modsx_match_pair_views_sharded(modsx_ctx *ctx, modsx_comm *comm, const modsx
 /* n_pairs (1..16) multi-view pairs in ONE sharded call -- what keeps the fixed costs of the exchange from growing with the world
  * size: the views of all 2 n_pairs images form one item list (item f = image * nviews + view belongs to rank f mod world), so a
  * rank's launch sets hold ~2 n_pairs nviews / world views whatever the world size; ONE all-gather moves the region rows +
- * descriptors of every image side, the n_pairs matching problems of a descriptor class share ONE all-gather of result rows, and
- * pair g is verified by rank (owner_base + g) mod world (owner_base < 0: by every rank; the other ranks fill the counters up to
- * n_tentatives).  results[g] is what modsx_match_pair_views returns for pair g.  Returns n_pairs. */
+ * descriptors of every image side.  owner_base >= 0: pair g is matched AND verified by rank (owner_base + g) mod world -- the
+ * exchange left all it needs there -- so the call holds ONE collective; results[g] is what modsx_match_pair_views returns for
+ * pair g on that rank, the other ranks fill n_regions1 / n_regions2 only.  owner_base < 0: every rank returns every pair (the
+ * query rows of the n_pairs problems of a descriptor class are split over the ranks, ONE all-gather of result rows per class).
+ * A rank that fails after the exchange (out of memory in its own matcher) returns the error alone; its peers meet the
+ * communicator's deadline at their next collective, as for a rank that died.  Returns n_pairs. */
 int modsx_match_pairs_views_sharded(modsx_ctx *ctx, modsx_comm *comm, const modsx_image *const *imgs1, const modsx_image *const *imgs2,
                                     int n_pairs, const modsx_view *views, int nviews, const modsx_pair_params *par, int owner_base,
                                     modsx_pair_result *results);

@@ -565,8 +565,8 @@ class Context(object):
         return _unpack_pair_result(res)
 
     def match_pairs_views_sharded(self, comm, imgs1, imgs2, views, params, owner_base=0, arrays=True):
-        """modsx_match_pairs_views_sharded: len(imgs1) <= 16 pairs in one sharded call; pair g is verified by rank
-        (owner_base + g) % world (owner_base < 0: by every rank).  Returns the list of per-pair results."""
+        """modsx_match_pairs_views_sharded: len(imgs1) <= 16 pairs in one sharded call; pair g is matched and verified by rank
+        (owner_base + g) % world alone (owner_base < 0: every rank returns every pair).  Returns the list of per-pair results."""
         n = len(imgs1)
         a1 = (C.c_void_p * n)(*[im.h for im in imgs1])
         a2 = (C.c_void_p * n)(*[im.h for im in imgs2])
@@ -735,7 +735,7 @@ def comm_loopback_id(world):
     return buf.raw
 
 
-COMM_STATS = ["collectives", "bytes_gathered", "block_retries", "agreements", "lanes", "loopback", "dead"]
+COMM_STATS = ["collectives", "bytes_gathered", "block_retries", "agreements", "lanes", "loopback", "dead", "turn_wait_us"]
 
 
 def comm_stats(comm):

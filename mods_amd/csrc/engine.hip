@@ -1330,7 +1330,8 @@ void rows_to_tentatives(const MatchRow *rows, int n1, int nn, std::vector<modsx_
 // independent (query set, train set) problems that share the kernel launches (blockIdx.z) and one synchronisation
 int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
                        const double *const *pos2Host, double ratioT, double contradDist, int nn,
-                       std::vector<modsx_tentative> *out, const MatchShard *shard) {
+                       std::vector<modsx_tentative> *out, const MatchShard *shard, const double *const *pos2Dev) {
+  // pos2Dev (optional, unsharded branch): the positions already live on the device; pos2Host is then not read
   if (nb < 1 || nb > MATCH_MAXB) { set_error("match_device_batch: batch size"); return MODSX_ERR_ARG; }
   hipStream_t s = c->stream;
   const double sqminratio = ratioT * ratioT, contrDistSq = contradDist * contradDist;
@@ -1397,13 +1398,13 @@ int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int
   for (int k = 0; k < nl; k++) {
     const int i = live[k];
     pd1[k] = d1[i]; pd2[k] = d2[i]; pn1[k] = n1[i]; pn2[k] = n2[i];
-    ppos[k] = (const double *)((char *)c->pos2.p + posOfs[k]);
+    ppos[k] = pos2Dev ? pos2Dev[i] : (const double *)((char *)c->pos2.p + posOfs[k]);
     prow[k] = (MatchRow *)((char *)c->matchRows.p + rowOfs[k]);
     pwork[k] = (char *)c->matchWork.p + workOfs[k];
-    memcpy(hpos + posOfs[k], pos2Host[i], (size_t)n2[i] * 16);
+    if (!pos2Dev) memcpy(hpos + posOfs[k], pos2Host[i], (size_t)n2[i] * 16);
     work += 2.0 * n1[i] * (double)n2[i] * 128;
   }
-  MX_HIP(hipMemcpyAsync(c->pos2.p, hpos, posB, hipMemcpyHostToDevice, s));
+  if (!pos2Dev) MX_HIP(hipMemcpyAsync(c->pos2.p, hpos, posB, hipMemcpyHostToDevice, s));
   {
     // K_MATCH = every launch of the problem(s); K_MATCH_SWEEP1 = the one launch that carries the 2 N M 128 contraction
     hipEvent_t evS1[2];

@@ -93,7 +93,7 @@ int match_sharded(modsx_ctx *c, modsx_comm *cm, const uint8_t *d1, int n1, const
                   double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out);
 int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
                        const double *const *pos2Host, double ratioT, double contradDist, int nn,
-                       std::vector<modsx_tentative> *out, const MatchShard *shard);
+                       std::vector<modsx_tentative> *out, const MatchShard *shard, const double *const *pos2Dev = nullptr);
 int match_device(modsx_ctx *c, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2Host,
                  double ratioT, double contradDist, int nn, std::vector<modsx_tentative> &out);
 int match_host_desc(modsx_ctx *c, const float *desc1, int n1, const float *desc2, int n2, const double *pos2,

@@ -152,6 +152,7 @@ struct modsx_comm {
   std::mutex issueMu;                       // serialises enqueueing on the RCCL communicator with its abort
   bool aborted = false;                     // under issueMu: ncclCommAbort has run; nccl is never used again
   long bytes_gathered = 0, collectives = 0, retries = 0, agreements = 0;
+  std::atomic<long> turn_wait_us{0};        // time the lanes spent waiting for their turn (modsx_comm_stats)
 };
 
 namespace mx {
@@ -189,10 +190,19 @@ static int comm_dead_rc(modsx_comm *cm) {
 }
 
 // round-robin issue order over the lanes that are still active
+// MODSX_SHARD_FREE_ORDER=1 (a measurement aid, honoured at world 1 only, where no peer has to see the same order): lanes issue as
+// they arrive -- the difference to the default run is what the fixed order costs
+static bool free_order(const modsx_comm *cm) {
+  static const bool on = getenv("MODSX_SHARD_FREE_ORDER") && atoi(getenv("MODSX_SHARD_FREE_ORDER")) != 0;
+  return on && cm->world == 1;
+}
 static int turn_begin(modsx_comm *cm, int lane) {
+  if (free_order(cm)) return cm->dead.load() ? comm_dead_rc(cm) : MODSX_OK;
   std::unique_lock<std::mutex> lk(cm->mu);
   const int tmo = std::max(cm->turn_timeout_ms.load(), cm->timeout_ms.load());
-  const auto deadline = Clock::now() + std::chrono::milliseconds(tmo);
+  const auto t0 = Clock::now();
+  const auto deadline = t0 + std::chrono::milliseconds(tmo);
+  struct Acc { modsx_comm *cm; Clock::time_point t0; ~Acc() { cm->turn_wait_us += std::chrono::duration_cast<std::chrono::microseconds>(Clock::now() - t0).count(); } } acc{cm, t0};
   while (!cm->dead.load() && cm->turn != lane) {
     if (cm->cv.wait_until(lk, deadline) == std::cv_status::timeout && cm->turn != lane && !cm->dead.load()) {
       const int ahead = cm->turn;
@@ -214,6 +224,7 @@ static void turn_advance_locked(modsx_comm *cm) {
   cm->cv.notify_all();
 }
 static void turn_end(modsx_comm *cm) {
+  if (free_order(cm)) return;
   std::lock_guard<std::mutex> lk(cm->mu);
   turn_advance_locked(cm);
 }
@@ -772,9 +783,29 @@ int match_pairs_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *c
     for (int g = 0; g < np; g++) {
       d1[g] = (const uint8_t *)acc[k]->p + start[2 * g] * 128; d2[g] = (const uint8_t *)acc[k]->p + start[2 * g + 1] * 128;
     }
-    rc = match_sharded_batch(c, cm, np, d1.data(), n1.data(), d2.data(), n2.data(), nullptr, ds.ratio[k], pp.contradDist, pp.nn, part.data(),
-                             pdev.data());
-    if (rc) return rc;
+    if (owner_base < 0) {
+      // every rank wants every pair: the query rows of each problem are split over the ranks, one all-gather of result rows
+      rc = match_sharded_batch(c, cm, np, d1.data(), n1.data(), d2.data(), n2.data(), nullptr, ds.ratio[k], pp.contradDist, pp.nn, part.data(),
+                               pdev.data());
+      if (rc) return rc;
+    } else {
+      // a pair is matched where it is verified: the exchange left every descriptor and position of it on this rank, so the owner
+      // runs the whole problem (with np = world pairs per call that is one problem per rank, the load the row split had) and NO
+      // second collective follows -- a lane's turn comes once per call, and the lanes keep the stagger a ring order allows
+      std::vector<int> mine;
+      for (int g = 0; g < np; g++) if ((owner_base + g) % cm->world == cm->rank) mine.push_back(g);
+      for (size_t m0 = 0; m0 < mine.size(); m0 += MATCH_MAXB) {
+        const int nm = (int)std::min<size_t>(MATCH_MAXB, mine.size() - m0);
+        const uint8_t *q1[MATCH_MAXB], *q2[MATCH_MAXB];
+        const double *qp[MATCH_MAXB];
+        int m1[MATCH_MAXB], m2[MATCH_MAXB];
+        std::vector<modsx_tentative> tmp[MATCH_MAXB];
+        for (int i = 0; i < nm; i++) { const int g = mine[m0 + i]; q1[i] = d1[g]; q2[i] = d2[g]; qp[i] = pdev[g]; m1[i] = n1[g]; m2[i] = n2[g]; }
+        rc = match_device_batch(c, nm, q1, m1, q2, m2, nullptr, ds.ratio[k], pp.contradDist, pp.nn, tmp, nullptr, qp);
+        if (rc) return rc;
+        for (int i = 0; i < nm; i++) part[mine[m0 + i]].swap(tmp[i]);
+      }
+    }
     for (int g = 0; g < np; g++) {
       const int o1 = oi * n1[g], o2 = oi * n2[g];
       if (oi == 0) { tents[g].swap(part[g]); continue; }
@@ -970,7 +1001,7 @@ int modsx_comm_info(const modsx_comm *cm, int *rank, int *world, int *rccl_versi
 
 int modsx_comm_stats(const modsx_comm *cm, long *out, int n) {
   if (!cm || !out) { mx::set_error("modsx_comm_stats: null"); return MODSX_ERR_ARG; }
-  const long v[] = {cm->collectives, cm->bytes_gathered, cm->retries, cm->agreements, (long)cm->lanes.size(), cm->loop ? 1L : 0L, cm->dead.load() ? 1L : 0L};
+  const long v[] = {cm->collectives, cm->bytes_gathered, cm->retries, cm->agreements, (long)cm->lanes.size(), cm->loop ? 1L : 0L, cm->dead.load() ? 1L : 0L, cm->turn_wait_us.load()};
   const int m = (int)(sizeof v / sizeof v[0]);
   for (int i = 0; i < n && i < m; i++) out[i] = v[i];
   return m;

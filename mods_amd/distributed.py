@@ -53,8 +53,9 @@ class NativeComm:
         return r if owner < 0 or owner == self.rank else None
 
     def match_pairs_views_sharded(self, w, imgs1, imgs2, views, params, owner_base=0, arrays=True):
-        """Up to 16 pairs in one sharded call on lane w: one exchange for all image sides, one result all-gather per descriptor
-        class; pair g is verified by rank (owner_base + g) % world.  Every rank gets the list of results (non-owners: counters only)."""
+        """Up to 16 pairs in one sharded call on lane w: one exchange for all image sides; pair g is matched and verified by rank
+        (owner_base + g) % world (non-owners: region counts only); owner_base < 0: every rank returns every pair (row-split
+        matching, one result all-gather per descriptor class)."""
         return self.ctxs[w].match_pairs_views_sharded(self.comm, imgs1, imgs2, views, params, owner_base, arrays)
 
     def match_ladder_sharded(self, w, img1, img2, steps, params, min_matches=10):
