@@ -449,29 +449,38 @@ int modsx_comm_lane_done(modsx_comm *comm, int lane);
 int modsx_comm_reset_lanes(modsx_comm *comm);
 int modsx_comm_set_timeout(modsx_comm *comm, int milliseconds);
 int modsx_comm_info(const modsx_comm *comm, int *rank, int *world, int *rccl_version, long *bytes_gathered, long *collectives);
-/* out[0..n): collectives issued, bytes gathered, block-size retries, agreement collectives, lanes, loopback (0/1), dead (0/1).
- * Returns the number of statistics available. */
+/* out[0..n): collectives issued, bytes gathered, block-size retries, agreement collectives, lanes, loopback (0/1), dead (0/1),
+ * microseconds the lanes waited for their turn to issue.  Returns the number of statistics available. */
 int modsx_comm_stats(const modsx_comm *comm, long *out, int n);
 /* Where row j of the reference's list sits in the all-gathered buffer (rank r's padded block starts at r * maxrows):
  * counts[r * nviews + v] = regions of view v on rank r (0 unless r == v mod world).  Returns the list length (host only). */
 int modsx_view_block_order(const int *counts, int world, int nviews, int *src, int cap, int *maxrows_out);
 /* The wire format of one exchange, stated on the host -- what the pack / ordering kernels of the sharded calls do on the device
  * (the GPU tests compare the two byte for byte; the gloo CPU tests run world 2 and 3 over these functions without a device):
- *   block = header {magic "MXSH", rc, rows, items, counts[items]} padded to 64 B, then rows of sizeof(modsx_region) + 128 * ndesc
- *           bytes (the region, then its descriptor of every class of the step), padded to block_rows rows.
+ *   block = header {magic "MXSH", rc, rows, items, counts[items]} padded to 64 B, then rows of R + 128 * ndesc bytes (the region
+ *           part, then the region's descriptor of every class of the step), padded to block_rows rows.
+ *   row_format MODSX_SHARD_ROW_REGION: R = sizeof(modsx_region) = 200, the whole region -- the calls that return region lists
+ *           (modsx_detect_describe_views_sharded, the ladder);
+ *   row_format MODSX_SHARD_ROW_KP: R = 56, the doubles x, y, a11, a12, a21, a22, s of the region's reproj_kp -- all that the
+ *           matcher (positions) and DuplicateFiltering / LO-RANSAC read of a region: modsx_match_pairs_views_sharded, which
+ *           returns pair results only (184 B per region and descriptor class on the wire instead of 328).
  * Items = (image, view) pairs, f = image * nviews + view; item f belongs to rank f mod world.
  * _bytes: size of a block.  _pack: this rank's block (counts[f] = 0 for items of other ranks; a block that is too small keeps
- * the true row count in its header).  _unpack: the reference's list from the `world` gathered blocks; returns its length,
- * MODSX_ERR_CAPACITY (*need_rows = the largest row count) when a block was too small, or the rc a rank's header carries. */
-long modsx_shard_block_bytes(int items, int block_rows, int ndesc);
+ * the true row count in its header).  _unpack: the reference's list from the `world` gathered blocks -- regs_out is
+ * modsx_region[cap] (ROW_REGION) or double[cap][7] (ROW_KP); returns its length, MODSX_ERR_CAPACITY (*need_rows = the largest
+ * row count) when a block was too small, or the rc a rank's header carries. */
+#define MODSX_SHARD_ROW_REGION 0
+#define MODSX_SHARD_ROW_KP 1
+long modsx_shard_block_bytes(int items, int block_rows, int ndesc, int row_format);
 long modsx_shard_block_pack(const modsx_region *regs, const unsigned char *const *desc, int ndesc, int n, const int *counts, int items,
-                            int rc_local, int block_rows, void *block);
-long modsx_shard_blocks_unpack(const void *blocks, int world, int items, int block_rows, int ndesc, modsx_region *regs_out,
+                            int rc_local, int block_rows, int row_format, void *block);
+long modsx_shard_blocks_unpack(const void *blocks, int world, int items, int block_rows, int ndesc, int row_format, void *regs_out,
                                unsigned char *const *desc_out, long cap, int *item_counts, int *need_rows);
 /* test hooks (need a device): the same two steps through the device kernels, outputs copied back to the host */
-long modsx_shard_device_pack(modsx_ctx *ctx, const modsx_region *regs, const unsigned char *const *desc, int ndesc, int n, void *rows_out);
-long modsx_shard_device_unpack(modsx_ctx *ctx, const void *blocks, int world, int items, int block_rows, int ndesc, modsx_region *regs_out,
-                               unsigned char *const *desc_out, double *pos_out, long cap);
+long modsx_shard_device_pack(modsx_ctx *ctx, const modsx_region *regs, const unsigned char *const *desc, int ndesc, int n, int row_format,
+                             void *rows_out);
+long modsx_shard_device_unpack(modsx_ctx *ctx, const void *blocks, int world, int items, int block_rows, int ndesc, int row_format,
+                               void *regs_out, unsigned char *const *desc_out, double *pos_out, long cap);
 /* SynthDetectDescribeKeypoints with this rank taking views rank, rank + world, ...: one all-gather of padded blocks
  * (header with the per-view counts + rows of modsx_region + 128 u8 descriptor bytes = 328 B), device to device; the
  * reference's order is rebuilt on the device from the gathered headers; every rank returns
@@ -491,8 +500,8 @@ int modsx_match_pair_views_sharded(modsx_ctx *ctx, modsx_comm *comm, const modsx
                                    modsx_pair_result *res);
 /* n_pairs (1..16) multi-view pairs in ONE sharded call -- what keeps the fixed costs of the exchange from growing with the world
  * size: the views of all 2 n_pairs images form one item list (item f = image * nviews + view belongs to rank f mod world), so a
- * rank's launch sets hold ~2 n_pairs nviews / world views whatever the world size; ONE all-gather moves the region rows +
- * descriptors of every image side.  owner_base >= 0: pair g is matched AND verified by rank (owner_base + g) mod world -- the
+ * rank's launch sets hold ~2 n_pairs nviews / world views whatever the world size; ONE all-gather moves the rows of every image
+ * side (MODSX_SHARD_ROW_KP: 56 B of geometry + the u8 descriptors of a region).  owner_base >= 0: pair g is matched AND verified by rank (owner_base + g) mod world -- the
  * exchange left all it needs there -- so the call holds ONE collective; results[g] is what modsx_match_pair_views returns for
  * pair g on that rank, the other ranks fill n_regions1 / n_regions2 only.  owner_base < 0: every rank returns every pair (the
  * query rows of the n_pairs problems of a descriptor class are split over the ranks, ONE all-gather of result rows per class).

@@ -104,6 +104,8 @@ EXPORTS_DEGENSAC = ["exp_ransacHcustom", "exp_ransacFcustom", "HDs", "HDsi", "HD
                     "HDsSymMax", "HDsiSymMax", "HDsSymidxMax", "FDs", "FDsSym", "exFDs", "exFDsSym",
                     "modsx_ransac_set_seed"]
 
+SHARD_ROW_REGION, SHARD_ROW_KP = 0, 1     # include/modsx.h: what of a region travels in a row (all 200 B / the 56 B verification slice)
+KP_FIELDS = ("x", "y", "a11", "a12", "a21", "a22", "s")
 KERNEL_CLASSES = ["blur_hess", "hessian", "resize", "nms_localize", "baumberg", "orientation", "patch_sample",
                   "blur_rows", "describe", "match_fginn", "gray", "warp_affine", "view_blur", "blur_cols", "match_sweep1"]
 
@@ -576,28 +578,29 @@ class Context(object):
                                                      int(owner_base), res), "match_pairs_views_sharded")
         return [_unpack_pair_result(res[i], arrays) for i in range(n)]
 
-    def shard_device_pack(self, regs, descs):
-        """k_pack_rows on host-provided regions + descriptors: the rows part of a block, [n, 200 + 128 * ndesc] u8."""
+    def shard_device_pack(self, regs, descs, row_format=SHARD_ROW_REGION):
+        """k_pack_rows on host-provided regions + descriptors: the rows part of a block, [n, R + 128 * ndesc] u8 (R = 200 or 56)."""
         L = lib()
         L.modsx_shard_device_pack.restype = C.c_long
         regs = np.ascontiguousarray(regs, REGION)
         descs = [np.ascontiguousarray(d, np.uint8) for d in descs]
-        out = np.zeros((len(regs), REGION.itemsize + 128 * len(descs)), np.uint8)
-        _check(L.modsx_shard_device_pack(self._c(), _p(regs), _ptr_array(descs), len(descs), len(regs), _p(out)), "shard_device_pack")
+        out = np.zeros((len(regs), shard_region_bytes(row_format) + 128 * len(descs)), np.uint8)
+        _check(L.modsx_shard_device_pack(self._c(), _p(regs), _ptr_array(descs), len(descs), len(regs), int(row_format), _p(out)),
+               "shard_device_pack")
         return out
 
-    def shard_device_unpack(self, blocks, world, items, block_rows, ndesc=1):
-        """k_unpack_blocks on gathered blocks: (regs [world * block_rows], [desc per class], pos [.., 2]) -- rows past the list's
-        end are zero."""
+    def shard_device_unpack(self, blocks, world, items, block_rows, ndesc=1, row_format=SHARD_ROW_REGION):
+        """k_unpack_blocks on gathered blocks: (regs [world * block_rows] -- REGION records, or [.., 7] f64 for SHARD_ROW_KP --,
+        [desc per class], pos [.., 2]); rows past the list's end are zero."""
         L = lib()
         L.modsx_shard_device_unpack.restype = C.c_long
         blocks = np.ascontiguousarray(blocks, np.uint8)
         cap = world * block_rows
-        regs = np.zeros(cap, REGION)
+        regs = np.zeros(cap, REGION) if row_format == SHARD_ROW_REGION else np.zeros((cap, 7), np.float64)
         descs = [np.zeros((cap, 128), np.uint8) for _ in range(ndesc)]
         pos = np.zeros((cap, 2), np.float64)
-        _check(L.modsx_shard_device_unpack(self._c(), _p(blocks), int(world), int(items), int(block_rows), int(ndesc), _p(regs),
-                                           _ptr_array(descs), _p(pos), C.c_long(cap)), "shard_device_unpack")
+        _check(L.modsx_shard_device_unpack(self._c(), _p(blocks), int(world), int(items), int(block_rows), int(ndesc), int(row_format),
+                                           _p(regs), _ptr_array(descs), _p(pos), C.c_long(cap)), "shard_device_unpack")
         return regs, descs, pos
 
     def detect_msers(self, img, params=None, tilt=1.0, zoom=1.0):
@@ -682,13 +685,23 @@ def _ptr_array(arrs):
     return (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
 
 
-def shard_block_bytes(items, block_rows, ndesc=1):
+def shard_region_bytes(row_format):
+    return REGION.itemsize if row_format == SHARD_ROW_REGION else 56
+
+
+def shard_kp_rows(regs):
+    """The SHARD_ROW_KP slice of a region array: [n, 7] f64 = x, y, a11, a12, a21, a22, s of reproj_kp."""
+    k = np.asarray(regs)["reproj_kp"]
+    return np.stack([k[f] for f in KP_FIELDS], 1).astype(np.float64) if len(k) else np.zeros((0, 7))
+
+
+def shard_block_bytes(items, block_rows, ndesc=1, row_format=SHARD_ROW_REGION):
     L = lib()
     L.modsx_shard_block_bytes.restype = C.c_long
-    return int(L.modsx_shard_block_bytes(int(items), int(block_rows), int(ndesc)))
+    return int(L.modsx_shard_block_bytes(int(items), int(block_rows), int(ndesc), int(row_format)))
 
 
-def shard_block_pack(regs, descs, counts, block_rows, rc_local=0):
+def shard_block_pack(regs, descs, counts, block_rows, rc_local=0, row_format=SHARD_ROW_REGION):
     """This rank's block of one exchange (host statement of the wire format): regs in item order, descs = list of [n, 128] u8
     arrays (one per descriptor class), counts[f] per (image, view) item.  Returns the block as a uint8 array."""
     L = lib()
@@ -696,26 +709,26 @@ def shard_block_pack(regs, descs, counts, block_rows, rc_local=0):
     regs = np.ascontiguousarray(regs, REGION)
     descs = [np.ascontiguousarray(d, np.uint8) for d in descs]
     counts = np.ascontiguousarray(counts, np.int32)
-    out = np.zeros(shard_block_bytes(len(counts), block_rows, len(descs)), np.uint8)
+    out = np.zeros(shard_block_bytes(len(counts), block_rows, len(descs), row_format), np.uint8)
     n = _check(L.modsx_shard_block_pack(_p(regs), _ptr_array(descs), len(descs), len(regs), _p(counts), len(counts), int(rc_local),
-                                        int(block_rows), _p(out)), "shard_block_pack")
+                                        int(block_rows), int(row_format), _p(out)), "shard_block_pack")
     assert n == len(out)
     return out
 
 
-def shard_blocks_unpack(blocks, world, items, block_rows, ndesc=1, cap=None):
-    """The reference's list from `world` gathered blocks (host): (regs, [desc per class], item_counts).  Raises on a failed rank;
-    returns (None, None, need_rows) when a block was too small."""
+def shard_blocks_unpack(blocks, world, items, block_rows, ndesc=1, cap=None, row_format=SHARD_ROW_REGION):
+    """The reference's list from `world` gathered blocks (host): (regs -- REGION records, or [n, 7] f64 for SHARD_ROW_KP --,
+    [desc per class], item_counts).  Raises on a failed rank; returns (None, None, need_rows) when a block was too small."""
     L = lib()
     L.modsx_shard_blocks_unpack.restype = C.c_long
     blocks = np.ascontiguousarray(blocks, np.uint8)
     cap = int(cap if cap is not None else world * block_rows)
-    regs = np.zeros(max(1, cap), REGION)
+    regs = np.zeros(max(1, cap), REGION) if row_format == SHARD_ROW_REGION else np.zeros((max(1, cap), 7), np.float64)
     descs = [np.zeros((max(1, cap), 128), np.uint8) for _ in range(ndesc)]
     cnt = np.zeros(items, np.int32)
     need = C.c_int(0)
-    n = L.modsx_shard_blocks_unpack(_p(blocks), int(world), int(items), int(block_rows), int(ndesc), _p(regs), _ptr_array(descs),
-                                    C.c_long(cap), _p(cnt), C.byref(need))
+    n = L.modsx_shard_blocks_unpack(_p(blocks), int(world), int(items), int(block_rows), int(ndesc), int(row_format), _p(regs),
+                                    _ptr_array(descs), C.c_long(cap), _p(cnt), C.byref(need))
     if n == -5:      # MODSX_ERR_CAPACITY
         return None, None, need.value
     _check(n, "shard_blocks_unpack")

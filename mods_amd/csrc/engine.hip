@@ -1465,15 +1465,18 @@ void verify_tentatives(const std::vector<modsx_region> &r1, const std::vector<mo
   a.add(r1); b.add(r2);
   verify_tentatives(a, b, tents, pp, res);
 }
-void verify_tentatives(const RegList &r1, const RegList &r2, const std::vector<modsx_tentative> &tents,
-                       const modsx_pair_params &pp, modsx_pair_result *res) {
+// kp1(i) / kp2(i): the seven doubles x, y, a11, a12, a21, a22, s of region i's reproj_kp -- all that DuplicateFiltering and
+// LO-RANSAC read of a region
+template <class K1, class K2>
+static void verify_core(const K1 &kp1, const K2 &kp2, const std::vector<modsx_tentative> &tents, const modsx_pair_params &pp,
+                        modsx_pair_result *res) {
   HostMark hm;
   res->n_tentatives = (int)tents.size();
   const int T0 = (int)tents.size();
   std::vector<double> pts((size_t)T0 * 4 + 4), key(T0 + 1);
   for (int i = 0; i < T0; i++) {
-    const modsx_keypoint &a = r1[tents[i].q].reproj_kp, &b = r2[tents[i].t0].reproj_kp;
-    pts[4 * i] = a.x; pts[4 * i + 1] = a.y; pts[4 * i + 2] = b.x; pts[4 * i + 3] = b.y;
+    const double *a = kp1(tents[i].q), *b = kp2(tents[i].t0);
+    pts[4 * i] = a[0]; pts[4 * i + 1] = a[1]; pts[4 * i + 2] = b[0]; pts[4 * i + 3] = b[1];
     key[i] = tents[i].ratio;
   }
   hm.mark("verify: points");
@@ -1487,10 +1490,9 @@ void verify_tentatives(const RegList &r1, const RegList &r2, const std::vector<m
   res->n_unique = T;
   std::vector<double> p2((size_t)T * 4 + 4), l1((size_t)T * 5 + 5), l2((size_t)T * 5 + 5);
   for (int i = 0; i < T; i++) {
-    const modsx_keypoint &a = r1[uniq[i].q].reproj_kp, &b = r2[uniq[i].t0].reproj_kp;
-    p2[4 * i] = a.x; p2[4 * i + 1] = a.y; p2[4 * i + 2] = b.x; p2[4 * i + 3] = b.y;
-    l1[5 * i] = a.a11; l1[5 * i + 1] = a.a12; l1[5 * i + 2] = a.a21; l1[5 * i + 3] = a.a22; l1[5 * i + 4] = a.s;
-    l2[5 * i] = b.a11; l2[5 * i + 1] = b.a12; l2[5 * i + 2] = b.a21; l2[5 * i + 3] = b.a22; l2[5 * i + 4] = b.s;
+    const double *a = kp1(uniq[i].q), *b = kp2(uniq[i].t0);
+    p2[4 * i] = a[0]; p2[4 * i + 1] = a[1]; p2[4 * i + 2] = b[0]; p2[4 * i + 3] = b[1];
+    for (int k = 0; k < 5; k++) { l1[5 * i + k] = a[2 + k]; l2[5 * i + k] = b[2 + k]; }
   }
   res->tentatives = (modsx_tentative *)malloc(sizeof(modsx_tentative) * std::max(1, T));
   res->ransac_inlier = (unsigned char *)calloc(std::max(1, T), 1);
@@ -1513,6 +1515,18 @@ void verify_tentatives(const RegList &r1, const RegList &r2, const std::vector<m
   res->n_ransac_inliers = 0;
   for (int i = 0; i < T; i++) res->n_ransac_inliers += res->ransac_inlier[i];
   res->ransac_samples = dout[0]; res->ransac_lo = dout[1];
+}
+
+void verify_tentatives(const RegList &r1, const RegList &r2, const std::vector<modsx_tentative> &tents,
+                       const modsx_pair_params &pp, modsx_pair_result *res) {
+  static_assert(offsetof(modsx_keypoint, x) == 0 && offsetof(modsx_keypoint, s) == 48, "x, y, a11, a12, a21, a22, s are seven consecutive doubles");
+  verify_core([&](size_t i) { return &r1[i].reproj_kp.x; }, [&](size_t i) { return &r2[i].reproj_kp.x; }, tents, pp, res);
+}
+// The same on geometry rows (kp[7 i ..]: what the view-sharded pair call moves instead of whole regions).  The list of a step with
+// several descriptor classes repeats its n regions once per class (index = class * n + region), as the RegList of such a step does.
+void verify_tentatives_kp(const double *kp1, size_t n1, const double *kp2, size_t n2, const std::vector<modsx_tentative> &tents,
+                          const modsx_pair_params &pp, modsx_pair_result *res) {
+  verify_core([&](size_t i) { return kp1 + 7 * (n1 ? i % n1 : 0); }, [&](size_t i) { return kp2 + 7 * (n2 ? i % n2 : 0); }, tents, pp, res);
 }
 
 // One step of mods.cpp's loop (identity view) for G <= MAXB / 2 independent pairs at once: the 2G images go through

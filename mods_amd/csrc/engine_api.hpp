@@ -84,7 +84,7 @@ int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
 int detect_describe_items_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *const *imgs, int nimg, const modsx_view *views,
                                   int nviews, const modsx_pair_params &pp, const DescSet &ds, std::vector<modsx_region> &regs,
                                   DevBuf *const *descAcc, const size_t *base, int *itemCounts, const unsigned char *wantImg = nullptr,
-                                  std::vector<size_t> *regStart = nullptr, double **devPos = nullptr);
+                                  std::vector<size_t> *regStart = nullptr, double **devPos = nullptr, std::vector<double> *kpRows = nullptr);
 void rows_to_tentatives(const MatchRow *rows, int n1, int nn, std::vector<modsx_tentative> &o);
 int comm_rank(const modsx_comm *cm);
 int comm_world(const modsx_comm *cm);
@@ -119,6 +119,8 @@ void verify_tentatives(const RegList &r1, const RegList &r2, const std::vector<m
                        const modsx_pair_params &pp, modsx_pair_result *res);
 void verify_tentatives(const std::vector<modsx_region> &r1, const std::vector<modsx_region> &r2,
                        const std::vector<modsx_tentative> &tents, const modsx_pair_params &pp, modsx_pair_result *res);
+void verify_tentatives_kp(const double *kp1, size_t n1, const double *kp2, size_t n2, const std::vector<modsx_tentative> &tents,
+                          const modsx_pair_params &pp, modsx_pair_result *res);
 // A pair whose tentatives are matched but not yet verified: modsx_match_pairs hands these to helper threads so that a
 // context's stream is fed the next group while the host runs DuplicateFiltering + LO-RANSAC of this one.  The task owns the
 // region vectors its two lists point into (moving a vector keeps its heap block, so the segments stay valid).

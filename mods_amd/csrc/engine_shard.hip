@@ -159,7 +159,17 @@ namespace mx {
 
 constexpr int REG_B = (int)sizeof(modsx_region);
 static_assert(sizeof(modsx_region) == 200, "region rows are 200 + 128 bytes per descriptor class on the wire");
-static inline __host__ __device__ int row_bytes(int nd) { return REG_B + 128 * nd; }   // nd = descriptor classes of the step
+// What of a region travels in a row: the whole modsx_region (the calls that return region lists), or the seven geometry doubles
+// of its reproj_kp -- x, y, a11, a12, a21, a22, s: the matcher's positions and everything DuplicateFiltering / LO-RANSAC read
+// (verify_tentatives) -- for the calls that return pair results only.  regLen is a multiple of 8.
+struct RowFmt { int regOff, regLen, posOfs; };
+constexpr int KP_B = 7 * (int)sizeof(double);
+static_assert(offsetof(modsx_keypoint, s) == 6 * sizeof(double), "x, y, a11, a12, a21, a22, s lead modsx_keypoint");
+static RowFmt row_fmt(int format) {
+  if (format == MODSX_SHARD_ROW_KP) return RowFmt{(int)offsetof(modsx_region, reproj_kp), KP_B, 0};
+  return RowFmt{0, REG_B, (int)offsetof(modsx_region, reproj_kp)};
+}
+static inline __host__ __device__ int row_bytes(int regLen, int nd) { return regLen + 128 * nd; }   // nd = descriptor classes of the step
 struct DescPtrs { unsigned char *p[MODSX_MAX_DESC]; };
 constexpr int HDR_MAGIC = 0x4D585348;   // "MXSH"
 constexpr int HDR_FIXED = 4;            // ints before the per-view counts: magic, rc, rows, views
@@ -336,14 +346,14 @@ int comm_same_value(modsx_ctx *c, modsx_comm *cm, int value, const char *what) {
   return MODSX_OK;
 }
 
-// block = header + rows; rows[i] = region i (REG_B bytes, 8-byte words) followed by its 128 descriptor bytes
-__global__ void k_pack_rows(const unsigned char *regs, DescPtrs desc, int nd, int n, unsigned char *rows) {
+// block = header + rows; rows[i] = region record i (regLen bytes of `regs`, 8-byte words) followed by its 128 descriptor bytes
+__global__ void k_pack_rows(const unsigned char *regs, int regLen, DescPtrs desc, int nd, int n, unsigned char *rows) {
   const int i = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
   if (i >= n) return;
-  unsigned char *dst = rows + (size_t)i * row_bytes(nd);
-  if (l < REG_B / 8) reinterpret_cast<uint64_t *>(dst)[l] = reinterpret_cast<const uint64_t *>(regs + (size_t)i * REG_B)[l];
+  unsigned char *dst = rows + (size_t)i * row_bytes(regLen, nd);
+  if (l < regLen / 8) reinterpret_cast<uint64_t *>(dst)[l] = reinterpret_cast<const uint64_t *>(regs + (size_t)i * regLen)[l];
   for (int k = 0; k < nd; k++)
-    if (l < 16) reinterpret_cast<uint64_t *>(dst + REG_B + 128 * k)[l] = reinterpret_cast<const uint64_t *>(desc.p[k] + (size_t)i * 128)[l];
+    if (l < 16) reinterpret_cast<uint64_t *>(dst + regLen + 128 * k)[l] = reinterpret_cast<const uint64_t *>(desc.p[k] + (size_t)i * 128)[l];
 }
 
 // The reference's order from the gathered blocks, on the device: view v is rank v mod W's, at that rank's running offset;
@@ -351,7 +361,8 @@ __global__ void k_pack_rows(const unsigned char *regs, DescPtrs desc, int nd, in
 // (rank r, row i < G); every workgroup rebuilds the two small prefix tables from the W headers in LDS.
 constexpr int SHARD_MAXV = 1024, SHARD_MAXW = 64;
 __global__ __launch_bounds__(256) void k_unpack_blocks(const unsigned char *all, int W, int nv, int G, size_t blockB, int hdrB,
-                                                       unsigned char *regs, DescPtrs desc, int nd, size_t cap, double *pos, int posOfs) {
+                                                       unsigned char *regs, int regLen, DescPtrs desc, int nd, size_t cap, double *pos,
+                                                       int posOfs) {
   __shared__ int viewStart[SHARD_MAXV], runStart[SHARD_MAXV], cnt[SHARD_MAXV], run[SHARD_MAXW];
   for (int v = threadIdx.x; v < nv; v += 256) {
     const int *h = reinterpret_cast<const int *>(all + (size_t)(v % W) * blockB);
@@ -372,12 +383,12 @@ __global__ __launch_bounds__(256) void k_unpack_blocks(const unsigned char *all,
   while (v + W < nv && runStart[v + W] <= i) v += W;     // views of rank r in ascending order; an empty one shares its start with the next
   const size_t j = (size_t)viewStart[v] + (i - runStart[v]);
   if (j >= cap) return;
-  const unsigned char *s = all + (size_t)r * blockB + hdrB + (size_t)i * row_bytes(nd);
-  if (l < REG_B / 8) reinterpret_cast<uint64_t *>(regs + j * REG_B)[l] = reinterpret_cast<const uint64_t *>(s)[l];
+  const unsigned char *s = all + (size_t)r * blockB + hdrB + (size_t)i * row_bytes(regLen, nd);
+  if (l < regLen / 8) reinterpret_cast<uint64_t *>(regs + j * regLen)[l] = reinterpret_cast<const uint64_t *>(s)[l];
   // reproj_kp.x, .y of every region as the matcher's pos2 array: ranks that do not verify a pair never bring its regions to the host
   if (pos && l < 2) pos[2 * j + l] = reinterpret_cast<const double *>(s + posOfs)[l];
   for (int k = 0; k < nd; k++)
-    if (l < 16) reinterpret_cast<uint64_t *>(desc.p[k] + j * 128)[l] = reinterpret_cast<const uint64_t *>(s + REG_B + 128 * k)[l];
+    if (l < 16) reinterpret_cast<uint64_t *>(desc.p[k] + j * 128)[l] = reinterpret_cast<const uint64_t *>(s + regLen + 128 * k)[l];
 }
 
 // Position of every row of the reference's list inside the all-gathered buffer (the host statement of what
@@ -421,7 +432,7 @@ static int grow_keep(hipStream_t s, DevBuf &b, size_t keep, size_t bytes) {
 int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *img, const modsx_view *views, int nv,
                                   const modsx_pair_params &pp, const DescSet &ds, std::vector<modsx_region> &regs,
                                   DevBuf *const *descAcc, const size_t *base, int *viewCounts) {
-  return detect_describe_items_sharded(c, cm, &img, 1, views, nv, pp, ds, regs, descAcc, base, viewCounts, nullptr, nullptr, nullptr);
+  return detect_describe_items_sharded(c, cm, &img, 1, views, nv, pp, ds, regs, descAcc, base, viewCounts, nullptr, nullptr, nullptr, nullptr);
 }
 // The same for the views of SEVERAL images in one exchange (the batched pair call: 2 k images of k pairs).  The (image, view)
 // items are numbered f = image * nviews + view and item f belongs to rank f mod world; a rank runs all its items as one
@@ -431,13 +442,18 @@ int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
 // THOSE images' slices and regStart[j] .. regStart[j + 1] the slice of image j in it (empty for the others); without it `regs`
 // holds all images.  devPos (optional): receives the device array of (reproj x, y) of ALL regions in item order (the matcher's
 // pos2), valid until the lane's next exchange.
+// kpRows (optional): the rows carry the verification slice only (MODSX_SHARD_ROW_KP); `regs` stays empty and *kpRows receives what
+// `regs` would hold, seven doubles per region.
 int detect_describe_items_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *const *imgs, int nimg, const modsx_view *views,
                                   int nviews, const modsx_pair_params &pp, const DescSet &ds, std::vector<modsx_region> &regs,
                                   DevBuf *const *descAcc, const size_t *base, int *viewCounts, const unsigned char *wantImg,
-                                  std::vector<size_t> *regStart, double **devPos) {
+                                  std::vector<size_t> *regStart, double **devPos, std::vector<double> *kpRows) {
   regs.clear();
+  if (kpRows) kpRows->clear();
+  const RowFmt rf = row_fmt(kpRows ? MODSX_SHARD_ROW_KP : MODSX_SHARD_ROW_REGION);
+  const size_t RB = (size_t)rf.regLen;     // bytes of a region record on the device, in the staging buffers and on the wire
   const int nv = nimg * nviews;            // items: what the block headers call views
-  const int nd = ds.n, ROW_B = row_bytes(nd);
+  const int nd = ds.n, ROW_B = row_bytes(rf.regLen, nd);
   if (cm->dead.load()) return comm_dead_rc(cm);
   if (nimg < 1 || nviews < 1 || nv > SHARD_MAXV || cm->world > SHARD_MAXW) { set_error("sharded path: at most 1024 (image, view) items per exchange and 64 ranks"); return MODSX_ERR_ARG; }
   hipStream_t s = c->stream;
@@ -483,8 +499,8 @@ int detect_describe_items_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
     const size_t rowsCap = (size_t)W * G;
     if (!L.hHdr.ensure((size_t)hdrB * (W + 1))) { comm_kill(cm, "no pinned memory for a block header"); return MODSX_ERR_NOMEM; }
     if (!lrc) {
-      if (!L.regsIn.ensure((size_t)std::max(1, nloc) * REG_B) || !L.hRegs.ensure(std::max((size_t)std::max(1, nloc), rowsCap) * REG_B) ||
-          !L.regsOut.ensure(rowsCap * REG_B) || (devPos && !L.posOut.ensure(rowsCap * 16))) {
+      if (!L.regsIn.ensure((size_t)std::max(1, nloc) * RB) || !L.hRegs.ensure(std::max((size_t)std::max(1, nloc), rowsCap) * RB) ||
+          !L.regsOut.ensure(rowsCap * RB) || (devPos && !L.posOut.ensure(rowsCap * 16))) {
         lrc = MODSX_ERR_NOMEM; lerr = "sharded path: out of memory";
       }
       for (int k = 0; k < nd && !lrc; k++)
@@ -497,11 +513,12 @@ int detect_describe_items_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
     MX_HIP(hipMemcpyAsync(L.blkLocal.p, hh, hdrB, hipMemcpyHostToDevice, s));
     const int npack = lrc ? 0 : std::min(nloc, G);
     if (npack) {
-      memcpy(L.hRegs.p, local.data(), (size_t)npack * REG_B);
-      MX_HIP(hipMemcpyAsync(L.regsIn.p, L.hRegs.p, (size_t)npack * REG_B, hipMemcpyHostToDevice, s));
+      if (rf.regLen == REG_B) memcpy(L.hRegs.p, local.data(), (size_t)npack * REG_B);
+      else for (int i = 0; i < npack; i++) memcpy((char *)L.hRegs.p + (size_t)i * RB, (const char *)&local[i] + rf.regOff, RB);
+      MX_HIP(hipMemcpyAsync(L.regsIn.p, L.hRegs.p, (size_t)npack * RB, hipMemcpyHostToDevice, s));
       DescPtrs dp;
       for (int k = 0; k < MODSX_MAX_DESC; k++) dp.p[k] = (unsigned char *)c->shardLocal.p + (size_t)k * cap * 128;
-      hipLaunchKernelGGL(k_pack_rows, dim3((npack + 7) / 8), dim3(256), 0, s, (const unsigned char *)L.regsIn.p, dp, nd, npack,
+      hipLaunchKernelGGL(k_pack_rows, dim3((npack + 7) / 8), dim3(256), 0, s, (const unsigned char *)L.regsIn.p, rf.regLen, dp, nd, npack,
                          (unsigned char *)L.blkLocal.p + hdrB);
     }
     // 4. the exchange: one all-gather of the blocks
@@ -514,11 +531,11 @@ int detect_describe_items_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
       DescPtrs dp;
       for (int k = 0; k < MODSX_MAX_DESC; k++) dp.p[k] = k < nd ? (unsigned char *)descAcc[k]->p + base[k] * 128 : nullptr;
       hipLaunchKernelGGL(k_unpack_blocks, dim3((unsigned)((rowsCap + 7) / 8)), dim3(256), 0, s, (const unsigned char *)L.blkAll.p, W, nv, G,
-                         blockB, hdrB, (unsigned char *)L.regsOut.p, dp, nd, rowsCap, devPos ? (double *)L.posOut.p : nullptr,
-                         (int)offsetof(modsx_region, reproj_kp));
+                         blockB, hdrB, (unsigned char *)L.regsOut.p, rf.regLen, dp, nd, rowsCap, devPos ? (double *)L.posOut.p : nullptr,
+                         rf.posOfs);
       if (!wantImg) {     // all regions are wanted: a first guess comes down with the same wait as the headers
         got = std::min(rowsCap, L.lastN + L.lastN / 4 + 256);
-        MX_HIP(hipMemcpyAsync(L.hRegs.p, L.regsOut.p, got * REG_B, hipMemcpyDeviceToHost, s));
+        MX_HIP(hipMemcpyAsync(L.hRegs.p, L.regsOut.p, got * RB, hipMemcpyDeviceToHost, s));
       }
     }
     rc = comm_wait(cm, s);
@@ -557,26 +574,26 @@ int detect_describe_items_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
         devStart[j + 1] = devStart[j] + n;
         st[j + 1] = st[j] + (wantImg[j] ? n : 0);
       }
-      regs.resize(st[nimg]);
       bool any = false;
       for (int j = 0; j < nimg; j++)
         if (wantImg[j] && devStart[j + 1] > devStart[j]) {
-          MX_HIP(hipMemcpyAsync((char *)L.hRegs.p + st[j] * REG_B, (char *)L.regsOut.p + devStart[j] * REG_B,
-                                (devStart[j + 1] - devStart[j]) * REG_B, hipMemcpyDeviceToHost, s));
+          MX_HIP(hipMemcpyAsync((char *)L.hRegs.p + st[j] * RB, (char *)L.regsOut.p + devStart[j] * RB,
+                                (devStart[j + 1] - devStart[j]) * RB, hipMemcpyDeviceToHost, s));
           any = true;
         }
       if (any) { rc = comm_wait(cm, s); if (rc) return rc; }
-      if (st[nimg]) memcpy(regs.data(), L.hRegs.p, st[nimg] * REG_B);
+      if (kpRows) { kpRows->resize(st[nimg] * 7); if (st[nimg]) memcpy(kpRows->data(), L.hRegs.p, st[nimg] * RB); }
+      else { regs.resize(st[nimg]); if (st[nimg]) memcpy(regs.data(), L.hRegs.p, st[nimg] * REG_B); }
       if (regStart) *regStart = st;
       return MODSX_OK;
     }
-    regs.resize(N);
     if (N > got) {           // the speculative download was short (first call, or a much larger image)
-      MX_HIP(hipMemcpyAsync((char *)L.hRegs.p + got * REG_B, (char *)L.regsOut.p + got * REG_B, (N - got) * REG_B, hipMemcpyDeviceToHost, s));
+      MX_HIP(hipMemcpyAsync((char *)L.hRegs.p + got * RB, (char *)L.regsOut.p + got * RB, (N - got) * RB, hipMemcpyDeviceToHost, s));
       rc = comm_wait(cm, s);
       if (rc) return rc;
     }
-    if (N) memcpy(regs.data(), L.hRegs.p, N * REG_B);
+    if (kpRows) { kpRows->resize(N * 7); if (N) memcpy(kpRows->data(), L.hRegs.p, N * RB); }
+    else { regs.resize(N); if (N) memcpy(regs.data(), L.hRegs.p, N * REG_B); }
     return MODSX_OK;
   }
 }
@@ -750,23 +767,14 @@ int match_pairs_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *c
     const bool mine = owner_base < 0 || (owner_base + g) % cm->world == cm->rank;
     want[2 * g] = want[2 * g + 1] = mine ? 1 : 0;
   }
-  std::vector<size_t> hs;      // slice of image j in `regs` (empty when not wanted)
+  std::vector<size_t> hs;      // slice of image j in `kp` (empty when not wanted)
+  std::vector<double> kp;      // the call returns pair results, no region lists: a row carries the verification slice of a region only
   double *devPos = nullptr;
-  rc = detect_describe_items_sharded(c, cm, imgs.data(), nimg, views, nv, pp, ds, regs, acc, base0, counts.data(), want.data(), &hs, &devPos);
+  rc = detect_describe_items_sharded(c, cm, imgs.data(), nimg, views, nv, pp, ds, regs, acc, base0, counts.data(), want.data(), &hs, &devPos, &kp);
   if (rc) return rc;
   // the slice of every image in the gathered (device) lists
   std::vector<size_t> start(nimg + 1, 0);
   for (int j = 0; j < nimg; j++) { size_t n = 0; for (int v = 0; v < nv; v++) n += (size_t)counts[(size_t)j * nv + v]; start[j + 1] = start[j] + n; }
-  // ids re-based per image (AddRegionsToList on a fresh representation)
-  for (int j = 0; j < nimg; j++) {
-    if (!want[j]) continue;
-    size_t at = hs[j];
-    for (int v = 0; v < nv; v++) {
-      const size_t cnt = (size_t)counts[(size_t)j * nv + v], rel = at - hs[j];
-      for (size_t i = 0; i < cnt; i++) { regs[at + i].id += (int)rel; regs[at + i].parent_id += (int)rel; }
-      at += cnt;
-    }
-  }
   int ord[MODSX_MAX_DESC];
   desc_class_order(ds, ord);
   std::vector<std::vector<modsx_tentative>> tents(np);
@@ -822,9 +830,7 @@ int match_pairs_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *c
     res->n_regions1 = n1[g] * ds.n; res->n_regions2 = n2[g] * ds.n;
     res->n_tentatives = (int)tents[g].size();
     if (owner_base >= 0 && (owner_base + g) % cm->world != cm->rank) continue;
-    RegList l1, l2;
-    for (int oi = 0; oi < ds.n; oi++) { l1.add(regs.data() + hs[2 * g], (size_t)n1[g]); l2.add(regs.data() + hs[2 * g + 1], (size_t)n2[g]); }
-    verify_tentatives(l1, l2, tents[g], pp, res);
+    verify_tentatives_kp(kp.data() + 7 * hs[2 * g], (size_t)n1[g], kp.data() + 7 * hs[2 * g + 1], (size_t)n2[g], tents[g], pp, res);
   }
   prof_collect(c);
   return MODSX_OK;
@@ -1010,28 +1016,33 @@ int modsx_comm_stats(const modsx_comm *cm, long *out, int n) {
 /* The wire format of one exchange, stated on the host (what k_pack_rows / k_unpack_blocks do on the device; the GPU tests compare
  * the two byte for byte, the gloo CPU tests run ranks over it without a device):
  *   block = header {magic "MXSH", rc, rows, items, counts[items]} padded to 64 B, then `rows` records of
- *           sizeof(modsx_region) + 128 * ndesc bytes (the region, then its descriptor of every class), then padding up to
- *           block_rows records.
+ *           R + 128 * ndesc bytes (the region part, then the region's descriptor of every class), then padding up to
+ *           block_rows records.  row_format MODSX_SHARD_ROW_REGION: R = sizeof(modsx_region), the whole region (the calls that
+ *           return region lists); MODSX_SHARD_ROW_KP: R = 56, the doubles x, y, a11, a12, a21, a22, s of its reproj_kp (all the
+ *           matcher and the verification read: modsx_match_pairs_views_sharded).
  * modsx_shard_block_bytes: size of a block for `items` (image, view) items, block_rows rows and ndesc descriptor classes.
  * modsx_shard_block_pack:  this rank's block from its regions (item order), descriptors (desc[k]: [n][128] u8 of class k) and
  *                          per-item counts (counts[f] = 0 for items of other ranks); rows beyond block_rows are left out --
  *                          the header still carries the true row count, which is how every rank sees that the block was too
  *                          small.  Returns the bytes written.
  * modsx_shard_blocks_unpack: the reference's list from the `world` gathered blocks: item f sits in the block of rank f mod world
- *                          at that rank's running offset.  regs_out / desc_out[k]: capacity `cap` regions; item_counts: [items].
+ *                          at that rank's running offset.  regs_out (modsx_region[cap], or double[cap][7] for ROW_KP) /
+ *                          desc_out[k]: capacity `cap` regions; item_counts: [items].
  *                          Returns the list length, MODSX_ERR_CAPACITY (with *need_rows = the largest row count) when a block
  *                          was too small, a rank's rc when its header carries one, MODSX_ERR_ARG on a malformed header. */
-long modsx_shard_block_bytes(int items, int block_rows, int ndesc) {
-  if (items < 1 || block_rows < 0 || ndesc < 1 || ndesc > MODSX_MAX_DESC) return MODSX_ERR_ARG;
-  return (long)hdr_bytes(items) + (long)block_rows * row_bytes(ndesc);
+static bool fmt_ok(int f) { return f == MODSX_SHARD_ROW_REGION || f == MODSX_SHARD_ROW_KP; }
+long modsx_shard_block_bytes(int items, int block_rows, int ndesc, int row_format) {
+  if (items < 1 || block_rows < 0 || ndesc < 1 || ndesc > MODSX_MAX_DESC || !fmt_ok(row_format)) return MODSX_ERR_ARG;
+  return (long)hdr_bytes(items) + (long)block_rows * row_bytes(row_fmt(row_format).regLen, ndesc);
 }
 long modsx_shard_block_pack(const modsx_region *regs, const unsigned char *const *desc, int ndesc, int n, const int *counts, int items,
-                            int rc_local, int block_rows, void *block) {
-  if (!block || !counts || items < 1 || n < 0 || ndesc < 1 || ndesc > MODSX_MAX_DESC || (n > 0 && (!regs || !desc))) {
+                            int rc_local, int block_rows, int row_format, void *block) {
+  if (!block || !counts || items < 1 || n < 0 || ndesc < 1 || ndesc > MODSX_MAX_DESC || (n > 0 && (!regs || !desc)) || !fmt_ok(row_format)) {
     mx::set_error("modsx_shard_block_pack: bad argument");
     return MODSX_ERR_ARG;
   }
-  const int hdrB = hdr_bytes(items), ROW_B = row_bytes(ndesc);
+  const RowFmt rf = row_fmt(row_format);
+  const int hdrB = hdr_bytes(items), ROW_B = row_bytes(rf.regLen, ndesc);
   unsigned char *b = (unsigned char *)block;
   memset(b, 0, (size_t)hdrB + (size_t)block_rows * ROW_B);
   int *h = (int *)b;
@@ -1040,15 +1051,16 @@ long modsx_shard_block_pack(const modsx_region *regs, const unsigned char *const
   const int npack = rc_local ? 0 : std::min(n, block_rows);
   for (int i = 0; i < npack; i++) {
     unsigned char *row = b + hdrB + (size_t)i * ROW_B;
-    memcpy(row, regs + i, REG_B);
-    for (int k = 0; k < ndesc; k++) memcpy(row + REG_B + 128 * k, desc[k] + (size_t)i * 128, 128);
+    memcpy(row, (const char *)(regs + i) + rf.regOff, rf.regLen);
+    for (int k = 0; k < ndesc; k++) memcpy(row + rf.regLen + 128 * k, desc[k] + (size_t)i * 128, 128);
   }
   return (long)hdrB + (long)block_rows * ROW_B;
 }
-long modsx_shard_blocks_unpack(const void *blocks, int world, int items, int block_rows, int ndesc, modsx_region *regs_out,
+long modsx_shard_blocks_unpack(const void *blocks, int world, int items, int block_rows, int ndesc, int row_format, void *regs_out,
                                unsigned char *const *desc_out, long cap, int *item_counts, int *need_rows) {
-  if (!blocks || world < 1 || items < 1 || ndesc < 1 || ndesc > MODSX_MAX_DESC) { mx::set_error("modsx_shard_blocks_unpack: bad argument"); return MODSX_ERR_ARG; }
-  const int hdrB = hdr_bytes(items), ROW_B = row_bytes(ndesc);
+  if (!blocks || world < 1 || items < 1 || ndesc < 1 || ndesc > MODSX_MAX_DESC || !fmt_ok(row_format)) { mx::set_error("modsx_shard_blocks_unpack: bad argument"); return MODSX_ERR_ARG; }
+  const RowFmt rf = row_fmt(row_format);
+  const int hdrB = hdr_bytes(items), ROW_B = row_bytes(rf.regLen, ndesc);
   const size_t blockB = (size_t)hdrB + (size_t)block_rows * ROW_B;
   const unsigned char *all = (const unsigned char *)blocks;
   int maxrows = 0;
@@ -1070,55 +1082,63 @@ long modsx_shard_blocks_unpack(const void *blocks, int world, int items, int blo
     for (int i = 0; i < cnt; i++, j++) {
       if (j >= cap) { mx::set_error("modsx_shard_blocks_unpack: output capacity"); return MODSX_ERR_CAPACITY; }
       const unsigned char *row = all + r * blockB + hdrB + (size_t)(run[r] + i) * ROW_B;
-      if (regs_out) memcpy(regs_out + j, row, REG_B);
-      for (int k = 0; k < ndesc; k++) if (desc_out && desc_out[k]) memcpy(desc_out[k] + (size_t)j * 128, row + REG_B + 128 * k, 128);
+      if (regs_out) memcpy((char *)regs_out + (size_t)j * rf.regLen, row, rf.regLen);
+      for (int k = 0; k < ndesc; k++) if (desc_out && desc_out[k]) memcpy(desc_out[k] + (size_t)j * 128, row + rf.regLen + 128 * k, 128);
     }
     run[r] += cnt;
   }
   return j;
 }
-/* test hook: the device kernels on host-provided data (needs a device): packs `n` regions + descriptors into a block with
- * k_pack_rows, or orders `world` gathered blocks with k_unpack_blocks; outputs are copied back to the host */
-long modsx_shard_device_pack(modsx_ctx *ctx, const modsx_region *regs, const unsigned char *const *desc, int ndesc, int n, void *rows_out) {
-  if (!ctx || !regs || !desc || !rows_out || n < 1 || ndesc < 1 || ndesc > MODSX_MAX_DESC) { mx::set_error("modsx_shard_device_pack: bad argument"); return MODSX_ERR_ARG; }
+/* test hook: the device kernels on host-provided data (needs a device): packs `n` regions + descriptors into rows with
+ * k_pack_rows (fed the way the exchange feeds it: the region part of every record, contiguous), or orders `world` gathered blocks
+ * with k_unpack_blocks; outputs are copied back to the host */
+long modsx_shard_device_pack(modsx_ctx *ctx, const modsx_region *regs, const unsigned char *const *desc, int ndesc, int n, int row_format,
+                             void *rows_out) {
+  if (!ctx || !regs || !desc || !rows_out || n < 1 || ndesc < 1 || ndesc > MODSX_MAX_DESC || !fmt_ok(row_format)) { mx::set_error("modsx_shard_device_pack: bad argument"); return MODSX_ERR_ARG; }
   hipSetDevice(ctx->dev);
   hipStream_t s = ctx->stream;
+  const RowFmt rf = row_fmt(row_format);
   DevBuf dr, dd, dout;
-  const int ROW_B = row_bytes(ndesc);
-  if (!dr.ensure((size_t)n * REG_B) || !dd.ensure((size_t)n * 128 * ndesc) || !dout.ensure((size_t)n * ROW_B)) return MODSX_ERR_NOMEM;
-  MX_HIP(hipMemcpyAsync(dr.p, regs, (size_t)n * REG_B, hipMemcpyHostToDevice, s));
+  const int ROW_B = row_bytes(rf.regLen, ndesc);
+  if (!dr.ensure((size_t)n * rf.regLen) || !dd.ensure((size_t)n * 128 * ndesc) || !dout.ensure((size_t)n * ROW_B)) return MODSX_ERR_NOMEM;
+  std::vector<unsigned char> part((size_t)n * rf.regLen);
+  for (int i = 0; i < n; i++) memcpy(part.data() + (size_t)i * rf.regLen, (const char *)(regs + i) + rf.regOff, rf.regLen);
+  MX_HIP(hipMemcpyAsync(dr.p, part.data(), part.size(), hipMemcpyHostToDevice, s));
   DescPtrs dp;
   for (int k = 0; k < MODSX_MAX_DESC; k++) dp.p[k] = nullptr;
   for (int k = 0; k < ndesc; k++) {
     dp.p[k] = (unsigned char *)dd.p + (size_t)k * n * 128;
     MX_HIP(hipMemcpyAsync(dp.p[k], desc[k], (size_t)n * 128, hipMemcpyHostToDevice, s));
   }
-  hipLaunchKernelGGL(k_pack_rows, dim3((n + 7) / 8), dim3(256), 0, s, (const unsigned char *)dr.p, dp, ndesc, n, (unsigned char *)dout.p);
+  hipLaunchKernelGGL(k_pack_rows, dim3((n + 7) / 8), dim3(256), 0, s, (const unsigned char *)dr.p, rf.regLen, dp, ndesc, n, (unsigned char *)dout.p);
   MX_HIP(hipMemcpyAsync(rows_out, dout.p, (size_t)n * ROW_B, hipMemcpyDeviceToHost, s));
   MX_HIP(hipStreamSynchronize(s));
   dr.release(); dd.release(); dout.release();
   return (long)n * ROW_B;
 }
-long modsx_shard_device_unpack(modsx_ctx *ctx, const void *blocks, int world, int items, int block_rows, int ndesc, modsx_region *regs_out,
-                               unsigned char *const *desc_out, double *pos_out, long cap) {
-  if (!ctx || !blocks || !regs_out || !desc_out || world < 1 || world > SHARD_MAXW || items < 1 || items > SHARD_MAXV || ndesc < 1 || ndesc > MODSX_MAX_DESC) {
+long modsx_shard_device_unpack(modsx_ctx *ctx, const void *blocks, int world, int items, int block_rows, int ndesc, int row_format,
+                               void *regs_out, unsigned char *const *desc_out, double *pos_out, long cap) {
+  if (!ctx || !blocks || !regs_out || !desc_out || world < 1 || world > SHARD_MAXW || items < 1 || items > SHARD_MAXV || ndesc < 1 || ndesc > MODSX_MAX_DESC ||
+      !fmt_ok(row_format)) {
     mx::set_error("modsx_shard_device_unpack: bad argument");
     return MODSX_ERR_ARG;
   }
   hipSetDevice(ctx->dev);
   hipStream_t s = ctx->stream;
-  const int hdrB = hdr_bytes(items), ROW_B = row_bytes(ndesc);
+  const RowFmt rf = row_fmt(row_format);
+  const size_t RB = (size_t)rf.regLen;
+  const int hdrB = hdr_bytes(items), ROW_B = row_bytes(rf.regLen, ndesc);
   const size_t blockB = (size_t)hdrB + (size_t)block_rows * ROW_B, rowsCap = (size_t)world * block_rows;
   if ((size_t)cap < rowsCap) { mx::set_error("modsx_shard_device_unpack: cap must hold world * block_rows regions"); return MODSX_ERR_ARG; }
   DevBuf din, dregs, ddesc, dpos;
-  if (!din.ensure(blockB * world) || !dregs.ensure(rowsCap * REG_B + 64) || !ddesc.ensure(rowsCap * 128 * ndesc + 64) || !dpos.ensure(rowsCap * 16 + 64)) return MODSX_ERR_NOMEM;
+  if (!din.ensure(blockB * world) || !dregs.ensure(rowsCap * RB + 64) || !ddesc.ensure(rowsCap * 128 * ndesc + 64) || !dpos.ensure(rowsCap * 16 + 64)) return MODSX_ERR_NOMEM;
   MX_HIP(hipMemcpyAsync(din.p, blocks, blockB * world, hipMemcpyHostToDevice, s));
-  MX_HIP(hipMemsetAsync(dregs.p, 0, rowsCap * REG_B, s));
+  MX_HIP(hipMemsetAsync(dregs.p, 0, rowsCap * RB, s));
   DescPtrs dp;
   for (int k = 0; k < MODSX_MAX_DESC; k++) dp.p[k] = k < ndesc ? (unsigned char *)ddesc.p + (size_t)k * rowsCap * 128 : nullptr;
   hipLaunchKernelGGL(k_unpack_blocks, dim3((unsigned)((rowsCap + 7) / 8)), dim3(256), 0, s, (const unsigned char *)din.p, world, items, block_rows, blockB,
-                     hdrB, (unsigned char *)dregs.p, dp, ndesc, rowsCap, (double *)dpos.p, (int)offsetof(modsx_region, reproj_kp));
-  MX_HIP(hipMemcpyAsync(regs_out, dregs.p, rowsCap * REG_B, hipMemcpyDeviceToHost, s));
+                     hdrB, (unsigned char *)dregs.p, rf.regLen, dp, ndesc, rowsCap, (double *)dpos.p, rf.posOfs);
+  MX_HIP(hipMemcpyAsync(regs_out, dregs.p, rowsCap * RB, hipMemcpyDeviceToHost, s));
   for (int k = 0; k < ndesc; k++) MX_HIP(hipMemcpyAsync(desc_out[k], dp.p[k], rowsCap * 128, hipMemcpyDeviceToHost, s));
   if (pos_out) MX_HIP(hipMemcpyAsync(pos_out, dpos.p, rowsCap * 16, hipMemcpyDeviceToHost, s));
   MX_HIP(hipStreamSynchronize(s));

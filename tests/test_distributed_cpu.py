@@ -35,7 +35,7 @@ def _blocks():
     return blocks, counts, ref, z["desc"]
 
 
-def _exchange(mods_amd, rank, world, item_blocks, ndesc, first_rows, fail_rank=-1):
+def _exchange(mods_amd, rank, world, item_blocks, ndesc, first_rows, fail_rank=-1, fmt=0):
     """One exchange as engine_shard.hip runs it: pack, all-gather, unpack; a block that was too small is repeated with the size every
     rank derives from the gathered headers.  item_blocks[f] = (regs, desc) of item f.  Returns (regs, descs, counts, retries)."""
     items = len(item_blocks)
@@ -49,11 +49,11 @@ def _exchange(mods_amd, rank, world, item_blocks, ndesc, first_rows, fail_rank=-
         cnt[f] = len(item_blocks[f][0])
     rows, retries = first_rows, 0
     while True:
-        blk = mods_amd.shard_block_pack(regs_l, descs_l, cnt, rows, rc_local=(-3 if rank == fail_rank else 0))
+        blk = mods_amd.shard_block_pack(regs_l, descs_l, cnt, rows, rc_local=(-3 if rank == fail_rank else 0), row_format=fmt)
         parts = [torch.zeros(len(blk), dtype=torch.uint8) for _ in range(world)]
         dist.all_gather(parts, torch.from_numpy(blk))
         allb = torch.cat(parts).numpy()
-        regs, descs, got = mods_amd.shard_blocks_unpack(allb, world, items, rows, ndesc)
+        regs, descs, got = mods_amd.shard_blocks_unpack(allb, world, items, rows, ndesc, row_format=fmt)
         if regs is None:                 # every rank sees the overflow in the same headers and takes the same new size
             rows = got + got // 4 + 64
             retries += 1
@@ -92,6 +92,10 @@ def _worker(rank, world, port, ret):
     ok = ok and retries2 == 0 and np.array_equal(cnt2, [len(b[0]) for b in two])
     ok = ok and same_records(regs2, exp_regs) and np.array_equal(descs2[0], exp_desc) and np.array_equal(descs2[1], 255 - exp_desc)
     ok = ok and same_records(_rebase(regs2[:len(ref_regs)].copy(), cnt2[:nv]), ref_regs)        # image 0 of the item list
+    # 2b. the same exchange in the pair call's row format (56 B of geometry + descriptors): what modsx_match_pairs_views_sharded moves
+    kp2, dk2, ck2, rk2 = _exchange(mods_amd, rank, world, two, 2, first_rows=9, fmt=mods_amd.SHARD_ROW_KP)
+    ok = ok and rk2 == 1 and np.array_equal(ck2, cnt2) and np.array_equal(kp2, mods_amd.shard_kp_rows(exp_regs))
+    ok = ok and np.array_equal(dk2[0], exp_desc) and np.array_equal(dk2[1], 255 - exp_desc)
     # 3. a failing rank: its rc travels in the header, every rank raises the same error from the same call
     try:
         _exchange(mods_amd, rank, world, blocks, 1, first_rows=4096, fail_rank=world - 1)
@@ -154,6 +158,16 @@ def test_block_format_single_process():
                                        [np.concatenate([blocks[v][1] for v in range(r, nv, world)])], counts[r], 5) for r in range(world)]
     r_, d_, need = mods_amd.shard_blocks_unpack(np.concatenate(small), world, nv, 5, 1)
     assert r_ is None and need == rows
+    # the pair call's row format: 56 bytes of geometry (x, y, a11, a12, a21, a22, s of reproj_kp) instead of the whole region
+    KP = mods_amd.SHARD_ROW_KP
+    assert mods_amd.shard_block_bytes(nv, 10, 1, KP) == ((4 + nv) * 4 + 63) // 64 * 64 + 10 * 184
+    assert mods_amd.shard_block_bytes(nv, 10, 2, KP) == ((4 + nv) * 4 + 63) // 64 * 64 + 10 * 312
+    allk = [mods_amd.shard_block_pack(np.concatenate([blocks[v][0] for v in range(r, nv, world)]),
+                                      [np.concatenate([blocks[v][1] for v in range(r, nv, world)])], counts[r], rows, row_format=KP)
+            for r in range(world)]
+    kp, dk, ck = mods_amd.shard_blocks_unpack(np.concatenate(allk), world, nv, rows, 1, row_format=KP)
+    assert np.array_equal(ck, counts_ref) and np.array_equal(dk[0], ref_desc)
+    assert kp.shape == (len(regs), 7) and np.array_equal(kp, mods_amd.shard_kp_rows(regs))
 
 
 def test_view_block_order_and_sharding():

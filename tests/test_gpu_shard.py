@@ -72,11 +72,12 @@ def test_sharded_equals_unsharded(ctx, modsx, small_pair, world):
     ia.free(); ib.free()
 
 
-@pytest.mark.parametrize("world,ndesc", [(2, 1), (3, 2), (8, 1)])
-def test_device_pack_and_order_kernels_equal_the_host_wire_format(ctx, modsx, small_pair, world, ndesc):
+@pytest.mark.parametrize("world,ndesc,fmt", [(2, 1, 0), (3, 2, 0), (8, 1, 0), (2, 1, 1), (3, 2, 1), (8, 2, 1)])
+def test_device_pack_and_order_kernels_equal_the_host_wire_format(ctx, modsx, small_pair, world, ndesc, fmt):
     """k_pack_rows / k_unpack_blocks against modsx_shard_block_pack / modsx_shard_blocks_unpack (the host statement the gloo CPU
-    tests run ranks over): the rows a rank packs are the same bytes, and the device-side ordering of `world` gathered blocks gives
-    the same regions, descriptors (every class) and matcher positions as the host's."""
+    tests run ranks over), for both row formats (fmt 0: whole regions, 200 B; fmt 1: the 56-byte verification slice the batched
+    pair call moves): the rows a rank packs are the same bytes, and the device-side ordering of `world` gathered blocks gives the
+    same regions, descriptors (every class) and matcher positions as the host's."""
     a = small_pair[0]
     views = _views(modsx)
     par = modsx.default_pair_params(ransac_seed=4)
@@ -86,6 +87,8 @@ def test_device_pack_and_order_kernels_equal_the_host_wire_format(ctx, modsx, sm
     ia.free()
     items = 2 * nv                        # two images' worth of items (the second: the views in reverse order)
     blocks = per_view + per_view[::-1]
+    RB = modsx.shard_region_bytes(fmt)
+    assert RB == (200, 56)[fmt]
     rows = 0
     packs = []
     for r in range(world):
@@ -99,24 +102,35 @@ def test_device_pack_and_order_kernels_equal_the_host_wire_format(ctx, modsx, sm
         packs.append((regs, descs, cnt))
         rows = max(rows, len(regs))
     allb = []
-    hdrB = modsx.shard_block_bytes(items, 0, ndesc)
+    hdrB = modsx.shard_block_bytes(items, 0, ndesc, fmt)
+    assert modsx.shard_block_bytes(items, rows, ndesc, fmt) == hdrB + rows * (RB + 128 * ndesc)
     for regs, descs, cnt in packs:
-        blk = modsx.shard_block_pack(regs, descs, cnt, rows)
-        dev_rows = ctx.shard_device_pack(regs, descs)
+        blk = modsx.shard_block_pack(regs, descs, cnt, rows, row_format=fmt)
+        dev_rows = ctx.shard_device_pack(regs, descs, row_format=fmt)
         host_rows = blk[hdrB:].reshape(rows, -1)[:len(regs)]
-        # field-wise for the region part (struct padding is not data), bytes for the descriptors
-        assert same_records(np.frombuffer(np.ascontiguousarray(dev_rows[:, :200]).tobytes(), modsx.REGION),
-                            np.frombuffer(np.ascontiguousarray(host_rows[:, :200]).tobytes(), modsx.REGION))
-        assert np.array_equal(dev_rows[:, 200:], host_rows[:, 200:])
+        if fmt == 0:
+            # field-wise for the region part (struct padding is not data), bytes for the descriptors
+            assert same_records(np.frombuffer(np.ascontiguousarray(dev_rows[:, :200]).tobytes(), modsx.REGION),
+                                np.frombuffer(np.ascontiguousarray(host_rows[:, :200]).tobytes(), modsx.REGION))
+        else:
+            # the slice holds no padding: bytes, and they are the seven geometry doubles of reproj_kp
+            assert np.array_equal(dev_rows[:, :RB], host_rows[:, :RB])
+            assert np.array_equal(np.frombuffer(np.ascontiguousarray(host_rows[:, :RB]).tobytes(), np.float64).reshape(-1, 7),
+                                  modsx.shard_kp_rows(regs))
+        assert np.array_equal(dev_rows[:, RB:], host_rows[:, RB:])
         allb.append(blk)
     allb = np.concatenate(allb)
-    h_regs, h_descs, h_cnt = modsx.shard_blocks_unpack(allb, world, items, rows, ndesc)
-    d_regs, d_descs, d_pos = ctx.shard_device_unpack(allb, world, items, rows, ndesc)
+    h_regs, h_descs, h_cnt = modsx.shard_blocks_unpack(allb, world, items, rows, ndesc, row_format=fmt)
+    d_regs, d_descs, d_pos = ctx.shard_device_unpack(allb, world, items, rows, ndesc, row_format=fmt)
     n = len(h_regs)
     assert n == sum(len(b[0]) for b in blocks) and np.array_equal(h_cnt, [len(b[0]) for b in blocks])
-    assert same_records(d_regs[:n], h_regs)
     for k in range(ndesc):
         assert np.array_equal(d_descs[k][:n], h_descs[k])
+    if fmt == 1:
+        assert np.array_equal(d_regs[:n], h_regs) and np.array_equal(h_regs, modsx.shard_kp_rows(np.concatenate([b[0] for b in blocks])))
+        assert np.array_equal(d_pos[:n], h_regs[:, :2])
+        return
+    assert same_records(d_regs[:n], h_regs)
     assert np.array_equal(d_pos[:n, 0], h_regs["reproj_kp"]["x"]) and np.array_equal(d_pos[:n, 1], h_regs["reproj_kp"]["y"])
 
 
