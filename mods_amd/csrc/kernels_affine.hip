@@ -270,6 +270,43 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
     const unsigned long long liveMask = __ballot(live);
     if (!liveMask) break;
     const float A11 = u11 * ratio, A12 = u12 * ratio, A21 = u21 * ratio, A22 = u22 * ratio;
+    if constexpr (K == 2) {
+      // Sample coordinates of BOTH slots at once (helpers.cpp:563-585: f32 running sums down the rows, then along each row).
+      // The four chains -- slot 0 x, slot 0 y, slot 1 x, slot 1 y -- take one DPP row of 16 lanes each.  Row starts: lane i of
+      // a DPP row needs i steps of its chain, which `v = v[lane - 1] + step` (row_shr:1; lane 0 of a row has no source and is
+      // left alone) delivers for all 64 lanes in 15 instructions: lane i's value is final after step i and recomputed to the
+      // same number afterwards.  Rows 16..18 continue from lane 15.  Then every lane walks its row (19 columns), the lanes
+      // 0..2 of a DPP row a second one (rows 16..18) beside it in the other half of a packed add; the other lanes park that
+      // half in the slot's third array, which is free until the taps are stored.  ~50 vector instructions per iteration for
+      // what took ~150 per slot when each slot ran its x and y chains in the same 19 lanes.
+      const int dq = lane >> 5, dc = (lane >> 4) & 1, di = lane & 15;
+      const float s11 = __shfl(A11, 2 * dq), s12 = __shfl(A12, 2 * dq), s21 = __shfl(A21, 2 * dq), s22 = __shfl(A22, 2 * dq);
+      const float sox = __shfl(slx, 2 * dq), soy = __shfl(sly, 2 * dq);   // (both by every lane: a shuffle reads nothing from an idle lane)
+      const float so = dc ? soy : sox;
+      const float stepR = dc ? s22 : s12, stepC = dc ? s21 : s11;
+      float v = so - (float)half * stepR;
+      // (2 wait states between a VALU write and a DPP read of the same register; the hazard recognizer does not look inside asm)
+#define MX_ROWSTEP "s_nop 1\n\tv_add_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      asm volatile("s_nop 4\n\t" MX_ROWSTEP MX_ROWSTEP MX_ROWSTEP MX_ROWSTEP MX_ROWSTEP MX_ROWSTEP MX_ROWSTEP MX_ROWSTEP MX_ROWSTEP MX_ROWSTEP
+                   MX_ROWSTEP MX_ROWSTEP MX_ROWSTEP MX_ROWSTEP MX_ROWSTEP "s_nop 1"
+                   : "+v"(v)
+                   : "v"(stepR));
+#undef MX_ROWSTEP
+      const float e16 = __shfl(v, lane | 15) + stepR, e17 = e16 + stepR, e18 = e17 + stepR;
+      const float vx = di == 0 ? e16 : (di == 1 ? e17 : e18);
+      const float hc = (float)half * stepC;
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      v2f wv = {v - hc, vx - hc};
+      const v2f st = {stepC, stepC};
+      float *const b1 = &buf[dq][dc][di * W];
+      float *const b2 = di < 3 ? &buf[dq][dc][(16 + di) * W] : &buf[dq][2][0];
+#pragma unroll
+      for (int i = 0; i < W; i++) {
+        b1[i] = wv.x;
+        b2[i] = wv.y;
+        wv += st;
+      }
+    }
 #pragma unroll
     for (int q = 0; q < K; q++) {
       if (!((liveMask >> (2 * q)) & 1)) continue;
@@ -280,7 +317,7 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
       float *const simg = pc;
       const float a11 = __shfl(A11, 2 * q), a12 = __shfl(A12, 2 * q), a21 = __shfl(A21, 2 * q), a22 = __shfl(A22, 2 * q);
       const bool touch = check_borders(jb.cols, jb.rows, lx, ly, a11, a12, a21, a22, W, W);
-      {
+      if constexpr (K != 2) {
         // sample coordinates: lane j runs the f32 running sums of row j (helpers.cpp:563-585) into LDS
         float rx = lx - (float)half * a12, ry = ly - (float)half * a22;
 #pragma unroll

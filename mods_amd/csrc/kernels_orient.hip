@@ -25,9 +25,16 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, float *o
   // bin indices and the bin of every atan2LUT angle
   __shared__ __attribute__((aligned(16))) float bufX[PS * PSP];
   __shared__ __attribute__((aligned(16))) unsigned char sbin[PS * PSP];
+#ifdef MODSX_ORI_LDS_TABLE
   __shared__ __attribute__((aligned(16))) unsigned char sbt[ATAN_CASES];
+#else
+  // the 2 KB bin table is read where it lies: every wavefront of the launch hits the same 33 cache lines, and a copy per
+  // workgroup cost 2.1 of the 11.3 KB of LDS that bound the residency (14 -> 17 regions per CU)
+  const unsigned char *const sbt = binTab;
+#endif
   __shared__ float hist[40];
   static_assert(ATAN_CASES == 33 * 64, "one 4-byte word per lane and step");
+#ifdef MODSX_ORI_LDS_TABLE
   {   // the bin table: independent loads per lane, issued together
     unsigned t[9];
 #pragma unroll
@@ -36,6 +43,7 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, float *o
     for (int u = 0; u < 9; u++)
       if (lane + 64 * u < ATAN_CASES / 4) reinterpret_cast<unsigned *>(sbt)[lane + 64 * u] = t[u];
   }
+#endif
   const OriJob jb = jobs[k];
   const ImgRef im = imgs[jb.img];
   const int half = PS >> 1;
