@@ -21,10 +21,13 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, float *o
   const int k = xcd_chunk(blockIdx.x, n);   // regions are listed image by image: one part of the views per XCD's L2
   if (k >= n) return;
   const int lane = threadIdx.x;
-  // 11 KB of LDS per region (14 regions resident per CU): the patch, later overwritten by the histogram weights, the
-  // bin indices and the bin of every atan2LUT angle
+  // 7.4 KB of LDS per region (21 regions resident per CU; it was 11.3 KB / 14 with a table copy and a separate bin array, and
+  // the kernel is bound by the latency of its dependent phases, not by issue): the patch, later overwritten by the voting list
   __shared__ __attribute__((aligned(16))) float bufX[PS * PSP];
-  __shared__ __attribute__((aligned(16))) unsigned char sbin[PS * PSP];
+  // the bins of the compacted voting list live behind its weights in the patch's own buffer (the patch is dead by then: the
+  // gradients are staged in registers): at most ORI_NV + 4 weights, then the bytes -- 7.4 KB of LDS per region instead of 9.2
+  static_assert((ORI_NV + 4) * 4 + ORI_NV + 4 <= PS * PSP * 4 && (ORI_NV + 4) % 4 == 0, "the voting list fits in the patch buffer");
+  unsigned char *const sbin = reinterpret_cast<unsigned char *>(bufX + ORI_NV + 4);
 #ifdef MODSX_ORI_LDS_TABLE
   __shared__ __attribute__((aligned(16))) unsigned char sbt[ATAN_CASES];
 #else
