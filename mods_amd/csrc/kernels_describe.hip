@@ -579,7 +579,7 @@ __global__ __launch_bounds__(BLUR_T) void k_blur_cols_lds(const BlurTile *__rest
 //     8rb..8rb+7 the bin is the pixel's bin1 (weight w1), for rows 8rb+8..8rb+15 its bin0 (weight w0);
 //     same for columns -- this is precomputeBinsAndWeights (siftdesc.cpp:22-71) for 4 spatial bins
 //     and patch 41, where step = 5/40 makes xi = i/8.
-constexpr int PS = 41, NPX = PS * PS, PSP = 44;  // PSP: padded row stride (16-byte aligned rows)
+constexpr int PS = 41, NPX = PS * PS;
 
 struct SiftConst {
   int nmask;   // number of pixels with mask > 0
@@ -607,24 +607,26 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
   const int kreal = blockIdx.x * DR + reg;
   const bool alive = kreal < n;                                    // a region past the end repeats the last one and stores nothing
   const int k = alive ? kreal : n - 1;
-  // `patch` (unpadded 41 x 41) and `bufB` (padded rows) share one buffer: whatever replaces the patch is first staged
-  // in registers (14 values per thread) and written after a barrier
-  __shared__ __attribute__((aligned(16))) float patchB_[DR][PS * PSP];
-  float *const patch = patchB_[reg], *const bufB = patchB_[reg];
+  // 15.8 KB of LDS per region (it was 19.7: four workgroups of two regions per CU; now five, and the kernel's time follows its
+  // residency -- its phases are chains of dependent LDS / global accesses, not issue-bound).  Two pixel arrays, both unpadded
+  // (index p = 41 r + c):
+  //   bufO: the patch; after the gradients the pixel's orientation o = 8 (ori + 2 pi) / (2 pi) (staged in registers first) -- its
+  //         bin and the two orientation weights are formed from it where they are used (the gather's forming step);
+  //   bufA: WX (direct branch) / the resampling table (grid branch), the compacted masked values, later val = mask * |grad|.
+  constexpr int NPXP = (NPX + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float bufO_[DR][NPXP];
+  float *const patch = bufO_[reg], *const bufO = bufO_[reg];
   constexpr int PER_T = (NPX + 127) / 128;
-  __shared__ __attribute__((aligned(16))) float bufA_[DR][PS * PSP];   // WX (direct branch), compacted masked values, later val
+  __shared__ __attribute__((aligned(16))) float bufA_[DR][NPXP];
   float *const bufA = bufA_[reg];
   __shared__ __attribute__((aligned(16))) double slut_[DR][256];   // the descriptor vector and its partial sums (2 KB)
-  __shared__ __attribute__((aligned(16))) unsigned char sb0_[DR][PS * PSP];   // orientation bin bo0 % 8 of every pixel
-  unsigned char *const sb0 = sb0_[reg];
+  __shared__ __attribute__((aligned(16))) unsigned char sbs_[DR][4 * 64];   // gather: orientation bin bo0 % 8 of the step's 4 x 64 slots
   __shared__ float swr0_[DR][PS], swr1_[DR][PS];
   float *const swr0 = swr0_[reg], *const swr1 = swr1_[reg];
-  // 1 KB used twice: the resampling table of the sampling stage (smap, sfr), later the per-step weighted values of the
-  // gather (sv0; sv1 takes the norm's scratch)
-  __shared__ __attribute__((aligned(16))) unsigned char sraw_[DR][1024];
-  unsigned char *const sraw = sraw_[reg];
-  int4 *const smap = reinterpret_cast<int4 *>(sraw);
-  float *const sfr = reinterpret_cast<float *>(sraw + 672);
+  // the resampling table of the grid branch (smap, sfr) lies in bufA, which that branch does not use before the normalisation
+  int4 *const smap = reinterpret_cast<int4 *>(bufA);
+  float *const sfr = bufA + 168;
+  static_assert(PS * 16 <= 168 * 4 && (168 + PS) <= NPXP, "smap (41 x int4) and sfr (41 floats) fit in bufA");
   double *const vec = slut_[reg], *const part = slut_[reg] + 128;
   __shared__ float sstat_[DR][2];
   float *const sstat = sstat_[reg];
@@ -653,30 +655,37 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
       sfr[tid] = coordTab[jb.coordOfs + tid] - (float)m.z;     // wx_i = WX_i - x0_i (= wy for rows)
     }
     __syncthreads();
-    float g00[PER_T], g01[PER_T], g10[PER_T], g11[PER_T];
+    // two halves of seven samples: 28 grid values in flight per thread instead of 56 -- the registers of the second 28 were what
+    // held the kernel at four wavefronts per SIMD (117 VGPRs) once its LDS allowed five workgroups per CU
+    constexpr int HALF_T = PER_T / 2;
+    static_assert(PER_T == 2 * HALF_T, "an even number of samples per thread");
 #pragma unroll
-    for (int k = 0; k < PER_T; k++) {
-      const int p = tid + 128 * k, pp = p < NPX ? p : NPX - 1;
-      const int r = pp / PS, c = pp - r * PS;
-      const int4 mr = smap[r], mc = smap[c];
-      const bool ok = mr.w && mc.w;
-      const float *R0 = G + (size_t)(ok ? mr.x : 0) * NC, *R1 = G + (size_t)(ok ? mr.y : 0) * NC;
-      const int x0 = ok ? mc.x : 0, x1 = ok ? mc.y : 0;
-      g00[k] = R0[x0]; g01[k] = R0[x1]; g10[k] = R1[x0]; g11[k] = R1[x1];
-    }
-    __syncthreads();   // (the direct branch of another region of the workgroup has a barrier here)
+    for (int h = 0; h < 2; h++) {
+      float g00[HALF_T], g01[HALF_T], g10[HALF_T], g11[HALF_T];
 #pragma unroll
-    for (int k = 0; k < PER_T; k++) {
-      const int p = tid + 128 * k;
-      if (p < NPX) {
-        const int r = p / PS, c = p - r * PS;
-        float v = 0.f;
-        if (smap[r].w && smap[c].w) {
-          const float wx = sfr[c], wyd = sfr[r];
-          const float I1 = wx * (g01[k] - g00[k]) + g00[k];
-          v = wyd * (wx * (g11[k] - g10[k]) + g10[k] - I1) + I1;
+      for (int kk = 0; kk < HALF_T; kk++) {
+        const int p = tid + 128 * (h * HALF_T + kk), pp = p < NPX ? p : NPX - 1;
+        const int r = pp / PS, c = pp - r * PS;
+        const int4 mr = smap[r], mc = smap[c];
+        const bool ok = mr.w && mc.w;
+        const float *R0 = G + (size_t)(ok ? mr.x : 0) * NC, *R1 = G + (size_t)(ok ? mr.y : 0) * NC;
+        const int x0 = ok ? mc.x : 0, x1 = ok ? mc.y : 0;
+        g00[kk] = R0[x0]; g01[kk] = R0[x1]; g10[kk] = R1[x0]; g11[kk] = R1[x1];
+      }
+      if (h == 0) __syncthreads();   // (the direct branch of another region of the workgroup has a barrier here)
+#pragma unroll
+      for (int kk = 0; kk < HALF_T; kk++) {
+        const int p = tid + 128 * (h * HALF_T + kk);
+        if (p < NPX) {
+          const int r = p / PS, c = p - r * PS;
+          float v = 0.f;
+          if (smap[r].w && smap[c].w) {
+            const float wx = sfr[c], wyd = sfr[r];
+            const float I1 = wx * (g01[kk] - g00[kk]) + g00[kk];
+            v = wyd * (wx * (g11[kk] - g10[kk]) + g10[kk] - I1) + I1;
+          }
+          patch[p] = v;
         }
-        patch[p] = v;
       }
     }
   } else {
@@ -695,8 +704,8 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
       float WY = ry - (float)half * a21;
 #pragma unroll 1
       for (int i = 0; i < PS; i++) {
-        bufA[tid * PSP + i] = WX;
-        bufB[tid * PSP + i] = WY;
+        bufA[tid * PS + i] = WX;
+        bufO[tid * PS + i] = WY;
         WX += a11;
         WY += a21;
       }
@@ -707,7 +716,7 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
     for (int k = 0; k < PER_T; k++) {
       const int p = tid + 128 * k;
       const int r = p / PS, c = p - r * PS;
-      sv[k] = p < NPX ? bilinear_tap(as_global(src), srows, scols, bufA[r * PSP + c], bufB[r * PSP + c], touch) : 0.f;
+      sv[k] = p < NPX ? bilinear_tap(as_global(src), srows, scols, bufA[r * PS + c], bufO[r * PS + c], touch) : 0.f;
     }
     __syncthreads();   // every WY coordinate has been consumed; the samples may overwrite them
 #pragma unroll
@@ -783,16 +792,14 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
     // significant bits), so rounding it to f32 IS the f32 product; mask, g >= 0, so the + 0.0 changes nothing
     const float val = mask[p] * g;
     const float o = oTab[special ? 2048 : code * 256 + idx];
-    const int bo0 = (int)o;
-    ov[k] = o - (float)bo0;              // wo1 (siftdesc.cpp:111-117), formed once per pixel instead of once per bin
-    sb0[r * PSP + c] = (unsigned char)(bo0 & 7);   // o >= 4 (ori >= -pi), so bo0 % 8 = bo0 & 7
-    bufA[r * PSP + c] = val;     // the column weights wc0 / wc1 = (float)(w[c] * val) are formed in the gather
+    ov[k] = o;                   // bo0 = (int)o and wo1 = o - bo0 (siftdesc.cpp:111-117) are formed in the gather
+    bufA[p] = val;               // the column weights wc0 / wc1 = (float)(w[c] * val) are formed in the gather
   }
-  __syncthreads();   // all gradients taken: the patch may be replaced by wo1
+  __syncthreads();   // all gradients taken: the patch may be replaced by o
 #pragma unroll
   for (int k = 0; k < PER_T; k++) {
     const int p = tid + 128 * k;
-    if (p < NPX) { const int r = p / PS, c = p - r * PS; bufB[r * PSP + c] = ov[k]; }
+    if (p < NPX) bufO[p] = ov[k];
   }
   __syncthreads();
   // -- samplePatch: a bin gathers its 16x16 pixel block in raster order.  ONE wavefront per region does it, a lane owning two
@@ -806,8 +813,10 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
     const bool gth = tid < 64;
     const int rb = (tid >> 4) & 3, cb = (tid >> 2) & 3, oa = 2 * (tid & 3), ob = oa + 1, oam = (oa + 7) & 7;
     double accA = 0.0, accB = 0.0;
-    float(*const sv0)[64] = reinterpret_cast<float(*)[64]>(sraw);      // v (1 - wo1) of the step's 4 rows x 64 column slots
+    float(*const sv0)[64] = reinterpret_cast<float(*)[64]>(vec);       // v (1 - wo1) of the step's 4 rows x 64 column slots (the descriptor
+                                                                       // vector itself is written when the loop is over)
     float(*const sv1)[64] = reinterpret_cast<float(*)[64]>(part);      // v wo1 (the norm's scratch is idle until the gather is over)
+    unsigned char(*const sbs)[64] = reinterpret_cast<unsigned char(*)[64]>(sbs_[reg]);
     // Step rr touches rows 8 rb + rr (rb = 0..3) with one row weight each; a pixel's column weight is w1[c] in the block
     // whose first half holds column c and w0[c] in the block whose second half does.  The product
     // wr * (float)(w[c] * val) is the same for the orientation lanes of a bin block, so the 128 threads first form the
@@ -822,23 +831,24 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
         const float wrr = rr < 8 ? swr1[r] : swr0[r];
         // wc0 / wc1 = (float)(w[c] * (double)val) in the reference: the weights are multiples of 1/8 (exact in f32, checked
         // where the table is built), so the f64 product is exact and its rounding to f32 is the f32 product
-        const float wcv = (vc < 32 ? swr1[col] : swr0[col]) * bufA[r * PSP + col];
+        const float wcv = (vc < 32 ? swr1[col] : swr0[col]) * bufA[r * PS + col];
         const float v = wrr * wcv;
         const float vcl = v > 0 ? v : 0.f;
-        const float wo1 = bufB[r * PSP + col];
+        const float o = bufO[r * PS + col];
+        const int bo0 = (int)o;
+        const float wo1 = o - (float)bo0;      // formed per use (2.4 times per pixel) instead of being kept per pixel
         sv0[rbi][vc] = vcl * (1.0f - wo1);
         sv1[rbi][vc] = vcl * wo1;
+        sbs[rbi][vc] = (unsigned char)(bo0 & 7);   // o >= 4 (ori >= -pi), so bo0 % 8 = bo0 & 7
       }
       __syncthreads();
       if (gth) {
-        const int r = 8 * rb + rr;
-        const int q0 = r * PSP + 8 * cb;
 #pragma unroll
         for (int seg = 0; seg < 4; seg++) {
-          const int q = q0 + 4 * seg, sx = (seg < 2 ? 0 : 24) + 8 * cb + 4 * seg;
+          const int sx = (seg < 2 ? 0 : 24) + 8 * cb + 4 * seg;
           const float4 p0v = *reinterpret_cast<const float4 *>(&sv0[rb][sx]);
           const float4 p1v = *reinterpret_cast<const float4 *>(&sv1[rb][sx]);
-          const unsigned b4 = *reinterpret_cast<const unsigned *>(sb0 + q);
+          const unsigned b4 = *reinterpret_cast<const unsigned *>(&sbs[rb][sx]);
           const float p0s[4] = {p0v.x, p0v.y, p0v.z, p0v.w};
           const float p1s[4] = {p1v.x, p1v.y, p1v.z, p1v.w};
 #pragma unroll
