@@ -56,7 +56,7 @@ struct GrownRegion {
 
 struct Forest {
   int rows, cols, stride;
-  const uint8_t *grey;                 // padded (rows + 2) x stride, frame = 255
+  const uint8_t *grey;                 // padded (rows + 2) x stride
   // parent: -1 = pixel not seen yet (the hot array: four neighbour look-ups per pixel); node: per ROOT the counters of a small
   // component, or the index of its region (>= 0) -- written when a pixel becomes a root, so it needs no clearing
   struct Node { int area, perim, region; };
@@ -152,11 +152,7 @@ struct Forest {
 
   void run() {
     const size_t npx = (size_t)(rows + 2) * stride;
-    // parent[] needs no clearing: a pixel's entry is written when the pixel is visited, and the (grey, raster) test below only
-    // lets visited pixels through -- except for the frame at level 255, whose entries are therefore the only ones set here
-    node.resize(npx); parent.resize(npx);
-    for (int c = 0; c < stride; c++) parent[c] = parent[(size_t)(rows + 1) * stride + c] = -1;
-    for (int r = 1; r <= rows; r++) parent[(size_t)r * stride] = parent[(size_t)r * stride + cols + 1] = -1;
+    node.resize(npx); parent.assign(npx, -1);
     // bin sort: offsets per grey level in raster order (sortPixels.cpp:76-125)
     std::vector<int> start(257, 0);
     for (int r = 1; r <= rows; r++) { const uint8_t *g = grey + (size_t)r * stride; for (int c = 1; c <= cols; c++) start[g[c] + 1]++; }
@@ -173,11 +169,8 @@ struct Forest {
         const int nb[4] = {ofs - stride, ofs - 1, ofs + 1, ofs + stride};
         int roots[4], nroots = 0, touching = 0;
         for (int q = 0; q < 4; q++) {
-          // a neighbour was visited before this pixel iff it sorts first in (grey, raster) order: asked of the byte image (a
-          // quarter of parent[]'s footprint), so parent[] lines are only pulled for neighbours that are in the forest
-          if ((int)grey[nb[q]] > level - (q >> 1)) continue;
           const int pq = parent[nb[q]];
-          if (pq < 0) continue;                   // the 255 frame at level 255
+          if (pq < 0) continue;
           touching++;
           // inside a component the neighbours already point at (or one step from) the root found for an earlier neighbour
           if (nroots && (pq == roots[nroots - 1] || parent[pq] == roots[nroots - 1]) && parent[roots[nroots - 1]] == roots[nroots - 1]) continue;
@@ -317,7 +310,7 @@ void sym_sqrt(double c00, double c01, double c11, double A[4]) {
 struct MserScratch {
   std::vector<Forest::Node> node;
   std::vector<int> parent, order, stack;
-  std::vector<uint8_t> fence, mark;
+  std::vector<uint8_t> grey, fence, mark;
   std::vector<RowRun> runs;
 };
 static thread_local MserScratch t_scratch;
@@ -328,18 +321,17 @@ static void mser_polarity(const uint8_t *u8, int rows, int cols, const modsx_mse
   MserScratch &S = t_scratch;
   const int stride = cols + 2;
   const size_t npx = (size_t)(rows + 2) * stride;
-  // `fence`: the view inside a frame of 255.  The frame is never visited by the tree (only interior offsets are in `order`;
-  // its "sorts first" test can only take a frame pixel for a visited one at level 255, where parent[] = -1 says otherwise),
-  // and it stops the span fill of any threshold < 255 at the image border
-  S.fence.assign(npx, 255); S.mark.assign(npx, 0);
+  // `grey`: the padded image the tree is built on (frame 0, never visited: only interior offsets are in `order`);
+  // `fence`: the same pixels inside a frame of 255, which stops the span fill of any threshold < 255 at the image border
+  S.grey.assign(npx, 0); S.fence.assign(npx, 255); S.mark.assign(npx, 0);
   for (int r = 0; r < rows; r++) {
-    uint8_t *f = &S.fence[(size_t)(r + 1) * stride + 1];
+    uint8_t *g = &S.grey[(size_t)(r + 1) * stride + 1], *f = &S.fence[(size_t)(r + 1) * stride + 1];
     const uint8_t *src = u8 + (size_t)r * cols;
-    if (pol == 0) memcpy(f, src, cols);
-    else for (int c = 0; c < cols; c++) f[c] = (uint8_t)(255 - src[c]);
+    if (pol == 0) { memcpy(g, src, cols); memcpy(f, src, cols); }
+    else for (int c = 0; c < cols; c++) g[c] = f[c] = (uint8_t)(255 - src[c]);
   }
   Forest F(S.node, S.parent, S.order);
-  F.rows = rows; F.cols = cols; F.stride = stride; F.grey = S.fence.data();
+  F.rows = rows; F.cols = cols; F.stride = stride; F.grey = S.grey.data();
   F.minSize = par.min_size; F.promoteAt = std::min(10000, par.min_size);
   F.maxSize = (int)((double)cols * rows * par.max_area);
   F.minMargin = par.relative ? minMargin / 100.0 : minMargin;
