@@ -15,6 +15,11 @@ namespace mx {
 constexpr int PS = 41, PSP = 44;   // PSP: padded row stride so rows start 16-byte aligned in LDS
 constexpr int ORI_B = 21;          // taps of a patch row in flight per lane
 
+// LDS_TABLE: the launch is too small to fill the device (a lone pair of few views): every wavefront then runs alone on its SIMD,
+// its 20 table look-ups per lane are trips to L2 one after the other, and a copy of the table in LDS is the faster choice
+// (0.34 against 0.52 ms for the orientation stage of a 1-view pair).  Large launches read the table where it lies: 2.1 KB of LDS
+// less per region is three more regions per CU.
+template <bool LDS_TABLE>
 __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, float *out, int n, const ImgRef *imgs,
                                                     const unsigned short *maskIdx, const float *maskW,
                                                     const unsigned char *binTab, int doHalf, double th, int maxAngles) {
@@ -28,25 +33,20 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, float *o
   // gradients are staged in registers): at most ORI_NV + 4 weights, then the bytes -- 7.4 KB of LDS per region instead of 9.2
   static_assert((ORI_NV + 4) * 4 + ORI_NV + 4 <= PS * PSP * 4 && (ORI_NV + 4) % 4 == 0, "the voting list fits in the patch buffer");
   unsigned char *const sbin = reinterpret_cast<unsigned char *>(bufX + ORI_NV + 4);
-#ifdef MODSX_ORI_LDS_TABLE
-  __shared__ __attribute__((aligned(16))) unsigned char sbt[ATAN_CASES];
-#else
-  // the 2 KB bin table is read where it lies: every wavefront of the launch hits the same 33 cache lines, and a copy per
-  // workgroup cost 2.1 of the 11.3 KB of LDS that bound the residency (14 -> 17 regions per CU)
-  const unsigned char *const sbt = binTab;
-#endif
+  // the 2 KB bin table is read where it lies (every wavefront of the launch hits the same 33 cache lines; a copy per
+  // workgroup cost 2.1 of the 11.3 KB of LDS that bound the residency: 14 -> 17 regions per CU) unless the launch is small
+  __shared__ __attribute__((aligned(16))) unsigned char sbtLds[LDS_TABLE ? ATAN_CASES : 16];
+  const unsigned char *const sbt = LDS_TABLE ? sbtLds : binTab;
   __shared__ float hist[40];
   static_assert(ATAN_CASES == 33 * 64, "one 4-byte word per lane and step");
-#ifdef MODSX_ORI_LDS_TABLE
-  {   // the bin table: independent loads per lane, issued together
+  if (LDS_TABLE) {   // the bin table: independent loads per lane, issued together
     unsigned t[9];
 #pragma unroll
     for (int u = 0; u < 9; u++) t[u] = lane + 64 * u < ATAN_CASES / 4 ? reinterpret_cast<const unsigned *>(binTab)[lane + 64 * u] : 0u;
 #pragma unroll
     for (int u = 0; u < 9; u++)
-      if (lane + 64 * u < ATAN_CASES / 4) reinterpret_cast<unsigned *>(sbt)[lane + 64 * u] = t[u];
+      if (lane + 64 * u < ATAN_CASES / 4) reinterpret_cast<unsigned *>(sbtLds)[lane + 64 * u] = t[u];
   }
-#endif
   const OriJob jb = jobs[k];
   const ImgRef im = imgs[jb.img];
   const int half = PS >> 1;
@@ -205,8 +205,13 @@ void launch_orientation(hipStream_t s, const OriJob *jobs, float *out, int n, co
                           const unsigned short *maskIdx, const float *maskW, const unsigned char *binTab, int doHalf, double th,
                           int maxAngles) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_orientation, dim3(8 * ((n + 7) / 8)), dim3(64), 0, s, jobs, out, n, imgs, maskIdx, maskW, binTab, doHalf, th,
-                     maxAngles);
+  // fewer regions than two rounds of wavefronts over the chip: the launch is latency, not residency
+  if (n < 2 * 256 * 16)
+    hipLaunchKernelGGL(k_orientation<true>, dim3(8 * ((n + 7) / 8)), dim3(64), 0, s, jobs, out, n, imgs, maskIdx, maskW, binTab, doHalf, th,
+                       maxAngles);
+  else
+    hipLaunchKernelGGL(k_orientation<false>, dim3(8 * ((n + 7) / 8)), dim3(64), 0, s, jobs, out, n, imgs, maskIdx, maskW, binTab, doHalf, th,
+                       maxAngles);
 }
 
 }  // namespace mx
