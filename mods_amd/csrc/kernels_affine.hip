@@ -211,6 +211,13 @@ __global__ __launch_bounds__(64) void k_baumberg(const AffJob *jobs, AffOut *out
 // On its own the launch is no faster than k_baumberg (the dependent chains bound it); it issues 17 % fewer vector
 // instructions, and vector issue is what the pipeline's concurrent streams compete for.
 MX_D void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // LDS hand-over inside one wavefront
+#ifdef BAUM_TRACE
+// debugging aid (tools/trace_baumberg.py): shader-clock time of a wavefront per phase of its iterations, summed over the launch
+__device__ unsigned long long g_btrace[16];
+#define BT(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); bt_[i] += t_ - btl_; btl_ = t_; } while (0)
+#else
+#define BT(i) do { } while (0)
+#endif
 
 template <int K>
 __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffOut *out, int n, const float *mask, int chunk,
@@ -249,6 +256,9 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
     for (int i = next + lane; i < end; i += 64) { AffOut o; o.u11 = 1; o.u12 = 0; o.u21 = 0; o.u22 = 1; o.ok = 0; o.iters = 0; out[i] = o; }
     return;
   }
+#ifdef BAUM_TRACE
+  unsigned long long bt_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, btl_ = __builtin_readcyclecounter();
+#endif
   for (;;) {
     // refill: every idle slot takes the next keypoint of the chunk, in slot order
     {
@@ -269,6 +279,7 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
     }
     const unsigned long long liveMask = __ballot(live);
     if (!liveMask) break;
+    BT(0);
     const float A11 = u11 * ratio, A12 = u12 * ratio, A21 = u21 * ratio, A22 = u22 * ratio;
     if constexpr (K == 2) {
       // Sample coordinates of BOTH slots at once (helpers.cpp:563-585: f32 running sums down the rows, then along each row).
@@ -307,6 +318,7 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
         wv += st;
       }
     }
+    BT(1);
 #pragma unroll
     for (int q = 0; q < K; q++) {
       if (!((liveMask >> (2 * q)) & 1)) continue;
@@ -352,6 +364,7 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
           if (lane + 64 * u < WW) simg[lane + 64 * u] = sv[u];
       }
       wave_lds_sync();
+      BT(2 + 2 * (q & 1));
       {
         float qa[PERM], qb[PERM], qc[PERM];
 #pragma unroll
@@ -371,6 +384,7 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
           if (p < WW) { pa[p] = qa[u]; pb[p] = qb[u]; pc[p] = qc[u]; }
         }
       }
+      BT(3 + 2 * (q & 1));
     }
     wave_lds_sync();
     float acc = 0.f;
@@ -384,6 +398,7 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
       acc /= (float)WW;
     }
     float a = __shfl(acc, 3 * kq), b = __shfl(acc, 3 * kq + 1), c = __shfl(acc, 3 * kq + 2);
+    BT(6);
     if (live) {
       {   // invSqrt, helpers.cpp:463-502 (inv_sqrt_wave with the partner lane in the place of lanes 0 / 1)
         double t, r;
@@ -433,7 +448,14 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
         }
       }
     }
+    BT(7);
   }
+#ifdef BAUM_TRACE
+  if (lane == 0) {
+    for (int i = 0; i < 8; i++) atomicAdd(&g_btrace[i], bt_[i]);
+    atomicAdd(&g_btrace[8], 1ull);
+  }
+#endif
 }
 
 #ifndef MODSX_BAUMBERG_K
@@ -460,3 +482,11 @@ void launch_baumberg(hipStream_t s, const AffJob *jobs, AffOut *out, int n, cons
 }
 
 }  // namespace mx
+
+#ifdef BAUM_TRACE
+extern "C" __attribute__((visibility("default"))) int modsx_debug_baum_trace(unsigned long long *out, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mx::g_btrace), 16 * 8, 0, hipMemcpyDeviceToHost);
+  if (reset) { unsigned long long z[16] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(mx::g_btrace), z, sizeof z, 0, hipMemcpyHostToDevice); }
+  return rc;
+}
+#endif
