@@ -653,17 +653,21 @@ def main():
             hshare = {"verify_ms_per_pair": vms / max(1, vn), "helper_threads": vth}
             pF = mods_amd.default_pair_params(ransac_seed=1, useF=1, **WXBS)
             mods_amd.match_pairs(ctxs, imgs1, imgs2, pF)
+            mods_amd.verify_device_stats(reset=True)
             ta = time.perf_counter()
             stF = 3
             for _ in range(stF):
                 rF = mods_amd.match_pairs(ctxs, imgs1, imgs2, pF)
             dtF = time.perf_counter() - ta
             fms, fn, fth = mods_amd.last_batch_verify()
+            vst = mods_amd.verify_device_stats()
             out["wxbs"] = {
                 "H": {"pairs_per_s": value, **hshare,
                       "host_ransac_share_of_wall": (vms / max(1, vn)) / max(1, vth) / (1e3 / value) * 1.0},
                 "F": {"pairs_per_s": stF * nbatch / dtF, "verify_ms_per_pair": fms / max(1, fn), "helper_threads": fth,
                       "verified_last_pair": rF[0]["n_verified"],
+                      "rfth_loops_per_pair": vst["loops"] / float(stF * nbatch), "rfth_ms_per_loop": 1e-3 * vst["loop_us"] / max(1, vst["loops"]),
+                      "rfth_hypotheses_on_device": vst["hypotheses"], "rfth_device_batches": vst["batches"],
                       "host_ransac_share_of_wall": (fms / max(1, fn)) / max(1, fth) / (dtF / (stF * nbatch) * 1e3)},
                 "note": "DuplicateFiltering + LO-RANSAC run on helper threads beside the device pipeline; share = per-pair verify "
                         "time / helper threads / per-pair wall time (the fraction of the wall the helpers are busy)"}

@@ -314,6 +314,14 @@ int modsx_ransac_f(const double *u, int len, double th, double conf, int max_sam
 int modsx_loransac_f(const double *pts, const double *laf1, const double *laf2, int T, double err_threshold,
                      double confidence, int max_samples, int localOptimization, double LAFCoef, int doSymmCheck,
                      int error_type, unsigned seed, double *F, unsigned char *inl, unsigned char *keep, int *data_out);
+/* The hypothesis loop of DEGENSAC's plane-and-parallax step (rFtH, DegUtils.c:254-440: up to 2 x 10^4 two-point epipoles per
+ * H-degenerate sample, each scored with FDs over the off-plane correspondences) runs on the device when the calling thread has
+ * one: the host draws the samples of a batch from a copy of the PRNG, one device thread per hypothesis counts, the host acts on
+ * the first count that changes the loop's state exactly as the reference does.  Same trajectory, same F (tests/test_gpu_verify.py
+ * against the reference's compiled degensac).  MODSX_VERIFY_DEVICE=0 keeps the loop on the host; without a device it is there
+ * anyway.  out[0..6): device batches, hypotheses counted on the device, state-changing hypotheses, host / device disagreements,
+ * rFtH loops run (either way) and the microseconds they took (process-wide; reset != 0 clears them).  Returns 6. */
+int modsx_verify_device_stats(long *out, int reset);
 
 /* One step of mods.cpp's iteration loop (:229-415) for an identity view: detect + orient + describe both
  * images, match, filter duplicates, verify.  Images and all intermediates stay in HBM between stages. */

@@ -11,6 +11,9 @@
 // and ccmath svduv are replaced by a cyclic Jacobi eigen-solver (null vectors and the rank-2 projection are
 // unique up to sign, agreement ~1e-15).  Reads of uninitialised memory in the reference (u2f with fewer than
 // 8 points, exp_ranF.c ALO branch indexing errs[i] past the loop) are replaced by the intended computation.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
 #include "engine_api.hpp"
 #include "ransac_common.hpp"
 
@@ -63,17 +66,17 @@ static void jacobi_eig(const double *C, int n, double *ev, double *V) {
   for (int i = 0; i < n; i++) ev[i] = A[i * n + i];
 }
 
-static inline void cross3(double *o, const double *a, const double *b) {  // crossp, DegUtils.c:246-250
+static inline __host__ __device__ void cross3(double *o, const double *a, const double *b) {  // crossp, DegUtils.c:246-250
   o[0] = a[1] * b[2] - a[2] * b[1];
   o[1] = a[2] * b[0] - a[0] * b[2];
   o[2] = a[0] * b[1] - a[1] * b[0];
 }
-static inline void skew_sym(const double *a, double *ax) {  // DegUtils.c:212-222
+static inline __host__ __device__ void skew_sym(const double *a, double *ax) {  // DegUtils.c:212-222
   ax[0] = 0; ax[1] = -a[2]; ax[2] = a[1];
   ax[3] = a[2]; ax[4] = 0; ax[5] = -a[0];
   ax[6] = -a[1]; ax[7] = a[0]; ax[8] = 0;
 }
-static inline void mul3(double *o, const double *a, const double *b) {  // mmul, row-major 3x3
+static inline __host__ __device__ void mul3(double *o, const double *a, const double *b) {  // mmul, row-major 3x3
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) {
       double s = 0;
@@ -81,7 +84,7 @@ static inline void mul3(double *o, const double *a, const double *b) {  // mmul,
       o[i * 3 + j] = s;
     }
 }
-static inline void tr3(double *o, const double *a) {
+static inline __host__ __device__ void tr3(double *o, const double *a) {
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) o[j * 3 + i] = a[i * 3 + j];
 }
 
@@ -479,6 +482,107 @@ static inline Score tr_inlidxs(const double *err, int len, double th, int *inl) 
   RTRACE("S %u %.17g th %.3g\n", s.I, s.J, th);
   return s;
 }
+// ---- rFtH's hypothesis loop on the device ---------------------------------------------------------------------------------
+// rFtH (DegUtils.c:254-440) tries up to 2 x 10^4 epipoles, each from two off-plane correspondences, and counts for each the
+// off-plane correspondences within 2 th of the F it gives with the plane's H; only a count above the best so far changes any
+// state (innerFH, which also draws from the PRNG).  On a planar scene no hypothesis ever does and the loop is 15-20 ms of one
+// host core per DEGENSAC sample.  Between two such events the sample stream is a function of the PRNG state alone, so the loop
+// runs in batches: the host draws the next B samples from a COPY of the generator, one device thread per hypothesis forms the
+// epipole and F and counts (the f64 operations of the host code in the same order: the counts are the host's), the host takes
+// the first hypothesis whose count beats the best, replays the generator up to it and runs the reference's body for it.
+struct RfthArgs { double Ht[9]; double th2; int nN, B; };
+constexpr int RFTH_TILE = 512;     // off-plane correspondences staged in LDS at a time (24 KB)
+// All four arrays are pinned host memory mapped into the device's address space: a batch is ONE operation on the stream (no
+// copy in front of the kernel, none behind it) -- under a device saturated by 16 contexts every queued operation waits its turn,
+// and three of them made a batch slower than the host loop it replaces.  The points are read once per workgroup (into LDS).
+__global__ __launch_bounds__(256) void k_rfth_count(const double *__restrict__ us, const double *__restrict__ uN,
+                                                    const unsigned *__restrict__ pairs, RfthArgs A, unsigned *__restrict__ cnt) {
+  __shared__ double tile[RFTH_TILE * 6];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const bool live = j < A.B;
+  double F[9];
+  if (live) {
+    const double *a = us + 6 * (size_t)pairs[2 * j], *b = us + 6 * (size_t)pairs[2 * j + 1];
+    double c1[3], c2[3], ec[3], aFt[9], aFtH[9];
+    cross3(c1, a, a + 3);
+    cross3(c2, b, b + 3);
+    cross3(ec, c1, c2);
+    const double nrm = sqrt(ec[0] * ec[0] + ec[1] * ec[1] + ec[2] * ec[2]);
+    ec[0] = ec[0] / nrm; ec[1] = ec[1] / nrm; ec[2] = ec[2] / nrm;
+    skew_sym(ec, aFt);
+    mul3(aFtH, aFt, A.Ht);
+    tr3(F, aFtH);
+  }
+  unsigned no_i = 0;
+  for (int t0 = 0; t0 < A.nN; t0 += RFTH_TILE) {
+    const int m = min(RFTH_TILE, A.nN - t0);
+    __syncthreads();
+    for (int k = threadIdx.x; k < 6 * m; k += 256) tile[k] = uN[6 * (size_t)t0 + k];
+    __syncthreads();
+    if (live)
+      for (int i = 0; i < m; i++) {
+        const double *u = tile + 6 * i;     // the same LDS address in every lane: a broadcast
+        const double rxc = F[0] * u[3] + F[3] * u[4] + F[6];
+        const double ryc = F[1] * u[3] + F[4] * u[4] + F[7];
+        const double rwc = F[2] * u[3] + F[5] * u[4] + F[8];
+        const double r = (u[0] * rxc + u[1] * ryc + rwc);
+        const double rx = F[0] * u[0] + F[1] * u[1] + F[2];
+        const double ry = F[3] * u[0] + F[4] * u[1] + F[5];
+        const double d = r * r / (rxc * rxc + ryc * ryc + rx * rx + ry * ry);
+        if (d < A.th2) ++no_i;
+      }
+  }
+  if (live) cnt[j] = no_i;
+}
+
+// per host thread (the verifier runs on the contexts' helper threads): a stream and the few buffers of the loop, on the
+// thread's current device.  No device (the CPU test container), MODSX_VERIFY_DEVICE=0 or any HIP error: the host loop.
+static std::atomic<long> g_rfthStats[6];   // batches, hypotheses scored on the device, events, host / device disagreements, rFtH loops, their microseconds
+struct RfthDevice {
+  enum { BATCH = 20480 };   // a whole loop (2 x 10^4 hypotheses) in one round trip: speculation past an event costs the device nothing
+  bool tried = false, ok = false;
+  hipStream_t s = nullptr;
+  double *hUs = nullptr, *hUn = nullptr, *dUs = nullptr, *dUn = nullptr;     // pinned + mapped: host pointer / device alias
+  unsigned *hPairs = nullptr, *hCnt = nullptr, *dPairs = nullptr, *dCnt = nullptr;
+  size_t capPts = 0;
+  static bool pinned(void **h, void **d, size_t bytes) {
+    return hipHostMalloc(h, bytes, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(d, *h, 0) == hipSuccess;
+  }
+  bool init() {
+    if (tried) return ok;
+    tried = true;
+    const char *e = getenv("MODSX_VERIFY_DEVICE");
+    if (e && atoi(e) == 0) return false;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { (void)hipGetLastError(); return false; }
+    // the highest priority: a batch is a few wavefronts that must not queue behind the launch sets of 16 contexts
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) return false;
+    if (!pinned((void **)&hPairs, (void **)&dPairs, BATCH * 8) || !pinned((void **)&hCnt, (void **)&dCnt, BATCH * 4)) return false;
+    ok = true;
+    return true;
+  }
+  bool points(const double *us, const double *uN, size_t nN) {
+    if (nN > capPts) {
+      if (hUs) hipHostFree(hUs);
+      if (hUn) hipHostFree(hUn);
+      hUs = hUn = nullptr; capPts = 0;
+      const size_t cap = nN + nN / 2 + 64;
+      if (!pinned((void **)&hUs, (void **)&dUs, cap * 48) || !pinned((void **)&hUn, (void **)&dUn, cap * 48)) return false;
+      capPts = cap;
+    }
+    memcpy(hUs, us, nN * 48);
+    memcpy(hUn, uN, nN * 48);
+    return true;
+  }
+  bool count(const RfthArgs &A) {     // hPairs -> hCnt
+    hipLaunchKernelGGL(k_rfth_count, dim3((A.B + 255) / 256), dim3(256), 0, s, dUs, dUn, dPairs, A, dCnt);
+    return hipStreamSynchronize(s) == hipSuccess && hipGetLastError() == hipSuccess;
+  }
+};
+static thread_local RfthDevice t_rfth;
+
 struct RansacF {
   const double *u;
   int len;
@@ -768,11 +872,14 @@ struct RansacF {
     if (nN < 4 || nH < 6) return 0;
     double Ht[9];
     tr3(Ht, H);
-    for (unsigned no_sam = 1; no_sam < 2 * max_sam; ++no_sam) {
+    auto draw = [&](GlibcRandom &g, std::vector<unsigned> &p) {   // the two swaps of one iteration
       for (unsigned pos = 0; pos < 2; ++pos) {
-        const unsigned idx = pos + 1 + (unsigned)(rng.next() % (nN - pos - 1));
-        const unsigned t = ptr[pos]; ptr[pos] = ptr[idx]; ptr[idx] = t;
+        const unsigned idx = pos + 1 + (unsigned)(g.next() % (nN - pos - 1));
+        const unsigned t = p[pos]; p[pos] = p[idx]; p[idx] = t;
       }
+    };
+    // the body of an iteration once its sample is in ptr[0], ptr[1]; returns the count of the hypothesis
+    auto body = [&]() -> unsigned {
       double c1[3], c2[3], ec[3], aFt[9], aFtH[9], aF[9];
       cross3(c1, &us[6 * ptr[0]], &us[6 * ptr[0] + 3]);
       cross3(c2, &us[6 * ptr[1]], &us[6 * ptr[1] + 3]);
@@ -788,6 +895,7 @@ struct RansacF {
         if (DsN[i] < th * 2) { ++no_i; v[i] = 1; }
         else v[i] = 0;
       }
+      const unsigned counted = no_i;
       if (no_i > m_i) {
         no_i = 0;
         for (unsigned i = 0; i < nN; ++i)
@@ -805,6 +913,42 @@ struct RansacF {
           max_sam = max_sam > ns ? ns : max_sam;
         }
       }
+      return counted;
+    };
+    unsigned no_sam = 1;
+    struct LoopClock {
+      std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+      ~LoopClock() { g_rfthStats[4]++; g_rfthStats[5] += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); }
+    } loopClock;
+    RfthDevice &D = t_rfth;
+    bool dev = D.init() && D.points(us.data(), uN.data(), nN);
+    if (dev) {
+      RfthArgs A;
+      memcpy(A.Ht, Ht, sizeof Ht);
+      A.th2 = th * 2; A.nN = (int)nN;
+      std::vector<unsigned> ptr2;
+      while (dev && no_sam < 2 * max_sam) {
+        // the next B samples from a copy of the generator and of the permutation
+        const unsigned B = std::min<unsigned>(RfthDevice::BATCH, 2 * max_sam - no_sam);
+        GlibcRandom g2 = rng;
+        ptr2 = ptr;
+        for (unsigned j = 0; j < B; ++j) { draw(g2, ptr2); D.hPairs[2 * j] = ptr2[0]; D.hPairs[2 * j + 1] = ptr2[1]; }
+        A.B = (int)B;
+        if (!D.count(A)) { D.ok = false; dev = false; break; }      // a HIP error: the rest of the loop (and of the thread's calls) on the host
+        g_rfthStats[0]++; g_rfthStats[1] += B;
+        unsigned hit = B;
+        for (unsigned j = 0; j < B; ++j) if (D.hCnt[j] > m_i) { hit = j; break; }
+        if (hit == B) { rng = g2; ptr.swap(ptr2); no_sam += B; continue; }      // nothing in the batch changes the state
+        for (unsigned j = 0; j <= hit; ++j) draw(rng, ptr);                       // replay up to the event, then the reference's body
+        const unsigned counted = body();
+        no_sam += hit + 1;
+        g_rfthStats[2]++;
+        if (counted != D.hCnt[hit]) { g_rfthStats[3]++; D.ok = false; dev = false; }   // never seen; the host's count is what was acted on
+      }
+    }
+    for (; no_sam < 2 * max_sam; ++no_sam) {      // the reference's loop (no device, or what is left after a device error)
+      draw(rng, ptr);
+      body();
     }
     return max_i;
   }
@@ -1100,3 +1244,11 @@ int loransac_f(const double *pts, const double *laf1, const double *laf2, int T,
 }
 
 }  // namespace mx
+
+// out[0..4): device batches of rFtH's hypothesis loop, hypotheses counted on the device, state-changing hypotheses (each re-run on
+// the host), host / device disagreements (never seen: one switches the calling thread back to the host loop).  Process-wide.
+extern "C" __attribute__((visibility("default"))) int modsx_verify_device_stats(long *out, int reset) {
+  if (!out) return -1;
+  for (int i = 0; i < 6; i++) { out[i] = mx::g_rfthStats[i].load(); if (reset) mx::g_rfthStats[i].store(0); }
+  return 6;
+}

@@ -1,0 +1,52 @@
+"""DEGENSAC's plane-and-parallax hypothesis loop (rFtH, DegUtils.c:254-440) with its counting on the device (ransac_f.cpp:
+k_rfth_count): the verifier's trajectory must stay the reference's.  The same cases run through the host loop in
+tests/test_host_abi.py (no device in that container); here a device is present, so modsx.loransac_f takes the batched path."""
+import numpy as np
+import pytest
+
+from common import synth_two_view, synth_corr
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    assert (a["n"], a["samples"], a["lo_count"]) == (b["n"], b["samples"], b["lo_count"])
+    assert np.array_equal(a["inl"], b["inl"]) and np.array_equal(a["keep"], b["keep"])
+    Fa, Fb = a["F"] / max(np.linalg.norm(a["F"]), 1e-300), b["F"] / max(np.linalg.norm(b["F"]), 1e-300)
+    if (Fa * Fb).sum() < 0:
+        Fb = -Fb
+    assert np.abs(Fa - Fb).max() < 1e-9
+
+
+@pytest.mark.parametrize("planar_frac", [0.0, 0.5, 0.8, 1.0])
+@pytest.mark.parametrize("error_type", [0, 1])
+def test_degensac_with_device_counted_hypotheses_follows_the_reference(modsx, oracle, ctx, planar_frac, error_type):
+    """Scenes from general to a single plane (every sample H-degenerate: rFtH on each): sample count, LO count, degeneracy count,
+    inlier set, LAF-checked set and F of the reference's compiled degensac; on the planar scenes the device did the counting."""
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    modsx.verify_device_stats(reset=True)
+    for seed in (1, 2, 3, 4, 5, 6):
+        pts, laf = synth_two_view(seed, planar_frac=planar_frac, n_in=300 + 40 * seed, n_out=100 + 25 * seed)
+        a = oracle.loransac_f(pts, laf, laf, seed=seed, error_type=error_type)
+        b = modsx.loransac_f(pts, laf, laf, seed=seed, error_type=error_type)
+        _same(a, b)
+    st = modsx.verify_device_stats()
+    assert st["disagreements"] == 0
+    if planar_frac >= 0.5:
+        assert st["batches"] > 0 and st["hypotheses"] >= st["batches"], st
+
+
+def test_homography_scene_is_the_loops_worst_case(modsx, oracle, ctx):
+    """A pure homography with outliers (what bench.py --config wxbs verifies with useF): no two-point epipole ever beats the
+    plane, so every rFtH call runs its full 2 x 10^4 hypotheses -- all of them counted on the device, none changing the state."""
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    modsx.verify_device_stats(reset=True)
+    for seed in (3, 8):
+        pts, laf, _ = synth_corr(600, 0.7, noise=0.5, seed=seed)
+        a = oracle.loransac_f(pts, laf, laf, seed=seed)
+        b = modsx.loransac_f(pts, laf, laf, seed=seed)
+        _same(a, b)
+    st = modsx.verify_device_stats()
+    assert st["disagreements"] == 0 and st["hypotheses"] > 10000, st
