@@ -436,7 +436,10 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &A) {
 // ---------------- decide: merge splits, the hidden candidate of NN0's group, j = 1 of the walk ---------------------------
 // 16 lanes per query.  sweep 1 ranks group minima, so the one candidate it cannot have seen is the second-best inside the
 // group (same tile, same lane half) of the overall winner: lane l recomputes the distance of that group's row l exactly.
-constexpr int DECIDE_Q = 64;   // queries per 1024-thread workgroup of k_match_decide
+#ifndef MODSX_DECIDE_Q
+#define MODSX_DECIDE_Q 64
+#endif
+constexpr int DECIDE_Q = MODSX_DECIDE_Q;   // queries per workgroup of k_match_decide (16 lanes each)
 __device__ __forceinline__ void decide_body(const uint8_t *d1, const int *norm1, const uint8_t *d2, const int *norm2,
                                             const int4 *partial, MatchGeom g, const double *pos2, double sqminratio,
                                             double contrDistSq, MatchRow *rows, int *dmin, int *undecided, int *nUndecided) {
@@ -671,6 +674,7 @@ struct MatchBatch { MatchProblem p[MATCH_MAXB]; };
 
 __global__ __launch_bounds__(256) void k_match_pack(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *P.counter = 0;   // the undecided count (decide adds to it): no fill launch of its own
   pack_body(P.d1, P.g.n1, P.norm1, P.d2, P.g.n2, P.slots, P.tiles, P.cst, P.norm2);
 }
 #ifdef MATCH_TRACE
@@ -700,7 +704,7 @@ __global__ __launch_bounds__(256, sweep_wps(QS)) void k_match_sweep1(MatchBatch 
   if (threadIdx.x == 0 && wg < 16384) { g_mtrace[wg][1] = wall_clock64(); g_mtrace[wg][3] = __builtin_readcyclecounter() - g_mtrace[wg][3]; }
 #endif
 }
-__global__ __launch_bounds__(1024) void k_match_decide(MatchBatch b, double sqminratio, double contrDistSq) {
+__global__ __launch_bounds__(16 * DECIDE_Q) void k_match_decide(MatchBatch b, double sqminratio, double contrDistSq) {
   const MatchProblem &P = b.p[blockIdx.z];
   if ((int)blockIdx.x * DECIDE_Q >= P.g.n1) return;
   decide_body(P.d1, P.norm1, P.d2, P.norm2, P.partial, P.g, P.pos2, sqminratio, contrDistSq, P.rows, P.dmin, P.undecided,
@@ -742,7 +746,6 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
     P.evCnt = (int *)(w + L.evCnt); P.ev = (int *)(w + L.ev); P.evRes = (int4 *)(w + L.evRes);
     P.counter = (int *)(w + L.counter);
     P.d1 = d1[i]; P.d2 = d2[i]; P.pos2 = pos2[i]; P.rows = rows[i];
-    hipMemsetAsync(P.counter, 0, 4, s);
     maxN1 = std::max(maxN1, n1[i]); maxS = std::max(maxS, L.S); maxSlots = std::max(maxSlots, L.slots);
   }
   hipLaunchKernelGGL(k_match_pack, dim3((std::max(maxN1, maxSlots) + 255) / 256, 2, nb), dim3(256), 0, s, b);
@@ -752,7 +755,7 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
   if (qs == 4) hipLaunchKernelGGL(k_match_sweep1<4>, grid, dim3(256), 0, s, b);
   else hipLaunchKernelGGL(k_match_sweep1<2>, grid, dim3(256), 0, s, b);
   if (evSweep1) hipEventRecord(evSweep1[1], s);
-  hipLaunchKernelGGL(k_match_decide, dim3((maxN1 + DECIDE_Q - 1) / DECIDE_Q, 1, nb), dim3(1024), 0, s, b, sqminratio, contrDistSq);
+  hipLaunchKernelGGL(k_match_decide, dim3((maxN1 + DECIDE_Q - 1) / DECIDE_Q, 1, nb), dim3(16 * DECIDE_Q), 0, s, b, sqminratio, contrDistSq);
   // sweep 2: one round of workgroups dealt out on the device as (undecided block, split); more only if there could be more
   // undecided query blocks than that
   const dim3 grid2(std::max(NW2, (maxN1 + QPB - 1) / QPB), 1, nb);
