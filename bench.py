@@ -251,7 +251,7 @@ def main():
     ap.add_argument("--config", type=str, default="views31", choices=sorted(CONFIGS))
     ap.add_argument("--tilts", type=str, default="", help="override the tilt set of --config, e.g. 1,2,3,4,6")
     ap.add_argument("--phi", type=float, default=0.0)
-    ap.add_argument("--batch", type=int, default=0, help="pairs per step per GPU (default 64; 256 for views1, 128 for wxbs, 32 for ladder)")
+    ap.add_argument("--batch", type=int, default=0, help="pairs per step per GPU (default 64; 256 for views1, 128 for wxbs)")
     ap.add_argument("--blobs", type=int, default=0, help="blobs per 1024x768 of the synthetic scene (0 = per config)")
     ap.add_argument("--workers", type=int, default=16, help="contexts (thread + stream) per GPU")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs cycled through the batch")
@@ -296,7 +296,7 @@ def main():
     single_view = tilts == "1"
     # a step ends with the verification of its last pairs while the GPU drains: configs[1] (45 ms per 64 pairs) and
     # configs[4] take longer steps so that this tail stays a few per cent of the step
-    batch = args.batch or (128 if wxbs else 256 if single_view else 32 if ladder else 64)
+    batch = args.batch or (128 if wxbs else 256 if single_view else 64)   # (the ladder ran 32 per step until round 4: two pairs per context and step, i.e. the step's tail with most contexts idle was 8 % of it: 46.9 against 51.0 pairs/s)
     # blob density of the synthetic scene: 4000 per 1024x768 for configs[1], [3], [4]; 5500 for
     # the multi-view headline so that the 31-view default carries the >= 50 k descriptors per pair the north star is quoted
     # on (the 4000-blob figure of the same configuration is reported under `extra`)

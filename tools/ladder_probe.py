@@ -13,7 +13,7 @@ npairs = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 ctxs = [mods_amd.Context(0) for _ in range(workers)]
 pairs = [synthetic.make_pair(rows=768, cols=1024, nblobs=4000, seed=12345 + 17 * i) for i in range(8)]
 dev = [(ctxs[0].upload(a), ctxs[0].upload(b)) for a, b, _ in pairs]
-steps = cviu_ladder_steps(mods_amd, only=det)
+steps = cviu_ladder_steps(mods_amd, only=(det if det >= 0 else None))   # det < 0: the whole ladder
 par = mods_amd.default_pair_params(ransac_seed=1, ori_mrSize=5.1962)
 def run():
     nxt = itertools.count(); lock = threading.Lock()
