@@ -254,8 +254,8 @@ int modsx_describe_regions(modsx_ctx *ctx, const modsx_image *img, const modsx_r
  * desc*: [n][128] f32 holding integers 0..255 (anything else -- fractions, out-of-range values, NaN -- is refused with
  * MODSX_ERR_ARG: the int8 matrix-core path is exact only on that domain); pos2: [n2][2] reproj_kp x,y of list2.
  * A ratio >= 1 (the PDF branch, matching.cpp:397-428, unused by every shipped configuration) is refused as well.
- * nn must lie in [2, 64] (the reference takes any nn, default 50; the device walk logs at most 64 groups of trains per
- * query): other values return MODSX_ERR_ARG on every match path, the sharded and fused ones included.
+ * nn must lie in [2, 256] (the reference takes any nn, default 50; the device walk lists fewer than nn groups of trains per
+ * query, in 256 slots): other values return MODSX_ERR_ARG on every match path, the sharded and fused ones included.
  * Images must have at least 2 rows and 2 columns (modsx_image_upload / modsx_image_wrap_device refuse smaller ones). */
 int modsx_match_fginn(modsx_ctx *ctx, const float *desc1, int n1, const float *desc2, int n2, const double *pos2,
                       double ratio, double contradDist, int nn, modsx_tentative **out);

@@ -1336,8 +1336,8 @@ int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int
   hipStream_t s = c->stream;
   const double sqminratio = ratioT * ratioT, contrDistSq = contradDist * contradDist;
   if (!(sqminratio < 1.0)) { set_error("match ratio >= 1 (PDF mode of MatchFlannFGINN) is not supported"); return MODSX_ERR_ARG; }
-  // nn = neighbours the walk may look at (default 50, matching.hpp:268-269); the event lists of the device matcher hold up to 64 groups
-  if (nn < 2 || nn > 64) { set_error("match: nn must be in [2, 64]"); return MODSX_ERR_ARG; }
+  // nn = neighbours the walk may look at (default 50, matching.hpp:268-269); the event lists of the device matcher hold up to MATCH_NN_MAX groups
+  if (nn < 2 || nn > MATCH_NN_MAX) { set_error("match: nn must be in [2, 256]"); return MODSX_ERR_ARG; }
   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
   if (shard) {
     // view-sharded run (engine_shard.hip): this rank matches the query rows [lo, lo + per) of ONE problem; the result rows

@@ -246,6 +246,7 @@ void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, i
 #ifndef MODSX_BLUR_LDS_C
 #define MODSX_BLUR_LDS_C 9984
 #endif
+constexpr int MATCH_NN_MAX = 256;   // largest `nn` of the FGINN walk (matching.hpp:268-269: 50): the event kernel lists fewer than nn groups per query
 constexpr int MATCH_MAXB = 4;   // independent matching problems per launch set (blockIdx.z)
 void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
                         const double *const *pos2, double sqminratio, double contrDistSq, int nn, MatchRow *const *rows,

@@ -669,7 +669,7 @@ int match_sharded_batch(modsx_ctx *c, modsx_comm *cm, int nb, const uint8_t *con
   if (cm->dead.load()) return comm_dead_rc(cm);
   const double sqminratio = ratioT * ratioT, contrDistSq = contradDist * contradDist;
   if (!(sqminratio < 1.0)) { set_error("match ratio >= 1 (PDF mode of MatchFlannFGINN) is not supported"); return MODSX_ERR_ARG; }
-  if (nn < 2 || nn > 64) { set_error("match: nn must be in [2, 64]"); return MODSX_ERR_ARG; }
+  if (nn < 2 || nn > MATCH_NN_MAX) { set_error("match: nn must be in [2, 256]"); return MODSX_ERR_ARG; }
   const int W = cm->world, R = cm->rank;
   hipStream_t s = c->stream;
   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };

@@ -516,7 +516,7 @@ __device__ __forceinline__ void events_body(const uint8_t *d1, const int *norm1,
                                             const double *pos2, double contrDistSq, MatchRow *rows, const int *dmin,
                                             const int *undecided, const int *nUndecided, const int *evCnt, const int *ev,
                                             int nn, const int2 *partial2) {
-  __shared__ int sRec[4][64];           // per wave: the event groups of its query as (tile << 1 | lane half)
+  __shared__ int sRec[4][MATCH_NN_MAX];  // per wave: the event groups of its query as (tile << 1 | lane half); fewer than nn of them
   const int w = threadIdx.x >> 6;
   const int u = blockIdx.x * 4 + w;
   const int nUnd = *nUndecided;
@@ -570,7 +570,7 @@ __device__ __forceinline__ void events_body(const uint8_t *d1, const int *norm1,
       if (dx * dx + dy * dy > contrDistSq) nbad++;
     } else if (lex_less(d, t, dj, tj)) { dj = d; tj = t; }
   };
-  // gather the (fewer than nn <= 64) logged groups of all streams into one list; a stream that ran out of slots is
+  // gather the (fewer than nn <= MATCH_NN_MAX) logged groups of all streams into one list; a stream that ran out of slots is
   // rescanned exactly over its own tiles afterwards (its logged groups are then ignored); the groups it did not flag hold
   // no train below Dmin and their candidates d >= Dmin are already in the sweep's minimum
   int nrec = 0;
@@ -586,10 +586,10 @@ __device__ __forceinline__ void events_body(const uint8_t *d1, const int *norm1,
     for (int m = 1; m < 64; m <<= 1) { const int v = __shfl_up(pre, m); if (lane >= m) pre += v; }
     const int base = nrec + pre - c;
     for (int e = 0; e < c; e++)
-      if (base + e < 64) sRec[w][base + e] = (ev[((size_t)u * nst + st) * EVCAP + e] << 1) | (st & 1);
+      if (base + e < MATCH_NN_MAX) sRec[w][base + e] = (ev[((size_t)u * nst + st) * EVCAP + e] << 1) | (st & 1);
     nrec += __shfl(pre, 63);
   }
-  nrec = min(nrec, 64);
+  nrec = min(nrec, MATCH_NN_MAX);
   for (int b = 0; b < nrec; b += 4) {      // wave-uniform trip count: the quarter waves shuffle among their own lanes
     const int e = b + sub;
     const int rec = e < nrec ? sRec[w][e] : 0;

@@ -249,7 +249,7 @@ def test_match_fginn_ties_ranks_and_ragged_sizes(ctx, oracle):
     with pytest.raises(RuntimeError):
         ctx.match_fginn(d, d, p2, ratio=1.2)          # the "PDF" branch of MatchFlannFGINN (matching.cpp:397-428)
     with pytest.raises(RuntimeError):
-        ctx.match_fginn(d, d, p2, nn=100)
+        ctx.match_fginn(d, d, p2, nn=300)             # the walk handles nn up to 256 (the reference's default is 50)
 
 
 def test_match_fginn_clustered_near_duplicates_and_split_ranges(ctx, oracle):
@@ -258,7 +258,7 @@ def test_match_fginn_clustered_near_duplicates_and_split_ranges(ctx, oracle):
     (more than the 16 event slots of a stream with fewer than nn groups in total -> the exact rescan of that stream), exact
     distance ties across tiles and lane halves, walks that end at rank nn - 1 / nn, and a query block boundary (n1 > 256)."""
     rs = np.random.RandomState(31)
-    for n1, n2, kmax in ((300, 2100, 40), (40, 5000, 25), (513, 1000, 12)):
+    for n1, n2, kmax in ((300, 2100, 40), (40, 5000, 25), (513, 1000, 12), (60, 3000, 150)):   # (the last: runs beyond 64, for nn > 64)
         base = rs.randint(0, 90, (n2, 128)).astype(np.float32)
         d2 = base.copy()
         d1 = rs.randint(0, 90, (n1, 128)).astype(np.float32)
@@ -280,7 +280,7 @@ def test_match_fginn_clustered_near_duplicates_and_split_ranges(ctx, oracle):
                 if t < n2:
                     d2[t] = np.clip(d1[q] + rs.randint(-2, 3, 128), 0, 255)
                     pos2[t] = pos2[t0 + 1] + rs.uniform(-3, 3, 2)
-        for ratio, cd, nn in ((0.8, 30.0, 50), (0.9, 30.0, 20), (0.8, 2.0, 50)):
+        for ratio, cd, nn in ((0.8, 30.0, 50), (0.9, 30.0, 20), (0.8, 2.0, 50), (0.9, 30.0, 100), (0.95, 40.0, 256), (0.9, 30.0, 65)):
             _check_tents(ctx.match_fginn(d1, d2, pos2, ratio, cd, nn), oracle.match_fginn(d1, d2, pos2, ratio, cd, nn))
 
 
