@@ -329,6 +329,14 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
       float *const simg = pc;
       const float a11 = __shfl(A11, 2 * q), a12 = __shfl(A12, 2 * q), a21 = __shfl(A21, 2 * q), a22 = __shfl(A22, 2 * q);
       const bool touch = check_borders(jb.cols, jb.rows, lx, ly, a11, a12, a21, a22, W, W);
+#ifdef BAUM_TRACE
+      if (lane == 0) {     // extent of the sampled window in the level: what a staged source tile would have to hold
+        const float bw = 18.f * (fabsf(a11) + fabsf(a12)) + 3.f, bh = 18.f * (fabsf(a21) + fabsf(a22)) + 3.f;
+        const float m = fmaxf(bw, bh);
+        const int b = m <= 16.f ? 0 : m <= 24.f ? 1 : m <= 32.f ? 2 : m <= 40.f ? 3 : m <= 48.f ? 4 : m <= 64.f ? 5 : 6;
+        atomicAdd(&g_btrace[9 + b], 1ull);
+      }
+#endif
       if constexpr (K != 2) {
         // sample coordinates: lane j runs the f32 running sums of row j (helpers.cpp:563-585) into LDS
         float rx = lx - (float)half * a12, ry = ly - (float)half * a22;

@@ -28,3 +28,6 @@ tot = t[:8].sum()
 print("wavefronts %d, %.0f clocks per wavefront" % (t[8], tot / max(1, t[8])))
 for n, v in zip(names, t[:8]):
     print("  %-42s %5.1f %%" % (n, 100 * v / tot))
+h = np.array(list(buf[9:16]), np.float64)
+print("window extent in the level (max of width, height; px) per slot-iteration: " +
+      ", ".join("%s %.1f %%" % (k, 100 * v / max(1, h.sum())) for k, v in zip(("<=16", "<=24", "<=32", "<=40", "<=48", "<=64", ">64"), h)))
