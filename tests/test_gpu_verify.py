@@ -50,3 +50,18 @@ def test_homography_scene_is_the_loops_worst_case(modsx, oracle, ctx):
         _same(a, b)
     st = modsx.verify_device_stats()
     assert st["disagreements"] == 0 and st["hypotheses"] > 10000, st
+
+
+def test_many_off_plane_correspondences_go_through_several_lds_tiles(modsx, oracle, ctx):
+    """More than 512 correspondences off the dominant plane: k_rfth_count stages them tile by tile; a plane with a few dozen
+    inliers among 1500 random pairs also makes state-changing hypotheses frequent (each re-draws the rest of the loop)."""
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built")
+    modsx.verify_device_stats(reset=True)
+    for seed, frac in ((11, 0.6), (12, 0.9)):
+        pts, laf = synth_two_view(seed, planar_frac=frac, n_in=400, n_out=1500)
+        a = oracle.loransac_f(pts, laf, laf, seed=seed, max_samples=20000)
+        b = modsx.loransac_f(pts, laf, laf, seed=seed, max_samples=20000)
+        _same(a, b)
+    st = modsx.verify_device_stats()
+    assert st["disagreements"] == 0 and st["batches"] > 0, st
