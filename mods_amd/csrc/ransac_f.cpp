@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include "engine_api.hpp"
 #include "ransac_common.hpp"
 
@@ -541,6 +542,7 @@ static std::atomic<long> g_rfthStats[6];   // batches, hypotheses scored on the 
 struct RfthDevice {
   enum { BATCH = 20480 };   // a whole loop (2 x 10^4 hypotheses) in one round trip: speculation past an event costs the device nothing
   bool tried = false, ok = false;
+  int dev = -1;                 // the device that was current when it was made: leased again only to threads on that device
   hipStream_t s = nullptr;
   double *hUs = nullptr, *hUn = nullptr, *dUs = nullptr, *dUn = nullptr;     // pinned + mapped: host pointer / device alias
   unsigned *hPairs = nullptr, *hCnt = nullptr, *dPairs = nullptr, *dCnt = nullptr;
@@ -581,7 +583,26 @@ struct RfthDevice {
     return hipStreamSynchronize(s) == hipSuccess && hipGetLastError() == hipSuccess;
   }
 };
-static thread_local RfthDevice t_rfth;
+// The verifier's threads come and go (modsx_match_pairs starts its helpers per call), so the device state is not theirs: a
+// thread borrows one from a process-wide pool for the duration of a loop and hands it back -- as many as ever verified at the
+// same time exist, they are reused for the life of the process and never torn down (no HIP call at thread or process exit).
+struct RfthLease {
+  RfthDevice *d = nullptr;
+  static std::mutex &mu() { static std::mutex m; return m; }
+  static std::vector<RfthDevice *> &idle() { static std::vector<RfthDevice *> v; return v; }
+  RfthLease() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; }
+    {
+      std::lock_guard<std::mutex> lk(mu());
+      std::vector<RfthDevice *> &v = idle();
+      for (size_t i = 0; i < v.size(); i++)
+        if (v[i]->dev == dev) { d = v[i]; v.erase(v.begin() + i); break; }
+    }
+    if (!d) { d = new RfthDevice; d->dev = dev; }
+  }
+  ~RfthLease() { std::lock_guard<std::mutex> lk(mu()); idle().push_back(d); }
+};
 
 struct RansacF {
   const double *u;
@@ -920,7 +941,8 @@ struct RansacF {
       std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
       ~LoopClock() { g_rfthStats[4]++; g_rfthStats[5] += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); }
     } loopClock;
-    RfthDevice &D = t_rfth;
+    RfthLease lease;
+    RfthDevice &D = *lease.d;
     bool dev = D.init() && D.points(us.data(), uN.data(), nN);
     if (dev) {
       RfthArgs A;
