@@ -5,39 +5,38 @@
 //   ascending with ties by ascending train index, walk j = 1..nn-1:
 //     accept at the first j with (float)d0/(float)dj <= ratio^2,
 //     give up at the first j whose position is farther than contradDist from NN0's.
-// Restated as reductions over the N x M distance matrix (no top-50 sort):
-//   sweep 1   top-2 of (d, t) per query: NN0, NN1
-//   decide    j = 1 of the walk needs only NN0/NN1: ratio(d0, d1) passes -> ACCEPT (NNj = NN1);
-//             NN1 farther than contradDist from NN0 -> REJECT; otherwise UNDECIDED
-//   sweep 2   only for UNDECIDED queries: Dmin = smallest integer distance passing the ratio test against
-//             d0 (the predicate is monotone); NNj = lex-min over d >= Dmin; nless = #{t != NN0 : d < Dmin};
-//             nbad = #{those farther than contradDist from NN0}
-//   accept  <=>  NNj exists, nbad == 0, nless <= nn-2          (rank of NNj is nless+1)
 // Distances come from the int8 matrix cores: with a'' = 127 - a, b' = b - 128 (both in [-128,127])
-//   |a-b|^2 - |a-128|^2 = (|b'|^2 + 2 sum b') + 2 a''.b'   exactly in int32;   a''.b' = v_mfma_i32_32x32x32_i8 over K = 128.
+//   |a-b|^2 - |a-128|^2 = (|b'|^2 + 2 sum b') + 2 a''.b' = c + 2 a''.b'   exactly in int32;   a''.b' = v_mfma_i32_32x32x32_i8 over K = 128.
 //
-// Work decomposition (gfx950: a plain VALU instruction costs 4 cycles per wavefront, a 32x32x32 int8 MFMA 32, so the
-// epilogue, not the matrix pipe, is what has to be made small):
-//  * TRAIN descriptors are the MFMA rows (A operand, streamed), QUERIES the columns (B operand, resident in VGPRs):
-//    a lane then owns ONE query per 32-query set and sees 16 trains (a "group": fixed tile, fixed lane half) per tile,
-//    so its running state is two keys, not 16 x 2, and the merge at the end is one lane exchange.
-//  * Per group the lane forms 16 keys (d - |a'|^2) << 8 | idx with one v_lshl_add each, reduces them with a v_min3 tree
-//    (8 ops) and feeds ONLY the group minimum to the running top-2 (v_med3 + v_min): 26 VALU per 4 MFMA instead of 48.
-//    The top-2 of group minima misses exactly one candidate -- the second-best INSIDE the group of the overall winner;
-//    k_match_decide recomputes the 15 other distances of NN0's group (dot4) and folds that candidate in.
-//  * idx = (tile in a 12-tile chunk + 1) << 4 | register: every 12 tiles the lane moves the indices of keys that
-//    changed into two index registers and clears the low byte, so older entries keep winning ties (ascending train
-//    index, as the reference's sort) and a split may be any number of tiles long.
-//  * k_match_pack rewrites the trains once as 4 KB tiles (b - 128, 16-byte slots XOR-swizzled so that the ds_read_b128
-//    fragment reads are conflict-free) plus the 32 per-train key constants of each tile; the sweeps then stage 4 tiles per
-//    barrier with direct global->LDS loads (no staging registers), double-buffered; a wave holds 2 x 32 queries, so every
-//    fragment read from LDS feeds two MFMA chains.
-//  * sweep 2 is the same loop with another two-instruction update: d < Dmin <=> key < (Dmin - |a'|^2) << 8, so a group
-//    without a sub-threshold train feeds its minimum to NNj, and a group WITH one is logged as a 4-byte event in the
-//    lane's own slots (no atomics); k_match_events recomputes the 16 distances of every event group exactly for
-//    nless / nbad / NNj (and falls back to an exact scan of all trains when a lane ran out of slots).
-//  * inside a wave the four MFMAs of one (tile, query set) chain are issued between the quarters of the reduction of the
-//    previous chain, so the matrix pipe and the vector ALU overlap without relying on other waves being out of phase.
+// Round 5: the epilogue, not the matrix pipe, was what bound the sweeps (26 vector instructions per 4 MFMAs for the running
+// top-2 of keys that carried their row index; a plain VALU instruction costs 4 cycles per wavefront, a 32x32x32 int8 MFMA 32).
+// The sweeps now spend 13:
+//  * c = 2 h + p.  The MFMA chain STARTS from h (its C operand is the per-row constant, read from LDS with the tile), so an
+//    accumulator element is t = h + a''.b' and d - |a'|^2 = 2 t + p with no instruction per element.
+//  * p, the parity of sum(b), is made a property of the TILE: k_match_pack partitions the trains by parity (stable) into two
+//    regions of the tile array, each padded to whole stages of 4 tiles; the sweeps run over the VIRTUAL tile sequence
+//    "even class, then odd class".  Equal distances are always in the same class, where slot order is train order, so
+//    "first seen wins" still is "lowest train index wins".  The ranks come from a one-pass scan: every 256-train workgroup
+//    publishes its two counts in an epoch-stamped status word and sums the words of the workgroups before it.
+//  * TRAIN descriptors are the MFMA rows, QUERIES the columns: a lane owns ONE query per 32-query set and sees 16 trains (a
+//    "group": fixed tile, fixed lane half) per tile.  It reduces the 16 elements with a v_min3 tree (8), forms ONE key
+//    (2 t + p) << 8 | tile code (1: v_lshl_add with the tile's constant) and inserts it into its K = 4 smallest group keys
+//    (3 v_med3 + v_min).  No row index anywhere in the loop.
+//  * k_match_decide merges the streams (split x lane half) of a query into the K smallest groups G[0..K-1] by (d, tile, half),
+//    recomputes groups EXACTLY (v_dot4 on the packed rows), one at a time as needed, and runs the reference's walk over the
+//    rows that are CERTAIN: a recomputed row r is certain iff (d_r, tile_r) < (d, tile) of the first group not yet recomputed
+//    -- every row outside the recomputed groups is at or after that group in (distance, slot) order.  With K >= 4, NN0 and
+//    NN1 are always certain.  On multi-view descriptors 98.7 % of the queries end their walk inside the first three groups
+//    (tests/match_model.py is the executable model of this logic, checked against the oracle on the CPU);
+//  * only the rest go through sweep 2: Dmin = smallest integer distance passing the ratio test against d0; groups whose
+//    minimum is below Dmin are logged as events (4 bytes in the lane's own slots, no atomics), the others feed the lane's two
+//    smallest keys; k_match_events recomputes event groups exactly for nless / nbad / NNj.
+//      accept  <=>  NNj exists, nbad == 0, nless <= nn-2          (rank of NNj is nless+1)
+//  * staging: 4 tiles (4 KB each, 16-byte slots XOR-swizzled for conflict-free ds_read_b128) + their 128 row constants + 4
+//    tile constants per barrier with direct global->LDS loads, double-buffered; a wave holds 2 x 32 queries, so every
+//    fragment read from LDS feeds two MFMA chains; the four MFMAs of a chain are issued between the quarters of the
+//    reduction of the previous chain.
+#include <atomic>
 #include <type_traits>
 #include "engine.hpp"
 
@@ -45,14 +44,18 @@ namespace mx {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
 
 constexpr int BIG = 0x7fffffff;
-constexpr int NONE = 0x7fffff00;           // empty slot of a running minimum: larger than every real key, low byte 0
+constexpr int NONE_H = 0x3fffff;           // row constant of a padding row: t = NONE_H + 0
+constexpr int NONE_KEY = NONE_H << 9;      // 0x7ffffe00: empty slot of a running minimum; every real key is smaller, every padding key larger
 constexpr int TPS = 4;                     // train tiles staged per barrier
-constexpr int CHUNK = 12;                  // tiles per index chunk (3 stages); tilesPerSplit is a multiple of it
+constexpr int CHUNK = 240;                 // tiles per index chunk (absolute tile numbers): the low byte of a key is tile % CHUNK + 1
+constexpr int MINT = 12;                   // fewest tiles a split is made of
+constexpr int KTOP = 4;                    // group keys a stream keeps (>= 4: NN0 and NN1 are then always certain in k_match_decide)
+constexpr int PB = 256;                    // trains per workgroup of k_match_pack
 // 32-query sets per wave (QS, even): 2 for most problems -- 3 wavefronts per SIMD --, 4 when both sides hold >= 40 k descriptors:
 // every LDS fragment read then feeds four MFMA chains (half the LDS bytes per matrix instruction) at 2 wavefronts per SIMD
-// (round 3: 0.392 against 0.402 ms at 46 k x 45 k, 0.155 against 0.151 ms at 24 k x 24 k, -25 % at 10 k; selected per problem)
 constexpr int sweep_wps(int qs) { return qs >= 4 ? 2 : 3; }   // waves per SIMD the sweeps are built for
 constexpr int qpb_of(int qs) { return 4 * 32 * qs; }          // queries per 256-thread workgroup
 constexpr int QPB_MAX = qpb_of(4), NW_MAX = 256 * 3;
@@ -61,8 +64,16 @@ static int match_qsets(int nb, int n1, int n2) {
   if (forced == 2 || forced == 4) return forced;
   return (nb == 1 && n1 >= 40000 && n2 >= 40000) ? 4 : 2;
 }
-constexpr int TILE_B = 4096, STAGE_B = TPS * TILE_B + TPS * 128;
+constexpr int TILE_B = 4096;
+constexpr int HOFF = TPS * TILE_B, STAGE_B = HOFF + TPS * 128;
 constexpr int MAXD = 128 * 255 * 255;      // largest possible squared distance
+
+// Tile geometry of a problem.  Host side: the capacity of one class region (either class may hold every train) and an upper
+// bound of the virtual tile count.  Device side (written by k_match_pack's last workgroup): the padded tile counts.
+MX_HD int region_tiles(int n2) { return (((n2 + 31) / 32 + TPS - 1) & ~(TPS - 1)) + TPS; }
+MX_HD int ntiles_ub(int n2) { return (((n2 + 31) / 32 + TPS - 1) & ~(TPS - 1)) + 2 * TPS; }
+struct TileGeo { int TEp, TOp, ntilesV, pad; };   // even / odd class tiles (multiples of TPS), their sum
+MX_D int phys_tile(int v, int TEp, int offT) { return v < TEp ? v : offT + v - TEp; }
 
 MX_D bool ratio_pass(float d0, float d, double sqminratio) {
   const float r = d0 / d;            // f32 division as in `double ratio = distsRow[0]/distsRow[j]`
@@ -81,36 +92,46 @@ MX_D int ratio_dmin(int d0i, double sqminratio) {
 MX_D bool lex_less(int da, int ia, int db, int ib) { return da < db || (da == db && ia < ib); }
 MX_D int imed3(int a, int b, int c) { return min(max(a, b), max(min(a, b), c)); }
 MX_D int imin3(int a, int b, int c) { return min(min(a, b), c); }
+MX_D u64 key64(int d, int lo) { return ((u64)(unsigned)d << 32) | (unsigned)lo; }   // d >= 0
+MX_D u64 shfl_xor64(u64 v, int m) {
+  const int lo = __shfl_xor((int)(unsigned)v, m), hi = __shfl_xor((int)(v >> 32), m);
+  return ((u64)(unsigned)hi << 32) | (unsigned)lo;
+}
+
+// minimum over the 16 lanes of a DPP row, in every lane (row rotations: no LDS crossbar, one instruction per step)
+MX_D int rowmin16(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false));
+  return v;
+}
 
 struct MatchGeom {
-  int n1, n2, S, tilesPerSplit, qs;
+  int n1, n2, S, tilesPerSplit, qs, ntilesUB, offT;   // offT: first tile of the odd class region
 };
 
-// Sweep 2 runs over the UNDECIDED queries only, whose number the host does not know at launch time.  With sweep 1's splits it
-// would be a handful of query blocks x S long splits -- a sixth of the machine busy for as long as a whole sweep 1 workgroup
-// takes (41 us of the 165 at 24 k x 24 k, where 15 % of the queries are undecided).  Every workgroup therefore derives the
-// split geometry from the device-side count: the NW workgroups of the launch are dealt out as (query block, split) with as
-// many splits as fill the machine once.  k_match_events uses the same function.
+// Sweep 2 runs over the UNDECIDED queries only, whose number the host does not know at launch time.  Every workgroup of a fixed
+// one-round launch therefore derives the split geometry from the device-side count: the NW workgroups are dealt out as
+// (query block, split) with as many splits as fill the machine once.  k_match_events uses the same function.
 struct Sweep2Geom { int nQB, S, tilesPerSplit; };
-MX_HD Sweep2Geom sweep2_geom(int nUnd, int n2, int qs) {
+MX_HD Sweep2Geom sweep2_geom(int nUnd, int ntiles, int qs) {
   Sweep2Geom G;
-  const int ntiles = (n2 + 31) >> 5;
   const int QPB = qpb_of(qs), SWEEP2_NW = 256 * sweep_wps(qs);    // one round of workgroups
   G.nQB = (nUnd + QPB - 1) / QPB;
   int S = G.nQB > 0 ? SWEEP2_NW / G.nQB : 1;
-  if (S > ntiles / CHUNK) S = ntiles / CHUNK;     // at least one index chunk per split
+  if (S > ntiles / MINT) S = ntiles / MINT;
   if (S < 1) S = 1;
   int tps = (ntiles + S - 1) / S;
-  tps = ((tps + CHUNK - 1) / CHUNK) * CHUNK;
+  tps = (tps + TPS - 1) & ~(TPS - 1);
   S = (ntiles + tps - 1) / tps;
   G.S = S < 1 ? 1 : S;
   G.tilesPerSplit = tps;
   return G;
 }
 // entries of the per-(undecided query, split) arrays of sweep 2, whatever the count turns out to be
-static size_t sweep2_entries(int n1, int n2) {
-  const int ntiles = (n2 + 31) >> 5;
-  const size_t smax = (size_t)std::max(1, ntiles / CHUNK);
+static size_t sweep2_entries(int n1, int ntiles) {
+  const size_t smax = (size_t)std::max(1, ntiles / MINT);
   const size_t a = std::max<size_t>((size_t)n1, (size_t)NW_MAX * QPB_MAX);   // nQB * S <= NW while S > 1; S = 1 beyond
   return std::min(a, (size_t)n1 * smax) + QPB_MAX;
 }
@@ -118,121 +139,202 @@ static size_t sweep2_entries(int n1, int n2) {
 // register r of the 32x32 accumulator of lane half `hi` holds MFMA row 8 (r >> 2) + 4 hi + (r & 3)
 MX_D int row_of(int r, int hi) { return 8 * (r >> 2) + 4 * hi + (r & 3); }
 
-// ---------------- pack: norms, swizzled tiles, key constants -------------------------------------------------------
-// y = 0: norm1[i] = |q_i - 128|^2.   y = 1: one thread per train slot t < ntilesPadded * 32:
-//   tiles[t >> 5] row t & 31 = b - 128 in 16-byte slots, slot s stored at s ^ ((row >> 1) & 7)
-//   cst[t] = (|b'|^2 + 2 sum b') << 8 | ((tile % 12) + 1) << 4 | register of the row;   past the end: zeros / NONE | idx
-//   norm2[t] = |b'|^2
-__device__ __forceinline__ void pack_body(const uint8_t *d1, int n1, int *norm1, const uint8_t *d2, int n2, int slots,
-                                          unsigned char *tiles, int *cst, int *norm2) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+// ---------------- pack: norms, parity classes, swizzled tiles, row / tile constants ---------------------------------------
+// y = 0: norm1[i] = |q_i - 128|^2, one thread per query.
+// y = 1: one 1024-thread workgroup per block of PB trains; thread i takes the trains i and i + 1024 of the block.
+//   slot of a train = block base + its rank among the block's trains of its class (even classes first, each class padded
+//   to whole tiles);  tiles[slot >> 5] row slot & 31 = b - 128 in 16-byte slots, slot s stored at s ^ ((row >> 1) & 7)
+//   hrow[slot] = (|b'|^2 + 2 sum b') >> 1,  norm2[slot] = |b'|^2,  perm[slot] = train index;  padding: zero row, NONE_H, -1
+//   tk[tile] = parity << 8 | (tile % CHUNK + 1)
+struct PackArgs {
+  const uint8_t *d1, *d2;
+  const double *pos2;
+  int n1, n2, offT;
+  unsigned epoch;
+  int *norm1, *norm2, *hrow, *perm;
+  double2 *pos2p;
+  unsigned char *tiles;
+  u64 *status;            // one word per pack workgroup: epoch << 32 | even trains << 16 | odd trains
+  TileGeo *geo;
+};
+// sum over the 8 lanes of a half DPP row (half-row mirror, quad reverse, quad pair swap): every lane ends with the total
+MX_D int sum8(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x1B, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+  return v;
+}
+// y = 0: norm1[i] = |q_i - 128|^2, eight lanes per query (coalesced 128-byte rows).
+// y = 1: one 256-thread workgroup per PB = 256 trains, eight lanes per train (one 16-byte slice each), 32 trains per pass:
+//   row = pass * 32 + tid / 8 is the train's place in the workgroup, so (pass, wave, group in the wave) is train order.
+//   slot of a train = its rank among ALL trains of its class: the workgroup's base (sum of the counts of the workgroups
+//   before it -- they were dispatched before it, so waiting for their status words cannot deadlock) + its rank inside.
+//   tiles[slot >> 5] row slot & 31 = b - 128 in 16-byte slots, slot s stored at s ^ ((row >> 1) & 7); the odd class starts
+//   at tile offT.  hrow[slot] = (|b'|^2 + 2 sum b') >> 1, norm2[slot] = |b'|^2, perm[slot] = train, pos2p[slot] = position.
+//   The last workgroup knows the totals: it writes the tile geometry and the padding rows (zero row, NONE_H, -1).
+__device__ __forceinline__ void pack_body(const PackArgs &A) {
+  const int tid = threadIdx.x;
   if (blockIdx.y == 0) {
-    if (i >= n1) return;
-    const v4i *p = reinterpret_cast<const v4i *>(d1 + (size_t)i * 128);
+    const int i = blockIdx.x * 32 + (tid >> 3);
     int s = 0;
+    if (i < A.n1) {
+      const v4i v = reinterpret_cast<const v4i *>(A.d1 + (size_t)i * 128)[tid & 7];
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const v4i v = p[q];
-#pragma unroll
-      for (int w = 0; w < 4; w++) {
-        const int x = v[w] ^ 0x80808080;
-#pragma unroll
-        for (int b = 0; b < 4; b++) { const int e = (int)(signed char)((x >> (8 * b)) & 0xff); s += e * e; }
-      }
+      for (int w = 0; w < 4; w++) { const int x = v[w] ^ 0x80808080; s = __builtin_amdgcn_sdot4(x, x, s, false); }
     }
-    norm1[i] = s;
+    s = sum8(s);
+    if (i < A.n1 && (tid & 7) == 0) A.norm1[i] = s;
     return;
   }
-  if (i >= slots) return;
-  const int tile = i >> 5, row = i & 31;
-  const int idx = (((tile % CHUNK) + 1) << 4) | (4 * (row >> 3) + (row & 3));
-  unsigned char *dst = tiles + (size_t)tile * TILE_B + row * 128;
-  const int sw = (row >> 1) & 7;
-  if (i >= n2) {
+  const int nwg = (A.n2 + PB - 1) / PB;
+  const int blk = blockIdx.x;
+  if (blk >= nwg) return;
+  __shared__ int sCnt[2][32];      // [class][pass * 4 + wave]: trains of the class, then their exclusive prefix
+  __shared__ int sTot[2], sBase[2][4];
+  __shared__ int sSlot[PB], sNv[PB], sHv[PB];   // per train of the workgroup: slot, |b'|^2, row constant
+  const int wave = tid >> 6, lane = tid & 63, slice = tid & 7, gw = lane >> 3;
+  constexpr int NP = PB / 32;
+  v4i row[NP];
+  int meta[NP];                    // valid | parity << 1 | rank among the wave's trains of the class << 2
 #pragma unroll
-    for (int q = 0; q < 8; q++) *reinterpret_cast<v4i *>(dst + ((q ^ sw) << 4)) = (v4i){0, 0, 0, 0};
-    cst[i] = NONE | idx;
-    return;
+  for (int p = 0; p < NP; p++) {   // all loads first: eight independent 16-byte loads in flight per lane
+    const int t = blk * PB + p * 32 + (tid >> 3);
+    row[p] = (v4i){(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+    if (t < A.n2) row[p] = reinterpret_cast<const v4i *>(A.d2 + (size_t)t * 128)[slice];
   }
-  const v4i *p = reinterpret_cast<const v4i *>(d2 + (size_t)i * 128);
-  int s = 0, lin = 0;
 #pragma unroll
-  for (int q = 0; q < 8; q++) {
-    v4i v = p[q];
+  for (int p = 0; p < NP; p++) {
+    const int t = blk * PB + p * 32 + (tid >> 3);
+    const bool valid = t < A.n2;
+    v4i v = row[p];
+    int s = 0, lin = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
       v[w] ^= 0x80808080;
-      const int x = v[w];
-#pragma unroll
-      for (int b = 0; b < 4; b++) { const int e = (int)(signed char)((x >> (8 * b)) & 0xff); s += e * e; lin += e; }
+      s = __builtin_amdgcn_sdot4(v[w], v[w], s, false);
+      lin = __builtin_amdgcn_sdot4(v[w], 0x01010101, lin, false);
     }
-    *reinterpret_cast<v4i *>(dst + ((q ^ sw) << 4)) = v;
+    row[p] = v;
+    s = sum8(s); lin = sum8(lin);
+    const int par = lin & 1;
+    const u64 balE = __ballot(valid && !par && slice == 0), balO = __ballot(valid && par && slice == 0);
+    const u64 below = (1ull << (gw * 8)) - 1;
+    const int rank = par ? __popcll(balO & below) : __popcll(balE & below);
+    meta[p] = (valid ? 1 : 0) | (par << 1) | (rank << 2);
+    if (slice == 0) { sNv[p * 32 + (tid >> 3)] = s; sHv[p * 32 + (tid >> 3)] = (s + 2 * lin) >> 1; }
+    if (lane == 0) { sCnt[0][p * 4 + wave] = __popcll(balE); sCnt[1][p * 4 + wave] = __popcll(balO); }
   }
-  norm2[i] = s;
-  cst[i] = ((s + 2 * lin) << 8) | idx;
+  __syncthreads();
+  if (wave < 2) {
+    // exclusive prefix of the 32 counts of class `wave`
+    const int c = lane < 32 ? sCnt[wave][lane] : 0;
+    int pre = c;
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) { const int v = __shfl_up(pre, m); if (lane >= m) pre += v; }
+    if (lane < 32) sCnt[wave][lane] = pre - c;
+    if (lane == 31) sTot[wave] = pre;
+  }
+  __syncthreads();
+  const int myE = sTot[0], myO = sTot[1];
+  if (tid == 0)
+    __hip_atomic_store(A.status + blk, ((u64)A.epoch << 32) | ((u64)myE << 16) | (u64)myO, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // the counts of the workgroups before this one (a word is valid when it carries this launch's epoch and sums to the
+  // workgroup's train count -- whatever an earlier launch or another use of the memory left there does not)
+  int bE = 0, bO = 0;
+  for (int j = tid; j < blk; j += 256) {
+    u64 w;
+    do {
+      w = __hip_atomic_load(A.status + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } while ((unsigned)(w >> 32) != A.epoch || (int)((w >> 16) & 0xffff) + (int)(w & 0xffff) != PB);
+    bE += (int)((w >> 16) & 0xffff); bO += (int)(w & 0xffff);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { bE += __shfl_xor(bE, m); bO += __shfl_xor(bO, m); }
+  if (lane == 0) { sBase[0][wave] = bE; sBase[1][wave] = bO; }
+  __syncthreads();
+  const int baseE = sBase[0][0] + sBase[0][1] + sBase[0][2] + sBase[0][3];
+  const int baseO = sBase[1][0] + sBase[1][1] + sBase[1][2] + sBase[1][3];
+  const int offS = A.offT * 32;
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    if (!(meta[p] & 1)) continue;
+    const int par = (meta[p] >> 1) & 1, rank = meta[p] >> 2;
+    const int slot = (par ? offS + baseO : baseE) + sCnt[par][p * 4 + wave] + rank;
+    const int tile = slot >> 5, r = slot & 31, sw = (r >> 1) & 7;
+    *reinterpret_cast<v4i *>(A.tiles + (size_t)tile * TILE_B + r * 128 + ((slice ^ sw) << 4)) = row[p];
+    if (slice == 0) sSlot[p * 32 + (tid >> 3)] = slot;
+  }
+  __syncthreads();
+  {
+    // per-slot constants and positions (k_match_decide / k_match_events read the positions with the rows), a thread per train
+    const int t = blk * PB + tid;
+    if (t < A.n2) {
+      const int slot = sSlot[tid];
+      A.hrow[slot] = sHv[tid]; A.norm2[slot] = sNv[tid]; A.perm[slot] = t;
+      A.pos2p[slot] = reinterpret_cast<const double2 *>(A.pos2)[t];
+    }
+  }
+  if (blk == nwg - 1) {
+    const int totE = baseE + myE, totO = baseO + myO;
+    const int TEp = (((totE + 31) >> 5) + TPS - 1) & ~(TPS - 1), TOp = (((totO + 31) >> 5) + TPS - 1) & ~(TPS - 1);
+    if (tid == 0) { TileGeo G; G.TEp = TEp; G.TOp = TOp; G.ntilesV = TEp + TOp; G.pad = 0; *A.geo = G; }
+    const int padE = TEp * 32 - totE, npad = padE + TOp * 32 - totO;     // at most 2 * (TPS * 32 - 1) slots
+    for (int k = tid >> 3; k < npad; k += 32) {
+      const int slot = k < padE ? totE + k : offS + totO + (k - padE);
+      *reinterpret_cast<v4i *>(A.tiles + (size_t)(slot >> 5) * TILE_B + (slot & 31) * 128 + (slice << 4)) = (v4i){0, 0, 0, 0};
+      if (slice == 0) { A.hrow[slot] = NONE_H; A.norm2[slot] = 0; A.perm[slot] = -1; }
+      if (slice == 1) A.pos2p[slot] = make_double2(0.0, 0.0);
+    }
+  }
 }
 
-// exact |a - b|^2 of two 128-byte descriptors: na + nb - 2 (a-128).(b-128), dot4 on the signed bytes
-MX_D int exact_dist(const uint8_t *a, int na, const uint8_t *b, int nb) {
-  const v4i *pa = reinterpret_cast<const v4i *>(a), *pb = reinterpret_cast<const v4i *>(b);
-  int dot = 0;
-#pragma unroll
-  for (int q = 0; q < 8; q++) {
-    const v4i x = pa[q], y = pb[q];
-#pragma unroll
-    for (int w = 0; w < 4; w++) dot = __builtin_amdgcn_sdot4(x[w] ^ 0x80808080, y[w] ^ 0x80808080, dot, false);
-  }
-  return na + nb - 2 * dot;
-}
-
-// Exact distances of one group (the 16 rows of tile `tile` that lane half `hi` of the sweeps owns) from query `qd`, by the
-// 16 lanes l = 0..15 of a quarter wave: lane l returns the distance of row row_of(l, hi).  Loads are coalesced: in step k
-// the lanes l < 8 read the eight 16-byte slices of row k, the lanes l >= 8 those of row k + 8 (two whole 128-byte rows per
-// step instead of sixteen scattered 16-byte pieces), partial dot products are summed over the eight lanes of a row.
-MX_D int group_dist16(const uint8_t *qd, int na, const uint8_t *d2, const int *norm2, int n2, int tile, int hi, int l, int *t_out) {
+// Exact distances of one group (the 16 rows of tile `vtile` that lane half `hi` of the sweeps owns; `ptile` is where the tile
+// lives) from query `qd`, by the 16 lanes l = 0..15 of a quarter wave: lane l returns the distance of row row_of(l, hi) (BIG for a
+// padding row), its VIRTUAL slot vtile * 32 + row (the order of the walk), its physical slot and its train index.
+// Loads are coalesced: in step k the lanes l < 8 read the eight 16-byte slices of row k, the lanes l >= 8 those of row k + 8
+// (two whole 128-byte rows per step), partial dot products are summed over the eight lanes of a row.
+MX_D int group_dist16(const uint8_t *qd, int na, const unsigned char *tiles, const int *norm2, const int *perm, int ptile, int vtile,
+                      int hi, int l, int *vslot_out, int *pslot_out, int *t_out) {
   const int slice = l & 7, half = l >> 3;
   v4i q = reinterpret_cast<const v4i *>(qd)[slice];
   q[0] ^= 0x80808080; q[1] ^= 0x80808080; q[2] ^= 0x80808080; q[3] ^= 0x80808080;
   int part[8];
+  const unsigned char *tb = tiles + (size_t)ptile * TILE_B;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    const int t = tile * 32 + row_of(k + 8 * half, hi);
-    v4i y = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
-    if (t < n2) y = reinterpret_cast<const v4i *>(d2 + (size_t)t * 128)[slice];
+    const int r = row_of(k + 8 * half, hi);
+    const v4i y = *reinterpret_cast<const v4i *>(tb + r * 128 + ((slice ^ ((r >> 1) & 7)) << 4));
     int dot = 0;
 #pragma unroll
-    for (int c = 0; c < 4; c++) dot = __builtin_amdgcn_sdot4(q[c], y[c] ^ 0x80808080, dot, false);
+    for (int c = 0; c < 4; c++) dot = __builtin_amdgcn_sdot4(q[c], y[c], dot, false);
     part[k] = dot;
   }
-  // sum over the 8 lanes of a half row with three DPP adds (half-row mirror, quad reverse, quad pair swap): every lane ends
-  // with the total; integer sums, so the order is immaterial
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    part[k] += __builtin_amdgcn_update_dpp(0, part[k], 0x141, 0xf, 0xf, false);
-    part[k] += __builtin_amdgcn_update_dpp(0, part[k], 0x1B, 0xf, 0xf, false);
-    part[k] += __builtin_amdgcn_update_dpp(0, part[k], 0xB1, 0xf, 0xf, false);
-  }
+  for (int k = 0; k < 8; k++) part[k] = sum8(part[k]);
   int dot = part[0];
 #pragma unroll
   for (int k = 1; k < 8; k++) dot = slice == k ? part[k] : dot;
-  const int t = tile * 32 + row_of(l, hi);
+  const int row = row_of(l, hi), pslot = ptile * 32 + row;
+  *vslot_out = vtile * 32 + row;
+  *pslot_out = pslot;
+  const int t = perm[pslot];
   *t_out = t;
-  return t < n2 ? na + norm2[t] - 2 * dot : BIG;
+  return t >= 0 ? na + norm2[pslot] - 2 * dot : BIG;
 }
 
 // ---------------- staging: 4 tiles + their constants, global -> LDS directly ------------------------------------------
 typedef const unsigned char __attribute__((address_space(1))) *gbptr;
 typedef unsigned char __attribute__((address_space(3))) *lbptr;
-MX_D void stage_group(const unsigned char *tiles, const int *cst, int g0, unsigned char *buf, int wave, int lane) {
-  const unsigned char *src = tiles + (size_t)g0 * TILE_B + lane * 16;
+MX_D void stage_group(const unsigned char *tiles, const int *hrow, int p0, unsigned char *buf, int wave, int lane) {
+  const unsigned char *src = tiles + (size_t)p0 * TILE_B + lane * 16;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int chunk = wave + 4 * i;   // 1 KB per wave instruction
     __builtin_amdgcn_global_load_lds((gbptr)(src + chunk * 1024), (lbptr)(buf + chunk * 1024), 16, 0, 0);
   }
   if (wave < 2)
-    __builtin_amdgcn_global_load_lds((gbptr)(reinterpret_cast<const unsigned char *>(cst + (size_t)g0 * 32) + wave * 256 + lane * 4),
-                                     (lbptr)(buf + TPS * TILE_B + wave * 256), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbptr)(reinterpret_cast<const unsigned char *>(hrow + (size_t)p0 * 32) + wave * 256 + lane * 4),
+                                     (lbptr)(buf + HOFF + wave * 256), 4, 0, 0);
 }
 MX_D v4i read_a(const unsigned char *tile, int row, int kb, int hi) {
   const int slot = 2 * kb + hi;
@@ -244,36 +346,34 @@ MX_D v4i load_q(const uint8_t *base, int row, int kb, int hi) {
   v[0] ^= 0x7f7f7f7f; v[1] ^= 0x7f7f7f7f; v[2] ^= 0x7f7f7f7f; v[3] ^= 0x7f7f7f7f;
   return v;
 }
-MX_D int tree_min16(const int *k) {
+MX_D int tree_min16(const v16i &k) {
   const int t0 = imin3(k[0], k[1], k[2]), t1 = imin3(k[3], k[4], k[5]), t2 = imin3(k[6], k[7], k[8]);
   const int t3 = imin3(k[9], k[10], k[11]), t4 = imin3(k[12], k[13], k[14]);
   return min(imin3(t0, t1, t2), imin3(t3, t4, k[15]));
 }
-// train index of a key of the current chunk (low byte = (tile in chunk + 1) << 4 | register)
-MX_D int decode_idx(int lb, int chunkTile0, int hi) {
-  return (chunkTile0 + (lb >> 4) - 1) * 32 + row_of(lb & 15, hi);
-}
 
-// ---------------- the sweep: MODE 0 = per (query, split) top-2 of the group minima, MODE 1 = NNj + event groups ------------
+// ---------------- the sweep: MODE 0 = per (query, split, half) the KTOP smallest group keys, MODE 1 = 2 smallest + event groups
 // One instruction stream per wave keeps both pipes busy: while the four MFMAs of a (tile, query set) chain run, the wave
-// reduces the accumulators of the previous chain (26 VALU), so the matrix pipe never waits for a whole wave to leave its
-// epilogue.  Fragments and key constants of the next tile are read from LDS one tile ahead (two register sets).
+// reduces the accumulators of the previous chain (13 VALU), so the matrix pipe never waits for a whole wave to leave its
+// epilogue.  Fragments and row constants of the next tile are read from LDS one tile ahead (two register sets).
 constexpr int EVCAP = 16;                  // event slots per (undecided query, split, lane half); more -> exact fallback
 struct SweepArgs {
   const uint8_t *d1;
   const int *norm1;
   const unsigned char *tiles;
-  const int *cst;
+  const int *hrow;
+  const TileGeo *geo;
   MatchGeom g;
-  int4 *partial;          // MODE 0
+  int2 *partial;          // MODE 0: [(q * S + split) * 2 + half][KTOP] (distance, tile), ascending; empty = (BIG, -1)
   const int *dmin, *undecided, *nUndecided;   // MODE 1
-  int2 *partial2;
+  int2 *partial2;         // MODE 1: [(u * S2 + split) * 2 + half][2]
   int *evCnt, *ev;
 };
 
 template <int MODE, int QSETS>
 __device__ __forceinline__ void sweep_body(const SweepArgs &A) {
   constexpr int QPB = qpb_of(QSETS);
+  constexpr int KS = MODE == 0 ? KTOP : 2;     // keys of the running state
   __shared__ __attribute__((aligned(16))) unsigned char sm[2][STAGE_B];
   const MatchGeom g = A.g;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -282,14 +382,15 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &A) {
   int sp, qb, S, tilesPerSplit;
   if (MODE == 0) { sp = blockIdx.y; qb = blockIdx.x; S = g.S; tilesPerSplit = g.tilesPerSplit; }
   else {
-    const Sweep2Geom G2 = sweep2_geom(nQ, g.n2, QSETS);
+    const Sweep2Geom G2 = sweep2_geom(nQ, g.ntilesUB, QSETS);
     S = G2.S; tilesPerSplit = G2.tilesPerSplit;
     qb = (int)blockIdx.x / S; sp = (int)blockIdx.x - qb * S;
   }
   if (qb * QPB >= nQ) return;
   const int q0 = qb * QPB + wave * (32 * QSETS);
   v4i bq[QSETS][4];
-  int mA[QSETS], mB[QSETS], iA[QSETS], iB[QSETS];   // MODE 0: m1, m2, i1, i2;  MODE 1: mj, threshold key, ij, event count
+  int m[QSETS][KS], I[QSETS][KS];
+  int thr[QSETS], nev[QSETS];                  // MODE 1: threshold key, events of this lane
   int qsel[QSETS];
 #pragma unroll
   for (int s = 0; s < QSETS; s++) {
@@ -297,74 +398,83 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &A) {
     qsel[s] = MODE == 0 ? u : A.undecided[u];
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) bq[s][kb] = load_q(A.d1, qsel[s], kb, hi);
-    mA[s] = NONE; iA[s] = -1;
-    if (MODE == 0) { mB[s] = NONE; iB[s] = -1; }
-    else { mB[s] = (A.dmin[qsel[s]] - A.norm1[qsel[s]]) << 8; iB[s] = 0; }   // d < Dmin  <=>  key < (Dmin - |a'|^2) << 8
+#pragma unroll
+    for (int k = 0; k < KS; k++) { m[s][k] = NONE_KEY; I[s][k] = -1; }
+    if (MODE == 1) { thr[s] = (A.dmin[qsel[s]] - A.norm1[qsel[s]]) << 8; nev[s] = 0; }   // d < Dmin  <=>  key < (Dmin - |a'|^2) << 8
+    else { thr[s] = 0; nev[s] = 0; }
   }
-  const int ntiles4 = (((g.n2 + 31) >> 5) + TPS - 1) & ~(TPS - 1);
-  const int tBeg = sp * tilesPerSplit, tEnd = min(tBeg + tilesPerSplit, ntiles4);
+  const int TEp = A.geo->TEp, offT = g.offT;
+  const int tBeg = sp * tilesPerSplit, tEnd = min(tBeg + tilesPerSplit, A.geo->ntilesV);   // virtual tiles: even class, then odd
+  // the constant of virtual tile v: parity << 8 | (v % CHUNK + 1), wave-uniform
+  auto tile_kv = [&](int v) { return ((v >= TEp ? 1 : 0) << 8) | (v % CHUNK + 1); };
+  // end of an index chunk: the tile numbers of keys that are new in this chunk move to the index registers, the low byte is
+  // cleared; keys with a cleared low byte are older entries and keep their order among themselves
   auto flush = [&](int chunkTile0) {
 #pragma unroll
     for (int s = 0; s < QSETS; s++) {
-      if (MODE == 0) {
-        const int lb1 = mA[s] & 255, lb2 = mB[s] & 255;
-        const int n2i = lb2 ? decode_idx(lb2, chunkTile0, hi) : (lb1 ? iA[s] : iB[s]);
-        const int n1i = lb1 ? decode_idx(lb1, chunkTile0, hi) : iA[s];
-        iA[s] = n1i; iB[s] = n2i;
-        mA[s] &= ~255; mB[s] &= ~255;
-      } else {
-        const int lb = mA[s] & 255;
-        if (lb) iA[s] = decode_idx(lb, chunkTile0, hi);
-        mA[s] &= ~255;
+      int o[KS];
+#pragma unroll
+      for (int k = 0; k < KS; k++) o[k] = I[s][k];
+#pragma unroll
+      for (int k = 0; k < KS; k++) {
+        const int lb = m[s][k] & 255;
+        I[s][k] = lb ? chunkTile0 + lb - 1 : o[0];
+        if (!lb) {
+#pragma unroll
+          for (int j = 0; j + 1 < KS; j++) o[j] = o[j + 1];
+        }
+        m[s][k] &= ~255;
       }
     }
   };
-  // reduce one accumulator: 16 keys, v_min3 tree, then the running state
-  auto epilogue = [&](const v16i &acc, const int *C, int s, int tile) {
-    int k[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) k[r] = (acc[r] << 9) + C[r];
-    const int t = tree_min16(k);
+  // reduce one accumulator: v_min3 tree, one key, then the running state
+  auto epilogue = [&](const v16i &acc, int kv, int s, int tile) {
+    const int key = (tree_min16(acc) << 9) + kv;
     if (MODE == 0) {
-      mB[s] = imed3(mA[s], mB[s], t);
-      mA[s] = min(mA[s], t);
-    } else if (t < mB[s]) {
-      // a train of this group is closer than Dmin: k_match_events takes the whole group (its other rows included)
+#pragma unroll
+      for (int k = KS - 1; k >= 1; k--) m[s][k] = imed3(m[s][k - 1], m[s][k], key);
+      m[s][0] = min(m[s][0], key);
+    } else if (key < thr[s]) {
+      // a train of this group is closer than Dmin: k_match_events takes the whole group
       const int u = q0 + 32 * s + col;
       if (u < nQ) {
-        if (iB[s] < EVCAP) A.ev[(((size_t)u * S + sp) * 2 + hi) * EVCAP + iB[s]] = tile;
-        iB[s]++;
+        if (nev[s] < EVCAP) A.ev[(((size_t)u * S + sp) * 2 + hi) * EVCAP + nev[s]] = tile;
+        nev[s]++;
       }
-    } else mA[s] = min(mA[s], t);
+    } else {
+      m[s][1] = imed3(m[s][0], m[s][1], key);
+      m[s][0] = min(m[s][0], key);
+    }
   };
   auto load_af = [&](const unsigned char *buf, int q, v4i *af) {
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) af[kb] = read_a(buf + q * TILE_B, col, kb, hi);
   };
-  auto load_c = [&](const unsigned char *buf, int q, int *C) {
+  auto load_c = [&](const unsigned char *buf, int q, v16i &C) {
 #pragma unroll
     for (int gq = 0; gq < 4; gq++) {
-      const v4i c4 = *reinterpret_cast<const v4i *>(buf + TPS * TILE_B + q * 128 + (8 * gq + 4 * hi) * 4);
+      const v4i c4 = *reinterpret_cast<const v4i *>(buf + HOFF + q * 128 + (8 * gq + 4 * hi) * 4);
       C[4 * gq] = c4[0]; C[4 * gq + 1] = c4[1]; C[4 * gq + 2] = c4[2]; C[4 * gq + 3] = c4[3];
     }
   };
   v4i af[2][4];
-  int C[2][16];
+  v16i C[2];
+  int kv[2];
   v16i acc[2];
-  acc[1] = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  // the pipeline starts with a neutral pending chain: zero accumulator, NONE constants -> keys that change nothing
+  // the pipeline starts with a neutral pending chain: keys that change nothing
 #pragma unroll
-  for (int r = 0; r < 16; r++) C[1][r] = NONE;
-  int pendTile = 0;
-  if (tBeg < tEnd) stage_group(A.tiles, A.cst, tBeg, sm[0], wave, lane);
+  for (int r = 0; r < 16; r++) acc[1][r] = NONE_H;
+  int kvPend = 0, pendTile = 0;
+  if (tBeg < tEnd) stage_group(A.tiles, A.hrow, phys_tile(tBeg, TEp, offT), sm[0], wave, lane);
   int it = 0;
   for (int tg = tBeg; tg < tEnd; tg += TPS, it++) {
     const unsigned char *buf = sm[it & 1];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tg + TPS < tEnd) stage_group(A.tiles, A.cst, tg + TPS, sm[(it & 1) ^ 1], wave, lane);
+    if (tg + TPS < tEnd) stage_group(A.tiles, A.hrow, phys_tile(tg + TPS, TEp, offT), sm[(it & 1) ^ 1], wave, lane);
     load_af(buf, 0, af[0]);
     load_c(buf, 0, C[0]);
+    kv[0] = tile_kv(tg);
 #pragma unroll
     for (int q = 0; q < TPS; q++) {
       const int cur = q & 1;
@@ -376,208 +486,306 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &A) {
       for (int s = 0; s < QSETS; s++) {
         if (q + 1 < TPS) {
           if (s == 0) load_af(buf, q + 1, af[cur ^ 1]);
-          if (s == 1) load_c(buf, q + 1, C[cur ^ 1]);     // C[cur ^ 1] was the pending chain's until phase 0 ended
+          if (s == 1) { load_c(buf, q + 1, C[cur ^ 1]); kv[cur ^ 1] = tile_kv(tg + q + 1); }
         }
         __builtin_amdgcn_sched_barrier(0);
         v16i &an = acc[s & 1];
-        an = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        an = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[cur][0], bq[s][0], C[cur], 0, 0, 0);
 #pragma unroll
-        for (int kb = 0; kb < 4; kb++) an = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[cur][kb], bq[s][kb], an, 0, 0, 0);
-        if (s == 0) epilogue(acc[1], C[cur ^ 1], QSETS - 1, pendTile);
-        else epilogue(acc[(s - 1) & 1], C[cur], s - 1, tg + q);
+        for (int kb = 1; kb < 4; kb++) an = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[cur][kb], bq[s][kb], an, 0, 0, 0);
+        if (s == 0) epilogue(acc[1], kvPend, QSETS - 1, pendTile);
+        else epilogue(acc[(s - 1) & 1], kv[cur], s - 1, tg + q);
+        // one MFMA, then a quarter of the reduction
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
 #pragma unroll
-        for (int kb = 0; kb < 4; kb++) {   // one MFMA, then a quarter of the reduction
+        for (int kb = 1; kb < 4; kb++) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
       pendTile = tg + q;
+      kvPend = kv[cur];
     }
-    if ((it % (CHUNK / TPS)) == CHUNK / TPS - 1) {
-      // end of an index chunk: drain the pending chain, then move the indices of changed keys out of the low byte
-      epilogue(acc[1], C[1], QSETS - 1, pendTile);
-      acc[1] = (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if ((tg + TPS) % CHUNK == 0) {
+      // end of an index chunk: drain the pending chain, then move the tile numbers of new keys out of the low byte
+      epilogue(acc[1], kvPend, QSETS - 1, pendTile);
 #pragma unroll
-      for (int r = 0; r < 16; r++) C[1][r] = NONE;
+      for (int r = 0; r < 16; r++) acc[1][r] = NONE_H;
+      kvPend = 0;
       flush(tg + TPS - CHUNK);
     }
   }
-  if (it % (CHUNK / TPS)) {
-    epilogue(acc[1], C[1], QSETS - 1, pendTile);
-    flush(tBeg + (it / (CHUNK / TPS)) * CHUNK);
+  if (tEnd > tBeg && tEnd % CHUNK) {
+    epilogue(acc[1], kvPend, QSETS - 1, pendTile);
+    flush((tEnd / CHUNK) * CHUNK);
   }
-  // the two lane halves of a query saw different rows: merge, convert keys to distances, store
+  // store the stream's keys as (distance, tile)
 #pragma unroll
   for (int s = 0; s < QSETS; s++) {
     const int q = q0 + 32 * s + col;
+    if (q >= nQ) continue;
     const int na = A.norm1[qsel[s]];
+    int2 e[KS];
+#pragma unroll
+    for (int k = 0; k < KS; k++) e[k] = m[s][k] >= NONE_KEY ? make_int2(BIG, -1) : make_int2((m[s][k] >> 8) + na, I[s][k]);
     if (MODE == 0) {
-      int d0 = iA[s] < 0 ? BIG : (mA[s] >> 8) + na, j0 = iA[s] < 0 ? BIG : iA[s];
-      int dd1 = iB[s] < 0 ? BIG : (mB[s] >> 8) + na, j1 = iB[s] < 0 ? BIG : iB[s];
-      const int od0 = __shfl_xor(d0, 32), oj0 = __shfl_xor(j0, 32), od1 = __shfl_xor(dd1, 32), oj1 = __shfl_xor(j1, 32);
-      if (lex_less(od0, oj0, d0, j0)) {
-        if (lex_less(od1, oj1, d0, j0)) { dd1 = od1; j1 = oj1; } else { dd1 = d0; j1 = j0; }
-        d0 = od0; j0 = oj0;
-      } else if (lex_less(od0, oj0, dd1, j1)) { dd1 = od0; j1 = oj0; }
-      if (hi == 0 && q < nQ) A.partial[(size_t)q * S + sp] = make_int4(d0, j0, dd1, j1);
+      int4 *dst = reinterpret_cast<int4 *>(A.partial + (((size_t)q * S + sp) * 2 + hi) * KS);
+#pragma unroll
+      for (int k = 0; k < KS; k += 2) dst[k >> 1] = make_int4(e[k].x, e[k].y, e[k + 1].x, e[k + 1].y);
     } else {
-      int dj = iA[s] < 0 ? BIG : (mA[s] >> 8) + na, tj = iA[s] < 0 ? BIG : iA[s];
-      const int od = __shfl_xor(dj, 32), ot = __shfl_xor(tj, 32);
-      if (lex_less(od, ot, dj, tj)) { dj = od; tj = ot; }
-      if (q < nQ) {
-        A.evCnt[((size_t)q * S + sp) * 2 + hi] = iB[s];
-        if (hi == 0) A.partial2[(size_t)q * S + sp] = make_int2(dj, tj);
-      }
+      A.evCnt[((size_t)q * S + sp) * 2 + hi] = nev[s];
+      *reinterpret_cast<int4 *>(A.partial2 + (((size_t)q * S + sp) * 2 + hi) * 2) = make_int4(e[0].x, e[0].y, e[1].x, e[1].y);
     }
   }
 }
 
-// ---------------- decide: merge splits, the hidden candidate of NN0's group, j = 1 of the walk ---------------------------
-// 16 lanes per query.  sweep 1 ranks group minima, so the one candidate it cannot have seen is the second-best inside the
-// group (same tile, same lane half) of the overall winner: lane l recomputes the distance of that group's row l exactly.
+// ---------------- decide: merge the streams, recompute groups exactly, walk the certain rows ------------------------------
+// 16 lanes per query (a DPP row); see the header and tests/match_model.py.
 #ifndef MODSX_DECIDE_Q
-#define MODSX_DECIDE_Q 64
+#define MODSX_DECIDE_Q 16
 #endif
 constexpr int DECIDE_Q = MODSX_DECIDE_Q;   // queries per workgroup of k_match_decide (16 lanes each)
-__device__ __forceinline__ void decide_body(const uint8_t *d1, const int *norm1, const uint8_t *d2, const int *norm2,
-                                            const int4 *partial, MatchGeom g, const double *pos2, double sqminratio,
-                                            double contrDistSq, MatchRow *rows, int *dmin, int *undecided, int *nUndecided) {
+struct DecideArgs {
+  const uint8_t *d1;
+  const int *norm1, *norm2, *perm;
+  const unsigned char *tiles;
+  const TileGeo *geo;
+  const int2 *partial;
+  MatchGeom g;
+  const double2 *pos2p;
+  double sqminratio, contrDistSq;
+  int nn;
+  MatchRow *rows;
+  int *dmin, *undecided, *nUndecided;
+  double *x0y0;           // NN0's position of the queries that go on to sweep 2
+};
+__device__ __forceinline__ void decide_body(const DecideArgs &A) {
   // undecided queries are compacted with ONE global atomic per workgroup (a counter word takes ~90 atomics per us)
   __shared__ int sList[DECIDE_Q], sCount, sBase;
   if (threadIdx.x == 0) sCount = 0;
   __syncthreads();
+  const MatchGeom g = A.g;
   const int l = threadIdx.x & 15;
   const int q = blockIdx.x * DECIDE_Q + (threadIdx.x >> 4);
   const bool live = q < g.n1;
   const int qc = live ? q : g.n1 - 1;
-  int d0 = BIG, i0 = BIG, dd1 = BIG, j1 = BIG;
-  for (int s = l; s < g.S; s += 16) {
-    const int4 p = partial[(size_t)qc * g.S + s];
-    if (lex_less(p.x, p.y, d0, i0)) {
-      if (lex_less(p.z, p.w, d0, i0)) { dd1 = p.z; j1 = p.w; } else { dd1 = d0; j1 = i0; }
-      d0 = p.x; i0 = p.y;
-    } else if (lex_less(p.x, p.y, dd1, j1)) { dd1 = p.x; j1 = p.y; }
-  }
+  // 1. this lane's streams -> its KTOP smallest (distance, group) keys in ascending order; group = tile * 2 + half; empty = (BIG, BIG)
+  int Ld[KTOP], Lg[KTOP];
+  const int nst = 2 * g.S;
+  {
+    int4 p[KTOP / 2];
 #pragma unroll
-  for (int m = 8; m >= 1; m >>= 1) {
-    const int od0 = __shfl_xor(d0, m), oi0 = __shfl_xor(i0, m), od1 = __shfl_xor(dd1, m), oj1 = __shfl_xor(j1, m);
-    if (lex_less(od0, oi0, d0, i0)) {
-      if (lex_less(od1, oj1, d0, i0)) { dd1 = od1; j1 = oj1; } else { dd1 = d0; j1 = i0; }
-      d0 = od0; i0 = oi0;
-    } else if (lex_less(od0, oi0, dd1, j1)) { dd1 = od0; j1 = oi0; }
-  }
-  if (i0 != BIG) {
-    const int tile = i0 >> 5, hi = ((i0 & 31) >> 2) & 1;
-    int ht;
-    int hd = group_dist16(d1 + (size_t)qc * 128, norm1[qc], d2, norm2, g.n2, tile, hi, l, &ht);
-    if (ht >= g.n2 || ht == i0) { hd = BIG; ht = BIG; }
+    for (int k2 = 0; k2 < KTOP / 2; k2++) p[k2] = make_int4(BIG, -1, BIG, -1);
+    if (l < nst) {
+      const int4 *src = reinterpret_cast<const int4 *>(A.partial + ((size_t)qc * nst + l) * KTOP);
 #pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) {
-      const int od = __shfl_xor(hd, m), ot = __shfl_xor(ht, m);
-      if (lex_less(od, ot, hd, ht)) { hd = od; ht = ot; }
+      for (int k2 = 0; k2 < KTOP / 2; k2++) p[k2] = src[k2];
     }
-    if (lex_less(hd, ht, dd1, j1)) { dd1 = hd; j1 = ht; }
+#pragma unroll
+    for (int k2 = 0; k2 < KTOP / 2; k2++) {
+      Ld[2 * k2] = p[k2].y < 0 ? BIG : p[k2].x; Lg[2 * k2] = p[k2].y < 0 ? BIG : p[k2].y * 2 + (l & 1);
+      Ld[2 * k2 + 1] = p[k2].w < 0 ? BIG : p[k2].z; Lg[2 * k2 + 1] = p[k2].w < 0 ? BIG : p[k2].w * 2 + (l & 1);
+    }
   }
-  if (live && l == 0) {
-    MatchRow o;
-    o.t0 = i0 == BIG ? -1 : i0; o.t1 = j1 == BIG ? -1 : j1; o.tj = -1; o.nless = 0; o.nbad = 0;
-    o.d0 = (float)d0; o.d1 = (float)dd1; o.dj = 0.f;
-    int dm = 0;
-    if (i0 != BIG && j1 != BIG) {
-      if (ratio_pass((float)d0, (float)dd1, sqminratio)) { o.tj = j1; o.dj = (float)dd1; }       // accepted at j = 1
+  for (int st = l + 16; st < nst; st += 16) {        // more than 16 streams (few queries, many splits): insertion
+    const int2 *src = A.partial + ((size_t)qc * nst + st) * KTOP;
+    for (int e = 0; e < KTOP; e++) {
+      const int2 pe = src[e];
+      if (pe.y < 0) break;
+      int ed = pe.x, eg = pe.y * 2 + (st & 1);
+#pragma unroll
+      for (int k = 0; k < KTOP; k++)
+        if (lex_less(ed, eg, Ld[k], Lg[k])) { const int td = Ld[k], tg = Lg[k]; Ld[k] = ed; Lg[k] = eg; ed = td; eg = tg; }
+    }
+  }
+  // 2. the KTOP smallest of the query: KTOP rounds of (lexicographic minimum of the heads over the 16 lanes, the owner pops)
+  int Gd[KTOP], Gg[KTOP];
+#pragma unroll
+  for (int k = 0; k < KTOP; k++) {
+    const int dm = rowmin16(Ld[0]);
+    const int gm = rowmin16(Ld[0] == dm ? Lg[0] : BIG);
+    Gd[k] = dm; Gg[k] = gm;
+    if (Ld[0] == dm && Lg[0] == gm) {
+#pragma unroll
+      for (int jj = 0; jj + 1 < KTOP; jj++) { Ld[jj] = Ld[jj + 1]; Lg[jj] = Lg[jj + 1]; }
+      Ld[KTOP - 1] = BIG; Lg[KTOP - 1] = BIG;
+    }
+  }
+  int nG = 0;
+#pragma unroll
+  for (int k = 0; k < KTOP; k++) nG += Gd[k] != BIG;
+  const int usable = nG < KTOP ? nG : KTOP - 1;
+  // 3. recomputed rows: lane l holds row l of every recomputed group -- distance, slot, train index and position, all loaded
+  //    with the group, so that the walk below is arithmetic and lane exchanges only
+  const uint8_t *qd = A.d1 + (size_t)qc * 128;
+  const int na = A.norm1[qc];
+  int pd[KTOP - 1], ps[KTOP - 1], pt[KTOP - 1];  // distance (BIG: padding / used), slot, train
+  double px[KTOP - 1], py[KTOP - 1];
+#pragma unroll
+  for (int k = 0; k < KTOP - 1; k++) { pd[k] = BIG; ps[k] = BIG; pt[k] = -1; px[k] = 0; py[k] = 0; }
+  int mrec = 0;
+  const int TEp = A.geo->TEp;
+  auto recompute = [&](int k) {                // static k: the pool lives in registers
+    int pslot;
+    pd[k] = group_dist16(qd, na, A.tiles, A.norm2, A.perm, phys_tile(Gg[k] >> 1, TEp, g.offT), Gg[k] >> 1, Gg[k] & 1, l, &ps[k],
+                         &pslot, &pt[k]);
+    const double2 xy = A.pos2p[pslot];
+    px[k] = xy.x; py[k] = xy.y;
+  };
+  if (usable > 0) { recompute(0); mrec = 1; }
+  if (usable > 1) { recompute(1); mrec = 2; }
+  // 4. the walk over the certain rows
+  int j = 0, res = 0;                          // res: 0 running, 1 accept, 2 reject / ran off the list, 3 sweep 2
+  int d0 = BIG, t0 = -1, dd1 = BIG, t1 = -1, dj = BIG, tj = -1;
+  double x0 = 0, y0 = 0;
+  const int grp = threadIdx.x & 48;            // first lane of this query's 16 within the wave
+  for (int guard = 0; guard < 16 * KTOP + 8 && res == 0; guard++) {
+    // the smallest unused recomputed row: (distance, slot), first in this lane, then over the 16 lanes
+    int ld = BIG, ls = BIG;
+#pragma unroll
+    for (int k = 0; k < KTOP - 1; k++) if (pd[k] != BIG && lex_less(pd[k], ps[k], ld, ls)) { ld = pd[k]; ls = ps[k]; }
+    const int cd = rowmin16(ld);
+    const int cs = rowmin16(ld == cd ? ls : BIG);
+    // the first group not recomputed bounds what is certain (none left and none dropped: everything is)
+    int bd = BIG, bg = BIG;
+#pragma unroll
+    for (int k = 0; k < KTOP; k++) if (k == mrec && k < nG) { bd = Gd[k]; bg = Gg[k]; }
+    const bool certain = cd != BIG && (bd == BIG || cd < bd || (cd == bd && (cs >> 5) < (bg >> 1)));
+    if (certain) {
+      // the owner lane (register index of the row inside its group) hands over train and position; it marks the row used
+      int ct = pt[0];
+      double cx = px[0], cy = py[0];
+#pragma unroll
+      for (int k = 1; k < KTOP - 1; k++) if (pd[k] == cd && ps[k] == cs) { ct = pt[k]; cx = px[k]; cy = py[k]; }
+#pragma unroll
+      for (int k = 0; k < KTOP - 1; k++) if (pd[k] == cd && ps[k] == cs) pd[k] = BIG;
+      const int rowc = cs & 31, owner = grp + (((rowc >> 3) << 2) | (rowc & 3));
+      ct = __shfl(ct, owner); cx = __shfl(cx, owner); cy = __shfl(cy, owner);
+      if (j == 0) { d0 = cd; t0 = ct; x0 = cx; y0 = cy; }
       else {
-        const double dx = pos2[2 * i0] - pos2[2 * j1], dy = pos2[2 * i0 + 1] - pos2[2 * j1 + 1];
-        if (dx * dx + dy * dy > contrDistSq) o.nbad = 1;                                      // first contradictive
+        if (j == 1) { dd1 = cd; t1 = ct; }
+        if (ratio_pass((float)d0, (float)cd, A.sqminratio)) { res = 1; dj = cd; tj = ct; }
         else {
-          dm = ratio_dmin(d0, sqminratio);
-          if (dm <= MAXD) {          // otherwise no distance can pass the ratio test: the walk ends without a match
-            sList[atomicAdd(&sCount, 1)] = q;
-            o.nless = -1;   // filled by sweep 2
-          }
+          const double dx = x0 - cx, dy = y0 - cy;
+          if (dx * dx + dy * dy > A.contrDistSq) res = 2;         // first contradictive
+          else if (j >= A.nn - 1) res = 2;                        // the walk looks at nn - 1 neighbours
         }
       }
+      j++;
+    } else if (mrec < usable) {
+#pragma unroll
+      for (int k = 2; k < KTOP - 1; k++) if (k == mrec) recompute(k);
+      mrec++;
+    } else res = nG < KTOP ? 2 : 3;
+  }
+  if (res == 0) res = 3;                       // not reached
+  if (live && l == 0) {
+    MatchRow o;
+    o.t0 = t0; o.t1 = t1; o.tj = -1; o.nless = 0; o.nbad = 0;
+    o.d0 = (float)d0; o.d1 = (float)dd1; o.dj = 0.f;
+    int dm = 0;
+    if (res == 1) { o.tj = tj; o.dj = (float)dj; o.nless = j - 2; }
+    else if (res == 2) o.nbad = t1 < 0 ? 0 : 1;
+    else if (t0 >= 0) {
+      dm = ratio_dmin(d0, A.sqminratio);
+      if (dm <= MAXD) {          // otherwise no distance can pass the ratio test: the walk ends without a match
+        sList[atomicAdd(&sCount, 1)] = q;
+        o.nless = -1;   // filled by sweep 2
+        A.x0y0[2 * q] = x0; A.x0y0[2 * q + 1] = y0;
+      }
     }
-    rows[q] = o;
-    dmin[q] = dm;
+    A.rows[q] = o;
+    A.dmin[q] = dm;
   }
   __syncthreads();
-  if (threadIdx.x == 0 && sCount) sBase = atomicAdd(nUndecided, sCount);
+  if (threadIdx.x == 0 && sCount) sBase = atomicAdd(A.nUndecided, sCount);
   __syncthreads();
-  if ((int)threadIdx.x < sCount) undecided[sBase + threadIdx.x] = sList[threadIdx.x];
+  if ((int)threadIdx.x < sCount) A.undecided[sBase + threadIdx.x] = sList[threadIdx.x];
 }
 
 // ---------------- events: the groups of sweep 2 that hold a train below Dmin, recomputed exactly ---------------------------
 // One wave per undecided query; each 16-lane quarter walks the event lists of every fourth (split, lane half) stream, one
-// group (16 rows) at a time.  Output per query: nless, nbad and the lex-smallest (d, t) with d >= Dmin among the rows of the
-// event groups (the sweep left those groups out of its own minimum).  A stream that ran out of its EVCAP slots sends the
-// query to the exact fallback: every train, one per lane (low-entropy inputs with thousands of near-duplicates).
-__device__ __forceinline__ void events_body(const uint8_t *d1, const int *norm1, const uint8_t *d2, const int *norm2, MatchGeom g,
-                                            const double *pos2, double contrDistSq, MatchRow *rows, const int *dmin,
-                                            const int *undecided, const int *nUndecided, const int *evCnt, const int *ev,
-                                            int nn, const int2 *partial2) {
+// group (16 rows) at a time.  Output per query: nless, nbad and the lex-smallest (d, slot) with d >= Dmin among the rows of the
+// event groups and the best group the sweep did not flag.  A stream that ran out of its EVCAP slots is rescanned exactly.
+struct EventsArgs {
+  const uint8_t *d1;
+  const int *norm1, *norm2, *perm;
+  const unsigned char *tiles;
+  const TileGeo *geo;
+  MatchGeom g;
+  const double2 *pos2p;
+  double contrDistSq;
+  MatchRow *rows;
+  const int *dmin, *undecided, *nUndecided, *evCnt, *ev;
+  const double *x0y0;
+  int nn;
+  const int2 *partial2;
+};
+__device__ __forceinline__ void events_body(const EventsArgs &A) {
   __shared__ int sRec[4][MATCH_NN_MAX];  // per wave: the event groups of its query as (tile << 1 | lane half); fewer than nn of them
+  const MatchGeom g = A.g;
   const int w = threadIdx.x >> 6;
   const int u = blockIdx.x * 4 + w;
-  const int nUnd = *nUndecided;
+  const int nUnd = *A.nUndecided;
   if (u >= nUnd) return;
   const int lane = threadIdx.x & 63, l = lane & 15, sub = lane >> 4;
-  const Sweep2Geom G2 = sweep2_geom(nUnd, g.n2, g.qs);      // the splits sweep 2 chose for this count
+  const Sweep2Geom G2 = sweep2_geom(nUnd, g.ntilesUB, g.qs);      // the splits sweep 2 chose for this count
+  const int TEp = A.geo->TEp, ntilesV = A.geo->ntilesV;
   const int S2 = G2.S;
   const int nst = 2 * S2;
+  const int nn = A.nn;
+  constexpr u64 INF = ~0ull;
   // Every event group holds at least one train below Dmin and at most one of all those trains is NN0, so nn or more
-  // groups mean nless > nn - 2: the walk gives up (matching.cpp:435-457) and nothing has to be recomputed.  (Look-alike
-  // regions -- a thousand similar blobs -- produce exactly this, and would otherwise dominate the kernel.)
+  // groups mean nless > nn - 2: the walk gives up (matching.cpp:435-457) and nothing has to be recomputed.
   int total = 0;
-  for (int st = lane; st < nst; st += 64) total += evCnt[(size_t)u * nst + st];
+  for (int st = lane; st < nst; st += 64) total += A.evCnt[(size_t)u * nst + st];
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) total += __shfl_xor(total, m);
-  const int q = undecided[u];
-  // the last step of the walk for this query: NNj = the lex-smallest of the event groups' candidate and the splits' minima of
-  // sweep 2, then the row gets tj / dj / nless / nbad (this used to be a launch of its own)
-  auto finish = [&](int nlessF, int nbadF, int djF, int tjF) {
-    for (int sp = lane; sp < S2; sp += 64) {
-      const int2 p = partial2[(size_t)u * S2 + sp];
-      if (lex_less(p.x, p.y, djF, tjF)) { djF = p.x; tjF = p.y; }
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-      const int od = __shfl_xor(djF, m), ot = __shfl_xor(tjF, m);
-      if (lex_less(od, ot, djF, tjF)) { djF = od; tjF = ot; }
-    }
-    if (lane == 0) {
-      MatchRow o = rows[q];
-      o.tj = tjF == BIG ? -1 : tjF;
-      o.dj = (float)djF;
-      o.nless = nlessF; o.nbad = nbadF;
-      rows[q] = o;
-    }
-  };
-  if (total >= nn) { finish(nn, 0, BIG, BIG); return; }
-  const int t0 = rows[q].t0, Dm = dmin[q], na = norm1[q];
-  const double x0 = pos2[2 * t0], y0 = pos2[2 * t0 + 1];
-  const uint8_t *qd = d1 + (size_t)q * 128;
-  int nless = 0, nbad = 0, dj = BIG, tj = BIG;
-  // one group (tile, lane half) per quarter wave: lane l gets the exact distance of the group's row l
+  const int q = A.undecided[u];
+  if (total >= nn) {
+    if (lane == 0) { MatchRow o = A.rows[q]; o.tj = -1; o.dj = (float)BIG; o.nless = nn; o.nbad = 0; A.rows[q] = o; }
+    return;
+  }
+  const int t0 = A.rows[q].t0, Dm = A.dmin[q], na = A.norm1[q];
+  const double x0 = A.x0y0[2 * q], y0 = A.x0y0[2 * q + 1];      // NN0's position, left by k_match_decide
+  const uint8_t *qd = A.d1 + (size_t)q * 128;
+  int nless = 0, nbad = 0, dj = BIG, sj = BIG, tjj = -1;
+  // one group (virtual tile, lane half) per quarter wave: lane l gets the exact distance of the group's row l
   auto visit_group = [&](int tile, int hi, bool active) {
-    int t;
-    const int d = group_dist16(qd, na, d2, norm2, g.n2, active ? tile : 0, hi, l, &t);
-    if (!active || t >= g.n2 || t == t0) return;
+    int vslot, pslot, t;
+    const int d = group_dist16(qd, na, A.tiles, A.norm2, A.perm, phys_tile(active ? tile : 0, TEp, g.offT), tile, hi, l, &vslot, &pslot, &t);
+    if (!active || d == BIG || t == t0) return;
     if (d < Dm) {
       nless++;
       // geometric consistency with NN0 (distanceSq, matching.cpp:174-179), f64
-      const double dx = x0 - pos2[2 * t], dy = y0 - pos2[2 * t + 1];
-      if (dx * dx + dy * dy > contrDistSq) nbad++;
-    } else if (lex_less(d, t, dj, tj)) { dj = d; tj = t; }
+      const double2 xy = A.pos2p[pslot];
+      const double dx = x0 - xy.x, dy = y0 - xy.y;
+      if (dx * dx + dy * dy > A.contrDistSq) nbad++;
+    } else if (lex_less(d, vslot, dj, sj)) { dj = d; sj = vslot; tjj = t; }
   };
+  // the best two groups the sweep did not flag: (distance, group) over all streams
+  u64 b0 = INF, b1 = INF;
+  for (int st = lane; st < nst; st += 64) {
+    const int4 p = *reinterpret_cast<const int4 *>(A.partial2 + ((size_t)u * nst + st) * 2);
+    u64 e0 = p.y < 0 ? INF : key64(p.x, p.y * 2 + (st & 1)), e1 = p.w < 0 ? INF : key64(p.z, p.w * 2 + (st & 1));
+    u64 lo = min(b0, e0); e0 = max(b0, e0); b0 = lo; b1 = min(b1, e0);
+    lo = min(b0, e1); e1 = max(b0, e1); b0 = lo; b1 = min(b1, e1);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    u64 o0 = shfl_xor64(b0, m), o1 = shfl_xor64(b1, m);
+    const u64 lo = min(b0, o0); o0 = max(b0, o0); b0 = lo; b1 = min(min(b1, o1), o0);
+  }
   // gather the (fewer than nn <= MATCH_NN_MAX) logged groups of all streams into one list; a stream that ran out of slots is
   // rescanned exactly over its own tiles afterwards (its logged groups are then ignored); the groups it did not flag hold
-  // no train below Dmin and their candidates d >= Dmin are already in the sweep's minimum
+  // no train below Dmin and their minimum is in the sweep's keys
   int nrec = 0;
   bool anyOver = false;
   for (int s0 = 0; s0 < nst; s0 += 64) {
     const int st = s0 + lane;
-    int c = st < nst ? evCnt[(size_t)u * nst + st] : 0;
+    int c = st < nst ? A.evCnt[(size_t)u * nst + st] : 0;
     const bool over = c > EVCAP;
     anyOver = anyOver || __any(over);
     if (over) c = 0;
@@ -586,19 +794,28 @@ __device__ __forceinline__ void events_body(const uint8_t *d1, const int *norm1,
     for (int m = 1; m < 64; m <<= 1) { const int v = __shfl_up(pre, m); if (lane >= m) pre += v; }
     const int base = nrec + pre - c;
     for (int e = 0; e < c; e++)
-      if (base + e < MATCH_NN_MAX) sRec[w][base + e] = (ev[((size_t)u * nst + st) * EVCAP + e] << 1) | (st & 1);
+      if (base + e < MATCH_NN_MAX) sRec[w][base + e] = (A.ev[((size_t)u * nst + st) * EVCAP + e] << 1) | (st & 1);
     nrec += __shfl(pre, 63);
   }
   nrec = min(nrec, MATCH_NN_MAX);
-  for (int b = 0; b < nrec; b += 4) {      // wave-uniform trip count: the quarter waves shuffle among their own lanes
+  // the sweep's best group is visited like an event group (all its rows are >= Dmin); the runner-up too when it could hold
+  // the smaller slot of an equal distance (same distance, same tile -- the other lane half)
+  int extra[2], nextra = 0;
+  if (b0 != INF) {
+    extra[nextra++] = (int)(unsigned)b0;
+    if (b1 != INF && (b1 >> 32) == (b0 >> 32) && ((unsigned)b1 >> 1) == ((unsigned)b0 >> 1)) extra[nextra++] = (int)(unsigned)b1;
+  }
+  for (int b = 0; b < nrec + nextra; b += 4) {      // wave-uniform trip count: the quarter waves shuffle among their own lanes
     const int e = b + sub;
-    const int rec = e < nrec ? sRec[w][e] : 0;
-    visit_group(rec >> 1, rec & 1, e < nrec);
+    int rec = 0;
+    if (e < nrec) rec = sRec[w][e];
+    else if (e < nrec + nextra) rec = e - nrec == 0 ? extra[0] : extra[1];
+    visit_group(rec >> 1, rec & 1, e < nrec + nextra);
   }
   if (anyOver) {
     for (int st = 0; st < nst; st++) {
-      if (evCnt[(size_t)u * nst + st] <= EVCAP) continue;
-      const int tb = (st >> 1) * G2.tilesPerSplit, te = min(tb + G2.tilesPerSplit, (g.n2 + 31) >> 5);
+      if (A.evCnt[(size_t)u * nst + st] <= EVCAP) continue;
+      const int tb = (st >> 1) * G2.tilesPerSplit, te = min(tb + G2.tilesPerSplit, ntilesV);
       for (int tile = tb; tile < te; tile += 4) visit_group(tile + sub, st & 1, tile + sub < te);
     }
   }
@@ -606,51 +823,62 @@ __device__ __forceinline__ void events_body(const uint8_t *d1, const int *norm1,
   for (int m = 32; m >= 1; m >>= 1) {
     nless += __shfl_xor(nless, m);
     nbad += __shfl_xor(nbad, m);
-    const int od = __shfl_xor(dj, m), ot = __shfl_xor(tj, m);
-    if (lex_less(od, ot, dj, tj)) { dj = od; tj = ot; }
+    const int od = __shfl_xor(dj, m), os = __shfl_xor(sj, m), ot = __shfl_xor(tjj, m);
+    if (lex_less(od, os, dj, sj)) { dj = od; sj = os; tjj = ot; }
   }
-  finish(nless, nbad, dj, tj);
+  if (lane == 0) {
+    MatchRow o = A.rows[q];
+    o.tj = sj == BIG ? -1 : tjj;
+    o.dj = (float)dj;
+    o.nless = nless; o.nbad = nbad;
+    A.rows[q] = o;
+  }
 }
 
 // ---- workspace layout: ONE description used by the size query and by the launcher -------------------------------------------
 struct MatchLayout {
-  int S, tilesPerSplit, slots;
-  size_t norm1, norm2, cst, tiles, partial, partial2, dmin, undecided, evCnt, ev, evRes, counter, bytes;
+  int S, tilesPerSplit, ntilesUB, offT;
+  size_t norm1, norm2, hrow, perm, pos2p, tiles, status, geo, partial, partial2, dmin, undecided, x0y0, evCnt, ev, counter, bytes;
 };
 static MatchLayout match_layout(int n1, int n2, int qs) {
   MatchLayout L;
   const int QPB = qpb_of(qs);
   const int nQB = (n1 + QPB - 1) / QPB;
-  const int ntiles = (n2 + 31) / 32;
-  // one round of workgroups: 3 per CU (the sweeps hold ~150 VGPRs) x 256 CUs; a second, partly filled round costs as much
-  // as the first.  Many query blocks (N > 196 k) simply take several rounds.
+  const int ntiles = ntiles_ub(n2);
+  // one round of workgroups: 3 per CU x 256 CUs; a second, partly filled round costs as much as the first.  Many query
+  // blocks (N > 196 k) simply take several rounds.
 #ifdef MATCH_TRACE
   static const int nwEnv = getenv("MODSX_MATCH_NW") ? atoi(getenv("MODSX_MATCH_NW")) : 0;   // workgroups per round, to trace 1 / 2 / 3 per CU
   int S = (nwEnv > 0 ? nwEnv : 256 * sweep_wps(qs)) / nQB;
 #else
   int S = (256 * sweep_wps(qs)) / nQB;
 #endif
-  if (S > ntiles / CHUNK) S = ntiles / CHUNK;     // at least one chunk per split
+  if (S > ntiles / MINT) S = ntiles / MINT;
   if (S < 1) S = 1;
   int tps = (ntiles + S - 1) / S;
-  tps = ((tps + CHUNK - 1) / CHUNK) * CHUNK;
+  tps = (tps + TPS - 1) & ~(TPS - 1);
   S = (ntiles + tps - 1) / tps;
   if (S < 1) S = 1;
-  L.S = S; L.tilesPerSplit = tps; L.slots = S * tps * 32;
+  L.S = S; L.tilesPerSplit = tps; L.ntilesUB = ntiles; L.offT = region_tiles(n2);
+  const size_t slots = (size_t)2 * L.offT * 32;       // two class regions
   size_t w = 0;
   auto take = [&](size_t bytes) { const size_t o = w; w += (bytes + 255) & ~(size_t)255; return o; };
   L.norm1 = take((size_t)n1 * 4);
-  L.norm2 = take((size_t)L.slots * 4);
-  L.cst = take((size_t)L.slots * 4);
-  L.tiles = take((size_t)L.slots * 128);
-  L.partial = take((size_t)n1 * S * 16);
-  const size_t e2 = sweep2_entries(n1, n2);
-  L.partial2 = take(e2 * 8);
+  L.norm2 = take(slots * 4);
+  L.hrow = take(slots * 4);
+  L.perm = take(slots * 4);
+  L.pos2p = take(slots * 16);
+  L.tiles = take(slots * 128);
+  L.status = take((size_t)((n2 + PB - 1) / PB) * 8);
+  L.geo = take(sizeof(TileGeo));
+  L.partial = take((size_t)n1 * S * 2 * KTOP * 8);
+  const size_t e2 = sweep2_entries(n1, ntiles);
+  L.partial2 = take(e2 * 2 * 2 * 8);
   L.dmin = take((size_t)n1 * 4);
   L.undecided = take((size_t)n1 * 4);
+  L.x0y0 = take((size_t)n1 * 16);
   L.evCnt = take(e2 * 2 * 4);
   L.ev = take(e2 * 2 * EVCAP * 4);
-  L.evRes = take((size_t)n1 * 16);
   L.counter = take(64);
   L.bytes = w;
   return L;
@@ -662,20 +890,26 @@ size_t match_workspace_bytes(int n1, int n2) { return std::max(match_layout(n1, 
 struct MatchProblem {
   const uint8_t *d1, *d2;
   const double *pos2;
-  int *norm1, *norm2, *cst, *dmin, *undecided, *counter, *evCnt, *ev;
+  int *norm1, *norm2, *hrow, *perm, *dmin, *undecided, *counter, *evCnt, *ev;
+  double2 *pos2p;
+  double *x0y0;
+  u64 *status;
+  TileGeo *geo;
   unsigned char *tiles;
-  int4 *partial, *evRes;
-  int2 *partial2;
+  int2 *partial, *partial2;
   MatchRow *rows;
   MatchGeom g;
-  int slots;
 };
-struct MatchBatch { MatchProblem p[MATCH_MAXB]; };
+struct MatchBatch { MatchProblem p[MATCH_MAXB]; unsigned epoch; };
 
 __global__ __launch_bounds__(256) void k_match_pack(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *P.counter = 0;   // the undecided count (decide adds to it): no fill launch of its own
-  pack_body(P.d1, P.g.n1, P.norm1, P.d2, P.g.n2, P.slots, P.tiles, P.cst, P.norm2);
+  PackArgs A;
+  A.d1 = P.d1; A.d2 = P.d2; A.pos2 = P.pos2; A.n1 = P.g.n1; A.n2 = P.g.n2; A.offT = P.g.offT; A.epoch = b.epoch;
+  A.norm1 = P.norm1; A.norm2 = P.norm2; A.hrow = P.hrow; A.perm = P.perm; A.pos2p = P.pos2p; A.tiles = P.tiles;
+  A.status = P.status; A.geo = P.geo;
+  pack_body(A);
 }
 #ifdef MATCH_TRACE
 // debugging aid (tools/trace_match.py): when and where every workgroup of the last k_match_sweep1 launch ran
@@ -697,32 +931,39 @@ __global__ __launch_bounds__(256, sweep_wps(QS)) void k_match_sweep1(MatchBatch 
   }
 #endif
   SweepArgs A;
-  A.d1 = P.d1; A.norm1 = P.norm1; A.tiles = P.tiles; A.cst = P.cst; A.g = P.g; A.partial = P.partial;
+  A.d1 = P.d1; A.norm1 = P.norm1; A.tiles = P.tiles; A.hrow = P.hrow; A.geo = P.geo; A.g = P.g; A.partial = P.partial;
   sweep_body<0, QS>(A);
 #ifdef MATCH_TRACE
   __syncthreads();
   if (threadIdx.x == 0 && wg < 16384) { g_mtrace[wg][1] = wall_clock64(); g_mtrace[wg][3] = __builtin_readcyclecounter() - g_mtrace[wg][3]; }
 #endif
 }
-__global__ __launch_bounds__(16 * DECIDE_Q) void k_match_decide(MatchBatch b, double sqminratio, double contrDistSq) {
+__global__ __launch_bounds__(16 * DECIDE_Q) void k_match_decide(MatchBatch b, double sqminratio, double contrDistSq, int nn) {
   const MatchProblem &P = b.p[blockIdx.z];
   if ((int)blockIdx.x * DECIDE_Q >= P.g.n1) return;
-  decide_body(P.d1, P.norm1, P.d2, P.norm2, P.partial, P.g, P.pos2, sqminratio, contrDistSq, P.rows, P.dmin, P.undecided,
-              P.counter);
+  DecideArgs A;
+  A.d1 = P.d1; A.norm1 = P.norm1; A.norm2 = P.norm2; A.perm = P.perm; A.tiles = P.tiles; A.geo = P.geo; A.partial = P.partial; A.g = P.g;
+  A.pos2p = P.pos2p; A.sqminratio = sqminratio; A.contrDistSq = contrDistSq; A.nn = nn; A.rows = P.rows; A.dmin = P.dmin;
+  A.undecided = P.undecided; A.nUndecided = P.counter; A.x0y0 = P.x0y0;
+  decide_body(A);
 }
 template <int QS>
 __global__ __launch_bounds__(256, sweep_wps(QS)) void k_match_sweep2(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
   SweepArgs A;
-  A.d1 = P.d1; A.norm1 = P.norm1; A.tiles = P.tiles; A.cst = P.cst; A.g = P.g;
+  A.d1 = P.d1; A.norm1 = P.norm1; A.tiles = P.tiles; A.hrow = P.hrow; A.geo = P.geo; A.g = P.g;
   A.dmin = P.dmin; A.undecided = P.undecided; A.nUndecided = P.counter; A.partial2 = P.partial2; A.evCnt = P.evCnt; A.ev = P.ev;
   sweep_body<1, QS>(A);
 }
 __global__ __launch_bounds__(256) void k_match_events(MatchBatch b, double contrDistSq, int nn) {
   const MatchProblem &P = b.p[blockIdx.z];
   if ((int)blockIdx.x * 4 >= P.g.n1) return;
-  events_body(P.d1, P.norm1, P.d2, P.norm2, P.g, P.pos2, contrDistSq, P.rows, P.dmin, P.undecided, P.counter, P.evCnt, P.ev,
-              nn, P.partial2);
+  EventsArgs A;
+  A.d1 = P.d1; A.norm1 = P.norm1; A.norm2 = P.norm2; A.perm = P.perm; A.tiles = P.tiles; A.geo = P.geo; A.g = P.g; A.pos2p = P.pos2p;
+  A.x0y0 = P.x0y0;
+  A.contrDistSq = contrDistSq; A.rows = P.rows; A.dmin = P.dmin; A.undecided = P.undecided; A.nUndecided = P.counter;
+  A.evCnt = P.evCnt; A.ev = P.ev; A.nn = nn; A.partial2 = P.partial2;
+  events_body(A);
 }
 // Problems with n1 == 0 or n2 == 0 must be left out by the caller.  workspace[i] holds match_workspace_bytes(n1[i], n2[i]).
 void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
@@ -731,31 +972,37 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
   if (nb <= 0) return;
   MatchBatch b;
   memset(&b, 0, sizeof b);
-  int maxN1 = 0, maxS = 0, maxSlots = 0;
+  // the epoch stamps the status words of k_match_pack's scan (nothing has to be cleared between launches)
+  static std::atomic<unsigned> epochCtr{0};
+  unsigned ep = ++epochCtr;
+  if (ep == 0) ep = ++epochCtr;
+  b.epoch = ep;
+  int maxN1 = 0, maxS = 0, maxWg = 0;
   const int qs = match_qsets(nb, n1[0], n2[0]);
   for (int i = 0; i < nb; i++) {
     MatchProblem &P = b.p[i];
     const MatchLayout L = match_layout(n1[i], n2[i], qs);
-    P.g.n1 = n1[i]; P.g.n2 = n2[i]; P.g.S = L.S; P.g.tilesPerSplit = L.tilesPerSplit; P.g.qs = qs;
-    P.slots = L.slots;
+    P.g.n1 = n1[i]; P.g.n2 = n2[i]; P.g.S = L.S; P.g.tilesPerSplit = L.tilesPerSplit; P.g.qs = qs; P.g.ntilesUB = L.ntilesUB;
+    P.g.offT = L.offT;
     char *w = (char *)workspace[i];
-    P.norm1 = (int *)(w + L.norm1); P.norm2 = (int *)(w + L.norm2); P.cst = (int *)(w + L.cst);
+    P.norm1 = (int *)(w + L.norm1); P.norm2 = (int *)(w + L.norm2); P.hrow = (int *)(w + L.hrow); P.perm = (int *)(w + L.perm);
+    P.pos2p = (double2 *)(w + L.pos2p); P.status = (u64 *)(w + L.status); P.geo = (TileGeo *)(w + L.geo);
     P.tiles = (unsigned char *)(w + L.tiles);
-    P.partial = (int4 *)(w + L.partial); P.partial2 = (int2 *)(w + L.partial2);
-    P.dmin = (int *)(w + L.dmin); P.undecided = (int *)(w + L.undecided);
-    P.evCnt = (int *)(w + L.evCnt); P.ev = (int *)(w + L.ev); P.evRes = (int4 *)(w + L.evRes);
+    P.partial = (int2 *)(w + L.partial); P.partial2 = (int2 *)(w + L.partial2);
+    P.dmin = (int *)(w + L.dmin); P.undecided = (int *)(w + L.undecided); P.x0y0 = (double *)(w + L.x0y0);
+    P.evCnt = (int *)(w + L.evCnt); P.ev = (int *)(w + L.ev);
     P.counter = (int *)(w + L.counter);
     P.d1 = d1[i]; P.d2 = d2[i]; P.pos2 = pos2[i]; P.rows = rows[i];
-    maxN1 = std::max(maxN1, n1[i]); maxS = std::max(maxS, L.S); maxSlots = std::max(maxSlots, L.slots);
+    maxN1 = std::max(maxN1, n1[i]); maxS = std::max(maxS, L.S); maxWg = std::max(maxWg, (n2[i] + PB - 1) / PB);
   }
-  hipLaunchKernelGGL(k_match_pack, dim3((std::max(maxN1, maxSlots) + 255) / 256, 2, nb), dim3(256), 0, s, b);
+  hipLaunchKernelGGL(k_match_pack, dim3(std::max((maxN1 + 31) / 32, maxWg), 2, nb), dim3(256), 0, s, b);
   const int QPB = qpb_of(qs), NW2 = 256 * sweep_wps(qs);
   const dim3 grid((maxN1 + QPB - 1) / QPB, maxS, nb);
   if (evSweep1) hipEventRecord(evSweep1[0], s);
   if (qs == 4) hipLaunchKernelGGL(k_match_sweep1<4>, grid, dim3(256), 0, s, b);
   else hipLaunchKernelGGL(k_match_sweep1<2>, grid, dim3(256), 0, s, b);
   if (evSweep1) hipEventRecord(evSweep1[1], s);
-  hipLaunchKernelGGL(k_match_decide, dim3((maxN1 + DECIDE_Q - 1) / DECIDE_Q, 1, nb), dim3(16 * DECIDE_Q), 0, s, b, sqminratio, contrDistSq);
+  hipLaunchKernelGGL(k_match_decide, dim3((maxN1 + DECIDE_Q - 1) / DECIDE_Q, 1, nb), dim3(16 * DECIDE_Q), 0, s, b, sqminratio, contrDistSq, nn);
   // sweep 2: one round of workgroups dealt out on the device as (undecided block, split); more only if there could be more
   // undecided query blocks than that
   const dim3 grid2(std::max(NW2, (maxN1 + QPB - 1) / QPB), 1, nb);
