@@ -130,9 +130,12 @@ struct ViewJob {
 
 // matching
 struct MatchRow {     // per-query result of the device matcher
-  int t0, t1, tj, nless, nbad;
-  float d0, d1, dj;
+  int t0, t1, nless, nbad;
+  int tj;             // (tj, dj) is one 8-byte word (dj the high half): k_match_resolve takes the minimum of (distance, train)
+  float dj;           // over the splits with a 64-bit atomic -- positive floats order like their bits
+  float d0, d1;
 };
+static_assert(sizeof(MatchRow) == 32, "match rows are 32 bytes");
 
 // ---- host side ---------------------------------------------------------------------------
 struct DevBuf {

@@ -52,7 +52,10 @@ constexpr int NONE_KEY = NONE_H << 9;      // 0x7ffffe00: empty slot of a runnin
 constexpr int TPS = 4;                     // train tiles staged per barrier
 constexpr int CHUNK = 240;                 // tiles per index chunk (absolute tile numbers): the low byte of a key is tile % CHUNK + 1
 constexpr int MINT = 12;                   // fewest tiles a split is made of
-constexpr int KTOP = 4;                    // group keys a stream keeps (>= 4: NN0 and NN1 are then always certain in k_match_decide)
+#ifndef MODSX_KTOP
+#define MODSX_KTOP 4
+#endif
+constexpr int KTOP = MODSX_KTOP;           // group keys a stream keeps (>= 4: NN0 and NN1 are then always certain in k_match_decide)
 constexpr int PB = 256;                    // trains per workgroup of k_match_pack
 // 32-query sets per wave (QS, even): 2 for most problems -- 3 wavefronts per SIMD --, 4 when both sides hold >= 40 k descriptors:
 // every LDS fragment read then feeds four MFMA chains (half the LDS bytes per matrix instruction) at 2 wavefronts per SIMD
@@ -547,6 +550,8 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &A) {
 #define MODSX_DECIDE_Q 16
 #endif
 constexpr int DECIDE_Q = MODSX_DECIDE_Q;   // queries per workgroup of k_match_decide (16 lanes each)
+struct UndRec { int q, na, t0, dm; double x0, y0; };
+static_assert(sizeof(UndRec) == 32, "undecided record");
 struct DecideArgs {
   const uint8_t *d1;
   const int *norm1, *norm2, *perm;
@@ -560,10 +565,12 @@ struct DecideArgs {
   MatchRow *rows;
   int *dmin, *undecided, *nUndecided;
   double *x0y0;           // NN0's position of the queries that go on to sweep 2
+  UndRec *und;            // everything k_match_resolve needs of an undecided query, in one record
 };
 __device__ __forceinline__ void decide_body(const DecideArgs &A) {
   // undecided queries are compacted with ONE global atomic per workgroup (a counter word takes ~90 atomics per us)
   __shared__ int sList[DECIDE_Q], sCount, sBase;
+  __shared__ UndRec sRec[DECIDE_Q];
   if (threadIdx.x == 0) sCount = 0;
   __syncthreads();
   const MatchGeom g = A.g;
@@ -691,8 +698,12 @@ __device__ __forceinline__ void decide_body(const DecideArgs &A) {
     else if (t0 >= 0) {
       dm = ratio_dmin(d0, A.sqminratio);
       if (dm <= MAXD) {          // otherwise no distance can pass the ratio test: the walk ends without a match
-        sList[atomicAdd(&sCount, 1)] = q;
-        o.nless = -1;   // filled by sweep 2
+        const int k = atomicAdd(&sCount, 1);
+        sList[k] = q;
+        UndRec r; r.q = q; r.na = na; r.t0 = t0; r.dm = dm; r.x0 = x0; r.y0 = y0;
+        sRec[k] = r;
+        // k_match_resolve adds to nless / nbad and takes the minimum of (dj, tj) over its splits
+        o.nless = 0; o.nbad = 0; o.tj = -1; o.dj = __int_as_float(0x7fffffff);
         A.x0y0[2 * q] = x0; A.x0y0[2 * q + 1] = y0;
       }
     }
@@ -702,7 +713,7 @@ __device__ __forceinline__ void decide_body(const DecideArgs &A) {
   __syncthreads();
   if (threadIdx.x == 0 && sCount) sBase = atomicAdd(A.nUndecided, sCount);
   __syncthreads();
-  if ((int)threadIdx.x < sCount) A.undecided[sBase + threadIdx.x] = sList[threadIdx.x];
+  if ((int)threadIdx.x < sCount) { A.undecided[sBase + threadIdx.x] = sList[threadIdx.x]; A.und[sBase + threadIdx.x] = sRec[threadIdx.x]; }
 }
 
 // ---------------- events: the groups of sweep 2 that hold a train below Dmin, recomputed exactly ---------------------------
@@ -835,10 +846,217 @@ __device__ __forceinline__ void events_body(const EventsArgs &A) {
   }
 }
 
+// ---------------- resolve: sweep 2 and the event groups in ONE launch -------------------------------------------------------
+// For the queries k_match_decide could not finish (about 1 % on multi-view descriptors).  A workgroup takes (block of
+// undecided queries, split of the virtual tiles), geometry from the device-side count as above, and
+//  1. sweeps its tiles with keys that carry the row, (2 t + p) << 8 | (tile % 12 + 1) << 4 | register (32 VALU per chain --
+//     this kernel is about a hundredth of sweep 1's work): a group whose minimum is below Dmin is logged in LDS, the
+//     others feed the lane's running minimum, which is NNj's exact (distance, slot) candidate of the stream;
+//  2. recomputes its logged groups exactly, one per quarter wave, for nless / nbad / the candidates >= Dmin inside them (a
+//     stream that ran out of slots is rescanned tile by tile); a query with nn or more groups here is not recomputed -- that
+//     many groups mean nless > nn - 2 whatever they hold (matching.cpp:435-457) -- and gets nn added to its nless;
+//  3. adds its counts to the query's row and takes the minimum of (dj, tj) with one 64-bit atomic: equal distances are in
+//     one parity class, where train order is slot order, so the minimum over (distance, train) is the one over
+//     (distance, slot).  No merge pass: the rows are complete when the launch ends.
+struct ResolveArgs {
+  const uint8_t *d1;
+  const int *norm2, *perm, *hrow;
+  const unsigned char *tiles;
+  const TileGeo *geo;
+  MatchGeom g;
+  const double2 *pos2p;
+  double contrDistSq;
+  int nn;
+  const UndRec *und;
+  const int *nUndecided;
+  MatchRow *rows;
+};
+#ifndef RKO
+#define RKO 0   // timing-only knock-outs of k_match_resolve: 1 = no recomputation of logged groups, 2 = no sweep
+#endif
+constexpr int RCHUNK = 12;                 // tiles per index chunk of the resolve sweep (4 bits of tile code beside 4 of register)
+
+template <int QSETS>
+__device__ __forceinline__ void resolve_body(const ResolveArgs &A) {
+  constexpr int QPB = qpb_of(QSETS);
+  constexpr int EVS = 8192 / (2 * QPB);                // slots per stream: 16 (QSETS 2) / 8 (QSETS 4), 32 KB of LDS either way
+  __shared__ __attribute__((aligned(16))) unsigned char sm[2][STAGE_B];
+  __shared__ int sEvt[2 * QPB][EVS];                   // logged groups (virtual tiles) per stream = (query in block) * 2 + half
+  __shared__ UndRec sU[QPB];
+  __shared__ int sEv[QPB], sNless[QPB], sNbad[QPB];
+  __shared__ u64 sCand[QPB];                           // (distance, train)
+  __shared__ int sNrec, sNover;
+  __shared__ unsigned short sOver[2 * QPB];
+  const MatchGeom g = A.g;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int col = lane & 31, hi = lane >> 5;
+  const int nQ = *A.nUndecided;
+  const Sweep2Geom G2 = sweep2_geom(nQ, g.ntilesUB, QSETS);
+  const int S = G2.S, tilesPerSplit = G2.tilesPerSplit;
+  const int qb = (int)blockIdx.x / S, sp = (int)blockIdx.x - qb * S;
+  if (qb * QPB >= nQ) return;
+  constexpr u64 INF = ~0ull;
+  for (int i = tid; i < QPB; i += 256) {
+    const int u = qb * QPB + i;
+    UndRec r; r.q = -1; r.na = 0; r.t0 = -1; r.dm = 0; r.x0 = 0; r.y0 = 0;
+    if (u < nQ) r = A.und[u];
+    sU[i] = r;
+    sEv[i] = 0; sNless[i] = 0; sNbad[i] = 0; sCand[i] = INF;
+  }
+  if (tid == 0) { sNrec = 0; sNover = 0; }
+  __syncthreads();
+  const int ul0 = wave * (32 * QSETS);
+  v4i bq[QSETS][4];
+  int m1[QSETS], I1[QSETS], thr[QSETS], nev[QSETS];
+#pragma unroll
+  for (int s = 0; s < QSETS; s++) {
+    const int ul = ul0 + 32 * s + col;
+    const int q = max(sU[ul].q, 0);
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) bq[s][kb] = load_q(A.d1, q, kb, hi);
+    m1[s] = NONE_KEY; I1[s] = -1; nev[s] = 0;
+    thr[s] = sU[ul].q < 0 ? (int)0x80000000 : (sU[ul].dm - sU[ul].na) << 8;   // d < Dmin  <=>  key < (Dmin - |a'|^2) << 8; nothing for a dead lane
+  }
+  const int TEp = A.geo->TEp, offT = g.offT, ntilesV = A.geo->ntilesV;
+  const int tBeg = sp * tilesPerSplit, tEnd = min(tBeg + tilesPerSplit, ntilesV);
+  auto flush = [&](int chunkTile0) {
+#pragma unroll
+    for (int s = 0; s < QSETS; s++) {
+      const int lb = m1[s] & 255;
+      if (lb) I1[s] = (chunkTile0 + (lb >> 4) - 1) * 32 + row_of(lb & 15, hi);
+      m1[s] &= ~255;
+    }
+  };
+  auto epilogue = [&](const v16i &acc, int kvb, int s, int tile) {
+    v16i k;
+#pragma unroll
+    for (int r = 0; r < 16; r++) k[r] = (acc[r] << 9) + (kvb + r);
+    const int t = tree_min16(k);
+    if (t < thr[s]) {
+      if (nev[s] < EVS) sEvt[(ul0 + 32 * s + col) * 2 + hi][nev[s]] = tile;
+      nev[s]++;
+    } else m1[s] = min(m1[s], t);
+  };
+  auto load_af = [&](const unsigned char *buf, int q, v4i *af) {
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) af[kb] = read_a(buf + q * TILE_B, col, kb, hi);
+  };
+  auto load_c = [&](const unsigned char *buf, int q, v16i &C) {
+#pragma unroll
+    for (int gq = 0; gq < 4; gq++) {
+      const v4i c4 = *reinterpret_cast<const v4i *>(buf + HOFF + q * 128 + (8 * gq + 4 * hi) * 4);
+      C[4 * gq] = c4[0]; C[4 * gq + 1] = c4[1]; C[4 * gq + 2] = c4[2]; C[4 * gq + 3] = c4[3];
+    }
+  };
+  auto tile_kvb = [&](int v) { return ((v >= TEp ? 1 : 0) << 8) | ((v % RCHUNK + 1) << 4); };
+  if (tBeg < tEnd) stage_group(A.tiles, A.hrow, phys_tile(tBeg, TEp, offT), sm[0], wave, lane);
+  int it = 0;
+  for (int tg = tBeg; tg < ((RKO & 2) ? tBeg : tEnd); tg += TPS, it++) {
+    const unsigned char *buf = sm[it & 1];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tg + TPS < tEnd) stage_group(A.tiles, A.hrow, phys_tile(tg + TPS, TEp, offT), sm[(it & 1) ^ 1], wave, lane);
+#pragma unroll
+    for (int q = 0; q < TPS; q++) {
+      v4i af[4];
+      v16i C;
+      load_af(buf, q, af);
+      load_c(buf, q, C);
+      const int kvb = tile_kvb(tg + q);
+#pragma unroll
+      for (int s = 0; s < QSETS; s++) {
+        v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bq[s][0], C, 0, 0, 0);
+#pragma unroll
+        for (int kb = 1; kb < 4; kb++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[kb], bq[s][kb], acc, 0, 0, 0);
+        epilogue(acc, kvb, s, tg + q);
+      }
+    }
+    if ((tg + TPS) % RCHUNK == 0) flush(tg + TPS - RCHUNK);
+  }
+  if (tEnd > tBeg && tEnd % RCHUNK) flush((tEnd / RCHUNK) * RCHUNK);
+  __syncthreads();                       // the staging buffers are free from here on: they hold the work list
+  // ---- 2. the logged groups: counts per query, a flat work list, streams that ran out of slots
+  int *sList = reinterpret_cast<int *>(&sm[0][0]);     // (query in block) << 23 | half << 22 | tile
+  static_assert(2 * STAGE_B / 4 >= 2 * QPB * EVS, "work list");
+#pragma unroll
+  for (int s = 0; s < QSETS; s++) {
+    const int ul = ul0 + 32 * s + col;
+    if (nev[s]) atomicAdd(&sEv[ul], nev[s]);
+    if (m1[s] < NONE_KEY && sU[ul].q >= 0) {
+      const int slot = I1[s];
+      const int t = A.perm[phys_tile(slot >> 5, TEp, offT) * 32 + (slot & 31)];
+      atomicMin(&sCand[ul], key64((m1[s] >> 8) + sU[ul].na, t));
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < QSETS; s++) {
+    const int ul = ul0 + 32 * s + col;
+    if (nev[s] == 0 || sEv[ul] >= A.nn) continue;      // nn or more groups in this split alone: the walk gives up
+    if (nev[s] > EVS) { sOver[atomicAdd(&sNover, 1)] = (unsigned short)(ul * 2 + hi); continue; }
+    const int base = atomicAdd(&sNrec, nev[s]);
+    for (int e = 0; e < nev[s]; e++) sList[base + e] = (ul << 23) | (hi << 22) | sEvt[ul * 2 + hi][e];
+  }
+  __syncthreads();
+  {
+    const int l = lane & 15, qw = tid >> 4;            // 16 quarter waves
+    auto visit = [&](int ul, int vtile, int h, bool active) {
+      const UndRec r = sU[active ? ul : 0];
+      int vslot, pslot, t;
+      const int d = group_dist16(A.d1 + (size_t)max(r.q, 0) * 128, r.na, A.tiles, A.norm2, A.perm, phys_tile(active ? vtile : 0, TEp, offT),
+                                 vtile, h, l, &vslot, &pslot, &t);
+      int nl = 0, nb = 0, cd = BIG, ct = BIG;
+      if (active && d != BIG && t != r.t0) {
+        if (d < r.dm) {
+          nl = 1;
+          // geometric consistency with NN0 (distanceSq, matching.cpp:174-179), f64
+          const double2 xy = A.pos2p[pslot];
+          const double dx = r.x0 - xy.x, dy = r.y0 - xy.y;
+          if (dx * dx + dy * dy > A.contrDistSq) nb = 1;
+        } else { cd = d; ct = t; }
+      }
+      // totals of the group over its 16 lanes; lane 0 adds them to the query's cells
+      nl += __builtin_amdgcn_update_dpp(0, nl, 0x128, 0xf, 0xf, false); nb += __builtin_amdgcn_update_dpp(0, nb, 0x128, 0xf, 0xf, false);
+      nl += __builtin_amdgcn_update_dpp(0, nl, 0x124, 0xf, 0xf, false); nb += __builtin_amdgcn_update_dpp(0, nb, 0x124, 0xf, 0xf, false);
+      nl += __builtin_amdgcn_update_dpp(0, nl, 0x122, 0xf, 0xf, false); nb += __builtin_amdgcn_update_dpp(0, nb, 0x122, 0xf, 0xf, false);
+      nl += __builtin_amdgcn_update_dpp(0, nl, 0x121, 0xf, 0xf, false); nb += __builtin_amdgcn_update_dpp(0, nb, 0x121, 0xf, 0xf, false);
+      const int md = rowmin16(cd), mt = rowmin16(cd == md ? ct : BIG);
+      if (active && l == 0) {
+        if (nl) atomicAdd(&sNless[ul], nl);
+        if (nb) atomicAdd(&sNbad[ul], nb);
+        if (md != BIG) atomicMin(&sCand[ul], key64(md, mt));
+      }
+    };
+    const int nrec = (RKO & 1) ? 0 : sNrec;
+    for (int b = 0; b < nrec; b += 16) {               // workgroup-uniform trip count
+      const int e = b + qw;
+      const int rec = e < nrec ? sList[e] : 0;
+      visit((unsigned)rec >> 23, rec & 0x3fffff, (rec >> 22) & 1, e < nrec);
+    }
+    const int nover = sNover;
+    for (int o = 0; o < nover; o++) {                  // a stream with more than EVS groups: every group of its tiles
+      const int st = sOver[o];
+      for (int tile = tBeg; tile < tEnd; tile += 16) visit(st >> 1, tile + qw, st & 1, tile + qw < tEnd);
+    }
+  }
+  __syncthreads();
+  // ---- 3. this split's share of the rows
+  for (int i = tid; i < QPB; i += 256) {
+    const int q = sU[i].q;
+    if (q < 0) continue;
+    MatchRow *row = A.rows + q;
+    const int nl = sEv[i] >= A.nn ? A.nn : sNless[i];
+    if (nl) atomicAdd(&row->nless, nl);
+    if (sNbad[i]) atomicAdd(&row->nbad, sNbad[i]);
+    const u64 c = sCand[i];                            // distance (an integer below 2^24) -> the bits of the float the row holds
+    if (c != INF) atomicMin(reinterpret_cast<u64 *>(&row->tj), ((u64)(unsigned)__float_as_int((float)(int)(c >> 32)) << 32) | (unsigned)c);
+  }
+}
+
 // ---- workspace layout: ONE description used by the size query and by the launcher -------------------------------------------
 struct MatchLayout {
   int S, tilesPerSplit, ntilesUB, offT;
-  size_t norm1, norm2, hrow, perm, pos2p, tiles, status, geo, partial, partial2, dmin, undecided, x0y0, evCnt, ev, counter, bytes;
+  size_t norm1, norm2, hrow, perm, pos2p, tiles, status, geo, partial, partial2, dmin, undecided, x0y0, evCnt, ev, und, counter, bytes;
 };
 static MatchLayout match_layout(int n1, int n2, int qs) {
   MatchLayout L;
@@ -879,6 +1097,7 @@ static MatchLayout match_layout(int n1, int n2, int qs) {
   L.x0y0 = take((size_t)n1 * 16);
   L.evCnt = take(e2 * 2 * 4);
   L.ev = take(e2 * 2 * EVCAP * 4);
+  L.und = take((size_t)n1 * 32);
   L.counter = take(64);
   L.bytes = w;
   return L;
@@ -897,6 +1116,7 @@ struct MatchProblem {
   TileGeo *geo;
   unsigned char *tiles;
   int2 *partial, *partial2;
+  UndRec *und;
   MatchRow *rows;
   MatchGeom g;
 };
@@ -944,7 +1164,7 @@ __global__ __launch_bounds__(16 * DECIDE_Q) void k_match_decide(MatchBatch b, do
   DecideArgs A;
   A.d1 = P.d1; A.norm1 = P.norm1; A.norm2 = P.norm2; A.perm = P.perm; A.tiles = P.tiles; A.geo = P.geo; A.partial = P.partial; A.g = P.g;
   A.pos2p = P.pos2p; A.sqminratio = sqminratio; A.contrDistSq = contrDistSq; A.nn = nn; A.rows = P.rows; A.dmin = P.dmin;
-  A.undecided = P.undecided; A.nUndecided = P.counter; A.x0y0 = P.x0y0;
+  A.undecided = P.undecided; A.nUndecided = P.counter; A.x0y0 = P.x0y0; A.und = P.und;
   decide_body(A);
 }
 template <int QS>
@@ -954,6 +1174,14 @@ __global__ __launch_bounds__(256, sweep_wps(QS)) void k_match_sweep2(MatchBatch 
   A.d1 = P.d1; A.norm1 = P.norm1; A.tiles = P.tiles; A.hrow = P.hrow; A.geo = P.geo; A.g = P.g;
   A.dmin = P.dmin; A.undecided = P.undecided; A.nUndecided = P.counter; A.partial2 = P.partial2; A.evCnt = P.evCnt; A.ev = P.ev;
   sweep_body<1, QS>(A);
+}
+template <int QS>
+__global__ __launch_bounds__(256) void k_match_resolve(MatchBatch b, double contrDistSq, int nn) {
+  const MatchProblem &P = b.p[blockIdx.z];
+  ResolveArgs A;
+  A.d1 = P.d1; A.norm2 = P.norm2; A.perm = P.perm; A.hrow = P.hrow; A.tiles = P.tiles; A.geo = P.geo; A.g = P.g;
+  A.pos2p = P.pos2p; A.contrDistSq = contrDistSq; A.nn = nn; A.und = P.und; A.nUndecided = P.counter; A.rows = P.rows;
+  resolve_body<QS>(A);
 }
 __global__ __launch_bounds__(256) void k_match_events(MatchBatch b, double contrDistSq, int nn) {
   const MatchProblem &P = b.p[blockIdx.z];
@@ -991,7 +1219,7 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
     P.partial = (int2 *)(w + L.partial); P.partial2 = (int2 *)(w + L.partial2);
     P.dmin = (int *)(w + L.dmin); P.undecided = (int *)(w + L.undecided); P.x0y0 = (double *)(w + L.x0y0);
     P.evCnt = (int *)(w + L.evCnt); P.ev = (int *)(w + L.ev);
-    P.counter = (int *)(w + L.counter);
+    P.counter = (int *)(w + L.counter); P.und = (UndRec *)(w + L.und);
     P.d1 = d1[i]; P.d2 = d2[i]; P.pos2 = pos2[i]; P.rows = rows[i];
     maxN1 = std::max(maxN1, n1[i]); maxS = std::max(maxS, L.S); maxWg = std::max(maxWg, (n2[i] + PB - 1) / PB);
   }
@@ -1006,9 +1234,13 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
   // sweep 2: one round of workgroups dealt out on the device as (undecided block, split); more only if there could be more
   // undecided query blocks than that
   const dim3 grid2(std::max(NW2, (maxN1 + QPB - 1) / QPB), 1, nb);
-  if (qs == 4) hipLaunchKernelGGL(k_match_sweep2<4>, grid2, dim3(256), 0, s, b);
-  else hipLaunchKernelGGL(k_match_sweep2<2>, grid2, dim3(256), 0, s, b);
-  hipLaunchKernelGGL(k_match_events, dim3((maxN1 + 3) / 4, 1, nb), dim3(256), 0, s, b, contrDistSq, nn);
+  static const bool old2 = getenv("MODSX_MATCH_OLD2") && atoi(getenv("MODSX_MATCH_OLD2"));   // the two-launch form (sweep 2, events), for comparison
+  if (old2) {
+    if (qs == 4) hipLaunchKernelGGL(k_match_sweep2<4>, grid2, dim3(256), 0, s, b);
+    else hipLaunchKernelGGL(k_match_sweep2<2>, grid2, dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_match_events, dim3((maxN1 + 3) / 4, 1, nb), dim3(256), 0, s, b, contrDistSq, nn);
+  } else if (qs == 4) hipLaunchKernelGGL(k_match_resolve<4>, grid2, dim3(256), 0, s, b, contrDistSq, nn);
+  else hipLaunchKernelGGL(k_match_resolve<2>, grid2, dim3(256), 0, s, b, contrDistSq, nn);
 }
 
 void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, int n2, const double *pos2,
