@@ -132,13 +132,6 @@ MX_HD Sweep2Geom sweep2_geom(int nUnd, int ntiles, int qs) {
   G.tilesPerSplit = tps;
   return G;
 }
-// entries of the per-(undecided query, split) arrays of sweep 2, whatever the count turns out to be
-static size_t sweep2_entries(int n1, int ntiles) {
-  const size_t smax = (size_t)std::max(1, ntiles / MINT);
-  const size_t a = std::max<size_t>((size_t)n1, (size_t)NW_MAX * QPB_MAX);   // nQB * S <= NW while S > 1; S = 1 beyond
-  return std::min(a, (size_t)n1 * smax) + QPB_MAX;
-}
-
 // register r of the 32x32 accumulator of lane half `hi` holds MFMA row 8 (r >> 2) + 4 hi + (r & 3)
 MX_D int row_of(int r, int hi) { return 8 * (r >> 2) + 4 * hi + (r & 3); }
 
@@ -355,111 +348,47 @@ MX_D int tree_min16(const v16i &k) {
   return min(imin3(t0, t1, t2), imin3(t3, t4, k[15]));
 }
 
-// ---------------- the sweep: MODE 0 = per (query, split, half) the KTOP smallest group keys, MODE 1 = 2 smallest + event groups
-// One instruction stream per wave keeps both pipes busy: while the four MFMAs of a (tile, query set) chain run, the wave
-// reduces the accumulators of the previous chain (13 VALU), so the matrix pipe never waits for a whole wave to leave its
-// epilogue.  Fragments and row constants of the next tile are read from LDS one tile ahead (two register sets).
-constexpr int EVCAP = 16;                  // event slots per (undecided query, split, lane half); more -> exact fallback
-struct SweepArgs {
-  const uint8_t *d1;
-  const int *norm1;
-  const unsigned char *tiles;
-  const int *hrow;
-  const TileGeo *geo;
-  MatchGeom g;
-  int2 *partial;          // MODE 0: [(q * S + split) * 2 + half][KTOP] (distance, tile), ascending; empty = (BIG, -1)
-  const int *dmin, *undecided, *nUndecided;   // MODE 1
-  int2 *partial2;         // MODE 1: [(u * S2 + split) * 2 + half][2]
-  int *evCnt, *ev;
-};
+// LDS reads of the sweep core as assembly (the waits are counted by hand there): the four fragment slices of tile Q of a stage,
+// and its 16 row constants
+template <int Q>
+MX_D void lds_load_af(unsigned base, const unsigned (&aAddr)[4], v4i *af) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[0]) : "v"(base + aAddr[0]), "n"(Q * TILE_B));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[1]) : "v"(base + aAddr[1]), "n"(Q * TILE_B));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[2]) : "v"(base + aAddr[2]), "n"(Q * TILE_B));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[3]) : "v"(base + aAddr[3]), "n"(Q * TILE_B));
+}
+template <int Q>
+MX_D void lds_load_c(unsigned addr, v16i &C) {
+  v4i c0, c1, c2, c3;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c0) : "v"(addr), "n"(Q * 128));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c1) : "v"(addr), "n"(Q * 128 + 32));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c2) : "v"(addr), "n"(Q * 128 + 64));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c3) : "v"(addr), "n"(Q * 128 + 96));
+  C = __builtin_shufflevector(__builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(c2, c3, 0, 1, 2, 3, 4, 5, 6, 7),
+                              0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+}
 
-template <int MODE, int QSETS>
-__device__ __forceinline__ void sweep_body(const SweepArgs &A) {
-  constexpr int QPB = qpb_of(QSETS);
-  constexpr int KS = MODE == 0 ? KTOP : 2;     // keys of the running state
-  __shared__ __attribute__((aligned(16))) unsigned char sm[2][STAGE_B];
-  const MatchGeom g = A.g;
+// ---------------- the sweep core: tiles through LDS, MFMA chains, an epilogue per chain ---------------------------------------
+// One instruction stream per wave keeps both pipes busy: while the four MFMAs of a (tile, query set) chain run, the wave
+// reduces the accumulators of the previous chain, so the matrix pipe never waits for a whole wave to leave its epilogue.
+// Fragments and row constants of the next tile are read from LDS one tile ahead (two register sets).  The epilogue is a policy:
+//   int  kv(v)                          the wave-uniform constant of virtual tile v
+//   void chain(acc, kv, s, tile)        reduce one accumulator (query set s, virtual tile `tile`)
+//   void flush(chunkTile0)              end of an index chunk (CH tiles, absolute tile numbers)
+template <int QSETS, int EPI_VALU, class Epi>
+__device__ __forceinline__ void sweep_core(const unsigned char *tiles, const int *hrow, int TEp, int offT, int tBeg, int tEnd,
+                                           const v4i (&bq)[QSETS][4], unsigned char (&sm)[2][STAGE_B], Epi &epi) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 31, hi = lane >> 5;
-  const int nQ = MODE == 0 ? g.n1 : *A.nUndecided;
-  int sp, qb, S, tilesPerSplit;
-  if (MODE == 0) { sp = blockIdx.y; qb = blockIdx.x; S = g.S; tilesPerSplit = g.tilesPerSplit; }
-  else {
-    const Sweep2Geom G2 = sweep2_geom(nQ, g.ntilesUB, QSETS);
-    S = G2.S; tilesPerSplit = G2.tilesPerSplit;
-    qb = (int)blockIdx.x / S; sp = (int)blockIdx.x - qb * S;
-  }
-  if (qb * QPB >= nQ) return;
-  const int q0 = qb * QPB + wave * (32 * QSETS);
-  v4i bq[QSETS][4];
-  int m[QSETS][KS], I[QSETS][KS];
-  int thr[QSETS], nev[QSETS];                  // MODE 1: threshold key, events of this lane
-  int qsel[QSETS];
+  // The LDS reads are written as assembly with the waits counted by hand: the compiler orders every wait behind the reads
+  // of the NEXT tile it has just issued (`s_waitcnt lgkmcnt(0)` -- a pending global->LDS load makes it give up counting), which
+  // exposed one LDS latency per tile.  Reads issue and return in order, so "all but the newest 4" is exactly "everything of
+  // the current tile".  Per-lane addresses: fragment slot 2 kb + hi of row col (swizzled), row constants 16 hi.
+  unsigned aAddr[4];
 #pragma unroll
-  for (int s = 0; s < QSETS; s++) {
-    const int u = min(q0 + 32 * s + col, nQ - 1);
-    qsel[s] = MODE == 0 ? u : A.undecided[u];
-#pragma unroll
-    for (int kb = 0; kb < 4; kb++) bq[s][kb] = load_q(A.d1, qsel[s], kb, hi);
-#pragma unroll
-    for (int k = 0; k < KS; k++) { m[s][k] = NONE_KEY; I[s][k] = -1; }
-    if (MODE == 1) { thr[s] = (A.dmin[qsel[s]] - A.norm1[qsel[s]]) << 8; nev[s] = 0; }   // d < Dmin  <=>  key < (Dmin - |a'|^2) << 8
-    else { thr[s] = 0; nev[s] = 0; }
-  }
-  const int TEp = A.geo->TEp, offT = g.offT;
-  const int tBeg = sp * tilesPerSplit, tEnd = min(tBeg + tilesPerSplit, A.geo->ntilesV);   // virtual tiles: even class, then odd
-  // the constant of virtual tile v: parity << 8 | (v % CHUNK + 1), wave-uniform
-  auto tile_kv = [&](int v) { return ((v >= TEp ? 1 : 0) << 8) | (v % CHUNK + 1); };
-  // end of an index chunk: the tile numbers of keys that are new in this chunk move to the index registers, the low byte is
-  // cleared; keys with a cleared low byte are older entries and keep their order among themselves
-  auto flush = [&](int chunkTile0) {
-#pragma unroll
-    for (int s = 0; s < QSETS; s++) {
-      int o[KS];
-#pragma unroll
-      for (int k = 0; k < KS; k++) o[k] = I[s][k];
-#pragma unroll
-      for (int k = 0; k < KS; k++) {
-        const int lb = m[s][k] & 255;
-        I[s][k] = lb ? chunkTile0 + lb - 1 : o[0];
-        if (!lb) {
-#pragma unroll
-          for (int j = 0; j + 1 < KS; j++) o[j] = o[j + 1];
-        }
-        m[s][k] &= ~255;
-      }
-    }
-  };
-  // reduce one accumulator: v_min3 tree, one key, then the running state
-  auto epilogue = [&](const v16i &acc, int kv, int s, int tile) {
-    const int key = (tree_min16(acc) << 9) + kv;
-    if (MODE == 0) {
-#pragma unroll
-      for (int k = KS - 1; k >= 1; k--) m[s][k] = imed3(m[s][k - 1], m[s][k], key);
-      m[s][0] = min(m[s][0], key);
-    } else if (key < thr[s]) {
-      // a train of this group is closer than Dmin: k_match_events takes the whole group
-      const int u = q0 + 32 * s + col;
-      if (u < nQ) {
-        if (nev[s] < EVCAP) A.ev[(((size_t)u * S + sp) * 2 + hi) * EVCAP + nev[s]] = tile;
-        nev[s]++;
-      }
-    } else {
-      m[s][1] = imed3(m[s][0], m[s][1], key);
-      m[s][0] = min(m[s][0], key);
-    }
-  };
-  auto load_af = [&](const unsigned char *buf, int q, v4i *af) {
-#pragma unroll
-    for (int kb = 0; kb < 4; kb++) af[kb] = read_a(buf + q * TILE_B, col, kb, hi);
-  };
-  auto load_c = [&](const unsigned char *buf, int q, v16i &C) {
-#pragma unroll
-    for (int gq = 0; gq < 4; gq++) {
-      const v4i c4 = *reinterpret_cast<const v4i *>(buf + HOFF + q * 128 + (8 * gq + 4 * hi) * 4);
-      C[4 * gq] = c4[0]; C[4 * gq + 1] = c4[1]; C[4 * gq + 2] = c4[2]; C[4 * gq + 3] = c4[3];
-    }
-  };
+  for (int kb = 0; kb < 4; kb++) aAddr[kb] = (unsigned)(col * 128 + (((2 * kb + hi) ^ ((col >> 1) & 7)) << 4));
+  const unsigned cAddr = (unsigned)(HOFF + 16 * hi);
+  const unsigned smBase = (unsigned)(size_t)(lbptr)&sm[0][0];
   v4i af[2][4];
   v16i C[2];
   int kv[2];
@@ -468,79 +397,156 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &A) {
 #pragma unroll
   for (int r = 0; r < 16; r++) acc[1][r] = NONE_H;
   int kvPend = 0, pendTile = 0;
-  if (tBeg < tEnd) stage_group(A.tiles, A.hrow, phys_tile(tBeg, TEp, offT), sm[0], wave, lane);
+  if (tBeg < tEnd) stage_group(tiles, hrow, phys_tile(tBeg, TEp, offT), sm[0], wave, lane);
   int it = 0;
   for (int tg = tBeg; tg < tEnd; tg += TPS, it++) {
-    const unsigned char *buf = sm[it & 1];
+    const unsigned base = smBase + (it & 1) * STAGE_B;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tg + TPS < tEnd) stage_group(A.tiles, A.hrow, phys_tile(tg + TPS, TEp, offT), sm[(it & 1) ^ 1], wave, lane);
-    load_af(buf, 0, af[0]);
-    load_c(buf, 0, C[0]);
-    kv[0] = tile_kv(tg);
-#pragma unroll
-    for (int q = 0; q < TPS; q++) {
-      const int cur = q & 1;
-      // Phase s of a tile: the chain of (tile q, set s) beside the reduction of the previous chain -- (tile q, set s - 1),
-      // or the last set of the previous tile.  QSETS is even, so the chains alternate between the two accumulators.
-      // The fragment / constant reads of the NEXT tile are issued as a burst in front of phases 0 and 1 and fenced there
-      // (sched_barrier): left to the scheduler they sink to just before their first use and every MFMA waits for LDS.
+    if (tg + TPS < tEnd) stage_group(tiles, hrow, phys_tile(tg + TPS, TEp, offT), sm[(it & 1) ^ 1], wave, lane);
+    lds_load_af<0>(base, aAddr, af[0]);
+    lds_load_c<0>(base + cAddr, C[0]);
+    kv[0] = epi.kv(tg);
+    // one tile: phase s = the chain of (tile q, set s) beside the reduction of the previous chain -- (tile q, set s - 1), or the
+    // last set of the previous tile.  QSETS is even, so the chains alternate between the two accumulators.  The fragment reads
+    // of the NEXT tile are issued in front of phase 0, its row constants in front of phase 1.
+    auto tile = [&](auto qc) {
+      constexpr int q = decltype(qc)::value, cur = q & 1;
 #pragma unroll
       for (int s = 0; s < QSETS; s++) {
         if (q + 1 < TPS) {
-          if (s == 0) load_af(buf, q + 1, af[cur ^ 1]);
-          if (s == 1) { load_c(buf, q + 1, C[cur ^ 1]); kv[cur ^ 1] = tile_kv(tg + q + 1); }
+          if (s == 0) lds_load_af<(q + 1) % TPS>(base, aAddr, af[cur ^ 1]);
+          if (s == 1) { lds_load_c<(q + 1) % TPS>(base + cAddr, C[cur ^ 1]); kv[cur ^ 1] = epi.kv(tg + q + 1); }
+        }
+        if (s == 0) {
+          // everything of THIS tile has landed once at most the reads just issued (4, none in the last tile of a stage) are pending
+          if (q + 1 < TPS)
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[cur][0]), "+v"(af[cur][1]), "+v"(af[cur][2]), "+v"(af[cur][3]), "+v"(C[cur]));
+          else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[cur][0]), "+v"(af[cur][1]), "+v"(af[cur][2]), "+v"(af[cur][3]), "+v"(C[cur]));
         }
         __builtin_amdgcn_sched_barrier(0);
         v16i &an = acc[s & 1];
         an = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[cur][0], bq[s][0], C[cur], 0, 0, 0);
 #pragma unroll
         for (int kb = 1; kb < 4; kb++) an = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[cur][kb], bq[s][kb], an, 0, 0, 0);
-        if (s == 0) epilogue(acc[1], kvPend, QSETS - 1, pendTile);
-        else epilogue(acc[(s - 1) & 1], kv[cur], s - 1, tg + q);
+        if (s == 0) epi.chain(acc[1], kvPend, QSETS - 1, pendTile);
+        else epi.chain(acc[(s - 1) & 1], kv[cur], s - 1, tg + q);
         // one MFMA, then a quarter of the reduction
+        constexpr int Q1 = (EPI_VALU + 3) / 4, Q2 = (EPI_VALU + 2) / 4, Q3 = (EPI_VALU + 1) / 4, Q4 = EPI_VALU / 4;
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-#pragma unroll
-        for (int kb = 1; kb < 4; kb++) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-        }
+        __builtin_amdgcn_sched_group_barrier(0x002, Q1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, Q2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, Q3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, Q4, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       pendTile = tg + q;
       kvPend = kv[cur];
-    }
-    if ((tg + TPS) % CHUNK == 0) {
-      // end of an index chunk: drain the pending chain, then move the tile numbers of new keys out of the low byte
-      epilogue(acc[1], kvPend, QSETS - 1, pendTile);
+    };
+    tile(std::integral_constant<int, 0>{});
+    tile(std::integral_constant<int, 1>{});
+    tile(std::integral_constant<int, 2>{});
+    tile(std::integral_constant<int, 3>{});
+    static_assert(TPS == 4, "four tiles per stage");
+    if ((tg + TPS) % Epi::CH == 0) {
+      // end of an index chunk: drain the pending chain, then move the indices of new keys out of the low byte
+      epi.chain(acc[1], kvPend, QSETS - 1, pendTile);
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[1][r] = NONE_H;
       kvPend = 0;
-      flush(tg + TPS - CHUNK);
+      epi.flush(tg + TPS - Epi::CH);
     }
   }
-  if (tEnd > tBeg && tEnd % CHUNK) {
-    epilogue(acc[1], kvPend, QSETS - 1, pendTile);
-    flush((tEnd / CHUNK) * CHUNK);
+  if (tEnd > tBeg && tEnd % Epi::CH) {
+    epi.chain(acc[1], kvPend, QSETS - 1, pendTile);
+    epi.flush((tEnd / Epi::CH) * Epi::CH);
   }
+}
+
+// ---------------- sweep 1: per (query, split, lane half) the KTOP smallest group keys ------------------------------------------
+struct SweepArgs {
+  const uint8_t *d1;
+  const int *norm1;
+  const unsigned char *tiles;
+  const int *hrow;
+  const TileGeo *geo;
+  MatchGeom g;
+  int2 *partial;          // [(q * S + split) * 2 + half][KTOP] (distance, virtual tile), ascending; empty = (BIG, -1)
+};
+// 8 (v_min3 tree) + 1 (key) + KTOP (insertion) vector instructions per chain
+template <int QSETS>
+struct TopKEpi {
+  static constexpr int CH = CHUNK;
+  int m[QSETS][KTOP], I[QSETS][KTOP];
+  int TEp;
+  MX_D int kv(int v) const { return ((v >= TEp ? 1 : 0) << 8) | (v % CHUNK + 1); }   // parity << 8 | tile code
+  MX_D void chain(const v16i &acc, int kvv, int s, int) {
+    const int key = (tree_min16(acc) << 9) + kvv;
+#pragma unroll
+    for (int k = KTOP - 1; k >= 1; k--) m[s][k] = imed3(m[s][k - 1], m[s][k], key);
+    m[s][0] = min(m[s][0], key);
+  }
+  // the tile numbers of keys that are new in this chunk move to the index registers, the low byte is cleared; keys with a
+  // cleared low byte are older entries and keep their order among themselves
+  MX_D void flush(int chunkTile0) {
+#pragma unroll
+    for (int s = 0; s < QSETS; s++) {
+      int o[KTOP];
+#pragma unroll
+      for (int k = 0; k < KTOP; k++) o[k] = I[s][k];
+#pragma unroll
+      for (int k = 0; k < KTOP; k++) {
+        const int lb = m[s][k] & 255;
+        I[s][k] = lb ? chunkTile0 + lb - 1 : o[0];
+        if (!lb) {
+#pragma unroll
+          for (int j = 0; j + 1 < KTOP; j++) o[j] = o[j + 1];
+        }
+        m[s][k] &= ~255;
+      }
+    }
+  }
+};
+template <int QSETS>
+__device__ __forceinline__ void sweep_body(const SweepArgs &A) {
+  constexpr int QPB = qpb_of(QSETS);
+  __shared__ __attribute__((aligned(16))) unsigned char sm[2][STAGE_B];
+  const MatchGeom g = A.g;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int col = lane & 31, hi = lane >> 5;
+  const int sp = blockIdx.y, qb = blockIdx.x, S = g.S;
+  if (qb * QPB >= g.n1) return;
+  const int q0 = qb * QPB + wave * (32 * QSETS);
+  v4i bq[QSETS][4];
+  TopKEpi<QSETS> epi;
+  int qsel[QSETS];
+#pragma unroll
+  for (int s = 0; s < QSETS; s++) {
+    qsel[s] = min(q0 + 32 * s + col, g.n1 - 1);
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) bq[s][kb] = load_q(A.d1, qsel[s], kb, hi);
+#pragma unroll
+    for (int k = 0; k < KTOP; k++) { epi.m[s][k] = NONE_KEY; epi.I[s][k] = -1; }
+  }
+  epi.TEp = A.geo->TEp;
+  const int tBeg = sp * g.tilesPerSplit, tEnd = min(tBeg + g.tilesPerSplit, A.geo->ntilesV);   // virtual tiles: even class, then odd
+  sweep_core<QSETS, 9 + KTOP>(A.tiles, A.hrow, epi.TEp, g.offT, tBeg, tEnd, bq, sm, epi);
   // store the stream's keys as (distance, tile)
 #pragma unroll
   for (int s = 0; s < QSETS; s++) {
     const int q = q0 + 32 * s + col;
-    if (q >= nQ) continue;
+    if (q >= g.n1) continue;
     const int na = A.norm1[qsel[s]];
-    int2 e[KS];
+    int2 e[KTOP];
 #pragma unroll
-    for (int k = 0; k < KS; k++) e[k] = m[s][k] >= NONE_KEY ? make_int2(BIG, -1) : make_int2((m[s][k] >> 8) + na, I[s][k]);
-    if (MODE == 0) {
-      int4 *dst = reinterpret_cast<int4 *>(A.partial + (((size_t)q * S + sp) * 2 + hi) * KS);
+    for (int k = 0; k < KTOP; k++) e[k] = epi.m[s][k] >= NONE_KEY ? make_int2(BIG, -1) : make_int2((epi.m[s][k] >> 8) + na, epi.I[s][k]);
+    int4 *dst = reinterpret_cast<int4 *>(A.partial + (((size_t)q * S + sp) * 2 + hi) * KTOP);
 #pragma unroll
-      for (int k = 0; k < KS; k += 2) dst[k >> 1] = make_int4(e[k].x, e[k].y, e[k + 1].x, e[k + 1].y);
-    } else {
-      A.evCnt[((size_t)q * S + sp) * 2 + hi] = nev[s];
-      *reinterpret_cast<int4 *>(A.partial2 + (((size_t)q * S + sp) * 2 + hi) * 2) = make_int4(e[0].x, e[0].y, e[1].x, e[1].y);
-    }
+    for (int k = 0; k < KTOP; k += 2) dst[k >> 1] = make_int4(e[k].x, e[k].y, e[k + 1].x, e[k + 1].y);
   }
 }
 
@@ -716,136 +722,6 @@ __device__ __forceinline__ void decide_body(const DecideArgs &A) {
   if ((int)threadIdx.x < sCount) { A.undecided[sBase + threadIdx.x] = sList[threadIdx.x]; A.und[sBase + threadIdx.x] = sRec[threadIdx.x]; }
 }
 
-// ---------------- events: the groups of sweep 2 that hold a train below Dmin, recomputed exactly ---------------------------
-// One wave per undecided query; each 16-lane quarter walks the event lists of every fourth (split, lane half) stream, one
-// group (16 rows) at a time.  Output per query: nless, nbad and the lex-smallest (d, slot) with d >= Dmin among the rows of the
-// event groups and the best group the sweep did not flag.  A stream that ran out of its EVCAP slots is rescanned exactly.
-struct EventsArgs {
-  const uint8_t *d1;
-  const int *norm1, *norm2, *perm;
-  const unsigned char *tiles;
-  const TileGeo *geo;
-  MatchGeom g;
-  const double2 *pos2p;
-  double contrDistSq;
-  MatchRow *rows;
-  const int *dmin, *undecided, *nUndecided, *evCnt, *ev;
-  const double *x0y0;
-  int nn;
-  const int2 *partial2;
-};
-__device__ __forceinline__ void events_body(const EventsArgs &A) {
-  __shared__ int sRec[4][MATCH_NN_MAX];  // per wave: the event groups of its query as (tile << 1 | lane half); fewer than nn of them
-  const MatchGeom g = A.g;
-  const int w = threadIdx.x >> 6;
-  const int u = blockIdx.x * 4 + w;
-  const int nUnd = *A.nUndecided;
-  if (u >= nUnd) return;
-  const int lane = threadIdx.x & 63, l = lane & 15, sub = lane >> 4;
-  const Sweep2Geom G2 = sweep2_geom(nUnd, g.ntilesUB, g.qs);      // the splits sweep 2 chose for this count
-  const int TEp = A.geo->TEp, ntilesV = A.geo->ntilesV;
-  const int S2 = G2.S;
-  const int nst = 2 * S2;
-  const int nn = A.nn;
-  constexpr u64 INF = ~0ull;
-  // Every event group holds at least one train below Dmin and at most one of all those trains is NN0, so nn or more
-  // groups mean nless > nn - 2: the walk gives up (matching.cpp:435-457) and nothing has to be recomputed.
-  int total = 0;
-  for (int st = lane; st < nst; st += 64) total += A.evCnt[(size_t)u * nst + st];
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) total += __shfl_xor(total, m);
-  const int q = A.undecided[u];
-  if (total >= nn) {
-    if (lane == 0) { MatchRow o = A.rows[q]; o.tj = -1; o.dj = (float)BIG; o.nless = nn; o.nbad = 0; A.rows[q] = o; }
-    return;
-  }
-  const int t0 = A.rows[q].t0, Dm = A.dmin[q], na = A.norm1[q];
-  const double x0 = A.x0y0[2 * q], y0 = A.x0y0[2 * q + 1];      // NN0's position, left by k_match_decide
-  const uint8_t *qd = A.d1 + (size_t)q * 128;
-  int nless = 0, nbad = 0, dj = BIG, sj = BIG, tjj = -1;
-  // one group (virtual tile, lane half) per quarter wave: lane l gets the exact distance of the group's row l
-  auto visit_group = [&](int tile, int hi, bool active) {
-    int vslot, pslot, t;
-    const int d = group_dist16(qd, na, A.tiles, A.norm2, A.perm, phys_tile(active ? tile : 0, TEp, g.offT), tile, hi, l, &vslot, &pslot, &t);
-    if (!active || d == BIG || t == t0) return;
-    if (d < Dm) {
-      nless++;
-      // geometric consistency with NN0 (distanceSq, matching.cpp:174-179), f64
-      const double2 xy = A.pos2p[pslot];
-      const double dx = x0 - xy.x, dy = y0 - xy.y;
-      if (dx * dx + dy * dy > A.contrDistSq) nbad++;
-    } else if (lex_less(d, vslot, dj, sj)) { dj = d; sj = vslot; tjj = t; }
-  };
-  // the best two groups the sweep did not flag: (distance, group) over all streams
-  u64 b0 = INF, b1 = INF;
-  for (int st = lane; st < nst; st += 64) {
-    const int4 p = *reinterpret_cast<const int4 *>(A.partial2 + ((size_t)u * nst + st) * 2);
-    u64 e0 = p.y < 0 ? INF : key64(p.x, p.y * 2 + (st & 1)), e1 = p.w < 0 ? INF : key64(p.z, p.w * 2 + (st & 1));
-    u64 lo = min(b0, e0); e0 = max(b0, e0); b0 = lo; b1 = min(b1, e0);
-    lo = min(b0, e1); e1 = max(b0, e1); b0 = lo; b1 = min(b1, e1);
-  }
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    u64 o0 = shfl_xor64(b0, m), o1 = shfl_xor64(b1, m);
-    const u64 lo = min(b0, o0); o0 = max(b0, o0); b0 = lo; b1 = min(min(b1, o1), o0);
-  }
-  // gather the (fewer than nn <= MATCH_NN_MAX) logged groups of all streams into one list; a stream that ran out of slots is
-  // rescanned exactly over its own tiles afterwards (its logged groups are then ignored); the groups it did not flag hold
-  // no train below Dmin and their minimum is in the sweep's keys
-  int nrec = 0;
-  bool anyOver = false;
-  for (int s0 = 0; s0 < nst; s0 += 64) {
-    const int st = s0 + lane;
-    int c = st < nst ? A.evCnt[(size_t)u * nst + st] : 0;
-    const bool over = c > EVCAP;
-    anyOver = anyOver || __any(over);
-    if (over) c = 0;
-    int pre = c;   // inclusive scan over the lanes
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) { const int v = __shfl_up(pre, m); if (lane >= m) pre += v; }
-    const int base = nrec + pre - c;
-    for (int e = 0; e < c; e++)
-      if (base + e < MATCH_NN_MAX) sRec[w][base + e] = (A.ev[((size_t)u * nst + st) * EVCAP + e] << 1) | (st & 1);
-    nrec += __shfl(pre, 63);
-  }
-  nrec = min(nrec, MATCH_NN_MAX);
-  // the sweep's best group is visited like an event group (all its rows are >= Dmin); the runner-up too when it could hold
-  // the smaller slot of an equal distance (same distance, same tile -- the other lane half)
-  int extra[2], nextra = 0;
-  if (b0 != INF) {
-    extra[nextra++] = (int)(unsigned)b0;
-    if (b1 != INF && (b1 >> 32) == (b0 >> 32) && ((unsigned)b1 >> 1) == ((unsigned)b0 >> 1)) extra[nextra++] = (int)(unsigned)b1;
-  }
-  for (int b = 0; b < nrec + nextra; b += 4) {      // wave-uniform trip count: the quarter waves shuffle among their own lanes
-    const int e = b + sub;
-    int rec = 0;
-    if (e < nrec) rec = sRec[w][e];
-    else if (e < nrec + nextra) rec = e - nrec == 0 ? extra[0] : extra[1];
-    visit_group(rec >> 1, rec & 1, e < nrec + nextra);
-  }
-  if (anyOver) {
-    for (int st = 0; st < nst; st++) {
-      if (A.evCnt[(size_t)u * nst + st] <= EVCAP) continue;
-      const int tb = (st >> 1) * G2.tilesPerSplit, te = min(tb + G2.tilesPerSplit, ntilesV);
-      for (int tile = tb; tile < te; tile += 4) visit_group(tile + sub, st & 1, tile + sub < te);
-    }
-  }
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    nless += __shfl_xor(nless, m);
-    nbad += __shfl_xor(nbad, m);
-    const int od = __shfl_xor(dj, m), os = __shfl_xor(sj, m), ot = __shfl_xor(tjj, m);
-    if (lex_less(od, os, dj, sj)) { dj = od; sj = os; tjj = ot; }
-  }
-  if (lane == 0) {
-    MatchRow o = A.rows[q];
-    o.tj = sj == BIG ? -1 : tjj;
-    o.dj = (float)dj;
-    o.nless = nless; o.nbad = nbad;
-    A.rows[q] = o;
-  }
-}
-
 // ---------------- resolve: sweep 2 and the event groups in ONE launch -------------------------------------------------------
 // For the queries k_match_decide could not finish (about 1 % on multi-view descriptors).  A workgroup takes (block of
 // undecided queries, split of the virtual tiles), geometry from the device-side count as above, and
@@ -871,10 +747,34 @@ struct ResolveArgs {
   const int *nUndecided;
   MatchRow *rows;
 };
-#ifndef RKO
-#define RKO 0   // timing-only knock-outs of k_match_resolve: 1 = no recomputation of logged groups, 2 = no sweep
-#endif
 constexpr int RCHUNK = 12;                 // tiles per index chunk of the resolve sweep (4 bits of tile code beside 4 of register)
+// keys that carry the row: 16 (keys) + 8 (tree) + 2 vector instructions per chain, and the rare branch of a logged group
+template <int QSETS, int EVS>
+struct ResolveEpi {
+  static constexpr int CH = RCHUNK;
+  int m1[QSETS], I1[QSETS], thr[QSETS], nev[QSETS];
+  int TEp, hi, stream0;                    // stream0: stream index of this lane's query set 0 (sets are 64 streams apart)
+  int (*evt)[EVS];
+  MX_D int kv(int v) const { return ((v >= TEp ? 1 : 0) << 8) | ((v % RCHUNK + 1) << 4); }
+  MX_D void chain(const v16i &acc, int kvb, int s, int tile) {
+    v16i k;
+#pragma unroll
+    for (int r = 0; r < 16; r++) k[r] = (acc[r] << 9) + (kvb + r);
+    const int t = tree_min16(k);
+    if (t < thr[s]) {
+      if (nev[s] < EVS) evt[stream0 + 64 * s][nev[s]] = tile;
+      nev[s]++;
+    } else m1[s] = min(m1[s], t);
+  }
+  MX_D void flush(int chunkTile0) {
+#pragma unroll
+    for (int s = 0; s < QSETS; s++) {
+      const int lb = m1[s] & 255;
+      if (lb) I1[s] = (chunkTile0 + (lb >> 4) - 1) * 32 + row_of(lb & 15, hi);
+      m1[s] &= ~255;
+    }
+  }
+};
 
 template <int QSETS>
 __device__ __forceinline__ void resolve_body(const ResolveArgs &A) {
@@ -907,73 +807,21 @@ __device__ __forceinline__ void resolve_body(const ResolveArgs &A) {
   __syncthreads();
   const int ul0 = wave * (32 * QSETS);
   v4i bq[QSETS][4];
-  int m1[QSETS], I1[QSETS], thr[QSETS], nev[QSETS];
+  ResolveEpi<QSETS, EVS> epi;
 #pragma unroll
   for (int s = 0; s < QSETS; s++) {
     const int ul = ul0 + 32 * s + col;
     const int q = max(sU[ul].q, 0);
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) bq[s][kb] = load_q(A.d1, q, kb, hi);
-    m1[s] = NONE_KEY; I1[s] = -1; nev[s] = 0;
-    thr[s] = sU[ul].q < 0 ? (int)0x80000000 : (sU[ul].dm - sU[ul].na) << 8;   // d < Dmin  <=>  key < (Dmin - |a'|^2) << 8; nothing for a dead lane
+    epi.m1[s] = NONE_KEY; epi.I1[s] = -1; epi.nev[s] = 0;
+    epi.thr[s] = sU[ul].q < 0 ? (int)0x80000000 : (sU[ul].dm - sU[ul].na) << 8;   // d < Dmin  <=>  key < (Dmin - |a'|^2) << 8; nothing for a dead lane
   }
   const int TEp = A.geo->TEp, offT = g.offT, ntilesV = A.geo->ntilesV;
+  epi.TEp = TEp; epi.hi = hi; epi.stream0 = (ul0 + col) * 2 + hi; epi.evt = sEvt;
   const int tBeg = sp * tilesPerSplit, tEnd = min(tBeg + tilesPerSplit, ntilesV);
-  auto flush = [&](int chunkTile0) {
-#pragma unroll
-    for (int s = 0; s < QSETS; s++) {
-      const int lb = m1[s] & 255;
-      if (lb) I1[s] = (chunkTile0 + (lb >> 4) - 1) * 32 + row_of(lb & 15, hi);
-      m1[s] &= ~255;
-    }
-  };
-  auto epilogue = [&](const v16i &acc, int kvb, int s, int tile) {
-    v16i k;
-#pragma unroll
-    for (int r = 0; r < 16; r++) k[r] = (acc[r] << 9) + (kvb + r);
-    const int t = tree_min16(k);
-    if (t < thr[s]) {
-      if (nev[s] < EVS) sEvt[(ul0 + 32 * s + col) * 2 + hi][nev[s]] = tile;
-      nev[s]++;
-    } else m1[s] = min(m1[s], t);
-  };
-  auto load_af = [&](const unsigned char *buf, int q, v4i *af) {
-#pragma unroll
-    for (int kb = 0; kb < 4; kb++) af[kb] = read_a(buf + q * TILE_B, col, kb, hi);
-  };
-  auto load_c = [&](const unsigned char *buf, int q, v16i &C) {
-#pragma unroll
-    for (int gq = 0; gq < 4; gq++) {
-      const v4i c4 = *reinterpret_cast<const v4i *>(buf + HOFF + q * 128 + (8 * gq + 4 * hi) * 4);
-      C[4 * gq] = c4[0]; C[4 * gq + 1] = c4[1]; C[4 * gq + 2] = c4[2]; C[4 * gq + 3] = c4[3];
-    }
-  };
-  auto tile_kvb = [&](int v) { return ((v >= TEp ? 1 : 0) << 8) | ((v % RCHUNK + 1) << 4); };
-  if (tBeg < tEnd) stage_group(A.tiles, A.hrow, phys_tile(tBeg, TEp, offT), sm[0], wave, lane);
-  int it = 0;
-  for (int tg = tBeg; tg < ((RKO & 2) ? tBeg : tEnd); tg += TPS, it++) {
-    const unsigned char *buf = sm[it & 1];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tg + TPS < tEnd) stage_group(A.tiles, A.hrow, phys_tile(tg + TPS, TEp, offT), sm[(it & 1) ^ 1], wave, lane);
-#pragma unroll
-    for (int q = 0; q < TPS; q++) {
-      v4i af[4];
-      v16i C;
-      load_af(buf, q, af);
-      load_c(buf, q, C);
-      const int kvb = tile_kvb(tg + q);
-#pragma unroll
-      for (int s = 0; s < QSETS; s++) {
-        v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], bq[s][0], C, 0, 0, 0);
-#pragma unroll
-        for (int kb = 1; kb < 4; kb++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[kb], bq[s][kb], acc, 0, 0, 0);
-        epilogue(acc, kvb, s, tg + q);
-      }
-    }
-    if ((tg + TPS) % RCHUNK == 0) flush(tg + TPS - RCHUNK);
-  }
-  if (tEnd > tBeg && tEnd % RCHUNK) flush((tEnd / RCHUNK) * RCHUNK);
+  sweep_core<QSETS, 26>(A.tiles, A.hrow, TEp, offT, tBeg, tEnd, bq, sm, epi);
+  int (&m1)[QSETS] = epi.m1, (&I1)[QSETS] = epi.I1, (&nev)[QSETS] = epi.nev;
   __syncthreads();                       // the staging buffers are free from here on: they hold the work list
   // ---- 2. the logged groups: counts per query, a flat work list, streams that ran out of slots
   int *sList = reinterpret_cast<int *>(&sm[0][0]);     // (query in block) << 23 | half << 22 | tile
@@ -1000,7 +848,10 @@ __device__ __forceinline__ void resolve_body(const ResolveArgs &A) {
   __syncthreads();
   {
     const int l = lane & 15, qw = tid >> 4;            // 16 quarter waves
-    auto visit = [&](int ul, int vtile, int h, bool active) {
+    // a visit = the exact distances of one group (compute), then its totals into the query's cells (commit); two visits are
+    // computed before either is committed, so that their loads overlap
+    struct Vis { int nl, nb, md, mt; };
+    auto compute = [&](int ul, int vtile, int h, bool active) {
       const UndRec r = sU[active ? ul : 0];
       int vslot, pslot, t;
       const int d = group_dist16(A.d1 + (size_t)max(r.q, 0) * 128, r.na, A.tiles, A.norm2, A.perm, phys_tile(active ? vtile : 0, TEp, offT),
@@ -1015,28 +866,35 @@ __device__ __forceinline__ void resolve_body(const ResolveArgs &A) {
           if (dx * dx + dy * dy > A.contrDistSq) nb = 1;
         } else { cd = d; ct = t; }
       }
-      // totals of the group over its 16 lanes; lane 0 adds them to the query's cells
+      // totals of the group over its 16 lanes
       nl += __builtin_amdgcn_update_dpp(0, nl, 0x128, 0xf, 0xf, false); nb += __builtin_amdgcn_update_dpp(0, nb, 0x128, 0xf, 0xf, false);
       nl += __builtin_amdgcn_update_dpp(0, nl, 0x124, 0xf, 0xf, false); nb += __builtin_amdgcn_update_dpp(0, nb, 0x124, 0xf, 0xf, false);
       nl += __builtin_amdgcn_update_dpp(0, nl, 0x122, 0xf, 0xf, false); nb += __builtin_amdgcn_update_dpp(0, nb, 0x122, 0xf, 0xf, false);
       nl += __builtin_amdgcn_update_dpp(0, nl, 0x121, 0xf, 0xf, false); nb += __builtin_amdgcn_update_dpp(0, nb, 0x121, 0xf, 0xf, false);
-      const int md = rowmin16(cd), mt = rowmin16(cd == md ? ct : BIG);
+      Vis v; v.nl = nl; v.nb = nb;
+      v.md = rowmin16(cd); v.mt = rowmin16(cd == v.md ? ct : BIG);
+      return v;
+    };
+    auto commit = [&](const Vis &v, int ul, bool active) {
       if (active && l == 0) {
-        if (nl) atomicAdd(&sNless[ul], nl);
-        if (nb) atomicAdd(&sNbad[ul], nb);
-        if (md != BIG) atomicMin(&sCand[ul], key64(md, mt));
+        if (v.nl) atomicAdd(&sNless[ul], v.nl);
+        if (v.nb) atomicAdd(&sNbad[ul], v.nb);
+        if (v.md != BIG) atomicMin(&sCand[ul], key64(v.md, v.mt));
       }
     };
-    const int nrec = (RKO & 1) ? 0 : sNrec;
-    for (int b = 0; b < nrec; b += 16) {               // workgroup-uniform trip count
-      const int e = b + qw;
-      const int rec = e < nrec ? sList[e] : 0;
-      visit((unsigned)rec >> 23, rec & 0x3fffff, (rec >> 22) & 1, e < nrec);
+    const int nrec = sNrec;
+    for (int b = 0; b < nrec; b += 32) {               // workgroup-uniform trip count
+      const int e0 = b + qw, e1 = b + 16 + qw;
+      const int r0 = e0 < nrec ? sList[e0] : 0, r1 = e1 < nrec ? sList[e1] : 0;
+      const Vis v0 = compute((unsigned)r0 >> 23, r0 & 0x3fffff, (r0 >> 22) & 1, e0 < nrec);
+      const Vis v1 = compute((unsigned)r1 >> 23, r1 & 0x3fffff, (r1 >> 22) & 1, e1 < nrec);
+      commit(v0, (unsigned)r0 >> 23, e0 < nrec);
+      commit(v1, (unsigned)r1 >> 23, e1 < nrec);
     }
     const int nover = sNover;
     for (int o = 0; o < nover; o++) {                  // a stream with more than EVS groups: every group of its tiles
       const int st = sOver[o];
-      for (int tile = tBeg; tile < tEnd; tile += 16) visit(st >> 1, tile + qw, st & 1, tile + qw < tEnd);
+      for (int tile = tBeg; tile < tEnd; tile += 16) commit(compute(st >> 1, tile + qw, st & 1, tile + qw < tEnd), st >> 1, tile + qw < tEnd);
     }
   }
   __syncthreads();
@@ -1056,7 +914,7 @@ __device__ __forceinline__ void resolve_body(const ResolveArgs &A) {
 // ---- workspace layout: ONE description used by the size query and by the launcher -------------------------------------------
 struct MatchLayout {
   int S, tilesPerSplit, ntilesUB, offT;
-  size_t norm1, norm2, hrow, perm, pos2p, tiles, status, geo, partial, partial2, dmin, undecided, x0y0, evCnt, ev, und, counter, bytes;
+  size_t norm1, norm2, hrow, perm, pos2p, tiles, status, geo, partial, dmin, undecided, x0y0, und, counter, bytes;
 };
 static MatchLayout match_layout(int n1, int n2, int qs) {
   MatchLayout L;
@@ -1090,13 +948,9 @@ static MatchLayout match_layout(int n1, int n2, int qs) {
   L.status = take((size_t)((n2 + PB - 1) / PB) * 8);
   L.geo = take(sizeof(TileGeo));
   L.partial = take((size_t)n1 * S * 2 * KTOP * 8);
-  const size_t e2 = sweep2_entries(n1, ntiles);
-  L.partial2 = take(e2 * 2 * 2 * 8);
   L.dmin = take((size_t)n1 * 4);
   L.undecided = take((size_t)n1 * 4);
   L.x0y0 = take((size_t)n1 * 16);
-  L.evCnt = take(e2 * 2 * 4);
-  L.ev = take(e2 * 2 * EVCAP * 4);
   L.und = take((size_t)n1 * 32);
   L.counter = take(64);
   L.bytes = w;
@@ -1109,13 +963,13 @@ size_t match_workspace_bytes(int n1, int n2) { return std::max(match_layout(n1, 
 struct MatchProblem {
   const uint8_t *d1, *d2;
   const double *pos2;
-  int *norm1, *norm2, *hrow, *perm, *dmin, *undecided, *counter, *evCnt, *ev;
+  int *norm1, *norm2, *hrow, *perm, *dmin, *undecided, *counter;
   double2 *pos2p;
   double *x0y0;
   u64 *status;
   TileGeo *geo;
   unsigned char *tiles;
-  int2 *partial, *partial2;
+  int2 *partial;
   UndRec *und;
   MatchRow *rows;
   MatchGeom g;
@@ -1152,7 +1006,7 @@ __global__ __launch_bounds__(256, sweep_wps(QS)) void k_match_sweep1(MatchBatch 
 #endif
   SweepArgs A;
   A.d1 = P.d1; A.norm1 = P.norm1; A.tiles = P.tiles; A.hrow = P.hrow; A.geo = P.geo; A.g = P.g; A.partial = P.partial;
-  sweep_body<0, QS>(A);
+  sweep_body<QS>(A);
 #ifdef MATCH_TRACE
   __syncthreads();
   if (threadIdx.x == 0 && wg < 16384) { g_mtrace[wg][1] = wall_clock64(); g_mtrace[wg][3] = __builtin_readcyclecounter() - g_mtrace[wg][3]; }
@@ -1168,30 +1022,12 @@ __global__ __launch_bounds__(16 * DECIDE_Q) void k_match_decide(MatchBatch b, do
   decide_body(A);
 }
 template <int QS>
-__global__ __launch_bounds__(256, sweep_wps(QS)) void k_match_sweep2(MatchBatch b) {
-  const MatchProblem &P = b.p[blockIdx.z];
-  SweepArgs A;
-  A.d1 = P.d1; A.norm1 = P.norm1; A.tiles = P.tiles; A.hrow = P.hrow; A.geo = P.geo; A.g = P.g;
-  A.dmin = P.dmin; A.undecided = P.undecided; A.nUndecided = P.counter; A.partial2 = P.partial2; A.evCnt = P.evCnt; A.ev = P.ev;
-  sweep_body<1, QS>(A);
-}
-template <int QS>
 __global__ __launch_bounds__(256) void k_match_resolve(MatchBatch b, double contrDistSq, int nn) {
   const MatchProblem &P = b.p[blockIdx.z];
   ResolveArgs A;
   A.d1 = P.d1; A.norm2 = P.norm2; A.perm = P.perm; A.hrow = P.hrow; A.tiles = P.tiles; A.geo = P.geo; A.g = P.g;
   A.pos2p = P.pos2p; A.contrDistSq = contrDistSq; A.nn = nn; A.und = P.und; A.nUndecided = P.counter; A.rows = P.rows;
   resolve_body<QS>(A);
-}
-__global__ __launch_bounds__(256) void k_match_events(MatchBatch b, double contrDistSq, int nn) {
-  const MatchProblem &P = b.p[blockIdx.z];
-  if ((int)blockIdx.x * 4 >= P.g.n1) return;
-  EventsArgs A;
-  A.d1 = P.d1; A.norm1 = P.norm1; A.norm2 = P.norm2; A.perm = P.perm; A.tiles = P.tiles; A.geo = P.geo; A.g = P.g; A.pos2p = P.pos2p;
-  A.x0y0 = P.x0y0;
-  A.contrDistSq = contrDistSq; A.rows = P.rows; A.dmin = P.dmin; A.undecided = P.undecided; A.nUndecided = P.counter;
-  A.evCnt = P.evCnt; A.ev = P.ev; A.nn = nn; A.partial2 = P.partial2;
-  events_body(A);
 }
 // Problems with n1 == 0 or n2 == 0 must be left out by the caller.  workspace[i] holds match_workspace_bytes(n1[i], n2[i]).
 void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
@@ -1216,9 +1052,8 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
     P.norm1 = (int *)(w + L.norm1); P.norm2 = (int *)(w + L.norm2); P.hrow = (int *)(w + L.hrow); P.perm = (int *)(w + L.perm);
     P.pos2p = (double2 *)(w + L.pos2p); P.status = (u64 *)(w + L.status); P.geo = (TileGeo *)(w + L.geo);
     P.tiles = (unsigned char *)(w + L.tiles);
-    P.partial = (int2 *)(w + L.partial); P.partial2 = (int2 *)(w + L.partial2);
+    P.partial = (int2 *)(w + L.partial);
     P.dmin = (int *)(w + L.dmin); P.undecided = (int *)(w + L.undecided); P.x0y0 = (double *)(w + L.x0y0);
-    P.evCnt = (int *)(w + L.evCnt); P.ev = (int *)(w + L.ev);
     P.counter = (int *)(w + L.counter); P.und = (UndRec *)(w + L.und);
     P.d1 = d1[i]; P.d2 = d2[i]; P.pos2 = pos2[i]; P.rows = rows[i];
     maxN1 = std::max(maxN1, n1[i]); maxS = std::max(maxS, L.S); maxWg = std::max(maxWg, (n2[i] + PB - 1) / PB);
@@ -1234,12 +1069,7 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
   // sweep 2: one round of workgroups dealt out on the device as (undecided block, split); more only if there could be more
   // undecided query blocks than that
   const dim3 grid2(std::max(NW2, (maxN1 + QPB - 1) / QPB), 1, nb);
-  static const bool old2 = getenv("MODSX_MATCH_OLD2") && atoi(getenv("MODSX_MATCH_OLD2"));   // the two-launch form (sweep 2, events), for comparison
-  if (old2) {
-    if (qs == 4) hipLaunchKernelGGL(k_match_sweep2<4>, grid2, dim3(256), 0, s, b);
-    else hipLaunchKernelGGL(k_match_sweep2<2>, grid2, dim3(256), 0, s, b);
-    hipLaunchKernelGGL(k_match_events, dim3((maxN1 + 3) / 4, 1, nb), dim3(256), 0, s, b, contrDistSq, nn);
-  } else if (qs == 4) hipLaunchKernelGGL(k_match_resolve<4>, grid2, dim3(256), 0, s, b, contrDistSq, nn);
+  if (qs == 4) hipLaunchKernelGGL(k_match_resolve<4>, grid2, dim3(256), 0, s, b, contrDistSq, nn);
   else hipLaunchKernelGGL(k_match_resolve<2>, grid2, dim3(256), 0, s, b, contrDistSq, nn);
 }
 
