@@ -170,3 +170,10 @@ def oracle_ladder(oracle, a, b, steps, min_matches, seed, ori=(1.0, 41, 1, 0.8),
         out = dict(n_regions=(len(r1), len(r2)), n_tentatives=len(tent), tent=tu, rr=rr, r1=r1, r2=r2, pts=pu)
         done += 1
     return out, done
+
+
+def need_ref(oracle):
+    """The RANSAC comparisons are made against the reference's own degensac (oracle/_ref, built from /root/reference in place and
+    carried to the GPU box with the snapshot).  On a GPU box a missing build is an ERROR, not a skip: a green run must mean that
+    the comparisons were made."""
+    assert oracle.ref_available(), "oracle/_ref is not built: run `make -C oracle ref` where /root/reference exists"

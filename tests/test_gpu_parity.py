@@ -10,7 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-from common import oracle_features, oracle_pair, laf_of, normH, same_records
+from common import oracle_features, oracle_pair, laf_of, normH, same_records, need_ref
 
 pytestmark = pytest.mark.gpu
 
@@ -114,6 +114,21 @@ def test_affine_keypoints_bit_exact(ctx, modsx, oracle, small_pair, mode, regn):
         assert same_records(got, ref.view(modsx.KEYPOINT))
 
 
+def test_affine_keypoints_without_baumberg(ctx, modsx, oracle, small_pair):
+    """doBaumberg = 0 (HessianAffineParams, detectors/structures.hpp; pyramid / affine detectors skip findAffineShape and export
+    the isotropic keypoint): the branch engine.hip takes around the Baumberg stage, in the two export modes that reach it."""
+    for mode, regn in ((0, 2000), (4, 150)):
+        for img in small_pair[:2]:
+            im = ctx.upload(img)
+            got = ctx.detect_affine_keypoints(im, modsx.default_hessaff_params(mode=mode, reg_number=regn, doBaumberg=0))
+            with_b = ctx.detect_affine_keypoints(im, modsx.default_hessaff_params(mode=mode, reg_number=regn))
+            im.free()
+            ref = oracle.detect_hessaff(img, oracle.default_params(mode=mode, reg_number=regn, doBaumberg=0))
+            assert len(ref) > 20
+            assert same_records(got, ref.view(modsx.KEYPOINT))
+            assert len(with_b) != len(got) or not same_records(with_b, got)      # the flag is seen
+
+
 @pytest.mark.parametrize("kw", [dict(smmWindowSize=15), dict(smmWindowSize=11, maxIterations=5), dict(maxIterations=1),
                                 dict(maxIterations=7, convergenceThreshold=0.01), dict(convergenceThreshold=0.3)])
 def test_baumberg_parameter_variants_bit_exact(ctx, modsx, oracle, small_pair, kw):
@@ -185,6 +200,22 @@ def test_orientation_half_mode_bit_exact(ctx, modsx, oracle, small_pair, mr, max
         assert len(ref) > 20 and same_records(got, ref.view(modsx.REGION))
         differs += int(len(plain) != len(got) or not same_records(plain, got))
     assert differs > 0
+
+
+@pytest.mark.parametrize("mr,max_ang,half", [(1.0, 1, 0), (5.1962, 5, 0), (5.1962, 5, 1), (5.1962, 18, 0)])
+def test_orientation_add_upright_bit_exact(ctx, modsx, oracle, small_pair, mr, max_ang, half):
+    """DetectOrientation(..., addUpRight = true) (imagerepresentation.cpp:1265-1269, synth-detection.cpp DetectOrientation): the
+    unrotated region is kept beside the oriented ones.  Plain and Half-folded histograms, one and several peaks."""
+    img = small_pair[0]
+    im = ctx.upload(img)
+    k = oracle.detect_hessaff(img, oracle.default_params())
+    regs = oracle.detect_affine_regions(k)
+    ref = oracle.detect_orientation(img, regs, mr_size=mr, half=half, max_ang=max_ang, upright=1)
+    got = ctx.detect_orientation(im, regs.view(modsx.REGION), mr_size=mr, half=half, max_ang=max_ang, upright=1)
+    without = ctx.detect_orientation(im, regs.view(modsx.REGION), mr_size=mr, half=half, max_ang=max_ang, upright=0)
+    im.free()
+    assert len(ref) > len(regs) and same_records(got, ref.view(modsx.REGION))
+    assert len(without) < len(got)
 
 
 def test_step_descriptor_list_one_pass_equals_separate_calls(ctx, modsx, oracle, small_pair):
@@ -286,8 +317,7 @@ def test_match_fginn_clustered_near_duplicates_and_split_ranges(ctx, oracle):
 
 def test_pair_end_to_end_identical_inliers(ctx, modsx, oracle, small_pair):
     a, b, H = small_pair
-    if not oracle.ref_available():
-        pytest.skip("oracle/_ref not built")
+    need_ref(oracle)
     ia, ib = ctx.upload(a), ctx.upload(b)
     for seed in (1, 77):
         got = ctx.match_pair(ia, ib, modsx.default_pair_params(ransac_seed=seed))
@@ -307,8 +337,7 @@ def test_pair_end_to_end_epipolar_verification(ctx, modsx, oracle, small_pair):
     """RANSACPars::useF = 1 (config 5 of BASELINE.json): the same pair verified by exp_ransacFcustom + F_LAF_check.
     The scene is planar, so DEGENSAC's plane-and-parallax branch is what runs."""
     a, b, _ = small_pair
-    if not oracle.ref_available():
-        pytest.skip("oracle/_ref not built")
+    need_ref(oracle)
     ia, ib = ctx.upload(a), ctx.upload(b)
     got = ctx.match_pair(ia, ib, modsx.default_pair_params(ransac_seed=3, useF=1, LAFCoef=2.0, err_threshold=4.0))
     ia.free(); ib.free()
@@ -585,8 +614,7 @@ def test_wxbs_config_full_hd_pair_h_and_f(ctx, modsx, oracle):
     counts, the de-duplicated tentative list field by field, and for both verification types (H: exp_ransacHcustom +
     H_LAF_check 13, F: exp_ransacFcustom + DEGENSAC + F_LAF_check 3) the RANSAC inlier flags, the verified set and the model."""
     from mods_amd import synthetic
-    if not oracle.ref_available():
-        pytest.skip("oracle/_ref not built")
+    need_ref(oracle)
     a, b, H = synthetic.make_pair(rows=1080, cols=1920, nblobs=3000, seed=77)
     r1, r2, tu, pu, ntent = _wxbs_oracle(oracle, a, b)
     ia, ib = ctx.upload(a), ctx.upload(b)

@@ -4,7 +4,7 @@ tests/test_host_abi.py (no device in that container); here a device is present, 
 import numpy as np
 import pytest
 
-from common import synth_two_view, synth_corr
+from common import synth_two_view, synth_corr, need_ref
 
 pytestmark = pytest.mark.gpu
 
@@ -23,8 +23,7 @@ def _same(a, b):
 def test_degensac_with_device_counted_hypotheses_follows_the_reference(modsx, oracle, ctx, planar_frac, error_type):
     """Scenes from general to a single plane (every sample H-degenerate: rFtH on each): sample count, LO count, degeneracy count,
     inlier set, LAF-checked set and F of the reference's compiled degensac; on the planar scenes the device did the counting."""
-    if not oracle.ref_available():
-        pytest.skip("oracle/_ref not built")
+    need_ref(oracle)
     modsx.verify_device_stats(reset=True)
     for seed in (1, 2, 3, 4, 5, 6):
         pts, laf = synth_two_view(seed, planar_frac=planar_frac, n_in=300 + 40 * seed, n_out=100 + 25 * seed)
@@ -40,8 +39,7 @@ def test_degensac_with_device_counted_hypotheses_follows_the_reference(modsx, or
 def test_homography_scene_is_the_loops_worst_case(modsx, oracle, ctx):
     """A pure homography with outliers (what bench.py --config wxbs verifies with useF): no two-point epipole ever beats the
     plane, so every rFtH call runs its full 2 x 10^4 hypotheses -- all of them counted on the device, none changing the state."""
-    if not oracle.ref_available():
-        pytest.skip("oracle/_ref not built")
+    need_ref(oracle)
     modsx.verify_device_stats(reset=True)
     for seed in (3, 8):
         pts, laf, _ = synth_corr(600, 0.7, noise=0.5, seed=seed)
@@ -55,8 +53,7 @@ def test_homography_scene_is_the_loops_worst_case(modsx, oracle, ctx):
 def test_many_off_plane_correspondences_go_through_several_lds_tiles(modsx, oracle, ctx):
     """More than 512 correspondences off the dominant plane: k_rfth_count stages them tile by tile; a plane with a few dozen
     inliers among 1500 random pairs also makes state-changing hypotheses frequent (each re-draws the rest of the loop)."""
-    if not oracle.ref_available():
-        pytest.skip("oracle/_ref not built")
+    need_ref(oracle)
     modsx.verify_device_stats(reset=True)
     for seed, frac in ((11, 0.6), (12, 0.9)):
         pts, laf = synth_two_view(seed, planar_frac=frac, n_in=400, n_out=1500)

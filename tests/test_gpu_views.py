@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from common import laf_of, normH, oracle_ladder, same_records
+from common import laf_of, normH, oracle_ladder, same_records, need_ref
 
 pytestmark = pytest.mark.gpu
 
@@ -52,8 +52,7 @@ def test_detect_describe_views_bit_exact(ctx, modsx, oracle, small_pair):
 
 def test_pair_views_end_to_end(ctx, modsx, oracle, small_pair):
     a, b, H = small_pair
-    if not oracle.ref_available():
-        pytest.skip("oracle/_ref not built")
+    need_ref(oracle)
     vo, vm = _views(oracle, modsx, [1, 2, 3], 360.0)
     ia, ib = ctx.upload(a), ctx.upload(b)
     got = ctx.match_pair_views(ia, ib, vm, modsx.default_pair_params(ransac_seed=4))
@@ -75,6 +74,39 @@ def test_pair_views_end_to_end(ctx, modsx, oracle, small_pair):
     assert np.abs(normH(got["H"]) - normH(rr["H"])).max() < 1e-4
     assert np.abs(normH(got["H"]) - H).max() < 1.5
     ia.free(); ib.free()
+
+
+def test_configs2_eight_views_full_size_end_to_end(ctx, modsx, oracle):
+    """configs[2] as BASELINE.json states it: the 1024x768 synthetic pair under TiltSet 1,2,3,4,6 / Phi 360 (8 views,
+    SURVEY.md section 8(d) item 3) through ONE match_pair_views call -- region counts, every unique tentative, the inlier set,
+    the verified set and H against the oracle's loop over the same views."""
+    import os
+    from mods_amd import synthetic
+    need_ref(oracle)
+    a, b, H = synthetic.make_pair(rows=768, cols=1024, nblobs=4000, seed=12345)
+    vo, vm = _views(oracle, modsx, [1, 2, 3, 4, 6], 360.0)
+    assert len(vm) == 8
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    got = ctx.match_pair_views(ia, ib, vm, modsx.default_pair_params(ransac_seed=4))
+    ia.free(); ib.free()
+    th = min(64, os.cpu_count() or 1)
+    r1, d1 = oracle.detect_describe_views(a, vo, threads=th)
+    r2, d2 = oracle.detect_describe_views(b, vo, threads=th)
+    assert got["n_regions"] == (len(r1), len(r2)) and len(r1) > 8000
+    pos2 = np.stack([r2["reproj_kp"]["x"], r2["reproj_kp"]["y"]], 1)
+    tent = oracle.match_fginn(d1, d2, pos2, 0.8, 30.0)
+    assert got["n_tentatives"] == len(tent) and len(tent) > 1000
+    pts = np.stack([r1["reproj_kp"]["x"][tent["q"]], r1["reproj_kp"]["y"][tent["q"]],
+                    r2["reproj_kp"]["x"][tent["t0"]], r2["reproj_kp"]["y"][tent["t0"]]], 1)
+    order, keep = oracle.duplicate_filtering(pts, tent["ratio"], 2.0, True)
+    sel = order[keep]
+    tu, pu = tent[sel], pts[sel]
+    for f in tu.dtype.names:
+        assert np.array_equal(got["tentatives"][f], tu[f]), f
+    rr = oracle.loransac_h(pu, laf_of(r1, tu["q"]), laf_of(r2, tu["t0"]), seed=4)
+    assert np.array_equal(got["ransac_inlier"], rr["inl"]) and np.array_equal(got["verified"], rr["keep"])
+    assert np.abs(normH(got["H"]) - normH(rr["H"])).max() < 1e-4
+    assert np.abs(normH(got["H"]) - H).max() < 1.5
 
 
 CAT_CENTRE_TOL_PX, CAT_CORNER_TOL_PX = 15.0, 75.0   # transfer error of the recovered H against build/examples/cat.txt over the support of the matches
@@ -183,8 +215,7 @@ def test_iteration_ladder_matches_oracle(ctx, modsx, oracle, small_pair, min_mat
     """HessianAffine steps 4-6 of iters_mods_cviu.ini in miniature: the view sets of later steps are de-duplicated
     against earlier ones (SetVSPars prev_par), regions accumulate, and the loop stops at minMatches."""
     a, b, H = small_pair
-    if not oracle.ref_available():
-        pytest.skip("oracle/_ref not built")
+    need_ref(oracle)
     prev_o, prev_m = [], []
     steps_o, steps_m = [], []
     for tilts, phi, ratio in (([1], 360.0, 0.8), ([1, 2], 360.0, 0.8), ([1, 2], 120.0, 0.85)):
@@ -227,8 +258,7 @@ def test_mixed_mser_hessaff_ladder_matches_oracle(ctx, modsx, oracle, small_pair
     """iters_mods_cviu.ini in miniature: an MSER step, then HessianAffine steps; the classes keep separate region lists
     and tentatives, the verified set comes from their concatenation (HessianAffine first)."""
     a, b, H = small_pair
-    if not oracle.ref_available():
-        pytest.skip("oracle/_ref not built")
+    need_ref(oracle)
     prev_o, prev_m, steps_o, steps_m = {0: [], 3: []}, {0: [], 3: []}, [], []
     for det, tilts, phi, sigma, ratio in ((3, [1], 360.0, 0.8, 0.85), (0, [1], 360.0, 0.2, 0.8), (3, [1, 3], 360.0, 0.8, 0.8),
                                           (0, [1, 2], 360.0, 0.2, 0.8)):
@@ -276,8 +306,7 @@ def test_configs3_full_cviu_ladder_all_steps_matches_oracle(ctx, modsx, oracle, 
     config_iter_mods_cviu.ini:103 (the configuration the ladder ships with); 5.1962 is the WxBS file's value on the same ladder."""
     import os
     from mods_amd import synthetic
-    if not oracle.ref_available():
-        pytest.skip("oracle/_ref not built")
+    need_ref(oracle)
     a, b, _ = synthetic.make_pair(rows=768, cols=1024, nblobs=4000, seed=12345)
     steps_o, steps_m = _cviu_ladder(oracle, modsx)
     assert [len(v) for v, _, _ in steps_m] == [3, 24, 11, 20, 30]        # 27 MSER views, 61 HessianAffine views
@@ -363,8 +392,7 @@ def test_wxbs_ladder_two_descriptor_classes_small(ctx, modsx, oracle, small_pair
     tentative list per (detector, descriptor), matches each with its own FGINN threshold (0.85 / 0.8 in [MSER2], 0.9 in
     [HessianAffine6]) and verifies the concatenation in std::map order -- H (ver_type 0) and F (ver_type 2)."""
     a, b, H = small_pair
-    if not oracle.ref_available():
-        pytest.skip("oracle/_ref not built")
+    need_ref(oracle)
     steps_o, steps_m = _wxbs_ladder(oracle, modsx)
     assert [len(v) for v, _, _, _ in steps_m] == [3, 24, 11, 20, 30]
     got, ref, done = _check_wxbs_ladder(oracle, modsx, ctx, a, b, steps_o, steps_m, useF, 7, 10 ** 6, 300, 120)
@@ -384,14 +412,44 @@ def test_configs4_wxbs_ladder_full_size_both_classes(ctx, modsx, oracle):
     classes), every tentative, the inlier set, the verified set and H against the oracle's loop."""
     import os
     from mods_amd import synthetic
-    if not oracle.ref_available():
-        pytest.skip("oracle/_ref not built")
+    need_ref(oracle)
     a, b, _ = synthetic.make_pair(rows=768, cols=1024, nblobs=4000, seed=12345)
     steps_o, steps_m = _wxbs_ladder(oracle, modsx, which=(0, 2, 3))
     assert [len(v) for v, _, _, _ in steps_m] == [3, 11, 20]
     got, ref, done = _check_wxbs_ladder(oracle, modsx, ctx, a, b, steps_o, steps_m, 0, 3, 10 ** 6, 2000, 500,
                                         threads=min(64, os.cpu_count() or 1))
     assert done == 3 and got["n_regions"][0] > 40000 and len(ref["tent"]) > 3000
+
+
+def test_configs4_wxbs_ladder_full_size_remaining_steps(ctx, modsx, oracle):
+    """The two steps of the WxBS ladder the test above leaves out, at 1024x768: [MSER3] (24 further MSER views: scales 1, 0.25,
+    0.125 x tilts 3, 6, 9) and [HessianAffine6] (30 further views at Phi 60, FGINN 0.9), each on top of its detector's first
+    step -- so all five steps of iters_mods_cviu_wxbs.ini meet the oracle at full size."""
+    import os
+    from mods_amd import synthetic
+    need_ref(oracle)
+    a, b, _ = synthetic.make_pair(rows=768, cols=1024, nblobs=4000, seed=12345)
+    th = min(64, os.cpu_count() or 1)
+    for which, nviews in (((0, 1), [3, 24]), ((2, 4), [11, 30])):
+        steps_o, steps_m = _wxbs_ladder(oracle, modsx, which=which)
+        assert [len(v) for v, _, _, _ in steps_m] == nviews
+        got, ref, done = _check_wxbs_ladder(oracle, modsx, ctx, a, b, steps_o, steps_m, 0, 3, 10 ** 6, 2000, 500, threads=th)
+        assert done == 2 and len(ref["tent"]) > 300
+
+
+def test_configs4_wxbs_ladder_1920x1080_identity_and_first_view_step(ctx, modsx, oracle):
+    """configs[4]'s image size: a 1920x1080 pair of the batch generator (seeds 1000 / 2000) through
+    [MSER2] (identity + two zooms) and [HessianAffine4] (11 views), H and F verification, against the oracle's loop."""
+    import os
+    from mods_amd import synthetic
+    need_ref(oracle)
+    a, b, _ = synthetic.make_pair(rows=1080, cols=1920, nblobs=4000, seed=1000)
+    th = min(64, os.cpu_count() or 1)
+    steps_o, steps_m = _wxbs_ladder(oracle, modsx, which=(0, 2))
+    assert [len(v) for v, _, _, _ in steps_m] == [3, 11]
+    for useF in (0, 1):
+        got, ref, done = _check_wxbs_ladder(oracle, modsx, ctx, a, b, steps_o, steps_m, useF, 3, 10 ** 6, 2000, 500, threads=th)
+        assert done == 2 and got["n_regions"][0] > 15000 and len(ref["tent"]) > 1000
 
 
 def test_cat_pair_full_ladder_stops_early_on_ground_truth(ctx, modsx, cat_pair):
