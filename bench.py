@@ -32,6 +32,7 @@ import json
 import os
 import sys
 import time
+import resource
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -267,6 +268,7 @@ def main():
     import numpy as np
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    exit_code = 0
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -377,11 +379,14 @@ def main():
                 res[i] = r
         return res
 
+    host_cpu = {}
+
     def timed(run, warmup, steps, g=None):
         results = None
         for _ in range(warmup):
             results = run()
         barrier(g)
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         nd = 0
         for _ in range(steps):
@@ -390,7 +395,10 @@ def main():
                 if r is not None:
                     nd += r["n_regions"][0] + r["n_regions"][1]
         barrier(g)
-        return time.perf_counter() - t0, nd, results
+        dt = time.perf_counter() - t0
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        host_cpu["s"] = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)     # this rank's threads, user + system
+        return dt, nd, results
 
     def reduce_over_ranks(elapsed, nd):
         if dist is None:
@@ -507,6 +515,9 @@ def main():
     # brackets queueing as well.  The same pairs are repeated on ONE stream and the launch durations come from that pass.
     iso, niso, mroof = {}, 0, None
     if rank == 0 and not views_hung and (group is None or views_world == 1 or args.loopback):
+        # really one stream: a lone multi-view pair would otherwise run image 2 on a peer context and every image in three parts on
+        # helper contexts (engine_views.hip), and the event brackets of this leg would include their queueing
+        os.environ["MODSX_PAIR_SERIAL"] = "1"; os.environ["MODSX_PAIR_NOSPLIT"] = "1"
         ctx.profile(True)
         niso = min(nbatch, 8 if single_view else 4)
         if single_view:
@@ -531,6 +542,7 @@ def main():
             if m and m["launches"]:
                 mroof = (m["ms"] / m["launches"], r0["n_regions"][0], r0["n_regions"][1], m["launches"],
                          m1["ms"] / m1["launches"] if m1 and m1["launches"] else None)
+        os.environ.pop("MODSX_PAIR_SERIAL", None); os.environ.pop("MODSX_PAIR_NOSPLIT", None)
 
     if rank == 0:
         pairs = args.steps * (nbatch if group is not None else world * nbatch)
@@ -557,6 +569,13 @@ def main():
                        "H_vs_generator_max_abs": float(np.abs(res["H"] / res["H"][2, 2] - Hgt).max())},
             "kernel_ms_per_pair_multi_stream": {k: v["ms"] / (PROF_STEPS * nbatch) for k, v in stats.items() if v["launches"]},
         }
+        # the same figure under a key that never changes meaning: with N > 1 `value` becomes the view-sharded one (below)
+        out["value_pair_sharded"] = value
+        if host_cpu.get("s") is not None:
+            # rank 0's own threads (workers, verification helpers, host pool) over its share of the timed pairs: on a node where N ranks
+            # share one host, N times this figure per second of throughput is what the host has to supply
+            out["host_cpu_s_per_pair_rank0"] = host_cpu["s"] / max(1, args.steps * nbatch)
+            out["host_threads"] = {"cpu_allowance": cpu_info()[2], "local_ranks": int(os.environ.get("LOCAL_WORLD_SIZE", "1"))}
         if group is not None:
             out["rccl"] = group.describe()
         if scaling_views is not None:
@@ -589,11 +608,11 @@ def main():
                     flops = 2.0 * n1 * n2 * 128
                 tf = flops / (ms * 1e-3) / 1e12
                 out["roofline"] = {
-                    "kernel": "k_match_* (every launch of one matching problem: pack, sweep 1, sweep 2, walk)",
+                    "kernel": "k_match_* (every launch of one matching problem: pack, sweep 1, decide, resolve)",
                     "bound": "mfma", "achieved": tf, "peak": INT8_PEAK_TOPS, "unit": "TFLOP/s", "frac": tf / INT8_PEAK_TOPS,
                     "traffic": None, "avg_launch_ms": ms, "algorithmic_work_per_launch": flops, "N": n1, "M": n2,
                     "binds": "mfma: 2*N*M*128 int8 ops against (N+M)*128 B is ~1e4 op/B, the kernel is compute-shaped; "
-                             "its limiter is VALU issue beside the MFMAs (DESIGN.md section 5)",
+                             "sweep 1 carries the contraction; pack / decide / resolve are latency chains (DESIGN.md section 5.6)",
                     "note": ("HIP events on the launch stream around the launches of ONE matching problem -- pair 0 of this run, "
                              "%d repetitions on one stream right after the timed region; N, M, the work and the time all belong "
                              "to that pair" % nl) if n1 is not None else
@@ -606,14 +625,14 @@ def main():
                     tf1 = flops / (ms1 * 1e-3) / 1e12
                     out["roofline_sweep1"] = {
                         "kernel": "k_match_sweep1 alone: the one launch that carries the 2*N*M*128 contraction of the problem above "
-                                  "(sweep 2 repeats part of it for the undecided queries; pack / decide / events issue no MFMA)",
+                                  "(k_match_resolve repeats about 1 % of it for the undecided queries; pack / decide issue no MFMA)",
                         "bound": "mfma", "achieved": tf1, "peak": INT8_PEAK_TOPS, "unit": "TFLOP/s", "frac": tf1 / INT8_PEAK_TOPS,
                         "avg_launch_ms": ms1, "algorithmic_work_per_launch": flops, "traffic": None,
                         "measured_ceilings_TOPs": {"mfma_only_descriptor_like_operands": 3800.0, "with_the_top2_reduction_VALU": 3000.0,
                                                    "source": "profiles/r03_ubench_mfma.txt (tools/ubench/mfma_chain_sift, mfma_lds)"},
                         "note": "HIP events on the launch stream around k_match_sweep1 of the same %d repetitions" % nl}
             tfile, tsrc = None, None
-            for tag in ("r04", "r03", "r02"):
+            for tag in ("r05", "r04", "r03", "r02"):
                 cand = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % tag)
                 if os.path.exists(cand):
                     tfile, tsrc = cand, "profiles/pmc_traffic_%s.json" % tag
@@ -621,6 +640,10 @@ def main():
             tj = json.load(open(tfile)) if tfile else {}
             if "roofline" in out and tj:
                 out["roofline"]["traffic"] = tj.get("k_match_total_views31")
+                if tj.get("k_match_total_views31") and tj.get("k_match_compulsory_bytes"):
+                    out["roofline"]["traffic_over_compulsory"] = tj["k_match_total_views31"] / tj["k_match_compulsory_bytes"]
+                if tj.get("hbm_counter_GB_per_pair"):
+                    out["hbm_counter_GB_per_pair"] = tj["hbm_counter_GB_per_pair"]      # whole pipeline, one stream, same profile
                 out["roofline"]["traffic_source"] = ("%s: FETCH_SIZE x2 + WRITE_SIZE of the k_match_* kernels from separate rocprofv3 --pmc "
                                                      "passes over tools/bench_match.py at %s (a committed profile, not measured in this run)"
                                                      % (tsrc, tj.get("k_match_problem", "24.1 k x 23.6 k real 31-view descriptors")))
@@ -817,12 +840,22 @@ def main():
         except OSError:
             pass
         sys.stdout.flush()
+        # --gpus N must mean N ranks in ONE RCCL communicator: anything else (a bootstrap that fell back to per-rank worlds, a launcher
+        # that started fewer ranks) is an error in the line and in the exit code, not a smaller number that looks like a result
+        rc_info = out.get("rccl") or {}
+        if args.gpus and args.gpus != world and not args.loopback:
+            out["error"] = "--gpus %d, but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world)
+            exit_code = 3
+        elif world > 1 and not args.loopback and rc_info.get("ranks_seen_by_rccl") != world:
+            out["error"] = ("--gpus %d, but the RCCL communicator holds %s ranks (transport %s): the view-sharded figure is not a %d-GPU "
+                            "measurement" % (world, rc_info.get("ranks_seen_by_rccl"), rc_info.get("transport"), world))
+            exit_code = 3
         if guard_flag:
             open(guard_flag, "w").close()     # from here on the line is this process's to print
         print(json.dumps(out), flush=True)
     if views_hung:
         sys.stdout.flush()
-        os._exit(0)
+        os._exit(exit_code or 0)
     for a_, b_ in dev:
         a_.free(); b_.free()
     if group is not None:
@@ -832,6 +865,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

@@ -457,6 +457,7 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
         t = std::move(vq.q.front());
         vq.q.pop_front();
       }
+      hipSetDevice(t.dev);     // a new thread starts on device 0: the verifier's device-side loops belong on the producing context's GPU
       const auto v0 = std::chrono::steady_clock::now();
       mx::verify_tentatives(t.l1, t.l2, t.tents, pp, t.res);
       g_verifyUs += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - v0).count();
@@ -539,6 +540,7 @@ int modsx_match_pairs_views(modsx_ctx *const *ctxs, int n_ctx, const modsx_image
         t = std::move(vq.q.front());
         vq.q.pop_front();
       }
+      hipSetDevice(t.dev);     // a new thread starts on device 0: the verifier's device-side loops belong on the producing context's GPU
       const auto v0 = std::chrono::steady_clock::now();
       mx::verify_tentatives(t.l1, t.l2, t.tents, pp, t.res);
       g_verifyUs += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - v0).count();

@@ -221,13 +221,18 @@ modsx_ctx *ctx_create(int device_id) {
     // whole CPU allowance of a container limited to 16 CPUs (the hosts this library is benchmarked on: cpu.max 1600000 100000),
     // and the verification / component-tree threads then run into the cgroup's throttle (stalls of 60-90 ms per 100 ms period).
     // MODSX_SYNC=block (default) waits on the interrupt instead; MODSX_SYNC=spin keeps the runtime's default.
-    static std::once_flag once;
-    std::call_once(once, [] {
-      const char *e = getenv("MODSX_SYNC");
-      if (e && !strcmp(e, "spin")) return;
-      hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
-      (void)hipGetLastError();
-    });
+    // The flag is per DEVICE (and changes how every user of that device in this process waits): it is set once for each device a
+    // context is made on.  A failure is reported once and is not fatal -- the runtime then keeps spinning.
+    static std::once_flag once[64];
+    if (device_id < 64)
+      std::call_once(once[device_id], [device_id] {
+        const char *e = getenv("MODSX_SYNC");
+        if (e && !strcmp(e, "spin")) return;
+        if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) {
+          (void)hipGetLastError();
+          fprintf(stderr, "modsx: hipSetDeviceFlags(hipDeviceScheduleBlockingSync) failed on device %d; host threads will spin-wait\n", device_id);
+        }
+      });
   }
   modsx_ctx *c = new modsx_ctx();
   c->dev = device_id;
@@ -1622,7 +1627,7 @@ int match_pair_group(modsx_ctx *c, const modsx_image *const *imgs1, const modsx_
       t.own.resize(2);
       t.own[0].swap(oriented[2 * g]); t.own[1].swap(oriented[2 * g + 1]);
       for (int oi = 0; oi < ds.n; oi++) { t.l1.add(t.own[0]); t.l2.add(t.own[1]); }
-      t.tents.swap(tentsv[g]); t.res = &res[g];
+      t.tents.swap(tentsv[g]); t.res = &res[g]; t.dev = c->dev;
     } else {
       const double m1 = now_ms();
       RegList l1, l2;

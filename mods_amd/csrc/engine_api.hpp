@@ -111,7 +111,8 @@ struct RegList {
   size_t size() const { return n ? end[n - 1] : 0; }
   const modsx_region &operator[](size_t i) const {
     int k = 0;
-    while (i >= end[k]) k++;
+    while (k < n - 1 && i >= end[k]) k++;     // an index past size() is a caller bug: it lands in the last segment and trips the check
+    if (i >= end[k]) abort();
     return p[k][i - (k ? end[k - 1] : 0)];
   }
 };
@@ -129,6 +130,12 @@ struct VerifyTask {
   RegList l1, l2;
   std::vector<modsx_tentative> tents;
   modsx_pair_result *res = nullptr;
+  int dev = 0;        // the device of the context that produced the task: the verifier's device-side loops (rFtH counting) run there
+  VerifyTask() = default;
+  VerifyTask(VerifyTask &&) = default;
+  VerifyTask &operator=(VerifyTask &&) = default;
+  VerifyTask(const VerifyTask &) = delete;              // l1 / l2 point into `own`: a copy would dangle
+  VerifyTask &operator=(const VerifyTask &) = delete;
 };
 // deferred == nullptr: verification runs inline, pair by pair.  Otherwise the G matching problems share the matcher's
 // launches and one VerifyTask per pair is appended to *deferred instead of being verified.

@@ -559,7 +559,7 @@ static int accumulate_views(modsx_ctx *c, LadderClass *const *ks, const DescSet 
       }
     }
   };
-  static const bool noSplit = getenv("MODSX_PAIR_NOSPLIT") != nullptr;
+  const bool noSplit = getenv("MODSX_PAIR_NOSPLIT") != nullptr;   // read per call: bench.py switches it on for its one-stream leg
   static const double splitBias = getenv("MODSX_SPLIT_BIAS") ? atof(getenv("MODSX_SPLIT_BIAS")) : 0.25;   // a view's fixed cost, in untilted-view areas
   static const int nParts = getenv("MODSX_PAIR_PARTS") ? std::max(1, std::min(8, atoi(getenv("MODSX_PAIR_PARTS")))) : 3;   // 31 views: 2 / 3 / 4 parts 13.7 / 12.8 / 13.1 ms per pair
   if (split && !cm && !noSplit && nParts > 1 && nv >= 6 * nParts) {
@@ -717,7 +717,7 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
       // overlaps the kernels of the other (31 views: 42 -> 32 ms per pair).  Only when this is the one ladder running in the
       // process: with many contexts at work the GPU is already full and the extra streams and scratch cost throughput
       // (16 workers: 123 -> 77 pairs/s).  MODSX_PAIR_SERIAL=1 keeps one stream (measurements).
-      static const bool serialEnv = getenv("MODSX_PAIR_SERIAL") != nullptr;
+      const bool serialEnv = getenv("MODSX_PAIR_SERIAL") != nullptr;   // read per call (see MODSX_PAIR_NOSPLIT)
       const bool serial = serialEnv || !alone || cm;   // a sharded ladder issues its collectives from one thread, in one order
       int rc0 = MODSX_OK, rc1 = MODSX_OK;
       std::string err1;
@@ -794,7 +794,7 @@ int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2,
           defer->own.emplace_back(std::move(k.regs[0])); defer->l1.add(defer->own.back());
           defer->own.emplace_back(std::move(k.regs[1])); defer->l2.add(defer->own.back());
         }
-      defer->tents = std::move(tents); defer->res = res;
+      defer->tents = std::move(tents); defer->res = res; defer->dev = c->dev;
       step++;
       break;
     }

@@ -560,10 +560,23 @@ struct RfthDevice {
     // the highest priority: a batch is a few wavefronts that must not queue behind the launch sets of 16 contexts
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) return false;
-    if (!pinned((void **)&hPairs, (void **)&dPairs, BATCH * 8) || !pinned((void **)&hCnt, (void **)&dCnt, BATCH * 4)) return false;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); s = nullptr; return false; }
+    if (!pinned((void **)&hPairs, (void **)&dPairs, BATCH * 8) || !pinned((void **)&hCnt, (void **)&dCnt, BATCH * 4)) {
+      (void)hipGetLastError();
+      release();       // a state that failed part-way keeps nothing
+      return false;
+    }
     ok = true;
     return true;
+  }
+  void release() {
+    if (hPairs) hipHostFree(hPairs);
+    if (hCnt) hipHostFree(hCnt);
+    if (hUs) hipHostFree(hUs);
+    if (hUn) hipHostFree(hUn);
+    if (s) hipStreamDestroy(s);
+    hPairs = hCnt = nullptr; hUs = hUn = nullptr; capPts = 0; s = nullptr;
+    (void)hipGetLastError();
   }
   bool points(const double *us, const double *uN, size_t nN) {
     if (nN > capPts) {
@@ -601,7 +614,14 @@ struct RfthLease {
     }
     if (!d) { d = new RfthDevice; d->dev = dev; }
   }
-  ~RfthLease() { std::lock_guard<std::mutex> lk(mu()); idle().push_back(d); }
+  ~RfthLease() {
+    if (d->tried && !d->ok) {      // failed or disagreed: its resources go, and the next loop on this device starts a fresh state
+      const char *e = getenv("MODSX_VERIFY_DEVICE");
+      if (!(e && atoi(e) == 0) && d->dev >= 0) { d->release(); delete d; return; }
+    }
+    std::lock_guard<std::mutex> lk(mu());
+    idle().push_back(d);
+  }
 };
 
 struct RansacF {
@@ -936,6 +956,24 @@ struct RansacF {
       }
       return counted;
     };
+    // the count of a hypothesis alone (the first half of body(), no state touched)
+    auto count_only = [&](unsigned p0, unsigned p1) -> unsigned {
+      double c1[3], c2[3], ec[3], aFt[9], aFtH[9];
+      cross3(c1, &us[6 * p0], &us[6 * p0 + 3]);
+      cross3(c2, &us[6 * p1], &us[6 * p1 + 3]);
+      cross3(ec, c1, c2);
+      const double nrm = sqrt(ec[0] * ec[0] + ec[1] * ec[1] + ec[2] * ec[2]);
+      ec[0] = ec[0] / nrm; ec[1] = ec[1] / nrm; ec[2] = ec[2] / nrm;
+      skew_sym(ec, aFt);
+      mul3(aFtH, aFt, Ht);
+      tr3(aFt, aFtH);
+      FDs(uN.data(), aFt, DsN.data(), (int)nN);
+      unsigned no_i = 0;
+      for (unsigned i = 0; i < nN; ++i) if (DsN[i] < th * 2) ++no_i;
+      return no_i;
+    };
+    const char *chk = getenv("MODSX_VERIFY_DEVICE_CHECK");
+    const bool checkAll = chk && atoi(chk) != 0;
     unsigned no_sam = 1;
     struct LoopClock {
       std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -958,6 +996,16 @@ struct RansacF {
         A.B = (int)B;
         if (!D.count(A)) { D.ok = false; dev = false; break; }      // a HIP error: the rest of the loop (and of the thread's calls) on the host
         g_rfthStats[0]++; g_rfthStats[1] += B;
+        if (checkAll) {
+          // MODSX_VERIFY_DEVICE_CHECK=1: the whole batch is counted again on the host -- a device UNDER-count would otherwise skip
+          // a state change silently (only the hypotheses the device flags are re-run below)
+          GlibcRandom g3 = rng;
+          std::vector<unsigned> ptr3 = ptr;
+          for (unsigned j = 0; j < B; ++j) {
+            draw(g3, ptr3);
+            if (count_only(ptr3[0], ptr3[1]) != D.hCnt[j]) g_rfthStats[3]++;
+          }
+        }
         unsigned hit = B;
         for (unsigned j = 0; j < B; ++j) if (D.hCnt[j] > m_i) { hit = j; break; }
         if (hit == B) { rng = g2; ptr.swap(ptr2); no_sam += B; continue; }      // nothing in the batch changes the state

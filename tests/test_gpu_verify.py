@@ -62,3 +62,19 @@ def test_many_off_plane_correspondences_go_through_several_lds_tiles(modsx, orac
         _same(a, b)
     st = modsx.verify_device_stats()
     assert st["disagreements"] == 0 and st["batches"] > 0, st
+
+
+def test_every_device_count_of_a_batch_equals_the_host_count(modsx, oracle, ctx, monkeypatch):
+    """MODSX_VERIFY_DEVICE_CHECK=1: every hypothesis of every batch is counted again by the host's FDs -- not only the ones the
+    device flags.  A device under-count (different f64 rounding in sqrt / division / operation order) would otherwise skip a state
+    change without a trace; here it would show up as a disagreement."""
+    need_ref(oracle)
+    monkeypatch.setenv("MODSX_VERIFY_DEVICE_CHECK", "1")
+    modsx.verify_device_stats(reset=True)
+    for seed, frac, n_out in ((1, 0.8, 150), (2, 1.0, 200), (11, 0.6, 1500)):
+        pts, laf = synth_two_view(seed, planar_frac=frac, n_in=350, n_out=n_out)
+        a = oracle.loransac_f(pts, laf, laf, seed=seed, max_samples=20000)
+        b = modsx.loransac_f(pts, laf, laf, seed=seed, max_samples=20000)
+        _same(a, b)
+    st = modsx.verify_device_stats()
+    assert st["disagreements"] == 0 and st["hypotheses"] > 20000, st

@@ -3,7 +3,7 @@
 # what is to be judged into profiles/).  Kernel-trace summaries and counter passes are separate rocprofv3 runs; counter
 # passes use --kernel-trace only.
 R=$GRAFT_REPO_ROOT
-TAG=${ROUND_TAG:-r04}
+TAG=${ROUND_TAG:-r05}
 OUT=$R/gpurun_out/profiles
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -68,6 +68,18 @@ try:   # the describe chunk of the profiled run: its algorithmic bytes (bench.py
     t["describe_chunk_algorithmic_bytes"] = json.loads(line)["roofline_describe"]["algorithmic_work_per_launch"]
 except Exception as e:
     print("no roofline_describe in the fetch pass:", e)
+if mm:
+    t["k_match_compulsory_bytes"] = (int(mm.group(1)) + int(mm.group(2))) * 128 + int(mm.group(1)) * 32
+try:   # HBM bytes of the whole pipeline per pair: every kernel's FETCH_SIZE x2 + WRITE_SIZE of the one-stream pass over its pairs
+    tot = 0
+    for ln in open("$OUT/${TAG}_pmc_hbm.txt"):
+        if ln.startswith("#") or ln.startswith("kernel"): continue
+        p = ln.rstrip().rsplit(None, 4)
+        if len(p) == 5: tot += float(p[1]) * (float(p[3]) + float(p[4])) if p[1].replace(".", "").isdigit() else 0
+    npairs = 3 * 4      # bench.py $ONE: (1 warm-up + 2 steps) x 4 pairs
+    t["hbm_counter_GB_per_pair"] = tot / npairs / 1e9
+except Exception as e:
+    print("no per-pair total:", e)
 t["k_match_problem"] = ("%s x %s real 31-view descriptors (tools/bench_match.py --tilts 1,2,4,6,8 --phi 120)" % (mm.group(1), mm.group(2))) if mm else "24 k x 24 k real 31-view descriptors"
 json.dump(dict(sorted(t.items())), open("$OUT/pmc_traffic_${TAG}.json", "w"), indent=1)
 PY
