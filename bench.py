@@ -245,6 +245,7 @@ class ShardGroup:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--step-barrier", action="store_true", help="a host-side barrier after every timed step (the form of rounds 1-4)")
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=768)
@@ -381,7 +382,30 @@ def main():
 
     host_cpu = {}
 
-    def timed(run, warmup, steps, g=None):
+    def run_steps_back_to_back(nsteps, i1=imgs1, i2=imgs2, cx=ctxs):
+        """K steps of the default (multi-view, pair-sharded) workload issued back to back: every context goes from the last
+        pair of step k straight to the first of step k + 1, as a training loop issues its steps without a host-side barrier
+        between them.  The work is that of K calls of run_batch; what goes away is the idle tail of each step (the last pairs
+        finishing while most contexts wait for the step's barrier).  Returns the K steps' result lists."""
+        n = len(i1)
+        nxt = itertools.count()
+        lock = threading.Lock()
+
+        def work(w):
+            out = []
+            while True:
+                with lock:
+                    k = next(nxt)
+                if k >= nsteps * n:
+                    return out
+                out.append((k, cx[w].match_pair_views(i1[k % n], i2[k % n], views, params)))
+        res = [[None] * n for _ in range(nsteps)]
+        for part in pool.map(work, range(len(cx))):
+            for k, r in part:
+                res[k // n][k % n] = r
+        return res
+
+    def timed(run, warmup, steps, g=None, back_to_back=False):
         results = None
         for _ in range(warmup):
             results = run()
@@ -389,8 +413,7 @@ def main():
         ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         nd = 0
-        for _ in range(steps):
-            results = run()
+        for results in (run_steps_back_to_back(steps) if back_to_back else (run() for _ in range(steps))):
             for r in results:
                 if r is not None:
                     nd += r["n_regions"][0] + r["n_regions"][1]
@@ -409,7 +432,16 @@ def main():
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         return float(tmax[0]), float(tsum[1])
 
-    elapsed, ndesc, results = timed(run_batch, args.warmup, args.steps, group)
+    # the K timed steps are bracketed by a barrier + synchronize on both sides; the default workload issues them back to back
+    # (--step-barrier: a host-side barrier after every step, the form of rounds 1-4, whose figure stays in the line beside it)
+    b2b = group is None and not single_view and not args.batch_api and lsteps is None and not args.step_barrier
+    elapsed, ndesc, results = timed(run_batch, args.warmup, args.steps, group, back_to_back=b2b)
+    barrier_form = None
+    if b2b:
+        eb, nb_, _ = timed(run_batch, 0, args.steps, group)
+        eb, nb_ = reduce_over_ranks(eb, nb_)
+        barrier_form = {"value": args.steps * world * nbatch / eb, "unit": "image-pairs/s", "ms_per_step": 1e3 * eb / args.steps,
+                        "note": "the same K steps with a host-side barrier after every step (rounds 1-4 reported this form)"}
     res = next((r for r in results if r is not None), None)
     verify_timed = mods_amd.last_batch_verify() if single_view else None   # host share of the last batch of the timed region
     elapsed, ndesc_total = reduce_over_ranks(elapsed, ndesc)
@@ -571,6 +603,11 @@ def main():
         }
         # the same figure under a key that never changes meaning: with N > 1 `value` becomes the view-sharded one (below)
         out["value_pair_sharded"] = value
+        out["steps_issue"] = ("back to back: a context goes from the last pair of step k to the first of step k + 1, no host-side barrier "
+                              "between the K timed steps (barrier + synchronize before the first and after the last)") if b2b else \
+                             "a host-side barrier after every step"
+        if barrier_form is not None:
+            out["value_with_step_barrier"] = barrier_form
         if host_cpu.get("s") is not None:
             # rank 0's own threads (workers, verification helpers, host pool) over its share of the timed pairs: on a node where N ranks
             # share one host, N times this figure per second of throughput is what the host has to supply

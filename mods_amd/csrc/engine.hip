@@ -228,7 +228,8 @@ modsx_ctx *ctx_create(int device_id) {
       std::call_once(once[device_id], [device_id] {
         const char *e = getenv("MODSX_SYNC");
         if (e && !strcmp(e, "spin")) return;
-        if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) {
+        const unsigned flag = (e && !strcmp(e, "yield")) ? hipDeviceScheduleYield : hipDeviceScheduleBlockingSync;
+        if (hipSetDeviceFlags(flag) != hipSuccess) {
           (void)hipGetLastError();
           fprintf(stderr, "modsx: hipSetDeviceFlags(hipDeviceScheduleBlockingSync) failed on device %d; host threads will spin-wait\n", device_id);
         }
@@ -1343,6 +1344,8 @@ int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int
   if (!(sqminratio < 1.0)) { set_error("match ratio >= 1 (PDF mode of MatchFlannFGINN) is not supported"); return MODSX_ERR_ARG; }
   // nn = neighbours the walk may look at (default 50, matching.hpp:268-269); the event lists of the device matcher hold up to MATCH_NN_MAX groups
   if (nn < 2 || nn > MATCH_NN_MAX) { set_error("match: nn must be in [2, 256]"); return MODSX_ERR_ARG; }
+  for (int i = 0; i < nb; i++)      // the matcher logs train tiles as 16-bit numbers (kernels_match.hip k_match_resolve)
+    if (n2[i] > 2000000) { set_error("match: more than 2 000 000 train descriptors in one problem"); return MODSX_ERR_ARG; }
   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
   if (shard) {
     // view-sharded run (engine_shard.hip): this rank matches the query rows [lo, lo + per) of ONE problem; the result rows

@@ -117,10 +117,11 @@ struct MatchGeom {
 // Sweep 2 runs over the UNDECIDED queries only, whose number the host does not know at launch time.  Every workgroup of a fixed
 // one-round launch therefore derives the split geometry from the device-side count: the NW workgroups are dealt out as
 // (query block, split) with as many splits as fill the machine once.  k_match_events uses the same function.
+constexpr int RESOLVE_NW = 256;            // workgroups of k_match_resolve that hold a (query block, split)
 struct Sweep2Geom { int nQB, S, tilesPerSplit; };
 MX_HD Sweep2Geom sweep2_geom(int nUnd, int ntiles, int qs) {
   Sweep2Geom G;
-  const int QPB = qpb_of(qs), SWEEP2_NW = 256 * sweep_wps(qs);    // one round of workgroups
+  const int QPB = qpb_of(qs), SWEEP2_NW = RESOLVE_NW;    // one workgroup per CU: its LDS leaves room for little more
   G.nQB = (nUnd + QPB - 1) / QPB;
   int S = G.nQB > 0 ? SWEEP2_NW / G.nQB : 1;
   if (S > ntiles / MINT) S = ntiles / MINT;
@@ -754,7 +755,7 @@ struct ResolveEpi {
   static constexpr int CH = RCHUNK;
   int m1[QSETS], I1[QSETS], thr[QSETS], nev[QSETS];
   int TEp, hi, stream0;                    // stream0: stream index of this lane's query set 0 (sets are 64 streams apart)
-  int (*evt)[EVS];
+  unsigned short (*evt)[EVS];
   MX_D int kv(int v) const { return ((v >= TEp ? 1 : 0) << 8) | ((v % RCHUNK + 1) << 4); }
   MX_D void chain(const v16i &acc, int kvb, int s, int tile) {
     v16i k;
@@ -762,7 +763,7 @@ struct ResolveEpi {
     for (int r = 0; r < 16; r++) k[r] = (acc[r] << 9) + (kvb + r);
     const int t = tree_min16(k);
     if (t < thr[s]) {
-      if (nev[s] < EVS) evt[stream0 + 64 * s][nev[s]] = tile;
+      if (nev[s] < EVS) evt[stream0 + 64 * s][nev[s]] = (unsigned short)tile;
       nev[s]++;
     } else m1[s] = min(m1[s], t);
   }
@@ -779,9 +780,9 @@ struct ResolveEpi {
 template <int QSETS>
 __device__ __forceinline__ void resolve_body(const ResolveArgs &A) {
   constexpr int QPB = qpb_of(QSETS);
-  constexpr int EVS = 8192 / (2 * QPB);                // slots per stream: 16 (QSETS 2) / 8 (QSETS 4), 32 KB of LDS either way
+  constexpr int EVS = 8192 / (2 * QPB);                // slots per stream: 16 (QSETS 2) / 8 (QSETS 4), 16 KB of LDS either way
   __shared__ __attribute__((aligned(16))) unsigned char sm[2][STAGE_B];
-  __shared__ int sEvt[2 * QPB][EVS];                   // logged groups (virtual tiles) per stream = (query in block) * 2 + half
+  __shared__ unsigned short sEvt[2 * QPB][EVS];        // logged groups (virtual tiles < 65536: the launcher's limit) per stream = (query in block) * 2 + half
   __shared__ UndRec sU[QPB];
   __shared__ int sEv[QPB], sNless[QPB], sNbad[QPB];
   __shared__ u64 sCand[QPB];                           // (distance, train)
@@ -1059,7 +1060,7 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
     maxN1 = std::max(maxN1, n1[i]); maxS = std::max(maxS, L.S); maxWg = std::max(maxWg, (n2[i] + PB - 1) / PB);
   }
   hipLaunchKernelGGL(k_match_pack, dim3(std::max((maxN1 + 31) / 32, maxWg), 2, nb), dim3(256), 0, s, b);
-  const int QPB = qpb_of(qs), NW2 = 256 * sweep_wps(qs);
+  const int QPB = qpb_of(qs), NW2 = RESOLVE_NW;
   const dim3 grid((maxN1 + QPB - 1) / QPB, maxS, nb);
   if (evSweep1) hipEventRecord(evSweep1[0], s);
   if (qs == 4) hipLaunchKernelGGL(k_match_sweep1<4>, grid, dim3(256), 0, s, b);
