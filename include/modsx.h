@@ -253,7 +253,8 @@ int modsx_describe_regions(modsx_ctx *ctx, const modsx_image *img, const modsx_r
  * matching/matching.hpp:268-269, .cpp:357-461 with vector_matcher = linear, vector_dist = L2.
  * desc*: [n][128] f32 holding integers 0..255 (anything else -- fractions, out-of-range values, NaN -- is refused with
  * MODSX_ERR_ARG: the int8 matrix-core path is exact only on that domain); pos2: [n2][2] reproj_kp x,y of list2.
- * A ratio >= 1 (the PDF branch, matching.cpp:397-428, unused by every shipped configuration) is refused as well.
+ * A ratio >= 1 takes the reference's "all points" branch (matching.cpp:397-428): a record per query, closed by its first
+ * contradictive neighbour or by neighbour nn - 1 (no ratio test).
  * nn must lie in [2, 256] (the reference takes any nn, default 50; the device walk lists fewer than nn groups of trains per
  * query, in 256 slots): other values return MODSX_ERR_ARG on every match path, the sharded and fused ones included.
  * Images must have at least 2 rows and 2 columns (modsx_image_upload / modsx_image_wrap_device refuse smaller ones). */

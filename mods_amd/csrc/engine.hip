@@ -1341,7 +1341,7 @@ int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int
   if (nb < 1 || nb > MATCH_MAXB) { set_error("match_device_batch: batch size"); return MODSX_ERR_ARG; }
   hipStream_t s = c->stream;
   const double sqminratio = ratioT * ratioT, contrDistSq = contradDist * contradDist;
-  if (!(sqminratio < 1.0)) { set_error("match ratio >= 1 (PDF mode of MatchFlannFGINN) is not supported"); return MODSX_ERR_ARG; }
+  if (!(sqminratio == sqminratio)) { set_error("match ratio is NaN"); return MODSX_ERR_ARG; }   // ratio >= 1: the "all points" branch (matching.cpp:397-428)
   // nn = neighbours the walk may look at (default 50, matching.hpp:268-269); the event lists of the device matcher hold up to MATCH_NN_MAX groups
   if (nn < 2 || nn > MATCH_NN_MAX) { set_error("match: nn must be in [2, 256]"); return MODSX_ERR_ARG; }
   for (int i = 0; i < nb; i++)      // the matcher logs train tiles as 16-bit numbers (kernels_match.hip k_match_resolve)

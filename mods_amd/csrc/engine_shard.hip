@@ -668,7 +668,7 @@ int match_sharded_batch(modsx_ctx *c, modsx_comm *cm, int nb, const uint8_t *con
   for (int g = 0; g < nb; g++) out[g].clear();
   if (cm->dead.load()) return comm_dead_rc(cm);
   const double sqminratio = ratioT * ratioT, contrDistSq = contradDist * contradDist;
-  if (!(sqminratio < 1.0)) { set_error("match ratio >= 1 (PDF mode of MatchFlannFGINN) is not supported"); return MODSX_ERR_ARG; }
+  if (!(sqminratio == sqminratio)) { set_error("match ratio is NaN"); return MODSX_ERR_ARG; }   // ratio >= 1: the "all points" branch (matching.cpp:397-428)
   if (nn < 2 || nn > MATCH_NN_MAX) { set_error("match: nn must be in [2, 256]"); return MODSX_ERR_ARG; }
   const int W = cm->world, R = cm->rank;
   hipStream_t s = c->stream;

@@ -680,12 +680,14 @@ __device__ __forceinline__ void decide_body(const DecideArgs &A) {
       if (j == 0) { d0 = cd; t0 = ct; x0 = cx; y0 = cy; }
       else {
         if (j == 1) { dd1 = cd; t1 = ct; }
-        if (ratio_pass((float)d0, (float)cd, A.sqminratio)) { res = 1; dj = cd; tj = ct; }
-        else {
-          const double dx = x0 - cx, dy = y0 - cy;
-          if (dx * dx + dy * dy > A.contrDistSq) res = 2;         // first contradictive
-          else if (j >= A.nn - 1) res = 2;                        // the walk looks at nn - 1 neighbours
-        }
+        const double dx = x0 - cx, dy = y0 - cy;
+        const bool far = dx * dx + dy * dy > A.contrDistSq;
+        if (A.sqminratio >= 1.0) {
+          // "to get all points" (matching.cpp:397-428): the record is closed by the first contradictive neighbour or by the last one
+          if (far || j == A.nn - 1) { res = 1; dj = cd; tj = ct; }
+        } else if (ratio_pass((float)d0, (float)cd, A.sqminratio)) { res = 1; dj = cd; tj = ct; }
+        else if (far) res = 2;                                    // first contradictive
+        else if (j >= A.nn - 1) res = 2;                          // the walk looks at nn - 1 neighbours
       }
       j++;
     } else if (mrec < usable) {
@@ -700,10 +702,10 @@ __device__ __forceinline__ void decide_body(const DecideArgs &A) {
     o.t0 = t0; o.t1 = t1; o.tj = -1; o.nless = 0; o.nbad = 0;
     o.d0 = (float)d0; o.d1 = (float)dd1; o.dj = 0.f;
     int dm = 0;
-    if (res == 1) { o.tj = tj; o.dj = (float)dj; o.nless = j - 2; }
+    if (res == 1) { o.tj = tj; o.dj = (float)dj; o.nless = A.sqminratio >= 1.0 ? 0 : j - 2; }
     else if (res == 2) o.nbad = t1 < 0 ? 0 : 1;
     else if (t0 >= 0) {
-      dm = ratio_dmin(d0, A.sqminratio);
+      dm = A.sqminratio >= 1.0 ? 0 : ratio_dmin(d0, A.sqminratio);      // all-points mode: k_match_pdf redoes the query's walk
       if (dm <= MAXD) {          // otherwise no distance can pass the ratio test: the walk ends without a match
         const int k = atomicAdd(&sCount, 1);
         sList[k] = q;
@@ -912,10 +914,94 @@ __device__ __forceinline__ void resolve_body(const ResolveArgs &A) {
   }
 }
 
+// ---------------- the "all points" mode (ratio >= 1, matching.cpp:397-428) for the queries k_match_decide could not finish -----------
+// Every query gives a record there, closed by its first contradictive neighbour or by neighbour nn - 1: a query whose first
+// neighbours all sit at NN0's place needs its exact sorted list down to rank nn - 1, which no reduction of the sweeps holds.
+// A niche mode ("for example, for calculating PDF"), so exactness comes before speed: a workgroup takes an undecided query,
+// writes the exact distance of every slot to its scratch row (a quarter wave per group of 16 rows) and then extracts the
+// neighbours one by one, each the smallest (distance, slot) above the last, until the walk's rule closes the record.
+struct PdfArgs {
+  const uint8_t *d1;
+  const int *norm2, *perm;
+  const unsigned char *tiles;
+  const TileGeo *geo;
+  MatchGeom g;
+  const double2 *pos2p;
+  double contrDistSq;
+  int nn;
+  const UndRec *und;
+  const int *nUndecided;
+  MatchRow *rows;
+  int *scratch;           // PDF_NW rows of 2 * offT * 32 distances
+};
+constexpr int PDF_NW = 64;
+__device__ __forceinline__ void pdf_body(const PdfArgs &A) {
+  __shared__ u64 sRed[4];
+  __shared__ int sStop;
+  const MatchGeom g = A.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l = tid & 15, qw = tid >> 4;
+  const int nQ = *A.nUndecided;
+  const int TEp = A.geo->TEp, ntilesV = A.geo->ntilesV;
+  int *dist = A.scratch + (size_t)blockIdx.x * (size_t)g.ntilesUB * 32;       // by VIRTUAL slot
+  constexpr u64 INF = ~0ull;
+  for (int u = blockIdx.x; u < nQ; u += PDF_NW) {
+    const UndRec r = A.und[u];
+    __syncthreads();                       // the scratch row of the previous query is no longer read
+    for (int grp = qw; grp < 2 * ntilesV; grp += 16) {
+      int vslot, pslot, t;
+      const int d = group_dist16(A.d1 + (size_t)r.q * 128, r.na, A.tiles, A.norm2, A.perm, phys_tile(grp >> 1, TEp, g.offT), grp >> 1, grp & 1,
+                                 l, &vslot, &pslot, &t);
+      dist[vslot] = d;                     // BIG for a padding row
+    }
+    __threadfence_block();
+    __syncthreads();
+    // the walk: neighbour j = the smallest (distance, slot) above neighbour j - 1
+    u64 last = 0;
+    bool first = true;
+    int d0 = 0, dj = 0, tj = -1, dd1 = 0, t1 = -1, t0 = -1, j = 0, closed = 0;
+    double x0 = 0, y0 = 0;
+    const int nslots = ntilesV * 32;
+    for (j = 0; j < A.nn && !closed; j++) {
+      u64 best = INF;
+      for (int s = tid; s < nslots; s += 256) {
+        const int d = dist[s];
+        if (d == BIG) continue;
+        const u64 k = key64(d, s);
+        if ((first || k > last) && k < best) best = k;
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) best = min(best, shfl_xor64(best, m));
+      if (lane == 0) sRed[wave] = best;
+      __syncthreads();
+      best = min(min(sRed[0], sRed[1]), min(sRed[2], sRed[3]));
+      __syncthreads();
+      if (best == INF) { closed = 2; break; }            // fewer than nn trains: the reference would read past its list
+      last = best; first = false;
+      const int cd = (int)(best >> 32), cs = (int)(unsigned)best;
+      const int pslot = phys_tile(cs >> 5, TEp, g.offT) * 32 + (cs & 31);
+      const int ct = A.perm[pslot];
+      const double2 xy = A.pos2p[pslot];
+      if (j == 0) { d0 = cd; t0 = ct; x0 = xy.x; y0 = xy.y; }
+      else {
+        if (j == 1) { dd1 = cd; t1 = ct; }
+        const double dx = x0 - xy.x, dy = y0 - xy.y;
+        if (j == A.nn - 1 || dx * dx + dy * dy > A.contrDistSq) { closed = 1; dj = cd; tj = ct; }
+      }
+    }
+    if (tid == 0) {
+      MatchRow o;
+      o.t0 = t0; o.t1 = t1; o.nless = 0; o.nbad = 0; o.tj = closed == 1 ? tj : -1;
+      o.dj = closed == 1 ? (float)dj : 0.f; o.d0 = (float)d0; o.d1 = (float)dd1;
+      A.rows[r.q] = o;
+    }
+    (void)sStop;
+  }
+}
+
 // ---- workspace layout: ONE description used by the size query and by the launcher -------------------------------------------
 struct MatchLayout {
   int S, tilesPerSplit, ntilesUB, offT;
-  size_t norm1, norm2, hrow, perm, pos2p, tiles, status, geo, partial, dmin, undecided, x0y0, und, counter, bytes;
+  size_t norm1, norm2, hrow, perm, pos2p, tiles, status, geo, partial, dmin, undecided, x0y0, und, pdf, counter, bytes;
 };
 static MatchLayout match_layout(int n1, int n2, int qs) {
   MatchLayout L;
@@ -953,6 +1039,7 @@ static MatchLayout match_layout(int n1, int n2, int qs) {
   L.undecided = take((size_t)n1 * 4);
   L.x0y0 = take((size_t)n1 * 16);
   L.und = take((size_t)n1 * 32);
+  L.pdf = take((size_t)PDF_NW * ntiles * 32 * 4);      // k_match_pdf's scratch rows (the ratio >= 1 mode)
   L.counter = take(64);
   L.bytes = w;
   return L;
@@ -964,7 +1051,7 @@ size_t match_workspace_bytes(int n1, int n2) { return std::max(match_layout(n1, 
 struct MatchProblem {
   const uint8_t *d1, *d2;
   const double *pos2;
-  int *norm1, *norm2, *hrow, *perm, *dmin, *undecided, *counter;
+  int *norm1, *norm2, *hrow, *perm, *dmin, *undecided, *counter, *pdf;
   double2 *pos2p;
   double *x0y0;
   u64 *status;
@@ -1030,6 +1117,13 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchBatch b, double cont
   A.pos2p = P.pos2p; A.contrDistSq = contrDistSq; A.nn = nn; A.und = P.und; A.nUndecided = P.counter; A.rows = P.rows;
   resolve_body<QS>(A);
 }
+__global__ __launch_bounds__(256) void k_match_pdf(MatchBatch b, double contrDistSq, int nn) {
+  const MatchProblem &P = b.p[blockIdx.z];
+  PdfArgs A;
+  A.d1 = P.d1; A.norm2 = P.norm2; A.perm = P.perm; A.tiles = P.tiles; A.geo = P.geo; A.g = P.g; A.pos2p = P.pos2p;
+  A.contrDistSq = contrDistSq; A.nn = nn; A.und = P.und; A.nUndecided = P.counter; A.rows = P.rows; A.scratch = P.pdf;
+  pdf_body(A);
+}
 // Problems with n1 == 0 or n2 == 0 must be left out by the caller.  workspace[i] holds match_workspace_bytes(n1[i], n2[i]).
 void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
                         const double *const *pos2, double sqminratio, double contrDistSq, int nn, MatchRow *const *rows,
@@ -1055,7 +1149,7 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
     P.tiles = (unsigned char *)(w + L.tiles);
     P.partial = (int2 *)(w + L.partial);
     P.dmin = (int *)(w + L.dmin); P.undecided = (int *)(w + L.undecided); P.x0y0 = (double *)(w + L.x0y0);
-    P.counter = (int *)(w + L.counter); P.und = (UndRec *)(w + L.und);
+    P.counter = (int *)(w + L.counter); P.und = (UndRec *)(w + L.und); P.pdf = (int *)(w + L.pdf);
     P.d1 = d1[i]; P.d2 = d2[i]; P.pos2 = pos2[i]; P.rows = rows[i];
     maxN1 = std::max(maxN1, n1[i]); maxS = std::max(maxS, L.S); maxWg = std::max(maxWg, (n2[i] + PB - 1) / PB);
   }
@@ -1070,7 +1164,8 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
   // sweep 2: one round of workgroups dealt out on the device as (undecided block, split); more only if there could be more
   // undecided query blocks than that
   const dim3 grid2(std::max(NW2, (maxN1 + QPB - 1) / QPB), 1, nb);
-  if (qs == 4) hipLaunchKernelGGL(k_match_resolve<4>, grid2, dim3(256), 0, s, b, contrDistSq, nn);
+  if (sqminratio >= 1.0) hipLaunchKernelGGL(k_match_pdf, dim3(PDF_NW, 1, nb), dim3(256), 0, s, b, contrDistSq, nn);
+  else if (qs == 4) hipLaunchKernelGGL(k_match_resolve<4>, grid2, dim3(256), 0, s, b, contrDistSq, nn);
   else hipLaunchKernelGGL(k_match_resolve<2>, grid2, dim3(256), 0, s, b, contrDistSq, nn);
 }
 

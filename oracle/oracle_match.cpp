@@ -150,6 +150,23 @@ int orc_match_fginn(const float *desc1, int n1, const float *desc2, int n2, int 
     for (int j = 1; j < nn; j++) {
       if (ir[j] < 0) break; /* fewer than nn trains: the reference would read garbage */
       double ratio = dr[0] / dr[j];
+      if (sqminratio >= 1.0) {
+        /* "to get all points (for example, for calculating PDF)", matching.cpp:397-428: every query gives a record, closed by its
+         * first contradictive neighbour or by the last one looked at; the ratio test is commented out there */
+        double dx = pos2[2 * ir[0]] - pos2[2 * ir[j]], dy = pos2[2 * ir[0] + 1] - pos2[2 * ir[j] + 1];
+        if (j == nn - 1 || dx * dx + dy * dy > contrDistSq) {
+          if (matches < cap) {
+            orc_tentative t;
+            t.q = i; t.t0 = ir[0]; t.tj = ir[j]; t.t1 = ir[1];
+            t.d1 = dr[0]; t.d2 = dr[j]; t.d2by2ndcl = dr[1];
+            t.ratio = sqrt(ratio);
+            out[matches] = t;
+          }
+          matches++;
+          break;
+        }
+        continue;
+      }
       if (ratio <= sqminratio) {
         if (matches < cap) {
           orc_tentative t;

@@ -54,6 +54,7 @@ def ratio_pass(d0, d, sq):
 
 
 def match_rows(d1, d2, pos2, ratio=0.8, contrad=30.0, nn=50, K=4, S=None, stats=None):
+    pdf = ratio >= 1.0      # matching.cpp:397-428: a record per query, closed by the first contradictive neighbour or the last one
     d1 = np.asarray(d1).astype(np.int64)
     d2 = np.asarray(d2).astype(np.int64)
     n1, n2 = len(d1), len(d2)
@@ -99,7 +100,11 @@ def match_rows(d1, d2, pos2, ratio=0.8, contrad=30.0, nn=50, K=4, S=None, stats=
                 used.add(c[1])
                 nbr.append(c)
                 j = len(nbr) - 1
-                if j >= 1:
+                if j >= 1 and pdf:
+                    p0, pj = pos2[perm[nbr[0][1]]], pos2[perm[c[1]]]
+                    if j == nn - 1 or ((p0 - pj) ** 2).sum() > cd2:
+                        res = ("accept", j)
+                elif j >= 1:
                     if ratio_pass(nbr[0][0], c[0], sq):
                         res = ("accept", j)
                     else:
@@ -146,6 +151,12 @@ def match_rows(d1, d2, pos2, ratio=0.8, contrad=30.0, nn=50, K=4, S=None, stats=
             for t in order:
                 if t == t0:
                     continue
+                if pdf:      # device: k_match_pdf walks the query's whole sorted list
+                    if nless + 1 == nn - 1 or ((pos2[t0] - pos2[t]) ** 2).sum() > cd2:
+                        row["tj"], row["dj"] = int(t), float(Dq[t])
+                        break
+                    nless += 1
+                    continue
                 if ratio_pass(d0, Dq[t], sq):
                     row["tj"], row["dj"] = int(t), float(Dq[t])
                     break
@@ -163,6 +174,7 @@ def rows_to_tentatives(rows, nn):
     for r in rows:
         if r["t0"] < 0 or r["tj"] < 0 or r["nbad"] != 0 or r["nless"] > nn - 2:
             continue
-        ratio = np.float64(np.float32(r["d0"]) / np.float32(r["dj"])) if r["dj"] != 0 else np.float64("nan")
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ratio = np.float64(np.float32(r["d0"]) / np.float32(r["dj"]))
         t.append((r["q"], r["t0"], r["tj"], r["t1"], r["d0"], r["dj"], r["d1"], np.sqrt(ratio)))
     return t

@@ -278,9 +278,36 @@ def test_match_fginn_ties_ranks_and_ragged_sizes(ctx, oracle):
         with pytest.raises(RuntimeError):
             ctx.match_fginn(bad.astype(np.float32), d, p2)
     with pytest.raises(RuntimeError):
-        ctx.match_fginn(d, d, p2, ratio=1.2)          # the "PDF" branch of MatchFlannFGINN (matching.cpp:397-428)
-    with pytest.raises(RuntimeError):
         ctx.match_fginn(d, d, p2, nn=300)             # the walk handles nn up to 256 (the reference's default is 50)
+
+
+def test_match_fginn_all_points_mode(ctx, oracle, small_pair):
+    """ratio >= 1: the "to get all points (for example, for calculating PDF)" branch of MatchFlannFGINN (matching.cpp:397-428) -- a
+    record per query, closed by its first contradictive neighbour or by neighbour nn - 1.  Real descriptors, and runs of
+    near-duplicates at one place whose walks go down to rank nn - 1 (k_match_pdf: the query's exact sorted list)."""
+    a, b, _ = small_pair
+    _, r1, d1 = oracle_features(oracle, a)
+    _, r2, d2 = oracle_features(oracle, b)
+    pos2 = np.stack([r2["reproj_kp"]["x"], r2["reproj_kp"]["y"]], 1)
+    for ratio, cd, nn in ((1.0, 30.0, 50), (1.3, 5.0, 20), (1.0, 1000.0, 12)):
+        ref = oracle.match_fginn(d1, d2, pos2, ratio, cd, nn)
+        assert len(ref) == len(d1)
+        _check_tents(ctx.match_fginn(d1, d2, pos2, ratio, cd, nn), ref)
+    rs = np.random.RandomState(5)
+    n1, n2 = 300, 3000
+    e2 = rs.randint(1, 90, (n2, 128)).astype(np.float32)
+    e1 = rs.randint(1, 90, (n1, 128)).astype(np.float32)
+    p2 = rs.uniform(0, 300, (n2, 2))
+    for q in range(0, n1, 2):
+        k = int(rs.randint(2, 60))
+        start = int(rs.randint(0, n2 - k))
+        e2[start:start + k] = np.clip(e1[q][None, :] + rs.randint(-2, 3, (k, 128)), 1, 255)
+        p2[start:start + k] = p2[start] + rs.uniform(-3, 3, (k, 2))
+    e2[7] = e2[8]                                                   # an exact tie
+    for ratio, cd, nn in ((1.0, 30.0, 50), (1.5, 10.0, 8), (1.0, 500.0, 100)):
+        _check_tents(ctx.match_fginn(e1, e2, p2, ratio, cd, nn), oracle.match_fginn(e1, e2, p2, ratio, cd, nn))
+    # fewer than nn trains: a walk that never meets a contradictive neighbour runs off the list and leaves no record
+    _check_tents(ctx.match_fginn(e1[:40], e2[:30], p2[:30], 1.0, 1e6, 50), oracle.match_fginn(e1[:40], e2[:30], p2[:30], 1.0, 1e6, 50))
 
 
 def test_match_fginn_clustered_near_duplicates_and_split_ranges(ctx, oracle):

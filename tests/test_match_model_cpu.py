@@ -13,7 +13,8 @@ def _cmp(oracle, d1, d2, pos2, ratio, cd, nn=50, K=4, S=None):
     assert len(got) == len(ref)
     for g, r in zip(got, ref):
         assert g[:4] == (r["q"], r["t0"], r["tj"], r["t1"])
-        assert g[4] == r["d1"] and g[5] == r["d2"] and g[6] == r["d2by2ndcl"] and g[7] == r["ratio"]
+        assert g[4] == r["d1"] and g[5] == r["d2"] and g[6] == r["d2by2ndcl"]
+        assert g[7] == r["ratio"] or (np.isnan(g[7]) and np.isnan(r["ratio"]))
 
 
 def test_model_ties_duplicates_ragged(oracle):
@@ -56,3 +57,19 @@ def test_model_clustered_runs_and_splits(oracle):
                 d2[start + k - 1] = d2[start]
         for ratio, cd, nn in ((0.8, 30.0, 50), (0.9, 30.0, 20), (0.8, 2.0, 50)):
             _cmp(oracle, d1, d2, pos2, ratio, cd, nn)
+
+
+def test_model_pdf_mode(oracle):
+    """ratio >= 1 (matching.cpp:397-428): a record per query, closed by its first contradictive neighbour or by neighbour nn - 1"""
+    rs = np.random.RandomState(5)
+    n1, n2 = 60, 1500
+    d2 = rs.randint(0, 90, (n2, 128)).astype(np.float32)
+    d1 = rs.randint(0, 90, (n1, 128)).astype(np.float32)
+    pos2 = rs.uniform(0, 300, (n2, 2))
+    for q in range(0, n1, 2):          # runs of near-duplicates at one place: walks that go deep
+        k = int(rs.randint(2, 30))
+        start = int(rs.randint(0, n2 - k))
+        d2[start:start + k] = np.clip(d1[q][None, :] + rs.randint(-2, 3, (k, 128)), 0, 255)
+        pos2[start:start + k] = pos2[start] + rs.uniform(-3, 3, (k, 2))
+    for ratio, cd, nn in ((1.0, 30.0, 50), (1.5, 10.0, 8), (1.0, 500.0, 12)):
+        _cmp(oracle, d1, d2, pos2, ratio, cd, nn)
