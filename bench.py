@@ -727,6 +727,7 @@ def main():
                 "F": {"pairs_per_s": stF * nbatch / dtF, "verify_ms_per_pair": fms / max(1, fn), "helper_threads": fth,
                       "verified_last_pair": rF[0]["n_verified"],
                       "rfth_loops_per_pair": vst["loops"] / float(stF * nbatch), "rfth_ms_per_loop": 1e-3 * vst["loop_us"] / max(1, vst["loops"]),
+                      "rfth_ms_per_loop_parts": {k: 1e-3 * vst[k + "_us"] / max(1, vst["loops"]) for k in ("draw", "device_wait", "host_phase", "event_body")},
                       "rfth_hypotheses_on_device": vst["hypotheses"], "rfth_device_batches": vst["batches"],
                       "host_ransac_share_of_wall": (fms / max(1, fn)) / max(1, fth) / (dtF / (stF * nbatch) * 1e3)},
                 "note": "DuplicateFiltering + LO-RANSAC run on helper threads beside the device pipeline; share = per-pair verify "

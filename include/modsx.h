@@ -323,6 +323,10 @@ int modsx_loransac_f(const double *pts, const double *laf1, const double *laf2, 
  * anyway.  out[0..6): device batches, hypotheses counted on the device, state-changing hypotheses, host / device disagreements,
  * rFtH loops run (either way) and the microseconds they took (process-wide; reset != 0 clears them).  Returns 6. */
 int modsx_verify_device_stats(long *out, int reset);
+/* out[0..4): microseconds of those loops spent drawing samples ahead of a batch, waiting for the device, in the host phase
+ * (hypotheses that changed nothing, counted on the host at the start of a loop and after every state change) and in the bodies of
+ * state-changing hypotheses.  Process-wide; reset != 0 clears them.  Returns 4. */
+int modsx_verify_device_timing(long *out, int reset);
 
 /* One step of mods.cpp's iteration loop (:229-415) for an identity view: detect + orient + describe both
  * images, match, filter duplicates, verify.  Images and all intermediates stay in HBM between stages. */

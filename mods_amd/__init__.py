@@ -98,7 +98,7 @@ EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "m
            "modsx_match_pair_views_sharded", "modsx_match_pairs_views_sharded", "modsx_match_ladder_sharded", "modsx_comm_loopback_id", "modsx_comm_set_lanes",
            "modsx_comm_attach", "modsx_comm_lane_done", "modsx_comm_reset_lanes", "modsx_comm_set_timeout", "modsx_comm_stats",
            "modsx_shard_block_bytes", "modsx_shard_block_pack", "modsx_shard_blocks_unpack", "modsx_shard_device_pack",
-           "modsx_shard_device_unpack", "modsx_verify_device_stats"]
+           "modsx_shard_device_unpack", "modsx_verify_device_stats", "modsx_verify_device_timing"]
 # include/modsx_degensac.h: the reference's own verification symbols (link-time drop-in for libdegensac)
 EXPORTS_DEGENSAC = ["exp_ransacHcustom", "exp_ransacFcustom", "HDs", "HDsi", "HDsidx", "HDsSym", "HDsiSym", "HDsSymidx",
                     "HDsSymMax", "HDsiSymMax", "HDsSymidxMax", "FDs", "FDsSym", "exFDs", "exFDsSym",
@@ -318,7 +318,11 @@ def verify_device_stats(reset=False):
     """modsx_verify_device_stats: how much of DEGENSAC's rFtH hypothesis loop ran on the device (process-wide counters)."""
     out = (C.c_long * 6)()
     lib().modsx_verify_device_stats(out, int(bool(reset)))
-    return dict(zip(("batches", "hypotheses", "events", "disagreements", "loops", "loop_us"), list(out)))
+    d = dict(zip(("batches", "hypotheses", "events", "disagreements", "loops", "loop_us"), list(out)))
+    t = (C.c_long * 4)()
+    lib().modsx_verify_device_timing(t, int(bool(reset)))
+    d.update(zip(("draw_us", "device_wait_us", "host_phase_us", "event_body_us"), list(t)))
+    return d
 
 
 class RegionClass(C.Structure):

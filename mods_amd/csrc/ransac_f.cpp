@@ -538,7 +538,9 @@ __global__ __launch_bounds__(256) void k_rfth_count(const double *__restrict__ u
 
 // per host thread (the verifier runs on the contexts' helper threads): a stream and the few buffers of the loop, on the
 // thread's current device.  No device (the CPU test container), MODSX_VERIFY_DEVICE=0 or any HIP error: the host loop.
-static std::atomic<long> g_rfthStats[6];   // batches, hypotheses scored on the device, events, host / device disagreements, rFtH loops, their microseconds
+static std::atomic<long> g_rfthStats[10];   // [6..9]: microseconds drawing samples ahead, waiting for the device, in the host phase, in event bodies
+static inline long rfth_us(std::chrono::steady_clock::time_point a) { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - a).count(); }
+//   // batches, hypotheses scored on the device, events, host / device disagreements, rFtH loops, their microseconds
 struct RfthDevice {
   enum { BATCH = 20480 };   // a whole loop (2 x 10^4 hypotheses) in one round trip: speculation past an event costs the device nothing
   bool tried = false, ok = false;
@@ -987,14 +989,36 @@ struct RansacF {
       memcpy(A.Ht, Ht, sizeof Ht);
       A.th2 = th * 2; A.nN = (int)nN;
       std::vector<unsigned> ptr2;
+      // Events (a count above the best so far) come in a burst at the start of a loop -- the best count starts at 4 -- and each one
+      // invalidates the rest of a batch drawn ahead of it: a loop used to take ~5 round trips through a busy device.  So the loop
+      // runs on the host until `quietMin` hypotheses in a row have changed nothing, and only then goes to the device in batches;
+      // an event there sends it back to the host.  (Same samples, same order, same counts: the trajectory does not depend on where
+      // a hypothesis was counted.)
+      static const unsigned quietMin = getenv("MODSX_RFTH_QUIET") ? (unsigned)atoi(getenv("MODSX_RFTH_QUIET")) : 192;
+      unsigned quiet = 0;
       while (dev && no_sam < 2 * max_sam) {
+        if (quiet < quietMin) {
+          const auto th0 = std::chrono::steady_clock::now();
+          draw(rng, ptr);
+          const unsigned before = m_i;
+          body();
+          ++no_sam;
+          quiet = m_i != before ? 0 : quiet + 1;
+          g_rfthStats[m_i != before ? 9 : 8] += rfth_us(th0);
+          continue;
+        }
         // the next B samples from a copy of the generator and of the permutation
         const unsigned B = std::min<unsigned>(RfthDevice::BATCH, 2 * max_sam - no_sam);
+        const auto td0 = std::chrono::steady_clock::now();
         GlibcRandom g2 = rng;
         ptr2 = ptr;
         for (unsigned j = 0; j < B; ++j) { draw(g2, ptr2); D.hPairs[2 * j] = ptr2[0]; D.hPairs[2 * j + 1] = ptr2[1]; }
         A.B = (int)B;
-        if (!D.count(A)) { D.ok = false; dev = false; break; }      // a HIP error: the rest of the loop (and of the thread's calls) on the host
+        g_rfthStats[6] += rfth_us(td0);
+        const auto tw0 = std::chrono::steady_clock::now();
+        const bool okc = D.count(A);
+        g_rfthStats[7] += rfth_us(tw0);
+        if (!okc) { D.ok = false; dev = false; break; }      // a HIP error: the rest of the loop (and of the thread's calls) on the host
         g_rfthStats[0]++; g_rfthStats[1] += B;
         if (checkAll) {
           // MODSX_VERIFY_DEVICE_CHECK=1: the whole batch is counted again on the host -- a device UNDER-count would otherwise skip
@@ -1009,9 +1033,12 @@ struct RansacF {
         unsigned hit = B;
         for (unsigned j = 0; j < B; ++j) if (D.hCnt[j] > m_i) { hit = j; break; }
         if (hit == B) { rng = g2; ptr.swap(ptr2); no_sam += B; continue; }      // nothing in the batch changes the state
+        const auto te0 = std::chrono::steady_clock::now();
         for (unsigned j = 0; j <= hit; ++j) draw(rng, ptr);                       // replay up to the event, then the reference's body
         const unsigned counted = body();
+        g_rfthStats[9] += rfth_us(te0);
         no_sam += hit + 1;
+        quiet = 0;
         g_rfthStats[2]++;
         if (counted != D.hCnt[hit]) { g_rfthStats[3]++; D.ok = false; dev = false; }   // never seen; the host's count is what was acted on
       }
@@ -1321,4 +1348,11 @@ extern "C" __attribute__((visibility("default"))) int modsx_verify_device_stats(
   if (!out) return -1;
   for (int i = 0; i < 6; i++) { out[i] = mx::g_rfthStats[i].load(); if (reset) mx::g_rfthStats[i].store(0); }
   return 6;
+}
+// out[0..4): microseconds of the rFtH loops spent drawing samples ahead of a batch, waiting for the device, in the host phase
+// (hypotheses that changed nothing), in the bodies of state-changing hypotheses.  Process-wide; reset clears.
+extern "C" __attribute__((visibility("default"))) int modsx_verify_device_timing(long *out, int reset) {
+  if (!out) return -1;
+  for (int i = 0; i < 4; i++) { out[i] = mx::g_rfthStats[6 + i].load(); if (reset) mx::g_rfthStats[6 + i].store(0); }
+  return 4;
 }
