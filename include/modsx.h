@@ -82,6 +82,8 @@ typedef struct modsx_hessaff_params {
   int smmWindowSize;
   float affInitialSigma;
   int doBaumberg;
+  int detectorType;   /* PyramidParams::DetectorType (structures.hpp:148): MODSX_DET_HESSIAN (default), MODSX_DET_DOG or MODSX_DET_HARRIS --
+                       * ScaleSpaceDetector::Response (pyramid.cpp:132-175), thresholds pyramid.h:47-67, point types pyramid.cpp:66-130 */
 } modsx_hessaff_params;
 
 /* scale-space keypoint before affine adaptation: the arguments of

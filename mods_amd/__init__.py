@@ -31,7 +31,7 @@ class HessAffParams(C.Structure):
                 ("rel_threshold", C.c_float), ("rel_reg_number", C.c_float), ("numberOfScales", C.c_int),
                 ("initialSigma", C.c_float), ("edgeEigenValueRatio", C.c_double), ("border", C.c_int),
                 ("maxIterations", C.c_int), ("convergenceThreshold", C.c_float), ("smmWindowSize", C.c_int),
-                ("affInitialSigma", C.c_float), ("doBaumberg", C.c_int)]
+                ("affInitialSigma", C.c_float), ("doBaumberg", C.c_int), ("detectorType", C.c_int)]
 
 
 class MserParams(C.Structure):

@@ -79,6 +79,7 @@ void modsx_default_hessaff_params(modsx_hessaff_params *p) {
   p->smmWindowSize = 19;
   p->affInitialSigma = 1.6f;
   p->doBaumberg = 1;
+  p->detectorType = MODSX_DET_HESSIAN;
 }
 
 void modsx_default_mser_params(modsx_mser_params *p);

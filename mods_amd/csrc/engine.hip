@@ -314,6 +314,11 @@ int build_pyramids(modsx_ctx *c, const modsx_image *const *imgs, int n, const mo
                    bool singleOctaveFromFirstLevel) {
   if (n <= 0 || n > MAXB) { set_error("batch size"); return MODSX_ERR_ARG; }
   if (p.numberOfScales < 1 || p.numberOfScales > 6) { set_error("numberOfScales"); return MODSX_ERR_ARG; }
+  if (p.detectorType != MODSX_DET_HESSIAN && p.detectorType != MODSX_DET_DOG && p.detectorType != MODSX_DET_HARRIS) {
+    set_error("detectorType must be Hessian (0), DoG (1) or Harris (2)");
+    return MODSX_ERR_ARG;
+  }
+  const bool hess = p.detectorType == MODSX_DET_HESSIAN;    // its response is fused into the blur / resize kernels; the others follow below
   const SigmaPlan sp = make_sigma_plan(p);
   const int L = sp.levels;
   const int minSize = 2 * p.border + 2;
@@ -359,7 +364,7 @@ int build_pyramids(modsx_ctx *c, const modsx_image *const *imgs, int n, const mo
         if (c->pyr[i].nOct <= 0) continue;
         Octave &oc = c->pyr[i].oct[0];
         BlurJob &j = bb.j[nj++];
-        j.src = imgs[i]->d; j.blur = oc.blur[0]; j.resp = oc.resp[0]; j.rows = oc.rows; j.cols = oc.cols;
+        j.src = imgs[i]->d; j.blur = oc.blur[0]; j.resp = hess ? oc.resp[0] : nullptr; j.rows = oc.rows; j.cols = oc.cols;
         j.norm = sp.curSigma[0] * sp.curSigma[0];
         mr = std::max(mr, oc.rows); mc = std::max(mc, oc.cols);
         if (!preBlur) {
@@ -371,7 +376,7 @@ int build_pyramids(modsx_ctx *c, const modsx_image *const *imgs, int n, const mo
       for (int q = 0; q < nj; q++) px += (double)bb.j[q].rows * bb.j[q].cols;
       if (nj) {
         if (preBlur) { ProfScope ps(c, K_BLUR_HESS, px * 12); launch_blur_hess(s, bb, nj, mr, mc); }
-        else { ProfScope ps(c, K_HESSIAN, px * 8); launch_hessian(s, bb, nj, mr, mc); }
+        else if (hess) { ProfScope ps(c, K_HESSIAN, px * 8); launch_hessian(s, bb, nj, mr, mc); }
       }
     } else {
       ResizeBatch rb;
@@ -382,7 +387,7 @@ int build_pyramids(modsx_ctx *c, const modsx_image *const *imgs, int n, const mo
         ResizeJob &r = rb.j[nj];
         r.src = pv.blur[p.numberOfScales]; r.dst = oc.blur[0];
         r.srows = pv.rows; r.scols = pv.cols; r.drows = oc.rows; r.dcols = oc.cols;
-        r.resp = oc.resp[0]; r.norm = sp.curSigma[0] * sp.curSigma[0];   // resize + Hessian of the new level in one launch
+        r.resp = hess ? oc.resp[0] : nullptr; r.norm = sp.curSigma[0] * sp.curSigma[0];   // resize + Hessian of the new level in one launch
         BlurJob &j = bb.j[nj++];
         j.src = oc.blur[0]; j.blur = nullptr; j.resp = oc.resp[0]; j.rows = oc.rows; j.cols = oc.cols;
         j.norm = sp.curSigma[0] * sp.curSigma[0];
@@ -405,13 +410,64 @@ int build_pyramids(modsx_ctx *c, const modsx_image *const *imgs, int n, const mo
         if (c->pyr[i].nOct <= o) continue;
         Octave &oc = c->pyr[i].oct[o];
         BlurJob &j = b2.j[k++];
-        j.src = oc.blur[l - 1]; j.blur = oc.blur[l]; j.resp = oc.resp[l]; j.rows = oc.rows; j.cols = oc.cols;
+        j.src = oc.blur[l - 1]; j.blur = oc.blur[l]; j.resp = hess ? oc.resp[l] : nullptr; j.rows = oc.rows; j.cols = oc.cols;
         j.norm = sp.curSigma[l] * sp.curSigma[l];
       }
       double px = 0;
       for (int q = 0; q < k; q++) px += (double)b2.j[q].rows * b2.j[q].cols;
       ProfScope ps(c, K_BLUR_HESS, px * 12);
       launch_blur_hess(s, b2, k, mr, mc);
+    }
+    if (!hess) {
+      // DoG / Harris (ScaleSpaceDetector::dogResponse :176-181, HarrisResponse :283-305; norm = sigma^2 of the level, :475,490):
+      // the response of every level from its blur, with the generic any-sigma filter passes (the DoG of a level is the level minus
+      // its blur with sigma = norm; Harris blurs three gradient products with sqrt(0.6 norm)) -- separate launches per image and
+      // level: these detectors are on no shipped configuration's path, the Hessian's fused kernels are untouched
+      for (int l = 0; l < L; l++) {
+        const float norm = sp.curSigma[l] * sp.curSigma[l];
+        const float sigma = p.detectorType == MODSX_DET_DOG ? norm : sqrtf((float)(0.6 * norm));
+        const int nt = blur_ksize(sigma);
+        if (2 * nt > 2 * 4096) { set_error("response blur kernel too large"); return MODSX_ERR_ARG; }
+        if (!c->viewTaps.ensure((size_t)L * 2 * 4100 * 4) || !c->hViewTaps.ensure((size_t)L * 2 * 4100 * 4)) return MODSX_ERR_NOMEM;
+        // one slice of the staging buffers per level, so that no upload overwrites taps a queued launch still reads
+        float *dT = (float *)c->viewTaps.p + (size_t)l * 2 * 4100, *hT = (float *)c->hViewTaps.p + (size_t)l * 2 * 4100;
+        bool tapsUp = false;
+        for (int i = 0; i < n; i++) {
+          if (c->pyr[i].nOct <= o) continue;
+          Octave &oc = c->pyr[i].oct[o];
+          const int rows = oc.rows, cols = oc.cols;
+          const size_t npx = (size_t)rows * cols;
+          if (!c->scratchA.ensure(npx * 4 * 8)) return MODSX_ERR_NOMEM;
+          float *buf = (float *)c->scratchA.p, *tmp = buf, *a = buf + npx, *b = buf + 2 * npx, *cc = buf + 3 * npx;
+          float *ba = buf + 4 * npx, *bb2 = buf + 5 * npx, *bc = buf + 6 * npx;
+          const int nx = cols == 1 ? 1 : nt, ny = rows == 1 ? 1 : nt;
+          if (!tapsUp || nx != nt || ny != nt) {
+            std::vector<float> kx = gaussian_kernel(nx, sigma), ky = gaussian_kernel(ny, sigma);
+            if (tapsUp) MX_HIP(hipStreamSynchronize(s));      // a degenerate (one-row / one-column) level re-uses the slice
+            memcpy(hT, kx.data(), nx * 4); memcpy(hT + nx, ky.data(), ny * 4);
+            MX_HIP(hipMemcpyAsync(dT, hT, (size_t)(nx + ny) * 4, hipMemcpyHostToDevice, s));
+            tapsUp = nx == nt && ny == nt;
+          }
+          auto blur = [&](const float *src, float *dst) {
+            if (nt == 1) { MX_HIP(hipMemcpyAsync(dst, src, npx * 4, hipMemcpyDeviceToDevice, s)); return MODSX_OK; }
+            launch_blur_pass(s, src, tmp, rows, cols, dT, nx, 0, 1);
+            launch_blur_pass(s, tmp, dst, rows, cols, dT + nx, ny, 1, 1);
+            return MODSX_OK;
+          };
+          if (p.detectorType == MODSX_DET_DOG) {
+            int rc = blur(oc.blur[l], a);
+            if (rc) return rc;
+            launch_sub(s, oc.blur[l], a, oc.resp[l], npx);
+          } else {
+            launch_grad_products(s, oc.blur[l], rows, cols, a, b, cc);
+            int rc = blur(a, ba);
+            if (!rc) rc = blur(b, bb2);
+            if (!rc) rc = blur(cc, bc);
+            if (rc) return rc;
+            launch_harris_combine(s, ba, bb2, bc, (float)(0.6 * norm), oc.resp[l], npx);
+          }
+        }
+      }
     }
   }
   MX_HIP(hipGetLastError());
@@ -440,9 +496,9 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
   float finalTh = p.threshold;
   float posTh = (float)(0.8 * finalTh);
   float negTh = -posTh;
-  finalTh = p.threshold * p.threshold;
+  if (p.detectorType == MODSX_DET_HESSIAN) finalTh = p.threshold * p.threshold;     // pyramid.h:56-57: squared for DET_HESSIAN only
   if (p.mode != MODSX_FIXED_TH) finalTh = posTh = negTh = 0.0f;
-  nb.posTh = posTh; nb.negTh = negTh; nb.finalTh = finalTh; nb.border = p.border;
+  nb.posTh = posTh; nb.negTh = negTh; nb.finalTh = finalTh; nb.border = p.border; nb.detType = p.detectorType;
   int maxOct = 0;
   for (int i = 0; i < n; i++) maxOct = std::max(maxOct, c->pyr[i].nOct);
   // all (image, octave, level) scans of the batch in one launch (NMS_MAXJ jobs at most per launch).  With the shipped

@@ -52,6 +52,7 @@ struct NmsBatch {   // thresholds of one scan; the (image, octave, level) jobs a
   float posTh, negTh, finalTh;
   int border;
   double edgeScoreThreshold;
+  int detType, pad;      // getPointType (pyramid.cpp:66-130): Hessian dark / bright / saddle, DoG 10 / 11, Harris 30 / 31
 };
 struct Candidate {
   int img, octave, level, type;

@@ -298,7 +298,9 @@ MX_D bool nms_refine(const NmsBatch &batch, const NmsJob &jb, int r, int c, Cand
   }
   if (fabsf(b[0]) > 1.5f || fabsf(b[1]) > 1.5f || fabsf(b[2]) > 1.5f || fabsf(val) < batch.finalTh) return false;
   int type;
-  if (val < 0) type = 2;
+  if (batch.detType == MODSX_DET_DOG) type = val < 0 ? 11 : 10;            // DOG_BRIGHT / DOG_DARK
+  else if (batch.detType == MODSX_DET_HARRIS) type = val < 0 ? 31 : 30;    // HARRIS_BRIGHT / HARRIS_DARK
+  else if (val < 0) type = 2;
   else {
     const float *p = jb.blur + (size_t)r * cols + c;
     float Lxx = (p[-1] - 2 * p[0] + p[1]);

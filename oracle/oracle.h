@@ -54,6 +54,7 @@ typedef struct orc_hessaff_params {
   int smmWindowSize;
   float affInitialSigma;
   int doBaumberg;
+  int detectorType;    /* detector_type, detectors/structures.hpp:16-19: 0 Hessian, 1 DoG, 2 Harris (ScaleSpaceDetector::Response) */
 } orc_hessaff_params;
 
 /* a scale-space keypoint before affine adaptation (debug / stage parity) */

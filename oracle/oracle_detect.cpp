@@ -142,7 +142,7 @@ struct Detector {
     finalThreshold = p.threshold;
     positiveThreshold = (float)(0.8 * finalThreshold);
     negativeThreshold = -positiveThreshold;
-    finalThreshold = p.threshold * p.threshold; /* DET_HESSIAN */
+    if (p.detectorType == 0) finalThreshold = p.threshold * p.threshold; /* DET_HESSIAN only, pyramid.h:56-57 */
     if (p.mode != 0) finalThreshold = positiveThreshold = negativeThreshold = 0.0f;
     mask = Img(p.smmWindowSize, p.smmWindowSize);
     gauss_mask(mask);
@@ -202,9 +202,11 @@ struct Detector {
       return;
     octaveMap[(size_t)r * cols + c] = 1;
     float scale = curScale * powf(2.0f, b[2] / par.numberOfScales);
-    /* getPointType (DET_HESSIAN), pyramid.cpp:66-130; read from the detection-level blur */
+    /* getPointType, pyramid.cpp:66-130; DET_HESSIAN reads the detection-level blur */
     int type;
-    if (val < 0) type = 2; /* HESSIAN_SADDLE */
+    if (par.detectorType == 1) type = val < 0 ? 11 /* DOG_BRIGHT */ : 10 /* DOG_DARK */;
+    else if (par.detectorType == 2) type = val < 0 ? 31 /* HARRIS_BRIGHT */ : 30 /* HARRIS_DARK */;
+    else if (val < 0) type = 2; /* HESSIAN_SADDLE */
     else {
       const float *ptr = blur.row(r) + c;
       float Lxx = (ptr[-1] - 2 * ptr[0] + ptr[1]);
@@ -246,6 +248,12 @@ struct Detector {
       }
   }
 
+  /* ScaleSpaceDetector::Response, pyramid.cpp:132-175 */
+  void response(const Img &in, float norm, Img &out) {
+    if (par.detectorType == 1) dog_response(in, norm, out);
+    else if (par.detectorType == 2) harris_response(in, norm, out);
+    else hessian_response(in, norm, out);
+  }
   /* detectOctaveKeypoints, pyramid.cpp:455-538 */
   void octave(const Img &firstLevel, float pixelDistance, Img &next, float *dumpBlurs, float *dumpResps) {
     octaveMap.assign((size_t)firstLevel.rows * firstLevel.cols, 0);
@@ -253,7 +261,7 @@ struct Detector {
     float curSigma = par.initialSigma;
     int numLevels = 1;
     blur = firstLevel;
-    hessian_response(blur, curSigma * curSigma, cur);
+    response(blur, curSigma * curSigma, cur);
     size_t npx = blur.v.size();
     if (dumpBlurs) memcpy(dumpBlurs, blur.v.data(), npx * 4);
     if (dumpResps) memcpy(dumpResps, cur.v.data(), npx * 4);
@@ -262,7 +270,7 @@ struct Detector {
       Img nextBlur;
       gaussian_blur(blur, sigma, nextBlur);
       sigma = curSigma * sigmaStep;
-      hessian_response(nextBlur, sigma * sigma, high);
+      response(nextBlur, sigma * sigma, high);
       if (dumpBlurs) memcpy(dumpBlurs + i * npx, nextBlur.v.data(), npx * 4);
       if (dumpResps) memcpy(dumpResps + i * npx, high.v.data(), npx * 4);
       numLevels++;
@@ -377,6 +385,7 @@ void orc_default_hessaff_params(orc_hessaff_params *p) {
   p->smmWindowSize = 19;
   p->affInitialSigma = 1.6f;
   p->doBaumberg = 1;
+  p->detectorType = 0;
 }
 
 void orc_octave_levels(const float *first, int rows, int cols, const orc_hessaff_params *p, float *blurs,

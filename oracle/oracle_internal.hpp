@@ -34,6 +34,8 @@ int blur_ksize(float sigma);
 void gaussian_blur(const Img &in, float sigma, Img &out);
 void resize_half(const Img &in, Img &out);
 void hessian_response(const Img &in, float norm, Img &out);
+void dog_response(const Img &in, float norm, Img &out);
+void harris_response(const Img &in, float norm, Img &out);
 bool interpolate_check_borders(int orig_w, int orig_h, float ofsx, float ofsy, float a11, float a12,
                                float a21, float a22, int res_w, int res_h);
 bool interpolate(const Img &im, float ofsx, float ofsy, float a11, float a12, float a21, float a22, Img &res);

@@ -103,6 +103,28 @@ def test_scalespace_keypoints_bit_exact(ctx, modsx, oracle, small_pair, mode):
         _check_sskp(got, ref)
 
 
+@pytest.mark.parametrize("det,th", [(1, 1.5), (2, 400.0)])
+def test_dog_and_harris_scale_space_detectors_bit_exact(ctx, modsx, oracle, small_pair, det, th):
+    """PyramidParams::DetectorType = DET_DOG / DET_HARRIS inside the scale-space loop (ScaleSpaceDetector::Response,
+    pyramid.cpp:132-175: dogResponse = the level minus its blur with sigma = norm, HarrisResponse :283-305), with their thresholds
+    (pyramid.h:47-67: not squared) and point types (DOG_DARK / DOG_BRIGHT = 10 / 11, HARRIS_* = 30 / 31, pyramid.cpp:92-107): the
+    scale-space keypoints with every field, then the affine keypoints, FixedTh and NotLessThanRegions."""
+    for img in small_pair[:2]:
+        im = ctx.upload(img)
+        for mode, regn in ((0, 2000), (4, 120)):
+            got = ctx.detect_scalespace(im, modsx.default_hessaff_params(mode=mode, detectorType=det, threshold=th))
+            ref = oracle.detect_scalespace(img, oracle.default_params(mode=mode, detectorType=det, threshold=th))
+            assert len(ref) > 30, len(ref)
+            _check_sskp(got, ref)
+            assert set(np.unique(ref["type"])) <= ({10, 11} if det == 1 else {30, 31})
+            gk = ctx.detect_affine_keypoints(im, modsx.default_hessaff_params(mode=mode, reg_number=regn, detectorType=det, threshold=th))
+            rk = oracle.detect_hessaff(img, oracle.default_params(mode=mode, reg_number=regn, detectorType=det, threshold=th))
+            assert len(rk) > 15 and same_records(gk, rk.view(modsx.KEYPOINT))
+        im.free()
+    with pytest.raises(RuntimeError):
+        ctx.detect_scalespace(ctx.upload(small_pair[0]), modsx.default_hessaff_params(detectorType=7))
+
+
 @pytest.mark.parametrize("mode,regn", [(0, 2000), (4, 150), (2, 40)])
 def test_affine_keypoints_bit_exact(ctx, modsx, oracle, small_pair, mode, regn):
     for img in small_pair[:2]:
