@@ -54,7 +54,7 @@ def test_struct_layouts_match_reference_structs(modsx):
     # AffineKeypoint is 8 doubles + int + double + int (88 B); AffineRegion = 5 ints + 2 keypoints
     assert modsx.KEYPOINT.itemsize == 88 and modsx.REGION.itemsize == 200
     assert modsx.KEYPOINT.fields["pyramid_scale"][1] == 72 and modsx.REGION.fields["det_kp"][1] == 24
-    assert ctypes.sizeof(modsx.HessAffParams) == 64
+    assert ctypes.sizeof(modsx.HessAffParams) == 72      # + detectorType (round 5)
 
 
 @pytest.mark.skipif(HAS_GPU, reason="only meaningful without a device")
