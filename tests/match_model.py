@@ -6,22 +6,22 @@ the kernels that is logic rather than arithmetic -- which candidates a sweep may
 how ties fall -- is checked on the CPU, where a GPU is not needed.
 
 What it models
-  pack     trains are partitioned by the parity of sum(b) inside blocks of PB trains (stable: ascending train index inside a
-           class), each class padded to whole 32-row tiles; a block owns TPB = PB/32 + 1 tile slots.  d - |a'|^2 = 2 t + p
-           with p the tile's parity, so a key (2 t + p) << 8 | tile code orders by exact distance, and equal distances are
-           always in the same class, where slot order is train order.
+  pack     trains are partitioned by the parity of sum(b) (stable: ascending train index inside a class), each class padded
+           to whole stages of 32-row tiles; the sweeps walk "even class, then odd class".  d - |a'|^2 = 2 t + p with p the
+           tile's parity, so a key (2 t + p) << 8 | tile code orders by exact distance, and equal distances are always in
+           the same class, where slot order is train order.
   sweep 1  per (query, split, lane half) stream: the K smallest GROUP minima (group = the 16 rows of a tile that a lane half
            owns) as (d, tile), ties by ascending tile -- no row index.
   decide   merges the streams into the K smallest groups G[0..K-1] by (d, tile, half), recomputes groups exactly one at a
            time and walks the rows that are CERTAIN: a recomputed row r is certain iff (d_r, tile_r) < (d, tile) of the first
            group not yet recomputed (every row outside the recomputed groups is at or after that group).  The FGINN walk runs
            over the certain rows; when they run out before it ends, the query goes to sweep 2 (which only needs NN0).
-  sweep 2 / events   by definition: Dmin, nless, nbad, NNj over all trains (the device recomputes event groups exactly).
+  resolve  (queries whose walk outruns the certain rows) by definition: Dmin, nless, nbad, NNj over all trains -- the device
+           sweeps again and recomputes the groups below Dmin exactly; ratio >= 1: the query's whole sorted list (k_match_pdf).
 """
 import numpy as np
 
-PB = 2048
-TPB = PB // 32 + 1
+TPS = 4          # tiles per stage of the sweeps: each parity class is padded to whole stages
 BIG = np.int64(1) << 40
 
 
@@ -30,20 +30,19 @@ def row_of(r, hi):
 
 
 def pack(d2):
-    """slot -> train index (-1 = padding), number of tile slots"""
-    n2 = len(d2)
+    """virtual slot -> train index (-1 = padding), parity of every virtual tile: the even class, then the odd class, each in train
+    order and padded to a multiple of TPS tiles (k_match_pack; on the device the two classes live in two regions of the tile
+    array and the sweeps walk them as one virtual sequence)"""
     par = (d2.astype(np.int64).sum(1) & 1).astype(np.int64)
-    nblk = (n2 + PB - 1) // PB
-    perm = -np.ones(nblk * TPB * 32, np.int64)
-    tpar = np.zeros(nblk * TPB, np.int64)
-    for b in range(nblk):
-        idx = np.arange(b * PB, min(n2, (b + 1) * PB))
-        ev, od = idx[par[idx] == 0], idx[par[idx] == 1]
-        E = (len(ev) + 31) // 32
-        base = b * TPB * 32
-        perm[base:base + len(ev)] = ev
-        perm[base + E * 32: base + E * 32 + len(od)] = od
-        tpar[b * TPB + E: (b + 1) * TPB] = 1
+    idx = np.arange(len(d2))
+    ev, od = idx[par == 0], idx[par == 1]
+    TE = ((len(ev) + 31) // 32 + TPS - 1) // TPS * TPS
+    TO = ((len(od) + 31) // 32 + TPS - 1) // TPS * TPS
+    perm = -np.ones((TE + TO) * 32, np.int64)
+    perm[:len(ev)] = ev
+    perm[TE * 32: TE * 32 + len(od)] = od
+    tpar = np.zeros(TE + TO, np.int64)
+    tpar[TE:] = 1
     return perm, tpar
 
 
