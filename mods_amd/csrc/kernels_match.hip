@@ -117,12 +117,16 @@ struct MatchGeom {
 // Sweep 2 runs over the UNDECIDED queries only, whose number the host does not know at launch time.  Every workgroup of a fixed
 // one-round launch therefore derives the split geometry from the device-side count: the NW workgroups are dealt out as
 // (query block, split) with as many splits as fill the machine once.  k_match_events uses the same function.
-constexpr int RESOLVE_NW = 256;            // workgroups of k_match_resolve that hold a (query block, split)
+// workgroups of k_match_resolve that hold a (query block, split): one per CU while the undecided queries fill at most two
+// blocks (the usual 1-3 %: more workgroups would only wait for LDS), a full round of the sweeps' size beyond that (inputs with
+// many near-duplicates per query: shorter splits, fewer logged groups per stream)
+MX_HD int resolve_nw(int nQB, int qs) { return nQB <= 2 ? 256 : 256 * sweep_wps(qs); }
 struct Sweep2Geom { int nQB, S, tilesPerSplit; };
 MX_HD Sweep2Geom sweep2_geom(int nUnd, int ntiles, int qs) {
   Sweep2Geom G;
-  const int QPB = qpb_of(qs), SWEEP2_NW = RESOLVE_NW;    // one workgroup per CU: its LDS leaves room for little more
+  const int QPB = qpb_of(qs);
   G.nQB = (nUnd + QPB - 1) / QPB;
+  const int SWEEP2_NW = resolve_nw(G.nQB, qs);
   int S = G.nQB > 0 ? SWEEP2_NW / G.nQB : 1;
   if (S > ntiles / MINT) S = ntiles / MINT;
   if (S < 1) S = 1;
@@ -782,7 +786,8 @@ struct ResolveEpi {
 template <int QSETS>
 __device__ __forceinline__ void resolve_body(const ResolveArgs &A) {
   constexpr int QPB = qpb_of(QSETS);
-  constexpr int EVS = 8192 / (2 * QPB);                // slots per stream: 16 (QSETS 2) / 8 (QSETS 4), 16 KB of LDS either way
+  constexpr int EVS = 16;                              // slots per stream: 16 / 32 KB of LDS (QSETS 2 / 4)
+  constexpr int LCAP = 2 * STAGE_B / 4;                // entries of the work list (it lives in the staging buffers)
   __shared__ __attribute__((aligned(16))) unsigned char sm[2][STAGE_B];
   __shared__ unsigned short sEvt[2 * QPB][EVS];        // logged groups (virtual tiles < 65536: the launcher's limit) per stream = (query in block) * 2 + half
   __shared__ UndRec sU[QPB];
@@ -828,7 +833,6 @@ __device__ __forceinline__ void resolve_body(const ResolveArgs &A) {
   __syncthreads();                       // the staging buffers are free from here on: they hold the work list
   // ---- 2. the logged groups: counts per query, a flat work list, streams that ran out of slots
   int *sList = reinterpret_cast<int *>(&sm[0][0]);     // (query in block) << 23 | half << 22 | tile
-  static_assert(2 * STAGE_B / 4 >= 2 * QPB * EVS, "work list");
 #pragma unroll
   for (int s = 0; s < QSETS; s++) {
     const int ul = ul0 + 32 * s + col;
@@ -846,6 +850,11 @@ __device__ __forceinline__ void resolve_body(const ResolveArgs &A) {
     if (nev[s] == 0 || sEv[ul] >= A.nn) continue;      // nn or more groups in this split alone: the walk gives up
     if (nev[s] > EVS) { sOver[atomicAdd(&sNover, 1)] = (unsigned short)(ul * 2 + hi); continue; }
     const int base = atomicAdd(&sNrec, nev[s]);
+    if (base + nev[s] > LCAP) {      // the list is full: the stream is rescanned like one that ran out of slots; its reserved entries are void
+      for (int e = base; e < LCAP; e++) sList[e] = -1;
+      sOver[atomicAdd(&sNover, 1)] = (unsigned short)(ul * 2 + hi);
+      continue;
+    }
     for (int e = 0; e < nev[s]; e++) sList[base + e] = (ul << 23) | (hi << 22) | sEvt[ul * 2 + hi][e];
   }
   __syncthreads();
@@ -885,14 +894,17 @@ __device__ __forceinline__ void resolve_body(const ResolveArgs &A) {
         if (v.md != BIG) atomicMin(&sCand[ul], key64(v.md, v.mt));
       }
     };
-    const int nrec = sNrec;
+    const int nrec = min(sNrec, LCAP);
     for (int b = 0; b < nrec; b += 32) {               // workgroup-uniform trip count
       const int e0 = b + qw, e1 = b + 16 + qw;
-      const int r0 = e0 < nrec ? sList[e0] : 0, r1 = e1 < nrec ? sList[e1] : 0;
-      const Vis v0 = compute((unsigned)r0 >> 23, r0 & 0x3fffff, (r0 >> 22) & 1, e0 < nrec);
-      const Vis v1 = compute((unsigned)r1 >> 23, r1 & 0x3fffff, (r1 >> 22) & 1, e1 < nrec);
-      commit(v0, (unsigned)r0 >> 23, e0 < nrec);
-      commit(v1, (unsigned)r1 >> 23, e1 < nrec);
+      int r0 = e0 < nrec ? sList[e0] : -1, r1 = e1 < nrec ? sList[e1] : -1;
+      const bool on0 = r0 != -1, on1 = r1 != -1;
+      if (!on0) r0 = 0;
+      if (!on1) r1 = 0;
+      const Vis v0 = compute((unsigned)r0 >> 23, r0 & 0x3fffff, (r0 >> 22) & 1, on0);
+      const Vis v1 = compute((unsigned)r1 >> 23, r1 & 0x3fffff, (r1 >> 22) & 1, on1);
+      commit(v0, (unsigned)r0 >> 23, on0);
+      commit(v1, (unsigned)r1 >> 23, on1);
     }
     const int nover = sNover;
     for (int o = 0; o < nover; o++) {                  // a stream with more than EVS groups: every group of its tiles
@@ -1154,7 +1166,7 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
     maxN1 = std::max(maxN1, n1[i]); maxS = std::max(maxS, L.S); maxWg = std::max(maxWg, (n2[i] + PB - 1) / PB);
   }
   hipLaunchKernelGGL(k_match_pack, dim3(std::max((maxN1 + 31) / 32, maxWg), 2, nb), dim3(256), 0, s, b);
-  const int QPB = qpb_of(qs), NW2 = RESOLVE_NW;
+  const int QPB = qpb_of(qs), NW2 = 256 * sweep_wps(qs);
   const dim3 grid((maxN1 + QPB - 1) / QPB, maxS, nb);
   if (evSweep1) hipEventRecord(evSweep1[0], s);
   if (qs == 4) hipLaunchKernelGGL(k_match_sweep1<4>, grid, dim3(256), 0, s, b);
