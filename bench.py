@@ -749,7 +749,7 @@ def main():
                 lat.append((time.perf_counter() - ta) / 3 * 1e3)
             lad["one_pair_idle_gpu_ms_cumulative_by_step"] = lat
             lad["one_pair_idle_gpu_ms_by_step"] = [lat[0]] + [lat[k] - lat[k - 1] for k in range(1, len(lat))]
-            lad["host_threads"] = os.environ.get("MODSX_HOST_THREADS", "min(hardware threads, 64)")
+            lad["host_threads"] = os.environ.get("MODSX_HOST_THREADS", "min(hardware threads, cgroup CPU allowance, 64) / local ranks")
             lad["note"] = ("the component trees of the MSER steps run on the host worker pool ((view, polarity) tasks) while other "
                            "contexts keep the device busy; mser_steps_only / hessaff_steps_only are the same contexts on a ladder cut to "
                            "that detector's steps")

@@ -76,7 +76,7 @@ try:   # HBM bytes of the whole pipeline per pair: every kernel's FETCH_SIZE x2 
         if ln.startswith("#") or ln.startswith("kernel"): continue
         p = ln.rstrip().rsplit(None, 4)
         if len(p) == 5: tot += float(p[1]) * (float(p[3]) + float(p[4])) if p[1].replace(".", "").isdigit() else 0
-    npairs = 25         # bench.py $ONE: (1 warm-up + 2 steps) x 4 pairs, the 1-step kernel-time leg (4), the one-stream leg (4) and the 5 repetitions of the roofline leg
+    npairs = 33         # bench.py $ONE: (1 warm-up + 2 steps back to back + the same 2 steps with a step barrier) x 4 pairs, the 1-step kernel-time leg (4), the one-stream leg (4) and the 5 repetitions of the roofline leg
     t["hbm_counter_GB_per_pair"] = tot / npairs / 1e9
 except Exception as e:
     print("no per-pair total:", e)
