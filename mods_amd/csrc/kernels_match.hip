@@ -61,7 +61,6 @@ constexpr int PB = 256;                    // trains per workgroup of k_match_pa
 // every LDS fragment read then feeds four MFMA chains (half the LDS bytes per matrix instruction) at 2 wavefronts per SIMD
 constexpr int sweep_wps(int qs) { return qs >= 4 ? 2 : 3; }   // waves per SIMD the sweeps are built for
 constexpr int qpb_of(int qs) { return 4 * 32 * qs; }          // queries per 256-thread workgroup
-constexpr int QPB_MAX = qpb_of(4), NW_MAX = 256 * 3;
 static int match_qsets(int nb, int n1, int n2) {
   static const int forced = getenv("MODSX_MATCH_QSETS") ? atoi(getenv("MODSX_MATCH_QSETS")) : 0;
   if (forced == 2 || forced == 4) return forced;
@@ -574,13 +573,12 @@ struct DecideArgs {
   double sqminratio, contrDistSq;
   int nn;
   MatchRow *rows;
-  int *dmin, *undecided, *nUndecided;
-  double *x0y0;           // NN0's position of the queries that go on to sweep 2
+  int *nUndecided;
   UndRec *und;            // everything k_match_resolve needs of an undecided query, in one record
 };
 __device__ __forceinline__ void decide_body(const DecideArgs &A) {
   // undecided queries are compacted with ONE global atomic per workgroup (a counter word takes ~90 atomics per us)
-  __shared__ int sList[DECIDE_Q], sCount, sBase;
+  __shared__ int sCount, sBase;
   __shared__ UndRec sRec[DECIDE_Q];
   if (threadIdx.x == 0) sCount = 0;
   __syncthreads();
@@ -712,21 +710,18 @@ __device__ __forceinline__ void decide_body(const DecideArgs &A) {
       dm = A.sqminratio >= 1.0 ? 0 : ratio_dmin(d0, A.sqminratio);      // all-points mode: k_match_pdf redoes the query's walk
       if (dm <= MAXD) {          // otherwise no distance can pass the ratio test: the walk ends without a match
         const int k = atomicAdd(&sCount, 1);
-        sList[k] = q;
         UndRec r; r.q = q; r.na = na; r.t0 = t0; r.dm = dm; r.x0 = x0; r.y0 = y0;
         sRec[k] = r;
         // k_match_resolve adds to nless / nbad and takes the minimum of (dj, tj) over its splits
         o.nless = 0; o.nbad = 0; o.tj = -1; o.dj = __int_as_float(0x7fffffff);
-        A.x0y0[2 * q] = x0; A.x0y0[2 * q + 1] = y0;
       }
     }
     A.rows[q] = o;
-    A.dmin[q] = dm;
   }
   __syncthreads();
   if (threadIdx.x == 0 && sCount) sBase = atomicAdd(A.nUndecided, sCount);
   __syncthreads();
-  if ((int)threadIdx.x < sCount) { A.undecided[sBase + threadIdx.x] = sList[threadIdx.x]; A.und[sBase + threadIdx.x] = sRec[threadIdx.x]; }
+  if ((int)threadIdx.x < sCount) A.und[sBase + threadIdx.x] = sRec[threadIdx.x];
 }
 
 // ---------------- resolve: sweep 2 and the event groups in ONE launch -------------------------------------------------------
@@ -1013,7 +1008,7 @@ __device__ __forceinline__ void pdf_body(const PdfArgs &A) {
 // ---- workspace layout: ONE description used by the size query and by the launcher -------------------------------------------
 struct MatchLayout {
   int S, tilesPerSplit, ntilesUB, offT;
-  size_t norm1, norm2, hrow, perm, pos2p, tiles, status, geo, partial, dmin, undecided, x0y0, und, pdf, counter, bytes;
+  size_t norm1, norm2, hrow, perm, pos2p, tiles, status, geo, partial, und, pdf, counter, bytes;
 };
 static MatchLayout match_layout(int n1, int n2, int qs) {
   MatchLayout L;
@@ -1047,9 +1042,6 @@ static MatchLayout match_layout(int n1, int n2, int qs) {
   L.status = take((size_t)((n2 + PB - 1) / PB) * 8);
   L.geo = take(sizeof(TileGeo));
   L.partial = take((size_t)n1 * S * 2 * KTOP * 8);
-  L.dmin = take((size_t)n1 * 4);
-  L.undecided = take((size_t)n1 * 4);
-  L.x0y0 = take((size_t)n1 * 16);
   L.und = take((size_t)n1 * 32);
   L.pdf = take((size_t)PDF_NW * ntiles * 32 * 4);      // k_match_pdf's scratch rows (the ratio >= 1 mode)
   L.counter = take(64);
@@ -1063,9 +1055,8 @@ size_t match_workspace_bytes(int n1, int n2) { return std::max(match_layout(n1, 
 struct MatchProblem {
   const uint8_t *d1, *d2;
   const double *pos2;
-  int *norm1, *norm2, *hrow, *perm, *dmin, *undecided, *counter, *pdf;
+  int *norm1, *norm2, *hrow, *perm, *counter, *pdf;
   double2 *pos2p;
-  double *x0y0;
   u64 *status;
   TileGeo *geo;
   unsigned char *tiles;
@@ -1117,8 +1108,8 @@ __global__ __launch_bounds__(16 * DECIDE_Q) void k_match_decide(MatchBatch b, do
   if ((int)blockIdx.x * DECIDE_Q >= P.g.n1) return;
   DecideArgs A;
   A.d1 = P.d1; A.norm1 = P.norm1; A.norm2 = P.norm2; A.perm = P.perm; A.tiles = P.tiles; A.geo = P.geo; A.partial = P.partial; A.g = P.g;
-  A.pos2p = P.pos2p; A.sqminratio = sqminratio; A.contrDistSq = contrDistSq; A.nn = nn; A.rows = P.rows; A.dmin = P.dmin;
-  A.undecided = P.undecided; A.nUndecided = P.counter; A.x0y0 = P.x0y0; A.und = P.und;
+  A.pos2p = P.pos2p; A.sqminratio = sqminratio; A.contrDistSq = contrDistSq; A.nn = nn; A.rows = P.rows;
+  A.nUndecided = P.counter; A.und = P.und;
   decide_body(A);
 }
 template <int QS>
@@ -1160,7 +1151,6 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
     P.pos2p = (double2 *)(w + L.pos2p); P.status = (u64 *)(w + L.status); P.geo = (TileGeo *)(w + L.geo);
     P.tiles = (unsigned char *)(w + L.tiles);
     P.partial = (int2 *)(w + L.partial);
-    P.dmin = (int *)(w + L.dmin); P.undecided = (int *)(w + L.undecided); P.x0y0 = (double *)(w + L.x0y0);
     P.counter = (int *)(w + L.counter); P.und = (UndRec *)(w + L.und); P.pdf = (int *)(w + L.pdf);
     P.d1 = d1[i]; P.d2 = d2[i]; P.pos2 = pos2[i]; P.rows = rows[i];
     maxN1 = std::max(maxN1, n1[i]); maxS = std::max(maxS, L.S); maxWg = std::max(maxWg, (n2[i] + PB - 1) / PB);
