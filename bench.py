@@ -19,7 +19,7 @@ orientation -> RootSIFT per view, then brute-force FGINN matching of the ~24 k x
   --loopback W   one GPU: the view-sharded path with W in-process ranks (loopback transport: the all-gather is W
              device-to-device copies, everything else is the code the RCCL transport runs), workers / W lanes per rank
 Rank 0 prints ONE JSON line: value = pairs/s of the whole job, `roofline` = the distance kernels (all k_match_*
-launches, sweep 2 included, on the descriptors of this run) against the int8 MFMA peak, `roofline_describe` = the
+launches -- pack, sweep 1, decide, resolve -- on the descriptors of this run) against the int8 MFMA peak, `roofline_describe` = the
 describe stage against HBM with SURVEY section 8(d) bytes, `cpu_baseline` = the CPU oracle (restatement of the reference's
 CPU path) on the same workload with all host cores and with one, `parity` = GPU vs that CPU path on one pair of the run.
 """

@@ -28,9 +28,10 @@
 //    -- every row outside the recomputed groups is at or after that group in (distance, slot) order.  With K >= 4, NN0 and
 //    NN1 are always certain.  On multi-view descriptors 98.7 % of the queries end their walk inside the first three groups
 //    (tests/match_model.py is the executable model of this logic, checked against the oracle on the CPU);
-//  * only the rest go through sweep 2: Dmin = smallest integer distance passing the ratio test against d0; groups whose
-//    minimum is below Dmin are logged as events (4 bytes in the lane's own slots, no atomics), the others feed the lane's two
-//    smallest keys; k_match_events recomputes event groups exactly for nless / nbad / NNj.
+//  * only the rest go through k_match_resolve, a second sweep for them alone: Dmin = smallest integer distance passing the ratio
+//    test against d0; groups whose minimum is below Dmin are logged (2 bytes in the stream's own LDS slots, no atomics), the
+//    others feed the lane's running minimum (keys WITH the row there: the kernel is a hundredth of sweep 1's work); the
+//    workgroup then recomputes its logged groups exactly for nless / nbad / NNj and adds them to the query's row.
 //      accept  <=>  NNj exists, nbad == 0, nless <= nn-2          (rank of NNj is nless+1)
 //  * staging: 4 tiles (4 KB each, 16-byte slots XOR-swizzled for conflict-free ds_read_b128) + their 128 row constants + 4
 //    tile constants per barrier with direct global->LDS loads, double-buffered; a wave holds 2 x 32 queries, so every
@@ -115,7 +116,7 @@ struct MatchGeom {
 
 // Sweep 2 runs over the UNDECIDED queries only, whose number the host does not know at launch time.  Every workgroup of a fixed
 // one-round launch therefore derives the split geometry from the device-side count: the NW workgroups are dealt out as
-// (query block, split) with as many splits as fill the machine once.  k_match_events uses the same function.
+// (query block, split) with as many splits as fill the machine once.
 // workgroups of k_match_resolve that hold a (query block, split): one per CU while the undecided queries fill at most two
 // blocks (the usual 1-3 %: more workgroups would only wait for LDS), a full round of the sweeps' size beyond that (inputs with
 // many near-duplicates per query: shorter splits, fewer logged groups per stream)
@@ -266,7 +267,7 @@ __device__ __forceinline__ void pack_body(const PackArgs &A) {
   }
   __syncthreads();
   {
-    // per-slot constants and positions (k_match_decide / k_match_events read the positions with the rows), a thread per train
+    // per-slot constants and positions (k_match_decide / k_match_resolve read the positions with the rows), a thread per train
     const int t = blk * PB + tid;
     if (t < A.n2) {
       const int slot = sSlot[tid];
@@ -653,7 +654,7 @@ __device__ __forceinline__ void decide_body(const DecideArgs &A) {
   if (usable > 0) { recompute(0); mrec = 1; }
   if (usable > 1) { recompute(1); mrec = 2; }
   // 4. the walk over the certain rows
-  int j = 0, res = 0;                          // res: 0 running, 1 accept, 2 reject / ran off the list, 3 sweep 2
+  int j = 0, res = 0;                          // res: 0 running, 1 accept, 2 reject / ran off the list, 3 k_match_resolve
   int d0 = BIG, t0 = -1, dd1 = BIG, t1 = -1, dj = BIG, tj = -1;
   double x0 = 0, y0 = 0;
   const int grp = threadIdx.x & 48;            // first lane of this query's 16 within the wave
@@ -724,7 +725,7 @@ __device__ __forceinline__ void decide_body(const DecideArgs &A) {
   if ((int)threadIdx.x < sCount) A.und[sBase + threadIdx.x] = sRec[threadIdx.x];
 }
 
-// ---------------- resolve: sweep 2 and the event groups in ONE launch -------------------------------------------------------
+// ---------------- resolve: the second sweep and its logged groups in ONE launch -------------------------------------------------------
 // For the queries k_match_decide could not finish (about 1 % on multi-view descriptors).  A workgroup takes (block of
 // undecided queries, split of the virtual tiles), geometry from the device-side count as above, and
 //  1. sweeps its tiles with keys that carry the row, (2 t + p) << 8 | (tile % 12 + 1) << 4 | register (32 VALU per chain --
@@ -1163,7 +1164,7 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
   else hipLaunchKernelGGL(k_match_sweep1<2>, grid, dim3(256), 0, s, b);
   if (evSweep1) hipEventRecord(evSweep1[1], s);
   hipLaunchKernelGGL(k_match_decide, dim3((maxN1 + DECIDE_Q - 1) / DECIDE_Q, 1, nb), dim3(16 * DECIDE_Q), 0, s, b, sqminratio, contrDistSq, nn);
-  // sweep 2: one round of workgroups dealt out on the device as (undecided block, split); more only if there could be more
+  // resolve: one round of workgroups dealt out on the device as (undecided block, split); more only if there could be more
   // undecided query blocks than that
   const dim3 grid2(std::max(NW2, (maxN1 + QPB - 1) / QPB), 1, nb);
   if (sqminratio >= 1.0) hipLaunchKernelGGL(k_match_pdf, dim3(PDF_NW, 1, nb), dim3(256), 0, s, b, contrDistSq, nn);

@@ -3,8 +3,8 @@
 
 The descriptors are those of a synthetic 1024x768 pair under a view ladder (default: TiltSet 1,2,3,4,6, Phi 360 = 8 views,
 ~10 k regions per side; --tilts 1,2,4,6,8 --phi 120 gives 31 views, ~24 k per side), i.e. what the matcher sees in the
-multi-view configurations: many near-duplicate trains per query, so most matched queries go through sweep 2.
-All matcher launches (pack, sweep 1, decide, sweep 2, events) are inside the timed bracket.
+multi-view configurations: many near-duplicate trains per query, so many walks go past the second neighbour.
+All matcher launches (pack, sweep 1, decide, resolve) are inside the timed bracket.
   --check N   compare the first N queries with the CPU oracle (test infrastructure, ~1.4 s per 1000 x 20 k)
   --rep K     descriptors replicated K times with +-1 noise on a few entries (bigger problems from the same statistics)
 """
