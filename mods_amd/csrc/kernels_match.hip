@@ -58,6 +58,10 @@ constexpr int MINT = 12;                   // fewest tiles a split is made of
 #endif
 constexpr int KTOP = MODSX_KTOP;           // group keys a stream keeps (>= 4: NN0 and NN1 are then always certain in k_match_decide)
 constexpr int PB = 256;                    // trains per workgroup of k_match_pack
+#ifndef MODSX_PACK_POLLS
+#define MODSX_PACK_POLLS 256
+#endif
+constexpr int PACK_POLLS = MODSX_PACK_POLLS;   // looks at a predecessor's status word before its trains are counted here instead
 // 32-query sets per wave (QS, even): 2 for most problems -- 3 wavefronts per SIMD --, 4 when both sides hold >= 40 k descriptors:
 // every LDS fragment read then feeds four MFMA chains (half the LDS bytes per matrix instruction) at 2 wavefronts per SIMD
 constexpr int sweep_wps(int qs) { return qs >= 4 ? 2 : 3; }   // waves per SIMD the sweeps are built for
@@ -191,10 +195,11 @@ __device__ __forceinline__ void pack_body(const PackArgs &A) {
   const int blk = blockIdx.x;
   if (blk >= nwg) return;
   __shared__ int sCnt[2][32];      // [class][pass * 4 + wave]: trains of the class, then their exclusive prefix
-  __shared__ int sTot[2], sBase[2][4];
+  __shared__ int sTot[2], sBase[2][4], sMiss[256], sNmiss;
   __shared__ int sSlot[PB], sNv[PB], sHv[PB];   // per train of the workgroup: slot, |b'|^2, row constant
   const int wave = tid >> 6, lane = tid & 63, slice = tid & 7, gw = lane >> 3;
   constexpr int NP = PB / 32;
+  if (tid == 0) sNmiss = 0;
   v4i row[NP];
   int meta[NP];                    // valid | parity << 1 | rank among the wave's trains of the class << 2
 #pragma unroll
@@ -241,13 +246,39 @@ __device__ __forceinline__ void pack_body(const PackArgs &A) {
     __hip_atomic_store(A.status + blk, ((u64)A.epoch << 32) | ((u64)myE << 16) | (u64)myO, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // the counts of the workgroups before this one (a word is valid when it carries this launch's epoch and sums to the
   // workgroup's train count -- whatever an earlier launch or another use of the memory left there does not)
+  // The wait is BOUNDED: a predecessor whose word has not come after PACK_POLLS looks (~0.2 ms; it normally comes within a few
+  // microseconds) is counted by this workgroup itself, from its trains -- so the kernel ends whatever the order in which the
+  // hardware starts workgroups and whatever else holds the CUs (the order argument above needs per-queue in-order dispatch; with
+  // many streams packing at once, workgroups that spin could in principle hold every slot a late predecessor needs).
   int bE = 0, bO = 0;
   for (int j = tid; j < blk; j += 256) {
-    u64 w;
-    do {
+    u64 w = 0;
+    bool ok = false;
+    for (int poll = 0; poll < PACK_POLLS && !ok; poll++) {
       w = __hip_atomic_load(A.status + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } while ((unsigned)(w >> 32) != A.epoch || (int)((w >> 16) & 0xffff) + (int)(w & 0xffff) != PB);
-    bE += (int)((w >> 16) & 0xffff); bO += (int)(w & 0xffff);
+      ok = (unsigned)(w >> 32) == A.epoch && (int)((w >> 16) & 0xffff) + (int)(w & 0xffff) == PB;
+      if (!ok) __builtin_amdgcn_s_sleep(2);
+    }
+    if (ok) { bE += (int)((w >> 16) & 0xffff); bO += (int)(w & 0xffff); }
+    else sMiss[atomicAdd(&sNmiss, 1) & 255] = j;       // (more than 256 at once: the list wraps and the sum below would be short --
+  }                                                    //  see the check after it)
+  __syncthreads();
+  {
+    const int nmiss = sNmiss;
+    if (nmiss > 256) __builtin_trap();                 // not reachable in practice: 256 predecessors all silent for 0.2 ms
+    for (int mi = 0; mi < nmiss; mi++) {               // count block sMiss[mi] ourselves: eight lanes per train, 32 trains per pass
+      const int j = sMiss[mi];
+      int odd = 0;
+      for (int p = 0; p < NP; p++) {
+        const v4i v = reinterpret_cast<const v4i *>(A.d2 + (size_t)(j * PB + p * 32 + (tid >> 3)) * 128)[slice];   // j < blk: a full block
+        int lin = 0;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; w4++) lin = __builtin_amdgcn_sdot4(v[w4] ^ 0x80808080, 0x01010101, lin, false);
+        lin = sum8(lin);
+        if (slice == 0) odd += lin & 1;
+      }
+      bO += odd; bE += slice == 0 ? NP - odd : 0;      // each train is counted once, by the lane with slice 0
+    }
   }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) { bE += __shfl_xor(bE, m); bO += __shfl_xor(bO, m); }
