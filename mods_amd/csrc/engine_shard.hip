@@ -121,6 +121,65 @@ static std::mutex g_loopMu;
 static std::map<uint64_t, std::shared_ptr<LoopGroup>> g_loopGroups;
 static uint64_t g_loopNext = 1;
 
+// ---- a stand-in for librccl inside this process (tests only: modsx_debug_mock_rccl) -----------------------------------------------
+// RCCL with more than one rank cannot run on a one-GPU box.  The mock fills the SAME function table the real library fills, so
+// W in-process ranks go through modsx_comm_create's RCCL branch and transport_all_gather's RCCL branch (issueMu, the abort
+// rules, the per-communicator issue order) -- everything but librccl itself.  Its all-gather is the loopback algorithm: W
+// device-to-device copies ordered by events, two host barriers.
+struct MockComm { std::shared_ptr<LoopGroup> g; int rank; };
+static std::mutex g_mockMu;
+static std::map<uint64_t, std::shared_ptr<LoopGroup>> g_mockGroups;
+static uint64_t g_mockNext = 1;
+static RcclApi g_rcclSaved;
+static bool g_mockOn = false;
+static ncclResult_t mock_GetUniqueId(ncclUniqueId *id) {
+  memset(id, 0, sizeof *id);
+  std::lock_guard<std::mutex> lk(g_mockMu);
+  const uint64_t key = g_mockNext++;
+  memcpy(id->internal, "MXMOCK01", 8);
+  memcpy(id->internal + 8, &key, 8);
+  return ncclSuccess;
+}
+static ncclResult_t mock_CommInitRank(ncclComm_t *out, int world, ncclUniqueId id, int rank) {
+  if (memcmp(id.internal, "MXMOCK01", 8)) return ncclInvalidArgument;
+  uint64_t key;
+  memcpy(&key, id.internal + 8, 8);
+  std::lock_guard<std::mutex> lk(g_mockMu);
+  std::shared_ptr<LoopGroup> &g = g_mockGroups[key];
+  if (!g) { g = std::make_shared<LoopGroup>(); g->world = world; g->slots.resize(world); hipGetDevice(&g->dev); }
+  if (g->world != world || rank < 0 || rank >= world || g->slots[rank].taken) return ncclInvalidArgument;
+  LoopGroup::Slot &sl = g->slots[rank];
+  if (hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess)
+    return ncclUnhandledCudaError;
+  sl.taken = true;
+  MockComm *mc = new MockComm{g, rank};
+  if (++g->joined == world) g_mockGroups.erase(key);
+  *out = reinterpret_cast<ncclComm_t>(mc);
+  return ncclSuccess;
+}
+static ncclResult_t mock_CommDestroy(ncclComm_t c) { delete reinterpret_cast<MockComm *>(c); return ncclSuccess; }
+static ncclResult_t mock_CommAbort(ncclComm_t c) { reinterpret_cast<MockComm *>(c)->g->kill(); return ncclSuccess; }
+static ncclResult_t mock_GetVersion(int *v) { *v = 0; return ncclSuccess; }
+static const char *mock_GetErrorString(ncclResult_t) { return "mock rccl error"; }
+static ncclResult_t mock_AllGather(const void *send, void *recv, size_t bytes, ncclDataType_t, ncclComm_t c, hipStream_t s) {
+  MockComm *mc = reinterpret_cast<MockComm *>(c);
+  LoopGroup &g = *mc->g;
+  const int W = g.world;
+  LoopGroup::Slot &me = g.slots[mc->rank];
+  me.send = send; me.recv = recv; me.bytes = bytes;
+  if (hipEventRecord(me.ready, s) != hipSuccess) return ncclUnhandledCudaError;
+  if (!g.barrier(20000)) return ncclSystemError;
+  for (int p = 0; p < W; p++) if (g.slots[p].bytes != bytes) return ncclInvalidArgument;
+  for (int p = 0; p < W; p++) {
+    if (hipStreamWaitEvent(s, g.slots[p].ready, 0) != hipSuccess) return ncclUnhandledCudaError;
+    if (bytes && hipMemcpyAsync((char *)recv + (size_t)p * bytes, g.slots[p].send, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return ncclUnhandledCudaError;
+  }
+  if (hipEventRecord(me.done, s) != hipSuccess) return ncclUnhandledCudaError;
+  if (!g.barrier(20000)) return ncclSystemError;
+  for (int p = 0; p < W; p++) if (hipStreamWaitEvent(s, g.slots[p].done, 0) != hipSuccess) return ncclUnhandledCudaError;
+  return ncclSuccess;
+}
+
 struct ShardLane {
   DevBuf blkLocal, blkAll, regsIn, regsOut, mLocal, mAll, rcDev, order, posOut;
   PinBuf hRegs, hHdr, hRc;
@@ -1235,3 +1294,23 @@ int modsx_match_ladder_sharded(modsx_ctx *ctx, modsx_comm *comm, const modsx_ima
 }
 
 }  // extern "C"
+
+// Test hook: enable != 0 puts the in-process stand-in into librccl's function table (the real one, if it was loaded, is kept and
+// comes back with enable == 0).  Communicators made under one table must be destroyed under it.
+extern "C" __attribute__((visibility("default"))) int modsx_debug_mock_rccl(int enable) {
+  using namespace mx;
+  std::lock_guard<std::mutex> lk(g_rcclMu);
+  if (enable && !g_mockOn) {
+    g_rcclSaved = g_rccl;
+    RcclApi a;
+    a.h = (void *)1;
+    a.GetUniqueId = mock_GetUniqueId; a.CommInitRank = mock_CommInitRank; a.CommDestroy = mock_CommDestroy; a.CommAbort = mock_CommAbort;
+    a.AllGather = mock_AllGather; a.GetVersion = mock_GetVersion; a.GetErrorString = mock_GetErrorString;
+    g_rccl = a;
+    g_mockOn = true;
+  } else if (!enable && g_mockOn) {
+    g_rccl = g_rcclSaved;
+    g_mockOn = false;
+  }
+  return MODSX_OK;
+}

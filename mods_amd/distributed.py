@@ -111,3 +111,38 @@ def run_loopback(world, fn, lanes=1, device=0, timeout_ms=None):
         if e is not None:
             raise e
     return out
+
+
+def run_mock_rccl(world, fn, lanes=1, device=0, timeout_ms=None):
+    """run_loopback's twin for the RCCL branch: the ranks are made with an id from `modsx_comm_unique_id` while an in-process stand-in
+    fills librccl's function table (`modsx_debug_mock_rccl`), so `modsx_comm_create` and every collective take the code path a real
+    multi-GPU run takes -- everything but librccl itself.  Tests only."""
+    L = mods_amd.lib()
+    mods_amd._check(L.modsx_debug_mock_rccl(1), "debug_mock_rccl")
+    try:
+        uid = mods_amd.comm_unique_id()
+        ctxs = [[mods_amd.Context(device) for _ in range(lanes)] for _ in range(world)]
+        comms = [NativeComm(ctxs[r], rank=r, world=world, uid=uid, timeout_ms=timeout_ms) for r in range(world)]
+        out, err = [None] * world, [None] * world
+
+        def body(r):
+            try:
+                out[r] = fn(r, comms[r])
+            except BaseException as e:   # noqa: BLE001 -- reported to the caller below
+                err[r] = e
+
+        th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for r in range(world):
+            comms[r].close()
+            for c in ctxs[r]:
+                c.close()
+    finally:
+        L.modsx_debug_mock_rccl(0)
+    for e in err:
+        if e is not None:
+            raise e
+    return out

@@ -72,6 +72,34 @@ def test_sharded_equals_unsharded(ctx, modsx, small_pair, world):
     ia.free(); ib.free()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_rccl_branch_with_an_in_process_stand_in(ctx, modsx, small_pair, world):
+    """The branch a multi-GPU run takes (`modsx_comm_create` with an RCCL id, `transport_all_gather` through librccl's function table,
+    its issue lock and abort rules) with W > 1 -- which a one-GPU box cannot do with the real library: `modsx_debug_mock_rccl` fills the
+    table with an in-process stand-in.  The single-pair call and a batched call of three pairs (one exchange for all image sides, row-split
+    matching, one result all-gather) against the unsharded result, on every rank."""
+    from mods_amd import distributed as D
+    a, b, _ = small_pair
+    views = _views(modsx)
+    par = modsx.default_pair_params(ransac_seed=4)
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    ref = ctx.match_pair_views(ia, ib, views, par)
+
+    def rank_body(r, comm):
+        one = comm.ctxs[0].match_pair_views_sharded(comm.comm, ia, ib, views, par, -1)
+        many = comm.match_pairs_views_sharded(0, [ia, ia, ia], [ib, ib, ib], views, par, owner_base=-1)
+        return one, many, comm.describe()
+
+    out = D.run_mock_rccl(world, rank_body)
+    for r, (one, many, info) in enumerate(out):
+        _same_pair_result(one, ref)
+        assert len(many) == 3
+        for m in many:
+            _same_pair_result(m, ref)
+        assert info["transport"] == "rccl" and info["ranks_seen_by_rccl"] == world and info["all_gather_calls_rank0"] > 0, info
+    ia.free(); ib.free()
+
+
 @pytest.mark.parametrize("world,ndesc,fmt", [(2, 1, 0), (3, 2, 0), (8, 1, 0), (2, 1, 1), (3, 2, 1), (8, 2, 1)])
 def test_device_pack_and_order_kernels_equal_the_host_wire_format(ctx, modsx, small_pair, world, ndesc, fmt):
     """k_pack_rows / k_unpack_blocks against modsx_shard_block_pack / modsx_shard_blocks_unpack (the host statement the gloo CPU
