@@ -260,14 +260,15 @@ __device__ __forceinline__ void pack_body(const PackArgs &A) {
       if (!ok) __builtin_amdgcn_s_sleep(2);
     }
     if (ok) { bE += (int)((w >> 16) & 0xffff); bO += (int)(w & 0xffff); }
-    else sMiss[atomicAdd(&sNmiss, 1) & 255] = j;       // (more than 256 at once: the list wraps and the sum below would be short --
-  }                                                    //  see the check after it)
+    else sMiss[atomicAdd(&sNmiss, 1) & 255] = j;       // (more than 256 at once: the list wraps; handled below)
+  }
   __syncthreads();
   {
-    const int nmiss = sNmiss;
-    if (nmiss > 256) __builtin_trap();                 // not reachable in practice: 256 predecessors all silent for 0.2 ms
-    for (int mi = 0; mi < nmiss; mi++) {               // count block sMiss[mi] ourselves: eight lanes per train, 32 trains per pass
-      const int j = sMiss[mi];
+    int nmiss = sNmiss;
+    const bool all = nmiss > 256;                      // the list wrapped (hundreds of predecessors silent at once): count EVERY block before
+    if (all) { bE = 0; bO = 0; nmiss = blk; }          // this one here and use none of the words
+    for (int mi = 0; mi < nmiss; mi++) {               // count block j ourselves: eight lanes per train, 32 trains per pass
+      const int j = all ? mi : sMiss[mi];
       int odd = 0;
       for (int p = 0; p < NP; p++) {
         const v4i v = reinterpret_cast<const v4i *>(A.d2 + (size_t)(j * PB + p * 32 + (tid >> 3)) * 128)[slice];   // j < blk: a full block
