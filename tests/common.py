@@ -17,9 +17,9 @@ def laf_of(regs, idx):
     return np.stack([k["a11"], k["a12"], k["a21"], k["a22"], k["s"]], 1)
 
 
-def oracle_pair(O, a, b, seed=1, mode=0, ratio=0.8, contrad=30.0):
-    k1, r1, d1 = oracle_features(O, a, mode)
-    k2, r2, d2 = oracle_features(O, b, mode)
+def oracle_pair(O, a, b, seed=1, mode=0, ratio=0.8, contrad=30.0, **det_kw):
+    k1, r1, d1 = oracle_features(O, a, mode, **det_kw)
+    k2, r2, d2 = oracle_features(O, b, mode, **det_kw)
     pos2 = np.stack([r2["reproj_kp"]["x"], r2["reproj_kp"]["y"]], 1)
     tent = O.match_fginn(d1, d2, pos2, ratio, contrad)
     pts = np.stack([r1["reproj_kp"]["x"][tent["q"]], r1["reproj_kp"]["y"][tent["q"]],

@@ -382,6 +382,23 @@ def test_pair_end_to_end_identical_inliers(ctx, modsx, oracle, small_pair):
     ia.free(); ib.free()
 
 
+@pytest.mark.parametrize("det,th", [(1, 1.5), (2, 400.0)])
+def test_pair_end_to_end_with_dog_and_harris_detectors(ctx, modsx, oracle, small_pair, det, th):
+    """The whole pair path (detect -> orient -> describe -> match -> duplicate filter -> LO-RANSAC) with DetectorType = DoG / Harris in
+    the scale-space loop: the regions' keypoint sub-types, every unique tentative and the inlier set against the oracle's pipeline."""
+    a, b, _ = small_pair
+    need_ref(oracle)
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    got = ctx.match_pair(ia, ib, modsx.default_pair_params(ransac_seed=5, detectorType=det, threshold=th))
+    ref = oracle_pair(oracle, a, b, seed=5, detectorType=det, threshold=th)
+    ia.free(); ib.free()
+    assert got["n_regions"] == (len(ref["d1"]), len(ref["d2"])) and len(ref["d1"]) > 50
+    assert got["n_tentatives"] == len(ref["tent"]) and got["n_unique"] == len(ref["uniq"]) and len(ref["uniq"]) > 10
+    _check_tents(got["tentatives"], ref["uniq"])
+    rr = ref["ransac"]
+    assert np.array_equal(got["ransac_inlier"], rr["inl"]) and np.array_equal(got["verified"], rr["keep"])
+
+
 def test_pair_end_to_end_epipolar_verification(ctx, modsx, oracle, small_pair):
     """RANSACPars::useF = 1 (config 5 of BASELINE.json): the same pair verified by exp_ransacFcustom + F_LAF_check.
     The scene is planar, so DEGENSAC's plane-and-parallax branch is what runs."""
