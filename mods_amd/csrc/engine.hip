@@ -14,6 +14,14 @@
 #include <mutex>
 #include "engine_api.hpp"
 
+#ifdef MODSX_DUP_BUILD
+namespace mx {
+int dup_count(int cls) {
+  static const long mask = getenv("MODSX_DUP") ? strtol(getenv("MODSX_DUP"), nullptr, 0) : 0;
+  return 1 + (int)((mask >> cls) & 1);
+}
+}  // namespace mx
+#endif
 namespace mx {
 
 static thread_local std::string g_err;

@@ -259,6 +259,14 @@ void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const i
 }  // namespace mx
 
 namespace mx {
+// experiment aid (builds with -DMODSX_DUP_BUILD only; tools/ab_dup.sh): MODSX_DUP=<bit mask of KClass> launches the kernels of those
+// classes twice, which prices a kernel under the bench's 16 streams without changing any result (the launches are idempotent)
+#ifdef MODSX_DUP_BUILD
+int dup_count(int cls);
+#define MX_DUP(cls) for (int dupLeft_ = mx::dup_count(cls); dupLeft_ > 0; dupLeft_--)
+#else
+#define MX_DUP(cls)
+#endif
 enum KClass { K_BLUR_HESS = 0, K_HESSIAN, K_RESIZE, K_NMS, K_BAUMBERG, K_ORIENT, K_PATCH_SAMPLE, K_BLUR_ROWS, K_DESCRIBE,
               K_MATCH, K_GRAY, K_WARP, K_VIEW_BLUR, K_BLUR_COLS, K_MATCH_SWEEP1, K_NCLASS };
 struct Profiler {

@@ -483,7 +483,7 @@ void launch_baumberg(hipStream_t s, const AffJob *jobs, AffOut *out, int n, cons
     int chunk = n / 16384;
     chunk = chunk < K ? K : (chunk > MODSX_BAUMBERG_CHUNK ? MODSX_BAUMBERG_CHUNK : chunk);
     const int nchunks = (n + chunk - 1) / chunk;
-    hipLaunchKernelGGL(k_baumberg_stream<K>, dim3(8 * ((nchunks + 7) / 8)), dim3(64), 0, s, jobs, out, n, mask, chunk, nchunks, maxIter,
+    MX_DUP(K_BAUMBERG) hipLaunchKernelGGL(k_baumberg_stream<K>, dim3(8 * ((nchunks + 7) / 8)), dim3(64), 0, s, jobs, out, n, mask, chunk, nchunks, maxIter,
                        convTh, affInitialSigma);
   } else if (W == 19) hipLaunchKernelGGL(k_baumberg<19>, dim3(n), dim3(64), 0, s, jobs, out, n, mask, W, maxIter, convTh, affInitialSigma);
   else hipLaunchKernelGGL(k_baumberg<0>, dim3(n), dim3(64), 0, s, jobs, out, n, mask, W, maxIter, convTh, affInitialSigma);

@@ -958,18 +958,18 @@ void launch_patch_sample(hipStream_t s, const DescJob *jobs, const int *tilePref
 }
 void launch_expand_blur_tiles(hipStream_t s, const DescJob *jobs, const int *prefixRows, const int *prefixCols, int nJobs,
                               const int *needTab, BlurTile *tilesRows, BlurTile *tilesCols, float2 *rowStarts) {
-  if (nJobs > 0) hipLaunchKernelGGL(k_expand_blur_tiles, dim3(nJobs, 2), dim3(64), 0, s, jobs, prefixRows, prefixCols, nJobs, needTab,
+  if (nJobs > 0) MX_DUP(K_PATCH_SAMPLE) hipLaunchKernelGGL(k_expand_blur_tiles, dim3(nJobs, 2), dim3(64), 0, s, jobs, prefixRows, prefixCols, nJobs, needTab,
                                     tilesRows, tilesCols, rowStarts);
 }
 void launch_sample_rows(hipStream_t s, const DescJob *jobs, const BlurTile *tiles, int nTiles, const ImgRef *imgs, const float *taps,
                         const int *needTab, float *dst, const float2 *rowStarts, float *dstGrid) {
   if (nTiles <= 0) return;
-  hipLaunchKernelGGL(k_sample_rows_lds, dim3(8 * ((nTiles + 7) / 8)), dim3(BLUR_T), 0, s, tiles, jobs, imgs, taps, needTab, dst, nTiles,
+  MX_DUP(K_BLUR_ROWS) hipLaunchKernelGGL(k_sample_rows_lds, dim3(8 * ((nTiles + 7) / 8)), dim3(BLUR_T), 0, s, tiles, jobs, imgs, taps, needTab, dst, nTiles,
                      rowStarts, dstGrid);
 }
 void launch_blur_cols(hipStream_t s, const BlurTile *tiles, int nTiles, const float *taps, const int *needTab, const float *src,
                       float *dst) {
-  if (nTiles > 0) hipLaunchKernelGGL(k_blur_cols_lds, dim3(nTiles), dim3(BLUR_T), 0, s, tiles, taps, needTab, src, dst);
+  if (nTiles > 0) MX_DUP(K_BLUR_COLS) hipLaunchKernelGGL(k_blur_cols_lds, dim3(nTiles), dim3(BLUR_T), 0, s, tiles, taps, needTab, src, dst);
 }
 void launch_patch_blur(hipStream_t s, const DescJob *jobs, const int *tilePrefix, const int *tileJob, int nTiles,
                        const float *taps, const int *needTab, const float *src, float *dst, int pass) {
@@ -982,7 +982,7 @@ void launch_describe(hipStream_t s, const DescJob *jobs, int n, const ImgRef *im
   if (n <= 0) return;
   SiftConst sc;
   sc.nmask = nmask;
-  hipLaunchKernelGGL(k_describe, dim3((n + DR - 1) / DR), dim3(128 * DR), 0, s, jobs, n, imgs, grid, needTab, coordTab, mask, maskIdx, oTab, bins,
+  MX_DUP(K_DESCRIBE) hipLaunchKernelGGL(k_describe, dim3((n + DR - 1) / DR), dim3(128 * DR), 0, s, jobs, n, imgs, grid, needTab, coordTab, mask, maskIdx, oTab, bins,
                      wts, sc,
                      photoNorm, descTypes, nOut, maxBin, outs);
 }

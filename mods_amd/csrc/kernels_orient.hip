@@ -207,10 +207,10 @@ void launch_orientation(hipStream_t s, const OriJob *jobs, float *out, int n, co
   if (n <= 0) return;
   // fewer regions than two rounds of wavefronts over the chip: the launch is latency, not residency
   if (n < 2 * 256 * 16)
-    hipLaunchKernelGGL(k_orientation<true>, dim3(8 * ((n + 7) / 8)), dim3(64), 0, s, jobs, out, n, imgs, maskIdx, maskW, binTab, doHalf, th,
+    MX_DUP(K_ORIENT) hipLaunchKernelGGL(k_orientation<true>, dim3(8 * ((n + 7) / 8)), dim3(64), 0, s, jobs, out, n, imgs, maskIdx, maskW, binTab, doHalf, th,
                        maxAngles);
   else
-    hipLaunchKernelGGL(k_orientation<false>, dim3(8 * ((n + 7) / 8)), dim3(64), 0, s, jobs, out, n, imgs, maskIdx, maskW, binTab, doHalf, th,
+    MX_DUP(K_ORIENT) hipLaunchKernelGGL(k_orientation<false>, dim3(8 * ((n + 7) / 8)), dim3(64), 0, s, jobs, out, n, imgs, maskIdx, maskW, binTab, doHalf, th,
                        maxAngles);
 }
 

@@ -553,7 +553,7 @@ static int fill_tiles(BlurBatch &b, int nj, int tw, int th) {
 template <int TH>
 static void launch_blur_hess_th(hipStream_t s, const BlurBatch &b, int tiles) {
   dim3 grid(tiles);
-  switch (b.n >> 1) {
+  MX_DUP(K_BLUR_HESS) switch (b.n >> 1) {
     case 1: hipLaunchKernelGGL((k_blur_hess<1, TH>), grid, dim3(256), 0, s, b); break;
     case 2: hipLaunchKernelGGL((k_blur_hess<2, TH>), grid, dim3(256), 0, s, b); break;
     case 3: hipLaunchKernelGGL((k_blur_hess<3, TH>), grid, dim3(256), 0, s, b); break;
@@ -584,7 +584,7 @@ void launch_resize_half(hipStream_t s, const ResizeBatch &bin, int nj, int, int)
   int t = 0;
   for (int i = 0; i < nj; i++) { b.tile0[i] = t; t += ((b.j[i].dcols + 63) / 64) * ((b.j[i].drows + 3) / 4); }
   b.tile0[nj] = t;
-  if (t > 0) hipLaunchKernelGGL(k_resize_half, dim3(t), dim3(256), 0, s, b);
+  if (t > 0) MX_DUP(K_RESIZE) hipLaunchKernelGGL(k_resize_half, dim3(t), dim3(256), 0, s, b);
 }
 
 // The extrema found by the scan are few and scattered (about one per wavefront), and each needs a chain of ~10 dependent

@@ -298,7 +298,7 @@ void launch_harris_combine(hipStream_t s, const float *bxx, const float *byy, co
   hipLaunchKernelGGL(k_harris_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, bxx, byy, bxy, sigmasq, o, n);
 }
 void launch_views_warp(hipStream_t s, const ViewJob *jobs, int n, int tiles, int stage) {
-  if (tiles > 0) hipLaunchKernelGGL(k_views_warp, dim3(tiles), dim3(256), 0, s, jobs, n, stage);
+  if (tiles > 0) MX_DUP(K_WARP) hipLaunchKernelGGL(k_views_warp, dim3(tiles), dim3(256), 0, s, jobs, n, stage);
 }
 void launch_views_blur(hipStream_t s, const ViewJob *jobs, int n, int tiles, const float *taps, int pass) {
   if (tiles > 0) hipLaunchKernelGGL(k_views_blur, dim3(tiles), dim3(256), 0, s, jobs, n, taps, pass);
@@ -306,7 +306,7 @@ void launch_views_blur(hipStream_t s, const ViewJob *jobs, int n, int tiles, con
 void launch_views_rotblur(hipStream_t s, const ViewJob *jobs, int n, int tiles, const float *taps, int maxRx, int maxRy) {
   if (tiles <= 0) return;
   const int wFloats = (VF_TH + 2 * maxRy) * (VF_TW + 2 * maxRx), tFloats = (VF_TH + 2 * maxRy) * VF_TW;
-  hipLaunchKernelGGL(k_views_rotblur, dim3(tiles), dim3(256), (size_t)(wFloats + tFloats) * 4, s, jobs, n, taps, wFloats);
+  MX_DUP(K_VIEW_BLUR) hipLaunchKernelGGL(k_views_rotblur, dim3(tiles), dim3(256), (size_t)(wFloats + tFloats) * 4, s, jobs, n, taps, wFloats);
 }
 
 }  // namespace mx

@@ -1,10 +1,8 @@
-# usage: ab_bench.sh out.log lib1 lib2 ...  (variants built by tools/build_variant.sh; "main" = mods_amd/libmodsx.so)   (default bench, 5 steps, alternating)
-out=$1; shift
-mkdir -p $(dirname $out)
+#!/bin/bash
+# usage: ab_bench.sh <variant> ...   -- bench.py (no CPU baseline, no extras) under each library variant ("base" = the tree's), twice round robin
+R=$GRAFT_REPO_ROOT
 for rep in 1 2; do
 for v in "$@"; do
-  lib=mods_amd/libmodsx_$v.so; [ "$v" = "main" ] && lib=mods_amd/libmodsx.so
-  val=$(MODSX_LIB=$lib timeout 600 python bench.py --no-extra --no-cpu-baseline --steps 5 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(j['value'],1))")
-  echo "$v $val" >> $out
-done
-done
+  if [ "$v" = base ]; then L=$R/mods_amd/libmodsx.so; else L=$R/mods_amd/libmodsx_$v.so; fi
+  MODSX_LIB=$L python $R/bench.py --no-cpu-baseline --no-extra 2>/dev/null | python $R/tools/bench_line.py $v
+done; done
