@@ -175,9 +175,10 @@ class ShardGroup:
     Loopback (one GPU): W in-process ranks, each with its own contexts / lanes.  Pair i of a step runs on lane i % lanes of
     EVERY rank (static map: all ranks must issue the collectives of a lane in the same order); rank i % world verifies."""
 
-    def __init__(self, mods_amd, device, lanes, dist=None, loopback=0, ctxs=None):
+    def __init__(self, mods_amd, device, lanes, dist=None, loopback=0, ctxs=None, exchange="allgather"):
         from mods_amd import distributed as D
         self.lanes = lanes
+        self.exchange = exchange
         if loopback:
             self.world = loopback
             uid = mods_amd.comm_loopback_id(loopback)
@@ -189,6 +190,9 @@ class ShardGroup:
             self.ctxs = [list(ctxs[:lanes])]
             self.comms = [D.NativeComm(self.ctxs[0], dist)]
             self.own_ctxs = False
+        if exchange == "owner":        # a pair's rows travel to the rank that matches and verifies it, not to every rank
+            for cm in self.comms:
+                cm.set_exchange(mods_amd.EXCHANGE_OWNER)
         from concurrent.futures import ThreadPoolExecutor
         self.pool = ThreadPoolExecutor(len(self.comms) * lanes)
 
@@ -230,6 +234,7 @@ class ShardGroup:
     def describe(self):
         d = self.comms[0].describe()
         d["ranks_in_this_process"] = len(self.comms)
+        d["exchange"] = self.exchange
         return d
 
     def close(self):
@@ -246,8 +251,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--step-barrier", action="store_true", help="a host-side barrier after every timed step (the form of rounds 1-4)")
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=768)
     ap.add_argument("--cols", type=int, default=1024)
     ap.add_argument("--config", type=str, default="views31", choices=sorted(CONFIGS))
@@ -260,6 +265,8 @@ def main():
     ap.add_argument("--init-sigma", type=float, default=0.2)
     ap.add_argument("--shard", type=str, default="", choices=["", "pairs", "views"])
     ap.add_argument("--loopback", type=int, default=0, help="one GPU: W in-process ranks of the view-sharded path")
+    ap.add_argument("--exchange", type=str, default="allgather", choices=["allgather", "owner"],
+                    help="view-sharded path: rows of a pair to every rank (the north star's all-gather) or to its owner rank only")
     ap.add_argument("--no-scaling-views", action="store_true", help="N > 1: skip the view-sharded second measurement")
     ap.add_argument("--batch-api", action="store_true", help="multi-view configs: run a step as ONE modsx_match_pairs_views call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -331,7 +338,7 @@ def main():
     group = None
     if shard == "views":
         lanes = max(1, len(ctxs) // args.loopback) if args.loopback else len(ctxs)
-        group = ShardGroup(mods_amd, local_rank, lanes, dist=dist, loopback=args.loopback, ctxs=ctxs)
+        group = ShardGroup(mods_amd, local_rank, lanes, dist=dist, loopback=args.loopback, ctxs=ctxs, exchange=args.exchange)
 
     def barrier(g=None):
         for c in ctxs:
@@ -500,7 +507,7 @@ def main():
                 nb_v = batch * world
                 v1 = [vdev[i % len(vdev)][0] for i in range(nb_v)]
                 v2 = [vdev[i % len(vdev)][1] for i in range(nb_v)]
-                vg = ShardGroup(mods_amd, local_rank, len(ctxs), dist=dist, ctxs=ctxs)
+                vg = ShardGroup(mods_amd, local_rank, len(ctxs), dist=dist, ctxs=ctxs, exchange=args.exchange)
                 el_v, nd_v, res_v = timed(lambda: vg.step(v1, v2, views, params), max(1, args.warmup), args.steps, vg)
                 el_v, nd_v = reduce_over_ranks(el_v, nd_v)
                 box["out"] = {"value": args.steps * nb_v / el_v, "unit": "image-pairs/s", "ms_per_step": 1e3 * el_v / args.steps,

@@ -465,8 +465,29 @@ int modsx_comm_reset_lanes(modsx_comm *comm);
 int modsx_comm_set_timeout(modsx_comm *comm, int milliseconds);
 int modsx_comm_info(const modsx_comm *comm, int *rank, int *world, int *rccl_version, long *bytes_gathered, long *collectives);
 /* out[0..n): collectives issued, bytes gathered, block-size retries, agreement collectives, lanes, loopback (0/1), dead (0/1),
- * microseconds the lanes waited for their turn to issue.  Returns the number of statistics available. */
+ * microseconds the lanes waited for their turn to issue, bytes received in owner-only exchanges, owner-only exchanges.
+ * Returns the number of statistics available. */
 int modsx_comm_stats(const modsx_comm *comm, long *out, int n);
+/* How modsx_match_pairs_views_sharded (owner_base >= 0) moves the rows of an image side.  MODSX_EXCHANGE_ALL_GATHER (default, the
+ * north star's "all-gather of regions + descriptors"): every rank receives every row.  MODSX_EXCHANGE_OWNER: the per-item counts go
+ * to every rank (an all-gather of a few KB), the rows of pair g only to the rank that matches and verifies it (ncclSend / ncclRecv
+ * in one group): 1 / world of the all-gather's bytes on the wire, exact sizes (no padded blocks, no retry), one more host wait per
+ * call.  Set it alike on every rank before the first sharded call (ranks set differently stop with MODSX_ERR_TIMEOUT at the first
+ * exchange: the mode travels in the header).  The calls that return lists to every rank keep the all-gather. */
+#define MODSX_EXCHANGE_ALL_GATHER 0
+#define MODSX_EXCHANGE_OWNER 1
+int modsx_comm_set_exchange(modsx_comm *comm, int mode);
+/* The owner-only exchange stated on the host (what the device path derives from the gathered headers; the gloo CPU test runs ranks
+ * over it): item_counts[f] = regions of item f = image * nviews + view (item f belongs to rank f mod world, its rows sit in that
+ * rank's local buffer in item order), image_owner[j] = the rank that reads image j.  For `rank`:
+ *   sends[k] = {peer, image, first local row, rows}: the messages it sends, in issue order (images ascending);
+ *   recvs[k] = {peer, image, first row of its receive buffer, rows}: the messages it receives (images ascending, then source ranks);
+ *   jobs[k]  = {first row of the receive buffer, first row of the list, rows, 0}: where the rows of each item of an owned image go
+ *              (list rows count ALL items: the lists keep the all-gather's positions).
+ * n[0..5) = messages sent, messages received, jobs, rows of the receive buffer, list length.  cap = capacity of each array in
+ * entries (4 ints each); MODSX_ERR_CAPACITY when one is too small (n[] is still filled).  Returns MODSX_OK. */
+int modsx_shard_owner_plan(const int *item_counts, int nimages, int nviews, int world, int rank, const int *image_owner, int *sends,
+                           int *recvs, int *jobs, int cap, long *n);
 /* Where row j of the reference's list sits in the all-gathered buffer (rank r's padded block starts at r * maxrows):
  * counts[r * nviews + v] = regions of view v on rank r (0 unless r == v mod world).  Returns the list length (host only). */
 int modsx_view_block_order(const int *counts, int world, int nviews, int *src, int cap, int *maxrows_out);

@@ -98,13 +98,15 @@ EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "m
            "modsx_match_pair_views_sharded", "modsx_match_pairs_views_sharded", "modsx_match_ladder_sharded", "modsx_comm_loopback_id", "modsx_comm_set_lanes",
            "modsx_comm_attach", "modsx_comm_lane_done", "modsx_comm_reset_lanes", "modsx_comm_set_timeout", "modsx_comm_stats",
            "modsx_shard_block_bytes", "modsx_shard_block_pack", "modsx_shard_blocks_unpack", "modsx_shard_device_pack",
-           "modsx_shard_device_unpack", "modsx_verify_device_stats", "modsx_verify_device_timing"]
+           "modsx_shard_device_unpack", "modsx_verify_device_stats", "modsx_verify_device_timing", "modsx_comm_set_exchange",
+           "modsx_shard_owner_plan"]
 # include/modsx_degensac.h: the reference's own verification symbols (link-time drop-in for libdegensac)
 EXPORTS_DEGENSAC = ["exp_ransacHcustom", "exp_ransacFcustom", "HDs", "HDsi", "HDsidx", "HDsSym", "HDsiSym", "HDsSymidx",
                     "HDsSymMax", "HDsiSymMax", "HDsSymidxMax", "FDs", "FDsSym", "exFDs", "exFDsSym",
                     "modsx_ransac_set_seed"]
 
 SHARD_ROW_REGION, SHARD_ROW_KP = 0, 1     # include/modsx.h: what of a region travels in a row (all 200 B / the 56 B verification slice)
+EXCHANGE_ALL_GATHER, EXCHANGE_OWNER = 0, 1   # include/modsx.h: modsx_comm_set_exchange
 KP_FIELDS = ("x", "y", "a11", "a12", "a21", "a22", "s")
 KERNEL_CLASSES = ["blur_hess", "hessian", "resize", "nms_localize", "baumberg", "orientation", "patch_sample",
                   "blur_rows", "describe", "match_fginn", "gray", "warp_affine", "view_blur", "blur_cols", "match_sweep1"]
@@ -692,6 +694,22 @@ def view_block_order(counts):
     return src[:n].copy(), mr.value
 
 
+def shard_owner_plan(item_counts, nviews, world, rank, image_owner):
+    """modsx_shard_owner_plan: the owner-only exchange of `rank` from the per-item counts (item f = image * nviews + view) ->
+    dict(sends, recvs: [k, 4] = peer, image, first row, rows; jobs: [k, 4] = receive row, list row, rows, 0; recv_rows, list_rows)."""
+    cnt = np.ascontiguousarray(item_counts, np.int32)
+    own = np.ascontiguousarray(image_owner, np.int32)
+    nimg = len(own)
+    assert len(cnt) == nimg * nviews
+    cap = max(1, len(cnt), nimg * world)
+    sends, recvs, jobs = (np.zeros((cap, 4), np.int32) for _ in range(3))
+    n = (C.c_long * 5)()
+    L = lib()
+    L.modsx_shard_owner_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    _check(L.modsx_shard_owner_plan(_p(cnt), nimg, nviews, world, rank, _p(own), _p(sends), _p(recvs), _p(jobs), cap, n), "shard_owner_plan")
+    return {"sends": sends[:n[0]].copy(), "recvs": recvs[:n[1]].copy(), "jobs": jobs[:n[2]].copy(), "recv_rows": int(n[3]), "list_rows": int(n[4])}
+
+
 def _ptr_array(arrs):
     return (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
 
@@ -759,7 +777,8 @@ def comm_loopback_id(world):
     return buf.raw
 
 
-COMM_STATS = ["collectives", "bytes_gathered", "block_retries", "agreements", "lanes", "loopback", "dead", "turn_wait_us"]
+COMM_STATS = ["collectives", "bytes_gathered", "block_retries", "agreements", "lanes", "loopback", "dead", "turn_wait_us", "bytes_received",
+              "exchanges"]
 
 
 def comm_stats(comm):

@@ -84,7 +84,8 @@ int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
 int detect_describe_items_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *const *imgs, int nimg, const modsx_view *views,
                                   int nviews, const modsx_pair_params &pp, const DescSet &ds, std::vector<modsx_region> &regs,
                                   DevBuf *const *descAcc, const size_t *base, int *itemCounts, const unsigned char *wantImg = nullptr,
-                                  std::vector<size_t> *regStart = nullptr, double **devPos = nullptr, std::vector<double> *kpRows = nullptr);
+                                  std::vector<size_t> *regStart = nullptr, double **devPos = nullptr, std::vector<double> *kpRows = nullptr,
+                                  const int *ownerImg = nullptr);   // ownerImg[j]: the one rank that reads image j's rows (owner-only exchange)
 void rows_to_tentatives(const MatchRow *rows, int n1, int nn, std::vector<modsx_tentative> &o);
 int comm_rank(const modsx_comm *cm);
 int comm_world(const modsx_comm *cm);

@@ -58,6 +58,11 @@ struct RcclApi {
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GetVersion)(int *) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  // the owner-only exchange (optional: a librccl without them still serves the all-gather paths)
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
 };
 static RcclApi g_rccl;
 static std::mutex g_rcclMu;
@@ -78,6 +83,10 @@ static bool rccl_load() {
   a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
   a.GetVersion = (decltype(a.GetVersion))dlsym(h, "ncclGetVersion");
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+  a.Send = (decltype(a.Send))dlsym(h, "ncclSend");
+  a.Recv = (decltype(a.Recv))dlsym(h, "ncclRecv");
+  a.GroupStart = (decltype(a.GroupStart))dlsym(h, "ncclGroupStart");
+  a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
   if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.CommAbort || !a.AllGather || !a.GetVersion || !a.GetErrorString) {
     set_error("librccl lacks an expected symbol");
     return false;
@@ -88,6 +97,9 @@ static bool rccl_load() {
 
 // ---- loopback transport: W ranks of one process on one device ---------------------------------------------------------
 constexpr char LOOP_MAGIC[8] = {'M', 'X', 'L', 'O', 'O', 'P', '0', '1'};
+// one point-to-point transfer of an exchange: `bytes` at `ptr` to / from rank `peer`.  The k-th send of rank a to rank b meets the
+// k-th receive of rank b from rank a (the order ncclSend / ncclRecv match in inside a group).
+struct Xfer { int peer; void *ptr; size_t bytes; };
 struct LoopGroup {
   int world = 0;
   std::mutex mu;
@@ -97,7 +109,8 @@ struct LoopGroup {
   bool dead = false;
   // the events of a rank's slot belong to the GROUP: peers wait on them after the last barrier of a collective, so they are
   // destroyed with the group (when the last rank has left), never by the rank that recorded them
-  struct Slot { const void *send = nullptr; void *recv = nullptr; size_t bytes = 0; hipEvent_t ready = nullptr, done = nullptr; bool taken = false; };
+  struct Slot { const void *send = nullptr; void *recv = nullptr; size_t bytes = 0; hipEvent_t ready = nullptr, done = nullptr; bool taken = false;
+                const std::vector<Xfer> *sends = nullptr; };   // sends: the rank's send list of a point-to-point exchange
   std::vector<Slot> slots;
   int dev = 0;
   ~LoopGroup() {
@@ -117,6 +130,39 @@ struct LoopGroup {
   }
   void kill() { std::lock_guard<std::mutex> lk(mu); dead = true; cv.notify_all(); }
 };
+// The point-to-point exchange of W in-process ranks: every rank publishes its send list, copies what its receives name out of the
+// peers' send buffers (device to device, behind the peers' `ready` events) and lets go of its own send buffers once every peer
+// has copied (`done`).  0 = ok, 1 = a rank did not show up, 2 = the lists of two ranks do not match, 3 = a HIP call failed.
+static int loop_exchange(LoopGroup &g, int R, const std::vector<Xfer> &sends, const std::vector<Xfer> &recvs, hipStream_t s, int timeout_ms) {
+  const int W = g.world;
+  LoopGroup::Slot &me = g.slots[R];
+  me.sends = &sends;
+  if (hipEventRecord(me.ready, s) != hipSuccess) return 3;
+  if (!g.barrier(timeout_ms)) return 1;
+  int bad = 0;
+  std::vector<size_t> nextFrom(W, 0);      // how far into peer p's send list the search for "to me" has come
+  std::vector<char> waited(W, 0);
+  for (const Xfer &rv : recvs) {
+    if (rv.peer < 0 || rv.peer >= W) { bad = 2; break; }
+    const std::vector<Xfer> &ps = *g.slots[rv.peer].sends;
+    size_t &k = nextFrom[rv.peer];
+    while (k < ps.size() && ps[k].peer != R) k++;
+    if (k == ps.size() || ps[k].bytes != rv.bytes) { bad = 2; break; }
+    if (!waited[rv.peer]) { if (hipStreamWaitEvent(s, g.slots[rv.peer].ready, 0) != hipSuccess) { bad = 3; break; } waited[rv.peer] = 1; }
+    if (rv.bytes && hipMemcpyAsync(rv.ptr, ps[k].ptr, rv.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) { bad = 3; break; }
+    k++;
+  }
+  if (!bad)
+    for (int p = 0; p < W && !bad; p++) {       // every send to me must have met a receive
+      const std::vector<Xfer> &ps = *g.slots[p].sends;
+      for (size_t k = nextFrom[p]; k < ps.size(); k++) if (ps[k].peer == R) { bad = 2; break; }
+    }
+  if (hipEventRecord(me.done, s) != hipSuccess) bad = bad ? bad : 3;
+  if (!g.barrier(timeout_ms)) return 1;      // the send lists stay valid until every rank has read them
+  if (bad) return bad;
+  for (int p = 0; p < W; p++) if (hipStreamWaitEvent(s, g.slots[p].done, 0) != hipSuccess) return 3;
+  return 0;
+}
 static std::mutex g_loopMu;
 static std::map<uint64_t, std::shared_ptr<LoopGroup>> g_loopGroups;
 static uint64_t g_loopNext = 1;
@@ -179,12 +225,42 @@ static ncclResult_t mock_AllGather(const void *send, void *recv, size_t bytes, n
   for (int p = 0; p < W; p++) if (hipStreamWaitEvent(s, g.slots[p].done, 0) != hipSuccess) return ncclUnhandledCudaError;
   return ncclSuccess;
 }
+// ncclGroupStart .. ncclGroupEnd of the stand-in: the sends and receives of the calling thread are collected and run as ONE
+// loop_exchange at the group's end (a rank is one host thread here, as it is one process with the real library)
+struct MockPending { MockComm *mc = nullptr; hipStream_t s = nullptr; std::vector<Xfer> sends, recvs; int depth = 0; bool bad = false; };
+static thread_local MockPending t_mockPending;
+static ncclResult_t mock_GroupStart() { t_mockPending.depth++; return ncclSuccess; }
+static ncclResult_t mock_p2p(bool send, void *ptr, size_t bytes, int peer, ncclComm_t c, hipStream_t s) {
+  MockPending &P = t_mockPending;
+  MockComm *mc = reinterpret_cast<MockComm *>(c);
+  if (P.depth < 1) return ncclInvalidUsage;          // the library only issues them inside a group
+  if (P.mc && (P.mc != mc || P.s != s)) P.bad = true;
+  P.mc = mc; P.s = s;
+  (send ? P.sends : P.recvs).push_back(Xfer{peer, ptr, bytes});
+  return ncclSuccess;
+}
+static ncclResult_t mock_Send(const void *p, size_t n, ncclDataType_t, int peer, ncclComm_t c, hipStream_t s) { return mock_p2p(true, const_cast<void *>(p), n, peer, c, s); }
+static ncclResult_t mock_Recv(void *p, size_t n, ncclDataType_t, int peer, ncclComm_t c, hipStream_t s) { return mock_p2p(false, p, n, peer, c, s); }
+static ncclResult_t mock_GroupEnd() {
+  MockPending &P = t_mockPending;
+  if (P.depth < 1) return ncclInvalidUsage;
+  if (--P.depth) return ncclSuccess;
+  ncclResult_t r = ncclSuccess;
+  if (P.bad) r = ncclInvalidUsage;
+  else if (P.mc) {
+    const int e = loop_exchange(*P.mc->g, P.mc->rank, P.sends, P.recvs, P.s, 20000);
+    r = e == 0 ? ncclSuccess : e == 1 ? ncclSystemError : e == 2 ? ncclInvalidArgument : ncclUnhandledCudaError;
+  }
+  P = MockPending();
+  return r;
+}
 
 struct ShardLane {
-  DevBuf blkLocal, blkAll, regsIn, regsOut, mLocal, mAll, rcDev, order, posOut;
-  PinBuf hRegs, hHdr, hRc;
+  DevBuf blkLocal, blkAll, regsIn, regsOut, mLocal, mAll, rcDev, order, posOut, ownSend, ownRecv, ownJobs;
+  PinBuf hRegs, hHdr, hRc, hJobs;
   size_t capBlock = 0;    // agreed: bytes of one region block the lane's buffers hold (blkLocal; blkAll = world x)
   size_t capMatch = 0;    // agreed: bytes of one match block (mLocal; mAll = world x)
+  size_t capOwnSend = 0, capOwnRecv = 0, capOwnList = 0;   // agreed (owner-only exchange): rows the send / receive buffers and the list buffers hold
   int guessRows = 0;      // agreed: rows per block of the next exchange (a function of the headers gathered so far)
   size_t lastN = 0;       // local: list length of the last exchange (sizes the speculative region download)
   size_t localCap = 0;    // local: region capacity the rank's own descriptor scratch needed last time (a too small first guess runs the views twice)
@@ -211,6 +287,8 @@ struct modsx_comm {
   std::mutex issueMu;                       // serialises enqueueing on the RCCL communicator with its abort
   bool aborted = false;                     // under issueMu: ncclCommAbort has run; nccl is never used again
   long bytes_gathered = 0, collectives = 0, retries = 0, agreements = 0;
+  long bytes_received = 0, exchanges = 0;   // the owner-only exchange: bytes this rank received in point-to-point transfers, calls
+  std::atomic<int> exchange_mode{MODSX_EXCHANGE_ALL_GATHER};   // modsx_comm_set_exchange: the same on every rank
   std::atomic<long> turn_wait_us{0};        // time the lanes spent waiting for their turn (modsx_comm_stats)
 };
 
@@ -231,6 +309,7 @@ static RowFmt row_fmt(int format) {
 static inline __host__ __device__ int row_bytes(int regLen, int nd) { return regLen + 128 * nd; }   // nd = descriptor classes of the step
 struct DescPtrs { unsigned char *p[MODSX_MAX_DESC]; };
 constexpr int HDR_MAGIC = 0x4D585348;   // "MXSH"
+constexpr int HDR_MAGIC_OWNER = 0x4D58534F;   // "MXSO": a header of the owner-only exchange (no rows behind it)
 constexpr int HDR_FIXED = 4;            // ints before the per-view counts: magic, rc, rows, views
 static int hdr_bytes(int nv) { return ((HDR_FIXED + nv) * 4 + 63) & ~63; }
 
@@ -353,6 +432,39 @@ static int transport_all_gather(modsx_comm *cm, const void *send, void *recv, si
   cm->collectives++;
   return MODSX_OK;
 }
+// the transport of the owner-only exchange: this rank's sends and receives as ONE group on stream s (the lane's turn is held by the
+// caller).  Every rank derives its lists from the same gathered headers, so the k-th send of a to b has the size of the k-th receive
+// of b from a.
+static int transport_exchange(modsx_comm *cm, const std::vector<Xfer> &sends, const std::vector<Xfer> &recvs, hipStream_t s) {
+  if (cm->dead.load()) return comm_dead_rc(cm);
+  if (!cm->loop) {
+    ncclResult_t r = ncclSuccess;
+    {
+      std::lock_guard<std::mutex> lk(cm->issueMu);
+      if (cm->aborted || !cm->nccl) return comm_dead_rc(cm);
+      if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd) { set_error("librccl lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd"); return MODSX_ERR_DEVICE; }
+      r = g_rccl.GroupStart();
+      for (size_t k = 0; k < recvs.size() && r == ncclSuccess; k++) r = g_rccl.Recv(recvs[k].ptr, recvs[k].bytes, ncclUint8, recvs[k].peer, cm->nccl, s);
+      for (size_t k = 0; k < sends.size() && r == ncclSuccess; k++) r = g_rccl.Send(sends[k].ptr, sends[k].bytes, ncclUint8, sends[k].peer, cm->nccl, s);
+      const ncclResult_t e = g_rccl.GroupEnd();      // always closed, also after a failed call inside
+      if (r == ncclSuccess) r = e;
+    }
+    if (r != ncclSuccess) {
+      set_error(std::string("ncclSend / ncclRecv: ") + g_rccl.GetErrorString(r));
+      comm_kill(cm, "the owner-only exchange failed");
+      return MODSX_ERR_DEVICE;
+    }
+  } else {
+    const int e = loop_exchange(*cm->loop, cm->rank, sends, recvs, s, cm->timeout_ms.load());
+    if (e) {
+      comm_kill(cm, e == 1 ? "loopback: a rank did not reach the exchange" : e == 2 ? "loopback: the ranks' send and receive lists do not match" : "loopback: a device call failed");
+      return comm_dead_rc(cm);
+    }
+  }
+  for (const Xfer &x : recvs) cm->bytes_received += (long)x.bytes;
+  cm->exchanges++;
+  return MODSX_OK;
+}
 static int ordered_all_gather(modsx_comm *cm, int lane, const void *send, void *recv, size_t bytes, hipStream_t s) {
   int rc = turn_begin(cm, lane);
   if (rc) return rc;
@@ -463,6 +575,67 @@ int view_block_order(const int *counts, int world, int nviews, int maxrows, std:
   return (int)src.size();
 }
 
+// ---- the owner-only exchange ---------------------------------------------------------------------------------------------------
+// modsx_match_pairs_views_sharded verifies pair g on ONE rank, and only that rank reads the pair's rows: with
+// modsx_comm_set_exchange(MODSX_EXCHANGE_OWNER) the rows of image j travel to owner[j] alone (ncclSend / ncclRecv inside one
+// group) instead of to every rank -- 1 / world of the all-gather's volume on the wire, the same bytes into the owner.  The
+// per-item counts still go to every rank (an all-gather of the headers, a few KB): from them every rank derives, alike,
+//   * the messages: rank r sends the rows of its items of image j (consecutive in its local order) to owner[j], images ascending;
+//     the owner's receive buffer holds them image by image, source ranks ascending;
+//   * the unpack jobs of an owner: item f of an owned image = rows of the receive buffer -> rows [start[f], start[f] + count[f]) of
+//     the list, where start[] counts ALL items -- a rank's lists keep the global positions, the slices of images it does not own
+//     stay unwritten and unread;
+//   * the capacities every rank's buffers need (the maxima over the ranks), so that growth happens at agreed points.
+struct OwnerMsg { int peer, image, row0, rows; };   // row0: first LOCAL row (send) / first row of the receive buffer (recv)
+struct OwnerJob { int src0, dst0, n, pad; };        // n rows from row src0 of the receive buffer to row dst0 of the list
+struct OwnerPlan {
+  std::vector<OwnerMsg> sends, recvs;
+  std::vector<OwnerJob> jobs;
+  size_t recvRows = 0, sendRows = 0, maxRecvRows = 0, maxSendRows = 0, N = 0;
+};
+static void owner_plan(const int *cnt, int nimg, int nviews, int W, int R, const int *owner, OwnerPlan &P) {
+  P = OwnerPlan();
+  const int nv = nimg * nviews;
+  std::vector<size_t> start(nv + 1, 0), perRank(W, 0), perOwner(W, 0);
+  for (int f = 0; f < nv; f++) { start[f + 1] = start[f] + (size_t)cnt[f]; perRank[f % W] += (size_t)cnt[f]; perOwner[owner[f / nviews]] += (size_t)cnt[f]; }
+  P.N = start[nv];
+  for (int r = 0; r < W; r++) { P.maxSendRows = std::max(P.maxSendRows, perRank[r]); P.maxRecvRows = std::max(P.maxRecvRows, perOwner[r]); }
+  P.sendRows = perRank[R];
+  size_t localRow = 0;
+  std::vector<size_t> rowsOf(W);
+  for (int j = 0; j < nimg; j++) {
+    std::fill(rowsOf.begin(), rowsOf.end(), 0);
+    for (int v = 0; v < nviews; v++) { const int f = j * nviews + v; rowsOf[f % W] += (size_t)cnt[f]; }
+    if (rowsOf[R]) P.sends.push_back(OwnerMsg{owner[j], j, (int)localRow, (int)rowsOf[R]});
+    localRow += rowsOf[R];
+    if (owner[j] != R) continue;
+    std::vector<size_t> seg(W);
+    for (int r = 0; r < W; r++) {
+      seg[r] = P.recvRows;
+      if (rowsOf[r]) P.recvs.push_back(OwnerMsg{r, j, (int)P.recvRows, (int)rowsOf[r]});
+      P.recvRows += rowsOf[r];
+    }
+    for (int v = 0; v < nviews; v++) {
+      const int f = j * nviews + v, r = f % W;
+      if (cnt[f]) P.jobs.push_back(OwnerJob{(int)seg[r], (int)start[f], cnt[f], 0});
+      seg[r] += (size_t)cnt[f];
+    }
+  }
+}
+// rows of the receive buffer to their list positions: blockIdx.y = job, one 32-lane group per row
+__global__ __launch_bounds__(256) void k_unpack_jobs(const OwnerJob *jobs, const unsigned char *recv, unsigned char *regs, int regLen, DescPtrs desc,
+                                                     int nd, double *pos, int posOfs) {
+  const OwnerJob jb = jobs[blockIdx.y];
+  const int i = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+  if (i >= jb.n) return;
+  const unsigned char *s = recv + (size_t)(jb.src0 + i) * row_bytes(regLen, nd);
+  const size_t j = (size_t)jb.dst0 + i;
+  if (l < regLen / 8) reinterpret_cast<uint64_t *>(regs + j * regLen)[l] = reinterpret_cast<const uint64_t *>(s)[l];
+  if (pos && l < 2) pos[2 * j + l] = reinterpret_cast<const double *>(s + posOfs)[l];
+  for (int k = 0; k < nd; k++)
+    if (l < 16) reinterpret_cast<uint64_t *>(desc.p[k] + j * 128)[l] = reinterpret_cast<const uint64_t *>(s + regLen + 128 * k)[l];
+}
+
 int comm_rank(const modsx_comm *cm) { return cm->rank; }
 int comm_world(const modsx_comm *cm) { return cm->world; }
 
@@ -506,7 +679,7 @@ int detect_describe_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
 int detect_describe_items_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *const *imgs, int nimg, const modsx_view *views,
                                   int nviews, const modsx_pair_params &pp, const DescSet &ds, std::vector<modsx_region> &regs,
                                   DevBuf *const *descAcc, const size_t *base, int *viewCounts, const unsigned char *wantImg,
-                                  std::vector<size_t> *regStart, double **devPos, std::vector<double> *kpRows) {
+                                  std::vector<size_t> *regStart, double **devPos, std::vector<double> *kpRows, const int *ownerImg) {
   regs.clear();
   if (kpRows) kpRows->clear();
   const RowFmt rf = row_fmt(kpRows ? MODSX_SHARD_ROW_KP : MODSX_SHARD_ROW_REGION);
@@ -542,6 +715,113 @@ int detect_describe_items_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
   if (lrc) { lerr = last_error(); local.clear(); std::fill(cnt.begin(), cnt.end(), 0); }
   const int nloc = (int)local.size();
   const int hdrB = hdr_bytes(nv);
+  if (ownerImg && cm->exchange_mode.load() == MODSX_EXCHANGE_OWNER) {
+    // ---- the owner-only exchange: headers to every rank, rows to the rank that reads them (see owner_plan) ----
+    for (int j = 0; j < nimg; j++) if (ownerImg[j] < 0 || ownerImg[j] >= W) { set_error("sharded path: an image owner is not a rank"); return MODSX_ERR_ARG; }
+    // a. the headers: an all-gather of hdrB bytes per rank; the mode travels in the magic, so ranks set differently stop here
+    if ((size_t)hdrB > L.capBlock) {
+      int arc = MODSX_OK;
+      if (!L.blkLocal.ensure(hdrB) || !L.blkAll.ensure((size_t)hdrB * W)) arc = MODSX_ERR_NOMEM;
+      arc = comm_agree(cm, lane, s, arc);
+      if (arc) return arc;
+      L.capBlock = hdrB;
+    }
+    if (!L.hHdr.ensure((size_t)hdrB * (W + 1))) { comm_kill(cm, "no pinned memory for a block header"); return MODSX_ERR_NOMEM; }
+    int *hh = (int *)L.hHdr.p;
+    memset(hh, 0, hdrB);
+    hh[0] = HDR_MAGIC_OWNER; hh[1] = lrc; hh[2] = lrc ? 0 : nloc; hh[3] = nv;
+    if (!lrc) memcpy(hh + HDR_FIXED, cnt.data(), (size_t)nv * 4);
+    MX_HIP(hipMemcpyAsync(L.blkLocal.p, hh, hdrB, hipMemcpyHostToDevice, s));
+    int rc = ordered_all_gather(cm, lane, L.blkLocal.p, L.blkAll.p, hdrB, s);
+    if (rc) return rc;
+    MX_HIP(hipMemcpyAsync((char *)L.hHdr.p + hdrB, L.blkAll.p, (size_t)hdrB * W, hipMemcpyDeviceToHost, s));
+    rc = comm_wait(cm, s);
+    if (rc) return rc;
+    std::vector<int> vc(nv, 0);
+    for (int r = 0; r < W; r++) {
+      const int *h = (const int *)((char *)L.hHdr.p + (size_t)hdrB * (r + 1));
+      if (h[0] != HDR_MAGIC_OWNER || h[3] != nv) { comm_kill(cm, "a gathered header is malformed (ranks out of step, or set to different exchange modes)"); return comm_dead_rc(cm); }
+      if (h[1]) {
+        if (r == R) set_error(lerr); else set_error("rank " + std::to_string(r) + " failed in the sharded detect / describe (" + std::to_string(h[1]) + ")");
+        return h[1];
+      }
+      for (int v = r; v < nv; v += W) vc[v] = h[HDR_FIXED + v];
+    }
+    // b. the plan, and the buffers it needs: capacities are the maxima over the ranks, so every rank grows at the same calls
+    OwnerPlan P;
+    owner_plan(vc.data(), nimg, nviews, W, R, ownerImg, P);
+    if ((size_t)nloc != P.sendRows) { comm_kill(cm, "a rank's header does not count its rows"); return comm_dead_rc(cm); }
+    const size_t listRows = std::max<size_t>(P.N, 1);
+    if (P.maxSendRows > L.capOwnSend || P.maxRecvRows > L.capOwnRecv || listRows > L.capOwnList) {
+      const size_t ns = std::max(L.capOwnSend, P.maxSendRows + P.maxSendRows / 4 + 64), nr = std::max(L.capOwnRecv, P.maxRecvRows + P.maxRecvRows / 4 + 64);
+      const size_t nl = std::max(L.capOwnList, listRows + listRows / 4 + 64);
+      int arc = MODSX_OK;
+      if (!L.ownSend.ensure(ns * ROW_B) || !L.ownRecv.ensure(nr * ROW_B) || !L.regsIn.ensure(ns * RB) || !L.hRegs.ensure(std::max(ns, nl) * RB) ||
+          !L.regsOut.ensure(nl * RB) || !L.posOut.ensure(nl * 16))
+        arc = MODSX_ERR_NOMEM;
+      for (int k = 0; k < nd && !arc; k++)
+        if (grow_keep(s, *descAcc[k], base[k] * 128, (base[k] + nl) * 128) != MODSX_OK) arc = MODSX_ERR_NOMEM;
+      arc = comm_agree(cm, lane, s, arc);
+      if (arc) return arc;
+      L.capOwnSend = ns; L.capOwnRecv = nr; L.capOwnList = nl;
+    }
+    // the caller's descriptor lists are its own: they may be other buffers than at the last agreed growth
+    for (int k = 0; k < nd; k++)
+      if (grow_keep(s, *descAcc[k], base[k] * 128, (base[k] + L.capOwnList) * 128) != MODSX_OK) { comm_kill(cm, "out of memory for a descriptor list"); return MODSX_ERR_NOMEM; }
+    const size_t jobB = std::max<size_t>(1, P.jobs.size()) * sizeof(OwnerJob);
+    if (!L.hJobs.ensure(jobB) || !L.ownJobs.ensure(jobB)) { comm_kill(cm, "out of memory for the unpack jobs"); return MODSX_ERR_NOMEM; }
+    // c. this rank's rows, packed in local (item) order
+    if (nloc) {
+      if (rf.regLen == REG_B) memcpy(L.hRegs.p, local.data(), (size_t)nloc * REG_B);
+      else for (int i = 0; i < nloc; i++) memcpy((char *)L.hRegs.p + (size_t)i * RB, (const char *)&local[i] + rf.regOff, RB);
+      MX_HIP(hipMemcpyAsync(L.regsIn.p, L.hRegs.p, (size_t)nloc * RB, hipMemcpyHostToDevice, s));
+      DescPtrs dp;
+      for (int k = 0; k < MODSX_MAX_DESC; k++) dp.p[k] = (unsigned char *)c->shardLocal.p + (size_t)k * cap * 128;
+      hipLaunchKernelGGL(k_pack_rows, dim3((nloc + 7) / 8), dim3(256), 0, s, (const unsigned char *)L.regsIn.p, rf.regLen, dp, nd, nloc,
+                         (unsigned char *)L.ownSend.p);
+    }
+    // d. the exchange: one group of sends and receives, in the lane's turn
+    std::vector<Xfer> sends, recvs;
+    for (const OwnerMsg &m : P.sends) sends.push_back(Xfer{m.peer, (char *)L.ownSend.p + (size_t)m.row0 * ROW_B, (size_t)m.rows * ROW_B});
+    for (const OwnerMsg &m : P.recvs) recvs.push_back(Xfer{m.peer, (char *)L.ownRecv.p + (size_t)m.row0 * ROW_B, (size_t)m.rows * ROW_B});
+    rc = turn_begin(cm, lane);
+    if (rc) return rc;
+    rc = transport_exchange(cm, sends, recvs, s);
+    turn_end(cm);
+    if (rc) return rc;
+    // e. the owned images' rows to their places in the list
+    if (!P.jobs.empty()) {
+      memcpy(L.hJobs.p, P.jobs.data(), P.jobs.size() * sizeof(OwnerJob));
+      MX_HIP(hipMemcpyAsync(L.ownJobs.p, L.hJobs.p, P.jobs.size() * sizeof(OwnerJob), hipMemcpyHostToDevice, s));
+      int maxn = 0;
+      for (const OwnerJob &jb : P.jobs) maxn = std::max(maxn, jb.n);
+      DescPtrs dp;
+      for (int k = 0; k < MODSX_MAX_DESC; k++) dp.p[k] = k < nd ? (unsigned char *)descAcc[k]->p + base[k] * 128 : nullptr;
+      hipLaunchKernelGGL(k_unpack_jobs, dim3((maxn + 7) / 8, (unsigned)P.jobs.size()), dim3(256), 0, s, (const OwnerJob *)L.ownJobs.p,
+                         (const unsigned char *)L.ownRecv.p, (unsigned char *)L.regsOut.p, rf.regLen, dp, nd, devPos ? (double *)L.posOut.p : nullptr, rf.posOfs);
+    }
+    L.lastN = P.N;
+    if (viewCounts) for (int v = 0; v < nv; v++) viewCounts[v] = vc[v];
+    if (devPos) *devPos = (double *)L.posOut.p;
+    // f. the regions the caller reads on the host: the flagged images it owns (others were never received)
+    std::vector<size_t> st(nimg + 1, 0), devStart(nimg + 1, 0);
+    for (int j = 0; j < nimg; j++) {
+      size_t n = 0;
+      for (int v = 0; v < nviews; v++) n += (size_t)vc[(size_t)j * nviews + v];
+      devStart[j + 1] = devStart[j] + n;
+      st[j + 1] = st[j] + ((!wantImg || wantImg[j]) && ownerImg[j] == R ? n : 0);
+    }
+    for (int j = 0; j < nimg; j++)
+      if (st[j + 1] > st[j])
+        MX_HIP(hipMemcpyAsync((char *)L.hRegs.p + st[j] * RB, (char *)L.regsOut.p + devStart[j] * RB, (devStart[j + 1] - devStart[j]) * RB, hipMemcpyDeviceToHost, s));
+    rc = comm_wait(cm, s);
+    if (rc) return rc;
+    MX_HIP(hipGetLastError());
+    if (kpRows) { kpRows->resize(st[nimg] * 7); if (st[nimg]) memcpy(kpRows->data(), L.hRegs.p, st[nimg] * RB); }
+    else { regs.resize(st[nimg]); if (st[nimg]) memcpy(regs.data(), L.hRegs.p, st[nimg] * REG_B); }
+    if (regStart) *regStart = st;
+    return MODSX_OK;
+  }
   if (!L.guessRows) L.guessRows = 4096;
   for (int attempt = 0;; attempt++) {
     const int G = L.guessRows;
@@ -829,7 +1109,11 @@ int match_pairs_views_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_image *c
   std::vector<size_t> hs;      // slice of image j in `kp` (empty when not wanted)
   std::vector<double> kp;      // the call returns pair results, no region lists: a row carries the verification slice of a region only
   double *devPos = nullptr;
-  rc = detect_describe_items_sharded(c, cm, imgs.data(), nimg, views, nv, pp, ds, regs, acc, base0, counts.data(), want.data(), &hs, &devPos, &kp);
+  // owner_base >= 0: only the owner of a pair reads its rows -- with MODSX_EXCHANGE_OWNER they travel to that rank alone
+  std::vector<int> ownerImg(nimg, 0);
+  for (int g = 0; g < np && owner_base >= 0; g++) ownerImg[2 * g] = ownerImg[2 * g + 1] = (owner_base + g) % cm->world;
+  rc = detect_describe_items_sharded(c, cm, imgs.data(), nimg, views, nv, pp, ds, regs, acc, base0, counts.data(), want.data(), &hs, &devPos, &kp,
+                                     owner_base >= 0 ? ownerImg.data() : nullptr);
   if (rc) return rc;
   // the slice of every image in the gathered (device) lists
   std::vector<size_t> start(nimg + 1, 0);
@@ -990,9 +1274,9 @@ int modsx_comm_set_lanes(modsx_comm *cm, int nlanes) {
   hipSetDevice(cm->dev);
   std::lock_guard<std::mutex> lk(cm->mu);
   for (ShardLane &L : cm->lanes) {
-    DevBuf *bufs[] = {&L.blkLocal, &L.blkAll, &L.regsIn, &L.regsOut, &L.mLocal, &L.mAll, &L.rcDev, &L.order, &L.posOut};
+    DevBuf *bufs[] = {&L.blkLocal, &L.blkAll, &L.regsIn, &L.regsOut, &L.mLocal, &L.mAll, &L.rcDev, &L.order, &L.posOut, &L.ownSend, &L.ownRecv, &L.ownJobs};
     for (DevBuf *b : bufs) b->release();
-    L.hRegs.release(); L.hHdr.release(); L.hRc.release();
+    L.hRegs.release(); L.hHdr.release(); L.hRc.release(); L.hJobs.release();
   }
   return comm_make_lanes(cm, nlanes);
 }
@@ -1047,11 +1331,33 @@ void modsx_comm_destroy(modsx_comm *cm) {
     cm->loop.reset();
   }
   for (ShardLane &L : cm->lanes) {
-    DevBuf *bufs[] = {&L.blkLocal, &L.blkAll, &L.regsIn, &L.regsOut, &L.mLocal, &L.mAll, &L.rcDev, &L.order, &L.posOut};
+    DevBuf *bufs[] = {&L.blkLocal, &L.blkAll, &L.regsIn, &L.regsOut, &L.mLocal, &L.mAll, &L.rcDev, &L.order, &L.posOut, &L.ownSend, &L.ownRecv, &L.ownJobs};
     for (DevBuf *b : bufs) b->release();
-    L.hRegs.release(); L.hHdr.release(); L.hRc.release();
+    L.hRegs.release(); L.hHdr.release(); L.hRc.release(); L.hJobs.release();
   }
   delete cm;
+}
+
+int modsx_comm_set_exchange(modsx_comm *cm, int mode) {
+  if (!cm || (mode != MODSX_EXCHANGE_ALL_GATHER && mode != MODSX_EXCHANGE_OWNER)) { mx::set_error("modsx_comm_set_exchange: bad argument"); return MODSX_ERR_ARG; }
+  cm->exchange_mode.store(mode);
+  return MODSX_OK;
+}
+
+int modsx_shard_owner_plan(const int *item_counts, int nimages, int nviews, int world, int rank, const int *image_owner, int *sends,
+                           int *recvs, int *jobs, int cap, long *n) {
+  if (!item_counts || !image_owner || !n || nimages < 1 || nviews < 1 || world < 1 || rank < 0 || rank >= world || cap < 0 ||
+      (cap > 0 && (!sends || !recvs || !jobs))) { mx::set_error("modsx_shard_owner_plan: bad argument"); return MODSX_ERR_ARG; }
+  for (int j = 0; j < nimages; j++) if (image_owner[j] < 0 || image_owner[j] >= world) { mx::set_error("modsx_shard_owner_plan: an owner is not a rank"); return MODSX_ERR_ARG; }
+  for (int f = 0; f < nimages * nviews; f++) if (item_counts[f] < 0) { mx::set_error("modsx_shard_owner_plan: negative count"); return MODSX_ERR_ARG; }
+  OwnerPlan P;
+  owner_plan(item_counts, nimages, nviews, world, rank, image_owner, P);
+  n[0] = (long)P.sends.size(); n[1] = (long)P.recvs.size(); n[2] = (long)P.jobs.size(); n[3] = (long)P.recvRows; n[4] = (long)P.N;
+  if ((long)cap < n[0] || (long)cap < n[1] || (long)cap < n[2]) return MODSX_ERR_CAPACITY;
+  for (size_t k = 0; k < P.sends.size(); k++) { const OwnerMsg &m = P.sends[k]; int *o = sends + 4 * k; o[0] = m.peer; o[1] = m.image; o[2] = m.row0; o[3] = m.rows; }
+  for (size_t k = 0; k < P.recvs.size(); k++) { const OwnerMsg &m = P.recvs[k]; int *o = recvs + 4 * k; o[0] = m.peer; o[1] = m.image; o[2] = m.row0; o[3] = m.rows; }
+  for (size_t k = 0; k < P.jobs.size(); k++) { const OwnerJob &jb = P.jobs[k]; int *o = jobs + 4 * k; o[0] = jb.src0; o[1] = jb.dst0; o[2] = jb.n; o[3] = 0; }
+  return MODSX_OK;
 }
 
 int modsx_comm_info(const modsx_comm *cm, int *rank, int *world, int *rccl_version, long *bytes_gathered, long *collectives) {
@@ -1066,7 +1372,8 @@ int modsx_comm_info(const modsx_comm *cm, int *rank, int *world, int *rccl_versi
 
 int modsx_comm_stats(const modsx_comm *cm, long *out, int n) {
   if (!cm || !out) { mx::set_error("modsx_comm_stats: null"); return MODSX_ERR_ARG; }
-  const long v[] = {cm->collectives, cm->bytes_gathered, cm->retries, cm->agreements, (long)cm->lanes.size(), cm->loop ? 1L : 0L, cm->dead.load() ? 1L : 0L, cm->turn_wait_us.load()};
+  const long v[] = {cm->collectives, cm->bytes_gathered, cm->retries, cm->agreements, (long)cm->lanes.size(), cm->loop ? 1L : 0L, cm->dead.load() ? 1L : 0L, cm->turn_wait_us.load(),
+                    cm->bytes_received, cm->exchanges};
   const int m = (int)(sizeof v / sizeof v[0]);
   for (int i = 0; i < n && i < m; i++) out[i] = v[i];
   return m;
@@ -1306,6 +1613,7 @@ extern "C" __attribute__((visibility("default"))) int modsx_debug_mock_rccl(int 
     a.h = (void *)1;
     a.GetUniqueId = mock_GetUniqueId; a.CommInitRank = mock_CommInitRank; a.CommDestroy = mock_CommDestroy; a.CommAbort = mock_CommAbort;
     a.AllGather = mock_AllGather; a.GetVersion = mock_GetVersion; a.GetErrorString = mock_GetErrorString;
+    a.Send = mock_Send; a.Recv = mock_Recv; a.GroupStart = mock_GroupStart; a.GroupEnd = mock_GroupEnd;
     g_rccl = a;
     g_mockOn = true;
   } else if (!enable && g_mockOn) {

@@ -61,6 +61,10 @@ class NativeComm:
     def match_ladder_sharded(self, w, img1, img2, steps, params, min_matches=10):
         return self.ctxs[w].match_ladder(img1, img2, steps, params, min_matches, comm=self.comm)
 
+    def set_exchange(self, mode):
+        """mods_amd.EXCHANGE_OWNER: the rows of a pair travel to its owner rank only (modsx_comm_set_exchange; alike on every rank)."""
+        mods_amd._check(mods_amd.lib().modsx_comm_set_exchange(C.c_void_p(self.comm), int(mode)), "comm_set_exchange")
+
     def lane_done(self, w):
         mods_amd.lib().modsx_comm_lane_done(C.c_void_p(self.comm), int(w))
 
@@ -74,6 +78,7 @@ class NativeComm:
         return {"ranks_seen_by_rccl": wd.value, "rccl_version": ver.value, "communicators_per_rank": 1, "lanes": len(self.ctxs),
                 "all_gather_calls_rank0": ncol.value, "bytes_all_gathered_rank0": byts.value,
                 "block_retries": st["block_retries"], "agreement_collectives": st["agreements"],
+                "owner_exchanges_rank0": st["exchanges"], "bytes_received_owner_exchange_rank0": st["bytes_received"],
                 "transport": "loopback" if st["loopback"] else "rccl"}
 
     def close(self):

@@ -122,6 +122,109 @@ def test_view_shard_exchange_in_the_shipped_block_format(world):
     assert dict(ret) == {r: True for r in range(world)}
 
 
+def _owner_worker(rank, world, port, ret):
+    """The owner-only exchange (modsx_comm_set_exchange(MODSX_EXCHANGE_OWNER)) over gloo: counts to every rank, then the messages
+    modsx_shard_owner_plan states -- rows of image j to owner[j] alone -- as point-to-point sends and receives, and the plan's jobs put
+    the received rows at the list positions the all-gather path gives them."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mods_amd
+    blocks, counts_ref, ref_regs, ref_desc = _blocks()
+    nviews = len(blocks)
+    item_blocks = blocks + blocks[::-1] + blocks            # three images
+    owners = [0, world - 1, 1 % world]
+    items = len(item_blocks)
+    KP = mods_amd.SHARD_ROW_KP
+    row_b = 56 + 128
+    mine = [f for f in range(items) if f % world == rank]
+    regs_l = np.concatenate([item_blocks[f][0] for f in mine])
+    desc_l = np.concatenate([item_blocks[f][1] for f in mine])
+    cnt = np.zeros(items, np.int32)
+    for f in mine:
+        cnt[f] = len(item_blocks[f][0])
+    hdr_b = mods_amd.shard_block_bytes(items, 0, 1, KP)
+    blk = mods_amd.shard_block_pack(regs_l, [desc_l], cnt, len(regs_l), row_format=KP)      # the rows a rank packs, in item order
+    rows_l = blk[hdr_b:].reshape(len(regs_l), row_b)
+    # counts to every rank (the device path all-gathers the headers; the counts are all it reads from them)
+    parts = [torch.zeros(items, dtype=torch.int32) for _ in range(world)]
+    dist.all_gather(parts, torch.from_numpy(cnt))
+    counts = torch.stack(parts).sum(0).numpy().astype(np.int32)
+    ok = np.array_equal(counts, [len(b[0]) for b in item_blocks])
+    plan = mods_amd.shard_owner_plan(counts, nviews, world, rank, owners)
+    recv = np.zeros((max(1, plan["recv_rows"]), row_b), np.uint8)
+    # gloo has no send to self: a rank's own messages are copied, in order, like the k-th send meets the k-th receive of a peer
+    self_sends = [m for m in plan["sends"] if m[0] == rank]
+    self_recvs = [m for m in plan["recvs"] if m[0] == rank]
+    ok = ok and len(self_sends) == len(self_recvs)
+    for sm, rm in zip(self_sends, self_recvs):
+        ok = ok and sm[3] == rm[3] and sm[1] == rm[1]
+        recv[rm[2]:rm[2] + rm[3]] = rows_l[sm[2]:sm[2] + sm[3]]
+    reqs, bufs = [], []
+    for peer, image, row0, rows in plan["recvs"]:
+        if peer != rank:
+            t = torch.zeros(rows * row_b, dtype=torch.uint8)
+            bufs.append((t, row0, rows))
+            reqs.append(dist.irecv(t, src=int(peer)))
+    for peer, image, row0, rows in plan["sends"]:
+        if peer != rank:
+            ok = ok and owners[image] == peer
+            reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(rows_l[row0:row0 + rows]).reshape(-1)), dst=int(peer)))
+    for q in reqs:
+        q.wait()
+    for t, row0, rows in bufs:
+        recv[row0:row0 + rows] = t.numpy().reshape(rows, row_b)
+    lst = np.zeros((plan["list_rows"], row_b), np.uint8)
+    filled = np.zeros(plan["list_rows"], bool)
+    for src0, dst0, n, _ in plan["jobs"]:
+        lst[dst0:dst0 + n] = recv[src0:src0 + n]
+        filled[dst0:dst0 + n] = True
+    # an owner holds exactly its images, at the positions of the full list, with the rows the all-gather path would give it
+    exp_regs = np.concatenate([b[0] for b in item_blocks]); exp_desc = np.concatenate([b[1] for b in item_blocks])
+    exp_kp = mods_amd.shard_kp_rows(exp_regs)
+    start = np.concatenate([[0], np.cumsum(counts)])
+    for j in range(3):
+        lo, hi = start[j * nviews], start[(j + 1) * nviews]
+        if owners[j] == rank:
+            ok = ok and filled[lo:hi].all()
+            ok = ok and np.array_equal(lst[lo:hi, :56].copy().view(np.float64).reshape(-1, 7), exp_kp[lo:hi])
+            ok = ok and np.array_equal(lst[lo:hi, 56:], exp_desc[lo:hi])
+        else:
+            ok = ok and not filled[lo:hi].any()
+    ok = ok and plan["recv_rows"] == sum(int(start[(j + 1) * nviews] - start[j * nviews]) for j in range(3) if owners[j] == rank)
+    dist.barrier()
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_owner_only_exchange_over_gloo(world):
+    port = 31500 + (os.getpid() % 2000) + world
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_owner_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_owner_plan_single_process():
+    """modsx_shard_owner_plan by hand on a small case: 2 images x 3 views over 2 ranks, image 0 read by rank 1, image 1 by rank 0."""
+    sys.path.insert(0, ROOT)
+    import mods_amd
+    counts = [2, 1, 3, 0, 4, 5]          # items 0..5; rank 0 holds items 0, 2, 4 (local rows 2 + 3 + 4), rank 1 items 1, 3, 5 (1 + 0 + 5)
+    p0 = mods_amd.shard_owner_plan(counts, 3, 2, 0, [1, 0])
+    p1 = mods_amd.shard_owner_plan(counts, 3, 2, 1, [1, 0])
+    assert p0["sends"].tolist() == [[1, 0, 0, 5], [0, 1, 5, 4]]          # image 0: local rows 0..4 to rank 1; image 1: rows 5..8 to itself
+    assert p1["sends"].tolist() == [[1, 0, 0, 1], [0, 1, 1, 5]]
+    assert p0["recvs"].tolist() == [[0, 1, 0, 4], [1, 1, 4, 5]] and p0["recv_rows"] == 9      # image 1: from rank 0, then from rank 1
+    assert p1["recvs"].tolist() == [[0, 0, 0, 5], [1, 0, 5, 1]] and p1["recv_rows"] == 6
+    assert p0["list_rows"] == p1["list_rows"] == 15
+    # jobs: items 3 (empty), 4, 5 of image 1 on rank 0; items 0, 1, 2 of image 0 on rank 1 (list rows count all items)
+    assert p0["jobs"].tolist() == [[0, 6, 4, 0], [4, 10, 5, 0]]
+    assert p1["jobs"].tolist() == [[0, 0, 2, 0], [5, 2, 1, 0], [2, 3, 3, 0]]
+
+
 def test_block_format_single_process():
     """The host statement of the wire format without any transport: sizes, the header, a too-small block, capacity, and that the
     ordering is the one modsx_view_block_order states."""

@@ -197,6 +197,99 @@ def test_batched_pairs_one_exchange_equals_single_pairs(ctx, modsx, small_pair, 
         d.free()
 
 
+@pytest.mark.parametrize("world,npairs,transport", [(2, 3, "loopback"), (3, 5, "loopback"), (8, 4, "loopback"), (8, 1, "loopback"),
+                                                     (2, 3, "mock_rccl"), (3, 4, "mock_rccl")])
+def test_owner_only_exchange_equals_the_all_gather(ctx, modsx, small_pair, world, npairs, transport):
+    """MODSX_EXCHANGE_OWNER: the rows of pair g travel to rank (owner_base + g) mod world alone (headers to every rank, then one group
+    of sends and receives -- ncclSend / ncclRecv on the RCCL branch, here through the in-process stand-in) instead of to every rank.
+    Every owner's result == modsx_match_pair_views of that pair, the other ranks carry the region counts, two calls in a row (the
+    second without any growth), and a rank receives only its pairs' rows: the bytes of the point-to-point transfers summed over the
+    ranks are the rows of all pairs ONCE (the all-gather moves them `world` times, padded)."""
+    from mods_amd import distributed as D
+    a, b, _ = small_pair
+    imgs = [a, b, a[:200, :300].copy(), b[:200, :300].copy(), np.ascontiguousarray(a[::-1]), b]
+    dev = [ctx.upload(x) for x in imgs]
+    pairs = [(0, 1), (1, 0), (2, 3), (4, 5), (0, 5)][:npairs]
+    views = _views(modsx)
+    par = modsx.default_pair_params(ransac_seed=4)
+    refs = [ctx.match_pair_views(dev[i], dev[j], views, par) for i, j in pairs]
+
+    def rank_body(r, comm):
+        i1, i2 = [dev[i] for i, _ in pairs], [dev[j] for _, j in pairs]
+        ag = comm.match_pairs_views_sharded(0, i1, i2, views, par, owner_base=1)       # the default exchange first
+        st0 = modsx.comm_stats(comm.comm)
+        comm.set_exchange(modsx.EXCHANGE_OWNER)
+        out = comm.match_pairs_views_sharded(0, i1, i2, views, par, owner_base=1)
+        st1 = modsx.comm_stats(comm.comm)
+        out_b = comm.match_pairs_views_sharded(0, i1, i2, views, par, owner_base=0)
+        st2 = modsx.comm_stats(comm.comm)
+        every = comm.match_pairs_views_sharded(0, i1, i2, views, par, owner_base=-1)   # every rank wants every pair: stays an all-gather
+        st3 = modsx.comm_stats(comm.comm)
+        return ag, out, out_b, every, st0, st1, st2, st3
+
+    res = (D.run_loopback if transport == "loopback" else D.run_mock_rccl)(world, rank_body)
+    row_b = 56 + 128                                                            # MODSX_SHARD_ROW_KP, one descriptor class
+    total_rows = sum(ref["n_regions"][0] + ref["n_regions"][1] for ref in refs)
+    for r, (ag, out, out_b, every, st0, st1, st2, st3) in enumerate(res):
+        for g, ref in enumerate(refs):
+            _same_pair_result(every[g], ref)
+            for got, base in ((ag, 1), (out, 1), (out_b, 0)):
+                if (base + g) % world == r:
+                    _same_pair_result(got[g], ref)
+                else:
+                    assert got[g]["n_regions"] == ref["n_regions"] and got[g]["n_tentatives"] == 0 and got[g]["n_verified"] == 0
+        assert st0["exchanges"] == 0 and st1["exchanges"] == 1 and st2["exchanges"] == 2 and st3["exchanges"] == 2
+        assert st2["agreements"] == st1["agreements"]                           # the second owner-only call grows nothing
+        mine = sum(refs[g]["n_regions"][0] + refs[g]["n_regions"][1] for g in range(len(refs)) if (1 + g) % world == r)
+        assert st1["bytes_received"] - st0["bytes_received"] == mine * row_b, (r, st0, st1, mine)
+        # the headers still go to every rank: one small all-gather per owner-only call (plus agreed growth)
+        assert st1["bytes_gathered"] - st0["bytes_gathered"] < 64 * 1024 * world
+    assert sum(x[5]["bytes_received"] - x[4]["bytes_received"] for x in res) == total_rows * row_b
+    for d in dev:
+        d.free()
+
+
+def test_owner_only_exchange_errors_are_collective(ctx, modsx, small_pair):
+    """In the owner-only mode a rank-local failure still travels in the header every rank receives (same error, same call, the
+    communicator keeps working), and ranks set to DIFFERENT modes do not hang: the mode is part of the header's magic."""
+    from mods_amd import distributed as D
+    a, b, _ = small_pair
+    good = _views(modsx)[:4]
+    bad = list(good)
+    bad[1] = modsx.make_view(1e9, 0.0, 1.0, 0.2, 1)
+    par = modsx.default_pair_params(ransac_seed=4)
+    ia, ib = ctx.upload(a), ctx.upload(b)
+    ref = ctx.match_pair_views(ia, ib, good, par)
+
+    def rank_body(r, comm):
+        comm.set_exchange(modsx.EXCHANGE_OWNER)
+        try:
+            comm.match_pairs_views_sharded(0, [ia, ia], [ib, ib], bad, par, owner_base=0)
+            err = None
+        except RuntimeError as e:
+            err = str(e)
+        out = comm.match_pairs_views_sharded(0, [ia, ia], [ib, ib], good, par, owner_base=0)
+        return err, out
+
+    for r, (err, out) in enumerate(D.run_loopback(2, rank_body)):
+        assert err is not None and ("degenerate" in err if r == 1 else "rank 1" in err), (r, err)
+        _same_pair_result(out[r], ref)
+
+    def mixed(r, comm):
+        if r == 0:
+            comm.set_exchange(modsx.EXCHANGE_OWNER)
+        t0 = time.time()
+        try:
+            comm.match_pairs_views_sharded(0, [ia], [ib], good, par, owner_base=0)
+            return None, time.time() - t0
+        except RuntimeError as e:
+            return str(e), time.time() - t0
+
+    for err, dt in D.run_loopback(2, mixed, timeout_ms=3000):
+        assert err is not None and dt < 20, (err, dt)
+    ia.free(); ib.free()
+
+
 def test_sharded_block_retry_and_unbalanced_ranks(ctx, modsx, small_pair, monkeypatch):
     """A first block size far below a rank's row count: every rank sees the overflow in the gathered headers, all grow alike
     and repeat the exchange (and agree on the allocation)."""
