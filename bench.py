@@ -721,18 +721,27 @@ def main():
             pF = mods_amd.default_pair_params(ransac_seed=1, useF=1, **WXBS)
             mods_amd.match_pairs(ctxs, imgs1, imgs2, pF)
             mods_amd.verify_device_stats(reset=True)
+            ruF0 = resource.getrusage(resource.RUSAGE_SELF)
             ta = time.perf_counter()
             stF = 3
-            for _ in range(stF):
-                rF = mods_amd.match_pairs(ctxs, imgs1, imgs2, pF)
+            # the stF steps' pairs in ONE call of the batch API (what back-to-back steps are for the per-pair calls: no idle tail of
+            # 16 contexts and their verification helpers between steps); the per-step form stays beside it
+            rF = mods_amd.match_pairs(ctxs, imgs1 * stF, imgs2 * stF, pF)
             dtF = time.perf_counter() - ta
+            ruF1 = resource.getrusage(resource.RUSAGE_SELF)
+            cpuF = (ruF1.ru_utime - ruF0.ru_utime) + (ruF1.ru_stime - ruF0.ru_stime)
             fms, fn, fth = mods_amd.last_batch_verify()
             vst = mods_amd.verify_device_stats()
+            tb = time.perf_counter()
+            for _ in range(stF):
+                mods_amd.match_pairs(ctxs, imgs1, imgs2, pF)
+            dtFstep = time.perf_counter() - tb
             out["wxbs"] = {
                 "H": {"pairs_per_s": value, **hshare,
                       "host_ransac_share_of_wall": (vms / max(1, vn)) / max(1, vth) / (1e3 / value) * 1.0},
-                "F": {"pairs_per_s": stF * nbatch / dtF, "verify_ms_per_pair": fms / max(1, fn), "helper_threads": fth,
-                      "verified_last_pair": rF[0]["n_verified"],
+                "F": {"pairs_per_s": stF * nbatch / dtF, "pairs_per_s_one_call_per_step": stF * nbatch / dtFstep, "verify_ms_per_pair": fms / max(1, fn), "helper_threads": fth,
+                      "verified_last_pair": rF[0]["n_verified"], "host_cpu_s_per_pair": cpuF / (stF * nbatch),
+                      "host_cores_busy": cpuF / dtF, "host_cpu_system_share": (ruF1.ru_stime - ruF0.ru_stime) / max(cpuF, 1e-9),
                       "rfth_loops_per_pair": vst["loops"] / float(stF * nbatch), "rfth_ms_per_loop": 1e-3 * vst["loop_us"] / max(1, vst["loops"]),
                       "rfth_ms_per_loop_parts": {k: 1e-3 * vst[k + "_us"] / max(1, vst["loops"]) for k in ("draw", "device_wait", "host_phase", "event_body")},
                       "rfth_hypotheses_on_device": vst["hypotheses"], "rfth_device_batches": vst["batches"],

@@ -192,6 +192,31 @@ static inline void lin_hg(const double *u, double *dst, const int *inl, int len)
 
 // normu, utools.c:7-52.  The two sums of distances keep their order; the distances themselves (two square roots per point)
 // are formed four points at a time in front of the additions.
+#if defined(__x86_64__)
+// the distance pass of normu eight points at a time (one 512-bit square root per image side); the sums keep their order.
+// Returns the number of points done.
+__attribute__((target("avx512f"))) static inline int normu_dist8(const double *u, const int *inl, int len, double m1x, double m1y, double m2x,
+                                                                 double m2y, double *s1io, double *s2io) {
+  typedef double nv8 __attribute__((vector_size(64)));
+  const nv8 M1x = {m1x, m1x, m1x, m1x, m1x, m1x, m1x, m1x}, M1y = {m1y, m1y, m1y, m1y, m1y, m1y, m1y, m1y};
+  const nv8 M2x = {m2x, m2x, m2x, m2x, m2x, m2x, m2x, m2x}, M2y = {m2y, m2y, m2y, m2y, m2y, m2y, m2y, m2y};
+  double s1 = *s1io, s2 = *s2io;
+  int j = 0;
+  for (; j + 8 <= len; j += 8) {
+    const double *p[8];
+    for (int k = 0; k < 8; k++) p[k] = u + 6 * inl[j + k];
+    const nv8 ax = (nv8){p[0][0], p[1][0], p[2][0], p[3][0], p[4][0], p[5][0], p[6][0], p[7][0]} - M1x;
+    const nv8 ay = (nv8){p[0][1], p[1][1], p[2][1], p[3][1], p[4][1], p[5][1], p[6][1], p[7][1]} - M1y;
+    const nv8 bx = (nv8){p[0][3], p[1][3], p[2][3], p[3][3], p[4][3], p[5][3], p[6][3], p[7][3]} - M2x;
+    const nv8 by = (nv8){p[0][4], p[1][4], p[2][4], p[3][4], p[4][4], p[5][4], p[6][4], p[7][4]} - M2y;
+    nv8 q1 = ax * ax + ay * ay, q2 = bx * bx + by * by;
+    for (int k = 0; k < 8; k++) { q1[k] = sqrt(q1[k]); q2[k] = sqrt(q2[k]); }   // one vsqrtpd each
+    for (int k = 0; k < 8; k++) { s1 += q1[k]; s2 += q2[k]; }
+  }
+  *s1io = s1; *s2io = s2;
+  return j;
+}
+#endif
 static inline void normu(const double *u, const int *inl, int len, double *A1, double *A2) {
   typedef double nv4 __attribute__((vector_size(32)));
   for (int j = 0; j < 3; j++) { A1[j] = 0; A2[j] = 0; }
@@ -210,6 +235,10 @@ static inline void normu(const double *u, const int *inl, int len, double *A1, d
   const nv4 m2x = {A2[1], A2[1], A2[1], A2[1]}, m2y = {A2[2], A2[2], A2[2], A2[2]};
   double s1 = A1[0], s2 = A2[0];
   int j = 0;
+#if defined(__x86_64__)
+  static const bool wide = __builtin_cpu_supports("avx512f");
+  if (wide) j = normu_dist8(u, inl, len, A1[1], A1[2], A2[1], A2[2], &s1, &s2);
+#endif
   for (; j + 4 <= len; j += 4) {
     const double *p0 = u + 6 * inl[j], *p1 = u + 6 * inl[j + 1], *p2 = u + 6 * inl[j + 2], *p3 = u + 6 * inl[j + 3];
     const nv4 ax = (nv4){p0[0], p1[0], p2[0], p3[0]} - m1x, ay = (nv4){p0[1], p1[1], p2[1], p3[1]} - m1y;
@@ -253,7 +282,46 @@ static inline void lin_hgN(const double *u, double *p, const int *inl, int len, 
 
 // cov_mat, utools.c:170-183: Cv[i][j] = sum_k Z[k][i] * Z[k][j].  The row loop is hoisted outside so the 45
 // running sums advance together; each individual sum still adds its terms in row order k = 0, 1, ...
+// siz == 9 (every caller in the pipeline): row i of the lower triangle is z[i] * (z[0], ..., z[i]), formed four columns at a time
+// (15 packed multiply + add pairs per row of Z instead of 45 scalar ones; the lanes beyond column i hold products nobody
+// reads).  A lane is one sum: the same products added in the same order, so the matrix is the same bits.  (In the WxBS bench this
+// routine and the linearisation in front of it were 44 % of the F verification's host time: tools/hprof_bench.py.)
 static inline void cov_mat(double *Cv, const double *Z, int len, int siz) {
+  if (siz == 9) {
+    typedef double cv4 __attribute__((vector_size(32), aligned(8)));
+    cv4 a0[9], a1[5], a2 = {0, 0, 0, 0};          // a0[i]: columns 0-3 of row i; a1[i - 4]: columns 4-7 of rows 4-8; a2: column 8 of row 8
+    for (int i = 0; i < 9; i++) a0[i] = (cv4){0, 0, 0, 0};
+    for (int i = 0; i < 5; i++) a1[i] = (cv4){0, 0, 0, 0};
+    int k = 0;
+    for (; k + 1 < len; k++) {        // the 12-wide loads of a row reach 3 doubles into the next one: the last row goes through the tail below
+      const double *z = Z + (size_t)k * 9;
+      const cv4 v0 = *reinterpret_cast<const cv4 *>(z), v1 = *reinterpret_cast<const cv4 *>(z + 4), v2 = *reinterpret_cast<const cv4 *>(z + 8);
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        const cv4 zi = {z[i], z[i], z[i], z[i]};
+        a0[i] += zi * v0;
+        if (i >= 4) a1[i - 4] += zi * v1;
+        if (i == 8) a2 += zi * v2;
+      }
+    }
+    double acc[9][9];
+    for (int i = 0; i < 9; i++) {
+      for (int j = 0; j < 4; j++) acc[i][j] = a0[i][j];
+      if (i >= 4) for (int j = 0; j < 4; j++) acc[i][4 + j] = a1[i - 4][j];
+    }
+    acc[8][8] = a2[0];
+    for (; k < len; k++) {
+      const double *z = Z + (size_t)k * 9;
+      for (int i = 0; i < 9; i++) {
+        const double zi = z[i];
+        for (int j = 0; j <= i; j++) acc[i][j] += zi * z[j];
+      }
+    }
+    if (len <= 0) for (int i = 0; i < 9; i++) for (int j = 0; j <= i; j++) acc[i][j] = 0;
+    for (int i = 0; i < 9; i++)
+      for (int j = 0; j <= i; j++) { Cv[9 * i + j] = acc[i][j]; Cv[i + 9 * j] = acc[i][j]; }
+    return;
+  }
   double acc[9][9];
   for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) acc[i][j] = 0;
   for (int k = 0; k < len; k++) {
@@ -285,44 +353,83 @@ static inline void cov_mat_hgN(double *Cv, const double *Z, int npts) {
     for (int j = 0; j <= i; j++) { Cv[9 * i + j] = acc[i][j]; Cv[i + 9 * j] = acc[i][j]; }
 }
 
+// ---- symmetric Jacobi eigen-solver, n <= 9: eigenvalues in ev, eigenvectors in the columns of V ----------
+// Cyclic sweeps over (p, q), a rotation = a column pass, a row pass and the same pass over the eigenvectors.  The size is a
+// template constant and the eigenvectors are kept transposed while the sweeps run, so two of the three passes of a rotation are
+// over contiguous rows (4-wide vector code); every element still goes through the same multiplications and additions in the same
+// order as in the plain three-loop form.
+// The stopping rule.  RULE 0: `off <= 1e-32 diag` alone -- a threshold AT the rounding floor (eps^2), where the off-diagonal mass
+// hovers: 15-28 sweeps for the 9 x 9 matrices of u2f / u2h, of which all but the first ~5 rotate by angles below an ulp and move
+// nothing but off-diagonal dust.  RULE 2 (in use): additionally stop after the first sweep that leaves the diagonal AND every
+// eigenvector component bit for bit where they were -- the later sweeps of RULE 0 only shrink the dust further, so the eigenpairs
+// are RULE 0's bits (checked: -DMODSX_JACOBI_CHECK runs both on every call and counts smallest-eigenpair differences; 0 over the
+// sweeps of tools/sweep_ransac_ref.py, near-degenerate planar scenes included) at 4.6 sweeps per call instead of 15.4.
+// RULE 1 (one more sweep once off <= 1e-22 diag: "quadratic convergence") is NOT safe: with two close eigenvalues a tiny
+// off-diagonal entry still means a large rotation, and 3 of 2 598 calls of one planar problem ended on another eigenvector --
+// another F, 30 other inliers than the reference's degensac.  It stays here as the counter-example the check build measures.
+constexpr double JACOBI_LAST = 1e-22;
+#ifndef JACOBI_RULE
+#define JACOBI_RULE 2
+#endif
+template <int N, int RULE>
+static int jacobi_eig_rule(const double *C, double *ev, double *V) {
+  alignas(32) double A[N * N], VT[N * N];
+  for (int i = 0; i < N * N; i++) A[i] = C[i];
+  for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) VT[i * N + j] = (i == j);
+  bool last = false;
+  int sweep = 0;
+  for (; sweep < 100; sweep++) {
+    double off = 0, diag = 0;
+    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) (i == j ? diag : off) += A[i * N + j] * A[i * N + j];
+    if (off <= 1e-32 * diag || off == 0 || last) break;
+    if (RULE == 1) last = off <= JACOBI_LAST * diag;
+    bool changed = false;      // RULE 2: did this sweep move the diagonal or an eigenvector component at all?
+    for (int p = 0; p < N - 1; p++)
+      for (int q = p + 1; q < N; q++) {
+        const double apq = A[p * N + q];
+        if (apq == 0) continue;
+        const double theta = (A[q * N + q] - A[p * N + p]) / (2 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+        const double cs = 1 / sqrt(t * t + 1), sn = t * cs;
+        const double dp0 = A[p * N + p], dq0 = A[q * N + q];
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+          const double akp = A[k * N + p], akq = A[k * N + q];
+          A[k * N + p] = cs * akp - sn * akq;
+          A[k * N + q] = sn * akp + cs * akq;
+        }
+        double *Ap = A + p * N, *Aq = A + q * N, *Vp = VT + p * N, *Vq = VT + q * N;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+          const double apk = Ap[k], aqk = Aq[k];
+          Ap[k] = cs * apk - sn * aqk;
+          Aq[k] = sn * apk + cs * aqk;
+        }
+        if (RULE == 2 && (A[p * N + p] != dp0 || A[q * N + q] != dq0)) changed = true;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+          const double vkp = Vp[k], vkq = Vq[k];
+          const double np_ = cs * vkp - sn * vkq, nq_ = sn * vkp + cs * vkq;
+          if (RULE == 2 && (np_ != vkp || nq_ != vkq)) changed = true;
+          Vp[k] = np_;
+          Vq[k] = nq_;
+        }
+      }
+    if (RULE == 2 && !changed) last = true;
+  }
+  for (int i = 0; i < N; i++) ev[i] = A[i * N + i];
+  for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) V[i * N + j] = VT[j * N + i];
+  return sweep;
+}
+
 // eigenvector of the smallest eigenvalue of a symmetric 9x9 (stands in for lap_eig = dsyev_, whose
 // first returned column is that vector: lapwrap.c:62-97, Htools.c:118-121)
 static inline void smallest_eigvec9(const double *C, double *v) {
-  const int n = 9;
-  double A[81], V[81];
-  memcpy(A, C, sizeof A);
-  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) V[i * n + j] = (i == j);
-  for (int sweep = 0; sweep < 100; sweep++) {
-    double off = 0, diag = 0;
-    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) (i == j ? diag : off) += A[i * n + j] * A[i * n + j];
-    if (off <= 1e-32 * diag || off == 0) break;
-    for (int p = 0; p < n - 1; p++)
-      for (int q = p + 1; q < n; q++) {
-        double apq = A[p * n + q];
-        if (apq == 0) continue;
-        double theta = (A[q * n + q] - A[p * n + p]) / (2 * apq);
-        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
-        double cs = 1 / sqrt(t * t + 1), sn = t * cs;
-        for (int k = 0; k < n; k++) {
-          double akp = A[k * n + p], akq = A[k * n + q];
-          A[k * n + p] = cs * akp - sn * akq;
-          A[k * n + q] = sn * akp + cs * akq;
-        }
-        for (int k = 0; k < n; k++) {
-          double apk = A[p * n + k], aqk = A[q * n + k];
-          A[p * n + k] = cs * apk - sn * aqk;
-          A[q * n + k] = sn * apk + cs * aqk;
-        }
-        for (int k = 0; k < n; k++) {
-          double vkp = V[k * n + p], vkq = V[k * n + q];
-          V[k * n + p] = cs * vkp - sn * vkq;
-          V[k * n + q] = sn * vkp + cs * vkq;
-        }
-      }
-  }
+  double ev[9], V[81];
+  jacobi_eig_rule<9, JACOBI_RULE>(C, ev, V);
   int best = 0;
-  for (int i = 1; i < n; i++) if (A[i * n + i] < A[best * n + best]) best = i;
-  for (int k = 0; k < n; k++) v[k] = V[k * n + best];
+  for (int i = 1; i < 9; i++) if (ev[i] < ev[best]) best = i;
+  for (int k = 0; k < 9; k++) v[k] = V[k * 9 + best];
 }
 
 // denormH, utools.c:74-92 (F[] is the 3x3 in the _f1.._f9 order = F[0..8])

@@ -27,44 +27,45 @@
 #define RTRACE(...) ((void)0)
 #endif
 namespace mx {
+// host profile of the F verification (builds with -DMODSX_HPROF only; tools/hprof_f.py): nanoseconds and calls per section
+#ifdef MODSX_HPROF
+static std::atomic<long> g_hprof[2][24];
+struct HProfScope {
+  int id; std::chrono::steady_clock::time_point t0;
+  explicit HProfScope(int i) : id(i), t0(std::chrono::steady_clock::now()) {}
+  ~HProfScope() { g_hprof[0][id] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); g_hprof[1][id]++; }
+};
+#define HPROF(id) HProfScope hprofScope_##id(id)
+#else
+#define HPROF(id)
+#endif
 
 typedef void (*FdsFn)(const double *, const double *, double *, int);
 typedef void (*ExFdsFn)(const double *, const double *, double *, double *, int);
 
-// ---- symmetric Jacobi eigen-solver, n <= 9: eigenvalues in ev, eigenvectors in the columns of V ----------
-static void jacobi_eig(const double *C, int n, double *ev, double *V) {
-  double A[81];
-  for (int i = 0; i < n * n; i++) A[i] = C[i];
-  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) V[i * n + j] = (i == j);
-  for (int sweep = 0; sweep < 100; sweep++) {
-    double off = 0, diag = 0;
-    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) (i == j ? diag : off) += A[i * n + j] * A[i * n + j];
-    if (off <= 1e-32 * diag || off == 0) break;
-    for (int p = 0; p < n - 1; p++)
-      for (int q = p + 1; q < n; q++) {
-        const double apq = A[p * n + q];
-        if (apq == 0) continue;
-        const double theta = (A[q * n + q] - A[p * n + p]) / (2 * apq);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
-        const double cs = 1 / sqrt(t * t + 1), sn = t * cs;
-        for (int k = 0; k < n; k++) {
-          const double akp = A[k * n + p], akq = A[k * n + q];
-          A[k * n + p] = cs * akp - sn * akq;
-          A[k * n + q] = sn * akp + cs * akq;
-        }
-        for (int k = 0; k < n; k++) {
-          const double apk = A[p * n + k], aqk = A[q * n + k];
-          A[p * n + k] = cs * apk - sn * aqk;
-          A[q * n + k] = sn * apk + cs * aqk;
-        }
-        for (int k = 0; k < n; k++) {
-          const double vkp = V[k * n + p], vkq = V[k * n + q];
-          V[k * n + p] = cs * vkp - sn * vkq;
-          V[k * n + q] = sn * vkp + cs * vkq;
-        }
-      }
-  }
-  for (int i = 0; i < n; i++) ev[i] = A[i * n + i];
+// ---- symmetric Jacobi eigen-solver: jacobi_eig_rule of ransac_common.hpp (eigenvalues in ev, eigenvectors in the columns of V) ----
+#ifdef MODSX_JACOBI_CHECK
+static std::atomic<long> g_jc[8];
+struct JcReport { ~JcReport() { fprintf(stderr, "jacobi check: calls %ld, rule1 differs %ld, rule2 differs %ld, sweeps old %ld rule1 %ld rule2 %ld\n", g_jc[0].load(), g_jc[1].load(), g_jc[2].load(), g_jc[3].load(), g_jc[4].load(), g_jc[5].load()); } } g_jcReport;
+#endif
+template <int N>
+static void jacobi_eig_n(const double *C, double *ev, double *V) {
+#ifdef MODSX_JACOBI_CHECK
+  double e1[N], V1[N * N], e2[N], V2[N * N];
+  const int s0 = jacobi_eig_rule<N, 0>(C, ev, V), s1 = jacobi_eig_rule<N, 1>(C, e1, V1), s2 = jacobi_eig_rule<N, 2>(C, e2, V2);
+  int m0 = 0, m1 = 0, m2 = 0;
+  for (int i = 1; i < N; i++) { if (ev[i] < ev[m0]) m0 = i; if (e1[i] < e1[m1]) m1 = i; if (e2[i] < e2[m2]) m2 = i; }
+  bool d1 = m0 != m1 || ev[m0] != e1[m1], d2 = m0 != m2 || ev[m0] != e2[m2];
+  for (int k = 0; k < N; k++) { d1 = d1 || V[k * N + m0] != V1[k * N + m1]; d2 = d2 || V[k * N + m0] != V2[k * N + m2]; }
+  g_jc[0]++; g_jc[1] += d1; g_jc[2] += d2; g_jc[3] += s0; g_jc[4] += s1; g_jc[5] += s2;
+#else
+  jacobi_eig_rule<N, JACOBI_RULE>(C, ev, V);
+#endif
+}
+static void jacobi_eig(const double *C, int n, double *ev, double *V) {   // the callers' sizes: 9 (u2f, left_null9) and 3 (singulF)
+  if (n == 9) return jacobi_eig_n<9>(C, ev, V);
+  if (n == 3) return jacobi_eig_n<3>(C, ev, V);
+  abort();
 }
 
 static inline __host__ __device__ void cross3(double *o, const double *a, const double *b) {  // crossp, DegUtils.c:246-250
@@ -225,6 +226,79 @@ static void lin_fmN(const double *u, double *p, const int *inl, int len, const d
       for (int l = 0; l < 3; l++) *p++ = a[l] * b[k];
   }
 }
+// lin_fmN + (the weights of u2fw) + cov_mat in one pass, without the len x 9 matrix in memory: row i of it is
+// z[3 k + l] = a[l] * b[k] with a = (a0, a1, 1), b = (b0, b1, 1) the normalised points (times w[inl[i]] when weighted), and the 45
+// sums of Z^T Z take their terms in row order, four columns at a time as in cov_mat -- the same products, the same additions, the
+// same order: the matrix is bit-identical to cov_mat(lin_fmN(...)).  (1 * x is x: the products with a[2] = b[2] = 1 are not formed.)
+// The same on 512-bit vectors where the CPU has them (row i = z[i] * (z[0] .. z[7]), column 8 apart: 9 accumulators instead of 14,
+// which no longer spill out of the 256-bit register file; the lanes are the same sums)
+#if defined(__x86_64__)
+__attribute__((target("avx512f"))) static void cov_fmN_fused_w8(double *Cv, const double *u, const int *inl, int len, const double *A1, const double *A2,
+                                                                const double *w) {
+  typedef double cv8 __attribute__((vector_size(64)));
+  cv8 a[9];
+  double a88 = 0;
+  for (int i = 0; i < 9; i++) a[i] = (cv8){0, 0, 0, 0, 0, 0, 0, 0};
+  const double s1 = A1[0], s2 = A2[0];
+  for (int i = 0; i < len; i++) {
+    const double *s = u + 6 * inl[i];
+    const double x0 = s[0] * s1 + A1[1], x1 = s[1] * s1 + A1[2];
+    const double y0 = s[3] * s2 + A2[1], y1 = s[4] * s2 + A2[2];
+    cv8 v = {x0 * y0, x1 * y0, y0, x0 * y1, x1 * y1, y1, x0, x1};
+    double z8 = 1;
+    if (w) {
+      const double m = w[inl[i]];
+      v *= (cv8){m, m, m, m, m, m, m, m};
+      z8 *= m;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) { const double zr = v[r]; a[r] += (cv8){zr, zr, zr, zr, zr, zr, zr, zr} * v; }
+    a[8] += (cv8){z8, z8, z8, z8, z8, z8, z8, z8} * v;
+    a88 += z8 * z8;
+  }
+  for (int i = 0; i < 9; i++)
+    for (int j = 0; j <= i; j++) { const double x = j < 8 ? a[i][j] : a88; Cv[9 * i + j] = x; Cv[i + 9 * j] = x; }
+}
+#endif
+static void cov_fmN_fused(double *Cv, const double *u, const int *inl, int len, const double *A1, const double *A2, const double *w) {
+#if defined(__x86_64__)
+  static const bool wide = __builtin_cpu_supports("avx512f");
+  if (wide) return cov_fmN_fused_w8(Cv, u, inl, len, A1, A2, w);
+#endif
+  typedef double cv4 __attribute__((vector_size(32)));
+  cv4 a0[9], a1[5];
+  double a88 = 0;
+  for (int i = 0; i < 9; i++) a0[i] = (cv4){0, 0, 0, 0};
+  for (int i = 0; i < 5; i++) a1[i] = (cv4){0, 0, 0, 0};
+  const double s1 = A1[0], s2 = A2[0];
+  for (int i = 0; i < len; i++) {
+    const double *s = u + 6 * inl[i];
+    const double x0 = s[0] * s1 + A1[1], x1 = s[1] * s1 + A1[2];
+    const double y0 = s[3] * s2 + A2[1], y1 = s[4] * s2 + A2[2];
+    cv4 v0 = {x0 * y0, x1 * y0, y0, x0 * y1}, v1 = {x1 * y1, y1, x0, x1};
+    double z8 = 1;
+    if (w) {
+      const double m = w[inl[i]];
+      const cv4 mm = {m, m, m, m};
+      v0 *= mm; v1 *= mm; z8 *= m;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const cv4 zi = {v0[r], v0[r], v0[r], v0[r]}; a0[r] += zi * v0; }
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const cv4 zi = {v1[r], v1[r], v1[r], v1[r]}; a0[4 + r] += zi * v0; a1[r] += zi * v1; }
+    const cv4 z8v = {z8, z8, z8, z8};
+    a0[8] += z8v * v0; a1[4] += z8v * v1;
+    a88 += z8 * z8;
+  }
+  double acc[9][9];
+  for (int i = 0; i < 9; i++) {
+    for (int j = 0; j < 4; j++) acc[i][j] = a0[i][j];
+    if (i >= 4) for (int j = 0; j < 4; j++) acc[i][4 + j] = a1[i - 4][j];
+  }
+  acc[8][8] = a88;
+  for (int i = 0; i < 9; i++)
+    for (int j = 0; j <= i; j++) { Cv[9 * i + j] = acc[i][j]; Cv[i + 9 * j] = acc[i][j]; }
+}
 // slcm, Ftools.c:37-85: the cubic det(x A + (1 - x) B) = p0 x^3 + p1 x^2 + p2 x + p3; B leaves as A - B.
 // The roots feed the orientation test (all_ori_valid), a sign decision that is ill-conditioned whenever an epipolar line of the
 // sample is nearly horizontal: a relative 3e-13 in a root flipped it on a 31-tentative problem and sent the trajectory elsewhere.
@@ -295,61 +369,96 @@ static int rroots3(const double *po, double *r) {
   r[2] = R2 * cos(pit + phit) - bt;
   return 3;
 }
-// FDs (Sampson), Ftools.c:87-107
+// FDs (Sampson), Ftools.c:87-107; FDsSym (symmetric epipolar distance), :109-131; exFDs, :162-185; exFDsSym, :186-210.
+// Four points per step on 256-bit vectors, eight where the CPU has 512-bit ones (hds_ld4 / hds_ld8 of ransac_common.hpp gather a
+// coordinate of consecutive points): every lane runs the scalar expression of its own point -- the same operations in the same
+// order, IEEE mul / add / div / sqrt, no contraction -- so the values are those of the scalar loops that finish the last points.
+#define FDS_COMMON(T, X1, Y1, X2, Y2) \
+  const T rxc = F[0] * X2 + F[3] * Y2 + F[6]; \
+  const T ryc = F[1] * X2 + F[4] * Y2 + F[7]; \
+  const T rwc = F[2] * X2 + F[5] * Y2 + F[8]; \
+  const T r = (X1 * rxc + Y1 * ryc + rwc); \
+  const T rx = F[0] * X1 + F[1] * Y1 + F[2]; \
+  const T ry = F[3] * X1 + F[4] * Y1 + F[5];
+// KIND 0 FDs, 1 FDsSym, 2 exFDs, 3 exFDsSym
+#define FDS_VECTOR_LOOP(V, W, LD, KIND) \
+  for (; i + W <= len; i += W) { \
+    const double *uu = u + (size_t)6 * i; \
+    const V x1 = LD(uu, 6), y1 = LD(uu + 1, 6), x2 = LD(uu + 3, 6), y2 = LD(uu + 4, 6); \
+    FDS_COMMON(V, x1, y1, x2, y2) \
+    if (KIND == 0) { \
+      const V o = r * r / (rxc * rxc + ryc * ryc + rx * rx + ry * ry); \
+      for (int k = 0; k < W; k++) p[i + k] = o[k]; \
+    } else if (KIND == 1) { \
+      const V a = rxc * rxc + ryc * ryc, b = rx * rx + ry * ry; \
+      const V o = r * r * (a + b) / (a * b); \
+      for (int k = 0; k < W; k++) p[i + k] = o[k]; \
+    } else if (KIND == 2) { \
+      const V ww = rxc * rxc + ryc * ryc + rx * rx + ry * ry; \
+      const V o = r * r / ww; \
+      for (int k = 0; k < W; k++) { p[i + k] = o[k]; w[i + k] = 1 / sqrt(ww[k]); } \
+    } else { \
+      const V a = rxc * rxc + ryc * ryc, b = rx * rx + ry * ry; \
+      const V ww = (a * b) / (a + b); \
+      const V o = r * r / ww; \
+      for (int k = 0; k < W; k++) { w[i + k] = ww[k]; p[i + k] = o[k]; } \
+    } \
+  }
+#if defined(__x86_64__)
+template <int KIND>
+__attribute__((target("avx512f"))) static int fds_loop8(const double *u, const double *F, double *p, double *w, int len) {
+  int i = 0;
+  FDS_VECTOR_LOOP(hds_v8, 8, hds_ld8, KIND)
+  return i;
+}
+#endif
+template <int KIND>
+static inline int fds_vector(const double *u, const double *F, double *p, double *w, int len) {
+  int i = 0;
+#if defined(__x86_64__)
+  static const bool wide = __builtin_cpu_supports("avx512f");
+  if (wide) i = fds_loop8<KIND>(u, F, p, w, len);
+#endif
+  FDS_VECTOR_LOOP(hds_v4, 4, hds_ld4, KIND)
+  return i;
+}
 static void FDs(const double *u, const double *F, double *p, int len) {
-  for (int i = 0; i < len; i++, u += 6) {
-    const double rxc = F[0] * u[3] + F[3] * u[4] + F[6];
-    const double ryc = F[1] * u[3] + F[4] * u[4] + F[7];
-    const double rwc = F[2] * u[3] + F[5] * u[4] + F[8];
-    const double r = (u[0] * rxc + u[1] * ryc + rwc);
-    const double rx = F[0] * u[0] + F[1] * u[1] + F[2];
-    const double ry = F[3] * u[0] + F[4] * u[1] + F[5];
+  int i = fds_vector<0>(u, F, p, nullptr, len);
+  for (u += (size_t)6 * i; i < len; i++, u += 6) {
+    FDS_COMMON(double, u[0], u[1], u[3], u[4])
     p[i] = r * r / (rxc * rxc + ryc * ryc + rx * rx + ry * ry);
   }
 }
-// FDsSym (symmetric epipolar distance), Ftools.c:109-131
 static void FDsSym(const double *u, const double *F, double *p, int len) {
-  for (int i = 0; i < len; i++, u += 6) {
-    const double rxc = F[0] * u[3] + F[3] * u[4] + F[6];
-    const double ryc = F[1] * u[3] + F[4] * u[4] + F[7];
-    const double rwc = F[2] * u[3] + F[5] * u[4] + F[8];
-    const double r = (u[0] * rxc + u[1] * ryc + rwc);
-    const double rx = F[0] * u[0] + F[1] * u[1] + F[2];
-    const double ry = F[3] * u[0] + F[4] * u[1] + F[5];
+  int i = fds_vector<1>(u, F, p, nullptr, len);
+  for (u += (size_t)6 * i; i < len; i++, u += 6) {
+    FDS_COMMON(double, u[0], u[1], u[3], u[4])
     const double a = rxc * rxc + ryc * ryc;
     const double b = rx * rx + ry * ry;
     p[i] = r * r * (a + b) / (a * b);
   }
 }
-// exFDs, Ftools.c:162-185
 static void exFDs(const double *u, const double *F, double *p, double *w, int len) {
-  for (int i = 0; i < len; i++, u += 6) {
-    const double rxc = F[0] * u[3] + F[3] * u[4] + F[6];
-    const double ryc = F[1] * u[3] + F[4] * u[4] + F[7];
-    const double rwc = F[2] * u[3] + F[5] * u[4] + F[8];
-    const double r = (u[0] * rxc + u[1] * ryc + rwc);
-    const double rx = F[0] * u[0] + F[1] * u[1] + F[2];
-    const double ry = F[3] * u[0] + F[4] * u[1] + F[5];
+  int i = fds_vector<2>(u, F, p, w, len);
+  for (u += (size_t)6 * i; i < len; i++, u += 6) {
+    FDS_COMMON(double, u[0], u[1], u[3], u[4])
     w[i] = rxc * rxc + ryc * ryc + rx * rx + ry * ry;
     p[i] = r * r / w[i];
     w[i] = 1 / sqrt(w[i]);
   }
 }
-// exFDsSym, Ftools.c:186-210
 static void exFDsSym(const double *u, const double *F, double *p, double *w, int len) {
-  for (int i = 0; i < len; i++, u += 6) {
-    const double rxc = F[0] * u[3] + F[3] * u[4] + F[6];
-    const double ryc = F[1] * u[3] + F[4] * u[4] + F[7];
-    const double rwc = F[2] * u[3] + F[5] * u[4] + F[8];
-    const double r = (u[0] * rxc + u[1] * ryc + rwc);
-    const double rx = F[0] * u[0] + F[1] * u[1] + F[2];
-    const double ry = F[3] * u[0] + F[4] * u[1] + F[5];
+  int i = fds_vector<3>(u, F, p, w, len);
+  for (u += (size_t)6 * i; i < len; i++, u += 6) {
+    FDS_COMMON(double, u[0], u[1], u[3], u[4])
     const double a = rxc * rxc + ryc * ryc;
     const double b = rx * rx + ry * ry;
     w[i] = (a * b) / (a + b);
     p[i] = r * r / w[i];
   }
 }
+#undef FDS_COMMON
+#undef FDS_VECTOR_LOOP
 // singulF, Ftools.c:292-312: closest rank-2 matrix = F (I - v v^T), v the right singular vector of the
 // smallest singular value (dgesvd_ + zeroed third singular value in the reference)
 static void singulF(double *F) {
@@ -405,15 +514,10 @@ static void u2fw(const double *u, const int *inl, const double *w, int len, doub
   double *Z = buffer;
   if (len > 8) {
     double V[81], ev[9], E[81];
-    normu(u, inl, len, A1, A2);
-    lin_fmN(u, Z, inl, len, A1, A2);
-    if (w)
-      for (int i = 0; i < len; i++) {
-        const double m = w[inl[i]];
-        for (int c = 0; c < 9; c++) Z[(size_t)9 * i + c] *= m;
-      }
-    cov_mat(V, Z, len, 9);
-    jacobi_eig(V, 9, ev, E);
+    // lin_fmN(u, Z, inl, len, A1, A2); Z[i][.] *= w[inl[i]] when weighted; cov_mat(V, Z, len, 9) -- in one pass:
+    { HPROF(8); normu(u, inl, len, A1, A2); }
+    { HPROF(9); cov_fmN_fused(V, u, inl, len, A1, A2, w); }
+    { HPROF(10); jacobi_eig(V, 9, ev, E); }
     int j = 0;
     for (int i = 1; i < 9; i++) if (ev[i] < ev[j]) j = i;
     for (int i = 0; i < 9; i++) F[i] = E[i * 9 + j];
@@ -427,8 +531,9 @@ static void u2fw(const double *u, const int *inl, const double *w, int len, doub
         for (int c = 0; c < 9; c++)
           if (i + 9 * c < 9 * len) Z[i + 9 * c] *= m;
       }
-    left_null9(Z, len, F);
+    { HPROF(12); left_null9(Z, len, F); }
   }
+  HPROF(11);
   singulF(F);
   if (len > 8) denormF(F, A1, A2);
 }
@@ -634,6 +739,15 @@ struct RansacF {
   std::vector<double> buffer, lin;
   FdsFn fds;
   ExFdsFn exfds;
+  // Scratch of the nested local-optimisation routines, one set per routine (innerFH calls u2Fit, innerH calls inHrani calls iterH),
+  // sized at first use and kept for the call: they used to be vectors constructed per invocation -- ~300 times per verification,
+  // half a megabyte each at 6 k tentatives, i.e. mmap + page faults + munmap under the process-wide mm lock that 16 verifying
+  // threads share.  Every buffer is written before it is read, except innerH's error planes, which are cleared as the vectors were.
+  template <class T> static T *grab(std::vector<T> &v, size_t n) { if (v.size() < n) v.resize(n); return v.data(); }
+  std::vector<double> sFitDs, sFitBuf, sFhUsam, sFhDs, sFhBuf, sIhErr, sIhZ;
+  std::vector<int> sFitInl, sFhAll, sIhInliers, sHraniInt;
+  std::vector<unsigned char> sFhV;
+  std::vector<unsigned> sDualA, sDualB;
 
   int *randsubset(int *pool, int max_sz, int siz) {  // rtools.c:25-39
     for (int i = 0; i < siz; i++) {
@@ -683,7 +797,7 @@ struct RansacF {
     Score S, maxS = {0, 0};
     double h[9];
     if (ninl < 8) return maxS;
-    std::vector<int> intbuff(len);
+    int *intbuff = grab(sHraniInt, len);
     int ssiz = ninl / 2;
     if (ssiz > 12) ssiz = 12;
     double *d = errs[2]; errs[2] = errs[0]; errs[0] = d;
@@ -693,7 +807,7 @@ struct RansacF {
       u2h(u, sample, ssiz, h, buffer.data());
       HDs(Z, u, h, errs[0], len);
       errs[4] = errs[0];
-      S = iterH(Z, intbuff.data(), th, 4 * th, h, errs, inlLimit);
+      S = iterH(Z, intbuff, th, 4 * th, h, errs, inlLimit);
       if (score_less(maxS, S)) {
         maxS = S;
         d = errs[2]; errs[2] = errs[0]; errs[0] = d;
@@ -705,16 +819,17 @@ struct RansacF {
   }
   // innerH, DegUtils.c:689-729
   unsigned innerH(double *H, double th, unsigned iters, unsigned char *inl) {
-    std::vector<double> err((size_t)len * 4), Z((size_t)len * 18);
-    std::vector<int> inliers(len);
+    double *err = grab(sIhErr, (size_t)len * 4), *Z = grab(sIhZ, (size_t)len * 18);
+    std::fill(err, err + (size_t)len * 4, 0.0);
+    int *inliers = grab(sIhInliers, len);
     double *errs[5];
-    for (int i = 0; i < 4; i++) errs[i] = err.data() + (size_t)i * len;
+    for (int i = 0; i < 4; i++) errs[i] = err + (size_t)i * len;
     errs[4] = errs[3];
-    lin_hg_rows(u, Z.data(), len);
+    lin_hg_rows(u, Z, len);
     double *d = errs[0];
-    HDs(Z.data(), u, H, d, len);
-    Score S = inlidxs(d, len, th, inliers.data());
-    S = inHrani(Z.data(), inliers.data(), (int)S.I, th, errs, H, iters);
+    HDs(Z, u, H, d, len);
+    Score S = inlidxs(d, len, th, inliers);
+    S = inHrani(Z, inliers, (int)S.I, th, errs, H, iters);
     d = errs[0];
     unsigned I = 0;
     for (int j = 0; j < len; j++) {
@@ -813,12 +928,13 @@ struct RansacF {
 
   // u2Fit, DegUtils.c:631-686
   unsigned u2Fit(double *F, unsigned char *inl, double th, double ths, unsigned iters) {
+    HPROF(2);
     const double dth = (ths - th) / (iters - 1);
-    std::vector<int> inlI(len);
-    std::vector<double> Ds(len), buf((size_t)9 * len);
+    int *inlI = grab(sFitInl, len);
+    double *Ds = grab(sFitDs, len), *buf = grab(sFitBuf, (size_t)9 * len);
     unsigned no_i;
     for (unsigned iter = 0; iter < iters; ++iter) {
-      FDs(u, F, Ds.data(), len);
+      { HPROF(3); FDs(u, F, Ds, len); }
       no_i = 0;
       for (int i = 0; i < len; ++i) {
         if (Ds[i] < ths) { inl[i] = 1; ++no_i; }
@@ -827,10 +943,10 @@ struct RansacF {
       if (no_i < 8) return no_i;
       no_i = 0;
       for (int i = 0; i < len; ++i) if (inl[i]) inlI[no_i++] = i;
-      u2f(u, inlI.data(), (int)no_i, F, buf.data());
+      { HPROF(4); u2f(u, inlI, (int)no_i, F, buf); }
       ths -= dth;
     }
-    FDs(u, F, Ds.data(), len);
+    FDs(u, F, Ds, len);
     no_i = 0;
     for (int i = 0; i < len; ++i) {
       if (Ds[i] < th) { inl[i] = 1; ++no_i; }
@@ -840,7 +956,7 @@ struct RansacF {
   }
   // dual_sample, DegUtils.c:592-628
   void dual_sample(const double *uA, unsigned lenA, unsigned sA, const double *uB, unsigned lenB, unsigned sB, double *usam) {
-    std::vector<unsigned> pA(lenA), pB(lenB);
+    unsigned *pA = grab(sDualA, lenA), *pB = grab(sDualB, lenB);
     for (unsigned i = 0; i < lenA; ++i) pA[i] = i;
     for (unsigned i = 0; i < lenB; ++i) pB[i] = i;
     for (unsigned pos = 0; pos < sA; ++pos) {
@@ -857,28 +973,29 @@ struct RansacF {
   // innerFH, DegUtils.c:478-589
   void innerFH(const double *uH, unsigned lenH, const double *uO, unsigned lenO, double th, unsigned repCount,
                unsigned sH, unsigned sO, double *F, unsigned char *inl) {
+    HPROF(6);
     double aF[9];
-    std::vector<unsigned char> v(len);
-    std::vector<double> usam((size_t)6 * (sH + sO)), Ds(len), buf((size_t)9 * (sH + sO));
-    std::vector<int> all(sH + sO);
+    unsigned char *v = grab(sFhV, len);
+    double *usam = grab(sFhUsam, (size_t)6 * (sH + sO)), *Ds = grab(sFhDs, len), *buf = grab(sFhBuf, (size_t)9 * (sH + sO));
+    int *all = grab(sFhAll, sH + sO);
     for (unsigned i = 0; i < sH + sO; ++i) all[i] = (int)i;
     for (int i = 0; i < 9; ++i) F[i] = 1;
     for (int i = 0; i < len; ++i) inl[i] = 0;
     unsigned max_i = 0, max_s = 0;
     for (unsigned rep = 0; rep < repCount; ++rep) {
-      dual_sample(uH, lenH, sH, uO, lenO, sO, usam.data());
-      u2f(usam.data(), all.data(), (int)(sH + sO), aF, buf.data());
-      FDs(u, aF, Ds.data(), len);
+      { HPROF(5); dual_sample(uH, lenH, sH, uO, lenO, sO, usam); }
+      { HPROF(1); u2f(usam, all, (int)(sH + sO), aF, buf); }
+      { HPROF(0); FDs(u, aF, Ds, len); }
       unsigned no_i = 0;
       for (int i = 0; i < len; ++i) {
         if (Ds[i] < th) { v[i] = 1; ++no_i; }
         else v[i] = 0;
       }
-      if (max_i < no_i) { memcpy(inl, v.data(), len); memcpy(F, aF, sizeof aF); max_i = no_i; }
+      if (max_i < no_i) { memcpy(inl, v, len); memcpy(F, aF, sizeof aF); max_i = no_i; }
       if (no_i > max_s) {
         max_s = no_i;
-        no_i = u2Fit(aF, v.data(), th, th * 3, 4);
-        if (max_i < no_i) { memcpy(inl, v.data(), len); memcpy(F, aF, sizeof aF); max_i = no_i; }
+        no_i = u2Fit(aF, v, th, th * 3, 4);
+        if (max_i < no_i) { memcpy(inl, v, len); memcpy(F, aF, sizeof aF); max_i = no_i; }
       }
     }
   }
@@ -1157,7 +1274,7 @@ int ransac_f(const double *u, int len, double th, double conf, int max_sam, doub
   // the plane-and-parallax branch shared by the main loop and the final ALO step (exp_ranF.c:946-1001, 1066-1111)
   auto degenerate_update = [&](unsigned I, double *fcur, double *derr_alt, int &new_max) {
     if (I > 6) {
-      I = R.rFtH(inl, th, H, fcur);
+      { HPROF(15); I = R.rFtH(inl, th, H, fcur); }
       RTRACE("rFtH %u F0 %.17g\n", I, fcur[0]);
       if (I > maxS.I) {
         R.fds(u, fcur, errs[3], len);
@@ -1176,6 +1293,7 @@ int ransac_f(const double *u, int len, double th, double conf, int max_sam, doub
     }
   };
   auto lsq_and_lo = [&](const double *base, int *sidx) {  // __LSQ_BEFORE_LO__ + exp_inFranicustom
+    HPROF(16);
     (void)sidx;
     d = errs[0];
     S = tr_inlidxs(base, len, 4 * th * 2, inliers.data());
@@ -1210,8 +1328,8 @@ int ransac_f(const double *u, int len, double th, double conf, int max_sam, doub
       for (int j = 0; j < 9; j++) f[j] = f1[j] * roots[i] + f2[j] * (1 - roots[i]);
       { const int ov = all_ori_valid(f, u, samidx, 7); RTRACE("ori %d\n", ov); if (!ov) continue; }
       d = errs[i];
-      R.fds(u, f, d, len);
-      S = tr_inlidxs(d, len, th, inliers.data());
+      { HPROF(13); R.fds(u, f, d, len);
+      S = tr_inlidxs(d, len, th, inliers.data()); }
       if ((int)S.I > LmaxI) LmaxI = (int)S.I;
       if (score_less(maxS, S)) {
         if (doSymCheck) {
@@ -1239,7 +1357,7 @@ int ransac_f(const double *u, int len, double th, double conf, int max_sam, doub
           unsigned I = 0;
           for (int j = 0; j < len; ++j) if (HDsv[j] < th * 3) ++I;
           if (I < 8) break;
-          I = R.innerH(H, 16 * th, 10, inl);
+          { HPROF(14); I = R.innerH(H, 16 * th, 10, inl); }
           RTRACE("innerH %u H0 %.17g\n", I, H[0]);
           degenerate_update(I, f, errs[i], new_max);
         } else {
@@ -1313,8 +1431,9 @@ int loransac_f(const double *pts, const double *laf1, const double *laf2, int T,
     u2[6 * i] = pts[4 * i]; u2[6 * i + 1] = pts[4 * i + 1]; u2[6 * i + 2] = 1.;
     u2[6 * i + 3] = pts[4 * i + 2]; u2[6 * i + 4] = pts[4 * i + 3]; u2[6 * i + 5] = 1.;
   }
+  { HPROF(17);
   ransac_f(u2.data(), T, err_threshold * err_threshold, confidence, max_samples, F, inl, data_out3, lo, 0, error_type,
-           doSymmCheck, seed);
+           doSymmCheck, seed); }
   const FdsFn fds = error_type == 0 ? FDs : FDsSym;
   const double affErr = LAFCoef * err_threshold;
   int kept = 0;
@@ -1344,6 +1463,12 @@ int loransac_f(const double *pts, const double *laf1, const double *laf2, int T,
 
 // out[0..4): device batches of rFtH's hypothesis loop, hypotheses counted on the device, state-changing hypotheses (each re-run on
 // the host), host / device disagreements (never seen: one switches the calling thread back to the host loop).  Process-wide.
+#ifdef MODSX_HPROF
+extern "C" __attribute__((visibility("default"))) int modsx_debug_hprof(long *out, int reset) {
+  for (int k = 0; k < 2; k++) for (int i = 0; i < 24; i++) { out[k * 24 + i] = mx::g_hprof[k][i].load(); if (reset) mx::g_hprof[k][i] = 0; }
+  return 0;
+}
+#endif
 extern "C" __attribute__((visibility("default"))) int modsx_verify_device_stats(long *out, int reset) {
   if (!out) return -1;
   for (int i = 0; i < 6; i++) { out[i] = mx::g_rfthStats[i].load(); if (reset) mx::g_rfthStats[i].store(0); }
