@@ -7,6 +7,7 @@ python bench.py --config wxbs > $out/bench_wxbs.json 2> $out/bench_wxbs.err
 python bench.py --config views61 --no-cpu-baseline --no-extra > $out/bench_views61.json 2> /dev/null
 python bench.py --no-cpu-baseline --no-extra --shard views > $out/rccl_world1.json 2> /dev/null
 for W in 1 2 4 8; do python bench.py --no-cpu-baseline --no-extra --loopback $W > $out/loopback_$W.json 2> /dev/null; done
+for W in 2 8; do python bench.py --no-cpu-baseline --no-extra --loopback $W --exchange owner > $out/loopback_owner_$W.json 2> /dev/null; done
 python tools/latency.py > $out/latency.log 2>&1
 python - <<PY
 import json, glob
