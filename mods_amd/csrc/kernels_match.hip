@@ -1161,9 +1161,18 @@ __global__ __launch_bounds__(256) void k_match_pdf(MatchBatch b, double contrDis
   pdf_body(A);
 }
 // Problems with n1 == 0 or n2 == 0 must be left out by the caller.  workspace[i] holds match_workspace_bytes(n1[i], n2[i]).
+static void launch_match_batch_once(hipStream_t s, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
+                                    const double *const *pos2, double sqminratio, double contrDistSq, int nn, MatchRow *const *rows,
+                                    void *const *workspace, hipEvent_t *evSweep1);
 void launch_match_batch(hipStream_t s, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
                         const double *const *pos2, double sqminratio, double contrDistSq, int nn, MatchRow *const *rows,
                         void *const *workspace, hipEvent_t *evSweep1) {
+  // (the four launches of a batch start from the inputs every time: issuing them twice -- MX_DUP, an experiment aid -- changes nothing)
+  MX_DUP(K_MATCH) launch_match_batch_once(s, nb, d1, n1, d2, n2, pos2, sqminratio, contrDistSq, nn, rows, workspace, evSweep1);
+}
+static void launch_match_batch_once(hipStream_t s, int nb, const uint8_t *const *d1, const int *n1, const uint8_t *const *d2, const int *n2,
+                                    const double *const *pos2, double sqminratio, double contrDistSq, int nn, MatchRow *const *rows,
+                                    void *const *workspace, hipEvent_t *evSweep1) {
   if (nb <= 0) return;
   MatchBatch b;
   memset(&b, 0, sizeof b);
