@@ -65,7 +65,21 @@ constexpr int PACK_POLLS = MODSX_PACK_POLLS;   // looks at a predecessor's statu
 // 32-query sets per wave (QS, even): 2 for most problems -- 3 wavefronts per SIMD --, 4 when both sides hold >= 40 k descriptors:
 // every LDS fragment read then feeds four MFMA chains (half the LDS bytes per matrix instruction) at 2 wavefronts per SIMD
 constexpr int sweep_wps(int qs) { return qs >= 4 ? 2 : 3; }   // waves per SIMD the sweeps are built for
-constexpr int qpb_of(int qs) { return 4 * 32 * qs; }          // queries per 256-thread workgroup
+constexpr int qpb_of(int qs) { return 4 * 32 * qs; }          // queries per 256-thread workgroup (k_match_resolve)
+// Sweep 1 has two shapes.  THIN: 256-thread workgroups, three (QS = 2) or two (QS = 4) per CU.  FAT: ONE workgroup per CU that holds
+// every wavefront the CU is meant to carry (12 / 8) and stages four groups of tiles per barrier.  With thin workgroups the SIMDs serve
+// the oldest wavefront first -- the first workgroup of a CU leaves at 37 us, the last at 64, alone (tools/trace_sweep_phases.py) --
+// while wavefronts that meet at the same barriers advance and leave together, and the staged tiles are fetched once per CU instead
+// of three times: -3.7 % at 24 k x 24 k and 48 k x 47 k (62.9 against 65.4 us, 225 against 233); at 10 k x 10 k, where a launch is
+// latency and not work, the fat shape has too few workgroups to hide behind and loses 1.2 us -- so it is taken from 16 k queries on.
+constexpr int s1_waves(int qs, bool fat) { return fat ? 4 * sweep_wps(qs) : 4; }      // wavefronts per workgroup of k_match_sweep1
+constexpr int s1_qpb(int qs, bool fat) { return s1_waves(qs, fat) * 32 * qs; }         // its queries
+constexpr int s1_round(int qs, bool fat) { return fat ? 256 : 256 * sweep_wps(qs); }   // workgroups of one round
+constexpr int s1_spb(bool fat) { return fat ? 4 : 1; }      // groups of 4 tiles a workgroup stages per barrier (2 x SPB x 16.5 KB of LDS)
+static bool match_fat(int n1) {
+  static const int forced = getenv("MODSX_SWEEP1_FAT") ? atoi(getenv("MODSX_SWEEP1_FAT")) : -1;    // 0 / 1: one shape for every size
+  return forced >= 0 ? forced != 0 : n1 >= 16000;
+}
 static int match_qsets(int nb, int n1, int n2) {
   static const int forced = getenv("MODSX_MATCH_QSETS") ? atoi(getenv("MODSX_MATCH_QSETS")) : 0;
   if (forced == 2 || forced == 4) return forced;
@@ -358,16 +372,17 @@ MX_D int group_dist16(const uint8_t *qd, int na, const unsigned char *tiles, con
 // ---------------- staging: 4 tiles + their constants, global -> LDS directly ------------------------------------------
 typedef const unsigned char __attribute__((address_space(1))) *gbptr;
 typedef unsigned char __attribute__((address_space(3))) *lbptr;
+template <int NW>      // wavefronts of the workgroup: 16 chunks of tile bytes (1 KB per wave instruction) + 2 of row constants, dealt round robin
 MX_D void stage_group(const unsigned char *tiles, const int *hrow, int p0, unsigned char *buf, int wave, int lane) {
   const unsigned char *src = tiles + (size_t)p0 * TILE_B + lane * 16;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int chunk = wave + 4 * i;   // 1 KB per wave instruction
-    __builtin_amdgcn_global_load_lds((gbptr)(src + chunk * 1024), (lbptr)(buf + chunk * 1024), 16, 0, 0);
+  for (int i = 0; i < (18 + NW - 1) / NW; i++) {
+    const int chunk = wave + NW * i;
+    if (chunk < 16) __builtin_amdgcn_global_load_lds((gbptr)(src + chunk * 1024), (lbptr)(buf + chunk * 1024), 16, 0, 0);
+    else if (chunk < 18)
+      __builtin_amdgcn_global_load_lds((gbptr)(reinterpret_cast<const unsigned char *>(hrow + (size_t)p0 * 32) + (chunk - 16) * 256 + lane * 4),
+                                       (lbptr)(buf + HOFF + (chunk - 16) * 256), 4, 0, 0);
   }
-  if (wave < 2)
-    __builtin_amdgcn_global_load_lds((gbptr)(reinterpret_cast<const unsigned char *>(hrow + (size_t)p0 * 32) + wave * 256 + lane * 4),
-                                     (lbptr)(buf + HOFF + wave * 256), 4, 0, 0);
 }
 MX_D v4i read_a(const unsigned char *tile, int row, int kb, int hi) {
   const int slot = 2 * kb + hi;
@@ -412,9 +427,11 @@ MX_D void lds_load_c(unsigned addr, v16i &C) {
 //   int  kv(v)                          the wave-uniform constant of virtual tile v
 //   void chain(acc, kv, s, tile)        reduce one accumulator (query set s, virtual tile `tile`)
 //   void flush(chunkTile0)              end of an index chunk (CH tiles, absolute tile numbers)
-template <int QSETS, int EPI_VALU, class Epi>
+// SPB: groups of TPS tiles per barrier.  A workgroup that is alone on its CU (sweep 1) has nobody to cover the bubble at a
+// barrier -- every wavefront refills its pipeline at the same moment --, so it stages SPB groups at once and meets 1 / SPB as often.
+template <int QSETS, int EPI_VALU, int NW, int SPB, class Epi>
 __device__ __forceinline__ void sweep_core(const unsigned char *tiles, const int *hrow, int TEp, int offT, int tBeg, int tEnd,
-                                           const v4i (&bq)[QSETS][4], unsigned char (&sm)[2][STAGE_B], Epi &epi) {
+                                           const v4i (&bq)[QSETS][4], unsigned char (&sm)[2 * SPB][STAGE_B], Epi &epi) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 31, hi = lane >> 5;
   // The LDS reads are written as assembly with the waits counted by hand: the compiler orders every wait behind the reads
@@ -434,13 +451,22 @@ __device__ __forceinline__ void sweep_core(const unsigned char *tiles, const int
 #pragma unroll
   for (int r = 0; r < 16; r++) acc[1][r] = NONE_H;
   int kvPend = 0, pendTile = 0;
-  if (tBeg < tEnd) stage_group(tiles, hrow, phys_tile(tBeg, TEp, offT), sm[0], wave, lane);
+#pragma unroll
+  for (int j = 0; j < SPB; j++)
+    if (tBeg + j * TPS < tEnd) stage_group<NW>(tiles, hrow, phys_tile(tBeg + j * TPS, TEp, offT), sm[j], wave, lane);
   int it = 0;
-  for (int tg = tBeg; tg < tEnd; tg += TPS, it++) {
-    const unsigned base = smBase + (it & 1) * STAGE_B;
+  for (int tb = tBeg; tb < tEnd; tb += TPS * SPB, it++) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tg + TPS < tEnd) stage_group(tiles, hrow, phys_tile(tg + TPS, TEp, offT), sm[(it & 1) ^ 1], wave, lane);
+#pragma unroll
+    for (int j = 0; j < SPB; j++) {
+      const int t = tb + TPS * SPB + j * TPS;
+      if (t < tEnd) stage_group<NW>(tiles, hrow, phys_tile(t, TEp, offT), sm[((it & 1) ^ 1) * SPB + j], wave, lane);
+    }
+   for (int j = 0; j < SPB; j++) {
+    const int tg = tb + j * TPS;
+    if (tg >= tEnd) break;
+    const unsigned base = smBase + ((it & 1) * SPB + j) * STAGE_B;
     lds_load_af<0>(base, aAddr, af[0]);
     lds_load_c<0>(base + cAddr, C[0]);
     kv[0] = epi.kv(tg);
@@ -497,6 +523,7 @@ __device__ __forceinline__ void sweep_core(const unsigned char *tiles, const int
       kvPend = 0;
       epi.flush(tg + TPS - Epi::CH);
     }
+   }
   }
   if (tEnd > tBeg && tEnd % Epi::CH) {
     epi.chain(acc[1], kvPend, QSETS - 1, pendTile);
@@ -548,10 +575,10 @@ struct TopKEpi {
     }
   }
 };
-template <int QSETS>
+template <int QSETS, bool FAT>
 __device__ __forceinline__ void sweep_body(const SweepArgs &A) {
-  constexpr int QPB = qpb_of(QSETS);
-  __shared__ __attribute__((aligned(16))) unsigned char sm[2][STAGE_B];
+  constexpr int QPB = s1_qpb(QSETS, FAT);
+  __shared__ __attribute__((aligned(16))) unsigned char sm[2 * s1_spb(FAT)][STAGE_B];
   const MatchGeom g = A.g;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 31, hi = lane >> 5;
@@ -571,7 +598,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs &A) {
   }
   epi.TEp = A.geo->TEp;
   const int tBeg = sp * g.tilesPerSplit, tEnd = min(tBeg + g.tilesPerSplit, A.geo->ntilesV);   // virtual tiles: even class, then odd
-  sweep_core<QSETS, 9 + KTOP>(A.tiles, A.hrow, epi.TEp, g.offT, tBeg, tEnd, bq, sm, epi);
+  sweep_core<QSETS, 9 + KTOP, s1_waves(QSETS, FAT), s1_spb(FAT)>(A.tiles, A.hrow, epi.TEp, g.offT, tBeg, tEnd, bq, sm, epi);
   // store the stream's keys as (distance, tile)
 #pragma unroll
   for (int s = 0; s < QSETS; s++) {
@@ -856,7 +883,7 @@ __device__ __forceinline__ void resolve_body(const ResolveArgs &A) {
   const int TEp = A.geo->TEp, offT = g.offT, ntilesV = A.geo->ntilesV;
   epi.TEp = TEp; epi.hi = hi; epi.stream0 = (ul0 + col) * 2 + hi; epi.evt = sEvt;
   const int tBeg = sp * tilesPerSplit, tEnd = min(tBeg + tilesPerSplit, ntilesV);
-  sweep_core<QSETS, 26>(A.tiles, A.hrow, TEp, offT, tBeg, tEnd, bq, sm, epi);
+  sweep_core<QSETS, 26, 4, 1>(A.tiles, A.hrow, TEp, offT, tBeg, tEnd, bq, sm, epi);
   int (&m1)[QSETS] = epi.m1, (&I1)[QSETS] = epi.I1, (&nev)[QSETS] = epi.nev;
   __syncthreads();                       // the staging buffers are free from here on: they hold the work list
   // ---- 2. the logged groups: counts per query, a flat work list, streams that ran out of slots
@@ -1043,18 +1070,18 @@ struct MatchLayout {
   int S, tilesPerSplit, ntilesUB, offT;
   size_t norm1, norm2, hrow, perm, pos2p, tiles, status, geo, partial, und, pdf, counter, bytes;
 };
-static MatchLayout match_layout(int n1, int n2, int qs) {
+static MatchLayout match_layout(int n1, int n2, int qs, bool fat) {
   MatchLayout L;
-  const int QPB = qpb_of(qs);
+  const int QPB = s1_qpb(qs, fat);
   const int nQB = (n1 + QPB - 1) / QPB;
   const int ntiles = ntiles_ub(n2);
-  // one round of workgroups: 3 per CU x 256 CUs; a second, partly filled round costs as much as the first.  Many query
-  // blocks (N > 196 k) simply take several rounds.
+  // one round of workgroups (one per CU); a second, partly filled round costs as much as the first.  Many query blocks
+  // (N > 196 k) simply take several rounds.
 #ifdef MATCH_TRACE
   static const int nwEnv = getenv("MODSX_MATCH_NW") ? atoi(getenv("MODSX_MATCH_NW")) : 0;   // workgroups per round, to trace 1 / 2 / 3 per CU
-  int S = (nwEnv > 0 ? nwEnv : 256 * sweep_wps(qs)) / nQB;
+  int S = (nwEnv > 0 ? nwEnv : s1_round(qs, fat)) / nQB;
 #else
-  int S = (256 * sweep_wps(qs)) / nQB;
+  int S = s1_round(qs, fat) / nQB;
 #endif
   if (S > ntiles / MINT) S = ntiles / MINT;
   if (S < 1) S = 1;
@@ -1082,7 +1109,11 @@ static MatchLayout match_layout(int n1, int n2, int qs) {
   return L;
 }
 // the larger of the two geometries: the caller sizes the workspace before the launcher picks one
-size_t match_workspace_bytes(int n1, int n2) { return std::max(match_layout(n1, n2, 2).bytes, match_layout(n1, n2, 4).bytes); }
+size_t match_workspace_bytes(int n1, int n2) {     // whatever shape the launcher picks (a batch takes the shape of its first problem)
+  size_t b = 0;
+  for (int qs = 2; qs <= 4; qs += 2) for (int fat = 0; fat < 2; fat++) b = std::max(b, match_layout(n1, n2, qs, fat != 0).bytes);
+  return b;
+}
 
 // ---- batched entry points: blockIdx.z selects one of up to MATCH_MAXB independent problems (the pairs of a launch set).
 struct MatchProblem {
@@ -1113,10 +1144,10 @@ __global__ __launch_bounds__(256) void k_match_pack(MatchBatch b) {
 // debugging aid (tools/trace_match.py): when and where every workgroup of the last k_match_sweep1 launch ran
 __device__ unsigned long long g_mtrace[16384][4];
 #endif
-template <int QS>
-__global__ __launch_bounds__(256, sweep_wps(QS)) void k_match_sweep1(MatchBatch b) {
+template <int QS, bool FAT>
+__global__ __launch_bounds__(64 * s1_waves(QS, FAT), FAT ? 1 : sweep_wps(QS)) void k_match_sweep1(MatchBatch b) {
   const MatchProblem &P = b.p[blockIdx.z];
-  if ((int)blockIdx.x * qpb_of(QS) >= P.g.n1 || (int)blockIdx.y >= P.g.S) return;
+  if ((int)blockIdx.x * s1_qpb(QS, FAT) >= P.g.n1 || (int)blockIdx.y >= P.g.S) return;
 #ifdef MATCH_TRACE
   const int wg = blockIdx.x + gridDim.x * blockIdx.y;
   if (threadIdx.x == 0 && wg < 16384) {
@@ -1130,7 +1161,7 @@ __global__ __launch_bounds__(256, sweep_wps(QS)) void k_match_sweep1(MatchBatch 
 #endif
   SweepArgs A;
   A.d1 = P.d1; A.norm1 = P.norm1; A.tiles = P.tiles; A.hrow = P.hrow; A.geo = P.geo; A.g = P.g; A.partial = P.partial;
-  sweep_body<QS>(A);
+  sweep_body<QS, FAT>(A);
 #ifdef MATCH_TRACE
   __syncthreads();
   if (threadIdx.x == 0 && wg < 16384) { g_mtrace[wg][1] = wall_clock64(); g_mtrace[wg][3] = __builtin_readcyclecounter() - g_mtrace[wg][3]; }
@@ -1183,9 +1214,10 @@ static void launch_match_batch_once(hipStream_t s, int nb, const uint8_t *const 
   b.epoch = ep;
   int maxN1 = 0, maxS = 0, maxWg = 0;
   const int qs = match_qsets(nb, n1[0], n2[0]);
+  const bool fat = match_fat(n1[0]);
   for (int i = 0; i < nb; i++) {
     MatchProblem &P = b.p[i];
-    const MatchLayout L = match_layout(n1[i], n2[i], qs);
+    const MatchLayout L = match_layout(n1[i], n2[i], qs, fat);
     P.g.n1 = n1[i]; P.g.n2 = n2[i]; P.g.S = L.S; P.g.tilesPerSplit = L.tilesPerSplit; P.g.qs = qs; P.g.ntilesUB = L.ntilesUB;
     P.g.offT = L.offT;
     char *w = (char *)workspace[i];
@@ -1198,11 +1230,13 @@ static void launch_match_batch_once(hipStream_t s, int nb, const uint8_t *const 
     maxN1 = std::max(maxN1, n1[i]); maxS = std::max(maxS, L.S); maxWg = std::max(maxWg, (n2[i] + PB - 1) / PB);
   }
   hipLaunchKernelGGL(k_match_pack, dim3(std::max((maxN1 + 31) / 32, maxWg), 2, nb), dim3(256), 0, s, b);
-  const int QPB = qpb_of(qs), NW2 = 256 * sweep_wps(qs);
-  const dim3 grid((maxN1 + QPB - 1) / QPB, maxS, nb);
+  const int QPB = qpb_of(qs), NW2 = 256 * sweep_wps(qs), QPB1 = s1_qpb(qs, fat);
+  const dim3 grid((maxN1 + QPB1 - 1) / QPB1, maxS, nb), block1(64 * s1_waves(qs, fat));
   if (evSweep1) hipEventRecord(evSweep1[0], s);
-  if (qs == 4) hipLaunchKernelGGL(k_match_sweep1<4>, grid, dim3(256), 0, s, b);
-  else hipLaunchKernelGGL(k_match_sweep1<2>, grid, dim3(256), 0, s, b);
+  if (qs == 4 && fat) hipLaunchKernelGGL((k_match_sweep1<4, true>), grid, block1, 0, s, b);
+  else if (qs == 4) hipLaunchKernelGGL((k_match_sweep1<4, false>), grid, block1, 0, s, b);
+  else if (fat) hipLaunchKernelGGL((k_match_sweep1<2, true>), grid, block1, 0, s, b);
+  else hipLaunchKernelGGL((k_match_sweep1<2, false>), grid, block1, 0, s, b);
   if (evSweep1) hipEventRecord(evSweep1[1], s);
   hipLaunchKernelGGL(k_match_decide, dim3((maxN1 + DECIDE_Q - 1) / DECIDE_Q, 1, nb), dim3(16 * DECIDE_Q), 0, s, b, sqminratio, contrDistSq, nn);
   // resolve: one round of workgroups dealt out on the device as (undecided block, split); more only if there could be more
