@@ -5,6 +5,7 @@
 // in mods.cpp:229-415.  Dense per-pixel / per-patch work runs in the HIP kernels; the host keeps the
 // order-dependent bookkeeping (detection order, first-come octaveMap claims, std::sort) and the few
 // libm transcendentals (powf / cos / sin / exp) so they are evaluated by the same libm as on the CPU path.
+#include <atomic>
 #include <math.h>
 #include <stdio.h>
 #include <algorithm>
@@ -26,6 +27,10 @@ namespace mx {
 
 static thread_local std::string g_err;
 void set_error(const std::string &s) { g_err = s; }
+static std::atomic<int> g_busyContexts{0};
+bool gpu_shared() { return g_busyContexts.load(std::memory_order_relaxed) > 1; }
+CtxBusy::CtxBusy(modsx_ctx *ctx) : c(ctx) { if (c && c->busyDepth++ == 0) g_busyContexts.fetch_add(1, std::memory_order_relaxed); }
+CtxBusy::~CtxBusy() { if (c && --c->busyDepth == 0) g_busyContexts.fetch_sub(1, std::memory_order_relaxed); }
 const char *last_error() { return g_err.c_str(); }
 
 bool DevBuf::ensure(size_t bytes) {
@@ -1402,6 +1407,7 @@ int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int
                        const double *const *pos2Host, double ratioT, double contradDist, int nn,
                        std::vector<modsx_tentative> *out, const MatchShard *shard, const double *const *pos2Dev) {
   // pos2Dev (optional, unsharded branch): the positions already live on the device; pos2Host is then not read
+  CtxBusy busy(c);
   if (nb < 1 || nb > MATCH_MAXB) { set_error("match_device_batch: batch size"); return MODSX_ERR_ARG; }
   hipStream_t s = c->stream;
   const double sqminratio = ratioT * ratioT, contrDistSq = contradDist * contradDist;
@@ -1606,6 +1612,7 @@ void verify_tentatives_kp(const double *kp1, size_t n1, const double *kp2, size_
 // each pair is matched and verified.  Results are those of G separate calls.
 int match_pair_group(modsx_ctx *c, const modsx_image *const *imgs1, const modsx_image *const *imgs2, int G,
                      const modsx_pair_params &pp, modsx_pair_result *res, std::vector<VerifyTask> *deferred) {
+  CtxBusy busy(c);
   if (G < 1 || G > PAIR_GROUP || 2 * G > MAXB) { set_error("match_pair_group: group size"); return MODSX_ERR_ARG; }
   for (int g = 0; g < G; g++) {
     memset(&res[g], 0, sizeof res[g]);

@@ -165,6 +165,11 @@ struct Pyramid {
 };
 
 void set_error(const std::string &s);
+// How many contexts are inside a call that keeps the device busy (a pair, a view set, a matching problem).  One: the call has the GPU
+// to itself and may launch shapes that take whole CUs (k_match_sweep1's fat workgroups: -4 % alone); more: its launches share the
+// CUs with the other contexts' and stay good neighbours (the fat shape waits for a drained CU there: -0.4 % pairs/s under 16 streams).
+bool gpu_shared();
+struct CtxBusy { modsx_ctx *c; explicit CtxBusy(modsx_ctx *c); ~CtxBusy(); CtxBusy(const CtxBusy &) = delete; CtxBusy &operator=(const CtxBusy &) = delete; };
 #define MX_HIP(expr)                                                                          \
   do {                                                                                        \
     hipError_t e_ = (expr);                                                                   \
@@ -318,6 +323,7 @@ struct modsx_ctx {
   double timings[6];
   mx::Profiler prof;
   size_t lastCandCount = 0;    // scale-space candidates of the context's last launch set (sizes the speculative download)
+  int busyDepth = 0;           // nesting of mx::CtxBusy on this context (its driving thread only)
   int shardLane = 0;           // lane of the rank's communicator this context issues its collectives on (engine_shard.hip)
   modsx_ctx *peer = nullptr;   // second stream + buffers, created on demand: the two images of a multi-view pair run side by side
   modsx_ctx *half = nullptr;   // a lone pair: the second part of an image's views runs here (accumulate_views)

@@ -269,6 +269,7 @@ int detect_describe_items(modsx_ctx *c, const modsx_image *const *itemImg, const
                           const modsx_pair_params &pp, std::vector<modsx_region> &regs,
                           float *devF, uint8_t *devU8, size_t devCapRegions, float *hostDesc, int *itemCounts,
                           const DescSet *dsIn, uint8_t *const *devU8x) {
+  CtxBusy busy(c);
   regs.clear();
   // the step's descriptor classes: class 0 goes to devF / devU8 / hostDesc, class k >= 1 to devU8x[k - 1] (same capacity);
   // without devU8x only class 0 is produced -- the orientation mode still follows the whole list
@@ -688,6 +689,7 @@ int match_pair_views(modsx_ctx *c, const modsx_image *img1, const modsx_image *i
 int match_ladder(modsx_ctx *c, const modsx_image *img1, const modsx_image *img2, const modsx_ladder_step *steps, int nsteps,
                  int min_matches, const modsx_pair_params &pp, modsx_pair_result *res, int *steps_done, VerifyTask *defer,
                  modsx_comm *cm, int owner) {
+  CtxBusy busy(c);
   if (defer && nsteps != 1) { set_error("deferred verification needs a one-step ladder"); return MODSX_ERR_ARG; }
   memset(res, 0, sizeof *res);
   for (int i = 0; i < 9; i++) res->H[i] = -1;

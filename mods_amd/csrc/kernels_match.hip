@@ -1214,7 +1214,7 @@ static void launch_match_batch_once(hipStream_t s, int nb, const uint8_t *const 
   b.epoch = ep;
   int maxN1 = 0, maxS = 0, maxWg = 0;
   const int qs = match_qsets(nb, n1[0], n2[0]);
-  const bool fat = match_fat(n1[0]);
+  const bool fat = match_fat(n1[0]) && !gpu_shared();     // whole-CU workgroups only when no other context's launches want the CUs
   for (int i = 0; i < nb; i++) {
     MatchProblem &P = b.p[i];
     const MatchLayout L = match_layout(n1[i], n2[i], qs, fat);
