@@ -18,8 +18,8 @@ run() { # tag, rocprof args..., -- command
   find /tmp/rp_$tag -name "*.db" | head -1
 }
 # 1. the default bench (31 views, 16 streams): durations include time-slicing between the streams
-DB=$(run def --kernel-trace --stats -d /tmp/rp_def -o p -- python $R/bench.py --no-cpu-baseline --no-extra)
-python $R/tools/rocprof_summary.py $DB $OUT/${TAG}_kernel_stats_default.txt "python bench.py --no-cpu-baseline --no-extra  (default workload: 31 views per image, 16 workers x 16 pairs/step; kernels of the 16 streams overlap, durations include time-slicing)" > /dev/null 2> $OUT/${TAG}_default.err || { echo "default summary failed: DB=[$DB]"; tail -5 /tmp/rp_def.log; ls -la /tmp/rp_def | head; } > $OUT/${TAG}_default.diag 2>&1
+DB=$(run def --kernel-trace --stats -d /tmp/rp_def -o p -- python $R/bench.py --no-cpu-baseline --no-extra --steps 6 --warmup 2)
+python $R/tools/rocprof_summary.py $DB $OUT/${TAG}_kernel_stats_default.txt "python bench.py --no-cpu-baseline --no-extra --steps 6 --warmup 2  (default workload: 31 views per image, 16 workers x 16 pairs/step; kernels of the 16 streams overlap, durations include time-slicing)" > /dev/null 2> $OUT/${TAG}_default.err || { echo "default summary failed: DB=[$DB]"; tail -5 /tmp/rp_def.log; ls -la /tmp/rp_def | head; } > $OUT/${TAG}_default.diag 2>&1
 # 2. one stream, same workload: the durations the roofline objects of bench.py are compared with
 DB=$(run one --kernel-trace --stats -d /tmp/rp_one -o p -- python $R/bench.py $ONE)
 python $R/tools/rocprof_summary.py $DB $OUT/${TAG}_kernel_stats_single_stream.txt "python bench.py $ONE  (31 views per image, one stream)" > /dev/null
