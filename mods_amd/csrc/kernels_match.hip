@@ -427,6 +427,15 @@ MX_D void lds_load_c(unsigned addr, v16i &C) {
 //   int  kv(v)                          the wave-uniform constant of virtual tile v
 //   void chain(acc, kv, s, tile)        reduce one accumulator (query set s, virtual tile `tile`)
 //   void flush(chunkTile0)              end of an index chunk (CH tiles, absolute tile numbers)
+#ifdef SWEEP_PHASE_TRACE
+// debugging aid (tools/trace_sweep_phases.py; tools/build_variant.sh ptrace "-DSWEEP_PHASE_TRACE"): per wavefront of the last
+// k_match_sweep1 launch, shader-clock cycles spent waiting at the stage barriers / issuing the next stage's DMA / in the tiles, its
+// total, stages, and the 100 MHz wall clock at its start and end.  (A stamp is an s_memtime + s_waitcnt: a few hundred cycles each.)
+__device__ unsigned long long g_ptrace[16384][8];
+#define PTRACE(x) x
+#else
+#define PTRACE(x)
+#endif
 // SPB: groups of TPS tiles per barrier.  A workgroup that is alone on its CU (sweep 1) has nobody to cover the bubble at a
 // barrier -- every wavefront refills its pipeline at the same moment --, so it stages SPB groups at once and meets 1 / SPB as often.
 template <int QSETS, int EPI_VALU, int NW, int SPB, class Epi>
@@ -455,14 +464,17 @@ __device__ __forceinline__ void sweep_core(const unsigned char *tiles, const int
   for (int j = 0; j < SPB; j++)
     if (tBeg + j * TPS < tEnd) stage_group<NW>(tiles, hrow, phys_tile(tBeg + j * TPS, TEp, offT), sm[j], wave, lane);
   int it = 0;
+  PTRACE(unsigned long long pa0 = 0; unsigned long long pa1 = 0; unsigned long long pa2 = 0; unsigned long long pt0 = __builtin_readcyclecounter(); const unsigned long long pstart = pt0; const unsigned long long pwall = wall_clock64();)
   for (int tb = tBeg; tb < tEnd; tb += TPS * SPB, it++) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    PTRACE(const unsigned long long pt1 = __builtin_readcyclecounter();)
 #pragma unroll
     for (int j = 0; j < SPB; j++) {
       const int t = tb + TPS * SPB + j * TPS;
       if (t < tEnd) stage_group<NW>(tiles, hrow, phys_tile(t, TEp, offT), sm[((it & 1) ^ 1) * SPB + j], wave, lane);
     }
+    PTRACE(const unsigned long long pt2 = __builtin_readcyclecounter(); pa0 += pt1 - pt0; pa1 += pt2 - pt1;)
    for (int j = 0; j < SPB; j++) {
     const int tg = tb + j * TPS;
     if (tg >= tEnd) break;
@@ -524,11 +536,22 @@ __device__ __forceinline__ void sweep_core(const unsigned char *tiles, const int
       epi.flush(tg + TPS - Epi::CH);
     }
    }
+   PTRACE({ const unsigned long long pt3 = __builtin_readcyclecounter(); pa2 += pt3 - pt2; pt0 = pt3; })
   }
   if (tEnd > tBeg && tEnd % Epi::CH) {
     epi.chain(acc[1], kvPend, QSETS - 1, pendTile);
     epi.flush((tEnd / Epi::CH) * Epi::CH);
   }
+#ifdef SWEEP_PHASE_TRACE
+  if (Epi::CH == CHUNK && lane == 0) {       // sweep 1 only (k_match_resolve runs the same core)
+    const int wg = blockIdx.x + gridDim.x * blockIdx.y;
+    if (wg * NW + wave < 16384) {
+      unsigned long long *o = g_ptrace[wg * NW + wave];
+      o[0] = pa0; o[1] = pa1; o[2] = pa2; o[3] = __builtin_readcyclecounter() - pstart; o[4] = (unsigned long long)it * SPB; o[5] = wall_clock64();
+      o[6] = (unsigned long long)QSETS; o[7] = pwall;
+    }
+  }
+#endif
 }
 
 // ---------------- sweep 1: per (query, split, lane half) the KTOP smallest group keys ------------------------------------------
@@ -1255,6 +1278,11 @@ void launch_match(hipStream_t s, const uint8_t *d1, int n1, const uint8_t *d2, i
 
 }  // namespace mx
 
+#ifdef SWEEP_PHASE_TRACE
+extern "C" __attribute__((visibility("default"))) int modsx_debug_phase_trace(unsigned long long *out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mx::g_ptrace), (size_t)n * 64, 0, hipMemcpyDeviceToHost);
+}
+#endif
 #ifdef MATCH_TRACE
 extern "C" __attribute__((visibility("default"))) int modsx_debug_match_trace(unsigned long long *out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mx::g_mtrace), (size_t)n * 32, 0, hipMemcpyDeviceToHost);
