@@ -372,17 +372,25 @@ MX_D int group_dist16(const uint8_t *qd, int na, const unsigned char *tiles, con
 // ---------------- staging: 4 tiles + their constants, global -> LDS directly ------------------------------------------
 typedef const unsigned char __attribute__((address_space(1))) *gbptr;
 typedef unsigned char __attribute__((address_space(3))) *lbptr;
-template <int NW>      // wavefronts of the workgroup: 16 chunks of tile bytes (1 KB per wave instruction) + 2 of row constants, dealt round robin
+template <int NW>      // wavefronts of the workgroup.  16 chunks of tile bytes (1 KB per wave instruction) + 2 of row constants
 MX_D void stage_group(const unsigned char *tiles, const int *hrow, int p0, unsigned char *buf, int wave, int lane) {
-  const unsigned char *src = tiles + (size_t)p0 * TILE_B + lane * 16;
-#pragma unroll
-  for (int i = 0; i < (18 + NW - 1) / NW; i++) {
-    const int chunk = wave + NW * i;
-    if (chunk < 16) __builtin_amdgcn_global_load_lds((gbptr)(src + chunk * 1024), (lbptr)(buf + chunk * 1024), 16, 0, 0);
-    else if (chunk < 18)
-      __builtin_amdgcn_global_load_lds((gbptr)(reinterpret_cast<const unsigned char *>(hrow + (size_t)p0 * 32) + (chunk - 16) * 256 + lane * 4),
-                                       (lbptr)(buf + HOFF + (chunk - 16) * 256), 4, 0, 0);
+  // a producing wavefront takes CPW CONSECUTIVE chunks: one address pair and one M0 for all of them, the instruction's immediate
+  // offset (applied to the global and to the LDS address alike) steps through them
+  constexpr int CPW = NW >= 8 ? 2 : 4, NPROD = 16 / CPW;
+  if (wave < NPROD) {
+    const unsigned char *src = tiles + (size_t)p0 * TILE_B + (size_t)wave * (CPW * 1024) + lane * 16;
+    unsigned char *dst = buf + wave * (CPW * 1024);
+    __builtin_amdgcn_global_load_lds((gbptr)src, (lbptr)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbptr)src, (lbptr)dst, 16, 1024, 0);
+    if (CPW == 4) {
+      __builtin_amdgcn_global_load_lds((gbptr)src, (lbptr)dst, 16, 2048, 0);
+      __builtin_amdgcn_global_load_lds((gbptr)src, (lbptr)dst, 16, 3072, 0);
+    }
   }
+  const int k = NW - 1 - wave;        // the last two wavefronts bring the row constants
+  if (k < 2)
+    __builtin_amdgcn_global_load_lds((gbptr)(reinterpret_cast<const unsigned char *>(hrow + (size_t)p0 * 32) + k * 256 + lane * 4),
+                                     (lbptr)(buf + HOFF + k * 256), 4, 0, 0);
 }
 MX_D v4i read_a(const unsigned char *tile, int row, int kb, int hi) {
   const int slot = 2 * kb + hi;
