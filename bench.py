@@ -443,6 +443,7 @@ def main():
     # (--step-barrier: a host-side barrier after every step, the form of rounds 1-4, whose figure stays in the line beside it)
     b2b = group is None and not single_view and not args.batch_api and lsteps is None and not args.step_barrier
     elapsed, ndesc, results = timed(run_batch, args.warmup, args.steps, group, back_to_back=b2b)
+    host_cpu_headline = host_cpu["s"]       # of the K timed steps (later legs run through timed() too)
     barrier_form = None
     if b2b:
         eb, nb_, _ = timed(run_batch, 0, args.steps, group)
@@ -451,6 +452,42 @@ def main():
                         "note": "the same K steps with a host-side barrier after every step (rounds 1-4 reported this form)"}
     res = next((r for r in results if r is not None), None)
     verify_timed = mods_amd.last_batch_verify() if single_view else None   # host share of the last batch of the timed region
+    wxbs_f = None
+    if wxbs and rank == 0 and group is None:
+        # configs[4] with epipolar verification: measured HERE, before any leg that brackets launches with timing events -- once a
+        # context has recorded such events the runtime keeps per-dispatch completion signals on its queue, which costs the context's
+        # host thread ~20 ms of CPU per pair from then on (tools/wxbs_cpu_probe.py: 8.5 -> 29 ms), and this leg is the one that is
+        # short of CPU (rounds 3-5 measured it after the profiling legs: 245-285 pairs/s for what is 313-319)
+        pF = mods_amd.default_pair_params(ransac_seed=1, useF=1, **WXBS)
+        mods_amd.match_pairs(ctxs, imgs1, imgs2, pF)
+        mods_amd.verify_device_stats(reset=True)
+        ruF0 = resource.getrusage(resource.RUSAGE_SELF)
+        ta = time.perf_counter()
+        stF = 3
+        # the stF steps' pairs in ONE call of the batch API (what back-to-back steps are for the per-pair calls: no idle tail of
+        # 16 contexts and their verification helpers between steps); the per-step form stays beside it
+        rF = mods_amd.match_pairs(ctxs, imgs1 * stF, imgs2 * stF, pF)
+        dtF = time.perf_counter() - ta
+        ruF1 = resource.getrusage(resource.RUSAGE_SELF)
+        cpuF = (ruF1.ru_utime - ruF0.ru_utime) + (ruF1.ru_stime - ruF0.ru_stime)
+        fms, fn, fth = mods_amd.last_batch_verify()
+        vst = mods_amd.verify_device_stats()
+        import ctypes as _C
+        cw, ch = _C.c_double(), _C.c_double()
+        mods_amd.lib().modsx_debug_last_batch_cpu(_C.byref(cw), _C.byref(ch))
+        tb = time.perf_counter()
+        for _ in range(stF):
+            mods_amd.match_pairs(ctxs, imgs1, imgs2, pF)
+        dtFstep = time.perf_counter() - tb
+        wxbs_f = (fms, fn, fth, vst, cw, ch, dtF, dtFstep, cpuF, ruF0, ruF1, rF, stF)
+    ladder_parts = {}
+    if ladder and rank == 0 and group is None:
+        # the MSER steps alone and the HessianAffine steps alone: the former are short of host CPU, so they too are measured before the
+        # contexts have recorded timing events
+        for name, det in (("mser_steps_only", 3), ("hessaff_steps_only", 0)):
+            st = cviu_ladder_steps(mods_amd, only=det)
+            el, nd, _ = timed(lambda st=st: run_batch(steps_l=st), 1, 2)
+            ladder_parts[name] = {"pairs_per_s": 2 * nbatch / el, "descriptors_per_pair": nd / (2 * nbatch), "views_per_image": sum(len(v) for v, _, _ in st)}
     elapsed, ndesc_total = reduce_over_ranks(elapsed, ndesc)
     if res is None:   # view-sharded: this rank verified none of the last step's pairs
         res = {"n_regions": (0, 0), "n_tentatives": 0, "n_unique": 0, "n_verified": 0, "H": np.eye(3)}
@@ -618,7 +655,7 @@ def main():
         if host_cpu.get("s") is not None:
             # rank 0's own threads (workers, verification helpers, host pool) over its share of the timed pairs: on a node where N ranks
             # share one host, N times this figure per second of throughput is what the host has to supply
-            out["host_cpu_s_per_pair_rank0"] = host_cpu["s"] / max(1, args.steps * nbatch)
+            out["host_cpu_s_per_pair_rank0"] = host_cpu_headline / max(1, args.steps * nbatch)
             out["host_threads"] = {"cpu_allowance": cpu_info()[2], "local_ranks": int(os.environ.get("LOCAL_WORLD_SIZE", "1"))}
         if group is not None:
             out["rccl"] = group.describe()
@@ -714,34 +751,18 @@ def main():
                     out["roofline_describe"]["traffic_source"] = ("%s: %.0f MB per chunk of %.0f MB algorithmic bytes in the committed one-stream "
                                                                   "31-view profile, scaled to this run's chunk (x %.3f)"
                                                                   % (tsrc, (tprof or 0) / 1e6, aprof / 1e6, byts / aprof))
-        if wxbs:
+        if wxbs and wxbs_f:
             # H verification was the timed region; the same batch with epipolar verification, and the host share of both
             vms, vn, vth = verify_timed
             hshare = {"verify_ms_per_pair": vms / max(1, vn), "helper_threads": vth}
-            pF = mods_amd.default_pair_params(ransac_seed=1, useF=1, **WXBS)
-            mods_amd.match_pairs(ctxs, imgs1, imgs2, pF)
-            mods_amd.verify_device_stats(reset=True)
-            ruF0 = resource.getrusage(resource.RUSAGE_SELF)
-            ta = time.perf_counter()
-            stF = 3
-            # the stF steps' pairs in ONE call of the batch API (what back-to-back steps are for the per-pair calls: no idle tail of
-            # 16 contexts and their verification helpers between steps); the per-step form stays beside it
-            rF = mods_amd.match_pairs(ctxs, imgs1 * stF, imgs2 * stF, pF)
-            dtF = time.perf_counter() - ta
-            ruF1 = resource.getrusage(resource.RUSAGE_SELF)
-            cpuF = (ruF1.ru_utime - ruF0.ru_utime) + (ruF1.ru_stime - ruF0.ru_stime)
-            fms, fn, fth = mods_amd.last_batch_verify()
-            vst = mods_amd.verify_device_stats()
-            tb = time.perf_counter()
-            for _ in range(stF):
-                mods_amd.match_pairs(ctxs, imgs1, imgs2, pF)
-            dtFstep = time.perf_counter() - tb
+            (fms, fn, fth, vst, cw, ch, dtF, dtFstep, cpuF, ruF0, ruF1, rF, stF) = wxbs_f
             out["wxbs"] = {
                 "H": {"pairs_per_s": value, **hshare,
                       "host_ransac_share_of_wall": (vms / max(1, vn)) / max(1, vth) / (1e3 / value) * 1.0},
                 "F": {"pairs_per_s": stF * nbatch / dtF, "pairs_per_s_one_call_per_step": stF * nbatch / dtFstep, "verify_ms_per_pair": fms / max(1, fn), "helper_threads": fth,
                       "verified_last_pair": rF[0]["n_verified"], "host_cpu_s_per_pair": cpuF / (stF * nbatch),
-                      "host_cores_busy": cpuF / dtF, "host_cpu_system_share": (ruF1.ru_stime - ruF0.ru_stime) / max(cpuF, 1e-9),
+                      "host_cores_busy": cpuF / dtF, "cpu_s_per_pair_context_threads": cw.value / (stF * nbatch),
+                      "cpu_s_per_pair_verification_helpers": ch.value / (stF * nbatch), "host_cpu_system_share": (ruF1.ru_stime - ruF0.ru_stime) / max(cpuF, 1e-9),
                       "rfth_loops_per_pair": vst["loops"] / float(stF * nbatch), "rfth_ms_per_loop": 1e-3 * vst["loop_us"] / max(1, vst["loops"]),
                       "rfth_ms_per_loop_parts": {k: 1e-3 * vst[k + "_us"] / max(1, vst["loops"]) for k in ("draw", "device_wait", "host_phase", "event_body")},
                       "rfth_hypotheses_on_device": vst["hypotheses"], "rfth_device_batches": vst["batches"],
@@ -752,10 +773,7 @@ def main():
             # where a ladder's time goes: the MSER steps alone and the HessianAffine steps alone (throughput, same contexts), and
             # one pair on an otherwise idle GPU step by step (latency)
             lad = {"steps": [{"detector": "MSER" if d == 3 else "HessianAffine", "views": len(v), "match_ratio": r} for v, r, d in lsteps]}
-            for name, det in (("mser_steps_only", 3), ("hessaff_steps_only", 0)):
-                st = cviu_ladder_steps(mods_amd, only=det)
-                el, nd, _ = timed(lambda st=st: run_batch(steps_l=st), 1, 2)
-                lad[name] = {"pairs_per_s": 2 * nbatch / el, "descriptors_per_pair": nd / (2 * nbatch), "views_per_image": sum(len(v) for v, _, _ in st)}
+            lad.update(ladder_parts)        # measured right after the timed region (see wxbs_f above: before any event-bracketed leg)
             lat = []
             ctx.match_ladder(imgs1[0], imgs2[0], lsteps, params, min_matches=10 ** 6)
             for k in range(1, len(lsteps) + 1):

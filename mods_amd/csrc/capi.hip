@@ -27,6 +27,15 @@ static T *to_malloc(const std::vector<T> &v) {
 // the number of helper threads that ran them
 static std::atomic<long> g_verifyUs(0);
 static std::atomic<int> g_verifyThreads(0), g_verifyPairs(0);
+// CPU time (not wall) of the last batch call, by kind of thread: the contexts' own threads and the verification helpers
+static std::atomic<long> g_cpuWorkerUs(0), g_cpuHelperUs(0);
+// helper threads of a batch call: one per working context unless MODSX_VERIFY_HELPERS says otherwise
+static int verify_helpers(int nw) {
+  static const int cap = getenv("MODSX_VERIFY_HELPERS") ? atoi(getenv("MODSX_VERIFY_HELPERS")) : 0;
+  return cap > 0 ? (cap < nw ? cap : nw) : nw;
+}
+static long thread_cpu_us() { timespec t; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t); return t.tv_sec * 1000000L + t.tv_nsec / 1000; }
+struct ThreadCpu { std::atomic<long> &acc; long t0; explicit ThreadCpu(std::atomic<long> &a) : acc(a), t0(thread_cpu_us()) {} ~ThreadCpu() { acc += thread_cpu_us() - t0; } };
 
 extern "C" {
 
@@ -449,6 +458,7 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
   } vq;
   const modsx_pair_params pp = *par;
   auto helper = [&]() {
+    ThreadCpu cpu(g_cpuHelperUs);
     for (;;) {
       mx::VerifyTask t;
       {
@@ -467,6 +477,7 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
   };
   auto worker = [&](int w) {
     modsx_ctx *c = ctxs[w];
+    ThreadCpu cpu(g_cpuWorkerUs);
     hipSetDevice(c->dev);
     std::vector<mx::VerifyTask> tasks;
     for (;;) {
@@ -489,8 +500,8 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
   std::vector<std::thread> th, hth;
   const int ngroups = (n_pairs + group - 1) / group;
   const int nw = n_ctx < ngroups ? n_ctx : ngroups;
-  g_verifyUs = 0; g_verifyPairs = 0; g_verifyThreads = nw;
-  for (int w = 0; w < nw; w++) hth.emplace_back(helper);
+  g_verifyUs = 0; g_verifyPairs = 0; g_verifyThreads = nw; g_cpuWorkerUs = 0; g_cpuHelperUs = 0;
+  for (int w = 0; w < verify_helpers(nw); w++) hth.emplace_back(helper);
   for (int w = 1; w < nw; w++) th.emplace_back(worker, w);
   if (nw > 0) worker(0);
   for (auto &t : th) t.join();
@@ -532,6 +543,7 @@ int modsx_match_pairs_views(modsx_ctx *const *ctxs, int n_ctx, const modsx_image
   } vq;
   const modsx_pair_params pp = *par;
   auto helper = [&]() {
+    ThreadCpu cpu(g_cpuHelperUs);
     for (;;) {
       mx::VerifyTask t;
       {
@@ -550,6 +562,7 @@ int modsx_match_pairs_views(modsx_ctx *const *ctxs, int n_ctx, const modsx_image
   };
   auto worker = [&](int w) {
     modsx_ctx *c = ctxs[w];
+    ThreadCpu cpu(g_cpuWorkerUs);
     hipSetDevice(c->dev);
     for (;;) {
       if (failed.load()) break;
@@ -568,8 +581,8 @@ int modsx_match_pairs_views(modsx_ctx *const *ctxs, int n_ctx, const modsx_image
   };
   std::vector<std::thread> th, hth;
   const int nw = n_ctx < n_pairs ? n_ctx : n_pairs;
-  g_verifyUs = 0; g_verifyPairs = 0; g_verifyThreads = nw;
-  for (int w = 0; w < nw; w++) hth.emplace_back(helper);
+  g_verifyUs = 0; g_verifyPairs = 0; g_verifyThreads = nw; g_cpuWorkerUs = 0; g_cpuHelperUs = 0;
+  for (int w = 0; w < verify_helpers(nw); w++) hth.emplace_back(helper);
   for (int w = 1; w < nw; w++) th.emplace_back(worker, w);
   if (nw > 0) worker(0);
   for (auto &t : th) t.join();
@@ -594,6 +607,13 @@ int modsx_last_batch_verify(double *sum_ms, int *pairs, int *threads) {
   if (sum_ms) *sum_ms = g_verifyUs.load() / 1000.0;
   if (pairs) *pairs = g_verifyPairs.load();
   if (threads) *threads = g_verifyThreads.load();
+  return MODSX_OK;
+}
+
+// CPU seconds (thread CPU clocks, not wall) the last batch call spent in the contexts' own threads and in its verification helpers
+extern "C" __attribute__((visibility("default"))) int modsx_debug_last_batch_cpu(double *worker_s, double *helper_s) {
+  if (worker_s) *worker_s = g_cpuWorkerUs.load() / 1e6;
+  if (helper_s) *helper_s = g_cpuHelperUs.load() / 1e6;
   return MODSX_OK;
 }
 
