@@ -578,7 +578,10 @@ int modsx_load_regions(const char *path, const char *det_name, const char *desc_
  * class, GPU milliseconds, launch count and algorithmic work (bytes; flops for the matcher).  Classes in order:
  * blur_hess, hessian, resize, nms_localize (scan + refine), baumberg, orientation, patch_sample, blur_rows, describe,
  * match_fginn, gray, warp_affine, view_blur, blur_cols, match_sweep1 (the one k_match launch that carries the 2 N M 128
- * contraction; also part of match_fginn).  modsx_kernel_stats returns the number of classes. */
+ * contraction; also part of match_fginn).  modsx_kernel_stats returns the number of classes.
+ * Cost: with ROCm 7 a stream that has recorded timing events keeps per-dispatch completion signals on its queue -- every later
+ * launch of that context costs its host thread more CPU (measured: 8.5 -> 29 ms per 1920x1080 pair of ~220 launches), also after
+ * modsx_profile(ctx, 0).  Profile on contexts made for it, or after the throughput measurement (bench.py orders its legs so). */
 int modsx_profile(modsx_ctx *ctx, int enable);
 int modsx_kernel_stats(modsx_ctx *ctx, double *ms, double *work, long *launches, int n);
 
