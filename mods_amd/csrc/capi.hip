@@ -496,6 +496,22 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
         vq.cv.notify_all();
       }
     }
+    // out of pairs: the context's thread helps the verification helpers with what is still queued (the tail of a batch call is
+    // the verification of its last pairs, with the device already idle)
+    for (;;) {
+      mx::VerifyTask t;
+      {
+        std::lock_guard<std::mutex> lk(vq.m);
+        if (vq.q.empty()) break;
+        t = std::move(vq.q.front());
+        vq.q.pop_front();
+      }
+      hipSetDevice(t.dev);
+      const auto v0 = std::chrono::steady_clock::now();
+      mx::verify_tentatives(t.l1, t.l2, t.tents, pp, t.res);
+      g_verifyUs += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - v0).count();
+      g_verifyPairs++;
+    }
   };
   std::vector<std::thread> th, hth;
   const int ngroups = (n_pairs + group - 1) / group;
@@ -577,6 +593,20 @@ int modsx_match_pairs_views(modsx_ctx *const *ctxs, int n_ctx, const modsx_image
       }
       { std::lock_guard<std::mutex> lk(vq.m); vq.q.push_back(std::move(task)); }
       vq.cv.notify_one();
+    }
+    for (;;) {      // out of pairs: help with the verifications still queued (see modsx_match_pairs)
+      mx::VerifyTask t;
+      {
+        std::lock_guard<std::mutex> lk(vq.m);
+        if (vq.q.empty()) break;
+        t = std::move(vq.q.front());
+        vq.q.pop_front();
+      }
+      hipSetDevice(t.dev);
+      const auto v0 = std::chrono::steady_clock::now();
+      mx::verify_tentatives(t.l1, t.l2, t.tents, pp, t.res);
+      g_verifyUs += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - v0).count();
+      g_verifyPairs++;
     }
   };
   std::vector<std::thread> th, hth;
