@@ -574,15 +574,21 @@ def main():
     # per-kernel time of the multi-stream regime: an extra step with the event brackets on
     PROF_STEPS = 1
     stats = {}
+    pctxs = ctxs
     if views_hung:
         pass
     elif (rank == 0 and group is None) or (group is not None and not args.loopback):
-        for c in ctxs:
+        # the event-bracketed legs run on contexts of their own where they can (pair-sharded runs): a context that has recorded timing
+        # events costs its host thread more CPU per launch for good (include/modsx.h, modsx_profile), and the legs that follow
+        # (`extra`, configs[4]'s and the ladder's parts) are measured on the timed region's contexts
+        if group is None:
+            pctxs = [mods_amd.Context(local_rank) for _ in ctxs]
+        for c in pctxs:
             c.profile(True)
         for _ in range(PROF_STEPS):
-            run_batch()
-        barrier(group) if group is not None else [c.synchronize() for c in ctxs]
-        for c in ctxs:
+            run_batch(cx=pctxs)
+        barrier(group) if group is not None else [c.synchronize() for c in pctxs]
+        for c in pctxs:
             for k, v in c.kernel_stats().items():
                 d = stats.setdefault(k, dict(ms=0.0, work=0.0, launches=0))
                 d["ms"] += v["ms"]; d["work"] += v["work"]; d["launches"] += v["launches"]
@@ -594,31 +600,35 @@ def main():
         # really one stream: a lone multi-view pair would otherwise run image 2 on a peer context and every image in three parts on
         # helper contexts (engine_views.hip), and the event brackets of this leg would include their queueing
         os.environ["MODSX_PAIR_SERIAL"] = "1"; os.environ["MODSX_PAIR_NOSPLIT"] = "1"
-        ctx.profile(True)
+        pctx = pctxs[0]
+        pctx.profile(True)
         niso = min(nbatch, 8 if single_view else 4)
         if single_view:
             for i0 in range(0, niso, 4):
-                mods_amd.match_pairs([ctx], imgs1[i0:min(i0 + 4, niso)], imgs2[i0:min(i0 + 4, niso)], params)
+                mods_amd.match_pairs([pctx], imgs1[i0:min(i0 + 4, niso)], imgs2[i0:min(i0 + 4, niso)], params)
         else:
             for i in range(niso):
-                ctx.match_pair_views(imgs1[i], imgs2[i], views, params)
-        ctx.synchronize()
-        iso = {k: v for k, v in ctx.kernel_stats().items() if v["launches"]}
-        ctx.profile(False)
+                pctx.match_pair_views(imgs1[i], imgs2[i], views, params)
+        pctx.synchronize()
+        iso = {k: v for k, v in pctx.kernel_stats().items() if v["launches"]}
+        pctx.profile(False)
         if not single_view:
             # the matcher's roofline: ONE pair (pair 0), repeated; N, M and the work all come from that pair
-            ctx.profile(True)
+            pctx.profile(True)
             REP = 5
             for _ in range(REP):
-                r0 = ctx.match_pair_views(imgs1[0], imgs2[0], views, params)
-            ctx.synchronize()
-            ks = ctx.kernel_stats()
+                r0 = pctx.match_pair_views(imgs1[0], imgs2[0], views, params)
+            pctx.synchronize()
+            ks = pctx.kernel_stats()
             m, m1 = ks.get("match_fginn"), ks.get("match_sweep1")
-            ctx.profile(False)
+            pctx.profile(False)
             if m and m["launches"]:
                 mroof = (m["ms"] / m["launches"], r0["n_regions"][0], r0["n_regions"][1], m["launches"],
                          m1["ms"] / m1["launches"] if m1 and m1["launches"] else None)
         os.environ.pop("MODSX_PAIR_SERIAL", None); os.environ.pop("MODSX_PAIR_NOSPLIT", None)
+    if pctxs is not ctxs:
+        for c in pctxs:
+            c.close()
 
     if rank == 0:
         pairs = args.steps * (nbatch if group is not None else world * nbatch)
