@@ -614,15 +614,16 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
   //         bin and the two orientation weights are formed from it where they are used (the gather's forming step);
   //   bufA: WX (direct branch) / the resampling table (grid branch), the compacted masked values, later val = mask * |grad|.
   constexpr int NPXP = (NPX + 3) & ~3;
-  __shared__ __attribute__((aligned(16))) float bufO_[DR][NPXP];
-  float *const patch = bufO_[reg], *const bufO = bufO_[reg];
+  __shared__ __attribute__((aligned(16))) float buf_[DR][2][NPXP];   // [0] bufO, [1] bufA: contiguous (the order-free gather's
+                                                                     // accumulators span both)
+  float *const patch = buf_[reg][0], *const bufO = buf_[reg][0];
   constexpr int PER_T = (NPX + 127) / 128;
-  __shared__ __attribute__((aligned(16))) float bufA_[DR][NPXP];
-  float *const bufA = bufA_[reg];
+  float *const bufA = buf_[reg][1];
   __shared__ __attribute__((aligned(16))) double slut_[DR][256];   // the descriptor vector and its partial sums (2 KB)
   __shared__ __attribute__((aligned(16))) unsigned char sbs_[DR][4 * 64];   // gather: orientation bin bo0 % 8 of the step's 4 x 64 slots
-  __shared__ float swr0_[DR][PS], swr1_[DR][PS];
-  float *const swr0 = swr0_[reg], *const swr1 = swr1_[reg];
+  // precomputeBinsAndWeights (siftdesc.cpp:22-71) per row / column index i: {w0[i], w1[i], the smaller nonzero one of the two (1
+  // if both are 0), bin0 | bin1 << 2 with the bins in 0..3}; one table for the workgroup
+  __shared__ float4 stab[PS];
   // the resampling table of the grid branch (smap, sfr) lies in bufA, which that branch does not use before the normalisation
   int4 *const smap = reinterpret_cast<int4 *>(bufA);
   float *const sfr = bufA + 168;
@@ -637,8 +638,11 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
   if (tidw == 0) spad_[MODSX_DESCRIBE_PAD - 1] = 1;
 #endif
   const DescJob jb = jobs[k];
-  if (tid < PS) {
-    swr0[tid] = (float)wTab[tid]; swr1[tid] = (float)wTab[PS + tid];   // const float wr0 = w0[r] (siftdesc.cpp:79-81)
+  if (tidw < PS) {
+    const float w0 = (float)wTab[tidw], w1 = (float)wTab[PS + tidw];   // const float wr0 = w0[r] (siftdesc.cpp:79-81)
+    const int q = tidw >> 3, b0 = min(max(q - 1, 0), 3), b1 = min(q, 3);   // a bin outside 0..3 comes with weight 0
+    const float wm = w0 > 0 ? (w1 > 0 ? fminf(w0, w1) : w0) : (w1 > 0 ? w1 : 1.f);
+    stab[tidw] = make_float4(w0, w1, wm, __int_as_float(b0 | (b1 << 2)));
   }
   if (jb.P > 0) {
     // interpolate(smoothed, P/2, P/2, i2p, 0, 0, i2p, patch) (synth-detection.hpp:211-212) on the compact blurred grid:
@@ -733,7 +737,7 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
     __syncthreads();
     if (tidw < DR) {   // lane q of wavefront 0 runs region q's chain
       float sum = 0.f;
-      const float *vals = bufA_[tidw];
+      const float *vals = buf_[tidw][1];
       const float4 *v4 = reinterpret_cast<const float4 *>(vals);
       const int full = nm >> 2;
 #pragma unroll 8
@@ -749,7 +753,7 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
     __syncthreads();
     if (tidw < DR) {
       float var = 0.f;
-      const float *vals = bufA_[tidw];
+      const float *vals = buf_[tidw][1];
       const float4 *v4 = reinterpret_cast<const float4 *>(vals);
       const int full = nm >> 2;
 #pragma unroll 8
@@ -771,11 +775,11 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
     __syncthreads();
   }
   // -- gradients, orientation, per-pixel weights (siftdesc.cpp:346-379, 73-131)
-  float ov[PER_T];
+  float ov[PER_T], vv[PER_T];   // o and val = mask * |grad| of the thread's pixels p = tid + 128 k
 #pragma unroll
   for (int k = 0; k < PER_T; k++) {
     const int p = tid + 128 * k;
-    ov[k] = 0.f;
+    ov[k] = 0.f; vv[k] = 0.f;
     if (p >= NPX) continue;
     const int r = p / PS, c = p - r * PS;
     // one-sided differences on the patch's frame, central ones inside (siftdesc.cpp:346-360): the neighbour that does not
@@ -790,18 +794,119 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
     const bool special = atan2lut_case(yg, xg, code, idx);
     // val = (float)(0.0 + (1.0 * (double)mask) * (double)g) in the reference: the f64 product of two f32 values is exact (48
     // significant bits), so rounding it to f32 IS the f32 product; mask, g >= 0, so the + 0.0 changes nothing
-    const float val = mask[p] * g;
-    const float o = oTab[special ? 2048 : code * 256 + idx];
-    ov[k] = o;                   // bo0 = (int)o and wo1 = o - bo0 (siftdesc.cpp:111-117) are formed in the gather
-    bufA[p] = val;               // the column weights wc0 / wc1 = (float)(w[c] * val) are formed in the gather
+    vv[k] = mask[p] * g;         // the column weights wc0 / wc1 = (float)(w[c] * val) are formed in the gather
+    ov[k] = oTab[special ? 2048 : code * 256 + idx];   // bo0 = (int)o and wo1 = o - bo0 (siftdesc.cpp:111-117) are formed in the gather
   }
-  __syncthreads();   // all gradients taken: the patch may be replaced by o
+  // -- samplePatch, order-free form.  vec[bin] += val * wo (siftdesc.cpp:73-131) adds f32 terms >= +0 to an f64 accumulator in
+  // raster order.  Scale the region by a power of two S (exact) so that every nonzero term is an INTEGER (x >= 2^23 makes an f32
+  // one) and add the terms as 64-bit integers -- associative, so any order and any number of partial accumulators give the
+  // exact sum X.  If X < 2^53, every partial sum of the reference's loop is an integer below 2^53 too, i.e. exactly
+  // representable: no add of that loop ever rounds and its result is X / S.  Otherwise (a term below 2^23 after scaling, a bin
+  // at 2^53 or more, no usable S) the workgroup runs the ordered gather below: 1 % of the regions -- a pixel pair one ulp apart
+  // under a small orientation weight, against a bin 2^23 times larger.
+  //   S = 2^(47 - E) for max val < 2^E: every term is below 2^47 (32 of them fit under the 2^52 conversion constant), 5 binades of room for a bin
+  //   against the largest val (2^(E + 6) was never reached on 10^4 regions, 2^(E + 5) by 2 in 10^4), 23 binades below it for the
+  //   smallest term.
+  // Every thread adds the 8 terms of each of its 14 pixels straight to the bins with LDS 64-bit integer atomics (twice the
+  // rate of f64 ones here: tools/ubench/lds_atomics.hip): 8 copies of the bins, one per column mod 8 and skewed by one 8-byte
+  // bank (neighbouring pixels mostly share a bin), 9 orientation slots per cell so that bin b0 + 1 is always the next word
+  // (slot 8 is slot 0's).  A quarter of the ordered gather's vector instructions, no barrier per step.
+  constexpr int ACS = 145, NAC = 8 * ACS;                      // copy stride and total in 8-byte words
+  static_assert(NAC * 2 <= 2 * NPXP, "8 skewed copies of 16 x 9 bins fit in bufO + bufA");
+  unsigned long long *const acc = reinterpret_cast<unsigned long long *>(buf_[reg][0]);
+  __shared__ unsigned smin_[DR][2], smax_[DR][2];
+  {
+    unsigned mb = 0;               // val >= +0: the bit patterns order like the values, and a NaN or an infinity (which end in
+                                   // the ordered gather) above all finite ones
 #pragma unroll
-  for (int k = 0; k < PER_T; k++) {
-    const int p = tid + 128 * k;
-    if (p < NPX) bufO[p] = ov[k];
+    for (int k = 0; k < PER_T; k++) mb = max(mb, __float_as_uint(vv[k]) & 0x7fffffffu);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, off));
+    if ((tid & 63) == 0) smax_[reg][tid >> 6] = mb;
   }
+  __syncthreads();   // all gradients taken: the patch and bufA are dead
+  {
+    float4 *const z = reinterpret_cast<float4 *>(buf_[reg][0]);
+    for (int i = tid; i < (NAC * 2 + 3) / 4; i += 128) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const unsigned mxb = max(smax_[reg][0], smax_[reg][1]);
+  const int E = (int)(mxb >> 23) - 126;                          // max val in [2^(E - 1), 2^E)
+  const bool scalable = mxb >= 0x00800000u && mxb < 0x7f800000u && E >= -60 && E <= 100;   // (a region of zeros: ordered, it is rare)
+  const float S = __uint_as_float((unsigned)(127 + 47 - (scalable ? E : 47)) << 23);
   __syncthreads();
+  unsigned tmin = 0xffffffffu;     // (bits of the smallest nonzero scaled term) - 1: +0 wraps to the maximum and never wins
+  {
+    int r = tid / PS, c = tid - r * PS;
+#pragma unroll
+    for (int k = 0; k < PER_T; k++) {
+      const float val = vv[k] * S;   // exact: a power of two, no overflow, and scaling up makes no denormal
+      if (val > 0) {                 // not: outside the mask's disc (a quarter of the pixels), flat, past the patch, NaN
+        const float o = ov[k];
+        const int bo0 = (int)o;
+        const float wo1 = o - (float)bo0, wo0 = 1.0f - wo1;
+        const float4 tr = stab[r], tc = stab[c];
+        const int pr = __float_as_int(tr.w), pc = __float_as_int(tc.w);
+        // wc = (float)(w[c] * (double)val): the weights are multiples of 1/8, so the f64 product is exact and its rounding to f32
+        // is the f32 product (checked where the table is built)
+        const float wc0 = tc.x * val, wc1 = tc.y * val;
+        // byte offsets: copy (c & 7), cell (row bin, column bin), slot b0 = bo0 % 8 = bo0 & 7 (o >= 4: ori >= -pi)
+        const int ob = (c & 7) * (ACS * 8) + (bo0 & 7) * 8;
+        const int r0 = (pr & 3) * 288, r1 = (pr >> 2) * 288, c0 = (pc & 3) * 72 + ob, c1 = (pc >> 2) * 72 + ob;
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f wcv = {wc0, wc1}, wov = {wo0, wo1};
+        const v2f va = wcv * tr.x, vb = wcv * tr.y;                      // (row bin0 | bin1) x (column bin0, bin1)
+        const v2f ts[4] = {wov * va.x, wov * va.y, wov * vb.x, wov * vb.y};   // the slot's terms for bins b0, b0 + 1
+        const int bs[4] = {r0 + c0, r0 + c1, r1 + c0, r1 + c1};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          // x + 2^52 of an integer x < 2^52 holds x in its low 52 bits.  The words are added as they are: a (copy, bin) word takes
+          // at most one term of each of the 2 x 16 pixels of its column pair, 32 x 2^47 <= 2^52, so the low 52 bits of the word
+          // are the sum of its terms and the exponent fields pile up above them, to be masked off by the merge
+          const double d0 = (double)ts[q].x + 4503599627370496.0, d1 = (double)ts[q].y + 4503599627370496.0;
+          unsigned long long *const a = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(acc) + bs[q]);
+          __hip_atomic_fetch_add(a, (unsigned long long)__double_as_longlong(d0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(a + 1, (unsigned long long)__double_as_longlong(d1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        // the smallest nonzero term of the pixel: products of non-negative factors round monotonically, so it is the one of
+        // the smallest nonzero row weight, column weight and orientation weight
+        const float wom = wo1 > 0 ? fminf(wo0, wo1) : wo0;
+        tmin = min(tmin, __float_as_uint((tr.z * (tc.z * val)) * wom) - 1u);
+      }
+      c += 128 - 3 * PS; r += 3;     // p += 128
+      if (c >= PS) { c -= PS; r++; }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) tmin = min(tmin, (unsigned)__shfl_xor((int)tmin, off));
+  if ((tid & 63) == 0) smin_[reg][tid >> 6] = tmin;
+  __syncthreads();
+  double binT;
+  bool inexact;
+  {
+    const int cell = tid >> 3, slot = tid & 7;
+    unsigned long long X = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      constexpr unsigned long long M52 = (1ull << 52) - 1ull;
+      X += acc[q * ACS + cell * 9 + slot] & M52;
+      if (slot == 0) X += acc[q * ACS + cell * 9 + 8] & M52;
+    }
+    const unsigned m = min(smin_[reg][0], smin_[reg][1]);   // 0xffffffff: no nonzero term at all (every bin is +0)
+    inexact = !scalable || (m != 0xffffffffu && m + 1u < 0x4b000000u) || (X >> 53) != 0;
+    // X < 2^53: the two halves convert exactly and so does their sum; the division by S is a change of exponent
+    binT = ldexp((double)(unsigned)(X >> 32) * 4294967296.0 + (double)(unsigned)X, (scalable ? E : 47) - 47);
+  }
+#ifdef MODSX_DESC_ORDERED_ONLY   // test build: every workgroup takes the ordered gather
+  inexact = true;
+#endif
+  const int ordered = __syncthreads_or(inexact);   // the regions of a workgroup share the barriers of the ordered gather
+  if (ordered) {
+#pragma unroll
+    for (int k = 0; k < PER_T; k++) {
+      const int p = tid + 128 * k;
+      if (p < NPX) { bufA[p] = vv[k]; bufO[p] = ov[k]; }
+    }
+    __syncthreads();
   // -- samplePatch: a bin gathers its 16x16 pixel block in raster order.  ONE wavefront per region does it, a lane owning two
   // neighbouring orientation bins of a spatial cell: a pixel's orientation falls into bin b0 with weight 1 - wo1 and into
   // b0 + 1 with wo1, so the lane of bins (2p, 2p + 1) takes something from the pixels with b0 in {2p - 1, 2p, 2p + 1} -- the same
@@ -828,10 +933,10 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
       for (int u = 0; u < 2; u++) {
         const int i = tid + 128 * u, rbi = i >> 6, vc = i & 63;
         const int col = vc < 32 ? vc : vc - 24, r = 8 * rbi + rr;
-        const float wrr = rr < 8 ? swr1[r] : swr0[r];
+        const float wrr = rr < 8 ? stab[r].y : stab[r].x;
         // wc0 / wc1 = (float)(w[c] * (double)val) in the reference: the weights are multiples of 1/8 (exact in f32, checked
         // where the table is built), so the f64 product is exact and its rounding to f32 is the f32 product
-        const float wcv = (vc < 32 ? swr1[col] : swr0[col]) * bufA[r * PS + col];
+        const float wcv = (vc < 32 ? stab[col].y : stab[col].x) * bufA[r * PS + col];
         const float v = wrr * wcv;
         const float vcl = v > 0 ? v : 0.f;
         const float o = bufO[r * PS + col];
@@ -867,6 +972,7 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
     }
     if (gth) { vec[(rb * 4 + cb) * 8 + oa] = accA; vec[(rb * 4 + cb) * 8 + ob] = accB; }
   }
+  } else vec[tid] = binT;
   __syncthreads();
   // The descriptors of one step share everything up to here (SIFTDescriptor::operator(), siftdesc.cpp:401-442: RootSIFT and
   // HalfRootSIFT run the same computeRootSiftDescriptor on the same patch and differ in the fold and the norm), so a step
