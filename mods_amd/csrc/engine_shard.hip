@@ -756,8 +756,12 @@ int detect_describe_items_sharded(modsx_ctx *c, modsx_comm *cm, const modsx_imag
       const size_t ns = std::max(L.capOwnSend, P.maxSendRows + P.maxSendRows / 4 + 64), nr = std::max(L.capOwnRecv, P.maxRecvRows + P.maxRecvRows / 4 + 64);
       const size_t nl = std::max(L.capOwnList, listRows + listRows / 4 + 64);
       int arc = MODSX_OK;
-      if (!L.ownSend.ensure(ns * ROW_B) || !L.ownRecv.ensure(nr * ROW_B) || !L.regsIn.ensure(ns * RB) || !L.hRegs.ensure(std::max(ns, nl) * RB) ||
-          !L.regsOut.ensure(nl * RB) || !L.posOut.ensure(nl * 16))
+      // capacities are agreed in ROWS, so the bytes behind them are those of the widest row any later call on this lane may
+      // carry (full region record + MODSX_MAX_DESC descriptor classes): a call with more classes and row counts under the
+      // caps does not pass through this branch again
+      const size_t ROW_CAP = (size_t)row_bytes(REG_B, MODSX_MAX_DESC), RB_CAP = (size_t)REG_B;
+      if (!L.ownSend.ensure(ns * ROW_CAP) || !L.ownRecv.ensure(nr * ROW_CAP) || !L.regsIn.ensure(ns * RB_CAP) || !L.hRegs.ensure(std::max(ns, nl) * RB_CAP) ||
+          !L.regsOut.ensure(nl * RB_CAP) || !L.posOut.ensure(nl * 16))
         arc = MODSX_ERR_NOMEM;
       for (int k = 0; k < nd && !arc; k++)
         if (grow_keep(s, *descAcc[k], base[k] * 128, (base[k] + nl) * 128) != MODSX_OK) arc = MODSX_ERR_NOMEM;

@@ -219,6 +219,9 @@ __device__ unsigned long long g_btrace[16];
 #define BT(i) do { } while (0)
 #endif
 
+#ifndef MODSX_BAUMBERG_K
+#define MODSX_BAUMBERG_K 2
+#endif
 template <int K>
 __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffOut *out, int n, const float *mask, int chunk,
                                                         int nchunks, int maxIter, float convTh, float affInitialSigma) {
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
   const bool slotLane = lane < 2 * K;
   float u11 = 1.0f, u12 = 0.0f, u21 = 0.0f, u22 = 1.0f, l1 = 1.0f, l2 = 1.0f, era = 0.0f, erb = 0.0f, ratio = 0.f;
   float slx = 0.f, sly = 0.f;   // the keypoint's position in its pyramid level (x / pixelDistance): formed once per keypoint
+  int scols = 4, srows = 4;     // size of that level (interpolateCheckBorders is evaluated in the slot's state lanes)
   int ok = 0, it = 0, kidx = -1;
   // the job list is image-major in detection order (octave, level, row, column): XCD x takes the x-th contiguous eighth of
   // the chunks, so that the blur planes a keypoint's windows read stay in ONE L2 (round 2: 1.03 GB fetched per launch, every
@@ -271,6 +275,7 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
         const AffJob sj = jobs[cand];
         ratio = sj.s / (affInitialSigma * sj.pixelDistance);
         slx = sj.x / sj.pixelDistance; sly = sj.y / sj.pixelDistance;
+        scols = sj.cols; srows = sj.rows;
         u11 = 1.0f; u12 = 0.0f; u21 = 0.0f; u22 = 1.0f; l1 = 1.0f; l2 = 1.0f; era = 0.0f; erb = 0.0f;
         ok = 0; it = 0;
         live = true;
@@ -281,6 +286,9 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
     if (!liveMask) break;
     BT(0);
     const float A11 = u11 * ratio, A12 = u12 * ratio, A21 = u21 * ratio, A22 = u22 * ratio;
+    // interpolateCheckBorders (helpers.cpp:524-549) of every slot at once, each in its own state lanes: one evaluation per
+    // iteration instead of one per slot behind six broadcasts of the slot's matrix and position
+    const unsigned long long touchMask = __ballot(check_borders(scols, srows, slx, sly, A11, A12, A21, A22, W, W));
     if constexpr (K == 2) {
       // Sample coordinates of BOTH slots at once (helpers.cpp:563-585: f32 running sums down the rows, then along each row).
       // The four chains -- slot 0 x, slot 0 y, slot 1 x, slot 1 y -- take one DPP row of 16 lanes each.  Row starts: lane i of
@@ -322,13 +330,21 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
 #pragma unroll
     for (int q = 0; q < K; q++) {
       if (!((liveMask >> (2 * q)) & 1)) continue;
+#ifdef MODSX_BAUM_VECTOR_JOB   // round-5 form: the job through a vector index (the level's base is then a VGPR pair per tap)
       const AffJob jb = jobs[__shfl(kidx, 2 * q)];
-      const float lx = __shfl(slx, 2 * q), ly = __shfl(sly, 2 * q);
+#else
+      // the slot's job through a SCALAR index (v_readlane of the slot's even lane): its fields arrive by scalar loads, so the
+      // level's base pointer, rows and cols are SGPRs and a tap's loads take the scalar base + 32-bit vector offset form --
+      // no 64-bit vector address per tap row (two v_lshl_add_u64 + two moves of the 20 vector instructions of a tap)
+      const AffJob jb = jobs[__builtin_amdgcn_readlane(kidx, 2 * q)];
+#endif
       const gcfloat_p img = as_global(jb.blur);
       float *const pa = buf[q][0], *const pb = buf[q][1], *const pc = buf[q][2];
       float *const simg = pc;
+      const bool touch = (touchMask >> (2 * q)) & 1;
+#ifdef BAUM_TRACE
       const float a11 = __shfl(A11, 2 * q), a12 = __shfl(A12, 2 * q), a21 = __shfl(A21, 2 * q), a22 = __shfl(A22, 2 * q);
-      const bool touch = check_borders(jb.cols, jb.rows, lx, ly, a11, a12, a21, a22, W, W);
+#endif
 #ifdef BAUM_TRACE
       if (lane == 0) {     // extent of the sampled window in the level: what a staged source tile would have to hold
         const float bw = 18.f * (fabsf(a11) + fabsf(a12)) + 3.f, bh = 18.f * (fabsf(a21) + fabsf(a22)) + 3.f;
@@ -339,6 +355,8 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
 #endif
       if constexpr (K != 2) {
         // sample coordinates: lane j runs the f32 running sums of row j (helpers.cpp:563-585) into LDS
+        const float lx = __shfl(slx, 2 * q), ly = __shfl(sly, 2 * q);
+        const float a11 = __shfl(A11, 2 * q), a12 = __shfl(A12, 2 * q), a21 = __shfl(A21, 2 * q), a22 = __shfl(A22, 2 * q);
         float rx = lx - (float)half * a12, ry = ly - (float)half * a22;
 #pragma unroll
         for (int j = 1; j < W; j++)
@@ -466,9 +484,6 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
 #endif
 }
 
-#ifndef MODSX_BAUMBERG_K
-#define MODSX_BAUMBERG_K 2
-#endif
 #ifndef MODSX_BAUMBERG_CHUNK
 #define MODSX_BAUMBERG_CHUNK 8
 #endif

@@ -312,8 +312,10 @@ __device__ __forceinline__ void blur_rows_from_lds(const BlurTile &bt, const flo
     for (int q = 0; q < NQ; q++) {
       int e = base + q * BLUR_T;
       e = e < total ? e : total - 1;                                      // idle slots repeat the last pair, not stored
-      const int r = (int)(((unsigned)e * (unsigned)bt.magic) >> 20), m = e - r * NP;   // e / NP (exact for e < 4096, NP <= 96)
-      p[q] = r * RW + sneed[2 * m];
+      // e / NP (exact for e < 4096, NP <= 96); every product here is 24 bit x 24 bit (e < 2^12, magic <= 2^20, rows and strides
+      // < 2^12): v_mul_u32_u24 issues at the full rate, the 32-bit v_mul_lo_u32 the plain `*` compiles to at a quarter of it
+      const int r = (int)(__umul24((unsigned)e, (unsigned)bt.magic) >> 20), m = e - (int)__umul24((unsigned)r, (unsigned)NP);
+      p[q] = (int)__umul24((unsigned)r, (unsigned)RW) + sneed[2 * m];
     }
     if (n == 1) {
 #pragma unroll
@@ -346,8 +348,8 @@ __device__ __forceinline__ void blur_rows_from_lds(const BlurTile &bt, const flo
     for (int q = 0; q < NQ; q++) {
       const int e = base + q * BLUR_T;
       if (e < total) {
-        const int r = (int)(((unsigned)e * (unsigned)bt.magic) >> 20), m = e - r * NP;
-        float *o = out + r * ostride + 2 * m;
+        const int r = (int)(__umul24((unsigned)e, (unsigned)bt.magic) >> 20), m = e - (int)__umul24((unsigned)r, (unsigned)NP);
+        float *o = out + (__umul24((unsigned)r, (unsigned)ostride) + 2u * (unsigned)m);
         o[0] = v0[q];
         if (2 * m + 1 < NC) o[1] = v1[q];
       }
@@ -371,8 +373,8 @@ __device__ __forceinline__ void blur_cols_from_lds(int NC, int n, int ro0, int n
     for (int q = 0; q < NQ; q++) {
       int e = base + q * BLUR_T;
       e = e < total ? e : total - 1;
-      const int ri = (int)(((unsigned)e * (unsigned)magic) >> 20), m = e - ri * NP;
-      pc[q] = (sneed[ro0 + ri] - lo) * LS + 2 * m;
+      const int ri = (int)(__umul24((unsigned)e, (unsigned)magic) >> 20), m = e - (int)__umul24((unsigned)ri, (unsigned)NP);
+      pc[q] = (int)__umul24((unsigned)(sneed[ro0 + ri] - lo), (unsigned)LS) + 2 * m;   // (parked row >= 0)
     }
     if (n == 1) {
 #pragma unroll
@@ -399,8 +401,8 @@ __device__ __forceinline__ void blur_cols_from_lds(int NC, int n, int ro0, int n
     for (int q = 0; q < NQ; q++) {
       const int e = base + q * BLUR_T;
       if (e < total) {
-        const int ri = (int)(((unsigned)e * (unsigned)magic) >> 20), m = e - ri * NP;
-        float *o = out + ri * NC + 2 * m;
+        const int ri = (int)(__umul24((unsigned)e, (unsigned)magic) >> 20), m = e - (int)__umul24((unsigned)ri, (unsigned)NP);
+        float *o = out + (__umul24((unsigned)ri, (unsigned)NC) + 2u * (unsigned)m);
         o[0] = v[q].x;
         if (2 * m + 1 < NC) o[1] = v[q].y;
       }
@@ -436,7 +438,7 @@ __device__ __forceinline__ void sample_chunk_lds(const ImgRef &im, const float *
 #pragma unroll
   for (int u = 0; u < PER; u++) {
     const int e = lane + 64 * u, r = e / C, c = e - r * C;
-    if (e < tot && c < nc) dst[r * RW + c] = v[u];
+    if (e < tot && c < nc) dst[__umul24((unsigned)r, (unsigned)RW) + (unsigned)c] = v[u];
   }
 }
 
@@ -508,11 +510,19 @@ __global__ __launch_bounds__(BLUR_T, MODSX_SR_WGS) void k_sample_rows_lds(const 
   else sample_rows_tile<SR_CW>(bt, jb, im, rowStart, win, cxw, cyw, lane, wave);
   __syncthreads();
   // replicated border: R copies of the first and of the last sample of every row
-  for (int i = threadIdx.x; i < nr * 2 * R; i += BLUR_T) {
-    const int ri = i / (2 * R), k = i - ri * 2 * R;
-    float *rowp = win + ri * RW;
-    if (k < R) rowp[k] = rowp[R];
-    else rowp[P + k] = rowp[R + P - 1];
+  // (2^s >= 2 R lanes per row, 64 >> s rows per wavefront and pass: no division by the run-time 2 R per element)
+  if (R > 0) {
+    const int twoR = 2 * R;
+    int s = 32 - __clz(twoR - 1);
+    s = s > 6 ? 6 : s;
+    const int kl = lane & ((1 << s) - 1), rsub = lane >> s, rpp = 64 >> s;
+    for (int ri = wave * rpp + rsub; ri < nr; ri += BLUR_W * rpp) {
+      float *rowp = win + __umul24((unsigned)ri, (unsigned)RW);
+      for (int k = kl; k < twoR; k += 1 << s) {
+        if (k < R) rowp[k] = rowp[R];
+        else rowp[P + k] = rowp[R + P - 1];
+      }
+    }
   }
   __syncthreads();
   if (jb.ro1 >= 0) { blur_rows_from_lds(bt, win, sneed, taps, dst + bt.dstOfs, NC); return; }
@@ -536,7 +546,7 @@ __device__ __forceinline__ void blur_cols_tile(const BlurTile &bt, float *win, i
   const int P = bt.P, NC = bt.NC;
   const int n = bt.n;
   const int ro0 = bt.first, nro = bt.count, lo = bt.lo, S = bt.span;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();   // (wave-uniform: a parked row's source address is scalar arithmetic)
   for (int i = threadIdx.x; i < NC; i += BLUR_T) sneed[i] = needTab[bt.needOfs + i];
   const float *T = src + bt.srcOfs;   // P x NC
   {   // direct global -> LDS loads, one parked row (64-column chunk) per instruction
@@ -663,25 +673,36 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
     // held the kernel at four wavefronts per SIMD (117 VGPRs) once its LDS allowed five workgroups per CU
     constexpr int HALF_T = PER_T / 2;
     static_assert(PER_T == 2 * HALF_T, "an even number of samples per thread");
+    // Addresses: 32-bit BYTE offsets from the region's (wave-uniform) grid base -- one 24-bit multiply per grid row and an
+    // add + shift per load, the loads in the scalar base + vector offset form (the size_t row products this replaces were
+    // quarter-rate 32-bit multiplies and 64-bit adds: two thirds of the issue slots of the sampling).  An entry that is not valid
+    // has idx0 = idx1 = 0 in the host's table (engine.hip), so every address is inside the grid whatever `valid` says and the
+    // select happens once, on the value.  (r, c) of p = tid + 128 k advance by (3, 5): 128 = 3 * 41 + 5 -- no division per sample.
+    typedef const char __attribute__((address_space(1))) *gbyte_p;
+    const gbyte_p Gb = (gbyte_p)as_global(G);
+    const unsigned NCu = (unsigned)NC;
+    int rs = tid / PS, cs = tid - rs * PS;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       float g00[HALF_T], g01[HALF_T], g10[HALF_T], g11[HALF_T];
+      int rr[HALF_T], cc[HALF_T];
 #pragma unroll
       for (int kk = 0; kk < HALF_T; kk++) {
-        const int p = tid + 128 * (h * HALF_T + kk), pp = p < NPX ? p : NPX - 1;
-        const int r = pp / PS, c = pp - r * PS;
+        const int r = rs < PS ? rs : PS - 1, c = rs < PS ? cs : PS - 1;   // p >= NPX: the last pixel again, not stored
+        rr[kk] = r; cc[kk] = c;
         const int4 mr = smap[r], mc = smap[c];
-        const bool ok = mr.w && mc.w;
-        const float *R0 = G + (size_t)(ok ? mr.x : 0) * NC, *R1 = G + (size_t)(ok ? mr.y : 0) * NC;
-        const int x0 = ok ? mc.x : 0, x1 = ok ? mc.y : 0;
-        g00[kk] = R0[x0]; g01[kk] = R0[x1]; g10[kk] = R1[x0]; g11[kk] = R1[x1];
+        const unsigned o0 = __umul24((unsigned)mr.x, NCu), o1 = __umul24((unsigned)mr.y, NCu);
+        g00[kk] = *(gcfloat_p)(Gb + ((o0 + (unsigned)mc.x) << 2)); g01[kk] = *(gcfloat_p)(Gb + ((o0 + (unsigned)mc.y) << 2));
+        g10[kk] = *(gcfloat_p)(Gb + ((o1 + (unsigned)mc.x) << 2)); g11[kk] = *(gcfloat_p)(Gb + ((o1 + (unsigned)mc.y) << 2));
+        cs += 128 - 3 * PS; rs += 3;     // p += 128
+        if (cs >= PS) { cs -= PS; rs++; }
       }
       if (h == 0) __syncthreads();   // (the direct branch of another region of the workgroup has a barrier here)
 #pragma unroll
       for (int kk = 0; kk < HALF_T; kk++) {
         const int p = tid + 128 * (h * HALF_T + kk);
         if (p < NPX) {
-          const int r = p / PS, c = p - r * PS;
+          const int r = rr[kk], c = cc[kk];
           float v = 0.f;
           if (smap[r].w && smap[c].w) {
             const float wx = sfr[c], wyd = sfr[r];
@@ -851,7 +872,7 @@ __global__ __launch_bounds__(128 * DR) void k_describe(const DescJob *jobs, int 
         const float wc0 = tc.x * val, wc1 = tc.y * val;
         // byte offsets: copy (c & 7), cell (row bin, column bin), slot b0 = bo0 % 8 = bo0 & 7 (o >= 4: ori >= -pi)
         const int ob = (c & 7) * (ACS * 8) + (bo0 & 7) * 8;
-        const int r0 = (pr & 3) * 288, r1 = (pr >> 2) * 288, c0 = (pc & 3) * 72 + ob, c1 = (pc >> 2) * 72 + ob;
+        const int r0 = (pr & 3) * 288, r1 = ((pr >> 2) & 3) * 288, c0 = (pc & 3) * 72 + ob, c1 = ((pc >> 2) & 3) * 72 + ob;   // (& 3: the bins are 0..3 -- a 24-bit multiply to the compiler)
         typedef float v2f __attribute__((ext_vector_type(2)));
         const v2f wcv = {wc0, wc1}, wov = {wo0, wo1};
         const v2f va = wcv * tr.x, vb = wcv * tr.y;                      // (row bin0 | bin1) x (column bin0, bin1)
