@@ -261,7 +261,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="pairs per step per GPU (default 64; 256 for views1, 128 for wxbs)")
     ap.add_argument("--blobs", type=int, default=0, help="blobs per 1024x768 of the synthetic scene (0 = per config)")
     ap.add_argument("--workers", type=int, default=16, help="contexts (thread + stream) per GPU")
-    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs cycled through the batch")
+    ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic pairs cycled through the batch (0 = as many as a step holds: "
+                    "every pair of a step is another pair, as BASELINE.json's configs state them)")
     ap.add_argument("--init-sigma", type=float, default=0.2)
     ap.add_argument("--shard", type=str, default="", choices=["", "pairs", "views"])
     ap.add_argument("--loopback", type=int, default=0, help="one GPU: W in-process ranks of the view-sharded path")
@@ -306,7 +307,7 @@ def main():
     single_view = tilts == "1"
     # a step ends with the verification of its last pairs while the GPU drains: configs[1] (45 ms per 64 pairs) and
     # configs[4] take longer steps so that this tail stays a few per cent of the step
-    batch = args.batch or (128 if wxbs else 256 if single_view else 64)   # (the ladder ran 32 per step until round 4: two pairs per context and step, i.e. the step's tail with most contexts idle was 8 % of it: 46.9 against 51.0 pairs/s)
+    batch = args.batch or (256 if (wxbs or single_view) else 64)   # configs[4]: "batch of 256 random 1920x1080 pairs"   # (the ladder ran 32 per step until round 4: two pairs per context and step, i.e. the step's tail with most contexts idle was 8 % of it: 46.9 against 51.0 pairs/s)
     # blob density of the synthetic scene: 4000 per 1024x768 for configs[1], [3], [4]; 5500 for
     # the multi-view headline so that the 31-view default carries the >= 50 k descriptors per pair the north star is quoted
     # on (the 4000-blob figure of the same configuration is reported under `extra`)
@@ -319,9 +320,19 @@ def main():
     views = mods_amd.set_vs_pars([1.0], [float(t) for t in tilts.split(",")], phi, args.init_sigma, 1, [])
     lsteps = cviu_ladder_steps(mods_amd) if ladder else None
 
-    def make_images(seed0, count, nb):
-        host = [synthetic.make_pair(rows=args.rows, cols=args.cols, nblobs=nb, seed=seed0 + 17 * i) for i in range(max(1, count))]
-        devp = [(ctx.upload(a), ctx.upload(b)) for a, b, _ in host]
+    gen_procs = max(1, min(32, cpu_info()[2]))
+
+    def make_images(seed0, count, nb, keep_host=True):
+        """count distinct pairs: rendered by worker processes into a cache of u8 files (mods_amd/synthetic.py make_pairs), uploaded as
+        f32.  configs[4] takes SURVEY section 8(d) item 5's seeds (1000 + i for image A, 2000 + i for B's noise), the other
+        configurations the seeds of rounds 1-5 (seed0 + 17 i, B: + 42000)."""
+        count = max(1, count)
+        if wxbs:
+            specs = [(args.rows, args.cols, nb, 1000 + i, 2000 + i) for i in range(count)]
+        else:
+            specs = [(args.rows, args.cols, nb, seed0 + 17 * i, seed0 + 17 * i + 42000) for i in range(count)]
+        host = synthetic.make_pairs(specs, procs=gen_procs, as_u8=True)
+        devp = [(ctx.upload(a), ctx.upload(b)) for a, b, _ in host]       # u8 in, f32 on the device (modsx_image_upload)
         return host, devp
 
     # pairs: in the view-sharded mode every rank holds every pair of the (N x larger) batch; otherwise its own pairs
@@ -330,7 +341,10 @@ def main():
         seed0, nbatch = 12345, batch * views_world
     else:
         seed0, nbatch = 12345 + 1000 * rank, batch
-    pairs_host, dev = make_images(seed0, args.distinct, nblobs)
+    t_gen = time.perf_counter()
+    distinct = args.distinct or nbatch
+    pairs_host, dev = make_images(seed0, distinct, nblobs)
+    t_gen = time.perf_counter() - t_gen
     Hgt = pairs_host[0][2]
     imgs1 = [dev[i % len(dev)][0] for i in range(nbatch)]
     imgs2 = [dev[i % len(dev)][1] for i in range(nbatch)]
@@ -452,6 +466,61 @@ def main():
                         "note": "the same K steps with a host-side barrier after every step (rounds 1-4 reported this form)"}
     res = next((r for r in results if r is not None), None)
     verify_timed = mods_amd.last_batch_verify() if single_view else None   # host share of the last batch of the timed region
+    verify_each_h = mods_amd.last_batch_verify_each() if single_view else None   # per pair, last step of the timed region
+
+    # ---- the same steps with every pair's images handed over as HOST buffers (the reference loads a pair per iteration, mods.cpp:117-127):
+    # `value` is measured with the images resident in HBM; this is the PCIe-inclusive figure beside it.  u8 grey images, as cv::imread
+    # delivers them: modsx_image_update refills the two images a context keeps (no allocation per pair), the device converts to f32.
+    upload_form = None
+    if rank == 0 and group is None and lsteps is None and not os.environ.get("MODSX_BENCH_NO_UPLOAD_LEG"):
+        nst = max(1, min(args.steps, 3))
+        n = len(imgs1)
+        hostA = [pairs_host[i % len(pairs_host)][0] for i in range(n)]
+        hostB = [pairs_host[i % len(pairs_host)][1] for i in range(n)]
+        up_s = [0.0]
+        if single_view:
+            # the batch API takes device images: the step's pairs are uploaded (one allocation + copy each), matched, freed
+            barrier(group)
+            tu0 = time.perf_counter()
+            for _ in range(nst):
+                tu = time.perf_counter()
+                d1 = [ctx.upload(a_) for a_ in hostA]
+                d2 = [ctx.upload(b_) for b_ in hostB]
+                up_s[0] += time.perf_counter() - tu
+                mods_amd.match_pairs(ctxs, d1, d2, params)
+                for im_ in d1 + d2:
+                    im_.free()
+            barrier(group)
+            du = time.perf_counter() - tu0
+            note = "every step uploads its pairs (modsx_image_upload: allocation + H2D + conversion, one stream), then matches them: the upload is not overlapped"
+        else:
+            slots = [(c.upload(hostA[0]), c.upload(hostB[0])) for c in ctxs]
+            nxt = itertools.count()
+            lock = threading.Lock()
+
+            def work_up(w):
+                t_up = 0.0
+                sa, sb = slots[w]
+                while True:
+                    with lock:
+                        k = next(nxt)
+                    if k >= nst * n:
+                        return t_up
+                    tu = time.perf_counter()
+                    sa.update(hostA[k % n]); sb.update(hostB[k % n])
+                    t_up += time.perf_counter() - tu
+                    ctxs[w].match_pair_views(sa, sb, views, params)
+            barrier(group)
+            tu0 = time.perf_counter()
+            up_s[0] = sum(pool.map(work_up, range(len(ctxs))))
+            barrier(group)
+            du = time.perf_counter() - tu0
+            for sa, sb in slots:
+                sa.free(); sb.free()
+            note = ("every context refills its two images from host buffers before each pair (modsx_image_update on its own stream: H2D + "
+                    "conversion, overlapped with the other contexts' kernels)")
+        upload_form = {"value": nst * n / du, "unit": "image-pairs/s", "steps": nst, "upload_ms_per_pair": 1e3 * up_s[0] / (nst * n),
+                       "bytes_per_pair": int(hostA[0].nbytes + hostB[0].nbytes), "note": note}
     wxbs_f = None
     if wxbs and rank == 0 and group is None:
         # configs[4] with epipolar verification: measured HERE, before any leg that brackets launches with timing events -- once a
@@ -471,6 +540,7 @@ def main():
         ruF1 = resource.getrusage(resource.RUSAGE_SELF)
         cpuF = (ruF1.ru_utime - ruF0.ru_utime) + (ruF1.ru_stime - ruF0.ru_stime)
         fms, fn, fth = mods_amd.last_batch_verify()
+        veF = mods_amd.last_batch_verify_each()      # every pair of that call (stF steps of distinct pairs)
         vst = mods_amd.verify_device_stats()
         import ctypes as _C
         cw, ch = _C.c_double(), _C.c_double()
@@ -479,7 +549,7 @@ def main():
         for _ in range(stF):
             mods_amd.match_pairs(ctxs, imgs1, imgs2, pF)
         dtFstep = time.perf_counter() - tb
-        wxbs_f = (fms, fn, fth, vst, cw, ch, dtF, dtFstep, cpuF, ruF0, ruF1, rF, stF)
+        wxbs_f = (fms, fn, fth, vst, cw, ch, dtF, dtFstep, cpuF, ruF0, ruF1, rF, stF, veF)
     ladder_parts = {}
     if ladder and rank == 0 and group is None:
         # the MSER steps alone and the HessianAffine steps alone: the former are short of host CPU, so they too are measured before the
@@ -540,7 +610,7 @@ def main():
                 if os.environ.get("MODSX_BENCH_CRASH_IN_VIEWS"):   # test hook for the guard above
                     import signal
                     os.kill(os.getpid(), signal.SIGSEGV)
-                vhost, vdev = make_images(12345, args.distinct, nblobs)       # every rank holds every pair
+                vhost, vdev = make_images(12345, args.distinct or batch * world, nblobs)       # every rank holds every pair
                 nb_v = batch * world
                 v1 = [vdev[i % len(vdev)][0] for i in range(nb_v)]
                 v2 = [vdev[i % len(vdev)][1] for i in range(nb_v)]
@@ -662,11 +732,24 @@ def main():
                              "a host-side barrier after every step"
         if barrier_form is not None:
             out["value_with_step_barrier"] = barrier_form
+        out["upload_in_timed_region"] = False      # inputs are resident in HBM when the timed region starts (the bench contract)
+        if upload_form is not None:
+            out["value_with_upload"] = upload_form
+        out["config"]["image_generation_s"] = round(t_gen, 2)
         if host_cpu.get("s") is not None:
             # rank 0's own threads (workers, verification helpers, host pool) over its share of the timed pairs: on a node where N ranks
             # share one host, N times this figure per second of throughput is what the host has to supply
             out["host_cpu_s_per_pair_rank0"] = host_cpu_headline / max(1, args.steps * nbatch)
-            out["host_threads"] = {"cpu_allowance": cpu_info()[2], "local_ranks": int(os.environ.get("LOCAL_WORLD_SIZE", "1"))}
+            allowance, lranks = cpu_info()[2], int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+            out["host_threads"] = {"cpu_allowance": allowance, "local_ranks": lranks}
+            # what the host can feed: the node's CPU allowance over the CPU-seconds a pair costs a rank's threads.  With N ranks on one
+            # host the allowance is shared: host_limited says that the measured (or, at N = 1, the N-fold) throughput is at that bound
+            hb = allowance / max(out["host_cpu_s_per_pair_rank0"], 1e-9)
+            out["host_bound_pairs_per_s"] = hb
+            out["host_limited"] = bool(value >= 0.9 * hb)
+            out["host_bound_note"] = ("cpu_allowance / host_cpu_s_per_pair_rank0 for the whole node: %d CPUs feed at most %.0f pairs/s of this workload, "
+                                      "i.e. %.1f GPUs at this run's per-GPU rate; host_limited = the job's value is within 10 %% of that bound"
+                                      % (allowance, hb, hb / max(value / max(1, world), 1e-9)))
         if group is not None:
             out["rccl"] = group.describe()
         if scaling_views is not None:
@@ -765,11 +848,16 @@ def main():
             # H verification was the timed region; the same batch with epipolar verification, and the host share of both
             vms, vn, vth = verify_timed
             hshare = {"verify_ms_per_pair": vms / max(1, vn), "helper_threads": vth}
-            (fms, fn, fth, vst, cw, ch, dtF, dtFstep, cpuF, ruF0, ruF1, rF, stF) = wxbs_f
+            (fms, fn, fth, vst, cw, ch, dtF, dtFstep, cpuF, ruF0, ruF1, rF, stF, veF) = wxbs_f
+            def _mmm(x):
+                x = np.sort(np.asarray(x, float))
+                return {"min": float(x[0]), "median": float(x[len(x) // 2]), "max": float(x[-1]), "pairs": int(len(x))} if len(x) else None
+            hshare["verify_ms_per_pair_min_median_max"] = _mmm(verify_each_h)
             out["wxbs"] = {
                 "H": {"pairs_per_s": value, **hshare,
                       "host_ransac_share_of_wall": (vms / max(1, vn)) / max(1, vth) / (1e3 / value) * 1.0},
                 "F": {"pairs_per_s": stF * nbatch / dtF, "pairs_per_s_one_call_per_step": stF * nbatch / dtFstep, "verify_ms_per_pair": fms / max(1, fn), "helper_threads": fth,
+                      "verify_ms_per_pair_min_median_max": _mmm(veF),
                       "verified_last_pair": rF[0]["n_verified"], "host_cpu_s_per_pair": cpuF / (stF * nbatch),
                       "host_cores_busy": cpuF / dtF, "cpu_s_per_pair_context_threads": cw.value / (stF * nbatch),
                       "cpu_s_per_pair_verification_helpers": ch.value / (stF * nbatch), "host_cpu_system_share": (ruF1.ru_stime - ruF0.ru_stime) / max(cpuF, 1e-9),
@@ -814,7 +902,7 @@ def main():
                                "descriptors_per_s": nd / el, "blobs_per_1024x768": blobs}
             if not args.blobs and not single_view:
                 # the scene of SURVEY section 8(d) item 2 (4000 blobs per 1024x768) under the headline's view ladder
-                h4, d4 = make_images(12345, args.distinct, int(4000 * args.rows * args.cols / (768.0 * 1024)))
+                h4, d4 = make_images(12345, distinct, int(4000 * args.rows * args.cols / (768.0 * 1024)))
                 i1 = [d4[i % len(d4)][0] for i in range(nbatch)]
                 i2 = [d4[i % len(d4)][1] for i in range(nbatch)]
                 el, nd, _ = timed(lambda: run_batch(views, False, i1, i2), 1, 3)
@@ -824,7 +912,7 @@ def main():
                     a_.free(); b_.free()
                 # configs[2] with a scene dense enough that the per-view costs (synthesis, pyramid) are amortised over more regions:
                 # 8 views, 16000 blobs per 1024x768 -- the configuration in which the path delivers its most descriptors per second
-                h8, d8 = make_images(12345, args.distinct, int(16000 * args.rows * args.cols / (768.0 * 1024)))
+                h8, d8 = make_images(12345, min(distinct, 64), int(16000 * args.rows * args.cols / (768.0 * 1024)))
                 tl, ph, _ = CONFIGS["views8"]
                 vw = mods_amd.set_vs_pars([1.0], [float(t) for t in tl.split(",")], ph, args.init_sigma, 1, [])
                 i1 = [d8[i % len(d8)][0] for i in range(64)]
@@ -836,7 +924,7 @@ def main():
                 # views of the headline -- what the per-view costs (view synthesis, pyramid: ~22 % of the headline's kernel time) weigh
                 for a_, b_ in d8:
                     a_.free(); b_.free()
-                h16, d16 = make_images(12345, args.distinct, int(20000 * args.rows * args.cols / (768.0 * 1024)))
+                h16, d16 = make_images(12345, min(distinct, 64), int(20000 * args.rows * args.cols / (768.0 * 1024)))
                 vw16 = mods_amd.set_vs_pars([1.0], [1.0, 2.0, 3.0, 4.0, 6.0], 180.0, args.init_sigma, 1, [])
                 i1 = [d16[i % len(d16)][0] for i in range(64)]
                 i2 = [d16[i % len(d16)][1] for i in range(64)]
@@ -850,7 +938,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not wxbs and not ladder and group is None:
             from oracle import pyoracle as O
             model, ncpu, usable = cpu_info()
-            a, b, _ = pairs_host[0]
+            a, b = pairs_host[0][0].astype(np.float32), pairs_host[0][1].astype(np.float32)
             vo = O.set_vs_pars([1.0], [float(t) for t in tilts.split(",")], phi, args.init_sigma, 1, [])
             O.detect_describe_views(a[:64, :64].copy(), vo[:1])     # lazy tables (single-threaded once)
             full = oracle_pair_views(O, a, b, vo, params, threads=usable, seed=1)

@@ -181,6 +181,9 @@ void modsx_default_pair_params(modsx_pair_params *p);
  * (identity view: out_img.pixels = gray, :278-289). */
 /* images are limited to 16384 px per side and 64 Mpx (32-bit pixel addressing in the samplers); larger ones are refused */
 modsx_image *modsx_image_upload(modsx_ctx *ctx, const void *pixels, int rows, int cols, int channels, int dtype);
+/* new pixels for an image made by modsx_image_upload, same size: no allocation (a caller that streams pairs through a context
+ * keeps two images per context and refills them).  Synchronous like the upload: the buffer is the caller's again on return. */
+int modsx_image_update(modsx_ctx *ctx, modsx_image *img, const void *pixels, int rows, int cols, int channels, int dtype);
 /* wrap pixels that already live in HBM (f32, 1 channel, dense rows); not owned */
 modsx_image *modsx_image_wrap_device(modsx_ctx *ctx, const float *dev_pixels, int rows, int cols);
 void modsx_image_free(modsx_ctx *ctx, modsx_image *img);

@@ -85,7 +85,7 @@ class PairResult(C.Structure):
 
 
 EXPORTS = ["modsx_version", "modsx_last_error", "modsx_free", "modsx_create", "modsx_destroy", "modsx_synchronize",
-           "modsx_default_hessaff_params", "modsx_default_pair_params", "modsx_image_upload",
+           "modsx_default_hessaff_params", "modsx_default_pair_params", "modsx_image_upload", "modsx_image_update",
            "modsx_image_wrap_device", "modsx_image_free", "modsx_image_download", "modsx_detect_affine_keypoints",
            "modsx_detect_scalespace", "modsx_octave_levels", "modsx_gaussian_blur", "modsx_resize_half", "modsx_response",
            "modsx_detect_affine_regions", "modsx_detect_orientation", "modsx_reproject_regions", "modsx_reproject_regions_touch_boundary",
@@ -150,6 +150,8 @@ def lib():
         L.modsx_free.argtypes = [C.c_void_p]
         L.modsx_image_upload.restype = C.c_void_p
         L.modsx_image_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.modsx_image_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.modsx_debug_last_batch_verify_each.argtypes = [C.c_void_p, C.c_int]
         L.modsx_image_wrap_device.restype = C.c_void_p
         L.modsx_image_wrap_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.modsx_image_free.argtypes = [C.c_void_p, C.c_void_p]
@@ -384,6 +386,15 @@ class Image(object):
         if self.h:
             lib().modsx_image_free(self.ctx.h, self.h)
             self.h = None
+
+    def update(self, pixels):
+        """modsx_image_update: new pixels (u8 or f32, 1 or 3 channels) for this uploaded image, same size, no allocation."""
+        a = np.ascontiguousarray(pixels)
+        if a.dtype != np.uint8:
+            a = np.ascontiguousarray(a, np.float32)
+        ch = 1 if a.ndim == 2 else a.shape[2]
+        _check(lib().modsx_image_update(C.c_void_p(self.ctx.h), C.c_void_p(self.h), _p(a), a.shape[0], a.shape[1], ch,
+                                        0 if a.dtype == np.uint8 else 1), "image_update")
 
     def download(self):
         out = np.empty((self.rows, self.cols), np.float32)
@@ -674,6 +685,14 @@ class Context(object):
 
 class _ImageStruct(C.Structure):   # mirrors struct modsx_image (engine.hpp) for reading rows/cols of a handle
     _fields_ = [("d", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("owned", C.c_bool)]
+
+
+def last_batch_verify_each():
+    """Verification time in ms of every pair of the last batch call (completion order)."""
+    n = lib().modsx_debug_last_batch_verify_each(None, 0)
+    out = np.zeros(max(n, 1), np.float64)
+    n = min(n, lib().modsx_debug_last_batch_verify_each(_p(out), len(out)))
+    return out[:n]
 
 
 def last_batch_verify():

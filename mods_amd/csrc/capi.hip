@@ -27,6 +27,9 @@ static T *to_malloc(const std::vector<T> &v) {
 // the number of helper threads that ran them
 static std::atomic<long> g_verifyUs(0);
 static std::atomic<int> g_verifyThreads(0), g_verifyPairs(0);
+static std::mutex g_verifyEachMu;
+static std::vector<int> g_verifyEachUs;    // verification time of every pair of the last batch call, in completion order
+static void verify_timed(mx::VerifyTask &t, const modsx_pair_params &pp);
 // CPU time (not wall) of the last batch call, by kind of thread: the contexts' own threads and the verification helpers
 static std::atomic<long> g_cpuWorkerUs(0), g_cpuHelperUs(0);
 // helper threads of a batch call: one per working context unless MODSX_VERIFY_HELPERS says otherwise
@@ -142,6 +145,22 @@ modsx_image *modsx_image_upload(modsx_ctx *ctx, const void *pixels, int rows, in
   launch_gray(ctx->stream, ctx->misc.p, im->d, n, channels, dtype);
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) { mx::set_error("image upload sync failed"); hipFree(im->d); delete im; return nullptr; }
   return im;
+}
+
+int modsx_image_update(modsx_ctx *ctx, modsx_image *im, const void *pixels, int rows, int cols, int channels, int dtype) {
+  NEED(ctx); NEED(im); NEED(pixels);
+  if ((channels != 1 && channels != 3) || (dtype != 0 && dtype != 1) || !im->owned || rows != im->rows || cols != im->cols) {
+    mx::set_error("modsx_image_update: bad argument (the image must be an uploaded one of the same size)");
+    return MODSX_ERR_ARG;
+  }
+  hipSetDevice(ctx->dev);
+  const size_t n = (size_t)rows * cols, inBytes = n * channels * (dtype == 0 ? 1 : 4);
+  if (!ctx->misc.ensure(inBytes)) return MODSX_ERR_NOMEM;
+  if (hipMemcpyAsync(ctx->misc.p, pixels, inBytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { mx::set_error("image H2D copy failed"); return MODSX_ERR_DEVICE; }
+  launch_gray(ctx->stream, ctx->misc.p, im->d, n, channels, dtype);
+  // the caller's buffer is its own again on return (a copy from pageable memory is staged by the runtime; this wait also covers pinned sources)
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) { mx::set_error("image update sync failed"); return MODSX_ERR_DEVICE; }
+  return MODSX_OK;
 }
 
 modsx_image *modsx_image_wrap_device(modsx_ctx *ctx, const float *dev_pixels, int rows, int cols) {
@@ -425,6 +444,22 @@ int modsx_loransac_h_errtype(const double *pts, const double *laf1, const double
                     seed, H, Hraw, inl, keep, data_out, error_type);
 }
 
+static void verify_timed(mx::VerifyTask &t, const modsx_pair_params &pp) {
+  const auto v0 = std::chrono::steady_clock::now();
+  mx::verify_tentatives(t.l1, t.l2, t.tents, pp, t.res);
+  const long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - v0).count();
+  g_verifyUs += us;
+  g_verifyPairs++;
+  std::lock_guard<std::mutex> lk(g_verifyEachMu);
+  g_verifyEachUs.push_back((int)us);
+}
+// the caller's current HIP device is its own: worker(0) of the batch calls runs on the caller's thread and sets the contexts'
+struct DeviceGuard {
+  int dev = -1;
+  DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+  ~DeviceGuard() { if (dev >= 0) hipSetDevice(dev); }
+};
+
 int modsx_match_pair(modsx_ctx *ctx, const modsx_image *img1, const modsx_image *img2, const modsx_pair_params *par,
                      modsx_pair_result *res) {
   NEED(ctx); NEED(img1); NEED(img2); NEED(par); NEED(res);
@@ -469,10 +504,7 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
         vq.q.pop_front();
       }
       hipSetDevice(t.dev);     // a new thread starts on device 0: the verifier's device-side loops belong on the producing context's GPU
-      const auto v0 = std::chrono::steady_clock::now();
-      mx::verify_tentatives(t.l1, t.l2, t.tents, pp, t.res);
-      g_verifyUs += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - v0).count();
-      g_verifyPairs++;
+      verify_timed(t, pp);
     }
   };
   auto worker = [&](int w) {
@@ -507,16 +539,15 @@ int modsx_match_pairs(modsx_ctx *const *ctxs, int n_ctx, const modsx_image *cons
         vq.q.pop_front();
       }
       hipSetDevice(t.dev);
-      const auto v0 = std::chrono::steady_clock::now();
-      mx::verify_tentatives(t.l1, t.l2, t.tents, pp, t.res);
-      g_verifyUs += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - v0).count();
-      g_verifyPairs++;
+      verify_timed(t, pp);
     }
   };
   std::vector<std::thread> th, hth;
   const int ngroups = (n_pairs + group - 1) / group;
   const int nw = n_ctx < ngroups ? n_ctx : ngroups;
   g_verifyUs = 0; g_verifyPairs = 0; g_verifyThreads = nw; g_cpuWorkerUs = 0; g_cpuHelperUs = 0;
+  { std::lock_guard<std::mutex> lk(g_verifyEachMu); g_verifyEachUs.clear(); }
+  DeviceGuard restoreCallerDevice;
   for (int w = 0; w < verify_helpers(nw); w++) hth.emplace_back(helper);
   for (int w = 1; w < nw; w++) th.emplace_back(worker, w);
   if (nw > 0) worker(0);
@@ -570,10 +601,7 @@ int modsx_match_pairs_views(modsx_ctx *const *ctxs, int n_ctx, const modsx_image
         vq.q.pop_front();
       }
       hipSetDevice(t.dev);     // a new thread starts on device 0: the verifier's device-side loops belong on the producing context's GPU
-      const auto v0 = std::chrono::steady_clock::now();
-      mx::verify_tentatives(t.l1, t.l2, t.tents, pp, t.res);
-      g_verifyUs += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - v0).count();
-      g_verifyPairs++;
+      verify_timed(t, pp);
     }
   };
   auto worker = [&](int w) {
@@ -603,15 +631,14 @@ int modsx_match_pairs_views(modsx_ctx *const *ctxs, int n_ctx, const modsx_image
         vq.q.pop_front();
       }
       hipSetDevice(t.dev);
-      const auto v0 = std::chrono::steady_clock::now();
-      mx::verify_tentatives(t.l1, t.l2, t.tents, pp, t.res);
-      g_verifyUs += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - v0).count();
-      g_verifyPairs++;
+      verify_timed(t, pp);
     }
   };
   std::vector<std::thread> th, hth;
   const int nw = n_ctx < n_pairs ? n_ctx : n_pairs;
   g_verifyUs = 0; g_verifyPairs = 0; g_verifyThreads = nw; g_cpuWorkerUs = 0; g_cpuHelperUs = 0;
+  { std::lock_guard<std::mutex> lk(g_verifyEachMu); g_verifyEachUs.clear(); }
+  DeviceGuard restoreCallerDevice;
   for (int w = 0; w < verify_helpers(nw); w++) hth.emplace_back(helper);
   for (int w = 1; w < nw; w++) th.emplace_back(worker, w);
   if (nw > 0) worker(0);
@@ -638,6 +665,14 @@ int modsx_last_batch_verify(double *sum_ms, int *pairs, int *threads) {
   if (pairs) *pairs = g_verifyPairs.load();
   if (threads) *threads = g_verifyThreads.load();
   return MODSX_OK;
+}
+
+// verification time (DuplicateFiltering + LO-RANSAC + the LAF checks, wall of the verifying thread) of every pair of the last batch call
+extern "C" __attribute__((visibility("default"))) int modsx_debug_last_batch_verify_each(double *ms, int cap) {
+  std::lock_guard<std::mutex> lk(g_verifyEachMu);
+  const int n = (int)g_verifyEachUs.size();
+  for (int i = 0; i < n && i < cap; i++) ms[i] = g_verifyEachUs[i] / 1000.0;
+  return n;
 }
 
 // CPU seconds (thread CPU clocks, not wall) the last batch call spent in the contexts' own threads and in its verification helpers

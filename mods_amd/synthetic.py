@@ -64,3 +64,81 @@ def make_pair(rows=768, cols=1024, nblobs=4000, seed=12345, H=None):
     a = blob_image(rows, cols, nblobs, seed)
     b = warp_homography(a, H, seed=seed + 42000)
     return a, b, H
+
+
+# ---- many pairs at once: a cache of generated images + worker processes ---------------------------------------------------------
+# bench.py runs every configuration on as many DISTINCT pairs as a step holds (64 at 1024x768, 256 at 1920x1080 for configs[4]);
+# the blob renderer above is a python loop (~1 s per 1024x768 pair on the GPU box's host cores), so the pairs are rendered by worker
+# processes and kept as u8 files (the images are floored and clipped: integers 0..255, so u8 is exact) under a cache directory that
+# later runs on the same box reuse.  spec = (rows, cols, nblobs, seed_a, seed_b): image A = blob_image(seed_a), image B = A warped by
+# H_DEFAULT with noise seed seed_b -- make_pair(seed) is the spec (.., seed, seed + 42000).
+def _cache_dir():
+    import os
+    d = os.environ.get("MODSX_SYNTH_CACHE", "/tmp/modsx_synth_cache")
+    try:
+        os.makedirs(d, exist_ok=True)
+        return d if os.access(d, os.W_OK) else None
+    except OSError:
+        return None
+
+
+def _spec_path(d, spec):
+    import os
+    return os.path.join(d, "pair_%dx%d_b%d_a%d_b%d.npy" % tuple(spec))
+
+
+def _render(spec):
+    rows, cols, nblobs, sa, sb = spec
+    a = blob_image(rows, cols, nblobs, sa)
+    b = warp_homography(a, H_DEFAULT, seed=sb)
+    return np.stack([a, b]).astype(np.uint8)
+
+
+def _render_to_cache(d, spec):
+    import os
+    path = _spec_path(d, spec)
+    tmp = path + ".tmp%d.npy" % os.getpid()
+    np.save(tmp, _render(spec))
+    os.replace(tmp, path)
+
+
+def make_pairs(specs, procs=1, as_u8=False):
+    """-> [(a, b, H)] for specs = [(rows, cols, nblobs, seed_a, seed_b)], f32 images (u8 with as_u8) -- the arrays make_pair gives."""
+    import os
+    import subprocess
+    import sys
+    import json
+    specs = [tuple(int(x) for x in s) for s in specs]
+    d = _cache_dir()
+    out = {}
+    if d is not None:
+        missing = [s for s in dict.fromkeys(specs) if not os.path.exists(_spec_path(d, s))]
+        procs = max(1, min(int(procs), len(missing)))
+        if missing and procs > 1:
+            children = [subprocess.Popen([sys.executable, os.path.abspath(__file__), d, json.dumps(missing[i::procs])],
+                                         env=dict(os.environ, OMP_NUM_THREADS="1")) for i in range(procs)]
+            for c in children:
+                c.wait()
+        for s in dict.fromkeys(specs):
+            path = _spec_path(d, s)
+            if not os.path.exists(path):
+                _render_to_cache(d, s)      # one process, or a child that failed
+            try:
+                out[s] = np.load(path)
+            except (OSError, ValueError):
+                out[s] = _render(s)
+    else:
+        for s in dict.fromkeys(specs):
+            out[s] = _render(s)
+    res = []
+    for s in specs:
+        ab = out[s]
+        res.append((ab[0], ab[1], H_DEFAULT) if as_u8 else (ab[0].astype(np.float32), ab[1].astype(np.float32), H_DEFAULT))
+    return res
+
+
+if __name__ == "__main__":      # worker: synthetic.py <cache dir> <json list of specs>
+    import json
+    import sys
+    for _s in json.loads(sys.argv[2]):
+        _render_to_cache(sys.argv[1], tuple(_s))

@@ -76,9 +76,37 @@ def run_problem(p, mods=None, oracle=None, device=False):
             if (Ma * Mb).sum() < 0:
                 Mb = -Mb
             d = float(np.abs(Ma - Mb).max())
-    return dict(name=name_of(p), same=bool(same), n_ref=int(a["n"]), n_here=int(b["n"]), samples_ref=int(a["samples"]),
+    return dict(name=name_of(p), same=bool(same), sig_ref=_sig(a), sig_here=_sig(b), n_ref=int(a["n"]), n_here=int(b["n"]), samples_ref=int(a["samples"]),
                 samples_here=int(b["samples"]), inl_diff=int(np.count_nonzero(np.asarray(a["inl"]) != np.asarray(b["inl"]))), d=d,
                 kind=p["kind"], size=p["size"])
+
+
+def _sig(r):
+    import hashlib
+    return hashlib.md5(np.asarray(r["inl"], np.uint8).tobytes() + np.asarray(r["keep"], np.uint8).tobytes()
+                       + np.asarray([r["n"], r["samples"], r["lo_count"]], np.int64).tobytes()).hexdigest()[:12]
+
+
+def reference_signatures(p, tries=6):
+    """The reference's result on ONE problem from `tries` fresh processes.  The reference is not reproducible on every problem: its
+    least-squares refits go through LAPACK's dsyev_ (scipy's OpenBLAS here), whose kernels depend on where the process' buffers
+    happen to lie, and on a near-degenerate problem the last bits of a null vector decide which of two near-tied inlier sets wins
+    (e.g. sweep 4 case 1051, F small: 8 kept inliers in two of six processes, none in the other four).  libmodsx's host code is
+    reproducible (fixed summation orders, its own eigen-solver).  -> the set of distinct signatures."""
+    import json
+    import subprocess
+    import tempfile
+    f = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
+    json.dump([p], f); f.close()
+    sigs = set()
+    try:
+        for _ in range(tries):
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), f.name], stdout=subprocess.PIPE, check=True,
+                                 env=dict(os.environ, OMP_NUM_THREADS="1")).stdout
+            sigs.add(json.loads(out.decode().strip().splitlines()[-1])[0]["sig_ref"])
+    finally:
+        os.unlink(f.name)
+    return sigs
 
 
 def _worker(ps):
@@ -86,17 +114,39 @@ def _worker(ps):
 
 
 def run_parallel(ps, procs):
-    """The reference's degensac keeps process-global state (HASH_TABLE, the libc PRNG), so the sweep is spread over PROCESSES
-    (spawned: nothing of the parent -- HIP runtime, OpenMP pools -- is inherited)."""
+    """The reference's degensac keeps process-global state (HASH_TABLE, the libc PRNG), so the sweep is spread over PROCESSES:
+    `python tests/ransac_sweep.py <problems.json>` children (nothing of the parent -- HIP runtime, OpenMP pools -- is inherited),
+    each printing its results as one JSON line."""
     if procs <= 1 or len(ps) < 8:
         return _worker(ps)
-    import multiprocessing as mp
-    ctx = mp.get_context("spawn")
+    import json
+    import subprocess
+    import tempfile
     chunks = [ps[i::procs] for i in range(procs)]       # interleaved: the mid-size problems are the expensive ones
-    with ctx.Pool(procs) as pool:
-        parts = pool.map(_worker, chunks)
+    files, children = [], []
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for ch in chunks:
+        f = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)
+        json.dump(ch, f); f.close()
+        files.append(f.name)
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), f.name], stdout=subprocess.PIPE, env=env))
     by_name = {}
-    for part in parts:
-        for r in part:
-            by_name[r["name"]] = r
+    try:
+        for c in children:
+            out, _ = c.communicate()
+            if c.returncode != 0:
+                raise RuntimeError("a sweep child failed (exit code %d)" % c.returncode)
+            for r in json.loads(out.decode().strip().splitlines()[-1]):
+                by_name[r["name"]] = r
+    finally:
+        for c in children:
+            if c.poll() is None:
+                c.kill()
+        for f in files:
+            os.unlink(f)
     return [by_name[name_of(p)] for p in ps]
+
+
+if __name__ == "__main__":
+    import json
+    print(json.dumps(_worker(json.load(open(sys.argv[1])))))

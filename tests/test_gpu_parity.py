@@ -525,10 +525,10 @@ def test_cat_pair_every_stage_field_by_field(ctx, modsx, oracle, cat_pair):
     got = ctx.match_pair_views(i1, i2, vm, par)
     assert got["n_tentatives"] == len(tent)
     _check_tents(got["tentatives"], tent[order[keep]])
-    if oracle.ref_available():
-        tu, pu = tent[order[keep]], pts[order[keep]]
-        rr = oracle.loransac_h(pu, laf_of(r1, tu["q"]), laf_of(r2, tu["t0"]), seed=3)
-        assert np.array_equal(got["ransac_inlier"], rr["inl"]) and np.array_equal(got["verified"], rr["keep"])
+    need_ref(oracle)
+    tu, pu = tent[order[keep]], pts[order[keep]]
+    rr = oracle.loransac_h(pu, laf_of(r1, tu["q"]), laf_of(r2, tu["t0"]), seed=3)
+    assert np.array_equal(got["ransac_inlier"], rr["inl"]) and np.array_equal(got["verified"], rr["keep"])
     i1.free(); i2.free()
 
 

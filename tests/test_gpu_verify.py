@@ -78,3 +78,22 @@ def test_every_device_count_of_a_batch_equals_the_host_count(modsx, oracle, ctx,
         _same(a, b)
     st = modsx.verify_device_stats()
     assert st["disagreements"] == 0 and st["hypotheses"] > 20000, st
+
+
+def test_sweep_f_problems_with_the_device_counted_loop(modsx, oracle, ctx):
+    """The -m gpu twin of tests/test_ransac_sweep_cpu.py: the F problems of two sweeps (8-2400 correspondences, a quarter planar) with a
+    device present, i.e. rFtH's hypothesis counting on k_rfth_count wherever the loop goes quiet -- same allowances (the one KNOWN
+    problem, problems on which the reference disagrees with itself between processes), plus the counter-example of the unsafe
+    eigen-solver rule."""
+    need_ref(oracle)
+    import ransac_sweep as S
+    from test_ransac_sweep_cpu import _check, RULE1_COUNTER_EXAMPLES
+    modsx.verify_device_stats(reset=True)
+    ps = [p for p in S.problems(60, 7) if p["kind"] == "F"] + [p for p in S.problems(160, 4) if p["kind"] == "F" and p["planar"] >= 0.5]
+    for seed0, case, kind, size in RULE1_COUNTER_EXAMPLES:
+        ps += [p for p in S.problems(case + 1, seed0) if (p["case"], p["kind"], p["size"]) == (case, kind, size)]
+    assert len(ps) >= 250
+    rs = [S.run_problem(p, mods=modsx, oracle=oracle) for p in ps]
+    _check(ps, rs)
+    st = modsx.verify_device_stats()
+    assert st["disagreements"] == 0 and st["batches"] > 0 and st["hypotheses"] > 10000, st
