@@ -13,6 +13,8 @@
 #include <map>
 #include <unordered_set>
 #include <mutex>
+#include <dlfcn.h>
+#include <string>
 #include "engine_api.hpp"
 
 #ifdef MODSX_DUP_BUILD
@@ -576,6 +578,30 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
   // host cores that are otherwise idle and overlap the other contexts' device work.
   static const bool deviceOrder = getenv("MODSX_DEVICE_ORDER") != nullptr && atoi(getenv("MODSX_DEVICE_ORDER")) != 0;
   if (deviceOrder) {
+    // the opt-in path lives in libmodsx_cand.so beside this library (kernels_cand.hip), loaded on first use
+    typedef size_t (*temp_fn)(unsigned);
+    typedef int (*order_fn)(hipStream_t, const Candidate *, const unsigned *, unsigned, unsigned long long *, unsigned long long *, unsigned *, unsigned *,
+                            void *, size_t, unsigned long long *, unsigned *, unsigned, unsigned *, Candidate *, unsigned *);
+    static temp_fn cand_sort_temp_bytes = nullptr;
+    static order_fn launch_cand_order = nullptr;
+    static std::once_flag candOnce;
+    std::call_once(candOnce, [] {
+      Dl_info di;
+      std::string path = "libmodsx_cand.so";
+      if (dladdr((const void *)&modsx_create, &di) && di.dli_fname) {
+        const std::string self(di.dli_fname);
+        const size_t sl = self.rfind('/');
+        if (sl != std::string::npos) path = self.substr(0, sl + 1) + "libmodsx_cand.so";
+      }
+      if (void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL)) {
+        cand_sort_temp_bytes = (temp_fn)dlsym(h, "modsx_cand_sort_temp_bytes");
+        launch_cand_order = (order_fn)dlsym(h, "modsx_cand_order");
+      }
+    });
+    if (!cand_sort_temp_bytes || !launch_cand_order) {
+      set_error("MODSX_DEVICE_ORDER=1, but libmodsx_cand.so (make -C mods_amd/csrc cand) is not beside libmodsx.so");
+      return MODSX_ERR_DEVICE;
+    }
     if (!c->hMisc.ensure(64)) return MODSX_ERR_NOMEM;
     for (int attempt = 0;; attempt++) {
       // the sort runs over a host-chosen capacity (the device-side count is not known here): what the context's last set had

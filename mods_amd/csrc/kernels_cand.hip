@@ -97,3 +97,15 @@ int launch_cand_order(hipStream_t s, const Candidate *cand, const unsigned *coun
 }
 
 }  // namespace mx
+
+// The device-side order is an opt-in path (MODSX_DEVICE_ORDER=1) that measured 9 % slower than the host's order, and its rocPRIM
+// radix / merge sort instantiations are 2.4 MB of code objects: it is built as a library of its own (libmodsx_cand.so, next to
+// libmodsx.so) that engine.hip loads on first use, so the product library does not carry it.
+extern "C" __attribute__((visibility("default"))) size_t modsx_cand_sort_temp_bytes(unsigned nsort) { return mx::cand_sort_temp_bytes(nsort); }
+extern "C" __attribute__((visibility("default"))) int modsx_cand_order(hipStream_t s, const mx::Candidate *cand, const unsigned *counter, unsigned nsort,
+                                                                        unsigned long long *keys, unsigned long long *keys2, unsigned *idx,
+                                                                        unsigned *idx2, void *temp, size_t tempBytes, unsigned long long *tabKey,
+                                                                        unsigned *tabRank, unsigned tabSize, unsigned *slotOf, mx::Candidate *out,
+                                                                        unsigned *outCount) {
+  return mx::launch_cand_order(s, cand, counter, nsort, keys, keys2, idx, idx2, temp, tempBytes, tabKey, tabRank, tabSize, slotOf, out, outCount);
+}

@@ -76,7 +76,9 @@ __global__ __launch_bounds__(256) void k_blur_hess(BlurBatch batch) {
       int gy = ty0 - 1 - R + ly, gx = tx0 - 1 - R + lx;
       gy = gy < 0 ? 0 : (gy > rows - 1 ? rows - 1 : gy);
       gx = gx < 0 ? 0 : (gx > cols - 1 ? cols - 1 : gx);
-      t[u] = jb.src[(size_t)gy * cols + gx];
+      // 32-bit element offset from the job's (wave-uniform) plane: one 24-bit multiply-add, the load in the scalar base + vector
+      // offset form (a level is far below 2^24 px per side and 2^30 px in all, capi.hip image_size_ok)
+      t[u] = as_global(jb.src)[__umul24((unsigned)gy, (unsigned)cols) + (unsigned)gx];
     }
 #pragma unroll
     for (int u = 0; u < PER; u++) {
@@ -135,7 +137,8 @@ __global__ __launch_bounds__(256) void k_blur_hess(BlurBatch batch) {
     const int gy = ty0 + ly, gx = tx0 + lx;
     if (gy >= rows || gx >= cols) continue;
     const float *B = blr + (ly + 1) * TMP_W + (lx + 1);
-    jb.blur[(size_t)gy * cols + gx] = B[0];
+    const unsigned gofs = __umul24((unsigned)gy, (unsigned)cols) + (unsigned)gx;
+    jb.blur[gofs] = B[0];
     if (jb.resp) {
       float o = 0.f;
       if (gy >= 1 && gy < rows - 1 && gx >= 1 && gx < cols - 1) {
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void k_blur_hess(BlurBatch batch) {
         float Lxy = (v13 - v11 + v31 - v33) / 4.0f;
         o = (Lxx * Lyy - Lxy * Lxy) * norm2;
       }
-      jb.resp[(size_t)gy * cols + gx] = o;
+      jb.resp[gofs] = o;
     }
   }
 }
