@@ -431,6 +431,11 @@ def main():
         for _ in range(warmup):
             results = run()
         barrier(g)
+        sampler = os.environ.get("MODSX_HOST_SAMPLER") if not host_cpu.get("sampled") else None
+        if sampler:      # tools/host_sampler.py: the library's sampling profiler over the first timed region (the headline's K steps)
+            import ctypes as _C
+            mods_amd.lib().modsx_debug_sampler.argtypes = [_C.c_int, _C.c_char_p, _C.c_int]
+            mods_amd.lib().modsx_debug_sampler(1, None, 1000)
         ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         nd = 0
@@ -441,6 +446,9 @@ def main():
         barrier(g)
         dt = time.perf_counter() - t0
         ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        if sampler:
+            mods_amd.lib().modsx_debug_sampler(0, sampler.encode(), 0)
+            host_cpu["sampled"] = True
         host_cpu["s"] = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)     # this rank's threads, user + system
         return dt, nd, results
 

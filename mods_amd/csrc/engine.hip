@@ -158,6 +158,14 @@ static int upload_tables(modsx_ctx *c) {
         }
     if ((int)idx.size() > ORI_NV) { set_error("orientation voting list exceeds ORI_NV"); return MODSX_ERR_ARG; }
     while ((int)idx.size() < ORI_NV) { idx.push_back((unsigned short)(PSP + 1)); w.push_back(0.f); }
+    {   // k_orientation's lane l takes the CONTIGUOUS list elements [PER_L l, PER_L (l + 1)) and reads table entry lane + 64 q
+      constexpr int PER_L = ORI_NV / 64;
+      std::vector<unsigned short> idx2(ORI_NV);
+      std::vector<float> w2(ORI_NV);
+      for (int l = 0; l < 64; l++)
+        for (int q = 0; q < PER_L; q++) { idx2[l + 64 * q] = idx[PER_L * l + q]; w2[l + 64 * q] = w[PER_L * l + q]; }
+      idx.swap(idx2); w.swap(w2);
+    }
     MX_HIP(hipMalloc(&c->dOriMask, ORI_NV * 4));
     MX_HIP(hipMalloc(&c->dOriIdx, ORI_NV * 2));
     MX_HIP(hipMemcpy(c->dOriMask, w.data(), ORI_NV * 4, hipMemcpyHostToDevice));

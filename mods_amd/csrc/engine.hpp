@@ -206,7 +206,7 @@ void launch_gray(hipStream_t s, const void *src, float *dst, size_t n, int chann
 void launch_baumberg(hipStream_t s, const AffJob *jobs, AffOut *out, int n, const float *mask, int W, int maxIter,
                      float convTh, float affInitialSigma);
 constexpr int ATAN_CASES = 2048 + 64;   // 8 x 256 (sign / octant bits, table index) values of atan2LUTff's angle + the special case (entry 2048), padded
-constexpr int ORI_NV = 1280;   // entries of the orientation kernel's voting-pixel list (1245 under the mask, padded)
+constexpr int ORI_NV = 1344;   // entries of the orientation kernel's voting-pixel list (1245 under the mask, padded to 64 lanes x 21)
 void launch_orientation(hipStream_t s, const OriJob *jobs, float *out, int n, const ImgRef *imgs,
                         const unsigned short *maskIdx, const float *maskW,
                         const unsigned char *binTab, int doHalf, double th, int maxAngles);

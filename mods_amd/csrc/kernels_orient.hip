@@ -29,10 +29,6 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, float *o
   // 7.4 KB of LDS per region (21 regions resident per CU; it was 11.3 KB / 14 with a table copy and a separate bin array, and
   // the kernel is bound by the latency of its dependent phases, not by issue): the patch, later overwritten by the voting list
   __shared__ __attribute__((aligned(16))) float bufX[PS * PSP];
-  // the bins of the compacted voting list live behind its weights in the patch's own buffer (the patch is dead by then: the
-  // gradients are staged in registers): at most ORI_NV + 4 weights, then the bytes -- 7.4 KB of LDS per region instead of 9.2
-  static_assert((ORI_NV + 4) * 4 + ORI_NV + 4 <= PS * PSP * 4 && (ORI_NV + 4) % 4 == 0, "the voting list fits in the patch buffer");
-  unsigned char *const sbin = reinterpret_cast<unsigned char *>(bufX + ORI_NV + 4);
   // the 2 KB bin table is read where it lies (every wavefront of the launch hits the same 33 cache lines; a copy per
   // workgroup cost 2.1 of the 11.3 KB of LDS that bound the residency: 14 -> 17 regions per CU) unless the launch is small
   __shared__ __attribute__((aligned(16))) unsigned char sbtLds[LDS_TABLE ? ATAN_CASES : 16];
@@ -91,7 +87,8 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, float *o
   // gradients -> (bin, weight) per pixel, staged in registers so that the weights can take the patch's place.  Only the
   // pixels under the circular mask can vote (mask > 0: a disc of radius 20, 1245 of the 1681 pixels, all of them interior),
   // so the wave walks the host-built raster-ordered list of those pixels (padded LDS index + mask value, padded with
-  // mask 0 to ORI_NV entries) instead of the whole 44 x 41 grid: 20 passes instead of 29 of the kernel's most expensive
+  // mask 0 to ORI_NV entries; table entry lane + 64 q = list element PER_L lane + q, see the histogram below) instead of the whole
+  // 44 x 41 grid: 21 passes instead of 29 of the kernel's most expensive
   // per-pixel code (IEEE sqrt, two IEEE divisions, the f64 look-up).
   constexpr int PER_L = ORI_NV / 64;
   float wreg[PER_L];
@@ -117,54 +114,87 @@ __global__ __launch_bounds__(64) void k_orientation(const OriJob *jobs, float *o
     wreg[q] = w; breg[q] = bin;
   }
   __syncthreads();
-  // Only pixels with a gradient above 1 vote, so the (bin, weight) pairs are first compacted IN RASTER ORDER: list entry
-  // e = lane + 64 q, so chunk q precedes chunk q + 1 and within a chunk lanes are ordered -- a ballot prefix keeps the order.
-  int nv = 0;   // wave-uniform
+  // The histogram: bin b is the f32 running sum of its votes in raster order (the reference's loop, synth-detection.cpp:771-787).
+  // Until round 5 lane b added its votes one instruction per vote with EXEC opened for that lane alone -- 1245 single-lane adds, the
+  // largest stage of the kernel.  Now the votes are first SORTED BY BIN, stably, and lane b then adds only its own: the list is
+  // laid out so that lane l holds the CONTIGUOUS segment [PER_L l, PER_L (l + 1)) of the raster-ordered voting list in its
+  // registers (the host permutes the pixel table: entry lane + 64 q = list element PER_L lane + q), so a counting sort needs no
+  // lane exchange: (1) every lane counts its votes per bin in its own column of a [bin][lane] table of 16-bit counters (and keeps a
+  // vote's rank among the lane's earlier votes of that bin), (2) lane b turns row b into exclusive prefix sums -- (bin, lane) order
+  // IS raster order within a bin -- and the row totals into the bins' bases, (3) a vote's slot is base[bin] + row prefix + rank,
+  // (4) the weights go to their slots, (5) lane b adds its slots in order.  ~550 vector instructions instead of ~2000, the same sums.
+  // The counters live in the patch buffer (dead: the gradients are in registers), the sorted weights replace them.
+  constexpr int NB = 37;                              // bins 0..36 (36: ori == pi, a slot of its own that nothing reads, as in the reference)
+  constexpr int NROW = NB + 1;                        // + a row for the pixels that do not vote (no branch per pixel)
+  constexpr int DUMP = ORI_NV;                        // their weights go to slots DUMP + lane, which nothing reads
+  static_assert(NROW * 64 * 2 <= PS * PSP * 4 && (ORI_NV + 64) * 4 <= PS * PSP * 4, "counters and sorted weights fit in the patch buffer");
+  unsigned short *const cnt = reinterpret_cast<unsigned short *>(bufX);
+  __shared__ int sbase[64];
+  {
+    float4 *const z = reinterpret_cast<float4 *>(bufX);
+    for (int i = lane; i < (NROW * 64 * 2 + 15) / 16; i += 64) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  int slot[PER_L], crow[PER_L];                       // rank among the lane's earlier votes of the bin, later the vote's slot; counter index
 #pragma unroll
   for (int q = 0; q < PER_L; q++) {
-    const bool valid = breg[q] != 255;
-    const unsigned long long m = __ballot(valid);
-    const int pos = nv + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-    if (valid) { bufX[pos] = wreg[q]; sbin[pos] = breg[q]; }
-    nv += __popcll(m);
+    const int bq = breg[q] == 255 ? NB : (int)breg[q];
+    crow[q] = bq * 64 + lane;
+    const unsigned short c = cnt[crow[q]];            // (LDS operations of a wavefront execute in order: a later vote of the same bin sees this increment)
+    slot[q] = c;
+    cnt[crow[q]] = (unsigned short)(c + 1);
   }
-  if (lane < 4) { bufX[nv + lane] = 0.f; sbin[nv + lane] = 255; }   // pad the last group of four
   __syncthreads();
-  // lane b owns histogram bin b and adds its pixels in raster order (f32 running sum of the reference).  This loop is the
-  // kernel's largest stage and is bound by VALU issue, so a vote is ONE vector instruction: the four bins of a group are
-  // wave-uniform (every lane reads the same LDS word), so they go to a scalar register once per group and the scalar unit
-  // -- which issues beside the vector unit -- opens EXEC for exactly lane `bin` (s_bfe + s_lshl of 1) before each add.
-  // The 255 of padding selects lane 63, whose sum is never read.  All 64 lanes of the single wavefront are active here.
+  int nmine = 0;                                      // lane b < NB: votes of bin b
+  if (lane < NB) {
+    uint4 *const row = reinterpret_cast<uint4 *>(bufX) + lane * 8;   // 64 counters = 8 x 16 bytes
+    unsigned run = 0;
+    auto pre = [&run](unsigned w) { const unsigned lo = w & 0xffffu, hi = w >> 16; const unsigned o = run | ((run + lo) << 16); run += lo + hi; return o; };
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      uint4 w = row[i];
+      w.x = pre(w.x); w.y = pre(w.y); w.z = pre(w.z); w.w = pre(w.w);
+      row[i] = w;
+    }
+    nmine = (int)run;
+  }
+  int base;                                           // slot of bin b's first vote: exclusive prefix of the totals over the lanes (0 beyond NB)
   {
+    int incl = nmine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+    base = incl - nmine;
+    sbase[lane] = base;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < PER_L; q++) {
+    const int bq = crow[q] >> 6;
+    const int sl = slot[q] + (int)cnt[crow[q]] + sbase[bq];
+    slot[q] = bq == NB ? DUMP + lane : sl;
+  }
+  __syncthreads();                                    // every slot is known: the sorted weights may take the counters' place
+#pragma unroll
+  for (int q = 0; q < PER_L; q++) bufX[slot[q]] = wreg[q];
+  __syncthreads();
+  {
+    int nmax = nmine;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off));
+    nmax = __builtin_amdgcn_readfirstlane(nmax);
     float h = 0.f;
-    const unsigned *b4 = reinterpret_cast<const unsigned *>(sbin);
-    const float4 *w4 = reinterpret_cast<const float4 *>(bufX);
-    const int ng = (nv + 3) >> 2;
-#pragma unroll 4
-    for (int g = 0; g < ng; g++) {
-      const unsigned b = __builtin_amdgcn_readfirstlane(b4[g]);
-      const float4 w = w4[g];
-      unsigned t;
-      unsigned long long ex;   // the incoming EXEC is saved and restored (the block is entered with all 64 lanes of the
-                               // launch's single wavefront active, but nothing here depends on that)
-      asm volatile(
-          "s_mov_b64 %2, exec\n\t"
-          "s_bfe_u32 %1, %3, 0x60000\n\t"
-          "s_lshl_b64 exec, 1, %1\n\t"
-          "v_add_f32_e32 %0, %0, %4\n\t"
-          "s_bfe_u32 %1, %3, 0x60008\n\t"
-          "s_lshl_b64 exec, 1, %1\n\t"
-          "v_add_f32_e32 %0, %0, %5\n\t"
-          "s_bfe_u32 %1, %3, 0x60010\n\t"
-          "s_lshl_b64 exec, 1, %1\n\t"
-          "v_add_f32_e32 %0, %0, %6\n\t"
-          "s_bfe_u32 %1, %3, 0x60018\n\t"
-          "s_lshl_b64 exec, 1, %1\n\t"
-          "v_add_f32_e32 %0, %0, %7\n\t"
-          "s_mov_b64 exec, %2"
-          : "+v"(h), "=&s"(t), "=&s"(ex)
-          : "s"(b), "v"(w.x), "v"(w.y), "v"(w.z), "v"(w.w)
-          : "scc", "memory");
+    // eight slots per step, read together (a lane past its own votes reads its neighbours' slots and drops them: the address stays
+    // inside the buffer), added in order
+    for (int k0 = 0; k0 < nmax; k0 += 8) {
+      const float *m8 = bufX + min(base + k0, ORI_NV + 56);
+      const int rem = nmine - k0;
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = m8[u];
+      asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));   // (the loads stay together)
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (rem > u) h += v[u];
     }
     if (lane < 36) hist[lane] = h;
   }
