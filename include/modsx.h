@@ -325,7 +325,8 @@ int modsx_loransac_f(const double *pts, const double *laf1, const double *laf2, 
  * one: the host draws the samples of a batch from a copy of the PRNG, one device thread per hypothesis counts, the host acts on
  * the first count that changes the loop's state exactly as the reference does.  Same trajectory, same F (tests/test_gpu_verify.py
  * against the reference's compiled degensac).  MODSX_VERIFY_DEVICE=0 keeps the loop on the host; without a device it is there
- * anyway.  out[0..6): device batches, hypotheses counted on the device, state-changing hypotheses, host / device disagreements,
+ * anyway.  A device state that failed to set up, hit a HIP error or disagreed with the host's recount is torn down, the loop at
+ * hand finishes on the host, and the next loop starts a fresh state; after 8 such failures in a process the loops stay on the host.  out[0..6): device batches, hypotheses counted on the device, state-changing hypotheses, host / device disagreements,
  * rFtH loops run (either way) and the microseconds they took (process-wide; reset != 0 clears them).  Returns 6. */
 int modsx_verify_device_stats(long *out, int reset);
 /* out[0..4): microseconds of those loops spent drawing samples ahead of a batch, waiting for the device, in the host phase
@@ -475,8 +476,11 @@ int modsx_comm_stats(const modsx_comm *comm, long *out, int n);
  * north star's "all-gather of regions + descriptors"): every rank receives every row.  MODSX_EXCHANGE_OWNER: the per-item counts go
  * to every rank (an all-gather of a few KB), the rows of pair g only to the rank that matches and verifies it (ncclSend / ncclRecv
  * in one group): 1 / world of the all-gather's bytes on the wire, exact sizes (no padded blocks, no retry), one more host wait per
- * call.  Set it alike on every rank before the first sharded call (ranks set differently stop with MODSX_ERR_TIMEOUT at the first
- * exchange: the mode travels in the header).  The calls that return lists to every rank keep the all-gather. */
+ * call.  Set it alike on every rank before the first sharded call: it is part of the call's contract, like the view list.  The mode
+ * travels in the header, and on the loopback transport (which checks sizes) ranks set differently stop with MODSX_ERR_TIMEOUT at the
+ * first exchange; over RCCL they would issue all-gathers of different byte counts, which the collective library does not define
+ * (a hang that ends in the communicator's deadline, or garbage that the header check then rejects) -- the library cannot detect the
+ * mismatch there before the collective.  The calls that return lists to every rank keep the all-gather. */
 #define MODSX_EXCHANGE_ALL_GATHER 0
 #define MODSX_EXCHANGE_OWNER 1
 int modsx_comm_set_exchange(modsx_comm *comm, int mode);

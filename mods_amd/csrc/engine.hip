@@ -261,7 +261,6 @@ modsx_ctx *ctx_create(int device_id) {
   modsx_ctx *c = new modsx_ctx();
   c->dev = device_id;
   if (hipStreamCreate(&c->stream) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
-  for (int i = 0; i < 8; i++) hipEventCreate(&c->ev[i]);
   for (int i = 0; i < 2; i++) hipEventCreateWithFlags(&c->descEv[i], hipEventDisableTiming);
   for (int i = 0; i < 6; i++) c->timings[i] = 0;
   if (upload_tables(c) != MODSX_OK) { delete c; return nullptr; }
@@ -288,7 +287,6 @@ void ctx_destroy(modsx_ctx *c) {
   for (PinBuf *b : pins) b->release();
   hipFree(c->dSmmMask); hipFree(c->dOriMask); hipFree(c->dOriIdx); hipFree(c->dSiftMask); hipFree(c->dSiftMaskIdx); hipFree(c->dAtan); hipFree(c->dOriBinTab); hipFree(c->dSiftOTab); hipFree(c->dSiftBins);
   hipFree(c->dSiftW);
-  for (int i = 0; i < 8; i++) hipEventDestroy(c->ev[i]);
   for (int i = 0; i < 2; i++) hipEventDestroy(c->descEv[i]);
   c->hDescB.release();
   hipStreamDestroy(c->stream);

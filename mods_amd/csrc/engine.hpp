@@ -319,7 +319,6 @@ struct modsx_ctx {
   float *dSiftOTab = nullptr;            // fractional SIFT orientation bin of every atan2LUT angle
   int *dSiftBins = nullptr;    // bin0[41], bin1[41]
   double *dSiftW = nullptr;    // w0[41], w1[41]
-  hipEvent_t ev[8];
   double timings[6];
   mx::Profiler prof;
   size_t lastCandCount = 0;    // scale-space candidates of the context's last launch set (sizes the speculative download)

@@ -53,9 +53,10 @@ extern "C" __attribute__((visibility("default"))) int modsx_debug_sampler(int st
   if (!path) return n;
   Dl_info self;
   const char *selfName = dladdr((void *)&modsx_debug_sampler, &self) ? self.dli_fname : "";
-  std::map<std::string, long> leaf, inlib, mods;
+  std::map<std::string, long> leaf, inlib, mods, rt;      // rt: innermost libmodsx frame of the samples whose innermost frame is NOT in libmodsx
   for (int i = 0; i < n; i++) {
-    bool haveLeaf = false, haveLib = false;
+    bool haveLeaf = false, haveLib = false, leafInLib = false;
+    std::string leafMod;
     for (int f = 0; f < g_depth[i]; f++) {
       void *pc = g_frames[(size_t)i * DEPTH + f];
       Dl_info di;
@@ -63,11 +64,14 @@ extern "C" __attribute__((visibility("default"))) int modsx_debug_sampler(int st
       if (f < 2) continue;               // [0] the handler, [1] libc's signal return trampoline, [2] the interrupted pc
       char key[512];
       snprintf(key, sizeof key, "%s %lx", di.dli_fname, (unsigned long)((char *)pc - (char *)di.dli_fbase));
-      if (!haveLeaf) { leaf[key]++; mods[di.dli_fname]++; haveLeaf = true; }
-      if (!haveLib && !strcmp(di.dli_fname, selfName)) { inlib[key]++; haveLib = true; }
+      if (!haveLeaf) { leaf[key]++; mods[di.dli_fname]++; haveLeaf = true; leafInLib = !strcmp(di.dli_fname, selfName); leafMod = di.dli_fname; }
+      if (!haveLib && !strcmp(di.dli_fname, selfName)) {
+        inlib[key]++; haveLib = true;
+        if (!leafInLib) rt[std::string(key) + " <- " + leafMod.substr(leafMod.rfind('/') + 1)]++;
+      }
       if (haveLeaf && haveLib) break;
     }
-    if (!haveLib) inlib["(outside-libmodsx) 0"]++;
+    if (!haveLib) { inlib["(outside-libmodsx) 0"]++; rt["(outside-libmodsx) 0 <- " + leafMod.substr(leafMod.rfind('/') + 1)]++; }
   }
   FILE *fp = fopen(path, "w");
   if (!fp) return -1;
@@ -75,6 +79,7 @@ extern "C" __attribute__((visibility("default"))) int modsx_debug_sampler(int st
   for (auto &m : mods) fprintf(fp, "M %ld %s\n", m.second, m.first.c_str());
   for (auto &m : leaf) fprintf(fp, "L %ld %s\n", m.second, m.first.c_str());
   for (auto &m : inlib) fprintf(fp, "I %ld %s\n", m.second, m.first.c_str());
+  for (auto &m : rt) fprintf(fp, "R %ld %s\n", m.second, m.first.c_str());
   fclose(fp);
   return n;
 }

@@ -289,7 +289,9 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
     // interpolateCheckBorders (helpers.cpp:524-549) of every slot at once, each in its own state lanes: one evaluation per
     // iteration instead of one per slot behind six broadcasts of the slot's matrix and position
     const unsigned long long touchMask = __ballot(check_borders(scols, srows, slx, sly, A11, A12, A21, A22, W, W));
-    if constexpr (K == 2) {
+    if constexpr (K % 2 == 0) {
+#pragma unroll
+      for (int sp = 0; sp < K; sp += 2) {       // the slots two at a time (K = 2: once)
       // Sample coordinates of BOTH slots at once (helpers.cpp:563-585: f32 running sums down the rows, then along each row).
       // The four chains -- slot 0 x, slot 0 y, slot 1 x, slot 1 y -- take one DPP row of 16 lanes each.  Row starts: lane i of
       // a DPP row needs i steps of its chain, which `v = v[lane - 1] + step` (row_shr:1; lane 0 of a row has no source and is
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
       // 0..2 of a DPP row a second one (rows 16..18) beside it in the other half of a packed add; the other lanes park that
       // half in the slot's third array, which is free until the taps are stored.  ~50 vector instructions per iteration for
       // what took ~150 per slot when each slot ran its x and y chains in the same 19 lanes.
-      const int dq = lane >> 5, dc = (lane >> 4) & 1, di = lane & 15;
+      const int dq = sp + (lane >> 5), dc = (lane >> 4) & 1, di = lane & 15;   // slot, x / y chain, lane of the DPP row
       const float s11 = __shfl(A11, 2 * dq), s12 = __shfl(A12, 2 * dq), s21 = __shfl(A21, 2 * dq), s22 = __shfl(A22, 2 * dq);
       const float sox = __shfl(slx, 2 * dq), soy = __shfl(sly, 2 * dq);   // (both by every lane: a shuffle reads nothing from an idle lane)
       const float so = dc ? soy : sox;
@@ -324,6 +326,7 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
         b1[i] = wv.x;
         b2[i] = wv.y;
         wv += st;
+      }
       }
     }
     BT(1);
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(64) void k_baumberg_stream(const AffJob *jobs, AffO
         atomicAdd(&g_btrace[9 + b], 1ull);
       }
 #endif
-      if constexpr (K != 2) {
+      if constexpr (K % 2 != 0) {
         // sample coordinates: lane j runs the f32 running sums of row j (helpers.cpp:563-585) into LDS
         const float lx = __shfl(slx, 2 * q), ly = __shfl(sly, 2 * q);
         const float a11 = __shfl(A11, 2 * q), a12 = __shfl(A12, 2 * q), a21 = __shfl(A21, 2 * q), a22 = __shfl(A22, 2 * q);

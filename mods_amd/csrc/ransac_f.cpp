@@ -657,11 +657,16 @@ struct RfthDevice {
   static bool pinned(void **h, void **d, size_t bytes) {
     return hipHostMalloc(h, bytes, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(d, *h, 0) == hipSuccess;
   }
+  // failed initialisations / host-device disagreements in this process: after RFTH_GIVE_UP of them the loops stay on the host (a box
+  // where the set-up keeps failing would otherwise pay stream + pinned allocations on every rFtH loop)
+  static std::atomic<int> &failures() { static std::atomic<int> f(0); return f; }
+  enum { RFTH_GIVE_UP = 8 };
   bool init() {
     if (tried) return ok;
     tried = true;
     const char *e = getenv("MODSX_VERIFY_DEVICE");
     if (e && atoi(e) == 0) return false;
+    if (failures().load() >= RFTH_GIVE_UP) return false;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { (void)hipGetLastError(); return false; }
     // the highest priority: a batch is a few wavefronts that must not queue behind the launch sets of 16 contexts
@@ -724,7 +729,7 @@ struct RfthLease {
   ~RfthLease() {
     if (d->tried && !d->ok) {      // failed or disagreed: its resources go, and the next loop on this device starts a fresh state
       const char *e = getenv("MODSX_VERIFY_DEVICE");
-      if (!(e && atoi(e) == 0) && d->dev >= 0) { d->release(); delete d; return; }
+      if (!(e && atoi(e) == 0) && d->dev >= 0) { RfthDevice::failures()++; d->release(); delete d; return; }
     }
     std::lock_guard<std::mutex> lk(mu());
     idle().push_back(d);

@@ -41,18 +41,25 @@ def name_of(path, off):
     i = bisect.bisect_right(tab, (off, "\xff")) - 1
     return tab[i][1][:110] if i >= 0 else "%s+0x%x" % (os.path.basename(path), off)
 
-agg = {"M": {}, "L": {}, "I": {}}
+agg = {"M": {}, "L": {}, "I": {}, "R": {}}
 for ln in open(raw):
     p = ln.rstrip("\n").split(" ", 3)
     if p[0] == "M":
         p = ln.rstrip("\n").split(" ", 2)
         agg["M"][os.path.basename(p[2])] = agg["M"].get(os.path.basename(p[2]), 0) + int(p[1])
+    elif p[0] == "R":
+        p = ln.rstrip("\n").split(" ", 3)      # R count path offset <- module
+        path, rest = p[2], p[3]
+        off, mod = rest.split(" <- ")
+        key = ("(no libmodsx frame)" if path.startswith("(outside") else name_of(path, int(off, 16))) + "  <-  " + mod
+        agg["R"][key] = agg["R"].get(key, 0) + int(p[1])
     elif p[0] in "LI" and len(p) == 4:
         path, off = p[2], int(p[3], 16)
         key = "(outside libmodsx)" if path.startswith("(outside") else "%s: %s" % (os.path.basename(path), name_of(path, off))
         agg[p[0]][key] = agg[p[0]].get(key, 0) + int(p[1])
 with open(out, "w") as f:
-    for title, k, top in (("CPU samples per module", "M", 20), ("innermost function", "L", 45), ("innermost libmodsx function on the stack", "I", 60)):
+    for title, k, top in (("CPU samples per module", "M", 20), ("innermost function", "L", 45), ("innermost libmodsx function on the stack", "I", 60),
+                          ("samples inside the runtime / libc: innermost libmodsx function <- module of the innermost frame", "R", 50)):
         f.write("== %s (%d samples of 1 ms CPU)\n" % (title, n))
         for name, c in sorted(agg[k].items(), key=lambda kv: -kv[1])[:top]:
             f.write("%6.2f %%  %7d  %s\n" % (100.0 * c / max(n, 1), c, name))
