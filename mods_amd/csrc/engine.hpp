@@ -185,7 +185,9 @@ int blur_ksize(float sigma);
 void gauss_mask(float *mask, int size);
 void circular_gauss_mask(float *mask, int size, float sigma);
 const double *atan_lut_host();
-bool check_borders_host(int w, int h, float ofsx, float ofsy, float a11, float a12, float a21, float a22, int rw, int rh);
+inline bool check_borders_host(int w, int h, float ofsx, float ofsy, float a11, float a12, float a21, float a22, int rw, int rh) {
+  return check_borders(w, h, ofsx, ofsy, a11, a12, a21, a22, rw, rh);     // kmath.hpp (host build of the kernels' expression)
+}
 bool invert3(const double *S, double *t);
 void rectify(double &a11, double &a12, double &a21, double &a22);
 

@@ -83,10 +83,6 @@ const double *atan_lut_host() {
   return lut;
 }
 
-bool check_borders_host(int w, int h, float ofsx, float ofsy, float a11, float a12, float a21, float a22, int rw, int rh) {
-  return check_borders(w, h, ofsx, ofsy, a11, a12, a21, a22, rw, rh);
-}
-
 // cv::invert(3x3, DECOMP_LU): closed-form adjugate / determinant (OpenCV 2.4.9 lapack.cpp)
 bool invert3(const double *S, double *t) {
   double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);

@@ -249,6 +249,39 @@ def test_owner_only_exchange_equals_the_all_gather(ctx, modsx, small_pair, world
         d.free()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_owner_only_exchange_with_alternating_descriptor_lists(ctx, modsx, small_pair, world):
+    """One communicator, one lane, calls that alternate between one descriptor class and two (RootSIFT, then RootSIFT + HalfRootSIFT as
+    the WxBS steps carry them, then one again): the owner-only buffers are agreed in ROWS, and a row of a two-class call is 128 bytes
+    wider -- with row counts under the caps of the first call the second must still fit (round-5 advisor finding: the buffers were sized
+    for the rows of the call that grew them).  Every owner's result == the unsharded call with the same parameters."""
+    from mods_amd import distributed as D
+    a, b, _ = small_pair
+    dev = [ctx.upload(x) for x in (a, b)]
+    views = _views(modsx)
+    pars = [modsx.default_pair_params(ransac_seed=4),
+            modsx.default_pair_params(ransac_seed=4, descs=[(1, 0.8), (3, 0.8)]),
+            modsx.default_pair_params(ransac_seed=4)]
+    pairs = [(0, 1), (1, 0), (0, 1)]
+    refs = [[ctx.match_pair_views(dev[i], dev[j], views, par) for i, j in pairs] for par in pars]
+
+    def rank_body(r, comm):
+        comm.set_exchange(modsx.EXCHANGE_OWNER)
+        i1, i2 = [dev[i] for i, _ in pairs], [dev[j] for _, j in pairs]
+        return [comm.match_pairs_views_sharded(0, i1, i2, views, par, owner_base=0) for par in pars]
+
+    res = D.run_loopback(world, rank_body)
+    for r, outs in enumerate(res):
+        for k, out in enumerate(outs):
+            for g, ref in enumerate(refs[k]):
+                if g % world == r:
+                    _same_pair_result(out[g], ref)
+                else:
+                    assert out[g]["n_regions"] == ref["n_regions"] and out[g]["n_tentatives"] == 0
+    for d in dev:
+        d.free()
+
+
 def test_owner_only_exchange_errors_are_collective(ctx, modsx, small_pair):
     """In the owner-only mode a rank-local failure still travels in the header every rank receives (same error, same call, the
     communicator keeps working), and ranks set to DIFFERENT modes do not hang: the mode is part of the header's magic."""
