@@ -288,7 +288,7 @@ void ctx_destroy(modsx_ctx *c) {
   hipFree(c->dSmmMask); hipFree(c->dOriMask); hipFree(c->dOriIdx); hipFree(c->dSiftMask); hipFree(c->dSiftMaskIdx); hipFree(c->dAtan); hipFree(c->dOriBinTab); hipFree(c->dSiftOTab); hipFree(c->dSiftBins);
   hipFree(c->dSiftW);
   for (int i = 0; i < 2; i++) hipEventDestroy(c->descEv[i]);
-  c->hDescB.release();
+  c->hDescB.release(); c->hRefs.release();
   hipStreamDestroy(c->stream);
   delete c;
 }
@@ -942,8 +942,11 @@ static int upload_img_refs(modsx_ctx *c, const modsx_image *const *imgs, int n) 
   for (int i = 0; i < n; i++) { refs[i].d = imgs[i]->d; refs[i].rows = imgs[i]->rows; refs[i].cols = imgs[i]->cols; }
   // orientation and description of a launch set name the same images: the table on the device is already right
   if (!fresh && memcmp(refs, c->imgRefsHost, sizeof refs) == 0) return MODSX_OK;
-  MX_HIP(hipMemcpyAsync(c->imgRefs.p, refs, sizeof refs, hipMemcpyHostToDevice, c->stream));
-  MX_HIP(hipStreamSynchronize(c->stream));  // refs[] is a stack buffer
+  // through a pinned copy of its own, in stream order and without a wait: the stream is idle when a stage begins (every stage ends
+  // in a synchronize), so the previous table's copy has long completed when this buffer is written again
+  if (!c->hRefs.ensure(sizeof refs)) return MODSX_ERR_NOMEM;
+  memcpy(c->hRefs.p, refs, sizeof refs);
+  MX_HIP(hipMemcpyAsync(c->imgRefs.p, c->hRefs.p, sizeof refs, hipMemcpyHostToDevice, c->stream));
   memcpy(c->imgRefsHost, refs, sizeof refs);
   return MODSX_OK;
 }

@@ -305,7 +305,7 @@ struct modsx_ctx {
   mx::PinBuf hDescB;           // second staging blob of describe_batch: chunk k + 1 is prepared while chunk k runs
   hipEvent_t descEv[2];
   bool descEvPending[2] = {false, false};
-  mx::PinBuf hCand, hAff, hOri, hDesc, hMisc, hNms, hMatch, hViewTaps, hViewJobs, hMser;
+  mx::PinBuf hCand, hAff, hOri, hDesc, hMisc, hNms, hMatch, hViewTaps, hViewJobs, hMser, hRefs;
   // constant tables on device
   float *dSmmMask = nullptr;   // 19x19 computeGaussMask
   int smmW = 0;

@@ -15,7 +15,7 @@
 #include <vector>
 
 namespace {
-constexpr int MAXS = 1 << 18, DEPTH = 20;
+constexpr int MAXS = 1 << 16, DEPTH = 64;
 void **g_frames = nullptr;             // MAXS x DEPTH
 unsigned char *g_depth = nullptr;
 std::atomic<int> g_n(0);
@@ -53,15 +53,20 @@ extern "C" __attribute__((visibility("default"))) int modsx_debug_sampler(int st
   if (!path) return n;
   Dl_info self;
   const char *selfName = dladdr((void *)&modsx_debug_sampler, &self) ? self.dli_fname : "";
-  std::map<std::string, long> leaf, inlib, mods, rt;      // rt: innermost libmodsx frame of the samples whose innermost frame is NOT in libmodsx
+  std::map<std::string, long> leaf, inlib, mods, rt, chains;      // rt: innermost libmodsx frame of the samples whose innermost frame is NOT in libmodsx
   for (int i = 0; i < n; i++) {
     bool haveLeaf = false, haveLib = false, leafInLib = false;
-    std::string leafMod;
+    std::string leafMod, chainStr, lastMod;
     for (int f = 0; f < g_depth[i]; f++) {
       void *pc = g_frames[(size_t)i * DEPTH + f];
       Dl_info di;
       if (!dladdr(pc, &di) || !di.dli_fname) continue;
       if (f < 2) continue;               // [0] the handler, [1] libc's signal return trampoline, [2] the interrupted pc
+      {   // the chain of modules from the innermost frame outwards (consecutive repeats folded): which kind of thread was this
+        const char *b = strrchr(di.dli_fname, '/');
+        const std::string mod = b ? b + 1 : di.dli_fname;
+        if (mod != lastMod) { chainStr += (chainStr.empty() ? "" : " < ") + mod; lastMod = mod; }
+      }
       char key[512];
       snprintf(key, sizeof key, "%s %lx", di.dli_fname, (unsigned long)((char *)pc - (char *)di.dli_fbase));
       if (!haveLeaf) { leaf[key]++; mods[di.dli_fname]++; haveLeaf = true; leafInLib = !strcmp(di.dli_fname, selfName); leafMod = di.dli_fname; }
@@ -69,8 +74,8 @@ extern "C" __attribute__((visibility("default"))) int modsx_debug_sampler(int st
         inlib[key]++; haveLib = true;
         if (!leafInLib) rt[std::string(key) + " <- " + leafMod.substr(leafMod.rfind('/') + 1)]++;
       }
-      if (haveLeaf && haveLib) break;
     }
+    chains[chainStr]++;
     if (!haveLib) { inlib["(outside-libmodsx) 0"]++; rt["(outside-libmodsx) 0 <- " + leafMod.substr(leafMod.rfind('/') + 1)]++; }
   }
   FILE *fp = fopen(path, "w");
@@ -80,6 +85,7 @@ extern "C" __attribute__((visibility("default"))) int modsx_debug_sampler(int st
   for (auto &m : leaf) fprintf(fp, "L %ld %s\n", m.second, m.first.c_str());
   for (auto &m : inlib) fprintf(fp, "I %ld %s\n", m.second, m.first.c_str());
   for (auto &m : rt) fprintf(fp, "R %ld %s\n", m.second, m.first.c_str());
+  for (auto &m : chains) fprintf(fp, "C %ld %s\n", m.second, m.first.c_str());
   fclose(fp);
   return n;
 }

@@ -41,12 +41,15 @@ def name_of(path, off):
     i = bisect.bisect_right(tab, (off, "\xff")) - 1
     return tab[i][1][:110] if i >= 0 else "%s+0x%x" % (os.path.basename(path), off)
 
-agg = {"M": {}, "L": {}, "I": {}, "R": {}}
+agg = {"M": {}, "L": {}, "I": {}, "R": {}, "C": {}}
 for ln in open(raw):
     p = ln.rstrip("\n").split(" ", 3)
     if p[0] == "M":
         p = ln.rstrip("\n").split(" ", 2)
         agg["M"][os.path.basename(p[2])] = agg["M"].get(os.path.basename(p[2]), 0) + int(p[1])
+    elif p[0] == "C":
+        p = ln.rstrip("\n").split(" ", 2)
+        agg["C"][p[2]] = agg["C"].get(p[2], 0) + int(p[1])
     elif p[0] == "R":
         p = ln.rstrip("\n").split(" ", 3)      # R count path offset <- module
         path, rest = p[2], p[3]
@@ -59,7 +62,8 @@ for ln in open(raw):
         agg[p[0]][key] = agg[p[0]].get(key, 0) + int(p[1])
 with open(out, "w") as f:
     for title, k, top in (("CPU samples per module", "M", 20), ("innermost function", "L", 45), ("innermost libmodsx function on the stack", "I", 60),
-                          ("samples inside the runtime / libc: innermost libmodsx function <- module of the innermost frame", "R", 50)):
+                          ("samples inside the runtime / libc: innermost libmodsx function <- module of the innermost frame", "R", 50),
+                          ("module chain of the stack, innermost first", "C", 40)):
         f.write("== %s (%d samples of 1 ms CPU)\n" % (title, n))
         for name, c in sorted(agg[k].items(), key=lambda kv: -kv[1])[:top]:
             f.write("%6.2f %%  %7d  %s\n" % (100.0 * c / max(n, 1), c, name))
