@@ -6,7 +6,7 @@ the bench's 16 streams (<tag>_kernel_stats_default.txt), vector instructions per
 import os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
-pairs = float(sys.argv[2]) if len(sys.argv) > 2 else 33.0      # pairs of the one-stream profile run (regen_profiles.sh)
+pairs = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0       # pairs of the one-stream profile run; default: the k_match_sweep1 launches of that run (one per pair)
 
 def short(name):
     return re.sub(r"<.*", "", name.replace("void ", "").strip())
@@ -54,6 +54,8 @@ dflt = stats(os.path.join(ROOT, "profiles", tag + "_kernel_stats_default.txt"))
 sq, sqc = counters(os.path.join(ROOT, "profiles", tag + "_pmc_sq.txt"))
 hbm, hbc = counters(os.path.join(ROOT, "profiles", tag + "_pmc_hbm.txt"))
 tot = sum(v[1] for v in one.values())
+if pairs <= 0:
+    pairs = one.get("k_match_sweep1", [33.0, 0.0])[0]
 print("| kernel | launches / pair | µs / launch, one stream | ms / pair, one stream | share | µs / launch under 16 streams | M vector instr. / launch | VALU issue | HBM MB / launch |")
 print("|---|---|---|---|---|---|---|---|---|")
 for name, (calls, total) in sorted(one.items(), key=lambda kv: -kv[1][1]):

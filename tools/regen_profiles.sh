@@ -76,7 +76,10 @@ try:   # HBM bytes of the whole pipeline per pair: every kernel's FETCH_SIZE x2 
         if ln.startswith("#") or ln.startswith("kernel"): continue
         p = ln.rstrip().rsplit(None, 4)
         if len(p) == 5: tot += float(p[1]) * (float(p[3]) + float(p[4])) if p[1].replace(".", "").isdigit() else 0
-    npairs = 33         # bench.py $ONE: (1 warm-up + 2 steps back to back + the same 2 steps with a step barrier) x 4 pairs, the 1-step kernel-time leg (4), the one-stream leg (4) and the 5 repetitions of the roofline leg
+    npairs = 0          # pairs of bench.py $ONE = its k_match_sweep1 launches (one matching problem per pair)
+    for ln in open("$OUT/${TAG}_kernel_stats_single_stream.txt"):
+        if ln.startswith("k_match_sweep1"): npairs += int(ln.split()[-10])
+    t["pairs_in_one_stream_profile"] = npairs
     t["hbm_counter_GB_per_pair"] = tot / npairs / 1e9
 except Exception as e:
     print("no per-pair total:", e)
