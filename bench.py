@@ -814,7 +814,7 @@ def main():
                                                    "source": "profiles/r03_ubench_mfma.txt (tools/ubench/mfma_chain_sift, mfma_lds)"},
                         "note": "HIP events on the launch stream around k_match_sweep1 of the same %d repetitions" % nl}
             tfile, tsrc = None, None
-            for tag in ("r05", "r04", "r03", "r02"):
+            for tag in ("r06", "r05", "r04", "r03", "r02"):
                 cand = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % tag)
                 if os.path.exists(cand):
                     tfile, tsrc = cand, "profiles/pmc_traffic_%s.json" % tag
