@@ -414,10 +414,13 @@ def main():
 
         def work(w):
             out = []
+            tc0 = time.thread_time()
             while True:
                 with lock:
                     k = next(nxt)
                 if k >= nsteps * n:
+                    with lock:       # CPU of the contexts' own threads (the rest of the process' CPU: helper, pool and runtime threads)
+                        host_cpu["ctx_threads"] = host_cpu.get("ctx_threads", 0.0) + time.thread_time() - tc0
                     return out
                 out.append((k, cx[w].match_pair_views(i1[k % n], i2[k % n], views, params)))
         res = [[None] * n for _ in range(nsteps)]
@@ -437,6 +440,7 @@ def main():
             mods_amd.lib().modsx_debug_sampler.argtypes = [_C.c_int, _C.c_char_p, _C.c_int]
             mods_amd.lib().modsx_debug_sampler(1, None, 1000)
         ru0 = resource.getrusage(resource.RUSAGE_SELF)
+        host_cpu["ctx_threads"] = 0.0
         t0 = time.perf_counter()
         nd = 0
         for results in (run_steps_back_to_back(steps) if back_to_back else (run() for _ in range(steps))):
@@ -450,6 +454,8 @@ def main():
             mods_amd.lib().modsx_debug_sampler(0, sampler.encode(), 0)
             host_cpu["sampled"] = True
         host_cpu["s"] = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)     # this rank's threads, user + system
+        host_cpu["sys"] = ru1.ru_stime - ru0.ru_stime
+        host_cpu["ctx"] = host_cpu.get("ctx_threads", 0.0)
         return dt, nd, results
 
     def reduce_over_ranks(elapsed, nd):
@@ -466,6 +472,7 @@ def main():
     b2b = group is None and not single_view and not args.batch_api and lsteps is None and not args.step_barrier
     elapsed, ndesc, results = timed(run_batch, args.warmup, args.steps, group, back_to_back=b2b)
     host_cpu_headline = host_cpu["s"]       # of the K timed steps (later legs run through timed() too)
+    host_cpu_split = (host_cpu.get("ctx", 0.0), host_cpu.get("sys", 0.0))
     barrier_form = None
     if b2b:
         eb, nb_, _ = timed(run_batch, 0, args.steps, group)
@@ -748,6 +755,16 @@ def main():
             # rank 0's own threads (workers, verification helpers, host pool) over its share of the timed pairs: on a node where N ranks
             # share one host, N times this figure per second of throughput is what the host has to supply
             out["host_cpu_s_per_pair_rank0"] = host_cpu_headline / max(1, args.steps * nbatch)
+            try:
+                out["host_wait"] = "runtime (hipStreamSynchronize)" if mods_amd.lib().modsx_debug_host_wait_runtime() else "flag word + naps (MODSX_HOST_WAIT)"
+            except Exception:
+                pass
+            if b2b and host_cpu_split[0] > 0:
+                npz = max(1, args.steps * nbatch)
+                out["host_cpu_split_s_per_pair"] = {"context_threads": host_cpu_split[0] / npz, "other_threads": (host_cpu_headline - host_cpu_split[0]) / npz,
+                                                    "of_which_system_time": host_cpu_split[1] / npz,
+                                                    "note": "context_threads = the threads that drive the contexts (thread CPU clocks); other_threads = verification helpers, "
+                                                            "host pool and the HIP / HSA runtime's own threads; system time = all threads"}
             allowance, lranks = cpu_info()[2], int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
             out["host_threads"] = {"cpu_allowance": allowance, "local_ranks": lranks}
             # what the host can feed: the node's CPU allowance over the CPU-seconds a pair costs a rank's threads.  With N ranks on one

@@ -682,6 +682,9 @@ extern "C" __attribute__((visibility("default"))) int modsx_debug_last_batch_cpu
   return MODSX_OK;
 }
 
+// 1: stage boundaries wait through the runtime (hipStreamSynchronize), 0: through the context's flag word (engine.hip, MODSX_HOST_WAIT)
+extern "C" __attribute__((visibility("default"))) int modsx_debug_host_wait_runtime() { return mx::host_wait_runtime() ? 1 : 0; }
+
 int modsx_last_timings(modsx_ctx *ctx, double *ms6) {
   NEED(ctx); NEED(ms6);
   for (int i = 0; i < 6; i++) ms6[i] = ctx->timings[i];

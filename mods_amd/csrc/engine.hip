@@ -54,6 +54,118 @@ bool PinBuf::ensure(size_t bytes) {
 }
 void PinBuf::release() { if (p) hipHostFree(p); p = nullptr; cap = 0; }
 
+// ---- stage boundaries without the runtime's wait machinery -------------------------------------------------------------------------
+// What a stage boundary costs the HOST was measured in isolation (tools/ubench/host_sync.hip, 16 threads with a stream each, 8
+// kernels + results + wait per iteration, waits of ~3 ms): with hipMemcpyAsync + hipStreamSynchronize 500 us of CPU per
+// iteration (340 in the caller: the runtime watches the signal for 200 us before it sleeps in the kernel driver, and 160 in the
+// runtime's own threads), 3 ms when an H2D hipMemcpyAsync is part of the iteration (the wait then spins to the end) -- against
+// 73 us when the last kernel writes a sequence word into pinned memory and the thread looks at it between naps.  So the hot path
+// neither copies nor waits through the runtime:
+//   ctx_copy   device <-> PINNED host memory by a kernel on the context's stream (system-scope accesses on the host side);
+//   ctx_sync   a one-lane kernel writes the context's next sequence number to its pinned flag word behind everything issued so
+//              far; the thread spins for a few microseconds, then naps (10 us growing to 100 us, timer slack 2 us) until it
+//              sees it.  After 20 s without it hipStreamSynchronize is asked (a faulted queue never writes the flag).
+// In the pipeline the gain is smaller than in isolation (host_wait_runtime below says when it is taken): most of a pair's host CPU
+// is the engine's own loops in the context threads (19-20 of 25 ms), not the waits.
+}  // namespace mx
+#include <sys/prctl.h>
+#include <time.h>
+namespace mx {
+__global__ void k_flag(unsigned *flag, unsigned seq) {
+  __threadfence_system();
+  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// HOST_SRC: the source is pinned host memory -- a system-scope acquire in front of the loads drops whatever an earlier launch left
+// in the caches of those addresses; otherwise the destination is, and a system-scope release follows the stores.  16 bytes per lane
+// (1 KB per wave instruction: the PCIe link sees whole cache lines; 8-byte system-scope atomics per lane moved a 2 MB table at a
+// fifth of the rate and cost the pipeline 10 %).
+template <bool HOST_SRC>
+__global__ __launch_bounds__(256) void k_copy_pinned(uint4 *dst, const uint4 *src, size_t n16, int tail) {
+  if (HOST_SRC) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+  if (tail && blockIdx.x == 0 && threadIdx.x < (unsigned)tail)
+    reinterpret_cast<unsigned char *>(dst + n16)[threadIdx.x] = reinterpret_cast<const unsigned char *>(src + n16)[threadIdx.x];
+  if (!HOST_SRC) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+}
+// MODSX_HOST_WAIT = runtime | flag | auto (default).  Measured on the headline workload (16 contexts, one GPU, 16 CPUs): the flag wait
+// takes 0.0255 -> 0.0215 CPU-s per pair (the runtime's own threads 4.7 -> 2.1 ms, system time 3.7 -> 1.7 ms) and costs 1.2 % of the
+// pairs/s (the naps wake tens of microseconds late at ~30 boundaries per pair).  So the runtime's wait stays where CPUs are plentiful
+// and the flag wait is taken where they are what limits the node: fewer than 8 CPUs for this rank (8 ranks on a 16-CPU allowance).
+bool host_wait_runtime() {
+  static const bool rt = [] {
+    const char *e = getenv("MODSX_HOST_WAIT");
+    if (e && !strcmp(e, "runtime")) return true;
+    if (e && !strcmp(e, "flag")) return false;
+    return host_cpus_per_rank() >= 8;
+  }();
+  return rt;
+}
+hipError_t ctx_copy(modsx_ctx *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+  if (!bytes) return hipSuccess;
+  const bool h2d = kind == hipMemcpyHostToDevice;
+  static const bool rtCopy = [] { const char *e = getenv("MODSX_HOST_COPY"); return e && !strcmp(e, "runtime"); }();
+  // tables above 64 KB stay with the runtime's copy engines: as kernels on the stream they cost the pipeline 3 % (the describe
+  // blobs and candidate lists are megabytes; a copy kernel holds the stream for tens of microseconds that the DMA engine overlaps)
+  static const size_t rtAbove = getenv("MODSX_HOST_COPY_MAX") ? (size_t)atol(getenv("MODSX_HOST_COPY_MAX")) : 65536;
+  if (host_wait_runtime() || rtCopy || bytes > rtAbove || (!h2d && kind != hipMemcpyDeviceToHost) || (((uintptr_t)dst | (uintptr_t)src) & 15))
+    return hipMemcpyAsync(dst, src, bytes, kind, c->stream);
+  const size_t n16 = bytes >> 4;
+  const int tail = (int)(bytes & 15);
+  const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>((n16 + 1023) / 1024, 1), 512);
+  if (h2d) hipLaunchKernelGGL(k_copy_pinned<true>, dim3(grid), dim3(256), 0, c->stream, (uint4 *)dst, (const uint4 *)src, n16, tail);
+  else hipLaunchKernelGGL(k_copy_pinned<false>, dim3(grid), dim3(256), 0, c->stream, (uint4 *)dst, (const uint4 *)src, n16, tail);
+  return hipGetLastError();
+}
+unsigned ctx_mark(modsx_ctx *c) {
+  const unsigned seq = ++c->flagSeq;
+  hipLaunchKernelGGL(k_flag, dim3(1), dim3(1), 0, c->stream, c->hFlag, seq);
+  return seq;
+}
+bool ctx_mark_reached(modsx_ctx *c, unsigned seq) {
+  return (int)(__atomic_load_n(c->hFlag, __ATOMIC_ACQUIRE) - seq) >= 0;
+}
+hipError_t ctx_wait_mark(modsx_ctx *c, unsigned seq) {
+  static const int spinUs = getenv("MODSX_WAIT_SPIN_US") ? atoi(getenv("MODSX_WAIT_SPIN_US")) : 6;
+  static const long napMax = getenv("MODSX_WAIT_NAP_MAX_US") ? atol(getenv("MODSX_WAIT_NAP_MAX_US")) * 1000 : 100000;
+  if (ctx_mark_reached(c, seq)) return hipSuccess;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto us_since = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
+  for (int i = 0;; i++) {
+    if (ctx_mark_reached(c, seq)) return hipSuccess;
+    __builtin_ia32_pause();
+    if ((i & 15) == 15 && us_since() >= spinUs) break;
+  }
+  static thread_local bool slack = false;
+  if (!slack) { prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0); slack = true; }   // the naps below mean what they say (default slack: 50 us)
+  // naps of 10 us growing to 100: 20-30 looks at a wait of 1-3 ms.  (Tried: one long nap sized from the last waits at the same call
+  // site, then close looks -- under 16 streams a stage's wait varies too much, the thread woke late and the pairs/s fell by 3 %;
+  // naps of 5 us throughout: the runtime's throughput for more CPU than the runtime's own wait takes.)
+  long nap = std::min(10000L, napMax);
+  for (int k = 0;; k++) {
+    timespec ts = {0, nap};
+    nanosleep(&ts, nullptr);
+    if (ctx_mark_reached(c, seq)) return hipSuccess;
+    if ((k & 1) && nap < napMax) nap = std::min(nap * 2, napMax);
+    if ((k & 255) == 255 && us_since() > 20e6) break;
+  }
+  const hipError_t e = hipStreamSynchronize(c->stream);     // a queue that faulted never writes the flag: let the runtime say what happened
+  if (e == hipSuccess && !ctx_mark_reached(c, seq)) return hipErrorUnknown;
+  return e;
+}
+hipError_t ctx_sync(modsx_ctx *c) {
+  if (host_wait_runtime() || !c->hFlag) return hipStreamSynchronize(c->stream);
+  const unsigned seq = ctx_mark(c);
+  const hipError_t le = hipGetLastError();
+  if (le != hipSuccess) return le;
+  return ctx_wait_mark(c, seq);
+}
+
 // ---- per-kernel-class GPU timing with HIP events on the launch stream ------------------------------
 struct ProfScope {
   modsx_ctx *c;
@@ -262,6 +374,8 @@ modsx_ctx *ctx_create(int device_id) {
   c->dev = device_id;
   if (hipStreamCreate(&c->stream) != hipSuccess) { set_error("hipStreamCreate failed"); delete c; return nullptr; }
   for (int i = 0; i < 2; i++) hipEventCreateWithFlags(&c->descEv[i], hipEventDisableTiming);
+  if (hipHostMalloc((void **)&c->hFlag, 64, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); hipStreamDestroy(c->stream); delete c; return nullptr; }
+  c->hFlag[0] = 0; c->flagSeq = 0;
   for (int i = 0; i < 6; i++) c->timings[i] = 0;
   if (upload_tables(c) != MODSX_OK) { delete c; return nullptr; }
   return c;
@@ -290,6 +404,7 @@ void ctx_destroy(modsx_ctx *c) {
   for (int i = 0; i < 2; i++) hipEventDestroy(c->descEv[i]);
   c->hDescB.release(); c->hRefs.release();
   hipStreamDestroy(c->stream);
+  if (c->hFlag) hipHostFree(c->hFlag);
   delete c;
 }
 
@@ -464,9 +579,9 @@ int build_pyramids(modsx_ctx *c, const modsx_image *const *imgs, int n, const mo
           const int nx = cols == 1 ? 1 : nt, ny = rows == 1 ? 1 : nt;
           if (!tapsUp || nx != nt || ny != nt) {
             std::vector<float> kx = gaussian_kernel(nx, sigma), ky = gaussian_kernel(ny, sigma);
-            if (tapsUp) MX_HIP(hipStreamSynchronize(s));      // a degenerate (one-row / one-column) level re-uses the slice
+            if (tapsUp) MX_HIP(ctx_sync(c));      // a degenerate (one-row / one-column) level re-uses the slice
             memcpy(hT, kx.data(), nx * 4); memcpy(hT + nx, ky.data(), ny * 4);
-            MX_HIP(hipMemcpyAsync(dT, hT, (size_t)(nx + ny) * 4, hipMemcpyHostToDevice, s));
+            MX_HIP(ctx_copy(c, dT, hT, (size_t)(nx + ny) * 4, hipMemcpyHostToDevice));
             tapsUp = nx == nt && ny == nt;
           }
           auto blur = [&](const float *src, float *dst) {
@@ -539,7 +654,7 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
     memcpy(c->hNms.p, hjobs.data(), jobBytes);
     memcpy((char *)c->hNms.p + jobBytes, hpfx.data(), pfxBytes);
     if (!hfirst.empty()) memcpy((char *)c->hNms.p + jobBytes + pfxBytes, hfirst.data(), hfirst.size() * 4);
-    MX_HIP(hipMemcpyAsync(c->nmsJobs.p, c->hNms.p, jobBytes + pfxBytes + firstBytes, hipMemcpyHostToDevice, s));
+    MX_HIP(ctx_copy(c, c->nmsJobs.p, c->hNms.p, jobBytes + pfxBytes + firstBytes, hipMemcpyHostToDevice));
     if (!c->tileJob.ensure((size_t)hpfx.back() * 4 + 4)) return MODSX_ERR_NOMEM;
     const int *dPfx = (const int *)((char *)c->nmsJobs.p + jobBytes);
     launch_expand_tiles(s, dPfx, np, (int *)c->tileJob.p);
@@ -553,7 +668,7 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
                  p.numberOfScales);
     }
     // the host tables are reused by the next flush; after the last one the counter read-back below waits for the launch
-    if (!last) MX_HIP(hipStreamSynchronize(s));
+    if (!last) MX_HIP(ctx_sync(c));
     hjobs.clear(); hpfx.assign(1, 0); hfirst.clear(); px = 0;
     return MODSX_OK;
   };
@@ -629,9 +744,9 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
                             (Candidate *)c->candOut.p, survivors)) { set_error("device-side detection order failed"); return MODSX_ERR_DEVICE; }
       const size_t spec = std::min<size_t>(nsort, c->lastSurvivors + c->lastSurvivors / 4 + 1024);
       if (!c->hCand.ensure(std::max<size_t>(spec, 1) * sizeof(Candidate))) return MODSX_ERR_NOMEM;
-      MX_HIP(hipMemcpyAsync(c->hMisc.p, c->counter.p, 12, hipMemcpyDeviceToHost, s));
-      MX_HIP(hipMemcpyAsync(c->hCand.p, c->candOut.p, spec * sizeof(Candidate), hipMemcpyDeviceToHost, s));
-      MX_HIP(hipStreamSynchronize(s));
+      MX_HIP(ctx_copy(c, c->hMisc.p, c->counter.p, 12, hipMemcpyDeviceToHost));
+      MX_HIP(ctx_copy(c, c->hCand.p, c->candOut.p, spec * sizeof(Candidate), hipMemcpyDeviceToHost));
+      MX_HIP(ctx_sync(c));
       const unsigned cnt = ((unsigned *)c->hMisc.p)[0], nsurv = ((unsigned *)c->hMisc.p)[2];
       if (cnt > CAND_CAP || ((unsigned *)c->hMisc.p)[1]) { set_error("candidate buffer overflow"); return MODSX_ERR_NOMEM; }
       c->lastCandCount = cnt;
@@ -642,8 +757,8 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
       c->lastSurvivors = nsurv;
       if (nsurv > spec) {
         if (!c->hCand.ensure((size_t)nsurv * sizeof(Candidate))) return MODSX_ERR_NOMEM;   // (re-allocation loses the first part: copy all)
-        MX_HIP(hipMemcpyAsync(c->hCand.p, c->candOut.p, (size_t)nsurv * sizeof(Candidate), hipMemcpyDeviceToHost, s));
-        MX_HIP(hipStreamSynchronize(s));
+        MX_HIP(ctx_copy(c, c->hCand.p, c->candOut.p, (size_t)nsurv * sizeof(Candidate), hipMemcpyDeviceToHost));
+        MX_HIP(ctx_sync(c));
       }
       HostMark hm;
       const Candidate *cd = (const Candidate *)c->hCand.p;
@@ -684,16 +799,16 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
   if (!c->hMisc.ensure(64)) return MODSX_ERR_NOMEM;
   const size_t spec = std::min<size_t>(CAND_CAP, c->lastCandCount + c->lastCandCount / 4 + 1024);
   if (!c->hCand.ensure(spec * sizeof(Candidate))) return MODSX_ERR_NOMEM;
-  MX_HIP(hipMemcpyAsync(c->hMisc.p, c->counter.p, 8, hipMemcpyDeviceToHost, s));
-  MX_HIP(hipMemcpyAsync(c->hCand.p, c->cand.p, spec * sizeof(Candidate), hipMemcpyDeviceToHost, s));
-  MX_HIP(hipStreamSynchronize(s));
+  MX_HIP(ctx_copy(c, c->hMisc.p, c->counter.p, 8, hipMemcpyDeviceToHost));
+  MX_HIP(ctx_copy(c, c->hCand.p, c->cand.p, spec * sizeof(Candidate), hipMemcpyDeviceToHost));
+  MX_HIP(ctx_sync(c));
   unsigned cnt = *(unsigned *)c->hMisc.p;
   if (cnt > CAND_CAP || ((unsigned *)c->hMisc.p)[1]) { set_error("candidate buffer overflow"); return MODSX_ERR_NOMEM; }
   c->lastCandCount = cnt;
   if (cnt > spec) {
     if (!c->hCand.ensure((size_t)cnt * sizeof(Candidate))) return MODSX_ERR_NOMEM;   // (re-allocation loses the first part: copy all)
-    MX_HIP(hipMemcpyAsync(c->hCand.p, c->cand.p, (size_t)cnt * sizeof(Candidate), hipMemcpyDeviceToHost, s));
-    MX_HIP(hipStreamSynchronize(s));
+    MX_HIP(ctx_copy(c, c->hCand.p, c->cand.p, (size_t)cnt * sizeof(Candidate), hipMemcpyDeviceToHost));
+    MX_HIP(ctx_sync(c));
   }
   HostMark hm;
   const Candidate *cd = (const Candidate *)c->hCand.p;
@@ -861,12 +976,12 @@ int detect_keypoints_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, 
   });
   hm.mark("AffJob build");
   if (p.doBaumberg) {
-    MX_HIP(hipMemcpyAsync(c->affJobs.p, hj, total * sizeof(AffJob), hipMemcpyHostToDevice, s));
+    MX_HIP(ctx_copy(c, c->affJobs.p, hj, total * sizeof(AffJob), hipMemcpyHostToDevice));
     ProfScope ps(c, K_BAUMBERG, (double)total * 361 * 4 * 2);
     launch_baumberg(s, (AffJob *)c->affJobs.p, (AffOut *)c->affOut.p, (int)total, c->dSmmMask, p.smmWindowSize,
                     p.maxIterations, p.convergenceThreshold, p.affInitialSigma);
-    MX_HIP(hipMemcpyAsync(ho, c->affOut.p, total * sizeof(AffOut), hipMemcpyDeviceToHost, s));
-    MX_HIP(hipStreamSynchronize(s));
+    MX_HIP(ctx_copy(c, ho, c->affOut.p, total * sizeof(AffOut), hipMemcpyDeviceToHost));
+    MX_HIP(ctx_sync(c));
   } else {
     for (size_t i = 0; i < total; i++) { ho[i].u11 = 1; ho[i].u12 = 0; ho[i].u21 = 0; ho[i].u22 = 1; ho[i].ok = 1; ho[i].iters = 0; }
   }
@@ -946,7 +1061,7 @@ static int upload_img_refs(modsx_ctx *c, const modsx_image *const *imgs, int n) 
   // in a synchronize), so the previous table's copy has long completed when this buffer is written again
   if (!c->hRefs.ensure(sizeof refs)) return MODSX_ERR_NOMEM;
   memcpy(c->hRefs.p, refs, sizeof refs);
-  MX_HIP(hipMemcpyAsync(c->imgRefs.p, c->hRefs.p, sizeof refs, hipMemcpyHostToDevice, c->stream));
+  MX_HIP(ctx_copy(c, c->imgRefs.p, c->hRefs.p, sizeof refs, hipMemcpyHostToDevice));
   memcpy(c->imgRefsHost, refs, sizeof refs);
   return MODSX_OK;
 }
@@ -1005,12 +1120,12 @@ int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n
     memcpy(c->hOri.p, jobs.data(), nj * sizeof(OriJob));
     float *hres = (float *)((char *)c->hOri.p + nj * sizeof(OriJob));
     res = hres;
-    MX_HIP(hipMemcpyAsync(c->oriJobs.p, c->hOri.p, nj * sizeof(OriJob), hipMemcpyHostToDevice, s));
+    MX_HIP(ctx_copy(c, c->oriJobs.p, c->hOri.p, nj * sizeof(OriJob), hipMemcpyHostToDevice));
     ProfScope ps(c, K_ORIENT, (double)nj * 41 * 41 * 4);
     launch_orientation(s, (OriJob *)c->oriJobs.p, (float *)c->oriOut.p, (int)nj, (ImgRef *)c->imgRefs.p, c->dOriIdx,
                        c->dOriMask, c->dOriBinTab, doHalfSIFT, th, maxA);
-    MX_HIP(hipMemcpyAsync(hres, c->oriOut.p, nj * oriB, hipMemcpyDeviceToHost, s));
-    MX_HIP(hipStreamSynchronize(s));
+    MX_HIP(ctx_copy(c, hres, c->oriOut.p, nj * oriB, hipMemcpyDeviceToHost));
+    MX_HIP(ctx_sync(c));
   }
   hm.mark("orientation launch + wait");
   host_parallel_light(n, [&](int i) {
@@ -1349,7 +1464,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       // two staging blobs in turn: the copy of chunk k may still be in flight while chunk k + 1 is being prepared
       const int slot = chunkNo & 1;
       PinBuf &hblob = slot ? c->hDescB : c->hDesc;
-      if (c->descEvPending[slot]) { MX_HIP(hipEventSynchronize(c->descEv[slot])); c->descEvPending[slot] = false; }
+      if (c->descEvPending[slot]) { MX_HIP(host_wait_runtime() ? hipEventSynchronize(c->descEv[slot]) : ctx_wait_mark(c, c->descMark[slot])); c->descEvPending[slot] = false; }
       if (!c->descJobs.ensure(blobB) || !hblob.ensure(blobB) ||
           !c->scratchA.ensure(std::max<size_t>(1, arenaA) * 4) || !c->scratchB.ensure(std::max<size_t>(1, arenaB) * 4) ||
           !c->scratchC.ensure(std::max<size_t>(1, arenaC) * 4) || !c->rowStarts.ensure(std::max<size_t>(1, rowStarts) * 8) ||
@@ -1366,8 +1481,8 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       if (!needTab.empty()) memcpy(hb + oNeed, needTab.data(), needTab.size() * 4);
       if (!coordTab.empty()) memcpy(hb + oCoord, coordTab.data(), coordTab.size() * 4);
       hm.mark("desc tables + blob");
-      MX_HIP(hipMemcpyAsync(db, hb, blobB, hipMemcpyHostToDevice, s));
-      MX_HIP(hipEventRecord(c->descEv[slot], s));
+      MX_HIP(ctx_copy(c, db, hb, blobB, hipMemcpyHostToDevice));
+      if (host_wait_runtime()) MX_HIP(hipEventRecord(c->descEv[slot], s)); else c->descMark[slot] = ctx_mark(c);
       c->descEvPending[slot] = true;
       int *dPfxS = (int *)(db + oPfx), *dPfxR = (int *)(db + oPfx + pfxB), *dPfxC = (int *)(db + oPfx + 2 * pfxB);
       int *dPfxRL = (int *)(db + oPfx + 3 * pfxB), *dPfxCL = (int *)(db + oPfx + 4 * pfxB);
@@ -1402,7 +1517,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
     }
   }
   hm.mark("desc launches");
-  MX_HIP(hipStreamSynchronize(s));   // callers read the descriptor buffers and reuse the staging blobs
+  MX_HIP(ctx_sync(c));   // callers read the descriptor buffers and reuse the staging blobs
   hm.mark("desc wait");
   c->descEvPending[0] = c->descEvPending[1] = false;
   if (descHost) {
@@ -1471,7 +1586,7 @@ int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int
     char *hpos = (char *)c->hMatch.p, *hrow = hpos ? hpos + posB : nullptr;
     if (!lrc) {
       memcpy(hpos, pos2Host[0], (size_t)M * 16);
-      if (hipMemcpyAsync(c->pos2.p, hpos, (size_t)M * 16, hipMemcpyHostToDevice, s) != hipSuccess) { set_error("sharded match: upload failed"); lrc = MODSX_ERR_DEVICE; }
+      if (ctx_copy(c, c->pos2.p, hpos, (size_t)M * 16, hipMemcpyHostToDevice) != hipSuccess) { set_error("sharded match: upload failed"); lrc = MODSX_ERR_DEVICE; }
     }
     if (!lrc && nloc > 0) {
       ProfScope ps(c, K_MATCH, 2.0 * nloc * (double)M * 128);
@@ -1517,7 +1632,7 @@ int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int
     if (!pos2Dev) memcpy(hpos + posOfs[k], pos2Host[i], (size_t)n2[i] * 16);
     work += 2.0 * n1[i] * (double)n2[i] * 128;
   }
-  if (!pos2Dev) MX_HIP(hipMemcpyAsync(c->pos2.p, hpos, posB, hipMemcpyHostToDevice, s));
+  if (!pos2Dev) MX_HIP(ctx_copy(c, c->pos2.p, hpos, posB, hipMemcpyHostToDevice));
   {
     // K_MATCH = every launch of the problem(s); K_MATCH_SWEEP1 = the one launch that carries the 2 N M 128 contraction
     hipEvent_t evS1[2];
@@ -1525,8 +1640,8 @@ int match_device_batch(modsx_ctx *c, int nb, const uint8_t *const *d1, const int
     ProfScope ps(c, K_MATCH, work);
     launch_match_batch(s, nl, pd1, pn1, pd2, pn2, ppos, sqminratio, contrDistSq, nn, prow, pwork, tS1 ? evS1 : nullptr);
   }
-  MX_HIP(hipMemcpyAsync(hrow, c->matchRows.p, rowB, hipMemcpyDeviceToHost, s));
-  MX_HIP(hipStreamSynchronize(s));
+  MX_HIP(ctx_copy(c, hrow, c->matchRows.p, rowB, hipMemcpyDeviceToHost));
+  MX_HIP(ctx_sync(c));
   MX_HIP(hipGetLastError());
   for (int k = 0; k < nl; k++) rows_to_tentatives((const MatchRow *)(hrow + rowOfs[k]), pn1[k], nn, out[live[k]]);
   return MODSX_OK;

@@ -170,6 +170,15 @@ void set_error(const std::string &s);
 // CUs with the other contexts' and stay good neighbours (the fat shape waits for a drained CU there: -0.4 % pairs/s under 16 streams).
 bool gpu_shared();
 struct CtxBusy { modsx_ctx *c; explicit CtxBusy(modsx_ctx *c); ~CtxBusy(); CtxBusy(const CtxBusy &) = delete; CtxBusy &operator=(const CtxBusy &) = delete; };
+// stage boundaries without the runtime's copy / wait calls (engine.hip): a kernel copies between device and PINNED host memory,
+// a one-lane kernel writes a sequence number into the context's pinned flag word, the host thread naps until it sees it
+hipError_t ctx_copy(modsx_ctx *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
+hipError_t ctx_sync(modsx_ctx *c);
+unsigned ctx_mark(modsx_ctx *c);
+bool ctx_mark_reached(modsx_ctx *c, unsigned seq);
+hipError_t ctx_wait_mark(modsx_ctx *c, unsigned seq);
+bool host_wait_runtime();
+int host_cpus_per_rank();      // mser.cpp: CPUs this process may use (cgroup allowance / local ranks)
 #define MX_HIP(expr)                                                                          \
   do {                                                                                        \
     hipError_t e_ = (expr);                                                                   \
@@ -305,6 +314,9 @@ struct modsx_ctx {
   mx::PinBuf hDescB;           // second staging blob of describe_batch: chunk k + 1 is prepared while chunk k runs
   hipEvent_t descEv[2];
   bool descEvPending[2] = {false, false};
+  unsigned descMark[2] = {0, 0};   // ... as sequence numbers of the context's flag word (ctx_mark) when the runtime's waits are not used
+  unsigned *hFlag = nullptr;   // pinned word the stream's flag kernel writes (ctx_sync, engine.hip)
+  unsigned flagSeq = 0;        // last sequence number issued
   mx::PinBuf hCand, hAff, hOri, hDesc, hMisc, hNms, hMatch, hViewTaps, hViewJobs, hMser, hRefs;
   // constant tables on device
   float *dSmmMask = nullptr;   // 19x19 computeGaussMask

@@ -220,7 +220,7 @@ static int synth_views_batch(modsx_ctx *c, const modsx_image *const *grays, cons
   char *hb = (char *)c->hViewJobs.p;
   memcpy(hb, jobs.data(), jobB);
   if (!taps.empty()) memcpy(hb + jobB, taps.data(), taps.size() * 4);
-  MX_HIP(hipMemcpyAsync(c->viewJobs.p, hb, jobB + tapB, hipMemcpyHostToDevice, s));
+  MX_HIP(ctx_copy(c, c->viewJobs.p, hb, jobB + tapB, hipMemcpyHostToDevice));
   const ViewJob *dj = (const ViewJob *)c->viewJobs.p;
   const float *dt = (const float *)((char *)c->viewJobs.p + jobB);
   size_t pslot;
@@ -254,7 +254,7 @@ int synth_view(modsx_ctx *c, const modsx_image *gray, const modsx_view &v, modsx
   if (hipMalloc(&im->d, (size_t)P.ow * P.oh * 4) != hipSuccess) { delete im; set_error("hipMalloc view"); return MODSX_ERR_NOMEM; }
   float *dst[1] = {im->d};
   rc = synth_views_batch(c, &gray, &P, dst, 1);
-  if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("view synthesis failed"); rc = MODSX_ERR_DEVICE; }
+  if (!rc && ctx_sync(c) != hipSuccess) { set_error("view synthesis failed"); rc = MODSX_ERR_DEVICE; }
   if (rc) { hipFree(im->d); delete im; return rc; }
   *out = im;
   return MODSX_OK;
@@ -333,8 +333,8 @@ int detect_describe_items(modsx_ctx *c, const modsx_image *const *itemImg, const
         if (!c->misc.ensure(tot + 64) || !c->hMser.ensure(tot + 64)) rc = MODSX_ERR_NOMEM;
         for (int i = 0; i < n && !rc; i++)
           launch_trunc_u8(c->stream, cimg[i]->d, (uint8_t *)c->misc.p + ofs[i], (size_t)cimg[i]->rows * cimg[i]->cols);
-        if (!rc && (hipMemcpyAsync(c->hMser.p, c->misc.p, tot, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                    hipStreamSynchronize(c->stream) != hipSuccess)) { set_error("MSER view download failed"); rc = MODSX_ERR_DEVICE; }
+        if (!rc && (ctx_copy(c, c->hMser.p, c->misc.p, tot, hipMemcpyDeviceToHost) != hipSuccess ||
+                    ctx_sync(c) != hipSuccess)) { set_error("MSER view download failed"); rc = MODSX_ERR_DEVICE; }
         const double tdl = tnow();
         if (!rc) {
           const uint8_t *src[MAXB];
@@ -402,7 +402,7 @@ int detect_describe_items(modsx_ctx *c, const modsx_image *const *itemImg, const
           host_parallel_light(n, [&](int i) { if (!ro[i].empty()) memcpy(regs.data() + at[i], ro[i].data(), ro[i].size() * sizeof(modsx_region)); });
           total += at[n] - at[0];
         }
-        hipStreamSynchronize(c->stream);
+        if (hostDesc) hipStreamSynchronize(c->stream);    // (copies into the caller's pageable memory; everything else was waited for by describe_batch)
         if (tim2) fprintf(stderr, "  host %-28s %.3f ms\n", "region list append", tnow() - tq);
       }
     }
@@ -537,7 +537,7 @@ static int accumulate_views(modsx_ctx *c, LadderClass *const *ks, const DescSet 
       if (!bigger.ensure(cap * 128)) return MODSX_ERR_NOMEM;
       if (base[j]) {
         MX_HIP(hipMemcpyAsync(bigger.p, buf.p, base[j] * 128, hipMemcpyDeviceToDevice, c->stream));
-        MX_HIP(hipStreamSynchronize(c->stream));
+        MX_HIP(ctx_sync(c));
       }
       buf.release();
       buf = bigger;
@@ -637,7 +637,7 @@ static int accumulate_views(modsx_ctx *c, LadderClass *const *ks, const DescSet 
           at += part[p].size();
           for (int v = cut[p]; v < cut[p + 1]; v++) counts[v] = cnt[p][v];
         }
-        MX_HIP(hipStreamSynchronize(c->stream));
+        MX_HIP(ctx_sync(c));
         step.reserve(total);
         for (int p = 1; p < P; p++) step.insert(step.end(), part[p].begin(), part[p].end());
         append();

@@ -45,30 +45,35 @@ __global__ __launch_bounds__(64) void k_expand_tiles(const int *prefix, int nJob
 
 // tile descriptors of the LDS blur kernels: everything a workgroup needs in one 48-byte scalar load, so that its first
 // vector loads (the inputs it parks in LDS) are two dependent round trips from the launch instead of three
-// (blockIdx.y = pass: 0 = the row tiles of the fused sampling kernel, 1 = the tiles of the column filter)
-__global__ __launch_bounds__(64) void k_expand_blur_tiles(const DescJob *jobs, const int *prefix0, const int *prefix1, int nJobs,
-                                                          const int *needTab, BlurTile *tiles0, BlurTile *tiles1, float2 *rowStart) {
-  const int j = blockIdx.x, pass = blockIdx.y;
+// (blockIdx.y = 0: the row tiles of the fused sampling kernel, 1: the tiles of the column filter, 2: the windows' row starts)
+// One THREAD per job: a workgroup per job (round 5) was 2 x 12 k one-wave workgroups of a few stores each per chunk, 27 us of
+// dispatch for 2 us of work.
+__global__ __launch_bounds__(256) void k_expand_blur_tiles(const DescJob *jobs, const int *prefix0, const int *prefix1, int nJobs,
+                                                           const int *needTab, BlurTile *tiles0, BlurTile *tiles1, float2 *rowStart) {
+  const int j = blockIdx.x * 256 + threadIdx.x, pass = blockIdx.y;
   if (j >= nJobs) return;
-  const int *prefix = pass ? prefix1 : prefix0;
-  BlurTile *tiles = pass ? tiles1 : tiles0;
+  const int *prefix = pass == 1 ? prefix1 : prefix0;
   const int b = prefix[j], e = prefix[j + 1];
-  if (b == e) return;
-  const DescJob jb = jobs[j];
-  const int R = jb.ksize >> 1;
-  if (pass == 0 && threadIdx.x == 63) {
+  if (pass == 2) {
     // row starts of interpolate() (rx += a12, ry += a22 per row, helpers.cpp:563-566): one serial chain per window, run
     // here once instead of by every row tile of the fused sampling kernel (a tile of a large window is a few rows only)
+    if (b == e) return;
+    const DescJob jb = jobs[j];
     float2 *rs = rowStart + jb.scratchOfs;
     const int half = jb.P >> 1;
     float rx = jb.x - (float)half * jb.a12, ry = jb.y - (float)half * jb.a22;
     for (int r = 0; r < jb.P; r++) { rs[r] = make_float2(rx, ry); rx += jb.a12; ry += jb.a22; }
+    return;
   }
-  for (int t = b + threadIdx.x; t < e; t += 64) {
-    BlurTile bt;
-    bt.P = jb.P; bt.NC = jb.NC; bt.n = jb.ksize; bt.tapOfs = jb.tapOfs; bt.needOfs = jb.needOfs;
-    bt.job = j; bt.pad = 0;
-    { const int NP = (jb.NC + 1) >> 1; bt.magic = ((1 << 20) + NP - 1) / NP; }
+  if (b == e) return;
+  BlurTile *tiles = pass ? tiles1 : tiles0;
+  const DescJob jb = jobs[j];
+  const int R = jb.ksize >> 1;
+  BlurTile bt;
+  bt.P = jb.P; bt.NC = jb.NC; bt.n = jb.ksize; bt.tapOfs = jb.tapOfs; bt.needOfs = jb.needOfs;
+  bt.job = j; bt.pad = 0;
+  { const int NP = (jb.NC + 1) >> 1; bt.magic = ((1 << 20) + NP - 1) / NP; }
+  for (int t = b; t < e; t++) {
     if (pass == 0) {
       const int r0 = (t - b) * jb.rows0;
       bt.count = jb.P - r0 < jb.rows0 ? jb.P - r0 : jb.rows0;
@@ -1085,7 +1090,7 @@ void launch_patch_sample(hipStream_t s, const DescJob *jobs, const int *tilePref
 }
 void launch_expand_blur_tiles(hipStream_t s, const DescJob *jobs, const int *prefixRows, const int *prefixCols, int nJobs,
                               const int *needTab, BlurTile *tilesRows, BlurTile *tilesCols, float2 *rowStarts) {
-  if (nJobs > 0) MX_DUP(K_PATCH_SAMPLE) hipLaunchKernelGGL(k_expand_blur_tiles, dim3(nJobs, 2), dim3(64), 0, s, jobs, prefixRows, prefixCols, nJobs, needTab,
+  if (nJobs > 0) MX_DUP(K_PATCH_SAMPLE) hipLaunchKernelGGL(k_expand_blur_tiles, dim3((nJobs + 255) / 256, 3), dim3(256), 0, s, jobs, prefixRows, prefixCols, nJobs, needTab,
                                     tilesRows, tilesCols, rowStarts);
 }
 void launch_sample_rows(hipStream_t s, const DescJob *jobs, const BlurTile *tiles, int nTiles, const ImgRef *imgs, const float *taps,

@@ -386,6 +386,28 @@ static void mser_export(std::vector<modsx_keypoint> &out, const modsx_mser_param
   }
 }
 
+// CPUs this process may use: the host's threads, capped by the container's allowance (cgroup v2 cpu.max, v1 cfs quota -- the GPU
+// boxes show 256 logical CPUs and allow 16), divided by the ranks that share the host (torchrun / mpirun export the local world size)
+int host_cpus_per_rank() {
+  int n = (int)std::thread::hardware_concurrency();
+  double quota = 0;
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64]; double per = 0;
+    if (fscanf(f, "%63s %lf", q, &per) == 2 && strcmp(q, "max") && per > 0) quota = atof(q) / per;
+    fclose(f);
+  } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+    double qv = 0, per = 0;
+    if (fscanf(g, "%lf", &qv) == 1 && qv > 0) {
+      if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lf", &per) == 1 && per > 0) quota = qv / per; fclose(h); }
+    }
+    fclose(g);
+  }
+  if (quota >= 1) n = std::min(n, (int)(quota + 0.5));
+  for (const char *v : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MV2_COMM_WORLD_LOCAL_SIZE"})
+    if (const char *e = getenv(v)) { const int w = atoi(e); if (w > 1) { n = std::max(1, n / w); break; } }
+  return std::max(1, n);
+}
+
 // ---- host worker pool: the (view, polarity) component trees of a view set are independent (the reference runs one view
 // per OpenMP thread, imagerepresentation.cpp:612-622, with threadprivate MSER globals) -------------------------------------
 namespace {
@@ -428,24 +450,7 @@ class HostPool {
     // process per GPU, 8 per node), capped by OMP_NUM_THREADS when the launcher set one; MODSX_HOST_THREADS overrides
     // ... of the CPUs this process may actually use: a container's allowance (cgroup v2 cpu.max, v1 cfs quota) is what the
     // GPU boxes limit (256 logical CPUs visible, 16 allowed) -- threads beyond it only buy throttling
-    int n = (int)std::thread::hardware_concurrency();
-    {
-      double quota = 0;
-      if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-        char q[64]; double per = 0;
-        if (fscanf(f, "%63s %lf", q, &per) == 2 && strcmp(q, "max") && per > 0) quota = atof(q) / per;
-        fclose(f);
-      } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
-        double qv = 0, per = 0;
-        if (fscanf(g, "%lf", &qv) == 1 && qv > 0) {
-          if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lf", &per) == 1 && per > 0) quota = qv / per; fclose(h); }
-        }
-        fclose(g);
-      }
-      if (quota >= 1) n = std::min(n, (int)(quota + 0.5));
-    }
-    for (const char *v : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MV2_COMM_WORLD_LOCAL_SIZE"})
-      if (const char *e = getenv(v)) { const int w = atoi(e); if (w > 1) { n = std::max(1, n / w); break; } }
+    int n = host_cpus_per_rank();
     if (const char *e = getenv("OMP_NUM_THREADS")) { const int o = atoi(e); if (o > 0) n = std::min(n, std::max(o, 4)); }
     if (const char *e = getenv("MODSX_HOST_THREADS")) n = atoi(e);
     if (const char *e = getenv("MODSX_HOST_SPIN_US")) spinUs_ = atoi(e);
