@@ -153,13 +153,51 @@ struct Forest {
   void run() {
     const size_t npx = (size_t)(rows + 2) * stride;
     node.resize(npx); parent.assign(npx, -1);
-    // bin sort: offsets per grey level in raster order (sortPixels.cpp:76-125)
+    parent[0] = 0;     // the sentinel chain of the neighbour look-ups below: offset 0 is a frame pixel, never visited
+    // bin sort: offsets per grey level in raster order (sortPixels.cpp:76-125).  The rows are cut into NS strips that are counted and
+    // scattered side by side: neighbouring pixels mostly share their grey level, and one counter per level makes every step wait
+    // for the store of the step before it (a store-to-load forward per pixel); NS independent counters per level do not.
+    constexpr int NS = 4;
     std::vector<int> start(257, 0);
-    for (int r = 1; r <= rows; r++) { const uint8_t *g = grey + (size_t)r * stride; for (int c = 1; c <= cols; c++) start[g[c] + 1]++; }
-    for (int l = 0; l < 256; l++) start[l + 1] += start[l];
+    static thread_local std::vector<int> cnt;
+    cnt.assign((size_t)NS * 256, 0);
+    int rb[NS + 1];
+    for (int q = 0; q <= NS; q++) rb[q] = 1 + (int)((long)rows * q / NS);
+    {
+      int *c0 = &cnt[0], *c1 = &cnt[256], *c2 = &cnt[512], *c3 = &cnt[768];
+      const int len = rb[1] - rb[0];                    // strips 0..2 have len or len + 1 rows; walk `len` rows of all four together
+      for (int i = 0; i < len; i++) {
+        const uint8_t *g0 = grey + (size_t)(rb[0] + i) * stride, *g1 = grey + (size_t)(rb[1] + i) * stride;
+        const uint8_t *g2 = grey + (size_t)(rb[2] + i) * stride, *g3 = grey + (size_t)(rb[3] + i) * stride;
+        for (int c = 1; c <= cols; c++) { c0[g0[c]]++; c1[g1[c]]++; c2[g2[c]]++; c3[g3[c]]++; }
+      }
+      for (int q = 0; q < NS; q++)
+        for (int r = rb[q] + len; r < rb[q + 1]; r++) { const uint8_t *g = grey + (size_t)r * stride; int *cq = &cnt[q * 256]; for (int c = 1; c <= cols; c++) cq[g[c]]++; }
+    }
+    for (int l = 0; l < 256; l++) {                     // level l: strip 0's pixels, then strip 1's, ... = raster order
+      int at = start[l];
+      for (int q = 0; q < NS; q++) { const int n = cnt[q * 256 + l]; cnt[q * 256 + l] = at; at += n; }
+      start[l + 1] = at;
+    }
     order.resize((size_t)rows * cols);
-    std::vector<int> fill(start.begin(), start.end() - 1);
-    for (int r = 1; r <= rows; r++) { const uint8_t *g = grey + (size_t)r * stride; const int o0 = r * stride; for (int c = 1; c <= cols; c++) order[fill[g[c]]++] = o0 + c; }
+    {
+      int *ord = order.data();
+      int *c0 = &cnt[0], *c1 = &cnt[256], *c2 = &cnt[512], *c3 = &cnt[768];
+      const int len = rb[1] - rb[0];
+      for (int i = 0; i < len; i++) {
+        const int r0 = rb[0] + i, r1 = rb[1] + i, r2 = rb[2] + i, r3 = rb[3] + i;
+        const uint8_t *g0 = grey + (size_t)r0 * stride, *g1 = grey + (size_t)r1 * stride, *g2 = grey + (size_t)r2 * stride, *g3 = grey + (size_t)r3 * stride;
+        const int o0 = r0 * stride, o1 = r1 * stride, o2 = r2 * stride, o3 = r3 * stride;
+        for (int c = 1; c <= cols; c++) {
+          ord[c0[g0[c]]++] = o0 + c; ord[c1[g1[c]]++] = o1 + c; ord[c2[g2[c]]++] = o2 + c; ord[c3[g3[c]]++] = o3 + c;
+        }
+      }
+      for (int q = 0; q < NS; q++)
+        for (int r = rb[q] + len; r < rb[q + 1]; r++) {
+          const uint8_t *g = grey + (size_t)r * stride; int *cq = &cnt[q * 256]; const int o = r * stride;
+          for (int c = 1; c <= cols; c++) ord[cq[g[c]]++] = o + c;
+        }
+    }
     static const int PF = getenv("MODSX_MSER_PF") ? atoi(getenv("MODSX_MSER_PF")) : 12;
     int lastRoot = -1;
     for (int level = 0; level < 256; level++)
@@ -168,16 +206,26 @@ struct Forest {
         if (k + PF < start[256]) { const int f = order[k + PF]; __builtin_prefetch(&parent[f - stride]); __builtin_prefetch(&parent[f]); __builtin_prefetch(&parent[f + stride]); }
         const int nb[4] = {ofs - stride, ofs - 1, ofs + 1, ofs + stride};
         int roots[4], nroots = 0, touching = 0;
-        for (int q = 0; q < 4; q++) {
-          const int pq = parent[nb[q]];
-          if (pq < 0) continue;
-          touching++;
-          // inside a component the neighbours already point at (or one step from) the root found for an earlier neighbour
-          if (nroots && (pq == roots[nroots - 1] || parent[pq] == roots[nroots - 1]) && parent[roots[nroots - 1]] == roots[nroots - 1]) continue;
-          const int r = find(nb[q]);
-          bool dup = false;
-          for (int z = 0; z < nroots; z++) dup = dup || roots[z] == r;
-          if (!dup) roots[nroots++] = r;
+        {
+          // the common case without a data-dependent branch per neighbour: an unseen neighbour reads the sentinel chain 0 -> 0
+          // (offset 0 is a frame pixel, never visited), a seen one is at most two steps from its root in a compressed forest
+          const int p0 = parent[nb[0]], p1 = parent[nb[1]], p2 = parent[nb[2]], p3 = parent[nb[3]];
+          touching = (p0 >= 0) + (p1 >= 0) + (p2 >= 0) + (p3 >= 0);
+          const int a0 = p0 < 0 ? 0 : p0, a1 = p1 < 0 ? 0 : p1, a2 = p2 < 0 ? 0 : p2, a3 = p3 < 0 ? 0 : p3;
+          const int r0 = parent[a0], r1 = parent[a1], r2 = parent[a2], r3 = parent[a3];
+          const int m = std::max(std::max(r0, r1), std::max(r2, r3));
+          const bool same = ((r0 == 0) | (r0 == m)) & ((r1 == 0) | (r1 == m)) & ((r2 == 0) | (r2 == m)) & ((r3 == 0) | (r3 == m));
+          if (same && m > 0 && parent[m] == m) { roots[0] = m; nroots = 1; }
+          else if (touching) {
+            for (int q = 0; q < 4; q++) {
+              const int pq = parent[nb[q]];
+              if (pq < 0) continue;
+              const int r = find(nb[q]);
+              bool dup = false;
+              for (int z = 0; z < nroots; z++) dup = dup || roots[z] == r;
+              if (!dup) roots[nroots++] = r;
+            }
+          }
         }
         if (nroots == 0) {                       // a new component: area 1, perimeter 4
           parent[ofs] = ofs; node[ofs] = Node{1, 4, -1};
