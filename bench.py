@@ -756,7 +756,7 @@ def main():
             # share one host, N times this figure per second of throughput is what the host has to supply
             out["host_cpu_s_per_pair_rank0"] = host_cpu_headline / max(1, args.steps * nbatch)
             try:
-                out["host_wait"] = "runtime (hipStreamSynchronize)" if mods_amd.lib().modsx_debug_host_wait_runtime() else "flag word + naps (MODSX_HOST_WAIT)"
+                out["host_wait"] = (os.environ.get("MODSX_HOST_WAIT") or "auto (by CPU load: flag word + naps when the process uses > 80 % of its CPU allowance, the runtime's wait below 60 %)") + "; at the end of the run: " + ("runtime" if mods_amd.lib().modsx_debug_host_wait_runtime() else "flag")
             except Exception:
                 pass
             if b2b and host_cpu_split[0] > 0:

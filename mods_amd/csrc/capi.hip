@@ -682,7 +682,8 @@ extern "C" __attribute__((visibility("default"))) int modsx_debug_last_batch_cpu
   return MODSX_OK;
 }
 
-// 1: stage boundaries wait through the runtime (hipStreamSynchronize), 0: through the context's flag word (engine.hip, MODSX_HOST_WAIT)
+// 1: stage boundaries wait through the runtime (hipStreamSynchronize) right now, 0: through the context's flag word (engine.hip, MODSX_HOST_WAIT;
+// `auto` follows the process' CPU load)
 extern "C" __attribute__((visibility("default"))) int modsx_debug_host_wait_runtime() { return mx::host_wait_runtime() ? 1 : 0; }
 
 int modsx_last_timings(modsx_ctx *ctx, double *ms6) {

@@ -93,18 +93,41 @@ __global__ __launch_bounds__(256) void k_copy_pinned(uint4 *dst, const uint4 *sr
     reinterpret_cast<unsigned char *>(dst + n16)[threadIdx.x] = reinterpret_cast<const unsigned char *>(src + n16)[threadIdx.x];
   if (!HOST_SRC) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
 }
-// MODSX_HOST_WAIT = runtime | flag | auto (default).  Measured on the headline workload (16 contexts, one GPU, 16 CPUs): the flag wait
-// takes 0.0255 -> 0.0215 CPU-s per pair (the runtime's own threads 4.7 -> 2.1 ms, system time 3.7 -> 1.7 ms) and costs 1.2 % of the
-// pairs/s (the naps wake tens of microseconds late at ~30 boundaries per pair).  So the runtime's wait stays where CPUs are plentiful
-// and the flag wait is taken where they are what limits the node: fewer than 8 CPUs for this rank (8 ranks on a 16-CPU allowance).
+// MODSX_HOST_WAIT = runtime | flag | auto (default).  Measured (16 contexts, one GPU, 16 CPUs): on the headline workload, which uses a
+// third of the CPUs, the flag wait takes 0.0255 -> 0.0215 CPU-s per pair (the runtime's own threads 4.7 -> 2.1 ms, system time
+// 3.7 -> 1.7 ms) and costs 1.2 % of the pairs/s (the naps wake tens of microseconds late at ~30 boundaries per pair); on the cviu
+// ladder, whose MSER steps keep all 16 CPUs busy, it takes 0.244 -> 0.206 CPU-s per pair and GIVES 13 % (61.7 -> 70.0 pairs/s).
+// So `auto` looks at what the process is short of: every 50 ms it compares the CPU time the process used with its allowance
+// (cgroup quota / local ranks) -- above 80 % the host is the limit and the flag wait is taken, below 60 % the runtime's wait.
+}  // namespace mx
+#include <sys/resource.h>
+namespace mx {
 bool host_wait_runtime() {
-  static const bool rt = [] {
+  static const int forced = [] {
     const char *e = getenv("MODSX_HOST_WAIT");
-    if (e && !strcmp(e, "runtime")) return true;
-    if (e && !strcmp(e, "flag")) return false;
-    return host_cpus_per_rank() >= 8;
+    if (e && !strcmp(e, "runtime")) return 1;
+    if (e && !strcmp(e, "flag")) return 0;
+    return -1;
   }();
-  return rt;
+  if (forced >= 0) return forced != 0;
+  static const double allowance = (double)host_cpus_per_rank();
+  static std::atomic<int> rt{allowance >= 8 ? 1 : 0};
+  static std::atomic<long long> nextNs{0};
+  static std::atomic<long long> lastWallNs{0}, lastCpuUs{0};
+  const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  long long due = nextNs.load(std::memory_order_relaxed);
+  if (now >= due && nextNs.compare_exchange_strong(due, now + 50000000LL, std::memory_order_relaxed)) {     // one thread per period
+    rusage ru;
+    getrusage(RUSAGE_SELF, &ru);
+    const long long cpu = (ru.ru_utime.tv_sec + ru.ru_stime.tv_sec) * 1000000LL + ru.ru_utime.tv_usec + ru.ru_stime.tv_usec;
+    const long long w0 = lastWallNs.exchange(now), c0 = lastCpuUs.exchange(cpu);
+    if (w0 && now - w0 < 1000000000LL) {           // (a longer gap: the process was idle in between, the figure says nothing)
+      const double load = (double)(cpu - c0) * 1e3 / (double)(now - w0) / allowance;
+      if (load > 0.80) rt.store(0, std::memory_order_relaxed);
+      else if (load < 0.60) rt.store(1, std::memory_order_relaxed);
+    }
+  }
+  return rt.load(std::memory_order_relaxed) != 0;
 }
 hipError_t ctx_copy(modsx_ctx *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
   if (!bytes) return hipSuccess;
@@ -1464,7 +1487,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       // two staging blobs in turn: the copy of chunk k may still be in flight while chunk k + 1 is being prepared
       const int slot = chunkNo & 1;
       PinBuf &hblob = slot ? c->hDescB : c->hDesc;
-      if (c->descEvPending[slot]) { MX_HIP(host_wait_runtime() ? hipEventSynchronize(c->descEv[slot]) : ctx_wait_mark(c, c->descMark[slot])); c->descEvPending[slot] = false; }
+      if (c->descEvPending[slot]) { MX_HIP(c->descByEvent[slot] ? hipEventSynchronize(c->descEv[slot]) : ctx_wait_mark(c, c->descMark[slot])); c->descEvPending[slot] = false; }
       if (!c->descJobs.ensure(blobB) || !hblob.ensure(blobB) ||
           !c->scratchA.ensure(std::max<size_t>(1, arenaA) * 4) || !c->scratchB.ensure(std::max<size_t>(1, arenaB) * 4) ||
           !c->scratchC.ensure(std::max<size_t>(1, arenaC) * 4) || !c->rowStarts.ensure(std::max<size_t>(1, rowStarts) * 8) ||
@@ -1482,7 +1505,8 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       if (!coordTab.empty()) memcpy(hb + oCoord, coordTab.data(), coordTab.size() * 4);
       hm.mark("desc tables + blob");
       MX_HIP(ctx_copy(c, db, hb, blobB, hipMemcpyHostToDevice));
-      if (host_wait_runtime()) MX_HIP(hipEventRecord(c->descEv[slot], s)); else c->descMark[slot] = ctx_mark(c);
+      c->descByEvent[slot] = host_wait_runtime() || !c->hFlag;      // (the mode may change between this record and its wait)
+      if (c->descByEvent[slot]) MX_HIP(hipEventRecord(c->descEv[slot], s)); else c->descMark[slot] = ctx_mark(c);
       c->descEvPending[slot] = true;
       int *dPfxS = (int *)(db + oPfx), *dPfxR = (int *)(db + oPfx + pfxB), *dPfxC = (int *)(db + oPfx + 2 * pfxB);
       int *dPfxRL = (int *)(db + oPfx + 3 * pfxB), *dPfxCL = (int *)(db + oPfx + 4 * pfxB);

@@ -314,6 +314,7 @@ struct modsx_ctx {
   mx::PinBuf hDescB;           // second staging blob of describe_batch: chunk k + 1 is prepared while chunk k runs
   hipEvent_t descEv[2];
   bool descEvPending[2] = {false, false};
+  bool descByEvent[2] = {true, true};
   unsigned descMark[2] = {0, 0};   // ... as sequence numbers of the context's flag word (ctx_mark) when the runtime's waits are not used
   unsigned *hFlag = nullptr;   // pinned word the stream's flag kernel writes (ctx_sync, engine.hip)
   unsigned flagSeq = 0;        // last sequence number issued

@@ -56,15 +56,13 @@ struct GrownRegion {
 
 struct Forest {
   int rows, cols, stride;
-  const uint8_t *grey;                 // padded (rows + 2) x stride
   // parent: -1 = pixel not seen yet (the hot array: four neighbour look-ups per pixel); node: per ROOT the counters of a small
   // component, or the index of its region (>= 0) -- written when a pixel becomes a root, so it needs no clearing
   struct Node { int area, perim, region; };
   std::vector<Node> &node;
   std::vector<int> &parent;
-  std::vector<int> &order;             // pixel offsets in (grey level, raster) order
   std::vector<GrownRegion> regions;    // promotion order = output order
-  Forest(std::vector<Node> &n, std::vector<int> &par, std::vector<int> &o) : node(n), parent(par), order(o) {}
+  Forest(std::vector<Node> &n, std::vector<int> &par) : node(n), parent(par) {}
   int minSize, promoteAt, maxSize;
   double minMargin;
   bool relative, inverted;
@@ -150,60 +148,19 @@ struct Forest {
     }
   }
 
-  void run() {
+  // order / start: the view's pixel offsets (padded coordinates) in (grey level, raster) order and the first place of every level
+  // (sort_pixels below); inverted: the tree of 255 - grey walks the same buckets from level 255 down
+  void run(const int *order, const int *start) {
     const size_t npx = (size_t)(rows + 2) * stride;
     node.resize(npx); parent.assign(npx, -1);
     parent[0] = 0;     // the sentinel chain of the neighbour look-ups below: offset 0 is a frame pixel, never visited
-    // bin sort: offsets per grey level in raster order (sortPixels.cpp:76-125).  The rows are cut into NS strips that are counted and
-    // scattered side by side: neighbouring pixels mostly share their grey level, and one counter per level makes every step wait
-    // for the store of the step before it (a store-to-load forward per pixel); NS independent counters per level do not.
-    constexpr int NS = 4;
-    std::vector<int> start(257, 0);
-    static thread_local std::vector<int> cnt;
-    cnt.assign((size_t)NS * 256, 0);
-    int rb[NS + 1];
-    for (int q = 0; q <= NS; q++) rb[q] = 1 + (int)((long)rows * q / NS);
-    {
-      int *c0 = &cnt[0], *c1 = &cnt[256], *c2 = &cnt[512], *c3 = &cnt[768];
-      const int len = rb[1] - rb[0];                    // strips 0..2 have len or len + 1 rows; walk `len` rows of all four together
-      for (int i = 0; i < len; i++) {
-        const uint8_t *g0 = grey + (size_t)(rb[0] + i) * stride, *g1 = grey + (size_t)(rb[1] + i) * stride;
-        const uint8_t *g2 = grey + (size_t)(rb[2] + i) * stride, *g3 = grey + (size_t)(rb[3] + i) * stride;
-        for (int c = 1; c <= cols; c++) { c0[g0[c]]++; c1[g1[c]]++; c2[g2[c]]++; c3[g3[c]]++; }
-      }
-      for (int q = 0; q < NS; q++)
-        for (int r = rb[q] + len; r < rb[q + 1]; r++) { const uint8_t *g = grey + (size_t)r * stride; int *cq = &cnt[q * 256]; for (int c = 1; c <= cols; c++) cq[g[c]]++; }
-    }
-    for (int l = 0; l < 256; l++) {                     // level l: strip 0's pixels, then strip 1's, ... = raster order
-      int at = start[l];
-      for (int q = 0; q < NS; q++) { const int n = cnt[q * 256 + l]; cnt[q * 256 + l] = at; at += n; }
-      start[l + 1] = at;
-    }
-    order.resize((size_t)rows * cols);
-    {
-      int *ord = order.data();
-      int *c0 = &cnt[0], *c1 = &cnt[256], *c2 = &cnt[512], *c3 = &cnt[768];
-      const int len = rb[1] - rb[0];
-      for (int i = 0; i < len; i++) {
-        const int r0 = rb[0] + i, r1 = rb[1] + i, r2 = rb[2] + i, r3 = rb[3] + i;
-        const uint8_t *g0 = grey + (size_t)r0 * stride, *g1 = grey + (size_t)r1 * stride, *g2 = grey + (size_t)r2 * stride, *g3 = grey + (size_t)r3 * stride;
-        const int o0 = r0 * stride, o1 = r1 * stride, o2 = r2 * stride, o3 = r3 * stride;
-        for (int c = 1; c <= cols; c++) {
-          ord[c0[g0[c]]++] = o0 + c; ord[c1[g1[c]]++] = o1 + c; ord[c2[g2[c]]++] = o2 + c; ord[c3[g3[c]]++] = o3 + c;
-        }
-      }
-      for (int q = 0; q < NS; q++)
-        for (int r = rb[q] + len; r < rb[q + 1]; r++) {
-          const uint8_t *g = grey + (size_t)r * stride; int *cq = &cnt[q * 256]; const int o = r * stride;
-          for (int c = 1; c <= cols; c++) ord[cq[g[c]]++] = o + c;
-        }
-    }
     static const int PF = getenv("MODSX_MSER_PF") ? atoi(getenv("MODSX_MSER_PF")) : 12;
     int lastRoot = -1;
-    for (int level = 0; level < 256; level++)
-      for (int k = start[level]; k < start[level + 1]; k++) {
+    for (int level = 0; level < 256; level++) {
+      const int bucket = inverted ? 255 - level : level, kEnd = start[bucket + 1];
+      for (int k = start[bucket]; k < kEnd; k++) {
         const int ofs = order[k];
-        if (k + PF < start[256]) { const int f = order[k + PF]; __builtin_prefetch(&parent[f - stride]); __builtin_prefetch(&parent[f]); __builtin_prefetch(&parent[f + stride]); }
+        if (k + PF < kEnd) { const int f = order[k + PF]; __builtin_prefetch(&parent[f - stride]); __builtin_prefetch(&parent[f]); __builtin_prefetch(&parent[f + stride]); }
         const int nb[4] = {ofs - stride, ofs - 1, ofs + 1, ofs + stride};
         int roots[4], nroots = 0, touching = 0;
         {
@@ -268,6 +225,7 @@ struct Forest {
         add_pixel(keep, ofs, level, touching);
         lastRoot = keep;
       }
+    }
     if (rows > 0 && cols > 0) {
       const int root = find(stride + 1);
       if (node[root].region >= 0) close_region(regions[node[root].region]);
@@ -276,7 +234,63 @@ struct Forest {
   }
 };
 
+// The bin sort of a view (sortPixels.cpp:76-125): pixel offsets (padded coordinates, stride cols + 2) per grey level in raster order.
+// Both polarities walk the same buckets (the inverted image's level l is this one's 255 - l, raster order inside a level is the
+// same), so a view is sorted ONCE: every caller counts for itself (a third of a millisecond) and the two polarity tasks scatter one
+// half of the rows each -- whoever comes first takes the other half too if nobody has.  The rows are cut into four strips that are
+// counted, and two at a time scattered, side by side: neighbouring pixels mostly share their grey level, and one counter per level
+// makes every step wait for the store of the step before it (a store-to-load forward per pixel); independent counters do not.
+struct ViewSort {
+  std::vector<int> order;
+  std::atomic<int> part[2];     // the scatter of strips 0-1 / 2-3: 0 free, 1 taken, 2 done
+  ViewSort() { part[0].store(0); part[1].store(0); }
+};
+void sort_pixels(const uint8_t *u8, int rows, int cols, ViewSort &V, int mine, int *start /* [257] */) {
+  constexpr int NS = 4;
+  const int stride = cols + 2;
+  int cnt[NS * 256];
+  memset(cnt, 0, sizeof cnt);
+  int rb[NS + 1];
+  for (int q = 0; q <= NS; q++) rb[q] = (int)((long)rows * q / NS);
+  {
+    int *c0 = &cnt[0], *c1 = &cnt[256], *c2 = &cnt[512], *c3 = &cnt[768];
+    const int len = rb[1] - rb[0];                    // every strip has len or len + 1 rows; walk `len` rows of all four together
+    for (int i = 0; i < len; i++) {
+      const uint8_t *g0 = u8 + (size_t)(rb[0] + i) * cols, *g1 = u8 + (size_t)(rb[1] + i) * cols;
+      const uint8_t *g2 = u8 + (size_t)(rb[2] + i) * cols, *g3 = u8 + (size_t)(rb[3] + i) * cols;
+      for (int c = 0; c < cols; c++) { c0[g0[c]]++; c1[g1[c]]++; c2[g2[c]]++; c3[g3[c]]++; }
+    }
+    for (int q = 0; q < NS; q++)
+      for (int r = rb[q] + len; r < rb[q + 1]; r++) { const uint8_t *g = u8 + (size_t)r * cols; int *cq = &cnt[q * 256]; for (int c = 0; c < cols; c++) cq[g[c]]++; }
+  }
+  start[0] = 0;
+  for (int l = 0; l < 256; l++) {                     // level l: strip 0's pixels, then strip 1's, ... = raster order
+    int at = start[l];
+    for (int q = 0; q < NS; q++) { const int n = cnt[q * 256 + l]; cnt[q * 256 + l] = at; at += n; }
+    start[l + 1] = at;
+  }
+  int *ord = V.order.data();
+  for (int turn = 0; turn < 2; turn++) {
+    const int h = turn ? 1 - mine : mine;
+    int free0 = 0;
+    if (!V.part[h].compare_exchange_strong(free0, 1, std::memory_order_acquire)) continue;
+    int *ca = &cnt[(2 * h) * 256], *cb = &cnt[(2 * h + 1) * 256];
+    const int ra = rb[2 * h], rbb = rb[2 * h + 1], na = rbb - ra, nb = rb[2 * h + 2] - rbb, len = na < nb ? na : nb;
+    for (int i = 0; i < len; i++) {
+      const uint8_t *ga = u8 + (size_t)(ra + i) * cols, *gb = u8 + (size_t)(rbb + i) * cols;
+      const int oa = (ra + i + 1) * stride + 1, ob = (rbb + i + 1) * stride + 1;
+      for (int c = 0; c < cols; c++) { ord[ca[ga[c]]++] = oa + c; ord[cb[gb[c]]++] = ob + c; }
+    }
+    for (int r = ra + len; r < rbb; r++) { const uint8_t *g = u8 + (size_t)r * cols; const int o = (r + 1) * stride + 1; for (int c = 0; c < cols; c++) ord[ca[g[c]]++] = o + c; }
+    for (int r = rbb + len; r < rb[2 * h + 2]; r++) { const uint8_t *g = u8 + (size_t)r * cols; const int o = (r + 1) * stride + 1; for (int c = 0; c < cols; c++) ord[cb[g[c]]++] = o + c; }
+    V.part[h].store(2, std::memory_order_release);
+  }
+  for (int spin = 0; V.part[0].load(std::memory_order_acquire) != 2 || V.part[1].load(std::memory_order_acquire) != 2; spin++)
+    if (spin > 64) std::this_thread::yield();       // the other polarity's task is scattering its half right now
+}
+
 struct RowRun { int line, c0, c1; };
+
 
 // row runs (raster order) of the 4-connected component of {grey <= level} that contains `seed`: a span fill -- a pixel
 // taken off the stack is grown to its maximal horizontal span (which IS a row run of the component), the spans above and
@@ -357,34 +371,36 @@ void sym_sqrt(double c00, double c01, double c11, double A[4]) {
 // not page in fresh memory for every view
 struct MserScratch {
   std::vector<Forest::Node> node;
-  std::vector<int> parent, order, stack;
-  std::vector<uint8_t> grey, fence, mark;
+  std::vector<int> parent, stack;
+  std::vector<uint8_t> fence, mark;
   std::vector<RowRun> runs;
 };
 static thread_local MserScratch t_scratch;
 
 // MSER+ (pol 0) or MSER- (pol 1: the inverted image, extremaInvertImage) of one view, in region / threshold order
-static void mser_polarity(const uint8_t *u8, int rows, int cols, const modsx_mser_params &par, double minMargin, int pol,
+static void mser_polarity(const uint8_t *u8, int rows, int cols, const modsx_mser_params &par, double minMargin, int pol, ViewSort &vs,
                           std::vector<modsx_keypoint> &out) {
   MserScratch &S = t_scratch;
   const int stride = cols + 2;
   const size_t npx = (size_t)(rows + 2) * stride;
-  // `grey`: the padded image the tree is built on (frame 0, never visited: only interior offsets are in `order`);
-  // `fence`: the same pixels inside a frame of 255, which stops the span fill of any threshold < 255 at the image border
-  S.grey.assign(npx, 0); S.fence.assign(npx, 255); S.mark.assign(npx, 0);
+  // `fence`: the polarity's pixels inside a frame of 255, which stops the span fill of any threshold < 255 at the image border
+  // (the tree itself only sees the sorted offsets)
+  S.fence.assign(npx, 255); S.mark.assign(npx, 0);
   for (int r = 0; r < rows; r++) {
-    uint8_t *g = &S.grey[(size_t)(r + 1) * stride + 1], *f = &S.fence[(size_t)(r + 1) * stride + 1];
+    uint8_t *f = &S.fence[(size_t)(r + 1) * stride + 1];
     const uint8_t *src = u8 + (size_t)r * cols;
-    if (pol == 0) { memcpy(g, src, cols); memcpy(f, src, cols); }
-    else for (int c = 0; c < cols; c++) g[c] = f[c] = (uint8_t)(255 - src[c]);
+    if (pol == 0) memcpy(f, src, cols);
+    else for (int c = 0; c < cols; c++) f[c] = (uint8_t)(255 - src[c]);
   }
-  Forest F(S.node, S.parent, S.order);
-  F.rows = rows; F.cols = cols; F.stride = stride; F.grey = S.grey.data();
+  int start[257];
+  sort_pixels(u8, rows, cols, vs, pol, start);
+  Forest F(S.node, S.parent);
+  F.rows = rows; F.cols = cols; F.stride = stride;
   F.minSize = par.min_size; F.promoteAt = std::min(10000, par.min_size);
   F.maxSize = (int)((double)cols * rows * par.max_area);
   F.minMargin = par.relative ? minMargin / 100.0 : minMargin;
   F.relative = par.relative != 0; F.inverted = pol == 1;
-  F.run();
+  F.run(vs.order.data(), start);
   for (const GrownRegion &g : F.regions) {
     if (!g.kept) continue;
     for (const StableLevel &t : g.levels) {
@@ -588,7 +604,9 @@ int detect_msers_host(const uint8_t *u8, int rows, int cols, const modsx_mser_pa
   out.clear();
   if (rows <= 0 || cols <= 0) return MODSX_OK;
   const double minMargin = par.mode != MODSX_FIXED_TH ? 1.0 : par.min_margin;
-  for (int pol = 0; pol < 2; pol++) mser_polarity(u8, rows, cols, par, minMargin, pol, out);
+  ViewSort vs;
+  vs.order.resize((size_t)rows * cols);
+  for (int pol = 0; pol < 2; pol++) mser_polarity(u8, rows, cols, par, minMargin, pol, vs, out);
   mser_export(out, par, minMargin, tilt, zoom);
   return MODSX_OK;
 }
@@ -598,6 +616,8 @@ int detect_msers_views(const uint8_t *const *u8, const int *rows, const int *col
                        const double *tilts, const double *zooms, std::vector<modsx_keypoint> *out) {
   const double minMargin = par.mode != MODSX_FIXED_TH ? 1.0 : par.min_margin;
   std::vector<std::vector<modsx_keypoint>> part((size_t)2 * n);
+  std::vector<ViewSort> sorts((size_t)n);         // one bin sort per view, shared by its two polarity tasks
+  for (int v = 0; v < n; v++) if (rows[v] > 0 && cols[v] > 0) sorts[v].order.resize((size_t)rows[v] * cols[v]);
   std::vector<int> task((size_t)2 * n);
   for (int i = 0; i < 2 * n; i++) task[i] = i;
   std::stable_sort(task.begin(), task.end(), [&](int a, int b) { return (long)rows[a / 2] * cols[a / 2] > (long)rows[b / 2] * cols[b / 2]; });
@@ -609,7 +629,7 @@ int detect_msers_views(const uint8_t *const *u8, const int *rows, const int *col
   host_parallel_for(2 * n, [&](int k) {
     const int t = task[k], v = t / 2;
     if (trace) { tb[k] = nowms() - t00; tid[k] = std::hash<std::thread::id>()(std::this_thread::get_id()) % 1000; }
-    if (rows[v] > 0 && cols[v] > 0) mser_polarity(u8[v], rows[v], cols[v], par, minMargin, t & 1, part[t]);
+    if (rows[v] > 0 && cols[v] > 0) mser_polarity(u8[v], rows[v], cols[v], par, minMargin, t & 1, sorts[v], part[t]);
     if (trace) te[k] = nowms() - t00;
   });
   if (trace && nowms() - t00 > 30) {
