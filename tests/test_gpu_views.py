@@ -1,10 +1,13 @@
 """GPU: view synthesis and the multi-view loop against the oracle (bit-exact)."""
+import os
+
 import numpy as np
 import pytest
 
 from common import laf_of, normH, oracle_ladder, same_records, need_ref
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _views(oracle, modsx, tilts, phi, sigma=0.2):
@@ -277,6 +280,51 @@ def test_mixed_mser_hessaff_ladder_matches_oracle(ctx, modsx, oracle, small_pair
     assert np.array_equal(got["ransac_inlier"], ref["rr"]["inl"]) and np.array_equal(got["verified"], ref["rr"]["keep"])
     assert np.abs(normH(got["H"]) - normH(ref["rr"]["H"])).max() < 1e-4
     assert np.abs(normH(got["H"]) - H).max() < 1.5
+
+
+def test_flag_word_wait_path_gives_the_same_results():
+    """MODSX_HOST_WAIT=flag (engine.hip: stage boundaries through the context's pinned flag word and small tables by copy kernels
+    instead of hipStreamSynchronize / hipMemcpyAsync; `auto` takes it when the process is short of CPUs, so the default test process
+    never runs it): Hessian-Affine and MSER view sets and a pair end to end against the oracle, twice on one context (the staging
+    buffers and the flag's sequence numbers are reused), in a child process (the switch is read once per process)."""
+    import json, os, subprocess, sys
+    code = (
+        "import sys, json, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import mods_amd\n"
+        "from mods_amd import synthetic\n"
+        "from oracle import pyoracle as O\n"
+        "from common import same_records, oracle_pair\n"
+        "assert mods_amd.lib().modsx_debug_host_wait_runtime() == 0\n"
+        "a, b, _ = synthetic.make_pair(rows=240, cols=320, nblobs=420, seed=777)\n"
+        "ctx = mods_amd.Context(0)\n"
+        "ok = True\n"
+        "vm = mods_amd.set_vs_pars([1.0], [1, 2, 3], 360.0, 0.2, 1, [])\n"
+        "vo = O.set_vs_pars([1.0], [1, 2, 3], 360.0, 0.2, 1, [])\n"
+        "rr, dd = O.detect_describe_views(a, vo)\n"
+        "vm2 = mods_amd.set_vs_pars([1.0], [1, 2], 360.0, 0.8, 1, [])\n"
+        "vo2 = O.set_vs_pars([1.0], [1, 2], 360.0, 0.8, 1, [])\n"
+        "mr, md = O.detect_describe_views(a, vo2, ori=(5.1962, 41, 1, 0.8), mser=dict(min_size=30, max_area=0.05, min_margin=8.0))\n"
+        "ref = oracle_pair(O, a, b, seed=3) if O.ref_available() else None\n"
+        "n = 0\n"
+        "for rep in range(2):\n"
+        "    ia, ib = ctx.upload(a), ctx.upload(b)\n"
+        "    r, d = ctx.detect_describe_views(ia, vm, mods_amd.default_pair_params())\n"
+        "    ok = ok and same_records(r, rr.view(mods_amd.REGION)) and bool(np.array_equal(d, dd))\n"
+        "    r2, d2 = ctx.detect_describe_views(ia, vm2, mods_amd.default_pair_params(detector=3, ori_mrSize=5.1962))\n"
+        "    ok = ok and same_records(r2, mr.view(mods_amd.REGION)) and bool(np.array_equal(d2, md))\n"
+        "    res = ctx.match_pair(ia, ib, mods_amd.default_pair_params(ransac_seed=3))\n"
+        "    if ref is not None:\n"
+        "        ok = ok and res['n_tentatives'] == len(ref['tent']) and bool(np.array_equal(res['ransac_inlier'], ref['ransac']['inl']))\n"
+        "    n = len(r) + len(r2)\n"
+        "    ia.free(); ib.free()\n"
+        "print(json.dumps({'ok': bool(ok), 'n': int(n), 'verified': int(res['n_verified'])}))\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, MODSX_HOST_WAIT="flag")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["n"] > 300 and res["verified"] > 20
 
 
 def _cviu_ladder(oracle, modsx):
