@@ -31,7 +31,18 @@ static thread_local std::string g_err;
 void set_error(const std::string &s) { g_err = s; }
 static std::atomic<int> g_busyContexts{0};
 bool gpu_shared() { return g_busyContexts.load(std::memory_order_relaxed) > 1; }
-CtxBusy::CtxBusy(modsx_ctx *ctx) : c(ctx) { if (c && c->busyDepth++ == 0) g_busyContexts.fetch_add(1, std::memory_order_relaxed); }
+CtxBusy::CtxBusy(modsx_ctx *ctx) : c(ctx) {
+  if (c && c->busyDepth++ == 0) {
+    g_busyContexts.fetch_add(1, std::memory_order_relaxed);
+    // how this call waits at its stage boundaries is decided once, here (MODSX_HOST_WAIT=auto follows the process' CPU load): a
+    // context that goes back from the flag word to the runtime's wait first lets the runtime catch up with its stream -- the
+    // runtime has not been asked about that stream since the context left its wait, and the small copies it does with the CPU
+    // (rocprofv3 run of the 16-stream bench: SIGSEGV inside hipMemcpyAsync) rest on its own picture of what has completed
+    const bool rt = host_wait_runtime() || !c->hFlag;
+    if (rt && !c->waitRuntime) hipStreamSynchronize(c->stream);
+    c->waitRuntime = rt;
+  }
+}
 CtxBusy::~CtxBusy() { if (c && --c->busyDepth == 0) g_busyContexts.fetch_sub(1, std::memory_order_relaxed); }
 const char *last_error() { return g_err.c_str(); }
 
@@ -136,7 +147,7 @@ hipError_t ctx_copy(modsx_ctx *c, void *dst, const void *src, size_t bytes, hipM
   // tables above 64 KB stay with the runtime's copy engines: as kernels on the stream they cost the pipeline 3 % (the describe
   // blobs and candidate lists are megabytes; a copy kernel holds the stream for tens of microseconds that the DMA engine overlaps)
   static const size_t rtAbove = getenv("MODSX_HOST_COPY_MAX") ? (size_t)atol(getenv("MODSX_HOST_COPY_MAX")) : 65536;
-  if (host_wait_runtime() || rtCopy || bytes > rtAbove || (!h2d && kind != hipMemcpyDeviceToHost) || (((uintptr_t)dst | (uintptr_t)src) & 15))
+  if (c->waitRuntime || rtCopy || bytes > rtAbove || (!h2d && kind != hipMemcpyDeviceToHost) || (((uintptr_t)dst | (uintptr_t)src) & 15))
     return hipMemcpyAsync(dst, src, bytes, kind, c->stream);
   const size_t n16 = bytes >> 4;
   const int tail = (int)(bytes & 15);
@@ -182,7 +193,7 @@ hipError_t ctx_wait_mark(modsx_ctx *c, unsigned seq) {
   return e;
 }
 hipError_t ctx_sync(modsx_ctx *c) {
-  if (host_wait_runtime() || !c->hFlag) return hipStreamSynchronize(c->stream);
+  if (c->waitRuntime || !c->hFlag) return hipStreamSynchronize(c->stream);
   const unsigned seq = ctx_mark(c);
   const hipError_t le = hipGetLastError();
   if (le != hipSuccess) return le;
@@ -399,6 +410,7 @@ modsx_ctx *ctx_create(int device_id) {
   for (int i = 0; i < 2; i++) hipEventCreateWithFlags(&c->descEv[i], hipEventDisableTiming);
   if (hipHostMalloc((void **)&c->hFlag, 64, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); hipStreamDestroy(c->stream); delete c; return nullptr; }
   c->hFlag[0] = 0; c->flagSeq = 0;
+  c->waitRuntime = host_wait_runtime();
   for (int i = 0; i < 6; i++) c->timings[i] = 0;
   if (upload_tables(c) != MODSX_OK) { delete c; return nullptr; }
   return c;
@@ -1505,7 +1517,7 @@ int describe_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, const st
       if (!coordTab.empty()) memcpy(hb + oCoord, coordTab.data(), coordTab.size() * 4);
       hm.mark("desc tables + blob");
       MX_HIP(ctx_copy(c, db, hb, blobB, hipMemcpyHostToDevice));
-      c->descByEvent[slot] = host_wait_runtime() || !c->hFlag;      // (the mode may change between this record and its wait)
+      c->descByEvent[slot] = c->waitRuntime || !c->hFlag;
       if (c->descByEvent[slot]) MX_HIP(hipEventRecord(c->descEv[slot], s)); else c->descMark[slot] = ctx_mark(c);
       c->descEvPending[slot] = true;
       int *dPfxS = (int *)(db + oPfx), *dPfxR = (int *)(db + oPfx + pfxB), *dPfxC = (int *)(db + oPfx + 2 * pfxB);

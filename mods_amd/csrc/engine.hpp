@@ -318,6 +318,7 @@ struct modsx_ctx {
   unsigned descMark[2] = {0, 0};   // ... as sequence numbers of the context's flag word (ctx_mark) when the runtime's waits are not used
   unsigned *hFlag = nullptr;   // pinned word the stream's flag kernel writes (ctx_sync, engine.hip)
   unsigned flagSeq = 0;        // last sequence number issued
+  bool waitRuntime = true;     // how the call in progress waits and copies (latched by CtxBusy from MODSX_HOST_WAIT / the CPU load)
   mx::PinBuf hCand, hAff, hOri, hDesc, hMisc, hNms, hMatch, hViewTaps, hViewJobs, hMser, hRefs;
   // constant tables on device
   float *dSmmMask = nullptr;   // 19x19 computeGaussMask
