@@ -24,6 +24,7 @@
 // 32767 pixels are merged before promotion (impossible for min_size <= 8191); AffineKeypoint::octave_number and
 // pyramid_scale are uninitialised stack values in the reference and 0 here; thresholds at level 255, for which the
 // reference never builds a boundary and would dereference NULL, are skipped.
+#include <emmintrin.h>
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
@@ -305,18 +306,47 @@ void component_runs(const uint8_t *grey, int stride, int seed, int level, std::v
     const int o = stack.back(); stack.pop_back();
     if (mark[o]) continue;
     int a = o, b = o;
-    while (grey[a - 1] <= level && !mark[a - 1]) a--;
-    while (grey[b + 1] <= level && !mark[b + 1]) b++;
+    {
+      // the maximal span around o, 16 pixels per look (the frame of 255s ends every row, so a look never matters past it)
+      const __m128i lvl = _mm_set1_epi8((char)level), zero = _mm_setzero_si128();
+      auto open16 = [&](int at) {
+        const __m128i g = _mm_loadu_si128(reinterpret_cast<const __m128i *>(grey + at));
+        const __m128i m = _mm_loadu_si128(reinterpret_cast<const __m128i *>(mark.data() + at));
+        return (unsigned)_mm_movemask_epi8(_mm_and_si128(_mm_cmpeq_epi8(_mm_max_epu8(g, lvl), lvl), _mm_cmpeq_epi8(m, zero)));
+      };
+      for (;;) {
+        const unsigned open = open16(b + 1);
+        if (open == 0xffffu) { b += 16; continue; }
+        b += __builtin_ctz(~open);
+        break;
+      }
+      for (;;) {
+        if (a < 16) { while (grey[a - 1] <= level && !mark[a - 1]) a--; break; }
+        const unsigned open = open16(a - 16);          // bit i = pixel a - 16 + i
+        if (open == 0xffffu) { a -= 16; continue; }
+        a -= __builtin_clz((~open & 0xffffu) << 16);
+        break;
+      }
+    }
     memset(&mark[a], 1, (size_t)(b - a + 1));
     const int line = a / stride;
     runs.push_back({line - 1, a - line * stride - 1, b - line * stride - 1});
+    // the rows above and below: every start of a stretch of open pixels (grey <= level, not marked) under the span is a seed.
+    // 16 pixels per step (the arrays are padded by 32 bytes for the reads past b): open = bytes that pass both tests, a start is
+    // an open pixel whose left neighbour (the last pixel of the step before, for bit 0) is not.
+    const __m128i lvl = _mm_set1_epi8((char)level), zero = _mm_setzero_si128();
     for (int dir = -1; dir <= 1; dir += 2) {
       const int base = dir * stride;
-      bool in = false;
-      for (int q = a; q <= b; q++) {
-        const bool ok = grey[q + base] <= level && !mark[q + base];
-        if (ok && !in) stack.push_back(q + base);
-        in = ok;
+      unsigned carry = 0;
+      for (int q = a; q <= b; q += 16) {
+        const __m128i g = _mm_loadu_si128(reinterpret_cast<const __m128i *>(grey + q + base));
+        const __m128i m = _mm_loadu_si128(reinterpret_cast<const __m128i *>(mark.data() + q + base));
+        unsigned open = (unsigned)_mm_movemask_epi8(_mm_and_si128(_mm_cmpeq_epi8(_mm_max_epu8(g, lvl), lvl), _mm_cmpeq_epi8(m, zero)));
+        const int left = b - q + 1;                    // pixels of the span in this step
+        if (left < 16) open &= (1u << left) - 1u;
+        unsigned starts = open & ~((open << 1) | carry);
+        carry = (open >> 15) & 1u;
+        while (starts) { const int bit = __builtin_ctz(starts); starts &= starts - 1; stack.push_back(q + bit + base); }
       }
     }
   }
@@ -385,7 +415,7 @@ static void mser_polarity(const uint8_t *u8, int rows, int cols, const modsx_mse
   const size_t npx = (size_t)(rows + 2) * stride;
   // `fence`: the polarity's pixels inside a frame of 255, which stops the span fill of any threshold < 255 at the image border
   // (the tree itself only sees the sorted offsets)
-  S.fence.assign(npx, 255); S.mark.assign(npx, 0);
+  S.fence.assign(npx + 32, 255); S.mark.assign(npx + 32, 0);     // (+ 32: the span fill reads 16 bytes at a time)
   for (int r = 0; r < rows; r++) {
     uint8_t *f = &S.fence[(size_t)(r + 1) * stride + 1];
     const uint8_t *src = u8 + (size_t)r * cols;
