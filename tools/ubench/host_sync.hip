@@ -36,6 +36,20 @@ int main(int argc, char **argv) {
   hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
   hipFree(0);
   const unsigned long long cycles = (unsigned long long)(kus * 100.0);   // wall_clock64: 100 MHz
+  {   // does an asynchronous copy call return while the stream is busy?  (wall time of the CALL behind a 2 ms kernel)
+    hipStream_t s; hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    unsigned *d, *h, *big, *hbig; hipMalloc(&d, 4096); hipHostMalloc(&h, 4096, hipHostMallocDefault);
+    hipMalloc(&big, 4 << 20); hipHostMalloc(&hbig, 4 << 20, hipHostMallocDefault);
+    for (int rep = 0; rep < 3; rep++)
+      for (size_t bytes : {(size_t)4096, (size_t)65536, (size_t)(2 << 20)}) {
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, d, 200000ull, 1u, (unsigned *)nullptr);
+        double a = wall(); hipMemcpyAsync(big, hbig, bytes, hipMemcpyHostToDevice, s); double b = wall();
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, d, 100ull, 1u, (unsigned *)nullptr);
+        double c = wall(); hipMemcpyAsync(hbig, big, bytes, hipMemcpyDeviceToHost, s); double e = wall();
+        hipStreamSynchronize(s);
+        if (rep == 2) printf("behind a 2 ms kernel: hipMemcpyAsync H2D of %zu bytes returns after %.1f us, D2H after %.1f us\n", bytes, (b - a) * 1e6, (e - c) * 1e6);
+      }
+  }
   for (int mode = 0; mode < 5; mode++) {
     std::vector<double> tcpu(T, 0.0);
     std::atomic<int> ready(0);
