@@ -27,6 +27,8 @@
 #include <emmintrin.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <sys/mman.h>
 #include <string.h>
 #include <algorithm>
 #include <atomic>
@@ -60,10 +62,10 @@ struct Forest {
   // parent: -1 = pixel not seen yet (the hot array: four neighbour look-ups per pixel); node: per ROOT the counters of a small
   // component, or the index of its region (>= 0) -- written when a pixel becomes a root, so it needs no clearing
   struct Node { int area, perim, region; };
-  std::vector<Node> &node;
-  std::vector<int> &parent;
+  Node *node;
+  int *parent;
   std::vector<GrownRegion> regions;    // promotion order = output order
-  Forest(std::vector<Node> &n, std::vector<int> &par) : node(n), parent(par) {}
+  Forest(Node *n, int *par) : node(n), parent(par) {}
   int minSize, promoteAt, maxSize;
   double minMargin;
   bool relative, inverted;
@@ -153,7 +155,7 @@ struct Forest {
   // (sort_pixels below); inverted: the tree of 255 - grey walks the same buckets from level 255 down
   void run(const int *order, const int *start) {
     const size_t npx = (size_t)(rows + 2) * stride;
-    node.resize(npx); parent.assign(npx, -1);
+    memset(parent, 0xff, npx * sizeof(int));       // -1 = not seen
     parent[0] = 0;     // the sentinel chain of the neighbour look-ups below: offset 0 is a frame pixel, never visited
     static const int PF = getenv("MODSX_MSER_PF") ? atoi(getenv("MODSX_MSER_PF")) : 12;
     int lastRoot = -1;
@@ -399,9 +401,26 @@ void sym_sqrt(double c00, double c01, double c11, double A[4]) {
 
 // per-thread scratch of the component tree (12-16 bytes per pixel): reused from call to call, so that a worker thread does
 // not page in fresh memory for every view
+// the forest's two arrays (4 + 12 bytes per pixel, read in grey-level order: every look-up a different page) on transparent huge
+// pages where the system hands them out on request
+struct HugeBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  void *ensure(size_t bytes) {
+    if (bytes <= cap) return p;
+    if (p) free(p);
+    const size_t want = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+    if (posix_memalign(&p, 2u << 20, want)) { p = nullptr; cap = 0; return nullptr; }
+    static const bool off = getenv("MODSX_MSER_NOHUGE") != nullptr;
+    if (!off) madvise(p, want, MADV_HUGEPAGE);
+    cap = want;
+    return p;
+  }
+  ~HugeBuf() { if (p) free(p); }
+};
 struct MserScratch {
-  std::vector<Forest::Node> node;
-  std::vector<int> parent, stack;
+  HugeBuf node, parent;
+  std::vector<int> stack;
   std::vector<uint8_t> fence, mark;
   std::vector<RowRun> runs;
 };
@@ -424,7 +443,8 @@ static void mser_polarity(const uint8_t *u8, int rows, int cols, const modsx_mse
   }
   int start[257];
   sort_pixels(u8, rows, cols, vs, pol, start);
-  Forest F(S.node, S.parent);
+  Forest F((Forest::Node *)S.node.ensure(npx * sizeof(Forest::Node)), (int *)S.parent.ensure(npx * sizeof(int)));
+  if (!F.node || !F.parent) return;              // (out of memory: no keys for this view)
   F.rows = rows; F.cols = cols; F.stride = stride;
   F.minSize = par.min_size; F.promoteAt = std::min(10000, par.min_size);
   F.maxSize = (int)((double)cols * rows * par.max_area);
