@@ -170,6 +170,11 @@ void modsx_free(void *p);
  * ~100 MB of host tables a pair allocates and frees stay mapped between calls (1 ms of page faults per 31-view pair otherwise).
  * Opt-in because it changes malloc for the whole host process. */
 modsx_ctx *modsx_create(int device_id);
+/* How the calling thread waits inside the calls that keep the device busy (MODSX_HOST_WAIT = runtime | flag | auto, default auto):
+ * through hipStreamSynchronize, or by napping until a pinned flag word shows the sequence number that a one-lane kernel writes
+ * behind the stage's launches (15 % less host CPU per pair, about 1 % fewer pairs/s when CPUs are plentiful, more pairs/s when they
+ * are not).  `auto` takes the flag wait while the process uses more than 80 % of its CPU allowance (cgroup quota / local ranks).
+ * A thread that naps there has its timer slack set to 2 us (prctl PR_SET_TIMERSLACK, once): its later sleeps wake on time. */
 void modsx_destroy(modsx_ctx *ctx);
 int modsx_synchronize(modsx_ctx *ctx);
 

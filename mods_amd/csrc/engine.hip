@@ -118,8 +118,10 @@ bool host_wait_runtime() {
     const char *e = getenv("MODSX_HOST_WAIT");
     if (e && !strcmp(e, "runtime")) return 1;
     if (e && !strcmp(e, "flag")) return 0;
+    if (e && !strcmp(e, "alternate")) return 2;      // test aid: every call of this function answers the other way (the transitions)
     return -1;
   }();
+  if (forced == 2) { static std::atomic<unsigned> flip{0}; return (flip.fetch_add(1, std::memory_order_relaxed) & 1) != 0; }
   if (forced >= 0) return forced != 0;
   static const double allowance = (double)host_cpus_per_rank();
   static std::atomic<int> rt{allowance >= 8 ? 1 : 0};

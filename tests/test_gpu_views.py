@@ -286,7 +286,8 @@ def test_flag_word_wait_path_gives_the_same_results():
     """MODSX_HOST_WAIT=flag (engine.hip: stage boundaries through the context's pinned flag word and small tables by copy kernels
     instead of hipStreamSynchronize / hipMemcpyAsync; `auto` takes it when the process is short of CPUs, so the default test process
     never runs it): Hessian-Affine and MSER view sets and a pair end to end against the oracle, twice on one context (the staging
-    buffers and the flag's sequence numbers are reused), in a child process (the switch is read once per process)."""
+    buffers and the flag's sequence numbers are reused), in a child process (the switch is read once per process); then the same
+    with MODSX_HOST_WAIT=alternate, where calls take the two ways of waiting in turn."""
     import json, os, subprocess, sys
     code = (
         "import sys, json, numpy as np\n"
@@ -295,7 +296,8 @@ def test_flag_word_wait_path_gives_the_same_results():
         "from mods_amd import synthetic\n"
         "from oracle import pyoracle as O\n"
         "from common import same_records, oracle_pair\n"
-        "assert mods_amd.lib().modsx_debug_host_wait_runtime() == 0\n"
+        "import os\n"
+        "assert os.environ['MODSX_HOST_WAIT'] != 'flag' or mods_amd.lib().modsx_debug_host_wait_runtime() == 0\n"
         "a, b, _ = synthetic.make_pair(rows=240, cols=320, nblobs=420, seed=777)\n"
         "ctx = mods_amd.Context(0)\n"
         "ok = True\n"
@@ -320,11 +322,12 @@ def test_flag_word_wait_path_gives_the_same_results():
         "    ia.free(); ib.free()\n"
         "print(json.dumps({'ok': bool(ok), 'n': int(n), 'verified': int(res['n_verified'])}))\n"
     ) % (ROOT, os.path.join(ROOT, "tests"))
-    env = dict(os.environ, MODSX_HOST_WAIT="flag")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    res = json.loads(out.stdout.strip().splitlines()[-1])
-    assert res["ok"] and res["n"] > 300 and res["verified"] > 20
+    for mode in ("flag", "alternate"):      # alternate: every call latches the other mode (runtime <-> flag transitions, the drain)
+        env = dict(os.environ, MODSX_HOST_WAIT=mode)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, (mode, out.stderr[-2000:])
+        res = json.loads(out.stdout.strip().splitlines()[-1])
+        assert res["ok"] and res["n"] > 300 and res["verified"] > 20, mode
 
 
 def _cviu_ladder(oracle, modsx):
