@@ -222,6 +222,9 @@ void launch_orientation(hipStream_t s, const OriJob *jobs, float *out, int n, co
                         const unsigned short *maskIdx, const float *maskW,
                         const unsigned char *binTab, int doHalf, double th, int maxAngles);
 void launch_trunc_u8(hipStream_t s, const float *src, uint8_t *dst, size_t n);
+size_t mser_sort_blocks(const int *rows, int n);
+void launch_mser_sort(hipStream_t s, const uint8_t *const *u8, const int *rows, const int *cols, const size_t *ordOfs, int n, int *blockHist,
+                      int *start, int *order);
 void launch_expand_blur_tiles(hipStream_t s, const DescJob *jobs, const int *prefixRows, const int *prefixCols, int nJobs,
                               const int *needTab, BlurTile *tilesRows, BlurTile *tilesCols, float2 *rowStarts);
 void launch_sample_rows(hipStream_t s, const DescJob *jobs, const BlurTile *tiles, int nTiles, const ImgRef *imgs, const float *taps,

@@ -158,8 +158,11 @@ int load_regions(const char *path, const char *det_name, const char *desc_name, 
                  std::vector<float> &desc, int *dim, std::string *found_det, std::string *found_desc);
 int detect_msers_host(const uint8_t *u8, int rows, int cols, const modsx_mser_params &par, double tilt, double zoom,
                       std::vector<modsx_keypoint> &out);
+// devOrder[i] / devStart[i]: view i's pixel offsets in (grey level, raster) order and the 257 level starts when the device sorted the
+// view (launch_mser_sort), or null: the host sorts
 int detect_msers_views(const uint8_t *const *u8, const int *rows, const int *cols, int n, const modsx_mser_params &par,
-                       const double *tilts, const double *zooms, std::vector<modsx_keypoint> *out);
+                       const double *tilts, const double *zooms, std::vector<modsx_keypoint> *out, const int *const *devOrder = nullptr,
+                       const int *const *devStart = nullptr);
 // fn(0) .. fn(n - 1) on the process-wide host worker pool (MODSX_HOST_THREADS, default min(hardware threads, 64)) + the caller
 void host_parallel_for(int n, const std::function<void(int)> &fn, bool light = false);
 void host_light_pool(bool on);   // this thread's short host loops may use the pool regardless of the sets in flight

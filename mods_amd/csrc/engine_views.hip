@@ -328,19 +328,41 @@ int detect_describe_items(modsx_ctx *c, const modsx_image *const *itemImg, const
         // DetectAffineRegions(temp_img1, temp_kp1, det_par.MSERParam, DET_MSER, DetectMSERs), imagerepresentation.cpp:1037:
         // u8 truncation of every view on the device, one D2H of bytes, the component trees on host threads' time
         // all views of the set in one buffer, ONE download; the 2 n (view, polarity) trees then run on the host pool
-        size_t ofs[MAXB + 1], tot = 0;
-        for (int i = 0; i < n; i++) { ofs[i] = tot; tot += ((size_t)cimg[i]->rows * cimg[i]->cols + 63) & ~(size_t)63; }
-        if (!c->misc.ensure(tot + 64) || !c->hMser.ensure(tot + 64)) rc = MODSX_ERR_NOMEM;
+        // ... and the bin sort of every view (the pixel offsets per grey level in raster order that the component tree walks) on the
+        // device too: bytes + sorted offsets + level starts in ONE block, one download (MODSX_MSER_DEVICE_SORT=0: the host sorts)
+        static const bool devSort = !(getenv("MODSX_MSER_DEVICE_SORT") && !atoi(getenv("MODSX_MSER_DEVICE_SORT")));
+        size_t ofs[MAXB + 1], tot = 0, ordOfs[MAXB], npxAll = 0;
+        int vr[MAXB], vc[MAXB];
+        for (int i = 0; i < n; i++) {
+          ofs[i] = tot; tot += ((size_t)cimg[i]->rows * cimg[i]->cols + 63) & ~(size_t)63;
+          vr[i] = cimg[i]->rows; vc[i] = cimg[i]->cols;
+          ordOfs[i] = npxAll; npxAll += (size_t)vr[i] * vc[i];
+        }
+        // layout of the block: [u8 views | start: n x 257 ints | order: npxAll ints]; blockHist behind it on the device only
+        const size_t oStart = (tot + 255) & ~(size_t)255, oOrder = oStart + (((size_t)n * 257 * 4 + 255) & ~(size_t)255);
+        const size_t blockB = devSort ? oOrder + npxAll * 4 : tot;
+        const size_t histB = devSort ? mser_sort_blocks(vr, n) * 256 * 4 : 0;
+        if (!c->misc.ensure(((blockB + 255) & ~(size_t)255) + histB + 64) || !c->hMser.ensure(blockB + 64)) rc = MODSX_ERR_NOMEM;
         for (int i = 0; i < n && !rc; i++)
-          launch_trunc_u8(c->stream, cimg[i]->d, (uint8_t *)c->misc.p + ofs[i], (size_t)cimg[i]->rows * cimg[i]->cols);
-        if (!rc && (ctx_copy(c, c->hMser.p, c->misc.p, tot, hipMemcpyDeviceToHost) != hipSuccess ||
+          launch_trunc_u8(c->stream, cimg[i]->d, (uint8_t *)c->misc.p + ofs[i], (size_t)vr[i] * vc[i]);
+        if (!rc && devSort) {
+          const uint8_t *du8[MAXB];
+          for (int i = 0; i < n; i++) du8[i] = (const uint8_t *)c->misc.p + ofs[i];
+          char *base = (char *)c->misc.p;
+          launch_mser_sort(c->stream, du8, vr, vc, ordOfs, n, (int *)(base + ((blockB + 255) & ~(size_t)255)), (int *)(base + oStart), (int *)(base + oOrder));
+        }
+        if (!rc && (ctx_copy(c, c->hMser.p, c->misc.p, blockB, hipMemcpyDeviceToHost) != hipSuccess ||
                     ctx_sync(c) != hipSuccess)) { set_error("MSER view download failed"); rc = MODSX_ERR_DEVICE; }
         const double tdl = tnow();
         if (!rc) {
           const uint8_t *src[MAXB];
-          int vr[MAXB], vc[MAXB];
-          for (int i = 0; i < n; i++) { src[i] = (const uint8_t *)c->hMser.p + ofs[i]; vr[i] = cimg[i]->rows; vc[i] = cimg[i]->cols; }
-          rc = detect_msers_views(src, vr, vc, n, pp.mser, tilts, zooms, kps);
+          const int *ho[MAXB], *hs[MAXB];
+          for (int i = 0; i < n; i++) {
+            src[i] = (const uint8_t *)c->hMser.p + ofs[i];
+            ho[i] = (const int *)((const char *)c->hMser.p + oOrder) + ordOfs[i];
+            hs[i] = (const int *)((const char *)c->hMser.p + oStart) + (size_t)i * 257;
+          }
+          rc = detect_msers_views(src, vr, vc, n, pp.mser, tilts, zooms, kps, devSort ? ho : nullptr, devSort ? hs : nullptr);
         }
         if (tim) fprintf(stderr, "  mser set of %d views: u8 + download %.2f ms, component trees %.2f ms\n", n, tdl - t1, tnow() - tdl);
       } else rc = detect_keypoints_batch(c, cimg, n, pp.det, tilts, zooms, kps);

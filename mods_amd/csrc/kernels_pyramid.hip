@@ -649,6 +649,100 @@ void launch_trunc_u8(hipStream_t s, const float *src, uint8_t *dst, size_t n) {
   const size_t threads = (n + 3) / 4;
   hipLaunchKernelGGL(k_trunc_u8, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, src, dst, n);
 }
+// ---- the bin sort of the MSER views (sortPixels.cpp:76-125) on the device -------------------------------------------------------------
+// The component tree takes a view's pixel offsets (padded coordinates, stride cols + 2) per grey level in raster order.  Counting
+// sort in three launches over all views of a set: a block = MSB_ROWS consecutive rows of one view, one wavefront.
+//   k_mser_hist     per block the 256 counts of its rows
+//   k_mser_scan     per view: start[l] = pixels below level l; base[block][l] = start[l] + the counts of the view's earlier blocks
+//   k_mser_scatter  a wavefront walks its rows 64 pixels at a time: a lane's rank among the lanes of its step that hold the same grey
+//                   value (eight ballots: the lanes that agree in every bit) + the level's running count = its place; raster order
+//                   inside a level is the order of (block, step, lane), so the result is the host's stable sort bit for bit
+constexpr int MSB_ROWS = 8;
+struct MserSortBatch {
+  const uint8_t *u8[MAXB];
+  int rows[MAXB], cols[MAXB], blk0[MAXB + 1];     // blk0: first block of every view
+  unsigned long long ordOfs[MAXB];                // first place of the view in `order`
+  int n;
+};
+MX_D int mser_view_of(const MserSortBatch &b, int blk) {
+  int v = 0;
+  while (v + 1 < b.n && blk >= b.blk0[v + 1]) v++;
+  return v;
+}
+__global__ __launch_bounds__(64) void k_mser_hist(MserSortBatch b, int *blockHist) {
+  __shared__ int h[256];
+  const int blk = blockIdx.x, v = mser_view_of(b, blk), lane = threadIdx.x;
+  for (int i = lane; i < 256; i += 64) h[i] = 0;
+  __syncthreads();
+  const int r0 = (blk - b.blk0[v]) * MSB_ROWS, r1 = min(r0 + MSB_ROWS, b.rows[v]), cols = b.cols[v];
+  const uint8_t *src = b.u8[v];
+  for (int r = r0; r < r1; r++)
+    for (int c = lane; c < cols; c += 64) atomicAdd(&h[src[(size_t)r * cols + c]], 1);
+  __syncthreads();
+  for (int i = lane; i < 256; i += 64) blockHist[(size_t)blk * 256 + i] = h[i];
+}
+__global__ __launch_bounds__(256) void k_mser_scan(MserSortBatch b, int *blockHist, int *start) {
+  __shared__ int tot[256];
+  const int v = blockIdx.x, l = threadIdx.x;
+  const int b0 = b.blk0[v], b1 = b.blk0[v + 1];
+  int run = 0;
+  for (int k = b0; k < b1; k++) { const int c = blockHist[(size_t)k * 256 + l]; blockHist[(size_t)k * 256 + l] = run; run += c; }
+  tot[l] = run;
+  __syncthreads();
+  if (l == 0) { int at = 0; for (int i = 0; i < 256; i++) { const int c = tot[i]; tot[i] = at; at += c; } start[v * 257 + 256] = at; }
+  __syncthreads();
+  const int st = tot[l];
+  start[v * 257 + l] = st;
+  for (int k = b0; k < b1; k++) blockHist[(size_t)k * 256 + l] += st;
+}
+__global__ __launch_bounds__(64) void k_mser_scatter(MserSortBatch b, const int *blockBase, int *order) {
+  __shared__ int cnt[256];
+  const int blk = blockIdx.x, v = mser_view_of(b, blk), lane = threadIdx.x;
+  for (int i = lane; i < 256; i += 64) cnt[i] = blockBase[(size_t)blk * 256 + i];
+  __syncthreads();
+  const int r0 = (blk - b.blk0[v]) * MSB_ROWS, r1 = min(r0 + MSB_ROWS, b.rows[v]), cols = b.cols[v], stride = cols + 2;
+  const uint8_t *src = b.u8[v];
+  int *ord = order + b.ordOfs[v];
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int r = r0; r < r1; r++)
+    for (int c0 = 0; c0 < cols; c0 += 64) {
+      const int c = c0 + lane;
+      const bool on = c < cols;
+      const int g = on ? src[(size_t)r * cols + c] : 0;
+      unsigned long long same = __ballot(on);
+#pragma unroll
+      for (int bit = 0; bit < 8; bit++) {
+        const unsigned long long m = __ballot((g >> bit) & 1);
+        same &= ((g >> bit) & 1) ? m : ~m;
+      }
+      const int rank = __popcll(same & below);
+      int at = 0;
+      if (on) at = cnt[g];
+      if (on) ord[at + rank] = (r + 1) * stride + c + 1;
+      if (on && rank == 0) cnt[g] = at + __popcll(same);      // (one lane per value; every lane of the step has read the count above)
+    }
+}
+size_t mser_sort_blocks(const int *rows, int n) { size_t t = 0; for (int i = 0; i < n; i++) t += (size_t)(rows[i] + MSB_ROWS - 1) / MSB_ROWS; return t; }
+// u8[i]: rows[i] x cols[i] bytes on the device; order: sum of rows x cols ints (view i from ordOfs[i]); start: n x 257 ints;
+// blockHist: mser_sort_blocks(rows, n) x 256 ints of scratch
+void launch_mser_sort(hipStream_t s, const uint8_t *const *u8, const int *rows, const int *cols, const size_t *ordOfs, int n, int *blockHist,
+                      int *start, int *order) {
+  if (n <= 0) return;
+  MserSortBatch b;
+  memset(&b, 0, sizeof b);
+  b.n = n;
+  int t = 0;
+  for (int i = 0; i < n; i++) {
+    b.u8[i] = u8[i]; b.rows[i] = rows[i]; b.cols[i] = cols[i]; b.ordOfs[i] = ordOfs[i];
+    b.blk0[i] = t;
+    t += (rows[i] + MSB_ROWS - 1) / MSB_ROWS;
+  }
+  b.blk0[n] = t;
+  if (t <= 0) return;
+  hipLaunchKernelGGL(k_mser_hist, dim3(t), dim3(64), 0, s, b, blockHist);
+  hipLaunchKernelGGL(k_mser_scan, dim3(n), dim3(256), 0, s, b, blockHist, start);
+  hipLaunchKernelGGL(k_mser_scatter, dim3(t), dim3(64), 0, s, b, (const int *)blockHist, order);
+}
 void launch_gray(hipStream_t s, const void *src, float *dst, size_t n, int channels, int dtype) {
   dim3 grid((unsigned)((n + 255) / 256));
   if (dtype == 0) hipLaunchKernelGGL(k_gray_u8, grid, dim3(256), 0, s, (const uint8_t *)src, dst, n, channels);

@@ -427,8 +427,9 @@ struct MserScratch {
 static thread_local MserScratch t_scratch;
 
 // MSER+ (pol 0) or MSER- (pol 1: the inverted image, extremaInvertImage) of one view, in region / threshold order
+// devOrder / devStart: the view's sorted offsets and level starts when the device has sorted it (kernels_pyramid.hip: k_mser_*), or null
 static void mser_polarity(const uint8_t *u8, int rows, int cols, const modsx_mser_params &par, double minMargin, int pol, ViewSort &vs,
-                          std::vector<modsx_keypoint> &out) {
+                          std::vector<modsx_keypoint> &out, const int *devOrder = nullptr, const int *devStart = nullptr) {
   MserScratch &S = t_scratch;
   const int stride = cols + 2;
   const size_t npx = (size_t)(rows + 2) * stride;
@@ -442,7 +443,8 @@ static void mser_polarity(const uint8_t *u8, int rows, int cols, const modsx_mse
     else for (int c = 0; c < cols; c++) f[c] = (uint8_t)(255 - src[c]);
   }
   int start[257];
-  sort_pixels(u8, rows, cols, vs, pol, start);
+  if (devOrder) memcpy(start, devStart, sizeof start);
+  else sort_pixels(u8, rows, cols, vs, pol, start);
   Forest F((Forest::Node *)S.node.ensure(npx * sizeof(Forest::Node)), (int *)S.parent.ensure(npx * sizeof(int)));
   if (!F.node || !F.parent) return;              // (out of memory: no keys for this view)
   F.rows = rows; F.cols = cols; F.stride = stride;
@@ -450,7 +452,7 @@ static void mser_polarity(const uint8_t *u8, int rows, int cols, const modsx_mse
   F.maxSize = (int)((double)cols * rows * par.max_area);
   F.minMargin = par.relative ? minMargin / 100.0 : minMargin;
   F.relative = par.relative != 0; F.inverted = pol == 1;
-  F.run(vs.order.data(), start);
+  F.run(devOrder ? devOrder : vs.order.data(), start);
   for (const GrownRegion &g : F.regions) {
     if (!g.kept) continue;
     for (const StableLevel &t : g.levels) {
@@ -663,11 +665,12 @@ int detect_msers_host(const uint8_t *u8, int rows, int cols, const modsx_mser_pa
 
 // The views of a set: 2 n independent (view, polarity) trees on the host pool, largest first; out[i] = DetectMSERs of view i
 int detect_msers_views(const uint8_t *const *u8, const int *rows, const int *cols, int n, const modsx_mser_params &par,
-                       const double *tilts, const double *zooms, std::vector<modsx_keypoint> *out) {
+                       const double *tilts, const double *zooms, std::vector<modsx_keypoint> *out, const int *const *devOrder,
+                       const int *const *devStart) {
   const double minMargin = par.mode != MODSX_FIXED_TH ? 1.0 : par.min_margin;
   std::vector<std::vector<modsx_keypoint>> part((size_t)2 * n);
   std::vector<ViewSort> sorts((size_t)n);         // one bin sort per view, shared by its two polarity tasks
-  for (int v = 0; v < n; v++) if (rows[v] > 0 && cols[v] > 0) sorts[v].order.resize((size_t)rows[v] * cols[v]);
+  if (!devOrder) for (int v = 0; v < n; v++) if (rows[v] > 0 && cols[v] > 0) sorts[v].order.resize((size_t)rows[v] * cols[v]);
   std::vector<int> task((size_t)2 * n);
   for (int i = 0; i < 2 * n; i++) task[i] = i;
   std::stable_sort(task.begin(), task.end(), [&](int a, int b) { return (long)rows[a / 2] * cols[a / 2] > (long)rows[b / 2] * cols[b / 2]; });
@@ -679,7 +682,8 @@ int detect_msers_views(const uint8_t *const *u8, const int *rows, const int *col
   host_parallel_for(2 * n, [&](int k) {
     const int t = task[k], v = t / 2;
     if (trace) { tb[k] = nowms() - t00; tid[k] = std::hash<std::thread::id>()(std::this_thread::get_id()) % 1000; }
-    if (rows[v] > 0 && cols[v] > 0) mser_polarity(u8[v], rows[v], cols[v], par, minMargin, t & 1, sorts[v], part[t]);
+    if (rows[v] > 0 && cols[v] > 0)
+      mser_polarity(u8[v], rows[v], cols[v], par, minMargin, t & 1, sorts[v], part[t], devOrder ? devOrder[v] : nullptr, devOrder ? devStart[v] : nullptr);
     if (trace) te[k] = nowms() - t00;
   });
   if (trace && nowms() - t00 > 30) {
