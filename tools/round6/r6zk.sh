@@ -1,0 +1,4 @@
+R=$GRAFT_REPO_ROOT; cd $R
+export MODSX_BENCH_NO_UPLOAD_LEG=1
+for i in 1 2 3; do timeout 600 python bench.py --config ladder --no-cpu-baseline --no-extra 2>/dev/null | python tools/bench_line.py ladder_help; done
+timeout 600 python -m pytest tests/test_gpu_views.py -x -q -k "mser or ladder or flag" 2>&1 | grep -E "passed|failed"
