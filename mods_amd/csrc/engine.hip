@@ -855,8 +855,8 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
   // claim through a small open-addressing table and builds its keypoints -- one task per image on the host pool.
   for (unsigned k = 0; k < cnt; k++) {
     const Candidate &q = cd[k];
-    if ((unsigned)q.img >= (unsigned)n || (unsigned)q.octave >= 32u || (unsigned)q.level >= 32u || (unsigned)q.r0 >= (1u << 24) ||
-        (unsigned)q.c0 >= (1u << 24) || (unsigned)q.r >= (1u << 24) || (unsigned)q.c >= (1u << 24)) {
+    if ((unsigned)q.img >= (unsigned)n || (unsigned)q.octave >= 32u || (unsigned)q.level >= 32u || (unsigned)q.r0 >= (1u << 14) ||
+        (unsigned)q.c0 >= (1u << 14) || (unsigned)q.r >= (1u << 24) || (unsigned)q.c >= (1u << 24)) {
       set_error("candidate outside the sort key's range");
       return MODSX_ERR_DEVICE;
     }
@@ -880,22 +880,25 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
     if (!m) return;
     // keys are unique (one candidate per (octave, level, pixel)), so the order is the same whatever sorts them: an LSD radix
     // sort of (key, index), 11 bits per pass, passes whose digit is the same for every key left out
-    static thread_local std::vector<std::pair<uint64_t, uint32_t>> order, order2;
+    // key and index share ONE 64-bit word (octave 5 | level 5 | row 14 | column 14 | index 21 bits: images are at most 16384 px per side,
+    // a set holds at most 2^21 candidates): half the bytes per pass of the (key, index) pairs sorted until round 6
+    static thread_local std::vector<uint64_t> order, order2;
+    static_assert(CAND_CAP <= (1u << 21), "index field of the packed sort key");
     order.resize(m); order2.resize(m);
     for (size_t k = 0; k < m; k++) {
       const Candidate &q = cd[idx[k]];
-      order[k] = {((uint64_t)q.octave << 53) | ((uint64_t)q.level << 48) | ((uint64_t)q.r0 << 24) | (uint64_t)q.c0, idx[k]};
+      order[k] = ((uint64_t)q.octave << 54) | ((uint64_t)q.level << 49) | ((uint64_t)(q.r0 & 0x3fff) << 35) | ((uint64_t)(q.c0 & 0x3fff) << 21) | idx[k];
     }
     {
       constexpr int BITS = 11, NB = 1 << BITS;
       uint32_t hist[NB];
-      for (int shift = 0; shift < 58; shift += BITS) {
+      for (int shift = 21; shift < 59; shift += BITS) {
         memset(hist, 0, sizeof hist);
-        for (size_t k = 0; k < m; k++) hist[(order[k].first >> shift) & (NB - 1)]++;
-        if (hist[(order[0].first >> shift) & (NB - 1)] == m) continue;
+        for (size_t k = 0; k < m; k++) hist[(order[k] >> shift) & (NB - 1)]++;
+        if (hist[(order[0] >> shift) & (NB - 1)] == m) continue;
         uint32_t sum = 0;
         for (int b = 0; b < NB; b++) { const uint32_t h = hist[b]; hist[b] = sum; sum += h; }
-        for (size_t k = 0; k < m; k++) order2[hist[(order[k].first >> shift) & (NB - 1)]++] = order[k];
+        for (size_t k = 0; k < m; k++) order2[hist[(order[k] >> shift) & (NB - 1)]++] = order[k];
         order.swap(order2);
       }
     }
@@ -904,7 +907,7 @@ int detect_scalespace_batch(modsx_ctx *c, const modsx_image *const *imgs, int n,
     std::vector<uint64_t> claimed(tabSize, 0);  // key + 1, 0 = empty
     dst.reserve(m);
     for (size_t kk = 0; kk < m; kk++) {
-      const Candidate &q = cd[order[kk].second];
+      const Candidate &q = cd[order[kk] & 0x1fffffu];
       const uint64_t key = (((uint64_t)q.octave << 48) | ((uint64_t)q.r << 24) | (uint64_t)q.c) + 1;
       size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & (tabSize - 1);
       bool taken = false;
