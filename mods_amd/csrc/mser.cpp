@@ -435,7 +435,8 @@ static void mser_polarity(const uint8_t *u8, int rows, int cols, const modsx_mse
   const size_t npx = (size_t)(rows + 2) * stride;
   // `fence`: the polarity's pixels inside a frame of 255, which stops the span fill of any threshold < 255 at the image border
   // (the tree itself only sees the sorted offsets)
-  S.fence.assign(npx + 32, 255); S.mark.assign(npx + 32, 0);     // (+ 32: the span fill reads 16 bytes at a time)
+  S.fence.assign(npx + 32, 255);                                   // (+ 32: the span fill reads 16 bytes at a time)
+  if (S.mark.size() < npx + 32) S.mark.assign(npx + 32, 0);        // all-zero between calls: component_runs clears what it marks
   for (int r = 0; r < rows; r++) {
     uint8_t *f = &S.fence[(size_t)(r + 1) * stride + 1];
     const uint8_t *src = u8 + (size_t)r * cols;
