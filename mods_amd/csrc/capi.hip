@@ -822,6 +822,25 @@ int modsx_detect_msers_u8(const unsigned char *gray, int rows, int cols, const m
   return (int)k.size();
 }
 
+// The host half of the MSER view loop without a device (test aid): DetectMSERs of n u8 views as the engine runs them -- 2 n (view,
+// polarity) tasks on the host pool that share a view's bin sort.  counts[i] = keys of view i; *out = the views' keys one after the
+// other (modsx_free).  Returns the total or a negative status.
+extern "C" __attribute__((visibility("default"))) int modsx_debug_msers_views_u8(const unsigned char *const *gray, const int *rows, const int *cols,
+                                                                                  int n, const modsx_mser_params *par, const double *tilts,
+                                                                                  const double *zooms, int *counts, modsx_keypoint **out) {
+  if (!gray || !rows || !cols || n <= 0 || n > mx::MAXB || !par || !tilts || !zooms || !counts || !out) { mx::set_error("modsx_debug_msers_views_u8: bad argument"); return MODSX_ERR_ARG; }
+  std::vector<modsx_keypoint> k[mx::MAXB];
+  int rc = mx::detect_msers_views(gray, rows, cols, n, *par, tilts, zooms, k);
+  if (rc) return rc;
+  size_t total = 0;
+  for (int i = 0; i < n; i++) { counts[i] = (int)k[i].size(); total += k[i].size(); }
+  *out = (modsx_keypoint *)malloc(sizeof(modsx_keypoint) * std::max<size_t>(1, total));
+  if (!*out) { mx::set_error("out of memory"); return MODSX_ERR_NOMEM; }
+  size_t at = 0;
+  for (int i = 0; i < n; i++) { if (!k[i].empty()) memcpy(*out + at, k[i].data(), sizeof(modsx_keypoint) * k[i].size()); at += k[i].size(); }
+  return (int)total;
+}
+
 int modsx_save_regions(const char *path, const modsx_region_class *classes, int nclasses) {
   if (!path || !classes || nclasses <= 0) { mx::set_error("modsx_save_regions: bad argument"); return MODSX_ERR_ARG; }
   for (int i = 0; i < nclasses; i++) {

@@ -78,3 +78,34 @@ def test_disc_gives_its_moments(modsx):
     assert abs(k["x"][0] - (xx[disc].mean() + 0.5)) < 1e-9 and abs(k["y"][0] - (yy[disc].mean() + 0.5)) < 1e-9
     r2 = k["a11"][0] * k["a22"][0] - k["a12"][0] * k["a21"][0]
     assert abs(np.sqrt(r2) * 2 - 12) < 0.5                               # sqrt(cov) of a disc = r / 2
+
+
+def test_view_set_on_the_host_pool_equals_single_views(modsx):
+    """detect_msers_views (the engine's MSER step: 2 n (view, polarity) tasks on the host pool, the two tasks of a view share one bin
+    sort and scatter half of its rows each) against the one-view entry point, view by view -- several rounds, so that task order and
+    who sorts which half vary."""
+    import ctypes as C
+    L = modsx.lib()
+    imgs = [np.ascontiguousarray(i.astype(np.uint8)) for i in _images()]
+    imgs = imgs + [np.ascontiguousarray(imgs[0][::2, ::2]), np.ascontiguousarray(imgs[2][:, ::3])]
+    n = len(imgs)
+    par = modsx.default_mser_params(min_margin=5.0, min_size=10, max_area=0.2)
+    single = [modsx.detect_msers_u8(g, par) for g in imgs]
+    assert sum(len(s) for s in single) > 200
+    ptrs = (C.c_void_p * n)(*[g.ctypes.data for g in imgs])
+    rows = (C.c_int * n)(*[g.shape[0] for g in imgs]); cols = (C.c_int * n)(*[g.shape[1] for g in imgs])
+    ones = (C.c_double * n)(*([1.0] * n))
+    for rep in range(6):
+        counts = (C.c_int * n)()
+        out = C.c_void_p()
+        tot = L.modsx_debug_msers_views_u8(ptrs, rows, cols, n, C.byref(par), ones, ones, counts, C.byref(out))
+        assert tot == sum(len(s) for s in single)
+        arr = np.frombuffer((C.c_char * (max(tot, 1) * modsx.KEYPOINT.itemsize)).from_address(out.value), dtype=modsx.KEYPOINT, count=tot).copy()
+        L.modsx_free(out)
+        at = 0
+        for i in range(n):
+            assert counts[i] == len(single[i])
+            got = arr[at:at + counts[i]]; at += counts[i]
+            for f in got.dtype.names:
+                assert np.array_equal(got[f], single[i][f]), (rep, i, f)
+
