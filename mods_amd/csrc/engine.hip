@@ -1053,7 +1053,7 @@ int detect_keypoints_batch(modsx_ctx *c, const modsx_image *const *imgs, int n, 
 void detect_affine_regions(const modsx_keypoint *kps, int n, int img_id, int det_type, modsx_region *out) {
   for (int i = 0; i < n; i++) {
     modsx_keypoint k = kps[i];
-    modsx_region r;
+    modsx_region &r = out[i];         // built in place (a 200-byte record)
     memset(&r, 0, sizeof r);
     r.img_id = img_id; r.img_reproj_id = 0; r.type = det_type; r.id = i;
     r.det_kp.s = k.s * sqrt(fabs(k.a11 * k.a22 - k.a12 * k.a21));
@@ -1062,7 +1062,6 @@ void detect_affine_regions(const modsx_keypoint *kps, int n, int img_id, int det
     r.det_kp.a11 = k.a11; r.det_kp.a12 = k.a12; r.det_kp.a21 = k.a21; r.det_kp.a22 = k.a22;
     r.det_kp.response = k.response;
     r.det_kp.sub_type = k.sub_type;
-    out[i] = r;
   }
 }
 
@@ -1174,25 +1173,27 @@ int detect_orientation_batch(modsx_ctx *c, const modsx_image *const *imgs, int n
     out[i].reserve(in[i].size() + in[i].size() / 4);
     for (size_t r = 0; r < in[i].size(); r++) {
       if (!passed[i][r]) continue;
-      modsx_region base = in[i][r];
+      // (a region is a 200-byte record: it is copied once, into its place in the list, and edited there)
+      const modsx_region &base = in[i][r];
       if (maxAngNum > 0) {
-        base.id = 0;  // const_temp_region.id = count, count is never incremented (synth-detection.cpp:854,889)
         const float *o = res + (jk++) * (size_t)(1 + maxA);
         int on;
         memcpy(&on, o, 4);
+        const double b11 = base.det_kp.a11, b12 = base.det_kp.a12, b21 = base.det_kp.a21, b22 = base.det_kp.a22;
         for (int a = 0; a < on; a++) {
           // `using namespace std` in synth-detection.cpp:30 => cos/sin(float) are the f32 overloads
           double ci = cosf(-o[1 + a]);
           double si = sinf(-o[1 + a]);
-          modsx_region t = base;
-          t.det_kp.a11 = base.det_kp.a11 * ci - base.det_kp.a12 * si;
-          t.det_kp.a12 = base.det_kp.a11 * si + base.det_kp.a12 * ci;
-          t.det_kp.a21 = base.det_kp.a21 * ci - base.det_kp.a22 * si;
-          t.det_kp.a22 = base.det_kp.a21 * si + base.det_kp.a22 * ci;
-          out[i].push_back(t);
+          out[i].push_back(base);
+          modsx_region &t = out[i].back();
+          t.id = 0;  // const_temp_region.id = count, count is never incremented (synth-detection.cpp:854,889)
+          t.det_kp.a11 = b11 * ci - b12 * si;
+          t.det_kp.a12 = b11 * si + b12 * ci;
+          t.det_kp.a21 = b21 * ci - b22 * si;
+          t.det_kp.a22 = b21 * si + b22 * ci;
         }
       }
-      if (addUpRight) out[i].push_back(base);
+      if (addUpRight) { out[i].push_back(base); if (maxAngNum > 0) out[i].back().id = 0; }
     }
   });
   hm.mark("rotated regions");
@@ -1228,7 +1229,7 @@ int reproject_regions_box(modsx_region *regs, int n, const double *H, int orig_w
     if ((k.x < orig_w) && (k.y < orig_h) && (k.x > 0) && (k.y > 0)) {
       if (!check_borders_host(orig_w, orig_h, (float)k.x, (float)k.y, (float)k.a11, (float)k.a12, (float)k.a21,
                               (float)k.a22, (int)(boxk * k.s), (int)(boxk * k.s)))
-        regs[m++] = regs[i];
+      { if (m != i) regs[m] = regs[i]; m++; }
     }
   }
   return m;

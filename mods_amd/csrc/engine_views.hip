@@ -420,8 +420,9 @@ int detect_describe_items(modsx_ctx *c, const modsx_image *const *itemImg, const
           size_t at[MAXB + 1];
           at[0] = regs.size();
           for (int i = 0; i < n; i++) at[i + 1] = at[i] + ro[i].size();
-          regs.resize(at[n]);
-          host_parallel_light(n, [&](int i) { if (!ro[i].empty()) memcpy(regs.data() + at[i], ro[i].data(), ro[i].size() * sizeof(modsx_region)); });
+          // appended view by view (resize + copy would zero-fill 200 bytes per region first)
+          if (regs.capacity() < at[n]) regs.reserve(std::max(at[n], 2 * regs.capacity()));
+          for (int i = 0; i < n; i++) regs.insert(regs.end(), ro[i].begin(), ro[i].end());
           total += at[n] - at[0];
         }
         if (hostDesc) hipStreamSynchronize(c->stream);    // (copies into the caller's pageable memory; everything else was waited for by describe_batch)
